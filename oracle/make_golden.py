@@ -1,0 +1,180 @@
+"""Generate the golden vectors under tests/golden from the REAL reference.
+
+DEV-CONTAINER ONLY (needs /root/reference).  Run:  python -m oracle.make_golden
+
+For every case the real ``PARQDecoder`` / ``AddRayPE`` is imported in place
+(oracle/reference_loader.py), loaded with the seeded synthetic weights of
+``parq_amd/synth.py`` and run on the seeded synthetic scene; only the OUTPUTS
+(plus the case description needed to regenerate the inputs, and decision
+margins) are written.  No reference source or bytecode is stored.
+
+Cases:
+  g1_cfg1        BASELINE cfg 1: 2 views 60x80, Q=64, I=1, d=256, noise features
+  g2_forced      B=2, 4 views 60x80, Q=64, I=8, d=256, noise features — consumed
+                 teacher-forced: iteration k is fed norm(coord_pos_k)
+  g3_damped      B=1, 4 views 60x80, Q=64, I=8, smooth features, centre head x0.05 —
+                 consumed free-running
+  g4_edges       hand-placed reference points (behind camera, partial texels,
+                 all views invalid, clamp limits), ragged Q=40, N=429, d=128/H=2
+  g5_raype       AddRayPE on a 2-view 6x8 grid, C=64
+  g6_shipped     shipped dims d=1024/H=4 (head dim 256), FFN 768, 2 views 15x20, Q=32, I=2
+  g7_fp64        the g2 case run by the reference in float64
+  g8_unshared    SHARE_WEIGHTS=False, 2 layers, d=128/H=2
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from parq_amd import synth                      # noqa: E402
+from oracle import reference_loader as RL        # noqa: E402
+from oracle import parq_oracle as O              # noqa: E402
+
+OUT_DIR = os.path.join(ROOT, "tests", "golden")
+KEYS = ("pred_logits", "center_unnormalized", "size_unnormalized", "ortho6d", "sem_cls_prob", "coord_pos")
+
+CASES = {
+    "g1_cfg1": dict(cfg=dict(dim=256, queries=64, heads=4, ffn=768, layers=1), wseed=11, sseed=101,
+                    B=1, V=2, h=60, w=80, smooth=False, damped=False),
+    "g2_forced": dict(cfg=dict(dim=256, queries=64, heads=4, ffn=768, layers=8), wseed=12, sseed=102,
+                      B=2, V=4, h=60, w=80, smooth=False, damped=False),
+    "g3_damped": dict(cfg=dict(dim=256, queries=64, heads=4, ffn=768, layers=8), wseed=13, sseed=103,
+                      B=1, V=4, h=60, w=80, smooth=True, damped=True),
+    "g4_edges": dict(cfg=dict(dim=128, queries=40, heads=2, ffn=96, layers=2,
+                              scale=[-3.0, 3.0, -2.0, 0.5, -1.0, 5.25]), wseed=14, sseed=104,
+                     B=2, V=3, h=11, w=13, smooth=False, damped=False, edges=True),
+    "g6_shipped": dict(cfg=dict(dim=1024, queries=32, heads=4, ffn=768, layers=2), wseed=16, sseed=106,
+                       B=1, V=2, h=15, w=20, smooth=False, damped=False),
+    "g7_fp64": dict(cfg=dict(dim=256, queries=64, heads=4, ffn=768, layers=8), wseed=12, sseed=102,
+                    B=2, V=4, h=60, w=80, smooth=False, damped=False, double=True),
+    "g8_unshared": dict(cfg=dict(dim=128, queries=32, heads=2, ffn=192, layers=2, share_weights=False),
+                        wseed=18, sseed=108, B=1, V=2, h=12, w=16, smooth=False, damped=False),
+}
+
+RAYPE_CASE = dict(dim=64, seed=15, sseed=105, B=1, V=2, h=6, w=8,
+                  ray_points_scale=[-3.0, 3.0, -2.0, 0.5, 0.25, 5.25])
+
+
+def case_inputs(case):
+    """(cfg, weights, scene) of a golden case — shared with the tests."""
+    cfg = synth.decoder_cfg(**case["cfg"])
+    W = synth.make_decoder_weights(cfg, case["wseed"], damped=case.get("damped", False))
+    sc = synth.make_scene(case["sseed"], case["B"], case["V"], case["h"], case["w"], cfg.DIM_IN,
+                          smooth=case.get("smooth", False))
+    if case.get("edges"):
+        W["refpoint.weight"] = edge_refpoints(cfg, sc, case)
+    return cfg, W, sc
+
+
+def edge_refpoints(cfg, sc, case):
+    """Hand-placed reference points for g4 (SURVEY.md Appendix B traps 1-3, 6).
+
+    View 0 of scene 0 is given an identity camera<-local transform by making all
+    three poses of that view identity-compatible, so pixel coordinates of the
+    hand-placed points are known in closed form there.
+    """
+    Q = cfg.NUM_QUERIES
+    scale = cfg.TRANSFORMER.SCALE
+    lo = np.array(scale[0::2])
+    hi = np.array(scale[1::2])
+    # make T_camera_local(view 0, every scene) = identity: T_cp = I, T_wp = T_wl
+    sc["T_camera_pseudoCam"][:, 0] = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], np.float32)
+    sc["T_world_pseudoCam"][:, 0] = sc["T_world_local"][:, 0]
+    w, h, fx, fy, cx, cy = [float(x) for x in sc["camera"][0, 0]]
+    rng = synth.uniform(case["wseed"], "edge.base", (Q, 3), 0.05, 0.95).astype(np.float64)
+    P = rng * (hi - lo) + lo
+
+    def at_pixel(u, v, z):
+        return np.array([(u - cx) * z / fx, (v - cy) * z / fy, z])
+    P[0] = at_pixel(-0.5, 3.3, 2.0)            # partial texel left of the image: invalid but sampled
+    P[1] = at_pixel(w - 0.5, 4.2, 2.0)         # partial texel right of the image
+    P[2] = at_pixel(5.5, -0.75, 1.5)           # partial texel above
+    P[3] = at_pixel(6.25, h - 0.25, 1.5)       # partial texel below
+    P[4] = at_pixel(0.0, 0.0, 1.0)             # (numerically near) the closed corner
+    P[5] = at_pixel(w - 1.0, h - 1.0, 1.0)
+    P[6] = np.array([0.3, -0.4, -0.5])         # behind the camera (z < 0)
+    P[7] = np.array([0.2, -0.1, 5e-4])         # z below the 1e-3 front threshold
+    P[8] = np.array([2.9, -1.9, 0.3])          # far outside every view
+    P[9] = at_pixel(3.0, 2.0, 4.0)             # exact texel centre
+    r = (P - lo) / (hi - lo)
+    wgt = np.log(np.clip(r, 1e-9, 1 - 1e-9) / (1 - np.clip(r, 1e-9, 1 - 1e-9)))
+    wgt[10] = [20.0, -20.0, 0.0]               # sigmoid saturates: isig clamp limits (eps=1e-3)
+    wgt[11] = [-20.0, 20.0, 20.0]
+    wgt[12] = [7.5, -7.5, 0.0]                 # within 1e-3 of 0/1: clamped centre update
+    return wgt.astype(np.float32)
+
+
+def run_reference(ref, case):
+    cfg, W, sc = case_inputs(case)
+    double = case.get("double", False)
+    dec = RL.build_reference_decoder(ref, cfg, W, double=double)
+    cast = (lambda a: torch.from_numpy(a).double()) if double else torch.from_numpy
+    with torch.no_grad():
+        outs = dec(cast(sc["tokens"]), ref.Camera(cast(sc["camera"])),
+                   ref.Pose(cast(sc["T_camera_pseudoCam"])), ref.Pose(cast(sc["T_world_pseudoCam"])),
+                   ref.Pose(cast(sc["T_world_local"])))
+    return cfg, W, sc, outs
+
+
+def margins(cfg, W, sc, outs):
+    """Decision margins per iteration (float64 oracle at the reference's own
+    reference points): top-2 class-probability gap and the distance of every
+    projected point to the closed validity boundary [0,size-1] / z=1e-3."""
+    od = O.OracleDecoder(cfg, W, synth.SCANNET_MEAN_SIZES, dtype=torch.float64)
+    od.prepare(sc["tokens"], sc["camera"], sc["T_camera_pseudoCam"], sc["T_world_pseudoCam"],
+               sc["T_world_local"])
+    res = {}
+    for k, o in enumerate(outs):
+        ref_k = O.normalize(o["coord_pos"].double(), cfg.TRANSFORMER.SCALE)
+        pc = O.pose_transform(od.T_cl, O.denormalize(ref_k, cfg.TRANSFORMER.SCALE).unsqueeze(1))
+        p2d, _ = O.camera_project(od.cam, pc)
+        size = od.cam[..., :2].unsqueeze(-2)
+        d = torch.minimum(p2d.abs(), (p2d - (size - 1)).abs()).min(-1).values      # (B,V,Q)
+        d = torch.minimum(d, (pc[..., 2] - 1e-3).abs())
+        top2 = o["sem_cls_prob"].double().topk(2, -1).values
+        res["it%d_valid_margin" % k] = d.min(1).values.float().numpy()              # (B,Q)
+        res["it%d_cls_margin" % k] = (top2[..., 0] - top2[..., 1]).float().numpy()
+    return res
+
+
+def main(only=None):
+    ref = RL.load()
+    os.makedirs(OUT_DIR, exist_ok=True)
+    for name, case in CASES.items():
+        if only and name not in only:
+            continue
+        cfg, W, sc, outs = run_reference(ref, case)
+        arrays = {}
+        for k, o in enumerate(outs):
+            for key in KEYS:
+                a = o[key].detach().numpy()
+                arrays["it%d_%s" % (k, key)] = a.astype(np.float64 if case.get("double") else np.float32)
+        arrays.update(margins(cfg, W, sc, outs))
+        arrays["meta"] = np.frombuffer(json.dumps(case, sort_keys=True).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(OUT_DIR, name + ".npz"), **arrays)
+        print("wrote", name, {k: v.shape for k, v in list(arrays.items())[:3]})
+    if not only or "g5_raype" in only:
+        c = RAYPE_CASE
+        Wp = synth.make_ray_pe_weights(c["dim"], c["seed"])
+        cam, T_cp, T_wp, T_wl = synth.make_geometry(c["sseed"], c["B"], c["V"], c["h"], c["w"])
+        pe = ref.AddRayPE(c["dim"], c["ray_points_scale"], 64, 0.25, 5.25).eval()
+        pe.load_state_dict({k: torch.from_numpy(v) for k, v in Wp.items()}, strict=True)
+        feat = torch.zeros(c["B"], c["V"], c["dim"], c["h"], c["w"])
+        with torch.no_grad():
+            enc = pe(feat, ref.Camera(torch.from_numpy(cam)), ref.Pose(torch.from_numpy(T_cp)),
+                     ref.Pose(torch.from_numpy(T_wp)), ref.Pose(torch.from_numpy(T_wl)))
+        np.savez_compressed(os.path.join(OUT_DIR, "g5_raype.npz"), encoding=enc.numpy(),
+                            meta=np.frombuffer(json.dumps(c, sort_keys=True).encode(), dtype=np.uint8))
+        print("wrote g5_raype", tuple(enc.shape))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:] or None)
