@@ -1,0 +1,160 @@
+/*
+ * parq_hip.h — C ABI of the MI355X-native PARQ decoder path (libparq_hip.so).
+ *
+ * The reference (ymingxie/PARQ) is pure Python/PyTorch: it has no plugin, operator or
+ * FFI interface for this path.  Its boundary is the Python call
+ *     PARQDecoder.forward(intput_tokens, camera, T_camera_pseudoCam,
+ *                         T_world_pseudoCam, T_world_local)      model/parq_decoder.py:134-163
+ * and, once per forward before it,
+ *     AddRayPE.forward(images_feat, camera, T_cp, T_wp, T_wl)   model/ray_positional_encoding.py:61-139
+ * The entry points below are what a binding for those two calls needs: plain pointers,
+ * sizes and a hipStream_t.  No torch types, no exceptions, no ownership of caller memory.
+ * INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to float32 unless stated otherwise;
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t) and returns; nothing
+ *     synchronises, allocates or frees device memory;
+ *   - return value: PARQ_OK or an error code; parq_last_error() gives the message
+ *     (thread-local);
+ *   - tokens are channels-last (B, V*h*w, C), token index (v*h + y)*w + x
+ *     (model/parq_lightning.py:78-85); Pose = 12 floats [R row-major | t]
+ *     (utils/wrappers.py:194-213); Camera = 6 floats [w,h,fx,fy,cx,cy] (utils/wrappers.py:441-476).
+ */
+#ifndef PARQ_HIP_H
+#define PARQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct parq_ctx *parq_handle;
+typedef void *parq_stream; /* hipStream_t */
+
+enum {
+    PARQ_OK = 0,
+    PARQ_ERR_ARG = 1,         /* bad argument / unsupported shape */
+    PARQ_ERR_HIP = 2,         /* a HIP runtime call failed */
+    PARQ_ERR_STATE = 3,       /* call order violated (e.g. forward before pack_weights) */
+    PARQ_ERR_WORKSPACE = 4    /* workspace too small */
+};
+
+/* Fields PARQDecoder.__init__ reads from cfg (model/parq_decoder.py:40-82). */
+typedef struct parq_config {
+    int32_t dim;            /* DIM_IN = TRANSFORMER.DEC_DIM = QUERIES_DIM (C)            */
+    int32_t num_queries;    /* NUM_QUERIES (Q)                                           */
+    int32_t num_classes;    /* NUM_SEMCLS + 1 (background last)                          */
+    int32_t num_heads;      /* TRANSFORMER.DEC_HEADS; head dim C/H must be 32, 64, 128 or 256 */
+    int32_t ffn_dim;        /* TRANSFORMER.DEC_FFN_DIM                                   */
+    int32_t num_layers;     /* TRANSFORMER.DEC_LAYERS = recurrent iterations (I)         */
+    int32_t share_weights;  /* TRANSFORMER.SHARE_WEIGHTS                                 */
+    int32_t num_mean_sizes; /* rows of the mean-size table (BoxProcessor: 10)            */
+    float scale[6];         /* TRANSFORMER.SCALE = [x0,x1,y0,y1,z0,z1]                   */
+} parq_config;
+
+/* Inputs of one PARQDecoder.forward call (model/parq_decoder.py:134). */
+typedef struct parq_scene {
+    int32_t B, V, h, w;              /* scenes, views, feature-map height/width           */
+    const float *tokens;             /* (B, V*h*w, C)                                     */
+    const float *camera;             /* (B, V, 6)  feature-scale cameras                  */
+    const float *T_camera_pseudoCam; /* (B, V, 12)                                        */
+    const float *T_world_pseudoCam;  /* (B, V, 12)                                        */
+    const float *T_world_local;      /* (B, 1, 12)                                        */
+} parq_scene;
+
+/* The six tensors of one iteration's output dict (model/transformer_parq.py:271-279).
+ * For parq_forward each pointer addresses I consecutive (B,Q,·) blocks. */
+typedef struct parq_outputs {
+    float *pred_logits;          /* (B,Q,num_classes) */
+    float *center_unnormalized;  /* (B,Q,3) */
+    float *size_unnormalized;    /* (B,Q,3) */
+    float *ortho6d;              /* (B,Q,6) */
+    float *sem_cls_prob;         /* (B,Q,num_classes) */
+    float *coord_pos;            /* (B,Q,3) */
+} parq_outputs;
+
+const char *parq_last_error(void);
+const char *parq_version(void);
+
+/* ---- lifetime -------------------------------------------------------------------- */
+int parq_create(const parq_config *cfg, parq_handle *out);
+int parq_destroy(parq_handle h);
+
+/* ---- weights ---------------------------------------------------------------------
+ * Names are the reference decoder's state_dict keys, e.g.
+ *   "refpoint.weight", "mlp_heads.center_head.layers.0.weight",
+ *   "parq_module.decoder.layers.0.multihead_attn.in_proj_weight",
+ *   "parq_module.decoder.position_encoder.2.bias",
+ * plus "mean_sizes" = the (num_mean_sizes,3) float32 table BoxProcessor gathers from
+ * (utils/parq_utils.py:88,96-98).  parq_set_weight only records the pointer;
+ * parq_pack_weights copies every recorded tensor into the caller-provided arena
+ * (fusing the four first-layer head matrices into one), after which the original
+ * tensors are no longer referenced.  Call it again whenever the parameters change. */
+int parq_set_weight(parq_handle h, const char *name, const float *dev, int64_t numel);
+size_t parq_packed_weights_bytes(parq_handle h);
+int parq_pack_weights(parq_handle h, void *arena, size_t arena_bytes, parq_stream stream);
+
+/* ---- PARQDecoder.forward ---------------------------------------------------------- */
+size_t parq_workspace_bytes(parq_handle h, int32_t B, int32_t V, int32_t hh, int32_t ww);
+
+/* Whole forward: prologue + I iterations, reference points chained on device
+ * (model/transformer_parq.py:283-337).  No host synchronisation inside. */
+int parq_forward(parq_handle h, const parq_scene *scene, void *workspace, size_t workspace_bytes,
+                 const parq_outputs *outs, parq_stream stream);
+
+/* Stepping interface (teacher-forced parity tests, custom drivers):
+ *   parq_prepare  : T_camera_local and the hoisted K/V cache (transformer_parq.py:298-305)
+ *   parq_iterate  : one loop body (:310-335).  ref_in (B,Q,3) normalised reference points,
+ *                   or NULL to continue from the previous iteration (or from
+ *                   sigmoid(refpoint.weight) after parq_prepare).  ref_out (B,Q,3) may be NULL. */
+int parq_prepare(parq_handle h, const parq_scene *scene, void *workspace, size_t workspace_bytes,
+                 parq_stream stream);
+int parq_iterate(parq_handle h, const parq_scene *scene, void *workspace, size_t workspace_bytes,
+                 int32_t layer_num, const float *ref_in, const parq_outputs *outs, float *ref_out,
+                 parq_stream stream);
+
+/* Optional instrumentation: when enabled, parq_forward brackets each kernel group with
+ * hipEvents on `stream`; parq_profile_read synchronises those events and returns the
+ * accumulated milliseconds and launch count of group `which` (see PARQ_PROF_*). */
+enum {
+    PARQ_PROF_KV_PROJ = 0, PARQ_PROF_PROJECT_SAMPLE = 1, PARQ_PROF_CROSS_ATTN = 2,
+    PARQ_PROF_SELF_ATTN = 3, PARQ_PROF_LINEAR = 4, PARQ_PROF_OTHER = 5, PARQ_PROF_COUNT = 6
+};
+int parq_profile_enable(parq_handle h, int32_t on);
+int parq_profile_read(parq_handle h, int32_t which, double *total_ms, int64_t *launches);
+
+/* ---- single kernels (parity tests, roofline measurements) --------------------------- */
+
+/* K4+K5: project (B,Q,3) normalised reference points into every view and bilinearly
+ * sample + view-average the channels-last feature stack (transformer_parq.py:129-161).
+ * T_camera_local (B,V,12).  tgt (B,Q,C); coord_pos (B,Q,3) may be NULL. */
+int parq_k_project_sample(const float *tokens, const float *T_camera_local, const float *camera,
+                          const float *ref, const float *scale6_host, int32_t B, int32_t V, int32_t hh,
+                          int32_t ww, int32_t C, int32_t Q, float *tgt, float *coord_pos,
+                          parq_stream stream);
+
+/* T_camera_local = T_cp ∘ (inv(T_wp) ∘ T_wl)  (transformer_parq.py:298-300). */
+int parq_k_camera_local(const float *T_cp, const float *T_wp, const float *T_wl, int32_t B, int32_t V,
+                        float *T_cl, parq_stream stream);
+
+/* Y[M,N] = act(X[M,K] (+ X2[M,K]) @ W[N,K]^T + bias) (+ R[M,N]); fp32 MFMA.  K % 32 == 0. */
+int parq_k_linear(const float *X, const float *X2, const float *W, const float *bias, const float *R,
+                  float *Y, int32_t M, int32_t N, int32_t K, int32_t relu, parq_stream stream);
+
+/* softmax(Q K^T / sqrt(dh)) V for (B,H) heads; q (B,Lq,H*dh), k/v (B,Lk,H*dh) row-major;
+ * out (B,Lq,H*dh).  scratch must hold parq_k_attention_scratch_bytes(). */
+size_t parq_k_attention_scratch_bytes(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t dh);
+int parq_k_attention(const float *q, const float *k, const float *v, float *out, int32_t B, int32_t H,
+                     int32_t Lq, int32_t Lk, int32_t dh, void *scratch, size_t scratch_bytes,
+                     parq_stream stream);
+
+int parq_k_layernorm(const float *X, const float *gamma, const float *beta, float *Y, int32_t M,
+                     int32_t C, float eps, parq_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARQ_HIP_H */

@@ -161,6 +161,18 @@ def main(only=None):
         arrays["meta"] = np.frombuffer(json.dumps(case, sort_keys=True).encode(), dtype=np.uint8)
         np.savez_compressed(os.path.join(OUT_DIR, name + ".npz"), **arrays)
         print("wrote", name, {k: v.shape for k, v in list(arrays.items())[:3]})
+    if not only or "state_dict_keys" in only:
+        # schema of the reference module's state_dict (names + shapes only) for the drop-in check
+        schema = {}
+        for tag, kw in (("shared_d256", dict(dim=256, queries=64, heads=4, ffn=768, layers=8)),
+                        ("unshared_d128", dict(dim=128, queries=32, heads=2, ffn=192, layers=2, share_weights=False))):
+            cfg = synth.decoder_cfg(**kw)
+            cfg.MEAN_SIZE_PATH = ref.mean_size_path
+            sd = ref.PARQDecoder(cfg).state_dict()
+            schema[tag] = {"cfg": kw, "keys": {k: list(v.shape) for k, v in sd.items()}}
+        with open(os.path.join(OUT_DIR, "state_dict_keys.json"), "w") as f:
+            json.dump(schema, f, indent=1, sort_keys=True)
+        print("wrote state_dict_keys.json")
     if not only or "g5_raype" in only:
         c = RAYPE_CASE
         Wp = synth.make_ray_pe_weights(c["dim"], c["seed"])

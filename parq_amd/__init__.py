@@ -1,0 +1,16 @@
+"""parq_amd — MI355X-native implementation of PARQ's recurrent pixel-aligned decoder path.
+
+Public surface mirrors the reference (ymingxie/PARQ):
+    PARQDecoder  (model/parq_decoder.py:30)      forward on the HIP kernel chain
+    Pose, Camera (utils/wrappers.py:194,441)     tensor wrappers drivers pass in
+The compute lives in ``parq_amd/_C/libparq_hip.so`` (C ABI: include/parq_hip.h).
+"""
+from .wrappers import Camera, Pose, TensorWrapper  # noqa: F401
+
+
+def __getattr__(name):
+    # lazy: importing the package must not require the HIP library (CPU-only tooling, synth)
+    if name == "PARQDecoder":
+        from .decoder import PARQDecoder
+        return PARQDecoder
+    raise AttributeError(name)

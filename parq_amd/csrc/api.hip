@@ -1,0 +1,634 @@
+// C ABI of libparq_hip.so (include/parq_hip.h): handle, weight arena, workspace carving and
+// the host-side orchestration of the kernel chain.  Nothing here synchronises with the
+// device, allocates device memory or touches torch; the caller owns every buffer.
+#include "../../include/parq_hip.h"
+#include "common.hpp"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace parq;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(PARQ_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr int64_t kAlign = 64;   // floats (256 B)
+int64_t align_up(int64_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
+
+struct WeightRef { const float* p; int64_t n; };
+
+// offsets (in floats) into the packed arena
+struct LayerW {
+    int64_t self_in_w, self_in_b, self_out_w, self_out_b;
+    int64_t cross_in_w, cross_in_b, cross_out_w, cross_out_b;
+    int64_t lin1_w, lin1_b, lin2_w, lin2_b;
+    int64_t n1_w, n1_b, n2_w, n2_b, n3_w, n3_b;
+};
+struct Arena {
+    std::vector<LayerW> layers;
+    int64_t refpoint, pe0_w, pe0_b, pe2_w, pe2_b;
+    int64_t heads1_w, heads1_b;       // [NH1][C]: centre.0 | rotation.0 | sem_cls | size | zero pad
+    int64_t gn1_g, gn1_b;             // [2][C]  (centre, rotation) GroupNorm after layer 0
+    int64_t heads2_w;                 // [2][C][C]  centre.4 | rotation.4
+    int64_t gn2_g, gn2_b;             // [2][C]
+    int64_t heads3_w, heads3_b;       // [2][6][C], [2][6]: centre.8 padded to 6 rows | rotation.8
+    int64_t mean_sizes, dim_t;
+    int64_t total;
+};
+
+struct Workspace {
+    int64_t T_cl, kv, ref, ref_next, emb, pe_h, pos, tgt, qkv, attn, xa, x1, qc, xb, x2, ffn, xc, x3;
+    int64_t h1, h2, h3, st1, st2, flash;
+    int64_t total;
+    int self_split, cross_split;
+};
+
+struct ProfEvent { hipEvent_t a, b; int which; };
+
+}  // namespace
+
+struct parq_ctx {
+    parq_config cfg;
+    int C, Q, H, dh, F, I, ncls, NH1, nl;
+    ScaleBox sb;
+    std::map<std::string, WeightRef> named;
+    Arena ar;
+    const float* arena = nullptr;     // device arena after pack
+    bool packed = false;
+    bool prepared = false;
+    int ref_state = 0;                // 0: none, 1: ws.ref valid
+    bool profiling = false;
+    std::vector<ProfEvent> events;
+    double prof_ms[PARQ_PROF_COUNT] = {0};
+    int64_t prof_n[PARQ_PROF_COUNT] = {0};
+};
+
+namespace {
+
+void build_arena(parq_ctx* c) {
+    Arena& a = c->ar;
+    int64_t off = 0;
+    auto take = [&](int64_t n) { int64_t o = off; off += align_up(n); return o; };
+    const int64_t C = c->C, F = c->F, Q = c->Q;
+    a.layers.resize(c->nl);
+    for (auto& L : a.layers) {
+        L.self_in_w = take(3 * C * C); L.self_in_b = take(3 * C);
+        L.self_out_w = take(C * C);    L.self_out_b = take(C);
+        L.cross_in_w = take(3 * C * C); L.cross_in_b = take(3 * C);
+        L.cross_out_w = take(C * C);   L.cross_out_b = take(C);
+        L.lin1_w = take(F * C); L.lin1_b = take(F);
+        L.lin2_w = take(C * F); L.lin2_b = take(C);
+        L.n1_w = take(C); L.n1_b = take(C); L.n2_w = take(C); L.n2_b = take(C); L.n3_w = take(C); L.n3_b = take(C);
+    }
+    a.refpoint = take(Q * 3);
+    a.pe0_w = take(C * 384); a.pe0_b = take(C); a.pe2_w = take(C * C); a.pe2_b = take(C);
+    a.heads1_w = take((int64_t)c->NH1 * C); a.heads1_b = take(c->NH1);
+    a.gn1_g = take(2 * C); a.gn1_b = take(2 * C);
+    a.heads2_w = take(2 * C * C);
+    a.gn2_g = take(2 * C); a.gn2_b = take(2 * C);
+    a.heads3_w = take(2 * 6 * C); a.heads3_b = take(12);
+    a.mean_sizes = take((int64_t)c->cfg.num_mean_sizes * 3);
+    a.dim_t = take(128);
+    a.total = off;
+}
+
+int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws) {
+    const int64_t C = c->C, Q = c->Q, F = c->F;
+    const int64_t M = (int64_t)B * Q;
+    const int64_t N = (int64_t)V * h * w;
+    int64_t off = 0;
+    auto take = [&](int64_t n) { int64_t o = off; off += align_up(n); return o; };
+    ws->T_cl = take((int64_t)B * V * 12);
+    ws->kv = take((int64_t)c->nl * B * 2 * N * C);
+    ws->ref = take(M * 3); ws->ref_next = take(M * 3);
+    ws->emb = take(M * 384); ws->pe_h = take(M * C); ws->pos = take(M * C);
+    ws->tgt = take(M * C); ws->qkv = take(M * 3 * C); ws->attn = take(M * C);
+    ws->xa = take(M * C); ws->x1 = take(M * C); ws->qc = take(M * C);
+    ws->xb = take(M * C); ws->x2 = take(M * C); ws->ffn = take(M * F);
+    ws->xc = take(M * C); ws->x3 = take(M * C);
+    ws->h1 = take(M * c->NH1); ws->h2 = take(M * 2 * C); ws->h3 = take(M * 12);
+    ws->st1 = take((int64_t)B * 4); ws->st2 = take((int64_t)B * 4);
+    const int cus = device_num_cus();
+    ws->self_split = flash_pick_splits(B, c->H, c->Q, c->Q, c->dh, cus);
+    ws->cross_split = flash_pick_splits(B, c->H, c->Q, (int)N, c->dh, cus);
+    const size_t fs = flash_scratch_bytes(B, c->H, c->Q, c->dh, ws->self_split);
+    const size_t fc = flash_scratch_bytes(B, c->H, c->Q, c->dh, ws->cross_split);
+    ws->flash = take((int64_t)((fs > fc ? fs : fc) / sizeof(float)));
+    ws->total = off;
+    return PARQ_OK;
+}
+
+int check_scene(const parq_ctx* c, const parq_scene* s) {
+    if (!s) return fail(PARQ_ERR_ARG, "scene is NULL");
+    if (s->B < 1 || s->V < 1 || s->h < 2 || s->w < 2) return fail(PARQ_ERR_ARG, "bad scene dims B=%d V=%d h=%d w=%d", s->B, s->V, s->h, s->w);
+    if (!s->tokens || !s->camera || !s->T_camera_pseudoCam || !s->T_world_pseudoCam || !s->T_world_local)
+        return fail(PARQ_ERR_ARG, "scene has a NULL tensor");
+    if ((int64_t)s->B * c->Q > (1 << 22)) return fail(PARQ_ERR_ARG, "B*Q too large");
+    return PARQ_OK;
+}
+
+struct Prof {
+    parq_ctx* c; hipStream_t s; int which; hipEvent_t a = nullptr, b = nullptr;
+    Prof(parq_ctx* c_, hipStream_t s_, int w) : c(c_), s(s_), which(w) {
+        if (c->profiling) {
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+            (void)hipEventRecord(a, s);
+        }
+    }
+    ~Prof() {
+        if (a && b) {
+            (void)hipEventRecord(b, s);
+            c->events.push_back({a, b, which});
+        }
+    }
+};
+
+LinearArgs lin(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
+               int M, int N, int K) {
+    LinearArgs a;
+    memset(&a, 0, sizeof(a));
+    a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.Y = Y;
+    a.M = M; a.N = N; a.K = K;
+    a.rows_per_batch = M; a.y_batch = 0; a.y_row = ldy; a.col_blk = N; a.y_blk = 0;
+    return a;
+}
+
+int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& ws, hipStream_t s) {
+    const float* A = c->arena;
+    const int B = sc->B, V = sc->V;
+    const int64_t N = (int64_t)V * sc->h * sc->w;
+    const int C = c->C;
+    {
+        Prof p(c, s, PARQ_PROF_OTHER);
+        HIPCHK(launch_camera_local(sc->T_camera_pseudoCam, sc->T_world_pseudoCam, sc->T_world_local, B, V, wsp + ws.T_cl, s));
+        HIPCHK(launch_initial_ref(A + c->ar.refpoint, B, c->Q, wsp + ws.ref, s));
+    }
+    // hoisted K/V in-projection of the memory tokens: one GEMM per distinct layer,
+    // written head-major [b][{K heads, V heads}][N][dh] so the attention kernel streams contiguous panels
+    if ((int64_t)B * N > (int64_t)INT32_MAX) return fail(PARQ_ERR_ARG, "B*N too large");
+    for (int li = 0; li < c->nl; ++li) {
+        Prof p(c, s, PARQ_PROF_KV_PROJ);
+        const LayerW& L = c->ar.layers[li];
+        LinearArgs a = lin(sc->tokens, C, A + L.cross_in_w + (int64_t)C * C, C, A + L.cross_in_b + C,
+                           wsp + ws.kv + (int64_t)li * B * 2 * N * C, 0, (int)(B * N), 2 * C, C);
+        a.rows_per_batch = (int)N; a.y_batch = 2 * N * C; a.y_row = c->dh; a.col_blk = c->dh; a.y_blk = N * c->dh;
+        HIPCHK(launch_linear(a, 1, s));
+    }
+    c->prepared = true;
+    c->ref_state = 1;
+    return PARQ_OK;
+}
+
+int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& ws, int layer_num, const float* ref,
+               const parq_outputs* o, float* ref_out, hipStream_t s) {
+    const float* A = c->arena;
+    const Arena& ar = c->ar;
+    const int li = c->cfg.share_weights ? 0 : layer_num;
+    const LayerW& L = ar.layers[li];
+    const int B = sc->B, C = c->C, Q = c->Q, H = c->H, dh = c->dh, F = c->F;
+    const int M = B * Q;
+    const int64_t N = (int64_t)sc->V * sc->h * sc->w;
+
+    // K3: sine embedding -> position MLP (transformer_parq.py:317)
+    { Prof p(c, s, PARQ_PROF_OTHER); HIPCHK(launch_posemb(ref, A + ar.dim_t, M, wsp + ws.emb, s)); }
+    {
+        Prof p(c, s, PARQ_PROF_LINEAR);
+        LinearArgs a = lin(wsp + ws.emb, 384, A + ar.pe0_w, 384, A + ar.pe0_b, wsp + ws.pe_h, C, M, C, 384);
+        a.relu = 1;
+        HIPCHK(launch_linear(a, 1, s));
+        a = lin(wsp + ws.pe_h, C, A + ar.pe2_w, C, A + ar.pe2_b, wsp + ws.pos, C, M, C, C);
+        HIPCHK(launch_linear(a, 1, s));
+    }
+    // K4+K5: project + sample (transformer_parq.py:321)
+    {
+        Prof p(c, s, PARQ_PROF_PROJECT_SAMPLE);
+        HIPCHK(launch_project_sample(sc->tokens, wsp + ws.T_cl, sc->camera, ref, c->sb, B, sc->V, sc->h, sc->w, C, Q,
+                                     wsp + ws.tgt, o->coord_pos, s));
+    }
+    // K6: self-attention, q = k = tgt + pos, v = tgt (transformer_parq.py:372-376)
+    {
+        Prof p(c, s, PARQ_PROF_LINEAR);
+        LinearArgs a = lin(wsp + ws.tgt, C, A + L.self_in_w, C, A + L.self_in_b, wsp + ws.qkv, 3 * C, M, 3 * C, C);
+        a.X2 = wsp + ws.pos; a.ldx2 = C; a.x2_ncols = 2 * C;
+        HIPCHK(launch_linear(a, 1, s));
+    }
+    FlashArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.B = B; fa.H = H; fa.Lq = Q; fa.dh = dh;
+    fa.out = wsp + ws.attn; fa.out_batch = (int64_t)Q * C; fa.out_row = C;
+    {
+        Prof p(c, s, PARQ_PROF_SELF_ATTN);
+        fa.q = wsp + ws.qkv;         fa.q_batch = (int64_t)Q * 3 * C; fa.q_head = dh; fa.q_row = 3 * C;
+        fa.k = wsp + ws.qkv + C;     fa.k_batch = fa.q_batch; fa.k_head = dh; fa.k_row = 3 * C;
+        fa.v = wsp + ws.qkv + 2 * C; fa.v_batch = fa.q_batch; fa.v_head = dh; fa.v_row = 3 * C;
+        fa.Lk = Q; fa.nsplit = ws.self_split;
+        const int64_t lp = flash_lq_pad(Q);
+        fa.o_part = wsp + ws.flash;
+        fa.m_part = fa.o_part + (int64_t)B * H * fa.nsplit * dh * lp;
+        fa.l_part = fa.m_part + (int64_t)B * H * fa.nsplit * lp;
+        HIPCHK(launch_flash(fa, s));
+        HIPCHK(launch_flash_merge(fa, s));
+    }
+    {
+        Prof p(c, s, PARQ_PROF_LINEAR);
+        LinearArgs a = lin(wsp + ws.attn, C, A + L.self_out_w, C, A + L.self_out_b, wsp + ws.xa, C, M, C, C);
+        a.R = wsp + ws.tgt; a.ldr = C;
+        HIPCHK(launch_linear(a, 1, s));
+    }
+    { Prof p(c, s, PARQ_PROF_OTHER); HIPCHK(launch_layernorm(wsp + ws.xa, A + L.n1_w, A + L.n1_b, wsp + ws.x1, M, C, 1e-5f, s)); }
+    // K7: dense cross-attention against the cached K/V (transformer_parq.py:377-382)
+    {
+        Prof p(c, s, PARQ_PROF_LINEAR);
+        LinearArgs a = lin(wsp + ws.x1, C, A + L.cross_in_w, C, A + L.cross_in_b, wsp + ws.qc, C, M, C, C);
+        a.X2 = wsp + ws.pos; a.ldx2 = C; a.x2_ncols = C;
+        HIPCHK(launch_linear(a, 1, s));
+    }
+    {
+        Prof p(c, s, PARQ_PROF_CROSS_ATTN);
+        const float* kv = wsp + ws.kv + (int64_t)li * B * 2 * N * C;
+        fa.q = wsp + ws.qc; fa.q_batch = (int64_t)Q * C; fa.q_head = dh; fa.q_row = C;
+        fa.k = kv;                       fa.k_batch = 2 * N * C; fa.k_head = N * dh; fa.k_row = dh;
+        fa.v = kv + (int64_t)H * N * dh; fa.v_batch = 2 * N * C; fa.v_head = N * dh; fa.v_row = dh;
+        fa.Lk = (int)N; fa.nsplit = ws.cross_split;
+        const int64_t lp = flash_lq_pad(Q);
+        fa.o_part = wsp + ws.flash;
+        fa.m_part = fa.o_part + (int64_t)B * H * fa.nsplit * dh * lp;
+        fa.l_part = fa.m_part + (int64_t)B * H * fa.nsplit * lp;
+        HIPCHK(launch_flash(fa, s));
+        HIPCHK(launch_flash_merge(fa, s));
+    }
+    {
+        Prof p(c, s, PARQ_PROF_LINEAR);
+        LinearArgs a = lin(wsp + ws.attn, C, A + L.cross_out_w, C, A + L.cross_out_b, wsp + ws.xb, C, M, C, C);
+        a.R = wsp + ws.x1; a.ldr = C;
+        HIPCHK(launch_linear(a, 1, s));
+    }
+    { Prof p(c, s, PARQ_PROF_OTHER); HIPCHK(launch_layernorm(wsp + ws.xb, A + L.n2_w, A + L.n2_b, wsp + ws.x2, M, C, 1e-5f, s)); }
+    // K8: FFN (transformer_parq.py:383-385)
+    {
+        Prof p(c, s, PARQ_PROF_LINEAR);
+        LinearArgs a = lin(wsp + ws.x2, C, A + L.lin1_w, C, A + L.lin1_b, wsp + ws.ffn, F, M, F, C);
+        a.relu = 1;
+        HIPCHK(launch_linear(a, 1, s));
+        a = lin(wsp + ws.ffn, F, A + L.lin2_w, F, A + L.lin2_b, wsp + ws.xc, C, M, C, F);
+        a.R = wsp + ws.x2; a.ldr = C;
+        HIPCHK(launch_linear(a, 1, s));
+    }
+    { Prof p(c, s, PARQ_PROF_OTHER); HIPCHK(launch_layernorm(wsp + ws.xc, A + L.n3_w, A + L.n3_b, wsp + ws.x3, M, C, 1e-5f, s)); }
+    // K9: heads (transformer_parq.py:234-252; generic_mlp.py:85-110)
+    const int NH1 = c->NH1;
+    {
+        Prof p(c, s, PARQ_PROF_LINEAR);
+        LinearArgs a = lin(wsp + ws.x3, C, A + ar.heads1_w, C, A + ar.heads1_b, wsp + ws.h1, NH1, M, NH1, C);
+        HIPCHK(launch_linear(a, 1, s));
+    }
+    { Prof p(c, s, PARQ_PROF_OTHER); HIPCHK(launch_gn_stats(wsp + ws.h1, NH1, 0, C, 2, B, Q, 1e-5f, wsp + ws.st1, s)); }
+    {
+        Prof p(c, s, PARQ_PROF_LINEAR);
+        LinearArgs a = lin(wsp + ws.h1, NH1, A + ar.heads2_w, C, nullptr, wsp + ws.h2, 2 * C, M, C, C);
+        a.gn_stats = wsp + ws.st1; a.gn_gamma = A + ar.gn1_g; a.gn_beta = A + ar.gn1_b;
+        a.gn_rows_per_scene = Q; a.gn_ngroups = 2;
+        a.gX = C; a.gW = (int64_t)C * C; a.gY = C; a.gGamma = C;
+        HIPCHK(launch_linear(a, 2, s));
+    }
+    { Prof p(c, s, PARQ_PROF_OTHER); HIPCHK(launch_gn_stats(wsp + ws.h2, 2 * C, 0, C, 2, B, Q, 1e-5f, wsp + ws.st2, s)); }
+    {
+        Prof p(c, s, PARQ_PROF_LINEAR);
+        LinearArgs a = lin(wsp + ws.h2, 2 * C, A + ar.heads3_w, C, A + ar.heads3_b, wsp + ws.h3, 12, M, 6, C);
+        a.gn_stats = wsp + ws.st2; a.gn_gamma = A + ar.gn2_g; a.gn_beta = A + ar.gn2_b;
+        a.gn_rows_per_scene = Q; a.gn_ngroups = 2;
+        a.gX = C; a.gW = (int64_t)6 * C; a.gBias = 6; a.gY = 6; a.gGamma = C;
+        HIPCHK(launch_linear(a, 2, s));
+    }
+    // K10: box decode + reference point update (transformer_parq.py:242-279, 331-332)
+    {
+        Prof p(c, s, PARQ_PROF_OTHER);
+        BoxDecodeArgs d;
+        memset(&d, 0, sizeof(d));
+        d.h1 = wsp + ws.h1 + 2 * C; d.ld1 = NH1;
+        d.h3 = wsp + ws.h3; d.ld3 = 12;
+        d.ref = ref; d.mean_sizes = A + ar.mean_sizes; d.n_mean = c->cfg.num_mean_sizes;
+        d.sb = c->sb; d.M = M; d.ncls = c->ncls;
+        d.logits = o->pred_logits; d.center = o->center_unnormalized; d.size = o->size_unnormalized;
+        d.rot = o->ortho6d; d.prob = o->sem_cls_prob; d.ref_next = ref_out;
+        HIPCHK(launch_box_decode(d, s));
+    }
+    return PARQ_OK;
+}
+
+int check_outs(const parq_outputs* o) {
+    if (!o || !o->pred_logits || !o->center_unnormalized || !o->size_unnormalized || !o->ortho6d || !o->sem_cls_prob ||
+        !o->coord_pos)
+        return fail(PARQ_ERR_ARG, "outputs has a NULL tensor");
+    return PARQ_OK;
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+
+extern "C" {
+
+const char* parq_last_error(void) { return g_err; }
+const char* parq_version(void) { return "parq_hip 0.1 (gfx950, fp32 MFMA)"; }
+
+int parq_create(const parq_config* cfg, parq_handle* out) {
+    if (!cfg || !out) return fail(PARQ_ERR_ARG, "NULL argument");
+    if (cfg->dim < 32 || cfg->dim % 32 != 0 || cfg->dim > 1024) return fail(PARQ_ERR_ARG, "dim=%d must be a multiple of 32 in [32,1024]", cfg->dim);
+    if (cfg->num_heads < 1 || cfg->dim % cfg->num_heads != 0) return fail(PARQ_ERR_ARG, "dim %% num_heads != 0");
+    const int dh = cfg->dim / cfg->num_heads;
+    if (!(dh == 32 || dh == 64 || dh == 128 || dh == 256)) return fail(PARQ_ERR_ARG, "head dim %d unsupported (32/64/128/256)", dh);
+    if (cfg->ffn_dim < 32 || cfg->ffn_dim % 32 != 0) return fail(PARQ_ERR_ARG, "ffn_dim must be a multiple of 32");
+    if (cfg->num_queries < 1 || cfg->num_layers < 1) return fail(PARQ_ERR_ARG, "num_queries/num_layers must be >= 1");
+    if (cfg->num_classes < 2 || cfg->num_classes > 32) return fail(PARQ_ERR_ARG, "num_classes must be in [2,32]");
+    if (cfg->num_mean_sizes < 1) return fail(PARQ_ERR_ARG, "num_mean_sizes must be >= 1");
+    for (int i = 0; i < 3; ++i)
+        if (!(cfg->scale[2 * i + 1] > cfg->scale[2 * i])) return fail(PARQ_ERR_ARG, "scale must be increasing per axis");
+    parq_ctx* c = new parq_ctx();
+    c->cfg = *cfg;
+    c->C = cfg->dim; c->Q = cfg->num_queries; c->H = cfg->num_heads; c->dh = dh; c->F = cfg->ffn_dim;
+    c->I = cfg->num_layers; c->ncls = cfg->num_classes;
+    c->nl = cfg->share_weights ? 1 : cfg->num_layers;
+    c->NH1 = 2 * c->C + ((c->ncls + 3 + 3) / 4) * 4;
+    for (int i = 0; i < 3; ++i) { c->sb.lo[i] = cfg->scale[2 * i]; c->sb.hi[i] = cfg->scale[2 * i + 1]; }
+    build_arena(c);
+    *out = c;
+    return PARQ_OK;
+}
+
+int parq_destroy(parq_handle h) {
+    if (!h) return PARQ_OK;
+    for (auto& e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    delete h;
+    return PARQ_OK;
+}
+
+int parq_set_weight(parq_handle h, const char* name, const float* dev, int64_t numel) {
+    if (!h || !name || !dev || numel <= 0) return fail(PARQ_ERR_ARG, "bad argument to parq_set_weight");
+    std::string n(name);
+    const std::string dup = "parq_module.decoder.mlp_heads.";      // same storage as mlp_heads.* (parq_decoder.py:66)
+    if (n.compare(0, dup.size(), dup) == 0) n = "mlp_heads." + n.substr(dup.size());
+    h->named[n] = WeightRef{dev, numel};
+    h->packed = false;
+    return PARQ_OK;
+}
+
+size_t parq_packed_weights_bytes(parq_handle h) { return h ? (size_t)h->ar.total * sizeof(float) : 0; }
+
+int parq_pack_weights(parq_handle h, void* arena_v, size_t arena_bytes, parq_stream stream) {
+    if (!h || !arena_v) return fail(PARQ_ERR_ARG, "NULL argument");
+    if (arena_bytes < (size_t)h->ar.total * sizeof(float)) return fail(PARQ_ERR_WORKSPACE, "weight arena too small");
+    hipStream_t s = (hipStream_t)stream;
+    float* A = (float*)arena_v;
+    parq_ctx* c = h;
+    const int64_t C = c->C, F = c->F, Q = c->Q;
+    int rc = PARQ_OK;
+    auto get = [&](const std::string& name, int64_t numel) -> const float* {
+        auto it = c->named.find(name);
+        if (it == c->named.end()) { rc = fail(PARQ_ERR_STATE, "weight '%s' was never set", name.c_str()); return nullptr; }
+        if (it->second.n != numel) { rc = fail(PARQ_ERR_ARG, "weight '%s' has %lld elements, expected %lld", name.c_str(), (long long)it->second.n, (long long)numel); return nullptr; }
+        return it->second.p;
+    };
+    auto copy = [&](const std::string& name, int64_t dst, int64_t numel) -> bool {
+        const float* p = get(name, numel);
+        if (!p) return false;
+        hipError_t e = hipMemcpyAsync(A + dst, p, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) { rc = fail(PARQ_ERR_HIP, "hipMemcpyAsync(%s): %s", name.c_str(), hipGetErrorString(e)); return false; }
+        return true;
+    };
+    HIPCHK(hipMemsetAsync(A, 0, (size_t)c->ar.total * sizeof(float), s));
+    for (int li = 0; li < c->nl; ++li) {
+        const LayerW& L = c->ar.layers[li];
+        const std::string p = "parq_module.decoder.layers." + std::to_string(li) + ".";
+        if (!copy(p + "self_attn.in_proj_weight", L.self_in_w, 3 * C * C) || !copy(p + "self_attn.in_proj_bias", L.self_in_b, 3 * C) ||
+            !copy(p + "self_attn.out_proj.weight", L.self_out_w, C * C) || !copy(p + "self_attn.out_proj.bias", L.self_out_b, C) ||
+            !copy(p + "multihead_attn.in_proj_weight", L.cross_in_w, 3 * C * C) || !copy(p + "multihead_attn.in_proj_bias", L.cross_in_b, 3 * C) ||
+            !copy(p + "multihead_attn.out_proj.weight", L.cross_out_w, C * C) || !copy(p + "multihead_attn.out_proj.bias", L.cross_out_b, C) ||
+            !copy(p + "linear1.weight", L.lin1_w, F * C) || !copy(p + "linear1.bias", L.lin1_b, F) ||
+            !copy(p + "linear2.weight", L.lin2_w, C * F) || !copy(p + "linear2.bias", L.lin2_b, C) ||
+            !copy(p + "norm1.weight", L.n1_w, C) || !copy(p + "norm1.bias", L.n1_b, C) ||
+            !copy(p + "norm2.weight", L.n2_w, C) || !copy(p + "norm2.bias", L.n2_b, C) ||
+            !copy(p + "norm3.weight", L.n3_w, C) || !copy(p + "norm3.bias", L.n3_b, C))
+            return rc;
+    }
+    const Arena& ar = c->ar;
+    const std::string d = "parq_module.decoder.";
+    const std::string hc = "mlp_heads.center_head.layers.", hr = "mlp_heads.rotation_head.layers.";
+    const int ncls = c->ncls;
+    if (!copy("refpoint.weight", ar.refpoint, Q * 3) ||
+        !copy(d + "position_encoder.0.weight", ar.pe0_w, C * 384) || !copy(d + "position_encoder.0.bias", ar.pe0_b, C) ||
+        !copy(d + "position_encoder.2.weight", ar.pe2_w, C * C) || !copy(d + "position_encoder.2.bias", ar.pe2_b, C) ||
+        // fused first head layer: [centre.0 ; rotation.0 ; sem_cls ; size]
+        !copy(hc + "0.weight", ar.heads1_w, C * C) || !copy(hr + "0.weight", ar.heads1_w + C * C, C * C) ||
+        !copy("mlp_heads.sem_cls_head.layers.0.weight", ar.heads1_w + 2 * C * C, ncls * C) ||
+        !copy("mlp_heads.size_head.layers.0.weight", ar.heads1_w + (2 * C + ncls) * C, 3 * C) ||
+        !copy("mlp_heads.sem_cls_head.layers.0.bias", ar.heads1_b + 2 * C, ncls) ||
+        !copy("mlp_heads.size_head.layers.0.bias", ar.heads1_b + 2 * C + ncls, 3) ||
+        !copy(hc + "1.weight", ar.gn1_g, C) || !copy(hr + "1.weight", ar.gn1_g + C, C) ||
+        !copy(hc + "1.bias", ar.gn1_b, C) || !copy(hr + "1.bias", ar.gn1_b + C, C) ||
+        !copy(hc + "4.weight", ar.heads2_w, C * C) || !copy(hr + "4.weight", ar.heads2_w + C * C, C * C) ||
+        !copy(hc + "5.weight", ar.gn2_g, C) || !copy(hr + "5.weight", ar.gn2_g + C, C) ||
+        !copy(hc + "5.bias", ar.gn2_b, C) || !copy(hr + "5.bias", ar.gn2_b + C, C) ||
+        !copy(hc + "8.weight", ar.heads3_w, 3 * C) || !copy(hr + "8.weight", ar.heads3_w + 6 * C, 6 * C) ||
+        !copy(hc + "8.bias", ar.heads3_b, 3) || !copy(hr + "8.bias", ar.heads3_b + 6, 6) ||
+        !copy("mean_sizes", ar.mean_sizes, (int64_t)c->cfg.num_mean_sizes * 3))
+        return rc;
+    // dim_t[i] = 10000^(2*(i//2)/128) in float32 (transformer_parq.py:49-50)
+    float dim_t[128];
+    for (int i = 0; i < 128; ++i) dim_t[i] = powf(10000.0f, 2.0f * (float)(i / 2) / 128.0f);
+    // small host table: stage it through a pageable copy (synchronous w.r.t. the host buffer)
+    HIPCHK(hipMemcpyAsync(A + ar.dim_t, dim_t, sizeof(dim_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));   // dim_t lives on this stack frame
+    c->arena = A;
+    c->packed = true;
+    c->prepared = false;
+    return PARQ_OK;
+}
+
+size_t parq_workspace_bytes(parq_handle h, int32_t B, int32_t V, int32_t hh, int32_t ww) {
+    if (!h || B < 1 || V < 1 || hh < 1 || ww < 1) return 0;
+    Workspace ws;
+    carve_workspace(h, B, V, hh, ww, &ws);
+    return (size_t)ws.total * sizeof(float);
+}
+
+int parq_prepare(parq_handle h, const parq_scene* scene, void* workspace, size_t workspace_bytes, parq_stream stream) {
+    if (!h || !workspace) return fail(PARQ_ERR_ARG, "NULL argument");
+    if (!h->packed) return fail(PARQ_ERR_STATE, "parq_pack_weights must be called first");
+    int rc = check_scene(h, scene);
+    if (rc) return rc;
+    Workspace ws;
+    carve_workspace(h, scene->B, scene->V, scene->h, scene->w, &ws);
+    if (workspace_bytes < (size_t)ws.total * sizeof(float)) return fail(PARQ_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, (size_t)ws.total * sizeof(float));
+    return do_prepare(h, scene, (float*)workspace, ws, (hipStream_t)stream);
+}
+
+int parq_iterate(parq_handle h, const parq_scene* scene, void* workspace, size_t workspace_bytes, int32_t layer_num,
+                 const float* ref_in, const parq_outputs* outs, float* ref_out, parq_stream stream) {
+    if (!h || !workspace) return fail(PARQ_ERR_ARG, "NULL argument");
+    if (!h->packed || !h->prepared) return fail(PARQ_ERR_STATE, "parq_prepare must be called first");
+    int rc = check_scene(h, scene);
+    if (rc) return rc;
+    rc = check_outs(outs);
+    if (rc) return rc;
+    if (layer_num < 0 || layer_num >= h->I) return fail(PARQ_ERR_ARG, "layer_num out of range");
+    Workspace ws;
+    carve_workspace(h, scene->B, scene->V, scene->h, scene->w, &ws);
+    if (workspace_bytes < (size_t)ws.total * sizeof(float)) return fail(PARQ_ERR_WORKSPACE, "workspace too small");
+    float* wsp = (float*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    const float* ref = ref_in ? ref_in : wsp + ws.ref;
+    rc = do_iterate(h, scene, wsp, ws, layer_num, ref, outs, wsp + ws.ref_next, s);
+    if (rc) return rc;
+    const size_t rb = (size_t)scene->B * h->Q * 3 * sizeof(float);
+    HIPCHK(hipMemcpyAsync(wsp + ws.ref, wsp + ws.ref_next, rb, hipMemcpyDeviceToDevice, s));
+    if (ref_out) HIPCHK(hipMemcpyAsync(ref_out, wsp + ws.ref_next, rb, hipMemcpyDeviceToDevice, s));
+    return PARQ_OK;
+}
+
+int parq_forward(parq_handle h, const parq_scene* scene, void* workspace, size_t workspace_bytes,
+                 const parq_outputs* outs, parq_stream stream) {
+    if (!h || !workspace) return fail(PARQ_ERR_ARG, "NULL argument");
+    if (!h->packed) return fail(PARQ_ERR_STATE, "parq_pack_weights must be called first");
+    int rc = check_scene(h, scene);
+    if (rc) return rc;
+    rc = check_outs(outs);
+    if (rc) return rc;
+    Workspace ws;
+    carve_workspace(h, scene->B, scene->V, scene->h, scene->w, &ws);
+    if (workspace_bytes < (size_t)ws.total * sizeof(float)) return fail(PARQ_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, (size_t)ws.total * sizeof(float));
+    float* wsp = (float*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    rc = do_prepare(h, scene, wsp, ws, s);
+    if (rc) return rc;
+    const int64_t M = (int64_t)scene->B * h->Q;
+    float* ra = wsp + ws.ref;
+    float* rb = wsp + ws.ref_next;
+    for (int k = 0; k < h->I; ++k) {
+        parq_outputs o;
+        o.pred_logits = outs->pred_logits + k * M * h->ncls;
+        o.center_unnormalized = outs->center_unnormalized + k * M * 3;
+        o.size_unnormalized = outs->size_unnormalized + k * M * 3;
+        o.ortho6d = outs->ortho6d + k * M * 6;
+        o.sem_cls_prob = outs->sem_cls_prob + k * M * h->ncls;
+        o.coord_pos = outs->coord_pos + k * M * 3;
+        rc = do_iterate(h, scene, wsp, ws, k, ra, &o, rb, s);     // ping-pong the reference points
+        if (rc) return rc;
+        float* t = ra; ra = rb; rb = t;
+    }
+    h->ref_state = 0;       // ws.ref / ws.ref_next roles depend on parity; stepping must re-prepare
+    h->prepared = false;
+    return PARQ_OK;
+}
+
+int parq_profile_enable(parq_handle h, int32_t on) {
+    if (!h) return fail(PARQ_ERR_ARG, "NULL handle");
+    h->profiling = on != 0;
+    return PARQ_OK;
+}
+
+int parq_profile_read(parq_handle h, int32_t which, double* total_ms, int64_t* launches) {
+    if (!h || which < 0 || which >= PARQ_PROF_COUNT) return fail(PARQ_ERR_ARG, "bad argument");
+    for (auto& e : h->events) {
+        HIPCHK(hipEventSynchronize(e.b));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+        h->prof_ms[e.which] += ms;
+        h->prof_n[e.which] += 1;
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    h->events.clear();
+    if (total_ms) *total_ms = h->prof_ms[which];
+    if (launches) *launches = h->prof_n[which];
+    h->prof_ms[which] = 0;
+    h->prof_n[which] = 0;
+    return PARQ_OK;
+}
+
+// ------------------------------------------------------------------ single kernels
+
+int parq_k_camera_local(const float* T_cp, const float* T_wp, const float* T_wl, int32_t B, int32_t V, float* T_cl,
+                        parq_stream stream) {
+    if (!T_cp || !T_wp || !T_wl || !T_cl || B < 1 || V < 1) return fail(PARQ_ERR_ARG, "bad argument");
+    HIPCHK(launch_camera_local(T_cp, T_wp, T_wl, B, V, T_cl, (hipStream_t)stream));
+    return PARQ_OK;
+}
+
+int parq_k_project_sample(const float* tokens, const float* T_cl, const float* camera, const float* ref,
+                          const float* scale6_host, int32_t B, int32_t V, int32_t hh, int32_t ww, int32_t C, int32_t Q,
+                          float* tgt, float* coord_pos, parq_stream stream) {
+    if (!tokens || !T_cl || !camera || !ref || !scale6_host || !tgt) return fail(PARQ_ERR_ARG, "NULL argument");
+    if (B < 1 || V < 1 || hh < 2 || ww < 2 || Q < 1 || C % 4 != 0 || C > 1024) return fail(PARQ_ERR_ARG, "bad dims");
+    ScaleBox sb;
+    for (int i = 0; i < 3; ++i) { sb.lo[i] = scale6_host[2 * i]; sb.hi[i] = scale6_host[2 * i + 1]; }
+    HIPCHK(launch_project_sample(tokens, T_cl, camera, ref, sb, B, V, hh, ww, C, Q, tgt, coord_pos, (hipStream_t)stream));
+    return PARQ_OK;
+}
+
+int parq_k_linear(const float* X, const float* X2, const float* W, const float* bias, const float* R, float* Y,
+                  int32_t M, int32_t N, int32_t K, int32_t relu, parq_stream stream) {
+    if (!X || !W || !Y || M < 1 || N < 1 || K < 32 || K % 32 != 0) return fail(PARQ_ERR_ARG, "bad argument (K must be a multiple of 32)");
+    LinearArgs a = lin(X, K, W, K, bias, Y, N, M, N, K);
+    a.X2 = X2; a.ldx2 = K; a.x2_ncols = N;
+    a.R = R; a.ldr = N; a.relu = relu;
+    HIPCHK(launch_linear(a, 1, (hipStream_t)stream));
+    return PARQ_OK;
+}
+
+size_t parq_k_attention_scratch_bytes(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t dh) {
+    const int ns = flash_pick_splits(B, H, Lq, Lk, dh, device_num_cus());
+    return flash_scratch_bytes(B, H, Lq, dh, ns);
+}
+
+int parq_k_attention(const float* q, const float* k, const float* v, float* out, int32_t B, int32_t H, int32_t Lq,
+                     int32_t Lk, int32_t dh, void* scratch, size_t scratch_bytes, parq_stream stream) {
+    if (!q || !k || !v || !out || !scratch) return fail(PARQ_ERR_ARG, "NULL argument");
+    if (!(dh == 32 || dh == 64 || dh == 128 || dh == 256) || B < 1 || H < 1 || Lq < 1 || Lk < 1) return fail(PARQ_ERR_ARG, "bad dims");
+    FlashArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    const int64_t C = (int64_t)H * dh;
+    fa.B = B; fa.H = H; fa.Lq = Lq; fa.Lk = Lk; fa.dh = dh;
+    fa.q = q; fa.q_batch = Lq * C; fa.q_head = dh; fa.q_row = C;
+    fa.k = k; fa.k_batch = Lk * C; fa.k_head = dh; fa.k_row = C;
+    fa.v = v; fa.v_batch = Lk * C; fa.v_head = dh; fa.v_row = C;
+    fa.out = out; fa.out_batch = Lq * C; fa.out_row = C;
+    fa.nsplit = flash_pick_splits(B, H, Lq, Lk, dh, device_num_cus());
+    if (scratch_bytes < flash_scratch_bytes(B, H, Lq, dh, fa.nsplit)) return fail(PARQ_ERR_WORKSPACE, "attention scratch too small");
+    const int64_t lp = flash_lq_pad(Lq);
+    fa.o_part = (float*)scratch;
+    fa.m_part = fa.o_part + (int64_t)B * H * fa.nsplit * dh * lp;
+    fa.l_part = fa.m_part + (int64_t)B * H * fa.nsplit * lp;
+    HIPCHK(launch_flash(fa, (hipStream_t)stream));
+    HIPCHK(launch_flash_merge(fa, (hipStream_t)stream));
+    return PARQ_OK;
+}
+
+int parq_k_layernorm(const float* X, const float* gamma, const float* beta, float* Y, int32_t M, int32_t C, float eps,
+                     parq_stream stream) {
+    if (!X || !gamma || !beta || !Y || M < 1 || C < 1 || C > 1024) return fail(PARQ_ERR_ARG, "bad argument");
+    HIPCHK(launch_layernorm(X, gamma, beta, Y, M, C, eps, (hipStream_t)stream));
+    return PARQ_OK;
+}
+
+}  // extern "C"

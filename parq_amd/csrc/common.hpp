@@ -1,0 +1,98 @@
+// Shared declarations of the gfx950 kernel chain behind libparq_hip.so.
+// Everything here targets CDNA4 (wave64, MFMA f32 32x32x2) directly.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace parq {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWave = 64;
+
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Row of a 32x32 MFMA C/D tile held in register `reg` of lane `lane`
+// (col = lane & 31):  row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+__device__ __forceinline__ int mfma32_row(int reg, int lane) {
+    return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+}
+
+// ------------------------------------------------------------------ linear (small GEMM)
+struct LinearArgs {
+    const float* X;  int64_t ldx;       // A operand, row-major [M][K] with row stride ldx
+    const float* X2; int64_t ldx2;      // optional addend on A (e.g. + pos_feat) ...
+    int x2_ncols;                       // ... applied only to output columns < x2_ncols (tile granular)
+    const float* W;  int64_t ldw;       // [N][K] row-major (torch Linear / Conv1d(k=1) weight)
+    const float* bias;                  // [N] or nullptr
+    const float* R;  int64_t ldr;       // residual [M][N] or nullptr
+    float* Y;
+    int M, N, K;
+    int relu;
+    // output address: Y + (m / rows_per_batch) * y_batch + (m % rows_per_batch) * y_row
+    //                   + (n / col_blk) * y_blk + (n % col_blk)
+    int rows_per_batch; int64_t y_batch; int64_t y_row; int col_blk; int64_t y_blk;
+    // GroupNorm(1 group over rows_per_scene x K) + ReLU applied to A on load:
+    //   a' = relu((a - mean) * rstd * gamma[k] + beta[k]),  (mean, rstd) = gn_stats[scene][group]
+    const float* gn_stats; const float* gn_gamma; const float* gn_beta;
+    int gn_rows_per_scene; int gn_ngroups;
+    // grouped launch: blockIdx.y = g adds these element offsets
+    int64_t gX, gW, gBias, gY, gGamma;
+};
+hipError_t launch_linear(const LinearArgs& a, int groups, hipStream_t s);
+
+// ------------------------------------------------------------------ attention
+struct FlashArgs {
+    const float* q; int64_t q_batch, q_head, q_row;     // element strides
+    const float* k; int64_t k_batch, k_head, k_row;
+    const float* v; int64_t v_batch, v_head, v_row;
+    int B, H, Lq, Lk, dh;
+    int nsplit;                 // key splits (each writes one partial)
+    float* o_part;              // [B*H][nsplit][dh][Lq_pad]
+    float* m_part;              // [B*H][nsplit][Lq_pad]   (log2 domain running max)
+    float* l_part;              // [B*H][nsplit][Lq_pad]
+    float* out; int64_t out_batch, out_row;              // merged (b, q, h*dh + d)
+};
+int flash_key_tile(int dh);                    // keys per LDS tile
+int flash_lq_pad(int Lq);
+int flash_pick_nw(int B, int H, int Lq, int Lk, int dh, int num_cus);   // waves per workgroup
+int flash_pick_splits(int B, int H, int Lq, int Lk, int dh, int num_cus);
+int device_num_cus();                          // cached CU count of the current device
+size_t flash_scratch_bytes(int B, int H, int Lq, int dh, int nsplit);
+hipError_t launch_flash(const FlashArgs& a, hipStream_t s);       // partials
+hipError_t launch_flash_merge(const FlashArgs& a, hipStream_t s); // partials -> out
+
+// ------------------------------------------------------------------ elementwise / gather kernels
+hipError_t launch_camera_local(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V,
+                               float* T_cl, hipStream_t s);
+hipError_t launch_initial_ref(const float* refpoint_w, int B, int Q, float* ref, hipStream_t s);
+hipError_t launch_posemb(const float* ref, const float* dim_t, int M, float* emb, hipStream_t s);
+struct ScaleBox { float lo[3]; float hi[3]; };
+hipError_t launch_project_sample(const float* tokens, const float* T_cl, const float* cam, const float* ref,
+                                 ScaleBox sb, int B, int V, int h, int w, int C, int Q, float* tgt,
+                                 float* coord_pos, hipStream_t s);
+hipError_t launch_layernorm(const float* X, const float* gamma, const float* beta, float* Y, int M, int C,
+                            float eps, hipStream_t s);
+// mean / rstd over (rows_per_scene x ncols) blocks: stats[(b * ngroups + g) * 2 + {0,1}]
+hipError_t launch_gn_stats(const float* X, int64_t ldx, int col0, int ncols, int ngroups, int B,
+                           int rows_per_scene, float eps, float* stats, hipStream_t s);
+struct BoxDecodeArgs {
+    const float* h1; int64_t ld1;      // [M][..]: logits at cols [0,ncls), size_raw at [ncls, ncls+3)
+    const float* h3; int64_t ld3;      // [M][9]: centre_raw (3) | ortho6d (6)
+    const float* ref;                  // [M][3] normalised reference points of this iteration
+    const float* mean_sizes; int n_mean;
+    ScaleBox sb; int M; int ncls;
+    float *logits, *center, *size, *rot, *prob;     // outputs (coord_pos is written by project_sample)
+    float* ref_next;                   // [M][3] or nullptr
+};
+hipError_t launch_box_decode(const BoxDecodeArgs& a, hipStream_t s);
+// weight packing helpers
+hipError_t launch_copy_rows(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int rows, int cols,
+                            hipStream_t s);
+hipError_t launch_fill(float* dst, float value, int64_t n, hipStream_t s);
+
+}  // namespace parq

@@ -1,0 +1,428 @@
+// Gather / elementwise / reduction kernels of the PARQ decoder chain (gfx950).
+//
+//   camera_local    T_camera_local = T_cp ∘ (inv(T_wp) ∘ T_wl)          transformer_parq.py:298-300
+//   initial_ref     sigmoid(refpoint.weight) tiled over scenes           transformer_parq.py:122,309
+//   posemb          384-d sine embedding of the reference points         transformer_parq.py:45-64
+//   project_sample  3D->2D projection + bilinear gather + view mean      transformer_parq.py:129-161
+//   layernorm       post-norm LayerNorm                                  transformer_parq.py:354-356
+//   gn_stats        GroupNorm(1,C) statistics over a whole scene         generic_mlp.py:85-86
+//   box_decode      softmax / arg-max size gather / centre update        transformer_parq.py:242-279
+//
+// All of these are HBM- or latency-bound: wide coalesced loads, one wave per row
+// (or per query-view pair), wavefront/LDS reductions, no MFMA.
+#include "common.hpp"
+
+namespace parq {
+
+namespace {
+
+// ---------------------------------------------------------------- SE(3) on 12-vectors
+struct Pose12 { float R[9]; float t[3]; };
+
+__device__ __forceinline__ Pose12 load_pose(const float* p) {
+    Pose12 o;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o.R[i] = p[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o.t[i] = p[9 + i];
+    return o;
+}
+
+// utils/wrappers.py:247-251
+__device__ __forceinline__ Pose12 pose_inverse(const Pose12& a) {
+    Pose12 o;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o.R[i * 3 + j] = a.R[j * 3 + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        o.t[i] = -(o.R[i * 3 + 0] * a.t[0] + o.R[i * 3 + 1] * a.t[1] + o.R[i * 3 + 2] * a.t[2]);
+    return o;
+}
+
+// utils/wrappers.py:253-257
+__device__ __forceinline__ Pose12 pose_compose(const Pose12& a, const Pose12& b) {
+    Pose12 o;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            o.R[i * 3 + j] = a.R[i * 3 + 0] * b.R[0 * 3 + j] + a.R[i * 3 + 1] * b.R[1 * 3 + j] +
+                             a.R[i * 3 + 2] * b.R[2 * 3 + j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        o.t[i] = a.t[i] + (a.R[i * 3 + 0] * b.t[0] + a.R[i * 3 + 1] * b.t[1] + a.R[i * 3 + 2] * b.t[2]);
+    return o;
+}
+
+__global__ void camera_local_kernel(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V,
+                                    float* T_cl) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * V) return;
+    const int b = i / V;
+    const Pose12 cp = load_pose(T_cp + (int64_t)i * 12);
+    const Pose12 wp = load_pose(T_wp + (int64_t)i * 12);
+    const Pose12 wl = load_pose(T_wl + (int64_t)b * 12);
+    const Pose12 o = pose_compose(cp, pose_compose(pose_inverse(wp), wl));
+#pragma unroll
+    for (int k = 0; k < 9; ++k) T_cl[(int64_t)i * 12 + k] = o.R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) T_cl[(int64_t)i * 12 + 9 + k] = o.t[k];
+}
+
+__global__ void initial_ref_kernel(const float* w, int B, int Q, float* ref) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * Q * 3) return;
+    const float x = w[i % (Q * 3)];
+    ref[i] = 1.f / (1.f + expf(-x));
+}
+
+// ---------------------------------------------------------------- sine embedding
+// emb[m][blk*128 + i], blk order (y, x, z); a = ref*2pi / dim_t[i]; even i -> sin, odd i -> cos.
+__global__ void posemb_kernel(const float* ref, const float* dim_t, int M, float* emb) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * 384) return;
+    const int m = idx / 384;
+    const int k = idx - m * 384;
+    const int blk = k >> 7;
+    const int i = k & 127;
+    const int axis = blk == 0 ? 1 : (blk == 1 ? 0 : 2);
+    const float p = ref[m * 3 + axis] * 6.283185307179586f;
+    const float a = p / dim_t[i];
+    emb[idx] = (i & 1) ? cosf(a) : sinf(a);
+}
+
+// ---------------------------------------------------------------- project + sample
+// One workgroup per (scene, query); wave wv handles views wv, wv+nwv, ...; each lane owns
+// float4 channel groups, so one texel row (C floats, contiguous in the channels-last stack)
+// is a single fully coalesced wave load.  Views are reduced through LDS in a fixed order.
+constexpr int kMaxChunks = 4;   // C <= 1024
+
+template <int NCH>
+__global__ __launch_bounds__(1024) void project_sample_kernel(
+    const float* __restrict__ tokens, const float* __restrict__ T_cl, const float* __restrict__ cam,
+    const float* __restrict__ ref, ScaleBox sb, int V, int h, int w, int C, int Q, float* __restrict__ tgt,
+    float* __restrict__ coord_pos) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [nwv][C] + [nwv] counts
+    const int bq = blockIdx.x;
+    const int b = bq / Q;
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int nwv = blockDim.x >> 6;
+    const int C4 = C >> 2;
+
+    // denormalize (transformer_parq.py:198-209)
+    float P[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) P[i] = ref[(int64_t)bq * 3 + i] * (sb.hi[i] - sb.lo[i]) + sb.lo[i];
+    if (coord_pos && threadIdx.x < 3) coord_pos[(int64_t)bq * 3 + threadIdx.x] = P[threadIdx.x];
+
+    f32x4 acc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int nvalid = 0;
+
+    for (int v = wv; v < V; v += nwv) {
+        const float* T = T_cl + ((int64_t)b * V + v) * 12;
+        const float* cm = cam + ((int64_t)b * V + v) * 6;
+        // Pose.transform: p @ R^T + t (utils/wrappers.py:259-267)
+        const float x = P[0] * T[0] + P[1] * T[1] + P[2] * T[2] + T[9];
+        const float y = P[0] * T[3] + P[1] * T[4] + P[2] * T[5] + T[10];
+        const float z = P[0] * T[6] + P[1] * T[7] + P[2] * T[8] + T[11];
+        // Camera.project (utils/wrappers.py:511-522)
+        const bool front = z > 1e-3f;
+        const float zc = fmaxf(z, 1e-3f);
+        const float u = (x / zc) * cm[2] + cm[4];
+        const float vv = (y / zc) * cm[3] + cm[5];
+        const bool valid = front && (u >= 0.f) && (u <= cm[0] - 1.f) && (vv >= 0.f) && (vv <= cm[1] - 1.f);
+        nvalid += valid ? 1 : 0;
+        // grid_sample(bilinear, zeros, align_corners=True) incl. the reference's round trip through
+        // the normalised grid (transformer_parq.py:148-152)
+        const float gx = 2.f * u / (float)(w - 1) - 1.f;
+        const float gy = 2.f * vv / (float)(h - 1) - 1.f;
+        const float ix = (gx + 1.f) * ((float)(w - 1) * 0.5f);
+        const float iy = (gy + 1.f) * ((float)(h - 1) * 0.5f);
+        const float fx0 = floorf(ix);
+        const float fy0 = floorf(iy);
+        // any corner in range?  (tests in float: |ix| can be ~1e6 when z was clamped)
+        if (!(fx0 >= -1.f && fx0 <= (float)(w - 1) && fy0 >= -1.f && fy0 <= (float)(h - 1))) continue;
+        const int x0 = (int)fx0;
+        const int y0 = (int)fy0;
+        const float wx1 = ix - fx0, wx0 = 1.f - wx1;
+        const float wy1 = iy - fy0, wy0 = 1.f - wy1;
+        const bool x0ok = x0 >= 0, x1ok = x0 + 1 <= w - 1;
+        const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= h - 1;
+        const float* base = tokens + (((int64_t)b * V + v) * h) * (int64_t)w * C;
+        const float* r00 = base + ((int64_t)(y0ok ? y0 : 0) * w + (x0ok ? x0 : 0)) * C;
+        const float* r01 = base + ((int64_t)(y0ok ? y0 : 0) * w + (x1ok ? x0 + 1 : 0)) * C;
+        const float* r10 = base + ((int64_t)(y1ok ? y0 + 1 : 0) * w + (x0ok ? x0 : 0)) * C;
+        const float* r11 = base + ((int64_t)(y1ok ? y0 + 1 : 0) * w + (x1ok ? x0 + 1 : 0)) * C;
+        const float w00 = (x0ok && y0ok) ? wy0 * wx0 : 0.f;   // nw
+        const float w01 = (x1ok && y0ok) ? wy0 * wx1 : 0.f;   // ne
+        const float w10 = (x0ok && y1ok) ? wy1 * wx0 : 0.f;   // sw
+        const float w11 = (x1ok && y1ok) ? wy1 * wx1 : 0.f;   // se
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int c4 = lane + c * 64;
+            if (c4 < C4) {
+                const f32x4 a00 = reinterpret_cast<const f32x4*>(r00)[c4];
+                const f32x4 a01 = reinterpret_cast<const f32x4*>(r01)[c4];
+                const f32x4 a10 = reinterpret_cast<const f32x4*>(r10)[c4];
+                const f32x4 a11 = reinterpret_cast<const f32x4*>(r11)[c4];
+                acc[c] += a00 * w00 + a01 * w01 + a10 * w10 + a11 * w11;
+            }
+        }
+    }
+
+    // cross-view reduction in view-slot order
+    float* part = smem;
+    int* cnt = reinterpret_cast<int*>(smem + (size_t)nwv * C);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int c4 = lane + c * 64;
+        if (c4 < C4) reinterpret_cast<f32x4*>(part + (size_t)wv * C)[c4] = acc[c];
+    }
+    if (lane == 0) cnt[wv] = nvalid;
+    __syncthreads();
+    int total = 0;
+    for (int i = 0; i < nwv; ++i) total += cnt[i];
+    const float denom = (float)(total > 0 ? total : 1);
+    for (int c4 = threadIdx.x; c4 < C4; c4 += blockDim.x) {
+        f32x4 s = reinterpret_cast<const f32x4*>(part)[c4];
+        for (int i = 1; i < nwv; ++i) s += reinterpret_cast<const f32x4*>(part + (size_t)i * C)[c4];
+        reinterpret_cast<f32x4*>(tgt + (int64_t)bq * C)[c4] = s / denom;
+    }
+}
+
+// ---------------------------------------------------------------- LayerNorm: one wave per row
+constexpr int kLnMaxPerLane = 16;   // C <= 1024
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ Y,
+                                                        int M, int C, float eps) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    const float* x = X + (int64_t)row * C;
+    float v[kLnMaxPerLane];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnMaxPerLane; ++i) {
+        const int c = lane + i * 64;
+        v[i] = c < C ? x[c] : 0.f;
+        s += v[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnMaxPerLane; ++i) {
+        const int c = lane + i * 64;
+        const float d = c < C ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.f / sqrtf(q / (float)C + eps);
+    float* y = Y + (int64_t)row * C;
+#pragma unroll
+    for (int i = 0; i < kLnMaxPerLane; ++i) {
+        const int c = lane + i * 64;
+        if (c < C) y[c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+    }
+}
+
+// ---------------------------------------------------------------- GroupNorm(1,C) statistics
+// grid (ngroups, B): one workgroup reduces rows_per_scene x ncols elements (double accumulators).
+__global__ __launch_bounds__(1024) void gn_stats_kernel(const float* __restrict__ X, int64_t ldx, int col0,
+                                                         int ncols, int ngroups, int rows_per_scene, float eps,
+                                                         float* __restrict__ stats) {
+    __shared__ double sh[2][16];
+    const int g = blockIdx.x;
+    const int b = blockIdx.y;
+    const float* base = X + (int64_t)b * rows_per_scene * ldx + col0 + (int64_t)g * ncols;
+    const int n4 = ncols >> 2;
+    double s = 0.0, q = 0.0;
+    const int64_t total4 = (int64_t)rows_per_scene * n4;
+    for (int64_t i = threadIdx.x; i < total4; i += blockDim.x) {
+        const int r = (int)(i / n4);
+        const int c4 = (int)(i - (int64_t)r * n4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + (int64_t)r * ldx + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s += (double)v[e];
+            q += (double)v[e] * (double)v[e];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        q += __shfl_xor(q, o);
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sh[0][wv] = s;
+        sh[1][wv] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S = 0.0, Qs = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) {
+            S += sh[0][i];
+            Qs += sh[1][i];
+        }
+        const double n = (double)rows_per_scene * (double)ncols;
+        const double mean = S / n;
+        double var = Qs / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[((int64_t)b * ngroups + g) * 2 + 0] = (float)mean;
+        stats[((int64_t)b * ngroups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// ---------------------------------------------------------------- box decode + reference-point update
+constexpr int kMaxCls = 32;
+
+__global__ void box_decode_kernel(BoxDecodeArgs a) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= a.M) return;
+    const float* h1 = a.h1 + (int64_t)m * a.ld1;
+    const float* h3 = a.h3 + (int64_t)m * a.ld3;
+    // class probabilities: softmax over num_classes (utils/parq_utils.py:101-105)
+    float lg[kMaxCls];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < kMaxCls; ++c) {
+        lg[c] = c < a.ncls ? h1[c] : -INFINITY;
+        mx = fmaxf(mx, lg[c]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxCls; ++c) {
+        if (c < a.ncls) {
+            a.logits[(int64_t)m * a.ncls + c] = lg[c];
+            lg[c] = expf(lg[c] - mx);
+            sum += lg[c];
+        }
+    }
+    int arg = 0;
+    float best = -1.f;
+#pragma unroll
+    for (int c = 0; c < kMaxCls; ++c) {
+        if (c < a.ncls) {
+            const float p = lg[c] / sum;
+            a.prob[(int64_t)m * a.ncls + c] = p;
+            if (p > best) {       // first maximum, as torch.argmax
+                best = p;
+                arg = c;
+            }
+        }
+    }
+    // size = exp(size_scale) * mean_size[argmax]  (utils/parq_utils.py:94-99)
+    if (arg >= a.n_mean) arg = a.n_mean - 1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        a.size[(int64_t)m * 3 + i] = expf(h1[a.ncls + i]) * a.mean_sizes[arg * 3 + i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) a.rot[(int64_t)m * 6 + i] = h3[3 + i];
+    // centre = denorm(sigmoid(offset + inverse_sigmoid(ref)))  (transformer_parq.py:242-245, 38-42)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float r = a.ref[(int64_t)m * 3 + i];
+        r = fminf(fmaxf(r, 0.f), 1.f);
+        const float x1 = fmaxf(r, 1e-3f);
+        const float x2 = fmaxf(1.f - r, 1e-3f);
+        const float off = h3[i] + logf(x1 / x2);
+        const float sg = 1.f / (1.f + expf(-off));
+        const float ctr = sg * (a.sb.hi[i] - a.sb.lo[i]) + a.sb.lo[i];
+        a.center[(int64_t)m * 3 + i] = ctr;
+        // next reference point = normalize(centre), detached (transformer_parq.py:331-332)
+        if (a.ref_next) a.ref_next[(int64_t)m * 3 + i] = (ctr - a.sb.lo[i]) / (a.sb.hi[i] - a.sb.lo[i]);
+    }
+}
+
+__global__ void copy_rows_kernel(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int rows, int cols) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * cols) return;
+    const int r = (int)(i / cols);
+    const int c = (int)(i - (int64_t)r * cols);
+    dst[(int64_t)r * dst_ld + c] = src[(int64_t)r * src_ld + c];
+}
+
+__global__ void fill_kernel(float* dst, float value, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = value;
+}
+
+}  // namespace
+
+hipError_t launch_camera_local(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V, float* T_cl,
+                               hipStream_t s) {
+    hipLaunchKernelGGL(camera_local_kernel, dim3(ceil_div(B * V, 64)), dim3(64), 0, s, T_cp, T_wp, T_wl, B, V, T_cl);
+    return hipGetLastError();
+}
+
+hipError_t launch_initial_ref(const float* w, int B, int Q, float* ref, hipStream_t s) {
+    hipLaunchKernelGGL(initial_ref_kernel, dim3(ceil_div(B * Q * 3, 256)), dim3(256), 0, s, w, B, Q, ref);
+    return hipGetLastError();
+}
+
+hipError_t launch_posemb(const float* ref, const float* dim_t, int M, float* emb, hipStream_t s) {
+    hipLaunchKernelGGL(posemb_kernel, dim3(ceil_div(M * 384, 256)), dim3(256), 0, s, ref, dim_t, M, emb);
+    return hipGetLastError();
+}
+
+hipError_t launch_project_sample(const float* tokens, const float* T_cl, const float* cam, const float* ref,
+                                 ScaleBox sb, int B, int V, int h, int w, int C, int Q, float* tgt,
+                                 float* coord_pos, hipStream_t s) {
+    if (C % 4 != 0 || C > 256 * kMaxChunks || V <= 0) return hipErrorInvalidValue;
+    const int nwv = V < 16 ? V : 16;
+    const size_t smem = (size_t)nwv * C * sizeof(float) + (size_t)nwv * sizeof(int);
+    const int nch = ceil_div(C / 4, 64);
+    dim3 grid(B * Q), block(nwv * 64);
+    switch (nch) {
+        case 1: hipLaunchKernelGGL(project_sample_kernel<1>, grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos); break;
+        case 2: hipLaunchKernelGGL(project_sample_kernel<2>, grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos); break;
+        case 3: hipLaunchKernelGGL(project_sample_kernel<3>, grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos); break;
+        default: hipLaunchKernelGGL(project_sample_kernel<4>, grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_layernorm(const float* X, const float* gamma, const float* beta, float* Y, int M, int C, float eps,
+                            hipStream_t s) {
+    if (C > 64 * kLnMaxPerLane) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, s, X, gamma, beta, Y, M, C, eps);
+    return hipGetLastError();
+}
+
+hipError_t launch_gn_stats(const float* X, int64_t ldx, int col0, int ncols, int ngroups, int B, int rows_per_scene,
+                           float eps, float* stats, hipStream_t s) {
+    if (ncols % 4 != 0 || col0 % 4 != 0 || ldx % 4 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(ngroups, B), dim3(1024), 0, s, X, ldx, col0, ncols, ngroups, rows_per_scene,
+                       eps, stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_box_decode(const BoxDecodeArgs& a, hipStream_t s) {
+    if (a.ncls > kMaxCls || a.ncls < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(box_decode_kernel, dim3(ceil_div(a.M, 64)), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_rows(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int rows, int cols,
+                            hipStream_t s) {
+    const int64_t n = (int64_t)rows * cols;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, s, src, src_ld, dst, dst_ld, rows,
+                       cols);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill(float* dst, float value, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, s, dst, value, n);
+    return hipGetLastError();
+}
+
+}  // namespace parq

@@ -1,0 +1,379 @@
+// fp32 flash attention for the PARQ decoder (gfx950): dense cross-attention of Q queries
+// against all N = V*h*w memory tokens (transformer_parq.py:377-380) and the small
+// query self-attention (:372-376), without materialising the (H,Q,N) score tensor.
+//
+// Mapping onto CDNA4
+//   * v_mfma_f32_32x32x2_f32 (exact fp32).  Everything is kept in the "query = lane & 31"
+//     layout:   S^T = K Q^T   (A = K[key][d] from LDS, B = Q[q][d] from registers)
+//               O^T = V^T P^T (A = V[key][d] from LDS, B = P[q][key] = the S^T registers)
+//     The C/D layout of S^T (lane (q, half) holds keys (r&3)+8(r>>2)+4*half) is exactly a
+//     legal B-operand enumeration of the key contraction index, so the probabilities feed
+//     the second MFMA straight from registers — no cross-lane traffic, and softmax
+//     statistics are per-lane scalars (one shuffle joins the two lane halves).
+//   * The contraction over d is permuted so lane half kh owns d in [kh*dh/2, (kh+1)*dh/2):
+//     one ds_read_b128 of a K row feeds 4 MFMAs.  K tiles are XOR-swizzled in LDS
+//     (16-byte chunk index ^ row) so those reads are bank-conflict free; V tiles are read
+//     row-contiguously with ds_read_b32 (conflict free as is).
+//   * One workgroup = NW waves x 32 queries, streaming its key range through a
+//     double-buffered LDS tile (register-staged prefetch: loads for tile t+1 are issued
+//     before the MFMAs of tile t, written to the other buffer after them; one barrier/tile).
+//   * grid = (key splits, query tiles, B*H): splits give >= 1-2 workgroups per CU even
+//     for B = 1; partial (O, m, l) are combined by flash_merge_kernel.
+#include "common.hpp"
+
+namespace parq {
+
+namespace {
+
+template <int DH>
+struct Tile {
+    static constexpr int KT = DH <= 64 ? 64 : 32;           // keys per LDS tile
+    static constexpr int ROW4 = DH / 4;                     // float4 per row
+    static constexpr int SWZ = (ROW4 < 16 ? ROW4 : 16) - 1; // XOR mask on the chunk index
+    static constexpr size_t lds_bytes() { return (size_t)2 * 2 * KT * DH * sizeof(float); }
+};
+
+template <int DH, int NW>
+__global__ __launch_bounds__(NW * 64) void flash_f32_kernel(FlashArgs a) {
+    using T = Tile<DH>;
+    constexpr int KT = T::KT;
+    constexpr int NT = NW * 64;
+    constexpr int ROW4 = T::ROW4;
+    constexpr int TILE4 = KT * ROW4;
+    constexpr int LD4 = TILE4 / NT;
+    static_assert(TILE4 % NT == 0, "tile must divide evenly over the workgroup");
+    constexpr int NDT = DH / 32;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                    // [2][KT*DH] swizzled
+    float* Vs = smem + 2 * KT * DH;      // [2][KT*DH]
+
+    const int split = blockIdx.x;
+    const int bh = blockIdx.z;
+    const int b = bh / a.H;
+    const int h = bh - b * a.H;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int kh = lane >> 5;
+    const int q0 = (blockIdx.y * NW + wave) * 32;
+    const int q = q0 + li;
+    const bool active = q0 < a.Lq;       // wave-uniform
+    const int Lq_pad = (a.Lq + 31) & ~31;
+
+    // Q fragment (B operand): lane (kh, j) holds Q[q0+j][kh*DH/2 + t], pre-scaled by log2(e)/sqrt(dh)
+    float qf[DH / 2];
+    {
+        const float scale = 1.4426950408889634f / sqrtf((float)DH);
+        const float* qp = a.q + (int64_t)b * a.q_batch + (int64_t)h * a.q_head +
+                          (int64_t)(q < a.Lq ? q : 0) * a.q_row + kh * (DH / 2);
+#pragma unroll
+        for (int c = 0; c < DH / 8; ++c) {
+            f32x4 t4 = *reinterpret_cast<const f32x4*>(qp + c * 4);
+            if (q >= a.Lq) t4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qf[c * 4 + e] = t4[e] * scale;
+        }
+    }
+
+    const int nt = (a.Lk + KT - 1) / KT;
+    const int t_begin = (int)((int64_t)split * nt / a.nsplit);
+    const int t_end = (int)((int64_t)(split + 1) * nt / a.nsplit);
+
+    const float* kbase = a.k + (int64_t)b * a.k_batch + (int64_t)h * a.k_head;
+    const float* vbase = a.v + (int64_t)b * a.v_batch + (int64_t)h * a.v_head;
+
+    f32x4 kreg[LD4], vreg[LD4];
+    auto gload = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < LD4; ++i) {
+            const int f = tid + i * NT;
+            const int row = f / ROW4;
+            const int ch = f - row * ROW4;
+            const int key = tile * KT + row;
+            if (key < a.Lk) {
+                kreg[i] = *reinterpret_cast<const f32x4*>(kbase + (int64_t)key * a.k_row + ch * 4);
+                vreg[i] = *reinterpret_cast<const f32x4*>(vbase + (int64_t)key * a.v_row + ch * 4);
+            } else {
+                kreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                vreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LD4; ++i) {
+            const int f = tid + i * NT;
+            const int row = f / ROW4;
+            const int ch = f - row * ROW4;
+            *reinterpret_cast<f32x4*>(Ks + buf * KT * DH + row * DH + ((ch ^ (row & T::SWZ)) * 4)) = kreg[i];
+            *reinterpret_cast<f32x4*>(Vs + buf * KT * DH + row * DH + ch * 4) = vreg[i];
+        }
+    };
+
+    f32x16 o[NDT];
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY;
+    float l_run = 0.f;
+
+    if (t_begin < t_end) {
+        gload(t_begin);
+        swrite(0);
+    }
+    __syncthreads();
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        const bool more = t + 1 < t_end;
+        if (more) gload(t + 1);
+
+        if (active) {
+            const float* Kt = Ks + buf * KT * DH;
+            const float* Vt = Vs + buf * KT * DH;
+            const bool tail = (t == nt - 1) && (a.Lk % KT != 0);
+#pragma unroll
+            for (int kb = 0; kb < KT / 32; ++kb) {
+                // ---- S^T = K Q^T  (32 keys x 32 queries, contraction over DH)
+                f32x16 sacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+                const int krow = kb * 32 + li;
+                const float* kr = Kt + krow * DH;
+                const int sw = krow & T::SWZ;
+#pragma unroll
+                for (int u = 0; u < DH / 8; ++u) {
+                    const int ch = kh * (DH / 8) + u;
+                    const f32x4 kf = *reinterpret_cast<const f32x4*>(kr + ((ch ^ sw) * 4));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[u * 4 + e], sacc, 0, 0, 0);
+                }
+                if (tail) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = t * KT + kb * 32 + mfma32_row(r, lane);
+                        if (key >= a.Lk) sacc[r] = -INFINITY;
+                    }
+                }
+                // ---- online softmax (log2 domain); lane pair (l, l^32) shares one query
+                float mx = sacc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                float rs = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sacc[r] = __builtin_amdgcn_exp2f(sacc[r] - m_new);
+                    rs += sacc[r];
+                }
+                rs += __shfl_xor(rs, 32);
+                l_run = l_run * alpha + rs;
+                m_run = m_new;
+#pragma unroll
+                for (int d = 0; d < NDT; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                // ---- O^T += V^T P^T
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int vrow = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const float* vr = Vt + vrow * DH + li;
+#pragma unroll
+                    for (int d = 0; d < NDT; ++d)
+                        o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[d * 32], sacc[r], o[d], 0, 0, 0);
+                }
+            }
+        }
+        if (more) swrite(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (active) {
+        const int64_t pbase = (int64_t)bh * a.nsplit + split;
+        float* op = a.o_part + pbase * DH * Lq_pad;
+#pragma unroll
+        for (int d = 0; d < NDT; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) op[(int64_t)(d * 32 + mfma32_row(r, lane)) * Lq_pad + q] = o[d][r];
+        if (kh == 0) {
+            a.m_part[pbase * Lq_pad + q] = m_run;
+            a.l_part[pbase * Lq_pad + q] = l_run;
+        }
+    }
+}
+
+// Combine the key-split partials:  out[b][q][h*DH+d] = sum_s w_s O_s[d][q] / sum_s w_s l_s,
+// w_s = 2^(m_s - max_s m_s).  One workgroup per (32 queries, b*h); the result tile is
+// transposed through LDS so both the partial reads (q-contiguous) and the output writes
+// (d-contiguous) are coalesced.
+template <int DH>
+__global__ __launch_bounds__(256) void flash_merge_kernel(FlashArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wsm = smem;                               // [nsplit][32]
+    float* dsm = wsm + a.nsplit * 32;                // [8][32]
+    float* tile = dsm + 8 * 32;                      // [DH][33]
+    const int bh = blockIdx.y;
+    const int b = bh / a.H;
+    const int h = bh - b * a.H;
+    const int q0 = blockIdx.x * 32;
+    const int tq = threadIdx.x & 31;
+    const int td = threadIdx.x >> 5;
+    const int Lq_pad = (a.Lq + 31) & ~31;
+    const int q = q0 + tq;
+    const int64_t pb = (int64_t)bh * a.nsplit;
+
+    float mmax = -INFINITY;
+    for (int s = 0; s < a.nsplit; ++s) mmax = fmaxf(mmax, a.m_part[(pb + s) * Lq_pad + q]);
+    float den = 0.f;
+    for (int s = td; s < a.nsplit; s += 8) {
+        const float w = __builtin_amdgcn_exp2f(a.m_part[(pb + s) * Lq_pad + q] - mmax);
+        wsm[s * 32 + tq] = w;
+        den += w * a.l_part[(pb + s) * Lq_pad + q];
+    }
+    dsm[td * 32 + tq] = den;
+    __syncthreads();
+    den = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) den += dsm[i * 32 + tq];
+    const float inv = 1.f / den;
+    for (int d = td; d < DH; d += 8) {
+        float acc = 0.f;
+        for (int s = 0; s < a.nsplit; ++s)
+            acc += wsm[s * 32 + tq] * a.o_part[((pb + s) * DH + d) * Lq_pad + q];
+        tile[d * 33 + tq] = acc * inv;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 32 * DH; idx += 256) {
+        const int qq = idx / DH;
+        const int d = idx - qq * DH;
+        if (q0 + qq < a.Lq)
+            a.out[(int64_t)b * a.out_batch + (int64_t)(q0 + qq) * a.out_row + h * DH + d] = tile[d * 33 + qq];
+    }
+}
+
+template <int DH, int NW>
+hipError_t launch_one(const FlashArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t lds = Tile<DH>::lds_bytes();
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_f32_kernel<DH, NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid(a.nsplit, ceil_div(a.Lq, 32 * NW), a.B * a.H);
+    hipLaunchKernelGGL((flash_f32_kernel<DH, NW>), grid, dim3(NW * 64), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int DH>
+hipError_t launch_dh(const FlashArgs& a, int nw, hipStream_t s) {
+    switch (nw) {
+        case 1: return launch_one<DH, 1>(a, s);
+        case 2: return launch_one<DH, 2>(a, s);
+        case 4: return launch_one<DH, 4>(a, s);
+        case 8:
+            if constexpr (DH <= 64) return launch_one<DH, 8>(a, s);
+            else return hipErrorInvalidValue;
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int DH>
+hipError_t merge_dh(const FlashArgs& a, hipStream_t s) {
+    const size_t lds = ((size_t)a.nsplit * 32 + 8 * 32 + (size_t)DH * 33) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_merge_kernel<DH>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid(ceil_div(a.Lq, 32), a.B * a.H);
+    hipLaunchKernelGGL((flash_merge_kernel<DH>), grid, dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+int flash_key_tile(int dh) { return dh <= 64 ? 64 : 32; }
+int flash_lq_pad(int Lq) { return (Lq + 31) & ~31; }
+
+static int max_nw(int dh) { return dh <= 64 ? 8 : 4; }
+
+// Waves per workgroup: the largest that still leaves >= one workgroup per CU.
+int flash_pick_nw(int B, int H, int Lq, int Lk, int dh, int num_cus) {
+    const int nt = ceil_div(Lk, flash_key_tile(dh));
+    if (dh >= 128) {          // register budget: keep the staging registers per lane small
+        int nw = flash_lq_pad(Lq) / 32;
+        return nw >= 4 ? 4 : (nw >= 2 ? 2 : 1);
+    }
+    for (int nw = max_nw(dh); nw > 1; nw >>= 1) {
+        if (nw * 32 > flash_lq_pad(Lq) && nw > 1) continue;
+        const int64_t wgs = (int64_t)B * H * ceil_div(Lq, 32 * nw) * nt;
+        if (wgs >= num_cus) return nw;
+    }
+    return 1;
+}
+
+int flash_pick_splits(int B, int H, int Lq, int Lk, int dh, int num_cus) {
+    const int nw = flash_pick_nw(B, H, Lq, Lk, dh, num_cus);
+    const int nt = ceil_div(Lk, flash_key_tile(dh));
+    const int64_t base = (int64_t)B * H * ceil_div(Lq, 32 * nw);
+    const int per_cu = dh <= 64 ? 2 : 1;          // LDS: 64 KB tiles -> 2 workgroups per CU
+    int64_t want = ceil_div64((int64_t)num_cus * per_cu, base);
+    if (want < 1) want = 1;
+    if (want > nt) want = nt;
+    if (want > 256) want = 256;
+    return (int)want;
+}
+
+size_t flash_scratch_bytes(int B, int H, int Lq, int dh, int nsplit) {
+    const size_t lp = (size_t)flash_lq_pad(Lq);
+    return ((size_t)B * H * nsplit * lp * (size_t)(dh + 2)) * sizeof(float);
+}
+
+int device_num_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cus = n;
+        else
+            cus = 256;
+    }
+    return cus;
+}
+
+static bool dh_ok(int dh) { return dh == 32 || dh == 64 || dh == 128 || dh == 256; }
+
+hipError_t launch_flash(const FlashArgs& a, hipStream_t s) {
+    if (!dh_ok(a.dh) || a.nsplit < 1 || a.nsplit > 256) return hipErrorInvalidValue;
+    if (a.nsplit > ceil_div(a.Lk, flash_key_tile(a.dh))) return hipErrorInvalidValue;
+    const int nw = flash_pick_nw(a.B, a.H, a.Lq, a.Lk, a.dh, device_num_cus());
+    switch (a.dh) {
+        case 32: return launch_dh<32>(a, nw, s);
+        case 64: return launch_dh<64>(a, nw, s);
+        case 128: return launch_dh<128>(a, nw, s);
+        default: return launch_dh<256>(a, nw, s);
+    }
+}
+
+hipError_t launch_flash_merge(const FlashArgs& a, hipStream_t s) {
+    if (!dh_ok(a.dh)) return hipErrorInvalidValue;
+    switch (a.dh) {
+        case 32: return merge_dh<32>(a, s);
+        case 64: return merge_dh<64>(a, s);
+        case 128: return merge_dh<128>(a, s);
+        default: return merge_dh<256>(a, s);
+    }
+}
+
+}  // namespace parq

@@ -1,0 +1,345 @@
+"""PARQDecoder: host-side mirror of the reference module, running on the HIP kernel chain.
+
+Same constructor argument (``cfg.MODEL.DECODER``), same ``forward`` signature and return
+value, same ``state_dict`` keys as the reference class (model/parq_decoder.py:30-163,
+SURVEY.md §5.4), so a reference checkpoint loads with ``strict=True`` and reference-style
+drivers (eval.py:26-47) can swap the import.  All arithmetic of the forward pass runs in
+libparq_hip.so (include/parq_hip.h); this file only owns parameters, buffers and the
+packing of arguments.  There is no PyTorch/CPU fallback for the compute.
+
+Scope of this round: inference forward.  ``loss`` / metrics / autograd are
+the "next" rows of §8(f) and raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .box_processor import mean_size_table
+from .wrappers import raw
+
+OUTPUT_KEYS = ("pred_logits", "center_unnormalized", "size_unnormalized", "ortho6d", "sem_cls_prob", "coord_pos")
+
+
+# ---------------------------------------------------------------------------------------
+# parameter containers that reproduce the reference's state_dict layout
+# ---------------------------------------------------------------------------------------
+
+class _WB(nn.Module):
+    """A leaf holding ``weight`` (and optionally ``bias``)."""
+
+    def __init__(self, wshape, bias=True, bshape=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(*wshape))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(*(bshape or (wshape[0],))))
+        else:
+            self.register_parameter("bias", None)
+
+
+def _conv_init(m: _WB):
+    """torch Conv1d/Linear default init (kaiming_uniform(a=sqrt(5)))."""
+    fan_in = m.weight.shape[1]
+    bound = 1.0 / math.sqrt(fan_in)
+    nn.init.uniform_(m.weight, -bound, bound)
+    if m.bias is not None:
+        nn.init.uniform_(m.bias, -bound, bound)
+
+
+def _norm_init(m: _WB):
+    nn.init.ones_(m.weight)
+    nn.init.zeros_(m.bias)
+
+
+class _Head(nn.Module):
+    """GenericMLP parameter layout (model/generic_mlp.py:64-132): ``layers.<idx>``.
+
+    hidden=[]     -> layers.0 = Conv1d(C, out)
+    hidden=[C,C]  -> layers.0 Conv(no bias), .1 GroupNorm, (.2 ReLU, .3 Dropout),
+                     .4 Conv(no bias), .5 GroupNorm, (.6, .7), .8 Conv(bias)
+    """
+
+    def __init__(self, C_in, out, hidden):
+        super().__init__()
+        layers = nn.ModuleDict()
+        if hidden:
+            layers["0"] = _WB((C_in, C_in, 1), bias=False)
+            layers["1"] = _WB((C_in,), bshape=(C_in,))
+            layers["4"] = _WB((C_in, C_in, 1), bias=False)
+            layers["5"] = _WB((C_in,), bshape=(C_in,))
+            layers["8"] = _WB((out, C_in, 1))
+            for k in ("0", "4", "8"):
+                _conv_init(layers[k])
+            for k in ("1", "5"):
+                _norm_init(layers[k])
+        else:
+            layers["0"] = _WB((out, C_in, 1))
+            _conv_init(layers["0"])
+        self.layers = layers
+
+
+class _MHA(nn.Module):
+    """nn.MultiheadAttention parameter layout."""
+
+    def __init__(self, C_):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * C_, C_))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * C_))
+        self.out_proj = _WB((C_, C_))
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class _Layer(nn.Module):
+    def __init__(self, C_, F_):
+        super().__init__()
+        self.self_attn = _MHA(C_)
+        self.multihead_attn = _MHA(C_)
+        self.linear1 = _WB((F_, C_))
+        self.linear2 = _WB((C_, F_))
+        self.norm1, self.norm2, self.norm3 = (_WB((C_,), bshape=(C_,)) for _ in range(3))
+        for m in (self.linear1, self.linear2):
+            _conv_init(m)
+        for m in (self.norm1, self.norm2, self.norm3):
+            _norm_init(m)
+
+
+class _DecoderParams(nn.Module):
+    def __init__(self, C_, F_, n_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([_Layer(C_, F_) for _ in range(n_layers)])
+        self.norm = _WB((C_,), bshape=(C_,))          # in checkpoints, never applied (transformer_parq.py:174)
+        _norm_init(self.norm)
+        pe = nn.ModuleDict()
+        pe["0"] = _WB((C_, 384))
+        pe["2"] = _WB((C_, C_))
+        _conv_init(pe["0"])
+        _conv_init(pe["2"])
+        self.position_encoder = pe
+        self.mlp_heads = None                          # shared with PARQDecoder.mlp_heads (parq_decoder.py:66)
+
+
+class _TransformerParams(nn.Module):
+    def __init__(self, C_, F_, n_layers):
+        super().__init__()
+        self.decoder = _DecoderParams(C_, F_, n_layers)
+        for p in self.parameters():                    # transformer_parq.py:90-93
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+
+# ---------------------------------------------------------------------------------------
+
+class PARQDecoder(nn.Module):
+    """Drop-in for ``model.parq_decoder.PARQDecoder`` (forward path)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        T = cfg.TRANSFORMER
+        assert T.QUERIES_DIM == T.DEC_DIM, "queries dim needs to equal DEC_DIM (transformer_parq.py:76-78)"
+        assert cfg.DIM_IN == T.DEC_DIM
+        if not cfg.SHARE_MLP_HEADS:
+            raise NotImplementedError("SHARE_MLP_HEADS=False is broken in the reference (parq_decoder.py:119-123)")
+        self.dim_in = cfg.DIM_IN
+        self.num_queries = cfg.NUM_QUERIES
+        self.num_semcls = cfg.NUM_SEMCLS
+        self.loss_weight = cfg.LOSS_WEIGHT
+        self.for_vis = cfg.FOR_VIS
+        self.track_scale = cfg.TRACK_SCALE
+        self.share_mlp_heads = cfg.SHARE_MLP_HEADS
+        self.enable_nms = getattr(cfg, "ENABLE_NMS", True)
+        self.num_heads = T.DEC_HEADS
+        self.num_layers = T.DEC_LAYERS
+        self.ffn_dim = T.DEC_FFN_DIM
+        self.share_weights = bool(T.SHARE_WEIGHTS)
+        self.dropout_rate = float(T.DROPOUT_RATE)
+        self.scale = [float(x) for x in T.SCALE]
+        self.mean_size_path = getattr(cfg, "MEAN_SIZE_PATH", None)
+
+        Cd, ncls = self.dim_in, self.num_semcls + 1
+        self.mlp_heads = nn.ModuleDict([
+            ("sem_cls_head", _Head(Cd, ncls, hidden=False)),
+            ("center_head", _Head(Cd, 3, hidden=True)),
+            ("size_head", _Head(Cd, 3, hidden=False)),
+            ("rotation_head", _Head(Cd, 6, hidden=True)),
+        ])
+        self.parq_module = _TransformerParams(Cd, self.ffn_dim, 1 if self.share_weights else self.num_layers)
+        self.parq_module.decoder.mlp_heads = self.mlp_heads
+        self.refpoint = nn.Embedding(self.num_queries, 3)
+
+        self._mean_sizes = mean_size_table(self.mean_size_path)     # (rows,3) float64
+        self._h = None            # parq_handle
+        self._arena = None
+        self._arena_key = None
+        self._ws = {}
+        self._mean_dev = None
+
+    # ------------------------------------------------------------------ native handle
+    def _handle(self):
+        if self._h is None:
+            lib = _lib.load()
+            cfg = _lib.ParqConfig(self.dim_in, self.num_queries, self.num_semcls + 1, self.num_heads, self.ffn_dim,
+                                  self.num_layers, int(self.share_weights), int(self._mean_sizes.shape[0]),
+                                  (C.c_float * 6)(*self.scale))
+            h = C.c_void_p()
+            _lib.check(lib.parq_create(C.byref(cfg), C.byref(h)), "parq_create")
+            self._h = h
+        return self._h
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                _lib.load().parq_destroy(self._h)
+        except Exception:
+            pass
+
+    def _unique_params(self):
+        seen, out = set(), []
+        for name, p in self.named_parameters(remove_duplicate=True):
+            if id(p) not in seen:
+                seen.add(id(p))
+                out.append((name, p))
+        return out
+
+    def _ensure_packed(self, device):
+        params = self._unique_params()
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for _, p in params)
+        if key == self._arena_key:
+            return
+        lib, h = _lib.load(), self._handle()
+        keep = []
+        for name, p in params:
+            if name.startswith("parq_module.decoder.norm."):
+                continue                               # never applied by the forward pass
+            t = p.detach()
+            if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
+                t = t.to(device=device, dtype=torch.float32).contiguous()
+            keep.append(t)
+            _lib.check(lib.parq_set_weight(h, name.encode(), _lib.ptr(t), t.numel()), "parq_set_weight(%s)" % name)
+        # BoxProcessor table: float64 on the host, float32 at use (utils/parq_utils.py:88,98)
+        self._mean_dev = torch.from_numpy(self._mean_sizes.astype(np.float32)).to(device).contiguous()
+        _lib.check(lib.parq_set_weight(h, b"mean_sizes", _lib.ptr(self._mean_dev), self._mean_dev.numel()), "mean_sizes")
+        nbytes = lib.parq_packed_weights_bytes(h)
+        self._arena = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+        _lib.check(lib.parq_pack_weights(h, _lib.ptr(self._arena), nbytes, _lib.stream_ptr()), "parq_pack_weights")
+        del keep
+        self._arena_key = key
+
+    def _workspace(self, B, V, h, w, device):
+        k = (B, V, h, w, str(device))
+        ws = self._ws.get(k)
+        if ws is None:
+            nbytes = _lib.load().parq_workspace_bytes(self._handle(), B, V, h, w)
+            if nbytes == 0:
+                raise RuntimeError("parq_workspace_bytes returned 0 for B=%d V=%d h=%d w=%d" % (B, V, h, w))
+            self._ws.clear()                          # one live workspace: it holds the K/V cache
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+            self._ws[k] = ws
+        return ws
+
+    # ------------------------------------------------------------------ argument packing
+    def _scene(self, tokens, camera, T_cp, T_wp, T_wl, feat_hw):
+        tokens = raw(tokens)
+        cam, T_cp, T_wp, T_wl = raw(camera), raw(T_cp), raw(T_wp), raw(T_wl)
+        if not tokens.is_cuda:
+            raise RuntimeError("parq_amd.PARQDecoder runs on the GPU only: move the module and its inputs to 'cuda' "
+                               "(there is no CPU fallback)")
+        dev = tokens.device
+
+        def prep(t, last):
+            t = t.to(device=dev, dtype=torch.float32)
+            assert t.shape[-1] == last, (tuple(t.shape), last)
+            return t.contiguous()
+        tokens = prep(tokens, self.dim_in)
+        cam, T_cp, T_wp, T_wl = prep(cam, 6), prep(T_cp, 12), prep(T_wp, 12), prep(T_wl, 12)
+        B, N, _ = tokens.shape
+        assert cam.dim() == 3 and cam.shape[0] == B, "camera must be (B,V,6)"
+        V = cam.shape[1]
+        if T_wl.dim() == 2:
+            T_wl = T_wl.unsqueeze(1)
+        assert T_cp.shape == (B, V, 12) and T_wp.shape == (B, V, 12) and T_wl.shape == (B, 1, 12)
+        if feat_hw is None:
+            # the reference reads the size from the first camera on the host too
+            # (transformer_parq.py:301-302); pass feat_hw=(h,w) to avoid this sync
+            wf, hf = cam[0, 0, :2].tolist()
+            feat_hw = (int(hf), int(wf))
+        h, w = int(feat_hw[0]), int(feat_hw[1])
+        assert V * h * w == N, "tokens (N=%d) do not match V*h*w = %d*%d*%d" % (N, V, h, w)
+        sc = _lib.ParqScene(B, V, h, w, _lib.ptr(tokens), _lib.ptr(cam), _lib.ptr(T_cp), _lib.ptr(T_wp), _lib.ptr(T_wl))
+        return sc, (tokens, cam, T_cp, T_wp, T_wl), dev
+
+    def _alloc_outputs(self, lead, device):
+        ncls = self.num_semcls + 1
+        widths = (ncls, 3, 3, 6, ncls, 3)
+        return [torch.empty(*lead, wd, dtype=torch.float32, device=device) for wd in widths]
+
+    def _check_mode(self):
+        if self.training and self.dropout_rate > 0:
+            raise NotImplementedError(
+                "parq_amd.PARQDecoder: train-mode forward (dropout %.2f, autograd) is not built yet "
+                "(SURVEY.md §8f rank 1); call .eval()" % self.dropout_rate)
+
+    # ------------------------------------------------------------------ forward (model/parq_decoder.py:134-163)
+    @torch.no_grad()
+    def forward(self, intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw=None):
+        self._check_mode()
+        sc, keep, dev = self._scene(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
+        self._ensure_packed(dev)
+        ws = self._workspace(sc.B, sc.V, sc.h, sc.w, dev)
+        outs = self._alloc_outputs((self.num_layers, sc.B, self.num_queries), dev)
+        po = _lib.ParqOutputs(*[_lib.ptr(t) for t in outs])
+        _lib.check(_lib.load().parq_forward(self._handle(), C.byref(sc), _lib.ptr(ws), ws.numel() * 4, C.byref(po),
+                                            _lib.stream_ptr()), "parq_forward")
+        del keep
+        return [{k: t[i] for k, t in zip(OUTPUT_KEYS, outs)} for i in range(self.num_layers)]
+
+    # ------------------------------------------------------------------ stepping interface (tests, custom drivers)
+    @torch.no_grad()
+    def prepare(self, intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw=None):
+        self._check_mode()
+        sc, keep, dev = self._scene(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
+        self._ensure_packed(dev)
+        ws = self._workspace(sc.B, sc.V, sc.h, sc.w, dev)
+        _lib.check(_lib.load().parq_prepare(self._handle(), C.byref(sc), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()),
+                   "parq_prepare")
+        self._step = (sc, keep, ws, dev)
+
+    @torch.no_grad()
+    def iterate(self, layer_num, ref_in=None):
+        """One recurrent iteration; ``ref_in`` (B,Q,3) normalised reference points or None to
+        continue.  Returns (out_dict, next_ref)."""
+        sc, keep, ws, dev = self._step
+        outs = self._alloc_outputs((sc.B, self.num_queries), dev)
+        po = _lib.ParqOutputs(*[_lib.ptr(t) for t in outs])
+        nxt = torch.empty(sc.B, self.num_queries, 3, dtype=torch.float32, device=dev)
+        if ref_in is not None:
+            ref_in = ref_in.to(device=dev, dtype=torch.float32).contiguous()
+            assert ref_in.shape == (sc.B, self.num_queries, 3)
+        _lib.check(_lib.load().parq_iterate(self._handle(), C.byref(sc), _lib.ptr(ws), ws.numel() * 4, int(layer_num),
+                                            _lib.ptr(ref_in), C.byref(po), _lib.ptr(nxt), _lib.stream_ptr()),
+                   "parq_iterate")
+        return dict(zip(OUTPUT_KEYS, outs)), nxt
+
+    # ------------------------------------------------------------------ profiling hooks used by bench.py
+    def profile_enable(self, on=True):
+        _lib.check(_lib.load().parq_profile_enable(self._handle(), int(on)), "parq_profile_enable")
+
+    def profile_read(self):
+        lib, h = _lib.load(), self._handle()
+        res = {}
+        for i, name in enumerate(_lib.PROF_NAMES):
+            ms, n = C.c_double(), C.c_int64()
+            _lib.check(lib.parq_profile_read(h, i, C.byref(ms), C.byref(n)), "parq_profile_read")
+            res[name] = (ms.value, n.value)
+        return res
+
+    # ------------------------------------------------------------------ next-tier rows
+    def loss(self, *a, **k):
+        raise NotImplementedError("PARQDecoder.loss (Hungarian matcher + box losses) is a next-tier row (SURVEY.md §8f-2)")
+
+    def update_metrics(self, *a, **k):
+        raise NotImplementedError("eval post-processing is out of scope this round (SURVEY.md §8f-4)")

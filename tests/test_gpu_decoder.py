@@ -1,0 +1,138 @@
+"""GPU tier, whole path: PARQDecoder.forward on the HIP chain (through the C ABI) against
+  * the committed golden vectors captured from the real reference (teacher-forced per
+    iteration; free-running on the damped fixture) — tolerance 1e-4 on |a-b|/max(1,|b|),
+  * the CPU oracle on fresh seeded inputs,
+  * size-independent properties at the BASELINE cfg-3 size (scene independence,
+    determinism, probability simplex, recurrence consistency)."""
+import numpy as np
+import pytest
+import torch
+
+from parq_amd import synth
+from oracle import parq_oracle as O
+import golden_util as G
+from gpu_util import dev, make_decoder, scene_args, to_np, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _run_forced(name):
+    case, z = G.load(name)
+    cfg, W, sc = G.inputs(case)
+    dec = make_decoder(cfg, W)
+    dec.prepare(*scene_args(sc))
+    refs = G.forced_refs(z, cfg.TRANSFORMER.SCALE)
+    worst = {}
+    for k in range(G.num_iters(z)):
+        out, _ = dec.iterate(k, dev(refs[k]))
+        w = G.compare(to_np(out), z, k, TOL, what=name)
+        worst = {kk: max(v, worst.get(kk, 0.0)) for kk, v in w.items()}
+    return worst
+
+
+@pytest.mark.parametrize("name", ["g1_cfg1", "g2_forced", "g4_edges", "g8_unshared", "g6_shipped"])
+def test_golden_teacher_forced(name):
+    print(name, _run_forced(name))
+
+
+def test_golden_cfg1_forward_api():
+    """BASELINE cfg 1 through the public forward(): one iteration from sigmoid(refpoint)."""
+    case, z = G.load("g1_cfg1")
+    cfg, W, sc = G.inputs(case)
+    outs = make_decoder(cfg, W)(*scene_args(sc))
+    assert len(outs) == 1
+    G.compare(to_np(outs[0]), z, 0, TOL, what="g1 forward")
+
+
+def test_golden_free_running_damped():
+    case, z = G.load("g3_damped")
+    cfg, W, sc = G.inputs(case)
+    outs = make_decoder(cfg, W)(*scene_args(sc))
+    assert len(outs) == 8
+    for k, o in enumerate(outs):
+        G.compare(to_np(o), z, k, TOL, what="g3 free-running")
+
+
+def test_forward_equals_stepping_and_wrappers_accepted():
+    from parq_amd import Pose, Camera
+    case, z = G.load("g2_forced")
+    cfg, W, sc = G.inputs(case)
+    dec = make_decoder(cfg, W)
+    a = scene_args(sc)
+    outs = dec(a[0], Camera(a[1]), Pose(a[2]), Pose(a[3]), Pose(a[4]))
+    dec.prepare(*a)
+    for k in range(cfg.TRANSFORMER.DEC_LAYERS):
+        o, _ = dec.iterate(k, None)
+        for key in o:
+            assert torch.equal(o[key], outs[k][key]), (k, key)     # bit-identical: same kernels, same order
+
+
+def test_oracle_fresh_inputs_cfg2_shape():
+    """cfg-2 geometry (5 views 120x160 features, Q=128, 4 iterations) in fp32, teacher-forced
+    against the oracle (the fp32 CPU oracle takes a few seconds here)."""
+    cfg = synth.decoder_cfg(dim=256, queries=128, heads=4, ffn=768, layers=4)
+    W = synth.make_decoder_weights(cfg, 31)
+    sc = synth.make_scene(32, 1, 5, 120, 160, 256)
+    dec = make_decoder(cfg, W)
+    outs = [to_np(o) for o in dec(*scene_args(sc))]
+    od = O.OracleDecoder(cfg, W, synth.SCANNET_MEAN_SIZES)
+    forced = [O.normalize(torch.from_numpy(o["coord_pos"]), cfg.TRANSFORMER.SCALE) for o in outs]
+    with torch.no_grad():
+        want = od.forward(sc["tokens"], sc["camera"], sc["T_camera_pseudoCam"], sc["T_world_pseudoCam"],
+                          sc["T_world_local"], forced_refs=forced)
+    for k, (a, b) in enumerate(zip(outs, want)):
+        top2 = b["sem_cls_prob"].topk(2, -1).values
+        ok = ((top2[..., 0] - top2[..., 1]) > 1e-3).numpy()
+        for key in a:
+            x, y = a[key], b[key].numpy()
+            if key == "size_unnormalized":
+                x, y = x[ok], y[ok]
+            assert rel_err(x, y) < TOL, (k, key, rel_err(x, y))
+
+
+@pytest.fixture(scope="module")
+def cfg3():
+    """BASELINE cfg 3: 10 views 120x160 features, Q=256, 8 iterations, d=256 (tokens made on device)."""
+    cfg = synth.decoder_cfg(dim=256, queries=256, heads=4, ffn=768, layers=8)
+    W = synth.make_decoder_weights(cfg, 41, damped=True)
+    dec = make_decoder(cfg, W)
+    cam, T_cp, T_wp, T_wl = synth.make_geometry(42, 2, 10, 120, 160)
+    g = torch.Generator(device="cuda").manual_seed(43)
+    tokens = torch.randn(2, 10 * 120 * 160, 256, device="cuda", generator=g)
+    return cfg, dec, tokens, (dev(cam), dev(T_cp), dev(T_wp), dev(T_wl))
+
+
+def test_full_size_scene_independence_and_determinism(cfg3):
+    cfg, dec, tokens, geo = cfg3
+    both = dec(tokens, *geo, feat_hw=(120, 160))
+    both = [{k: v.clone() for k, v in o.items()} for o in both]
+    again = dec(tokens, *geo, feat_hw=(120, 160))
+    for a, b in zip(both, again):
+        for k in a:
+            assert torch.equal(a[k], b[k])          # run-to-run bit-identical
+    for s in (0, 1):                                 # scenes are independent: B=2 == two B=1 runs
+        one = dec(tokens[s:s + 1].contiguous(), *(g[s:s + 1].contiguous() for g in geo), feat_hw=(120, 160))
+        for k_it, (a, b) in enumerate(zip(both, one)):
+            for k in a:
+                assert rel_err(b[k][0].cpu().numpy(), a[k][s].cpu().numpy()) < 2e-5, (s, k_it, k)
+
+
+def test_full_size_output_properties(cfg3):
+    cfg, dec, tokens, geo = cfg3
+    outs = dec(tokens, *geo, feat_hw=(120, 160))
+    scale = cfg.TRANSFORMER.SCALE
+    lo = torch.tensor(scale[0::2], device="cuda"); hi = torch.tensor(scale[1::2], device="cuda")
+    for k, o in enumerate(outs):
+        for key, v in o.items():
+            assert torch.isfinite(v).all(), (k, key)
+        p = o["sem_cls_prob"]
+        assert (p >= 0).all() and torch.allclose(p.sum(-1), torch.ones_like(p[..., 0]), atol=1e-5)
+        assert torch.allclose(p, torch.softmax(o["pred_logits"], -1), atol=1e-6)
+        c = o["center_unnormalized"]
+        assert ((c >= lo - 1e-5) & (c <= hi + 1e-5)).all()         # sigmoid keeps centres inside SCALE
+        assert (o["size_unnormalized"] > 0).all()
+        if k + 1 < len(outs):                                       # recurrence: next coord_pos == this centre
+            assert torch.allclose(outs[k + 1]["coord_pos"], c, atol=2e-6)
+    ref0 = torch.sigmoid(dec.refpoint.weight) * (hi - lo) + lo
+    assert torch.allclose(outs[0]["coord_pos"][0], ref0, atol=2e-6)

@@ -1,0 +1,116 @@
+"""GPU tier, per kernel: each HIP kernel is called through the C ABI and compared with the
+CPU oracle's statement of the same operation on seeded inputs.  Tolerance 1e-4 on
+|a-b|/max(1,|b|) (fp32; north-star bar), tighter where the op is a plain fp32 chain."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from parq_amd import _lib, synth
+from oracle import parq_oracle as O
+from gpu_util import dev, lib, sptr, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,N,K,relu,use_x2,use_r", [
+    (256, 256, 256, 0, False, False), (256, 768, 256, 1, False, False), (256, 256, 768, 0, False, True),
+    (64, 256, 384, 1, True, False), (37, 19, 64, 0, True, True), (2048, 10, 256, 0, False, False),
+    (1, 3, 32, 0, False, False), (300, 525, 1024, 0, False, False)])
+def test_linear(M, N, K, relu, use_x2, use_r):
+    X = synth.normal(1, "X", (M, K)); X2 = synth.normal(2, "X2", (M, K))
+    W = synth.normal(3, "W", (N, K), std=K ** -0.5); b = synth.normal(4, "b", (N,)); R = synth.normal(5, "R", (M, N))
+    Y = torch.empty(M, N, device="cuda")
+    rc = lib().parq_k_linear(_lib.ptr(dev(X)), _lib.ptr(dev(X2)) if use_x2 else None, _lib.ptr(dev(W)), _lib.ptr(dev(b)),
+                             _lib.ptr(dev(R)) if use_r else None, _lib.ptr(Y), M, N, K, relu, sptr())
+    _lib.check(rc, "parq_k_linear")
+    A = torch.from_numpy(X).double() + (torch.from_numpy(X2).double() if use_x2 else 0)
+    want = A @ torch.from_numpy(W).double().T + torch.from_numpy(b).double()
+    if relu:
+        want = want.clamp(min=0)
+    if use_r:
+        want = want + torch.from_numpy(R).double()
+    assert rel_err(Y.cpu().numpy(), want.numpy()) < 2e-5
+
+
+def test_linear_rejects_bad_k():
+    X = torch.zeros(4, 48, device="cuda")
+    assert lib().parq_k_linear(_lib.ptr(X), None, _lib.ptr(X), None, None, _lib.ptr(X), 4, 4, 48, 0, sptr()) == 1
+    assert b"multiple of 32" in lib().parq_last_error()
+
+
+@pytest.mark.parametrize("M,Cn", [(256, 256), (7, 128), (33, 1024), (5, 64)])
+def test_layernorm(M, Cn):
+    X = synth.normal(1, "lnx", (M, Cn), std=2.0, mean=0.5)
+    g = synth.uniform(2, "lng", (Cn,), 0.5, 1.5); b = synth.normal(3, "lnb", (Cn,))
+    Y = torch.empty(M, Cn, device="cuda")
+    _lib.check(lib().parq_k_layernorm(_lib.ptr(dev(X)), _lib.ptr(dev(g)), _lib.ptr(dev(b)), _lib.ptr(Y), M, Cn, 1e-5, sptr()), "ln")
+    want = F.layer_norm(torch.from_numpy(X).double(), (Cn,), torch.from_numpy(g).double(), torch.from_numpy(b).double(), 1e-5)
+    assert rel_err(Y.cpu().numpy(), want.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,dh", [
+    (1, 4, 64, 9600, 64),       # cfg-1 cross-attention
+    (2, 4, 256, 256, 64),       # self-attention shape
+    (1, 2, 40, 429, 64),        # ragged Lq and Lk (tail masking)
+    (1, 1, 32, 64, 64), (1, 1, 1, 1, 64), (2, 2, 100, 1000, 32), (1, 2, 48, 300, 128), (1, 4, 32, 600, 256)])
+def test_attention(B, H, Lq, Lk, dh):
+    Cn = H * dh
+    q = synth.normal(1, "q", (B, Lq, Cn)); k = synth.normal(2, "k", (B, Lk, Cn)); v = synth.normal(3, "v", (B, Lk, Cn))
+    nbytes = lib().parq_k_attention_scratch_bytes(B, H, Lq, Lk, dh)
+    scratch = torch.empty(nbytes // 4 + 1, device="cuda")
+    out = torch.empty(B, Lq, Cn, device="cuda")
+    _lib.check(lib().parq_k_attention(_lib.ptr(dev(q)), _lib.ptr(dev(k)), _lib.ptr(dev(v)), _lib.ptr(out), B, H, Lq, Lk, dh,
+                                     _lib.ptr(scratch), nbytes, sptr()), "attention")
+    tq, tk, tv = (torch.from_numpy(x).double().view(B, -1, H, dh).transpose(1, 2) for x in (q, k, v))
+    want = (torch.softmax(tq @ tk.transpose(-1, -2) / dh ** 0.5, -1) @ tv).transpose(1, 2).reshape(B, Lq, Cn)
+    assert rel_err(out.cpu().numpy(), want.numpy()) < 2e-5
+
+
+def test_attention_spike_forces_rescale():
+    """A key that dominates late in the stream forces the online-softmax rescale branch."""
+    B, H, Lq, Lk, dh = 1, 1, 32, 4096, 64
+    q = synth.normal(1, "q", (B, Lq, dh)); k = synth.normal(2, "k", (B, Lk, dh)); v = synth.normal(3, "v", (B, Lk, dh))
+    k[0, 3000] = 8.0 * q[0, 5]          # score ~ 8*|q|^2/8 >> everything before it
+    k[0, 10] = 4.0 * q[0, 7]
+    nbytes = lib().parq_k_attention_scratch_bytes(B, H, Lq, Lk, dh)
+    scratch = torch.empty(nbytes // 4 + 1, device="cuda"); out = torch.empty(B, Lq, dh, device="cuda")
+    _lib.check(lib().parq_k_attention(_lib.ptr(dev(q)), _lib.ptr(dev(k)), _lib.ptr(dev(v)), _lib.ptr(out), B, H, Lq, Lk, dh,
+                                     _lib.ptr(scratch), nbytes, sptr()), "attention")
+    tq, tk, tv = (torch.from_numpy(x).double() for x in (q, k, v))
+    want = torch.softmax(tq @ tk.transpose(-1, -2) / dh ** 0.5, -1) @ tv
+    assert rel_err(out.cpu().numpy(), want.numpy()) < 2e-5
+
+
+def test_camera_local():
+    cam, T_cp, T_wp, T_wl = synth.make_geometry(4, 3, 5, 12, 16)
+    out = torch.empty(3, 5, 12, device="cuda")
+    _lib.check(lib().parq_k_camera_local(_lib.ptr(dev(T_cp)), _lib.ptr(dev(T_wp)), _lib.ptr(dev(T_wl)), 3, 5, _lib.ptr(out), sptr()), "cl")
+    want = O.camera_local_poses(torch.from_numpy(T_cp).double(), torch.from_numpy(T_wp).double(), torch.from_numpy(T_wl).double())
+    assert rel_err(out.cpu().numpy(), want.numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("B,V,h,w,Cn,Q", [(1, 2, 60, 80, 256, 64), (2, 3, 11, 13, 128, 40), (1, 20, 12, 16, 64, 33),
+                                          (1, 2, 15, 20, 1024, 32), (2, 10, 30, 40, 256, 256)])
+def test_project_sample(B, V, h, w, Cn, Q):
+    sc = synth.make_scene(21, B, V, h, w, Cn)
+    scale = synth.DEFAULT_SCALE
+    ref = synth.uniform(22, "ref", (B, Q, 3), 0.0, 1.0)
+    T_cl = O.camera_local_poses(*(torch.from_numpy(sc[k]) for k in ("T_camera_pseudoCam", "T_world_pseudoCam", "T_world_local")))
+    tgt = torch.empty(B, Q, Cn, device="cuda"); cp = torch.empty(B, Q, 3, device="cuda")
+    _lib.check(lib().parq_k_project_sample(_lib.ptr(dev(sc["tokens"])), _lib.ptr(T_cl.cuda().contiguous()), _lib.ptr(dev(sc["camera"])),
+                                          _lib.ptr(dev(ref)), (C.c_float * 6)(*scale), B, V, h, w, Cn, Q, _lib.ptr(tgt), _lib.ptr(cp),
+                                          sptr()), "project_sample")
+    P = O.denormalize(torch.from_numpy(ref), scale)
+    for ro in (False, True):
+        want, p2d, valid = O.project_and_sample(torch.from_numpy(sc["tokens"]), P, T_cl, torch.from_numpy(sc["camera"]), h, w, ro)
+        # queries whose valid-view count could flip under rounding are excluded
+        size = torch.from_numpy(sc["camera"])[..., :2].unsqueeze(-2)
+        margin = torch.minimum(p2d.abs(), (p2d - (size - 1)).abs()).min(-1).values.min(1).values
+        ok = (margin > 1e-3).numpy()
+        assert ok.mean() > 0.9
+        assert rel_err(tgt.cpu().numpy()[ok], want.numpy()[ok]) < 2e-5
+    assert rel_err(cp.cpu().numpy(), P.numpy()) < 1e-6
+    assert valid.any() and (~valid).any()      # the fixture exercises both branches
