@@ -116,6 +116,13 @@ int parq_iterate(parq_handle h, const parq_scene *scene, void *workspace, size_t
                  int32_t layer_num, const float *ref_in, const parq_outputs *outs, float *ref_out,
                  parq_stream stream);
 
+/* Introspection for parity tests: where a named intermediate of the last parq_iterate lives
+ * inside the workspace (offset and element count in floats).  Names: "T_camera_local_f64" (float64 payload),
+ * "kv_cache", "ref", "posemb", "pos_feat", "tgt", "self_qkv", "attn", "x1", "cross_q", "x2",
+ * "ffn_hidden", "x3", "heads1", "heads2", "heads3", "gn_stats1", "gn_stats2". */
+int parq_workspace_lookup(parq_handle h, int32_t B, int32_t V, int32_t hh, int32_t ww, const char *name,
+                          size_t *offset_floats, size_t *numel);
+
 /* Optional instrumentation: when enabled, parq_forward brackets each kernel group with
  * hipEvents on `stream`; parq_profile_read synchronises those events and returns the
  * accumulated milliseconds and launch count of group `which` (see PARQ_PROF_*). */

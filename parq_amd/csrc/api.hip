@@ -118,7 +118,7 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     const int64_t N = (int64_t)V * h * w;
     int64_t off = 0;
     auto take = [&](int64_t n) { int64_t o = off; off += align_up(n); return o; };
-    ws->T_cl = take((int64_t)B * V * 12);
+    ws->T_cl = take((int64_t)B * V * 12 * 2);      // float64 poses
     ws->kv = take((int64_t)c->nl * B * 2 * N * C);
     ws->ref = take(M * 3); ws->ref_next = take(M * 3);
     ws->emb = take(M * 384); ws->pe_h = take(M * C); ws->pos = take(M * C);
@@ -180,7 +180,8 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     const int C = c->C;
     {
         Prof p(c, s, PARQ_PROF_OTHER);
-        HIPCHK(launch_camera_local(sc->T_camera_pseudoCam, sc->T_world_pseudoCam, sc->T_world_local, B, V, wsp + ws.T_cl, s));
+        HIPCHK(launch_camera_local_f64(sc->T_camera_pseudoCam, sc->T_world_pseudoCam, sc->T_world_local, B, V,
+                                       reinterpret_cast<double*>(wsp + ws.T_cl), s));
         HIPCHK(launch_initial_ref(A + c->ar.refpoint, B, c->Q, wsp + ws.ref, s));
     }
     // hoisted K/V in-projection of the memory tokens: one GEMM per distinct layer,
@@ -222,7 +223,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     // K4+K5: project + sample (transformer_parq.py:321)
     {
         Prof p(c, s, PARQ_PROF_PROJECT_SAMPLE);
-        HIPCHK(launch_project_sample(sc->tokens, wsp + ws.T_cl, sc->camera, ref, c->sb, B, sc->V, sc->h, sc->w, C, Q,
+        HIPCHK(launch_project_sample_f64(sc->tokens, reinterpret_cast<const double*>(wsp + ws.T_cl), sc->camera, ref, c->sb, B, sc->V, sc->h, sc->w, C, Q,
                                      wsp + ws.tgt, o->coord_pos, s));
     }
     // K6: self-attention, q = k = tgt + pos, v = tgt (transformer_parq.py:372-376)
@@ -539,6 +540,25 @@ int parq_forward(parq_handle h, const parq_scene* scene, void* workspace, size_t
     h->ref_state = 0;       // ws.ref / ws.ref_next roles depend on parity; stepping must re-prepare
     h->prepared = false;
     return PARQ_OK;
+}
+
+int parq_workspace_lookup(parq_handle h, int32_t B, int32_t V, int32_t hh, int32_t ww, const char* name,
+                          size_t* offset_floats, size_t* numel) {
+    if (!h || !name || !offset_floats || !numel) return fail(PARQ_ERR_ARG, "NULL argument");
+    Workspace ws;
+    carve_workspace(h, B, V, hh, ww, &ws);
+    const int64_t C = h->C, Q = h->Q, F = h->F, M = (int64_t)B * Q, N = (int64_t)V * hh * ww;
+    struct E { const char* n; int64_t off, cnt; };
+    const E table[] = {
+        {"T_camera_local_f64", ws.T_cl, (int64_t)B * V * 24}, {"kv_cache", ws.kv, (int64_t)h->nl * B * 2 * N * C},
+        {"ref", ws.ref, M * 3}, {"ref_next", ws.ref_next, M * 3}, {"posemb", ws.emb, M * 384}, {"pos_feat", ws.pos, M * C},
+        {"tgt", ws.tgt, M * C}, {"self_qkv", ws.qkv, M * 3 * C}, {"attn", ws.attn, M * C}, {"x1", ws.x1, M * C},
+        {"cross_q", ws.qc, M * C}, {"x2", ws.x2, M * C}, {"ffn_hidden", ws.ffn, M * F}, {"x3", ws.x3, M * C},
+        {"heads1", ws.h1, M * h->NH1}, {"heads2", ws.h2, M * 2 * C}, {"heads3", ws.h3, M * 12},
+        {"gn_stats1", ws.st1, (int64_t)B * 4}, {"gn_stats2", ws.st2, (int64_t)B * 4}};
+    for (const E& e : table)
+        if (strcmp(e.n, name) == 0) { *offset_floats = (size_t)e.off; *numel = (size_t)e.cnt; return PARQ_OK; }
+    return fail(PARQ_ERR_ARG, "unknown workspace buffer '%s'", name);
 }
 
 int parq_profile_enable(parq_handle h, int32_t on) {

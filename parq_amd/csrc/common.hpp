@@ -69,12 +69,17 @@ hipError_t launch_flash_merge(const FlashArgs& a, hipStream_t s); // partials ->
 // ------------------------------------------------------------------ elementwise / gather kernels
 hipError_t launch_camera_local(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V,
                                float* T_cl, hipStream_t s);
+hipError_t launch_camera_local_f64(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V,
+                                   double* T_cl, hipStream_t s);
 hipError_t launch_initial_ref(const float* refpoint_w, int B, int Q, float* ref, hipStream_t s);
 hipError_t launch_posemb(const float* ref, const float* dim_t, int M, float* emb, hipStream_t s);
 struct ScaleBox { float lo[3]; float hi[3]; };
 hipError_t launch_project_sample(const float* tokens, const float* T_cl, const float* cam, const float* ref,
                                  ScaleBox sb, int B, int V, int h, int w, int C, int Q, float* tgt,
                                  float* coord_pos, hipStream_t s);
+hipError_t launch_project_sample_f64(const float* tokens, const double* T_cl, const float* cam, const float* ref,
+                                     ScaleBox sb, int B, int V, int h, int w, int C, int Q, float* tgt,
+                                     float* coord_pos, hipStream_t s);
 hipError_t launch_layernorm(const float* X, const float* gamma, const float* beta, float* Y, int M, int C,
                             float eps, hipStream_t s);
 // mean / rstd over (rows_per_scene x ncols) blocks: stats[(b * ngroups + g) * 2 + {0,1}]
@@ -82,7 +87,7 @@ hipError_t launch_gn_stats(const float* X, int64_t ldx, int col0, int ncols, int
                            int rows_per_scene, float eps, float* stats, hipStream_t s);
 struct BoxDecodeArgs {
     const float* h1; int64_t ld1;      // [M][..]: logits at cols [0,ncls), size_raw at [ncls, ncls+3)
-    const float* h3; int64_t ld3;      // [M][9]: centre_raw (3) | ortho6d (6)
+    const float* h3; int64_t ld3;      // [M][12]: centre_raw at cols 0..2, ortho6d at cols 6..11
     const float* ref;                  // [M][3] normalised reference points of this iteration
     const float* mean_sizes; int n_mean;
     ScaleBox sb; int M; int ncls;

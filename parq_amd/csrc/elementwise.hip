@@ -17,14 +17,19 @@ namespace parq {
 namespace {
 
 // ---------------------------------------------------------------- SE(3) on 12-vectors
-struct Pose12 { float R[9]; float t[3]; };
+// Geometry is evaluated in float64 from the float32 inputs.  The reference does these 3x3
+// products through torch matmul in float32, whose rounding order is a BLAS detail; pixel
+// coordinates amplify a 1-ulp pose difference to ~1e-5 px, which white-noise features turn
+// into ~5e-5 output noise.  Computing the geometry (near-)exactly keeps OUR contribution
+// to that noise at zero; it costs a few dozen fp64 flops per (query, view).
+struct Pose12 { double R[9]; double t[3]; };
 
 __device__ __forceinline__ Pose12 load_pose(const float* p) {
     Pose12 o;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) o.R[i] = p[i];
+    for (int i = 0; i < 9; ++i) o.R[i] = (double)p[i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) o.t[i] = p[9 + i];
+    for (int i = 0; i < 3; ++i) o.t[i] = (double)p[9 + i];
     return o;
 }
 
@@ -56,8 +61,9 @@ __device__ __forceinline__ Pose12 pose_compose(const Pose12& a, const Pose12& b)
     return o;
 }
 
+template <typename TOut>
 __global__ void camera_local_kernel(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V,
-                                    float* T_cl) {
+                                    TOut* T_cl) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * V) return;
     const int b = i / V;
@@ -66,9 +72,9 @@ __global__ void camera_local_kernel(const float* T_cp, const float* T_wp, const 
     const Pose12 wl = load_pose(T_wl + (int64_t)b * 12);
     const Pose12 o = pose_compose(cp, pose_compose(pose_inverse(wp), wl));
 #pragma unroll
-    for (int k = 0; k < 9; ++k) T_cl[(int64_t)i * 12 + k] = o.R[k];
+    for (int k = 0; k < 9; ++k) T_cl[(int64_t)i * 12 + k] = (TOut)o.R[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) T_cl[(int64_t)i * 12 + 9 + k] = o.t[k];
+    for (int k = 0; k < 3; ++k) T_cl[(int64_t)i * 12 + 9 + k] = (TOut)o.t[k];
 }
 
 __global__ void initial_ref_kernel(const float* w, int B, int Q, float* ref) {
@@ -99,9 +105,9 @@ __global__ void posemb_kernel(const float* ref, const float* dim_t, int M, float
 // is a single fully coalesced wave load.  Views are reduced through LDS in a fixed order.
 constexpr int kMaxChunks = 4;   // C <= 1024
 
-template <int NCH>
+template <int NCH, typename TPose>
 __global__ __launch_bounds__(1024) void project_sample_kernel(
-    const float* __restrict__ tokens, const float* __restrict__ T_cl, const float* __restrict__ cam,
+    const float* __restrict__ tokens, const TPose* __restrict__ T_cl, const float* __restrict__ cam,
     const float* __restrict__ ref, ScaleBox sb, int V, int h, int w, int C, int Q, float* __restrict__ tgt,
     float* __restrict__ coord_pos) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [nwv][C] + [nwv] counts
@@ -112,11 +118,16 @@ __global__ __launch_bounds__(1024) void project_sample_kernel(
     const int nwv = blockDim.x >> 6;
     const int C4 = C >> 2;
 
-    // denormalize (transformer_parq.py:198-209)
-    float P[3];
+    // denormalize (transformer_parq.py:198-209).  coord_pos mirrors the reference's float32
+    // mul-then-add (no FMA contraction); the projection uses the float64 value.
+    double P[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) P[i] = ref[(int64_t)bq * 3 + i] * (sb.hi[i] - sb.lo[i]) + sb.lo[i];
-    if (coord_pos && threadIdx.x < 3) coord_pos[(int64_t)bq * 3 + threadIdx.x] = P[threadIdx.x];
+    for (int i = 0; i < 3; ++i) {
+        const float r = ref[(int64_t)bq * 3 + i];
+        P[i] = (double)r * ((double)sb.hi[i] - (double)sb.lo[i]) + (double)sb.lo[i];
+        if (coord_pos && threadIdx.x == i)
+            coord_pos[(int64_t)bq * 3 + i] = __fadd_rn(__fmul_rn(r, __fsub_rn(sb.hi[i], sb.lo[i])), sb.lo[i]);
+    }
 
     f32x4 acc[NCH];
 #pragma unroll
@@ -124,33 +135,30 @@ __global__ __launch_bounds__(1024) void project_sample_kernel(
     int nvalid = 0;
 
     for (int v = wv; v < V; v += nwv) {
-        const float* T = T_cl + ((int64_t)b * V + v) * 12;
+        const TPose* T = T_cl + ((int64_t)b * V + v) * 12;
         const float* cm = cam + ((int64_t)b * V + v) * 6;
         // Pose.transform: p @ R^T + t (utils/wrappers.py:259-267)
-        const float x = P[0] * T[0] + P[1] * T[1] + P[2] * T[2] + T[9];
-        const float y = P[0] * T[3] + P[1] * T[4] + P[2] * T[5] + T[10];
-        const float z = P[0] * T[6] + P[1] * T[7] + P[2] * T[8] + T[11];
-        // Camera.project (utils/wrappers.py:511-522)
-        const bool front = z > 1e-3f;
-        const float zc = fmaxf(z, 1e-3f);
-        const float u = (x / zc) * cm[2] + cm[4];
-        const float vv = (y / zc) * cm[3] + cm[5];
-        const bool valid = front && (u >= 0.f) && (u <= cm[0] - 1.f) && (vv >= 0.f) && (vv <= cm[1] - 1.f);
+        const double x = P[0] * (double)T[0] + P[1] * (double)T[1] + P[2] * (double)T[2] + (double)T[9];
+        const double y = P[0] * (double)T[3] + P[1] * (double)T[4] + P[2] * (double)T[5] + (double)T[10];
+        const double z = P[0] * (double)T[6] + P[1] * (double)T[7] + P[2] * (double)T[8] + (double)T[11];
+        // Camera.project (utils/wrappers.py:511-522); eps is the float32 value of 1e-3
+        const double eps = (double)1e-3f;
+        const bool front = z > eps;
+        const double zc = z > eps ? z : eps;
+        const double u = (x / zc) * (double)cm[2] + (double)cm[4];
+        const double vv = (y / zc) * (double)cm[3] + (double)cm[5];
+        const bool valid = front && (u >= 0.0) && (u <= (double)cm[0] - 1.0) && (vv >= 0.0) && (vv <= (double)cm[1] - 1.0);
         nvalid += valid ? 1 : 0;
-        // grid_sample(bilinear, zeros, align_corners=True) incl. the reference's round trip through
-        // the normalised grid (transformer_parq.py:148-152)
-        const float gx = 2.f * u / (float)(w - 1) - 1.f;
-        const float gy = 2.f * vv / (float)(h - 1) - 1.f;
-        const float ix = (gx + 1.f) * ((float)(w - 1) * 0.5f);
-        const float iy = (gy + 1.f) * ((float)(h - 1) * 0.5f);
-        const float fx0 = floorf(ix);
-        const float fy0 = floorf(iy);
-        // any corner in range?  (tests in float: |ix| can be ~1e6 when z was clamped)
-        if (!(fx0 >= -1.f && fx0 <= (float)(w - 1) && fy0 >= -1.f && fy0 <= (float)(h - 1))) continue;
+        // grid_sample(bilinear, zeros, align_corners=True): the normalised-grid round trip of
+        // transformer_parq.py:148-152 is the identity on pixel coordinates
+        const double fx0 = floor(u);
+        const double fy0 = floor(vv);
+        // any corner in range?  (tests in floating point: |u| can be ~1e6 when z was clamped)
+        if (!(fx0 >= -1.0 && fx0 <= (double)(w - 1) && fy0 >= -1.0 && fy0 <= (double)(h - 1))) continue;
         const int x0 = (int)fx0;
         const int y0 = (int)fy0;
-        const float wx1 = ix - fx0, wx0 = 1.f - wx1;
-        const float wy1 = iy - fy0, wy0 = 1.f - wy1;
+        const float wx1 = (float)(u - fx0), wx0 = (float)(1.0 - (u - fx0));
+        const float wy1 = (float)(vv - fy0), wy0 = (float)(1.0 - (vv - fy0));
         const bool x0ok = x0 >= 0, x1ok = x0 + 1 <= w - 1;
         const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= h - 1;
         const float* base = tokens + (((int64_t)b * V + v) * h) * (int64_t)w * C;
@@ -326,7 +334,7 @@ __global__ void box_decode_kernel(BoxDecodeArgs a) {
     for (int i = 0; i < 3; ++i)
         a.size[(int64_t)m * 3 + i] = expf(h1[a.ncls + i]) * a.mean_sizes[arg * 3 + i];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) a.rot[(int64_t)m * 6 + i] = h3[3 + i];
+    for (int i = 0; i < 6; ++i) a.rot[(int64_t)m * 6 + i] = h3[6 + i];
     // centre = denorm(sigmoid(offset + inverse_sigmoid(ref)))  (transformer_parq.py:242-245, 38-42)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -336,10 +344,10 @@ __global__ void box_decode_kernel(BoxDecodeArgs a) {
         const float x2 = fmaxf(1.f - r, 1e-3f);
         const float off = h3[i] + logf(x1 / x2);
         const float sg = 1.f / (1.f + expf(-off));
-        const float ctr = sg * (a.sb.hi[i] - a.sb.lo[i]) + a.sb.lo[i];
+        const float ctr = __fadd_rn(__fmul_rn(sg, __fsub_rn(a.sb.hi[i], a.sb.lo[i])), a.sb.lo[i]);   // mul, then add: as torch
         a.center[(int64_t)m * 3 + i] = ctr;
         // next reference point = normalize(centre), detached (transformer_parq.py:331-332)
-        if (a.ref_next) a.ref_next[(int64_t)m * 3 + i] = (ctr - a.sb.lo[i]) / (a.sb.hi[i] - a.sb.lo[i]);
+        if (a.ref_next) a.ref_next[(int64_t)m * 3 + i] = __fsub_rn(ctr, a.sb.lo[i]) / __fsub_rn(a.sb.hi[i], a.sb.lo[i]);
     }
 }
 
@@ -360,7 +368,13 @@ __global__ void fill_kernel(float* dst, float value, int64_t n) {
 
 hipError_t launch_camera_local(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V, float* T_cl,
                                hipStream_t s) {
-    hipLaunchKernelGGL(camera_local_kernel, dim3(ceil_div(B * V, 64)), dim3(64), 0, s, T_cp, T_wp, T_wl, B, V, T_cl);
+    hipLaunchKernelGGL(camera_local_kernel<float>, dim3(ceil_div(B * V, 64)), dim3(64), 0, s, T_cp, T_wp, T_wl, B, V, T_cl);
+    return hipGetLastError();
+}
+
+hipError_t launch_camera_local_f64(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V, double* T_cl,
+                                   hipStream_t s) {
+    hipLaunchKernelGGL(camera_local_kernel<double>, dim3(ceil_div(B * V, 64)), dim3(64), 0, s, T_cp, T_wp, T_wl, B, V, T_cl);
     return hipGetLastError();
 }
 
@@ -374,21 +388,34 @@ hipError_t launch_posemb(const float* ref, const float* dim_t, int M, float* emb
     return hipGetLastError();
 }
 
-hipError_t launch_project_sample(const float* tokens, const float* T_cl, const float* cam, const float* ref,
-                                 ScaleBox sb, int B, int V, int h, int w, int C, int Q, float* tgt,
-                                 float* coord_pos, hipStream_t s) {
+template <typename TPose>
+static hipError_t launch_project_sample_t(const float* tokens, const TPose* T_cl, const float* cam, const float* ref,
+                                          ScaleBox sb, int B, int V, int h, int w, int C, int Q, float* tgt,
+                                          float* coord_pos, hipStream_t s) {
     if (C % 4 != 0 || C > 256 * kMaxChunks || V <= 0) return hipErrorInvalidValue;
     const int nwv = V < 16 ? V : 16;
     const size_t smem = (size_t)nwv * C * sizeof(float) + (size_t)nwv * sizeof(int);
     const int nch = ceil_div(C / 4, 64);
     dim3 grid(B * Q), block(nwv * 64);
     switch (nch) {
-        case 1: hipLaunchKernelGGL(project_sample_kernel<1>, grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos); break;
-        case 2: hipLaunchKernelGGL(project_sample_kernel<2>, grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos); break;
-        case 3: hipLaunchKernelGGL(project_sample_kernel<3>, grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos); break;
-        default: hipLaunchKernelGGL(project_sample_kernel<4>, grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos); break;
+        case 1: hipLaunchKernelGGL((project_sample_kernel<1, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos); break;
+        case 2: hipLaunchKernelGGL((project_sample_kernel<2, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos); break;
+        case 3: hipLaunchKernelGGL((project_sample_kernel<3, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos); break;
+        default: hipLaunchKernelGGL((project_sample_kernel<4, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos); break;
     }
     return hipGetLastError();
+}
+
+hipError_t launch_project_sample(const float* tokens, const float* T_cl, const float* cam, const float* ref,
+                                 ScaleBox sb, int B, int V, int h, int w, int C, int Q, float* tgt,
+                                 float* coord_pos, hipStream_t s) {
+    return launch_project_sample_t<float>(tokens, T_cl, cam, ref, sb, B, V, h, w, C, Q, tgt, coord_pos, s);
+}
+
+hipError_t launch_project_sample_f64(const float* tokens, const double* T_cl, const float* cam, const float* ref,
+                                     ScaleBox sb, int B, int V, int h, int w, int C, int Q, float* tgt,
+                                     float* coord_pos, hipStream_t s) {
+    return launch_project_sample_t<double>(tokens, T_cl, cam, ref, sb, B, V, h, w, C, Q, tgt, coord_pos, s);
 }
 
 hipError_t launch_layernorm(const float* X, const float* gamma, const float* beta, float* Y, int M, int C, float eps,

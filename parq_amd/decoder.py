@@ -324,6 +324,14 @@ class PARQDecoder(nn.Module):
                    "parq_iterate")
         return dict(zip(OUTPUT_KEYS, outs)), nxt
 
+    def intermediate(self, name):
+        """View of a named workspace buffer after prepare()/iterate() (parity tests)."""
+        sc, keep, ws, dev = self._step
+        off, n = C.c_size_t(), C.c_size_t()
+        _lib.check(_lib.load().parq_workspace_lookup(self._handle(), sc.B, sc.V, sc.h, sc.w, name.encode(),
+                                                     C.byref(off), C.byref(n)), "parq_workspace_lookup")
+        return ws[off.value: off.value + n.value]
+
     # ------------------------------------------------------------------ profiling hooks used by bench.py
     def profile_enable(self, on=True):
         _lib.check(_lib.load().parq_profile_enable(self._handle(), int(on)), "parq_profile_enable")

@@ -70,14 +70,14 @@ def test_forward_equals_stepping_and_wrappers_accepted():
 
 def test_oracle_fresh_inputs_cfg2_shape():
     """cfg-2 geometry (5 views 120x160 features, Q=128, 4 iterations) in fp32, teacher-forced
-    against the oracle (the fp32 CPU oracle takes a few seconds here)."""
+    against the float64 oracle (truth): the GPU fp32 path must sit within 1e-4 of it."""
     cfg = synth.decoder_cfg(dim=256, queries=128, heads=4, ffn=768, layers=4)
     W = synth.make_decoder_weights(cfg, 31)
     sc = synth.make_scene(32, 1, 5, 120, 160, 256)
     dec = make_decoder(cfg, W)
     outs = [to_np(o) for o in dec(*scene_args(sc))]
-    od = O.OracleDecoder(cfg, W, synth.SCANNET_MEAN_SIZES)
-    forced = [O.normalize(torch.from_numpy(o["coord_pos"]), cfg.TRANSFORMER.SCALE) for o in outs]
+    od = O.OracleDecoder(cfg, W, synth.SCANNET_MEAN_SIZES, dtype=torch.float64)
+    forced = [O.normalize(torch.from_numpy(o["coord_pos"]).double(), cfg.TRANSFORMER.SCALE) for o in outs]
     with torch.no_grad():
         want = od.forward(sc["tokens"], sc["camera"], sc["T_camera_pseudoCam"], sc["T_world_pseudoCam"],
                           sc["T_world_local"], forced_refs=forced)
@@ -89,6 +89,33 @@ def test_oracle_fresh_inputs_cfg2_shape():
             if key == "size_unnormalized":
                 x, y = x[ok], y[ok]
             assert rel_err(x, y) < TOL, (k, key, rel_err(x, y))
+
+
+def test_closer_to_fp64_truth_than_the_fp32_reference():
+    """g7 holds the reference run in float64 on the g2 inputs.  Teacher-forced with the SAME
+    per-iteration reference points, the HIP fp32 path must be no further from that truth than
+    the reference's own fp32 run (g2) is — i.e. the residual to the fp32 goldens is the
+    reference's rounding noise, not ours."""
+    case, z32 = G.load("g2_forced")
+    _, z64 = G.load("g7_fp64")
+    cfg, W, sc = G.inputs(case)
+    dec = make_decoder(cfg, W)
+    dec.prepare(*scene_args(sc))
+    od = O.OracleDecoder(cfg, W, synth.SCANNET_MEAN_SIZES, dtype=torch.float64)
+    od.prepare(sc["tokens"], sc["camera"], sc["T_camera_pseudoCam"], sc["T_world_pseudoCam"], sc["T_world_local"])
+    refs = G.forced_refs(z32, cfg.TRANSFORMER.SCALE)
+    mine_worst = ref_worst = 0.0
+    for k in range(G.num_iters(z32)):
+        out, _ = dec.iterate(k, dev(refs[k]))
+        with torch.no_grad():
+            truth, _, _ = od.iterate(torch.from_numpy(refs[k]).double(), k)
+        for key in ("pred_logits", "center_unnormalized", "ortho6d", "sem_cls_prob"):
+            t = truth[key].numpy()
+            mine_worst = max(mine_worst, rel_err(out[key].cpu().numpy(), t))
+            ref_worst = max(ref_worst, rel_err(z32["it%d_%s" % (k, key)], t))
+    print("max err vs fp64 truth: HIP fp32 %.3e, reference fp32 %.3e" % (mine_worst, ref_worst))
+    assert mine_worst < TOL
+    assert mine_worst <= ref_worst
 
 
 @pytest.fixture(scope="module")
@@ -111,9 +138,16 @@ def test_full_size_scene_independence_and_determinism(cfg3):
     for a, b in zip(both, again):
         for k in a:
             assert torch.equal(a[k], b[k])          # run-to-run bit-identical
-    for s in (0, 1):                                 # scenes are independent: B=2 == two B=1 runs
-        one = dec(tokens[s:s + 1].contiguous(), *(g[s:s + 1].contiguous() for g in geo), feat_hw=(120, 160))
-        for k_it, (a, b) in enumerate(zip(both, one)):
+    # scenes are independent: scene s of the B=2 run == a B=1 run on scene s.  The free-running
+    # recurrence amplifies rounding differences (different key-split counts at B=1), so the B=1
+    # run is teacher-forced with the B=2 run's own per-iteration reference points.
+    lo = torch.tensor(cfg.TRANSFORMER.SCALE[0::2], device="cuda")
+    hi = torch.tensor(cfg.TRANSFORMER.SCALE[1::2], device="cuda")
+    for s in (0, 1):
+        dec.prepare(tokens[s:s + 1].contiguous(), *(g[s:s + 1].contiguous() for g in geo), feat_hw=(120, 160))
+        for k_it, a in enumerate(both):
+            ref_in = ((a["coord_pos"][s:s + 1] - lo) / (hi - lo)).contiguous()
+            b, _ = dec.iterate(k_it, ref_in)
             for k in a:
                 assert rel_err(b[k][0].cpu().numpy(), a[k][s].cpu().numpy()) < 2e-5, (s, k_it, k)
 

@@ -23,8 +23,9 @@ def test_linear(M, N, K, relu, use_x2, use_r):
     X = synth.normal(1, "X", (M, K)); X2 = synth.normal(2, "X2", (M, K))
     W = synth.normal(3, "W", (N, K), std=K ** -0.5); b = synth.normal(4, "b", (N,)); R = synth.normal(5, "R", (M, N))
     Y = torch.empty(M, N, device="cuda")
-    rc = lib().parq_k_linear(_lib.ptr(dev(X)), _lib.ptr(dev(X2)) if use_x2 else None, _lib.ptr(dev(W)), _lib.ptr(dev(b)),
-                             _lib.ptr(dev(R)) if use_r else None, _lib.ptr(Y), M, N, K, relu, sptr())
+    dX, dX2, dW, db, dR = dev(X), dev(X2), dev(W), dev(b), dev(R)       # keep the device tensors alive
+    rc = lib().parq_k_linear(_lib.ptr(dX), _lib.ptr(dX2) if use_x2 else None, _lib.ptr(dW), _lib.ptr(db),
+                             _lib.ptr(dR) if use_r else None, _lib.ptr(Y), M, N, K, relu, sptr())
     _lib.check(rc, "parq_k_linear")
     A = torch.from_numpy(X).double() + (torch.from_numpy(X2).double() if use_x2 else 0)
     want = A @ torch.from_numpy(W).double().T + torch.from_numpy(b).double()
@@ -46,7 +47,8 @@ def test_layernorm(M, Cn):
     X = synth.normal(1, "lnx", (M, Cn), std=2.0, mean=0.5)
     g = synth.uniform(2, "lng", (Cn,), 0.5, 1.5); b = synth.normal(3, "lnb", (Cn,))
     Y = torch.empty(M, Cn, device="cuda")
-    _lib.check(lib().parq_k_layernorm(_lib.ptr(dev(X)), _lib.ptr(dev(g)), _lib.ptr(dev(b)), _lib.ptr(Y), M, Cn, 1e-5, sptr()), "ln")
+    dX, dg, db = dev(X), dev(g), dev(b)
+    _lib.check(lib().parq_k_layernorm(_lib.ptr(dX), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(Y), M, Cn, 1e-5, sptr()), "ln")
     want = F.layer_norm(torch.from_numpy(X).double(), (Cn,), torch.from_numpy(g).double(), torch.from_numpy(b).double(), 1e-5)
     assert rel_err(Y.cpu().numpy(), want.numpy()) < 1e-5
 
@@ -62,7 +64,8 @@ def test_attention(B, H, Lq, Lk, dh):
     nbytes = lib().parq_k_attention_scratch_bytes(B, H, Lq, Lk, dh)
     scratch = torch.empty(nbytes // 4 + 1, device="cuda")
     out = torch.empty(B, Lq, Cn, device="cuda")
-    _lib.check(lib().parq_k_attention(_lib.ptr(dev(q)), _lib.ptr(dev(k)), _lib.ptr(dev(v)), _lib.ptr(out), B, H, Lq, Lk, dh,
+    dq, dk, dv = dev(q), dev(k), dev(v)
+    _lib.check(lib().parq_k_attention(_lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(out), B, H, Lq, Lk, dh,
                                      _lib.ptr(scratch), nbytes, sptr()), "attention")
     tq, tk, tv = (torch.from_numpy(x).double().view(B, -1, H, dh).transpose(1, 2) for x in (q, k, v))
     want = (torch.softmax(tq @ tk.transpose(-1, -2) / dh ** 0.5, -1) @ tv).transpose(1, 2).reshape(B, Lq, Cn)
@@ -77,7 +80,8 @@ def test_attention_spike_forces_rescale():
     k[0, 10] = 4.0 * q[0, 7]
     nbytes = lib().parq_k_attention_scratch_bytes(B, H, Lq, Lk, dh)
     scratch = torch.empty(nbytes // 4 + 1, device="cuda"); out = torch.empty(B, Lq, dh, device="cuda")
-    _lib.check(lib().parq_k_attention(_lib.ptr(dev(q)), _lib.ptr(dev(k)), _lib.ptr(dev(v)), _lib.ptr(out), B, H, Lq, Lk, dh,
+    dq, dk, dv = dev(q), dev(k), dev(v)
+    _lib.check(lib().parq_k_attention(_lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(out), B, H, Lq, Lk, dh,
                                      _lib.ptr(scratch), nbytes, sptr()), "attention")
     tq, tk, tv = (torch.from_numpy(x).double() for x in (q, k, v))
     want = torch.softmax(tq @ tk.transpose(-1, -2) / dh ** 0.5, -1) @ tv
@@ -87,7 +91,8 @@ def test_attention_spike_forces_rescale():
 def test_camera_local():
     cam, T_cp, T_wp, T_wl = synth.make_geometry(4, 3, 5, 12, 16)
     out = torch.empty(3, 5, 12, device="cuda")
-    _lib.check(lib().parq_k_camera_local(_lib.ptr(dev(T_cp)), _lib.ptr(dev(T_wp)), _lib.ptr(dev(T_wl)), 3, 5, _lib.ptr(out), sptr()), "cl")
+    d1, d2, d3 = dev(T_cp), dev(T_wp), dev(T_wl)
+    _lib.check(lib().parq_k_camera_local(_lib.ptr(d1), _lib.ptr(d2), _lib.ptr(d3), 3, 5, _lib.ptr(out), sptr()), "cl")
     want = O.camera_local_poses(torch.from_numpy(T_cp).double(), torch.from_numpy(T_wp).double(), torch.from_numpy(T_wl).double())
     assert rel_err(out.cpu().numpy(), want.numpy()) < 1e-6
 
@@ -100,17 +105,25 @@ def test_project_sample(B, V, h, w, Cn, Q):
     ref = synth.uniform(22, "ref", (B, Q, 3), 0.0, 1.0)
     T_cl = O.camera_local_poses(*(torch.from_numpy(sc[k]) for k in ("T_camera_pseudoCam", "T_world_pseudoCam", "T_world_local")))
     tgt = torch.empty(B, Q, Cn, device="cuda"); cp = torch.empty(B, Q, 3, device="cuda")
-    _lib.check(lib().parq_k_project_sample(_lib.ptr(dev(sc["tokens"])), _lib.ptr(T_cl.cuda().contiguous()), _lib.ptr(dev(sc["camera"])),
-                                          _lib.ptr(dev(ref)), (C.c_float * 6)(*scale), B, V, h, w, Cn, Q, _lib.ptr(tgt), _lib.ptr(cp),
+    dtok, dT, dcam, dref = dev(sc["tokens"]), T_cl.cuda().contiguous(), dev(sc["camera"]), dev(ref)
+    _lib.check(lib().parq_k_project_sample(_lib.ptr(dtok), _lib.ptr(dT), _lib.ptr(dcam),
+                                          _lib.ptr(dref), (C.c_float * 6)(*scale), B, V, h, w, Cn, Q, _lib.ptr(tgt), _lib.ptr(cp),
                                           sptr()), "project_sample")
     P = O.denormalize(torch.from_numpy(ref), scale)
-    for ro in (False, True):
-        want, p2d, valid = O.project_and_sample(torch.from_numpy(sc["tokens"]), P, T_cl, torch.from_numpy(sc["camera"]), h, w, ro)
-        # queries whose valid-view count could flip under rounding are excluded
-        size = torch.from_numpy(sc["camera"])[..., :2].unsqueeze(-2)
-        margin = torch.minimum(p2d.abs(), (p2d - (size - 1)).abs()).min(-1).values.min(1).values
-        ok = (margin > 1e-3).numpy()
-        assert ok.mean() > 0.9
-        assert rel_err(tgt.cpu().numpy()[ok], want.numpy()[ok]) < 2e-5
+    tok64, cam64 = torch.from_numpy(sc["tokens"]).double(), torch.from_numpy(sc["camera"]).double()
+    T64 = O.camera_local_poses(*(torch.from_numpy(sc[k]).double() for k in ("T_camera_pseudoCam", "T_world_pseudoCam", "T_world_local")))
+    P64 = O.denormalize(torch.from_numpy(ref).double(), scale)
+    want64, p2d, valid = O.project_and_sample(tok64, P64, T64, cam64, h, w, False)
+    # queries whose valid-view count could flip under rounding are excluded
+    size = cam64[..., :2].unsqueeze(-2)
+    margin = torch.minimum(p2d.abs(), (p2d - (size - 1)).abs()).min(-1).values.min(1).values
+    ok = (margin > 1e-3).numpy()
+    assert ok.mean() > 0.9
+    # (the kernel is handed float32 poses here, so the float64 oracle gets the same rounded poses)
+    want64b, _, _ = O.project_and_sample(tok64, P64, T_cl.double(), cam64, h, w, False)
+    assert rel_err(tgt.cpu().numpy()[ok], want64b.numpy()[ok]) < 2e-6      # geometry in fp64, fp32 blend
+    for ro in (False, True):                                               # the fp32 reference ops carry ~5e-5 of
+        want, _, _ = O.project_and_sample(torch.from_numpy(sc["tokens"]), P, T_cl, torch.from_numpy(sc["camera"]), h, w, ro)
+        assert rel_err(tgt.cpu().numpy()[ok], want.numpy()[ok]) < 1e-4     # their own pixel-coordinate rounding noise
     assert rel_err(cp.cpu().numpy(), P.numpy()) < 1e-6
     assert valid.any() and (~valid).any()      # the fixture exercises both branches
