@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Benchmark of the PARQ recurrent decoder path on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--scenes-per-gpu B]
+
+metric  : decoder-iterations/sec = scenes x recurrent iterations / wall time of
+          PARQDecoder.forward (prologue incl. the hoisted K/V projection + I iterations)
+workload: BASELINE cfg 3 — 10 views of 480x640 images -> 120x160 feature maps (stride 4),
+          256 queries, 8 iterations, d=256, 4 heads, FFN 768, fp32, synthetic features,
+          random-init weights.  One "step" = one forward over the rank's batch of scenes.
+N > 1   : one process per GPU (torchrun), scenes sharded data-parallel (independent, no
+          data-path collective: SURVEY.md §8e); weak scaling, value = all ranks' iterations / max time.
+
+Also reported in the same JSON line:
+  roofline      dominant kernel (fp32-MFMA flash cross-attention): algorithmic FLOP per launch
+                (4*Q*N*C per scene) / mean launch time from hipEvents recorded by the library
+                on the launch stream during an instrumented repeat of the same K steps
+  roofline_project_sample   HBM-bound gather: algorithmic bytes (4*V*Q*C + Q*C)*4 per scene
+  cpu_baseline  the oracle in reference_ops mode (same ATen op sequence as the reference)
+                on the host cores, bounded sample (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+WORKLOAD = dict(views=10, image_hw=(480, 640), feat_hw=(120, 160), queries=256, iters=8, dim=256, heads=4, ffn=768)
+PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def build_inputs(B, device, seed):
+    from parq_amd import synth
+    V, (h, w), C = WORKLOAD["views"], WORKLOAD["feat_hw"], WORKLOAD["dim"]
+    cam, T_cp, T_wp, T_wl = synth.make_geometry(seed, B, V, h, w)
+    g = torch.Generator(device=device).manual_seed(seed)
+    tokens = torch.randn(B, V * h * w, C, device=device, generator=g)
+    dev = lambda a: torch.from_numpy(a).to(device)
+    return tokens, dev(cam), dev(T_cp), dev(T_wp), dev(T_wl)
+
+
+def build_decoder(device):
+    from parq_amd import synth
+    from parq_amd.decoder import PARQDecoder
+    cfg = synth.decoder_cfg(dim=WORKLOAD["dim"], queries=WORKLOAD["queries"], heads=WORKLOAD["heads"],
+                            ffn=WORKLOAD["ffn"], layers=WORKLOAD["iters"])
+    W = synth.make_decoder_weights(cfg, seed=2024)
+    dec = PARQDecoder(cfg).eval()
+    sd = dec.state_dict()
+    for k in sd:
+        sd[k] = torch.from_numpy(W[k.replace("parq_module.decoder.mlp_heads.", "mlp_heads.")]).reshape(sd[k].shape)
+    dec.load_state_dict(sd, strict=True)
+    return cfg, W, dec.to(device)
+
+
+def cpu_baseline(cfg, W, inputs, min_seconds=12.0, max_iters=24):
+    """The reference's op sequence on the host cores (oracle, reference_ops=True): time
+    recurrent iterations of scene 0 of the SAME workload until `min_seconds` of CPU work has
+    been measured (the reference hoists nothing, so its cost is linear in the iteration count)."""
+    import copy
+    from parq_amd import synth
+    from oracle import parq_oracle as O
+    cfg2 = copy.deepcopy(cfg)
+    tokens, cam, T_cp, T_wp, T_wl = [t[:1].cpu() for t in inputs]
+    od = O.OracleDecoder(cfg2, W, synth.SCANNET_MEAN_SIZES, reference_ops=True)
+    with torch.no_grad():
+        od.prepare(tokens, cam, T_cp, T_wp, T_wl)
+        ref = od.initial_ref()
+        _, ref, _ = od.iterate(ref, 0)                     # warm-up (thread pools, allocator)
+        t0 = time.perf_counter()
+        budget_iters = 0
+        while budget_iters < max_iters and (budget_iters < 2 or time.perf_counter() - t0 < min_seconds):
+            _, ref, _ = od.iterate(ref, budget_iters % cfg.TRANSFORMER.DEC_LAYERS)
+            budget_iters += 1
+        dt = time.perf_counter() - t0
+    return {"value": budget_iters / dt, "unit": "decoder-iterations/sec", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "%d recurrent iterations of 1 scene of the same workload (reference op sequence: per-iteration "
+                      "K/V projection, materialised softmax, head-averaged weights), %.1f s, host has %d logical CPUs"
+                      % (budget_iters, dt, os.cpu_count() or 0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scenes-per-gpu", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                         % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=device)      # "nccl" is RCCL on ROCm
+
+    B = args.scenes_per_gpu
+    I = WORKLOAD["iters"]
+    h, w = WORKLOAD["feat_hw"]
+    cfg, W, dec = build_decoder(device)
+    inputs = build_inputs(B, device, seed=1000 + rank)         # each rank owns its own scenes (sharded)
+
+    def step():
+        return dec(*inputs, feat_hw=(h, w))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- per-kernel-group times: hipEvents recorded by the library on the launch stream
+    dec.profile_enable(True)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    prof = dec.profile_read()
+    dec.profile_enable(False)
+
+    if rank == 0:
+        V, Q, C = WORKLOAD["views"], WORKLOAD["queries"], WORKLOAD["dim"]
+        N = V * h * w
+        total_iters = world * B * I * args.steps
+        ca_ms, ca_n = prof["cross_attn"]
+        ps_ms, ps_n = prof["project_sample"]
+        flop_per_launch = 4.0 * Q * N * C * B                       # QK^T + PV, all heads, B scenes
+        ach_tflops = flop_per_launch / (ca_ms / ca_n * 1e-3) / 1e12 if ca_n else None
+        bytes_per_launch = (4.0 * V * Q * C + Q * C) * 4.0 * B
+        ps_gbs = bytes_per_launch / (ps_ms / ps_n * 1e-3) / 1e9 if ps_n else None
+        out = {
+            "metric": "decoder-iterations/sec (10 views, 256 queries, d=256)",
+            "value": total_iters / dt, "unit": "decoder-iterations/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE cfg3: 10 views 480x640 (feature maps 120x160, N=192000 tokens), "
+                                   "256 queries, 8 iterations, d=256, 4 heads, FFN 768, ResNet-FPN-shaped synthetic features",
+                       "scenes_per_gpu": B, "parallelism": "dp%d (scene-sharded, no data-path collective)" % world},
+            "roofline": {"bound": "mfma", "kernel": "flash_f32_kernel (cross-attention QK^T+PV, fp32 MFMA)",
+                         "achieved": ach_tflops, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (ach_tflops / PEAK_F32_MATRIX_TFLOPS) if ach_tflops else None, "traffic": None,
+                         "avg_launch_ms": (ca_ms / ca_n) if ca_n else None, "launches": ca_n,
+                         "note": "group time covers the split kernel + its merge kernel"},
+            "roofline_project_sample": {"bound": "hbm", "kernel": "project_sample_kernel",
+                                        "achieved": ps_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                        "frac": (ps_gbs / PEAK_HBM_GBS) if ps_gbs else None, "traffic": None,
+                                        "avg_launch_ms": (ps_ms / ps_n) if ps_n else None, "launches": ps_n},
+            "kernel_groups_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, W, inputs)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
