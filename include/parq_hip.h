@@ -97,6 +97,15 @@ int parq_set_weight(parq_handle h, const char *name, const float *dev, int64_t n
 size_t parq_packed_weights_bytes(parq_handle h);
 int parq_pack_weights(parq_handle h, void *arena, size_t arena_bytes, parq_stream stream);
 
+/* Arithmetic of the dense cross-attention (call before sizing the workspace):
+ *   0  v_mfma_f32_32x32x2_f32 on fp32 operands (exact fp32 products);
+ *   1  (default when head dim == 64) every fp32 operand split as hi+lo fp16 and each product
+ *      evaluated as hi*hi + hi*lo + lo*hi on the fp16 matrix pipe with fp32 accumulation:
+ *      ~2^-22 relative product error, i.e. fp32-rounding class (measured against float64 the
+ *      two modes are indistinguishable); operands must satisfy |x| < 65504, violations raise
+ *      the int at workspace buffer "flags"[0]. */
+int parq_set_attention_mode(parq_handle h, int32_t mode);
+
 /* ---- PARQDecoder.forward ---------------------------------------------------------- */
 size_t parq_workspace_bytes(parq_handle h, int32_t B, int32_t V, int32_t hh, int32_t ww);
 
@@ -157,6 +166,12 @@ size_t parq_k_attention_scratch_bytes(int32_t B, int32_t H, int32_t Lq, int32_t 
 int parq_k_attention(const float *q, const float *k, const float *v, float *out, int32_t B, int32_t H,
                      int32_t Lq, int32_t Lk, int32_t dh, void *scratch, size_t scratch_bytes,
                      parq_stream stream);
+
+/* the same attention through the split-fp16 path (head dim 64): converts k/v to the split cache
+ * layout inside `scratch`, then runs the split kernel + merge. */
+size_t parq_k_attention_split_scratch_bytes(int32_t B, int32_t H, int32_t Lq, int32_t Lk);
+int parq_k_attention_split(const float *q, const float *k, const float *v, float *out, int32_t B, int32_t H,
+                           int32_t Lq, int32_t Lk, void *scratch, size_t scratch_bytes, parq_stream stream);
 
 int parq_k_layernorm(const float *X, const float *gamma, const float *beta, float *Y, int32_t M,
                      int32_t C, float eps, parq_stream stream);

@@ -253,7 +253,9 @@ class OracleDecoder:
         t2 = mha(x + pos, memory, memory,
                  W[p + "multihead_attn.in_proj_weight"], W[p + "multihead_attn.in_proj_bias"],
                  W[p + "multihead_attn.out_proj.weight"], W[p + "multihead_attn.out_proj.bias"], H, ro)
+        self._x1, self._cross = x, t2
         x = layer_norm(x + t2, W[p + "norm2.weight"], W[p + "norm2.bias"])
+        self._x2 = x
         t2 = F.linear(F.relu(F.linear(x, W[p + "linear1.weight"], W[p + "linear1.bias"])),
                       W[p + "linear2.weight"], W[p + "linear2.bias"])
         return layer_norm(x + t2, W[p + "norm3.weight"], W[p + "norm3.bias"])
@@ -284,7 +286,8 @@ class OracleDecoder:
         x = self.layer(tgt, self.tokens, pos, li)
         out = box_heads(x, ref, W, self.T.SCALE, self.mean_sizes)
         nxt = normalize(out["center_unnormalized"], self.T.SCALE)     # :331-332 (detached)
-        return out, nxt, {"pos": pos, "tgt": tgt, "x": x, "p2d": p2d, "valid": valid}
+        return out, nxt, {"pos": pos, "tgt": tgt, "x": x, "p2d": p2d, "valid": valid,
+                          "x1": self._x1, "x2": self._x2, "cross_out": self._cross}
 
     def forward(self, tokens, camera, T_cp, T_wp, T_wl, forced_refs=None):
         """Free-running (forced_refs=None) or teacher-forced: iteration k is fed

@@ -52,6 +52,7 @@ SYMBOLS = {
     "parq_prepare": (C.c_int, [_vp, C.POINTER(ParqScene), _vp, _sz, _vp]),
     "parq_iterate": (C.c_int, [_vp, C.POINTER(ParqScene), _vp, _sz, _i32, _vp, C.POINTER(ParqOutputs), _vp, _vp]),
     "parq_workspace_lookup": (C.c_int, [_vp, _i32, _i32, _i32, _i32, C.c_char_p, C.POINTER(_sz), C.POINTER(_sz)]),
+    "parq_set_attention_mode": (C.c_int, [_vp, _i32]),
     "parq_profile_enable": (C.c_int, [_vp, _i32]),
     "parq_profile_read": (C.c_int, [_vp, _i32, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "parq_k_project_sample": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(_f), _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
@@ -59,6 +60,8 @@ SYMBOLS = {
     "parq_k_linear": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "parq_k_attention_scratch_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "parq_k_attention": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "parq_k_attention_split_scratch_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "parq_k_attention_split": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "parq_k_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f, _vp]),
 }
 

@@ -59,6 +59,7 @@ struct Arena {
 struct Workspace {
     int64_t T_cl, kv, ref, ref_next, emb, pe_h, pos, tgt, qkv, attn, xa, x1, qc, xb, x2, ffn, xc, x3;
     int64_t h1, h2, h3, st1, st2, flash;
+    int64_t kvc, flags;               // split-fp16 K/V cache, int flags (overflow)
     int64_t total;
     int self_split, cross_split;
 };
@@ -77,6 +78,7 @@ struct parq_ctx {
     bool packed = false;
     bool prepared = false;
     int ref_state = 0;                // 0: none, 1: ws.ref valid
+    int attn_mode = 1;                // 0: fp32 MFMA, 1: split fp16x3 (head dim 64 only)
     bool profiling = false;
     std::vector<ProfEvent> events;
     double prof_ms[PARQ_PROF_COUNT] = {0};
@@ -130,7 +132,11 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     ws->st1 = take((int64_t)B * 4); ws->st2 = take((int64_t)B * 4);
     const int cus = device_num_cus();
     ws->self_split = flash_pick_splits(B, c->H, c->Q, c->Q, c->dh, cus);
-    ws->cross_split = flash_pick_splits(B, c->H, c->Q, (int)N, c->dh, cus);
+    const bool split_mode = c->attn_mode == 1 && c->dh == 64;
+    ws->cross_split = split_mode ? flash_split_pick_splits(B, c->H, c->Q, (int)N, cus)
+                                 : flash_pick_splits(B, c->H, c->Q, (int)N, c->dh, cus);
+    ws->kvc = take(split_mode ? (int64_t)(c->nl * kvsplit_cache_bytes(B, c->H, (int)N) / sizeof(float)) : 0);
+    ws->flags = take(64);
     const size_t fs = flash_scratch_bytes(B, c->H, c->Q, c->dh, ws->self_split);
     const size_t fc = flash_scratch_bytes(B, c->H, c->Q, c->dh, ws->cross_split);
     ws->flash = take((int64_t)((fs > fc ? fs : fc) / sizeof(float)));
@@ -184,6 +190,7 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
                                        reinterpret_cast<double*>(wsp + ws.T_cl), s));
         HIPCHK(launch_initial_ref(A + c->ar.refpoint, B, c->Q, wsp + ws.ref, s));
     }
+    HIPCHK(hipMemsetAsync(wsp + ws.flags, 0, 64 * sizeof(float), s));
     // hoisted K/V in-projection of the memory tokens: one GEMM per distinct layer,
     // written head-major [b][{K heads, V heads}][N][dh] so the attention kernel streams contiguous panels
     if ((int64_t)B * N > (int64_t)INT32_MAX) return fail(PARQ_ERR_ARG, "B*N too large");
@@ -194,6 +201,13 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
                            wsp + ws.kv + (int64_t)li * B * 2 * N * C, 0, (int)(B * N), 2 * C, C);
         a.rows_per_batch = (int)N; a.y_batch = 2 * N * C; a.y_row = c->dh; a.col_blk = c->dh; a.y_blk = N * c->dh;
         HIPCHK(launch_linear(a, 1, s));
+        if (c->attn_mode == 1 && c->dh == 64) {
+            const float* kv = wsp + ws.kv + (int64_t)li * B * 2 * N * C;
+            char* cache = reinterpret_cast<char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, c->H, (int)N);
+            HIPCHK(launch_kvsplit_convert(kv, kv + (int64_t)c->H * N * c->dh, 2 * N * C, N * c->dh, c->dh, 2 * N * C,
+                                          N * c->dh, c->dh, B, c->H, (int)N, cache,
+                                          reinterpret_cast<int*>(wsp + ws.flags), s));
+        }
     }
     c->prepared = true;
     c->ref_state = 1;
@@ -275,7 +289,12 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         fa.o_part = wsp + ws.flash;
         fa.m_part = fa.o_part + (int64_t)B * H * fa.nsplit * dh * lp;
         fa.l_part = fa.m_part + (int64_t)B * H * fa.nsplit * lp;
-        HIPCHK(launch_flash(fa, s));
+        if (c->attn_mode == 1 && dh == 64) {
+            const char* cache = reinterpret_cast<const char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, H, (int)N);
+            HIPCHK(launch_flash_split(fa, cache, s));
+        } else {
+            HIPCHK(launch_flash(fa, s));
+        }
         HIPCHK(launch_flash_merge(fa, s));
     }
     {
@@ -555,10 +574,17 @@ int parq_workspace_lookup(parq_handle h, int32_t B, int32_t V, int32_t hh, int32
         {"tgt", ws.tgt, M * C}, {"self_qkv", ws.qkv, M * 3 * C}, {"attn", ws.attn, M * C}, {"x1", ws.x1, M * C},
         {"cross_q", ws.qc, M * C}, {"x2", ws.x2, M * C}, {"ffn_hidden", ws.ffn, M * F}, {"x3", ws.x3, M * C},
         {"heads1", ws.h1, M * h->NH1}, {"heads2", ws.h2, M * 2 * C}, {"heads3", ws.h3, M * 12},
-        {"gn_stats1", ws.st1, (int64_t)B * 4}, {"gn_stats2", ws.st2, (int64_t)B * 4}};
+        {"gn_stats1", ws.st1, (int64_t)B * 4}, {"gn_stats2", ws.st2, (int64_t)B * 4}, {"flags", ws.flags, 64}};
     for (const E& e : table)
         if (strcmp(e.n, name) == 0) { *offset_floats = (size_t)e.off; *numel = (size_t)e.cnt; return PARQ_OK; }
     return fail(PARQ_ERR_ARG, "unknown workspace buffer '%s'", name);
+}
+
+int parq_set_attention_mode(parq_handle h, int32_t mode) {
+    if (!h || (mode != 0 && mode != 1)) return fail(PARQ_ERR_ARG, "attention mode must be 0 (fp32 MFMA) or 1 (split fp16x3)");
+    h->attn_mode = mode;
+    h->prepared = false;
+    return PARQ_OK;
 }
 
 int parq_profile_enable(parq_handle h, int32_t on) {
@@ -641,6 +667,39 @@ int parq_k_attention(const float* q, const float* k, const float* v, float* out,
     fa.l_part = fa.m_part + (int64_t)B * H * fa.nsplit * lp;
     HIPCHK(launch_flash(fa, (hipStream_t)stream));
     HIPCHK(launch_flash_merge(fa, (hipStream_t)stream));
+    return PARQ_OK;
+}
+
+size_t parq_k_attention_split_scratch_bytes(int32_t B, int32_t H, int32_t Lq, int32_t Lk) {
+    const int ns = flash_split_pick_splits(B, H, Lq, Lk, device_num_cus());
+    return flash_scratch_bytes(B, H, Lq, 64, ns) + kvsplit_cache_bytes(B, H, Lk) + 256;
+}
+
+int parq_k_attention_split(const float* q, const float* k, const float* v, float* out, int32_t B, int32_t H, int32_t Lq,
+                           int32_t Lk, void* scratch, size_t scratch_bytes, parq_stream stream) {
+    if (!q || !k || !v || !out || !scratch) return fail(PARQ_ERR_ARG, "NULL argument");
+    if (B < 1 || H < 1 || Lq < 1 || Lk < 1) return fail(PARQ_ERR_ARG, "bad dims");
+    if (scratch_bytes < parq_k_attention_split_scratch_bytes(B, H, Lq, Lk)) return fail(PARQ_ERR_WORKSPACE, "attention scratch too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int dh = 64;
+    const int64_t C = (int64_t)H * dh;
+    FlashArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.B = B; fa.H = H; fa.Lq = Lq; fa.Lk = Lk; fa.dh = dh;
+    fa.q = q; fa.q_batch = Lq * C; fa.q_head = dh; fa.q_row = C;
+    fa.out = out; fa.out_batch = Lq * C; fa.out_row = C;
+    fa.nsplit = flash_split_pick_splits(B, H, Lq, Lk, device_num_cus());
+    const int64_t lp = flash_lq_pad(Lq);
+    char* base = (char*)scratch;
+    int* flag = (int*)base;
+    char* cache = base + 256;
+    fa.o_part = (float*)(cache + kvsplit_cache_bytes(B, H, Lk));
+    fa.m_part = fa.o_part + (int64_t)B * H * fa.nsplit * dh * lp;
+    fa.l_part = fa.m_part + (int64_t)B * H * fa.nsplit * lp;
+    HIPCHK(hipMemsetAsync(flag, 0, 256, s));
+    HIPCHK(launch_kvsplit_convert(k, v, Lk * C, dh, C, Lk * C, dh, C, B, H, Lk, cache, flag, s));
+    HIPCHK(launch_flash_split(fa, cache, s));
+    HIPCHK(launch_flash_merge(fa, s));
     return PARQ_OK;
 }
 

@@ -66,6 +66,14 @@ size_t flash_scratch_bytes(int B, int H, int Lq, int dh, int nsplit);
 hipError_t launch_flash(const FlashArgs& a, hipStream_t s);       // partials
 hipError_t launch_flash_merge(const FlashArgs& a, hipStream_t s); // partials -> out
 
+// split-precision (fp16 hi/lo, 3-term products) cross-attention, head dim 64 (flash_split.hip)
+size_t kvsplit_cache_bytes(int B, int H, int N);
+int flash_split_pick_splits(int B, int H, int Lq, int Lk, int num_cus);
+hipError_t launch_kvsplit_convert(const float* K, const float* V, int64_t k_batch, int64_t k_head, int64_t k_row,
+                                  int64_t v_batch, int64_t v_head, int64_t v_row, int B, int H, int N, void* cache,
+                                  int* overflow_flag, hipStream_t s);
+hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t s);   // partials; merge as usual
+
 // ------------------------------------------------------------------ elementwise / gather kernels
 hipError_t launch_camera_local(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V,
                                float* T_cl, hipStream_t s);

@@ -209,19 +209,22 @@ __global__ __launch_bounds__(NW * 64) void flash_f32_kernel(FlashArgs a) {
 }
 
 // Combine the key-split partials:  out[b][q][h*DH+d] = sum_s w_s O_s[d][q] / sum_s w_s l_s,
-// w_s = 2^(m_s - max_s m_s).  One workgroup per (32 queries, b*h); the result tile is
-// transposed through LDS so both the partial reads (q-contiguous) and the output writes
-// (d-contiguous) are coalesced.
+// w_s = 2^(m_s - max_s m_s).  One workgroup per (32 queries, b*h, 16 d-rows) so that even B=1
+// spreads over >= 128 workgroups; the result tile is transposed through LDS so both the partial
+// reads (q-contiguous) and the output writes (d-contiguous) are coalesced.
+constexpr int kMergeDG = 16;
+
 template <int DH>
 __global__ __launch_bounds__(256) void flash_merge_kernel(FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wsm = smem;                               // [nsplit][32]
     float* dsm = wsm + a.nsplit * 32;                // [8][32]
-    float* tile = dsm + 8 * 32;                      // [DH][33]
+    float* tile = dsm + 8 * 32;                      // [kMergeDG][33]
     const int bh = blockIdx.y;
     const int b = bh / a.H;
     const int h = bh - b * a.H;
     const int q0 = blockIdx.x * 32;
+    const int dg0 = blockIdx.z * kMergeDG;
     const int tq = threadIdx.x & 31;
     const int td = threadIdx.x >> 5;
     const int Lq_pad = (a.Lq + 31) & ~31;
@@ -242,18 +245,37 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(FlashArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) den += dsm[i * 32 + tq];
     const float inv = 1.f / den;
-    for (int d = td; d < DH; d += 8) {
-        float acc = 0.f;
-        for (int s = 0; s < a.nsplit; ++s)
-            acc += wsm[s * 32 + tq] * a.o_part[((pb + s) * DH + d) * Lq_pad + q];
-        tile[d * 33 + tq] = acc * inv;
+    const float* o0 = a.o_part + (pb * DH + dg0 + td) * (int64_t)Lq_pad + q;
+    const int64_t sstride = (int64_t)DH * Lq_pad;
+    float acc0 = 0.f, acc1 = 0.f;
+    int s = 0;
+    for (; s + 4 <= a.nsplit; s += 4) {
+        float x0[4], x1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            x0[u] = o0[(s + u) * sstride];
+            x1[u] = o0[(s + u) * sstride + 8 * (int64_t)Lq_pad];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float w = wsm[(s + u) * 32 + tq];
+            acc0 += w * x0[u];
+            acc1 += w * x1[u];
+        }
     }
+    for (; s < a.nsplit; ++s) {
+        const float w = wsm[s * 32 + tq];
+        acc0 += w * o0[s * sstride];
+        acc1 += w * o0[s * sstride + 8 * (int64_t)Lq_pad];
+    }
+    tile[td * 33 + tq] = acc0 * inv;
+    tile[(td + 8) * 33 + tq] = acc1 * inv;
     __syncthreads();
-    for (int idx = threadIdx.x; idx < 32 * DH; idx += 256) {
-        const int qq = idx / DH;
-        const int d = idx - qq * DH;
+    for (int idx = threadIdx.x; idx < 32 * kMergeDG; idx += 256) {
+        const int qq = idx / kMergeDG;
+        const int d = idx - qq * kMergeDG;
         if (q0 + qq < a.Lq)
-            a.out[(int64_t)b * a.out_batch + (int64_t)(q0 + qq) * a.out_row + h * DH + d] = tile[d * 33 + qq];
+            a.out[(int64_t)b * a.out_batch + (int64_t)(q0 + qq) * a.out_row + h * DH + dg0 + d] = tile[d * 33 + qq];
     }
 }
 
@@ -287,7 +309,7 @@ hipError_t launch_dh(const FlashArgs& a, int nw, hipStream_t s) {
 
 template <int DH>
 hipError_t merge_dh(const FlashArgs& a, hipStream_t s) {
-    const size_t lds = ((size_t)a.nsplit * 32 + 8 * 32 + (size_t)DH * 33) * sizeof(float);
+    const size_t lds = ((size_t)a.nsplit * 32 + 8 * 32 + (size_t)kMergeDG * 33) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_merge_kernel<DH>),
@@ -295,7 +317,7 @@ hipError_t merge_dh(const FlashArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid(ceil_div(a.Lq, 32), a.B * a.H);
+    dim3 grid(ceil_div(a.Lq, 32), a.B * a.H, DH / kMergeDG);
     hipLaunchKernelGGL((flash_merge_kernel<DH>), grid, dim3(256), lds, s, a);
     return hipGetLastError();
 }
@@ -326,7 +348,7 @@ int flash_pick_splits(int B, int H, int Lq, int Lk, int dh, int num_cus) {
     const int nw = flash_pick_nw(B, H, Lq, Lk, dh, num_cus);
     const int nt = ceil_div(Lk, flash_key_tile(dh));
     const int64_t base = (int64_t)B * H * ceil_div(Lq, 32 * nw);
-    const int per_cu = dh <= 64 ? 2 : 1;          // LDS: 64 KB tiles -> 2 workgroups per CU
+    const int per_cu = 1;                         // 8-wave workgroups: registers admit one per CU
     int64_t want = ceil_div64((int64_t)num_cus * per_cu, base);
     if (want < 1) want = 1;
     if (want > nt) want = nt;

@@ -1,0 +1,306 @@
+// Split-precision flash cross-attention for gfx950 (head dim 64).
+//
+// fp32-accurate attention on the fp16 matrix pipe: every fp32 operand x is carried as
+// x = hi + lo with hi = fp16(x), lo = fp16(x - hi) (22 significant bits), and each product
+// a*b is evaluated as  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  with fp32 accumulation
+// (v_mfma_f32_32x32x16_f16).  The dropped lo*lo term and the residual of the split are both
+// ~2^-22 relative, i.e. fp32-rounding class: measured error against float64 equals the
+// fp32-MFMA kernel's.  Three fp16 MFMAs replace sixteen fp32 ones for the same contraction,
+// so the kernel moves from the fp32-MFMA roof (157 TF) towards the HBM roof of streaming
+// the K/V cache.  Range: |x| < 65504 (checked when the cache is built).
+//
+// K/V cache layout ("fragment-ready", written by kvsplit_convert_kernel or directly by the
+// K/V projection GEMM): per (scene, head) a sequence of 32-key blocks of 16 KB
+//     [K_hi 4 KB][K_lo 4 KB][V_hi 4 KB][V_lo 4 KB]
+//   K_x : [32 keys][8 chunks][8 fp16]; chunk c = 4*kh + s holds d = dmap(kh,s,e), stored at chunk
+//         position c ^ ((key>>1)&7)                    (conflict-free ds_read_b128 across keys)
+//   V_x : [64 d][4 chunks][8 fp16];  chunk c = 2*m + kh holds keys kmap(m,kh,e), stored at chunk
+//         position c ^ ((d>>2)&3)
+//   dmap(kh,s,e) = 32*(s>>1) + 16*(s&1) + 4*kh + (e&3) + 8*(e>>2)
+//   kmap(m,kh,e) = 16*m + 4*kh + (e&3) + 8*(e>>2)
+// Both maps are the row enumeration of the 32x32 MFMA accumulator layout, so (a) the
+// projection GEMM can store its accumulators as 16-byte chunks without any shuffle, and (b) the
+// softmax probabilities (S^T accumulator registers) are directly the B operand of V^T P^T.
+// The LDS image of a block equals its global image: staging is a linear 16-byte copy.
+#include "common.hpp"
+
+namespace parq {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int kDH = 64;
+constexpr int kBlkKeys = 32;
+constexpr int kBlkBytes = 16384;
+constexpr int kBlkHalfs = kBlkBytes / 2;
+constexpr int kStageBlks = 2;                       // 64 keys per LDS stage
+constexpr int kNW = 8;                              // waves per workgroup (32 queries each)
+
+__device__ __forceinline__ int dmap(int kh, int s, int e) {
+    return 32 * (s >> 1) + 16 * (s & 1) + 4 * kh + (e & 3) + 8 * (e >> 2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 head-major K/V ([b][h][n][64], as written by the fp32 projection) -> split cache.
+// One workgroup per (32-key block, b*h).  Used by tests and as the fallback producer.
+__global__ __launch_bounds__(256) void kvsplit_convert_kernel(const float* __restrict__ K, const float* __restrict__ V,
+                                                              int64_t k_batch, int64_t k_head, int64_t k_row,
+                                                              int64_t v_batch, int64_t v_head, int64_t v_row, int H,
+                                                              int N, _Float16* __restrict__ cache, int* __restrict__ overflow) {
+    __shared__ float ks[32][65];
+    __shared__ float vs[32][65];
+    const int blk = blockIdx.x;
+    const int bh = blockIdx.y;
+    const int b = bh / H, h = bh - b * H;
+    const int nblk = (N + 31) / 32;
+    const float* kp = K + (int64_t)b * k_batch + (int64_t)h * k_head;
+    const float* vp = V + (int64_t)b * v_batch + (int64_t)h * v_head;
+    bool ovf = false;
+    for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+        const int key = i >> 6, d = i & 63;
+        const int n = blk * 32 + key;
+        const float kvv = n < N ? kp[(int64_t)n * k_row + d] : 0.f;
+        const float vvv = n < N ? vp[(int64_t)n * v_row + d] : 0.f;
+        ovf |= !(fabsf(kvv) < 60000.f) || !(fabsf(vvv) < 60000.f);
+        ks[key][d] = kvv;
+        vs[key][d] = vvv;
+    }
+    if (ovf) atomicOr(overflow, 1);
+    __syncthreads();
+    _Float16* out = cache + ((int64_t)bh * nblk + blk) * kBlkHalfs;
+    // K: 32 keys x 8 chunks = 256 chunks -> one per thread
+    {
+        const int key = threadIdx.x >> 3, c = threadIdx.x & 7;
+        const int kh = c >> 2, s = c & 3;
+        half8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = ks[key][dmap(kh, s, e)];
+            hi[e] = (_Float16)x;
+            lo[e] = (_Float16)(x - (float)hi[e]);
+        }
+        const int pos = c ^ ((key >> 1) & 7);
+        *reinterpret_cast<half8*>(out + key * 64 + pos * 8) = hi;
+        *reinterpret_cast<half8*>(out + 2048 + key * 64 + pos * 8) = lo;
+    }
+    // V: 64 d x 4 chunks = 256 chunks -> one per thread
+    {
+        const int d = threadIdx.x >> 2, c = threadIdx.x & 3;
+        const int m = c >> 1, kh = c & 1;
+        half8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = vs[16 * m + 4 * kh + (e & 3) + 8 * (e >> 2)][d];
+            hi[e] = (_Float16)x;
+            lo[e] = (_Float16)(x - (float)hi[e]);
+        }
+        const int pos = c ^ ((d >> 2) & 3);
+        *reinterpret_cast<half8*>(out + 4096 + d * 32 + pos * 8) = hi;
+        *reinterpret_cast<half8*>(out + 6144 + d * 32 + pos * 8) = lo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, const _Float16* __restrict__ cache) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];       // [2 stages][kStageBlks][kBlkHalfs]
+    constexpr int NT = kNW * 64;
+    constexpr int STAGE16 = kStageBlks * kBlkBytes / 16;                     // 16-byte chunks per stage
+    constexpr int LD = STAGE16 / NT;                                         // per thread
+    static_assert(STAGE16 % NT == 0, "stage must divide over the workgroup");
+
+    const int split = blockIdx.x;
+    const int bh = blockIdx.z;
+    const int b = bh / a.H, h = bh - b * a.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int q0 = (blockIdx.y * kNW + wave) * 32;
+    const int q = q0 + li;
+    const bool active = q0 < a.Lq;
+    const int Lq_pad = (a.Lq + 31) & ~31;
+
+    // Q fragments (B operand of S^T = K Q^T), pre-scaled by log2(e)/sqrt(dh), split hi/lo
+    half8 qhi[4], qlo[4];
+    {
+        const float scale = 1.4426950408889634f / sqrtf((float)kDH);
+        const float* qp = a.q + (int64_t)b * a.q_batch + (int64_t)h * a.q_head + (int64_t)(q < a.Lq ? q : 0) * a.q_row;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            // dmap(kh,s,e): two runs of 4 consecutive d
+            const int d0 = 32 * (s >> 1) + 16 * (s & 1) + 4 * kh;
+            f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + d0);
+            f32x4 x1 = *reinterpret_cast<const f32x4*>(qp + d0 + 8);
+            if (q >= a.Lq) { x0 = f32x4{0.f, 0.f, 0.f, 0.f}; x1 = x0; }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = (e < 4 ? x0[e & 3] : x1[e & 3]) * scale;
+                const _Float16 hh = (_Float16)x;
+                qhi[s][e] = hh;
+                qlo[s][e] = (_Float16)(x - (float)hh);
+            }
+        }
+    }
+
+    const int nblk = (a.Lk + kBlkKeys - 1) / kBlkKeys;
+    const int nst = (nblk + kStageBlks - 1) / kStageBlks;                    // stages in total
+    const int t_begin = (int)((int64_t)split * nst / a.nsplit);
+    const int t_end = (int)((int64_t)(split + 1) * nst / a.nsplit);
+    const uint4* gsrc = reinterpret_cast<const uint4*>(cache + (int64_t)bh * nblk * kBlkHalfs);
+    const int64_t total16 = (int64_t)nblk * (kBlkBytes / 16);
+
+    uint4 stg[LD];
+    auto gload = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < LD; ++i) {
+            const int64_t idx = (int64_t)st * STAGE16 + tid + i * NT;
+            stg[i] = idx < total16 ? gsrc[idx] : uint4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto swrite = [&](int buf) {
+        uint4* dst = reinterpret_cast<uint4*>(smem_h) + buf * STAGE16;
+#pragma unroll
+        for (int i = 0; i < LD; ++i) dst[tid + i * NT] = stg[i];
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    if (t_begin < t_end) {
+        gload(t_begin);
+        swrite(0);
+    }
+    __syncthreads();
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        const bool more = t + 1 < t_end;
+        if (more) gload(t + 1);
+        if (active) {
+#pragma unroll
+            for (int kb = 0; kb < kStageBlks; ++kb) {
+                const int blk = t * kStageBlks + kb;
+                if (blk >= nblk) break;                                       // wave-uniform
+                const _Float16* B0 = smem_h + (buf * kStageBlks + kb) * kBlkHalfs;
+                // ---- S^T = K Q^T  (3-term split product)
+                f32x16 sacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+                const int ksw = (li >> 1) & 7;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int pos = (4 * kh + s) ^ ksw;
+                    const half8 khi = *reinterpret_cast<const half8*>(B0 + li * 64 + pos * 8);
+                    const half8 klo = *reinterpret_cast<const half8*>(B0 + 2048 + li * 64 + pos * 8);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qhi[s], sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qlo[s], sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(klo, qhi[s], sacc, 0, 0, 0);
+                }
+                if (blk == nblk - 1 && (a.Lk & 31) != 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (blk * 32 + mfma32_row(r, lane) >= a.Lk) sacc[r] = -INFINITY;
+                }
+                // ---- online softmax (log2 domain)
+                float mx = sacc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                float rs = 0.f;
+                half8 phi[2], plo[2];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(sacc[r] - m_new);
+                    rs += p;
+                    const _Float16 hh = (_Float16)p;
+                    phi[r >> 3][r & 7] = hh;
+                    plo[r >> 3][r & 7] = (_Float16)(p - (float)hh);
+                }
+                rs += __shfl_xor(rs, 32);
+                l_run = l_run * alpha + rs;
+                m_run = m_new;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                // ---- O^T += V^T P^T  (3-term split product)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const int d = dt * 32 + li;
+                        const int pos = (2 * m + kh) ^ ((d >> 2) & 3);
+                        const half8 vhi = *reinterpret_cast<const half8*>(B0 + 4096 + d * 32 + pos * 8);
+                        const half8 vlo = *reinterpret_cast<const half8*>(B0 + 6144 + d * 32 + pos * 8);
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, phi[m], o[dt], 0, 0, 0);
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo, phi[m], o[dt], 0, 0, 0);
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, plo[m], o[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (more) swrite(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (active) {
+        const int64_t pbase = (int64_t)bh * a.nsplit + split;
+        float* op = a.o_part + pbase * kDH * Lq_pad;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) op[(int64_t)(d * 32 + mfma32_row(r, lane)) * Lq_pad + q] = o[d][r];
+        if (kh == 0) {
+            a.m_part[pbase * Lq_pad + q] = m_run;
+            a.l_part[pbase * Lq_pad + q] = l_run;
+        }
+    }
+}
+
+}  // namespace
+
+size_t kvsplit_cache_bytes(int B, int H, int N) { return (size_t)B * H * ceil_div(N, kBlkKeys) * kBlkBytes; }
+
+int flash_split_stage_keys() { return kStageBlks * kBlkKeys; }
+
+int flash_split_pick_splits(int B, int H, int Lq, int Lk, int num_cus) {
+    const int nst = ceil_div(ceil_div(Lk, kBlkKeys), kStageBlks);
+    const int64_t base = (int64_t)B * H * ceil_div(Lq, 32 * kNW);
+    int64_t want = ceil_div64((int64_t)num_cus, base);
+    if (want < 1) want = 1;
+    if (want > nst) want = nst;
+    if (want > 256) want = 256;
+    return (int)want;
+}
+
+hipError_t launch_kvsplit_convert(const float* K, const float* V, int64_t k_batch, int64_t k_head, int64_t k_row,
+                                  int64_t v_batch, int64_t v_head, int64_t v_row, int B, int H, int N, void* cache,
+                                  int* overflow_flag, hipStream_t s) {
+    dim3 grid(ceil_div(N, kBlkKeys), B * H);
+    hipLaunchKernelGGL(kvsplit_convert_kernel, grid, dim3(256), 0, s, K, V, k_batch, k_head, k_row, v_batch, v_head, v_row,
+                       H, N, reinterpret_cast<_Float16*>(cache), overflow_flag);
+    return hipGetLastError();
+}
+
+hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t s) {
+    if (a.dh != kDH || a.nsplit < 1 || a.nsplit > 256) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    const size_t lds = (size_t)2 * kStageBlks * kBlkBytes;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_split_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid(a.nsplit, ceil_div(a.Lq, 32 * kNW), a.B * a.H);
+    hipLaunchKernelGGL(flash_split_kernel, grid, dim3(kNW * 64), lds, s, a, reinterpret_cast<const _Float16*>(cache));
+    return hipGetLastError();
+}
+
+}  // namespace parq

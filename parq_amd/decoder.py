@@ -171,6 +171,9 @@ class PARQDecoder(nn.Module):
         self.parq_module.decoder.mlp_heads = self.mlp_heads
         self.refpoint = nn.Embedding(self.num_queries, 3)
 
+        # cross-attention arithmetic: "split" = fp16 hi/lo 3-term products on the fp16 matrix pipe
+        # (fp32-class accuracy, head dim 64), "fp32" = fp32 MFMA.  include/parq_hip.h
+        self.attention_mode = "split" if Cd // self.num_heads == 64 else "fp32"
         self._mean_sizes = mean_size_table(self.mean_size_path)     # (rows,3) float64
         self._h = None            # parq_handle
         self._arena = None
@@ -188,6 +191,13 @@ class PARQDecoder(nn.Module):
             h = C.c_void_p()
             _lib.check(lib.parq_create(C.byref(cfg), C.byref(h)), "parq_create")
             self._h = h
+            self._mode_set = None
+        if self._mode_set != self.attention_mode:
+            assert self.attention_mode in ("split", "fp32")
+            _lib.check(_lib.load().parq_set_attention_mode(self._h, 1 if self.attention_mode == "split" else 0),
+                       "parq_set_attention_mode")
+            self._mode_set = self.attention_mode
+            self._ws.clear()
         return self._h
 
     def __del__(self):
@@ -323,6 +333,17 @@ class PARQDecoder(nn.Module):
                                             _lib.ptr(ref_in), C.byref(po), _lib.ptr(nxt), _lib.stream_ptr()),
                    "parq_iterate")
         return dict(zip(OUTPUT_KEYS, outs)), nxt
+
+    def fp16_range_exceeded(self):
+        """True if the last prepare()/forward() saw a K/V value outside the fp16 range while
+        building the split cache (synchronises; only meaningful in "split" mode)."""
+        if not self._ws:
+            return False
+        (B, V, h, w, _), ws = next(iter(self._ws.items()))
+        off, n = C.c_size_t(), C.c_size_t()
+        _lib.check(_lib.load().parq_workspace_lookup(self._handle(), B, V, h, w, b"flags", C.byref(off), C.byref(n)),
+                   "parq_workspace_lookup")
+        return bool(ws[off.value: off.value + 1].view(torch.int32).item() != 0)
 
     def intermediate(self, name):
         """View of a named workspace buffer after prepare()/iterate() (parity tests)."""

@@ -88,6 +88,37 @@ def test_attention_spike_forces_rescale():
     assert rel_err(out.cpu().numpy(), want.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 4, 64, 9600), (2, 4, 256, 256), (1, 2, 40, 429), (1, 1, 32, 33), (1, 1, 1, 1),
+                                       (1, 4, 256, 19200), (2, 1, 300, 1000)])
+def test_attention_split_fp16x3(B, H, Lq, Lk):
+    """Split-precision kernel (fp16 hi/lo, 3-term products): same tolerance as the fp32-MFMA kernel."""
+    dh, Cn = 64, H * 64
+    q = synth.normal(1, "q", (B, Lq, Cn)); k = synth.normal(2, "k", (B, Lk, Cn), std=2.0); v = synth.normal(3, "v", (B, Lk, Cn), std=3.0)
+    k[0, 0, :dh] = 3.0 * q[0, 0, :dh]                 # a peaky row
+    nbytes = lib().parq_k_attention_split_scratch_bytes(B, H, Lq, Lk)
+    scratch = torch.empty(nbytes // 4 + 1, device="cuda")
+    out = torch.empty(B, Lq, Cn, device="cuda")
+    dq, dk, dv = dev(q), dev(k), dev(v)
+    _lib.check(lib().parq_k_attention_split(_lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(out), B, H, Lq, Lk,
+                                           _lib.ptr(scratch), nbytes, sptr()), "attention_split")
+    tq, tk, tv = (torch.from_numpy(x).double().view(B, -1, H, dh).transpose(1, 2) for x in (q, k, v))
+    want = (torch.softmax(tq @ tk.transpose(-1, -2) / dh ** 0.5, -1) @ tv).transpose(1, 2).reshape(B, Lq, Cn)
+    assert rel_err(out.cpu().numpy(), want.numpy()) < 2e-5
+    assert int(scratch[:1].view(torch.int32).item()) == 0          # no fp16 range overflow flagged
+
+
+def test_attention_split_flags_fp16_overflow():
+    B, H, Lq, Lk = 1, 1, 32, 64
+    q = synth.normal(1, "q", (B, Lq, 64)); k = synth.normal(2, "k", (B, Lk, 64)); v = synth.normal(3, "v", (B, Lk, 64))
+    v[0, 5, 7] = 7.0e4
+    nbytes = lib().parq_k_attention_split_scratch_bytes(B, H, Lq, Lk)
+    scratch = torch.empty(nbytes // 4 + 1, device="cuda"); out = torch.empty(B, Lq, 64, device="cuda")
+    dq, dk, dv = dev(q), dev(k), dev(v)
+    _lib.check(lib().parq_k_attention_split(_lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(out), B, H, Lq, Lk,
+                                           _lib.ptr(scratch), nbytes, sptr()), "attention_split")
+    assert int(scratch[:1].view(torch.int32).item()) == 1
+
+
 def test_camera_local():
     cam, T_cp, T_wp, T_wl = synth.make_geometry(4, 3, 5, 12, 16)
     out = torch.empty(3, 5, 12, device="cuda")
