@@ -43,6 +43,7 @@ struct LayerW {
     int64_t cross_in_w, cross_in_b, cross_out_w, cross_out_b;
     int64_t lin1_w, lin1_b, lin2_w, lin2_b;
     int64_t n1_w, n1_b, n2_w, n2_b, n3_w, n3_b;
+    int64_t kv_whi, kv_wlo;           // fp16 hi/lo split of in_proj_weight[C:3C] (each 2C*C halfs)
 };
 struct Arena {
     std::vector<LayerW> layers;
@@ -101,6 +102,7 @@ void build_arena(parq_ctx* c) {
         L.lin1_w = take(F * C); L.lin1_b = take(F);
         L.lin2_w = take(C * F); L.lin2_b = take(C);
         L.n1_w = take(C); L.n1_b = take(C); L.n2_w = take(C); L.n2_b = take(C); L.n3_w = take(C); L.n3_b = take(C);
+        L.kv_whi = take(C * C); L.kv_wlo = take(C * C);
     }
     a.refpoint = take(Q * 3);
     a.pe0_w = take(C * 384); a.pe0_b = take(C); a.pe2_w = take(C * C); a.pe2_b = take(C);
@@ -121,7 +123,8 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     int64_t off = 0;
     auto take = [&](int64_t n) { int64_t o = off; off += align_up(n); return o; };
     ws->T_cl = take((int64_t)B * V * 12 * 2);      // float64 poses
-    ws->kv = take((int64_t)c->nl * B * 2 * N * C);
+    const bool split_mode = c->attn_mode == 1 && c->dh == 64;
+    ws->kv = take(split_mode ? 0 : (int64_t)c->nl * B * 2 * N * C);      // fp32 head-major K/V (fp32 mode only)
     ws->ref = take(M * 3); ws->ref_next = take(M * 3);
     ws->emb = take(M * 384); ws->pe_h = take(M * C); ws->pos = take(M * C);
     ws->tgt = take(M * C); ws->qkv = take(M * 3 * C); ws->attn = take(M * C);
@@ -132,7 +135,6 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     ws->st1 = take((int64_t)B * 4); ws->st2 = take((int64_t)B * 4);
     const int cus = device_num_cus();
     ws->self_split = flash_pick_splits(B, c->H, c->Q, c->Q, c->dh, cus);
-    const bool split_mode = c->attn_mode == 1 && c->dh == 64;
     ws->cross_split = split_mode ? flash_split_pick_splits(B, c->H, c->Q, (int)N, cus)
                                  : flash_pick_splits(B, c->H, c->Q, (int)N, c->dh, cus);
     ws->kvc = take(split_mode ? (int64_t)(c->nl * kvsplit_cache_bytes(B, c->H, (int)N) / sizeof(float)) : 0);
@@ -197,16 +199,15 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     for (int li = 0; li < c->nl; ++li) {
         Prof p(c, s, PARQ_PROF_KV_PROJ);
         const LayerW& L = c->ar.layers[li];
-        LinearArgs a = lin(sc->tokens, C, A + L.cross_in_w + (int64_t)C * C, C, A + L.cross_in_b + C,
-                           wsp + ws.kv + (int64_t)li * B * 2 * N * C, 0, (int)(B * N), 2 * C, C);
-        a.rows_per_batch = (int)N; a.y_batch = 2 * N * C; a.y_row = c->dh; a.col_blk = c->dh; a.y_blk = N * c->dh;
-        HIPCHK(launch_linear(a, 1, s));
         if (c->attn_mode == 1 && c->dh == 64) {
-            const float* kv = wsp + ws.kv + (int64_t)li * B * 2 * N * C;
             char* cache = reinterpret_cast<char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, c->H, (int)N);
-            HIPCHK(launch_kvsplit_convert(kv, kv + (int64_t)c->H * N * c->dh, 2 * N * C, N * c->dh, c->dh, 2 * N * C,
-                                          N * c->dh, c->dh, B, c->H, (int)N, cache,
-                                          reinterpret_cast<int*>(wsp + ws.flags), s));
+            HIPCHK(launch_kvproj_split(sc->tokens, A + L.kv_whi, A + L.kv_wlo, A + L.cross_in_b + C, B, (int)N, C, c->H,
+                                       cache, reinterpret_cast<int*>(wsp + ws.flags), s));
+        } else {
+            LinearArgs a = lin(sc->tokens, C, A + L.cross_in_w + (int64_t)C * C, C, A + L.cross_in_b + C,
+                               wsp + ws.kv + (int64_t)li * B * 2 * N * C, 0, (int)(B * N), 2 * C, C);
+            a.rows_per_batch = (int)N; a.y_batch = 2 * N * C; a.y_row = c->dh; a.col_blk = c->dh; a.y_blk = N * c->dh;
+            HIPCHK(launch_linear(a, 1, s));
         }
     }
     c->prepared = true;
@@ -450,6 +451,7 @@ int parq_pack_weights(parq_handle h, void* arena_v, size_t arena_bytes, parq_str
             !copy(p + "norm2.weight", L.n2_w, C) || !copy(p + "norm2.bias", L.n2_b, C) ||
             !copy(p + "norm3.weight", L.n3_w, C) || !copy(p + "norm3.bias", L.n3_b, C))
             return rc;
+        HIPCHK(launch_split_f32(A + L.cross_in_w + C * C, A + L.kv_whi, A + L.kv_wlo, 2 * C * C, s));
     }
     const Arena& ar = c->ar;
     const std::string d = "parq_module.decoder.";
@@ -569,7 +571,7 @@ int parq_workspace_lookup(parq_handle h, int32_t B, int32_t V, int32_t hh, int32
     const int64_t C = h->C, Q = h->Q, F = h->F, M = (int64_t)B * Q, N = (int64_t)V * hh * ww;
     struct E { const char* n; int64_t off, cnt; };
     const E table[] = {
-        {"T_camera_local_f64", ws.T_cl, (int64_t)B * V * 24}, {"kv_cache", ws.kv, (int64_t)h->nl * B * 2 * N * C},
+        {"T_camera_local_f64", ws.T_cl, (int64_t)B * V * 24}, {"kv_cache", ws.kv, (h->attn_mode == 1 && h->dh == 64) ? 0 : (int64_t)h->nl * B * 2 * N * C},
         {"ref", ws.ref, M * 3}, {"ref_next", ws.ref_next, M * 3}, {"posemb", ws.emb, M * 384}, {"pos_feat", ws.pos, M * C},
         {"tgt", ws.tgt, M * C}, {"self_qkv", ws.qkv, M * 3 * C}, {"attn", ws.attn, M * C}, {"x1", ws.x1, M * C},
         {"cross_q", ws.qc, M * C}, {"x2", ws.x2, M * C}, {"ffn_hidden", ws.ffn, M * F}, {"x3", ws.x3, M * C},

@@ -73,6 +73,10 @@ hipError_t launch_kvsplit_convert(const float* K, const float* V, int64_t k_batc
                                   int64_t v_batch, int64_t v_head, int64_t v_row, int B, int H, int N, void* cache,
                                   int* overflow_flag, hipStream_t s);
 hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t s);   // partials; merge as usual
+// kvproj_split.hip: tokens -> split cache directly (W pre-split with launch_split_f32)
+hipError_t launch_split_f32(const float* src, void* hi, void* lo, int64_t n, hipStream_t s);
+hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void* Wlo, const float* bias, int B, int N,
+                               int C, int H, void* cache, int* overflow, hipStream_t s);
 
 // ------------------------------------------------------------------ elementwise / gather kernels
 hipError_t launch_camera_local(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V,

@@ -1,0 +1,255 @@
+// Hoisted K/V in-projection of the memory tokens, written straight into the split-fp16
+// "fragment-ready" cache consumed by flash_split_kernel (layout: flash_split.hip header).
+//
+//   [K | V][b][n][:] = tokens[b][n][:] @ W_kv^T + b_kv        (transformer_parq.py:377-380, hoisted:
+//                                                              SURVEY.md 0.7 — weights shared, memory constant)
+//
+// fp32-accurate on the fp16 matrix pipe: tokens are split hi/lo on the fly, W is pre-split at
+// pack time, each product is hi*hi + hi*lo + lo*hi with fp32 accumulation.  The GEMM is
+// HBM-bound in this form (reads N*C*4, writes 2*N*C*4 bytes per scene; 151 GFLOP of fp16 MFMA
+// at cfg 3 is ~60 us of matrix time against ~110 us of HBM time).
+//
+// Tiling: workgroup = 4 waves = 128 tokens x 128 output columns (two heads of 64), wave (wr,wc)
+// owns 64 tokens x one head.  K heads are computed TRANSPOSED (A = W rows, B = tokens) and V heads
+// normally (A = tokens, B = W rows): in both cases a lane's 8 consecutive accumulator registers are
+// exactly one 16-byte chunk of the cache layout, so the epilogue is bias + split + 16-byte stores.
+#include "common.hpp"
+
+namespace parq {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int kBM = 128, kBN = 128, kBK = 64;
+constexpr int kThreads = 256;
+constexpr int kBlkHalfs = 8192;                 // one 32-key cache block (16 KB)
+
+struct KvProjArgs {
+    const float* X;            // tokens [B][N][C]
+    const _Float16* Whi;       // [2C][C]
+    const _Float16* Wlo;
+    const float* bias;         // [2C]
+    _Float16* cache;           // [B][H][nblk][16 KB]
+    int* overflow;
+    int N, C, H;
+};
+
+__device__ __forceinline__ void split8(const float* x, half8& hi, half8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 h = (_Float16)x[e];
+        hi[e] = h;
+        lo[e] = (_Float16)(x[e] - (float)h);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void kvproj_split_kernel(KvProjArgs a) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];      // A_hi | A_lo | W_hi | W_lo, each [128][64]
+    _Float16* Ahi = lds;
+    _Float16* Alo = lds + kBM * kBK;
+    _Float16* Bhi = lds + 2 * kBM * kBK;
+    _Float16* Blo = lds + 2 * kBM * kBK + kBN * kBK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int b = blockIdx.z;
+    const int m0 = blockIdx.y * kBM;               // first token of the tile within scene b
+    const int n0 = blockIdx.x * kBN;               // first output column
+    const int C = a.C;
+    const int nk = C / kBK;
+    const int headcol = (n0 >> 6) + wc;            // head index in [K heads | V heads]
+    const bool isK = headcol < a.H;
+
+    // ---- staging assignment: 1024 A chunks (row, c) and 2048 W chunks per stage
+    float4 areg[8];
+    uint4 wreg[8];
+    const float* Xb = a.X + ((int64_t)b * a.N) * C;
+    auto gload = [&](int ks) {
+        const int k0 = ks * kBK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * kThreads;      // 0..1023
+            const int row = id >> 3, c = id & 7;
+            const int tok = m0 + row;
+            if (tok < a.N) {
+                const float4* p = reinterpret_cast<const float4*>(Xb + (int64_t)tok * C + k0 + c * 8);
+                areg[2 * i] = p[0];
+                areg[2 * i + 1] = p[1];
+            } else {
+                areg[2 * i] = float4{0.f, 0.f, 0.f, 0.f};
+                areg[2 * i + 1] = float4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * kThreads;
+            const int row = id >> 3, c = id & 7;
+            const int64_t off = (int64_t)(n0 + row) * C + k0 + c * 8;
+            wreg[2 * i] = *reinterpret_cast<const uint4*>(a.Whi + off);
+            wreg[2 * i + 1] = *reinterpret_cast<const uint4*>(a.Wlo + off);
+        }
+    };
+    // LDS image: row-major [row][8 chunks]; logical chunk c = 4*kh + s lives at position c ^ ((row>>1)&7).
+    // A global chunk g (8 consecutive k) is logical chunk g directly: the k -> (kh, s, e) assignment is
+    // k = 32*kh + 8*s + e, the same for A and B, so the contraction is consistent.
+    auto swrite = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * kThreads;
+            const int row = id >> 3, c = id & 7;
+            const int pos = c ^ ((row >> 1) & 7);
+            float x[8] = {areg[2 * i].x, areg[2 * i].y, areg[2 * i].z, areg[2 * i].w,
+                          areg[2 * i + 1].x, areg[2 * i + 1].y, areg[2 * i + 1].z, areg[2 * i + 1].w};
+            half8 hi, lo;
+            split8(x, hi, lo);
+            *reinterpret_cast<half8*>(Ahi + row * kBK + pos * 8) = hi;
+            *reinterpret_cast<half8*>(Alo + row * kBK + pos * 8) = lo;
+            *reinterpret_cast<uint4*>(Bhi + row * kBK + pos * 8) = wreg[2 * i];
+            *reinterpret_cast<uint4*>(Blo + row * kBK + pos * 8) = wreg[2 * i + 1];
+        }
+    };
+
+    f32x16 acc[2][2];            // [token tile rt][d tile ct]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gload(0);
+    swrite();
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const bool more = ks + 1 < nk;
+        if (more) gload(ks + 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            half8 xh[2], xl[2], wh[2], wl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int row = wr * 64 + t * 32 + li;
+                const int posr = (4 * kh + s) ^ ((row >> 1) & 7);
+                xh[t] = *reinterpret_cast<const half8*>(Ahi + row * kBK + posr * 8);
+                xl[t] = *reinterpret_cast<const half8*>(Alo + row * kBK + posr * 8);
+                const int col = wc * 64 + t * 32 + li;
+                const int posc = (4 * kh + s) ^ ((col >> 1) & 7);
+                wh[t] = *reinterpret_cast<const half8*>(Bhi + col * kBK + posc * 8);
+                wl[t] = *reinterpret_cast<const half8*>(Blo + col * kBK + posc * 8);
+            }
+            if (isK) {      // transposed product: rows = d, cols = tokens
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ct], xh[rt], acc[rt][ct], 0, 0, 0);
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ct], xl[rt], acc[rt][ct], 0, 0, 0);
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ct], xh[rt], acc[rt][ct], 0, 0, 0);
+                    }
+            } else {        // rows = tokens, cols = d
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[rt], wh[ct], acc[rt][ct], 0, 0, 0);
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[rt], wl[ct], acc[rt][ct], 0, 0, 0);
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[rt], wh[ct], acc[rt][ct], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();
+        if (more) {
+            swrite();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: bias, split, 16-byte stores into the cache blocks
+    const int nblk = (a.N + 31) / 32;
+    const int h = isK ? headcol : headcol - a.H;
+    const float* bias = a.bias + headcol * 64;
+    bool ovf = false;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int blk = (m0 + wr * 64 + rt * 32) >> 5;
+        if (blk >= nblk) continue;                                   // wave-uniform
+        _Float16* out = a.cache + (((int64_t)b * a.H + h) * nblk + blk) * kBlkHalfs;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                float x[8];
+                if (isK) {
+                    // lane = key (li), registers 8m..8m+7 = d = 32ct + 16m + 4kh + (e&3) + 8(e>>2): chunk s = 2ct + m
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        x[e] = acc[rt][ct][8 * m + e] + bias[32 * ct + 16 * m + 4 * kh + (e & 3) + 8 * (e >> 2)];
+                } else {
+                    // lane = d (32ct + li), registers 8m..8m+7 = keys 16m + 4kh + (e&3) + 8(e>>2): chunk (m, kh)
+                    const float bv = bias[32 * ct + li];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = acc[rt][ct][8 * m + e] + bv;
+                }
+                half8 hi, lo;
+                split8(x, hi, lo);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ovf |= !(fabsf(x[e]) < 60000.f);
+                if (isK) {
+                    const int c = 4 * kh + 2 * ct + m;
+                    const int pos = c ^ ((li >> 1) & 7);
+                    *reinterpret_cast<half8*>(out + li * 64 + pos * 8) = hi;
+                    *reinterpret_cast<half8*>(out + 2048 + li * 64 + pos * 8) = lo;
+                } else {
+                    const int d = 32 * ct + li;
+                    const int pos = (2 * m + kh) ^ ((d >> 2) & 3);
+                    *reinterpret_cast<half8*>(out + 4096 + d * 32 + pos * 8) = hi;
+                    *reinterpret_cast<half8*>(out + 6144 + d * 32 + pos * 8) = lo;
+                }
+            }
+        }
+    }
+    if (ovf) atomicOr(a.overflow, 1);
+}
+
+// fp32 [rows][cols] -> hi/lo fp16 (weight pre-split at pack time)
+__global__ void split_f32_kernel(const float* __restrict__ src, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = src[i];
+    const _Float16 h = (_Float16)x;
+    hi[i] = h;
+    lo[i] = (_Float16)(x - (float)h);
+}
+
+}  // namespace
+
+hipError_t launch_split_f32(const float* src, void* hi, void* lo, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, s, src,
+                       reinterpret_cast<_Float16*>(hi), reinterpret_cast<_Float16*>(lo), n);
+    return hipGetLastError();
+}
+
+// tokens [B][N][C] -> split cache; Whi/Wlo [2C][C] fp16, bias [2C] fp32.  Needs C % 64 == 0, head dim 64.
+hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void* Wlo, const float* bias, int B, int N,
+                               int C, int H, void* cache, int* overflow, hipStream_t s) {
+    if (C % kBK != 0 || C != H * 64 || (2 * C) % kBN != 0) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    const size_t ldsb = (size_t)(2 * kBM * kBK + 2 * kBN * kBK) * sizeof(_Float16);      // 64 KB
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kvproj_split_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    KvProjArgs a;
+    a.X = tokens; a.Whi = reinterpret_cast<const _Float16*>(Whi); a.Wlo = reinterpret_cast<const _Float16*>(Wlo);
+    a.bias = bias; a.cache = reinterpret_cast<_Float16*>(cache); a.overflow = overflow; a.N = N; a.C = C; a.H = H;
+    dim3 grid(2 * C / kBN, ceil_div(N, kBM), B);
+    if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kvproj_split_kernel, grid, dim3(kThreads), ldsb, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace parq
