@@ -22,6 +22,32 @@ __device__ __forceinline__ int mfma32_row(int reg, int lane) {
     return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
 }
 
+// ------------------------------------------------------------------ fp32 -> (hi, lo) fp16 split
+// x ~= hi + lo with hi = fp16(x) and lo = fp16(x - hi).  `hi` MUST be the value the residual is
+// taken against: hipcc is free to materialise `(_Float16)x` twice (v_cvt_f16_f32 for the residual,
+// v_cvt_pk_f16_f32 for the packed MFMA operand) and on gfx950 the two disagree on exact ties, which
+// silently costs a full fp16 ulp (2^-11 relative).  Going through the packed round-toward-zero
+// builtin pins one conversion; the residual is derived from ITS result.
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split_pair(float x0, float x1, half2v& hi, half2v& lo) {
+    const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    hi = __builtin_bit_cast(half2v, h);
+    const float b0 = (float)hi[0], b1 = (float)hi[1];
+    lo = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(x0 - b0, x1 - b1));
+}
+
+__device__ __forceinline__ void split8(const float* x, half8& hi, half8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        half2v h, l;
+        split_pair(x[e], x[e + 1], h, l);
+        hi[e] = h[0]; hi[e + 1] = h[1];
+        lo[e] = l[0]; lo[e + 1] = l[1];
+    }
+}
+
 // ------------------------------------------------------------------ linear (small GEMM)
 struct LinearArgs {
     const float* X;  int64_t ldx;       // A operand, row-major [M][K] with row stride ldx
@@ -56,6 +82,7 @@ struct FlashArgs {
     float* m_part;              // [B*H][nsplit][Lq_pad]   (log2 domain running max)
     float* l_part;              // [B*H][nsplit][Lq_pad]
     float* out; int64_t out_batch, out_row;              // merged (b, q, h*dh + d)
+    float defer_log2;           // split kernel: running max moves only past this margin (0 = always)
 };
 int flash_key_tile(int dh);                    // keys per LDS tile
 int flash_lq_pad(int Lq);

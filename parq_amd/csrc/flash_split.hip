@@ -23,11 +23,10 @@
 // softmax probabilities (S^T accumulator registers) are directly the B operand of V^T P^T.
 // The LDS image of a block equals its global image: staging is a linear 16-byte copy.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace parq {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -37,6 +36,7 @@ constexpr int kBlkBytes = 16384;
 constexpr int kBlkHalfs = kBlkBytes / 2;
 constexpr int kStageBlks = 2;                       // 64 keys per LDS stage
 constexpr int kNW = 8;                              // waves per workgroup (32 queries each)
+constexpr float kDeferLog2 = 10.f;                  // running max moves only past this margin (log2 domain)
 
 __device__ __forceinline__ int dmap(int kh, int s, int e) {
     return 32 * (s >> 1) + 16 * (s & 1) + 4 * kh + (e & 3) + 8 * (e >> 2);
@@ -75,12 +75,10 @@ __global__ __launch_bounds__(256) void kvsplit_convert_kernel(const float* __res
         const int key = threadIdx.x >> 3, c = threadIdx.x & 7;
         const int kh = c >> 2, s = c & 3;
         half8 hi, lo;
+        float x[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float x = ks[key][dmap(kh, s, e)];
-            hi[e] = (_Float16)x;
-            lo[e] = (_Float16)(x - (float)hi[e]);
-        }
+        for (int e = 0; e < 8; ++e) x[e] = ks[key][dmap(kh, s, e)];
+        split8(x, hi, lo);
         const int pos = c ^ ((key >> 1) & 7);
         *reinterpret_cast<half8*>(out + key * 64 + pos * 8) = hi;
         *reinterpret_cast<half8*>(out + 2048 + key * 64 + pos * 8) = lo;
@@ -90,12 +88,10 @@ __global__ __launch_bounds__(256) void kvsplit_convert_kernel(const float* __res
         const int d = threadIdx.x >> 2, c = threadIdx.x & 3;
         const int m = c >> 1, kh = c & 1;
         half8 hi, lo;
+        float x[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float x = vs[16 * m + 4 * kh + (e & 3) + 8 * (e >> 2)][d];
-            hi[e] = (_Float16)x;
-            lo[e] = (_Float16)(x - (float)hi[e]);
-        }
+        for (int e = 0; e < 8; ++e) x[e] = vs[16 * m + 4 * kh + (e & 3) + 8 * (e >> 2)][d];
+        split8(x, hi, lo);
         const int pos = c ^ ((d >> 2) & 3);
         *reinterpret_cast<half8*>(out + 4096 + d * 32 + pos * 8) = hi;
         *reinterpret_cast<half8*>(out + 6144 + d * 32 + pos * 8) = lo;
@@ -132,13 +128,10 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
             f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + d0);
             f32x4 x1 = *reinterpret_cast<const f32x4*>(qp + d0 + 8);
             if (q >= a.Lq) { x0 = f32x4{0.f, 0.f, 0.f, 0.f}; x1 = x0; }
+            float x[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float x = (e < 4 ? x0[e & 3] : x1[e & 3]) * scale;
-                const _Float16 hh = (_Float16)x;
-                qhi[s][e] = hh;
-                qlo[s][e] = (_Float16)(x - (float)hh);
-            }
+            for (int e = 0; e < 8; ++e) x[e] = (e < 4 ? x0[e & 3] : x1[e & 3]) * scale;
+            split8(x, qhi[s], qlo[s]);
         }
     }
 
@@ -181,69 +174,86 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
         const bool more = t + 1 < t_end;
         if (more) gload(t + 1);
         if (active) {
+            const int nb = (nblk - t * kStageBlks) < kStageBlks ? (nblk - t * kStageBlks) : kStageBlks;   // wave-uniform
+            const _Float16* S0 = smem_h + buf * kStageBlks * kBlkHalfs;
+            const int ksw = (li >> 1) & 7;
+            // ---- S^T = K Q^T for every block of the stage (3-term split product), scores kept absolute
+            f32x16 sacc[kStageBlks];
+            float mx = -INFINITY;
 #pragma unroll
             for (int kb = 0; kb < kStageBlks; ++kb) {
-                const int blk = t * kStageBlks + kb;
-                if (blk >= nblk) break;                                       // wave-uniform
-                const _Float16* B0 = smem_h + (buf * kStageBlks + kb) * kBlkHalfs;
-                // ---- S^T = K Q^T  (3-term split product)
-                f32x16 sacc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-                const int ksw = (li >> 1) & 7;
+                for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+                if (kb < nb) {
+                    const _Float16* B0 = S0 + kb * kBlkHalfs;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int pos = (4 * kh + s) ^ ksw;
-                    const half8 khi = *reinterpret_cast<const half8*>(B0 + li * 64 + pos * 8);
-                    const half8 klo = *reinterpret_cast<const half8*>(B0 + 2048 + li * 64 + pos * 8);
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qhi[s], sacc, 0, 0, 0);
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qlo[s], sacc, 0, 0, 0);
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(klo, qhi[s], sacc, 0, 0, 0);
+                    for (int s = 0; s < 4; ++s) {
+                        const int pos = (4 * kh + s) ^ ksw;
+                        const half8 khi = *reinterpret_cast<const half8*>(B0 + li * 64 + pos * 8);
+                        const half8 klo = *reinterpret_cast<const half8*>(B0 + 2048 + li * 64 + pos * 8);
+                        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qhi[s], sacc[kb], 0, 0, 0);
+                        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qlo[s], sacc[kb], 0, 0, 0);
+                        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(klo, qhi[s], sacc[kb], 0, 0, 0);
+                    }
+                    const int blk = t * kStageBlks + kb;
+                    if (blk == nblk - 1 && (a.Lk & 31) != 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (blk * 32 + mfma32_row(r, lane) >= a.Lk) sacc[kb][r] = -INFINITY;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
                 }
-                if (blk == nblk - 1 && (a.Lk & 31) != 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (blk * 32 + mfma32_row(r, lane) >= a.Lk) sacc[r] = -INFINITY;
-                }
-                // ---- online softmax (log2 domain)
-                float mx = sacc[0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                const float m_new = fmaxf(m_run, mx);
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                float rs = 0.f;
-                half8 phi[2], plo[2];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(sacc[r] - m_new);
-                    rs += p;
-                    const _Float16 hh = (_Float16)p;
-                    phi[r >> 3][r & 7] = hh;
-                    plo[r >> 3][r & 7] = (_Float16)(p - (float)hh);
-                }
-                rs += __shfl_xor(rs, 32);
-                l_run = l_run * alpha + rs;
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            // ---- deferred running max: the reference m_run only moves when a score exceeds it by more
+            // than kDeferLog2 (probabilities stay <= 2^kDeferLog2, well inside fp16/fp32 range); the
+            // rescale of (l, O) is then a rare, wave-uniform branch.  m_run = -inf forces it on the first stage.
+            const bool need = mx > m_run + a.defer_log2;
+            if (__any(need)) {
+                const float m_new = need ? mx : m_run;
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // 1 for unchanged lanes, 0 at the start
+                l_run *= alpha;
                 m_run = m_new;
 #pragma unroll
                 for (int d = 0; d < 2; ++d)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-                // ---- O^T += V^T P^T  (3-term split product)
+            }
+            float rs = 0.f;
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
+            for (int kb = 0; kb < kStageBlks; ++kb) {
+                if (kb < nb) {
+                    const _Float16* B0 = S0 + kb * kBlkHalfs;
+                    half8 phi[2], plo[2];
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        const int d = dt * 32 + li;
-                        const int pos = (2 * m + kh) ^ ((d >> 2) & 3);
-                        const half8 vhi = *reinterpret_cast<const half8*>(B0 + 4096 + d * 32 + pos * 8);
-                        const half8 vlo = *reinterpret_cast<const half8*>(B0 + 6144 + d * 32 + pos * 8);
-                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, phi[m], o[dt], 0, 0, 0);
-                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo, phi[m], o[dt], 0, 0, 0);
-                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, plo[m], o[dt], 0, 0, 0);
+                    for (int m = 0; m < 2; ++m) {
+                        float p[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            p[e] = __builtin_amdgcn_exp2f(sacc[kb][8 * m + e] - m_run);
+                            rs += p[e];
+                        }
+                        split8(p, phi[m], plo[m]);
+                    }
+                    // ---- O^T += V^T P^T  (3-term split product)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) {
+                            const int d = dt * 32 + li;
+                            const int pos = (2 * m + kh) ^ ((d >> 2) & 3);
+                            const half8 vhi = *reinterpret_cast<const half8*>(B0 + 4096 + d * 32 + pos * 8);
+                            const half8 vlo = *reinterpret_cast<const half8*>(B0 + 6144 + d * 32 + pos * 8);
+                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, phi[m], o[dt], 0, 0, 0);
+                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo, phi[m], o[dt], 0, 0, 0);
+                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, plo[m], o[dt], 0, 0, 0);
+                        }
                     }
                 }
             }
+            rs += __shfl_xor(rs, 32);
+            l_run += rs;
         }
         if (more) swrite(buf ^ 1);
         __syncthreads();
@@ -298,8 +308,11 @@ hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    FlashArgs b = a;
+    b.defer_log2 = kDeferLog2;
+    if (const char* e = getenv("PARQ_DEFER_LOG2")) b.defer_log2 = (float)atof(e);      // debugging knob
     dim3 grid(a.nsplit, ceil_div(a.Lq, 32 * kNW), a.B * a.H);
-    hipLaunchKernelGGL(flash_split_kernel, grid, dim3(kNW * 64), lds, s, a, reinterpret_cast<const _Float16*>(cache));
+    hipLaunchKernelGGL(flash_split_kernel, grid, dim3(kNW * 64), lds, s, b, reinterpret_cast<const _Float16*>(cache));
     return hipGetLastError();
 }
 

@@ -17,8 +17,6 @@
 
 namespace parq {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-
 namespace {
 
 constexpr int kBM = 128, kBN = 128, kBK = 64;
@@ -34,15 +32,6 @@ struct KvProjArgs {
     int* overflow;
     int N, C, H;
 };
-
-__device__ __forceinline__ void split8(const float* x, half8& hi, half8& lo) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const _Float16 h = (_Float16)x[e];
-        hi[e] = h;
-        lo[e] = (_Float16)(x[e] - (float)h);
-    }
-}
 
 __global__ __launch_bounds__(kThreads) void kvproj_split_kernel(KvProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];      // A_hi | A_lo | W_hi | W_lo, each [128][64]
@@ -217,10 +206,10 @@ __global__ __launch_bounds__(kThreads) void kvproj_split_kernel(KvProjArgs a) {
 __global__ void split_f32_kernel(const float* __restrict__ src, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float x = src[i];
-    const _Float16 h = (_Float16)x;
-    hi[i] = h;
-    lo[i] = (_Float16)(x - (float)h);
+    half2v h, l;
+    split_pair(src[i], 0.f, h, l);
+    hi[i] = h[0];
+    lo[i] = l[0];
 }
 
 }  // namespace

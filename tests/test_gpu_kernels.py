@@ -95,6 +95,11 @@ def test_attention_split_fp16x3(B, H, Lq, Lk):
     dh, Cn = 64, H * 64
     q = synth.normal(1, "q", (B, Lq, Cn)); k = synth.normal(2, "k", (B, Lk, Cn), std=2.0); v = synth.normal(3, "v", (B, Lk, Cn), std=3.0)
     k[0, 0, :dh] = 3.0 * q[0, 0, :dh]                 # a peaky row
+    # exact fp16 rounding ties (and min-normal residuals): the hi/lo split must stay self-consistent
+    ties = np.array([1 + 2.0 ** -11, -(2 + 2.0 ** -10), 0.5 + 2.0 ** -12, 3 * 2.0 ** -14 + 2.0 ** -25, 0.20623779296875], np.float32)
+    k[0, Lk - 1, :5] = ties
+    v[0, 0, :5] = ties
+    q[0, Lq - 1, :5] = ties / np.float32(1.4426950408889634 / 8.0)
     nbytes = lib().parq_k_attention_split_scratch_bytes(B, H, Lq, Lk)
     scratch = torch.empty(nbytes // 4 + 1, device="cuda")
     out = torch.empty(B, Lq, Cn, device="cuda")
@@ -105,6 +110,24 @@ def test_attention_split_fp16x3(B, H, Lq, Lk):
     want = (torch.softmax(tq @ tk.transpose(-1, -2) / dh ** 0.5, -1) @ tv).transpose(1, 2).reshape(B, Lq, Cn)
     assert rel_err(out.cpu().numpy(), want.numpy()) < 2e-5
     assert int(scratch[:1].view(torch.int32).item()) == 0          # no fp16 range overflow flagged
+
+
+def test_attention_split_spike_forces_deferred_rescale():
+    """The split kernel defers the running-max update (threshold 2^10): keys that dominate late in
+    the stream must take the rescale branch; a moderately larger key (< threshold) must not need it."""
+    B, H, Lq, Lk, dh = 1, 1, 64, 8192, 64
+    q = synth.normal(1, "q", (B, Lq, dh)); k = synth.normal(2, "k", (B, Lk, dh)); v = synth.normal(3, "v", (B, Lk, dh))
+    k[0, 5000] = 8.0 * q[0, 5]          # score ~ |q|^2: far past the deferral threshold, late in the stream
+    k[0, 7000] = 1.0 * q[0, 9]          # ~ 8 in the log2 domain: inside the threshold
+    k[0, 100] = 4.0 * q[0, 40]
+    nbytes = lib().parq_k_attention_split_scratch_bytes(B, H, Lq, Lk)
+    scratch = torch.empty(nbytes // 4 + 1, device="cuda"); out = torch.empty(B, Lq, dh, device="cuda")
+    dq, dk, dv = dev(q), dev(k), dev(v)
+    _lib.check(lib().parq_k_attention_split(_lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(out), B, H, Lq, Lk,
+                                           _lib.ptr(scratch), nbytes, sptr()), "attention_split")
+    tq, tk, tv = (torch.from_numpy(x).double() for x in (q, k, v))
+    want = torch.softmax(tq @ tk.transpose(-1, -2) / dh ** 0.5, -1) @ tv
+    assert rel_err(out.cpu().numpy(), want.numpy()) < 2e-5
 
 
 def test_attention_split_flags_fp16_overflow():
