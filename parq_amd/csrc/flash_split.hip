@@ -181,29 +181,43 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
             f32x16 sacc[kStageBlks];
             float mx = -INFINITY;
 #pragma unroll
-            for (int kb = 0; kb < kStageBlks; ++kb) {
+            for (int kb = 0; kb < kStageBlks; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-                if (kb < nb) {
+            // consecutive MFMAs alternate between the blocks' accumulators (no back-to-back dependent issue)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int pos = (4 * kh + s) ^ ksw;
+                half8 khi[kStageBlks], klo[kStageBlks];
+#pragma unroll
+                for (int kb = 0; kb < kStageBlks; ++kb) {
                     const _Float16* B0 = S0 + kb * kBlkHalfs;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const int pos = (4 * kh + s) ^ ksw;
-                        const half8 khi = *reinterpret_cast<const half8*>(B0 + li * 64 + pos * 8);
-                        const half8 klo = *reinterpret_cast<const half8*>(B0 + 2048 + li * 64 + pos * 8);
-                        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qhi[s], sacc[kb], 0, 0, 0);
-                        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qlo[s], sacc[kb], 0, 0, 0);
-                        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(klo, qhi[s], sacc[kb], 0, 0, 0);
-                    }
-                    const int blk = t * kStageBlks + kb;
-                    if (blk == nblk - 1 && (a.Lk & 31) != 0) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (blk * 32 + mfma32_row(r, lane) >= a.Lk) sacc[kb][r] = -INFINITY;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+                    khi[kb] = *reinterpret_cast<const half8*>(B0 + li * 64 + pos * 8);
+                    klo[kb] = *reinterpret_cast<const half8*>(B0 + 2048 + li * 64 + pos * 8);
                 }
+#pragma unroll
+                for (int kb = 0; kb < kStageBlks; ++kb)
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi[kb], qhi[s], sacc[kb], 0, 0, 0);
+#pragma unroll
+                for (int kb = 0; kb < kStageBlks; ++kb)
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi[kb], qlo[s], sacc[kb], 0, 0, 0);
+#pragma unroll
+                for (int kb = 0; kb < kStageBlks; ++kb)
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(klo[kb], qhi[s], sacc[kb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int kb = 0; kb < kStageBlks; ++kb) {
+                const int blk = t * kStageBlks + kb;
+                if (kb >= nb) {                                           // block past the end of the cache (zero-filled)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[kb][r] = -INFINITY;
+                } else if (blk == nblk - 1 && (a.Lk & 31) != 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (blk * 32 + mfma32_row(r, lane) >= a.Lk) sacc[kb][r] = -INFINITY;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             // ---- deferred running max: the reference m_run only moves when a score exceeds it by more
@@ -236,19 +250,26 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
                         }
                         split8(p, phi[m], plo[m]);
                     }
-                    // ---- O^T += V^T P^T  (3-term split product)
+                    // ---- O^T += V^T P^T  (3-term split product; the two d-tiles' accumulators alternate)
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
+                        half8 vhi[2], vlo[2];
 #pragma unroll
                         for (int dt = 0; dt < 2; ++dt) {
                             const int d = dt * 32 + li;
                             const int pos = (2 * m + kh) ^ ((d >> 2) & 3);
-                            const half8 vhi = *reinterpret_cast<const half8*>(B0 + 4096 + d * 32 + pos * 8);
-                            const half8 vlo = *reinterpret_cast<const half8*>(B0 + 6144 + d * 32 + pos * 8);
-                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, phi[m], o[dt], 0, 0, 0);
-                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo, phi[m], o[dt], 0, 0, 0);
-                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, plo[m], o[dt], 0, 0, 0);
+                            vhi[dt] = *reinterpret_cast<const half8*>(B0 + 4096 + d * 32 + pos * 8);
+                            vlo[dt] = *reinterpret_cast<const half8*>(B0 + 6144 + d * 32 + pos * 8);
                         }
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt)
+                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[dt], phi[m], o[dt], 0, 0, 0);
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt)
+                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo[dt], phi[m], o[dt], 0, 0, 0);
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt)
+                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[dt], plo[m], o[dt], 0, 0, 0);
                     }
                 }
             }

@@ -128,24 +128,39 @@ __global__ __launch_bounds__(kThreads) void kvproj_split_kernel(KvProjArgs a) {
                 wh[t] = *reinterpret_cast<const half8*>(Bhi + col * kBK + posc * 8);
                 wl[t] = *reinterpret_cast<const half8*>(Blo + col * kBK + posc * 8);
             }
+            // three passes over the four accumulators: consecutive MFMAs never share an accumulator
             if (isK) {      // transposed product: rows = d, cols = tokens
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) {
+                    for (int ct = 0; ct < 2; ++ct)
                         acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ct], xh[rt], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
                         acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ct], xl[rt], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
                         acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ct], xh[rt], acc[rt][ct], 0, 0, 0);
-                    }
             } else {        // rows = tokens, cols = d
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) {
+                    for (int ct = 0; ct < 2; ++ct)
                         acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[rt], wh[ct], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
                         acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[rt], wl[ct], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
                         acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[rt], wh[ct], acc[rt][ct], 0, 0, 0);
-                    }
             }
         }
         __syncthreads();
