@@ -126,9 +126,10 @@ int parq_iterate(parq_handle h, const parq_scene *scene, void *workspace, size_t
                  parq_stream stream);
 
 /* Introspection for parity tests: where a named intermediate of the last parq_iterate lives
- * inside the workspace (offset and element count in floats).  Names: "T_camera_local_f64" (float64 payload),
- * "kv_cache", "ref", "posemb", "pos_feat", "tgt", "self_qkv", "attn", "x1", "cross_q", "x2",
- * "ffn_hidden", "x3", "heads1", "heads2", "heads3", "gn_stats1", "gn_stats2". */
+ * inside the workspace (offset and element count in floats).  Names: "T_camera_local_f64" and
+ * "gn_sums_f64" (float64 payloads), "kv_cache", "ref", "ref_next", "posemb", "pos_feat", "tgt",
+ * "self_qkv", "attn", "xa_prenorm1", "cross_q", "xb_prenorm2", "ffn_hidden", "xc_prenorm3",
+ * "heads1", "heads2", "ln1_stats", "ln2_stats", "flags". */
 int parq_workspace_lookup(parq_handle h, int32_t B, int32_t V, int32_t hh, int32_t ww, const char *name,
                           size_t *offset_floats, size_t *numel);
 

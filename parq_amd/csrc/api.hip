@@ -58,8 +58,8 @@ struct Arena {
 };
 
 struct Workspace {
-    int64_t T_cl, kv, ref, ref_next, emb, pe_h, pos, tgt, qkv, attn, xa, x1, qc, xb, x2, ffn, xc, x3;
-    int64_t h1, h2, h3, st1, st2, flash;
+    int64_t T_cl, kv, ref, ref_next, emb, pe_h, pos, tgt, qkv, attn, xa, qc, xb, ffn, xc;
+    int64_t h1, h2, gn_sums, ln1, ln2, flash;     // gn_sums: [2 layers][B][2 heads][2] fp64 moments; ln*: [M][2]
     int64_t kvc, flags;               // split-fp16 K/V cache, int flags (overflow)
     int64_t total;
     int self_split, cross_split;
@@ -78,6 +78,7 @@ struct parq_ctx {
     const float* arena = nullptr;     // device arena after pack
     bool packed = false;
     bool prepared = false;
+    bool emb_valid = false;           // workspace emb holds pos2posemb3d of the chained reference points
     int ref_state = 0;                // 0: none, 1: ws.ref valid
     int attn_mode = 1;                // 0: fp32 MFMA, 1: split fp16x3 (head dim 64 only)
     bool profiling = false;
@@ -128,11 +129,12 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     ws->ref = take(M * 3); ws->ref_next = take(M * 3);
     ws->emb = take(M * 384); ws->pe_h = take(M * C); ws->pos = take(M * C);
     ws->tgt = take(M * C); ws->qkv = take(M * 3 * C); ws->attn = take(M * C);
-    ws->xa = take(M * C); ws->x1 = take(M * C); ws->qc = take(M * C);
-    ws->xb = take(M * C); ws->x2 = take(M * C); ws->ffn = take(M * F);
-    ws->xc = take(M * C); ws->x3 = take(M * C);
-    ws->h1 = take(M * c->NH1); ws->h2 = take(M * 2 * C); ws->h3 = take(M * 12);
-    ws->st1 = take((int64_t)B * 4); ws->st2 = take((int64_t)B * 4);
+    ws->xa = take(M * C); ws->qc = take(M * C);
+    ws->xb = take(M * C); ws->ffn = take(M * F);
+    ws->xc = take(M * C);
+    ws->h1 = take(M * c->NH1); ws->h2 = take(M * 2 * C);
+    ws->gn_sums = take((int64_t)2 * B * 4 * 2);            // doubles
+    ws->ln1 = take(M * 2); ws->ln2 = take(M * 2);
     const int cus = device_num_cus();
     ws->self_split = flash_pick_splits(B, c->H, c->Q, c->Q, c->dh, cus);
     ws->cross_split = split_mode ? flash_split_pick_splits(B, c->H, c->Q, (int)N, cus)
@@ -211,12 +213,13 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         }
     }
     c->prepared = true;
+    c->emb_valid = false;
     c->ref_state = 1;
     return PARQ_OK;
 }
 
 int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& ws, int layer_num, const float* ref,
-               const parq_outputs* o, float* ref_out, hipStream_t s) {
+               bool emb_valid, const parq_outputs* o, float* ref_out, hipStream_t s) {
     const float* A = c->arena;
     const Arena& ar = c->ar;
     const int li = c->cfg.share_weights ? 0 : layer_num;
@@ -224,9 +227,13 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     const int B = sc->B, C = c->C, Q = c->Q, H = c->H, dh = c->dh, F = c->F;
     const int M = B * Q;
     const int64_t N = (int64_t)sc->V * sc->h * sc->w;
+    const float eps = 1e-5f;
+    double* gn1 = reinterpret_cast<double*>(wsp + ws.gn_sums);          // [B][2][2]
+    double* gn2 = gn1 + (int64_t)B * 4;
 
-    // K3: sine embedding -> position MLP (transformer_parq.py:317)
-    { Prof p(c, s, PARQ_PROF_OTHER); HIPCHK(launch_posemb(ref, A + ar.dim_t, M, wsp + ws.emb, s)); }
+    // K3: sine embedding (written by the previous iteration's decode kernel when chained) -> position MLP
+    // (transformer_parq.py:317)
+    if (!emb_valid) { Prof p(c, s, PARQ_PROF_OTHER); HIPCHK(launch_posemb(ref, A + ar.dim_t, M, wsp + ws.emb, s)); }
     {
         Prof p(c, s, PARQ_PROF_LINEAR);
         LinearArgs a = lin(wsp + ws.emb, 384, A + ar.pe0_w, 384, A + ar.pe0_b, wsp + ws.pe_h, C, M, C, 384);
@@ -235,11 +242,11 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         a = lin(wsp + ws.pe_h, C, A + ar.pe2_w, C, A + ar.pe2_b, wsp + ws.pos, C, M, C, C);
         HIPCHK(launch_linear(a, 1, s));
     }
-    // K4+K5: project + sample (transformer_parq.py:321)
+    // K4+K5: project + sample (transformer_parq.py:321); also clears this iteration's GroupNorm moments
     {
         Prof p(c, s, PARQ_PROF_PROJECT_SAMPLE);
-        HIPCHK(launch_project_sample_f64(sc->tokens, reinterpret_cast<const double*>(wsp + ws.T_cl), sc->camera, ref, c->sb, B, sc->V, sc->h, sc->w, C, Q,
-                                     wsp + ws.tgt, o->coord_pos, s));
+        HIPCHK(launch_project_sample_f64(sc->tokens, reinterpret_cast<const double*>(wsp + ws.T_cl), sc->camera, ref, c->sb,
+                                         B, sc->V, sc->h, sc->w, C, Q, wsp + ws.tgt, o->coord_pos, gn1, B * 8, s));
     }
     // K6: self-attention, q = k = tgt + pos, v = tgt (transformer_parq.py:372-376)
     {
@@ -254,37 +261,37 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     fa.out = wsp + ws.attn; fa.out_batch = (int64_t)Q * C; fa.out_row = C;
     {
         Prof p(c, s, PARQ_PROF_SELF_ATTN);
-        fa.q = wsp + ws.qkv;         fa.q_batch = (int64_t)Q * 3 * C; fa.q_head = dh; fa.q_row = 3 * C;
-        fa.k = wsp + ws.qkv + C;     fa.k_batch = fa.q_batch; fa.k_head = dh; fa.k_row = 3 * C;
-        fa.v = wsp + ws.qkv + 2 * C; fa.v_batch = fa.q_batch; fa.v_head = dh; fa.v_row = 3 * C;
-        fa.Lk = Q; fa.nsplit = ws.self_split;
-        const int64_t lp = flash_lq_pad(Q);
-        fa.o_part = wsp + ws.flash;
-        fa.m_part = fa.o_part + (int64_t)B * H * fa.nsplit * dh * lp;
-        fa.l_part = fa.m_part + (int64_t)B * H * fa.nsplit * lp;
-        HIPCHK(launch_flash(fa, s));
-        HIPCHK(launch_flash_merge(fa, s));
+        if (dh <= 64) {
+            HIPCHK(launch_self_attn(wsp + ws.qkv, 3 * C, B, H, Q, dh, wsp + ws.attn, C, s));
+        } else {
+            fa.q = wsp + ws.qkv;         fa.q_batch = (int64_t)Q * 3 * C; fa.q_head = dh; fa.q_row = 3 * C;
+            fa.k = wsp + ws.qkv + C;     fa.k_batch = fa.q_batch; fa.k_head = dh; fa.k_row = 3 * C;
+            fa.v = wsp + ws.qkv + 2 * C; fa.v_batch = fa.q_batch; fa.v_head = dh; fa.v_row = 3 * C;
+            fa.Lk = Q; fa.nsplit = ws.self_split;
+            const int64_t lp = flash_lq_pad(Q);
+            fa.o_part = wsp + ws.flash;
+            fa.m_part = fa.o_part + (int64_t)B * H * fa.nsplit * dh * lp;
+            fa.l_part = fa.m_part + (int64_t)B * H * fa.nsplit * lp;
+            HIPCHK(launch_flash(fa, s));
+            HIPCHK(launch_flash_merge(fa, s));
+        }
     }
     {
+        // xa = tgt + self_attn @ Wo  (pre-LayerNorm; norm1 is applied by the consumers)
         Prof p(c, s, PARQ_PROF_LINEAR);
         LinearArgs a = lin(wsp + ws.attn, C, A + L.self_out_w, C, A + L.self_out_b, wsp + ws.xa, C, M, C, C);
         a.R = wsp + ws.tgt; a.ldr = C;
         HIPCHK(launch_linear(a, 1, s));
-    }
-    { Prof p(c, s, PARQ_PROF_OTHER); HIPCHK(launch_layernorm(wsp + ws.xa, A + L.n1_w, A + L.n1_b, wsp + ws.x1, M, C, 1e-5f, s)); }
-    // K7: dense cross-attention against the cached K/V (transformer_parq.py:377-382)
-    {
-        Prof p(c, s, PARQ_PROF_LINEAR);
-        LinearArgs a = lin(wsp + ws.x1, C, A + L.cross_in_w, C, A + L.cross_in_b, wsp + ws.qc, C, M, C, C);
+        // K7: cross-attention query = (norm1(xa) + pos) @ Wq; publishes norm1's row statistics
+        a = lin(wsp + ws.xa, C, A + L.cross_in_w, C, A + L.cross_in_b, wsp + ws.qc, C, M, C, C);
+        a.ln_gamma = A + L.n1_w; a.ln_beta = A + L.n1_b; a.ln_stats_out = wsp + ws.ln1; a.norm_eps = eps;
         a.X2 = wsp + ws.pos; a.ldx2 = C; a.x2_ncols = C;
         HIPCHK(launch_linear(a, 1, s));
     }
     {
+        // dense cross-attention against the cached K/V (transformer_parq.py:377-382)
         Prof p(c, s, PARQ_PROF_CROSS_ATTN);
-        const float* kv = wsp + ws.kv + (int64_t)li * B * 2 * N * C;
         fa.q = wsp + ws.qc; fa.q_batch = (int64_t)Q * C; fa.q_head = dh; fa.q_row = C;
-        fa.k = kv;                       fa.k_batch = 2 * N * C; fa.k_head = N * dh; fa.k_row = dh;
-        fa.v = kv + (int64_t)H * N * dh; fa.v_batch = 2 * N * C; fa.v_head = N * dh; fa.v_row = dh;
         fa.Lk = (int)N; fa.nsplit = ws.cross_split;
         const int64_t lp = flash_lq_pad(Q);
         fa.o_part = wsp + ws.flash;
@@ -294,64 +301,56 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
             const char* cache = reinterpret_cast<const char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, H, (int)N);
             HIPCHK(launch_flash_split(fa, cache, s));
         } else {
+            const float* kv = wsp + ws.kv + (int64_t)li * B * 2 * N * C;
+            fa.k = kv;                       fa.k_batch = 2 * N * C; fa.k_head = N * dh; fa.k_row = dh;
+            fa.v = kv + (int64_t)H * N * dh; fa.v_batch = 2 * N * C; fa.v_head = N * dh; fa.v_row = dh;
             HIPCHK(launch_flash(fa, s));
         }
         HIPCHK(launch_flash_merge(fa, s));
     }
     {
         Prof p(c, s, PARQ_PROF_LINEAR);
+        // xb = norm1(xa) + cross_attn @ Wo   (residual recomputed from the published statistics)
         LinearArgs a = lin(wsp + ws.attn, C, A + L.cross_out_w, C, A + L.cross_out_b, wsp + ws.xb, C, M, C, C);
-        a.R = wsp + ws.x1; a.ldr = C;
+        a.R = wsp + ws.xa; a.ldr = C; a.rln_stats = wsp + ws.ln1; a.rln_gamma = A + L.n1_w; a.rln_beta = A + L.n1_b;
         HIPCHK(launch_linear(a, 1, s));
-    }
-    { Prof p(c, s, PARQ_PROF_OTHER); HIPCHK(launch_layernorm(wsp + ws.xb, A + L.n2_w, A + L.n2_b, wsp + ws.x2, M, C, 1e-5f, s)); }
-    // K8: FFN (transformer_parq.py:383-385)
-    {
-        Prof p(c, s, PARQ_PROF_LINEAR);
-        LinearArgs a = lin(wsp + ws.x2, C, A + L.lin1_w, C, A + L.lin1_b, wsp + ws.ffn, F, M, F, C);
+        // K8: FFN (transformer_parq.py:383-385): relu(norm2(xb) @ W1), publishes norm2's statistics
+        a = lin(wsp + ws.xb, C, A + L.lin1_w, C, A + L.lin1_b, wsp + ws.ffn, F, M, F, C);
+        a.ln_gamma = A + L.n2_w; a.ln_beta = A + L.n2_b; a.ln_stats_out = wsp + ws.ln2; a.norm_eps = eps;
         a.relu = 1;
         HIPCHK(launch_linear(a, 1, s));
+        // xc = norm2(xb) + ffn @ W2
         a = lin(wsp + ws.ffn, F, A + L.lin2_w, F, A + L.lin2_b, wsp + ws.xc, C, M, C, F);
-        a.R = wsp + ws.x2; a.ldr = C;
+        a.R = wsp + ws.xb; a.ldr = C; a.rln_stats = wsp + ws.ln2; a.rln_gamma = A + L.n2_w; a.rln_beta = A + L.n2_b;
         HIPCHK(launch_linear(a, 1, s));
-    }
-    { Prof p(c, s, PARQ_PROF_OTHER); HIPCHK(launch_layernorm(wsp + ws.xc, A + L.n3_w, A + L.n3_b, wsp + ws.x3, M, C, 1e-5f, s)); }
-    // K9: heads (transformer_parq.py:234-252; generic_mlp.py:85-110)
-    const int NH1 = c->NH1;
-    {
-        Prof p(c, s, PARQ_PROF_LINEAR);
-        LinearArgs a = lin(wsp + ws.x3, C, A + ar.heads1_w, C, A + ar.heads1_b, wsp + ws.h1, NH1, M, NH1, C);
+        // K9: heads (transformer_parq.py:234-252; generic_mlp.py:85-110) on norm3(xc); the first layers of the
+        // four heads are one GEMM, which also accumulates the GroupNorm moments of the two hidden blocks
+        const int NH1 = c->NH1;
+        a = lin(wsp + ws.xc, C, A + ar.heads1_w, C, A + ar.heads1_b, wsp + ws.h1, NH1, M, NH1, C);
+        a.ln_gamma = A + L.n3_w; a.ln_beta = A + L.n3_b; a.norm_eps = eps;
+        a.gn_out_sums = gn1; a.gn_out_ncols = 2 * C; a.gn_out_group_cols = C; a.gn_out_rows_per_scene = Q; a.gn_out_ngroups = 2;
         HIPCHK(launch_linear(a, 1, s));
-    }
-    { Prof p(c, s, PARQ_PROF_OTHER); HIPCHK(launch_gn_stats(wsp + ws.h1, NH1, 0, C, 2, B, Q, 1e-5f, wsp + ws.st1, s)); }
-    {
-        Prof p(c, s, PARQ_PROF_LINEAR);
-        LinearArgs a = lin(wsp + ws.h1, NH1, A + ar.heads2_w, C, nullptr, wsp + ws.h2, 2 * C, M, C, C);
-        a.gn_stats = wsp + ws.st1; a.gn_gamma = A + ar.gn1_g; a.gn_beta = A + ar.gn1_b;
+        a = lin(wsp + ws.h1, NH1, A + ar.heads2_w, C, nullptr, wsp + ws.h2, 2 * C, M, C, C);
+        a.gn_sums = gn1; a.gn_gamma = A + ar.gn1_g; a.gn_beta = A + ar.gn1_b; a.norm_eps = eps;
         a.gn_rows_per_scene = Q; a.gn_ngroups = 2;
         a.gX = C; a.gW = (int64_t)C * C; a.gY = C; a.gGamma = C;
+        a.gn_out_sums = gn2; a.gn_out_ncols = C; a.gn_out_group_cols = C; a.gn_out_rows_per_scene = Q; a.gn_out_ngroups = 2;
         HIPCHK(launch_linear(a, 2, s));
     }
-    { Prof p(c, s, PARQ_PROF_OTHER); HIPCHK(launch_gn_stats(wsp + ws.h2, 2 * C, 0, C, 2, B, Q, 1e-5f, wsp + ws.st2, s)); }
-    {
-        Prof p(c, s, PARQ_PROF_LINEAR);
-        LinearArgs a = lin(wsp + ws.h2, 2 * C, A + ar.heads3_w, C, A + ar.heads3_b, wsp + ws.h3, 12, M, 6, C);
-        a.gn_stats = wsp + ws.st2; a.gn_gamma = A + ar.gn2_g; a.gn_beta = A + ar.gn2_b;
-        a.gn_rows_per_scene = Q; a.gn_ngroups = 2;
-        a.gX = C; a.gW = (int64_t)6 * C; a.gBias = 6; a.gY = 6; a.gGamma = C;
-        HIPCHK(launch_linear(a, 2, s));
-    }
-    // K10: box decode + reference point update (transformer_parq.py:242-279, 331-332)
+    // K10: last head layers + box decode + reference point update + next sine embedding
+    // (transformer_parq.py:242-279, 331-332)
     {
         Prof p(c, s, PARQ_PROF_OTHER);
         BoxDecodeArgs d;
         memset(&d, 0, sizeof(d));
-        d.h1 = wsp + ws.h1 + 2 * C; d.ld1 = NH1;
-        d.h3 = wsp + ws.h3; d.ld3 = 12;
-        d.ref = ref; d.mean_sizes = A + ar.mean_sizes; d.n_mean = c->cfg.num_mean_sizes;
+        d.h1 = wsp + ws.h1 + 2 * C; d.ld1 = c->NH1;
+        d.h2 = wsp + ws.h2; d.ld2 = 2 * C;
+        d.gn_sums = gn2; d.gn_gamma = A + ar.gn2_g; d.gn_beta = A + ar.gn2_b;
+        d.w3 = A + ar.heads3_w; d.b3 = A + ar.heads3_b; d.C = C; d.rows_per_scene = Q; d.eps = eps;
+        d.ref = ref; d.mean_sizes = A + ar.mean_sizes; d.n_mean = c->cfg.num_mean_sizes; d.dim_t = A + ar.dim_t;
         d.sb = c->sb; d.M = M; d.ncls = c->ncls;
         d.logits = o->pred_logits; d.center = o->center_unnormalized; d.size = o->size_unnormalized;
-        d.rot = o->ortho6d; d.prob = o->sem_cls_prob; d.ref_next = ref_out;
+        d.rot = o->ortho6d; d.prob = o->sem_cls_prob; d.ref_next = ref_out; d.emb_next = wsp + ws.emb;
         HIPCHK(launch_box_decode(d, s));
     }
     return PARQ_OK;
@@ -520,7 +519,8 @@ int parq_iterate(parq_handle h, const parq_scene* scene, void* workspace, size_t
     float* wsp = (float*)workspace;
     hipStream_t s = (hipStream_t)stream;
     const float* ref = ref_in ? ref_in : wsp + ws.ref;
-    rc = do_iterate(h, scene, wsp, ws, layer_num, ref, outs, wsp + ws.ref_next, s);
+    rc = do_iterate(h, scene, wsp, ws, layer_num, ref, ref_in == nullptr && h->emb_valid, outs, wsp + ws.ref_next, s);
+    h->emb_valid = (rc == PARQ_OK);        // the decode kernel left pos2posemb3d(ref_next) in the workspace
     if (rc) return rc;
     const size_t rb = (size_t)scene->B * h->Q * 3 * sizeof(float);
     HIPCHK(hipMemcpyAsync(wsp + ws.ref, wsp + ws.ref_next, rb, hipMemcpyDeviceToDevice, s));
@@ -554,7 +554,7 @@ int parq_forward(parq_handle h, const parq_scene* scene, void* workspace, size_t
         o.ortho6d = outs->ortho6d + k * M * 6;
         o.sem_cls_prob = outs->sem_cls_prob + k * M * h->ncls;
         o.coord_pos = outs->coord_pos + k * M * 3;
-        rc = do_iterate(h, scene, wsp, ws, k, ra, &o, rb, s);     // ping-pong the reference points
+        rc = do_iterate(h, scene, wsp, ws, k, ra, k > 0, &o, rb, s);     // ping-pong the reference points
         if (rc) return rc;
         float* t = ra; ra = rb; rb = t;
     }
@@ -571,12 +571,14 @@ int parq_workspace_lookup(parq_handle h, int32_t B, int32_t V, int32_t hh, int32
     const int64_t C = h->C, Q = h->Q, F = h->F, M = (int64_t)B * Q, N = (int64_t)V * hh * ww;
     struct E { const char* n; int64_t off, cnt; };
     const E table[] = {
-        {"T_camera_local_f64", ws.T_cl, (int64_t)B * V * 24}, {"kv_cache", ws.kv, (h->attn_mode == 1 && h->dh == 64) ? 0 : (int64_t)h->nl * B * 2 * N * C},
+        {"T_camera_local_f64", ws.T_cl, (int64_t)B * V * 24},
+        {"kv_cache", ws.kv, (h->attn_mode == 1 && h->dh == 64) ? 0 : (int64_t)h->nl * B * 2 * N * C},
         {"ref", ws.ref, M * 3}, {"ref_next", ws.ref_next, M * 3}, {"posemb", ws.emb, M * 384}, {"pos_feat", ws.pos, M * C},
-        {"tgt", ws.tgt, M * C}, {"self_qkv", ws.qkv, M * 3 * C}, {"attn", ws.attn, M * C}, {"x1", ws.x1, M * C},
-        {"cross_q", ws.qc, M * C}, {"x2", ws.x2, M * C}, {"ffn_hidden", ws.ffn, M * F}, {"x3", ws.x3, M * C},
-        {"heads1", ws.h1, M * h->NH1}, {"heads2", ws.h2, M * 2 * C}, {"heads3", ws.h3, M * 12},
-        {"gn_stats1", ws.st1, (int64_t)B * 4}, {"gn_stats2", ws.st2, (int64_t)B * 4}, {"flags", ws.flags, 64}};
+        {"tgt", ws.tgt, M * C}, {"self_qkv", ws.qkv, M * 3 * C}, {"attn", ws.attn, M * C}, {"xa_prenorm1", ws.xa, M * C},
+        {"cross_q", ws.qc, M * C}, {"xb_prenorm2", ws.xb, M * C}, {"ffn_hidden", ws.ffn, M * F},
+        {"xc_prenorm3", ws.xc, M * C}, {"heads1", ws.h1, M * h->NH1}, {"heads2", ws.h2, M * 2 * C},
+        {"gn_sums_f64", ws.gn_sums, (int64_t)2 * B * 4 * 2}, {"ln1_stats", ws.ln1, M * 2}, {"ln2_stats", ws.ln2, M * 2},
+        {"flags", ws.flags, 64}};
     for (const E& e : table)
         if (strcmp(e.n, name) == 0) { *offset_floats = (size_t)e.off; *numel = (size_t)e.cnt; return PARQ_OK; }
     return fail(PARQ_ERR_ARG, "unknown workspace buffer '%s'", name);

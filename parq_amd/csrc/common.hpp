@@ -62,10 +62,22 @@ struct LinearArgs {
     // output address: Y + (m / rows_per_batch) * y_batch + (m % rows_per_batch) * y_row
     //                   + (n / col_blk) * y_blk + (n % col_blk)
     int rows_per_batch; int64_t y_batch; int64_t y_row; int col_blk; int64_t y_blk;
-    // GroupNorm(1 group over rows_per_scene x K) + ReLU applied to A on load:
-    //   a' = relu((a - mean) * rstd * gamma[k] + beta[k]),  (mean, rstd) = gn_stats[scene][group]
-    const float* gn_stats; const float* gn_gamma; const float* gn_beta;
+    float norm_eps;                     // eps of the fused LayerNorm / GroupNorm
+    // LayerNorm applied to the rows of A on load (statistics over the full K computed by the tile):
+    //   a' = (a - mean_m) * rstd_m * ln_gamma[k] + ln_beta[k]   (then + X2 if given)
+    // ln_stats_out[m] = (mean, rstd) is published by the first column tile for later residual use.
+    const float* ln_gamma; const float* ln_beta; float* ln_stats_out;
+    // residual taken as LayerNorm(R) recomputed from published row statistics:
+    //   r' = (R[m][n] - mean_m) * rstd_m * rln_gamma[n] + rln_beta[n]
+    const float* rln_stats; const float* rln_gamma; const float* rln_beta;
+    // GroupNorm(1 group over rows_per_scene x K) + ReLU applied to A on load, from the scene-wide
+    // moments (sum, sum of squares; fp64) the producer accumulated:
+    //   a' = relu((a - mean) * rstd * gamma[k] + beta[k]),  (S, Q) = gn_sums[scene][group]
+    const double* gn_sums; const float* gn_gamma; const float* gn_beta;
     int gn_rows_per_scene; int gn_ngroups;
+    // moments of the OUTPUT (columns < gn_out_ncols) accumulated with fp64 atomics into
+    // gn_out_sums[scene][(n + g*N) / gn_out_group_cols][2] (zeroed by an earlier kernel)
+    double* gn_out_sums; int gn_out_ncols; int gn_out_group_cols; int gn_out_rows_per_scene; int gn_out_ngroups;
     // grouped launch: blockIdx.y = g adds these element offsets
     int64_t gX, gW, gBias, gY, gGamma;
 };
@@ -112,26 +124,40 @@ hipError_t launch_camera_local_f64(const float* T_cp, const float* T_wp, const f
                                    double* T_cl, hipStream_t s);
 hipError_t launch_initial_ref(const float* refpoint_w, int B, int Q, float* ref, hipStream_t s);
 hipError_t launch_posemb(const float* ref, const float* dim_t, int M, float* emb, hipStream_t s);
+hipError_t launch_zero_f64(double* p, int n, hipStream_t s);
 struct ScaleBox { float lo[3]; float hi[3]; };
 hipError_t launch_project_sample(const float* tokens, const float* T_cl, const float* cam, const float* ref,
                                  ScaleBox sb, int B, int V, int h, int w, int C, int Q, float* tgt,
                                  float* coord_pos, hipStream_t s);
+// zero_f64/zero_n: accumulators (GroupNorm moments) this kernel clears for later kernels of the iteration
 hipError_t launch_project_sample_f64(const float* tokens, const double* T_cl, const float* cam, const float* ref,
                                      ScaleBox sb, int B, int V, int h, int w, int C, int Q, float* tgt,
-                                     float* coord_pos, hipStream_t s);
+                                     float* coord_pos, double* zero_f64, int zero_n, hipStream_t s);
+// self-attention of the Q queries in one launch (8 key slices per workgroup combined through LDS)
+hipError_t launch_self_attn(const float* qkv, int64_t row_stride, int B, int H, int Lq, int dh, float* out,
+                            int64_t out_row, hipStream_t s);
 hipError_t launch_layernorm(const float* X, const float* gamma, const float* beta, float* Y, int M, int C,
                             float eps, hipStream_t s);
 // mean / rstd over (rows_per_scene x ncols) blocks: stats[(b * ngroups + g) * 2 + {0,1}]
 hipError_t launch_gn_stats(const float* X, int64_t ldx, int col0, int ncols, int ngroups, int B,
                            int rows_per_scene, float eps, float* stats, hipStream_t s);
+// Last kernel of an iteration, one wave per query row: GroupNorm+ReLU of the second hidden layer,
+// the two output layers (centre 3, rotation 6), softmax / arg-max size gather / centre update
+// (transformer_parq.py:242-279), next reference point and its 384-d sine embedding (:45-64).
 struct BoxDecodeArgs {
     const float* h1; int64_t ld1;      // [M][..]: logits at cols [0,ncls), size_raw at [ncls, ncls+3)
-    const float* h3; int64_t ld3;      // [M][12]: centre_raw at cols 0..2, ortho6d at cols 6..11
+    const float* h2; int64_t ld2;      // [M][2C]: centre hidden | rotation hidden (pre-GroupNorm)
+    const double* gn_sums;             // [B][2][2] moments of h2 per scene and head
+    const float* gn_gamma; const float* gn_beta;       // [2][C]
+    const float* w3; const float* b3;  // [2][6][C] (centre rows 0..2 of group 0), [2][6]
+    int C; int rows_per_scene; float eps;
     const float* ref;                  // [M][3] normalised reference points of this iteration
     const float* mean_sizes; int n_mean;
+    const float* dim_t;                // [128]
     ScaleBox sb; int M; int ncls;
     float *logits, *center, *size, *rot, *prob;     // outputs (coord_pos is written by project_sample)
     float* ref_next;                   // [M][3] or nullptr
+    float* emb_next;                   // [M][384] or nullptr: pos2posemb3d(ref_next)
 };
 hipError_t launch_box_decode(const BoxDecodeArgs& a, hipStream_t s);
 // weight packing helpers

@@ -109,8 +109,10 @@ template <int NCH, typename TPose>
 __global__ __launch_bounds__(1024) void project_sample_kernel(
     const float* __restrict__ tokens, const TPose* __restrict__ T_cl, const float* __restrict__ cam,
     const float* __restrict__ ref, ScaleBox sb, int V, int h, int w, int C, int Q, float* __restrict__ tgt,
-    float* __restrict__ coord_pos) {
+    float* __restrict__ coord_pos, double* __restrict__ zero_f64, int zero_n) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [nwv][C] + [nwv] counts
+    if (blockIdx.x == 0)                                            // accumulators of later kernels
+        for (int i = threadIdx.x; i < zero_n; i += blockDim.x) zero_f64[i] = 0.0;
     const int bq = blockIdx.x;
     const int b = bq / Q;
     const int lane = threadIdx.x & 63;
@@ -290,65 +292,122 @@ __global__ __launch_bounds__(1024) void gn_stats_kernel(const float* __restrict_
     }
 }
 
-// ---------------------------------------------------------------- box decode + reference-point update
+// ---------------------------------------------------------------- heads' last layer + box decode + next reference point
 constexpr int kMaxCls = 32;
 
-__global__ void box_decode_kernel(BoxDecodeArgs a) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void box_decode_kernel(BoxDecodeArgs a) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= a.M) return;
+    const int lane = threadIdx.x & 63;
+    const int C = a.C;
+    const int scene = m / a.rows_per_scene;
+    // every independent load is issued before the first dependent use (this kernel is pure latency)
     const float* h1 = a.h1 + (int64_t)m * a.ld1;
-    const float* h3 = a.h3 + (int64_t)m * a.ld3;
-    // class probabilities: softmax over num_classes (utils/parq_utils.py:101-105)
-    float lg[kMaxCls];
-    float mx = -INFINITY;
+    const float lg_in = lane < a.ncls ? h1[lane] : -INFINITY;
+    const float sz_in = lane < 3 ? h1[a.ncls + lane] : 0.f;
+    const float ref_in = lane < 3 ? a.ref[(int64_t)m * 3 + lane] : 0.5f;
+    const float b3c = lane < 3 ? a.b3[lane] : 0.f;
+    const float b3r = lane < 6 ? a.b3[6 + lane] : 0.f;
+    double sums[4];
 #pragma unroll
-    for (int c = 0; c < kMaxCls; ++c) {
-        lg[c] = c < a.ncls ? h1[c] : -INFINITY;
-        mx = fmaxf(mx, lg[c]);
+    for (int i = 0; i < 4; ++i) sums[i] = a.gn_sums[scene * 4 + i];
+    // GroupNorm(1,C) of the second hidden layer from the scene-wide moments (generic_mlp.py:85-86)
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const double cnt = (double)a.rows_per_scene * (double)C;
+        const double mu = sums[2 * g] / cnt;
+        double var = sums[2 * g + 1] / cnt - mu * mu;
+        var = var < 0.0 ? 0.0 : var;
+        mean[g] = (float)mu;
+        rstd[g] = (float)(1.0 / sqrt(var + (double)a.eps));
     }
-    float sum = 0.f;
+    // output layers: centre (3 rows of group 0) and rotation (6 rows of group 1), K = C each
+    float acc[9];
 #pragma unroll
-    for (int c = 0; c < kMaxCls; ++c) {
-        if (c < a.ncls) {
-            a.logits[(int64_t)m * a.ncls + c] = lg[c];
-            lg[c] = expf(lg[c] - mx);
-            sum += lg[c];
+    for (int j = 0; j < 9; ++j) acc[j] = 0.f;
+    const float* h2 = a.h2 + (int64_t)m * a.ld2;
+    for (int c = lane; c < C; c += 64) {
+        float y0 = (h2[c] - mean[0]) * rstd[0] * a.gn_gamma[c] + a.gn_beta[c];
+        float y1 = (h2[C + c] - mean[1]) * rstd[1] * a.gn_gamma[C + c] + a.gn_beta[C + c];
+        y0 = y0 > 0.f ? y0 : 0.f;
+        y1 = y1 > 0.f ? y1 : 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] += y0 * a.w3[(int64_t)j * C + c];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[3 + j] += y1 * a.w3[(int64_t)(6 + j) * C + c];
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_xor(acc[j], o);
+
+    // class probabilities: softmax over num_classes, one class per lane (utils/parq_utils.py:101-105)
+    float mx = lg_in;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float ex = lane < a.ncls ? expf(lg_in - mx) : 0.f;
+    float sum = ex;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float prob = ex / sum;
+    if (lane < a.ncls) {
+        a.logits[(int64_t)m * a.ncls + lane] = lg_in;
+        a.prob[(int64_t)m * a.ncls + lane] = prob;
+    }
+    // arg-max with torch.argmax tie-breaking (first maximum)
+    float bestp = lane < a.ncls ? prob : -1.f;
+    int besti = lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float op = __shfl_xor(bestp, o);
+        const int oi = __shfl_xor(besti, o);
+        if (op > bestp || (op == bestp && oi < besti)) {
+            bestp = op;
+            besti = oi;
         }
     }
-    int arg = 0;
-    float best = -1.f;
-#pragma unroll
-    for (int c = 0; c < kMaxCls; ++c) {
-        if (c < a.ncls) {
-            const float p = lg[c] / sum;
-            a.prob[(int64_t)m * a.ncls + c] = p;
-            if (p > best) {       // first maximum, as torch.argmax
-                best = p;
-                arg = c;
-            }
-        }
-    }
+    int arg = besti < a.n_mean ? besti : a.n_mean - 1;
     // size = exp(size_scale) * mean_size[argmax]  (utils/parq_utils.py:94-99)
-    if (arg >= a.n_mean) arg = a.n_mean - 1;
+    if (lane < 3) a.size[(int64_t)m * 3 + lane] = expf(sz_in) * a.mean_sizes[arg * 3 + lane];
+    // ortho6d: lane j picks its own reduced dot product
+    float rotv = 0.f, ctrv = 0.f;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-        a.size[(int64_t)m * 3 + i] = expf(h1[a.ncls + i]) * a.mean_sizes[arg * 3 + i];
+    for (int j = 0; j < 6; ++j) rotv = lane == j ? acc[3 + j] : rotv;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) a.rot[(int64_t)m * 6 + i] = h3[6 + i];
+    for (int j = 0; j < 3; ++j) ctrv = lane == j ? acc[j] : ctrv;
+    if (lane < 6) a.rot[(int64_t)m * 6 + lane] = rotv + b3r;
     // centre = denorm(sigmoid(offset + inverse_sigmoid(ref)))  (transformer_parq.py:242-245, 38-42)
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        float r = a.ref[(int64_t)m * 3 + i];
-        r = fminf(fmaxf(r, 0.f), 1.f);
+    float nref = 0.f;
+    if (lane < 3) {
+        const float lo = lane == 0 ? a.sb.lo[0] : (lane == 1 ? a.sb.lo[1] : a.sb.lo[2]);
+        const float hi = lane == 0 ? a.sb.hi[0] : (lane == 1 ? a.sb.hi[1] : a.sb.hi[2]);
+        const float r = fminf(fmaxf(ref_in, 0.f), 1.f);
         const float x1 = fmaxf(r, 1e-3f);
         const float x2 = fmaxf(1.f - r, 1e-3f);
-        const float off = h3[i] + logf(x1 / x2);
+        const float off = (ctrv + b3c) + logf(x1 / x2);
         const float sg = 1.f / (1.f + expf(-off));
-        const float ctr = __fadd_rn(__fmul_rn(sg, __fsub_rn(a.sb.hi[i], a.sb.lo[i])), a.sb.lo[i]);   // mul, then add: as torch
-        a.center[(int64_t)m * 3 + i] = ctr;
+        const float ctr = __fadd_rn(__fmul_rn(sg, __fsub_rn(hi, lo)), lo);      // mul, then add: as torch
+        a.center[(int64_t)m * 3 + lane] = ctr;
         // next reference point = normalize(centre), detached (transformer_parq.py:331-332)
-        if (a.ref_next) a.ref_next[(int64_t)m * 3 + i] = __fsub_rn(ctr, a.sb.lo[i]) / __fsub_rn(a.sb.hi[i], a.sb.lo[i]);
+        nref = __fsub_rn(ctr, lo) / __fsub_rn(hi, lo);
+        if (a.ref_next) a.ref_next[(int64_t)m * 3 + lane] = nref;
     }
+    // sine embedding of the next reference point for the next iteration's position MLP
+    if (a.emb_next) {
+        const float n0 = __shfl(nref, 0), n1 = __shfl(nref, 1), n2 = __shfl(nref, 2);
+        for (int k = lane; k < 384; k += 64) {
+            const int blk = k >> 7, i = k & 127;
+            const float r = blk == 0 ? n1 : (blk == 1 ? n0 : n2);
+            const float ang = (r * 6.283185307179586f) / a.dim_t[i];
+            a.emb_next[(int64_t)m * 384 + k] = (i & 1) ? cosf(ang) : sinf(ang);
+        }
+    }
+}
+
+__global__ void zero_f64_kernel(double* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0;
 }
 
 __global__ void copy_rows_kernel(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int rows, int cols) {
@@ -391,17 +450,17 @@ hipError_t launch_posemb(const float* ref, const float* dim_t, int M, float* emb
 template <typename TPose>
 static hipError_t launch_project_sample_t(const float* tokens, const TPose* T_cl, const float* cam, const float* ref,
                                           ScaleBox sb, int B, int V, int h, int w, int C, int Q, float* tgt,
-                                          float* coord_pos, hipStream_t s) {
+                                          float* coord_pos, double* zero_f64, int zero_n, hipStream_t s) {
     if (C % 4 != 0 || C > 256 * kMaxChunks || V <= 0) return hipErrorInvalidValue;
     const int nwv = V < 16 ? V : 16;
     const size_t smem = (size_t)nwv * C * sizeof(float) + (size_t)nwv * sizeof(int);
     const int nch = ceil_div(C / 4, 64);
     dim3 grid(B * Q), block(nwv * 64);
     switch (nch) {
-        case 1: hipLaunchKernelGGL((project_sample_kernel<1, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos); break;
-        case 2: hipLaunchKernelGGL((project_sample_kernel<2, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos); break;
-        case 3: hipLaunchKernelGGL((project_sample_kernel<3, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos); break;
-        default: hipLaunchKernelGGL((project_sample_kernel<4, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos); break;
+        case 1: hipLaunchKernelGGL((project_sample_kernel<1, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n); break;
+        case 2: hipLaunchKernelGGL((project_sample_kernel<2, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n); break;
+        case 3: hipLaunchKernelGGL((project_sample_kernel<3, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n); break;
+        default: hipLaunchKernelGGL((project_sample_kernel<4, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n); break;
     }
     return hipGetLastError();
 }
@@ -409,13 +468,13 @@ static hipError_t launch_project_sample_t(const float* tokens, const TPose* T_cl
 hipError_t launch_project_sample(const float* tokens, const float* T_cl, const float* cam, const float* ref,
                                  ScaleBox sb, int B, int V, int h, int w, int C, int Q, float* tgt,
                                  float* coord_pos, hipStream_t s) {
-    return launch_project_sample_t<float>(tokens, T_cl, cam, ref, sb, B, V, h, w, C, Q, tgt, coord_pos, s);
+    return launch_project_sample_t<float>(tokens, T_cl, cam, ref, sb, B, V, h, w, C, Q, tgt, coord_pos, nullptr, 0, s);
 }
 
 hipError_t launch_project_sample_f64(const float* tokens, const double* T_cl, const float* cam, const float* ref,
                                      ScaleBox sb, int B, int V, int h, int w, int C, int Q, float* tgt,
-                                     float* coord_pos, hipStream_t s) {
-    return launch_project_sample_t<double>(tokens, T_cl, cam, ref, sb, B, V, h, w, C, Q, tgt, coord_pos, s);
+                                     float* coord_pos, double* zero_f64, int zero_n, hipStream_t s) {
+    return launch_project_sample_t<double>(tokens, T_cl, cam, ref, sb, B, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n, s);
 }
 
 hipError_t launch_layernorm(const float* X, const float* gamma, const float* beta, float* Y, int M, int C, float eps,
@@ -435,7 +494,12 @@ hipError_t launch_gn_stats(const float* X, int64_t ldx, int col0, int ncols, int
 
 hipError_t launch_box_decode(const BoxDecodeArgs& a, hipStream_t s) {
     if (a.ncls > kMaxCls || a.ncls < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(box_decode_kernel, dim3(ceil_div(a.M, 64)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(box_decode_kernel, dim3(ceil_div(a.M, 4)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_zero_f64(double* p, int n, hipStream_t s) {
+    hipLaunchKernelGGL(zero_f64_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, s, p, n);
     return hipGetLastError();
 }
 

@@ -209,9 +209,11 @@ __global__ __launch_bounds__(NW * 64) void flash_f32_kernel(FlashArgs a) {
 }
 
 // Combine the key-split partials:  out[b][q][h*DH+d] = sum_s w_s O_s[d][q] / sum_s w_s l_s,
-// w_s = 2^(m_s - max_s m_s).  One workgroup per (32 queries, b*h, 16 d-rows) so that even B=1
-// spreads over >= 128 workgroups; the result tile is transposed through LDS so both the partial
-// reads (q-contiguous) and the output writes (d-contiguous) are coalesced.
+// w_s = 2^(m_s - max_s m_s).  The partials are tens of MB and every output needs one value from each of
+// the S splits, so the kernel is built for bytes in flight: one workgroup per (32 queries, b*h, 16 d-rows)
+// (>= 128 workgroups at B = 1), each thread streams 16-byte rows of 4 queries for one d over half of the
+// splits, 8 loads deep; halves are reduced and the tile transposed through LDS so the output rows
+// (d-contiguous) are written coalesced.
 constexpr int kMergeDG = 16;
 
 template <int DH>
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wsm = smem;                               // [nsplit][32]
     float* dsm = wsm + a.nsplit * 32;                // [8][32]
-    float* tile = dsm + 8 * 32;                      // [kMergeDG][33]
+    float* part = dsm + 8 * 32;                      // [2 halves][kMergeDG][32]
     const int bh = blockIdx.y;
     const int b = bh / a.H;
     const int h = bh - b * a.H;
@@ -245,37 +247,170 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(FlashArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) den += dsm[i * 32 + tq];
     const float inv = 1.f / den;
-    const float* o0 = a.o_part + (pb * DH + dg0 + td) * (int64_t)Lq_pad + q;
+
+    // thread -> (4 queries, one d, one half of the splits)
+    const int q4 = threadIdx.x & 7;
+    const int dd = (threadIdx.x >> 3) & 15;
+    const int half = threadIdx.x >> 7;
+    const int s_begin = half ? (a.nsplit + 1) / 2 : 0;
+    const int s_end = half ? a.nsplit : (a.nsplit + 1) / 2;
     const int64_t sstride = (int64_t)DH * Lq_pad;
-    float acc0 = 0.f, acc1 = 0.f;
-    int s = 0;
-    for (; s + 4 <= a.nsplit; s += 4) {
-        float x0[4], x1[4];
+    const float* o0 = a.o_part + (pb * DH + dg0 + dd) * (int64_t)Lq_pad + q0 + q4 * 4;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    int s = s_begin;
+    for (; s + 8 <= s_end; s += 8) {
+        f32x4 x[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            x0[u] = o0[(s + u) * sstride];
-            x1[u] = o0[(s + u) * sstride + 8 * (int64_t)Lq_pad];
-        }
+        for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const f32x4*>(o0 + (s + u) * sstride);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float w = wsm[(s + u) * 32 + tq];
-            acc0 += w * x0[u];
-            acc1 += w * x1[u];
-        }
+        for (int u = 0; u < 8; ++u) acc += x[u] * *reinterpret_cast<const f32x4*>(&wsm[(s + u) * 32 + q4 * 4]);
     }
-    for (; s < a.nsplit; ++s) {
-        const float w = wsm[s * 32 + tq];
-        acc0 += w * o0[s * sstride];
-        acc1 += w * o0[s * sstride + 8 * (int64_t)Lq_pad];
-    }
-    tile[td * 33 + tq] = acc0 * inv;
-    tile[(td + 8) * 33 + tq] = acc1 * inv;
+    for (; s < s_end; ++s)
+        acc += *reinterpret_cast<const f32x4*>(o0 + s * sstride) * *reinterpret_cast<const f32x4*>(&wsm[s * 32 + q4 * 4]);
+    *reinterpret_cast<f32x4*>(&part[(half * kMergeDG + dd) * 32 + q4 * 4]) = acc;
     __syncthreads();
     for (int idx = threadIdx.x; idx < 32 * kMergeDG; idx += 256) {
         const int qq = idx / kMergeDG;
         const int d = idx - qq * kMergeDG;
-        if (q0 + qq < a.Lq)
-            a.out[(int64_t)b * a.out_batch + (int64_t)(q0 + qq) * a.out_row + h * DH + dg0 + d] = tile[d * 33 + qq];
+        if (q0 + qq < a.Lq) {
+            float dn = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dn += dsm[i * 32 + qq];
+            a.out[(int64_t)b * a.out_batch + (int64_t)(q0 + qq) * a.out_row + h * DH + dg0 + d] =
+                (part[d * 32 + qq] + part[(kMergeDG + d) * 32 + qq]) / dn;
+        }
+    }
+    (void)inv;
+}
+
+// Self-attention among the Q queries (transformer_parq.py:372-376) in ONE launch: a workgroup owns
+// 32 queries of one (scene, head); its 8 waves take disjoint key slices (fragments straight from
+// the fused in-projection output in global/L2 — 256 keys need no LDS staging), run the same
+// fp32-MFMA online softmax as above and combine their (m, l, O^T) through LDS.
+template <int DH>
+__global__ __launch_bounds__(512) void self_attn_kernel(const float* __restrict__ qkv, int64_t row_stride, int H, int L,
+                                                        float* __restrict__ out, int64_t out_row) {
+    constexpr int NW = 8;
+    constexpr int NDT = DH / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Os = smem;                         // [NW][DH][33]
+    float* Ms = Os + NW * DH * 33;            // [NW][32]
+    float* Ls = Ms + NW * 32;                 // [NW][32]
+    const int bh = blockIdx.y;
+    const int b = bh / H, h = bh - b * H;
+    const int C = H * DH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int q0 = blockIdx.x * 32;
+    const int q = q0 + li;
+    const float* base = qkv + (int64_t)b * L * row_stride + h * DH;     // q at +0, k at +C, v at +2C
+
+    float qf[DH / 2];
+    {
+        const float scale = 1.4426950408889634f / sqrtf((float)DH);
+        const float* qp = base + (int64_t)(q < L ? q : 0) * row_stride + kh * (DH / 2);
+#pragma unroll
+        for (int c = 0; c < DH / 8; ++c) {
+            f32x4 t4 = *reinterpret_cast<const f32x4*>(qp + c * 4);
+            if (q >= L) t4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qf[c * 4 + e] = t4[e] * scale;
+        }
+    }
+    const int per = ((((L + NW - 1) / NW) + 31) / 32) * 32;              // keys per wave, multiple of 32
+    const int k_begin = wave * per;
+    const int k_end = (k_begin + per < L) ? k_begin + per : L;
+
+    f32x16 o[NDT];
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int kb = k_begin; kb < k_end; kb += 32) {
+        // all loads of this 32-key block are issued up front (operands are L2-resident, the block is tiny:
+        // it is the load latency, not bandwidth, that sets this kernel's time)
+        const int key = kb + li;
+        const float* kr = base + C + (int64_t)(key < L ? key : 0) * row_stride + kh * (DH / 2);
+        f32x4 kf[DH / 8];
+#pragma unroll
+        for (int u = 0; u < DH / 8; ++u) kf[u] = *reinterpret_cast<const f32x4*>(kr + u * 4);
+        float vv[16][NDT];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int vk = kb + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const float* vr = base + 2 * C + (int64_t)(vk < L ? vk : 0) * row_stride + li;
+#pragma unroll
+            for (int d = 0; d < NDT; ++d) vv[r][d] = vr[d * 32];
+        }
+        if (key >= L) {
+#pragma unroll
+            for (int u = 0; u < DH / 8; ++u) kf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < DH / 8; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[u][e], qf[u * 4 + e], sacc, 0, 0, 0);
+        if (kb + 32 > L) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kb + mfma32_row(r, lane) >= L) sacc[r] = -INFINITY;
+        }
+        float mx = sacc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sacc[r] = __builtin_amdgcn_exp2f(sacc[r] - m_new);
+            rs += sacc[r];
+        }
+        rs += __shfl_xor(rs, 32);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < NDT; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int vk = kb + (r & 3) + 8 * (r >> 2) + 4 * kh;
+#pragma unroll
+            for (int d = 0; d < NDT; ++d)
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vk < L ? vv[r][d] : 0.f, sacc[r], o[d], 0, 0, 0);
+        }
+    }
+    // ---- combine the 8 key slices
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Os[(wave * DH + d * 32 + mfma32_row(r, lane)) * 33 + li] = o[d][r];
+    if (kh == 0) {
+        Ms[wave * 32 + li] = m_run;
+        Ls[wave * 32 + li] = l_run;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 32 * DH; idx += 512) {
+        const int qq = idx / DH;
+        const int d = idx - qq * DH;
+        float mmax = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) mmax = fmaxf(mmax, Ms[w * 32 + qq]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float wt = __builtin_amdgcn_exp2f(Ms[w * 32 + qq] - mmax);
+            num += wt * Os[(w * DH + d) * 33 + qq];
+            den += wt * Ls[w * 32 + qq];
+        }
+        if (q0 + qq < L) out[((int64_t)b * L + q0 + qq) * out_row + h * DH + d] = num / den;
     }
 }
 
@@ -309,7 +444,7 @@ hipError_t launch_dh(const FlashArgs& a, int nw, hipStream_t s) {
 
 template <int DH>
 hipError_t merge_dh(const FlashArgs& a, hipStream_t s) {
-    const size_t lds = ((size_t)a.nsplit * 32 + 8 * 32 + (size_t)kMergeDG * 33) * sizeof(float);
+    const size_t lds = ((size_t)a.nsplit * 32 + 8 * 32 + (size_t)2 * kMergeDG * 32) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_merge_kernel<DH>),
@@ -323,6 +458,30 @@ hipError_t merge_dh(const FlashArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+template <int DH>
+static hipError_t launch_self_dh(const float* qkv, int64_t row_stride, int B, int H, int L, float* out, int64_t out_row,
+                                 hipStream_t s) {
+    const size_t lds = ((size_t)8 * DH * 33 + 2 * 8 * 32) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_kernel<DH>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((self_attn_kernel<DH>), dim3(ceil_div(L, 32), B * H), dim3(512), lds, s, qkv, row_stride, H, L, out,
+                       out_row);
+    return hipGetLastError();
+}
+
+// qkv: (B, L, row_stride) with q | k | v at column offsets 0, H*dh, 2*H*dh.  dh in {32, 64}.
+hipError_t launch_self_attn(const float* qkv, int64_t row_stride, int B, int H, int L, int dh, float* out,
+                            int64_t out_row, hipStream_t s) {
+    if (dh == 64) return launch_self_dh<64>(qkv, row_stride, B, H, L, out, out_row, s);
+    if (dh == 32) return launch_self_dh<32>(qkv, row_stride, B, H, L, out, out_row, s);
+    return hipErrorInvalidValue;
+}
 
 int flash_key_tile(int dh) { return dh <= 64 ? 64 : 32; }
 int flash_lq_pad(int Lq) { return (Lq + 31) & ~31; }

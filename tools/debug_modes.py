@@ -28,8 +28,8 @@ for mode in ("fp32", "split"):
     torch.cuda.synchronize()
     Cn = 256
     g = lambda n: dec.intermediate(n).view(B, Q, Cn).cpu().numpy()
-    print(mode, "tgt %.2e x1 %.2e attn(cross, pre out-proj) |max| %.3e x2 %.2e x3 %.2e | logits %.2e center %.2e rot %.2e  range_flag=%s"
-          % (err(g("tgt"), i64["tgt"]), err(g("x1"), i64["x1"]), float(np.abs(g("attn")).max()), err(g("x2"), i64["x2"]),
-             err(g("x3"), i64["x"]), err(out["pred_logits"].cpu(), o64["pred_logits"]),
+    print(mode, "tgt %.2e pos %.2e | logits %.2e center %.2e rot %.2e size(rel) %.2e  range_flag=%s"
+          % (err(g("tgt"), i64["tgt"]), err(g("pos_feat"), i64["pos"]), err(out["pred_logits"].cpu(), o64["pred_logits"]),
              err(out["center_unnormalized"].cpu(), o64["center_unnormalized"]), err(out["ortho6d"].cpu(), o64["ortho6d"]),
+             float((np.abs(out["size_unnormalized"].cpu().numpy() - o64["size_unnormalized"].numpy()) / np.maximum(1, o64["size_unnormalized"].abs().numpy())).max()),
              dec.fp16_range_exceeded()))

@@ -33,7 +33,7 @@ def err(a, b):
 print("stage            mine-vs-fp64   oracle32-vs-fp64   mine-vs-oracle32")
 T = dec.intermediate("T_camera_local_f64").view(torch.float64).view(B, -1, 12).cpu().numpy()
 print("T_cl        %12.3e %12.3e %12.3e" % (err(T, od64.T_cl), err(od32.T_cl, od64.T_cl), err(T, od32.T_cl)))
-for nm, key in (("tgt", "tgt"), ("pos_feat", "pos"), ("x3", "x")):
+for nm, key in (("tgt", "tgt"), ("pos_feat", "pos")):
     m = dec.intermediate(nm).view(B, Q, Cn).cpu().numpy()
     print("%-10s  %12.3e %12.3e %12.3e" % (nm, err(m, i64[key]), err(i32[key], i64[key]), err(m, i32[key])))
     if nm == "tgt":
