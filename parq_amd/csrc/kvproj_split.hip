@@ -43,9 +43,24 @@ __global__ __launch_bounds__(kThreads) void kvproj_split_kernel(KvProjArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
-    const int b = blockIdx.z;
-    const int m0 = blockIdx.y * kBM;               // first token of the tile within scene b
-    const int n0 = blockIdx.x * kBN;               // first output column
+    // Tile mapping: workgroup id w runs on XCD w % 8 (observed dispatch rule; used for speed only).  The
+    // nct column tiles that share one 128-token A tile get ids that are equal mod 8 and at most 8*nct apart,
+    // so the A tile is fetched from HBM once and re-read from that XCD's L2.
+    const int nct = 2 * a.C / kBN;                 // column tiles
+    const int nrt = (a.N + kBM - 1) / kBM;         // row tiles per scene
+    const int b = blockIdx.y;
+    int rtile, ctile;
+    {
+        const int w = blockIdx.x;
+        const int per_group = 8 * nct;             // 8 row tiles x nct column tiles
+        const int grp = w / per_group;
+        const int r = w - grp * per_group;
+        rtile = grp * 8 + (r & 7);
+        ctile = r >> 3;
+    }
+    if (rtile >= nrt) return;                      // padding of the last group (uniform per workgroup)
+    const int m0 = rtile * kBM;                    // first token of the tile within scene b
+    const int n0 = ctile * kBN;                    // first output column
     const int C = a.C;
     const int nk = C / kBK;
     const int headcol = (n0 >> 6) + wc;            // head index in [K heads | V heads]
@@ -170,16 +185,17 @@ __global__ __launch_bounds__(kThreads) void kvproj_split_kernel(KvProjArgs a) {
         }
     }
 
-    // ---- epilogue: bias, split, 16-byte stores into the cache blocks
+    // ---- epilogue: bias, split, then through LDS so that every global store instruction writes 1 KB of
+    // contiguous cache image (a wave owns, per 32-token block, the contiguous 8 KB [x_hi | x_lo] region of
+    // its head: x = K or V).  The staging LDS is free after the last k-step (barrier above).
     const int nblk = (a.N + 31) / 32;
     const int h = isK ? headcol : headcol - a.H;
     const float* bias = a.bias + headcol * 64;
     bool ovf = false;
+    _Float16* wl = lds + wave * (2 * 4096);                          // 2 blocks x 8 KB per wave = 8192 halfs
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        const int blk = (m0 + wr * 64 + rt * 32) >> 5;
-        if (blk >= nblk) continue;                                   // wave-uniform
-        _Float16* out = a.cache + (((int64_t)b * a.H + h) * nblk + blk) * kBlkHalfs;
+    for (int rt2 = 0; rt2 < 2; ++rt2) {
+        _Float16* out = wl + rt2 * 4096;                             // [hi 2048 halfs | lo 2048 halfs]
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
@@ -189,12 +205,12 @@ __global__ __launch_bounds__(kThreads) void kvproj_split_kernel(KvProjArgs a) {
                     // lane = key (li), registers 8m..8m+7 = d = 32ct + 16m + 4kh + (e&3) + 8(e>>2): chunk s = 2ct + m
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        x[e] = acc[rt][ct][8 * m + e] + bias[32 * ct + 16 * m + 4 * kh + (e & 3) + 8 * (e >> 2)];
+                        x[e] = acc[rt2][ct][8 * m + e] + bias[32 * ct + 16 * m + 4 * kh + (e & 3) + 8 * (e >> 2)];
                 } else {
                     // lane = d (32ct + li), registers 8m..8m+7 = keys 16m + 4kh + (e&3) + 8(e>>2): chunk (m, kh)
                     const float bv = bias[32 * ct + li];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) x[e] = acc[rt][ct][8 * m + e] + bv;
+                    for (int e = 0; e < 8; ++e) x[e] = acc[rt2][ct][8 * m + e] + bv;
                 }
                 half8 hi, lo;
                 split8(x, hi, lo);
@@ -208,11 +224,24 @@ __global__ __launch_bounds__(kThreads) void kvproj_split_kernel(KvProjArgs a) {
                 } else {
                     const int d = 32 * ct + li;
                     const int pos = (2 * m + kh) ^ ((d >> 2) & 3);
-                    *reinterpret_cast<half8*>(out + 4096 + d * 32 + pos * 8) = hi;
-                    *reinterpret_cast<half8*>(out + 6144 + d * 32 + pos * 8) = lo;
+                    *reinterpret_cast<half8*>(out + d * 32 + pos * 8) = hi;
+                    *reinterpret_cast<half8*>(out + 2048 + d * 32 + pos * 8) = lo;
                 }
             }
         }
+    }
+    // same-wave LDS round trip: DS operations of one wave complete in order
+    __builtin_amdgcn_s_waitcnt(0xc07f);                              // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int rt2 = 0; rt2 < 2; ++rt2) {
+        const int blk = (m0 + wr * 64 + rt2 * 32) >> 5;
+        if (blk >= nblk) continue;                                   // wave-uniform
+        _Float16* gout = a.cache + (((int64_t)b * a.H + h) * nblk + blk) * kBlkHalfs + (isK ? 0 : 4096);
+        const uint4* src = reinterpret_cast<const uint4*>(wl + rt2 * 4096);
+        uint4* dst = reinterpret_cast<uint4*>(gout);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i * 64 + lane] = src[i * 64 + lane];
     }
     if (ovf) atomicOr(a.overflow, 1);
 }
@@ -250,8 +279,9 @@ hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void*
     KvProjArgs a;
     a.X = tokens; a.Whi = reinterpret_cast<const _Float16*>(Whi); a.Wlo = reinterpret_cast<const _Float16*>(Wlo);
     a.bias = bias; a.cache = reinterpret_cast<_Float16*>(cache); a.overflow = overflow; a.N = N; a.C = C; a.H = H;
-    dim3 grid(2 * C / kBN, ceil_div(N, kBM), B);
-    if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
+    const int nct = 2 * C / kBN, nrt = ceil_div(N, kBM);
+    dim3 grid(ceil_div(nrt, 8) * 8 * nct, B, 1);
+    if (grid.y > 65535) return hipErrorInvalidValue;
     hipLaunchKernelGGL(kvproj_split_kernel, grid, dim3(kThreads), ldsb, s, a);
     return hipGetLastError();
 }
