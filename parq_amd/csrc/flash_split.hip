@@ -177,36 +177,46 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
             const int nb = (nblk - t * kStageBlks) < kStageBlks ? (nblk - t * kStageBlks) : kStageBlks;   // wave-uniform
             const _Float16* S0 = smem_h + buf * kStageBlks * kBlkHalfs;
             const int ksw = (li >> 1) & 7;
-            // ---- S^T = K Q^T for every block of the stage (3-term split product), scores kept absolute
-            f32x16 sacc[kStageBlks];
-            float mx = -INFINITY;
+            static_assert(kStageBlks == 2, "the software pipeline below is written for two blocks per stage");
+            // Software pipeline over the two 32-key blocks of the stage, written so that every VALU section
+            // (softmax of one block) sits between the MFMAs of the other block and can issue in their shadow:
+            //     QK(b0) | QK(b1) + softmax(b0) | PV(b0) + softmax(b1) | PV(b1)
+            f32x16 sacc[2];
+            half8 phi[2][2], plo[2][2];
+            half8 kf[2][8];          // K fragments of both blocks: [kb][2*s + {hi,lo}]
+            half8 vf[2][8];          // V fragments: [kb][4*m + 2*dt + {hi,lo}]
+            float rs = 0.f;
+
+            // LDS fragment reads are issued a full MFMA group ahead of their use (ds_read latency is
+            // otherwise exposed in front of every 3-MFMA step: ~30 % of the wave's time)
+            auto load_k = [&](int kb) {
+                const _Float16* B0 = S0 + kb * kBlkHalfs;
 #pragma unroll
-            for (int kb = 0; kb < kStageBlks; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-            // consecutive MFMAs alternate between the blocks' accumulators (no back-to-back dependent issue)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int pos = (4 * kh + s) ^ ksw;
-                half8 khi[kStageBlks], klo[kStageBlks];
-#pragma unroll
-                for (int kb = 0; kb < kStageBlks; ++kb) {
-                    const _Float16* B0 = S0 + kb * kBlkHalfs;
-                    khi[kb] = *reinterpret_cast<const half8*>(B0 + li * 64 + pos * 8);
-                    klo[kb] = *reinterpret_cast<const half8*>(B0 + 2048 + li * 64 + pos * 8);
+                for (int s = 0; s < 4; ++s) {
+                    const int pos = (4 * kh + s) ^ ksw;
+                    kf[kb][2 * s] = *reinterpret_cast<const half8*>(B0 + li * 64 + pos * 8);
+                    kf[kb][2 * s + 1] = *reinterpret_cast<const half8*>(B0 + 2048 + li * 64 + pos * 8);
                 }
+            };
+            auto load_v = [&](int kb) {
+                const _Float16* B0 = S0 + kb * kBlkHalfs;
 #pragma unroll
-                for (int kb = 0; kb < kStageBlks; ++kb)
-                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi[kb], qhi[s], sacc[kb], 0, 0, 0);
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int kb = 0; kb < kStageBlks; ++kb)
-                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi[kb], qlo[s], sacc[kb], 0, 0, 0);
-#pragma unroll
-                for (int kb = 0; kb < kStageBlks; ++kb)
-                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(klo[kb], qhi[s], sacc[kb], 0, 0, 0);
-            }
-#pragma unroll
-            for (int kb = 0; kb < kStageBlks; ++kb) {
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const int d = dt * 32 + li;
+                        const int pos = (2 * m + kh) ^ ((d >> 2) & 3);
+                        vf[kb][4 * m + 2 * dt] = *reinterpret_cast<const half8*>(B0 + 4096 + d * 32 + pos * 8);
+                        vf[kb][4 * m + 2 * dt + 1] = *reinterpret_cast<const half8*>(B0 + 6144 + d * 32 + pos * 8);
+                    }
+            };
+            auto qk_step = [&](int kb, int s) {
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][2 * s], qhi[s], sacc[kb], 0, 0, 0);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][2 * s], qlo[s], sacc[kb], 0, 0, 0);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][2 * s + 1], qhi[s], sacc[kb], 0, 0, 0);
+            };
+            // block maximum (scores absolute), tail masking included
+            auto block_mx = [&](int kb) -> float {
                 const int blk = t * kStageBlks + kb;
                 if (kb >= nb) {                                           // block past the end of the cache (zero-filled)
 #pragma unroll
@@ -216,63 +226,83 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
                     for (int r = 0; r < 16; ++r)
                         if (blk * 32 + mfma32_row(r, lane) >= a.Lk) sacc[kb][r] = -INFINITY;
                 }
+                float mx = sacc[kb][0];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            // ---- deferred running max: the reference m_run only moves when a score exceeds it by more
-            // than kDeferLog2 (probabilities stay <= 2^kDeferLog2, well inside fp16/fp32 range); the
-            // rescale of (l, O) is then a rare, wave-uniform branch.  m_run = -inf forces it on the first stage.
-            const bool need = mx > m_run + a.defer_log2;
-            if (__any(need)) {
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+                return fmaxf(mx, __shfl_xor(mx, 32));
+            };
+            // deferred running max: move the reference only past the margin; (l, O) rescale is rare and
+            // wave-uniform.  Must not be called while probabilities of the old reference await their PV.
+            auto rescale = [&](float mx) {
+                const bool need = mx > m_run + a.defer_log2;
                 const float m_new = need ? mx : m_run;
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // 1 for unchanged lanes, 0 at the start
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // 1 for unchanged lanes, 0 at the start
                 l_run *= alpha;
+                rs *= alpha;                 // row sums of this stage already taken against the old reference
                 m_run = m_new;
 #pragma unroll
                 for (int d = 0; d < 2; ++d)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-            }
-            float rs = 0.f;
+            };
+            // probabilities of 8 accumulator registers (one MFMA k-step of PV) of block kb, split hi/lo
+            auto softmax_half = [&](int kb, int m) {
+                float p[8];
 #pragma unroll
-            for (int kb = 0; kb < kStageBlks; ++kb) {
-                if (kb < nb) {
-                    const _Float16* B0 = S0 + kb * kBlkHalfs;
-                    half8 phi[2], plo[2];
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        float p[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            p[e] = __builtin_amdgcn_exp2f(sacc[kb][8 * m + e] - m_run);
-                            rs += p[e];
-                        }
-                        split8(p, phi[m], plo[m]);
-                    }
-                    // ---- O^T += V^T P^T  (3-term split product; the two d-tiles' accumulators alternate)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        half8 vhi[2], vlo[2];
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt) {
-                            const int d = dt * 32 + li;
-                            const int pos = (2 * m + kh) ^ ((d >> 2) & 3);
-                            vhi[dt] = *reinterpret_cast<const half8*>(B0 + 4096 + d * 32 + pos * 8);
-                            vlo[dt] = *reinterpret_cast<const half8*>(B0 + 6144 + d * 32 + pos * 8);
-                        }
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt)
-                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[dt], phi[m], o[dt], 0, 0, 0);
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt)
-                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo[dt], phi[m], o[dt], 0, 0, 0);
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt)
-                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[dt], plo[m], o[dt], 0, 0, 0);
-                    }
+                for (int e = 0; e < 8; ++e) {
+                    p[e] = __builtin_amdgcn_exp2f(sacc[kb][8 * m + e] - m_run);
+                    rs += p[e];
                 }
+                split8(p, phi[kb][m], plo[kb][m]);
+            };
+            auto pv_step = [&](int kb, int m) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kb][4 * m + 2 * dt], phi[kb][m], o[dt], 0, 0, 0);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kb][4 * m + 2 * dt + 1], phi[kb][m], o[dt], 0, 0, 0);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kb][4 * m + 2 * dt], plo[kb][m], o[dt], 0, 0, 0);
+            };
+
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+            load_k(0);
+            load_k(1);
+            // ---- QK(b0)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qk_step(0, s);
+            load_v(0);
+            {
+                const float mx0 = block_mx(0);
+                if (__any(mx0 > m_run + a.defer_log2)) rescale(mx0);
             }
+            // ---- QK(b1) with softmax(b0) in its shadow
+            qk_step(1, 0);
+            qk_step(1, 1);
+            softmax_half(0, 0);
+            qk_step(1, 2);
+            qk_step(1, 3);
+            softmax_half(0, 1);
+            load_v(1);
+            const float mx1 = block_mx(1);
+            if (!__any(mx1 > m_run + a.defer_log2)) {
+                // ---- common case: PV(b0) with softmax(b1) in its shadow
+                pv_step(0, 0);
+                softmax_half(1, 0);
+                pv_step(0, 1);
+                softmax_half(1, 1);
+            } else {
+                pv_step(0, 0);
+                pv_step(0, 1);
+                rescale(mx1);
+                softmax_half(1, 0);
+                softmax_half(1, 1);
+            }
+            // ---- PV(b1)  (a block past the end has p = 0 and zero-filled V: contributes nothing)
+            pv_step(1, 0);
+            pv_step(1, 1);
             rs += __shfl_xor(rs, 32);
             l_run += rs;
         }
