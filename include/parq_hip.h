@@ -138,7 +138,7 @@ int parq_workspace_lookup(parq_handle h, int32_t B, int32_t V, int32_t hh, int32
  * accumulated milliseconds and launch count of group `which` (see PARQ_PROF_*). */
 enum {
     PARQ_PROF_KV_PROJ = 0, PARQ_PROF_PROJECT_SAMPLE = 1, PARQ_PROF_CROSS_ATTN = 2,
-    PARQ_PROF_SELF_ATTN = 3, PARQ_PROF_LINEAR = 4, PARQ_PROF_OTHER = 5, PARQ_PROF_COUNT = 6
+    PARQ_PROF_SELF_ATTN = 3, PARQ_PROF_LINEAR = 4, PARQ_PROF_OTHER = 5, PARQ_PROF_MERGE = 6, PARQ_PROF_COUNT = 7
 };
 int parq_profile_enable(parq_handle h, int32_t on);
 int parq_profile_read(parq_handle h, int32_t which, double *total_ms, int64_t *launches);

@@ -15,8 +15,8 @@ import torch  # noqa: F401  (loads the HIP runtime before our library)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_C", "libparq_hip.so")
 
-PROF_KV_PROJ, PROF_PROJECT_SAMPLE, PROF_CROSS_ATTN, PROF_SELF_ATTN, PROF_LINEAR, PROF_OTHER = range(6)
-PROF_NAMES = ["kv_proj", "project_sample", "cross_attn", "self_attn", "linear", "other"]
+PROF_KV_PROJ, PROF_PROJECT_SAMPLE, PROF_CROSS_ATTN, PROF_SELF_ATTN, PROF_LINEAR, PROF_OTHER, PROF_MERGE = range(7)
+PROF_NAMES = ["kv_proj", "project_sample", "cross_attn", "self_attn", "linear", "other", "cross_attn_merge"]
 
 
 class ParqConfig(C.Structure):

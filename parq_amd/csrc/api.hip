@@ -306,8 +306,8 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
             fa.v = kv + (int64_t)H * N * dh; fa.v_batch = 2 * N * C; fa.v_head = N * dh; fa.v_row = dh;
             HIPCHK(launch_flash(fa, s));
         }
-        HIPCHK(launch_flash_merge(fa, s));
     }
+    { Prof p(c, s, PARQ_PROF_MERGE); HIPCHK(launch_flash_merge(fa, s)); }
     {
         Prof p(c, s, PARQ_PROF_LINEAR);
         // xb = norm1(xa) + cross_attn @ Wo   (residual recomputed from the published statistics)

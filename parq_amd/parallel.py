@@ -1,0 +1,73 @@
+"""Scene-sharded data parallelism for the decoder path.
+
+Scenes are independent (the only cross-query coupling, GroupNorm, is within a scene), so N GPUs
+run N processes that each own a contiguous shard of the scenes; inference needs NO data-path
+collective.  The helpers here are the whole multi-GPU surface: rendezvous from the torchrun
+environment ("nccl" = RCCL on ROCm, "gloo" on CPU-only hosts), shard arithmetic, a barrier
+and the max-over-ranks reduction the benchmark contract asks for, plus an all-gather of
+per-scene outputs for drivers that want the full batch on every rank.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun environment (1 process -> (0, 0, 1))."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend: str | None = None, device: torch.device | None = None):
+    """Join the process group described by the environment; returns (rank, local_rank, world)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {}
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, local_rank, world
+
+
+def shard_range(num_scenes: int, rank: int, world: int):
+    """Contiguous, balanced shard [lo, hi) of `num_scenes` scenes owned by `rank`
+    (the first num_scenes % world ranks get one extra scene)."""
+    assert 0 <= rank < world
+    base, extra = divmod(num_scenes, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    """MAX all-reduce of a host scalar (the benchmark's wall time is the slowest rank's)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def all_gather_scenes(x: torch.Tensor, num_scenes: int) -> torch.Tensor:
+    """Concatenate the per-rank scene shards of `x` (leading dim = local scenes) in rank order.
+    Shards may be ragged (shard_range), so they are padded to the largest shard for the collective."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return x
+    world = dist.get_world_size()
+    sizes = [shard_range(num_scenes, r, world) for r in range(world)]
+    biggest = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((biggest,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    pad[: x.shape[0]] = x
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad)
+    return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(out, sizes)], dim=0)

@@ -1,0 +1,85 @@
+"""CPU tier: the N>1 path (scene sharding, barrier, max-over-ranks, ragged all-gather) with two real
+processes over gloo on 127.0.0.1.  The oracle stands in for the compute (the HIP path needs a GPU): rank r
+runs its shard of scenes, the shards are gathered and must equal the single-process run of the full batch —
+i.e. sharding by scene is exact and needs no data-path collective."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from parq_amd import parallel, synth
+from oracle import parq_oracle as O
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _case():
+    cfg = synth.decoder_cfg(dim=64, queries=16, heads=1, ffn=64, layers=2)
+    W = synth.make_decoder_weights(cfg, 3, damped=True)
+    sc = synth.make_scene(4, B=3, V=2, h=8, w=10, C=64, smooth=True)      # 3 scenes over 2 ranks: ragged shards
+    return cfg, W, sc
+
+
+def _run(cfg, W, sc, lo, hi):
+    od = O.OracleDecoder(cfg, W, synth.SCANNET_MEAN_SIZES)
+    with torch.no_grad():
+        outs = od.forward(*(sc[k][lo:hi] for k in ("tokens", "camera", "T_camera_pseudoCam", "T_world_pseudoCam",
+                                                    "T_world_local")))
+    return outs[-1]["center_unnormalized"], outs[-1]["pred_logits"]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    r, lr, w = parallel.init(backend="gloo")
+    assert (r, w) == (rank, world)
+    cfg, W, sc = _case()
+    lo, hi = parallel.shard_range(3, r, w)
+    ctr, logits = _run(cfg, W, sc, lo, hi)
+    parallel.barrier()
+    full_ctr = parallel.all_gather_scenes(ctr, 3)
+    full_logits = parallel.all_gather_scenes(logits, 3)
+    slowest = parallel.max_over_ranks(1.0 + rank)            # rank 1 reports 2.0
+    q.put((rank, (lo, hi), full_ctr.numpy(), full_logits.numpy(), slowest))
+    parallel.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_shard_range_is_a_balanced_partition():
+    for n in (1, 3, 8, 32, 33):
+        for world in (1, 2, 4, 8):
+            rs = [parallel.shard_range(n, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+            sizes = [hi - lo for lo, hi in rs]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_scene_sharding_matches_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    cfg, W, sc = _case()
+    want_ctr, want_logits = _run(cfg, W, sc, 0, 3)
+    assert sorted(r[1] for r in res) == [(0, 2), (2, 3)]
+    for rank, _, ctr, logits, slowest in res:
+        assert ctr.shape == (3, 16, 3)
+        assert np.abs(ctr - want_ctr.numpy()).max() < 1e-5, rank         # scenes are independent: exact up to fp32 batching
+        assert np.abs(logits - want_logits.numpy()).max() < 1e-5, rank
+        assert slowest == 2.0
