@@ -143,6 +143,21 @@ enum {
 int parq_profile_enable(parq_handle h, int32_t on);
 int parq_profile_read(parq_handle h, int32_t which, double *total_ms, int64_t *launches);
 
+/* ---- AddRayPE.forward + tokenisation (model/ray_positional_encoding.py:61-139,
+ *      model/parq_lightning.py:72-85), once per forward -------------------------------------
+ * tokens_out (B, V*h*w, C) channels-last = ray-point positional encoding of every pixel
+ *   encoder.2(relu(encoder.0(p))), p = inverse_sigmoid(box-normalised 3-D samples along the pixel ray)
+ * plus, when features_nchw (B, V, C, h, w) is given, the feature maps (the `+` and the einops
+ * rearrange of parq_lightning.py:75-85).  w1 (C, 3*num_samples), b1 (C), w2 (C, C), b2 (C) are
+ * AddRayPE.encoder.{0,2}.{weight,bias}; scale6_host = RAY_POINTS_SCALE (host pointer).
+ * Requires (3*num_samples) % 64 == 0 and C % 64 == 0 (shipped: 64 samples, C = 1024 or 256). */
+size_t parq_ray_pe_workspace_bytes(int32_t B, int32_t V, int32_t hh, int32_t ww, int32_t C, int32_t num_samples);
+int parq_ray_pe(const float *camera, const float *T_camera_pseudoCam, const float *T_world_pseudoCam,
+                const float *T_world_local, const float *w1, const float *b1, const float *w2, const float *b2,
+                const float *scale6_host, float min_depth, float max_depth, int32_t num_samples, int32_t B,
+                int32_t V, int32_t hh, int32_t ww, int32_t C, const float *features_nchw, float *tokens_out,
+                void *workspace, size_t workspace_bytes, parq_stream stream);
+
 /* ---- single kernels (parity tests, roofline measurements) --------------------------- */
 
 /* K4+K5: project (B,Q,3) normalised reference points into every view and bilinearly

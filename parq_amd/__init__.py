@@ -2,6 +2,7 @@
 
 Public surface mirrors the reference (ymingxie/PARQ):
     PARQDecoder  (model/parq_decoder.py:30)      forward on the HIP kernel chain
+    AddRayPE     (model/ray_positional_encoding.py:29)  ray-point PE (+ fused tokenisation)
     Pose, Camera (utils/wrappers.py:194,441)     tensor wrappers drivers pass in
 The compute lives in ``parq_amd/_C/libparq_hip.so`` (C ABI: include/parq_hip.h).
 """
@@ -13,4 +14,10 @@ def __getattr__(name):
     if name == "PARQDecoder":
         from .decoder import PARQDecoder
         return PARQDecoder
+    if name == "AddRayPE":
+        from .ray_pe import AddRayPE
+        return AddRayPE
+    if name == "PARQ":
+        from .module import PARQ
+        return PARQ
     raise AttributeError(name)

@@ -707,6 +707,46 @@ int parq_k_attention_split(const float* q, const float* k, const float* v, float
     return PARQ_OK;
 }
 
+// ------------------------------------------------------------------ AddRayPE + tokenisation
+static int64_t raype_align(int64_t x) { return (x + 63) / 64 * 64; }
+
+size_t parq_ray_pe_workspace_bytes(int32_t B, int32_t V, int32_t hh, int32_t ww, int32_t C, int32_t num_samples) {
+    if (B < 1 || V < 1 || hh < 1 || ww < 1 || C < 1 || num_samples < 1) return 0;
+    const int64_t M = (int64_t)B * V * hh * ww, K1 = 3 * (int64_t)num_samples;
+    // points [M][K1] | hidden [M][C] | W1 hi/lo (C*K1 halfs each) | W2 hi/lo (C*C halfs each)
+    const int64_t floats = raype_align(M * K1) + raype_align(M * C) + raype_align(C * K1) + raype_align((int64_t)C * C);
+    return (size_t)floats * sizeof(float);
+}
+
+int parq_ray_pe(const float* camera, const float* T_cp, const float* T_wp, const float* T_wl, const float* w1,
+                const float* b1, const float* w2, const float* b2, const float* scale6_host, float min_depth,
+                float max_depth, int32_t num_samples, int32_t B, int32_t V, int32_t hh, int32_t ww, int32_t C,
+                const float* features_nchw, float* tokens_out, void* workspace, size_t workspace_bytes, parq_stream stream) {
+    if (!camera || !T_cp || !T_wp || !T_wl || !w1 || !b1 || !w2 || !b2 || !scale6_host || !tokens_out || !workspace)
+        return fail(PARQ_ERR_ARG, "NULL argument");
+    if (B < 1 || V < 1 || hh < 1 || ww < 1 || num_samples < 1) return fail(PARQ_ERR_ARG, "bad dims");
+    if ((3 * num_samples) % 64 != 0 || C % 64 != 0) return fail(PARQ_ERR_ARG, "3*num_samples and C must be multiples of 64");
+    if (!(max_depth > min_depth && min_depth > 0.f)) return fail(PARQ_ERR_ARG, "need 0 < min_depth < max_depth");
+    if (workspace_bytes < parq_ray_pe_workspace_bytes(B, V, hh, ww, C, num_samples)) return fail(PARQ_ERR_WORKSPACE, "ray-PE workspace too small");
+    const int64_t M64 = (int64_t)B * V * hh * ww;
+    if (M64 > INT32_MAX) return fail(PARQ_ERR_ARG, "too many tokens");
+    const int M = (int)M64, K1 = 3 * num_samples;
+    hipStream_t s = (hipStream_t)stream;
+    float* wsp = (float*)workspace;
+    float* P = wsp;
+    float* Hd = P + raype_align((int64_t)M * K1);
+    float* W1s = Hd + raype_align((int64_t)M * C);
+    float* W2s = W1s + raype_align((int64_t)C * K1);
+    char* w1hi = (char*)W1s; char* w1lo = w1hi + (size_t)C * K1 * 2;
+    char* w2hi = (char*)W2s; char* w2lo = w2hi + (size_t)C * C * 2;
+    HIPCHK(launch_split_f32(w1, w1hi, w1lo, (int64_t)C * K1, s));
+    HIPCHK(launch_split_f32(w2, w2hi, w2lo, (int64_t)C * C, s));
+    HIPCHK(launch_raype_points(camera, T_cp, T_wp, T_wl, scale6_host, min_depth, max_depth, B, V, hh, ww, num_samples, P, s));
+    HIPCHK(launch_gemm_split(P, K1, w1hi, w1lo, b1, Hd, C, M, C, K1, 1, nullptr, 1, s));
+    HIPCHK(launch_gemm_split(Hd, C, w2hi, w2lo, b2, tokens_out, C, M, C, C, 0, features_nchw, hh * ww, s));
+    return PARQ_OK;
+}
+
 int parq_k_layernorm(const float* X, const float* gamma, const float* beta, float* Y, int32_t M, int32_t C, float eps,
                      parq_stream stream) {
     if (!X || !gamma || !beta || !Y || M < 1 || C < 1 || C > 1024) return fail(PARQ_ERR_ARG, "bad argument");

@@ -117,6 +117,13 @@ hipError_t launch_split_f32(const float* src, void* hi, void* lo, int64_t n, hip
 hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void* Wlo, const float* bias, int B, int N,
                                int C, int H, void* cache, int* overflow, hipStream_t s);
 
+// raype.hip: ray-point positional encoding + tokenisation
+hipError_t launch_raype_points(const float* cam, const float* T_cp, const float* T_wp, const float* T_wl,
+                               const float* scale6, float min_depth, float max_depth, int B, int V, int h, int w, int S,
+                               float* P, hipStream_t s);
+hipError_t launch_gemm_split(const float* X, int64_t ldx, const void* Whi, const void* Wlo, const float* bias, float* Y,
+                             int64_t ldy, int M, int N, int K, int relu, const float* feat, int hw, hipStream_t s);
+
 // ------------------------------------------------------------------ elementwise / gather kernels
 hipError_t launch_camera_local(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V,
                                float* T_cl, hipStream_t s);

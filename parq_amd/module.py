@@ -1,0 +1,63 @@
+"""PARQ: the reference Lightning module's interface (model/parq_lightning.py:28-145) over the HIP path.
+
+``forward(batch, batch_idx) -> (losses, outputs)`` reproduces model/parq_lightning.py:68-95 for the part
+that is in scope this round: ray positional encoding + tokenisation + decoder.  The 2-D backbone is not
+part of the decoder path (torchvision ResNet-FPN): pass any callable that adds
+``all_features`` (B,T,C,h,w) and ``camera_feature`` to the batch, or feed batches that already carry them.
+Lightning is used as the base class only when it is importable (it is not on the GPU image).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .decoder import PARQDecoder
+from .ray_pe import AddRayPE
+
+try:                                                    # pragma: no cover - absent on the target image
+    from pytorch_lightning import LightningModule as _Base
+except Exception:                                       # noqa: BLE001
+    _Base = nn.Module
+
+
+def _get(cfg, path):
+    for k in path.split("."):
+        cfg = cfg[k] if isinstance(cfg, dict) else getattr(cfg, k)
+    return cfg
+
+
+class PARQ(_Base):
+    def __init__(self, cfg, backbone2d=None):
+        super().__init__()
+        self.cfg = cfg
+        self.backbone2d = backbone2d
+        tk = _get(cfg, "MODEL.TOKENIZER")
+        self.add_ray_pe = AddRayPE(_get(tk, "OUT_CHANNELS"), _get(tk, "RAY_POINTS_SCALE"), _get(tk, "NUM_SAMPLES"),
+                                   _get(tk, "MIN_DEPTH"), _get(tk, "MAX_DEPTH"))
+        self.box3d_decoder = PARQDecoder(_get(cfg, "MODEL.DECODER"))
+        self.for_vis = _get(cfg, "MODEL.DECODER.FOR_VIS")
+
+    def forward(self, batch, batch_idx=0):
+        if self.backbone2d is not None:
+            batch = self.backbone2d(batch)
+        feats = batch["all_features"]
+        # encoding + `images_feat = features + encoding` + both einops rearranges, fused (parq_lightning.py:72-85)
+        input_tokens = self.add_ray_pe.tokens(feats, batch["camera_feature"], batch["T_camera_pseudoCam"],
+                                              batch["T_world_pseudoCam"], batch["T_world_local"])
+        outputs = self.box3d_decoder(input_tokens, batch["camera_feature"], batch["T_camera_pseudoCam"],
+                                     batch["T_world_pseudoCam"], batch["T_world_local"],
+                                     feat_hw=tuple(feats.shape[-2:]))
+        if "obbs_padded" in batch:
+            losses = self.box3d_decoder.loss(outputs, batch["obbs_padded"], batch["T_world_local"], batch["sym"])
+        else:
+            losses = {"total_loss": 0}
+        return losses, outputs
+
+    def validation_step(self, batch, batch_idx):
+        return self.forward(batch, batch_idx)
+
+    def test_step(self, batch, batch_idx=0):
+        return self.forward(batch, batch_idx)
+
+    def training_step(self, batch, batch_idx):
+        raise NotImplementedError("training (backward + DP all-reduce) is the next-tier row, SURVEY.md §8f-1")

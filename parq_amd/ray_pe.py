@@ -1,0 +1,74 @@
+"""AddRayPE: host-side mirror of model/ray_positional_encoding.py:29-139 on the HIP path.
+
+Same constructor arguments, same ``encoder.{0,2}`` state_dict keys, same ``forward`` signature
+and result (the encoding, shaped (B, T, C, H, W)) as the reference module.  The arithmetic runs in
+libparq_hip.so (``parq_ray_pe``); ``tokens()`` is the fused fast path that adds the feature maps
+and returns the channels-last token tensor the decoder consumes, skipping the NCHW round trip of
+model/parq_lightning.py:72-85.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib
+from .wrappers import raw
+
+
+class AddRayPE(nn.Module):
+    def __init__(self, dim_out: int, ray_points_scale=(-2, 2, -1.5, 0, 0.25, 4.25), num_samples: int = 64,
+                 min_depth: float = 0.25, max_depth: float = 5.25):
+        super().__init__()
+        self.dim_out = dim_out
+        self.ray_points_scale = [float(x) for x in ray_points_scale]
+        self.num_samples = num_samples
+        self.min_depth = float(min_depth)
+        self.max_depth = float(max_depth)
+        self.encoder = nn.Sequential(nn.Linear(3 * num_samples, dim_out), nn.ReLU(), nn.Linear(dim_out, dim_out))
+        self._ws = None
+
+    def _run(self, camera, T_cp, T_wp, T_wl, feat_hw, features):
+        cam, T_cp, T_wp, T_wl = (raw(x) for x in (camera, T_cp, T_wp, T_wl))
+        if not cam.is_cuda:
+            raise RuntimeError("parq_amd.AddRayPE runs on the GPU only (there is no CPU fallback)")
+        dev = cam.device
+        prep = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+        cam, T_cp, T_wp, T_wl = prep(cam), prep(T_cp), prep(T_wp), prep(T_wl)
+        B, V = cam.shape[:2]
+        if feat_hw is None:
+            wf, hf = cam[0, 0, :2].tolist()                 # the reference rounds the first camera's size too (:80-81)
+            feat_hw = (int(round(hf)), int(round(wf)))
+        h, w = feat_hw
+        Cd = self.dim_out
+        if features is not None:
+            features = prep(features)
+            assert features.shape == (B, V, Cd, h, w), tuple(features.shape)
+        lib = _lib.load()
+        nbytes = lib.parq_ray_pe_workspace_bytes(B, V, h, w, Cd, self.num_samples)
+        if self._ws is None or self._ws.numel() * 4 < nbytes or self._ws.device != dev:
+            self._ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=dev)
+        out = torch.empty(B, V * h * w, Cd, dtype=torch.float32, device=dev)
+        p = [prep(t.detach()) for t in (self.encoder[0].weight, self.encoder[0].bias, self.encoder[2].weight,
+                                        self.encoder[2].bias)]
+        _lib.check(lib.parq_ray_pe(_lib.ptr(cam), _lib.ptr(T_cp), _lib.ptr(T_wp), _lib.ptr(T_wl), _lib.ptr(p[0]),
+                                   _lib.ptr(p[1]), _lib.ptr(p[2]), _lib.ptr(p[3]), (C.c_float * 6)(*self.ray_points_scale),
+                                   self.min_depth, self.max_depth, self.num_samples, B, V, h, w, Cd, _lib.ptr(features),
+                                   _lib.ptr(out), _lib.ptr(self._ws), self._ws.numel() * 4, _lib.stream_ptr()),
+                   "parq_ray_pe")
+        return out, (B, V, h, w)
+
+    @torch.no_grad()
+    def forward(self, images_feat, camera=None, T_camera_pseudoCam=None, T_world_pseudoCam=None, T_world_local=None):
+        """The encoding (B, T, C, H, W), as the reference returns it (images_feat only supplies the shape)."""
+        hw = tuple(images_feat.shape[-2:])
+        enc, (B, V, h, w) = self._run(camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, hw, None)
+        return enc.view(B, V, h, w, self.dim_out).permute(0, 1, 4, 2, 3)
+
+    @torch.no_grad()
+    def tokens(self, images_feat, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local):
+        """features + encoding, tokenised channels-last (B, T*H*W, C) in one pass."""
+        hw = tuple(images_feat.shape[-2:])
+        out, _ = self._run(camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, hw, images_feat)
+        return out

@@ -186,3 +186,81 @@ def test_full_size_output_properties(cfg3):
             assert torch.allclose(outs[k + 1]["coord_pos"], c, atol=2e-6)
     ref0 = torch.sigmoid(dec.refpoint.weight) * (hi - lo) + lo
     assert torch.allclose(outs[0]["coord_pos"][0], ref0, atol=2e-6)
+
+
+def test_ray_pe_golden_and_fused_tokenisation():
+    """AddRayPE on the HIP path vs the golden captured from the reference (g5), and the fused
+    features+PE channels-last tokens vs the oracle's tokenize()."""
+    from parq_amd import AddRayPE
+    case, z = G.load("g5_raype")
+    Wp = synth.make_ray_pe_weights(case["dim"], case["seed"])
+    cam, T_cp, T_wp, T_wl = synth.make_geometry(case["sseed"], case["B"], case["V"], case["h"], case["w"])
+    pe = AddRayPE(case["dim"], case["ray_points_scale"], 64, 0.25, 5.25)
+    pe.load_state_dict({k: torch.from_numpy(v) for k, v in Wp.items()}, strict=True)
+    pe = pe.cuda().eval()
+    B, V, h, w, Cd = case["B"], case["V"], case["h"], case["w"], case["dim"]
+    feat = dev(synth.normal(9, "feat", (B, V, Cd, h, w)))
+    enc = pe(feat, dev(cam), dev(T_cp), dev(T_wp), dev(T_wl))
+    assert tuple(enc.shape) == (B, V, Cd, h, w)
+    assert rel_err(enc.cpu().numpy(), z["encoding"]) < 2e-5
+    tok = pe.tokens(feat, dev(cam), dev(T_cp), dev(T_wp), dev(T_wl))
+    want = O.tokenize(feat.cpu(), torch.from_numpy(z["encoding"]))
+    assert rel_err(tok.cpu().numpy(), want.numpy()) < 2e-5
+
+
+def test_ray_pe_vs_fp64_oracle_larger_grid():
+    from parq_amd import AddRayPE
+    B, V, h, w, Cd = 2, 3, 30, 40, 256
+    Wp = synth.make_ray_pe_weights(Cd, 77)
+    cam, T_cp, T_wp, T_wl = synth.make_geometry(78, B, V, h, w)
+    scale = synth.DEFAULT_SCALE
+    pe = AddRayPE(Cd, scale, 64, 0.25, 5.25)
+    pe.load_state_dict({k: torch.from_numpy(v) for k, v in Wp.items()}, strict=True)
+    pe = pe.cuda().eval()
+    feat = dev(synth.normal(9, "feat2", (B, V, Cd, h, w)))
+    tok = pe.tokens(feat, dev(cam), dev(T_cp), dev(T_wp), dev(T_wl))
+    with torch.no_grad():
+        enc64 = O.ray_pe(cam, T_cp, T_wp, T_wl, Wp, scale, dtype=torch.float64)
+    want = O.tokenize(feat.cpu().double(), enc64)
+    assert rel_err(tok.cpu().numpy(), want.numpy()) < 2e-5
+
+
+def test_parq_module_forward_matches_oracle_pipeline():
+    """PARQ.forward (ray-PE + tokenisation + decoder, model/parq_lightning.py:68-95) vs the float64 oracle
+    pipeline on a small synthetic batch, first iteration (free-running start)."""
+    from types import SimpleNamespace as NS
+    from parq_amd import PARQ, Camera, Pose
+    B, V, h, w, Cd, Qn = 2, 3, 12, 16, 128, 32
+    dcfg = synth.decoder_cfg(dim=Cd, queries=Qn, heads=2, ffn=192, layers=2)
+    scale = dcfg.TRANSFORMER.SCALE
+    cfg = NS(MODEL=NS(TOKENIZER=NS(OUT_CHANNELS=Cd, RAY_POINTS_SCALE=scale, NUM_SAMPLES=64, MIN_DEPTH=0.25, MAX_DEPTH=5.25),
+                      DECODER=dcfg))
+    model = PARQ(cfg).eval()
+    W = synth.make_decoder_weights(dcfg, 51)
+    Wp = synth.make_ray_pe_weights(Cd, 52)
+    sd = model.state_dict()
+    for k in sd:
+        if k.startswith("box3d_decoder."):
+            src = k[len("box3d_decoder."):].replace("parq_module.decoder.mlp_heads.", "mlp_heads.")
+            sd[k] = torch.from_numpy(W[src]).reshape(sd[k].shape)
+        else:
+            sd[k] = torch.from_numpy(Wp[k[len("add_ray_pe."):]])
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda()
+    cam, T_cp, T_wp, T_wl = synth.make_geometry(53, B, V, h, w)
+    feat = synth.normal(54, "feat", (B, V, Cd, h, w), std=0.5)
+    batch = {"all_features": dev(feat), "camera_feature": Camera(dev(cam)), "T_camera_pseudoCam": Pose(dev(T_cp)),
+             "T_world_pseudoCam": Pose(dev(T_wp)), "T_world_local": Pose(dev(T_wl))}
+    losses, outs = model(batch, 0)
+    assert losses == {"total_loss": 0} and len(outs) == 2
+    with torch.no_grad():
+        enc = O.ray_pe(cam, T_cp, T_wp, T_wl, Wp, scale, dtype=torch.float64)
+        tokens = O.tokenize(torch.from_numpy(feat).double(), enc)
+        # the HIP path rounds the tokens to float32 between the two stages: give the oracle the same tokens
+        tokens = tokens.float().double()
+        od = O.OracleDecoder(dcfg, W, synth.SCANNET_MEAN_SIZES, dtype=torch.float64)
+        od.prepare(tokens, cam, T_cp, T_wp, T_wl)
+        ref0 = od.initial_ref().float().double()
+        want, _, _ = od.iterate(ref0, 0)
+    for key in ("pred_logits", "center_unnormalized", "ortho6d", "sem_cls_prob"):
+        assert rel_err(outs[0][key].cpu().numpy(), want[key].numpy()) < TOL, key
