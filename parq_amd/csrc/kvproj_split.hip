@@ -258,6 +258,7 @@ __global__ __launch_bounds__(kThreads) void kvproj_split_kernel(KvProjArgs a) {
 // (one 32 KB k-step in flight behind the MFMAs, across tile boundaries too).  LDS holds only the split
 // token tile (double-buffered, one barrier per k-step); B operands never touch LDS.
 constexpr int kWsMaxKSteps = 4;          // K = C <= 256
+constexpr int kWsDepth = 2;              // token k-steps in flight
 
 __global__ __launch_bounds__(kThreads, 1) void kvproj_ws_kernel(KvProjArgs a, int total_rt, int nrt, int P) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];      // [2 buffers][A_hi 128x64 | A_lo 128x64]
@@ -298,8 +299,10 @@ __global__ __launch_bounds__(kThreads, 1) void kvproj_ws_kernel(KvProjArgs a, in
     const int h = isK ? headcol : headcol - a.H;
     const int nblk = (a.N + 31) / 32;
 
-    float4 areg[8];
-    auto gload = [&](int tile, int ks) {
+    // token staging registers, kWsDepth k-steps in flight (HBM latency under load is ~3 us, one k-step of MFMAs
+    // ~0.75 us: with a single step in flight the loop runs at latency, not at MFMA or HBM speed)
+    float4 areg[kWsDepth][8];
+    auto gload = [&](int tile, int ks, float4 (&dst)[8]) {
         const int b = tile / nrt, m0 = (tile - b * nrt) * kBM;
         const float* Xb = a.X + ((int64_t)b * a.N) * C + ks * kBK;
 #pragma unroll
@@ -309,15 +312,15 @@ __global__ __launch_bounds__(kThreads, 1) void kvproj_ws_kernel(KvProjArgs a, in
             const int tok = m0 + row;
             if (tok < a.N) {
                 const float4* q = reinterpret_cast<const float4*>(Xb + (int64_t)tok * C + c * 8);
-                areg[2 * i] = q[0];
-                areg[2 * i + 1] = q[1];
+                dst[2 * i] = q[0];
+                dst[2 * i + 1] = q[1];
             } else {
-                areg[2 * i] = float4{0.f, 0.f, 0.f, 0.f};
-                areg[2 * i + 1] = float4{0.f, 0.f, 0.f, 0.f};
+                dst[2 * i] = float4{0.f, 0.f, 0.f, 0.f};
+                dst[2 * i + 1] = float4{0.f, 0.f, 0.f, 0.f};
             }
         }
     };
-    auto swrite = [&](int buf) {
+    auto swrite = [&](int buf, const float4 (&src)[8]) {
         _Float16* Ahi = lds + buf * (2 * kBM * kBK);
         _Float16* Alo = Ahi + kBM * kBK;
 #pragma unroll
@@ -325,18 +328,26 @@ __global__ __launch_bounds__(kThreads, 1) void kvproj_ws_kernel(KvProjArgs a, in
             const int id = tid + i * kThreads;
             const int row = id >> 3, c = id & 7;
             const int pos = c ^ ((row >> 1) & 7);
-            float x[8] = {areg[2 * i].x, areg[2 * i].y, areg[2 * i].z, areg[2 * i].w,
-                          areg[2 * i + 1].x, areg[2 * i + 1].y, areg[2 * i + 1].z, areg[2 * i + 1].w};
+            float x[8] = {src[2 * i].x, src[2 * i].y, src[2 * i].z, src[2 * i].w,
+                          src[2 * i + 1].x, src[2 * i + 1].y, src[2 * i + 1].z, src[2 * i + 1].w};
             half8 hi, lo;
             split8(x, hi, lo);
             *reinterpret_cast<half8*>(Ahi + row * kBK + pos * 8) = hi;
             *reinterpret_cast<half8*>(Alo + row * kBK + pos * 8) = lo;
         }
     };
+    // linear k-step stream over this workgroup's tiles: step q -> (tile p + (q / nk) * P, ks = q % nk)
+    const int my_tiles = p < total_rt ? (total_rt - p + P - 1) / P : 0;
+    const int total_steps = my_tiles * nk;
+    auto issue = [&](int q, float4 (&dst)[8]) {
+        if (q < total_steps) gload(p + (q / nk) * P, q % nk, dst);
+    };
 
     bool ovf = false;
-    int step = 0;                                  // global k-step counter (LDS buffer parity)
-    if (p < total_rt) gload(p, 0);
+    int step = 0;                                  // global k-step counter (LDS buffer parity, staging slot)
+    static_assert(kWsDepth == 2 && kWsMaxKSteps % kWsDepth == 0, "slot arithmetic below assumes depth 2");
+    issue(0, areg[0]);
+    issue(1, areg[1]);
     for (int tile = p; tile < total_rt; tile += P) {
         f32x16 acc[4];
 #pragma unroll
@@ -347,9 +358,9 @@ __global__ __launch_bounds__(kThreads, 1) void kvproj_ws_kernel(KvProjArgs a, in
         for (int ks = 0; ks < kWsMaxKSteps; ++ks) {
             if (ks < nk) {
                 const int buf = step & 1;
-                swrite(buf);                                   // tokens of this k-step (loaded one step ago)
-                if (ks + 1 < nk) gload(tile, ks + 1);          // next k-step ...
-                else if (tile + P < total_rt) gload(tile + P, 0);   // ... or the first one of the next tile
+                // nk is even (C % 128 == 0 on this path), so the staging slot of k-step ks is ks & 1 at compile time
+                swrite(buf, areg[ks & 1]);                     // tokens of this k-step (requested two steps ago)
+                issue(step + kWsDepth, areg[ks & 1]);          // refill the slot: two k-steps ahead, across tiles
                 __syncthreads();
                 const _Float16* Ahi = lds + buf * (2 * kBM * kBK);
                 const _Float16* Alo = Ahi + kBM * kBK;
@@ -458,7 +469,7 @@ hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void*
     a.X = tokens; a.Whi = reinterpret_cast<const _Float16*>(Whi); a.Wlo = reinterpret_cast<const _Float16*>(Wlo);
     a.bias = bias; a.cache = reinterpret_cast<_Float16*>(cache); a.overflow = overflow; a.N = N; a.C = C; a.H = H;
     const int nct = 2 * C / kBN, nrt = ceil_div(N, kBM);
-    if (C <= kWsMaxKSteps * kBK) {
+    if (C <= kWsMaxKSteps * kBK && C % (2 * kBK) == 0) {
         // W-stationary persistent kernel: one workgroup per CU, column slices of one slot on one XCD
         static bool attr2 = false;
         const size_t lds2 = (size_t)2 * 2 * kBM * kBK * sizeof(_Float16);       // 64 KB
