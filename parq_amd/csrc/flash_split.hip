@@ -24,6 +24,7 @@
 // The LDS image of a block equals its global image: staging is a linear 16-byte copy.
 #include "common.hpp"
 #include <cstdlib>
+#include <type_traits>
 
 namespace parq {
 
@@ -184,7 +185,6 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
             f32x16 sacc[2];
             half8 phi[2][2], plo[2][2];
             half8 kf[2][8];          // K fragments of both blocks: [kb][2*s + {hi,lo}]
-            half8 vf[2][8];          // V fragments: [kb][4*m + 2*dt + {hi,lo}]
             float rs = 0.f;
 
             // LDS fragment reads are issued a full MFMA group ahead of their use (ds_read latency is
@@ -198,33 +198,25 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
                     kf[kb][2 * s + 1] = *reinterpret_cast<const half8*>(B0 + 2048 + li * 64 + pos * 8);
                 }
             };
-            auto load_v = [&](int kb) {
-                const _Float16* B0 = S0 + kb * kBlkHalfs;
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        const int d = dt * 32 + li;
-                        const int pos = (2 * m + kh) ^ ((d >> 2) & 3);
-                        vf[kb][4 * m + 2 * dt] = *reinterpret_cast<const half8*>(B0 + 4096 + d * 32 + pos * 8);
-                        vf[kb][4 * m + 2 * dt + 1] = *reinterpret_cast<const half8*>(B0 + 6144 + d * 32 + pos * 8);
-                    }
-            };
             auto qk_step = [&](int kb, int s) {
                 sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][2 * s], qhi[s], sacc[kb], 0, 0, 0);
                 sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][2 * s], qlo[s], sacc[kb], 0, 0, 0);
                 sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][2 * s + 1], qhi[s], sacc[kb], 0, 0, 0);
             };
-            // block maximum (scores absolute), tail masking included
-            auto block_mx = [&](int kb) -> float {
-                const int blk = t * kStageBlks + kb;
-                if (kb >= nb) {                                           // block past the end of the cache (zero-filled)
+            // block maximum (scores absolute).  Tail masking (keys >= Lk, blocks past the end) exists only in the
+            // TAIL instantiation of the stage body, so the common path stays free of branches between the MFMA
+            // groups (the scheduler can only interleave inside one basic block).
+            auto block_mx = [&](int kb, auto tail_tag) -> float {
+                if constexpr (decltype(tail_tag)::value) {
+                    const int blk = t * kStageBlks + kb;
+                    if (kb >= nb) {                                       // block past the end of the cache (zero-filled)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sacc[kb][r] = -INFINITY;
-                } else if (blk == nblk - 1 && (a.Lk & 31) != 0) {
+                        for (int r = 0; r < 16; ++r) sacc[kb][r] = -INFINITY;
+                    } else if (blk == nblk - 1 && (a.Lk & 31) != 0) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (blk * 32 + mfma32_row(r, lane) >= a.Lk) sacc[kb][r] = -INFINITY;
+                        for (int r = 0; r < 16; ++r)
+                            if (blk * 32 + mfma32_row(r, lane) >= a.Lk) sacc[kb][r] = -INFINITY;
+                    }
                 }
                 float mx = sacc[kb][0];
 #pragma unroll
@@ -256,14 +248,24 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
                 split8(p, phi[kb][m], plo[kb][m]);
             };
             auto pv_step = [&](int kb, int m) {
+                const _Float16* B0 = S0 + kb * kBlkHalfs;
+                half8 vhi[2], vlo[2];
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kb][4 * m + 2 * dt], phi[kb][m], o[dt], 0, 0, 0);
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int d = dt * 32 + li;
+                    const int pos = (2 * m + kh) ^ ((d >> 2) & 3);
+                    vhi[dt] = *reinterpret_cast<const half8*>(B0 + 4096 + d * 32 + pos * 8);
+                    vlo[dt] = *reinterpret_cast<const half8*>(B0 + 6144 + d * 32 + pos * 8);
+                }
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kb][4 * m + 2 * dt + 1], phi[kb][m], o[dt], 0, 0, 0);
+                for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[dt], phi[kb][m], o[dt], 0, 0, 0);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kb][4 * m + 2 * dt], plo[kb][m], o[dt], 0, 0, 0);
+                for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo[dt], phi[kb][m], o[dt], 0, 0, 0);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[dt], plo[kb][m], o[dt], 0, 0, 0);
             };
 
+            auto run_stage = [&](auto tail_tag) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -273,26 +275,36 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
             // ---- QK(b0)
 #pragma unroll
             for (int s = 0; s < 4; ++s) qk_step(0, s);
-            load_v(0);
             {
-                const float mx0 = block_mx(0);
+                const float mx0 = block_mx(0, tail_tag);
                 if (__any(mx0 > m_run + a.defer_log2)) rescale(mx0);
             }
-            // ---- QK(b1) with softmax(b0) in its shadow
+            // ---- QK(b1) with softmax(b0) in its shadow: one straight-line region, the scheduler is told to
+            // place ~8 VALU/TRANS instructions behind every MFMA (in-order issue: VALU work that merely FOLLOWS
+            // a run of MFMAs cannot overlap them)
             qk_step(1, 0);
             qk_step(1, 1);
             softmax_half(0, 0);
             qk_step(1, 2);
             qk_step(1, 3);
             softmax_half(0, 1);
-            load_v(1);
-            const float mx1 = block_mx(1);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x402, 9, 0);          // 9 VALU / TRANS
+            }
+            const float mx1 = block_mx(1, tail_tag);
             if (!__any(mx1 > m_run + a.defer_log2)) {
                 // ---- common case: PV(b0) with softmax(b1) in its shadow
                 pv_step(0, 0);
                 softmax_half(1, 0);
                 pv_step(0, 1);
                 softmax_half(1, 1);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x402, 9, 1);
+                }
             } else {
                 pv_step(0, 0);
                 pv_step(0, 1);
@@ -303,6 +315,10 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
             // ---- PV(b1)  (a block past the end has p = 0 and zero-filled V: contributes nothing)
             pv_step(1, 0);
             pv_step(1, 1);
+            };
+            const bool tail_stage = (nb < kStageBlks) || ((t + 1) * kStageBlks >= nblk && (a.Lk & 31) != 0);   // wave-uniform
+            if (tail_stage) run_stage(std::true_type{});
+            else run_stage(std::false_type{});
             rs += __shfl_xor(rs, 32);
             l_run += rs;
         }
