@@ -133,7 +133,7 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     ws->xb = take(M * C); ws->ffn = take(M * F);
     ws->xc = take(M * C);
     ws->h1 = take(M * c->NH1); ws->h2 = take(M * 2 * C);
-    ws->gn_sums = take((int64_t)2 * B * 4 * 2);            // doubles
+    ws->gn_sums = take((int64_t)2 * B * 4 * kGnSlots * 2);  // doubles: [2 layers][B][2 heads][kGnSlots][2]
     ws->ln1 = take(M * 2); ws->ln2 = take(M * 2);
     const int cus = device_num_cus();
     ws->self_split = flash_pick_splits(B, c->H, c->Q, c->Q, c->dh, cus);
@@ -229,7 +229,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     const int64_t N = (int64_t)sc->V * sc->h * sc->w;
     const float eps = 1e-5f;
     double* gn1 = reinterpret_cast<double*>(wsp + ws.gn_sums);          // [B][2][2]
-    double* gn2 = gn1 + (int64_t)B * 4;
+    double* gn2 = gn1 + (int64_t)B * 4 * kGnSlots;
 
     // K3: sine embedding (written by the previous iteration's decode kernel when chained) -> position MLP
     // (transformer_parq.py:317)
@@ -246,7 +246,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     {
         Prof p(c, s, PARQ_PROF_PROJECT_SAMPLE);
         HIPCHK(launch_project_sample_f64(sc->tokens, reinterpret_cast<const double*>(wsp + ws.T_cl), sc->camera, ref, c->sb,
-                                         B, sc->V, sc->h, sc->w, C, Q, wsp + ws.tgt, o->coord_pos, gn1, B * 8, s));
+                                         B, sc->V, sc->h, sc->w, C, Q, wsp + ws.tgt, o->coord_pos, gn1, B * 8 * kGnSlots, s));
     }
     // K6: self-attention, q = k = tgt + pos, v = tgt (transformer_parq.py:372-376)
     {
@@ -577,7 +577,7 @@ int parq_workspace_lookup(parq_handle h, int32_t B, int32_t V, int32_t hh, int32
         {"tgt", ws.tgt, M * C}, {"self_qkv", ws.qkv, M * 3 * C}, {"attn", ws.attn, M * C}, {"xa_prenorm1", ws.xa, M * C},
         {"cross_q", ws.qc, M * C}, {"xb_prenorm2", ws.xb, M * C}, {"ffn_hidden", ws.ffn, M * F},
         {"xc_prenorm3", ws.xc, M * C}, {"heads1", ws.h1, M * h->NH1}, {"heads2", ws.h2, M * 2 * C},
-        {"gn_sums_f64", ws.gn_sums, (int64_t)2 * B * 4 * 2}, {"ln1_stats", ws.ln1, M * 2}, {"ln2_stats", ws.ln2, M * 2},
+        {"gn_sums_f64", ws.gn_sums, (int64_t)2 * B * 4 * kGnSlots * 2}, {"ln1_stats", ws.ln1, M * 2}, {"ln2_stats", ws.ln2, M * 2},
         {"flags", ws.flags, 64}};
     for (const E& e : table)
         if (strcmp(e.n, name) == 0) { *offset_floats = (size_t)e.off; *numel = (size_t)e.cnt; return PARQ_OK; }

@@ -12,6 +12,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kWave = 64;
+constexpr int kGnSlots = 8;     // GroupNorm moment accumulators per (scene, group): spreads the fp64 atomics
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -76,7 +77,7 @@ struct LinearArgs {
     const double* gn_sums; const float* gn_gamma; const float* gn_beta;
     int gn_rows_per_scene; int gn_ngroups;
     // moments of the OUTPUT (columns < gn_out_ncols) accumulated with fp64 atomics into
-    // gn_out_sums[scene][(n + g*N) / gn_out_group_cols][2] (zeroed by an earlier kernel)
+    // gn_out_sums[scene][(n + g*N) / gn_out_group_cols][kGnSlots][2] (zeroed by an earlier kernel)
     double* gn_out_sums; int gn_out_ncols; int gn_out_group_cols; int gn_out_rows_per_scene; int gn_out_ngroups;
     // grouped launch: blockIdx.y = g adds these element offsets
     int64_t gX, gW, gBias, gY, gGamma;
@@ -154,7 +155,7 @@ hipError_t launch_gn_stats(const float* X, int64_t ldx, int col0, int ncols, int
 struct BoxDecodeArgs {
     const float* h1; int64_t ld1;      // [M][..]: logits at cols [0,ncls), size_raw at [ncls, ncls+3)
     const float* h2; int64_t ld2;      // [M][2C]: centre hidden | rotation hidden (pre-GroupNorm)
-    const double* gn_sums;             // [B][2][2] moments of h2 per scene and head
+    const double* gn_sums;             // [B][2][kGnSlots][2] moments of h2 per scene and head
     const float* gn_gamma; const float* gn_beta;       // [2][C]
     const float* w3; const float* b3;  // [2][6][C] (centre rows 0..2 of group 0), [2][6]
     int C; int rows_per_scene; float eps;

@@ -308,9 +308,14 @@ __global__ __launch_bounds__(256) void box_decode_kernel(BoxDecodeArgs a) {
     const float ref_in = lane < 3 ? a.ref[(int64_t)m * 3 + lane] : 0.5f;
     const float b3c = lane < 3 ? a.b3[lane] : 0.f;
     const float b3r = lane < 6 ? a.b3[6 + lane] : 0.f;
-    double sums[4];
+    double sums[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sums[i] = a.gn_sums[scene * 4 + i];
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int sl = 0; sl < kGnSlots; ++sl) {
+            sums[2 * g] += a.gn_sums[((scene * 2 + g) * kGnSlots + sl) * 2 + 0];
+            sums[2 * g + 1] += a.gn_sums[((scene * 2 + g) * kGnSlots + sl) * 2 + 1];
+        }
     // GroupNorm(1,C) of the second hidden layer from the scene-wide moments (generic_mlp.py:85-86)
     float mean[2], rstd[2];
 #pragma unroll
@@ -327,6 +332,7 @@ __global__ __launch_bounds__(256) void box_decode_kernel(BoxDecodeArgs a) {
 #pragma unroll
     for (int j = 0; j < 9; ++j) acc[j] = 0.f;
     const float* h2 = a.h2 + (int64_t)m * a.ld2;
+#pragma unroll 4
     for (int c = lane; c < C; c += 64) {
         float y0 = (h2[c] - mean[0]) * rstd[0] * a.gn_gamma[c] + a.gn_beta[c];
         float y1 = (h2[C + c] - mean[1]) * rstd[1] * a.gn_gamma[C + c] + a.gn_beta[C + c];

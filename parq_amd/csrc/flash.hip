@@ -233,13 +233,36 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(FlashArgs a) {
     const int q = q0 + tq;
     const int64_t pb = (int64_t)bh * a.nsplit;
 
+    // softmax statistics of the 32 queries: thread (tq, td) owns splits td, td+8, ...; all of its loads are
+    // issued together (a one-load-per-iteration loop here costs nsplit dependent L2 round trips)
+    constexpr int kMaxPer = 32;                      // nsplit <= 256
+    float mloc[kMaxPer], lloc[kMaxPer];
     float mmax = -INFINITY;
-    for (int s = 0; s < a.nsplit; ++s) mmax = fmaxf(mmax, a.m_part[(pb + s) * Lq_pad + q]);
+#pragma unroll
+    for (int i = 0; i < kMaxPer; ++i) {
+        const int s = td + i * 8;
+        if (i * 8 < a.nsplit) {                      // uniform per i
+            mloc[i] = s < a.nsplit ? a.m_part[(pb + s) * Lq_pad + q] : -INFINITY;
+            lloc[i] = s < a.nsplit ? a.l_part[(pb + s) * Lq_pad + q] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxPer; ++i)
+        if (i * 8 < a.nsplit) mmax = fmaxf(mmax, mloc[i]);
+    dsm[td * 32 + tq] = mmax;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mmax = fmaxf(mmax, dsm[i * 32 + tq]);
+    __syncthreads();
     float den = 0.f;
-    for (int s = td; s < a.nsplit; s += 8) {
-        const float w = __builtin_amdgcn_exp2f(a.m_part[(pb + s) * Lq_pad + q] - mmax);
-        wsm[s * 32 + tq] = w;
-        den += w * a.l_part[(pb + s) * Lq_pad + q];
+#pragma unroll
+    for (int i = 0; i < kMaxPer; ++i) {
+        const int s = td + i * 8;
+        if (i * 8 < a.nsplit && s < a.nsplit) {
+            const float w = __builtin_amdgcn_exp2f(mloc[i] - mmax);
+            wsm[s * 32 + tq] = w;
+            den += w * lloc[i];
+        }
     }
     dsm[td * 32 + tq] = den;
     __syncthreads();

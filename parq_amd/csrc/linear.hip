@@ -68,8 +68,13 @@ __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a
     if (a.gn_sums) {
         const int scene = (m_ok ? m : 0) / a.gn_rows_per_scene;
         const double cnt = (double)a.gn_rows_per_scene * (double)a.K;
-        const double S = a.gn_sums[(scene * a.gn_ngroups + g) * 2 + 0];
-        const double Qs = a.gn_sums[(scene * a.gn_ngroups + g) * 2 + 1];
+        // the producer spread its atomics over kGnSlots accumulators per (scene, group)
+        double S = 0.0, Qs = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < kGnSlots; ++sl) {
+            S += a.gn_sums[((scene * a.gn_ngroups + g) * kGnSlots + sl) * 2 + 0];
+            Qs += a.gn_sums[((scene * a.gn_ngroups + g) * kGnSlots + sl) * 2 + 1];
+        }
         const double mean = S / cnt;
         double var = Qs / cnt - mean * mean;
         var = var < 0.0 ? 0.0 : var;
@@ -285,12 +290,15 @@ __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a
                     S += dred[w * 2 + 0];
                     Q2 += dred[w * 2 + 1];
                 }
-                double* dst = a.gn_out_sums + ((int64_t)sc_first * a.gn_out_ngroups + grp) * 2;
+                // slot = row tile index: only the column tiles of one row block contend on an address
+                const int slot = (m0 / kTile) % kGnSlots;
+                double* dst = a.gn_out_sums + (((int64_t)sc_first * a.gn_out_ngroups + grp) * kGnSlots + slot) * 2;
                 atomicAdd(dst, S);
                 atomicAdd(dst + 1, Q2);
             }
         } else if (row_ok) {
-            double* dst = a.gn_out_sums + ((int64_t)(om / a.gn_out_rows_per_scene) * a.gn_out_ngroups + grp) * 2;
+            const int slot = (m0 / kTile) % kGnSlots;
+            double* dst = a.gn_out_sums + (((int64_t)(om / a.gn_out_rows_per_scene) * a.gn_out_ngroups + grp) * kGnSlots + slot) * 2;
             atomicAdd(dst, gs);
             atomicAdd(dst + 1, gq);
         }
