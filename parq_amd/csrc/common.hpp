@@ -12,7 +12,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kWave = 64;
-constexpr int kGnSlots = 8;     // GroupNorm moment accumulators per (scene, group): spreads the fp64 atomics
+constexpr int kGnSlots = 64;    // GroupNorm moment accumulators per (scene, group): spreads the fp64 atomics
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -111,8 +111,8 @@ __global__ __launch_bounds__(1024) void project_sample_kernel(
     const float* __restrict__ ref, ScaleBox sb, int V, int h, int w, int C, int Q, float* __restrict__ tgt,
     float* __restrict__ coord_pos, double* __restrict__ zero_f64, int zero_n) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [nwv][C] + [nwv] counts
-    if (blockIdx.x == 0)                                            // accumulators of later kernels
-        for (int i = threadIdx.x; i < zero_n; i += blockDim.x) zero_f64[i] = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += gridDim.x * blockDim.x)
+        zero_f64[i] = 0.0;                                          // accumulators of later kernels
     const int bq = blockIdx.x;
     const int b = bq / Q;
     const int lane = threadIdx.x & 63;
@@ -308,14 +308,18 @@ __global__ __launch_bounds__(256) void box_decode_kernel(BoxDecodeArgs a) {
     const float ref_in = lane < 3 ? a.ref[(int64_t)m * 3 + lane] : 0.5f;
     const float b3c = lane < 3 ? a.b3[lane] : 0.f;
     const float b3r = lane < 6 ? a.b3[6 + lane] : 0.f;
-    double sums[4] = {0.0, 0.0, 0.0, 0.0};
+    // scene-wide GroupNorm moments: kGnSlots (= one per lane) partial accumulators per (scene, head)
+    double sums[4];
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < 2; ++g) {
+        const double* src = a.gn_sums + ((int64_t)(scene * 2 + g) * kGnSlots + lane) * 2;
+        sums[2 * g] = src[0];
+        sums[2 * g + 1] = src[1];
+    }
 #pragma unroll
-        for (int sl = 0; sl < kGnSlots; ++sl) {
-            sums[2 * g] += a.gn_sums[((scene * 2 + g) * kGnSlots + sl) * 2 + 0];
-            sums[2 * g + 1] += a.gn_sums[((scene * 2 + g) * kGnSlots + sl) * 2 + 1];
-        }
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sums[j] += __shfl_xor(sums[j], o);
     // GroupNorm(1,C) of the second hidden layer from the scene-wide moments (generic_mlp.py:85-86)
     float mean[2], rstd[2];
 #pragma unroll

@@ -307,42 +307,70 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(FlashArgs a) {
 }
 
 // Self-attention among the Q queries (transformer_parq.py:372-376) in ONE launch: a workgroup owns
-// 32 queries of one (scene, head); its 8 waves take disjoint key slices (fragments straight from
-// the fused in-projection output in global/L2 — 256 keys need no LDS staging), run the same
-// fp32-MFMA online softmax as above and combine their (m, l, O^T) through LDS.
+// 32 queries of one (scene, head); its 8 waves take disjoint key slices, run the same fp32-MFMA
+// online softmax as above and combine their (m, l, O^T) through LDS.  The kernel is pure latency,
+// and a row-per-lane 16-byte load is 64 separate requests for the CU's L1 pipe, so the Q tile
+// (once per workgroup) and each wave's K block are fetched with row-contiguous loads (16 requests
+// per instruction) into LDS and the MFMA fragments are read from there; V fragments are
+// lane-contiguous in global memory already.
 template <int DH>
 __global__ __launch_bounds__(512) void self_attn_kernel(const float* __restrict__ qkv, int64_t row_stride, int H, int L,
                                                         float* __restrict__ out, int64_t out_row) {
     constexpr int NW = 8;
     constexpr int NDT = DH / 32;
+    constexpr int LDR = DH + 4;                  // LDS row stride of the staged Q / K blocks (floats)
+    constexpr int F4R = DH / 4;                  // float4 per row
+    constexpr int RPI = 64 / F4R;                // rows one wave-wide load instruction covers
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Os = smem;                         // [NW][DH][33]
-    float* Ms = Os + NW * DH * 33;            // [NW][32]
+    float* Os = smem;                         // [NW][DH][33]   (after the key loop)
+    float* Kst = smem;                        // [NW][32][LDR]  (during the key loop; aliases Os)
+    constexpr int kRegion = NW * DH * 33 > NW * 32 * LDR ? NW * DH * 33 : NW * 32 * LDR;
+    float* Ms = smem + kRegion;               // [NW][32]
     float* Ls = Ms + NW * 32;                 // [NW][32]
+    float* Qs = Ls + NW * 32;                 // [32][LDR]
     const int bh = blockIdx.y;
     const int b = bh / H, h = bh - b * H;
     const int C = H * DH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
     const int q0 = blockIdx.x * 32;
-    const int q = q0 + li;
     const float* base = qkv + (int64_t)b * L * row_stride + h * DH;     // q at +0, k at +C, v at +2C
 
-    float qf[DH / 2];
-    {
-        const float scale = 1.4426950408889634f / sqrtf((float)DH);
-        const float* qp = base + (int64_t)(q < L ? q : 0) * row_stride + kh * (DH / 2);
-#pragma unroll
-        for (int c = 0; c < DH / 8; ++c) {
-            f32x4 t4 = *reinterpret_cast<const f32x4*>(qp + c * 4);
-            if (q >= L) t4 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) qf[c * 4 + e] = t4[e] * scale;
-        }
+    // Q tile: 32 x DH floats, one float4 per thread (DH = 64) — row-contiguous
+    for (int idx = tid; idx < 32 * F4R; idx += 512) {
+        const int r = idx / F4R, c4 = idx - r * F4R;
+        const int qq = q0 + r;
+        f32x4 t4 = *reinterpret_cast<const f32x4*>(base + (int64_t)(qq < L ? qq : 0) * row_stride + c4 * 4);
+        if (qq >= L) t4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(&Qs[r * LDR + c4 * 4]) = t4;
     }
     const int per = ((((L + NW - 1) / NW) + 31) / 32) * 32;              // keys per wave, multiple of 32
     const int k_begin = wave * per;
     const int k_end = (k_begin + per < L) ? k_begin + per : L;
+    float* Kw = Kst + wave * 32 * LDR;
+    // first K block of this wave: requested before the Q tile is waited for
+    f32x4 kst[32 / RPI];
+    auto load_k = [&](int kb) {
+#pragma unroll
+        for (int j = 0; j < 32 / RPI; ++j) {
+            const int r = j * RPI + lane / F4R, c4 = lane % F4R;
+            const int key = kb + r;
+            kst[j] = *reinterpret_cast<const f32x4*>(base + C + (int64_t)(key < L ? key : 0) * row_stride + c4 * 4);
+            if (key >= L) kst[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    if (k_begin < k_end) load_k(k_begin);
+    __syncthreads();
+    float qf[DH / 2];
+    {
+        const float scale = 1.4426950408889634f / sqrtf((float)DH);
+#pragma unroll
+        for (int c = 0; c < DH / 8; ++c) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(&Qs[li * LDR + kh * (DH / 2) + c * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qf[c * 4 + e] = t4[e] * scale;
+        }
+    }
 
     f32x16 o[NDT];
 #pragma unroll
@@ -354,11 +382,7 @@ __global__ __launch_bounds__(512) void self_attn_kernel(const float* __restrict_
     for (int kb = k_begin; kb < k_end; kb += 32) {
         // all loads of this 32-key block are issued up front (operands are L2-resident, the block is tiny:
         // it is the load latency, not bandwidth, that sets this kernel's time)
-        const int key = kb + li;
-        const float* kr = base + C + (int64_t)(key < L ? key : 0) * row_stride + kh * (DH / 2);
-        f32x4 kf[DH / 8];
-#pragma unroll
-        for (int u = 0; u < DH / 8; ++u) kf[u] = *reinterpret_cast<const f32x4*>(kr + u * 4);
+        // V fragments (lane-contiguous rows) are requested first, then the staged K block goes through LDS
         float vv[16][NDT];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -367,10 +391,17 @@ __global__ __launch_bounds__(512) void self_attn_kernel(const float* __restrict_
 #pragma unroll
             for (int d = 0; d < NDT; ++d) vv[r][d] = vr[d * 32];
         }
-        if (key >= L) {
+        if (kb > k_begin) load_k(kb);
 #pragma unroll
-            for (int u = 0; u < DH / 8; ++u) kf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int j = 0; j < 32 / RPI; ++j)
+            *reinterpret_cast<f32x4*>(&Kw[(j * RPI + lane / F4R) * LDR + (lane % F4R) * 4]) = kst[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f32x4 kf[DH / 8];
+#pragma unroll
+        for (int u = 0; u < DH / 8; ++u) kf[u] = *reinterpret_cast<const f32x4*>(&Kw[li * LDR + kh * (DH / 2) + u * 4]);
+        __builtin_amdgcn_wave_barrier();            // the block is consumed before the next one overwrites it
         f32x16 sacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
@@ -410,7 +441,8 @@ __global__ __launch_bounds__(512) void self_attn_kernel(const float* __restrict_
                 o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vk < L ? vv[r][d] : 0.f, sacc[r], o[d], 0, 0, 0);
         }
     }
-    // ---- combine the 8 key slices
+    // ---- combine the 8 key slices (Os aliases the K staging area: every wave must be past its loop)
+    __syncthreads();
 #pragma unroll
     for (int d = 0; d < NDT; ++d)
 #pragma unroll
@@ -485,7 +517,8 @@ hipError_t merge_dh(const FlashArgs& a, hipStream_t s) {
 template <int DH>
 static hipError_t launch_self_dh(const float* qkv, int64_t row_stride, int B, int H, int L, float* out, int64_t out_row,
                                  hipStream_t s) {
-    const size_t lds = ((size_t)8 * DH * 33 + 2 * 8 * 32) * sizeof(float);
+    const size_t region = (size_t)8 * DH * 33 > (size_t)8 * 32 * (DH + 4) ? (size_t)8 * DH * 33 : (size_t)8 * 32 * (DH + 4);
+    const size_t lds = (region + 2 * 8 * 32 + 32 * (DH + 4)) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_kernel<DH>),

@@ -1,16 +1,20 @@
 // Small-GEMM kernel of the per-iteration chain:  Y = act(pro(X) @ W^T + b) (+ R)
 //
-// These GEMMs have M = B*Q rows (256..2048) and K, N of a few hundred: they are
-// latency-bound (every dependent launch costs ~4-5 us of dispatch + cross-XCD memory latency
-// on this chip), so the design goal is FEW launches with enough workgroups each:
-//   * one workgroup = 4 waves = one 32x32 output tile, so a 256x256 output is 64
-//     workgroups and a 256x768 one 192 — enough to spread over the 256 CUs;
-//   * the 4 waves split K four ways (in-workgroup split-K) and reduce through LDS,
-//     which cuts the dependent MFMA chain per tile to K/8 instructions;
-//   * v_mfma_f32_32x32x2_f32: exact fp32 (an fmaf chain), lane l supplies A[i=l&31][k=l>>5]
-//     and B[k=l>>5][j=l&31].  The contraction index may be permuted freely, so lane
-//     half kh takes a CONTIGUOUS run of k: one 16-byte global load feeds 4 MFMAs and
-//     both operands are read in their native K-contiguous layouts (X [M][K], W [N][K]);
+// These GEMMs have M = B*Q rows (256..2048) and K, N of a few hundred.  At one scene they are
+// LATENCY-bound: measured on MI355X (tools/bench_src/small_linear.hip) a dependent launch costs
+// ~2.6 us and the old row-per-lane kernel spent another ~3 us waiting for its operands, because a
+// 16-byte load whose 64 lanes sit on 64 different rows is 64 separate requests for the CU's
+// texture/L1 pipe.  Design:
+//   * v_mfma_f32_16x16x4_f32 (exact fp32, same rate as 32x32x2): lane (i = l&15, kq = l>>4)
+//     supplies A[i][kq] and B[kq][i].  The contraction index may be permuted freely, so for each
+//     16-wide K chunk lane (i, kq) loads the float4 at k = chunk*16 + kq*4: the four kq groups of a
+//     row read 64 contiguous bytes, one load instruction = 16 rows x 64 B = 16 requests instead
+//     of 64, and the float4 feeds 4 MFMAs.  Both operands are read in their native K-contiguous
+//     layouts (X [M][K], W [N][K]);
+//   * one workgroup = 4 waves = one TxT output tile; the 4 waves split K four ways (in-workgroup
+//     split-K) and reduce through LDS, so the dependent MFMA chain is K/16 (T=16) instructions.
+//     T = 16 when the 32x32 tiling would not fill the chip (256x256 output = 256 workgroups, whole
+//     K slice in registers with every load in flight at once), T = 32 (2x2 sub-tiles) otherwise;
 //   * everything that is row-local or a scene-wide scalar is fused instead of launched:
 //       prologues on A : LayerNorm of the input rows (statistics computed by the tile
 //                        itself, optionally published for later residual use), + second
@@ -21,65 +25,102 @@
 //                        atomics for the next layer's prologue.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace parq {
 
 namespace {
 
-constexpr int kTile = 32;
 constexpr int kWaves = 4;
-constexpr int kChunkBatch = 8;   // float4 chunks of A and B kept in flight per lane
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+template <int T>
 __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[kWaves * 16 * kWave];
+    constexpr int S = T / 16;                       // 16x16 sub-tiles per tile edge
+    constexpr int CB = (T == 16) ? 12 : 4;          // 16-wide K chunks held in registers per batch
+    constexpr int OPT = T * T / (kWaves * kWave);   // outputs per thread in the epilogue (1 or 4)
+    constexpr int TPR = T / OPT;                    // threads per output row
+    __shared__ __attribute__((aligned(16))) float red[kWaves * S * S * 4 * kWave];
 
     // 1-D tile index, column tiles fastest: the column tiles of one row block run together
     // and share its A rows through L2
     const int g = blockIdx.y;
-    const int ntn = (a.N + kTile - 1) / kTile;
-    const int n0 = (int)(blockIdx.x % ntn) * kTile;
-    const int m0 = (int)(blockIdx.x / ntn) * kTile;
+    const int ntn = (a.N + T - 1) / T;
+    const int n0 = (int)(blockIdx.x % ntn) * T;
+    const int m0 = (int)(blockIdx.x / ntn) * T;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int li = lane & 31;
-    const int kh = lane >> 5;
+    const int li = lane & 15;
+    const int kq = lane >> 4;
 
     const float* X = a.X + g * a.gX;
     const float* W = a.W + g * a.gW;
 
-    const int KS = a.K / kWaves;          // this wave's K slice
-    const int KH = KS / 2;                // this lane-half's run
-    const int kbase = wave * KS + kh * KH;
-    const int nchunks = KH / 4;
+    // 16-wide K chunks are dealt round-robin to the 4 waves (wave w takes chunks w, w+4, ...): the
+    // workgroup's concurrent loads of a row are contiguous and any K % 16 == 0 works
+    const int nchunks = (a.K / 16 - wave + kWaves - 1) / kWaves;
+    const int kbase = wave * 16 + kq * 4; // lane's float4 of its c-th chunk sits at kbase + 64 c
 
-    const int m = m0 + li;
-    const int n = n0 + li;
-    const bool m_ok = m < a.M;
-    const bool n_ok = n < a.N;
-    const float* xrow = X + (int64_t)(m_ok ? m : 0) * a.ldx + kbase;
-    const float* wrow = W + (int64_t)(n_ok ? n : 0) * a.ldw + kbase;
+    bool m_ok[S], n_ok[S];
+    const float* xrow[S];
+    const float* wrow[S];
+    const float* x2row[S];
     const bool add2 = (a.X2 != nullptr) && (n0 < a.x2_ncols);
-    const float* x2row = add2 ? a.X2 + (int64_t)(m_ok ? m : 0) * a.ldx2 + kbase : nullptr;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int m = m0 + s * 16 + li, n = n0 + s * 16 + li;
+        m_ok[s] = m < a.M;
+        n_ok[s] = n < a.N;
+        xrow[s] = X + (int64_t)(m_ok[s] ? m : 0) * a.ldx + kbase;
+        wrow[s] = W + (int64_t)(n_ok[s] ? n : 0) * a.ldw + kbase;
+        x2row[s] = add2 ? a.X2 + (int64_t)(m_ok[s] ? m : 0) * a.ldx2 + kbase : nullptr;
+    }
 
     // ---- GroupNorm(1,C) prologue: scene-wide moments accumulated by the producer's epilogue
-    float gn_mean = 0.f, gn_rstd = 1.f;
+    // (a tile's rows lie in one scene whenever rows_per_scene % T == 0; otherwise per sub-tile row)
+    float gn_mean[S], gn_rstd[S];
     const float* gam = nullptr;
     const float* bet = nullptr;
     if (a.gn_sums) {
-        const int scene = (m_ok ? m : 0) / a.gn_rows_per_scene;
         const double cnt = (double)a.gn_rows_per_scene * (double)a.K;
-        // the producer spread its atomics over kGnSlots accumulators per (scene, group)
-        double S = 0.0, Qs = 0.0;
+        const int sc_lo = m0 / a.gn_rows_per_scene;
+        const int sc_hi = (m0 + T - 1 < a.M ? m0 + T - 1 : a.M - 1) / a.gn_rows_per_scene;
+        if (sc_lo == sc_hi) {
+            // the producer spread its atomics over kGnSlots (= one per lane) accumulators per (scene, group)
+            const double* src = a.gn_sums + ((int64_t)(sc_lo * a.gn_ngroups + g) * kGnSlots + lane) * 2;
+            double Sm = src[0], Qs = src[1];
 #pragma unroll
-        for (int sl = 0; sl < kGnSlots; ++sl) {
-            S += a.gn_sums[((scene * a.gn_ngroups + g) * kGnSlots + sl) * 2 + 0];
-            Qs += a.gn_sums[((scene * a.gn_ngroups + g) * kGnSlots + sl) * 2 + 1];
+            for (int o = 32; o > 0; o >>= 1) {
+                Sm += __shfl_xor(Sm, o);
+                Qs += __shfl_xor(Qs, o);
+            }
+            const double mean = Sm / cnt;
+            double var = Qs / cnt - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                gn_mean[s] = (float)mean;
+                gn_rstd[s] = (float)(1.0 / sqrt(var + (double)a.norm_eps));
+            }
+        } else {
+            // tile straddles scenes (rows_per_scene not a multiple of the tile): per-row serial sum
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int m = m0 + s * 16 + li;
+                const int scene = (m_ok[s] ? m : 0) / a.gn_rows_per_scene;
+                double Sm = 0.0, Qs = 0.0;
+                for (int sl = 0; sl < kGnSlots; ++sl) {
+                    Sm += a.gn_sums[((int64_t)(scene * a.gn_ngroups + g) * kGnSlots + sl) * 2 + 0];
+                    Qs += a.gn_sums[((int64_t)(scene * a.gn_ngroups + g) * kGnSlots + sl) * 2 + 1];
+                }
+                const double mean = Sm / cnt;
+                double var = Qs / cnt - mean * mean;
+                var = var < 0.0 ? 0.0 : var;
+                gn_mean[s] = (float)mean;
+                gn_rstd[s] = (float)(1.0 / sqrt(var + (double)a.norm_eps));
+            }
         }
-        const double mean = S / cnt;
-        double var = Qs / cnt - mean * mean;
-        var = var < 0.0 ? 0.0 : var;
-        gn_mean = (float)mean;
-        gn_rstd = (float)(1.0 / sqrt(var + (double)a.norm_eps));
         gam = a.gn_gamma + g * a.gGamma + kbase;
         bet = a.gn_beta + g * a.gGamma + kbase;
     }
@@ -87,32 +128,32 @@ __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a
     // ---- issue every independent global load up front: this kernel is latency-bound (operands come
     // from the other XCDs' writes or from HBM/MALL after the attention kernel swept the L2s), so the
     // first A/B batch and all epilogue operands are requested before anything waits on anything.
-    f32x4 av[kChunkBatch], bv[kChunkBatch];
+    f32x4v av[S][CB], bv[S][CB];
     auto load_batch = [&](int c0) {
 #pragma unroll
-        for (int c = 0; c < kChunkBatch; ++c) {
-            const int cc = c0 + c;
-            if (cc < nchunks) {
-                av[c] = *reinterpret_cast<const f32x4*>(xrow + cc * 4);
-                bv[c] = *reinterpret_cast<const f32x4*>(wrow + cc * 4);
-            } else {
-                av[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-                bv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < CB; ++c) {
+            if (c0 + c < nchunks) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    av[s][c] = *reinterpret_cast<const f32x4v*>(xrow[s] + (c0 + c) * 64);
+                    bv[s][c] = *reinterpret_cast<const f32x4v*>(wrow[s] + (c0 + c) * 64);
+                }
             }
         }
     };
     load_batch(0);
-    // epilogue operands of this thread's (row, 4 cols)
-    const int erow = tid >> 3;
-    const int ec4 = (tid & 7) * 4;
+    // epilogue operands of this thread's (row, OPT cols)
+    const int erow = tid / TPR;
+    const int ec = (tid % TPR) * OPT;
     const int eom = m0 + erow;
     const bool erow_ok = eom < a.M;
     const float* bias = a.bias ? a.bias + g * a.gBias : nullptr;
-    float e_bias[4] = {0.f, 0.f, 0.f, 0.f}, e_r[4] = {0.f, 0.f, 0.f, 0.f}, e_rg[4] = {1.f, 1.f, 1.f, 1.f}, e_rb[4] = {0.f, 0.f, 0.f, 0.f};
+    float e_bias[OPT], e_r[OPT], e_rg[OPT], e_rb[OPT];
     float rmean = 0.f, rrstd = 1.f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int on = n0 + ec4 + e;
+    for (int e = 0; e < OPT; ++e) {
+        e_bias[e] = 0.f; e_r[e] = 0.f; e_rg[e] = 1.f; e_rb[e] = 0.f;
+        const int on = n0 + ec + e;
         if (on < a.N) {
             if (bias) e_bias[e] = bias[on];
             if (a.R && erow_ok) e_r[e] = a.R[(int64_t)eom * a.ldr + on];
@@ -127,123 +168,154 @@ __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a
         rrstd = a.rln_stats[(int64_t)eom * 2 + 1];
     }
 
-    // ---- LayerNorm prologue: row statistics of A over the full K, reduced across the lane halves and
-    // the 4 K-slices through LDS.  One pass over data shifted by the row's first element (the shift
+    // ---- LayerNorm prologue: row statistics of A over the full K, reduced across the 4 kq lane groups
+    // and the 4 K-slices through LDS.  One pass over data shifted by the row's first element (the shift
     // removes the cancellation of E[x^2] - mean^2).
-    float ln_mean = 0.f, ln_rstd = 1.f;
-    if (a.ln_gamma) {
-        const float shift = X[(int64_t)(m_ok ? m : 0) * a.ldx];
-        float s = 0.f, q = 0.f;
-        if (nchunks <= kChunkBatch) {                  // the lane's whole K run is already in registers
+    float ln_mean[S], ln_rstd[S];
 #pragma unroll
-            for (int c = 0; c < kChunkBatch; ++c)
+    for (int s = 0; s < S; ++s) { ln_mean[s] = 0.f; ln_rstd[s] = 1.f; }
+    if (a.ln_gamma) {
+        float sm[S], sq[S], shift[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            shift[s] = X[(int64_t)(m_ok[s] ? m0 + s * 16 + li : 0) * a.ldx];
+            sm[s] = 0.f;
+            sq[s] = 0.f;
+        }
+        if (nchunks <= CB) {                           // the lane's whole K share is already in registers
+#pragma unroll
+            for (int c = 0; c < CB; ++c)
                 if (c < nchunks) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float d = av[c][e] - shift;
-                        s += d;
-                        q += d * d;
-                    }
+                    for (int s = 0; s < S; ++s)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float d = av[s][c][e] - shift[s];
+                            sm[s] += d;
+                            sq[s] += d * d;
+                        }
                 }
         } else {
             for (int c = 0; c < nchunks; ++c) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(xrow + c * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float d = v[e] - shift;
-                    s += d;
-                    q += d * d;
+                for (int s = 0; s < S; ++s) {
+                    const f32x4v v = *reinterpret_cast<const f32x4v*>(xrow[s] + c * 64);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = v[e] - shift[s];
+                        sm[s] += d;
+                        sq[s] += d * d;
+                    }
                 }
             }
         }
-        s += __shfl_xor(s, 32);
-        q += __shfl_xor(q, 32);
-        if (kh == 0) {
-            red[wave * 64 + li] = s;
-            red[wave * 64 + 32 + li] = q;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            sm[s] += __shfl_xor(sm[s], 16);
+            sq[s] += __shfl_xor(sq[s], 16);
+            sm[s] += __shfl_xor(sm[s], 32);
+            sq[s] += __shfl_xor(sq[s], 32);
+            if (kq == 0) {
+                red[(wave * T + s * 16 + li) * 2 + 0] = sm[s];
+                red[(wave * T + s * 16 + li) * 2 + 1] = sq[s];
+            }
         }
-        __syncthreads();
-        const float S = red[li] + red[64 + li] + red[128 + li] + red[192 + li];
-        const float Q2 = red[32 + li] + red[96 + li] + red[160 + li] + red[224 + li];
         __syncthreads();
         const float invK = 1.f / (float)a.K;
-        const float dm = S * invK;
-        ln_mean = shift + dm;
-        const float var = fmaxf(Q2 * invK - dm * dm, 0.f);
-        ln_rstd = 1.f / sqrtf(var + a.norm_eps);
-        if (a.ln_stats_out && n0 == 0 && wave == 0 && kh == 0 && m_ok) {
-            a.ln_stats_out[(int64_t)m * 2 + 0] = ln_mean;
-            a.ln_stats_out[(int64_t)m * 2 + 1] = ln_rstd;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            float Ssum = 0.f, Q2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) {
+                Ssum += red[(w * T + s * 16 + li) * 2 + 0];
+                Q2 += red[(w * T + s * 16 + li) * 2 + 1];
+            }
+            const float dm = Ssum * invK;
+            ln_mean[s] = shift[s] + dm;
+            const float var = fmaxf(Q2 * invK - dm * dm, 0.f);
+            ln_rstd[s] = 1.f / sqrtf(var + a.norm_eps);
+            if (a.ln_stats_out && n0 == 0 && wave == 0 && kq == 0 && m_ok[s]) {
+                a.ln_stats_out[(int64_t)(m0 + s * 16 + li) * 2 + 0] = ln_mean[s];
+                a.ln_stats_out[(int64_t)(m0 + s * 16 + li) * 2 + 1] = ln_rstd[s];
+            }
         }
+        __syncthreads();
     }
     const float* lng = a.ln_gamma ? a.ln_gamma + kbase : nullptr;
     const float* lnb = a.ln_gamma ? a.ln_beta + kbase : nullptr;
 
-    f32x16 acc;
+    f32x4v acc[S][S];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int t = 0; t < S; ++t) acc[s][t] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-    for (int c0 = 0; c0 < nchunks; c0 += kChunkBatch) {
+    for (int c0 = 0; c0 < nchunks; c0 += CB) {
         if (c0 > 0) load_batch(c0);
-        if (a.ln_gamma) {
 #pragma unroll
-            for (int c = 0; c < kChunkBatch; ++c) {
-                if (c0 + c < nchunks) {
-                    const f32x4 gv = *reinterpret_cast<const f32x4*>(lng + (c0 + c) * 4);
-                    const f32x4 be = *reinterpret_cast<const f32x4*>(lnb + (c0 + c) * 4);
+        for (int c = 0; c < CB; ++c) {
+            if (c0 + c < nchunks) {
+                if (a.ln_gamma) {
+                    const f32x4v gv = *reinterpret_cast<const f32x4v*>(lng + (c0 + c) * 64);
+                    const f32x4v be = *reinterpret_cast<const f32x4v*>(lnb + (c0 + c) * 64);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) av[c][e] = (av[c][e] - ln_mean) * ln_rstd * gv[e] + be[e];
+                    for (int s = 0; s < S; ++s)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) av[s][c][e] = (av[s][c][e] - ln_mean[s]) * ln_rstd[s] * gv[e] + be[e];
                 }
-            }
-        }
-        if (add2) {
+                if (add2) {
 #pragma unroll
-            for (int c = 0; c < kChunkBatch; ++c)
-                if (c0 + c < nchunks) av[c] += *reinterpret_cast<const f32x4*>(x2row + (c0 + c) * 4);
-        }
-        if (a.gn_sums) {
-#pragma unroll
-            for (int c = 0; c < kChunkBatch; ++c) {
-                if (c0 + c < nchunks) {
-                    const f32x4 gv = *reinterpret_cast<const f32x4*>(gam + (c0 + c) * 4);
-                    const f32x4 be = *reinterpret_cast<const f32x4*>(bet + (c0 + c) * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float y = (av[c][e] - gn_mean) * gn_rstd * gv[e] + be[e];
-                        av[c][e] = y > 0.f ? y : 0.f;
-                    }
+                    for (int s = 0; s < S; ++s) av[s][c] += *reinterpret_cast<const f32x4v*>(x2row[s] + (c0 + c) * 64);
                 }
+                if (a.gn_sums) {
+                    const f32x4v gv = *reinterpret_cast<const f32x4v*>(gam + (c0 + c) * 64);
+                    const f32x4v be = *reinterpret_cast<const f32x4v*>(bet + (c0 + c) * 64);
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float y = (av[s][c][e] - gn_mean[s]) * gn_rstd[s] * gv[e] + be[e];
+                            av[s][c][e] = y > 0.f ? y : 0.f;
+                        }
+                }
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    if (!m_ok[s]) av[s][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                    if (!n_ok[s]) bv[s][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+#pragma unroll
+                        for (int t = 0; t < S; ++t)
+                            acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][c][e], bv[t][c][e], acc[s][t], 0, 0, 0);
             }
-        }
-        if (!m_ok) {
-#pragma unroll
-            for (int c = 0; c < kChunkBatch; ++c) av[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (!n_ok) {
-#pragma unroll
-            for (int c = 0; c < kChunkBatch; ++c) bv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int c = 0; c < kChunkBatch; ++c) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][e], bv[c][e], acc, 0, 0, 0);
         }
     }
 
-    // in-workgroup split-K reduction: red[wave][reg][lane]
+    // in-workgroup split-K reduction: red[wave][sub-tile][reg][lane]; the accumulator of sub-tile (s, t)
+    // holds rows 4*(lane>>4) + reg, column lane&15
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * kWave + lane] = acc[r];
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int t = 0; t < S; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(((wave * S + s) * S + t) * 4 + r) * kWave + lane] = acc[s][t][r];
     __syncthreads();
 
-    // thread -> (row, 4 consecutive cols) of the 32x32 tile
-    const int row = tid >> 3;
-    const int c4 = (tid & 7) * 4;
-    const int reg = (row & 3) + 4 * (row >> 3);
-    const int src_lane = c4 + 32 * ((row >> 2) & 1);
-    f32x4 sum = *reinterpret_cast<const f32x4*>(&red[(0 * 16 + reg) * kWave + src_lane]);
+    // thread -> (row, OPT consecutive cols) of the tile
+    float sum[OPT];
+    {
+        const int s = erow >> 4, rr = erow & 15, t = ec >> 4, cc = ec & 15;
+        const int src = (((0 * S + s) * S + t) * 4 + (rr & 3)) * kWave + (rr >> 2) * 16 + cc;
 #pragma unroll
-    for (int w = 1; w < kWaves; ++w) sum += *reinterpret_cast<const f32x4*>(&red[(w * 16 + reg) * kWave + src_lane]);
+        for (int e = 0; e < OPT; ++e) sum[e] = red[src + e];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w)
+#pragma unroll
+            for (int e = 0; e < OPT; ++e) sum[e] += red[src + w * S * S * 4 * kWave + e];
+    }
 
     const int om = eom;
     const bool row_ok = erow_ok;
@@ -253,8 +325,8 @@ __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a
         float* Ybase = a.Y + g * a.gY + (int64_t)(om / a.rows_per_batch) * a.y_batch +
                        (int64_t)(om % a.rows_per_batch) * a.y_row;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int on = n0 + c4 + e;
+        for (int e = 0; e < OPT; ++e) {
+            const int on = n0 + ec + e;
             if (on < a.N) {
                 float y = sum[e] + e_bias[e];
                 if (a.relu) y = y > 0.f ? y : 0.f;
@@ -269,7 +341,7 @@ __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a
         // scene-wide moments of the output block: one fp64 atomic pair per workgroup when the tile lies
         // in one scene (always, when Q % 32 == 0), else per thread
         const int sc_first = m0 / a.gn_out_rows_per_scene;
-        const int last_row = (m0 + kTile - 1 < a.M ? m0 + kTile - 1 : a.M - 1);
+        const int last_row = (m0 + T - 1 < a.M ? m0 + T - 1 : a.M - 1);
         const int grp = (n0 + g * a.N) / a.gn_out_group_cols;
         if (sc_first == last_row / a.gn_out_rows_per_scene) {
             __syncthreads();
@@ -290,14 +362,14 @@ __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a
                     S += dred[w * 2 + 0];
                     Q2 += dred[w * 2 + 1];
                 }
-                // slot = row tile index: only the column tiles of one row block contend on an address
-                const int slot = (m0 / kTile) % kGnSlots;
+                // slot = tile index mod kGnSlots: a handful of workgroups contend on one address
+                const int slot = (int)(blockIdx.x % kGnSlots);
                 double* dst = a.gn_out_sums + (((int64_t)sc_first * a.gn_out_ngroups + grp) * kGnSlots + slot) * 2;
                 atomicAdd(dst, S);
                 atomicAdd(dst + 1, Q2);
             }
         } else if (row_ok) {
-            const int slot = (m0 / kTile) % kGnSlots;
+            const int slot = (int)(blockIdx.x % kGnSlots);
             double* dst = a.gn_out_sums + (((int64_t)(om / a.gn_out_rows_per_scene) * a.gn_out_ngroups + grp) * kGnSlots + slot) * 2;
             atomicAdd(dst, gs);
             atomicAdd(dst + 1, gq);
@@ -307,12 +379,27 @@ __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a
 
 }  // namespace
 
+// tile edge: 16 while the 32x32 tiling would leave CUs idle (the latency-bound single-scene case)
+static int pick_tile(int64_t tiles32) {
+    static const int forced = [] {
+        const char* e = getenv("PARQ_LINEAR_TILE");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced == 16 || forced == 32) return forced;
+    return tiles32 < device_num_cus() ? 16 : 32;
+}
+
 hipError_t launch_linear(const LinearArgs& a, int groups, hipStream_t s) {
-    if (a.K % 32 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
-    const int64_t tiles = (int64_t)ceil_div(a.N, kTile) * ceil_div(a.M, kTile);
+    if (a.K % 16 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
+    const int64_t tiles32 = (int64_t)ceil_div(a.N, 32) * ceil_div(a.M, 32) * groups;
+    const int T = pick_tile(tiles32);
+    const int64_t tiles = (int64_t)ceil_div(a.N, T) * ceil_div(a.M, T);
     if (tiles > 0x7fffffffLL) return hipErrorInvalidValue;
     dim3 grid((unsigned)tiles, groups, 1);
-    hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(kWaves * kWave), 0, s, a);
+    if (T == 16)
+        hipLaunchKernelGGL(linear_f32_kernel<16>, grid, dim3(kWaves * kWave), 0, s, a);
+    else
+        hipLaunchKernelGGL(linear_f32_kernel<32>, grid, dim3(kWaves * kWave), 0, s, a);
     return hipGetLastError();
 }
 
