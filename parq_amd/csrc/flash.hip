@@ -307,163 +307,146 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(FlashArgs a) {
 }
 
 // Self-attention among the Q queries (transformer_parq.py:372-376) in ONE launch: a workgroup owns
-// 32 queries of one (scene, head); its 8 waves take disjoint key slices, run the same fp32-MFMA
-// online softmax as above and combine their (m, l, O^T) through LDS.  The kernel is pure latency,
-// and a row-per-lane 16-byte load is 64 separate requests for the CU's L1 pipe, so the Q tile
-// (once per workgroup) and each wave's K block are fetched with row-contiguous loads (16 requests
-// per instruction) into LDS and the MFMA fragments are read from there; V fragments are
-// lane-contiguous in global memory already.
+// 16 queries of one (scene, head); its 8 waves take disjoint key slices, run an fp32-MFMA online
+// softmax and combine their (m, l, O^T) through LDS.  The kernel is pure latency, so it is shaped
+// for short dependent chains and cheap loads:
+//   * v_mfma_f32_16x16x4_f32, lane (j = l&15, kq = l>>4).  S^T = K Q^T with A = K, B = Q^T: both
+//     operands are float4 loads at column c*16 + kq*4 of row j (16 rows x 64 B per instruction,
+//     16 requests for the L1 pipe instead of 64 for a row-per-lane layout), the contraction index
+//     is permuted identically on both sides;
+//   * the S^T accumulator of key sub-tile s holds keys s*16 + 4*kq + r for query j, which is
+//     exactly the B operand P^T[key][q] of O^T = V^T P^T when MFMA step (s, r) contracts over
+//     key = s*16 + 4*kq + r: probabilities never leave registers.  Its A operand V[key][d = 16 dt + j]
+//     is a lane-contiguous scalar load.
 template <int DH>
 __global__ __launch_bounds__(512) void self_attn_kernel(const float* __restrict__ qkv, int64_t row_stride, int H, int L,
                                                         float* __restrict__ out, int64_t out_row) {
     constexpr int NW = 8;
-    constexpr int NDT = DH / 32;
-    constexpr int LDR = DH + 4;                  // LDS row stride of the staged Q / K blocks (floats)
-    constexpr int F4R = DH / 4;                  // float4 per row
-    constexpr int RPI = 64 / F4R;                // rows one wave-wide load instruction covers
+    constexpr int NDT = DH / 16;                 // 16-wide d sub-tiles of O^T
+    constexpr int NC = DH / 16;                  // float4 chunks of a Q / K row per lane
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Os = smem;                         // [NW][DH][33]   (after the key loop)
-    float* Kst = smem;                        // [NW][32][LDR]  (during the key loop; aliases Os)
-    constexpr int kRegion = NW * DH * 33 > NW * 32 * LDR ? NW * DH * 33 : NW * 32 * LDR;
-    float* Ms = smem + kRegion;               // [NW][32]
-    float* Ls = Ms + NW * 32;                 // [NW][32]
-    float* Qs = Ls + NW * 32;                 // [32][LDR]
+    float* Os = smem;                         // [NW][DH][17]
+    float* Ms = Os + NW * DH * 17;            // [NW][16]
+    float* Ls = Ms + NW * 16;                 // [NW][16]
     const int bh = blockIdx.y;
     const int b = bh / H, h = bh - b * H;
     const int C = H * DH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, kh = lane >> 5;
-    const int q0 = blockIdx.x * 32;
+    const int lj = lane & 15, kq = lane >> 4;
+    const int q0 = blockIdx.x * 16;
+    const int q = q0 + lj;
     const float* base = qkv + (int64_t)b * L * row_stride + h * DH;     // q at +0, k at +C, v at +2C
 
-    // Q tile: 32 x DH floats, one float4 per thread (DH = 64) — row-contiguous
-    for (int idx = tid; idx < 32 * F4R; idx += 512) {
-        const int r = idx / F4R, c4 = idx - r * F4R;
-        const int qq = q0 + r;
-        f32x4 t4 = *reinterpret_cast<const f32x4*>(base + (int64_t)(qq < L ? qq : 0) * row_stride + c4 * 4);
-        if (qq >= L) t4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(&Qs[r * LDR + c4 * 4]) = t4;
+    f32x4v qf[NC];
+    {
+        const float* qp = base + (int64_t)(q < L ? q : 0) * row_stride + kq * 4;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) qf[c] = *reinterpret_cast<const f32x4v*>(qp + c * 16);
     }
     const int per = ((((L + NW - 1) / NW) + 31) / 32) * 32;              // keys per wave, multiple of 32
     const int k_begin = wave * per;
     const int k_end = (k_begin + per < L) ? k_begin + per : L;
-    float* Kw = Kst + wave * 32 * LDR;
-    // first K block of this wave: requested before the Q tile is waited for
-    f32x4 kst[32 / RPI];
-    auto load_k = [&](int kb) {
-#pragma unroll
-        for (int j = 0; j < 32 / RPI; ++j) {
-            const int r = j * RPI + lane / F4R, c4 = lane % F4R;
-            const int key = kb + r;
-            kst[j] = *reinterpret_cast<const f32x4*>(base + C + (int64_t)(key < L ? key : 0) * row_stride + c4 * 4);
-            if (key >= L) kst[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    if (k_begin < k_end) load_k(k_begin);
-    __syncthreads();
-    float qf[DH / 2];
-    {
-        const float scale = 1.4426950408889634f / sqrtf((float)DH);
-#pragma unroll
-        for (int c = 0; c < DH / 8; ++c) {
-            const f32x4 t4 = *reinterpret_cast<const f32x4*>(&Qs[li * LDR + kh * (DH / 2) + c * 4]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) qf[c * 4 + e] = t4[e] * scale;
-        }
-    }
+    const float scale = 1.4426950408889634f / sqrtf((float)DH);
 
-    f32x16 o[NDT];
+    f32x4v o[NDT];
 #pragma unroll
-    for (int d = 0; d < NDT; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    for (int d = 0; d < NDT; ++d) o[d] = f32x4v{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
+    bool q_scaled = false;
 
     for (int kb = k_begin; kb < k_end; kb += 32) {
-        // all loads of this 32-key block are issued up front (operands are L2-resident, the block is tiny:
-        // it is the load latency, not bandwidth, that sets this kernel's time)
-        // V fragments (lane-contiguous rows) are requested first, then the staged K block goes through LDS
-        float vv[16][NDT];
+        // all loads of this 32-key block are issued up front (it is the load latency that sets this kernel's time)
+        f32x4v kf[2][NC];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int vk = kb + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const float* vr = base + 2 * C + (int64_t)(vk < L ? vk : 0) * row_stride + li;
+        for (int s = 0; s < 2; ++s) {
+            const int key = kb + s * 16 + lj;
+            const float* kr = base + C + (int64_t)(key < L ? key : 0) * row_stride + kq * 4;
 #pragma unroll
-            for (int d = 0; d < NDT; ++d) vv[r][d] = vr[d * 32];
+            for (int c = 0; c < NC; ++c) kf[s][c] = *reinterpret_cast<const f32x4v*>(kr + c * 16);
         }
-        if (kb > k_begin) load_k(kb);
+        float vv[2][4][NDT];
 #pragma unroll
-        for (int j = 0; j < 32 / RPI; ++j)
-            *reinterpret_cast<f32x4*>(&Kw[(j * RPI + lane / F4R) * LDR + (lane % F4R) * 4]) = kst[j];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        f32x4 kf[DH / 8];
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int u = 0; u < DH / 8; ++u) kf[u] = *reinterpret_cast<const f32x4*>(&Kw[li * LDR + kh * (DH / 2) + u * 4]);
-        __builtin_amdgcn_wave_barrier();            // the block is consumed before the next one overwrites it
-        f32x16 sacc;
+            for (int r = 0; r < 4; ++r) {
+                const int vk = kb + s * 16 + 4 * kq + r;
+                const float* vr = base + 2 * C + (int64_t)(vk < L ? vk : 0) * row_stride + lj;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+                for (int d = 0; d < NDT; ++d) vv[s][r][d] = vk < L ? vr[d * 16] : 0.f;
+            }
+        if (!q_scaled) {                          // scores in the log2 domain
 #pragma unroll
-        for (int u = 0; u < DH / 8; ++u)
+            for (int c = 0; c < NC; ++c) qf[c] *= scale;
+            q_scaled = true;
+        }
+        f32x4v sacc[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[u][e], qf[u * 4 + e], sacc, 0, 0, 0);
+        for (int s = 0; s < 2; ++s) sacc[s] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    sacc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s][c][e], qf[c][e], sacc[s], 0, 0, 0);
         if (kb + 32 > L) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (kb + mfma32_row(r, lane) >= L) sacc[r] = -INFINITY;
-        }
-        float mx = sacc[0];
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
+                for (int r = 0; r < 4; ++r)
+                    if (kb + s * 16 + 4 * kq + r >= L) sacc[s][r] = -INFINITY;
+        }
+        float mx = fmaxf(fmaxf(fmaxf(sacc[0][0], sacc[0][1]), fmaxf(sacc[0][2], sacc[0][3])),
+                         fmaxf(fmaxf(sacc[1][0], sacc[1][1]), fmaxf(sacc[1][2], sacc[1][3])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float rs = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            sacc[r] = __builtin_amdgcn_exp2f(sacc[r] - m_new);
-            rs += sacc[r];
-        }
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sacc[s][r] = __builtin_amdgcn_exp2f(sacc[s][r] - m_new);
+                rs += sacc[s][r];
+            }
+        rs += __shfl_xor(rs, 16);
         rs += __shfl_xor(rs, 32);
         l_run = l_run * alpha + rs;
         m_run = m_new;
 #pragma unroll
-        for (int d = 0; d < NDT; ++d)
+        for (int d = 0; d < NDT; ++d) o[d] *= alpha;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int vk = kb + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int d = 0; d < NDT; ++d)
-                o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vk < L ? vv[r][d] : 0.f, sacc[r], o[d], 0, 0, 0);
-        }
+                for (int d = 0; d < NDT; ++d)
+                    o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[s][r][d], sacc[s][r], o[d], 0, 0, 0);
     }
-    // ---- combine the 8 key slices (Os aliases the K staging area: every wave must be past its loop)
-    __syncthreads();
+    // ---- combine the 8 key slices: O^T sub-tile d holds rows 16 d + 4 kq + r, column (query) lj
 #pragma unroll
     for (int d = 0; d < NDT; ++d)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Os[(wave * DH + d * 32 + mfma32_row(r, lane)) * 33 + li] = o[d][r];
-    if (kh == 0) {
-        Ms[wave * 32 + li] = m_run;
-        Ls[wave * 32 + li] = l_run;
+        for (int r = 0; r < 4; ++r) Os[(wave * DH + d * 16 + 4 * kq + r) * 17 + lj] = o[d][r];
+    if (kq == 0) {
+        Ms[wave * 16 + lj] = m_run;
+        Ls[wave * 16 + lj] = l_run;
     }
     __syncthreads();
-    for (int idx = tid; idx < 32 * DH; idx += 512) {
+    for (int idx = tid; idx < 16 * DH; idx += 512) {
         const int qq = idx / DH;
         const int d = idx - qq * DH;
         float mmax = -INFINITY;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) mmax = fmaxf(mmax, Ms[w * 32 + qq]);
+        for (int w = 0; w < NW; ++w) mmax = fmaxf(mmax, Ms[w * 16 + qq]);
         float num = 0.f, den = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-            const float wt = __builtin_amdgcn_exp2f(Ms[w * 32 + qq] - mmax);
-            num += wt * Os[(w * DH + d) * 33 + qq];
-            den += wt * Ls[w * 32 + qq];
+            const float wt = __builtin_amdgcn_exp2f(Ms[w * 16 + qq] - mmax);
+            num += wt * Os[(w * DH + d) * 17 + qq];
+            den += wt * Ls[w * 16 + qq];
         }
         if (q0 + qq < L) out[((int64_t)b * L + q0 + qq) * out_row + h * DH + d] = num / den;
     }
@@ -517,16 +500,8 @@ hipError_t merge_dh(const FlashArgs& a, hipStream_t s) {
 template <int DH>
 static hipError_t launch_self_dh(const float* qkv, int64_t row_stride, int B, int H, int L, float* out, int64_t out_row,
                                  hipStream_t s) {
-    const size_t region = (size_t)8 * DH * 33 > (size_t)8 * 32 * (DH + 4) ? (size_t)8 * DH * 33 : (size_t)8 * 32 * (DH + 4);
-    const size_t lds = (region + 2 * 8 * 32 + 32 * (DH + 4)) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_kernel<DH>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((self_attn_kernel<DH>), dim3(ceil_div(L, 32), B * H), dim3(512), lds, s, qkv, row_stride, H, L, out,
+    const size_t lds = ((size_t)8 * DH * 17 + 2 * 8 * 16) * sizeof(float);
+    hipLaunchKernelGGL((self_attn_kernel<DH>), dim3(ceil_div(L, 16), B * H), dim3(512), lds, s, qkv, row_stride, H, L, out,
                        out_row);
     return hipGetLastError();
 }

@@ -34,10 +34,9 @@ namespace {
 constexpr int kWaves = 4;
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int T>
+template <int T, int CB>                            // CB: 16-wide K chunks held in registers per batch
 __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a) {
     constexpr int S = T / 16;                       // 16x16 sub-tiles per tile edge
-    constexpr int CB = (T == 16) ? 12 : 4;          // 16-wide K chunks held in registers per batch
     constexpr int OPT = T * T / (kWaves * kWave);   // outputs per thread in the epilogue (1 or 4)
     constexpr int TPR = T / OPT;                    // threads per output row
     __shared__ __attribute__((aligned(16))) float red[kWaves * S * S * 4 * kWave];
@@ -77,11 +76,75 @@ __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a
         x2row[s] = add2 ? a.X2 + (int64_t)(m_ok[s] ? m : 0) * a.ldx2 + kbase : nullptr;
     }
 
+    const float* gam = a.gn_sums ? a.gn_gamma + g * a.gGamma + kbase : nullptr;
+    const float* bet = a.gn_sums ? a.gn_beta + g * a.gGamma + kbase : nullptr;
+
+    // ---- issue every independent global load up front: this kernel is latency-bound (operands come
+    // from the other XCDs' writes or from HBM/MALL after the attention kernel swept the L2s), so the
+    // first A/B batch and all epilogue operands are requested before anything waits on anything.
+    f32x4v av[S][CB], bv[S][CB];
+    auto load_batch = [&](int c0) {
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            if (c0 + c < nchunks) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    av[s][c] = *reinterpret_cast<const f32x4v*>(xrow[s] + (c0 + c) * 64);
+                    bv[s][c] = *reinterpret_cast<const f32x4v*>(wrow[s] + (c0 + c) * 64);
+                }
+            }
+        }
+    };
+    load_batch(0);
+    // prologue operands of the first PB chunks (covers K = 256): requested now, consumed after the row statistics
+    constexpr int PB = 4;
+    f32x4v pgam[PB], pbet[PB], px2[S][PB];
+    {
+        const float* pg = a.ln_gamma ? a.ln_gamma + kbase : gam;
+        const float* pb = a.ln_gamma ? a.ln_beta + kbase : bet;
+#pragma unroll
+        for (int c = 0; c < PB; ++c) {
+            if (c < nchunks) {
+                if (pg) {
+                    pgam[c] = *reinterpret_cast<const f32x4v*>(pg + c * 64);
+                    pbet[c] = *reinterpret_cast<const f32x4v*>(pb + c * 64);
+                }
+                if (add2) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) px2[s][c] = *reinterpret_cast<const f32x4v*>(x2row[s] + c * 64);
+                }
+            }
+        }
+    }
+    // epilogue operands of this thread's (row, OPT cols)
+    const int erow = tid / TPR;
+    const int ec = (tid % TPR) * OPT;
+    const int eom = m0 + erow;
+    const bool erow_ok = eom < a.M;
+    const float* bias = a.bias ? a.bias + g * a.gBias : nullptr;
+    float e_bias[OPT], e_r[OPT], e_rg[OPT], e_rb[OPT];
+    float rmean = 0.f, rrstd = 1.f;
+#pragma unroll
+    for (int e = 0; e < OPT; ++e) {
+        e_bias[e] = 0.f; e_r[e] = 0.f; e_rg[e] = 1.f; e_rb[e] = 0.f;
+        const int on = n0 + ec + e;
+        if (on < a.N) {
+            if (bias) e_bias[e] = bias[on];
+            if (a.R && erow_ok) e_r[e] = a.R[(int64_t)eom * a.ldr + on];
+            if (a.rln_stats) {
+                e_rg[e] = a.rln_gamma[on];
+                e_rb[e] = a.rln_beta[on];
+            }
+        }
+    }
+    if (a.rln_stats && erow_ok) {
+        rmean = a.rln_stats[(int64_t)eom * 2 + 0];
+        rrstd = a.rln_stats[(int64_t)eom * 2 + 1];
+    }
+
     // ---- GroupNorm(1,C) prologue: scene-wide moments accumulated by the producer's epilogue
     // (a tile's rows lie in one scene whenever rows_per_scene % T == 0; otherwise per sub-tile row)
     float gn_mean[S], gn_rstd[S];
-    const float* gam = nullptr;
-    const float* bet = nullptr;
     if (a.gn_sums) {
         const double cnt = (double)a.gn_rows_per_scene * (double)a.K;
         const int sc_lo = m0 / a.gn_rows_per_scene;
@@ -121,51 +184,6 @@ __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a
                 gn_rstd[s] = (float)(1.0 / sqrt(var + (double)a.norm_eps));
             }
         }
-        gam = a.gn_gamma + g * a.gGamma + kbase;
-        bet = a.gn_beta + g * a.gGamma + kbase;
-    }
-
-    // ---- issue every independent global load up front: this kernel is latency-bound (operands come
-    // from the other XCDs' writes or from HBM/MALL after the attention kernel swept the L2s), so the
-    // first A/B batch and all epilogue operands are requested before anything waits on anything.
-    f32x4v av[S][CB], bv[S][CB];
-    auto load_batch = [&](int c0) {
-#pragma unroll
-        for (int c = 0; c < CB; ++c) {
-            if (c0 + c < nchunks) {
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    av[s][c] = *reinterpret_cast<const f32x4v*>(xrow[s] + (c0 + c) * 64);
-                    bv[s][c] = *reinterpret_cast<const f32x4v*>(wrow[s] + (c0 + c) * 64);
-                }
-            }
-        }
-    };
-    load_batch(0);
-    // epilogue operands of this thread's (row, OPT cols)
-    const int erow = tid / TPR;
-    const int ec = (tid % TPR) * OPT;
-    const int eom = m0 + erow;
-    const bool erow_ok = eom < a.M;
-    const float* bias = a.bias ? a.bias + g * a.gBias : nullptr;
-    float e_bias[OPT], e_r[OPT], e_rg[OPT], e_rb[OPT];
-    float rmean = 0.f, rrstd = 1.f;
-#pragma unroll
-    for (int e = 0; e < OPT; ++e) {
-        e_bias[e] = 0.f; e_r[e] = 0.f; e_rg[e] = 1.f; e_rb[e] = 0.f;
-        const int on = n0 + ec + e;
-        if (on < a.N) {
-            if (bias) e_bias[e] = bias[on];
-            if (a.R && erow_ok) e_r[e] = a.R[(int64_t)eom * a.ldr + on];
-            if (a.rln_stats) {
-                e_rg[e] = a.rln_gamma[on];
-                e_rb[e] = a.rln_beta[on];
-            }
-        }
-    }
-    if (a.rln_stats && erow_ok) {
-        rmean = a.rln_stats[(int64_t)eom * 2 + 0];
-        rrstd = a.rln_stats[(int64_t)eom * 2 + 1];
     }
 
     // ---- LayerNorm prologue: row statistics of A over the full K, reduced across the 4 kq lane groups
@@ -256,8 +274,9 @@ __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a
         for (int c = 0; c < CB; ++c) {
             if (c0 + c < nchunks) {
                 if (a.ln_gamma) {
-                    const f32x4v gv = *reinterpret_cast<const f32x4v*>(lng + (c0 + c) * 64);
-                    const f32x4v be = *reinterpret_cast<const f32x4v*>(lnb + (c0 + c) * 64);
+                    const bool pre = (c < PB) && (c0 == 0);
+                    const f32x4v gv = pre ? pgam[c < PB ? c : 0] : *reinterpret_cast<const f32x4v*>(lng + (c0 + c) * 64);
+                    const f32x4v be = pre ? pbet[c < PB ? c : 0] : *reinterpret_cast<const f32x4v*>(lnb + (c0 + c) * 64);
 #pragma unroll
                     for (int s = 0; s < S; ++s)
 #pragma unroll
@@ -265,11 +284,13 @@ __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a
                 }
                 if (add2) {
 #pragma unroll
-                    for (int s = 0; s < S; ++s) av[s][c] += *reinterpret_cast<const f32x4v*>(x2row[s] + (c0 + c) * 64);
+                    for (int s = 0; s < S; ++s)
+                        av[s][c] += ((c < PB) && (c0 == 0)) ? px2[s][c < PB ? c : 0] : *reinterpret_cast<const f32x4v*>(x2row[s] + (c0 + c) * 64);
                 }
                 if (a.gn_sums) {
-                    const f32x4v gv = *reinterpret_cast<const f32x4v*>(gam + (c0 + c) * 64);
-                    const f32x4v be = *reinterpret_cast<const f32x4v*>(bet + (c0 + c) * 64);
+                    const bool pre = (c < PB) && (c0 == 0) && !a.ln_gamma;
+                    const f32x4v gv = pre ? pgam[c < PB ? c : 0] : *reinterpret_cast<const f32x4v*>(gam + (c0 + c) * 64);
+                    const f32x4v be = pre ? pbet[c < PB ? c : 0] : *reinterpret_cast<const f32x4v*>(bet + (c0 + c) * 64);
 #pragma unroll
                     for (int s = 0; s < S; ++s)
 #pragma unroll
@@ -386,7 +407,11 @@ static int pick_tile(int64_t tiles32) {
         return e ? atoi(e) : 0;
     }();
     if (forced == 16 || forced == 32) return forced;
-    return tiles32 < device_num_cus() ? 16 : 32;
+    static const int below = [] {
+        const char* e = getenv("PARQ_LINEAR_T16_BELOW");
+        return e ? atoi(e) : 0;
+    }();
+    return tiles32 < (below > 0 ? below : device_num_cus()) ? 16 : 32;
 }
 
 hipError_t launch_linear(const LinearArgs& a, int groups, hipStream_t s) {
@@ -396,10 +421,15 @@ hipError_t launch_linear(const LinearArgs& a, int groups, hipStream_t s) {
     const int64_t tiles = (int64_t)ceil_div(a.N, T) * ceil_div(a.M, T);
     if (tiles > 0x7fffffffLL) return hipErrorInvalidValue;
     dim3 grid((unsigned)tiles, groups, 1);
-    if (T == 16)
-        hipLaunchKernelGGL(linear_f32_kernel<16>, grid, dim3(kWaves * kWave), 0, s, a);
+    const int wave_chunks = ceil_div(a.K / 16, kWaves);       // whole K share in registers when it fits
+    if (T == 32)
+        hipLaunchKernelGGL((linear_f32_kernel<32, 4>), grid, dim3(kWaves * kWave), 0, s, a);
+    else if (wave_chunks <= 4)
+        hipLaunchKernelGGL((linear_f32_kernel<16, 4>), grid, dim3(kWaves * kWave), 0, s, a);
+    else if (wave_chunks <= 6)
+        hipLaunchKernelGGL((linear_f32_kernel<16, 6>), grid, dim3(kWaves * kWave), 0, s, a);
     else
-        hipLaunchKernelGGL(linear_f32_kernel<32>, grid, dim3(kWaves * kWave), 0, s, a);
+        hipLaunchKernelGGL((linear_f32_kernel<16, 12>), grid, dim3(kWaves * kWave), 0, s, a);
     return hipGetLastError();
 }
 

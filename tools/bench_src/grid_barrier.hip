@@ -42,13 +42,40 @@ __global__ void barrier_only(unsigned* counter, int phases) {
     for (int p = 0; p < phases; ++p) grid_barrier(counter, (unsigned)(gridDim.x * (p + 1)));
 }
 
+// single-XCD variant: launch 8x the workgroups, only blockIdx % 8 == 0 (all dispatched to XCD 0) participate
+__global__ void persistent_xcd(float* bufA, float* bufB, unsigned* counter, int phases) {
+    if (blockIdx.x & 7) return;
+    const int nb = gridDim.x >> 3, b = blockIdx.x >> 3;
+    for (int p = 0; p < phases; ++p) {
+        const float* in = (p & 1) ? bufB : bufA;
+        float* out = (p & 1) ? bufA : bufB;
+        phase_body(in, out, b, nb, p);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // same L2: no writeback needed
+            while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(nb * (p + 1))) __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+    }
+}
+__global__ void persistent_xcd_agent(float* bufA, float* bufB, unsigned* counter, int phases) {
+    if (blockIdx.x & 7) return;
+    const int nb = gridDim.x >> 3, b = blockIdx.x >> 3;
+    for (int p = 0; p < phases; ++p) {
+        const float* in = (p & 1) ? bufB : bufA;
+        float* out = (p & 1) ? bufA : bufB;
+        phase_body(in, out, b, nb, p);
+        grid_barrier(counter, (unsigned)(nb * (p + 1)));
+    }
+}
+
 int main() {
     const int phases = 200;
     float *A, *B; unsigned* c;
     hipMalloc(&A, 256 * 2048 * 4); hipMalloc(&B, 256 * 2048 * 4); hipMalloc(&c, 4);
     hipMemset(A, 0, 256 * 2048 * 4); hipMemset(B, 0, 256 * 2048 * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int nb : {32, 64, 128, 256}) {
+    for (int nb : {16, 32, 64, 128, 256}) {
         float ms;
         for (int rep = 0; rep < 2; ++rep) {
             hipMemset(c, 0, 4);
@@ -66,6 +93,24 @@ int main() {
             hipEventElapsedTime(&ms, e0, e1);
         }
         printf("G=%3d persistent + barrier: %.2f us/phase\n", nb, ms * 1e3 / phases);
+        if (nb <= 32) {
+            for (int rep = 0; rep < 2; ++rep) {
+                hipMemset(c, 0, 4);
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(persistent_xcd_agent, dim3(nb * 8), dim3(256), 0, 0, A, B, c, phases);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                hipEventElapsedTime(&ms, e0, e1);
+            }
+            printf("G=%3d one-XCD, agent-scope barrier: %.2f us/phase\n", nb, ms * 1e3 / phases);
+            for (int rep = 0; rep < 2; ++rep) {
+                hipMemset(c, 0, 4);
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(persistent_xcd, dim3(nb * 8), dim3(256), 0, 0, A, B, c, phases);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                hipEventElapsedTime(&ms, e0, e1);
+            }
+            printf("G=%3d one-XCD, relaxed barrier    : %.2f us/phase (result validity not checked)\n", nb, ms * 1e3 / phases);
+        }
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0);
             for (int p = 0; p < phases; ++p)
