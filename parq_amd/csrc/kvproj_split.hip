@@ -15,6 +15,8 @@
 // exactly one 16-byte chunk of the cache layout, so the epilogue is bias + split + 16-byte stores.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace parq {
 
 namespace {
@@ -260,13 +262,21 @@ __global__ __launch_bounds__(kThreads) void kvproj_split_kernel(KvProjArgs a) {
 constexpr int kWsMaxKSteps = 4;          // K = C <= 256
 constexpr int kWsDepth = 2;              // token k-steps in flight
 
-__global__ __launch_bounds__(kThreads, 1) void kvproj_ws_kernel(KvProjArgs a, int total_rt, int nrt, int P) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];      // [2 buffers][A_hi 128x64 | A_lo 128x64]
+// NWV waves own NWV*32 output columns; TM token rows per tile.  <4,128>: one wave per SIMD, 388 registers.
+// <8,64>: two waves per SIMD (<= 256 registers each) so one wave's load/barrier stalls are covered by the
+// other's MFMAs, and a token tile is re-read by 2 column slices instead of 4.
+template <int NWV, int TM>
+__global__ __launch_bounds__(NWV * 64, 1) void kvproj_ws_kernel(KvProjArgs a, int total_rt, int nrt, int P) {
+    constexpr int kThr = NWV * 64;
+    constexpr int kCols = NWV * 32;
+    constexpr int RT = TM / 32;                  // 32-row blocks per tile (accumulators per wave)
+    constexpr int NI = TM * 8 / kThr;            // 8-float pieces of a k-step tile per thread
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];      // [2 buffers][A_hi TMx64 | A_lo TMx64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
     const int C = a.C;
     const int nk = C / kBK;
-    const int nslice = 2 * C / kBN;
+    const int nslice = 2 * C / kCols;
     // id -> (persistent slot p, column slice): the slices of one slot share p % 8, i.e. the XCD (L2 reuse of tokens)
     int p, slice;
     {
@@ -277,7 +287,7 @@ __global__ __launch_bounds__(kThreads, 1) void kvproj_ws_kernel(KvProjArgs a, in
         slice = r >> 3;
     }
     if (p >= P) return;
-    const int n0 = slice * kBN;
+    const int n0 = slice * kCols;
     const int col = n0 + wave * 32 + li;          // this lane's output column (B operand row of W_kv)
     const int headcol = col >> 6;                 // wave-uniform: 32 columns never straddle a head
     const bool isK = headcol < a.H;
@@ -301,13 +311,13 @@ __global__ __launch_bounds__(kThreads, 1) void kvproj_ws_kernel(KvProjArgs a, in
 
     // token staging registers, kWsDepth k-steps in flight (HBM latency under load is ~3 us, one k-step of MFMAs
     // ~0.75 us: with a single step in flight the loop runs at latency, not at MFMA or HBM speed)
-    float4 areg[kWsDepth][8];
-    auto gload = [&](int tile, int ks, float4 (&dst)[8]) {
-        const int b = tile / nrt, m0 = (tile - b * nrt) * kBM;
+    float4 areg[kWsDepth][2 * NI];
+    auto gload = [&](int tile, int ks, float4 (&dst)[2 * NI]) {
+        const int b = tile / nrt, m0 = (tile - b * nrt) * TM;
         const float* Xb = a.X + ((int64_t)b * a.N) * C + ks * kBK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int id = tid + i * kThreads;
+        for (int i = 0; i < NI; ++i) {
+            const int id = tid + i * kThr;
             const int row = id >> 3, c = id & 7;
             const int tok = m0 + row;
             if (tok < a.N) {
@@ -320,12 +330,12 @@ __global__ __launch_bounds__(kThreads, 1) void kvproj_ws_kernel(KvProjArgs a, in
             }
         }
     };
-    auto swrite = [&](int buf, const float4 (&src)[8]) {
-        _Float16* Ahi = lds + buf * (2 * kBM * kBK);
-        _Float16* Alo = Ahi + kBM * kBK;
+    auto swrite = [&](int buf, const float4 (&src)[2 * NI]) {
+        _Float16* Ahi = lds + buf * (2 * TM * kBK);
+        _Float16* Alo = Ahi + TM * kBK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int id = tid + i * kThreads;
+        for (int i = 0; i < NI; ++i) {
+            const int id = tid + i * kThr;
             const int row = id >> 3, c = id & 7;
             const int pos = c ^ ((row >> 1) & 7);
             float x[8] = {src[2 * i].x, src[2 * i].y, src[2 * i].z, src[2 * i].w,
@@ -339,7 +349,7 @@ __global__ __launch_bounds__(kThreads, 1) void kvproj_ws_kernel(KvProjArgs a, in
     // linear k-step stream over this workgroup's tiles: step q -> (tile p + (q / nk) * P, ks = q % nk)
     const int my_tiles = p < total_rt ? (total_rt - p + P - 1) / P : 0;
     const int total_steps = my_tiles * nk;
-    auto issue = [&](int q, float4 (&dst)[8]) {
+    auto issue = [&](int q, float4 (&dst)[2 * NI]) {
         if (q < total_steps) gload(p + (q / nk) * P, q % nk, dst);
     };
 
@@ -349,9 +359,9 @@ __global__ __launch_bounds__(kThreads, 1) void kvproj_ws_kernel(KvProjArgs a, in
     issue(0, areg[0]);
     issue(1, areg[1]);
     for (int tile = p; tile < total_rt; tile += P) {
-        f32x16 acc[4];
+        f32x16 acc[RT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 #pragma unroll
@@ -362,13 +372,13 @@ __global__ __launch_bounds__(kThreads, 1) void kvproj_ws_kernel(KvProjArgs a, in
                 swrite(buf, areg[ks & 1]);                     // tokens of this k-step (requested two steps ago)
                 issue(step + kWsDepth, areg[ks & 1]);          // refill the slot: two k-steps ahead, across tiles
                 __syncthreads();
-                const _Float16* Ahi = lds + buf * (2 * kBM * kBK);
-                const _Float16* Alo = Ahi + kBM * kBK;
+                const _Float16* Ahi = lds + buf * (2 * TM * kBK);
+                const _Float16* Alo = Ahi + TM * kBK;
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) {
-                    half8 xh[4], xl[4];
+                    half8 xh[RT], xl[RT];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                    for (int t = 0; t < RT; ++t) {
                         const int row = t * 32 + li;
                         const int posr = (4 * kh + s2) ^ ((row >> 1) & 7);
                         xh[t] = *reinterpret_cast<const half8*>(Ahi + row * kBK + posr * 8);
@@ -377,18 +387,18 @@ __global__ __launch_bounds__(kThreads, 1) void kvproj_ws_kernel(KvProjArgs a, in
                     const half8 wh = wfr[ks][s2][0], wlo = wfr[ks][s2][1];
                     if (isK) {          // transposed product: rows = d, cols = tokens
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[t], acc[t], 0, 0, 0);
+                        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[t], acc[t], 0, 0, 0);
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[t], acc[t], 0, 0, 0);
+                        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[t], acc[t], 0, 0, 0);
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh[t], acc[t], 0, 0, 0);
+                        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh[t], acc[t], 0, 0, 0);
                     } else {            // rows = tokens, cols = d
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[t], wh, acc[t], 0, 0, 0);
+                        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[t], wh, acc[t], 0, 0, 0);
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[t], wlo, acc[t], 0, 0, 0);
+                        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[t], wlo, acc[t], 0, 0, 0);
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[t], wh, acc[t], 0, 0, 0);
+                        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[t], wh, acc[t], 0, 0, 0);
                     }
                 }
                 ++step;
@@ -396,9 +406,9 @@ __global__ __launch_bounds__(kThreads, 1) void kvproj_ws_kernel(KvProjArgs a, in
         }
         // ---- epilogue of this tile: bias, split, 16-byte chunks of the cache blocks (this wave owns one
         // 32-wide half `ct` of its head: chunks 2ct+m (K) / rows 32ct+li (V))
-        const int b = tile / nrt, m0 = (tile - b * nrt) * kBM;
+        const int b = tile / nrt, m0 = (tile - b * nrt) * TM;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < RT; ++t) {
             const int blk = (m0 >> 5) + t;
             if (blk >= nblk) continue;                                   // wave-uniform
             _Float16* out = a.cache + (((int64_t)b * a.H + h) * nblk + blk) * kBlkHalfs;
@@ -447,6 +457,26 @@ __global__ void split_f32_kernel(const float* __restrict__ src, _Float16* __rest
 
 }  // namespace
 
+template <int NWV, int TM>
+static hipError_t launch_ws(const KvProjArgs& a, int B, hipStream_t s) {
+    static bool attr = false;
+    const size_t lds = (size_t)2 * 2 * TM * kBK * sizeof(_Float16);
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kvproj_ws_kernel<NWV, TM>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    const int nslice = 2 * a.C / (NWV * 32), nrt = ceil_div(a.N, TM);
+    const int total_rt = B * nrt;
+    int P = device_num_cus() / nslice;
+    if (P < 1) P = 1;
+    if (P > total_rt) P = total_rt;
+    dim3 grid(ceil_div(P, 8) * 8 * nslice, 1, 1);
+    hipLaunchKernelGGL((kvproj_ws_kernel<NWV, TM>), grid, dim3(NWV * 64), lds, s, a, total_rt, nrt, P);
+    return hipGetLastError();
+}
+
 hipError_t launch_split_f32(const float* src, void* hi, void* lo, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, s, src,
                        reinterpret_cast<_Float16*>(hi), reinterpret_cast<_Float16*>(lo), n);
@@ -471,21 +501,12 @@ hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void*
     const int nct = 2 * C / kBN, nrt = ceil_div(N, kBM);
     if (C <= kWsMaxKSteps * kBK && C % (2 * kBK) == 0) {
         // W-stationary persistent kernel: one workgroup per CU, column slices of one slot on one XCD
-        static bool attr2 = false;
-        const size_t lds2 = (size_t)2 * 2 * kBM * kBK * sizeof(_Float16);       // 64 KB
-        if (!attr2) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kvproj_ws_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            if (e != hipSuccess) return e;
-            attr2 = true;
-        }
-        const int total_rt = B * nrt;
-        int P = device_num_cus() / nct;
-        if (P < 1) P = 1;
-        if (P > total_rt) P = total_rt;
-        dim3 grid(ceil_div(P, 8) * 8 * nct, 1, 1);
-        hipLaunchKernelGGL(kvproj_ws_kernel, grid, dim3(kThreads), lds2, s, a, total_rt, nrt, P);
-        return hipGetLastError();
+        static const int waves = [] {
+            const char* e = getenv("PARQ_KVPROJ_WAVES");
+            return e ? atoi(e) : 8;
+        }();
+        if (waves == 8 && (2 * C) % 256 == 0) return launch_ws<8, 64>(a, B, s);
+        return launch_ws<4, 128>(a, B, s);
     }
     dim3 grid(ceil_div(nrt, 8) * 8 * nct, B, 1);
     if (grid.y > 65535) return hipErrorInvalidValue;
