@@ -100,8 +100,17 @@ __global__ __launch_bounds__(256) void kvsplit_convert_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+// LDS holds a ring of kRing stages filled by LDS-DMA; every wave passes ONE workgroup barrier per stage (its
+// "sync point": wait for its own DMA of stage t+2, barrier, request stage t+3 into the slot of stage t-1).
+// Measured and rejected on this structure (flash launch, cfg 3): locking the two waves of a SIMD half a stage
+// apart by giving waves 4..7 their sync point mid-stage (165 us against 152 us in phase: out of phase the two
+// waves' MFMA runs collide, and the in-wave MFMA/VALU interleave already covers the dependent points);
+// reading the next stage's first K fragments before the barrier (+5..12 %, register pressure);
+// register staging instead of LDS-DMA (+0.5 %, 16 more VGPRs).
+constexpr int kRing = 4;
+
 __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, const _Float16* __restrict__ cache) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];       // [2 stages][kStageBlks][kBlkHalfs]
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];       // [kRing stages][kStageBlks][kBlkHalfs]
     constexpr int NT = kNW * 64;
     constexpr int STAGE16 = kStageBlks * kBlkBytes / 16;                     // 16-byte chunks per stage
     constexpr int LD = STAGE16 / NT;                                         // per thread
@@ -143,18 +152,18 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
     const uint4* gsrc = reinterpret_cast<const uint4*>(cache + (int64_t)bh * nblk * kBlkHalfs);
     const int64_t total16 = (int64_t)nblk * (kBlkBytes / 16);
 
-    uint4 stg[LD];
-    auto gload = [&](int st) {
+    // global -> LDS staging by LDS-DMA (global_load_lds_dwordx4): the LDS image of a stage equals its global
+    // image, so lane l of wave w copies 16-byte chunk (i*NT + w*64 + l) to the same chunk of the ring slot; no
+    // staging registers, no ds_write.  Lanes past the end of the cache are masked off (the slot keeps finite
+    // stale data there, see the zero fill below; such keys get probability 0).
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    auto gload = [&](int st, int slot) {
 #pragma unroll
         for (int i = 0; i < LD; ++i) {
             const int64_t idx = (int64_t)st * STAGE16 + tid + i * NT;
-            stg[i] = idx < total16 ? gsrc[idx] : uint4{0u, 0u, 0u, 0u};
+            lds_byte* dst = (lds_byte*)(smem_h) + ((size_t)slot * STAGE16 + i * NT + wave * 64) * 16;
+            if (idx < total16) __builtin_amdgcn_global_load_lds(gsrc + idx, dst, 16, 0, 0);
         }
-    };
-    auto swrite = [&](int buf) {
-        uint4* dst = reinterpret_cast<uint4*>(smem_h) + buf * STAGE16;
-#pragma unroll
-        for (int i = 0; i < LD; ++i) dst[tid + i * NT] = stg[i];
     };
 
     f32x16 o[2];
@@ -164,33 +173,45 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    if (t_begin < t_end) {
-        gload(t_begin);
-        swrite(0);
+    // a stage that reaches past the last cache block leaves part of its slot unwritten: make that finite
+    if ((nblk % kStageBlks) != 0 && t_end == nst) {
+        uint4* z = reinterpret_cast<uint4*>(smem_h);
+        for (int i = tid; i < kRing * STAGE16; i += NT) z[i] = uint4{0u, 0u, 0u, 0u};
+        __syncthreads();
     }
+    if (t_begin < t_end) gload(t_begin, 0);
+    if (t_begin + 1 < t_end) gload(t_begin + 1, 1);
+    if (t_begin + 2 < t_end) gload(t_begin + 2, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // one per stage and wave: stage t+2 (requested a stage ago) is published, stage t+3 is requested into the
+    // slot of stage t-1, which every wave left before the previous barrier
+    auto sync_point = [&](int t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA has landed (hipcc does not wait for it)
+        __syncthreads();
+        if (t + 3 < t_end) gload(t + 3, (t + 3 - t_begin) & (kRing - 1));
+    };
+
+    // state of the stage in flight
+    f32x16 sacc[2];
+    half8 phi[2][2], plo[2][2];
+    half8 kf[2][8];          // K fragments of both blocks: [kb][2*s + {hi,lo}]
+    float rs = 0.f, mx1 = 0.f;
 
     for (int t = t_begin; t < t_end; ++t) {
-        const int buf = (t - t_begin) & 1;
-        const bool more = t + 1 < t_end;
-        if (more) gload(t + 1);
-        if (active) {
-            const int nb = (nblk - t * kStageBlks) < kStageBlks ? (nblk - t * kStageBlks) : kStageBlks;   // wave-uniform
-            const _Float16* S0 = smem_h + buf * kStageBlks * kBlkHalfs;
-            const int ksw = (li >> 1) & 7;
-            static_assert(kStageBlks == 2, "the software pipeline below is written for two blocks per stage");
-            // Software pipeline over the two 32-key blocks of the stage, written so that every VALU section
-            // (softmax of one block) sits between the MFMAs of the other block and can issue in their shadow:
-            //     QK(b0) | QK(b1) + softmax(b0) | PV(b0) + softmax(b1) | PV(b1)
-            f32x16 sacc[2];
-            half8 phi[2][2], plo[2][2];
-            half8 kf[2][8];          // K fragments of both blocks: [kb][2*s + {hi,lo}]
-            float rs = 0.f;
-
+        const int buf = (t - t_begin) & (kRing - 1);
+        const int nb = (nblk - t * kStageBlks) < kStageBlks ? (nblk - t * kStageBlks) : kStageBlks;   // wave-uniform
+        const _Float16* S0 = smem_h + buf * kStageBlks * kBlkHalfs;
+        const int ksw = (li >> 1) & 7;
+        static_assert(kStageBlks == 2, "the software pipeline below is written for two blocks per stage");
+        // Software pipeline over the two 32-key blocks of the stage, written so that every VALU section
+        // (softmax of one block) sits between the MFMAs of the other block and can issue in their shadow:
+        //     QK(b0) | QK(b1) + softmax(b0) || PV(b0) + softmax(b1) | PV(b1)
+        {
             // LDS fragment reads are issued a full MFMA group ahead of their use (ds_read latency is
             // otherwise exposed in front of every 3-MFMA step: ~30 % of the wave's time)
-            auto load_k = [&](int kb) {
-                const _Float16* B0 = S0 + kb * kBlkHalfs;
+            auto load_k = [&](const _Float16* St, int kb) {
+                const _Float16* B0 = St + kb * kBlkHalfs;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int pos = (4 * kh + s) ^ ksw;
@@ -265,65 +286,70 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
                 for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[dt], plo[kb][m], o[dt], 0, 0, 0);
             };
 
-            auto run_stage = [&](auto tail_tag) {
+            auto first_half = [&](auto tail_tag) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-            load_k(0);
-            load_k(1);
-            // ---- QK(b0)
+                    for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+                rs = 0.f;
+                load_k(S0, 0);
+                load_k(S0, 1);
+                // ---- QK(b0)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) qk_step(0, s);
-            {
-                const float mx0 = block_mx(0, tail_tag);
-                if (__any(mx0 > m_run + a.defer_log2)) rescale(mx0);
-            }
-            // ---- QK(b1) with softmax(b0) in its shadow: one straight-line region, the scheduler is told to
-            // place ~8 VALU/TRANS instructions behind every MFMA (in-order issue: VALU work that merely FOLLOWS
-            // a run of MFMAs cannot overlap them)
-            qk_step(1, 0);
-            qk_step(1, 1);
-            softmax_half(0, 0);
-            qk_step(1, 2);
-            qk_step(1, 3);
-            softmax_half(0, 1);
-#pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x402, 9, 0);          // 9 VALU / TRANS
-            }
-            const float mx1 = block_mx(1, tail_tag);
-            if (!__any(mx1 > m_run + a.defer_log2)) {
-                // ---- common case: PV(b0) with softmax(b1) in its shadow
-                pv_step(0, 0);
-                softmax_half(1, 0);
-                pv_step(0, 1);
-                softmax_half(1, 1);
+                for (int s = 0; s < 4; ++s) qk_step(0, s);
+                {
+                    const float mx0 = block_mx(0, tail_tag);
+                    if (__any(mx0 > m_run + a.defer_log2)) rescale(mx0);
+                }
+                // ---- QK(b1) with softmax(b0) in its shadow: one straight-line region, the scheduler is told to
+                // place ~8 VALU/TRANS instructions behind every MFMA (in-order issue: VALU work that merely FOLLOWS
+                // a run of MFMAs cannot overlap them)
+                qk_step(1, 0);
+                qk_step(1, 1);
+                softmax_half(0, 0);
+                qk_step(1, 2);
+                qk_step(1, 3);
+                softmax_half(0, 1);
 #pragma unroll
                 for (int i = 0; i < 12; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x402, 9, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x402, 9, 0);          // 9 VALU / TRANS
                 }
-            } else {
-                pv_step(0, 0);
-                pv_step(0, 1);
-                rescale(mx1);
-                softmax_half(1, 0);
-                softmax_half(1, 1);
-            }
-            // ---- PV(b1)  (a block past the end has p = 0 and zero-filled V: contributes nothing)
-            pv_step(1, 0);
-            pv_step(1, 1);
+                mx1 = block_mx(1, tail_tag);
+            };
+            auto second_half = [&]() {
+                if (!__any(mx1 > m_run + a.defer_log2)) {
+                    // ---- common case: PV(b0) with softmax(b1) in its shadow
+                    pv_step(0, 0);
+                    softmax_half(1, 0);
+                    pv_step(0, 1);
+                    softmax_half(1, 1);
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                        __builtin_amdgcn_sched_group_barrier(0x402, 9, 1);
+                    }
+                } else {
+                    pv_step(0, 0);
+                    pv_step(0, 1);
+                    rescale(mx1);
+                    softmax_half(1, 0);
+                    softmax_half(1, 1);
+                }
+                // ---- PV(b1)  (a block past the end has p = 0 and zero-filled V: contributes nothing)
+                pv_step(1, 0);
+                pv_step(1, 1);
+                rs += __shfl_xor(rs, 32);
+                l_run += rs;
             };
             const bool tail_stage = (nb < kStageBlks) || ((t + 1) * kStageBlks >= nblk && (a.Lk & 31) != 0);   // wave-uniform
-            if (tail_stage) run_stage(std::true_type{});
-            else run_stage(std::false_type{});
-            rs += __shfl_xor(rs, 32);
-            l_run += rs;
+            if (active) {
+                if (tail_stage) first_half(std::true_type{});
+                else first_half(std::false_type{});
+            }
+            if (active) second_half();
+            sync_point(t);
         }
-        if (more) swrite(buf ^ 1);
-        __syncthreads();
     }
 
     if (active) {
@@ -368,13 +394,14 @@ hipError_t launch_kvsplit_convert(const float* K, const float* V, int64_t k_batc
 hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t s) {
     if (a.dh != kDH || a.nsplit < 1 || a.nsplit > 256) return hipErrorInvalidValue;
     static bool attr_set = false;
-    const size_t lds = (size_t)2 * kStageBlks * kBlkBytes;
+    const size_t lds = (size_t)kRing * kStageBlks * kBlkBytes;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_split_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+
     FlashArgs b = a;
     b.defer_log2 = kDeferLog2;
     if (const char* e = getenv("PARQ_DEFER_LOG2")) b.defer_log2 = (float)atof(e);      // debugging knob
