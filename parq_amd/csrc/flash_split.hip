@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void kvsplit_convert_kernel(const float* __res
 // apart by giving waves 4..7 their sync point mid-stage (165 us against 152 us in phase: out of phase the two
 // waves' MFMA runs collide, and the in-wave MFMA/VALU interleave already covers the dependent points);
 // reading the next stage's first K fragments before the barrier (+5..12 %, register pressure);
-// register staging instead of LDS-DMA (+0.5 %, 16 more VGPRs).
+// register staging instead of LDS-DMA (+0.5 %, 16 more VGPRs); one barrier per TWO stages (+4..6 %: the
+// barrier keeps the eight waves on the same LDS blocks, which the kernel evidently profits from).
 constexpr int kRing = 4;
 
 __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, const _Float16* __restrict__ cache) {
