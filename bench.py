@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scenes-per-gpu", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--attention-mode", default=None, choices=["split", "fp32", "fp16", "bf16"],
+                    help="cross-attention arithmetic; default = the library default (split: fp32-class accuracy). "
+                         "fp16 / bf16 are the reduced-precision configurations (NOT the headline number)")
     args = ap.parse_args()
 
     from parq_amd import parallel
@@ -114,6 +117,8 @@ def main():
     I = WORKLOAD["iters"]
     h, w = WORKLOAD["feat_hw"]
     cfg, W, dec = build_decoder(device)
+    if args.attention_mode:
+        dec.attention_mode = args.attention_mode
     inputs = build_inputs(B, device, seed=1000 + rank)         # each rank owns its own scenes (sharded)
 
     def step():
@@ -151,20 +156,24 @@ def main():
         ach_tflops = flop_per_launch / (ca_ms / ca_n * 1e-3) / 1e12 if ca_n else None
         bytes_per_launch = (4.0 * V * Q * C + Q * C) * 4.0 * B
         ps_gbs = bytes_per_launch / (ps_ms / ps_n * 1e-3) / 1e9 if ps_n else None
-        split = dec.attention_mode == "split"
+        mode = dec.attention_mode
+        split = mode == "split"
+        half = mode in ("fp16", "bf16")
         # dominant kernel: cross-attention QK^T + PV.  In "split" mode every fp32-accurate product costs
         # SPLIT_PASSES fp16 MFMAs, so the matrix roof for ALGORITHMIC flops is the dense fp16 peak / 3.
-        mfma_peak = PEAK_F16_MATRIX_TFLOPS / SPLIT_PASSES if split else PEAK_F32_MATRIX_TFLOPS
-        kv_bytes = 2.0 * N * C * 4.0 * B
+        mfma_peak = (PEAK_F16_MATRIX_TFLOPS / SPLIT_PASSES if split else
+                     PEAK_F16_MATRIX_TFLOPS if half else PEAK_F32_MATRIX_TFLOPS)
+        kv_bytes = 2.0 * N * C * (2.0 if half else 4.0) * B
         roofline = {"bound": "mfma",
-                    "kernel": ("flash_split_kernel (cross-attention QK^T+PV, fp16 hi/lo 3-term products, fp32 accumulate)"
-                               if split else "flash_f32_kernel (cross-attention QK^T+PV, fp32 MFMA)"),
+                    "kernel": ("flash_split_kernel<3> (cross-attention QK^T+PV, fp16 hi/lo 3-term products, fp32 accumulate)" if split
+                               else "flash_split_kernel<1> (cross-attention QK^T+PV, single %s products, fp32 accumulate)" % mode if half
+                               else "flash_f32_kernel (cross-attention QK^T+PV, fp32 MFMA)"),
                     "achieved": ach_tflops, "peak": mfma_peak, "unit": "TFLOP/s",
                     "frac": (ach_tflops / mfma_peak) if ach_tflops else None, "traffic": None,
                     "avg_launch_ms": (ca_ms / ca_n) if ca_n else None, "launches": ca_n,
                     "algorithmic_gflop_per_launch": flop_per_launch / 1e9,
                     "peak_note": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 passes per product; the fp32-MFMA peak is %.1f"
-                                  % PEAK_F32_MATRIX_TFLOPS) if split else "fp32 MFMA peak",
+                                  % PEAK_F32_MATRIX_TFLOPS) if split else "dense fp16/bf16 MFMA peak" if half else "fp32 MFMA peak",
                     "hbm_stream_gbs": (kv_bytes / (ca_ms / ca_n * 1e-3) / 1e9) if ca_n else None,
                     "note": "launch time from hipEvents around this kernel alone (its merge kernel is group cross_attn_merge)"}
         out = {
@@ -172,7 +181,9 @@ def main():
             "value": total_iters / dt, "unit": "decoder-iterations/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 (cross-attention and K/V projection as fp16 hi/lo split products with fp32 accumulation)" if split else "f32",
+            "vs_baseline": None, "dtype": ("f32 (cross-attention and K/V projection as fp16 hi/lo split products with fp32 accumulation)" if split
+                                          else "%s cross-attention and K/V projection operands, fp32 accumulation, fp32 elsewhere (reduced precision: not the headline configuration)" % mode if half
+                                          else "f32"),
             "data": "synthetic",
             "config": {"workload": "BASELINE cfg3: 10 views 480x640 (feature maps 120x160, N=192000 tokens), "
                                    "256 queries, 8 iterations, d=256, 4 heads, FFN 768, ResNet-FPN-shaped synthetic features",

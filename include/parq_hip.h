@@ -103,7 +103,12 @@ int parq_pack_weights(parq_handle h, void *arena, size_t arena_bytes, parq_strea
  *      evaluated as hi*hi + hi*lo + lo*hi on the fp16 matrix pipe with fp32 accumulation:
  *      ~2^-22 relative product error, i.e. fp32-rounding class (measured against float64 the
  *      two modes are indistinguishable); operands must satisfy |x| < 65504, violations raise
- *      the int at workspace buffer "flags"[0]. */
+ *      the int at workspace buffer "flags"[0];
+ *   2  single fp16 products, 3  single bf16 products (head dim 64, dim <= 256): the reduced-precision
+ *      configurations of the benchmark (BASELINE.json configs 2 and 5; the reference defines no mixed
+ *      precision).  Q, K, V and the probabilities are rounded to nearest 16-bit
+ *      once, accumulation stays fp32; the K/V cache shrinks to half.  Outputs agree with the fp32 path to
+ *      ~1e-3 (fp16) / ~1e-2 (bf16) on unit-scale features (tests state the tolerances). */
 int parq_set_attention_mode(parq_handle h, int32_t mode);
 
 /* ---- PARQDecoder.forward ---------------------------------------------------------- */
@@ -188,6 +193,12 @@ int parq_k_attention(const float *q, const float *k, const float *v, float *out,
 size_t parq_k_attention_split_scratch_bytes(int32_t B, int32_t H, int32_t Lq, int32_t Lk);
 int parq_k_attention_split(const float *q, const float *k, const float *v, float *out, int32_t B, int32_t H,
                            int32_t Lq, int32_t Lk, void *scratch, size_t scratch_bytes, parq_stream stream);
+
+/* the single-product reduced-precision variants (attention modes 2 / 3): bf16 != 0 selects bf16, else fp16 */
+size_t parq_k_attention_half_scratch_bytes(int32_t B, int32_t H, int32_t Lq, int32_t Lk);
+int parq_k_attention_half(const float *q, const float *k, const float *v, float *out, int32_t B, int32_t H,
+                          int32_t Lq, int32_t Lk, int32_t bf16, void *scratch, size_t scratch_bytes,
+                          parq_stream stream);
 
 int parq_k_layernorm(const float *X, const float *gamma, const float *beta, float *Y, int32_t M,
                      int32_t C, float eps, parq_stream stream);

@@ -80,7 +80,11 @@ struct parq_ctx {
     bool prepared = false;
     bool emb_valid = false;           // workspace emb holds pos2posemb3d of the chained reference points
     int ref_state = 0;                // 0: none, 1: ws.ref valid
-    int attn_mode = 1;                // 0: fp32 MFMA, 1: split fp16x3 (head dim 64 only)
+    int attn_mode = 1;                // 0: fp32 MFMA, 1: split fp16x3, 2: fp16, 3: bf16 (1..3: head dim 64 only)
+    int kv16_state = 1;               // what the arena's 16-bit W_kv copy currently holds (same numbering)
+    bool cache_mode() const { return attn_mode >= 1 && dh == 64; }
+    int terms() const { return attn_mode == 1 ? 3 : 1; }
+    int kind() const { return attn_mode == 3 ? kBF16 : kF16; }
     bool profiling = false;
     std::vector<ProfEvent> events;
     double prof_ms[PARQ_PROF_COUNT] = {0};
@@ -124,7 +128,7 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     int64_t off = 0;
     auto take = [&](int64_t n) { int64_t o = off; off += align_up(n); return o; };
     ws->T_cl = take((int64_t)B * V * 12 * 2);      // float64 poses
-    const bool split_mode = c->attn_mode == 1 && c->dh == 64;
+    const bool split_mode = c->cache_mode();
     ws->kv = take(split_mode ? 0 : (int64_t)c->nl * B * 2 * N * C);      // fp32 head-major K/V (fp32 mode only)
     ws->ref = take(M * 3); ws->ref_next = take(M * 3);
     ws->emb = take(M * 384); ws->pe_h = take(M * C); ws->pos = take(M * C);
@@ -139,7 +143,7 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     ws->self_split = flash_pick_splits(B, c->H, c->Q, c->Q, c->dh, cus);
     ws->cross_split = split_mode ? flash_split_pick_splits(B, c->H, c->Q, (int)N, cus)
                                  : flash_pick_splits(B, c->H, c->Q, (int)N, c->dh, cus);
-    ws->kvc = take(split_mode ? (int64_t)(c->nl * kvsplit_cache_bytes(B, c->H, (int)N) / sizeof(float)) : 0);
+    ws->kvc = take(split_mode ? (int64_t)(c->nl * kvsplit_cache_bytes(B, c->H, (int)N, c->terms()) / sizeof(float)) : 0);
     ws->flags = take(64);
     const size_t fs = flash_scratch_bytes(B, c->H, c->Q, c->dh, ws->self_split);
     const size_t fc = flash_scratch_bytes(B, c->H, c->Q, c->dh, ws->cross_split);
@@ -198,13 +202,23 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     // hoisted K/V in-projection of the memory tokens: one GEMM per distinct layer,
     // written head-major [b][{K heads, V heads}][N][dh] so the attention kernel streams contiguous panels
     if ((int64_t)B * N > (int64_t)INT32_MAX) return fail(PARQ_ERR_ARG, "B*N too large");
+    if (c->cache_mode() && c->kv16_state != c->attn_mode) {
+        // the arena's 16-bit copy of W_kv follows the mode: hi/lo split, or one round-to-nearest fp16 / bf16 copy
+        for (int li = 0; li < c->nl; ++li) {
+            const LayerW& L = c->ar.layers[li];
+            float* Aw = const_cast<float*>(A);
+            if (c->attn_mode == 1) HIPCHK(launch_split_f32(A + L.cross_in_w + C * C, Aw + L.kv_whi, Aw + L.kv_wlo, 2 * C * C, s));
+            else HIPCHK(launch_cvt16(A + L.cross_in_w + C * C, Aw + L.kv_whi, 2 * C * C, c->kind(), s));
+        }
+        c->kv16_state = c->attn_mode;
+    }
     for (int li = 0; li < c->nl; ++li) {
         Prof p(c, s, PARQ_PROF_KV_PROJ);
         const LayerW& L = c->ar.layers[li];
-        if (c->attn_mode == 1 && c->dh == 64) {
-            char* cache = reinterpret_cast<char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, c->H, (int)N);
+        if (c->cache_mode()) {
+            char* cache = reinterpret_cast<char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, c->H, (int)N, c->terms());
             HIPCHK(launch_kvproj_split(sc->tokens, A + L.kv_whi, A + L.kv_wlo, A + L.cross_in_b + C, B, (int)N, C, c->H,
-                                       cache, reinterpret_cast<int*>(wsp + ws.flags), s));
+                                       cache, reinterpret_cast<int*>(wsp + ws.flags), s, c->terms(), c->kind()));
         } else {
             LinearArgs a = lin(sc->tokens, C, A + L.cross_in_w + (int64_t)C * C, C, A + L.cross_in_b + C,
                                wsp + ws.kv + (int64_t)li * B * 2 * N * C, 0, (int)(B * N), 2 * C, C);
@@ -297,9 +311,9 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         fa.o_part = wsp + ws.flash;
         fa.m_part = fa.o_part + (int64_t)B * H * fa.nsplit * dh * lp;
         fa.l_part = fa.m_part + (int64_t)B * H * fa.nsplit * lp;
-        if (c->attn_mode == 1 && dh == 64) {
-            const char* cache = reinterpret_cast<const char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, H, (int)N);
-            HIPCHK(launch_flash_split(fa, cache, s));
+        if (c->cache_mode()) {
+            const char* cache = reinterpret_cast<const char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, H, (int)N, c->terms());
+            HIPCHK(launch_flash_split(fa, cache, s, c->terms(), c->kind()));
         } else {
             const float* kv = wsp + ws.kv + (int64_t)li * B * 2 * N * C;
             fa.k = kv;                       fa.k_batch = 2 * N * C; fa.k_head = N * dh; fa.k_row = dh;
@@ -452,6 +466,7 @@ int parq_pack_weights(parq_handle h, void* arena_v, size_t arena_bytes, parq_str
             return rc;
         HIPCHK(launch_split_f32(A + L.cross_in_w + C * C, A + L.kv_whi, A + L.kv_wlo, 2 * C * C, s));
     }
+    c->kv16_state = 1;
     const Arena& ar = c->ar;
     const std::string d = "parq_module.decoder.";
     const std::string hc = "mlp_heads.center_head.layers.", hr = "mlp_heads.rotation_head.layers.";
@@ -572,7 +587,7 @@ int parq_workspace_lookup(parq_handle h, int32_t B, int32_t V, int32_t hh, int32
     struct E { const char* n; int64_t off, cnt; };
     const E table[] = {
         {"T_camera_local_f64", ws.T_cl, (int64_t)B * V * 24},
-        {"kv_cache", ws.kv, (h->attn_mode == 1 && h->dh == 64) ? 0 : (int64_t)h->nl * B * 2 * N * C},
+        {"kv_cache", ws.kv, h->cache_mode() ? 0 : (int64_t)h->nl * B * 2 * N * C},
         {"ref", ws.ref, M * 3}, {"ref_next", ws.ref_next, M * 3}, {"posemb", ws.emb, M * 384}, {"pos_feat", ws.pos, M * C},
         {"tgt", ws.tgt, M * C}, {"self_qkv", ws.qkv, M * 3 * C}, {"attn", ws.attn, M * C}, {"xa_prenorm1", ws.xa, M * C},
         {"cross_q", ws.qc, M * C}, {"xb_prenorm2", ws.xb, M * C}, {"ffn_hidden", ws.ffn, M * F},
@@ -585,7 +600,9 @@ int parq_workspace_lookup(parq_handle h, int32_t B, int32_t V, int32_t hh, int32
 }
 
 int parq_set_attention_mode(parq_handle h, int32_t mode) {
-    if (!h || (mode != 0 && mode != 1)) return fail(PARQ_ERR_ARG, "attention mode must be 0 (fp32 MFMA) or 1 (split fp16x3)");
+    if (!h || mode < 0 || mode > 3) return fail(PARQ_ERR_ARG, "attention mode must be 0 (fp32 MFMA), 1 (split fp16x3), 2 (fp16) or 3 (bf16)");
+    if (mode >= 2 && (h->dh != 64 || h->C > 256 || (2 * h->C) % 256 != 0))
+        return fail(PARQ_ERR_ARG, "the fp16 / bf16 attention modes need head dim 64 and dim in {128, 256}");
     h->attn_mode = mode;
     h->prepared = false;
     return PARQ_OK;
@@ -703,6 +720,38 @@ int parq_k_attention_split(const float* q, const float* k, const float* v, float
     HIPCHK(hipMemsetAsync(flag, 0, 256, s));
     HIPCHK(launch_kvsplit_convert(k, v, Lk * C, dh, C, Lk * C, dh, C, B, H, Lk, cache, flag, s));
     HIPCHK(launch_flash_split(fa, cache, s));
+    HIPCHK(launch_flash_merge(fa, s));
+    return PARQ_OK;
+}
+
+size_t parq_k_attention_half_scratch_bytes(int32_t B, int32_t H, int32_t Lq, int32_t Lk) {
+    return parq_k_attention_split_scratch_bytes(B, H, Lq, Lk);      // the single-term cache is half the split one
+}
+
+int parq_k_attention_half(const float* q, const float* k, const float* v, float* out, int32_t B, int32_t H, int32_t Lq,
+                          int32_t Lk, int32_t bf16, void* scratch, size_t scratch_bytes, parq_stream stream) {
+    if (!q || !k || !v || !out || !scratch) return fail(PARQ_ERR_ARG, "NULL argument");
+    if (B < 1 || H < 1 || Lq < 1 || Lk < 1) return fail(PARQ_ERR_ARG, "bad dims");
+    if (scratch_bytes < parq_k_attention_half_scratch_bytes(B, H, Lq, Lk)) return fail(PARQ_ERR_WORKSPACE, "attention scratch too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int dh = 64, kind = bf16 ? kBF16 : kF16;
+    const int64_t C = (int64_t)H * dh;
+    FlashArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.B = B; fa.H = H; fa.Lq = Lq; fa.Lk = Lk; fa.dh = dh;
+    fa.q = q; fa.q_batch = Lq * C; fa.q_head = dh; fa.q_row = C;
+    fa.out = out; fa.out_batch = Lq * C; fa.out_row = C;
+    fa.nsplit = flash_split_pick_splits(B, H, Lq, Lk, device_num_cus());
+    const int64_t lp = flash_lq_pad(Lq);
+    char* base = (char*)scratch;
+    int* flag = (int*)base;
+    char* cache = base + 256;
+    fa.o_part = (float*)(cache + kvsplit_cache_bytes(B, H, Lk, 3));
+    fa.m_part = fa.o_part + (int64_t)B * H * fa.nsplit * dh * lp;
+    fa.l_part = fa.m_part + (int64_t)B * H * fa.nsplit * lp;
+    HIPCHK(hipMemsetAsync(flag, 0, 256, s));
+    HIPCHK(launch_kvsplit_convert(k, v, Lk * C, dh, C, Lk * C, dh, C, B, H, Lk, cache, flag, s, 1, kind));
+    HIPCHK(launch_flash_split(fa, cache, s, 1, kind));
     HIPCHK(launch_flash_merge(fa, s));
     return PARQ_OK;
 }

@@ -49,6 +49,32 @@ __device__ __forceinline__ void split8(const float* x, half8& hi, half8& lo) {
     }
 }
 
+// 16-bit operand kinds of the matrix pipe.  A half8 is used as the raw 8 x 16-bit container for both.
+enum : int { kF16 = 0, kBF16 = 1 };
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// round-to-nearest conversion of 8 floats (the single-term "half" attention modes)
+template <int KIND>
+__device__ __forceinline__ half8 cvt8_rn(const float* x) {
+    if constexpr (KIND == kF16) {
+        half8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = (_Float16)x[e];
+        return h;
+    } else {
+        bf16x8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = (__bf16)x[e];
+        return __builtin_bit_cast(half8, h);
+    }
+}
+
+template <int KIND>
+__device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
+    if constexpr (KIND == kF16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 // ------------------------------------------------------------------ linear (small GEMM)
 struct LinearArgs {
     const float* X;  int64_t ldx;       // A operand, row-major [M][K] with row stride ldx
@@ -106,17 +132,22 @@ size_t flash_scratch_bytes(int B, int H, int Lq, int dh, int nsplit);
 hipError_t launch_flash(const FlashArgs& a, hipStream_t s);       // partials
 hipError_t launch_flash_merge(const FlashArgs& a, hipStream_t s); // partials -> out
 
-// split-precision (fp16 hi/lo, 3-term products) cross-attention, head dim 64 (flash_split.hip)
-size_t kvsplit_cache_bytes(int B, int H, int N);
+// split-precision (fp16 hi/lo, 3-term products) cross-attention, head dim 64 (flash_split.hip).
+// `terms` = 3: split precision (fp32-class accuracy); 1: single fp16 / bf16 products (`kind` = kF16 / kBF16),
+// cache blocks hold only [K | V] (8 KB instead of 16 KB).
+size_t kvsplit_cache_bytes(int B, int H, int N, int terms = 3);
 int flash_split_pick_splits(int B, int H, int Lq, int Lk, int num_cus);
 hipError_t launch_kvsplit_convert(const float* K, const float* V, int64_t k_batch, int64_t k_head, int64_t k_row,
                                   int64_t v_batch, int64_t v_head, int64_t v_row, int B, int H, int N, void* cache,
-                                  int* overflow_flag, hipStream_t s);
-hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t s);   // partials; merge as usual
+                                  int* overflow_flag, hipStream_t s, int terms = 3, int kind = kF16);
+hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t s, int terms = 3,
+                              int kind = kF16);   // partials; merge as usual
 // kvproj_split.hip: tokens -> split cache directly (W pre-split with launch_split_f32)
 hipError_t launch_split_f32(const float* src, void* hi, void* lo, int64_t n, hipStream_t s);
 hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void* Wlo, const float* bias, int B, int N,
-                               int C, int H, void* cache, int* overflow, hipStream_t s);
+                               int C, int H, void* cache, int* overflow, hipStream_t s, int terms = 3, int kind = kF16);
+// fp32 -> 16-bit (round to nearest) weights of the single-term modes
+hipError_t launch_cvt16(const float* src, void* dst, int64_t n, int kind, hipStream_t s);
 
 // raype.hip: ray-point positional encoding + tokenisation
 hipError_t launch_raype_points(const float* cam, const float* T_cp, const float* T_wp, const float* T_wl,

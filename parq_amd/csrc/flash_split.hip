@@ -33,8 +33,15 @@ namespace {
 
 constexpr int kDH = 64;
 constexpr int kBlkKeys = 32;
-constexpr int kBlkBytes = 16384;
-constexpr int kBlkHalfs = kBlkBytes / 2;
+// cache block of 32 keys: TERMS = 3 -> [K_hi|K_lo|V_hi|V_lo] 16 KB; TERMS = 1 -> [K|V] 8 KB (offsets in 16-bit units)
+template <int TERMS>
+struct Blk {
+    static constexpr int bytes = TERMS == 3 ? 16384 : 8192;
+    static constexpr int halfs = bytes / 2;
+    static constexpr int k_lo = 2048;
+    static constexpr int v_hi = TERMS == 3 ? 4096 : 2048;
+    static constexpr int v_lo = 6144;
+};
 constexpr int kStageBlks = 2;                       // 64 keys per LDS stage
 constexpr int kNW = 8;                              // waves per workgroup (32 queries each)
 constexpr float kDeferLog2 = 10.f;                  // running max moves only past this margin (log2 domain)
@@ -46,6 +53,7 @@ __device__ __forceinline__ int dmap(int kh, int s, int e) {
 // ------------------------------------------------------------------------------------------------
 // fp32 head-major K/V ([b][h][n][64], as written by the fp32 projection) -> split cache.
 // One workgroup per (32-key block, b*h).  Used by tests and as the fallback producer.
+template <int TERMS, int KIND>
 __global__ __launch_bounds__(256) void kvsplit_convert_kernel(const float* __restrict__ K, const float* __restrict__ V,
                                                               int64_t k_batch, int64_t k_head, int64_t k_row,
                                                               int64_t v_batch, int64_t v_head, int64_t v_row, int H,
@@ -64,13 +72,13 @@ __global__ __launch_bounds__(256) void kvsplit_convert_kernel(const float* __res
         const int n = blk * 32 + key;
         const float kvv = n < N ? kp[(int64_t)n * k_row + d] : 0.f;
         const float vvv = n < N ? vp[(int64_t)n * v_row + d] : 0.f;
-        ovf |= !(fabsf(kvv) < 60000.f) || !(fabsf(vvv) < 60000.f);
+        if (KIND == kF16) ovf |= !(fabsf(kvv) < 60000.f) || !(fabsf(vvv) < 60000.f);
         ks[key][d] = kvv;
         vs[key][d] = vvv;
     }
     if (ovf) atomicOr(overflow, 1);
     __syncthreads();
-    _Float16* out = cache + ((int64_t)bh * nblk + blk) * kBlkHalfs;
+    _Float16* out = cache + ((int64_t)bh * nblk + blk) * Blk<TERMS>::halfs;
     // K: 32 keys x 8 chunks = 256 chunks -> one per thread
     {
         const int key = threadIdx.x >> 3, c = threadIdx.x & 7;
@@ -79,10 +87,14 @@ __global__ __launch_bounds__(256) void kvsplit_convert_kernel(const float* __res
         float x[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = ks[key][dmap(kh, s, e)];
-        split8(x, hi, lo);
         const int pos = c ^ ((key >> 1) & 7);
-        *reinterpret_cast<half8*>(out + key * 64 + pos * 8) = hi;
-        *reinterpret_cast<half8*>(out + 2048 + key * 64 + pos * 8) = lo;
+        if constexpr (TERMS == 3) {
+            split8(x, hi, lo);
+            *reinterpret_cast<half8*>(out + key * 64 + pos * 8) = hi;
+            *reinterpret_cast<half8*>(out + Blk<3>::k_lo + key * 64 + pos * 8) = lo;
+        } else {
+            *reinterpret_cast<half8*>(out + key * 64 + pos * 8) = cvt8_rn<KIND>(x);
+        }
     }
     // V: 64 d x 4 chunks = 256 chunks -> one per thread
     {
@@ -92,10 +104,14 @@ __global__ __launch_bounds__(256) void kvsplit_convert_kernel(const float* __res
         float x[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = vs[16 * m + 4 * kh + (e & 3) + 8 * (e >> 2)][d];
-        split8(x, hi, lo);
         const int pos = c ^ ((d >> 2) & 3);
-        *reinterpret_cast<half8*>(out + 4096 + d * 32 + pos * 8) = hi;
-        *reinterpret_cast<half8*>(out + 6144 + d * 32 + pos * 8) = lo;
+        if constexpr (TERMS == 3) {
+            split8(x, hi, lo);
+            *reinterpret_cast<half8*>(out + Blk<3>::v_hi + d * 32 + pos * 8) = hi;
+            *reinterpret_cast<half8*>(out + Blk<3>::v_lo + d * 32 + pos * 8) = lo;
+        } else {
+            *reinterpret_cast<half8*>(out + Blk<1>::v_hi + d * 32 + pos * 8) = cvt8_rn<KIND>(x);
+        }
     }
 }
 
@@ -110,8 +126,13 @@ __global__ __launch_bounds__(256) void kvsplit_convert_kernel(const float* __res
 // barrier keeps the eight waves on the same LDS blocks, which the kernel evidently profits from).
 constexpr int kRing = 4;
 
+// TERMS = 3: fp16 hi/lo split products (fp32-class accuracy).  TERMS = 1: single fp16 / bf16 products (KIND) —
+// the reduced-precision modes of BASELINE configs 2 and 5; same structure, a third of the MFMAs, half the bytes.
+template <int TERMS, int KIND>
 __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, const _Float16* __restrict__ cache) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];       // [kRing stages][kStageBlks][kBlkHalfs]
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];       // [kRing stages][kStageBlks][block]
+    constexpr int kBlkBytes = Blk<TERMS>::bytes;
+    constexpr int kBlkHalfs = Blk<TERMS>::halfs;
     constexpr int NT = kNW * 64;
     constexpr int STAGE16 = kStageBlks * kBlkBytes / 16;                     // 16-byte chunks per stage
     constexpr int LD = STAGE16 / NT;                                         // per thread
@@ -142,7 +163,8 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
             float x[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = (e < 4 ? x0[e & 3] : x1[e & 3]) * scale;
-            split8(x, qhi[s], qlo[s]);
+            if constexpr (TERMS == 3) split8(x, qhi[s], qlo[s]);
+            else qhi[s] = cvt8_rn<KIND>(x);
         }
     }
 
@@ -217,13 +239,15 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
                 for (int s = 0; s < 4; ++s) {
                     const int pos = (4 * kh + s) ^ ksw;
                     kf[kb][2 * s] = *reinterpret_cast<const half8*>(B0 + li * 64 + pos * 8);
-                    kf[kb][2 * s + 1] = *reinterpret_cast<const half8*>(B0 + 2048 + li * 64 + pos * 8);
+                    if constexpr (TERMS == 3) kf[kb][2 * s + 1] = *reinterpret_cast<const half8*>(B0 + Blk<3>::k_lo + li * 64 + pos * 8);
                 }
             };
             auto qk_step = [&](int kb, int s) {
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][2 * s], qhi[s], sacc[kb], 0, 0, 0);
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][2 * s], qlo[s], sacc[kb], 0, 0, 0);
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][2 * s + 1], qhi[s], sacc[kb], 0, 0, 0);
+                sacc[kb] = mfma16<KIND>(kf[kb][2 * s], qhi[s], sacc[kb]);
+                if constexpr (TERMS == 3) {
+                    sacc[kb] = mfma16<KIND>(kf[kb][2 * s], qlo[s], sacc[kb]);
+                    sacc[kb] = mfma16<KIND>(kf[kb][2 * s + 1], qhi[s], sacc[kb]);
+                }
             };
             // block maximum (scores absolute).  Tail masking (keys >= Lk, blocks past the end) exists only in the
             // TAIL instantiation of the stage body, so the common path stays free of branches between the MFMA
@@ -267,7 +291,8 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
                     p[e] = __builtin_amdgcn_exp2f(sacc[kb][8 * m + e] - m_run);
                     rs += p[e];
                 }
-                split8(p, phi[kb][m], plo[kb][m]);
+                if constexpr (TERMS == 3) split8(p, phi[kb][m], plo[kb][m]);
+                else phi[kb][m] = cvt8_rn<KIND>(p);
             };
             auto pv_step = [&](int kb, int m) {
                 const _Float16* B0 = S0 + kb * kBlkHalfs;
@@ -276,15 +301,17 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
                 for (int dt = 0; dt < 2; ++dt) {
                     const int d = dt * 32 + li;
                     const int pos = (2 * m + kh) ^ ((d >> 2) & 3);
-                    vhi[dt] = *reinterpret_cast<const half8*>(B0 + 4096 + d * 32 + pos * 8);
-                    vlo[dt] = *reinterpret_cast<const half8*>(B0 + 6144 + d * 32 + pos * 8);
+                    vhi[dt] = *reinterpret_cast<const half8*>(B0 + Blk<TERMS>::v_hi + d * 32 + pos * 8);
+                    if constexpr (TERMS == 3) vlo[dt] = *reinterpret_cast<const half8*>(B0 + Blk<3>::v_lo + d * 32 + pos * 8);
                 }
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[dt], phi[kb][m], o[dt], 0, 0, 0);
+                for (int dt = 0; dt < 2; ++dt) o[dt] = mfma16<KIND>(vhi[dt], phi[kb][m], o[dt]);
+                if constexpr (TERMS == 3) {
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo[dt], phi[kb][m], o[dt], 0, 0, 0);
+                    for (int dt = 0; dt < 2; ++dt) o[dt] = mfma16<KIND>(vlo[dt], phi[kb][m], o[dt]);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[dt], plo[kb][m], o[dt], 0, 0, 0);
+                    for (int dt = 0; dt < 2; ++dt) o[dt] = mfma16<KIND>(vhi[dt], plo[kb][m], o[dt]);
+                }
             };
 
             auto first_half = [&](auto tail_tag) {
@@ -312,9 +339,9 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
                 qk_step(1, 3);
                 softmax_half(0, 1);
 #pragma unroll
-                for (int i = 0; i < 12; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x402, 9, 0);          // 9 VALU / TRANS
+                for (int i = 0; i < 4 * TERMS; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x402, TERMS == 3 ? 9 : 16, 0);    // VALU / TRANS behind it
                 }
                 mx1 = block_mx(1, tail_tag);
             };
@@ -326,9 +353,9 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
                     pv_step(0, 1);
                     softmax_half(1, 1);
 #pragma unroll
-                    for (int i = 0; i < 12; ++i) {
+                    for (int i = 0; i < 4 * TERMS; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-                        __builtin_amdgcn_sched_group_barrier(0x402, 9, 1);
+                        __builtin_amdgcn_sched_group_barrier(0x402, TERMS == 3 ? 9 : 16, 1);
                     }
                 } else {
                     pv_step(0, 0);
@@ -369,7 +396,9 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
 
 }  // namespace
 
-size_t kvsplit_cache_bytes(int B, int H, int N) { return (size_t)B * H * ceil_div(N, kBlkKeys) * kBlkBytes; }
+size_t kvsplit_cache_bytes(int B, int H, int N, int terms) {
+    return (size_t)B * H * ceil_div(N, kBlkKeys) * (terms == 3 ? Blk<3>::bytes : Blk<1>::bytes);
+}
 
 int flash_split_stage_keys() { return kStageBlks * kBlkKeys; }
 
@@ -385,30 +414,43 @@ int flash_split_pick_splits(int B, int H, int Lq, int Lk, int num_cus) {
 
 hipError_t launch_kvsplit_convert(const float* K, const float* V, int64_t k_batch, int64_t k_head, int64_t k_row,
                                   int64_t v_batch, int64_t v_head, int64_t v_row, int B, int H, int N, void* cache,
-                                  int* overflow_flag, hipStream_t s) {
+                                  int* overflow_flag, hipStream_t s, int terms, int kind) {
     dim3 grid(ceil_div(N, kBlkKeys), B * H);
-    hipLaunchKernelGGL(kvsplit_convert_kernel, grid, dim3(256), 0, s, K, V, k_batch, k_head, k_row, v_batch, v_head, v_row,
-                       H, N, reinterpret_cast<_Float16*>(cache), overflow_flag);
+    _Float16* c = reinterpret_cast<_Float16*>(cache);
+    if (terms == 3)
+        hipLaunchKernelGGL((kvsplit_convert_kernel<3, kF16>), grid, dim3(256), 0, s, K, V, k_batch, k_head, k_row, v_batch, v_head,
+                           v_row, H, N, c, overflow_flag);
+    else if (kind == kF16)
+        hipLaunchKernelGGL((kvsplit_convert_kernel<1, kF16>), grid, dim3(256), 0, s, K, V, k_batch, k_head, k_row, v_batch, v_head,
+                           v_row, H, N, c, overflow_flag);
+    else
+        hipLaunchKernelGGL((kvsplit_convert_kernel<1, kBF16>), grid, dim3(256), 0, s, K, V, k_batch, k_head, k_row, v_batch,
+                           v_head, v_row, H, N, c, overflow_flag);
     return hipGetLastError();
 }
 
-hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t s) {
-    if (a.dh != kDH || a.nsplit < 1 || a.nsplit > 256) return hipErrorInvalidValue;
+template <int TERMS, int KIND>
+static hipError_t launch_flash_t(const FlashArgs& b, const void* cache, hipStream_t s) {
     static bool attr_set = false;
-    const size_t lds = (size_t)kRing * kStageBlks * kBlkBytes;
+    const size_t lds = (size_t)kRing * kStageBlks * Blk<TERMS>::bytes;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_split_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_split_kernel<TERMS, KIND>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * b.H);
+    hipLaunchKernelGGL((flash_split_kernel<TERMS, KIND>), grid, dim3(kNW * 64), lds, s, b, reinterpret_cast<const _Float16*>(cache));
+    return hipGetLastError();
+}
 
+hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t s, int terms, int kind) {
+    if (a.dh != kDH || a.nsplit < 1 || a.nsplit > 256) return hipErrorInvalidValue;
     FlashArgs b = a;
     b.defer_log2 = kDeferLog2;
     if (const char* e = getenv("PARQ_DEFER_LOG2")) b.defer_log2 = (float)atof(e);      // debugging knob
-    dim3 grid(a.nsplit, ceil_div(a.Lq, 32 * kNW), a.B * a.H);
-    hipLaunchKernelGGL(flash_split_kernel, grid, dim3(kNW * 64), lds, s, b, reinterpret_cast<const _Float16*>(cache));
-    return hipGetLastError();
+    if (terms == 3) return launch_flash_t<3, kF16>(b, cache, s);
+    return kind == kF16 ? launch_flash_t<1, kF16>(b, cache, s) : launch_flash_t<1, kBF16>(b, cache, s);
 }
 
 }  // namespace parq

@@ -265,8 +265,12 @@ constexpr int kWsDepth = 2;              // token k-steps in flight
 // NWV waves own NWV*32 output columns; TM token rows per tile.  <4,128>: one wave per SIMD, 388 registers.
 // <8,64>: two waves per SIMD (<= 256 registers each) so one wave's load/barrier stalls are covered by the
 // other's MFMAs, and a token tile is re-read by 2 column slices instead of 4.
-template <int NWV, int TM>
+// TERMS = 3: split products, cache blocks [K_hi|K_lo|V_hi|V_lo]; TERMS = 1: single fp16 / bf16 (KIND) products,
+// W given already converted in a.Whi, cache blocks [K|V] of 8 KB.
+template <int NWV, int TM, int TERMS, int KIND>
 __global__ __launch_bounds__(NWV * 64, 1) void kvproj_ws_kernel(KvProjArgs a, int total_rt, int nrt, int P) {
+    constexpr int kBlkH = TERMS == 3 ? 8192 : 4096;      // 16-bit units per 32-key cache block
+    constexpr int kVoff = TERMS == 3 ? 4096 : 2048;      // V_hi offset inside a block
     constexpr int kThr = NWV * 64;
     constexpr int kCols = NWV * 32;
     constexpr int RT = TM / 32;                  // 32-row blocks per tile (accumulators per wave)
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void kvproj_ws_kernel(KvProjArgs a, in
             if (ks < nk) {
                 const int64_t off = (int64_t)col * C + ks * kBK + 32 * kh + 8 * s2;
                 wfr[ks][s2][0] = *reinterpret_cast<const half8*>(a.Whi + off);
-                wfr[ks][s2][1] = *reinterpret_cast<const half8*>(a.Wlo + off);
+                if constexpr (TERMS == 3) wfr[ks][s2][1] = *reinterpret_cast<const half8*>(a.Wlo + off);
             }
         }
     const float* bias = a.bias + headcol * 64;
@@ -340,10 +344,14 @@ __global__ __launch_bounds__(NWV * 64, 1) void kvproj_ws_kernel(KvProjArgs a, in
             const int pos = c ^ ((row >> 1) & 7);
             float x[8] = {src[2 * i].x, src[2 * i].y, src[2 * i].z, src[2 * i].w,
                           src[2 * i + 1].x, src[2 * i + 1].y, src[2 * i + 1].z, src[2 * i + 1].w};
-            half8 hi, lo;
-            split8(x, hi, lo);
-            *reinterpret_cast<half8*>(Ahi + row * kBK + pos * 8) = hi;
-            *reinterpret_cast<half8*>(Alo + row * kBK + pos * 8) = lo;
+            if constexpr (TERMS == 3) {
+                half8 hi, lo;
+                split8(x, hi, lo);
+                *reinterpret_cast<half8*>(Ahi + row * kBK + pos * 8) = hi;
+                *reinterpret_cast<half8*>(Alo + row * kBK + pos * 8) = lo;
+            } else {
+                *reinterpret_cast<half8*>(Ahi + row * kBK + pos * 8) = cvt8_rn<KIND>(x);
+            }
         }
     };
     // linear k-step stream over this workgroup's tiles: step q -> (tile p + (q / nk) * P, ks = q % nk)
@@ -382,23 +390,27 @@ __global__ __launch_bounds__(NWV * 64, 1) void kvproj_ws_kernel(KvProjArgs a, in
                         const int row = t * 32 + li;
                         const int posr = (4 * kh + s2) ^ ((row >> 1) & 7);
                         xh[t] = *reinterpret_cast<const half8*>(Ahi + row * kBK + posr * 8);
-                        xl[t] = *reinterpret_cast<const half8*>(Alo + row * kBK + posr * 8);
+                        if constexpr (TERMS == 3) xl[t] = *reinterpret_cast<const half8*>(Alo + row * kBK + posr * 8);
                     }
                     const half8 wh = wfr[ks][s2][0], wlo = wfr[ks][s2][1];
                     if (isK) {          // transposed product: rows = d, cols = tokens
 #pragma unroll
-                        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[t], acc[t], 0, 0, 0);
+                        for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wh, xh[t], acc[t]);
+                        if constexpr (TERMS == 3) {
 #pragma unroll
-                        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[t], acc[t], 0, 0, 0);
+                            for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wh, xl[t], acc[t]);
 #pragma unroll
-                        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh[t], acc[t], 0, 0, 0);
+                            for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wlo, xh[t], acc[t]);
+                        }
                     } else {            // rows = tokens, cols = d
 #pragma unroll
-                        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[t], wh, acc[t], 0, 0, 0);
+                        for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(xh[t], wh, acc[t]);
+                        if constexpr (TERMS == 3) {
 #pragma unroll
-                        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[t], wlo, acc[t], 0, 0, 0);
+                            for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(xh[t], wlo, acc[t]);
 #pragma unroll
-                        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[t], wh, acc[t], 0, 0, 0);
+                            for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(xl[t], wh, acc[t]);
+                        }
                     }
                 }
                 ++step;
@@ -411,7 +423,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void kvproj_ws_kernel(KvProjArgs a, in
         for (int t = 0; t < RT; ++t) {
             const int blk = (m0 >> 5) + t;
             if (blk >= nblk) continue;                                   // wave-uniform
-            _Float16* out = a.cache + (((int64_t)b * a.H + h) * nblk + blk) * kBlkHalfs;
+            _Float16* out = a.cache + (((int64_t)b * a.H + h) * nblk + blk) * kBlkH;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 float x[8];
@@ -425,19 +437,22 @@ __global__ __launch_bounds__(NWV * 64, 1) void kvproj_ws_kernel(KvProjArgs a, in
                     for (int e = 0; e < 8; ++e) x[e] = acc[t][8 * m + e] + bv;
                 }
                 half8 hi, lo;
-                split8(x, hi, lo);
+                if constexpr (TERMS == 3) split8(x, hi, lo);
+                else hi = cvt8_rn<KIND>(x);
+                if constexpr (KIND == kF16) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) ovf |= !(fabsf(x[e]) < 60000.f);
+                    for (int e = 0; e < 8; ++e) ovf |= !(fabsf(x[e]) < 60000.f);
+                }
                 if (isK) {
                     const int c = 4 * kh + 2 * ct + m;
                     const int pos = c ^ ((li >> 1) & 7);
                     *reinterpret_cast<half8*>(out + li * 64 + pos * 8) = hi;
-                    *reinterpret_cast<half8*>(out + 2048 + li * 64 + pos * 8) = lo;
+                    if constexpr (TERMS == 3) *reinterpret_cast<half8*>(out + 2048 + li * 64 + pos * 8) = lo;
                 } else {
                     const int d = 32 * ct + li;
                     const int pos = (2 * m + kh) ^ ((d >> 2) & 3);
-                    *reinterpret_cast<half8*>(out + 4096 + d * 32 + pos * 8) = hi;
-                    *reinterpret_cast<half8*>(out + 6144 + d * 32 + pos * 8) = lo;
+                    *reinterpret_cast<half8*>(out + kVoff + d * 32 + pos * 8) = hi;
+                    if constexpr (TERMS == 3) *reinterpret_cast<half8*>(out + 6144 + d * 32 + pos * 8) = lo;
                 }
             }
         }
@@ -457,12 +472,28 @@ __global__ void split_f32_kernel(const float* __restrict__ src, _Float16* __rest
 
 }  // namespace
 
-template <int NWV, int TM>
+template <int KIND>
+__global__ void cvt16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = src[i + e];
+        *reinterpret_cast<half8*>(dst + i) = cvt8_rn<KIND>(x);
+    } else {
+        for (int64_t j = i; j < n; ++j) {
+            float x[8] = {src[j], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            dst[j] = cvt8_rn<KIND>(x)[0];
+        }
+    }
+}
+
+template <int NWV, int TM, int TERMS, int KIND>
 static hipError_t launch_ws(const KvProjArgs& a, int B, hipStream_t s) {
     static bool attr = false;
     const size_t lds = (size_t)2 * 2 * TM * kBK * sizeof(_Float16);
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kvproj_ws_kernel<NWV, TM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kvproj_ws_kernel<NWV, TM, TERMS, KIND>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr = true;
@@ -473,7 +504,16 @@ static hipError_t launch_ws(const KvProjArgs& a, int B, hipStream_t s) {
     if (P < 1) P = 1;
     if (P > total_rt) P = total_rt;
     dim3 grid(ceil_div(P, 8) * 8 * nslice, 1, 1);
-    hipLaunchKernelGGL((kvproj_ws_kernel<NWV, TM>), grid, dim3(NWV * 64), lds, s, a, total_rt, nrt, P);
+    hipLaunchKernelGGL((kvproj_ws_kernel<NWV, TM, TERMS, KIND>), grid, dim3(NWV * 64), lds, s, a, total_rt, nrt, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_cvt16(const float* src, void* dst, int64_t n, int kind, hipStream_t s) {
+    const unsigned blocks = (unsigned)ceil_div64(ceil_div64(n, 8), 256);
+    if (kind == kF16)
+        hipLaunchKernelGGL(cvt16_kernel<kF16>, dim3(blocks), dim3(256), 0, s, src, reinterpret_cast<_Float16*>(dst), n);
+    else
+        hipLaunchKernelGGL(cvt16_kernel<kBF16>, dim3(blocks), dim3(256), 0, s, src, reinterpret_cast<_Float16*>(dst), n);
     return hipGetLastError();
 }
 
@@ -485,7 +525,7 @@ hipError_t launch_split_f32(const float* src, void* hi, void* lo, int64_t n, hip
 
 // tokens [B][N][C] -> split cache; Whi/Wlo [2C][C] fp16, bias [2C] fp32.  Needs C % 64 == 0, head dim 64.
 hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void* Wlo, const float* bias, int B, int N,
-                               int C, int H, void* cache, int* overflow, hipStream_t s) {
+                               int C, int H, void* cache, int* overflow, hipStream_t s, int terms, int kind) {
     if (C % kBK != 0 || C != H * 64 || (2 * C) % kBN != 0) return hipErrorInvalidValue;
     static bool attr_set = false;
     const size_t ldsb = (size_t)(2 * kBM * kBK + 2 * kBN * kBK) * sizeof(_Float16);      // 64 KB
@@ -505,9 +545,14 @@ hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void*
             const char* e = getenv("PARQ_KVPROJ_WAVES");
             return e ? atoi(e) : 8;
         }();
-        if (waves == 8 && (2 * C) % 256 == 0) return launch_ws<8, 64>(a, B, s);
-        return launch_ws<4, 128>(a, B, s);
+        if (terms != 3) {
+            if ((2 * C) % 256 != 0) return hipErrorInvalidValue;
+            return kind == kF16 ? launch_ws<8, 64, 1, kF16>(a, B, s) : launch_ws<8, 64, 1, kBF16>(a, B, s);
+        }
+        if (waves == 8 && (2 * C) % 256 == 0) return launch_ws<8, 64, 3, kF16>(a, B, s);
+        return launch_ws<4, 128, 3, kF16>(a, B, s);
     }
+    if (terms != 3) return hipErrorInvalidValue;            // the single-term modes exist on the persistent kernel only
     dim3 grid(ceil_div(nrt, 8) * 8 * nct, B, 1);
     if (grid.y > 65535) return hipErrorInvalidValue;
     hipLaunchKernelGGL(kvproj_split_kernel, grid, dim3(kThreads), ldsb, s, a);

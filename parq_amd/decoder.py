@@ -134,6 +134,12 @@ class _TransformerParams(nn.Module):
 
 # ---------------------------------------------------------------------------------------
 
+# cross-attention arithmetic (include/parq_hip.h, parq_set_attention_mode): "split" = fp16 hi/lo 3-term products
+# (fp32-class accuracy, default at head dim 64), "fp32" = exact fp32 MFMA, "fp16" / "bf16" = single reduced-precision
+# products (BASELINE configs 2 and 5)
+ATTENTION_MODES = {"fp32": 0, "split": 1, "fp16": 2, "bf16": 3}
+
+
 class PARQDecoder(nn.Module):
     """Drop-in for ``model.parq_decoder.PARQDecoder`` (forward path)."""
 
@@ -193,8 +199,9 @@ class PARQDecoder(nn.Module):
             self._h = h
             self._mode_set = None
         if self._mode_set != self.attention_mode:
-            assert self.attention_mode in ("split", "fp32")
-            _lib.check(_lib.load().parq_set_attention_mode(self._h, 1 if self.attention_mode == "split" else 0),
+            if self.attention_mode not in ATTENTION_MODES:
+                raise ValueError(f"attention_mode must be one of {sorted(ATTENTION_MODES)}")
+            _lib.check(_lib.load().parq_set_attention_mode(self._h, ATTENTION_MODES[self.attention_mode]),
                        "parq_set_attention_mode")
             self._mode_set = self.attention_mode
             self._ws.clear()

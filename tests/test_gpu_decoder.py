@@ -76,27 +76,49 @@ def test_forward_equals_stepping_and_wrappers_accepted():
             assert torch.equal(o[key], outs[k][key]), (k, key)     # bit-identical: same kernels, same order
 
 
-def test_oracle_fresh_inputs_cfg2_shape():
-    """cfg-2 geometry (5 views 120x160 features, Q=128, 4 iterations) in fp32, teacher-forced
-    against the float64 oracle (truth): the GPU fp32 path must sit within 1e-4 of it."""
+def _cfg2_worst_error(mode):
+    """cfg-2 geometry (5 views 120x160 features, Q=128, 4 iterations), teacher-forced against the float64 oracle."""
     cfg = synth.decoder_cfg(dim=256, queries=128, heads=4, ffn=768, layers=4)
     W = synth.make_decoder_weights(cfg, 31)
     sc = synth.make_scene(32, 1, 5, 120, 160, 256)
     dec = make_decoder(cfg, W)
+    if mode is not None:
+        dec.attention_mode = mode
     outs = [to_np(o) for o in dec(*scene_args(sc))]
     od = O.OracleDecoder(cfg, W, synth.SCANNET_MEAN_SIZES, dtype=torch.float64)
     forced = [O.normalize(torch.from_numpy(o["coord_pos"]).double(), cfg.TRANSFORMER.SCALE) for o in outs]
     with torch.no_grad():
         want = od.forward(sc["tokens"], sc["camera"], sc["T_camera_pseudoCam"], sc["T_world_pseudoCam"],
                           sc["T_world_local"], forced_refs=forced)
+    worst = {}
     for k, (a, b) in enumerate(zip(outs, want)):
         top2 = b["sem_cls_prob"].topk(2, -1).values
-        ok = ((top2[..., 0] - top2[..., 1]) > 1e-3).numpy()
+        ok = ((top2[..., 0] - top2[..., 1]) > (1e-3 if mode in (None, "split", "fp32") else 0.1)).numpy()
         for key in a:
             x, y = a[key], b[key].numpy()
             if key == "size_unnormalized":
                 x, y = x[ok], y[ok]
-            assert rel_err(x, y) < TOL, (k, key, rel_err(x, y))
+            worst[key] = max(worst.get(key, 0.0), rel_err(x, y))
+    return worst, dec
+
+
+def test_oracle_fresh_inputs_cfg2_shape():
+    """cfg-2 geometry in fp32 (default split-precision attention): within 1e-4 of the float64 oracle (truth)."""
+    worst, _ = _cfg2_worst_error(None)
+    assert max(worst.values()) < TOL, worst
+
+
+@pytest.mark.parametrize("mode,tol", [("fp16", 1e-3), ("bf16", 1e-2)])
+def test_cfg2_reduced_precision_modes(mode, tol):
+    """BASELINE config 2 names bf16 (config 5 fp16); the reference defines no mixed precision, so
+    these modes are judged against the fp32/fp64 oracle with a looser, stated tolerance: cross-attention operands
+    (Q, K, V, probabilities) rounded once to 16 bits (2^-11 / 2^-8 relative), everything else fp32."""
+    worst, dec = _cfg2_worst_error(mode)
+    print("\nreduced precision", mode, worst)
+    assert max(worst.values()) < tol, worst
+    assert max(worst.values()) > 1e-5          # the reduced-precision kernels really ran
+    if mode == "fp16":
+        assert not dec.fp16_range_exceeded()
 
 
 def test_closer_to_fp64_truth_than_the_fp32_reference():

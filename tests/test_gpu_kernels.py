@@ -112,6 +112,27 @@ def test_attention_split_fp16x3(B, H, Lq, Lk):
     assert int(scratch[:1].view(torch.int32).item()) == 0          # no fp16 range overflow flagged
 
 
+@pytest.mark.parametrize("bf16,tol", [(0, 2e-3), (1, 1.5e-2)])
+@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 4, 64, 9600), (2, 2, 100, 1000), (1, 1, 32, 64), (1, 2, 256, 4097)])
+def test_attention_half(B, H, Lq, Lk, bf16, tol):
+    """Single-product fp16 / bf16 attention (modes 2 / 3): tolerance = a few 16-bit ulps of the value scale
+    (fp16 2^-11, bf16 2^-8 relative operand rounding), stated here; ragged Lq / Lk covered."""
+    dh, Cn = 64, H * 64
+    q = synth.normal(1, "q", (B, Lq, Cn)); k = synth.normal(2, "k", (B, Lk, Cn)); v = synth.normal(3, "v", (B, Lk, Cn), std=2.0)
+    k[0, 0, :dh] = 2.0 * q[0, 0, :dh]                 # a peaky row
+    nbytes = lib().parq_k_attention_half_scratch_bytes(B, H, Lq, Lk)
+    scratch = torch.empty(nbytes // 4 + 1, device="cuda")
+    out = torch.empty(B, Lq, Cn, device="cuda")
+    dq, dk, dv = dev(q), dev(k), dev(v)
+    _lib.check(lib().parq_k_attention_half(_lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(out), B, H, Lq, Lk, bf16,
+                                          _lib.ptr(scratch), nbytes, sptr()), "attention_half")
+    tq, tk, tv = (torch.from_numpy(x).double().view(B, -1, H, dh).transpose(1, 2) for x in (q, k, v))
+    want = (torch.softmax(tq @ tk.transpose(-1, -2) / dh ** 0.5, -1) @ tv).transpose(1, 2).reshape(B, Lq, Cn)
+    err = rel_err(out.cpu().numpy(), want.numpy())
+    assert err < tol, err
+    assert err > 1e-6            # it really is the reduced-precision path
+
+
 def test_attention_split_spike_forces_deferred_rescale():
     """The split kernel defers the running-max update (threshold 2^10): keys that dominate late in
     the stream must take the rescale branch; a moderately larger key (< threshold) must not need it."""
