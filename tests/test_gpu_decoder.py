@@ -210,6 +210,51 @@ def test_full_size_output_properties(cfg3):
     assert torch.allclose(outs[0]["coord_pos"][0], ref0, atol=2e-6)
 
 
+def test_cfg5_shape_modes_agree_at_full_size():
+    """BASELINE cfg 5 geometry: 20 views 960x1280 -> 240x320 features (N = 1 536 000 tokens, 1.57 GB), 512 queries,
+    12 iterations, fp16.  The CPU oracle cannot run this size, so the check is size-independent: the fp16 mode, the
+    split-precision mode and the exact-fp32 mode are three different kernel sets (different cache layouts, key
+    splits and arithmetic) and must agree when teacher-forced with the same reference points; also exercises
+    > 2^31-byte buffers and the two query tiles per head."""
+    cfg = synth.decoder_cfg(dim=256, queries=512, heads=4, ffn=768, layers=12)
+    W = synth.make_decoder_weights(cfg, 51, damped=True)
+    dec = make_decoder(cfg, W)
+    V, h, w = 20, 240, 320
+    cam, T_cp, T_wp, T_wl = synth.make_geometry(52, 1, V, h, w)
+    geo = (dev(cam), dev(T_cp), dev(T_wp), dev(T_wl))
+    g = torch.Generator(device="cuda").manual_seed(53)
+    tokens = torch.randn(1, V * h * w, 256, device="cuda", generator=g)
+    dec.attention_mode = "split"
+    dec.prepare(tokens, *geo, feat_hw=(h, w))
+    base, refs = [], [None]
+    for k_it in range(12):
+        o, nxt = dec.iterate(k_it, None)
+        base.append({k: v.clone() for k, v in o.items()})
+        refs.append(nxt.clone())
+    for o in base:
+        for key, v in o.items():
+            assert torch.isfinite(v).all(), key
+    for mode, tol, iters in (("fp16", 1e-3, 12), ("fp32", 2e-5, 2)):      # fp32 MFMA at this size: 2 iterations suffice
+        dec.attention_mode = mode
+        dec.prepare(tokens, *geo, feat_hw=(h, w))
+        worst = 0.0
+        for k_it in range(iters):
+            o, _ = dec.iterate(k_it, None if k_it == 0 else refs[k_it])
+            top2 = base[k_it]["sem_cls_prob"].topk(2, -1).values
+            ok = (top2[..., 0] - top2[..., 1]) > 0.05
+            for key in o:
+                x, y = o[key], base[k_it][key]
+                if key == "size_unnormalized":
+                    x, y = x[ok], y[ok]
+                worst = max(worst, rel_err(x.cpu().numpy(), y.cpu().numpy()))
+        print("\ncfg5 shape: %s vs split worst %.3e" % (mode, worst))
+        assert worst < tol, (mode, worst)
+        if mode == "fp16":
+            assert not dec.fp16_range_exceeded()
+    del tokens
+    torch.cuda.empty_cache()
+
+
 def test_ray_pe_golden_and_fused_tokenisation():
     """AddRayPE on the HIP path vs the golden captured from the reference (g5), and the fused
     features+PE channels-last tokens vs the oracle's tokenize()."""
