@@ -121,6 +121,35 @@ def test_cfg2_reduced_precision_modes(mode, tol):
         assert not dec.fp16_range_exceeded()
 
 
+@pytest.mark.parametrize("B,V,h,w,Q,heads,dim,ffn", [
+    (2, 3, 11, 13, 40, 4, 256, 768),       # 16-row tiles straddle the two scenes (Q % 16 != 0), odd feature map
+    (3, 1, 9, 7, 50, 2, 128, 96),          # single view, Q % 16 = 2, small dims (K = 96 is not a multiple of 64)
+    (9, 2, 8, 8, 33, 4, 256, 768),         # M = 297 rows: 32x32 tiles (tiles32 >= CUs is not reached -> 16) with 9 scenes
+    (1, 2, 6, 5, 7, 4, 256, 768),          # fewer queries than a tile
+])
+def test_ragged_shapes_vs_fp64_oracle(B, V, h, w, Q, heads, dim, ffn):
+    """Ragged query counts / scene counts / feature maps through the whole chain (tile tails of the small-GEMM,
+    GroupNorm scenes straddling tiles, partial attention blocks), teacher-forced against the float64 oracle."""
+    cfg = synth.decoder_cfg(dim=dim, queries=Q, heads=heads, ffn=ffn, layers=3)
+    W = synth.make_decoder_weights(cfg, 61)
+    sc = synth.make_scene(62, B, V, h, w, dim, smooth=True)
+    dec = make_decoder(cfg, W)
+    outs = [to_np(o) for o in dec(*scene_args(sc))]
+    od = O.OracleDecoder(cfg, W, synth.SCANNET_MEAN_SIZES, dtype=torch.float64)
+    forced = [O.normalize(torch.from_numpy(o["coord_pos"]).double(), cfg.TRANSFORMER.SCALE) for o in outs]
+    with torch.no_grad():
+        want = od.forward(sc["tokens"], sc["camera"], sc["T_camera_pseudoCam"], sc["T_world_pseudoCam"],
+                          sc["T_world_local"], forced_refs=forced)
+    for k, (a, b) in enumerate(zip(outs, want)):
+        top2 = b["sem_cls_prob"].topk(2, -1).values
+        ok = ((top2[..., 0] - top2[..., 1]) > 1e-3).numpy()
+        for key in a:
+            x, y = a[key], b[key].numpy()
+            if key == "size_unnormalized":
+                x, y = x[ok], y[ok]
+            assert rel_err(x, y) < TOL, (k, key, rel_err(x, y))
+
+
 def test_closer_to_fp64_truth_than_the_fp32_reference():
     """g7 holds the reference run in float64 on the g2 inputs.  Teacher-forced with the SAME
     per-iteration reference points, the HIP fp32 path must be no further from that truth than
