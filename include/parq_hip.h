@@ -155,13 +155,15 @@ int parq_profile_read(parq_handle h, int32_t which, double *total_ms, int64_t *l
  * plus, when features_nchw (B, V, C, h, w) is given, the feature maps (the `+` and the einops
  * rearrange of parq_lightning.py:75-85).  w1 (C, 3*num_samples), b1 (C), w2 (C, C), b2 (C) are
  * AddRayPE.encoder.{0,2}.{weight,bias}; scale6_host = RAY_POINTS_SCALE (host pointer).
+ * nchw_out != 0 writes the result as (B, V, C, h, w) instead (what AddRayPE.forward returns); available on the
+ * fused path (C = 256, 64 samples: operand tile generated in-kernel, two persistent W-stationary kernels).
  * Requires (3*num_samples) % 64 == 0 and C % 64 == 0 (shipped: 64 samples, C = 1024 or 256). */
 size_t parq_ray_pe_workspace_bytes(int32_t B, int32_t V, int32_t hh, int32_t ww, int32_t C, int32_t num_samples);
 int parq_ray_pe(const float *camera, const float *T_camera_pseudoCam, const float *T_world_pseudoCam,
                 const float *T_world_local, const float *w1, const float *b1, const float *w2, const float *b2,
                 const float *scale6_host, float min_depth, float max_depth, int32_t num_samples, int32_t B,
                 int32_t V, int32_t hh, int32_t ww, int32_t C, const float *features_nchw, float *tokens_out,
-                void *workspace, size_t workspace_bytes, parq_stream stream);
+                int32_t nchw_out, void *workspace, size_t workspace_bytes, parq_stream stream);
 
 /* ---- single kernels (parity tests, roofline measurements) --------------------------- */
 

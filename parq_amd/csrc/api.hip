@@ -762,15 +762,19 @@ static int64_t raype_align(int64_t x) { return (x + 63) / 64 * 64; }
 size_t parq_ray_pe_workspace_bytes(int32_t B, int32_t V, int32_t hh, int32_t ww, int32_t C, int32_t num_samples) {
     if (B < 1 || V < 1 || hh < 1 || ww < 1 || C < 1 || num_samples < 1) return 0;
     const int64_t M = (int64_t)B * V * hh * ww, K1 = 3 * (int64_t)num_samples;
-    // points [M][K1] | hidden [M][C] | W1 hi/lo (C*K1 halfs each) | W2 hi/lo (C*C halfs each)
-    const int64_t floats = raype_align(M * K1) + raype_align(M * C) + raype_align(C * K1) + raype_align((int64_t)C * C);
+    // hidden [M][C] | W1 hi/lo (C*K1 halfs each) | W2 hi/lo (C*C halfs each) | pose + depth tables (float64)
+    // | points [M][K1] (generic path only: C != 256 or num_samples != 64)
+    const bool fused = (C == 256 && num_samples == 64);
+    const int64_t floats = raype_align(M * C) + raype_align(C * K1) + raype_align((int64_t)C * C) +
+                           raype_align(2 * ((int64_t)B * V * 12 + num_samples)) + (fused ? 0 : raype_align(M * K1));
     return (size_t)floats * sizeof(float);
 }
 
 int parq_ray_pe(const float* camera, const float* T_cp, const float* T_wp, const float* T_wl, const float* w1,
                 const float* b1, const float* w2, const float* b2, const float* scale6_host, float min_depth,
                 float max_depth, int32_t num_samples, int32_t B, int32_t V, int32_t hh, int32_t ww, int32_t C,
-                const float* features_nchw, float* tokens_out, void* workspace, size_t workspace_bytes, parq_stream stream) {
+                const float* features_nchw, float* tokens_out, int32_t nchw_out, void* workspace, size_t workspace_bytes,
+                parq_stream stream) {
     if (!camera || !T_cp || !T_wp || !T_wl || !w1 || !b1 || !w2 || !b2 || !scale6_host || !tokens_out || !workspace)
         return fail(PARQ_ERR_ARG, "NULL argument");
     if (B < 1 || V < 1 || hh < 1 || ww < 1 || num_samples < 1) return fail(PARQ_ERR_ARG, "bad dims");
@@ -782,14 +786,22 @@ int parq_ray_pe(const float* camera, const float* T_cp, const float* T_wp, const
     const int M = (int)M64, K1 = 3 * num_samples;
     hipStream_t s = (hipStream_t)stream;
     float* wsp = (float*)workspace;
-    float* P = wsp;
-    float* Hd = P + raype_align((int64_t)M * K1);
+    float* Hd = wsp;
     float* W1s = Hd + raype_align((int64_t)M * C);
     float* W2s = W1s + raype_align((int64_t)C * K1);
+    double* tabs = reinterpret_cast<double*>(W2s + raype_align((int64_t)C * C));
+    float* P = reinterpret_cast<float*>(tabs) + raype_align(2 * ((int64_t)B * V * 12 + num_samples));
     char* w1hi = (char*)W1s; char* w1lo = w1hi + (size_t)C * K1 * 2;
     char* w2hi = (char*)W2s; char* w2lo = w2hi + (size_t)C * C * 2;
     HIPCHK(launch_split_f32(w1, w1hi, w1lo, (int64_t)C * K1, s));
     HIPCHK(launch_split_f32(w2, w2hi, w2lo, (int64_t)C * C, s));
+    if (C == 256 && num_samples == 64) {
+        HIPCHK(launch_raype_fused(camera, T_cp, T_wp, T_wl, scale6_host, min_depth, max_depth, B, V, hh, ww, w1hi, w1lo, b1,
+                                  w2hi, w2lo, b2, features_nchw, Hd, tabs, tabs + (int64_t)B * V * 12, tokens_out,
+                                  nchw_out ? 1 : 0, s));
+        return PARQ_OK;
+    }
+    if (nchw_out) return fail(PARQ_ERR_ARG, "NCHW output needs the fused path (C = 256, 64 samples)");
     HIPCHK(launch_raype_points(camera, T_cp, T_wp, T_wl, scale6_host, min_depth, max_depth, B, V, hh, ww, num_samples, P, s));
     HIPCHK(launch_gemm_split(P, K1, w1hi, w1lo, b1, Hd, C, M, C, K1, 1, nullptr, 1, s));
     HIPCHK(launch_gemm_split(Hd, C, w2hi, w2lo, b2, tokens_out, C, M, C, C, 0, features_nchw, hh * ww, s));

@@ -153,6 +153,10 @@ hipError_t launch_cvt16(const float* src, void* dst, int64_t n, int kind, hipStr
 hipError_t launch_raype_points(const float* cam, const float* T_cp, const float* T_wp, const float* T_wl,
                                const float* scale6, float min_depth, float max_depth, int B, int V, int h, int w, int S,
                                float* P, hipStream_t s);
+hipError_t launch_raype_fused(const float* cam, const float* T_cp, const float* T_wp, const float* T_wl, const float* scale6,
+                              float min_depth, float max_depth, int B, int V, int h, int w, const void* W1hi, const void* W1lo,
+                              const float* b1, const void* W2hi, const void* W2lo, const float* b2, const float* feat,
+                              float* hidden, double* Tl, double* depth, float* out, int nchw_out, hipStream_t s);
 hipError_t launch_gemm_split(const float* X, int64_t ldx, const void* Whi, const void* Wlo, const float* bias, float* Y,
                              int64_t ldy, int M, int N, int K, int relu, const float* feat, int hw, hipStream_t s);
 

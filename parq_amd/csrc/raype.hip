@@ -270,6 +270,328 @@ __global__ __launch_bounds__(kThreads) void gemm_split_kernel(GemmArgs a) {
     }
 }
 
+
+// ================================================================================================
+// Fused fast path (C = 256, 64 samples): two persistent W-stationary kernels, modelled on kvproj_ws_kernel.
+//
+//   raype_hidden_kernel  hidden = relu(p W1^T + b1).  A workgroup of 8 waves owns all 256 hidden units (each wave
+//                        keeps the hi/lo fragments of its 32 rows of W1 in registers), walks 64-token tiles and
+//                        GENERATES the operand tile p (64 x 192) itself: thread (token = tid & 63) computes three
+//                        8-value chunks in float64 geometry (one FMA per value: p_axis = depth_j * g_axis + t_axis
+//                        with g = R (rx, ry, 1) per token) + fp32 log, splits them hi/lo and writes them straight
+//                        into the swizzled LDS operand image.  The 147 MB point tensor never exists.
+//   raype_tokens_kernel  tokens = feat + hidden W2^T + b2 (or the NCHW encoding alone).  Same structure with the
+//                        hidden tile streamed from memory; products are taken TRANSPOSED (rows = channels,
+//                        columns = tokens) so that lanes walk consecutive pixels: the NCHW feature read (and the
+//                        NCHW encoding write) is 128-byte coalesced, a lane's 4 consecutive accumulator registers
+//                        are 4 consecutive channels = one 16-byte store into the channels-last token row.
+struct RayFusedArgs {
+    const float* cam;          // (B*V, 6)
+    const double* Tl;          // (B*V, 12): local <- camera, float64
+    const double* depth;       // (S)
+    double lo[3], inv[3];      // box normalisation u = (p - lo) * inv
+    int hw, w, S, M;           // M = B*V*h*w tokens
+    const _Float16* Whi; const _Float16* Wlo; const float* bias;   // this kernel's weight [256][K] hi/lo, bias [256]
+    float* hidden;             // [M][256]
+    const float* feat;         // NCHW features (B*V, 256, h, w) or nullptr
+    float* out;                // tokens [M][256] (nchw_out = 0) or encoding (B*V, 256, h, w) (nchw_out = 1)
+    int nchw_out;
+};
+
+constexpr int kFC = 256;       // channels / hidden units of the fused path
+constexpr int kFK1 = 192;      // 3 * 64 samples
+constexpr int kFTM = 64;       // tokens per tile
+constexpr int kFThreads = 512;
+constexpr int kOtLd = kFC + 4;   // row stride (floats) of the epilogue transpose tile
+
+__global__ void raype_pose_kernel(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V, float min_depth,
+                                  float max_depth, int S, double* Tl, double* depth) {
+    const int bv = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bv < B * V) {
+        const int b = bv / V;
+        const P12 T = pmul(pmul(pinv(ldp(T_wl + (int64_t)b * 12)), ldp(T_wp + (int64_t)bv * 12)), pinv(ldp(T_cp + (int64_t)bv * 12)));
+        for (int i = 0; i < 9; ++i) Tl[(int64_t)bv * 12 + i] = T.R[i];
+        for (int i = 0; i < 3; ++i) Tl[(int64_t)bv * 12 + 9 + i] = T.t[i];
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < S) {
+        const int j = threadIdx.x;
+        const double ramp = S > 1 ? (double)j / (double)(S - 1) : 0.0;
+        depth[j] = exp(log((double)min_depth) + log((double)max_depth / (double)min_depth) * ramp);   // encoding_utils.py:82-89
+    }
+}
+
+__global__ __launch_bounds__(kFThreads, 1) void raype_hidden_kernel(RayFusedArgs a, int ntiles, int P) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];      // [2 buffers][3 k-steps][A_hi 64x64 | A_lo 64x64]
+    __shared__ double dtab[64];
+    constexpr int kStep = 2 * kFTM * 64;                                // halfs per k-step (hi + lo)
+    constexpr int kBuf = 3 * kStep;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int p = blockIdx.x;
+    if (tid < 64) dtab[tid] = tid < a.S ? a.depth[tid] : 1.0;
+    // W1 fragments of this wave's 32 hidden units: [k-step][s2][hi, lo]
+    const int col = wave * 32 + li;
+    half8 wfr[3][4][2];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const int64_t off = (int64_t)col * kFK1 + ks * 64 + 32 * kh + 8 * s2;
+            wfr[ks][s2][0] = *reinterpret_cast<const half8*>(a.Whi + off);
+            wfr[ks][s2][1] = *reinterpret_cast<const half8*>(a.Wlo + off);
+        }
+    const float bias = a.bias[col];
+    __syncthreads();
+
+    // operand generator: thread (token row = tid & 63, wave) produces k = 24 wave .. 24 wave + 23, i.e. the three axes of
+    // depths j = 8 wave .. 8 wave + 7 (k = 3 j + axis): per value ONE float64 FMA u = depth_j * G_axis + T_axis with
+    // G = (R (rx, ry, 1)) / (hi - lo) and T = (t - lo) / (hi - lo) per token, clamps and 1 - u in float64 (the
+    // inverse_sigmoid is ill-conditioned at the clamp edges), ratio and log in fp32 (v_rcp / v_log: ~1e-7 relative).
+    const int grow = tid & 63;
+    auto generate = [&](int tile, int buf) {
+        const int m = tile * kFTM + grow;
+        double G[3] = {0.0, 0.0, 0.0}, T3[3] = {0.5, 0.5, 0.5};
+        if (m < a.M) {
+            const int bv = m / a.hw, pix = m - bv * a.hw;
+            const int y = pix / a.w, x = pix - y * a.w;
+            const float* cm = a.cam + (int64_t)bv * 6;
+            // integer pixel grid (no +0.5), unproject to z = 1 (utils/encoding_utils.py:15-20, utils/wrappers.py:543-548)
+            const double rx = ((double)x - (double)cm[4]) / (double)cm[2];
+            const double ry = ((double)y - (double)cm[5]) / (double)cm[3];
+            const double* T = a.Tl + (int64_t)bv * 12;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                G[i] = (T[i * 3] * rx + T[i * 3 + 1] * ry + T[i * 3 + 2]) * a.inv[i];
+                T3[i] = (T[9 + i] - a.lo[i]) * a.inv[i];
+            }
+        }
+        _Float16* B0 = lds + buf * kBuf;
+        double dj[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) dj[jj] = dtab[8 * wave + jj];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float x8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int q = 8 * i + e;                    // 0..23 inside this thread's run: depth q / 3, axis q % 3
+                const int jj = q / 3, ax = q - 3 * jj;      // compile-time after unrolling
+                double u = dj[jj] * G[ax] + T3[ax];
+                u = fmin(fmax(u, 0.0), 1.0);
+                const double x1 = fmax(u, 1e-3);
+                const double x2 = fmax(1.0 - u, 1e-3);
+                // inverse_sigmoid, eps 1e-3 (ray_positional_encoding.py:23-27)
+                x8[e] = __logf(__fdividef((float)x1, (float)x2));
+            }
+            half8 hi, lo8;
+            split8(x8, hi, lo8);
+            const int chunk = 3 * wave + i;                 // 8-value chunk index 0..23 of the 192-vector
+            const int ks = chunk >> 3, c = chunk & 7;
+            const int pos = c ^ ((grow >> 1) & 7);
+            _Float16* Ahi = B0 + ks * kStep;
+            *reinterpret_cast<half8*>(Ahi + grow * 64 + pos * 8) = hi;
+            *reinterpret_cast<half8*>(Ahi + kFTM * 64 + grow * 64 + pos * 8) = lo8;
+        }
+    };
+
+    int it = 0;
+    if (p < ntiles) generate(p, 0);
+    __syncthreads();
+    for (int tile = p; tile < ntiles; tile += P, ++it) {
+        const int buf = it & 1;
+        if (tile + P < ntiles) generate(tile + P, buf ^ 1);
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        const _Float16* B0 = lds + buf * kBuf;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const _Float16* Ahi = B0 + ks * kStep;
+            const _Float16* Alo = Ahi + kFTM * 64;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                half8 xh[2], xl[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int row = t * 32 + li;
+                    const int posr = (4 * kh + s2) ^ ((row >> 1) & 7);
+                    xh[t] = *reinterpret_cast<const half8*>(Ahi + row * 64 + posr * 8);
+                    xl[t] = *reinterpret_cast<const half8*>(Alo + row * 64 + posr * 8);
+                }
+                const half8 wh = wfr[ks][s2][0], wl = wfr[ks][s2][1];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[t], wh, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[t], wl, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[t], wh, acc[t], 0, 0, 0);
+            }
+        }
+        // rows = tokens, columns = hidden units: a register is one token row, lanes 32 consecutive units
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = tile * kFTM + t * 32 + mfma32_row(r, lane);
+                if (m < a.M) {
+                    const float y = acc[t][r] + bias;
+                    a.hidden[(int64_t)m * kFC + col] = y > 0.f ? y : 0.f;
+                }
+            }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kFThreads, 1) void raype_tokens_kernel(RayFusedArgs a, int ntiles, int P) {
+    // LDS: [2 buffers][A_hi 64x64 | A_lo 64x64] (32 KB), overlaid by the epilogue transpose tile ot[64][kOtLd] (66.5 KB);
+    // behind it the NCHW feature tile ftile[256 channels][64 pixels] (64 KB), filled by LDS-DMA during the k-loop
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    constexpr int kStep = 2 * kFTM * 64;
+    constexpr int nk = kFC / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int p = blockIdx.x;
+    const int col = wave * 32 + li;                  // this lane's row of W2 (output channel of the A operand)
+    half8 wfr[nk][4][2];
+#pragma unroll
+    for (int ks = 0; ks < nk; ++ks)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const int64_t off = (int64_t)col * kFC + ks * 64 + 32 * kh + 8 * s2;
+            wfr[ks][s2][0] = *reinterpret_cast<const half8*>(a.Whi + off);
+            wfr[ks][s2][1] = *reinterpret_cast<const half8*>(a.Wlo + off);
+        }
+    // hidden tile staging: 64 rows x 64 floats per k-step = 512 pieces of 8 floats, one per thread; two k-steps in flight
+    float4 areg[2][2];
+    const int srow = tid >> 3, sc = tid & 7;
+    auto gload = [&](int tile, int ks, float4 (&dst)[2]) {
+        const int m = tile * kFTM + srow;
+        if (m < a.M) {
+            const float4* q = reinterpret_cast<const float4*>(a.hidden + (int64_t)m * kFC + ks * 64 + sc * 8);
+            dst[0] = q[0];
+            dst[1] = q[1];
+        } else {
+            dst[0] = float4{0.f, 0.f, 0.f, 0.f};
+            dst[1] = float4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto swrite = [&](int buf, const float4 (&src)[2]) {
+        _Float16* Ahi = lds + buf * kStep;
+        _Float16* Alo = Ahi + kFTM * 64;
+        const int pos = sc ^ ((srow >> 1) & 7);
+        float x[8] = {src[0].x, src[0].y, src[0].z, src[0].w, src[1].x, src[1].y, src[1].z, src[1].w};
+        half8 hi, lo;
+        split8(x, hi, lo);
+        *reinterpret_cast<half8*>(Ahi + srow * 64 + pos * 8) = hi;
+        *reinterpret_cast<half8*>(Alo + srow * 64 + pos * 8) = lo;
+    };
+    const int my_tiles = p < ntiles ? (ntiles - p + P - 1) / P : 0;
+    const int total_steps = my_tiles * nk;
+    auto issue = [&](int q, float4 (&dst)[2]) {
+        if (q < total_steps) gload(p + (q / nk) * P, q % nk, dst);
+    };
+    int step = 0;
+    issue(0, areg[0]);
+    issue(1, areg[1]);
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    float* ot = reinterpret_cast<float*>(lds);                           // [64 tokens][kOtLd]
+    float* ftile = ot + kFTM * kOtLd;                                    // [256][64]
+    for (int tile = p; tile < ntiles; tile += P) {
+        // this tile's feature rows: one LDS-DMA instruction = 64 pixels of one channel (lanes = pixels)
+        if (a.feat) {
+            const int m = tile * kFTM + lane;
+            if (m < a.M) {
+                const int bv = m / a.hw, pix = m - bv * a.hw;
+                const float* fp = a.feat + (int64_t)bv * kFC * a.hw + pix;
+#pragma unroll 8
+                for (int i = 0; i < 32; ++i) {
+                    const int c = wave * 32 + i;
+                    __builtin_amdgcn_global_load_lds(fp + (int64_t)c * a.hw, (lds_byte*)(ftile + c * 64), 4, 0, 0);
+                }
+            }
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < nk; ++ks) {
+            const int buf = step & 1;
+            swrite(buf, areg[ks & 1]);
+            issue(step + 2, areg[ks & 1]);
+            __syncthreads();
+            const _Float16* Ahi = lds + buf * kStep;
+            const _Float16* Alo = Ahi + kFTM * 64;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                half8 xh[2], xl[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int row = t * 32 + li;
+                    const int posr = (4 * kh + s2) ^ ((row >> 1) & 7);
+                    xh[t] = *reinterpret_cast<const half8*>(Ahi + row * 64 + posr * 8);
+                    xl[t] = *reinterpret_cast<const half8*>(Alo + row * 64 + posr * 8);
+                }
+                const half8 wh = wfr[ks][s2][0], wl = wfr[ks][s2][1];
+                // transposed product: rows = channels, columns = tokens
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[t], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[t], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[t], acc[t], 0, 0, 0);
+            }
+            ++step;
+        }
+        // epilogue: register r of block t is channel 32 wave + mfma32_row(r, lane) of token tile*64 + 32 t + li.
+        // The NCHW encoding is written lane-contiguous as it is; channels-last token rows go through an LDS
+        // transpose (ot overlays the operand buffers: every wave is past its last fragment read) so that every store
+        // instruction writes one full 1 KB row.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // feature tile landed (hipcc does not track LDS-DMA)
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int m = tile * kFTM + t * 32 + li;
+            const bool ok = m < a.M;
+            const int bv = ok ? m / a.hw : 0, pix = ok ? m - bv * a.hw : 0;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int c0 = wave * 32 + 8 * g4 + 4 * kh;             // 4 consecutive channels in registers 4 g4 .. 4 g4 + 3
+                const float4 b4 = *reinterpret_cast<const float4*>(a.bias + c0);
+                float y[4] = {acc[t][4 * g4] + b4.x, acc[t][4 * g4 + 1] + b4.y, acc[t][4 * g4 + 2] + b4.z, acc[t][4 * g4 + 3] + b4.w};
+                if (a.feat && ok) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] += ftile[(c0 + e) * 64 + t * 32 + li];
+                }
+                if (a.nchw_out) {
+                    if (ok) {
+                        float* op = a.out + (int64_t)bv * kFC * a.hw + pix;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) op[(int64_t)(c0 + e) * a.hw] = y[e];
+                    }
+                } else {
+                    *reinterpret_cast<float4*>(ot + (t * 32 + li) * kOtLd + c0) = float4{y[0], y[1], y[2], y[3]};
+                }
+            }
+        }
+        __syncthreads();
+        if (!a.nchw_out) {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int row = wave * 8 + rr;
+                const int m = tile * kFTM + row;
+                if (m < a.M)
+                    *reinterpret_cast<float4*>(a.out + (int64_t)m * kFC + 4 * lane) =
+                        *reinterpret_cast<const float4*>(ot + row * kOtLd + 4 * lane);
+            }
+            __syncthreads();                                             // ot overlays the next tile's operand buffers
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_raype_points(const float* cam, const float* T_cp, const float* T_wp, const float* T_wl,
@@ -282,6 +604,47 @@ hipError_t launch_raype_points(const float* cam, const float* T_cp, const float*
     a.B = B; a.V = V; a.h = h; a.w = w; a.S = S; a.P = P;
     dim3 grid((unsigned)ceil_div64((int64_t)h * w * S, 256), B * V);
     hipLaunchKernelGGL(raype_points_kernel, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// Fused path: pose/depth tables, hidden layer, tokens (or NCHW encoding).  C = 256, S = 64 only.
+hipError_t launch_raype_fused(const float* cam, const float* T_cp, const float* T_wp, const float* T_wl, const float* scale6,
+                              float min_depth, float max_depth, int B, int V, int h, int w, const void* W1hi, const void* W1lo,
+                              const float* b1, const void* W2hi, const void* W2lo, const float* b2, const float* feat,
+                              float* hidden, double* Tl, double* depth, float* out, int nchw_out, hipStream_t s) {
+    const int S = 64;
+    const int64_t M64 = (int64_t)B * V * h * w;
+    if (M64 > 0x7fffffffLL) return hipErrorInvalidValue;
+    static bool attr = false;
+    const size_t lds_a = (size_t)2 * 3 * 2 * kFTM * 64 * sizeof(_Float16);      // 96 KB
+    const size_t lds_b = (size_t)kFTM * kOtLd * sizeof(float) + (size_t)kFC * 64 * sizeof(float);   // 66.5 KB (overlays the 32 KB operand buffers) + 64 KB feature tile
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&raype_hidden_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&raype_tokens_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(raype_pose_kernel, dim3(ceil_div(B * V, 64)), dim3(64), 0, s, T_cp, T_wp, T_wl, B, V, min_depth, max_depth,
+                       S, Tl, depth);
+    RayFusedArgs a;
+    a.cam = cam; a.Tl = Tl; a.depth = depth;
+    for (int i = 0; i < 3; ++i) {
+        a.lo[i] = (double)scale6[2 * i];
+        a.inv[i] = 1.0 / ((double)scale6[2 * i + 1] - (double)scale6[2 * i]);
+    }
+    a.hw = h * w; a.w = w; a.S = S; a.M = (int)M64;
+    a.hidden = hidden; a.feat = nullptr; a.out = nullptr; a.nchw_out = 0;
+    const int ntiles = ceil_div((int)M64, kFTM);
+    int P = device_num_cus();
+    if (P > ntiles) P = ntiles;
+    a.Whi = reinterpret_cast<const _Float16*>(W1hi); a.Wlo = reinterpret_cast<const _Float16*>(W1lo); a.bias = b1;
+    hipLaunchKernelGGL(raype_hidden_kernel, dim3(P), dim3(kFThreads), lds_a, s, a, ntiles, P);
+    a.Whi = reinterpret_cast<const _Float16*>(W2hi); a.Wlo = reinterpret_cast<const _Float16*>(W2lo); a.bias = b2;
+    a.feat = feat; a.out = out; a.nchw_out = nchw_out;
+    hipLaunchKernelGGL(raype_tokens_kernel, dim3(P), dim3(kFThreads), lds_b, s, a, ntiles, P);
     return hipGetLastError();
 }
 

@@ -29,7 +29,7 @@ class AddRayPE(nn.Module):
         self.encoder = nn.Sequential(nn.Linear(3 * num_samples, dim_out), nn.ReLU(), nn.Linear(dim_out, dim_out))
         self._ws = None
 
-    def _run(self, camera, T_cp, T_wp, T_wl, feat_hw, features):
+    def _run(self, camera, T_cp, T_wp, T_wl, feat_hw, features, nchw=False):
         cam, T_cp, T_wp, T_wl = (raw(x) for x in (camera, T_cp, T_wp, T_wl))
         if not cam.is_cuda:
             raise RuntimeError("parq_amd.AddRayPE runs on the GPU only (there is no CPU fallback)")
@@ -49,26 +49,28 @@ class AddRayPE(nn.Module):
         nbytes = lib.parq_ray_pe_workspace_bytes(B, V, h, w, Cd, self.num_samples)
         if self._ws is None or self._ws.numel() * 4 < nbytes or self._ws.device != dev:
             self._ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=dev)
-        out = torch.empty(B, V * h * w, Cd, dtype=torch.float32, device=dev)
+        fused = Cd == 256 and self.num_samples == 64          # the library's fused path can write (B, V, C, h, w) directly
+        nchw = bool(nchw and fused)
+        out = torch.empty((B, V, Cd, h, w) if nchw else (B, V * h * w, Cd), dtype=torch.float32, device=dev)
         p = [prep(t.detach()) for t in (self.encoder[0].weight, self.encoder[0].bias, self.encoder[2].weight,
                                         self.encoder[2].bias)]
         _lib.check(lib.parq_ray_pe(_lib.ptr(cam), _lib.ptr(T_cp), _lib.ptr(T_wp), _lib.ptr(T_wl), _lib.ptr(p[0]),
                                    _lib.ptr(p[1]), _lib.ptr(p[2]), _lib.ptr(p[3]), (C.c_float * 6)(*self.ray_points_scale),
                                    self.min_depth, self.max_depth, self.num_samples, B, V, h, w, Cd, _lib.ptr(features),
-                                   _lib.ptr(out), _lib.ptr(self._ws), self._ws.numel() * 4, _lib.stream_ptr()),
+                                   _lib.ptr(out), int(nchw), _lib.ptr(self._ws), self._ws.numel() * 4, _lib.stream_ptr()),
                    "parq_ray_pe")
-        return out, (B, V, h, w)
+        return out, (B, V, h, w), nchw
 
     @torch.no_grad()
     def forward(self, images_feat, camera=None, T_camera_pseudoCam=None, T_world_pseudoCam=None, T_world_local=None):
         """The encoding (B, T, C, H, W), as the reference returns it (images_feat only supplies the shape)."""
         hw = tuple(images_feat.shape[-2:])
-        enc, (B, V, h, w) = self._run(camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, hw, None)
-        return enc.view(B, V, h, w, self.dim_out).permute(0, 1, 4, 2, 3)
+        enc, (B, V, h, w), nchw = self._run(camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, hw, None, nchw=True)
+        return enc if nchw else enc.view(B, V, h, w, self.dim_out).permute(0, 1, 4, 2, 3)
 
     @torch.no_grad()
     def tokens(self, images_feat, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local):
         """features + encoding, tokenised channels-last (B, T*H*W, C) in one pass."""
         hw = tuple(images_feat.shape[-2:])
-        out, _ = self._run(camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, hw, images_feat)
+        out, _, _ = self._run(camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, hw, images_feat)
         return out
