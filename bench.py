@@ -91,6 +91,33 @@ def cpu_baseline(cfg, W, inputs, min_seconds=12.0, max_iters=24):
                       % (budget_iters, dt, os.cpu_count() or 0)}
 
 
+def ray_pe_timing(B, device):
+    """Not part of the metric (PARQDecoder.forward): the once-per-forward AddRayPE + tokenisation that precedes the
+    decoder in PARQ.forward (model/parq_lightning.py:70-85), timed at the same workload for the end-to-end picture."""
+    from parq_amd import AddRayPE
+    V, (h, w), C = WORKLOAD["views"], WORKLOAD["feat_hw"], WORKLOAD["dim"]
+    pe = AddRayPE(C, synth.DEFAULT_SCALE, 64, 0.25, 5.25)
+    Wp = synth.make_ray_pe_weights(C, 7)
+    pe.load_state_dict({k: torch.from_numpy(v) for k, v in Wp.items()}, strict=True)
+    pe = pe.to(device).eval()
+    cam, T_cp, T_wp, T_wl = (torch.from_numpy(x).to(device) for x in synth.make_geometry(8, B, V, h, w))
+    feat = torch.randn(B, V, C, h, w, device=device)
+    for _ in range(2):
+        pe.tokens(feat, cam, T_cp, T_wp, T_wl)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        pe.tokens(feat, cam, T_cp, T_wp, T_wl)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    N = V * h * w
+    return {"tokens_ms": ms, "algorithmic_gflop": 2.0 * B * N * (192 * C + C * C) / 1e9,
+            "min_traffic_gb": 2.0 * B * N * C * 4 / 1e9,
+            "note": "AddRayPE.tokens (ray-point encoding + feature add + channels-last tokenisation), outside the metric"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,6 +222,7 @@ def main():
                                         "avg_launch_ms": (ps_ms / ps_n) if ps_n else None, "launches": ps_n},
             "kernel_groups_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
         }
+        out["ray_pe"] = ray_pe_timing(B, device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, W, inputs)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -61,6 +61,10 @@ CASES = {
 
 RAYPE_CASE = dict(dim=64, seed=15, sseed=105, B=1, V=2, h=6, w=8,
                   ray_points_scale=[-3.0, 3.0, -2.0, 0.5, 0.25, 5.25])
+# d = 256: the dimension of the BASELINE configurations (the library's fused ray-PE path); 2 scenes x 3 views of
+# 7 x 9 pixels = 378 tokens, so the 64-token tiles straddle views and scenes and the last one is partial
+RAYPE_CASE_D256 = dict(dim=256, seed=16, sseed=106, B=2, V=3, h=7, w=9,
+                       ray_points_scale=[-3.0, 3.0, -2.0, 0.5, 0.25, 5.25])
 
 
 def case_inputs(case):
@@ -175,8 +179,9 @@ def main(only=None):
         with open(os.path.join(OUT_DIR, "state_dict_keys.json"), "w") as f:
             json.dump(schema, f, indent=1, sort_keys=True)
         print("wrote state_dict_keys.json")
-    if not only or "g5_raype" in only:
-        c = RAYPE_CASE
+    for gname, c in (("g5_raype", RAYPE_CASE), ("g9_raype_d256", RAYPE_CASE_D256)):
+        if only and gname not in only:
+            continue
         Wp = synth.make_ray_pe_weights(c["dim"], c["seed"])
         cam, T_cp, T_wp, T_wl = synth.make_geometry(c["sseed"], c["B"], c["V"], c["h"], c["w"])
         pe = ref.AddRayPE(c["dim"], c["ray_points_scale"], 64, 0.25, 5.25).eval()
@@ -185,10 +190,9 @@ def main(only=None):
         with torch.no_grad():
             enc = pe(feat, ref.Camera(torch.from_numpy(cam)), ref.Pose(torch.from_numpy(T_cp)),
                      ref.Pose(torch.from_numpy(T_wp)), ref.Pose(torch.from_numpy(T_wl)))
-        np.savez_compressed(os.path.join(OUT_DIR, "g5_raype.npz"), encoding=enc.numpy(),
+        np.savez_compressed(os.path.join(OUT_DIR, gname + ".npz"), encoding=enc.numpy(),
                             meta=np.frombuffer(json.dumps(c, sort_keys=True).encode(), dtype=np.uint8))
-        print("wrote g5_raype", tuple(enc.shape))
-
+        print("wrote", gname, tuple(enc.shape))
 
 if __name__ == "__main__":
     main(sys.argv[1:] or None)

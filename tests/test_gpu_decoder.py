@@ -284,11 +284,13 @@ def test_cfg5_shape_modes_agree_at_full_size():
     torch.cuda.empty_cache()
 
 
-def test_ray_pe_golden_and_fused_tokenisation():
-    """AddRayPE on the HIP path vs the golden captured from the reference (g5), and the fused
-    features+PE channels-last tokens vs the oracle's tokenize()."""
+@pytest.mark.parametrize("name", ["g5_raype", "g9_raype_d256"])
+def test_ray_pe_golden_and_fused_tokenisation(name):
+    """AddRayPE on the HIP path vs the goldens captured from the reference (g5: d = 64, generic path; g9: d = 256, the
+    fused in-kernel-generator path with tiles straddling views and scenes), and the fused features+PE channels-last
+    tokens vs the oracle's tokenize()."""
     from parq_amd import AddRayPE
-    case, z = G.load("g5_raype")
+    case, z = G.load(name)
     Wp = synth.make_ray_pe_weights(case["dim"], case["seed"])
     cam, T_cp, T_wp, T_wl = synth.make_geometry(case["sseed"], case["B"], case["V"], case["h"], case["w"])
     pe = AddRayPE(case["dim"], case["ray_points_scale"], 64, 0.25, 5.25)

@@ -65,8 +65,9 @@ def test_fp32_self_noise_is_inside_budget():
         G.compare({kk: v.numpy() for kk, v in o.items()}, z32, k, tol=1e-4, what="fp32 vs fp64")
 
 
-def test_ray_pe_golden():
-    case, z = G.load("g5_raype")
+@pytest.mark.parametrize("name", ["g5_raype", "g9_raype_d256"])
+def test_ray_pe_golden(name):
+    case, z = G.load(name)
     Wp = synth.make_ray_pe_weights(case["dim"], case["seed"])
     cam, T_cp, T_wp, T_wl = synth.make_geometry(case["sseed"], case["B"], case["V"], case["h"], case["w"])
     with torch.no_grad():
