@@ -94,7 +94,7 @@ def cpu_baseline(cfg, W, inputs, min_seconds=12.0, max_iters=24):
 def ray_pe_timing(B, device):
     """Not part of the metric (PARQDecoder.forward): the once-per-forward AddRayPE + tokenisation that precedes the
     decoder in PARQ.forward (model/parq_lightning.py:70-85), timed at the same workload for the end-to-end picture."""
-    from parq_amd import AddRayPE
+    from parq_amd import AddRayPE, synth
     V, (h, w), C = WORKLOAD["views"], WORKLOAD["feat_hw"], WORKLOAD["dim"]
     pe = AddRayPE(C, synth.DEFAULT_SCALE, 64, 0.25, 5.25)
     Wp = synth.make_ray_pe_weights(C, 7)
