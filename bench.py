@@ -91,6 +91,23 @@ def cpu_baseline(cfg, W, inputs, min_seconds=12.0, max_iters=24):
                       % (budget_iters, dt, os.cpu_count() or 0)}
 
 
+def pmc_traffic(kernel, scenes):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc.json, written from
+    `tools/collect_profiles.sh` output: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950 wide streaming reads).  Counters cannot be read from inside this process,
+    so the figure is the recorded one for the same kernel and scene count, or null."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        e = rec["kernels"][kernel]
+        if rec.get("scenes_per_gpu") != scenes:
+            return None
+        return (e["fetch_kb"] * e.get("fetch_correction", 2.0) + e["write_kb"]) * 1024.0
+    except Exception:
+        return None
+
+
 def ray_pe_timing(B, device):
     """Not part of the metric (PARQDecoder.forward): the once-per-forward AddRayPE + tokenisation that precedes the
     decoder in PARQ.forward (model/parq_lightning.py:70-85), timed at the same workload for the end-to-end picture."""
@@ -196,7 +213,9 @@ def main():
                                else "flash_split_kernel<1> (cross-attention QK^T+PV, single %s products, fp32 accumulate)" % mode if half
                                else "flash_f32_kernel (cross-attention QK^T+PV, fp32 MFMA)"),
                     "achieved": ach_tflops, "peak": mfma_peak, "unit": "TFLOP/s",
-                    "frac": (ach_tflops / mfma_peak) if ach_tflops else None, "traffic": None,
+                    "frac": (ach_tflops / mfma_peak) if ach_tflops else None,
+                    "traffic": pmc_traffic("flash_split_kernel", B) if split else None,
+                    "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc.json); algorithmic stream = 2*N*C*4*B bytes",
                     "avg_launch_ms": (ca_ms / ca_n) if ca_n else None, "launches": ca_n,
                     "algorithmic_gflop_per_launch": flop_per_launch / 1e9,
                     "peak_note": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 passes per product; the fp32-MFMA peak is %.1f"
@@ -218,7 +237,9 @@ def main():
             "roofline": roofline,
             "roofline_project_sample": {"bound": "hbm", "kernel": "project_sample_kernel",
                                         "achieved": ps_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                        "frac": (ps_gbs / PEAK_HBM_GBS) if ps_gbs else None, "traffic": None,
+                                        "frac": (ps_gbs / PEAK_HBM_GBS) if ps_gbs else None,
+                                        "traffic": pmc_traffic("project_sample_kernel", B),
+                                        "algorithmic_bytes_per_launch": bytes_per_launch,
                                         "avg_launch_ms": (ps_ms / ps_n) if ps_n else None, "launches": ps_n},
             "kernel_groups_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
         }
