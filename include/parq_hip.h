@@ -148,6 +148,24 @@ enum {
 int parq_profile_enable(parq_handle h, int32_t on);
 int parq_profile_read(parq_handle h, int32_t which, double *total_ms, int64_t *launches);
 
+/* ---- training: forward with saved activations + backward (model/parq_lightning.py:97-100) ----------
+ * The backward of the whole decoder chain as HIP kernels.  Needs attention mode 0 (the backward reads the fp32 K/V cache),
+ * head dim 32/64, dropout 0.  parq_forward_train = parq_forward that keeps every iteration's activations in the (larger)
+ * training workspace; parq_backward consumes them: `grads` holds d loss / d output per iteration (same (I,B,Q,k) layout as
+ * the outputs, NULL = zero), `grad_arena` receives d loss / d weight in the layout of the packed weight arena
+ * (parq_arena_lookup maps reference tensor names to offsets), `d_tokens` (B,N,C) or NULL receives d loss / d input tokens.
+ * Reference points are detached between iterations as in the reference (transformer_parq.py:331-332). */
+typedef struct parq_output_grads {
+    const float *pred_logits, *center_unnormalized, *size_unnormalized, *ortho6d;
+} parq_output_grads;
+size_t parq_train_workspace_bytes(parq_handle h, int32_t B, int32_t V, int32_t hh, int32_t ww);
+size_t parq_grad_arena_bytes(parq_handle h);
+int parq_forward_train(parq_handle h, const parq_scene *scene, void *workspace, size_t workspace_bytes,
+                       const parq_outputs *outs, parq_stream stream);
+int parq_backward(parq_handle h, const parq_scene *scene, void *workspace, size_t workspace_bytes, const parq_outputs *outs,
+                  const parq_output_grads *grads, float *grad_arena, float *d_tokens, parq_stream stream);
+int parq_arena_lookup(parq_handle h, const char *name, int64_t *offset, int64_t *rows, int64_t *cols, int64_t *ld);
+
 /* ---- AddRayPE.forward + tokenisation (model/ray_positional_encoding.py:61-139,
  *      model/parq_lightning.py:72-85), once per forward -------------------------------------
  * tokens_out (B, V*h*w, C) channels-last = ray-point positional encoding of every pixel

@@ -37,6 +37,11 @@ class ParqOutputs(C.Structure):
                 ("sem_cls_prob", C.c_void_p), ("coord_pos", C.c_void_p)]
 
 
+class ParqOutputGrads(C.Structure):
+    _fields_ = [("pred_logits", C.c_void_p), ("center_unnormalized", C.c_void_p),
+                ("size_unnormalized", C.c_void_p), ("ortho6d", C.c_void_p)]
+
+
 # every symbol include/parq_hip.h declares: (restype, argtypes)
 _vp, _i32, _i64, _sz, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.c_float
 SYMBOLS = {
@@ -55,6 +60,11 @@ SYMBOLS = {
     "parq_set_attention_mode": (C.c_int, [_vp, _i32]),
     "parq_profile_enable": (C.c_int, [_vp, _i32]),
     "parq_profile_read": (C.c_int, [_vp, _i32, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "parq_train_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32, _i32]),
+    "parq_grad_arena_bytes": (_sz, [_vp]),
+    "parq_forward_train": (C.c_int, [_vp, C.POINTER(ParqScene), _vp, _sz, C.POINTER(ParqOutputs), _vp]),
+    "parq_backward": (C.c_int, [_vp, C.POINTER(ParqScene), _vp, _sz, C.POINTER(ParqOutputs), C.POINTER(ParqOutputGrads), _vp, _vp, _vp]),
+    "parq_arena_lookup": (C.c_int, [_vp, C.c_char_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "parq_ray_pe_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "parq_ray_pe": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_f), _f, _f, _i32, _i32, _i32, _i32, _i32, _i32,
                               _vp, _vp, _i32, _vp, _sz, _vp]),

@@ -63,6 +63,14 @@ struct Workspace {
     int64_t kvc, flags;               // split-fp16 K/V cache, int flags (overflow)
     int64_t total;
     int self_split, cross_split;
+    // per-iteration activations live in [iter_begin, iter_end); a training forward keeps one copy per iteration:
+    // iteration k > 0 uses the same offsets shifted by stash + (k - 1) * (iter_end - iter_begin) - iter_begin
+    int64_t sa, ln3, lse_s, lse_c, refk;
+    int64_t iter_begin, iter_end, stash;
+    // backward scratch (training workspace only)
+    int64_t g_a, g_b, g_c, g_pos, g_tmp, g_ffh, g_h1, g_h2, g_z, g_act, g_h3, g_qkv, g_emb, g_ref, g_D, g_bs, wT, g_kv;
+    int64_t train_total;
+    int64_t shift(int k) const { return k == 0 ? 0 : stash + (int64_t)(k - 1) * (iter_end - iter_begin) - iter_begin; }
 };
 
 struct ProfEvent { hipEvent_t a, b; int which; };
@@ -138,7 +146,11 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     ws->xc = take(M * C);
     ws->h1 = take(M * c->NH1); ws->h2 = take(M * 2 * C);
     ws->gn_sums = take((int64_t)2 * B * 4 * kGnSlots * 2);  // doubles: [2 layers][B][2 heads][kGnSlots][2]
-    ws->ln1 = take(M * 2); ws->ln2 = take(M * 2);
+    ws->ln1 = take(M * 2); ws->ln2 = take(M * 2); ws->ln3 = take(M * 2);
+    ws->sa = take(M * C);
+    ws->lse_s = take((int64_t)B * c->H * flash_lq_pad((int)Q)); ws->lse_c = take((int64_t)B * c->H * flash_lq_pad((int)Q));
+    ws->refk = take(M * 3);
+    ws->iter_begin = ws->emb; ws->iter_end = off;
     const int cus = device_num_cus();
     ws->self_split = flash_pick_splits(B, c->H, c->Q, c->Q, c->dh, cus);
     ws->cross_split = split_mode ? flash_split_pick_splits(B, c->H, c->Q, (int)N, cus)
@@ -149,6 +161,18 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     const size_t fc = flash_scratch_bytes(B, c->H, c->Q, c->dh, ws->cross_split);
     ws->flash = take((int64_t)((fs > fc ? fs : fc) / sizeof(float)));
     ws->total = off;
+    // ---- training extras: activation stash of iterations 1..I-1, backward scratch
+    ws->stash = take((int64_t)(c->I - 1) * (ws->iter_end - ws->iter_begin));
+    const int64_t NH1 = c->NH1;
+    ws->g_a = take(M * C); ws->g_b = take(M * C); ws->g_c = take(M * C); ws->g_pos = take(M * C); ws->g_tmp = take(M * C);
+    ws->g_ffh = take(M * F); ws->g_h1 = take(M * NH1); ws->g_h2 = take(M * 2 * C); ws->g_z = take(M * 2 * C);
+    ws->g_act = take(M * 2 * C); ws->g_h3 = take(M * 16); ws->g_qkv = take(M * 3 * C); ws->g_emb = take(M * 384);
+    ws->g_ref = take(M * 3); ws->g_D = take((int64_t)B * c->H * flash_lq_pad((int)Q)); ws->g_bs = take((int64_t)B * 2 * 2 * 2);
+    // transposed weight copies of one layer: heads1 [C][NH1], heads2 2x[C][C], lin1^T [C][F], lin2^T [F][C],
+    // cross_out^T, cross_q^T, self_out^T [C][C] each, self_in^T [C][3C], pe2^T [C][C], pe0^T [384][C]
+    ws->wT = take(C * NH1 + 2 * C * C + 2 * C * F + 3 * C * C + 3 * C * C + C * C + 384 * C);
+    ws->g_kv = take(split_mode ? 0 : (int64_t)c->nl * B * 2 * N * C);
+    ws->train_total = off;
     return PARQ_OK;
 }
 
@@ -232,8 +256,13 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     return PARQ_OK;
 }
 
+// shift: offset (floats) of this iteration's activation copy (0 in inference: every iteration reuses one set);
+// emb_next: where the decode kernel leaves the next iteration's sine embedding; train: also keep what backward needs
 int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& ws, int layer_num, const float* ref,
-               bool emb_valid, const parq_outputs* o, float* ref_out, hipStream_t s) {
+               bool emb_valid, const parq_outputs* o, float* ref_out, hipStream_t s, int64_t shift = 0,
+               float* emb_next = nullptr, bool train = false) {
+    float* wi = wsp + shift;
+    if (!emb_next) emb_next = wi + ws.emb;
     const float* A = c->arena;
     const Arena& ar = c->ar;
     const int li = c->cfg.share_weights ? 0 : layer_num;
@@ -242,70 +271,73 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     const int M = B * Q;
     const int64_t N = (int64_t)sc->V * sc->h * sc->w;
     const float eps = 1e-5f;
-    double* gn1 = reinterpret_cast<double*>(wsp + ws.gn_sums);          // [B][2][2]
+    double* gn1 = reinterpret_cast<double*>(wi + ws.gn_sums);          // [B][2][2]
     double* gn2 = gn1 + (int64_t)B * 4 * kGnSlots;
 
     // K3: sine embedding (written by the previous iteration's decode kernel when chained) -> position MLP
     // (transformer_parq.py:317)
-    if (!emb_valid) { Prof p(c, s, PARQ_PROF_OTHER); HIPCHK(launch_posemb(ref, A + ar.dim_t, M, wsp + ws.emb, s)); }
+    if (!emb_valid) { Prof p(c, s, PARQ_PROF_OTHER); HIPCHK(launch_posemb(ref, A + ar.dim_t, M, wi + ws.emb, s)); }
     {
         Prof p(c, s, PARQ_PROF_LINEAR);
-        LinearArgs a = lin(wsp + ws.emb, 384, A + ar.pe0_w, 384, A + ar.pe0_b, wsp + ws.pe_h, C, M, C, 384);
+        LinearArgs a = lin(wi + ws.emb, 384, A + ar.pe0_w, 384, A + ar.pe0_b, wi + ws.pe_h, C, M, C, 384);
         a.relu = 1;
         HIPCHK(launch_linear(a, 1, s));
-        a = lin(wsp + ws.pe_h, C, A + ar.pe2_w, C, A + ar.pe2_b, wsp + ws.pos, C, M, C, C);
+        a = lin(wi + ws.pe_h, C, A + ar.pe2_w, C, A + ar.pe2_b, wi + ws.pos, C, M, C, C);
         HIPCHK(launch_linear(a, 1, s));
     }
     // K4+K5: project + sample (transformer_parq.py:321); also clears this iteration's GroupNorm moments
     {
         Prof p(c, s, PARQ_PROF_PROJECT_SAMPLE);
         HIPCHK(launch_project_sample_f64(sc->tokens, reinterpret_cast<const double*>(wsp + ws.T_cl), sc->camera, ref, c->sb,
-                                         B, sc->V, sc->h, sc->w, C, Q, wsp + ws.tgt, o->coord_pos, gn1, B * 8 * kGnSlots, s));
+                                         B, sc->V, sc->h, sc->w, C, Q, wi + ws.tgt, o->coord_pos, gn1, B * 8 * kGnSlots, s));
     }
     // K6: self-attention, q = k = tgt + pos, v = tgt (transformer_parq.py:372-376)
     {
         Prof p(c, s, PARQ_PROF_LINEAR);
-        LinearArgs a = lin(wsp + ws.tgt, C, A + L.self_in_w, C, A + L.self_in_b, wsp + ws.qkv, 3 * C, M, 3 * C, C);
-        a.X2 = wsp + ws.pos; a.ldx2 = C; a.x2_ncols = 2 * C;
+        LinearArgs a = lin(wi + ws.tgt, C, A + L.self_in_w, C, A + L.self_in_b, wi + ws.qkv, 3 * C, M, 3 * C, C);
+        a.X2 = wi + ws.pos; a.ldx2 = C; a.x2_ncols = 2 * C;
         HIPCHK(launch_linear(a, 1, s));
     }
     FlashArgs fa;
     memset(&fa, 0, sizeof(fa));
     fa.B = B; fa.H = H; fa.Lq = Q; fa.dh = dh;
-    fa.out = wsp + ws.attn; fa.out_batch = (int64_t)Q * C; fa.out_row = C;
+    fa.out = wi + ws.sa; fa.out_batch = (int64_t)Q * C; fa.out_row = C;
     {
         Prof p(c, s, PARQ_PROF_SELF_ATTN);
         if (dh <= 64) {
-            HIPCHK(launch_self_attn(wsp + ws.qkv, 3 * C, B, H, Q, dh, wsp + ws.attn, C, s));
+            HIPCHK(launch_self_attn(wi + ws.qkv, 3 * C, B, H, Q, dh, wi + ws.sa, C, s, train ? wi + ws.lse_s : nullptr));
         } else {
-            fa.q = wsp + ws.qkv;         fa.q_batch = (int64_t)Q * 3 * C; fa.q_head = dh; fa.q_row = 3 * C;
-            fa.k = wsp + ws.qkv + C;     fa.k_batch = fa.q_batch; fa.k_head = dh; fa.k_row = 3 * C;
-            fa.v = wsp + ws.qkv + 2 * C; fa.v_batch = fa.q_batch; fa.v_head = dh; fa.v_row = 3 * C;
+            fa.q = wi + ws.qkv;         fa.q_batch = (int64_t)Q * 3 * C; fa.q_head = dh; fa.q_row = 3 * C;
+            fa.k = wi + ws.qkv + C;     fa.k_batch = fa.q_batch; fa.k_head = dh; fa.k_row = 3 * C;
+            fa.v = wi + ws.qkv + 2 * C; fa.v_batch = fa.q_batch; fa.v_head = dh; fa.v_row = 3 * C;
             fa.Lk = Q; fa.nsplit = ws.self_split;
             const int64_t lp = flash_lq_pad(Q);
             fa.o_part = wsp + ws.flash;
             fa.m_part = fa.o_part + (int64_t)B * H * fa.nsplit * dh * lp;
             fa.l_part = fa.m_part + (int64_t)B * H * fa.nsplit * lp;
+            fa.lse = train ? wi + ws.lse_s : nullptr;
             HIPCHK(launch_flash(fa, s));
             HIPCHK(launch_flash_merge(fa, s));
         }
     }
+    fa.out = wi + ws.attn;
+    fa.lse = train ? wi + ws.lse_c : nullptr;
     {
         // xa = tgt + self_attn @ Wo  (pre-LayerNorm; norm1 is applied by the consumers)
         Prof p(c, s, PARQ_PROF_LINEAR);
-        LinearArgs a = lin(wsp + ws.attn, C, A + L.self_out_w, C, A + L.self_out_b, wsp + ws.xa, C, M, C, C);
-        a.R = wsp + ws.tgt; a.ldr = C;
+        LinearArgs a = lin(wi + ws.sa, C, A + L.self_out_w, C, A + L.self_out_b, wi + ws.xa, C, M, C, C);
+        a.R = wi + ws.tgt; a.ldr = C;
         HIPCHK(launch_linear(a, 1, s));
         // K7: cross-attention query = (norm1(xa) + pos) @ Wq; publishes norm1's row statistics
-        a = lin(wsp + ws.xa, C, A + L.cross_in_w, C, A + L.cross_in_b, wsp + ws.qc, C, M, C, C);
-        a.ln_gamma = A + L.n1_w; a.ln_beta = A + L.n1_b; a.ln_stats_out = wsp + ws.ln1; a.norm_eps = eps;
-        a.X2 = wsp + ws.pos; a.ldx2 = C; a.x2_ncols = C;
+        a = lin(wi + ws.xa, C, A + L.cross_in_w, C, A + L.cross_in_b, wi + ws.qc, C, M, C, C);
+        a.ln_gamma = A + L.n1_w; a.ln_beta = A + L.n1_b; a.ln_stats_out = wi + ws.ln1; a.norm_eps = eps;
+        a.X2 = wi + ws.pos; a.ldx2 = C; a.x2_ncols = C;
         HIPCHK(launch_linear(a, 1, s));
     }
     {
         // dense cross-attention against the cached K/V (transformer_parq.py:377-382)
         Prof p(c, s, PARQ_PROF_CROSS_ATTN);
-        fa.q = wsp + ws.qc; fa.q_batch = (int64_t)Q * C; fa.q_head = dh; fa.q_row = C;
+        fa.q = wi + ws.qc; fa.q_batch = (int64_t)Q * C; fa.q_head = dh; fa.q_row = C;
         fa.Lk = (int)N; fa.nsplit = ws.cross_split;
         const int64_t lp = flash_lq_pad(Q);
         fa.o_part = wsp + ws.flash;
@@ -325,26 +357,27 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     {
         Prof p(c, s, PARQ_PROF_LINEAR);
         // xb = norm1(xa) + cross_attn @ Wo   (residual recomputed from the published statistics)
-        LinearArgs a = lin(wsp + ws.attn, C, A + L.cross_out_w, C, A + L.cross_out_b, wsp + ws.xb, C, M, C, C);
-        a.R = wsp + ws.xa; a.ldr = C; a.rln_stats = wsp + ws.ln1; a.rln_gamma = A + L.n1_w; a.rln_beta = A + L.n1_b;
+        LinearArgs a = lin(wi + ws.attn, C, A + L.cross_out_w, C, A + L.cross_out_b, wi + ws.xb, C, M, C, C);
+        a.R = wi + ws.xa; a.ldr = C; a.rln_stats = wi + ws.ln1; a.rln_gamma = A + L.n1_w; a.rln_beta = A + L.n1_b;
         HIPCHK(launch_linear(a, 1, s));
         // K8: FFN (transformer_parq.py:383-385): relu(norm2(xb) @ W1), publishes norm2's statistics
-        a = lin(wsp + ws.xb, C, A + L.lin1_w, C, A + L.lin1_b, wsp + ws.ffn, F, M, F, C);
-        a.ln_gamma = A + L.n2_w; a.ln_beta = A + L.n2_b; a.ln_stats_out = wsp + ws.ln2; a.norm_eps = eps;
+        a = lin(wi + ws.xb, C, A + L.lin1_w, C, A + L.lin1_b, wi + ws.ffn, F, M, F, C);
+        a.ln_gamma = A + L.n2_w; a.ln_beta = A + L.n2_b; a.ln_stats_out = wi + ws.ln2; a.norm_eps = eps;
         a.relu = 1;
         HIPCHK(launch_linear(a, 1, s));
         // xc = norm2(xb) + ffn @ W2
-        a = lin(wsp + ws.ffn, F, A + L.lin2_w, F, A + L.lin2_b, wsp + ws.xc, C, M, C, F);
-        a.R = wsp + ws.xb; a.ldr = C; a.rln_stats = wsp + ws.ln2; a.rln_gamma = A + L.n2_w; a.rln_beta = A + L.n2_b;
+        a = lin(wi + ws.ffn, F, A + L.lin2_w, F, A + L.lin2_b, wi + ws.xc, C, M, C, F);
+        a.R = wi + ws.xb; a.ldr = C; a.rln_stats = wi + ws.ln2; a.rln_gamma = A + L.n2_w; a.rln_beta = A + L.n2_b;
         HIPCHK(launch_linear(a, 1, s));
         // K9: heads (transformer_parq.py:234-252; generic_mlp.py:85-110) on norm3(xc); the first layers of the
         // four heads are one GEMM, which also accumulates the GroupNorm moments of the two hidden blocks
         const int NH1 = c->NH1;
-        a = lin(wsp + ws.xc, C, A + ar.heads1_w, C, A + ar.heads1_b, wsp + ws.h1, NH1, M, NH1, C);
+        a = lin(wi + ws.xc, C, A + ar.heads1_w, C, A + ar.heads1_b, wi + ws.h1, NH1, M, NH1, C);
         a.ln_gamma = A + L.n3_w; a.ln_beta = A + L.n3_b; a.norm_eps = eps;
+        if (train) a.ln_stats_out = wi + ws.ln3;
         a.gn_out_sums = gn1; a.gn_out_ncols = 2 * C; a.gn_out_group_cols = C; a.gn_out_rows_per_scene = Q; a.gn_out_ngroups = 2;
         HIPCHK(launch_linear(a, 1, s));
-        a = lin(wsp + ws.h1, NH1, A + ar.heads2_w, C, nullptr, wsp + ws.h2, 2 * C, M, C, C);
+        a = lin(wi + ws.h1, NH1, A + ar.heads2_w, C, nullptr, wi + ws.h2, 2 * C, M, C, C);
         a.gn_sums = gn1; a.gn_gamma = A + ar.gn1_g; a.gn_beta = A + ar.gn1_b; a.norm_eps = eps;
         a.gn_rows_per_scene = Q; a.gn_ngroups = 2;
         a.gX = C; a.gW = (int64_t)C * C; a.gY = C; a.gGamma = C;
@@ -357,15 +390,229 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         Prof p(c, s, PARQ_PROF_OTHER);
         BoxDecodeArgs d;
         memset(&d, 0, sizeof(d));
-        d.h1 = wsp + ws.h1 + 2 * C; d.ld1 = c->NH1;
-        d.h2 = wsp + ws.h2; d.ld2 = 2 * C;
+        d.h1 = wi + ws.h1 + 2 * C; d.ld1 = c->NH1;
+        d.h2 = wi + ws.h2; d.ld2 = 2 * C;
         d.gn_sums = gn2; d.gn_gamma = A + ar.gn2_g; d.gn_beta = A + ar.gn2_b;
         d.w3 = A + ar.heads3_w; d.b3 = A + ar.heads3_b; d.C = C; d.rows_per_scene = Q; d.eps = eps;
         d.ref = ref; d.mean_sizes = A + ar.mean_sizes; d.n_mean = c->cfg.num_mean_sizes; d.dim_t = A + ar.dim_t;
         d.sb = c->sb; d.M = M; d.ncls = c->ncls;
         d.logits = o->pred_logits; d.center = o->center_unnormalized; d.size = o->size_unnormalized;
-        d.rot = o->ortho6d; d.prob = o->sem_cls_prob; d.ref_next = ref_out; d.emb_next = wsp + ws.emb;
+        d.rot = o->ortho6d; d.prob = o->sem_cls_prob; d.ref_next = ref_out; d.emb_next = emb_next;
         HIPCHK(launch_box_decode(d, s));
+    }
+    return PARQ_OK;
+}
+
+
+// =============================================================================== training: backward chain
+// One iteration of the decoder, reversed.  Activations come from the training forward's stash
+// (Workspace::shift(k)); gradients of the packed weights accumulate into `G`, an arena with the layout of the weight
+// arena; dK/dV of the hoisted K/V projection accumulate in ws.g_kv over the iterations and are pushed through the
+// projection once at the end.  Reference points are detached between iterations (transformer_parq.py:331-332): only
+// iteration 0 sends gradient to refpoint.weight, through the sine embedding, the projection and the centre update.
+struct BwdIO {
+    const float* g_logits; const float* g_center; const float* g_size; const float* g_rot;     // this iteration, may be null
+    const float* center; const float* size;                                                    // forward outputs
+};
+
+int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& ws, int k, const BwdIO& io, float* G,
+                     float* g_tokens, hipStream_t s) {
+    const float* A = c->arena;
+    const Arena& ar = c->ar;
+    const int li = c->cfg.share_weights ? 0 : k;
+    const LayerW& L = ar.layers[li];
+    const int B = sc->B, C = c->C, Q = c->Q, H = c->H, dh = c->dh, F = c->F, NH1 = c->NH1;
+    const int M = B * Q;
+    const int64_t N = (int64_t)sc->V * sc->h * sc->w;
+    const float eps = 1e-5f;
+    float* wi = wsp + ws.shift(k);
+    const double* gn1 = reinterpret_cast<const double*>(wi + ws.gn_sums);
+    const double* gn2 = gn1 + (int64_t)B * 4 * kGnSlots;
+    const float* ref = wi + ws.refk;
+    float *gA = wsp + ws.g_a, *gB = wsp + ws.g_b, *gC = wsp + ws.g_c, *gPos = wsp + ws.g_pos, *tmp = wsp + ws.g_tmp;
+    float *gFfh = wsp + ws.g_ffh, *gH1 = wsp + ws.g_h1, *gH2 = wsp + ws.g_h2, *gZ = wsp + ws.g_z, *act = wsp + ws.g_act;
+    float *gH3 = wsp + ws.g_h3, *gQkv = wsp + ws.g_qkv, *gEmb = wsp + ws.g_emb, *gRef = wsp + ws.g_ref, *Dd = wsp + ws.g_D;
+    double* bs = reinterpret_cast<double*>(wsp + ws.g_bs);
+    // transposed weight copies of this layer
+    float* wT = wsp + ws.wT;
+    float* h1T = wT;                      // [C][NH1]
+    float* h2T = h1T + (int64_t)C * NH1;  // 2 x [C][C]
+    float* l1T = h2T + 2 * (int64_t)C * C;   // lin1^T [C][F]
+    float* l2T = l1T + (int64_t)C * F;       // lin2^T [F][C]
+    float* coT = l2T + (int64_t)C * F;       // cross out^T
+    float* cqT = coT + (int64_t)C * C;       // cross q^T
+    float* soT = cqT + (int64_t)C * C;       // self out^T
+    float* siT = soT + (int64_t)C * C;       // self in^T [C][3C]
+    float* p2T = siT + 3 * (int64_t)C * C;   // pe2^T
+    float* p0T = p2T + (int64_t)C * C;       // pe0^T [384][C]
+    HIPCHK(launch_transpose(A + ar.heads1_w, C, h1T, NH1, NH1, C, s));
+    HIPCHK(launch_transpose(A + ar.heads2_w, C, h2T, C, C, C, s));
+    HIPCHK(launch_transpose(A + ar.heads2_w + (int64_t)C * C, C, h2T + (int64_t)C * C, C, C, C, s));
+    HIPCHK(launch_transpose(A + L.lin1_w, C, l1T, F, F, C, s));
+    HIPCHK(launch_transpose(A + L.lin2_w, F, l2T, C, C, F, s));
+    HIPCHK(launch_transpose(A + L.cross_out_w, C, coT, C, C, C, s));
+    HIPCHK(launch_transpose(A + L.cross_in_w, C, cqT, C, C, C, s));
+    HIPCHK(launch_transpose(A + L.self_out_w, C, soT, C, C, C, s));
+    HIPCHK(launch_transpose(A + L.self_in_w, C, siT, 3 * C, 3 * C, C, s));
+    HIPCHK(launch_transpose(A + ar.pe2_w, C, p2T, C, C, C, s));
+    HIPCHK(launch_transpose(A + ar.pe0_w, 384, p0T, C, C, 384, s));
+
+    auto mm = [&](const float* X, int64_t ldx, const float* WT, int K, int Nn, float* Y, int64_t ldy) {   // Y = X W  (W^T given [Nn][K])
+        return lin(X, ldx, WT, K, nullptr, Y, ldy, M, Nn, K);
+    };
+    HIPCHK(hipMemsetAsync(gRef, 0, (size_t)M * 3 * sizeof(float), s));
+
+    // ---- heads (transformer_parq.py:234-279)
+    HIPCHK(launch_decode_bwd(io.g_logits, io.g_center, io.g_size, io.g_rot, io.center, io.size, ref, c->sb, M, c->ncls, NH1, C, gH3, gH1,
+                             k == 0 ? gRef : nullptr, s));
+    // last layers: w3 rows 0..2 centre (input h2act[:, :C]), rows 6..11 rotation (input h2act[:, C:])
+    HIPCHK(launch_gn_apply(wi + ws.h2, 2 * C, gn2, A + ar.gn2_g, A + ar.gn2_b, M, C, 2, Q, eps, act, 2 * C, s));
+    HIPCHK(launch_gemm_tn(gH3, 16, act, 2 * C, G + ar.heads3_w, C, M, 3, C, 1, s));
+    HIPCHK(launch_gemm_tn(gH3 + 3, 16, act + C, 2 * C, G + ar.heads3_w + 6 * (int64_t)C, C, M, 6, C, 1, s));
+    HIPCHK(launch_colsum(gH3, 16, M, 3, G + ar.heads3_b, 1, s));
+    HIPCHK(launch_colsum(gH3 + 3, 16, M, 6, G + ar.heads3_b + 6, 1, s));
+    HIPCHK(launch_head3_bwd(gH3, A + ar.heads3_w, gZ, M, C, s));                       // gZ = d loss / d h2act
+    HIPCHK(launch_gn_bwd(wi + ws.h2, 2 * C, gn2, A + ar.gn2_g, A + ar.gn2_b, M, C, 2, Q, eps, gZ, 2 * C, act, bs, gH2, 2 * C,
+                         G + ar.gn2_g, G + ar.gn2_b, s));
+    // second layers (grouped): h2[:, g] = h1act[:, g] W2g^T
+    HIPCHK(launch_gn_apply(wi + ws.h1, NH1, gn1, A + ar.gn1_g, A + ar.gn1_b, M, C, 2, Q, eps, act, 2 * C, s));   // act = h1act
+    for (int g = 0; g < 2; ++g) {
+        HIPCHK(launch_gemm_tn(gH2 + g * C, 2 * C, act + g * C, 2 * C, G + ar.heads2_w + (int64_t)g * C * C, C, M, C, C, 1, s));
+        LinearArgs a = mm(gH2 + g * C, 2 * C, h2T + (int64_t)g * C * C, C, C, gZ + g * C, 2 * C);       // gZ = d / d h1act
+        HIPCHK(launch_linear(a, 1, s));
+    }
+    HIPCHK(launch_gn_bwd(wi + ws.h1, NH1, gn1, A + ar.gn1_g, A + ar.gn1_b, M, C, 2, Q, eps, gZ, 2 * C, act, bs, gH1, NH1,
+                         G + ar.gn1_g, G + ar.gn1_b, s));
+    // fused first layers on x3 = norm3(xc)
+    HIPCHK(launch_layernorm(wi + ws.xc, A + L.n3_w, A + L.n3_b, tmp, M, C, eps, s));           // tmp = x3
+    HIPCHK(launch_gemm_tn(gH1, NH1, tmp, C, G + ar.heads1_w, C, M, NH1, C, 1, s));
+    HIPCHK(launch_colsum(gH1 + 2 * C, NH1, M, NH1 - 2 * C, G + ar.heads1_b + 2 * C, 1, s));
+    {
+        LinearArgs a = mm(gH1, NH1, h1T, NH1, C, gA, C);                                       // gA = d / d x3
+        HIPCHK(launch_linear(a, 1, s));
+    }
+    // ---- norm3 / FFN (transformer_parq.py:383-385)
+    HIPCHK(launch_ln_bwd(gA, wi + ws.xc, wi + ws.ln3, A + L.n3_w, gB, M, C, 0, G + L.n3_w, G + L.n3_b, s));   // gB = d / d xc
+    HIPCHK(launch_gemm_tn(gB, C, wi + ws.ffn, F, G + L.lin2_w, F, M, C, F, 1, s));
+    HIPCHK(launch_colsum(gB, C, M, C, G + L.lin2_b, 1, s));
+    {
+        LinearArgs a = mm(gB, C, l2T, C, F, gFfh, F);                                          // d / d ffn hidden, through the ReLU
+        a.relu_mask = wi + ws.ffn; a.ldmask = F;
+        HIPCHK(launch_linear(a, 1, s));
+    }
+    HIPCHK(launch_layernorm(wi + ws.xb, A + L.n2_w, A + L.n2_b, tmp, M, C, eps, s));           // tmp = x2
+    HIPCHK(launch_gemm_tn(gFfh, F, tmp, C, G + L.lin1_w, C, M, F, C, 1, s));
+    HIPCHK(launch_colsum(gFfh, F, M, F, G + L.lin1_b, 1, s));
+    {
+        LinearArgs a = mm(gFfh, F, l1T, F, C, gA, C);                                          // gA = d / d x2 = gB + gFfh W1
+        a.R = gB; a.ldr = C;
+        HIPCHK(launch_linear(a, 1, s));
+    }
+    // ---- norm2 / cross-attention (transformer_parq.py:377-382)
+    HIPCHK(launch_ln_bwd(gA, wi + ws.xb, wi + ws.ln2, A + L.n2_w, gB, M, C, 0, G + L.n2_w, G + L.n2_b, s));   // gB = d / d xb
+    HIPCHK(launch_gemm_tn(gB, C, wi + ws.attn, C, G + L.cross_out_w, C, M, C, C, 1, s));
+    HIPCHK(launch_colsum(gB, C, M, C, G + L.cross_out_b, 1, s));
+    {
+        LinearArgs a = mm(gB, C, coT, C, C, gA, C);                                            // gA = d / d attention output
+        HIPCHK(launch_linear(a, 1, s));
+    }
+    HIPCHK(launch_attn_bwd_rowdot(gA, wi + ws.attn, (int64_t)Q * C, C, B, H, Q, dh, Dd, s));
+    HIPCHK(hipMemsetAsync(gC, 0, (size_t)M * C * sizeof(float), s));                           // gC = d / d q (atomics)
+    {
+        const float* kv = wsp + ws.kv + (int64_t)li * B * 2 * N * C;
+        float* gkv = wsp + ws.g_kv + (int64_t)li * B * 2 * N * C;
+        HIPCHK(launch_attn_bwd(wi + ws.qc, (int64_t)Q * C, dh, C, kv, 2 * N * C, N * dh, dh, kv + (int64_t)H * N * dh, 2 * N * C, N * dh, dh,
+                               gA, (int64_t)Q * C, dh, C, wi + ws.lse_c, Dd, gC, (int64_t)Q * C, dh, C, gkv, 2 * N * C, N * dh, dh,
+                               gkv + (int64_t)H * N * dh, 2 * N * C, N * dh, dh, B, H, Q, (int)N, dh, 1, s));
+    }
+    // q = (x1 + pos) Wq^T + bq,  x1 = norm1(xa)
+    HIPCHK(launch_layernorm(wi + ws.xa, A + L.n1_w, A + L.n1_b, tmp, M, C, eps, s));
+    HIPCHK(launch_add(tmp, wi + ws.pos, tmp, (int64_t)M * C, s));                              // tmp = x1 + pos
+    HIPCHK(launch_gemm_tn(gC, C, tmp, C, G + L.cross_in_w, C, M, C, C, 1, s));
+    HIPCHK(launch_colsum(gC, C, M, C, G + L.cross_in_b, 1, s));
+    {
+        LinearArgs a = mm(gC, C, cqT, C, C, gPos, C);                                          // gPos = d / d (x1 + pos) [cross]
+        HIPCHK(launch_linear(a, 1, s));
+    }
+    HIPCHK(launch_add(gB, gPos, gA, (int64_t)M * C, s));                                       // gA = d / d x1 (residual + query path)
+    // ---- norm1 / self-attention (transformer_parq.py:372-376)
+    HIPCHK(launch_ln_bwd(gA, wi + ws.xa, wi + ws.ln1, A + L.n1_w, gB, M, C, 0, G + L.n1_w, G + L.n1_b, s));   // gB = d / d xa
+    HIPCHK(launch_gemm_tn(gB, C, wi + ws.sa, C, G + L.self_out_w, C, M, C, C, 1, s));
+    HIPCHK(launch_colsum(gB, C, M, C, G + L.self_out_b, 1, s));
+    {
+        LinearArgs a = mm(gB, C, soT, C, C, gA, C);                                            // gA = d / d self-attention output
+        HIPCHK(launch_linear(a, 1, s));
+    }
+    HIPCHK(launch_attn_bwd_rowdot(gA, wi + ws.sa, (int64_t)Q * C, C, B, H, Q, dh, Dd, s));
+    HIPCHK(hipMemsetAsync(gQkv, 0, (size_t)M * 3 * C * sizeof(float), s));
+    HIPCHK(launch_attn_bwd(wi + ws.qkv, (int64_t)Q * 3 * C, dh, 3 * C, wi + ws.qkv + C, (int64_t)Q * 3 * C, dh, 3 * C,
+                           wi + ws.qkv + 2 * C, (int64_t)Q * 3 * C, dh, 3 * C, gA, (int64_t)Q * C, dh, C, wi + ws.lse_s, Dd,
+                           gQkv, (int64_t)Q * 3 * C, dh, 3 * C, gQkv + C, (int64_t)Q * 3 * C, dh, 3 * C, gQkv + 2 * C,
+                           (int64_t)Q * 3 * C, dh, 3 * C, B, H, Q, Q, dh, 0, s));
+    // in-projection: [q | k] = (tgt + pos) Wqk^T, v = tgt Wv^T
+    HIPCHK(launch_add(wi + ws.tgt, wi + ws.pos, tmp, (int64_t)M * C, s));                      // tmp = tgt + pos
+    HIPCHK(launch_gemm_tn(gQkv, 3 * C, tmp, C, G + L.self_in_w, C, M, 2 * C, C, 1, s));
+    HIPCHK(launch_gemm_tn(gQkv + 2 * C, 3 * C, wi + ws.tgt, C, G + L.self_in_w + 2 * (int64_t)C * C, C, M, C, C, 1, s));
+    HIPCHK(launch_colsum(gQkv, 3 * C, M, 3 * C, G + L.self_in_b, 1, s));
+    {
+        // d / d (tgt + pos) through q and k: rows 0 .. 2C-1 of W_in, i.e. columns 0 .. 2C-1 of W_in^T ([C][3C])
+        LinearArgs a = lin(gQkv, 3 * C, siT, 3 * C, nullptr, gA, C, M, C, 2 * C);
+        HIPCHK(launch_linear(a, 1, s));
+        HIPCHK(launch_add(gPos, gA, gPos, (int64_t)M * C, s));                                  // gPos = total d / d pos
+        // d / d tgt = gB (residual) + gA (q, k path) + gQkv_v Wv
+        a = lin(gQkv + 2 * C, 3 * C, siT + 2 * C, 3 * C, nullptr, gC, C, M, C, C);
+        a.R = gA; a.ldr = C;
+        HIPCHK(launch_linear(a, 1, s));
+        HIPCHK(launch_add(gC, gB, gC, (int64_t)M * C, s));                                      // gC = d / d tgt
+    }
+    // ---- project + sample (transformer_parq.py:321)
+    HIPCHK(launch_sample_bwd(sc->tokens, reinterpret_cast<const double*>(wsp + ws.T_cl), sc->camera, ref, c->sb, B, sc->V, sc->h, sc->w,
+                             C, Q, gC, g_tokens, k == 0 ? gRef : nullptr, s));
+    // ---- position MLP (transformer_parq.py:176-180,317): pos = relu(emb W0^T + b0) W2^T + b2
+    HIPCHK(launch_gemm_tn(gPos, C, wi + ws.pe_h, C, G + ar.pe2_w, C, M, C, C, 1, s));
+    HIPCHK(launch_colsum(gPos, C, M, C, G + ar.pe2_b, 1, s));
+    {
+        LinearArgs a = mm(gPos, C, p2T, C, C, gA, C);                                          // gA = d / d pe hidden
+        a.relu_mask = wi + ws.pe_h; a.ldmask = C;
+        HIPCHK(launch_linear(a, 1, s));
+    }
+    HIPCHK(launch_gemm_tn(gA, C, wi + ws.emb, 384, G + ar.pe0_w, 384, M, C, 384, 1, s));
+    HIPCHK(launch_colsum(gA, C, M, C, G + ar.pe0_b, 1, s));
+    if (k == 0) {
+        LinearArgs a = lin(gA, C, p0T, C, nullptr, gEmb, 384, M, 384, C);
+        HIPCHK(launch_linear(a, 1, s));
+        HIPCHK(launch_posemb_bwd(gEmb, ref, A + ar.dim_t, M, gRef, s));
+        HIPCHK(launch_refpoint_bwd(gRef, ref, B, Q, G + ar.refpoint, s));
+    }
+    return PARQ_OK;
+}
+
+// hoisted K/V projection backward: [K | V] = tokens W_kv^T + b_kv per layer; g_kv is head-major [b][{K,V}][h][n][dh]
+int do_backward_kvproj(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& ws, float* G, float* g_tokens, hipStream_t s) {
+    const float* A = c->arena;
+    const int B = sc->B, C = c->C, H = c->H, dh = c->dh;
+    const int64_t N = (int64_t)sc->V * sc->h * sc->w;
+    float* wT = wsp + ws.wT;            // W_kv^T per head block, reused: [C][dh]
+    for (int li = 0; li < c->nl; ++li) {
+        const LayerW& L = c->ar.layers[li];
+        for (int b = 0; b < B; ++b) {
+            for (int part = 0; part < 2; ++part)                         // K heads, then V heads
+                for (int hh = 0; hh < H; ++hh) {
+                    const float* g = wsp + ws.g_kv + (((int64_t)li * B + b) * 2 + part) * N * C + (int64_t)hh * N * dh;   // [N][dh]
+                    const int64_t wrow = (int64_t)C + (int64_t)part * C + (int64_t)hh * dh;      // rows of in_proj_weight
+                    const float* tok = sc->tokens + (int64_t)b * N * C;
+                    // dW[wrow .. +dh][C] += g^T tokens ; db += colsum(g)
+                    HIPCHK(launch_gemm_tn(g, dh, tok, C, G + L.cross_in_w + wrow * C, C, (int)N, dh, C, 1, s));
+                    HIPCHK(launch_colsum(g, dh, (int)N, dh, G + L.cross_in_b + wrow, 1, s));
+                    if (g_tokens) {
+                        // g_tokens[b] += g W[wrow .. +dh][:]   (W^T block [C][dh])
+                        HIPCHK(launch_transpose(A + L.cross_in_w + wrow * C, C, wT, dh, dh, C, s));
+                        LinearArgs a = lin(g, dh, wT, dh, nullptr, g_tokens + (int64_t)b * N * C, C, (int)N, C, dh);
+                        a.R = g_tokens + (int64_t)b * N * C; a.ldr = C;
+                        HIPCHK(launch_linear(a, 1, s));
+                    }
+                }
+        }
     }
     return PARQ_OK;
 }
@@ -606,6 +853,129 @@ int parq_set_attention_mode(parq_handle h, int32_t mode) {
     h->attn_mode = mode;
     h->prepared = false;
     return PARQ_OK;
+}
+
+/* ---- training ---------------------------------------------------- */
+size_t parq_train_workspace_bytes(parq_handle h, int32_t B, int32_t V, int32_t hh, int32_t ww) {
+    if (!h || B < 1 || V < 1 || hh < 1 || ww < 1) return 0;
+    Workspace ws;
+    carve_workspace(h, B, V, hh, ww, &ws);
+    return (size_t)ws.train_total * sizeof(float);
+}
+
+size_t parq_grad_arena_bytes(parq_handle h) { return h ? (size_t)h->ar.total * sizeof(float) : 0; }
+
+int parq_forward_train(parq_handle h, const parq_scene* scene, void* workspace, size_t workspace_bytes, const parq_outputs* outs,
+                       parq_stream stream) {
+    if (!h || !workspace) return fail(PARQ_ERR_ARG, "NULL argument");
+    if (!h->packed) return fail(PARQ_ERR_STATE, "parq_pack_weights must be called first");
+    if (h->cache_mode()) return fail(PARQ_ERR_STATE, "training needs attention mode 0 (the backward reads the fp32 K/V cache)");
+    if (h->dh != 64 && h->dh != 32) return fail(PARQ_ERR_ARG, "training needs head dim 32 or 64");
+    int rc = check_scene(h, scene);
+    if (rc) return rc;
+    rc = check_outs(outs);
+    if (rc) return rc;
+    Workspace ws;
+    carve_workspace(h, scene->B, scene->V, scene->h, scene->w, &ws);
+    if (workspace_bytes < (size_t)ws.train_total * sizeof(float)) return fail(PARQ_ERR_WORKSPACE, "training workspace too small: %zu < %zu", workspace_bytes, (size_t)ws.train_total * sizeof(float));
+    float* wsp = (float*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    rc = do_prepare(h, scene, wsp, ws, s);
+    if (rc) return rc;
+    const int64_t M = (int64_t)scene->B * h->Q;
+    // the reference points of iteration k live in that iteration's stash (initial_ref wrote ws.ref)
+    HIPCHK(hipMemcpyAsync(wsp + ws.shift(0) + ws.refk, wsp + ws.ref, (size_t)M * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    for (int k = 0; k < h->I; ++k) {
+        parq_outputs o;
+        o.pred_logits = outs->pred_logits + k * M * h->ncls;
+        o.center_unnormalized = outs->center_unnormalized + k * M * 3;
+        o.size_unnormalized = outs->size_unnormalized + k * M * 3;
+        o.ortho6d = outs->ortho6d + k * M * 6;
+        o.sem_cls_prob = outs->sem_cls_prob + k * M * h->ncls;
+        o.coord_pos = outs->coord_pos + k * M * 3;
+        const bool last = k + 1 == h->I;
+        float* ref_next = last ? wsp + ws.ref_next : wsp + ws.shift(k + 1) + ws.refk;
+        float* emb_next = last ? wsp + ws.g_emb : wsp + ws.shift(k + 1) + ws.emb;
+        rc = do_iterate(h, scene, wsp, ws, k, wsp + ws.shift(k) + ws.refk, k > 0, &o, ref_next, s, ws.shift(k), emb_next, true);
+        if (rc) return rc;
+    }
+    h->ref_state = 0;
+    h->prepared = false;
+    return PARQ_OK;
+}
+
+int parq_backward(parq_handle h, const parq_scene* scene, void* workspace, size_t workspace_bytes, const parq_outputs* outs,
+                  const parq_output_grads* g, float* grad_arena, float* d_tokens, parq_stream stream) {
+    if (!h || !workspace || !outs || !g || !grad_arena) return fail(PARQ_ERR_ARG, "NULL argument");
+    if (!h->packed) return fail(PARQ_ERR_STATE, "parq_pack_weights must be called first");
+    if (h->cache_mode()) return fail(PARQ_ERR_STATE, "training needs attention mode 0");
+    int rc = check_scene(h, scene);
+    if (rc) return rc;
+    Workspace ws;
+    carve_workspace(h, scene->B, scene->V, scene->h, scene->w, &ws);
+    if (workspace_bytes < (size_t)ws.train_total * sizeof(float)) return fail(PARQ_ERR_WORKSPACE, "training workspace too small");
+    float* wsp = (float*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t M = (int64_t)scene->B * h->Q;
+    const int64_t N = (int64_t)scene->V * scene->h * scene->w;
+    HIPCHK(hipMemsetAsync(grad_arena, 0, (size_t)h->ar.total * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(wsp + ws.g_kv, 0, (size_t)h->nl * scene->B * 2 * N * h->C * sizeof(float), s));
+    if (d_tokens) HIPCHK(hipMemsetAsync(d_tokens, 0, (size_t)scene->B * N * h->C * sizeof(float), s));
+    for (int k = h->I - 1; k >= 0; --k) {
+        BwdIO io;
+        io.g_logits = g->pred_logits ? g->pred_logits + k * M * h->ncls : nullptr;
+        io.g_center = g->center_unnormalized ? g->center_unnormalized + k * M * 3 : nullptr;
+        io.g_size = g->size_unnormalized ? g->size_unnormalized + k * M * 3 : nullptr;
+        io.g_rot = g->ortho6d ? g->ortho6d + k * M * 6 : nullptr;
+        io.center = outs->center_unnormalized + k * M * 3;
+        io.size = outs->size_unnormalized + k * M * 3;
+        rc = do_backward_iter(h, scene, wsp, ws, k, io, grad_arena, d_tokens, s);
+        if (rc) return rc;
+    }
+    return do_backward_kvproj(h, scene, wsp, ws, grad_arena, d_tokens, s);
+}
+
+/* offset (in floats) and element count of a named reference tensor inside the packed weight / gradient arena;
+ * `rows` x `cols` with row stride `ld` (fused head matrices are row slices of a wider block) */
+int parq_arena_lookup(parq_handle h, const char* name, int64_t* offset, int64_t* rows, int64_t* cols, int64_t* ld) {
+    if (!h || !name || !offset || !rows || !cols || !ld) return fail(PARQ_ERR_ARG, "NULL argument");
+    const int64_t C = h->C, F = h->F, Q = h->Q, ncls = h->ncls;
+    const Arena& ar = h->ar;
+    struct E { std::string n; int64_t off, r, c; };
+    std::vector<E> t;
+    for (int li = 0; li < h->nl; ++li) {
+        const LayerW& L = ar.layers[li];
+        const std::string p = "parq_module.decoder.layers." + std::to_string(li) + ".";
+        t.push_back({p + "self_attn.in_proj_weight", L.self_in_w, 3 * C, C}); t.push_back({p + "self_attn.in_proj_bias", L.self_in_b, 1, 3 * C});
+        t.push_back({p + "self_attn.out_proj.weight", L.self_out_w, C, C}); t.push_back({p + "self_attn.out_proj.bias", L.self_out_b, 1, C});
+        t.push_back({p + "multihead_attn.in_proj_weight", L.cross_in_w, 3 * C, C}); t.push_back({p + "multihead_attn.in_proj_bias", L.cross_in_b, 1, 3 * C});
+        t.push_back({p + "multihead_attn.out_proj.weight", L.cross_out_w, C, C}); t.push_back({p + "multihead_attn.out_proj.bias", L.cross_out_b, 1, C});
+        t.push_back({p + "linear1.weight", L.lin1_w, F, C}); t.push_back({p + "linear1.bias", L.lin1_b, 1, F});
+        t.push_back({p + "linear2.weight", L.lin2_w, C, F}); t.push_back({p + "linear2.bias", L.lin2_b, 1, C});
+        t.push_back({p + "norm1.weight", L.n1_w, 1, C}); t.push_back({p + "norm1.bias", L.n1_b, 1, C});
+        t.push_back({p + "norm2.weight", L.n2_w, 1, C}); t.push_back({p + "norm2.bias", L.n2_b, 1, C});
+        t.push_back({p + "norm3.weight", L.n3_w, 1, C}); t.push_back({p + "norm3.bias", L.n3_b, 1, C});
+    }
+    const std::string d = "parq_module.decoder.";
+    const std::string hc = "mlp_heads.center_head.layers.", hr = "mlp_heads.rotation_head.layers.";
+    t.push_back({"refpoint.weight", ar.refpoint, Q, 3});
+    t.push_back({d + "position_encoder.0.weight", ar.pe0_w, C, 384}); t.push_back({d + "position_encoder.0.bias", ar.pe0_b, 1, C});
+    t.push_back({d + "position_encoder.2.weight", ar.pe2_w, C, C}); t.push_back({d + "position_encoder.2.bias", ar.pe2_b, 1, C});
+    t.push_back({hc + "0.weight", ar.heads1_w, C, C}); t.push_back({hr + "0.weight", ar.heads1_w + C * C, C, C});
+    t.push_back({"mlp_heads.sem_cls_head.layers.0.weight", ar.heads1_w + 2 * C * C, ncls, C});
+    t.push_back({"mlp_heads.size_head.layers.0.weight", ar.heads1_w + (2 * C + ncls) * C, 3, C});
+    t.push_back({"mlp_heads.sem_cls_head.layers.0.bias", ar.heads1_b + 2 * C, 1, ncls});
+    t.push_back({"mlp_heads.size_head.layers.0.bias", ar.heads1_b + 2 * C + ncls, 1, 3});
+    t.push_back({hc + "1.weight", ar.gn1_g, 1, C}); t.push_back({hr + "1.weight", ar.gn1_g + C, 1, C});
+    t.push_back({hc + "1.bias", ar.gn1_b, 1, C}); t.push_back({hr + "1.bias", ar.gn1_b + C, 1, C});
+    t.push_back({hc + "4.weight", ar.heads2_w, C, C}); t.push_back({hr + "4.weight", ar.heads2_w + C * C, C, C});
+    t.push_back({hc + "5.weight", ar.gn2_g, 1, C}); t.push_back({hr + "5.weight", ar.gn2_g + C, 1, C});
+    t.push_back({hc + "5.bias", ar.gn2_b, 1, C}); t.push_back({hr + "5.bias", ar.gn2_b + C, 1, C});
+    t.push_back({hc + "8.weight", ar.heads3_w, 3, C}); t.push_back({hr + "8.weight", ar.heads3_w + 6 * C, 6, C});
+    t.push_back({hc + "8.bias", ar.heads3_b, 1, 3}); t.push_back({hr + "8.bias", ar.heads3_b + 6, 1, 6});
+    for (const E& e : t)
+        if (e.n == name) { *offset = e.off; *rows = e.r; *cols = e.c; *ld = e.c; return PARQ_OK; }
+    return fail(PARQ_ERR_ARG, "unknown tensor '%s'", name);
 }
 
 int parq_profile_enable(parq_handle h, int32_t on) {

@@ -86,6 +86,7 @@ struct LinearArgs {
     float* Y;
     int M, N, K;
     int relu;
+    const float* relu_mask; int64_t ldmask;   // backward of a ReLU: y = relu_mask[m][n] > 0 ? y : 0 (applied after bias)
     // output address: Y + (m / rows_per_batch) * y_batch + (m % rows_per_batch) * y_row
     //                   + (n / col_blk) * y_blk + (n % col_blk)
     int rows_per_batch; int64_t y_batch; int64_t y_row; int col_blk; int64_t y_blk;
@@ -122,6 +123,7 @@ struct FlashArgs {
     float* l_part;              // [B*H][nsplit][Lq_pad]
     float* out; int64_t out_batch, out_row;              // merged (b, q, h*dh + d)
     float defer_log2;           // split kernel: running max moves only past this margin (0 = always)
+    float* lse;                 // optional [B*H][Lq_pad]: log2-domain log-sum-exp of every query row (training)
 };
 int flash_key_tile(int dh);                    // keys per LDS tile
 int flash_lq_pad(int Lq);
@@ -157,6 +159,37 @@ hipError_t launch_raype_fused(const float* cam, const float* T_cp, const float* 
                               float min_depth, float max_depth, int B, int V, int h, int w, const void* W1hi, const void* W1lo,
                               const float* b1, const void* W2hi, const void* W2lo, const float* b2, const float* feat,
                               float* hidden, double* Tl, double* depth, float* out, int nchw_out, hipStream_t s);
+struct ScaleBox { float lo[3]; float hi[3]; };
+// ---- backward (backward.hip, attn_bwd.hip)
+hipError_t launch_transpose(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int R, int Cc, hipStream_t s);
+hipError_t launch_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* out, int64_t ldo, int M, int N, int K,
+                          int accumulate, hipStream_t s);
+hipError_t launch_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, hipStream_t s);
+hipError_t launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t s);
+hipError_t launch_axpy_rows(const float* x, int64_t ldx, float* y, int64_t ldy, int M, int N, int accumulate, hipStream_t s);
+hipError_t launch_ln_bwd(const float* gy, const float* x, const float* stats, const float* gamma, float* gx, int M, int C,
+                         int accumulate, float* dgamma, float* dbeta, hipStream_t s);
+hipError_t launch_gn_apply(const float* x, int64_t ldx, const double* sums, const float* gamma, const float* beta, int M, int C,
+                           int ngroups, int rows_per_scene, float eps, float* y, int64_t ldy, hipStream_t s);
+hipError_t launch_gn_bwd(const float* x, int64_t ldx, const double* sums, const float* gamma, const float* beta, int M, int C,
+                         int ngroups, int rows_per_scene, float eps, const float* gy, int64_t ldgy, float* gz, double* bsums,
+                         float* gx, int64_t ldgx, float* dgamma, float* dbeta, hipStream_t s);
+hipError_t launch_decode_bwd(const float* g_logits, const float* g_center, const float* g_size, const float* g_rot,
+                             const float* center, const float* size, const float* ref, ScaleBox sb, int M, int ncls, int NH1, int C,
+                             float* g_h3, float* g_h1, float* g_ref, hipStream_t s);
+hipError_t launch_head3_bwd(const float* g_h3, const float* w3, float* g_act, int M, int C, hipStream_t s);
+hipError_t launch_posemb_bwd(const float* g_emb, const float* ref, const float* dim_t, int M, float* g_ref, hipStream_t s);
+hipError_t launch_refpoint_bwd(const float* g_ref, const float* ref0, int B, int Q, float* g_w, hipStream_t s);
+hipError_t launch_sample_bwd(const float* tokens, const double* T_cl, const float* cam, const float* ref, ScaleBox sb, int B, int V,
+                             int h, int w, int C, int Q, const float* g_tgt, float* g_tokens, float* g_ref, hipStream_t s);
+hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int64_t q_row, const float* k, int64_t k_batch,
+                           int64_t k_head, int64_t k_row, const float* v, int64_t v_batch, int64_t v_head, int64_t v_row,
+                           const float* dO, int64_t do_batch, int64_t do_head, int64_t do_row, const float* lse, const float* D,
+                           float* gq, int64_t gq_batch, int64_t gq_head, int64_t gq_row, float* gk, int64_t gk_batch,
+                           int64_t gk_head, int64_t gk_row, float* gv, int64_t gv_batch, int64_t gv_head, int64_t gv_row, int B, int H,
+                           int Lq, int Lk, int dh, int accumulate_kv, hipStream_t s);
+hipError_t launch_attn_bwd_rowdot(const float* dO, const float* O, int64_t batch, int64_t row, int B, int H, int Lq, int dh, float* D,
+                                  hipStream_t s);
 hipError_t launch_gemm_split(const float* X, int64_t ldx, const void* Whi, const void* Wlo, const float* bias, float* Y,
                              int64_t ldy, int M, int N, int K, int relu, const float* feat, int hw, hipStream_t s);
 
@@ -168,7 +201,6 @@ hipError_t launch_camera_local_f64(const float* T_cp, const float* T_wp, const f
 hipError_t launch_initial_ref(const float* refpoint_w, int B, int Q, float* ref, hipStream_t s);
 hipError_t launch_posemb(const float* ref, const float* dim_t, int M, float* emb, hipStream_t s);
 hipError_t launch_zero_f64(double* p, int n, hipStream_t s);
-struct ScaleBox { float lo[3]; float hi[3]; };
 hipError_t launch_project_sample(const float* tokens, const float* T_cl, const float* cam, const float* ref,
                                  ScaleBox sb, int B, int V, int h, int w, int C, int Q, float* tgt,
                                  float* coord_pos, hipStream_t s);
@@ -178,7 +210,7 @@ hipError_t launch_project_sample_f64(const float* tokens, const double* T_cl, co
                                      float* coord_pos, double* zero_f64, int zero_n, hipStream_t s);
 // self-attention of the Q queries in one launch (8 key slices per workgroup combined through LDS)
 hipError_t launch_self_attn(const float* qkv, int64_t row_stride, int B, int H, int Lq, int dh, float* out,
-                            int64_t out_row, hipStream_t s);
+                            int64_t out_row, hipStream_t s, float* lse = nullptr);
 hipError_t launch_layernorm(const float* X, const float* gamma, const float* beta, float* Y, int M, int C,
                             float eps, hipStream_t s);
 // mean / rstd over (rows_per_scene x ncols) blocks: stats[(b * ngroups + g) * 2 + {0,1}]

@@ -270,6 +270,7 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(FlashArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) den += dsm[i * 32 + tq];
     const float inv = 1.f / den;
+    if (a.lse && blockIdx.z == 0 && td == 0 && q < a.Lq) a.lse[(int64_t)bh * Lq_pad + q] = mmax + log2f(den);
 
     // thread -> (4 queries, one d, one half of the splits)
     const int q4 = threadIdx.x & 7;
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(FlashArgs a) {
 //     is a lane-contiguous scalar load.
 template <int DH>
 __global__ __launch_bounds__(512) void self_attn_kernel(const float* __restrict__ qkv, int64_t row_stride, int H, int L,
-                                                        float* __restrict__ out, int64_t out_row) {
+                                                        float* __restrict__ out, int64_t out_row, float* __restrict__ lse) {
     constexpr int NW = 8;
     constexpr int NDT = DH / 16;                 // 16-wide d sub-tiles of O^T
     constexpr int NC = DH / 16;                  // float4 chunks of a Q / K row per lane
@@ -448,7 +449,10 @@ __global__ __launch_bounds__(512) void self_attn_kernel(const float* __restrict_
             num += wt * Os[(w * DH + d) * 17 + qq];
             den += wt * Ls[w * 16 + qq];
         }
-        if (q0 + qq < L) out[((int64_t)b * L + q0 + qq) * out_row + h * DH + d] = num / den;
+        if (q0 + qq < L) {
+            out[((int64_t)b * L + q0 + qq) * out_row + h * DH + d] = num / den;
+            if (lse && d == 0) lse[(int64_t)bh * ((L + 31) & ~31) + q0 + qq] = mmax + log2f(den);
+        }
     }
 }
 
@@ -499,18 +503,18 @@ hipError_t merge_dh(const FlashArgs& a, hipStream_t s) {
 
 template <int DH>
 static hipError_t launch_self_dh(const float* qkv, int64_t row_stride, int B, int H, int L, float* out, int64_t out_row,
-                                 hipStream_t s) {
+                                 hipStream_t s, float* lse) {
     const size_t lds = ((size_t)8 * DH * 17 + 2 * 8 * 16) * sizeof(float);
     hipLaunchKernelGGL((self_attn_kernel<DH>), dim3(ceil_div(L, 16), B * H), dim3(512), lds, s, qkv, row_stride, H, L, out,
-                       out_row);
+                       out_row, lse);
     return hipGetLastError();
 }
 
 // qkv: (B, L, row_stride) with q | k | v at column offsets 0, H*dh, 2*H*dh.  dh in {32, 64}.
 hipError_t launch_self_attn(const float* qkv, int64_t row_stride, int B, int H, int L, int dh, float* out,
-                            int64_t out_row, hipStream_t s) {
-    if (dh == 64) return launch_self_dh<64>(qkv, row_stride, B, H, L, out, out_row, s);
-    if (dh == 32) return launch_self_dh<32>(qkv, row_stride, B, H, L, out, out_row, s);
+                            int64_t out_row, hipStream_t s, float* lse) {
+    if (dh == 64) return launch_self_dh<64>(qkv, row_stride, B, H, L, out, out_row, s, lse);
+    if (dh == 32) return launch_self_dh<32>(qkv, row_stride, B, H, L, out, out_row, s, lse);
     return hipErrorInvalidValue;
 }
 

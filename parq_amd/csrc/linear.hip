@@ -351,6 +351,7 @@ __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a
             if (on < a.N) {
                 float y = sum[e] + e_bias[e];
                 if (a.relu) y = y > 0.f ? y : 0.f;
+                if (a.relu_mask) y = a.relu_mask[(int64_t)om * a.ldmask + on] > 0.f ? y : 0.f;
                 if (a.R) y += a.rln_stats ? (e_r[e] - rmean) * rrstd * e_rg[e] + e_rb[e] : e_r[e];
                 Ybase[(int64_t)(on / a.col_blk) * a.y_blk + (on % a.col_blk)] = y;
                 gs += (double)y;

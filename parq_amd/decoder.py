@@ -185,6 +185,7 @@ class PARQDecoder(nn.Module):
         self._arena = None
         self._arena_key = None
         self._ws = {}
+        self._train_ws = None
         self._mean_dev = None
 
     # ------------------------------------------------------------------ native handle
@@ -198,6 +199,7 @@ class PARQDecoder(nn.Module):
             _lib.check(lib.parq_create(C.byref(cfg), C.byref(h)), "parq_create")
             self._h = h
             self._mode_set = None
+            self._train_ws = None
         if self._mode_set != self.attention_mode:
             if self.attention_mode not in ATTENTION_MODES:
                 raise ValueError(f"attention_mode must be one of {sorted(ATTENTION_MODES)}")
@@ -313,6 +315,60 @@ class PARQDecoder(nn.Module):
                                             _lib.stream_ptr()), "parq_forward")
         del keep
         return [{k: t[i] for k, t in zip(OUTPUT_KEYS, outs)} for i in range(self.num_layers)]
+
+    # ------------------------------------------------------------------ training
+    @torch.no_grad()
+    def forward_train(self, intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw=None):
+        """Forward that keeps every iteration's activations for ``backward`` (attention mode "fp32", dropout 0).
+        Returns the same list of dicts as ``forward``."""
+        if self.dropout_rate > 0 and self.training:
+            raise NotImplementedError("parq_amd.PARQDecoder: dropout > 0 in train mode is not built (set DROPOUT_RATE = 0)")
+        if self.attention_mode != "fp32":
+            raise RuntimeError('training needs attention_mode = "fp32" (the backward kernels read the fp32 K/V cache)')
+        sc, keep, dev = self._scene(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
+        self._ensure_packed(dev)
+        lib, h = _lib.load(), self._handle()
+        nbytes = lib.parq_train_workspace_bytes(h, sc.B, sc.V, sc.h, sc.w)
+        if self._train_ws is None or self._train_ws.numel() * 4 < nbytes or self._train_ws.device != dev:
+            self._ws.clear()
+            self._train_ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=dev)
+        outs = self._alloc_outputs((self.num_layers, sc.B, self.num_queries), dev)
+        po = _lib.ParqOutputs(*[_lib.ptr(t) for t in outs])
+        _lib.check(lib.parq_forward_train(h, C.byref(sc), _lib.ptr(self._train_ws), self._train_ws.numel() * 4, C.byref(po),
+                                          _lib.stream_ptr()), "parq_forward_train")
+        self._train_state = (sc, keep, outs, po, dev)
+        return [{k: t[i] for k, t in zip(OUTPUT_KEYS, outs)} for i in range(self.num_layers)]
+
+    @torch.no_grad()
+    def backward(self, grad_outputs, want_token_grad=True):
+        """Backward of the last ``forward_train``.  ``grad_outputs``: dict with any of pred_logits / center_unnormalized /
+        size_unnormalized / ortho6d -> (I, B, Q, k) cotangents (missing = zero).  Returns ({reference tensor name:
+        gradient}, d_tokens or None); gradients of tensors registered under two names are returned once per name."""
+        sc, keep, outs, po, dev = self._train_state
+        lib, h = _lib.load(), self._handle()
+        gs = []
+        for key, wd in (("pred_logits", self.num_semcls + 1), ("center_unnormalized", 3), ("size_unnormalized", 3), ("ortho6d", 6)):
+            g = grad_outputs.get(key)
+            if g is not None:
+                g = g.to(device=dev, dtype=torch.float32).contiguous()
+                assert g.shape == (self.num_layers, sc.B, self.num_queries, wd), (key, tuple(g.shape))
+            gs.append(g)
+        pg = _lib.ParqOutputGrads(*[_lib.ptr(g) for g in gs])
+        arena = torch.empty(lib.parq_grad_arena_bytes(h) // 4, dtype=torch.float32, device=dev)
+        N = sc.V * sc.h * sc.w
+        d_tokens = torch.empty(sc.B, N, self.dim_in, dtype=torch.float32, device=dev) if want_token_grad else None
+        _lib.check(lib.parq_backward(h, C.byref(sc), _lib.ptr(self._train_ws), self._train_ws.numel() * 4, C.byref(po), C.byref(pg),
+                                     _lib.ptr(arena), _lib.ptr(d_tokens), _lib.stream_ptr()), "parq_backward")
+        grads = {}
+        off, rows, cols, ld = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        for name, p in self._unique_params():
+            if name.startswith("parq_module.decoder.norm."):
+                continue
+            _lib.check(lib.parq_arena_lookup(h, name.encode(), C.byref(off), C.byref(rows), C.byref(cols), C.byref(ld)),
+                       "parq_arena_lookup(%s)" % name)
+            g = arena[off.value: off.value + rows.value * cols.value].view(rows.value, cols.value)
+            grads[name] = g.reshape(p.shape).clone()
+        return grads, d_tokens
 
     # ------------------------------------------------------------------ stepping interface (tests, custom drivers)
     @torch.no_grad()

@@ -1,0 +1,80 @@
+"""Backward of the decoder chain against autograd of the float64 oracle.
+
+The oracle (oracle/parq_oracle.py) is plain torch, so `loss = sum_k <cotangent_k, output_k>` differentiated by autograd in
+float64 gives the reference gradients for every weight and for the input tokens.  As in the reference, the reference points
+are detached between iterations (model/transformer_parq.py:331-332); iteration 0 differentiates through
+sigmoid(refpoint.weight).  Tolerance per tensor: Frobenius-relative error < 2e-3 and max-norm-relative error < 2e-2 (fp32 chain
+with atomics against float64; a ReLU whose pre-activation sits within rounding of zero flips its mask between the two
+precisions and moves single gradient entries, which the max-norm bound allows for and the Frobenius bound averages).
+"""
+import numpy as np
+import pytest
+import torch
+
+from parq_amd import synth
+from oracle import parq_oracle as O
+from gpu_util import make_decoder, scene_args
+
+pytestmark = pytest.mark.gpu
+
+GKEYS = ("pred_logits", "center_unnormalized", "size_unnormalized", "ortho6d")
+
+
+def oracle_grads(cfg, W, sc, cots):
+    od = O.OracleDecoder(cfg, W, synth.SCANNET_MEAN_SIZES, dtype=torch.float64)
+    for k in od.W:
+        od.W[k].requires_grad_(True)
+    od.prepare(sc["tokens"], sc["camera"], sc["T_camera_pseudoCam"], sc["T_world_pseudoCam"], sc["T_world_local"])
+    od.tokens.requires_grad_(True)
+    ref = od.initial_ref()
+    loss = 0.0
+    outs = []
+    for k in range(cfg.TRANSFORMER.DEC_LAYERS):
+        out, nxt, _ = od.iterate(ref, k)
+        outs.append(out)
+        for key in GKEYS:
+            loss = loss + (out[key] * torch.from_numpy(cots[key][k]).double()).sum()
+        ref = nxt.detach()
+    loss.backward()
+    grads = {k: v.grad for k, v in od.W.items() if v.grad is not None}
+    return grads, od.tokens.grad, outs
+
+
+@pytest.mark.parametrize("B,V,h,w,Q,heads,dim,ffn,layers,shared", [
+    (2, 2, 8, 10, 32, 2, 128, 96, 2, True),
+    (1, 3, 6, 7, 40, 4, 256, 256, 3, True),
+    (2, 2, 5, 6, 16, 2, 128, 64, 2, False),
+])
+def test_backward_matches_oracle_autograd(B, V, h, w, Q, heads, dim, ffn, layers, shared):
+    cfg = synth.decoder_cfg(dim=dim, queries=Q, heads=heads, ffn=ffn, layers=layers, share_weights=shared, dropout=0.0)
+    W = synth.make_decoder_weights(cfg, 71)
+    sc = synth.make_scene(72, B, V, h, w, dim, smooth=True)
+    ncls = cfg.NUM_SEMCLS + 1
+    cots = {"pred_logits": synth.normal(73, "cl", (layers, B, Q, ncls)), "center_unnormalized": synth.normal(74, "cc", (layers, B, Q, 3)),
+            "size_unnormalized": synth.normal(75, "cs", (layers, B, Q, 3)), "ortho6d": synth.normal(76, "cr", (layers, B, Q, 6))}
+    want, want_tok, oouts = oracle_grads(cfg, W, sc, cots)
+
+    dec = make_decoder(cfg, W)
+    dec.attention_mode = "fp32"
+    outs = dec.forward_train(*scene_args(sc))
+    for k in range(layers):                                   # the training forward is the same forward
+        for key in GKEYS:
+            a, b = outs[k][key].cpu().numpy(), oouts[k][key].detach().numpy()
+            assert np.abs(a - b).max() / max(1.0, np.abs(b).max()) < 1e-4, (k, key)
+    grads, d_tok = dec.backward({k: torch.from_numpy(v) for k, v in cots.items()})
+    worst = {}
+    for name, g in grads.items():
+        if name not in want:
+            assert float(g.abs().max()) == 0.0, name          # e.g. never-used tensors
+            continue
+        ref = want[name].numpy()
+        d = g.cpu().numpy().astype(np.float64) - ref
+        worst[name] = (np.linalg.norm(d) / max(np.linalg.norm(ref), 1e-9), np.abs(d).max() / max(np.abs(ref).max(), 1e-9))
+    bad = {k: v for k, v in worst.items() if not (v[0] < 2e-3 and v[1] < 2e-2)}
+    print("\nworst relative gradient errors (frobenius, max):", sorted(worst.items(), key=lambda kv: -kv[1][0])[:5])
+    assert not bad, bad
+    rt = want_tok.numpy()
+    dt = d_tok.cpu().numpy().astype(np.float64) - rt
+    terr = (np.linalg.norm(dt) / max(np.linalg.norm(rt), 1e-9), np.abs(dt).max() / max(np.abs(rt).max(), 1e-9))
+    print("token gradient error (frobenius, max) %.3e %.3e" % terr)
+    assert terr[0] < 2e-3 and terr[1] < 2e-2, terr
