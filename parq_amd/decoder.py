@@ -140,6 +140,30 @@ class _TransformerParams(nn.Module):
 ATTENTION_MODES = {"fp32": 0, "split": 1, "fp16": 2, "bf16": 3}
 
 
+class _TrainFn(torch.autograd.Function):
+    """Autograd node of the whole decoder: forward = parq_forward_train, backward = parq_backward (HIP kernels)."""
+
+    @staticmethod
+    def forward(ctx, dec, tokens, camera, T_cp, T_wp, T_wl, feat_hw, *params):
+        outs = dec.forward_train(tokens, camera, T_cp, T_wp, T_wl, feat_hw=feat_hw)
+        stacked = dec._train_state[2]                       # six (I, B, Q, k) tensors
+        ctx.dec = dec
+        ctx.want_tokens = bool(tokens.requires_grad)
+        ctx.mark_non_differentiable(stacked[4], stacked[5])  # sem_cls_prob / coord_pos carry no gradient (transformer_parq.py:261-265)
+        del outs
+        return tuple(stacked)
+
+    @staticmethod
+    def backward(ctx, g_logits, g_center, g_size, g_rot, _g_prob, _g_coord):
+        dec = ctx.dec
+        grads, d_tokens = dec.backward({"pred_logits": g_logits, "center_unnormalized": g_center, "size_unnormalized": g_size,
+                                        "ortho6d": g_rot}, want_token_grad=ctx.want_tokens)
+        per_param = []
+        for name, p in dec._unique_params():
+            per_param.append(grads.get(name) if p.requires_grad else None)
+        return (None, d_tokens, None, None, None, None, None, *per_param)
+
+
 class PARQDecoder(nn.Module):
     """Drop-in for ``model.parq_decoder.PARQDecoder`` (forward path)."""
 
@@ -186,6 +210,7 @@ class PARQDecoder(nn.Module):
         self._arena_key = None
         self._ws = {}
         self._train_ws = None
+        self.dp_all_reduce = False        # True: backward() all-reduces the flat gradient arena over the default process group
         self._mean_dev = None
 
     # ------------------------------------------------------------------ native handle
@@ -303,8 +328,24 @@ class PARQDecoder(nn.Module):
                 "(SURVEY.md §8f rank 1); call .eval()" % self.dropout_rate)
 
     # ------------------------------------------------------------------ forward (model/parq_decoder.py:134-163)
-    @torch.no_grad()
     def forward(self, intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw=None):
+        if torch.is_grad_enabled() and self.training:
+            return self._forward_autograd(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
+        with torch.no_grad():
+            return self._forward_inference(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
+
+    def _forward_autograd(self, tokens, camera, T_cp, T_wp, T_wl, feat_hw):
+        """Train-mode forward under autograd: one autograd node whose backward is the HIP backward chain.  Uses the exact
+        fp32 attention kernels (attention_mode is switched to "fp32") and needs DROPOUT_RATE = 0."""
+        if self.dropout_rate > 0:
+            raise NotImplementedError("parq_amd.PARQDecoder: dropout %.2f in train mode is not built; set DROPOUT_RATE = 0 "
+                                      "or call .eval()" % self.dropout_rate)
+        self.attention_mode = "fp32"
+        params = [p for _, p in self._unique_params()]
+        stacked = _TrainFn.apply(self, raw(tokens), camera, T_cp, T_wp, T_wl, feat_hw, *params)
+        return [{k: t[i] for k, t in zip(OUTPUT_KEYS, stacked)} for i in range(self.num_layers)]
+
+    def _forward_inference(self, intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw=None):
         self._check_mode()
         sc, keep, dev = self._scene(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
         self._ensure_packed(dev)
@@ -359,6 +400,11 @@ class PARQDecoder(nn.Module):
         d_tokens = torch.empty(sc.B, N, self.dim_in, dtype=torch.float32, device=dev) if want_token_grad else None
         _lib.check(lib.parq_backward(h, C.byref(sc), _lib.ptr(self._train_ws), self._train_ws.numel() * 4, C.byref(po), C.byref(pg),
                                      _lib.ptr(arena), _lib.ptr(d_tokens), _lib.stream_ptr()), "parq_backward")
+        if self.dp_all_reduce and torch.distributed.is_available() and torch.distributed.is_initialized():
+            # data-parallel training: the gradient arena is one flat buffer -> a single RCCL all-reduce (mean), instead
+            # of one bucket per tensor (train.py:103 DDP semantics: mean over ranks)
+            torch.distributed.all_reduce(arena)
+            arena /= torch.distributed.get_world_size()
         grads = {}
         off, rows, cols, ld = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         for name, p in self._unique_params():

@@ -78,3 +78,46 @@ def test_backward_matches_oracle_autograd(B, V, h, w, Q, heads, dim, ffn, layers
     terr = (np.linalg.norm(dt) / max(np.linalg.norm(rt), 1e-9), np.abs(dt).max() / max(np.abs(rt).max(), 1e-9))
     print("token gradient error (frobenius, max) %.3e %.3e" % terr)
     assert terr[0] < 2e-3 and terr[1] < 2e-2, terr
+
+
+def test_autograd_node_and_adamw_steps():
+    """PARQDecoder in train mode under autograd: loss.backward() fills .grad of every parameter and of the input tokens
+    through the HIP backward, and a few AdamW steps (model/parq_lightning.py:161-199: AdamW, lr 1e-4 scale) lower a
+    regression loss on fixed targets."""
+    B, V, h, w, Q, dim = 2, 2, 8, 10, 32, 128
+    cfg = synth.decoder_cfg(dim=dim, queries=Q, heads=2, ffn=96, layers=2, dropout=0.0)
+    W = synth.make_decoder_weights(cfg, 81)
+    sc = synth.make_scene(82, B, V, h, w, dim, smooth=True)
+    dec = make_decoder(cfg, W).train()
+    args = list(scene_args(sc))
+    args[0] = args[0].clone().requires_grad_(True)
+    cots = {k: torch.from_numpy(synth.normal(83 + i, k, (2, B, Q, wd))).cuda()
+            for i, (k, wd) in enumerate((("pred_logits", cfg.NUM_SEMCLS + 1), ("center_unnormalized", 3), ("size_unnormalized", 3), ("ortho6d", 6)))}
+    outs = dec(*args)
+    loss = sum((outs[k][key] * cots[key][k]).sum() for k in range(2) for key in GKEYS)
+    loss.backward()
+    np_cots = {k: v.cpu().numpy() for k, v in cots.items()}
+    want, want_tok, _ = oracle_grads(cfg, W, sc, np_cots)
+    seen = 0
+    for name, p in dec.named_parameters():
+        if name in want and p.grad is not None:
+            ref = want[name].numpy()
+            assert np.linalg.norm(p.grad.cpu().numpy() - ref) / max(np.linalg.norm(ref), 1e-9) < 2e-3, name
+            seen += 1
+    assert seen >= 30
+    rt = want_tok.numpy()
+    assert np.linalg.norm(args[0].grad.cpu().numpy() - rt) / np.linalg.norm(rt) < 2e-3
+
+    opt = torch.optim.AdamW([p for p in dec.parameters() if p.requires_grad], lr=2e-3, weight_decay=1e-4)
+    target = torch.from_numpy(synth.uniform(90, "tgt", (B, Q, 3), -1.0, 1.0)).cuda()
+    losses = []
+    for _ in range(6):
+        opt.zero_grad(set_to_none=True)
+        outs = dec(*scene_args(sc))
+        l = sum(((o["center_unnormalized"] - target) ** 2).mean() for o in outs)
+        l.backward()
+        torch.nn.utils.clip_grad_norm_(dec.parameters(), 1.0)            # parq_lightning.py gradient_clip_val = 1
+        opt.step()
+        losses.append(float(l))
+    print("\nregression loss over AdamW steps:", ["%.4f" % x for x in losses])
+    assert losses[-1] < losses[0]
