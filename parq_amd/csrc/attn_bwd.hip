@@ -10,6 +10,8 @@
 // not the fast path (cfg 3: ~50 GFMA per iteration).
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace parq {
 
 namespace {
@@ -121,6 +123,173 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// MFMA version for long key sequences (the cross-attention against all view tokens), head dim 64, exact fp32
+// (v_mfma_f32_32x32x2_f32).  A workgroup owns 256 keys, each of its 8 waves 32 of them: K_j and V_j stay in registers as
+// B operands, dK^T / dV^T (d x keys) accumulate in registers over all queries, and the queries are streamed in tiles of
+// 32 through LDS.  With queries as accumulator ROWS and keys as COLUMNS (lanes):
+//     S  = Q K^T, dP = dO V^T          A = Q / dO tile from LDS, B = K / V registers
+//     P = exp2(S c2 - lse_q), dS = P (dP - D_q)                       (lse, D per accumulator row)
+//     dV^T += dO^T P, dK^T += Q^T dS   contraction over the queries = accumulator rows: P / dS registers ARE the B operand
+//     dQ  += dS K                      contraction over this wave's keys: dS goes through a per-wave LDS tile to become
+//                                      the A operand, K comes from a per-wave LDS copy; the 8 waves add their partial
+//                                      tiles into one LDS tile (ds_add_f32), which is added to global dQ with atomics.
+constexpr int kQs = 68;      // row stride (floats) of the Q / dO tiles
+constexpr int kKc = 65;      // row stride of the per-wave K copy
+constexpr int kDs = 33;      // row stride of the per-wave dS tile
+
+__global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(AttnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qs = smem;                       // [32][kQs]
+    float* Os = Qs + 32 * kQs;              // [32][kQs]  dO tile
+    float* st = Os + 32 * kQs;              // [2][32] lse, D
+    float* dQs = st + 64;                   // [32][64]
+    float* wave_base = dQs + 32 * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    float* Kc = wave_base + wave * (32 * kKc + 32 * kDs);    // [32][kKc]
+    float* Ds = Kc + 32 * kKc;                                // [32][kDs]
+    const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+    const int j0 = blockIdx.x * 256 + wave * 32;
+    const int j = j0 + li;
+    const bool jok = j < a.Lk;
+    const int Lq_pad = (a.Lq + 31) & ~31;
+    const float c2 = 1.4426950408889634f / 8.f;       // log2(e) / sqrt(64)
+    const float cn = 1.f / 8.f;
+
+    // K, V of this lane's key: lane (j, kh) holds d = kh*32 .. kh*32+31 (B operands); K also copied to LDS [j][d]
+    float kf[32], vf[32];
+    {
+        const float* kp = a.k + (int64_t)b * a.k_batch + (int64_t)h * a.k_head + (int64_t)(jok ? j : 0) * a.k_row + kh * 32;
+        const float* vp = a.v + (int64_t)b * a.v_batch + (int64_t)h * a.v_head + (int64_t)(jok ? j : 0) * a.v_row + kh * 32;
+#pragma unroll
+        for (int u = 0; u < 32; u += 4) {
+            float4 k4 = *reinterpret_cast<const float4*>(kp + u);
+            float4 v4 = *reinterpret_cast<const float4*>(vp + u);
+            if (!jok) { k4 = float4{0.f, 0.f, 0.f, 0.f}; v4 = k4; }
+            kf[u] = k4.x; kf[u + 1] = k4.y; kf[u + 2] = k4.z; kf[u + 3] = k4.w;
+            vf[u] = v4.x; vf[u + 1] = v4.y; vf[u + 2] = v4.z; vf[u + 3] = v4.w;
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) Kc[li * kKc + kh * 32 + u] = kf[u];
+    }
+    f32x16 gk[2], gv[2];                    // dK^T, dV^T: rows d (2 x 32), columns keys
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { gk[dt][r] = 0.f; gv[dt][r] = 0.f; }
+
+    for (int i0 = 0; i0 < a.Lq; i0 += 32) {
+        __syncthreads();                                    // previous tile fully consumed
+        for (int idx = tid; idx < 32 * 16; idx += 512) {    // Q and dO tiles: 32 rows x 16 float4
+            const int i = idx >> 4, c4 = idx & 15;
+            const bool ok = i0 + i < a.Lq;
+            float4 q4 = float4{0.f, 0.f, 0.f, 0.f}, o4 = q4;
+            if (ok) {
+                q4 = *reinterpret_cast<const float4*>(a.q + (int64_t)b * a.q_batch + (int64_t)h * a.q_head + (int64_t)(i0 + i) * a.q_row + c4 * 4);
+                o4 = *reinterpret_cast<const float4*>(a.dO + (int64_t)b * a.do_batch + (int64_t)h * a.do_head + (int64_t)(i0 + i) * a.do_row + c4 * 4);
+            }
+            *reinterpret_cast<float4*>(Qs + i * kQs + c4 * 4) = q4;
+            *reinterpret_cast<float4*>(Os + i * kQs + c4 * 4) = o4;
+        }
+        if (tid < 32) {
+            st[tid] = i0 + tid < a.Lq ? a.lse[(int64_t)bh * Lq_pad + i0 + tid] : 0.f;
+            st[32 + tid] = i0 + tid < a.Lq ? a.D[(int64_t)bh * Lq_pad + i0 + tid] : 0.f;
+        }
+        for (int idx = tid; idx < 32 * 64; idx += 512) dQs[idx] = 0.f;
+        __syncthreads();
+
+        // ---- S = Q K^T, dP = dO V^T   (rows = queries, columns = this wave's keys)
+        f32x16 sacc, pacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < 32; u += 4) {
+            const float4 q4 = *reinterpret_cast<const float4*>(Qs + li * kQs + kh * 32 + u);
+            const float4 o4 = *reinterpret_cast<const float4*>(Os + li * kQs + kh * 32 + u);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.x, kf[u], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.y, kf[u + 1], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.z, kf[u + 2], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.w, kf[u + 3], sacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(o4.x, vf[u], pacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(o4.y, vf[u + 1], pacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(o4.z, vf[u + 2], pacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(o4.w, vf[u + 3], pacc, 0, 0, 0);
+        }
+        // ---- P, dS (accumulator row r of this lane is query mfma32_row(r, lane))
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qi = mfma32_row(r, lane);
+            const bool ok = jok && (i0 + qi < a.Lq);
+            const float p = ok ? __builtin_amdgcn_exp2f(sacc[r] * c2 - st[qi]) : 0.f;
+            const float ds = p * (pacc[r] - st[32 + qi]);
+            sacc[r] = p;
+            pacc[r] = ds;
+            Ds[qi * kDs + li] = ds;
+        }
+        // ---- dV^T += dO^T P, dK^T += Q^T dS: MFMA step r contracts over the query pair (row(r,0), row(r,1))
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qi = mfma32_row(r, lane);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                gv[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[qi * kQs + dt * 32 + li], sacc[r], gv[dt], 0, 0, 0);
+                gk[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[qi * kQs + dt * 32 + li], pacc[r], gk[dt], 0, 0, 0);
+            }
+        }
+        // ---- dQ tile += dS K over this wave's 32 keys (same-wave LDS round trip for dS)
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        f32x16 gq[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gq[dt][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int jj = kh + 2 * t;
+            const float av = Ds[li * kDs + jj];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                gq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Kc[jj * kKc + dt * 32 + li], gq[dt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) atomicAdd(&dQs[mfma32_row(r, lane) * 64 + dt * 32 + li], gq[dt][r] * cn);
+        __syncthreads();
+        for (int idx = tid; idx < 32 * 64; idx += 512) {
+            const int i = idx >> 6, d = idx & 63;
+            if (i0 + i < a.Lq)
+                atomicAdd(a.gq + (int64_t)b * a.gq_batch + (int64_t)h * a.gq_head + (int64_t)(i0 + i) * a.gq_row + d, dQs[idx]);
+        }
+    }
+    // ---- dK, dV of this wave's keys: transpose (d x keys) -> [key][d] through the wave's LDS copy, then row-contiguous update
+    __builtin_amdgcn_wave_barrier();
+    for (int which = 0; which < 2; ++which) {
+        const float scale = which == 0 ? cn : 1.f;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Kc[li * kKc + dt * 32 + mfma32_row(r, lane)] = (which == 0 ? gk[dt][r] : gv[dt][r]) * scale;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        float* g = which == 0 ? a.gk + (int64_t)b * a.gk_batch + (int64_t)h * a.gk_head : a.gv + (int64_t)b * a.gv_batch + (int64_t)h * a.gv_head;
+        const int64_t grow = which == 0 ? a.gk_row : a.gv_row;
+        for (int idx = lane; idx < 32 * 64; idx += 64) {
+            const int jj = idx >> 6, d = idx & 63;
+            if (j0 + jj < a.Lk) {
+                float* o = g + (int64_t)(j0 + jj) * grow + d;
+                *o = (a.accumulate_kv ? *o : 0.f) + Kc[jj * kKc + d];
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // D[bh][i] = sum_d dO[i][h*dh + d] * O[i][h*dh + d]; one wave per (bh, i)
 __global__ __launch_bounds__(256) void attn_bwd_rowdot_kernel(const float* __restrict__ dO, const float* __restrict__ O, int64_t batch,
                                                               int64_t row, int BH, int H, int Lq, int dh, float* __restrict__ D) {
@@ -161,6 +330,22 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
     a.gv = gv; a.gv_batch = gv_batch; a.gv_head = gv_head; a.gv_row = gv_row;
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.accumulate_kv = accumulate_kv;
     dim3 grid(ceil_div(Lk, 256), B * H);
+    static const int force = [] {
+        const char* e = getenv("PARQ_ATTN_BWD");            // "naive" / "mfma": debugging override
+        return e ? (e[0] == 'n' ? 1 : 2) : 0;
+    }();
+    if (dh == 64 && force != 1 && (Lk >= 2048 || force == 2)) {
+        const size_t lds = (size_t)(2 * 32 * kQs + 64 + 32 * 64 + 8 * (32 * kKc + 32 * kDs)) * sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr = true;
+        }
+        hipLaunchKernelGGL(attn_bwd_mfma_kernel, grid, dim3(512), lds, s, a);
+        return hipGetLastError();
+    }
     if (dh == 64) {
         const size_t lds = (size_t)(2 * 32 * 64 + 32 * 257 + 256 * 65 + 64) * sizeof(float);
         static bool attr = false;

@@ -67,10 +67,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
     }
     const float* Ap = a.A + n0 + li;
     const float* Bp = a.B + k0 + li;
-    // rows dealt round-robin in groups of 4: wave w takes groups w, w+4, ...
-    for (int m0 = wave * 4; m0 < a.M; m0 += 16) {
+    // rows: blockIdx.y owns a contiguous chunk; inside it groups of 4 rows are dealt round-robin to the 4 waves
+    const int chunk = (((a.M + (int)gridDim.y - 1) / (int)gridDim.y) + 15) / 16 * 16;
+    const int m_begin = (int)blockIdx.y * chunk;
+    const int m_end = m_begin + chunk < a.M ? m_begin + chunk : a.M;
+    for (int m0 = m_begin + wave * 4; m0 < m_end; m0 += 16) {
         const int m = m0 + kq;
-        const bool mok = m < a.M;
+        const bool mok = m < m_end;
         float av[2], bv[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -107,7 +110,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
             const int k = k0 + c4 + e;
             if (k < a.K) {
                 float* o = a.out + (int64_t)n * a.ldo + k;
-                *o = a.accumulate ? *o + sum[e] : sum[e];
+                if (gridDim.y > 1) atomicAdd(o, sum[e]);          // row-split launch: out was zeroed / holds the running sum
+                else *o = a.accumulate ? *o + sum[e] : sum[e];
             }
         }
     }
@@ -119,14 +123,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     __shared__ float part[4][64];
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
     const int w = threadIdx.x >> 6;
+    const int chunk = (M + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int m_begin = (int)blockIdx.y * chunk;
+    const int m_end = m_begin + chunk < M ? m_begin + chunk : M;
     float s = 0.f;
     if (n < N)
-        for (int m = w; m < M; m += 4) s += X[(int64_t)m * ldx + n];
+        for (int m = m_begin + w; m < m_end; m += 4) s += X[(int64_t)m * ldx + n];
     part[w][threadIdx.x & 63] = s;
     __syncthreads();
     if (w == 0 && n < N) {
         const float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-        out[n] = accumulate ? out[n] + t : t;
+        if (gridDim.y > 1) atomicAdd(out + n, t);
+        else out[n] = accumulate ? out[n] + t : t;
     }
 }
 
@@ -559,11 +567,24 @@ hipError_t launch_gemm_tn(const float* A, int64_t lda, const float* B, int64_t l
                           int accumulate, hipStream_t s) {
     TnArgs a;
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.accumulate = accumulate;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(ceil_div(N, 32) * ceil_div(K, 32)), dim3(256), 0, s, a);
+    // many rows, few output tiles (the K/V projection backward: M = all tokens): split the rows, accumulate with atomics
+    int splits = 1;
+    const int tiles = ceil_div(N, 32) * ceil_div(K, 32);
+    if (accumulate && M >= 8192) {
+        splits = ceil_div(4 * device_num_cus(), tiles);
+        if (splits > M / 1024) splits = M / 1024;
+        if (splits < 1) splits = 1;
+    }
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64)), dim3(256), 0, s, X, ldx, M, N, out, accumulate);
+    int splits = 1;
+    if (accumulate && M >= 8192) {
+        splits = M / 1024;
+        if (splits > 1024) splits = 1024;
+    }
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64), splits), dim3(256), 0, s, X, ldx, M, N, out, accumulate);
     return hipGetLastError();
 }
 hipError_t launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t s) {
