@@ -193,6 +193,73 @@ def main(only=None):
         np.savez_compressed(os.path.join(OUT_DIR, gname + ".npz"), encoding=enc.numpy(),
                             meta=np.frombuffer(json.dumps(c, sort_keys=True).encode(), dtype=np.uint8))
         print("wrote", gname, tuple(enc.shape))
+    if not only or "g10_loss" in only:
+        make_loss_golden(ref)
+
+
+LOSS_CASE = dict(seed=31, B=3, Q=48, I=2, nbox=[4, 6, 3], np_seed=1234)    # (the reference raises on a scene without boxes)
+
+
+def loss_case_inputs(c):
+    """Random decoder outputs, padded ground-truth boxes, poses and symmetry classes of the loss golden (numpy)."""
+    B, Q, I = c["B"], c["Q"], c["I"]
+    rng = np.random.RandomState(c["seed"])
+    obbs = -np.ones((B, 12, 19), np.float32)
+    sym = -np.ones((B, 12), np.float32)
+    centers = []
+    for b in range(B):
+        cb = []
+        for j in range(c["nbox"][b]):
+            half = rng.uniform(0.2, 0.8, 3)
+            ang = rng.uniform(-np.pi, np.pi)
+            Rm = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+            t = rng.uniform(-1.5, 1.5, 3)
+            obbs[b, j, 0:6] = [-half[0], half[0], -half[1], half[1], -half[2], half[2]]
+            obbs[b, j, 6:15] = Rm.reshape(-1)
+            obbs[b, j, 15:18] = t
+            obbs[b, j, 18] = rng.randint(0, 9)
+            sym[b, j] = rng.randint(0, 4)
+            cb.append(t)
+        centers.append(cb)
+    T_wl = np.zeros((B, 1, 12), np.float32)
+    for b in range(B):
+        ang = rng.uniform(-0.3, 0.3)
+        T_wl[b, 0, :9] = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]]).reshape(-1)
+        T_wl[b, 0, 9:] = rng.uniform(-0.2, 0.2, 3)
+    outs = []
+    for k in range(I):
+        o = {"pred_logits": rng.normal(0, 1, (B, Q, 10)).astype(np.float32),
+             "center_unnormalized": rng.uniform(-2, 2, (B, Q, 3)).astype(np.float32),
+             "size_unnormalized": rng.uniform(0.2, 2, (B, Q, 3)).astype(np.float32),
+             "ortho6d": rng.normal(0, 1, (B, Q, 6)).astype(np.float32),
+             "coord_pos": rng.uniform(-2, 2, (B, Q, 3)).astype(np.float32)}
+        # a cluster of reference points around the first boxes: exercises the proximity matching and its cap of 10
+        for b in range(B):
+            if centers[b]:
+                # centres are in world coordinates; the matcher compares in the local frame: close enough for T_wl ~ identity
+                o["coord_pos"][b, :14] = (np.asarray(centers[b][0]) + rng.uniform(-0.04, 0.04, (14, 3))).astype(np.float32)
+                if len(centers[b]) > 1:
+                    o["coord_pos"][b, 14:18] = (np.asarray(centers[b][1]) + rng.uniform(-0.04, 0.04, (4, 3))).astype(np.float32)
+        outs.append(o)
+    return outs, obbs, T_wl, sym
+
+
+def make_loss_golden(ref):
+    c = LOSS_CASE
+    outs, obbs, T_wl, sym = loss_case_inputs(c)
+    cfg = synth.decoder_cfg(dim=64, queries=c["Q"], heads=1, ffn=64, layers=c["I"])
+    cfg.MEAN_SIZE_PATH = ref.mean_size_path
+    dec = ref.PARQDecoder(cfg)
+    touts = [{k: torch.from_numpy(v) for k, v in o.items()} for o in outs]
+    res = {}
+    for tag, s in (("sym", torch.from_numpy(sym)), ("nosym", None)):
+        np.random.seed(c["np_seed"])
+        ld = dec.loss(touts, ref.Obb3D(torch.from_numpy(obbs)), ref.Pose(torch.from_numpy(T_wl)), s)
+        for k, v in ld.items():
+            res["%s_%s" % (tag, k)] = np.float64(float(v))
+    np.savez_compressed(os.path.join(OUT_DIR, "g10_loss.npz"), meta=np.frombuffer(json.dumps(c, sort_keys=True).encode(), dtype=np.uint8), **res)
+    print("wrote g10_loss", {k: float(v) for k, v in res.items()})
+
 
 if __name__ == "__main__":
     main(sys.argv[1:] or None)

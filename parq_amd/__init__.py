@@ -6,7 +6,7 @@ Public surface mirrors the reference (ymingxie/PARQ):
     Pose, Camera (utils/wrappers.py:194,441)     tensor wrappers drivers pass in
 The compute lives in ``parq_amd/_C/libparq_hip.so`` (C ABI: include/parq_hip.h).
 """
-from .wrappers import Camera, Pose, TensorWrapper  # noqa: F401
+from .wrappers import Camera, Obb3D, Pose, TensorWrapper  # noqa: F401
 
 
 def __getattr__(name):

@@ -209,6 +209,7 @@ class PARQDecoder(nn.Module):
         self._arena = None
         self._arena_key = None
         self._ws = {}
+        self._matcher = None
         self._train_ws = None
         self.dp_all_reduce = False        # True: backward() all-reduces the flat gradient arena over the default process group
         self._mean_dev = None
@@ -476,8 +477,16 @@ class PARQDecoder(nn.Module):
         return res
 
     # ------------------------------------------------------------------ next-tier rows
-    def loss(self, *a, **k):
-        raise NotImplementedError("PARQDecoder.loss (Hungarian matcher + box losses) is a next-tier row (SURVEY.md §8f-2)")
+    def loss(self, out_dict_list, obbs_padded, T_world_local, sym=None, *argv):
+        """Hungarian-matched set loss, model/parq_decoder.py:264-370 (host-side torch + scipy as in the reference;
+        parq_amd/loss.py).  Under autograd its gradient reaches the weights through the HIP backward chain."""
+        from .loss import HungarianMatcherModified, decoder_loss
+        if self._matcher is None:
+            self._matcher = HungarianMatcherModified(cost_class=2, cost_bbox=0.25)          # parq_decoder.py:71
+            self._class_weight = torch.ones(self.num_semcls + 1)
+            self._class_weight[self.num_semcls] = 0.1                                        # background (:46-48)
+        return decoder_loss(out_dict_list, obbs_padded, T_world_local, sym, matcher=self._matcher,
+                            loss_weight=self.loss_weight, num_semcls=self.num_semcls, class_weight=self._class_weight)
 
     def update_metrics(self, *a, **k):
         raise NotImplementedError("eval post-processing is out of scope this round (SURVEY.md §8f-4)")

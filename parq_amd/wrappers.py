@@ -185,6 +185,54 @@ class Camera(TensorWrapper):
         return torch.cat([xy, xy.new_ones(xy.shape[:-1] + (1,))], dim=-1)
 
 
+class Obb3D(TensorWrapper):
+    """Oriented 3-D boxes as 19-vectors [xmin,xmax,ymin,ymax,zmin,zmax | T_world_object (12) | sem_id]
+    (utils/wrappers.py:297-436); a row of all -1 is padding."""
+    _width = 19
+
+    @classmethod
+    def separate_init(cls, bb3_object, T_world_object, sem_id):
+        bb3_object, T_world_object, sem_id = _as_tensor(bb3_object), raw(T_world_object), _as_tensor(sem_id)
+        if sem_id.dim() != bb3_object.dim():
+            sem_id = sem_id.unsqueeze(-1)
+        return cls(torch.cat([bb3_object, T_world_object, sem_id.to(bb3_object.dtype)], dim=-1))
+
+    bb3_object = property(lambda self: self._data[..., :6])
+    bb3_min_object = property(lambda self: self._data[..., 0:6:2])
+    bb3_max_object = property(lambda self: self._data[..., 1:6:2])
+    bb3_center_object = property(lambda self: 0.5 * (self._data[..., 0:6:2] + self._data[..., 1:6:2]))
+    bb3_size = property(lambda self: self._data[..., 1:6:2] - self._data[..., 0:6:2])
+    T_world_object = property(lambda self: Pose(self._data[..., 6:18]))
+    sem_id = property(lambda self: self._data[..., 18].unsqueeze(-1))
+
+    @property
+    def bb3corners_object(self):
+        """The 8 corners (..., 8, 3): bottom face (z = zmin) counter-clockwise from (xmin, ymin), then the top face."""
+        lo, hi = self.bb3_min_object, self.bb3_max_object
+        pick = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)]
+        pts = [torch.stack([(hi if sx else lo)[..., 0], (hi if sy else lo)[..., 1], (hi if sz else lo)[..., 2]], dim=-1)
+               for sx, sy, sz in pick]
+        return torch.stack(pts, dim=-2)
+
+    def add_padding(self, max_box=100):
+        assert self._data.ndim <= 2
+        n = self._data.shape[0]
+        if n >= max_box:
+            return type(self)(self._data[:max_box])
+        pad = -self._data.new_ones(max_box - n, self._data.shape[-1])
+        return type(self)(torch.cat([self._data, pad], dim=0))
+
+    def remove_padding(self):
+        """Boxes before the first all -1 row count (the reference counts non-padding rows and takes that many leading rows)."""
+        assert self._data.ndim <= 3
+        if self._data.ndim == 1:
+            return self
+        keep = ~torch.all(self._data == -1, dim=-1)
+        if self._data.ndim == 2:
+            return type(self)(self._data[:int(keep.sum())])
+        return [type(self)(self._data[b][:int(keep[b].sum())]) for b in range(self._data.shape[0])]
+
+
 def raw(x):
     """The underlying tensor of a wrapper (ours or a duck-typed reference one) or a tensor."""
     return x._data if hasattr(x, "_data") else _as_tensor(x)
