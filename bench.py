@@ -135,6 +135,63 @@ def ray_pe_timing(B, device):
             "note": "AddRayPE.tokens (ray-point encoding + feature add + channels-last tokenisation), outside the metric"}
 
 
+def train_bench(args):
+    """--train: one data-parallel training step per "step" at the per-GPU shard of BASELINE config 4 (batch 32 scenes over 8 GPUs
+    = 4 scenes per GPU, 10 views, 256 queries, 8 iterations): decoder forward with saved activations, the reference's set loss on
+    synthetic boxes, HIP backward, ONE all-reduce of the flat gradient arena over RCCL, AdamW.  Reported beside the headline
+    metric (which stays the inference number); dropout 0, exact-fp32 attention kernels."""
+    from parq_amd import Obb3D, PARQDecoder, Pose, parallel, synth
+    rank, local_rank, world = parallel.env_world()
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    parallel.init(backend="nccl" if world > 1 else None, device=device)
+    B = args.scenes_per_gpu if args.scenes_per_gpu > 1 else 4
+    V, (h, w), Q, C, I = WORKLOAD["views"], WORKLOAD["feat_hw"], WORKLOAD["queries"], WORKLOAD["dim"], WORKLOAD["iters"]
+    cfg = synth.decoder_cfg(dim=C, queries=Q, heads=WORKLOAD["heads"], ffn=WORKLOAD["ffn"], layers=I, dropout=0.0)
+    W = synth.make_decoder_weights(cfg, 41, damped=True)
+    dec = PARQDecoder(cfg)
+    dec.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=False)
+    dec = dec.to(device).train()
+    dec.dp_all_reduce = world > 1
+    inputs = build_inputs(B, device, seed=2000 + rank)
+    obbs, sym = synth.make_boxes(3000 + rank, B, 12)
+    obbs, sym = Obb3D(torch.from_numpy(obbs).to(device)), torch.from_numpy(sym).to(device)
+    T_wl = Pose(inputs[4])
+    opt = torch.optim.AdamW([p for p in dec.parameters() if p.requires_grad], lr=1e-4 * (B * world) / 256.0, foreach=True)
+    np.random.seed(1 + rank)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        outs = dec(*inputs, feat_hw=(h, w))
+        loss = dec.loss(outs, obbs, T_wl, sym)["total_loss"]
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(dec.parameters(), 1.0)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(); parallel.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize(); parallel.barrier(); torch.cuda.synchronize()
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, device=device)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training steps/sec (decoder forward + set loss + HIP backward + gradient all-reduce + AdamW)",
+            "value": args.steps / dt, "unit": "steps/sec", "scenes_per_sec": args.steps * B * world / dt,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "final_loss": float(loss),
+            "config": {"workload": "BASELINE cfg4 per-GPU shard: %d scenes, 10 views 480x640 (120x160 features), 256 queries, 8 iterations, "
+                                   "d=256; dropout 0; 12 synthetic boxes per scene" % B,
+                       "scenes_per_gpu": B, "parallelism": "dp%d (one flat gradient all-reduce per step)" % world}}))
+    if world > 1:
+        parallel.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,7 +202,10 @@ def main():
     ap.add_argument("--attention-mode", default=None, choices=["split", "fp32", "fp16", "bf16"],
                     help="cross-attention arithmetic; default = the library default (split: fp32-class accuracy). "
                          "fp16 / bf16 are the reduced-precision configurations (NOT the headline number)")
+    ap.add_argument("--train", action="store_true", help="time the training step of BASELINE config 4's per-GPU shard instead")
     args = ap.parse_args()
+    if args.train:
+        return train_bench(args)
 
     from parq_amd import parallel
     rank, local_rank, world = parallel.env_world()

@@ -60,4 +60,21 @@ class PARQ(_Base):
         return self.forward(batch, batch_idx)
 
     def training_step(self, batch, batch_idx):
-        raise NotImplementedError("training (backward + DP all-reduce) is the next-tier row, SURVEY.md §8f-1")
+        """model/parq_lightning.py:97-100.  In train mode the decoder forward is an autograd node whose backward is the HIP
+        backward chain (DROPOUT_RATE must be 0); the decoder's weights receive gradients.  The ray-PE MLP and the 2-D
+        backbone sit in front of that node: their backward is not built (tokens are produced without a graph)."""
+        losses, _ = self.forward(batch, batch_idx)
+        return losses["total_loss"]
+
+    def configure_optimizers(self):
+        """AdamW with the reference's batch-size learning-rate rule (model/parq_lightning.py:150-168); the reference's
+        `torch.optim._multi_tensor.AdamW` no longer exists in torch 2: `foreach=True` is the same implementation."""
+        lr = _get(self.cfg, "OPTIMIZER.LEARNING_RATE")
+        try:
+            eff = (_get(self.cfg, "DATAMODULE.BATCH_SIZE") * _get(self.cfg, "TRAINER.NUM_NODES") * _get(self.cfg, "TRAINER.GPUS") *
+                   _get(self.cfg, "TRAINER.ACCUMULATE_GRAD_BATCHES"))
+            if _get(self.cfg, "OPTIMIZER.AUTOSCALE_LR"):
+                lr = lr * eff / 256.0
+        except (KeyError, AttributeError):
+            pass
+        return torch.optim.AdamW([p for p in self.parameters() if p.requires_grad], lr=lr, foreach=True)

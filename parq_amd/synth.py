@@ -265,6 +265,28 @@ def make_scene(seed: int, B: int, V: int, h: int, w: int, C: int, smooth: bool =
                 T_world_pseudoCam=T_wp, T_world_local=T_wl)
 
 
+def make_boxes(seed: int, B: int, nbox: int, max_box: int = 100):
+    """Synthetic ground truth for the loss / training step: (B, max_box, 19) padded Obb3D rows
+    [xmin,xmax,ymin,ymax,zmin,zmax | R (9) t (3) | class], all -1 = padding (utils/wrappers.py:297-409), and the
+    symmetry classes (B, max_box) padded with -1 (datasets/scannet_dataset.py:151-165)."""
+    obbs = -np.ones((B, max_box, 19), np.float32)
+    sym = -np.ones((B, max_box), np.float32)
+    half = uniform(seed, "box_half", (B, nbox, 3), 0.15, 0.7)
+    ang = uniform(seed, "box_ang", (B, nbox), -np.pi, np.pi)
+    t = uniform(seed, "box_t", (B, nbox, 3), -1.0, 1.0) * np.array([2.5, 1.0, 2.0], np.float32) + np.array([0.0, -0.75, 2.75], np.float32)
+    cls = (uniform(seed, "box_cls", (B, nbox), 0.0, 8.999)).astype(np.int64)
+    sy = (uniform(seed, "box_sym", (B, nbox), 0.0, 3.999)).astype(np.int64)
+    for b in range(B):
+        for j in range(nbox):
+            c, s_ = np.cos(ang[b, j]), np.sin(ang[b, j])
+            obbs[b, j, 0:6] = [-half[b, j, 0], half[b, j, 0], -half[b, j, 1], half[b, j, 1], -half[b, j, 2], half[b, j, 2]]
+            obbs[b, j, 6:15] = [c, 0, s_, 0, 1, 0, -s_, 0, c]
+            obbs[b, j, 15:18] = t[b, j]
+            obbs[b, j, 18] = cls[b, j]
+            sym[b, j] = sy[b, j]
+    return obbs, sym
+
+
 # per-class mean box sizes of the 8 named ScanNet classes in class-id order
 # (chair, table, cabinet, trash bin, bookshelf, display, sofa, bathtub), then
 # "other" and "non-object" = [1,1,1].  These are the rows BoxProcessor builds
