@@ -68,7 +68,7 @@ struct Workspace {
     int64_t sa, ln3, lse_s, lse_c, refk;
     int64_t iter_begin, iter_end, stash;
     // backward scratch (training workspace only)
-    int64_t g_a, g_b, g_c, g_pos, g_tmp, g_ffh, g_h1, g_h2, g_z, g_act, g_h3, g_qkv, g_emb, g_ref, g_D, g_bs, wT, g_kv;
+    int64_t g_a, g_b, g_c, g_pos, g_tmp, g_ffh, g_h1, g_h2, g_z, g_act, g_h3, g_qkv, g_emb, g_ref, g_D, g_bs, wT, g_kv, g_dqp;
     int64_t train_total;
     int64_t shift(int k) const { return k == 0 ? 0 : stash + (int64_t)(k - 1) * (iter_end - iter_begin) - iter_begin; }
 };
@@ -172,6 +172,7 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     // cross_out^T, cross_q^T, self_out^T [C][C] each, self_in^T [C][3C], pe2^T [C][C], pe0^T [384][C]
     ws->wT = take(C * NH1 + 2 * C * C + 2 * C * F + 3 * C * C + 3 * C * C + C * C + 384 * C);
     ws->g_kv = take(split_mode ? 0 : (int64_t)c->nl * B * 2 * N * C);
+    ws->g_dqp = take((int64_t)attn_bwd_dq_partial_floats(B, c->H, (int)Q, (int)N, c->dh));
     ws->train_total = off;
     return PARQ_OK;
 }
@@ -523,7 +524,8 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
         float* gkv = wsp + ws.g_kv + (int64_t)li * B * 2 * N * C;
         HIPCHK(launch_attn_bwd(wi + ws.qc, (int64_t)Q * C, dh, C, kv, 2 * N * C, N * dh, dh, kv + (int64_t)H * N * dh, 2 * N * C, N * dh, dh,
                                gA, (int64_t)Q * C, dh, C, wi + ws.lse_c, Dd, gC, (int64_t)Q * C, dh, C, gkv, 2 * N * C, N * dh, dh,
-                               gkv + (int64_t)H * N * dh, 2 * N * C, N * dh, dh, B, H, Q, (int)N, dh, 1, s));
+                               gkv + (int64_t)H * N * dh, 2 * N * C, N * dh, dh, B, H, Q, (int)N, dh, 1, s,
+                               attn_bwd_dq_partial_floats(B, H, Q, (int)N, dh) ? wsp + ws.g_dqp : nullptr));
     }
     // q = (x1 + pos) Wq^T + bq,  x1 = norm1(xa)
     HIPCHK(launch_layernorm(wi + ws.xa, A + L.n1_w, A + L.n1_b, tmp, M, C, eps, s));

@@ -24,6 +24,8 @@ struct AttnBwdArgs {
     const float* lse;          // [B*H][Lq_pad], log2 domain
     const float* D;            // [B*H][Lq_pad]
     float* gq; int64_t gq_batch, gq_head, gq_row;     // += (atomic)
+    float* gq_part;            // optional [B*H][key blocks of 256][Lq_pad][64]: per-workgroup dQ partials (MFMA kernel), summed
+                               // by attn_bwd_dq_reduce_kernel instead of ~50 M global float atomics per scene and iteration
     float* gk; int64_t gk_batch, gk_head, gk_row;     // = or += (accumulate)
     float* gv; int64_t gv_batch, gv_head, gv_row;
     int B, H, Lq, Lk, accumulate_kv;
@@ -136,20 +138,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
 //                                      the A operand, K comes from a per-wave LDS copy; the 8 waves add their partial
 //                                      tiles into one LDS tile (ds_add_f32), which is added to global dQ with atomics.
 constexpr int kQs = 68;      // row stride (floats) of the Q / dO tiles
-constexpr int kKc = 65;      // row stride of the per-wave K copy
-constexpr int kDs = 33;      // row stride of the per-wave dS tile
+constexpr int kKc = 80;      // row stride of the per-wave K copy (16 q-lanes x 4 key rows of the 16x16x4 B operand: conflict-free)
+constexpr int kDs = 260;     // row stride of the workgroup's dS tile [32 queries][256 keys]
 
 __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qs = smem;                       // [32][kQs]
     float* Os = Qs + 32 * kQs;              // [32][kQs]  dO tile
     float* st = Os + 32 * kQs;              // [2][32] lse, D
-    float* dQs = st + 64;                   // [32][64]
-    float* wave_base = dQs + 32 * 64;
+    float* Ds = st + 64;                    // [32][kDs]: dS of the current query tile against all 256 keys of the workgroup
+    float* Kall = Ds + 32 * kDs;            // [256][kKc]: K of the workgroup's keys, wave w owns rows 32 w ..
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
-    float* Kc = wave_base + wave * (32 * kKc + 32 * kDs);    // [32][kKc]
-    float* Ds = Kc + 32 * kKc;                                // [32][kDs]
+    float* Kc = Kall + wave * 32 * kKc;     // this wave's [32][kKc]
     const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
     const int j0 = blockIdx.x * 256 + wave * 32;
     const int j = j0 + li;
@@ -197,7 +198,6 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(AttnBwdArgs a) {
             st[tid] = i0 + tid < a.Lq ? a.lse[(int64_t)bh * Lq_pad + i0 + tid] : 0.f;
             st[32 + tid] = i0 + tid < a.Lq ? a.D[(int64_t)bh * Lq_pad + i0 + tid] : 0.f;
         }
-        for (int idx = tid; idx < 32 * 64; idx += 512) dQs[idx] = 0.f;
         __syncthreads();
 
         // ---- S = Q K^T, dP = dO V^T   (rows = queries, columns = this wave's keys)
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(AttnBwdArgs a) {
             const float ds = p * (pacc[r] - st[32 + qi]);
             sacc[r] = p;
             pacc[r] = ds;
-            Ds[qi * kDs + li] = ds;
+            Ds[qi * kDs + wave * 32 + li] = ds;
         }
         // ---- dV^T += dO^T P, dK^T += Q^T dS: MFMA step r contracts over the query pair (row(r,0), row(r,1))
 #pragma unroll
@@ -238,35 +238,36 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(AttnBwdArgs a) {
                 gk[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[qi * kQs + dt * 32 + li], pacc[r], gk[dt], 0, 0, 0);
             }
         }
-        // ---- dQ tile += dS K over this wave's 32 keys (same-wave LDS round trip for dS)
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        f32x16 gq[2];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) gq[dt][r] = 0.f;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int jj = kh + 2 * t;
-            const float av = Ds[li * kDs + jj];
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-                gq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Kc[jj * kKc + dt * 32 + li], gq[dt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) atomicAdd(&dQs[mfma32_row(r, lane) * 64 + dt * 32 + li], gq[dt][r] * cn);
+        // ---- dQ tile = dS K over ALL 256 keys of the workgroup: v_mfma_f32_16x16x4_f32, wave w owns the 16 x 16 block
+        // (queries 16 (w >> 2) .., d 16 (w & 3) ..) of the 32 x 64 tile, so no cross-wave reduction is needed
         __syncthreads();
-        for (int idx = tid; idx < 32 * 64; idx += 512) {
-            const int i = idx >> 6, d = idx & 63;
-            if (i0 + i < a.Lq)
-                atomicAdd(a.gq + (int64_t)b * a.gq_batch + (int64_t)h * a.gq_head + (int64_t)(i0 + i) * a.gq_row + d, dQs[idx]);
+        {
+            typedef float f32x4v __attribute__((ext_vector_type(4)));
+            const int l15 = lane & 15, kq = lane >> 4;
+            const int qb = (wave >> 2) * 16, db = (wave & 3) * 16;
+            f32x4v g4 = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 16
+            for (int t = 0; t < 64; ++t) {
+                const int jj = 4 * t + kq;                       // key 0..255 inside the workgroup
+                g4 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ds[(qb + l15) * kDs + jj], Kall[jj * kKc + db + l15], g4, 0, 0, 0);
+            }
+            // accumulator: rows qb + 4 kq + r, column db + l15
+            if (a.gq_part) {
+                float* part = a.gq_part + (((int64_t)bh * gridDim.x + blockIdx.x) * Lq_pad + i0) * 64;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[(qb + 4 * kq + r) * 64 + db + l15] = g4[r] * cn;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + qb + 4 * kq + r;
+                    if (i < a.Lq)
+                        atomicAdd(a.gq + (int64_t)b * a.gq_batch + (int64_t)h * a.gq_head + (int64_t)i * a.gq_row + db + l15, g4[r] * cn);
+                }
+            }
         }
     }
     // ---- dK, dV of this wave's keys: transpose (d x keys) -> [key][d] through the wave's LDS copy, then row-contiguous update
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();                                     // every wave is done reading the other waves' K copies
     for (int which = 0; which < 2; ++which) {
         const float scale = which == 0 ? cn : 1.f;
 #pragma unroll
@@ -288,6 +289,26 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(AttnBwdArgs a) {
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// gq[b][i][h*64 + d] += sum_kb part[bh][kb][i][d]
+__global__ __launch_bounds__(256) void attn_bwd_dq_reduce_kernel(const float* __restrict__ part, int nkb, int Lq, int Lq_pad, int H,
+                                                                 float* __restrict__ gq, int64_t gq_batch, int64_t gq_head, int64_t gq_row) {
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // (i, d)
+    const int i = idx >> 6, d = idx & 63;
+    if (i >= Lq) return;
+    const float* p = part + ((int64_t)bh * nkb * Lq_pad + i) * 64 + d;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int kb = 0;
+    for (; kb + 4 <= nkb; kb += 4) {
+        s0 += p[(int64_t)kb * Lq_pad * 64];
+        s1 += p[(int64_t)(kb + 1) * Lq_pad * 64];
+        s2 += p[(int64_t)(kb + 2) * Lq_pad * 64];
+        s3 += p[(int64_t)(kb + 3) * Lq_pad * 64];
+    }
+    for (; kb < nkb; ++kb) s0 += p[(int64_t)kb * Lq_pad * 64];
+    gq[(int64_t)b * gq_batch + (int64_t)h * gq_head + (int64_t)i * gq_row + d] += (s0 + s1) + (s2 + s3);
 }
 
 // D[bh][i] = sum_d dO[i][h*dh + d] * O[i][h*dh + d]; one wave per (bh, i)
@@ -317,7 +338,7 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
                            const float* dO, int64_t do_batch, int64_t do_head, int64_t do_row, const float* lse, const float* D,
                            float* gq, int64_t gq_batch, int64_t gq_head, int64_t gq_row, float* gk, int64_t gk_batch,
                            int64_t gk_head, int64_t gk_row, float* gv, int64_t gv_batch, int64_t gv_head, int64_t gv_row, int B, int H,
-                           int Lq, int Lk, int dh, int accumulate_kv, hipStream_t s) {
+                           int Lq, int Lk, int dh, int accumulate_kv, hipStream_t s, float* gq_part) {
     if (dh != 64 && dh != 32) return hipErrorInvalidValue;
     AttnBwdArgs a;
     a.q = q; a.q_batch = q_batch; a.q_head = q_head; a.q_row = q_row;
@@ -328,14 +349,14 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
     a.gq = gq; a.gq_batch = gq_batch; a.gq_head = gq_head; a.gq_row = gq_row;
     a.gk = gk; a.gk_batch = gk_batch; a.gk_head = gk_head; a.gk_row = gk_row;
     a.gv = gv; a.gv_batch = gv_batch; a.gv_head = gv_head; a.gv_row = gv_row;
-    a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.accumulate_kv = accumulate_kv;
+    a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.accumulate_kv = accumulate_kv; a.gq_part = nullptr;
     dim3 grid(ceil_div(Lk, 256), B * H);
     static const int force = [] {
         const char* e = getenv("PARQ_ATTN_BWD");            // "naive" / "mfma": debugging override
         return e ? (e[0] == 'n' ? 1 : 2) : 0;
     }();
     if (dh == 64 && force != 1 && (Lk >= 2048 || force == 2)) {
-        const size_t lds = (size_t)(2 * 32 * kQs + 64 + 32 * 64 + 8 * (32 * kKc + 32 * kDs)) * sizeof(float);
+        const size_t lds = (size_t)(2 * 32 * kQs + 64 + 32 * kDs + 256 * kKc) * sizeof(float);
         static bool attr = false;
         if (!attr) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_kernel),
@@ -343,7 +364,13 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
             if (e != hipSuccess) return e;
             attr = true;
         }
+        a.gq_part = gq_part;
         hipLaunchKernelGGL(attn_bwd_mfma_kernel, grid, dim3(512), lds, s, a);
+        if (gq_part) {
+            const int Lq_pad = (Lq + 31) & ~31;
+            hipLaunchKernelGGL(attn_bwd_dq_reduce_kernel, dim3(ceil_div(Lq * 64, 256), B * H), dim3(256), 0, s, gq_part, (int)grid.x, Lq,
+                               Lq_pad, H, gq, gq_batch, gq_head, gq_row);
+        }
         return hipGetLastError();
     }
     if (dh == 64) {
@@ -368,6 +395,12 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
         hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, dim3(256), lds, s, a);
     }
     return hipGetLastError();
+}
+
+// scratch floats for the dQ partials of launch_attn_bwd (0 when the atomics path is taken)
+size_t attn_bwd_dq_partial_floats(int B, int H, int Lq, int Lk, int dh) {
+    if (dh != 64 || Lk < 2048) return 0;
+    return (size_t)B * H * ceil_div(Lk, 256) * ((Lq + 31) & ~31) * 64;
 }
 
 hipError_t launch_attn_bwd_rowdot(const float* dO, const float* O, int64_t batch, int64_t row, int B, int H, int Lq, int dh, float* D,

@@ -187,7 +187,8 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
                            const float* dO, int64_t do_batch, int64_t do_head, int64_t do_row, const float* lse, const float* D,
                            float* gq, int64_t gq_batch, int64_t gq_head, int64_t gq_row, float* gk, int64_t gk_batch,
                            int64_t gk_head, int64_t gk_row, float* gv, int64_t gv_batch, int64_t gv_head, int64_t gv_row, int B, int H,
-                           int Lq, int Lk, int dh, int accumulate_kv, hipStream_t s);
+                           int Lq, int Lk, int dh, int accumulate_kv, hipStream_t s, float* gq_part = nullptr);
+size_t attn_bwd_dq_partial_floats(int B, int H, int Lq, int Lk, int dh);
 hipError_t launch_attn_bwd_rowdot(const float* dO, const float* O, int64_t batch, int64_t row, int B, int H, int Lq, int dh, float* D,
                                   hipStream_t s);
 hipError_t launch_gemm_split(const float* X, int64_t ldx, const void* Whi, const void* Wlo, const float* bias, float* Y,

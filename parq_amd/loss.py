@@ -74,17 +74,18 @@ class HungarianMatcherModified:
             cost = self.cost_bbox * l1 - self.cost_class * prob[b][:, ids]
             rows, cols = linear_sum_assignment(cost.cpu())
             extra_p, extra_g = [], []
-            mask = None
+            near_all = (l1 < self.ratio).cpu().numpy()            # one host copy per scene instead of one per box
+            mask_np = None
             for j in range(len(ids)):                           # reference points close to box j (:83-99)
-                near = l1[:, j] < self.ratio
-                pidx = torch.nonzero(near).squeeze(1).cpu().numpy()
-                mask = torch.ones_like(near).bool()
-                mask[pidx] = False
+                pidx = np.nonzero(near_all[:, j])[0]
+                mask_np = np.ones(near_all.shape[0], dtype=bool)
+                mask_np[pidx] = False
                 if pidx.shape[0] > self.max_padding:
                     pidx = pidx[np.random.choice(pidx.shape[0], self.max_padding, replace=False)]
-                mask[pidx] = True
+                mask_np[pidx] = True
                 extra_p.append(pidx)
                 extra_g.append(np.ones_like(pidx) * j)
+            mask = torch.from_numpy(mask_np).to(l1.device)
             p = np.concatenate([rows, np.concatenate(extra_p)])
             g = np.concatenate([cols, np.concatenate(extra_g)])
             _, first = np.unique(p, return_index=True)           # one ground truth per prediction (:107-110)
@@ -113,19 +114,33 @@ def parse_target(obbs_padded: Obb3D, T_world_local):
     return out
 
 
+_ROTY_CACHE = {}
+
+
+def _roty_table(m, device):
+    """The m y-rotations of a symmetry class, (m, 3, 3) float32, built once per device."""
+    key = (m, str(device))
+    if key not in _ROTY_CACHE:
+        _ROTY_CACHE[key] = torch.stack([roty((k * 2.0 / m) * math.pi) for k in range(m)]).to(device)
+    return _ROTY_CACHE[key]
+
+
 def rotation_loss_with_sym(rot_pred, rot_tgt, sym):
     """Mean over objects of the squared-error rotation loss, minimised over the y-rotations the object's symmetry class
-    allows: 1 -> 2-fold, 2 -> 4-fold, 3 -> 36 samples of a full revolution (model/parq_decoder.py:205-262)."""
+    allows: 1 -> 2-fold, 2 -> 4-fold, 3 -> 36 samples of a full revolution (model/parq_decoder.py:205-262).  The reference
+    loops over objects and candidates in Python (tens of thousands of tiny launches per step); here the objects of one
+    class are evaluated together — same arithmetic per candidate."""
     folds = {1: 2, 2: 4, 3: 36}
-    per_obj = []
-    for o in range(sym.shape[0]):
-        m = folds.get(int(sym[o]), 0)
-        if m:
-            cand = [((rot_pred[o] - rot_tgt[o] @ roty((k * 2.0 / m) * math.pi, rot_pred.device)) ** 2).mean() for k in range(m)]
-            per_obj.append(torch.min(torch.stack(cand)))
-        else:
-            per_obj.append(((rot_pred[o] - rot_tgt[o]) ** 2).mean())
-    return torch.mean(torch.stack(per_obj))
+    sym = sym.to(torch.int64) if sym.dtype.is_floating_point else sym
+    per_obj = ((rot_pred - rot_tgt) ** 2).mean(dim=(1, 2))                     # classes without symmetry
+    for cls, m in folds.items():
+        sel = torch.nonzero(sym == cls).squeeze(1)
+        if sel.numel() == 0:
+            continue
+        cand = rot_tgt[sel].unsqueeze(1) @ _roty_table(m, rot_pred.device).to(rot_pred.dtype)      # (n, m, 3, 3)
+        err = ((rot_pred[sel].unsqueeze(1) - cand) ** 2).mean(dim=(2, 3))                           # (n, m)
+        per_obj = per_obj.index_put((sel,), err.min(dim=1).values)
+    return per_obj.mean()
 
 
 def decoder_loss(out_dict_list, obbs_padded, T_world_local, sym=None, *, matcher, loss_weight, num_semcls, class_weight):
