@@ -521,10 +521,11 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     HIPCHK(hipMemsetAsync(gC, 0, (size_t)M * C * sizeof(float), s));                           // gC = d / d q (atomics)
     {
         const float* kv = wsp + ws.kv + (int64_t)li * B * 2 * N * C;
+        // dK | dV accumulate token-major: g_kv[layer][b][n][2C], K heads at columns h*dh, V heads at C + h*dh
         float* gkv = wsp + ws.g_kv + (int64_t)li * B * 2 * N * C;
         HIPCHK(launch_attn_bwd(wi + ws.qc, (int64_t)Q * C, dh, C, kv, 2 * N * C, N * dh, dh, kv + (int64_t)H * N * dh, 2 * N * C, N * dh, dh,
-                               gA, (int64_t)Q * C, dh, C, wi + ws.lse_c, Dd, gC, (int64_t)Q * C, dh, C, gkv, 2 * N * C, N * dh, dh,
-                               gkv + (int64_t)H * N * dh, 2 * N * C, N * dh, dh, B, H, Q, (int)N, dh, 1, s,
+                               gA, (int64_t)Q * C, dh, C, wi + ws.lse_c, Dd, gC, (int64_t)Q * C, dh, C, gkv, 2 * N * C, dh, 2 * C,
+                               gkv + C, 2 * N * C, dh, 2 * C, B, H, Q, (int)N, dh, 1, s,
                                attn_bwd_dq_partial_floats(B, H, Q, (int)N, dh) ? wsp + ws.g_dqp : nullptr));
     }
     // q = (x1 + pos) Wq^T + bq,  x1 = norm1(xa)
@@ -589,31 +590,25 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     return PARQ_OK;
 }
 
-// hoisted K/V projection backward: [K | V] = tokens W_kv^T + b_kv per layer; g_kv is head-major [b][{K,V}][h][n][dh]
+// hoisted K/V projection backward: [K | V] = tokens W_kv^T + b_kv per layer; g_kv is token-major [layer][b][n][2C], so the
+// whole projection is one TN GEMM (dW_kv = g^T tokens), one column sum (db_kv) and one GEMM (d tokens += g W_kv)
 int do_backward_kvproj(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& ws, float* G, float* g_tokens, hipStream_t s) {
     const float* A = c->arena;
-    const int B = sc->B, C = c->C, H = c->H, dh = c->dh;
+    const int B = sc->B, C = c->C;
     const int64_t N = (int64_t)sc->V * sc->h * sc->w;
-    float* wT = wsp + ws.wT;            // W_kv^T per head block, reused: [C][dh]
+    if ((int64_t)B * N > (int64_t)INT32_MAX) return fail(PARQ_ERR_ARG, "B*N too large");
+    float* wT = wsp + ws.wT;            // W_kv^T [C][2C]
     for (int li = 0; li < c->nl; ++li) {
         const LayerW& L = c->ar.layers[li];
-        for (int b = 0; b < B; ++b) {
-            for (int part = 0; part < 2; ++part)                         // K heads, then V heads
-                for (int hh = 0; hh < H; ++hh) {
-                    const float* g = wsp + ws.g_kv + (((int64_t)li * B + b) * 2 + part) * N * C + (int64_t)hh * N * dh;   // [N][dh]
-                    const int64_t wrow = (int64_t)C + (int64_t)part * C + (int64_t)hh * dh;      // rows of in_proj_weight
-                    const float* tok = sc->tokens + (int64_t)b * N * C;
-                    // dW[wrow .. +dh][C] += g^T tokens ; db += colsum(g)
-                    HIPCHK(launch_gemm_tn(g, dh, tok, C, G + L.cross_in_w + wrow * C, C, (int)N, dh, C, 1, s));
-                    HIPCHK(launch_colsum(g, dh, (int)N, dh, G + L.cross_in_b + wrow, 1, s));
-                    if (g_tokens) {
-                        // g_tokens[b] += g W[wrow .. +dh][:]   (W^T block [C][dh])
-                        HIPCHK(launch_transpose(A + L.cross_in_w + wrow * C, C, wT, dh, dh, C, s));
-                        LinearArgs a = lin(g, dh, wT, dh, nullptr, g_tokens + (int64_t)b * N * C, C, (int)N, C, dh);
-                        a.R = g_tokens + (int64_t)b * N * C; a.ldr = C;
-                        HIPCHK(launch_linear(a, 1, s));
-                    }
-                }
+        const float* g = wsp + ws.g_kv + (int64_t)li * B * 2 * N * C;          // [B*N][2C]
+        const int Mr = (int)(B * N);
+        HIPCHK(launch_gemm_tn(g, 2 * C, sc->tokens, C, G + L.cross_in_w + (int64_t)C * C, C, Mr, 2 * C, C, 1, s));
+        HIPCHK(launch_colsum(g, 2 * C, Mr, 2 * C, G + L.cross_in_b + C, 1, s));
+        if (g_tokens) {
+            HIPCHK(launch_transpose(A + L.cross_in_w + (int64_t)C * C, C, wT, 2 * C, 2 * C, C, s));
+            LinearArgs a = lin(g, 2 * C, wT, 2 * C, nullptr, g_tokens, C, Mr, C, 2 * C);
+            a.R = g_tokens; a.ldr = C;
+            HIPCHK(launch_linear(a, 1, s));
         }
     }
     return PARQ_OK;

@@ -139,20 +139,23 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
 //                                      tiles into one LDS tile (ds_add_f32), which is added to global dQ with atomics.
 constexpr int kQs = 68;      // row stride (floats) of the Q / dO tiles
 constexpr int kKc = 80;      // row stride of the per-wave K copy (16 q-lanes x 4 key rows of the 16x16x4 B operand: conflict-free)
-constexpr int kDs = 260;     // row stride of the workgroup's dS tile [32 queries][256 keys]
 
-__global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(AttnBwdArgs a) {
+template <int NWV>        // waves per workgroup = 32-key blocks per workgroup: 8 for the long cross-attention, 2 for the 256-key self-attention
+__global__ __launch_bounds__(NWV * 64) void attn_bwd_mfma_kernel(AttnBwdArgs a) {
+    constexpr int NT = NWV * 64;
+    constexpr int KW = NWV * 32;            // keys per workgroup
+    constexpr int kDs = KW + 4;             // row stride of the workgroup's dS tile [32 queries][KW keys]
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qs = smem;                       // [32][kQs]
     float* Os = Qs + 32 * kQs;              // [32][kQs]  dO tile
     float* st = Os + 32 * kQs;              // [2][32] lse, D
     float* Ds = st + 64;                    // [32][kDs]: dS of the current query tile against all 256 keys of the workgroup
-    float* Kall = Ds + 32 * kDs;            // [256][kKc]: K of the workgroup's keys, wave w owns rows 32 w ..
+    float* Kall = Ds + 32 * kDs;            // [KW][kKc]: K of the workgroup's keys, wave w owns rows 32 w ..
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
     float* Kc = Kall + wave * 32 * kKc;     // this wave's [32][kKc]
     const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-    const int j0 = blockIdx.x * 256 + wave * 32;
+    const int j0 = blockIdx.x * KW + wave * 32;
     const int j = j0 + li;
     const bool jok = j < a.Lk;
     const int Lq_pad = (a.Lq + 31) & ~31;
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(AttnBwdArgs a) {
 
     for (int i0 = 0; i0 < a.Lq; i0 += 32) {
         __syncthreads();                                    // previous tile fully consumed
-        for (int idx = tid; idx < 32 * 16; idx += 512) {    // Q and dO tiles: 32 rows x 16 float4
+        for (int idx = tid; idx < 32 * 16; idx += NT) {    // Q and dO tiles: 32 rows x 16 float4
             const int i = idx >> 4, c4 = idx & 15;
             const bool ok = i0 + i < a.Lq;
             float4 q4 = float4{0.f, 0.f, 0.f, 0.f}, o4 = q4;
@@ -244,24 +247,26 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(AttnBwdArgs a) {
         {
             typedef float f32x4v __attribute__((ext_vector_type(4)));
             const int l15 = lane & 15, kq = lane >> 4;
-            const int qb = (wave >> 2) * 16, db = (wave & 3) * 16;
-            f32x4v g4 = f32x4v{0.f, 0.f, 0.f, 0.f};
+            for (int blk = wave; blk < 8; blk += NWV) {          // 8 blocks of 16 x 16 cover the 32 x 64 tile
+                const int qb = (blk >> 2) * 16, db = (blk & 3) * 16;
+                f32x4v g4 = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 16
-            for (int t = 0; t < 64; ++t) {
-                const int jj = 4 * t + kq;                       // key 0..255 inside the workgroup
-                g4 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ds[(qb + l15) * kDs + jj], Kall[jj * kKc + db + l15], g4, 0, 0, 0);
-            }
-            // accumulator: rows qb + 4 kq + r, column db + l15
-            if (a.gq_part) {
-                float* part = a.gq_part + (((int64_t)bh * gridDim.x + blockIdx.x) * Lq_pad + i0) * 64;
+                for (int t = 0; t < KW / 4; ++t) {
+                    const int jj = 4 * t + kq;                   // key inside the workgroup
+                    g4 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ds[(qb + l15) * kDs + jj], Kall[jj * kKc + db + l15], g4, 0, 0, 0);
+                }
+                // accumulator: rows qb + 4 kq + r, column db + l15
+                if (a.gq_part) {
+                    float* part = a.gq_part + (((int64_t)bh * gridDim.x + blockIdx.x) * Lq_pad + i0) * 64;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) part[(qb + 4 * kq + r) * 64 + db + l15] = g4[r] * cn;
-            } else {
+                    for (int r = 0; r < 4; ++r) part[(qb + 4 * kq + r) * 64 + db + l15] = g4[r] * cn;
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = i0 + qb + 4 * kq + r;
-                    if (i < a.Lq)
-                        atomicAdd(a.gq + (int64_t)b * a.gq_batch + (int64_t)h * a.gq_head + (int64_t)i * a.gq_row + db + l15, g4[r] * cn);
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = i0 + qb + 4 * kq + r;
+                        if (i < a.Lq)
+                            atomicAdd(a.gq + (int64_t)b * a.gq_batch + (int64_t)h * a.gq_head + (int64_t)i * a.gq_row + db + l15, g4[r] * cn);
+                    }
                 }
             }
         }
@@ -355,20 +360,27 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
         const char* e = getenv("PARQ_ATTN_BWD");            // "naive" / "mfma": debugging override
         return e ? (e[0] == 'n' ? 1 : 2) : 0;
     }();
-    if (dh == 64 && force != 1 && (Lk >= 2048 || force == 2)) {
-        const size_t lds = (size_t)(2 * 32 * kQs + 64 + 32 * kDs + 256 * kKc) * sizeof(float);
-        static bool attr = false;
+    if (dh == 64 && force != 1) {
+        const bool big = Lk >= 2048;
+        const int nwv = big ? 8 : 2;
+        const int KW = nwv * 32;
+        const size_t lds = (size_t)(2 * 32 * kQs + 64 + 32 * (KW + 4) + KW * kKc) * sizeof(float);
+        static bool attr8 = false, attr2 = false;
+        bool& attr = big ? attr8 : attr2;
         if (!attr) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_kernel),
+            hipError_t e = hipFuncSetAttribute(big ? reinterpret_cast<const void*>(&attn_bwd_mfma_kernel<8>)
+                                                   : reinterpret_cast<const void*>(&attn_bwd_mfma_kernel<2>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             attr = true;
         }
-        a.gq_part = gq_part;
-        hipLaunchKernelGGL(attn_bwd_mfma_kernel, grid, dim3(512), lds, s, a);
-        if (gq_part) {
+        dim3 g2(ceil_div(Lk, KW), B * H);
+        a.gq_part = big ? gq_part : nullptr;
+        if (big) hipLaunchKernelGGL(attn_bwd_mfma_kernel<8>, g2, dim3(512), lds, s, a);
+        else hipLaunchKernelGGL(attn_bwd_mfma_kernel<2>, g2, dim3(128), lds, s, a);
+        if (a.gq_part) {
             const int Lq_pad = (Lq + 31) & ~31;
-            hipLaunchKernelGGL(attn_bwd_dq_reduce_kernel, dim3(ceil_div(Lq * 64, 256), B * H), dim3(256), 0, s, gq_part, (int)grid.x, Lq,
+            hipLaunchKernelGGL(attn_bwd_dq_reduce_kernel, dim3(ceil_div(Lq * 64, 256), B * H), dim3(256), 0, s, gq_part, (int)g2.x, Lq,
                                Lq_pad, H, gq, gq_batch, gq_head, gq_row);
         }
         return hipGetLastError();
