@@ -7,8 +7,10 @@ drivers (eval.py:26-47) can swap the import.  All arithmetic of the forward pass
 libparq_hip.so (include/parq_hip.h); this file only owns parameters, buffers and the
 packing of arguments.  There is no PyTorch/CPU fallback for the compute.
 
-Scope of this round: inference forward.  ``loss`` / metrics / autograd are
-the "next" rows of §8(f) and raise NotImplementedError.
+Scope: the inference forward (rows a-e) and, as first versions of the "next" rows, training: in
+``train()`` mode under autograd the forward is one autograd node whose backward is the HIP backward chain
+(``parq_backward``; DROPOUT_RATE must be 0), and ``loss`` mirrors the reference's set loss.  Eval metrics
+(``update_metrics`` etc., §8f-4) raise NotImplementedError.
 """
 from __future__ import annotations
 
