@@ -403,11 +403,11 @@ class PARQDecoder(nn.Module):
         d_tokens = torch.empty(sc.B, N, self.dim_in, dtype=torch.float32, device=dev) if want_token_grad else None
         _lib.check(lib.parq_backward(h, C.byref(sc), _lib.ptr(self._train_ws), self._train_ws.numel() * 4, C.byref(po), C.byref(pg),
                                      _lib.ptr(arena), _lib.ptr(d_tokens), _lib.stream_ptr()), "parq_backward")
-        if self.dp_all_reduce and torch.distributed.is_available() and torch.distributed.is_initialized():
+        if self.dp_all_reduce:
             # data-parallel training: the gradient arena is one flat buffer -> a single RCCL all-reduce (mean), instead
             # of one bucket per tensor (train.py:103 DDP semantics: mean over ranks)
-            torch.distributed.all_reduce(arena)
-            arena /= torch.distributed.get_world_size()
+            from .parallel import all_reduce_mean_
+            all_reduce_mean_(arena)
         grads = {}
         off, rows, cols, ld = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         for name, p in self._unique_params():

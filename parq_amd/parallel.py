@@ -71,3 +71,13 @@ def all_gather_scenes(x: torch.Tensor, num_scenes: int) -> torch.Tensor:
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad)
     return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(out, sizes)], dim=0)
+
+
+def all_reduce_mean_(flat: torch.Tensor) -> torch.Tensor:
+    """Data-parallel gradient averaging of ONE flat buffer (the gradient arena of parq_backward has the layout of the packed
+    weight arena, so a training step needs a single collective instead of one bucket per tensor): in place, mean over the
+    ranks of the default process group (RCCL over xGMI on GPUs, gloo in the CPU tests); identity without a group."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        torch.distributed.all_reduce(flat)
+        flat /= torch.distributed.get_world_size()
+    return flat

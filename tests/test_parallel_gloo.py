@@ -83,3 +83,54 @@ def test_two_rank_scene_sharding_matches_single_process():
         assert np.abs(ctr - want_ctr.numpy()).max() < 1e-5, rank         # scenes are independent: exact up to fp32 batching
         assert np.abs(logits - want_logits.numpy()).max() < 1e-5, rank
         assert slowest == 2.0
+
+
+# ---------------------------------------------------------------- data-parallel gradient step (flat-arena all-reduce)
+def _grad_flat(cfg, W, sc, lo, hi):
+    """Gradient of the mean-over-scenes surrogate loss on scenes [lo, hi), flattened in sorted-key order (the oracle's
+    autograd stands in for parq_backward, which needs a GPU)."""
+    od = O.OracleDecoder(cfg, W, synth.SCANNET_MEAN_SIZES, dtype=torch.float64)
+    for k in od.W:
+        od.W[k].requires_grad_(True)
+    od.prepare(*(sc[k][lo:hi] for k in ("tokens", "camera", "T_camera_pseudoCam", "T_world_pseudoCam", "T_world_local")))
+    ref = od.initial_ref()
+    loss = 0.0
+    for k in range(cfg.TRANSFORMER.DEC_LAYERS):
+        out, nxt, _ = od.iterate(ref, k)
+        loss = loss + (out["center_unnormalized"] ** 2).mean() + (out["pred_logits"] ** 2).mean()
+        ref = nxt.detach()
+    loss.backward()
+    keys = sorted(k for k, v in od.W.items() if v.grad is not None)
+    return torch.cat([od.W[k].grad.reshape(-1) for k in keys])
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    parallel.init(backend="gloo")
+    cfg, W, sc = _case()
+    lo, hi = parallel.shard_range(2, rank, world)                # 2 scenes, one per rank
+    flat = _grad_flat(cfg, W, sc, lo, hi)
+    parallel.all_reduce_mean_(flat)
+    q.put((rank, flat.numpy()))
+    parallel.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_flat_gradient_all_reduce_equals_single_process_mean():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    cfg, W, sc = _case()
+    want = 0.5 * (_grad_flat(cfg, W, sc, 0, 1) + _grad_flat(cfg, W, sc, 1, 2)).numpy()
+    assert np.array_equal(res[0], res[1])                          # every rank holds the same averaged gradient
+    assert np.abs(res[0] - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
