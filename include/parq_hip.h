@@ -183,6 +183,16 @@ int parq_ray_pe(const float *camera, const float *T_camera_pseudoCam, const floa
                 int32_t V, int32_t hh, int32_t ww, int32_t C, const float *features_nchw, float *tokens_out,
                 int32_t nchw_out, void *workspace, size_t workspace_bytes, parq_stream stream);
 
+/* Backward of the encoding + tokenisation (training): given d loss / d tokens (B, V*h*w, C) it returns the gradients of
+ * encoder.{0,2}.{weight,bias} and, optionally, d loss / d features (B, V, C, h, w).  `fwd_workspace` is the workspace the
+ * forward call left behind (it holds the hidden layer); the geometry has no learnable part. */
+size_t parq_ray_pe_backward_workspace_bytes(int32_t B, int32_t V, int32_t hh, int32_t ww, int32_t C, int32_t num_samples);
+int parq_ray_pe_backward(const float *camera, const float *T_camera_pseudoCam, const float *T_world_pseudoCam,
+                         const float *T_world_local, const float *w2, const float *scale6_host, float min_depth,
+                         float max_depth, int32_t num_samples, int32_t B, int32_t V, int32_t hh, int32_t ww, int32_t C,
+                         const float *d_tokens, const void *fwd_workspace, void *bwd_workspace, size_t bwd_workspace_bytes,
+                         float *dw1, float *db1, float *dw2, float *db2, float *d_features_nchw, parq_stream stream);
+
 /* ---- single kernels (parity tests, roofline measurements) --------------------------- */
 
 /* K4+K5: project (B,Q,3) normalised reference points into every view and bilinearly

@@ -1175,6 +1175,55 @@ int parq_ray_pe(const float* camera, const float* T_cp, const float* T_wp, const
     return PARQ_OK;
 }
 
+size_t parq_ray_pe_backward_workspace_bytes(int32_t B, int32_t V, int32_t hh, int32_t ww, int32_t C, int32_t num_samples) {
+    if (B < 1 || V < 1 || hh < 1 || ww < 1 || C < 1 || num_samples < 1) return 0;
+    const int64_t M = (int64_t)B * V * hh * ww, K1 = 3 * (int64_t)num_samples;
+    // points [M][K1] | d hidden [M][C] | W2^T [C][C]
+    return (size_t)(raype_align(M * K1) + raype_align(M * C) + raype_align((int64_t)C * C)) * sizeof(float);
+}
+
+int parq_ray_pe_backward(const float* camera, const float* T_cp, const float* T_wp, const float* T_wl, const float* w2,
+                         const float* scale6_host, float min_depth, float max_depth, int32_t num_samples, int32_t B, int32_t V,
+                         int32_t hh, int32_t ww, int32_t C, const float* d_tokens, const void* fwd_workspace, void* bwd_workspace,
+                         size_t bwd_workspace_bytes, float* dw1, float* db1, float* dw2, float* db2, float* d_features_nchw,
+                         parq_stream stream) {
+    if (!camera || !T_cp || !T_wp || !T_wl || !w2 || !scale6_host || !d_tokens || !fwd_workspace || !bwd_workspace || !dw1 || !db1 ||
+        !dw2 || !db2)
+        return fail(PARQ_ERR_ARG, "NULL argument");
+    if (B < 1 || V < 1 || hh < 1 || ww < 1 || num_samples < 1 || (3 * num_samples) % 64 != 0 || C % 64 != 0) return fail(PARQ_ERR_ARG, "bad dims");
+    if (bwd_workspace_bytes < parq_ray_pe_backward_workspace_bytes(B, V, hh, ww, C, num_samples)) return fail(PARQ_ERR_WORKSPACE, "ray-PE backward workspace too small");
+    const int64_t M64 = (int64_t)B * V * hh * ww;
+    if (M64 > INT32_MAX) return fail(PARQ_ERR_ARG, "too many tokens");
+    const int M = (int)M64, K1 = 3 * num_samples;
+    hipStream_t s = (hipStream_t)stream;
+    const float* Hd = (const float*)fwd_workspace;                  // hidden activations of the forward (first region)
+    float* P = (float*)bwd_workspace;
+    float* gHd = P + raype_align((int64_t)M * K1);
+    float* W2T = gHd + raype_align((int64_t)M * C);
+    // tokens = features + relu(p W1^T + b1) W2^T + b2   (ray_positional_encoding.py:128-136, parq_lightning.py:75)
+    HIPCHK(hipMemsetAsync(db2, 0, (size_t)C * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(db1, 0, (size_t)C * sizeof(float), s));
+    HIPCHK(launch_colsum(d_tokens, C, M, C, db2, 1, s));
+    HIPCHK(hipMemsetAsync(dw2, 0, (size_t)C * C * sizeof(float), s));
+    HIPCHK(launch_gemm_tn(d_tokens, C, Hd, C, dw2, C, M, C, C, 1, s));
+    HIPCHK(launch_transpose(w2, C, W2T, C, C, C, s));
+    {
+        LinearArgs a = lin(d_tokens, C, W2T, C, nullptr, gHd, C, M, C, C);
+        a.relu_mask = Hd; a.ldmask = C;
+        HIPCHK(launch_linear(a, 1, s));
+    }
+    HIPCHK(launch_colsum(gHd, C, M, C, db1, 1, s));
+    HIPCHK(launch_raype_points(camera, T_cp, T_wp, T_wl, scale6_host, min_depth, max_depth, B, V, hh, ww, num_samples, P, s));
+    HIPCHK(hipMemsetAsync(dw1, 0, (size_t)C * K1 * sizeof(float), s));
+    HIPCHK(launch_gemm_tn(gHd, C, P, K1, dw1, K1, M, C, K1, 1, s));
+    if (d_features_nchw) {
+        const int hw = hh * ww;
+        for (int i = 0; i < B * V; ++i)                                 // (hw, C) -> (C, hw) per image
+            HIPCHK(launch_transpose(d_tokens + (int64_t)i * hw * C, C, d_features_nchw + (int64_t)i * C * hw, hw, hw, C, s));
+    }
+    return PARQ_OK;
+}
+
 int parq_k_layernorm(const float* X, const float* gamma, const float* beta, float* Y, int32_t M, int32_t C, float eps,
                      parq_stream stream) {
     if (!X || !gamma || !beta || !Y || M < 1 || C < 1 || C > 1024) return fail(PARQ_ERR_ARG, "bad argument");

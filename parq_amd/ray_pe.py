@@ -17,6 +17,40 @@ from . import _lib
 from .wrappers import raw
 
 
+class _RayPeFn(torch.autograd.Function):
+    """tokens = features + encoding as one autograd node: backward = parq_ray_pe_backward (gradients of the encoder MLP and
+    of the feature maps; the ray geometry has no learnable part)."""
+
+    @staticmethod
+    def forward(ctx, mod, features, camera, T_cp, T_wp, T_wl, w1, b1, w2, b2):
+        out, dims, _ = mod._run(camera, T_cp, T_wp, T_wl, tuple(features.shape[-2:]), features)
+        ctx.mod, ctx.dims = mod, dims
+        ctx.geo = mod._last_geo
+        ctx.want_feat = bool(features.requires_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_tokens):
+        mod = ctx.mod
+        B, V, h, w = ctx.dims
+        Cd, S = mod.dim_out, mod.num_samples
+        cam, T_cp, T_wp, T_wl = ctx.geo
+        dev = cam.device
+        lib = _lib.load()
+        g = g_tokens.to(dtype=torch.float32).contiguous()
+        nbytes = lib.parq_ray_pe_backward_workspace_bytes(B, V, h, w, Cd, S)
+        bws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=dev)
+        dw1 = torch.empty(Cd, 3 * S, device=dev); db1 = torch.empty(Cd, device=dev)
+        dw2 = torch.empty(Cd, Cd, device=dev); db2 = torch.empty(Cd, device=dev)
+        dfeat = torch.empty(B, V, Cd, h, w, device=dev) if ctx.want_feat else None
+        w2 = mod.encoder[2].weight.detach().to(device=dev, dtype=torch.float32).contiguous()
+        _lib.check(lib.parq_ray_pe_backward(_lib.ptr(cam), _lib.ptr(T_cp), _lib.ptr(T_wp), _lib.ptr(T_wl), _lib.ptr(w2),
+                                            (C.c_float * 6)(*mod.ray_points_scale), mod.min_depth, mod.max_depth, S, B, V, h, w, Cd,
+                                            _lib.ptr(g), _lib.ptr(mod._ws), _lib.ptr(bws), bws.numel() * 4, _lib.ptr(dw1), _lib.ptr(db1),
+                                            _lib.ptr(dw2), _lib.ptr(db2), _lib.ptr(dfeat), _lib.stream_ptr()), "parq_ray_pe_backward")
+        return None, dfeat, None, None, None, None, dw1, db1, dw2, db2
+
+
 class AddRayPE(nn.Module):
     def __init__(self, dim_out: int, ray_points_scale=(-2, 2, -1.5, 0, 0.25, 4.25), num_samples: int = 64,
                  min_depth: float = 0.25, max_depth: float = 5.25):
@@ -36,6 +70,7 @@ class AddRayPE(nn.Module):
         dev = cam.device
         prep = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
         cam, T_cp, T_wp, T_wl = prep(cam), prep(T_cp), prep(T_wp), prep(T_wl)
+        self._last_geo = (cam, T_cp, T_wp, T_wl)
         B, V = cam.shape[:2]
         if feat_hw is None:
             wf, hf = cam[0, 0, :2].tolist()                 # the reference rounds the first camera's size too (:80-81)
@@ -68,9 +103,14 @@ class AddRayPE(nn.Module):
         enc, (B, V, h, w), nchw = self._run(camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, hw, None, nchw=True)
         return enc if nchw else enc.view(B, V, h, w, self.dim_out).permute(0, 1, 4, 2, 3)
 
-    @torch.no_grad()
     def tokens(self, images_feat, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local):
-        """features + encoding, tokenised channels-last (B, T*H*W, C) in one pass."""
-        hw = tuple(images_feat.shape[-2:])
-        out, _, _ = self._run(camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, hw, images_feat)
-        return out
+        """features + encoding, tokenised channels-last (B, T*H*W, C) in one pass.  In train mode under autograd the call is
+        an autograd node (one outstanding forward per module: its workspace holds the hidden layer for the backward)."""
+        if torch.is_grad_enabled() and self.training:
+            e0, e2 = self.encoder[0], self.encoder[2]
+            return _RayPeFn.apply(self, images_feat, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local,
+                                  e0.weight, e0.bias, e2.weight, e2.bias)
+        with torch.no_grad():
+            hw = tuple(images_feat.shape[-2:])
+            out, _, _ = self._run(camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, hw, images_feat)
+            return out

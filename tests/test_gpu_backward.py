@@ -122,3 +122,70 @@ def test_autograd_node_and_adamw_steps():
         losses.append(float(l))
     print("\nregression loss over AdamW steps:", ["%.4f" % x for x in losses])
     assert losses[-1] < losses[0]
+
+
+def test_ray_pe_backward_matches_oracle_autograd(monkeypatch):
+    """AddRayPE.tokens as an autograd node: gradients of encoder.{0,2}.{weight,bias} and of the feature maps against float64
+    autograd of the oracle's ray_pe + tokenize (tiles straddle views; d = 256 is the fused forward path)."""
+    from parq_amd import AddRayPE
+    B, V, h, w, Cd = 2, 3, 7, 9, 256
+    scale = [-3.0, 3.0, -2.0, 0.5, 0.25, 5.25]
+    Wp = synth.make_ray_pe_weights(Cd, 91)
+    cam, T_cp, T_wp, T_wl = synth.make_geometry(92, B, V, h, w)
+    feat = synth.normal(93, "feat", (B, V, Cd, h, w))
+    cot = synth.normal(94, "cot", (B, V * h * w, Cd))
+    # oracle, float64, leaf tensors passed through unchanged
+    W64 = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in Wp.items()}
+    f64 = torch.from_numpy(feat).double().requires_grad_(True)
+    monkeypatch.setattr(O, "_as_torch", lambda Wd, dtype: Wd)
+    enc = O.ray_pe(cam, T_cp, T_wp, T_wl, W64, scale, dtype=torch.float64)
+    (O.tokenize(f64, enc) * torch.from_numpy(cot).double()).sum().backward()
+
+    pe = AddRayPE(Cd, scale, 64, 0.25, 5.25)
+    pe.load_state_dict({k: torch.from_numpy(v) for k, v in Wp.items()}, strict=True)
+    pe = pe.cuda().train()
+    fg = torch.from_numpy(feat).cuda().requires_grad_(True)
+    tok = pe.tokens(fg, *(torch.from_numpy(x).cuda() for x in (cam, T_cp, T_wp, T_wl)))
+    (tok * torch.from_numpy(cot).cuda()).sum().backward()
+    for name, p in pe.named_parameters():
+        ref = W64[name].grad.numpy()
+        err = np.linalg.norm(p.grad.cpu().numpy() - ref) / np.linalg.norm(ref)
+        assert err < 1e-4, (name, err)
+    ref = f64.grad.numpy()
+    assert np.abs(fg.grad.cpu().numpy() - ref).max() < 1e-6
+
+
+def test_parq_module_training_steps_with_set_loss():
+    """PARQ.training_step end to end (model/parq_lightning.py:97-100): ray-PE node -> decoder node -> the reference's set loss
+    on synthetic boxes; every parameter of the encoder MLP and of the decoder receives a gradient and AdamW lowers the loss."""
+    from types import SimpleNamespace as NS
+    from parq_amd import PARQ, Camera, Obb3D, Pose
+    B, V, h, w, Cd, Qn = 2, 2, 8, 10, 128, 32
+    dcfg = synth.decoder_cfg(dim=Cd, queries=Qn, heads=2, ffn=96, layers=2, dropout=0.0)
+    cfg = NS(MODEL=NS(TOKENIZER=NS(OUT_CHANNELS=Cd, RAY_POINTS_SCALE=dcfg.TRANSFORMER.SCALE, NUM_SAMPLES=64, MIN_DEPTH=0.25, MAX_DEPTH=5.25),
+                      DECODER=dcfg), OPTIMIZER=NS(LEARNING_RATE=2e-3, AUTOSCALE_LR=False))
+    torch.manual_seed(0)
+    model = PARQ(cfg).cuda().train()
+    cam, T_cp, T_wp, T_wl = synth.make_geometry(95, B, V, h, w)
+    obbs, sym = synth.make_boxes(96, B, 5, max_box=8)
+    to = lambda a: torch.from_numpy(a).cuda()
+    batch = {"all_features": to(synth.normal(97, "f", (B, V, Cd, h, w), std=0.5)), "camera_feature": Camera(to(cam)),
+             "T_camera_pseudoCam": Pose(to(T_cp)), "T_world_pseudoCam": Pose(to(T_wp)), "T_world_local": Pose(to(T_wl)),
+             "obbs_padded": Obb3D(to(obbs)), "sym": to(sym)}
+    opt = model.configure_optimizers()
+    np.random.seed(5)
+    losses = []
+    for it in range(5):
+        opt.zero_grad(set_to_none=True)
+        loss = model.training_step(batch, it)
+        loss.backward()
+        if it == 0:
+            missing = [n for n, p in model.named_parameters() if p.grad is None and "decoder.norm." not in n]
+            assert not missing, missing
+            assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+            assert float(model.add_ray_pe.encoder[0].weight.grad.abs().max()) > 0
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        losses.append(float(loss.detach()))
+    print("\nset loss over AdamW steps:", ["%.4f" % x for x in losses])
+    assert losses[-1] < losses[0]
