@@ -193,6 +193,15 @@ int parq_ray_pe_backward(const float *camera, const float *T_camera_pseudoCam, c
                          const float *d_tokens, const void *fwd_workspace, void *bwd_workspace, size_t bwd_workspace_bytes,
                          float *dw1, float *db1, float *dw2, float *db2, float *d_features_nchw, parq_stream stream);
 
+/* ---- eval post-processing (model/parq_decoder.py:372-424 parse_pred + utils/nms.py), one workgroup per scene ----------
+ * From the LAST iteration's outputs: obbs_out (B,Q,19) = [-s/2, s/2 per axis | R(ortho6d) centre | arg-max class],
+ * mask_out (B,Q) bytes = NMS keep mask AND validity window (centre x in (ts[0], ts[1]), z in (ts[4], ts[5]); all valid when
+ * for_vis).  NMS on the axis-aligned bounds of the boxes, background class (num_classes - 1) excluded: IoU > 0.1
+ * class-agnostic, or IoU > 0.2 within a class when for_vis. */
+int parq_parse_pred(const float *center, const float *size, const float *ortho6d, const float *sem_cls_prob, int32_t B,
+                    int32_t Q, int32_t num_classes, const float *track_scale6_host, int32_t for_vis, int32_t enable_nms,
+                    float *obbs_out, unsigned char *mask_out, parq_stream stream);
+
 /* ---- single kernels (parity tests, roofline measurements) --------------------------- */
 
 /* K4+K5: project (B,Q,3) normalised reference points into every view and bilinearly

@@ -195,6 +195,53 @@ def main(only=None):
         print("wrote", gname, tuple(enc.shape))
     if not only or "g10_loss" in only:
         make_loss_golden(ref)
+    if not only or "g11_parse_pred" in only:
+        make_parse_golden(ref)
+
+
+PARSE_CASE = dict(seed=41, B=2, Q=96, track_scale=[-1.5, 1.5, -2, 1, 0, 2])
+
+
+def parse_case_inputs(c):
+    """Last-iteration outputs for the parse_pred golden: clustered boxes so that the NMS has work to do."""
+    rng = np.random.RandomState(c["seed"])
+    B, Q = c["B"], c["Q"]
+    anchors = rng.uniform(-1.2, 1.2, (B, 12, 3)) * np.array([1.0, 0.5, 1.0]) + np.array([0.0, -0.5, 1.0])
+    which = rng.randint(0, 12, (B, Q))
+    center = np.take_along_axis(anchors, which[..., None].repeat(3, -1), 1) + rng.normal(0, 0.08, (B, Q, 3))
+    center[:, :6] += rng.uniform(-3, 3, (B, 6, 3))                         # some outside the validity window
+    size = rng.uniform(0.3, 0.9, (B, Q, 3))
+    rot6 = rng.normal(0, 1, (B, Q, 6))
+    logits = rng.normal(0, 1.5, (B, Q, 10))
+    prob = np.exp(logits) / np.exp(logits).sum(-1, keepdims=True)
+    return {k: v.astype(np.float32) for k, v in dict(center=center, size=size, rot6=rot6, prob=prob).items()}
+
+
+def make_parse_golden(ref):
+    """parse_pred of the reference (model/parq_decoder.py:372-424) evaluated piecewise on the CPU: the method itself hard-codes
+    .cuda(); its building blocks (ortho6d -> R, Pose.from_Rt, Obb3D.separate_init, utils/nms.nms) are the reference's own."""
+    import importlib
+    if not hasattr(np, "bool"):
+        np.bool = bool                                   # utils/nms.py:46 predates numpy 2
+    nms_mod = importlib.import_module("utils.nms")
+    o6 = importlib.import_module("utils.ortho6d_transforms")
+    c = PARSE_CASE
+    x = {k: torch.from_numpy(v) for k, v in parse_case_inputs(c).items()}
+    B, Q = c["B"], c["Q"]
+    scores, labels = torch.max(x["prob"], -1)
+    Rm = o6.compute_rotation_matrix_from_ortho6d(x["rot6"].contiguous().view(-1, 6)).view(B, -1, 3, 3)
+    T = ref.Pose.from_Rt(Rm, x["center"])
+    s = x["size"]
+    c3o = torch.stack([-s[..., 0] / 2, s[..., 0] / 2, -s[..., 1] / 2, s[..., 1] / 2, -s[..., 2] / 2, s[..., 2] / 2], dim=-1)
+    obbs = ref.Obb3D.separate_init(bb3_object=c3o, T_world_object=T._data, sem_id=labels)
+    ts = c["track_scale"]
+    cp = x["center"]
+    valid = (cp[..., 0] > ts[0]) & (cp[..., 0] < ts[1]) & (cp[..., 2] > ts[4]) & (cp[..., 2] < ts[5])
+    m_eval = torch.tensor(nms_mod.nms(obbs, scores, 9, 0.1, "nms_3d_faster")) & valid
+    m_vis = torch.tensor(nms_mod.nms(obbs, scores, 9, 0.2, "nms_3d_faster_samecls"))
+    np.savez_compressed(os.path.join(OUT_DIR, "g11_parse_pred.npz"), obbs=obbs._data.numpy(), mask_eval=m_eval.numpy(),
+                        mask_vis=m_vis.numpy(), meta=np.frombuffer(json.dumps(c, sort_keys=True).encode(), dtype=np.uint8))
+    print("wrote g11_parse_pred: kept", int(m_eval.sum()), "of", B * Q, "(eval),", int(m_vis.sum()), "(vis)")
 
 
 LOSS_CASE = dict(seed=31, B=3, Q=48, I=2, nbox=[4, 6, 3], np_seed=1234)    # (the reference raises on a scene without boxes)

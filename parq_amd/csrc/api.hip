@@ -1224,6 +1224,16 @@ int parq_ray_pe_backward(const float* camera, const float* T_cp, const float* T_
     return PARQ_OK;
 }
 
+int parq_parse_pred(const float* center, const float* size, const float* ortho6d, const float* sem_cls_prob, int32_t B, int32_t Q,
+                    int32_t num_classes, const float* track_scale6_host, int32_t for_vis, int32_t enable_nms, float* obbs_out,
+                    unsigned char* mask_out, parq_stream stream) {
+    if (!center || !size || !ortho6d || !sem_cls_prob || !track_scale6_host || !obbs_out || !mask_out) return fail(PARQ_ERR_ARG, "NULL argument");
+    if (B < 1 || Q < 1 || Q > 1024 || num_classes < 2) return fail(PARQ_ERR_ARG, "bad dims (1 <= Q <= 1024)");
+    HIPCHK(launch_parse_pred(center, size, ortho6d, sem_cls_prob, B, Q, num_classes, num_classes - 1, track_scale6_host, for_vis,
+                             enable_nms, obbs_out, mask_out, (hipStream_t)stream));
+    return PARQ_OK;
+}
+
 int parq_k_layernorm(const float* X, const float* gamma, const float* beta, float* Y, int32_t M, int32_t C, float eps,
                      parq_stream stream) {
     if (!X || !gamma || !beta || !Y || M < 1 || C < 1 || C > 1024) return fail(PARQ_ERR_ARG, "bad argument");

@@ -191,6 +191,10 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
 size_t attn_bwd_dq_partial_floats(int B, int H, int Lq, int Lk, int dh);
 hipError_t launch_attn_bwd_rowdot(const float* dO, const float* O, int64_t batch, int64_t row, int B, int H, int Lq, int dh, float* D,
                                   hipStream_t s);
+// postproc.hip: parse_pred + 3-D NMS on the device
+hipError_t launch_parse_pred(const float* center, const float* size, const float* rot6, const float* prob, int B, int Q, int ncls,
+                             int num_semcls, const float* track_scale6, int for_vis, int enable_nms, float* obbs,
+                             unsigned char* mask, hipStream_t s);
 hipError_t launch_gemm_split(const float* X, int64_t ldx, const void* Whi, const void* Wlo, const float* bias, float* Y,
                              int64_t ldy, int M, int N, int K, int relu, const float* feat, int hw, hipStream_t s);
 

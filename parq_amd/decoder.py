@@ -490,5 +490,25 @@ class PARQDecoder(nn.Module):
         return decoder_loss(out_dict_list, obbs_padded, T_world_local, sym, matcher=self._matcher,
                             loss_weight=self.loss_weight, num_semcls=self.num_semcls, class_weight=self._class_weight)
 
+    @torch.no_grad()
+    def parse_pred(self, out_dict):
+        """model/parq_decoder.py:372-424 on the device (parq_parse_pred: one workgroup per scene builds the boxes, the
+        validity window and runs the 3-D NMS; the reference round-trips through NumPy).  Adds ``obbs_pred`` (Obb3D, (B,Q,19))
+        and ``pred_mask`` (bool (B,Q)) to the last iteration's dict and returns it."""
+        from .wrappers import Obb3D
+        out = out_dict[-1] if isinstance(out_dict, (list, tuple)) else out_dict
+        ctr, size, rot6, prob = (out[k].detach().to(torch.float32).contiguous() for k in
+                                 ("center_unnormalized", "size_unnormalized", "ortho6d", "sem_cls_prob"))
+        B, Q = ctr.shape[:2]
+        obbs = torch.empty(B, Q, 19, dtype=torch.float32, device=ctr.device)
+        mask = torch.empty(B, Q, dtype=torch.uint8, device=ctr.device)
+        _lib.check(_lib.load().parq_parse_pred(_lib.ptr(ctr), _lib.ptr(size), _lib.ptr(rot6), _lib.ptr(prob), B, Q, self.num_semcls + 1,
+                                               (C.c_float * 6)(*[float(x) for x in self.track_scale]), int(bool(self.for_vis)),
+                                               int(bool(self.enable_nms)), _lib.ptr(obbs), C.c_void_p(mask.data_ptr()),
+                                               _lib.stream_ptr()), "parq_parse_pred")
+        out["obbs_pred"] = Obb3D(obbs)
+        out["pred_mask"] = mask.bool()
+        return out
+
     def update_metrics(self, *a, **k):
         raise NotImplementedError("eval post-processing is out of scope this round (SURVEY.md §8f-4)")

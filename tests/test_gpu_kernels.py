@@ -202,3 +202,26 @@ def test_project_sample(B, V, h, w, Cn, Q):
         assert rel_err(tgt.cpu().numpy()[ok], want.numpy()[ok]) < 1e-4     # their own pixel-coordinate rounding noise
     assert rel_err(cp.cpu().numpy(), P.numpy()) < 1e-6
     assert valid.any() and (~valid).any()      # the fixture exercises both branches
+
+
+@pytest.mark.parametrize("for_vis,key", [(0, "mask_eval"), (1, "mask_vis")])
+def test_parse_pred_matches_reference_golden(for_vis, key):
+    """Device parse_pred + 3-D NMS against the golden computed with the reference's own building blocks (ortho6d -> R,
+    Obb3D.separate_init, utils/nms.nms) on the CPU: boxes within 2e-6, keep masks identical."""
+    import json
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    from make_golden import PARSE_CASE, parse_case_inputs
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "g11_parse_pred.npz"))
+    assert json.loads(bytes(z["meta"]).decode()) == json.loads(json.dumps(PARSE_CASE))
+    x = parse_case_inputs(PARSE_CASE)
+    B, Q = PARSE_CASE["B"], PARSE_CASE["Q"]
+    d = {k: dev(v) for k, v in x.items()}
+    obbs = torch.empty(B, Q, 19, device="cuda"); mask = torch.empty(B, Q, dtype=torch.uint8, device="cuda")
+    ts = (C.c_float * 6)(*[float(t) for t in PARSE_CASE["track_scale"]])
+    _lib.check(lib().parq_parse_pred(_lib.ptr(d["center"]), _lib.ptr(d["size"]), _lib.ptr(d["rot6"]), _lib.ptr(d["prob"]), B, Q, 10, ts,
+                                    for_vis, 1, _lib.ptr(obbs), C.c_void_p(mask.data_ptr()), sptr()), "parse_pred")
+    assert np.abs(obbs.cpu().numpy() - z["obbs"]).max() < 2e-6
+    assert np.array_equal(mask.cpu().numpy().astype(bool), z[key])
+    assert 0 < int(mask.sum()) < B * Q
