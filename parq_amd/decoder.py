@@ -217,7 +217,7 @@ class PARQDecoder(nn.Module):
         self._mean_dev = None
 
     # ------------------------------------------------------------------ native handle
-    def _handle(self):
+    def _handle(self, apply_mode=True):
         if self._h is None:
             lib = _lib.load()
             cfg = _lib.ParqConfig(self.dim_in, self.num_queries, self.num_semcls + 1, self.num_heads, self.ffn_dim,
@@ -228,7 +228,7 @@ class PARQDecoder(nn.Module):
             self._h = h
             self._mode_set = None
             self._train_ws = None
-        if self._mode_set != self.attention_mode:
+        if apply_mode and self._mode_set != self.attention_mode:
             if self.attention_mode not in ATTENTION_MODES:
                 raise ValueError(f"attention_mode must be one of {sorted(ATTENTION_MODES)}")
             _lib.check(_lib.load().parq_set_attention_mode(self._h, ATTENTION_MODES[self.attention_mode]),
@@ -236,6 +236,16 @@ class PARQDecoder(nn.Module):
             self._mode_set = self.attention_mode
             self._ws.clear()
         return self._h
+
+    def _handle_in_mode(self, mode):
+        """The handle switched to `mode` without touching the user-facing ``attention_mode`` (the training entry points need
+        the exact-fp32 attention kernels: their backward reads the fp32 K/V cache); the next inference call switches back."""
+        h = self._handle(apply_mode=False)
+        if self._mode_set != mode:
+            _lib.check(_lib.load().parq_set_attention_mode(h, ATTENTION_MODES[mode]), "parq_set_attention_mode")
+            self._mode_set = mode
+            self._ws.clear()
+        return h
 
     def __del__(self):
         try:
@@ -339,11 +349,10 @@ class PARQDecoder(nn.Module):
 
     def _forward_autograd(self, tokens, camera, T_cp, T_wp, T_wl, feat_hw):
         """Train-mode forward under autograd: one autograd node whose backward is the HIP backward chain.  Uses the exact
-        fp32 attention kernels (attention_mode is switched to "fp32") and needs DROPOUT_RATE = 0."""
+        fp32 attention kernels for this call (``attention_mode`` keeps governing inference) and needs DROPOUT_RATE = 0."""
         if self.dropout_rate > 0:
             raise NotImplementedError("parq_amd.PARQDecoder: dropout %.2f in train mode is not built; set DROPOUT_RATE = 0 "
                                       "or call .eval()" % self.dropout_rate)
-        self.attention_mode = "fp32"
         params = [p for _, p in self._unique_params()]
         stacked = _TrainFn.apply(self, raw(tokens), camera, T_cp, T_wp, T_wl, feat_hw, *params)
         return [{k: t[i] for k, t in zip(OUTPUT_KEYS, stacked)} for i in range(self.num_layers)]
@@ -367,11 +376,9 @@ class PARQDecoder(nn.Module):
         Returns the same list of dicts as ``forward``."""
         if self.dropout_rate > 0 and self.training:
             raise NotImplementedError("parq_amd.PARQDecoder: dropout > 0 in train mode is not built (set DROPOUT_RATE = 0)")
-        if self.attention_mode != "fp32":
-            raise RuntimeError('training needs attention_mode = "fp32" (the backward kernels read the fp32 K/V cache)')
         sc, keep, dev = self._scene(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
         self._ensure_packed(dev)
-        lib, h = _lib.load(), self._handle()
+        lib, h = _lib.load(), self._handle_in_mode("fp32")
         nbytes = lib.parq_train_workspace_bytes(h, sc.B, sc.V, sc.h, sc.w)
         if self._train_ws is None or self._train_ws.numel() * 4 < nbytes or self._train_ws.device != dev:
             self._ws.clear()
@@ -389,7 +396,7 @@ class PARQDecoder(nn.Module):
         size_unnormalized / ortho6d -> (I, B, Q, k) cotangents (missing = zero).  Returns ({reference tensor name:
         gradient}, d_tokens or None); gradients of tensors registered under two names are returned once per name."""
         sc, keep, outs, po, dev = self._train_state
-        lib, h = _lib.load(), self._handle()
+        lib, h = _lib.load(), self._handle_in_mode("fp32")
         gs = []
         for key, wd in (("pred_logits", self.num_semcls + 1), ("center_unnormalized", 3), ("size_unnormalized", 3), ("ortho6d", 6)):
             g = grad_outputs.get(key)
