@@ -150,7 +150,7 @@ int parq_profile_read(parq_handle h, int32_t which, double *total_ms, int64_t *l
 
 /* ---- training: forward with saved activations + backward (model/parq_lightning.py:97-100) ----------
  * The backward of the whole decoder chain as HIP kernels.  Needs attention mode 0 (the backward reads the fp32 K/V cache),
- * head dim 32/64, dropout 0.  parq_forward_train = parq_forward that keeps every iteration's activations in the (larger)
+ * head dim 32/64.  parq_forward_train = parq_forward that keeps every iteration's activations in the (larger)
  * training workspace; parq_backward consumes them: `grads` holds d loss / d output per iteration (same (I,B,Q,k) layout as
  * the outputs, NULL = zero), `grad_arena` receives d loss / d weight in the layout of the packed weight arena
  * (parq_arena_lookup maps reference tensor names to offsets), `d_tokens` (B,N,C) or NULL receives d loss / d input tokens.
@@ -158,6 +158,15 @@ int parq_profile_read(parq_handle h, int32_t which, double *total_ms, int64_t *l
 typedef struct parq_output_grads {
     const float *pred_logits, *center_unnormalized, *size_unnormalized, *ortho6d;
 } parq_output_grads;
+/* Dropout of the decoder layer in training (transformer_parq.py:339-386: attention-probability dropout of both attentions,
+ * dropout1/2/3 on the sub-layer outputs, dropout on the FFN hidden layer; all with probability p): counter-based masks from
+ * `seed` (draw a new one per step), regenerated identically by parq_backward.  p = 0 (default) switches it off.
+ * parq_k_dropout_mask writes the keep-mask scaled by 1/(1-p) of (iteration, site) over a rows x cols index space — sites:
+ * 0 self-attention probabilities (rows = B*H*Q, cols = Q), 1 self out-proj (B*Q x C), 2 cross-attention probabilities
+ * (B*H*Q x N), 3 cross out-proj, 4 FFN hidden (B*Q x F), 5 FFN output — for tests that feed the same masks to an oracle. */
+int parq_set_dropout(parq_handle h, float p, uint32_t seed);
+int parq_k_dropout_mask(parq_handle h, int32_t iteration, int32_t site, int64_t rows, int64_t cols, float *out,
+                        parq_stream stream);
 size_t parq_train_workspace_bytes(parq_handle h, int32_t B, int32_t V, int32_t hh, int32_t ww);
 size_t parq_grad_arena_bytes(parq_handle h);
 int parq_forward_train(parq_handle h, const parq_scene *scene, void *workspace, size_t workspace_bytes,

@@ -60,6 +60,8 @@ SYMBOLS = {
     "parq_set_attention_mode": (C.c_int, [_vp, _i32]),
     "parq_profile_enable": (C.c_int, [_vp, _i32]),
     "parq_profile_read": (C.c_int, [_vp, _i32, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "parq_set_dropout": (C.c_int, [_vp, _f, C.c_uint32]),
+    "parq_k_dropout_mask": (C.c_int, [_vp, _i32, _i32, _i64, _i64, _vp, _vp]),
     "parq_train_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32, _i32]),
     "parq_grad_arena_bytes": (_sz, [_vp]),
     "parq_forward_train": (C.c_int, [_vp, C.POINTER(ParqScene), _vp, _sz, C.POINTER(ParqOutputs), _vp]),

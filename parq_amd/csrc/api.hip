@@ -68,7 +68,7 @@ struct Workspace {
     int64_t sa, ln3, lse_s, lse_c, refk;
     int64_t iter_begin, iter_end, stash;
     // backward scratch (training workspace only)
-    int64_t g_a, g_b, g_c, g_pos, g_tmp, g_ffh, g_h1, g_h2, g_z, g_act, g_h3, g_qkv, g_emb, g_ref, g_D, g_bs, wT, g_kv, g_dqp;
+    int64_t g_a, g_b, g_c, g_pos, g_tmp, g_ffh, g_h1, g_h2, g_z, g_act, g_h3, g_qkv, g_emb, g_ref, g_D, g_bs, wT, g_kv, g_dqp, g_drop;
     int64_t train_total;
     int64_t shift(int k) const { return k == 0 ? 0 : stash + (int64_t)(k - 1) * (iter_end - iter_begin) - iter_begin; }
 };
@@ -90,6 +90,9 @@ struct parq_ctx {
     int ref_state = 0;                // 0: none, 1: ws.ref valid
     int attn_mode = 1;                // 0: fp32 MFMA, 1: split fp16x3, 2: fp16, 3: bf16 (1..3: head dim 64 only)
     int kv16_state = 1;               // what the arena's 16-bit W_kv copy currently holds (same numbering)
+    float drop_p = 0.f;               // training dropout (decoder layer, transformer_parq.py:339-386) and its base seed
+    uint32_t drop_seed = 0;
+    uint32_t site_seed(int k, int site) const { return rng_stream(drop_seed, (uint32_t)(k * 8 + site)); }
     bool cache_mode() const { return attn_mode >= 1 && dh == 64; }
     int terms() const { return attn_mode == 1 ? 3 : 1; }
     int kind() const { return attn_mode == 3 ? kBF16 : kF16; }
@@ -173,6 +176,7 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     ws->wT = take(C * NH1 + 2 * C * C + 2 * C * F + 3 * C * C + 3 * C * C + C * C + 384 * C);
     ws->g_kv = take(split_mode ? 0 : (int64_t)c->nl * B * 2 * N * C);
     ws->g_dqp = take((int64_t)attn_bwd_dq_partial_floats(B, c->H, (int)Q, (int)N, c->dh));
+    ws->g_drop = take(M * C);
     ws->train_total = off;
     return PARQ_OK;
 }
@@ -264,6 +268,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
                float* emb_next = nullptr, bool train = false) {
     float* wi = wsp + shift;
     if (!emb_next) emb_next = wi + ws.emb;
+    const float dp = train ? c->drop_p : 0.f;          // dropout exists in training only (nn.Dropout / MHA dropout)
     const float* A = c->arena;
     const Arena& ar = c->ar;
     const int li = c->cfg.share_weights ? 0 : layer_num;
@@ -306,7 +311,8 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     {
         Prof p(c, s, PARQ_PROF_SELF_ATTN);
         if (dh <= 64) {
-            HIPCHK(launch_self_attn(wi + ws.qkv, 3 * C, B, H, Q, dh, wi + ws.sa, C, s, train ? wi + ws.lse_s : nullptr));
+            HIPCHK(launch_self_attn(wi + ws.qkv, 3 * C, B, H, Q, dh, wi + ws.sa, C, s, train ? wi + ws.lse_s : nullptr, dp,
+                                    c->site_seed(layer_num, 0)));
         } else {
             fa.q = wi + ws.qkv;         fa.q_batch = (int64_t)Q * 3 * C; fa.q_head = dh; fa.q_row = 3 * C;
             fa.k = wi + ws.qkv + C;     fa.k_batch = fa.q_batch; fa.k_head = dh; fa.k_row = 3 * C;
@@ -317,17 +323,20 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
             fa.m_part = fa.o_part + (int64_t)B * H * fa.nsplit * dh * lp;
             fa.l_part = fa.m_part + (int64_t)B * H * fa.nsplit * lp;
             fa.lse = train ? wi + ws.lse_s : nullptr;
+            fa.drop_p = dp; fa.drop_seed = c->site_seed(layer_num, 0);
             HIPCHK(launch_flash(fa, s));
             HIPCHK(launch_flash_merge(fa, s));
         }
     }
     fa.out = wi + ws.attn;
     fa.lse = train ? wi + ws.lse_c : nullptr;
+    fa.drop_p = dp; fa.drop_seed = c->site_seed(layer_num, 2);
     {
         // xa = tgt + self_attn @ Wo  (pre-LayerNorm; norm1 is applied by the consumers)
         Prof p(c, s, PARQ_PROF_LINEAR);
         LinearArgs a = lin(wi + ws.sa, C, A + L.self_out_w, C, A + L.self_out_b, wi + ws.xa, C, M, C, C);
         a.R = wi + ws.tgt; a.ldr = C;
+        a.drop_p = dp; a.drop_seed = c->site_seed(layer_num, 1);
         HIPCHK(launch_linear(a, 1, s));
         // K7: cross-attention query = (norm1(xa) + pos) @ Wq; publishes norm1's row statistics
         a = lin(wi + ws.xa, C, A + L.cross_in_w, C, A + L.cross_in_b, wi + ws.qc, C, M, C, C);
@@ -360,15 +369,18 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         // xb = norm1(xa) + cross_attn @ Wo   (residual recomputed from the published statistics)
         LinearArgs a = lin(wi + ws.attn, C, A + L.cross_out_w, C, A + L.cross_out_b, wi + ws.xb, C, M, C, C);
         a.R = wi + ws.xa; a.ldr = C; a.rln_stats = wi + ws.ln1; a.rln_gamma = A + L.n1_w; a.rln_beta = A + L.n1_b;
+        a.drop_p = dp; a.drop_seed = c->site_seed(layer_num, 3);
         HIPCHK(launch_linear(a, 1, s));
         // K8: FFN (transformer_parq.py:383-385): relu(norm2(xb) @ W1), publishes norm2's statistics
         a = lin(wi + ws.xb, C, A + L.lin1_w, C, A + L.lin1_b, wi + ws.ffn, F, M, F, C);
         a.ln_gamma = A + L.n2_w; a.ln_beta = A + L.n2_b; a.ln_stats_out = wi + ws.ln2; a.norm_eps = eps;
         a.relu = 1;
+        a.drop_p = dp; a.drop_seed = c->site_seed(layer_num, 4);
         HIPCHK(launch_linear(a, 1, s));
         // xc = norm2(xb) + ffn @ W2
         a = lin(wi + ws.ffn, F, A + L.lin2_w, F, A + L.lin2_b, wi + ws.xc, C, M, C, F);
         a.R = wi + ws.xb; a.ldr = C; a.rln_stats = wi + ws.ln2; a.rln_gamma = A + L.n2_w; a.rln_beta = A + L.n2_b;
+        a.drop_p = dp; a.drop_seed = c->site_seed(layer_num, 5);
         HIPCHK(launch_linear(a, 1, s));
         // K9: heads (transformer_parq.py:234-252; generic_mlp.py:85-110) on norm3(xc); the first layers of the
         // four heads are one GEMM, which also accumulates the GroupNorm moments of the two hidden blocks
@@ -434,6 +446,15 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     float *gFfh = wsp + ws.g_ffh, *gH1 = wsp + ws.g_h1, *gH2 = wsp + ws.g_h2, *gZ = wsp + ws.g_z, *act = wsp + ws.g_act;
     float *gH3 = wsp + ws.g_h3, *gQkv = wsp + ws.g_qkv, *gEmb = wsp + ws.g_emb, *gRef = wsp + ws.g_ref, *Dd = wsp + ws.g_D;
     double* bs = reinterpret_cast<double*>(wsp + ws.g_bs);
+    float* gD = wsp + ws.g_drop;                       // gradient entering a dropout site's branch
+    const float dp = c->drop_p;
+    const float inv_keep = dp > 0.f ? 1.f / (1.f - dp) : 1.f;
+    // the gradient that flows into a dropped branch: g * keep / (1 - p); the residual path keeps the plain g
+    auto through_dropout = [&](const float* g, int site) -> const float* {
+        if (!(dp > 0.f)) return g;
+        if (launch_dropout_apply(g, gD, M, C, dp, c->site_seed(k, site), s) != hipSuccess) return nullptr;
+        return gD;
+    };
     // transposed weight copies of this layer
     float* wT = wsp + ws.wT;
     float* h1T = wT;                      // [C][NH1]
@@ -494,11 +515,13 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     }
     // ---- norm3 / FFN (transformer_parq.py:383-385)
     HIPCHK(launch_ln_bwd(gA, wi + ws.xc, wi + ws.ln3, A + L.n3_w, gB, M, C, 0, G + L.n3_w, G + L.n3_b, s));   // gB = d / d xc
-    HIPCHK(launch_gemm_tn(gB, C, wi + ws.ffn, F, G + L.lin2_w, F, M, C, F, 1, s));
-    HIPCHK(launch_colsum(gB, C, M, C, G + L.lin2_b, 1, s));
     {
-        LinearArgs a = mm(gB, C, l2T, C, F, gFfh, F);                                          // d / d ffn hidden, through the ReLU
-        a.relu_mask = wi + ws.ffn; a.ldmask = F;
+        const float* gd = through_dropout(gB, 5);
+        if (!gd) return fail(PARQ_ERR_HIP, "dropout_apply failed");
+        HIPCHK(launch_gemm_tn(gd, C, wi + ws.ffn, F, G + L.lin2_w, F, M, C, F, 1, s));
+        HIPCHK(launch_colsum(gd, C, M, C, G + L.lin2_b, 1, s));
+        LinearArgs a = mm(gd, C, l2T, C, F, gFfh, F);                // d / d ffn hidden, through dropout (the stash holds the dropped,
+        a.relu_mask = wi + ws.ffn; a.ldmask = F; a.mask_scale = inv_keep;   // rescaled hidden: zero = dropped or ReLU-inactive) and the ReLU
         HIPCHK(launch_linear(a, 1, s));
     }
     HIPCHK(launch_layernorm(wi + ws.xb, A + L.n2_w, A + L.n2_b, tmp, M, C, eps, s));           // tmp = x2
@@ -511,10 +534,12 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     }
     // ---- norm2 / cross-attention (transformer_parq.py:377-382)
     HIPCHK(launch_ln_bwd(gA, wi + ws.xb, wi + ws.ln2, A + L.n2_w, gB, M, C, 0, G + L.n2_w, G + L.n2_b, s));   // gB = d / d xb
-    HIPCHK(launch_gemm_tn(gB, C, wi + ws.attn, C, G + L.cross_out_w, C, M, C, C, 1, s));
-    HIPCHK(launch_colsum(gB, C, M, C, G + L.cross_out_b, 1, s));
     {
-        LinearArgs a = mm(gB, C, coT, C, C, gA, C);                                            // gA = d / d attention output
+        const float* gd = through_dropout(gB, 3);
+        if (!gd) return fail(PARQ_ERR_HIP, "dropout_apply failed");
+        HIPCHK(launch_gemm_tn(gd, C, wi + ws.attn, C, G + L.cross_out_w, C, M, C, C, 1, s));
+        HIPCHK(launch_colsum(gd, C, M, C, G + L.cross_out_b, 1, s));
+        LinearArgs a = mm(gd, C, coT, C, C, gA, C);                                            // gA = d / d attention output
         HIPCHK(launch_linear(a, 1, s));
     }
     HIPCHK(launch_attn_bwd_rowdot(gA, wi + ws.attn, (int64_t)Q * C, C, B, H, Q, dh, Dd, s));
@@ -526,7 +551,7 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
         HIPCHK(launch_attn_bwd(wi + ws.qc, (int64_t)Q * C, dh, C, kv, 2 * N * C, N * dh, dh, kv + (int64_t)H * N * dh, 2 * N * C, N * dh, dh,
                                gA, (int64_t)Q * C, dh, C, wi + ws.lse_c, Dd, gC, (int64_t)Q * C, dh, C, gkv, 2 * N * C, dh, 2 * C,
                                gkv + C, 2 * N * C, dh, 2 * C, B, H, Q, (int)N, dh, 1, s,
-                               attn_bwd_dq_partial_floats(B, H, Q, (int)N, dh) ? wsp + ws.g_dqp : nullptr));
+                               attn_bwd_dq_partial_floats(B, H, Q, (int)N, dh) ? wsp + ws.g_dqp : nullptr, dp, c->site_seed(k, 2)));
     }
     // q = (x1 + pos) Wq^T + bq,  x1 = norm1(xa)
     HIPCHK(launch_layernorm(wi + ws.xa, A + L.n1_w, A + L.n1_b, tmp, M, C, eps, s));
@@ -540,10 +565,12 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     HIPCHK(launch_add(gB, gPos, gA, (int64_t)M * C, s));                                       // gA = d / d x1 (residual + query path)
     // ---- norm1 / self-attention (transformer_parq.py:372-376)
     HIPCHK(launch_ln_bwd(gA, wi + ws.xa, wi + ws.ln1, A + L.n1_w, gB, M, C, 0, G + L.n1_w, G + L.n1_b, s));   // gB = d / d xa
-    HIPCHK(launch_gemm_tn(gB, C, wi + ws.sa, C, G + L.self_out_w, C, M, C, C, 1, s));
-    HIPCHK(launch_colsum(gB, C, M, C, G + L.self_out_b, 1, s));
     {
-        LinearArgs a = mm(gB, C, soT, C, C, gA, C);                                            // gA = d / d self-attention output
+        const float* gd = through_dropout(gB, 1);
+        if (!gd) return fail(PARQ_ERR_HIP, "dropout_apply failed");
+        HIPCHK(launch_gemm_tn(gd, C, wi + ws.sa, C, G + L.self_out_w, C, M, C, C, 1, s));
+        HIPCHK(launch_colsum(gd, C, M, C, G + L.self_out_b, 1, s));
+        LinearArgs a = mm(gd, C, soT, C, C, gA, C);                                            // gA = d / d self-attention output
         HIPCHK(launch_linear(a, 1, s));
     }
     HIPCHK(launch_attn_bwd_rowdot(gA, wi + ws.sa, (int64_t)Q * C, C, B, H, Q, dh, Dd, s));
@@ -551,7 +578,7 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     HIPCHK(launch_attn_bwd(wi + ws.qkv, (int64_t)Q * 3 * C, dh, 3 * C, wi + ws.qkv + C, (int64_t)Q * 3 * C, dh, 3 * C,
                            wi + ws.qkv + 2 * C, (int64_t)Q * 3 * C, dh, 3 * C, gA, (int64_t)Q * C, dh, C, wi + ws.lse_s, Dd,
                            gQkv, (int64_t)Q * 3 * C, dh, 3 * C, gQkv + C, (int64_t)Q * 3 * C, dh, 3 * C, gQkv + 2 * C,
-                           (int64_t)Q * 3 * C, dh, 3 * C, B, H, Q, Q, dh, 0, s));
+                           (int64_t)Q * 3 * C, dh, 3 * C, B, H, Q, Q, dh, 0, s, nullptr, dp, c->site_seed(k, 0)));
     // in-projection: [q | k] = (tgt + pos) Wqk^T, v = tgt Wv^T
     HIPCHK(launch_add(wi + ws.tgt, wi + ws.pos, tmp, (int64_t)M * C, s));                      // tmp = tgt + pos
     HIPCHK(launch_gemm_tn(gQkv, 3 * C, tmp, C, G + L.self_in_w, C, M, 2 * C, C, 1, s));
@@ -858,6 +885,22 @@ size_t parq_train_workspace_bytes(parq_handle h, int32_t B, int32_t V, int32_t h
     Workspace ws;
     carve_workspace(h, B, V, hh, ww, &ws);
     return (size_t)ws.train_total * sizeof(float);
+}
+
+int parq_set_dropout(parq_handle h, float p, uint32_t seed) {
+    if (!h || !(p >= 0.f) || !(p < 1.f)) return fail(PARQ_ERR_ARG, "dropout probability must be in [0, 1)");
+    h->drop_p = p;
+    h->drop_seed = seed;
+    return PARQ_OK;
+}
+
+int parq_k_dropout_mask(parq_handle h, int32_t iteration, int32_t site, int64_t rows, int64_t cols, float* out, parq_stream stream) {
+    if (!h || !out || rows < 1 || cols < 1 || rows * cols > INT32_MAX) return fail(PARQ_ERR_ARG, "bad argument");
+    if (!(h->drop_p > 0.f)) return fail(PARQ_ERR_STATE, "dropout is off");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(launch_fill(out, 1.f, rows * cols, s));
+    HIPCHK(launch_dropout_apply(out, out, (int)rows, (int)cols, h->drop_p, h->site_seed(iteration, site), s));
+    return PARQ_OK;
 }
 
 size_t parq_grad_arena_bytes(parq_handle h) { return h ? (size_t)h->ar.total * sizeof(float) : 0; }

@@ -29,6 +29,7 @@ struct AttnBwdArgs {
     float* gk; int64_t gk_batch, gk_head, gk_row;     // = or += (accumulate)
     float* gv; int64_t gv_batch, gv_head, gv_row;
     int B, H, Lq, Lk, accumulate_kv;
+    float drop_p; uint32_t drop_seed;   // dropout on the probabilities (same stream as the forward)
 };
 
 template <int DH>
@@ -87,12 +88,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
             }
             const bool ok = jok && (i0 + i < a.Lq);
             const float p = ok ? __builtin_amdgcn_exp2f(s * c2 - st[i]) : 0.f;
-            const float ds = p * (dp - st[32 + i]);
+            float keep = 1.f;
+            if (a.drop_p > 0.f)
+                keep = drop_keep(a.drop_seed, ((uint64_t)bh * (uint64_t)a.Lq + (uint64_t)(i0 + i)) * (uint64_t)a.Lk + (uint64_t)j, a.drop_p)
+                           ? 1.f / (1.f - a.drop_p) : 0.f;
+            const float ds = p * (dp * keep - st[32 + i]);
             dS[i * 257 + tid] = ds;
 #pragma unroll
             for (int d = 0; d < DH; ++d) {
                 gkj[d] += ds * Qt[i * DH + d];
-                gvj[d] += p * Ot[i * DH + d];
+                gvj[d] += p * keep * Ot[i * DH + d];
             }
         }
         __syncthreads();
@@ -226,8 +231,12 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_mfma_kernel(AttnBwdArgs a) 
             const int qi = mfma32_row(r, lane);
             const bool ok = jok && (i0 + qi < a.Lq);
             const float p = ok ? __builtin_amdgcn_exp2f(sacc[r] * c2 - st[qi]) : 0.f;
-            const float ds = p * (pacc[r] - st[32 + qi]);
-            sacc[r] = p;
+            float keep = 1.f;
+            if (a.drop_p > 0.f)
+                keep = drop_keep(a.drop_seed, ((uint64_t)bh * (uint64_t)a.Lq + (uint64_t)(i0 + qi)) * (uint64_t)a.Lk + (uint64_t)j, a.drop_p)
+                           ? 1.f / (1.f - a.drop_p) : 0.f;
+            const float ds = p * (pacc[r] * keep - st[32 + qi]);
+            sacc[r] = p * keep;
             pacc[r] = ds;
             Ds[qi * kDs + wave * 32 + li] = ds;
         }
@@ -343,7 +352,7 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
                            const float* dO, int64_t do_batch, int64_t do_head, int64_t do_row, const float* lse, const float* D,
                            float* gq, int64_t gq_batch, int64_t gq_head, int64_t gq_row, float* gk, int64_t gk_batch,
                            int64_t gk_head, int64_t gk_row, float* gv, int64_t gv_batch, int64_t gv_head, int64_t gv_row, int B, int H,
-                           int Lq, int Lk, int dh, int accumulate_kv, hipStream_t s, float* gq_part) {
+                           int Lq, int Lk, int dh, int accumulate_kv, hipStream_t s, float* gq_part, float drop_p, uint32_t drop_seed) {
     if (dh != 64 && dh != 32) return hipErrorInvalidValue;
     AttnBwdArgs a;
     a.q = q; a.q_batch = q_batch; a.q_head = q_head; a.q_row = q_row;
@@ -355,6 +364,7 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
     a.gk = gk; a.gk_batch = gk_batch; a.gk_head = gk_head; a.gk_row = gk_row;
     a.gv = gv; a.gv_batch = gv_batch; a.gv_head = gv_head; a.gv_row = gv_row;
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.accumulate_kv = accumulate_kv; a.gq_part = nullptr;
+    a.drop_p = drop_p; a.drop_seed = drop_seed;
     dim3 grid(ceil_div(Lk, 256), B * H);
     static const int force = [] {
         const char* e = getenv("PARQ_ATTN_BWD");            // "naive" / "mfma": debugging override

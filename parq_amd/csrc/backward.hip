@@ -154,6 +154,13 @@ __global__ void axpy_rows_kernel(const float* __restrict__ x, int64_t ldx, float
     *o = accumulate ? *o + v : v;
 }
 
+// dst[m][n] = keep(m * N + n) ? src[m][n] / (1 - p) : 0   (gradient through a dropout site; also used to dump masks in tests)
+__global__ void dropout_apply_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n_total, float p, uint32_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    dst[i] = drop_keep(seed, (uint64_t)i, p) ? src[i] / (1.f - p) : 0.f;
+}
+
 // ------------------------------------------------------------------ LayerNorm backward, one wave per row
 //   y = xhat * gamma + beta, xhat = (x - mean) * rstd   ->   gx = rstd (gxh - mean(gxh) - xhat mean(gxh xhat)), gxh = gy gamma
 constexpr int kLnPer = 16;      // C <= 1024
@@ -593,6 +600,11 @@ hipError_t launch_add(const float* a, const float* b, float* y, int64_t n, hipSt
 }
 hipError_t launch_axpy_rows(const float* x, int64_t ldx, float* y, int64_t ldy, int M, int N, int accumulate, hipStream_t s) {
     hipLaunchKernelGGL(axpy_rows_kernel, dim3((unsigned)ceil_div64((int64_t)M * N, 256)), dim3(256), 0, s, x, ldx, y, ldy, M, N, accumulate);
+    return hipGetLastError();
+}
+hipError_t launch_dropout_apply(const float* src, float* dst, int M, int N, float p, uint32_t seed, hipStream_t s) {
+    const int64_t n = (int64_t)M * N;
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, s, src, dst, n, p, seed);
     return hipGetLastError();
 }
 hipError_t launch_ln_bwd(const float* gy, const float* x, const float* stats, const float* gamma, float* gx, int M, int C,

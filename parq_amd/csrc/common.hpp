@@ -49,6 +49,18 @@ __device__ __forceinline__ void split8(const float* x, half8& hi, half8& lo) {
     }
 }
 
+// ---- dropout (training): counter-based keep decision, identical in forward and backward.  Element `idx` of stream `seed`
+// is kept when a 24-bit hash is >= p * 2^24; kept values are scaled by 1 / (1 - p) (torch.nn.Dropout semantics).
+__host__ __device__ inline uint32_t rng_mix(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ inline uint32_t rng_stream(uint32_t base, uint32_t stream) { return rng_mix(base ^ rng_mix(stream * 0x9e3779b9U + 0x85ebca6bU)); }
+__host__ __device__ inline bool drop_keep(uint32_t seed, uint64_t idx, float p) {
+    const uint32_t h = rng_mix(rng_mix(seed ^ (uint32_t)(idx >> 32)) ^ (uint32_t)idx);
+    return (float)(h >> 8) >= p * 16777216.0f;
+}
+
 // 16-bit operand kinds of the matrix pipe.  A half8 is used as the raw 8 x 16-bit container for both.
 enum : int { kF16 = 0, kBF16 = 1 };
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -86,7 +98,10 @@ struct LinearArgs {
     float* Y;
     int M, N, K;
     int relu;
-    const float* relu_mask; int64_t ldmask;   // backward of a ReLU: y = relu_mask[m][n] > 0 ? y : 0 (applied after bias)
+    const float* relu_mask; int64_t ldmask;   // backward of a ReLU: y = relu_mask[m][n] > 0 ? y * mask_scale : 0 (applied after bias)
+    float mask_scale;                         // 0 is read as 1
+    // training dropout on the output, after bias / ReLU and before the residual: element m * N + n of stream drop_seed
+    float drop_p; uint32_t drop_seed;
     // output address: Y + (m / rows_per_batch) * y_batch + (m % rows_per_batch) * y_row
     //                   + (n / col_blk) * y_blk + (n % col_blk)
     int rows_per_batch; int64_t y_batch; int64_t y_row; int col_blk; int64_t y_blk;
@@ -124,6 +139,7 @@ struct FlashArgs {
     float* out; int64_t out_batch, out_row;              // merged (b, q, h*dh + d)
     float defer_log2;           // split kernel: running max moves only past this margin (0 = always)
     float* lse;                 // optional [B*H][Lq_pad]: log2-domain log-sum-exp of every query row (training)
+    float drop_p; uint32_t drop_seed;   // training: dropout on the attention probabilities, element (bh * Lq + q) * Lk + key
 };
 int flash_key_tile(int dh);                    // keys per LDS tile
 int flash_lq_pad(int Lq);
@@ -187,7 +203,10 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
                            const float* dO, int64_t do_batch, int64_t do_head, int64_t do_row, const float* lse, const float* D,
                            float* gq, int64_t gq_batch, int64_t gq_head, int64_t gq_row, float* gk, int64_t gk_batch,
                            int64_t gk_head, int64_t gk_row, float* gv, int64_t gv_batch, int64_t gv_head, int64_t gv_row, int B, int H,
-                           int Lq, int Lk, int dh, int accumulate_kv, hipStream_t s, float* gq_part = nullptr);
+                           int Lq, int Lk, int dh, int accumulate_kv, hipStream_t s, float* gq_part = nullptr, float drop_p = 0.f,
+                           uint32_t drop_seed = 0);
+// dst = dropout(src): keep mask of stream `seed` over the (M, N) index space, scaled by 1 / (1 - p)
+hipError_t launch_dropout_apply(const float* src, float* dst, int M, int N, float p, uint32_t seed, hipStream_t s);
 size_t attn_bwd_dq_partial_floats(int B, int H, int Lq, int Lk, int dh);
 hipError_t launch_attn_bwd_rowdot(const float* dO, const float* O, int64_t batch, int64_t row, int B, int H, int Lq, int dh, float* D,
                                   hipStream_t s);
@@ -215,7 +234,7 @@ hipError_t launch_project_sample_f64(const float* tokens, const double* T_cl, co
                                      float* coord_pos, double* zero_f64, int zero_n, hipStream_t s);
 // self-attention of the Q queries in one launch (8 key slices per workgroup combined through LDS)
 hipError_t launch_self_attn(const float* qkv, int64_t row_stride, int B, int H, int Lq, int dh, float* out,
-                            int64_t out_row, hipStream_t s, float* lse = nullptr);
+                            int64_t out_row, hipStream_t s, float* lse = nullptr, float drop_p = 0.f, uint32_t drop_seed = 0);
 hipError_t launch_layernorm(const float* X, const float* gamma, const float* beta, float* Y, int M, int C,
                             float eps, hipStream_t s);
 // mean / rstd over (rows_per_scene x ncols) blocks: stats[(b * ngroups + g) * 2 + {0,1}]

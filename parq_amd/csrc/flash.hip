@@ -175,6 +175,15 @@ __global__ __launch_bounds__(NW * 64) void flash_f32_kernel(FlashArgs a) {
                 rs += __shfl_xor(rs, 32);
                 l_run = l_run * alpha + rs;
                 m_run = m_new;
+                if (a.drop_p > 0.f) {           // training: dropout on the probabilities; the normaliser stays undropped
+                    const float inv = 1.f / (1.f - a.drop_p);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint64_t key = (uint64_t)(t * KT + kb * 32 + mfma32_row(r, lane));
+                        const uint64_t idx = ((uint64_t)bh * (uint64_t)a.Lq + (uint64_t)q) * (uint64_t)a.Lk + key;
+                        sacc[r] = drop_keep(a.drop_seed, idx, a.drop_p) ? sacc[r] * inv : 0.f;
+                    }
+                }
 #pragma unroll
                 for (int d = 0; d < NDT; ++d)
 #pragma unroll
@@ -321,7 +330,8 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(FlashArgs a) {
 //     is a lane-contiguous scalar load.
 template <int DH>
 __global__ __launch_bounds__(512) void self_attn_kernel(const float* __restrict__ qkv, int64_t row_stride, int H, int L,
-                                                        float* __restrict__ out, int64_t out_row, float* __restrict__ lse) {
+                                                        float* __restrict__ out, int64_t out_row, float* __restrict__ lse,
+                                                        float drop_p, uint32_t drop_seed) {
     constexpr int NW = 8;
     constexpr int NDT = DH / 16;                 // 16-wide d sub-tiles of O^T
     constexpr int NC = DH / 16;                  // float4 chunks of a Q / K row per lane
@@ -416,6 +426,16 @@ __global__ __launch_bounds__(512) void self_attn_kernel(const float* __restrict_
         rs += __shfl_xor(rs, 32);
         l_run = l_run * alpha + rs;
         m_run = m_new;
+        if (drop_p > 0.f) {
+            const float inv = 1.f / (1.f - drop_p);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint64_t idx = ((uint64_t)bh * (uint64_t)L + (uint64_t)q) * (uint64_t)L + (uint64_t)(kb + s * 16 + 4 * kq + r);
+                    sacc[s][r] = drop_keep(drop_seed, idx, drop_p) ? sacc[s][r] * inv : 0.f;
+                }
+        }
 #pragma unroll
         for (int d = 0; d < NDT; ++d) o[d] *= alpha;
 #pragma unroll
@@ -503,18 +523,18 @@ hipError_t merge_dh(const FlashArgs& a, hipStream_t s) {
 
 template <int DH>
 static hipError_t launch_self_dh(const float* qkv, int64_t row_stride, int B, int H, int L, float* out, int64_t out_row,
-                                 hipStream_t s, float* lse) {
+                                 hipStream_t s, float* lse, float drop_p, uint32_t drop_seed) {
     const size_t lds = ((size_t)8 * DH * 17 + 2 * 8 * 16) * sizeof(float);
     hipLaunchKernelGGL((self_attn_kernel<DH>), dim3(ceil_div(L, 16), B * H), dim3(512), lds, s, qkv, row_stride, H, L, out,
-                       out_row, lse);
+                       out_row, lse, drop_p, drop_seed);
     return hipGetLastError();
 }
 
 // qkv: (B, L, row_stride) with q | k | v at column offsets 0, H*dh, 2*H*dh.  dh in {32, 64}.
 hipError_t launch_self_attn(const float* qkv, int64_t row_stride, int B, int H, int L, int dh, float* out,
-                            int64_t out_row, hipStream_t s, float* lse) {
-    if (dh == 64) return launch_self_dh<64>(qkv, row_stride, B, H, L, out, out_row, s, lse);
-    if (dh == 32) return launch_self_dh<32>(qkv, row_stride, B, H, L, out, out_row, s, lse);
+                            int64_t out_row, hipStream_t s, float* lse, float drop_p, uint32_t drop_seed) {
+    if (dh == 64) return launch_self_dh<64>(qkv, row_stride, B, H, L, out, out_row, s, lse, drop_p, drop_seed);
+    if (dh == 32) return launch_self_dh<32>(qkv, row_stride, B, H, L, out, out_row, s, lse, drop_p, drop_seed);
     return hipErrorInvalidValue;
 }
 

@@ -335,10 +335,11 @@ class PARQDecoder(nn.Module):
         return [torch.empty(*lead, wd, dtype=torch.float32, device=device) for wd in widths]
 
     def _check_mode(self):
+        """Inference entry points ignore dropout exactly like nn.Dropout in eval mode; in train mode WITHOUT autograd
+        (torch.no_grad around a training module) the reference would still drop: use forward_train for that."""
         if self.training and self.dropout_rate > 0:
-            raise NotImplementedError(
-                "parq_amd.PARQDecoder: train-mode forward (dropout %.2f, autograd) is not built yet "
-                "(SURVEY.md §8f rank 1); call .eval()" % self.dropout_rate)
+            raise RuntimeError("parq_amd.PARQDecoder is in train mode with dropout %.2f but autograd is disabled: call "
+                               ".eval() for inference or forward_train() for a dropout forward without a graph" % self.dropout_rate)
 
     # ------------------------------------------------------------------ forward (model/parq_decoder.py:134-163)
     def forward(self, intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw=None):
@@ -349,10 +350,8 @@ class PARQDecoder(nn.Module):
 
     def _forward_autograd(self, tokens, camera, T_cp, T_wp, T_wl, feat_hw):
         """Train-mode forward under autograd: one autograd node whose backward is the HIP backward chain.  Uses the exact
-        fp32 attention kernels for this call (``attention_mode`` keeps governing inference) and needs DROPOUT_RATE = 0."""
-        if self.dropout_rate > 0:
-            raise NotImplementedError("parq_amd.PARQDecoder: dropout %.2f in train mode is not built; set DROPOUT_RATE = 0 "
-                                      "or call .eval()" % self.dropout_rate)
+        fp32 attention kernels for this call (``attention_mode`` keeps governing inference).  DROPOUT_RATE > 0 applies the
+        decoder layer's six dropout sites with counter-based masks (seeded from torch's generator per call)."""
         params = [p for _, p in self._unique_params()]
         stacked = _TrainFn.apply(self, raw(tokens), camera, T_cp, T_wp, T_wl, feat_hw, *params)
         return [{k: t[i] for k, t in zip(OUTPUT_KEYS, stacked)} for i in range(self.num_layers)]
@@ -372,13 +371,16 @@ class PARQDecoder(nn.Module):
     # ------------------------------------------------------------------ training
     @torch.no_grad()
     def forward_train(self, intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw=None):
-        """Forward that keeps every iteration's activations for ``backward`` (attention mode "fp32", dropout 0).
+        """Forward that keeps every iteration's activations for ``backward`` (exact-fp32 attention kernels; dropout when
+        the module is in train mode).
         Returns the same list of dicts as ``forward``."""
-        if self.dropout_rate > 0 and self.training:
-            raise NotImplementedError("parq_amd.PARQDecoder: dropout > 0 in train mode is not built (set DROPOUT_RATE = 0)")
         sc, keep, dev = self._scene(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
         self._ensure_packed(dev)
         lib, h = _lib.load(), self._handle_in_mode("fp32")
+        # decoder-layer dropout (train mode only, as nn.Dropout): a fresh mask seed per call, reused by backward()
+        p_drop = float(self.dropout_rate) if self.training else 0.0
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
+        _lib.check(lib.parq_set_dropout(h, p_drop, seed), "parq_set_dropout")
         nbytes = lib.parq_train_workspace_bytes(h, sc.B, sc.V, sc.h, sc.w)
         if self._train_ws is None or self._train_ws.numel() * 4 < nbytes or self._train_ws.device != dev:
             self._ws.clear()

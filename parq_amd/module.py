@@ -61,7 +61,7 @@ class PARQ(_Base):
 
     def training_step(self, batch, batch_idx):
         """model/parq_lightning.py:97-100.  In train mode the decoder forward is an autograd node whose backward is the HIP
-        backward chain (DROPOUT_RATE must be 0), and AddRayPE.tokens is an autograd node too: the decoder and the ray-PE
+        backward chain, and AddRayPE.tokens is an autograd node too: the decoder and the ray-PE
         encoder receive gradients, and d loss / d features is handed to whatever produced ``all_features``."""
         losses, _ = self.forward(batch, batch_idx)
         return losses["total_loss"]

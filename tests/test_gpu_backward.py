@@ -189,3 +189,98 @@ def test_parq_module_training_steps_with_set_loss():
         losses.append(float(loss.detach()))
     print("\nset loss over AdamW steps:", ["%.4f" % x for x in losses])
     assert losses[-1] < losses[0]
+
+
+def _masked_mha(xq, xk, xv, in_w, in_b, out_w, out_b, H, pmask):
+    """nn.MultiheadAttention forward with an explicit keep-mask (already scaled by 1/(1-p)) on the probabilities."""
+    Cd = xq.shape[-1]
+    dh = Cd // H
+    q = torch.nn.functional.linear(xq, in_w[:Cd], in_b[:Cd])
+    k = torch.nn.functional.linear(xk, in_w[Cd:2 * Cd], in_b[Cd:2 * Cd])
+    v = torch.nn.functional.linear(xv, in_w[2 * Cd:], in_b[2 * Cd:])
+    B, Lq, Lk = q.shape[0], q.shape[1], k.shape[1]
+    q = q.view(B, Lq, H, dh).transpose(1, 2); k = k.view(B, Lk, H, dh).transpose(1, 2); v = v.view(B, Lk, H, dh).transpose(1, 2)
+    p = torch.softmax(q @ k.transpose(-1, -2) / dh ** 0.5, -1) * pmask.view(B, H, Lq, Lk)
+    return torch.nn.functional.linear((p @ v).transpose(1, 2).reshape(B, Lq, Cd), out_w, out_b)
+
+
+def test_dropout_forward_backward_match_masked_oracle():
+    """Train-mode dropout (six sites of the decoder layer, transformer_parq.py:339-386): the library's counter-based masks are
+    dumped (parq_k_dropout_mask) and applied at the same sites in a float64 torch restatement of the layer; outputs and all
+    gradients must then agree like in the dropout-free test.  Also: masks change with the seed, the drop rate is ~p."""
+    import ctypes as C
+    from parq_amd import _lib
+    F_ = torch.nn.functional
+    B, V, h, w, Q, dim, Hh, ffn, I = 2, 2, 8, 10, 32, 128, 2, 96, 2
+    pdrop = 0.25
+    cfg = synth.decoder_cfg(dim=dim, queries=Q, heads=Hh, ffn=ffn, layers=I, dropout=pdrop)
+    W = synth.make_decoder_weights(cfg, 101)
+    sc = synth.make_scene(102, B, V, h, w, dim, smooth=True)
+    ncls = cfg.NUM_SEMCLS + 1
+    cots = {"pred_logits": synth.normal(103, "cl", (I, B, Q, ncls)), "center_unnormalized": synth.normal(104, "cc", (I, B, Q, 3)),
+            "size_unnormalized": synth.normal(105, "cs", (I, B, Q, 3)), "ortho6d": synth.normal(106, "cr", (I, B, Q, 6))}
+    dec = make_decoder(cfg, W).train()
+    torch.manual_seed(7)
+    outs = dec.forward_train(*scene_args(sc))
+    N, M = V * h * w, B * Q
+    lib, hd = _lib.load(), dec._handle(apply_mode=False)
+
+    def mask(k, site, rows, cols):
+        t = torch.empty(rows, cols, device="cuda")
+        _lib.check(lib.parq_k_dropout_mask(hd, k, site, rows, cols, _lib.ptr(t), _lib.stream_ptr()), "mask")
+        return t.cpu().double()
+    shapes = {0: (B * Hh * Q, Q), 1: (M, dim), 2: (B * Hh * Q, N), 3: (M, dim), 4: (M, ffn), 5: (M, dim)}
+    masks = {(k, s): mask(k, s, *shapes[s]) for k in range(I) for s in range(6)}
+    frac = float((masks[(0, 2)] == 0).double().mean())
+    assert abs(frac - pdrop) < 0.01, frac
+    assert not torch.equal(masks[(0, 1)], masks[(1, 1)])
+
+    # float64 restatement with the same masks
+    od = O.OracleDecoder(cfg, W, synth.SCANNET_MEAN_SIZES, dtype=torch.float64)
+    for kk in od.W:
+        od.W[kk].requires_grad_(True)
+    od.prepare(sc["tokens"], sc["camera"], sc["T_camera_pseudoCam"], sc["T_world_pseudoCam"], sc["T_world_local"])
+    od.tokens.requires_grad_(True)
+    Wd = od.W
+    ref = od.initial_ref()
+    loss = 0.0
+    oouts = []
+    d = "parq_module.decoder.position_encoder."
+    p = "parq_module.decoder.layers.0."
+    for k in range(I):
+        pos = F_.linear(F_.relu(F_.linear(O.pos2posemb3d(ref), Wd[d + "0.weight"], Wd[d + "0.bias"])), Wd[d + "2.weight"], Wd[d + "2.bias"])
+        tgt, _, _ = O.project_and_sample(od.tokens, O.denormalize(ref, cfg.TRANSFORMER.SCALE), od.T_cl, od.cam, od.h, od.w)
+        qk = tgt + pos
+        sa = _masked_mha(qk, qk, tgt, Wd[p + "self_attn.in_proj_weight"], Wd[p + "self_attn.in_proj_bias"],
+                         Wd[p + "self_attn.out_proj.weight"], Wd[p + "self_attn.out_proj.bias"], Hh, masks[(k, 0)])
+        x = O.layer_norm(tgt + sa * masks[(k, 1)].view(B, Q, dim), Wd[p + "norm1.weight"], Wd[p + "norm1.bias"])
+        ca = _masked_mha(x + pos, od.tokens, od.tokens, Wd[p + "multihead_attn.in_proj_weight"], Wd[p + "multihead_attn.in_proj_bias"],
+                         Wd[p + "multihead_attn.out_proj.weight"], Wd[p + "multihead_attn.out_proj.bias"], Hh, masks[(k, 2)])
+        x = O.layer_norm(x + ca * masks[(k, 3)].view(B, Q, dim), Wd[p + "norm2.weight"], Wd[p + "norm2.bias"])
+        hid = F_.relu(F_.linear(x, Wd[p + "linear1.weight"], Wd[p + "linear1.bias"])) * masks[(k, 4)].view(B, Q, ffn)
+        ff = F_.linear(hid, Wd[p + "linear2.weight"], Wd[p + "linear2.bias"])
+        x = O.layer_norm(x + ff * masks[(k, 5)].view(B, Q, dim), Wd[p + "norm3.weight"], Wd[p + "norm3.bias"])
+        out = O.box_heads(x, ref, Wd, cfg.TRANSFORMER.SCALE, od.mean_sizes)
+        oouts.append(out)
+        for key in GKEYS:
+            loss = loss + (out[key] * torch.from_numpy(cots[key][k]).double()).sum()
+        ref = O.normalize(out["center_unnormalized"], cfg.TRANSFORMER.SCALE).detach()
+    loss.backward()
+    for k in range(I):
+        for key in GKEYS:
+            a, b = outs[k][key].cpu().numpy(), oouts[k][key].detach().numpy()
+            assert np.abs(a - b).max() / max(1.0, np.abs(b).max()) < 1e-4, (k, key)
+    grads, d_tok = dec.backward({k: torch.from_numpy(v) for k, v in cots.items()})
+    worst = {}
+    for name, g in grads.items():
+        if name in Wd and Wd[name].grad is not None:
+            refg = Wd[name].grad.numpy()
+            dd = g.cpu().numpy().astype(np.float64) - refg
+            worst[name] = np.linalg.norm(dd) / max(np.linalg.norm(refg), 1e-9)
+    print("\nworst gradient errors with dropout:", sorted(worst.items(), key=lambda kv: -kv[1])[:4])
+    assert max(worst.values()) < 2e-3, max(worst.values())
+    rt = od.tokens.grad.numpy()
+    assert np.linalg.norm(d_tok.cpu().numpy() - rt) / np.linalg.norm(rt) < 2e-3
+    # a second call draws a new seed -> different outputs; eval mode ignores dropout
+    outs2 = dec.forward_train(*scene_args(sc))
+    assert not torch.equal(outs2[0]["ortho6d"], outs[0]["ortho6d"])

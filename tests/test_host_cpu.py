@@ -90,7 +90,7 @@ def test_decoder_refuses_cpu_tensors():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         dec(torch.from_numpy(sc["tokens"]), Camera(sc["camera"]), Pose(sc["T_camera_pseudoCam"]),
             Pose(sc["T_world_pseudoCam"]), Pose(sc["T_world_local"]))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):          # the training path has no CPU fallback either
         dec.train()(torch.from_numpy(sc["tokens"]), Camera(sc["camera"]), Pose(sc["T_camera_pseudoCam"]),
                     Pose(sc["T_world_pseudoCam"]), Pose(sc["T_world_local"]))
 
