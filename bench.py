@@ -139,7 +139,7 @@ def train_bench(args):
     """--train: one data-parallel training step per "step" at the per-GPU shard of BASELINE config 4 (batch 32 scenes over 8 GPUs
     = 4 scenes per GPU, 10 views, 256 queries, 8 iterations): decoder forward with saved activations, the reference's set loss on
     synthetic boxes, HIP backward, ONE all-reduce of the flat gradient arena over RCCL, AdamW.  Reported beside the headline
-    metric (which stays the inference number); dropout 0, exact-fp32 attention kernels."""
+    metric (which stays the inference number); dropout 0.1 as in config/train.yaml, exact-fp32 attention kernels."""
     from parq_amd import Obb3D, PARQDecoder, Pose, parallel, synth
     rank, local_rank, world = parallel.env_world()
     torch.cuda.set_device(local_rank)
@@ -147,7 +147,7 @@ def train_bench(args):
     parallel.init(backend="nccl" if world > 1 else None, device=device)
     B = args.scenes_per_gpu if args.scenes_per_gpu > 1 else 4
     V, (h, w), Q, C, I = WORKLOAD["views"], WORKLOAD["feat_hw"], WORKLOAD["queries"], WORKLOAD["dim"], WORKLOAD["iters"]
-    cfg = synth.decoder_cfg(dim=C, queries=Q, heads=WORKLOAD["heads"], ffn=WORKLOAD["ffn"], layers=I, dropout=0.0)
+    cfg = synth.decoder_cfg(dim=C, queries=Q, heads=WORKLOAD["heads"], ffn=WORKLOAD["ffn"], layers=I, dropout=0.1)   # config/train.yaml:53
     W = synth.make_decoder_weights(cfg, 41, damped=True)
     dec = PARQDecoder(cfg)
     dec.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=False)
@@ -185,7 +185,7 @@ def train_bench(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "final_loss": float(loss),
             "config": {"workload": "BASELINE cfg4 per-GPU shard: %d scenes, 10 views 480x640 (120x160 features), 256 queries, 8 iterations, "
-                                   "d=256; dropout 0; 12 synthetic boxes per scene" % B,
+                                   "d=256; dropout 0.1; 12 synthetic boxes per scene" % B,
                        "scenes_per_gpu": B, "parallelism": "dp%d (one flat gradient all-reduce per step)" % world}}))
     if world > 1:
         parallel.barrier()
