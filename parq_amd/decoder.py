@@ -213,6 +213,7 @@ class PARQDecoder(nn.Module):
         self._ws = {}
         self._matcher = None
         self._train_ws = None
+        self.loss_batched = True          # loss(): all (iteration, scene) pairs in ~40 launches (False: the reference's per-pair loop)
         self.dp_all_reduce = False        # True: backward() all-reduces the flat gradient arena over the default process group
         self._mean_dev = None
 
@@ -491,13 +492,14 @@ class PARQDecoder(nn.Module):
     def loss(self, out_dict_list, obbs_padded, T_world_local, sym=None, *argv):
         """Hungarian-matched set loss, model/parq_decoder.py:264-370 (host-side torch + scipy as in the reference;
         parq_amd/loss.py).  Under autograd its gradient reaches the weights through the HIP backward chain."""
-        from .loss import HungarianMatcherModified, decoder_loss
+        from .loss import HungarianMatcherModified, decoder_loss, decoder_loss_batched
         if self._matcher is None:
             self._matcher = HungarianMatcherModified(cost_class=2, cost_bbox=0.25)          # parq_decoder.py:71
             self._class_weight = torch.ones(self.num_semcls + 1)
             self._class_weight[self.num_semcls] = 0.1                                        # background (:46-48)
-        return decoder_loss(out_dict_list, obbs_padded, T_world_local, sym, matcher=self._matcher,
-                            loss_weight=self.loss_weight, num_semcls=self.num_semcls, class_weight=self._class_weight)
+        fn = decoder_loss_batched if self.loss_batched else decoder_loss
+        return fn(out_dict_list, obbs_padded, T_world_local, sym, matcher=self._matcher, loss_weight=self.loss_weight,
+                  num_semcls=self.num_semcls, class_weight=self._class_weight)
 
     @torch.no_grad()
     def parse_pred(self, out_dict):

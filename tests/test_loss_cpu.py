@@ -12,28 +12,30 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
 from make_golden import LOSS_CASE, loss_case_inputs  # noqa: E402  (inputs are regenerated from the seed: data only)
 from parq_amd import Obb3D, Pose  # noqa: E402
-from parq_amd.loss import HungarianMatcherModified, decoder_loss, rot_to_6d, rotation_from_ortho6d  # noqa: E402
+from parq_amd.loss import (HungarianMatcherModified, decoder_loss, decoder_loss_batched, rot_to_6d,  # noqa: E402
+                           rotation_from_ortho6d)
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "g10_loss.npz")
 
 
-def _loss(sym_on):
+def _loss(sym_on, fn=decoder_loss):
     c = LOSS_CASE
     outs, obbs, T_wl, sym = loss_case_inputs(c)
     touts = [{k: torch.from_numpy(v) for k, v in o.items()} for o in outs]
     cw = torch.ones(10)
     cw[9] = 0.1
     np.random.seed(c["np_seed"])
-    return decoder_loss(touts, Obb3D(torch.from_numpy(obbs)), Pose(torch.from_numpy(T_wl)), torch.from_numpy(sym) if sym_on else None,
-                        matcher=HungarianMatcherModified(cost_class=2, cost_bbox=0.25), loss_weight=[5.0, 5.0, 5.0, 1.0],
-                        num_semcls=9, class_weight=cw)
+    return fn(touts, Obb3D(torch.from_numpy(obbs)), Pose(torch.from_numpy(T_wl)), torch.from_numpy(sym) if sym_on else None,
+              matcher=HungarianMatcherModified(cost_class=2, cost_bbox=0.25), loss_weight=[5.0, 5.0, 5.0, 1.0],
+              num_semcls=9, class_weight=cw)
 
 
+@pytest.mark.parametrize("fn", [decoder_loss, decoder_loss_batched])
 @pytest.mark.parametrize("tag,sym_on", [("sym", True), ("nosym", False)])
-def test_loss_matches_reference_golden(tag, sym_on):
+def test_loss_matches_reference_golden(tag, sym_on, fn):
     z = np.load(GOLD)
     assert json.loads(bytes(z["meta"]).decode()) == json.loads(json.dumps(LOSS_CASE))
-    got = _loss(sym_on)
+    got = _loss(sym_on, fn)
     for k in ("center_loss", "size_loss", "rot_loss", "cat_loss", "total_loss"):
         want = float(z["%s_%s" % (tag, k)])
         assert abs(float(got[k]) - want) < 2e-5 * max(1.0, abs(want)), (k, float(got[k]), want)
@@ -55,3 +57,20 @@ def test_rotation_6d_round_trip_and_empty_scene():
     l = decoder_loss(touts, Obb3D(torch.from_numpy(obbs2)), Pose(torch.from_numpy(T_wl)), None,
                      matcher=HungarianMatcherModified(2, 0.25), loss_weight=[5.0, 5.0, 5.0, 1.0], num_semcls=9, class_weight=cw)
     assert torch.isfinite(l["total_loss"])
+
+
+def test_batched_loss_gradients_equal_the_loop_version():
+    c = LOSS_CASE
+    outs, obbs, T_wl, sym = loss_case_inputs(c)
+    cw = torch.ones(10)
+    cw[9] = 0.1
+    grads = []
+    for fn in (decoder_loss, decoder_loss_batched):
+        touts = [{k: torch.from_numpy(v).clone().requires_grad_(k != "coord_pos") for k, v in o.items()} for o in outs]
+        np.random.seed(c["np_seed"])
+        l = fn(touts, Obb3D(torch.from_numpy(obbs)), Pose(torch.from_numpy(T_wl)), torch.from_numpy(sym),
+               matcher=HungarianMatcherModified(2, 0.25), loss_weight=[5.0, 5.0, 5.0, 1.0], num_semcls=9, class_weight=cw)
+        l["total_loss"].backward()
+        grads.append([o[k].grad.clone() for o in touts for k in ("pred_logits", "center_unnormalized", "size_unnormalized", "ortho6d")])
+    for a, b in zip(*grads):
+        assert torch.allclose(a, b, atol=1e-6, rtol=1e-5)
