@@ -149,8 +149,8 @@ int parq_profile_enable(parq_handle h, int32_t on);
 int parq_profile_read(parq_handle h, int32_t which, double *total_ms, int64_t *launches);
 
 /* ---- training: forward with saved activations + backward (model/parq_lightning.py:97-100) ----------
- * The backward of the whole decoder chain as HIP kernels.  Needs attention mode 0 (the backward reads the fp32 K/V cache),
- * head dim 32/64.  parq_forward_train = parq_forward that keeps every iteration's activations in the (larger)
+ * The backward of the whole decoder chain as HIP kernels.  Attention mode 0 or 1 (in mode 1 the forward streams the split
+ * cache and the backward gets fp32 K / V rebuilt from it), head dim 32/64.  parq_forward_train = parq_forward that keeps every iteration's activations in the (larger)
  * training workspace; parq_backward consumes them: `grads` holds d loss / d output per iteration (same (I,B,Q,k) layout as
  * the outputs, NULL = zero), `grad_arena` receives d loss / d weight in the layout of the packed weight arena
  * (parq_arena_lookup maps reference tensor names to offsets), `d_tokens` (B,N,C) or NULL receives d loss / d input tokens.

@@ -68,7 +68,7 @@ struct Workspace {
     int64_t sa, ln3, lse_s, lse_c, refk;
     int64_t iter_begin, iter_end, stash;
     // backward scratch (training workspace only)
-    int64_t g_a, g_b, g_c, g_pos, g_tmp, g_ffh, g_h1, g_h2, g_z, g_act, g_h3, g_qkv, g_emb, g_ref, g_D, g_bs, wT, g_kv, g_dqp, g_drop;
+    int64_t g_a, g_b, g_c, g_pos, g_tmp, g_ffh, g_h1, g_h2, g_z, g_act, g_h3, g_qkv, g_emb, g_ref, g_D, g_bs, wT, g_kv, g_dqp, g_drop, kv_train;
     int64_t train_total;
     int64_t shift(int k) const { return k == 0 ? 0 : stash + (int64_t)(k - 1) * (iter_end - iter_begin) - iter_begin; }
 };
@@ -174,7 +174,8 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     // transposed weight copies of one layer: heads1 [C][NH1], heads2 2x[C][C], lin1^T [C][F], lin2^T [F][C],
     // cross_out^T, cross_q^T, self_out^T [C][C] each, self_in^T [C][3C], pe2^T [C][C], pe0^T [384][C]
     ws->wT = take(C * NH1 + 2 * C * C + 2 * C * F + 3 * C * C + 3 * C * C + C * C + 384 * C);
-    ws->g_kv = take(split_mode ? 0 : (int64_t)c->nl * B * 2 * N * C);
+    ws->g_kv = take((int64_t)c->nl * B * 2 * N * C);
+    ws->kv_train = take(split_mode ? (int64_t)c->nl * B * 2 * N * C : 0);     // fp32 K / V rebuilt from the split cache for the backward
     ws->g_dqp = take((int64_t)attn_bwd_dq_partial_floats(B, c->H, (int)Q, (int)N, c->dh));
     ws->g_drop = take(M * C);
     ws->train_total = off;
@@ -545,7 +546,7 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     HIPCHK(launch_attn_bwd_rowdot(gA, wi + ws.attn, (int64_t)Q * C, C, B, H, Q, dh, Dd, s));
     HIPCHK(hipMemsetAsync(gC, 0, (size_t)M * C * sizeof(float), s));                           // gC = d / d q (atomics)
     {
-        const float* kv = wsp + ws.kv + (int64_t)li * B * 2 * N * C;
+        const float* kv = wsp + (c->cache_mode() ? ws.kv_train : ws.kv) + (int64_t)li * B * 2 * N * C;
         // dK | dV accumulate token-major: g_kv[layer][b][n][2C], K heads at columns h*dh, V heads at C + h*dh
         float* gkv = wsp + ws.g_kv + (int64_t)li * B * 2 * N * C;
         HIPCHK(launch_attn_bwd(wi + ws.qc, (int64_t)Q * C, dh, C, kv, 2 * N * C, N * dh, dh, kv + (int64_t)H * N * dh, 2 * N * C, N * dh, dh,
@@ -909,7 +910,8 @@ int parq_forward_train(parq_handle h, const parq_scene* scene, void* workspace, 
                        parq_stream stream) {
     if (!h || !workspace) return fail(PARQ_ERR_ARG, "NULL argument");
     if (!h->packed) return fail(PARQ_ERR_STATE, "parq_pack_weights must be called first");
-    if (h->cache_mode()) return fail(PARQ_ERR_STATE, "training needs attention mode 0 (the backward reads the fp32 K/V cache)");
+    if (h->cache_mode() && h->terms() != 3)
+        return fail(PARQ_ERR_STATE, "training needs attention mode 0 or 1 (the backward works on fp32-accurate K / V)");
     if (h->dh != 64 && h->dh != 32) return fail(PARQ_ERR_ARG, "training needs head dim 32 or 64");
     int rc = check_scene(h, scene);
     if (rc) return rc;
@@ -923,6 +925,16 @@ int parq_forward_train(parq_handle h, const parq_scene* scene, void* workspace, 
     rc = do_prepare(h, scene, wsp, ws, s);
     if (rc) return rc;
     const int64_t M = (int64_t)scene->B * h->Q;
+    if (h->cache_mode()) {
+        // split mode: the forward streams the split cache; the backward gets fp32 K / V rebuilt from it (hi + lo)
+        const int64_t N = (int64_t)scene->V * scene->h * scene->w;
+        const int C = h->C, dh = h->dh, H = h->H, B = scene->B;
+        for (int li = 0; li < h->nl; ++li) {
+            const char* cache = reinterpret_cast<const char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, H, (int)N, 3);
+            float* kv = wsp + ws.kv_train + (int64_t)li * B * 2 * N * C;
+            HIPCHK(launch_kvsplit_to_f32(cache, B, H, (int)N, kv, kv + (int64_t)H * N * dh, 2 * N * C, N * dh, 2 * N * C, N * dh, s));
+        }
+    }
     // the reference points of iteration k live in that iteration's stash (initial_ref wrote ws.ref)
     HIPCHK(hipMemcpyAsync(wsp + ws.shift(0) + ws.refk, wsp + ws.ref, (size_t)M * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
     for (int k = 0; k < h->I; ++k) {
@@ -948,7 +960,7 @@ int parq_backward(parq_handle h, const parq_scene* scene, void* workspace, size_
                   const parq_output_grads* g, float* grad_arena, float* d_tokens, parq_stream stream) {
     if (!h || !workspace || !outs || !g || !grad_arena) return fail(PARQ_ERR_ARG, "NULL argument");
     if (!h->packed) return fail(PARQ_ERR_STATE, "parq_pack_weights must be called first");
-    if (h->cache_mode()) return fail(PARQ_ERR_STATE, "training needs attention mode 0");
+    if (h->cache_mode() && h->terms() != 3) return fail(PARQ_ERR_STATE, "training needs attention mode 0 or 1");
     int rc = check_scene(h, scene);
     if (rc) return rc;
     Workspace ws;

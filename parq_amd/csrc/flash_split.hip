@@ -116,6 +116,45 @@ __global__ __launch_bounds__(256) void kvsplit_convert_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+// split cache -> fp32 head-major K / V ([b][h][n][64]): hi + lo is the fp32 value to 2^-22.  Training runs the forward on
+// the split cache and hands the backward kernels plain fp32 K / V rebuilt from it (instead of a second, fp32 projection).
+__global__ __launch_bounds__(256) void kvsplit_to_f32_kernel(const _Float16* __restrict__ cache, int H, int N, float* __restrict__ K,
+                                                             float* __restrict__ V, int64_t k_batch, int64_t k_head, int64_t v_batch,
+                                                             int64_t v_head) {
+    const int blk = blockIdx.x, bh = blockIdx.y;
+    const int b = bh / H, h = bh - b * H;
+    const int nblk = (N + 31) / 32;
+    const _Float16* in = cache + ((int64_t)bh * nblk + blk) * Blk<3>::halfs;
+    float* kp = K + (int64_t)b * k_batch + (int64_t)h * k_head;
+    float* vp = V + (int64_t)b * v_batch + (int64_t)h * v_head;
+    {   // K: thread -> (key, stored chunk position)
+        const int key = threadIdx.x >> 3, pos = threadIdx.x & 7;
+        const int c = pos ^ ((key >> 1) & 7), kh = c >> 2, s2 = c & 3;
+        const half8 hi = *reinterpret_cast<const half8*>(in + key * 64 + pos * 8);
+        const half8 lo = *reinterpret_cast<const half8*>(in + Blk<3>::k_lo + key * 64 + pos * 8);
+        const int n = blk * 32 + key;
+        if (n < N) {
+            const int d0 = 32 * (s2 >> 1) + 16 * (s2 & 1) + 4 * kh;
+            float4 a = {(float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]};
+            float4 c4 = {(float)hi[4] + (float)lo[4], (float)hi[5] + (float)lo[5], (float)hi[6] + (float)lo[6], (float)hi[7] + (float)lo[7]};
+            *reinterpret_cast<float4*>(kp + (int64_t)n * 64 + d0) = a;
+            *reinterpret_cast<float4*>(kp + (int64_t)n * 64 + d0 + 8) = c4;
+        }
+    }
+    {   // V: thread -> (d, stored chunk position)
+        const int d = threadIdx.x >> 2, pos = threadIdx.x & 3;
+        const int c = pos ^ ((d >> 2) & 3), m = c >> 1, kh = c & 1;
+        const half8 hi = *reinterpret_cast<const half8*>(in + Blk<3>::v_hi + d * 32 + pos * 8);
+        const half8 lo = *reinterpret_cast<const half8*>(in + Blk<3>::v_lo + d * 32 + pos * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = blk * 32 + 16 * m + 4 * kh + (e & 3) + 8 * (e >> 2);
+            if (n < N) vp[(int64_t)n * 64 + d] = (float)hi[e] + (float)lo[e];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LDS holds a ring of kRing stages filled by LDS-DMA; every wave passes ONE workgroup barrier per stage (its
 // "sync point": wait for its own DMA of stage t+2, barrier, request stage t+3 into the slot of stage t-1).
 // Measured and rejected on this structure (flash launch, cfg 3): locking the two waves of a SIMD half a stage
@@ -128,7 +167,9 @@ constexpr int kRing = 4;
 
 // TERMS = 3: fp16 hi/lo split products (fp32-class accuracy).  TERMS = 1: single fp16 / bf16 products (KIND) —
 // the reduced-precision modes of BASELINE configs 2 and 5; same structure, a third of the MFMAs, half the bytes.
-template <int TERMS, int KIND>
+// DROP: training-time dropout on the probabilities (counter-based keep mask of FlashArgs::drop_seed, see common.hpp); a
+// separate instantiation so that the inference kernel keeps its register allocation.
+template <int TERMS, int KIND, bool DROP = false>
 __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, const _Float16* __restrict__ cache) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];       // [kRing stages][kStageBlks][block]
     constexpr int kBlkBytes = Blk<TERMS>::bytes;
@@ -291,6 +332,15 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
                     p[e] = __builtin_amdgcn_exp2f(sacc[kb][8 * m + e] - m_run);
                     rs += p[e];
                 }
+                if constexpr (DROP) {           // the normaliser above stays undropped (nn.MultiheadAttention dropout)
+                    const float inv = 1.f / (1.f - a.drop_p);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const uint64_t key = (uint64_t)((t * kStageBlks + kb) * kBlkKeys + mfma32_row(8 * m + e, lane));
+                        const uint64_t idx = ((uint64_t)bh * (uint64_t)a.Lq + (uint64_t)q) * (uint64_t)a.Lk + key;
+                        p[e] = drop_keep(a.drop_seed, idx, a.drop_p) ? p[e] * inv : 0.f;
+                    }
+                }
                 if constexpr (TERMS == 3) split8(p, phi[kb][m], plo[kb][m]);
                 else phi[kb][m] = cvt8_rn<KIND>(p);
             };
@@ -429,18 +479,25 @@ hipError_t launch_kvsplit_convert(const float* K, const float* V, int64_t k_batc
     return hipGetLastError();
 }
 
-template <int TERMS, int KIND>
+hipError_t launch_kvsplit_to_f32(const void* cache, int B, int H, int N, float* K, float* V, int64_t k_batch, int64_t k_head,
+                                 int64_t v_batch, int64_t v_head, hipStream_t s) {
+    hipLaunchKernelGGL(kvsplit_to_f32_kernel, dim3(ceil_div(N, kBlkKeys), B * H), dim3(256), 0, s, reinterpret_cast<const _Float16*>(cache),
+                       H, N, K, V, k_batch, k_head, v_batch, v_head);
+    return hipGetLastError();
+}
+
+template <int TERMS, int KIND, bool DROP = false>
 static hipError_t launch_flash_t(const FlashArgs& b, const void* cache, hipStream_t s) {
     static bool attr_set = false;
     const size_t lds = (size_t)kRing * kStageBlks * Blk<TERMS>::bytes;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_split_kernel<TERMS, KIND>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_split_kernel<TERMS, KIND, DROP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * b.H);
-    hipLaunchKernelGGL((flash_split_kernel<TERMS, KIND>), grid, dim3(kNW * 64), lds, s, b, reinterpret_cast<const _Float16*>(cache));
+    hipLaunchKernelGGL((flash_split_kernel<TERMS, KIND, DROP>), grid, dim3(kNW * 64), lds, s, b, reinterpret_cast<const _Float16*>(cache));
     return hipGetLastError();
 }
 
@@ -449,7 +506,8 @@ hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t
     FlashArgs b = a;
     b.defer_log2 = kDeferLog2;
     if (const char* e = getenv("PARQ_DEFER_LOG2")) b.defer_log2 = (float)atof(e);      // debugging knob
-    if (terms == 3) return launch_flash_t<3, kF16>(b, cache, s);
+    if (terms == 3) return b.drop_p > 0.f ? launch_flash_t<3, kF16, true>(b, cache, s) : launch_flash_t<3, kF16>(b, cache, s);
+    if (b.drop_p > 0.f) return hipErrorInvalidValue;           // dropout exists on the fp32-accurate paths only
     return kind == kF16 ? launch_flash_t<1, kF16>(b, cache, s) : launch_flash_t<1, kBF16>(b, cache, s);
 }
 

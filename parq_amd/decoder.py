@@ -238,6 +238,11 @@ class PARQDecoder(nn.Module):
             self._ws.clear()
         return self._h
 
+    def _train_mode(self):
+        """Attention arithmetic of the training entry points: the split-precision forward when the head dim allows it (the
+        backward kernels then work on fp32 K / V rebuilt from the split cache), else the exact-fp32 kernels."""
+        return "split" if self.dim_in // self.num_heads == 64 and self.attention_mode != "fp32" else "fp32"
+
     def _handle_in_mode(self, mode):
         """The handle switched to `mode` without touching the user-facing ``attention_mode`` (the training entry points need
         the exact-fp32 attention kernels: their backward reads the fp32 K/V cache); the next inference call switches back."""
@@ -377,7 +382,7 @@ class PARQDecoder(nn.Module):
         Returns the same list of dicts as ``forward``."""
         sc, keep, dev = self._scene(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
         self._ensure_packed(dev)
-        lib, h = _lib.load(), self._handle_in_mode("fp32")
+        lib, h = _lib.load(), self._handle_in_mode(self._train_mode())
         # decoder-layer dropout (train mode only, as nn.Dropout): a fresh mask seed per call, reused by backward()
         p_drop = float(self.dropout_rate) if self.training else 0.0
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
@@ -399,7 +404,7 @@ class PARQDecoder(nn.Module):
         size_unnormalized / ortho6d -> (I, B, Q, k) cotangents (missing = zero).  Returns ({reference tensor name:
         gradient}, d_tokens or None); gradients of tensors registered under two names are returned once per name."""
         sc, keep, outs, po, dev = self._train_state
-        lib, h = _lib.load(), self._handle_in_mode("fp32")
+        lib, h = _lib.load(), self._handle_in_mode(self._train_mode())
         gs = []
         for key, wd in (("pred_logits", self.num_semcls + 1), ("center_unnormalized", 3), ("size_unnormalized", 3), ("ortho6d", 6)):
             g = grad_outputs.get(key)
