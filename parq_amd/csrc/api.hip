@@ -552,7 +552,8 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
         HIPCHK(launch_attn_bwd(wi + ws.qc, (int64_t)Q * C, dh, C, kv, 2 * N * C, N * dh, dh, kv + (int64_t)H * N * dh, 2 * N * C, N * dh, dh,
                                gA, (int64_t)Q * C, dh, C, wi + ws.lse_c, Dd, gC, (int64_t)Q * C, dh, C, gkv, 2 * N * C, dh, 2 * C,
                                gkv + C, 2 * N * C, dh, 2 * C, B, H, Q, (int)N, dh, 1, s,
-                               attn_bwd_dq_partial_floats(B, H, Q, (int)N, dh) ? wsp + ws.g_dqp : nullptr, dp, c->site_seed(k, 2)));
+                               attn_bwd_dq_partial_floats(B, H, Q, (int)N, dh) ? wsp + ws.g_dqp : nullptr, dp, c->site_seed(k, 2),
+                               reinterpret_cast<unsigned int*>(wsp + ws.g_bs)));      // g_bs: free between the GroupNorm passes
     }
     // q = (x1 + pos) Wq^T + bq,  x1 = norm1(xa)
     HIPCHK(launch_layernorm(wi + ws.xa, A + L.n1_w, A + L.n1_b, tmp, M, C, eps, s));

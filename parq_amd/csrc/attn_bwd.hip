@@ -11,6 +11,8 @@
 #include "common.hpp"
 
 #include <cstdlib>
+#include <cstring>
+#include <cmath>
 
 namespace parq {
 
@@ -90,8 +92,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
             const float p = ok ? __builtin_amdgcn_exp2f(s * c2 - st[i]) : 0.f;
             float keep = 1.f;
             if (a.drop_p > 0.f)
-                keep = drop_keep(a.drop_seed, ((uint64_t)bh * (uint64_t)a.Lq + (uint64_t)(i0 + i)) * (uint64_t)a.Lk + (uint64_t)j, a.drop_p)
-                           ? 1.f / (1.f - a.drop_p) : 0.f;
+                keep = drop_keep(drop_rowhash(a.drop_seed, (uint32_t)(bh * a.Lq + i0 + i)), (uint32_t)j, a.drop_p) ? 1.f / (1.f - a.drop_p) : 0.f;
             const float ds = p * (dp * keep - st[32 + i]);
             dS[i * 257 + tid] = ds;
 #pragma unroll
@@ -233,8 +234,7 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_mfma_kernel(AttnBwdArgs a) 
             const float p = ok ? __builtin_amdgcn_exp2f(sacc[r] * c2 - st[qi]) : 0.f;
             float keep = 1.f;
             if (a.drop_p > 0.f)
-                keep = drop_keep(a.drop_seed, ((uint64_t)bh * (uint64_t)a.Lq + (uint64_t)(i0 + qi)) * (uint64_t)a.Lk + (uint64_t)j, a.drop_p)
-                           ? 1.f / (1.f - a.drop_p) : 0.f;
+                keep = drop_keep(drop_rowhash(a.drop_seed, (uint32_t)(bh * a.Lq + i0 + qi)), (uint32_t)j, a.drop_p) ? 1.f / (1.f - a.drop_p) : 0.f;
             const float ds = p * (pacc[r] * keep - st[32 + qi]);
             sacc[r] = p * keep;
             pacc[r] = ds;
@@ -305,6 +305,278 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_mfma_kernel(AttnBwdArgs a) 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Split-precision version of the kernel above (head dim 64, 256 keys per workgroup): every product runs on the fp16 matrix
+// pipe as hi*hi + hi*lo + lo*hi with fp32 accumulation (fp32-class accuracy, see flash_split.hip), 5.3x fewer MFMA cycles
+// than the exact-fp32 kernel.  dO is multiplied by a power of two `oscale` (chosen by the caller from max|dO|) so that the
+// small gradient values keep their low halves out of the fp16 subnormals; results are multiplied back (exact).
+//   LDS (fp16 hi and lo images of everything an MFMA reads as A or as a key-indexed B operand):
+//     Qa / Oa [32 q][64 d]   rows, 8-d chunks swizzled by (q>>1)&7        -> A of S = Q K^T and dP = dO V^T
+//     Qt / Ot [64 d][32 q]   d-major, chunk (m, kh) holds queries 16m+4kh+(e&3)+8(e>>2), swizzled by (d>>2)&3
+//                                                                          -> A of dK^T += Q^T dS and dV^T += dO^T P
+//     Ds      [32 q][256 j]  8-key chunks swizzled by q&15                -> A of dQ = dS K   (16x16x32 MFMA)
+//     Kt      [64 d][256 j]  8-key chunks swizzled by d&15                -> B of dQ = dS K
+//   registers: K_j, V_j fragments (B of S / dP), P and dS accumulators re-used as B operands (rows = queries), dK^T, dV^T.
+constexpr int kSpKW = 256;
+
+__device__ __forceinline__ void split4(const float* x, _Float16* hi, _Float16* lo) {
+    half2v h0, l0, h1, l1;
+    split_pair(x[0], x[1], h0, l0);
+    split_pair(x[2], x[3], h1, l1);
+    hi[0] = h0[0]; hi[1] = h0[1]; hi[2] = h1[0]; hi[3] = h1[1];
+    lo[0] = l0[0]; lo[1] = l0[1]; lo[2] = l1[0]; lo[3] = l1[1];
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(512) void attn_bwd_split_kernel(AttnBwdArgs a, const float* __restrict__ oscale_ptr) {
+    const float oscale = *oscale_ptr;
+    extern __shared__ __attribute__((aligned(16))) _Float16 sm[];
+    _Float16* Qa = sm;                      // [hi | lo][32][64]
+    _Float16* Oa = Qa + 2 * 2048;
+    _Float16* Qt = Oa + 2 * 2048;           // [hi | lo][64][32]
+    _Float16* Ot = Qt + 2 * 2048;
+    _Float16* Ds = Ot + 2 * 2048;           // [hi | lo][32][256]
+    _Float16* Kt = Ds + 2 * 8192;           // [hi | lo][64][256]
+    float* st = reinterpret_cast<float*>(Kt + 2 * 16384);   // [2][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+    const int jw = wave * 32 + li;                   // key inside the workgroup
+    const int j = blockIdx.x * kSpKW + jw;
+    const bool jok = j < a.Lk;
+    const int Lq_pad = (a.Lq + 31) & ~31;
+    const float c2 = 1.4426950408889634f / 8.f, cn = 1.f / 8.f;
+    const float inv_os = 1.f / oscale;
+
+    // ---- K, V of this lane's key as B fragments: step t holds d = 16 t + 8 kh + e; K also goes d-major into LDS
+    half8 kfh[4], kfl[4], vfh[4], vfl[4];
+    {
+        const float* kp = a.k + (int64_t)b * a.k_batch + (int64_t)h * a.k_head + (int64_t)(jok ? j : 0) * a.k_row;
+        const float* vp = a.v + (int64_t)b * a.v_batch + (int64_t)h * a.v_head + (int64_t)(jok ? j : 0) * a.v_row;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int d0 = 16 * t + 8 * kh;
+            float kx[8], vx[8];
+#pragma unroll
+            for (int e = 0; e < 8; e += 4) {
+                const float4 k4 = *reinterpret_cast<const float4*>(kp + d0 + e);
+                const float4 v4 = *reinterpret_cast<const float4*>(vp + d0 + e);
+                kx[e] = jok ? k4.x : 0.f; kx[e + 1] = jok ? k4.y : 0.f; kx[e + 2] = jok ? k4.z : 0.f; kx[e + 3] = jok ? k4.w : 0.f;
+                vx[e] = jok ? v4.x : 0.f; vx[e + 1] = jok ? v4.y : 0.f; vx[e + 2] = jok ? v4.z : 0.f; vx[e + 3] = jok ? v4.w : 0.f;
+            }
+            split8(kx, kfh[t], kfl[t]);
+            split8(vx, vfh[t], vfl[t]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int d = d0 + e;
+                const int off = d * 256 + (((jw >> 3) ^ (d & 15)) << 3) + (jw & 7);
+                Kt[off] = kfh[t][e];
+                Kt[16384 + off] = kfl[t][e];
+            }
+        }
+    }
+    f32x16 gk[2], gv[2];                    // dK^T, dV^T: rows d (2 x 32), columns this wave's keys
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { gk[dt][r] = 0.f; gv[dt][r] = 0.f; }
+
+    for (int i0 = 0; i0 < a.Lq; i0 += 32) {
+        __syncthreads();                                    // previous tile fully consumed (also orders the Kt writes)
+        {   // tile loader: thread -> (query i, 4 consecutive d); both layouts, hi and lo
+            const int i = tid >> 4, d4 = (tid & 15) * 4;
+            const bool ok = i0 + i < a.Lq;
+            float q4[4] = {0.f, 0.f, 0.f, 0.f}, o4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                const float4 qq = *reinterpret_cast<const float4*>(a.q + (int64_t)b * a.q_batch + (int64_t)h * a.q_head + (int64_t)(i0 + i) * a.q_row + d4);
+                const float4 oo = *reinterpret_cast<const float4*>(a.dO + (int64_t)b * a.do_batch + (int64_t)h * a.do_head + (int64_t)(i0 + i) * a.do_row + d4);
+                q4[0] = qq.x; q4[1] = qq.y; q4[2] = qq.z; q4[3] = qq.w;
+                o4[0] = oo.x * oscale; o4[1] = oo.y * oscale; o4[2] = oo.z * oscale; o4[3] = oo.w * oscale;
+            }
+            _Float16 qh[4], ql[4], oh[4], ol[4];
+            split4(q4, qh, ql);
+            split4(o4, oh, ol);
+            const int ca = ((d4 >> 3) ^ ((i >> 1) & 7)) * 8 + (d4 & 4);       // natural layout: chunk swizzle, 4-half offset
+            typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<half4v*>(Qa + i * 64 + ca) = half4v{qh[0], qh[1], qh[2], qh[3]};
+            *reinterpret_cast<half4v*>(Qa + 2048 + i * 64 + ca) = half4v{ql[0], ql[1], ql[2], ql[3]};
+            *reinterpret_cast<half4v*>(Oa + i * 64 + ca) = half4v{oh[0], oh[1], oh[2], oh[3]};
+            *reinterpret_cast<half4v*>(Oa + 2048 + i * 64 + ca) = half4v{ol[0], ol[1], ol[2], ol[3]};
+            // transposed layout: query i = 16 m + 4 kh' + (e&3) + 8 (e>>2)  ->  chunk 2m + kh', element e; the 4 consecutive d of
+            // this thread share (d >> 2), so their addresses differ by the constant row stride
+            const int m = i >> 4, r16 = i & 15, khq = (r16 >> 2) & 1, eq = (r16 & 3) + 4 * (r16 >> 3);
+            const int tb = d4 * 32 + (((2 * m + khq) ^ ((d4 >> 2) & 3)) << 3) + eq;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                Qt[tb + e * 32] = qh[e]; Qt[2048 + tb + e * 32] = ql[e];
+                Ot[tb + e * 32] = oh[e]; Ot[2048 + tb + e * 32] = ol[e];
+            }
+        }
+        if (tid < 32) {
+            st[tid] = i0 + tid < a.Lq ? a.lse[(int64_t)bh * Lq_pad + i0 + tid] : 0.f;
+            st[32 + tid] = i0 + tid < a.Lq ? a.D[(int64_t)bh * Lq_pad + i0 + tid] * oscale : 0.f;
+            if (DROP) reinterpret_cast<uint32_t*>(st + 64)[tid] = drop_rowhash(a.drop_seed, (uint32_t)(bh * a.Lq + i0 + tid));
+        }
+        __syncthreads();
+
+        // ---- S = Q K^T, dP = dO V^T  (rows = queries, columns = this wave's keys)
+        f32x16 sacc, pacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int pos = ((2 * t + kh) ^ ((li >> 1) & 7)) * 8;
+            const half8 qh8 = *reinterpret_cast<const half8*>(Qa + li * 64 + pos);
+            const half8 ql8 = *reinterpret_cast<const half8*>(Qa + 2048 + li * 64 + pos);
+            const half8 oh8 = *reinterpret_cast<const half8*>(Oa + li * 64 + pos);
+            const half8 ol8 = *reinterpret_cast<const half8*>(Oa + 2048 + li * 64 + pos);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh8, kfh[t], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh8, kfl[t], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql8, kfh[t], sacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh8, vfh[t], pacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh8, vfl[t], pacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ol8, vfh[t], pacc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);          // keep the fragment loads of step t+1 from being hoisted (register budget)
+        }
+        // ---- P (with dropout), dS; accumulator register r is query mfma32_row(r, lane), column = this lane's key
+        half8 ph[2], pl[2], sh[2], sl[2];
+        const int ds_jk = (jw >> 3) ^ (4 * kh);
+        // dropout element = (row bh * Lq + query, col key): the row hashes of the tile's 32 queries sit in LDS (st[64 ..])
+        const float drop_inv = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
+        unsigned keep_bits = 0xffffu;               // bit r: accumulator register r is kept (a rolled loop keeps the register count down)
+        if constexpr (DROP) {
+            keep_bits = 0u;
+            const uint32_t* rhs = reinterpret_cast<const uint32_t*>(st + 64);
+#pragma unroll 1
+            for (int r = 0; r < 16; ++r)
+                keep_bits |= (drop_keep(rhs[(r & 3) + 8 * (r >> 2) + 4 * kh], (uint32_t)j, a.drop_p) ? 1u : 0u) << r;
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            float pv[8], dv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = 8 * m + e;
+                const int qi = mfma32_row(r, lane);
+                const bool ok = jok && (i0 + qi < a.Lq);
+                const float p = ok ? __builtin_amdgcn_exp2f(sacc[r] * c2 - st[qi]) : 0.f;
+                float keep = 1.f;
+                if constexpr (DROP) keep = ((keep_bits >> r) & 1u) ? drop_inv : 0.f;
+                pv[e] = p * keep;
+                dv[e] = p * (pacc[r] * keep - st[32 + qi]);
+            }
+            split8(pv, ph[m], pl[m]);
+            split8(dv, sh[m], sl[m]);
+            // dS of (query qi, key jw) also goes to LDS for the dQ product
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                constexpr int kRow[8] = {0, 1, 2, 3, 8, 9, 10, 11};      // mfma32_row(8 m + e, lane) = 16 m + kRow[e] + 4 kh
+                const int qi = 16 * m + kRow[e] + 4 * kh;
+                const int off = qi * 256 + ((ds_jk ^ kRow[e]) << 3) + (jw & 7);    // chunk (jw >> 3) ^ (qi & 15), qi & 15 = kRow[e] ^ 4 kh
+                Ds[off] = sh[m][e];
+                Ds[8192 + off] = sl[m][e];
+            }
+        }
+        // ---- dV^T += dO^T P, dK^T += Q^T dS: contraction over the queries kmap(m, kh, e) = accumulator rows
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int d = dt * 32 + li;
+                const int pos = d * 32 + (((2 * m + kh) ^ ((d >> 2) & 3)) << 3);
+                const half8 oth = *reinterpret_cast<const half8*>(Ot + pos);
+                const half8 otl = *reinterpret_cast<const half8*>(Ot + 2048 + pos);
+                const half8 qth = *reinterpret_cast<const half8*>(Qt + pos);
+                const half8 qtl = *reinterpret_cast<const half8*>(Qt + 2048 + pos);
+                gv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(oth, ph[m], gv[dt], 0, 0, 0);
+                gv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(oth, pl[m], gv[dt], 0, 0, 0);
+                gv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(otl, ph[m], gv[dt], 0, 0, 0);
+                gk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qth, sh[m], gk[dt], 0, 0, 0);
+                gk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qth, sl[m], gk[dt], 0, 0, 0);
+                gk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtl, sh[m], gk[dt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        // ---- dQ tile = dS K over the 256 keys of the workgroup: wave w owns the 16 x 16 block (queries 16 (w>>2).., d 16 (w&3)..)
+        __syncthreads();
+        {
+            typedef float f32x4v __attribute__((ext_vector_type(4)));
+            const int l15 = lane & 15, kq = lane >> 4;
+            const int qrow = (wave >> 2) * 16 + l15, dcol = (wave & 3) * 16 + l15;
+            f32x4v g4 = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int c = 4 * t + kq;                        // 8-key chunk 0..31
+                const int pa = qrow * 256 + ((c ^ (qrow & 15)) << 3);
+                const int pb = dcol * 256 + ((c ^ (dcol & 15)) << 3);
+                const half8 ah = *reinterpret_cast<const half8*>(Ds + pa);
+                const half8 al = *reinterpret_cast<const half8*>(Ds + 8192 + pa);
+                const half8 bh8 = *reinterpret_cast<const half8*>(Kt + pb);
+                const half8 bl8 = *reinterpret_cast<const half8*>(Kt + 16384 + pb);
+                g4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh8, g4, 0, 0, 0);
+                g4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl8, g4, 0, 0, 0);
+                g4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh8, g4, 0, 0, 0);
+                if (t & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            // accumulator: rows (wave>>2)*16 + 4 kq + r, column dcol
+            const int qb = (wave >> 2) * 16;
+            if (a.gq_part) {
+                float* part = a.gq_part + (((int64_t)bh * gridDim.x + blockIdx.x) * Lq_pad + i0) * 64;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[(qb + 4 * kq + r) * 64 + dcol] = g4[r] * cn * inv_os;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + qb + 4 * kq + r;
+                    if (i < a.Lq)
+                        atomicAdd(a.gq + (int64_t)b * a.gq_batch + (int64_t)h * a.gq_head + (int64_t)i * a.gq_row + dcol, g4[r] * cn * inv_os);
+                }
+            }
+        }
+    }
+    // ---- dK, dV of this wave's keys: (d x keys) accumulators -> [key][d] through LDS (the Ds region, free now), row-contiguous update
+    __syncthreads();
+    float* tr = reinterpret_cast<float*>(Ds) + wave * (32 * 65);         // 8 waves x 8.3 KB <= 32 KB + Kt head room
+    for (int which = 0; which < 2; ++which) {
+        const float scale = (which == 0 ? cn : 1.f) * inv_os;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tr[li * 65 + dt * 32 + mfma32_row(r, lane)] = (which == 0 ? gk[dt][r] : gv[dt][r]) * scale;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        float* g = which == 0 ? a.gk + (int64_t)b * a.gk_batch + (int64_t)h * a.gk_head : a.gv + (int64_t)b * a.gv_batch + (int64_t)h * a.gv_head;
+        const int64_t grow = which == 0 ? a.gk_row : a.gv_row;
+        const int j0 = blockIdx.x * kSpKW + wave * 32;
+        for (int idx = lane; idx < 32 * 64; idx += 64) {
+            const int jj = idx >> 6, d = idx & 63;
+            if (j0 + jj < a.Lk) {
+                float* o = g + (int64_t)(j0 + jj) * grow + d;
+                *o = (a.accumulate_kv ? *o : 0.f) + tr[jj * 65 + d];
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// scale[0] = 2^(10 - exponent(max |dO|)) from the bit pattern left by absmax_kernel (1 when the gradient is all zero)
+__global__ void oscale_kernel(const unsigned int* __restrict__ bits, float* __restrict__ scale) {
+    const float mx = __uint_as_float(bits[0]);
+    int ex = 0;
+    if (mx > 0.f && mx < 3.0e38f) frexpf(mx, &ex);
+    scale[0] = ldexpf(1.f, 10 - ex);
+}
+
+// max |x| over a buffer -> *out (float bits via atomicMax on the non-negative pattern); out must be zeroed
+__global__ void absmax_kernel(const float* __restrict__ x, int64_t n, unsigned int* __restrict__ out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
 // gq[b][i][h*64 + d] += sum_kb part[bh][kb][i][d]
 __global__ __launch_bounds__(256) void attn_bwd_dq_reduce_kernel(const float* __restrict__ part, int nkb, int Lq, int Lq_pad, int H,
                                                                  float* __restrict__ gq, int64_t gq_batch, int64_t gq_head, int64_t gq_row) {
@@ -352,7 +624,8 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
                            const float* dO, int64_t do_batch, int64_t do_head, int64_t do_row, const float* lse, const float* D,
                            float* gq, int64_t gq_batch, int64_t gq_head, int64_t gq_row, float* gk, int64_t gk_batch,
                            int64_t gk_head, int64_t gk_row, float* gv, int64_t gv_batch, int64_t gv_head, int64_t gv_row, int B, int H,
-                           int Lq, int Lk, int dh, int accumulate_kv, hipStream_t s, float* gq_part, float drop_p, uint32_t drop_seed) {
+                           int Lq, int Lk, int dh, int accumulate_kv, hipStream_t s, float* gq_part, float drop_p, uint32_t drop_seed,
+                           unsigned int* absmax) {
     if (dh != 64 && dh != 32) return hipErrorInvalidValue;
     AttnBwdArgs a;
     a.q = q; a.q_batch = q_batch; a.q_head = q_head; a.q_row = q_row;
@@ -367,9 +640,37 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
     a.drop_p = drop_p; a.drop_seed = drop_seed;
     dim3 grid(ceil_div(Lk, 256), B * H);
     static const int force = [] {
-        const char* e = getenv("PARQ_ATTN_BWD");            // "naive" / "mfma": debugging override
+        const char* e = getenv("PARQ_ATTN_BWD");            // "naive" / "mfma" (exact fp32 MFMA): debugging overrides of the split kernel
         return e ? (e[0] == 'n' ? 1 : 2) : 0;
     }();
+    if (dh == 64 && force == 0 && Lk >= 2048 && absmax) {
+        // split-precision kernel: dO scaled by a power of two so that max |dO| sits near 2^10 (keeps the low halves of the small
+        // gradient values out of the fp16 subnormals); the scale is computed and consumed on the device (absmax[0] bits, absmax[1] scale)
+        hipError_t e = hipMemsetAsync(absmax, 0, sizeof(unsigned int), s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, s, dO, (int64_t)B * do_batch, absmax);
+        float* oscale = reinterpret_cast<float*>(absmax + 1);
+        hipLaunchKernelGGL(oscale_kernel, dim3(1), dim3(1), 0, s, absmax, oscale);
+        const size_t lds = (size_t)(8 * 2048 + 2 * 8192 + 2 * 16384) * sizeof(_Float16) + 96 * sizeof(float);
+        static bool attr_s = false;
+        if (!attr_s) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_s = true;
+        }
+        dim3 g2(ceil_div(Lk, kSpKW), B * H);
+        a.gq_part = gq_part;
+        if (drop_p > 0.f) hipLaunchKernelGGL(attn_bwd_split_kernel<true>, g2, dim3(512), lds, s, a, oscale);
+        else hipLaunchKernelGGL(attn_bwd_split_kernel<false>, g2, dim3(512), lds, s, a, oscale);
+        if (a.gq_part) {
+            const int Lq_pad = (Lq + 31) & ~31;
+            hipLaunchKernelGGL(attn_bwd_dq_reduce_kernel, dim3(ceil_div(Lq * 64, 256), B * H), dim3(256), 0, s, gq_part, (int)g2.x, Lq,
+                               Lq_pad, H, gq, gq_batch, gq_head, gq_row);
+        }
+        return hipGetLastError();
+    }
     if (dh == 64 && force != 1) {
         const bool big = Lk >= 2048;
         const int nwv = big ? 8 : 2;

@@ -155,10 +155,11 @@ __global__ void axpy_rows_kernel(const float* __restrict__ x, int64_t ldx, float
 }
 
 // dst[m][n] = keep(m * N + n) ? src[m][n] / (1 - p) : 0   (gradient through a dropout site; also used to dump masks in tests)
-__global__ void dropout_apply_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n_total, float p, uint32_t seed) {
+__global__ void dropout_apply_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n_total, int N, float p, uint32_t seed) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_total) return;
-    dst[i] = drop_keep(seed, (uint64_t)i, p) ? src[i] / (1.f - p) : 0.f;
+    const uint32_t row = (uint32_t)(i / N), col = (uint32_t)(i - (int64_t)row * N);
+    dst[i] = drop_keep(drop_rowhash(seed, row), col, p) ? src[i] / (1.f - p) : 0.f;
 }
 
 // ------------------------------------------------------------------ LayerNorm backward, one wave per row
@@ -604,7 +605,7 @@ hipError_t launch_axpy_rows(const float* x, int64_t ldx, float* y, int64_t ldy, 
 }
 hipError_t launch_dropout_apply(const float* src, float* dst, int M, int N, float p, uint32_t seed, hipStream_t s) {
     const int64_t n = (int64_t)M * N;
-    hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, s, src, dst, n, p, seed);
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, s, src, dst, n, N, p, seed);
     return hipGetLastError();
 }
 hipError_t launch_ln_bwd(const float* gy, const float* x, const float* stats, const float* gamma, float* gx, int M, int C,

@@ -49,15 +49,19 @@ __device__ __forceinline__ void split8(const float* x, half8& hi, half8& lo) {
     }
 }
 
-// ---- dropout (training): counter-based keep decision, identical in forward and backward.  Element `idx` of stream `seed`
+// ---- dropout (training): counter-based keep decision, identical in forward and backward.  Element (row, col) of stream `seed`
 // is kept when a 24-bit hash is >= p * 2^24; kept values are scaled by 1 / (1 - p) (torch.nn.Dropout semantics).
 __host__ __device__ inline uint32_t rng_mix(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
 __host__ __device__ inline uint32_t rng_stream(uint32_t base, uint32_t stream) { return rng_mix(base ^ rng_mix(stream * 0x9e3779b9U + 0x85ebca6bU)); }
-__host__ __device__ inline bool drop_keep(uint32_t seed, uint64_t idx, float p) {
-    const uint32_t h = rng_mix(rng_mix(seed ^ (uint32_t)(idx >> 32)) ^ (uint32_t)idx);
+// The index space of a dropout site is 2-D, (row, col): activations (m, n); attention probabilities (bh * Lq + q, key).  The row
+// part of the hash is computed once per row (per lane in the forward attention kernels, per query tile in the backward ones),
+// leaving one multiply-xorshift round per element.
+__host__ __device__ inline uint32_t drop_rowhash(uint32_t seed, uint32_t row) { return rng_mix(seed ^ (row * 0x9e3779b1U)); }
+__host__ __device__ inline bool drop_keep(uint32_t rowhash, uint32_t col, float p) {
+    const uint32_t h = rng_mix(rowhash ^ (col * 0x85ebca77U));
     return (float)(h >> 8) >= p * 16777216.0f;
 }
 
@@ -100,7 +104,7 @@ struct LinearArgs {
     int relu;
     const float* relu_mask; int64_t ldmask;   // backward of a ReLU: y = relu_mask[m][n] > 0 ? y * mask_scale : 0 (applied after bias)
     float mask_scale;                         // 0 is read as 1
-    // training dropout on the output, after bias / ReLU and before the residual: element m * N + n of stream drop_seed
+    // training dropout on the output, after bias / ReLU and before the residual: element (m, n) of stream drop_seed
     float drop_p; uint32_t drop_seed;
     // output address: Y + (m / rows_per_batch) * y_batch + (m % rows_per_batch) * y_row
     //                   + (n / col_blk) * y_blk + (n % col_blk)
@@ -139,7 +143,7 @@ struct FlashArgs {
     float* out; int64_t out_batch, out_row;              // merged (b, q, h*dh + d)
     float defer_log2;           // split kernel: running max moves only past this margin (0 = always)
     float* lse;                 // optional [B*H][Lq_pad]: log2-domain log-sum-exp of every query row (training)
-    float drop_p; uint32_t drop_seed;   // training: dropout on the attention probabilities, element (bh * Lq + q) * Lk + key
+    float drop_p; uint32_t drop_seed;   // training: dropout on the attention probabilities, element (row bh * Lq + q, col key)
 };
 int flash_key_tile(int dh);                    // keys per LDS tile
 int flash_lq_pad(int Lq);
@@ -207,7 +211,7 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
                            float* gq, int64_t gq_batch, int64_t gq_head, int64_t gq_row, float* gk, int64_t gk_batch,
                            int64_t gk_head, int64_t gk_row, float* gv, int64_t gv_batch, int64_t gv_head, int64_t gv_row, int B, int H,
                            int Lq, int Lk, int dh, int accumulate_kv, hipStream_t s, float* gq_part = nullptr, float drop_p = 0.f,
-                           uint32_t drop_seed = 0);
+                           uint32_t drop_seed = 0, unsigned int* absmax = nullptr);   // absmax: 8-byte device scratch -> split-precision kernel
 // dst = dropout(src): keep mask of stream `seed` over the (M, N) index space, scaled by 1 / (1 - p)
 hipError_t launch_dropout_apply(const float* src, float* dst, int M, int N, float p, uint32_t seed, hipStream_t s);
 size_t attn_bwd_dq_partial_floats(int B, int H, int Lq, int Lk, int dh);

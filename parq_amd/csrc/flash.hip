@@ -177,12 +177,10 @@ __global__ __launch_bounds__(NW * 64) void flash_f32_kernel(FlashArgs a) {
                 m_run = m_new;
                 if (a.drop_p > 0.f) {           // training: dropout on the probabilities; the normaliser stays undropped
                     const float inv = 1.f / (1.f - a.drop_p);
+                    const uint32_t rh = drop_rowhash(a.drop_seed, (uint32_t)(bh * a.Lq + q));
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const uint64_t key = (uint64_t)(t * KT + kb * 32 + mfma32_row(r, lane));
-                        const uint64_t idx = ((uint64_t)bh * (uint64_t)a.Lq + (uint64_t)q) * (uint64_t)a.Lk + key;
-                        sacc[r] = drop_keep(a.drop_seed, idx, a.drop_p) ? sacc[r] * inv : 0.f;
-                    }
+                    for (int r = 0; r < 16; ++r)
+                        sacc[r] = drop_keep(rh, (uint32_t)(t * KT + kb * 32 + mfma32_row(r, lane)), a.drop_p) ? sacc[r] * inv : 0.f;
                 }
 #pragma unroll
                 for (int d = 0; d < NDT; ++d)
@@ -428,13 +426,12 @@ __global__ __launch_bounds__(512) void self_attn_kernel(const float* __restrict_
         m_run = m_new;
         if (drop_p > 0.f) {
             const float inv = 1.f / (1.f - drop_p);
+            const uint32_t rh = drop_rowhash(drop_seed, (uint32_t)(bh * L + q));
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const uint64_t idx = ((uint64_t)bh * (uint64_t)L + (uint64_t)q) * (uint64_t)L + (uint64_t)(kb + s * 16 + 4 * kq + r);
-                    sacc[s][r] = drop_keep(drop_seed, idx, drop_p) ? sacc[s][r] * inv : 0.f;
-                }
+                for (int r = 0; r < 4; ++r)
+                    sacc[s][r] = drop_keep(rh, (uint32_t)(kb + s * 16 + 4 * kq + r), drop_p) ? sacc[s][r] * inv : 0.f;
         }
 #pragma unroll
         for (int d = 0; d < NDT; ++d) o[d] *= alpha;

@@ -256,6 +256,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
         if (t + 3 < t_end) gload(t + 3, (t + 3 - t_begin) & (kRing - 1));
     };
 
+    const uint32_t drop_rh = DROP ? drop_rowhash(a.drop_seed, (uint32_t)(bh * a.Lq + q)) : 0u;      // this lane's query row
     // state of the stage in flight
     f32x16 sacc[2];
     half8 phi[2][2], plo[2][2];
@@ -335,11 +336,9 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
                 if constexpr (DROP) {           // the normaliser above stays undropped (nn.MultiheadAttention dropout)
                     const float inv = 1.f / (1.f - a.drop_p);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const uint64_t key = (uint64_t)((t * kStageBlks + kb) * kBlkKeys + mfma32_row(8 * m + e, lane));
-                        const uint64_t idx = ((uint64_t)bh * (uint64_t)a.Lq + (uint64_t)q) * (uint64_t)a.Lk + key;
-                        p[e] = drop_keep(a.drop_seed, idx, a.drop_p) ? p[e] * inv : 0.f;
-                    }
+                    for (int e = 0; e < 8; ++e)
+                        p[e] = drop_keep(drop_rh, (uint32_t)((t * kStageBlks + kb) * kBlkKeys + mfma32_row(8 * m + e, lane)), a.drop_p)
+                                   ? p[e] * inv : 0.f;
                 }
                 if constexpr (TERMS == 3) split8(p, phi[kb][m], plo[kb][m]);
                 else phi[kb][m] = cvt8_rn<KIND>(p);

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a
                 float y = sum[e] + e_bias[e];
                 if (a.relu) y = y > 0.f ? y : 0.f;
                 if (a.relu_mask) y = a.relu_mask[(int64_t)om * a.ldmask + on] > 0.f ? y * (a.mask_scale != 0.f ? a.mask_scale : 1.f) : 0.f;
-                if (a.drop_p > 0.f) y = drop_keep(a.drop_seed, (uint64_t)om * (uint64_t)a.N + (uint64_t)on, a.drop_p) ? y / (1.f - a.drop_p) : 0.f;
+                if (a.drop_p > 0.f) y = drop_keep(drop_rowhash(a.drop_seed, (uint32_t)om), (uint32_t)on, a.drop_p) ? y / (1.f - a.drop_p) : 0.f;
                 if (a.R) y += a.rln_stats ? (e_r[e] - rmean) * rrstd * e_rg[e] + e_rb[e] : e_r[e];
                 Ybase[(int64_t)(on / a.col_blk) * a.y_blk + (on % a.col_blk)] = y;
                 gs += (double)y;

@@ -204,14 +204,15 @@ def _masked_mha(xq, xk, xv, in_w, in_b, out_w, out_b, H, pmask):
     return torch.nn.functional.linear((p @ v).transpose(1, 2).reshape(B, Lq, Cd), out_w, out_b)
 
 
-def test_dropout_forward_backward_match_masked_oracle():
+@pytest.mark.parametrize("h,w", [(8, 10), (32, 40)])          # N = 160: exact-fp32 attention backward; N = 2560: split-precision kernel
+def test_dropout_forward_backward_match_masked_oracle(h, w):
     """Train-mode dropout (six sites of the decoder layer, transformer_parq.py:339-386): the library's counter-based masks are
     dumped (parq_k_dropout_mask) and applied at the same sites in a float64 torch restatement of the layer; outputs and all
     gradients must then agree like in the dropout-free test.  Also: masks change with the seed, the drop rate is ~p."""
     import ctypes as C
     from parq_amd import _lib
     F_ = torch.nn.functional
-    B, V, h, w, Q, dim, Hh, ffn, I = 2, 2, 8, 10, 32, 128, 2, 96, 2
+    B, V, Q, dim, Hh, ffn, I = 2, 2, 32, 128, 2, 96, 2
     pdrop = 0.25
     cfg = synth.decoder_cfg(dim=dim, queries=Q, heads=Hh, ffn=ffn, layers=I, dropout=pdrop)
     W = synth.make_decoder_weights(cfg, 101)
