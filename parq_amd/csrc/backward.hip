@@ -210,9 +210,11 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restr
     __shared__ float p1[4][64], p2[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int w = threadIdx.x >> 6;
+    const int chunk = (M + (int)gridDim.y - 1) / (int)gridDim.y;          // rows of this workgroup
+    const int m_begin = (int)blockIdx.y * chunk, m_end = m_begin + chunk < M ? m_begin + chunk : M;
     float sg = 0.f, sb = 0.f;
     if (c < C)
-        for (int m = w; m < M; m += 4) {
+        for (int m = m_begin + w; m < m_end; m += 4) {
             const float g = gy[(int64_t)m * C + c];
             const float xh = (x[(int64_t)m * C + c] - stats[(int64_t)m * 2]) * stats[(int64_t)m * 2 + 1];
             sg += g * xh;
@@ -222,8 +224,8 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restr
     p2[w][threadIdx.x & 63] = sb;
     __syncthreads();
     if (w == 0 && c < C) {
-        dgamma[c] += p1[0][threadIdx.x] + p1[1][threadIdx.x] + p1[2][threadIdx.x] + p1[3][threadIdx.x];
-        dbeta[c] += p2[0][threadIdx.x] + p2[1][threadIdx.x] + p2[2][threadIdx.x] + p2[3][threadIdx.x];
+        atomicAdd(dgamma + c, p1[0][threadIdx.x] + p1[1][threadIdx.x] + p1[2][threadIdx.x] + p1[3][threadIdx.x]);
+        atomicAdd(dbeta + c, p2[0][threadIdx.x] + p2[1][threadIdx.x] + p2[2][threadIdx.x] + p2[3][threadIdx.x]);
     }
 }
 
@@ -340,10 +342,12 @@ __global__ __launch_bounds__(256) void gn_param_grad_kernel(GnArgs a) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int w = threadIdx.x >> 6;
     float sg = 0.f, sb = 0.f;
+    const int chunk = (a.M + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int m_begin = (int)blockIdx.z * chunk, m_end = m_begin + chunk < a.M ? m_begin + chunk : a.M;
     if (c < a.C) {
         int cur_scene = -1;
         float mean = 0.f, rstd = 1.f;
-        for (int m = w; m < a.M; m += 4) {
+        for (int m = m_begin + w; m < m_end; m += 4) {
             const int scene = m / a.rows_per_scene;
             if (scene != cur_scene) {
                 gn_moments(a.sums, scene, a.ngroups, g, (double)a.rows_per_scene * a.C, a.eps, mean, rstd);
@@ -358,8 +362,8 @@ __global__ __launch_bounds__(256) void gn_param_grad_kernel(GnArgs a) {
     p2[w][threadIdx.x & 63] = sb;
     __syncthreads();
     if (w == 0 && c < a.C) {
-        a.dgamma[g * a.C + c] += p1[0][threadIdx.x] + p1[1][threadIdx.x] + p1[2][threadIdx.x] + p1[3][threadIdx.x];
-        a.dbeta[g * a.C + c] += p2[0][threadIdx.x] + p2[1][threadIdx.x] + p2[2][threadIdx.x] + p2[3][threadIdx.x];
+        atomicAdd(a.dgamma + g * a.C + c, p1[0][threadIdx.x] + p1[1][threadIdx.x] + p1[2][threadIdx.x] + p1[3][threadIdx.x]);
+        atomicAdd(a.dbeta + g * a.C + c, p2[0][threadIdx.x] + p2[1][threadIdx.x] + p2[2][threadIdx.x] + p2[3][threadIdx.x]);
     }
 }
 
@@ -588,8 +592,8 @@ hipError_t launch_gemm_tn(const float* A, int64_t lda, const float* B, int64_t l
 }
 hipError_t launch_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, hipStream_t s) {
     int splits = 1;
-    if (accumulate && M >= 8192) {
-        splits = M / 1024;
+    if (accumulate && M >= 512) {                 // few columns, many rows: spread the rows over workgroups (float atomics)
+        splits = M >= 8192 ? M / 1024 : M / 128;
         if (splits > 1024) splits = 1024;
     }
     hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64), splits), dim3(256), 0, s, X, ldx, M, N, out, accumulate);
@@ -612,7 +616,11 @@ hipError_t launch_ln_bwd(const float* gy, const float* x, const float* stats, co
                          int accumulate, float* dgamma, float* dbeta, hipStream_t s) {
     if (C > 64 * kLnPer) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, s, gy, x, stats, gamma, gx, M, C, accumulate);
-    if (dgamma) hipLaunchKernelGGL(ln_param_grad_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, s, gy, x, stats, M, C, dgamma, dbeta);
+    if (dgamma) {
+        int splits = M / 64;
+        splits = splits < 1 ? 1 : (splits > 64 ? 64 : splits);
+        hipLaunchKernelGGL(ln_param_grad_kernel, dim3(ceil_div(C, 64), splits), dim3(256), 0, s, gy, x, stats, M, C, dgamma, dbeta);
+    }
     return hipGetLastError();
 }
 // y = relu(GroupNorm(x)) from the forward moments
@@ -641,7 +649,11 @@ hipError_t launch_gn_bwd(const float* x, int64_t ldx, const double* sums, const 
     dim3 grid((unsigned)ceil_div64((int64_t)rows_per_scene * C, 1024), ngroups, B);
     hipLaunchKernelGGL(gn_bwd_reduce_kernel, grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, dim3(256), 0, s, a);
-    if (dgamma) hipLaunchKernelGGL(gn_param_grad_kernel, dim3(ceil_div(C, 64), ngroups), dim3(256), 0, s, a);
+    if (dgamma) {
+        int splits = M / 64;
+        splits = splits < 1 ? 1 : (splits > 64 ? 64 : splits);
+        hipLaunchKernelGGL(gn_param_grad_kernel, dim3(ceil_div(C, 64), ngroups, splits), dim3(256), 0, s, a);
+    }
     return hipGetLastError();
 }
 hipError_t launch_decode_bwd(const float* g_logits, const float* g_center, const float* g_size, const float* g_rot,
