@@ -183,7 +183,7 @@ def train_bench(args):
             "value": args.steps / dt, "unit": "steps/sec", "scenes_per_sec": args.steps * B * world / dt,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "final_loss": float(loss),
+            "final_loss": float(loss.detach()),
             "config": {"workload": "BASELINE cfg4 per-GPU shard: %d scenes, 10 views 480x640 (120x160 features), 256 queries, 8 iterations, "
                                    "d=256; dropout 0.1; 12 synthetic boxes per scene" % B,
                        "scenes_per_gpu": B, "parallelism": "dp%d (one flat gradient all-reduce per step)" % world}}))

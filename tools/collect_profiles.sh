@@ -9,6 +9,7 @@ rm -rf $out; mkdir -p $out
 python bench.py > $out/bench.json 2> $out/bench.err
 python bench.py --scenes-per-gpu 8 --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_8scenes.json 2>> $out/bench.err
 python bench.py --attention-mode fp16 --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_fp16.json 2>> $out/bench.err
+python bench.py --train --steps 8 --warmup 2 > $out/bench_train.json 2>> $out/bench.err
 export TMPDIR=/tmp
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/kt.log 2>&1)
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS"; do
