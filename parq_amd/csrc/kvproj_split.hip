@@ -259,6 +259,11 @@ __global__ __launch_bounds__(kThreads) void kvproj_split_kernel(KvProjArgs a) {
 // whole launch and the workgroup walks the row tiles of the scene batch, streaming only tokens
 // (one 32 KB k-step in flight behind the MFMAs, across tile boundaries too).  LDS holds only the split
 // token tile (double-buffered, one barrier per k-step); B operands never touch LDS.
+// Measured and rejected on this kernel (MI355X, cfg 3, 205 us as is): 4 token k-steps in flight instead of 2 (no change:
+// the loop is not latency-bound); removing the stores -> 179 us, the MFMAs -> 178 us, the loads -> 221 us (no single
+// phase dominates); a software-pipelined k-step (fragments of step q read before the conversion + LDS write of step q+1,
+// barrier at the end) -> 239 us; that plus the previous tile's stores spread between the next tile's MFMAs -> 336 us
+// (64 more live registers, spills).
 constexpr int kWsMaxKSteps = 4;          // K = C <= 256
 constexpr int kWsDepth = 2;              // token k-steps in flight
 
