@@ -197,6 +197,10 @@ def main(only=None):
         make_loss_golden(ref)
     if not only or "g11_parse_pred" in only:
         make_parse_golden(ref)
+    if not only or "g12_f1" in only:
+        make_f1_golden(ref)
+    if not only or "g13_lr_schedule" in only:
+        make_lr_golden(ref)
 
 
 PARSE_CASE = dict(seed=41, B=2, Q=96, track_scale=[-1.5, 1.5, -2, 1, 0, 2])
@@ -306,6 +310,135 @@ def make_loss_golden(ref):
             res["%s_%s" % (tag, k)] = np.float64(float(v))
     np.savez_compressed(os.path.join(OUT_DIR, "g10_loss.npz"), meta=np.frombuffer(json.dumps(c, sort_keys=True).encode(), dtype=np.uint8), **res)
     print("wrote g10_loss", {k: float(v) for k, v in res.items()})
+
+
+F1_CASE = dict(seed=53, scenes=["scene_a", "scene_b", "scene_c"], snippets=4, Q=40, ngt=7, np_seed=4321, conf=0.1)
+
+
+def _yaw_box_corners(center, half, yaw):
+    """World corners (8,3) of a box rotated about the world z axis, in the corner order of Obb3D.bb3corners_object with the
+    object's y axis along world +z (the convention the reference's IoU routine assumes, utils/f1_eval.py:77-100)."""
+    sx, sy, sz = half
+    obj = np.array([[-sx, -sy, -sz], [sx, -sy, -sz], [sx, sy, -sz], [-sx, sy, -sz],
+                    [-sx, -sy, sz], [sx, -sy, sz], [sx, sy, sz], [-sx, sy, sz]])
+    c, s_ = np.cos(yaw), np.sin(yaw)
+    Rz = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]])
+    R0 = np.array([[1.0, 0, 0], [0, 0, -1.0], [0, 1.0, 0]])          # object y -> world +z
+    return obj @ (Rz @ R0).T + center
+
+
+def f1_case_inputs(c):
+    """Per snippet: predicted corners / class probabilities / mask for every scene, and the visible ground truth.
+    Predictions are noisy copies of the scene's boxes plus clutter, so tracks merge, get replaced and new ones appear."""
+    rng = np.random.RandomState(c["seed"])
+    S, Q = len(c["scenes"]), c["Q"]
+    world = []
+    for s_ in range(S):
+        boxes = []
+        for j in range(c["ngt"]):
+            boxes.append(dict(center=rng.uniform(-2.5, 2.5, 3) * np.array([1, 1, 0.3]), half=rng.uniform(0.25, 0.7, 3),
+                              yaw=rng.uniform(-np.pi, np.pi), cls=int(rng.randint(0, 9))))
+        world.append(boxes)
+    steps = []
+    for t in range(c["snippets"]):
+        order = list(range(S)) if t % 2 == 0 else [2, 0]                 # a ragged batch and a different scene order
+        corners = np.zeros((len(order), Q, 8, 3), np.float32)
+        prob = np.zeros((len(order), Q, 10), np.float32)
+        mask = np.zeros((len(order), Q), bool)
+        gts = []
+        for bi, s_ in enumerate(order):
+            vis = [j for j in range(c["ngt"]) if rng.rand() < 0.7]
+            gts.append(dict(labels=np.array([world[s_][j]["cls"] for j in vis], np.int64),
+                            corners=np.stack([_yaw_box_corners(world[s_][j]["center"], world[s_][j]["half"], world[s_][j]["yaw"])
+                                              for j in vis]).astype(np.float32) if vis else np.zeros((0, 8, 3), np.float32)))
+            for q in range(Q):
+                logits = rng.normal(0, 1, 10)
+                if q < 2 * c["ngt"] and rng.rand() < 0.75:                 # a detection of box q % ngt
+                    bx = world[s_][q % c["ngt"]]
+                    cen = bx["center"] + rng.normal(0, 0.10, 3)
+                    half = bx["half"] * rng.uniform(0.75, 1.25, 3)
+                    yaw = bx["yaw"] + rng.normal(0, 0.15)
+                    logits[bx["cls"] if rng.rand() < 0.85 else rng.randint(0, 10)] += rng.uniform(1.5, 4.0)
+                else:                                                      # clutter
+                    cen = rng.uniform(-3, 3, 3) * np.array([1, 1, 0.3])
+                    half = rng.uniform(0.2, 0.6, 3)
+                    yaw = rng.uniform(-np.pi, np.pi)
+                    logits[9] += rng.uniform(0.0, 3.0)
+                corners[bi, q] = _yaw_box_corners(cen, half, yaw)
+                e = np.exp(logits - logits.max())
+                prob[bi, q] = e / e.sum()
+                mask[bi, q] = rng.rand() < 0.8
+        steps.append(dict(scenes=[c["scenes"][s_] for s_ in order], corners=corners, prob=prob, mask=mask, gts=gts))
+    return steps
+
+
+def make_f1_golden(ref):
+    """The reference's F1Calculator (utils/f1_eval.py:254-557) driven snippet by snippet through step(); the jitter it adds to
+    the ground truth draws from NumPy's global generator, seeded here."""
+    import importlib
+    f1 = importlib.import_module("utils.f1_eval")
+    c = F1_CASE
+    steps = f1_case_inputs(c)
+    calc = f1.F1Calculator(c["conf"])
+    np.random.seed(c["np_seed"])
+    import contextlib, io
+    for st in steps:
+        out = {"pred_corners_world": torch.from_numpy(st["corners"]), "sem_cls_prob": torch.from_numpy(st["prob"]),
+               "pred_mask": torch.from_numpy(st["mask"]), "scene_name": st["scenes"]}
+        gl = [{"labels": torch.from_numpy(g["labels"]), "gt_corners_world": torch.from_numpy(g["corners"])} for g in st["gts"]]
+        calc.step(out, gl)
+    with contextlib.redirect_stdout(io.StringIO()):
+        metrics = calc.compute_metrics()
+    res = {"metric_" + k: np.float64(v) for k, v in metrics.items()}
+    for name in c["scenes"]:
+        res["ntrack_" + name] = np.int64(len(calc.preds[name]))
+        res["ngt_" + name] = np.int64(len(calc.gts[name]))
+        res["trackcls_" + name] = np.array([t[0] for t in calc.preds[name]], np.int64)
+        res["trackid_" + name] = np.array([t[-1] for t in calc.preds[name]], np.int64)
+        res["trackscore_" + name] = np.array([t[2] for t in calc.preds[name]], np.float64)
+    # a few raw IoUs of the reference routine, for the IoU restatement on its own
+    rng = np.random.RandomState(7)
+    pairs, ious = [], []
+    rot = f1.rotx(np.pi / 2)
+    for _ in range(24):
+        cen = rng.uniform(-1, 1, 3) * np.array([1, 1, 0.2])
+        a = _yaw_box_corners(cen, rng.uniform(0.3, 0.8, 3), rng.uniform(-np.pi, np.pi))
+        b = _yaw_box_corners(cen + rng.normal(0, 0.35, 3) * np.array([1, 1, 0.3]), rng.uniform(0.3, 0.8, 3), rng.uniform(-np.pi, np.pi))
+        ra = (rot @ a[[4, 0, 1, 5, 7, 3, 2, 6]].T).T
+        rb = (rot @ b[[4, 0, 1, 5, 7, 3, 2, 6]].T).T
+        with contextlib.redirect_stdout(io.StringIO()):
+            i3, i2 = f1.iou3d(ra, rb)
+        pairs.append(np.stack([a, b]))
+        ious.append([i3, i2])
+    res["iou_pairs"] = np.stack(pairs)
+    res["iou_values"] = np.array(ious, np.float64)
+    np.savez_compressed(os.path.join(OUT_DIR, "g12_f1.npz"), meta=np.frombuffer(json.dumps(c, sort_keys=True).encode(), dtype=np.uint8), **res)
+    print("wrote g12_f1", {k: float(v) for k, v in metrics.items()}, [int(res["ntrack_" + n]) for n in c["scenes"]])
+
+
+LR_CASES = [dict(first=10, mult=1.0, max_lr=1e-3, min_lr=1e-5, warmup=3, steps=35),
+            dict(first=7, mult=2.0, max_lr=4e-4, min_lr=4e-4 / 256, warmup=0, steps=40),
+            dict(first=12, mult=1.5, max_lr=2e-3, min_lr=1e-6, warmup=5, steps=60)]
+
+
+def make_lr_golden(ref):
+    """Learning-rate sequences of the reference's CosineAnnealingWarmupRestarts (utils/train_utils.py:18-145), stepped once
+    per epoch as Lightning does (model/parq_lightning.py:183-199)."""
+    import importlib
+    tu = importlib.import_module("utils.train_utils")
+    res = {}
+    for i, c in enumerate(LR_CASES):
+        opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=c["max_lr"])
+        sch = tu.CosineAnnealingWarmupRestarts(opt, c["first"], c["mult"], c["max_lr"], c["min_lr"], c["warmup"])
+        seq = [opt.param_groups[0]["lr"]]
+        for _ in range(c["steps"]):
+            opt.step()
+            sch.step()
+            seq.append(opt.param_groups[0]["lr"])
+        res["lr_%d" % i] = np.array(seq, np.float64)
+    np.savez_compressed(os.path.join(OUT_DIR, "g13_lr_schedule.npz"),
+                        meta=np.frombuffer(json.dumps(LR_CASES, sort_keys=True).encode(), dtype=np.uint8), **res)
+    print("wrote g13_lr_schedule", [len(v) for v in res.values()])
 
 
 if __name__ == "__main__":

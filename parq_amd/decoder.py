@@ -184,6 +184,11 @@ class PARQDecoder(nn.Module):
         self.track_scale = cfg.TRACK_SCALE
         self.share_mlp_heads = cfg.SHARE_MLP_HEADS
         self.enable_nms = getattr(cfg, "ENABLE_NMS", True)
+        # evaluation trackers, one per EVAL_TYPE entry (model/parq_decoder.py:73-80; only "f1" exists in the reference)
+        from .f1_eval import F1Calculator
+        eval_type = getattr(cfg, "EVAL_TYPE", "f1")
+        self.metrics_calculator = [F1Calculator(getattr(cfg, "CONF_THRESH", 0.1))
+                                   for et in (eval_type if isinstance(eval_type, (list, tuple)) else [eval_type]) if et == "f1"]
         self.num_heads = T.DEC_HEADS
         self.num_layers = T.DEC_LAYERS
         self.ffn_dim = T.DEC_FFN_DIM
@@ -526,5 +531,27 @@ class PARQDecoder(nn.Module):
         out["pred_mask"] = mask.bool()
         return out
 
-    def update_metrics(self, *a, **k):
-        raise NotImplementedError("eval post-processing is out of scope this round (SURVEY.md §8f-4)")
+    @torch.no_grad()
+    def update_metrics(self, out_dict, obbs_padded, T_world_local, scene_name=None):
+        """model/parq_decoder.py:426-459: boxes + keep-mask of the last iteration (``parse_pred``, on the device), box corners
+        in world coordinates, then one step of every tracker (host side, parq_amd/f1_eval.py)."""
+        from .loss import parse_target
+        from .wrappers import Pose, raw
+        assert raw(obbs_padded).ndim == 3, tuple(raw(obbs_padded).shape)
+        out = self.parse_pred(out_dict)
+        targets = parse_target(obbs_padded, T_world_local)
+        obbs = out["obbs_pred"]
+        out["scene_name"] = scene_name
+        out["pred_corners_world"] = Pose(raw(T_world_local)).transform(obbs.T_world_object.transform(obbs.bb3corners_object))
+        for calc in self.metrics_calculator:
+            calc.step(out, targets)
+
+    def compute_metrics(self):
+        metrics = {}
+        for calc in self.metrics_calculator:
+            metrics.update(calc.compute_metrics())
+        return metrics
+
+    def reset_metrics(self):
+        for calc in self.metrics_calculator:
+            calc.reset()

@@ -8,6 +8,8 @@ Lightning is used as the base class only when it is importable (it is not on the
 """
 from __future__ import annotations
 
+import math
+
 import torch
 from torch import nn
 
@@ -54,7 +56,19 @@ class PARQ(_Base):
         return losses, outputs
 
     def validation_step(self, batch, batch_idx):
-        return self.forward(batch, batch_idx)
+        """model/parq_lightning.py:102-112 without the image logging: with ground truth in the batch the scene-level F1
+        trackers are advanced by this snippet batch."""
+        losses, outputs = self.forward(batch, batch_idx)
+        if "obbs_padded" in batch:
+            self.box3d_decoder.update_metrics(outputs, batch["obbs_padded"], batch["T_world_local"], batch["scene_name"])
+        return losses["total_loss"]
+
+    def on_validation_epoch_start(self):
+        self.box3d_decoder.reset_metrics()
+
+    def validation_epoch_end(self, outs=None):
+        """model/parq_lightning.py:118-142: {"0.25_f1", ...}; `eval.py` calls this directly and prints the result."""
+        return self.box3d_decoder.compute_metrics()
 
     def test_step(self, batch, batch_idx=0):
         return self.forward(batch, batch_idx)
@@ -67,14 +81,29 @@ class PARQ(_Base):
         return losses["total_loss"]
 
     def configure_optimizers(self):
-        """AdamW with the reference's batch-size learning-rate rule (model/parq_lightning.py:150-168); the reference's
-        `torch.optim._multi_tensor.AdamW` no longer exists in torch 2: `foreach=True` is the same implementation."""
-        lr = _get(self.cfg, "OPTIMIZER.LEARNING_RATE")
+        """AdamW with the reference's batch-size learning-rate rule and its warm-up + cosine-restart schedule, stepped per
+        epoch (model/parq_lightning.py:150-199).  The reference's `torch.optim._multi_tensor.AdamW` no longer exists in
+        torch 2 (`foreach=True` is the same implementation) and its 1-tuple return value is not inherited: this returns the
+        Lightning dictionary itself, or the bare optimizer when the config carries no schedule section."""
+        from .schedule import CosineAnnealingWarmupRestarts
+        base = _get(self.cfg, "OPTIMIZER.LEARNING_RATE")
+        lr, eff = base, None
         try:
             eff = (_get(self.cfg, "DATAMODULE.BATCH_SIZE") * _get(self.cfg, "TRAINER.NUM_NODES") * _get(self.cfg, "TRAINER.GPUS") *
                    _get(self.cfg, "TRAINER.ACCUMULATE_GRAD_BATCHES"))
             if _get(self.cfg, "OPTIMIZER.AUTOSCALE_LR"):
-                lr = lr * eff / 256.0
+                lr = base * eff / 256.0
         except (KeyError, AttributeError):
             pass
-        return torch.optim.AdamW([p for p in self.parameters() if p.requires_grad], lr=lr, foreach=True)
+        optimizer = torch.optim.AdamW([p for p in self.parameters() if p.requires_grad], lr=lr, foreach=True)
+        try:
+            warmup = _get(self.cfg, "OPTIMIZER.WARMUP_EPOCHS")
+            mult = _get(self.cfg, "OPTIMIZER.CYCLE_MULT")
+            restarts = _get(self.cfg, "OPTIMIZER.NUM_RESTARTS")
+            epochs = _get(self.cfg, "TRAINER.MAX_EPOCHS")
+        except (KeyError, AttributeError):
+            return optimizer
+        lr_min = base / 256.0 if (eff is not None and eff <= 256) else base
+        cycle0 = math.ceil(epochs / sum(pow(mult, i) for i in range(restarts)))
+        scheduler = CosineAnnealingWarmupRestarts(optimizer, cycle0, mult, lr, lr_min, warmup)
+        return {"optimizer": optimizer, "lr_scheduler": {"scheduler": scheduler, "interval": "epoch"}}

@@ -4,11 +4,14 @@
   * the CPU oracle on fresh seeded inputs,
   * size-independent properties at the BASELINE cfg-3 size (scene independence,
     determinism, probability simplex, recurrence consistency)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
-from parq_amd import synth
+from parq_amd import synth, Pose
 from oracle import parq_oracle as O
 import golden_util as G
 from gpu_util import dev, make_decoder, scene_args, to_np, rel_err
@@ -362,3 +365,54 @@ def test_parq_module_forward_matches_oracle_pipeline():
         want, _, _ = od.iterate(ref0, 0)
     for key in ("pred_logits", "center_unnormalized", "ortho6d", "sem_cls_prob"):
         assert rel_err(outs[0][key].cpu().numpy(), want[key].numpy()) < TOL, key
+
+
+def test_update_metrics_drives_the_f1_trackers():
+    """PARQDecoder.update_metrics (model/parq_decoder.py:426-459): device parse_pred + world corners + tracker step.  Checked
+    against the same tracker fed by hand from the g11 golden boxes/mask (reference building blocks) with NumPy geometry."""
+    import json
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    from make_golden import PARSE_CASE, parse_case_inputs
+    from parq_amd import Obb3D
+    from parq_amd.decoder import PARQDecoder
+    from parq_amd.f1_eval import F1Calculator
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "g11_parse_pred.npz"))
+    x = parse_case_inputs(PARSE_CASE)
+    B, Q = PARSE_CASE["B"], PARSE_CASE["Q"]
+    cfg = synth.decoder_cfg(dim=64, queries=Q, heads=1, ffn=64, layers=1)
+    cfg.TRACK_SCALE = PARSE_CASE["track_scale"]
+    dec = PARQDecoder(cfg).cuda().eval()
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    outs = [{"center_unnormalized": to(x["center"]), "size_unnormalized": to(x["size"]), "ortho6d": to(x["rot6"]),
+             "sem_cls_prob": to(x["prob"])}]
+    gt, _ = synth.make_boxes(77, B, 6, max_box=10)
+    _, _, _, T_wl = synth.make_geometry(78, B, 2, 8, 10)
+    names = ["room0", "room1"]
+    np.random.seed(11)
+    dec.reset_metrics()
+    dec.update_metrics(outs, Obb3D(to(gt)), Pose(to(T_wl)), names)
+    dec.update_metrics(outs, Obb3D(to(gt)), Pose(to(T_wl)), names)            # second snippet: every track re-associates
+    got = dec.compute_metrics()
+    tracks = {n: len(dec.metrics_calculator[0].preds[n]) for n in names}
+
+    # by hand: golden boxes (19-vectors) -> object corners -> world, with float64 NumPy
+    ob = z["obbs"].astype(np.float64)
+    lo, hi = ob[..., 0:6:2], ob[..., 1:6:2]
+    pick = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)]
+    corners = np.stack([np.stack([(hi if s[a] else lo)[..., a] for a in range(3)], -1) for s in pick], -2)       # (B,Q,8,3)
+    R, t = ob[..., 6:15].reshape(B, Q, 3, 3), ob[..., 15:18]
+    local = np.einsum("bqij,bqkj->bqki", R, corners) + t[:, :, None]
+    Rw, tw = T_wl[:, 0, :9].reshape(B, 3, 3).astype(np.float64), T_wl[:, 0, 9:].astype(np.float64)
+    world = np.einsum("bij,bqkj->bqki", Rw, local) + tw[:, None, None]
+    want_calc = F1Calculator(cfg.CONF_THRESH)
+    np.random.seed(11)
+    from parq_amd.loss import parse_target
+    tg = parse_target(Obb3D(torch.from_numpy(gt)), Pose(torch.from_numpy(T_wl)))
+    for _ in range(2):
+        want_calc.step({"pred_corners_world": world.astype(np.float32), "sem_cls_prob": x["prob"], "pred_mask": z["mask_eval"],
+                        "scene_name": names}, tg)
+    want = want_calc.compute_metrics()
+    assert tracks == {n: len(want_calc.preds[n]) for n in names} and min(tracks.values()) > 3
+    assert got == want, (got, want)
+    dec.reset_metrics()
+    assert dec.metrics_calculator[0].preds == {}
