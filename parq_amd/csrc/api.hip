@@ -68,7 +68,8 @@ struct Workspace {
     int64_t sa, ln3, lse_s, lse_c, refk;
     int64_t iter_begin, iter_end, stash;
     // backward scratch (training workspace only)
-    int64_t g_a, g_b, g_c, g_pos, g_tmp, g_ffh, g_h1, g_h2, g_z, g_act, g_h3, g_qkv, g_emb, g_ref, g_D, g_bs, wT, g_kv, g_dqp, g_drop, kv_train;
+    int64_t g_a, g_b, g_c, g_pos, g_tmp, g_ffh, g_h1, g_h2, g_z, g_act, g_h3, g_qkv, g_emb, g_ref, g_D, g_bs, wT, g_kv, g_dqp, g_drop, kv_train, g_do, g_res, g_dq, g_Dall;
+    bool bwd_batched;                 // cross-attention backward of all iterations in one launch (shared layer weights, split cache)
     int64_t train_total;
     int64_t shift(int k) const { return k == 0 ? 0 : stash + (int64_t)(k - 1) * (iter_end - iter_begin) - iter_begin; }
 };
@@ -132,6 +133,15 @@ void build_arena(parq_ctx* c) {
     a.total = off;
 }
 
+// Training: the cross-attention backward of all recurrent iterations can run as ONE launch when the iterations share the layer
+// weights (hence K / V) and the split-precision kernel applies (head dim 64, long key axis); PARQ_BWD_BATCHED=0 restores the
+// per-iteration launches.
+bool bwd_batched_ok(const parq_ctx* c, int64_t N) {
+    const char* e = getenv("PARQ_BWD_BATCHED");          // read per call: the parity test compares both paths in one process
+    const int env = e ? atoi(e) : 1;
+    return env != 0 && c->nl == 1 && c->dh == 64 && N >= 2048 && c->I > 1 && c->I <= 16;
+}
+
 int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws) {
     const int64_t C = c->C, Q = c->Q, F = c->F;
     const int64_t M = (int64_t)B * Q;
@@ -176,8 +186,16 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     ws->wT = take(C * NH1 + 2 * C * C + 2 * C * F + 3 * C * C + 3 * C * C + C * C + 384 * C);
     ws->g_kv = take((int64_t)c->nl * B * 2 * N * C);
     ws->kv_train = take(split_mode ? (int64_t)c->nl * B * 2 * N * C : 0);     // fp32 K / V rebuilt from the split cache for the backward
-    ws->g_dqp = take((int64_t)attn_bwd_dq_partial_floats(B, c->H, (int)Q, (int)N, c->dh));
+    // batched cross-attention backward (see parq_backward): per-iteration dO, residual gradient, dQ and D rows, and one set of
+    // dQ partials per iteration
+    ws->bwd_batched = bwd_batched_ok(c, N);
+    const int64_t nit = ws->bwd_batched ? c->I : 1;
+    ws->g_dqp = take(nit * (int64_t)attn_bwd_dq_partial_floats(B, c->H, (int)Q, (int)N, c->dh));
     ws->g_drop = take(M * C);
+    ws->g_do = take(ws->bwd_batched ? nit * M * C : 0);
+    ws->g_res = take(ws->bwd_batched ? nit * M * C : 0);
+    ws->g_dq = take(ws->bwd_batched ? nit * M * C : 0);
+    ws->g_Dall = take(ws->bwd_batched ? nit * (int64_t)B * c->H * flash_lq_pad((int)Q) : 0);
     ws->train_total = off;
     return PARQ_OK;
 }
@@ -429,8 +447,42 @@ struct BwdIO {
     const float* center; const float* size;                                                    // forward outputs
 };
 
+// transposed copies of layer li's weights for the dX GEMMs (layout: see do_backward_iter)
+int do_backward_transposes(parq_ctx* c, float* wsp, const Workspace& ws, int li, hipStream_t s) {
+    const float* A = c->arena;
+    const Arena& ar = c->ar;
+    const LayerW& L = ar.layers[li];
+    const int C = c->C, F = c->F, NH1 = c->NH1;
+    float* wT = wsp + ws.wT;
+    float* h1T = wT;
+    float* h2T = h1T + (int64_t)C * NH1;
+    float* l1T = h2T + 2 * (int64_t)C * C;
+    float* l2T = l1T + (int64_t)C * F;
+    float* coT = l2T + (int64_t)C * F;
+    float* cqT = coT + (int64_t)C * C;
+    float* soT = cqT + (int64_t)C * C;
+    float* siT = soT + (int64_t)C * C;
+    float* p2T = siT + 3 * (int64_t)C * C;
+    float* p0T = p2T + (int64_t)C * C;
+    HIPCHK(launch_transpose(A + ar.heads1_w, C, h1T, NH1, NH1, C, s));
+    HIPCHK(launch_transpose(A + ar.heads2_w, C, h2T, C, C, C, s));
+    HIPCHK(launch_transpose(A + ar.heads2_w + (int64_t)C * C, C, h2T + (int64_t)C * C, C, C, C, s));
+    HIPCHK(launch_transpose(A + L.lin1_w, C, l1T, F, F, C, s));
+    HIPCHK(launch_transpose(A + L.lin2_w, F, l2T, C, C, F, s));
+    HIPCHK(launch_transpose(A + L.cross_out_w, C, coT, C, C, C, s));
+    HIPCHK(launch_transpose(A + L.cross_in_w, C, cqT, C, C, C, s));
+    HIPCHK(launch_transpose(A + L.self_out_w, C, soT, C, C, C, s));
+    HIPCHK(launch_transpose(A + L.self_in_w, C, siT, 3 * C, 3 * C, C, s));
+    HIPCHK(launch_transpose(A + ar.pe2_w, C, p2T, C, C, C, s));
+    HIPCHK(launch_transpose(A + ar.pe0_w, 384, p0T, C, C, 384, s));
+    return PARQ_OK;
+}
+
+// phase 0: the whole iteration.  Batched mode (Workspace::bwd_batched) cuts the chain at the cross-attention: phase 1 runs from the
+// outputs down to dO (kept per iteration in ws.g_do, with the residual gradient in ws.g_res and the D rows in ws.g_Dall), the
+// attention backward of all iterations is one launch in parq_backward, and phase 2 continues from that iteration's dQ (ws.g_dq).
 int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& ws, int k, const BwdIO& io, float* G,
-                     float* g_tokens, hipStream_t s) {
+                     float* g_tokens, hipStream_t s, int phase = 0) {
     const float* A = c->arena;
     const Arena& ar = c->ar;
     const int li = c->cfg.share_weights ? 0 : k;
@@ -468,21 +520,20 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     float* siT = soT + (int64_t)C * C;       // self in^T [C][3C]
     float* p2T = siT + 3 * (int64_t)C * C;   // pe2^T
     float* p0T = p2T + (int64_t)C * C;       // pe0^T [384][C]
-    HIPCHK(launch_transpose(A + ar.heads1_w, C, h1T, NH1, NH1, C, s));
-    HIPCHK(launch_transpose(A + ar.heads2_w, C, h2T, C, C, C, s));
-    HIPCHK(launch_transpose(A + ar.heads2_w + (int64_t)C * C, C, h2T + (int64_t)C * C, C, C, C, s));
-    HIPCHK(launch_transpose(A + L.lin1_w, C, l1T, F, F, C, s));
-    HIPCHK(launch_transpose(A + L.lin2_w, F, l2T, C, C, F, s));
-    HIPCHK(launch_transpose(A + L.cross_out_w, C, coT, C, C, C, s));
-    HIPCHK(launch_transpose(A + L.cross_in_w, C, cqT, C, C, C, s));
-    HIPCHK(launch_transpose(A + L.self_out_w, C, soT, C, C, C, s));
-    HIPCHK(launch_transpose(A + L.self_in_w, C, siT, 3 * C, 3 * C, C, s));
-    HIPCHK(launch_transpose(A + ar.pe2_w, C, p2T, C, C, C, s));
-    HIPCHK(launch_transpose(A + ar.pe0_w, 384, p0T, C, C, 384, s));
+    if (phase == 0) {
+        int rc = do_backward_transposes(c, wsp, ws, li, s);
+        if (rc) return rc;
+    }
 
     auto mm = [&](const float* X, int64_t ldx, const float* WT, int K, int Nn, float* Y, int64_t ldy) {   // Y = X W  (W^T given [Nn][K])
         return lin(X, ldx, WT, K, nullptr, Y, ldy, M, Nn, K);
     };
+    const int64_t MC = (int64_t)M * C;
+    if (phase == 2) {                                  // resume below the cross-attention with this iteration's dQ and residual gradient
+        gC = wsp + ws.g_dq + k * MC;
+        gB = wsp + ws.g_res + k * MC;
+    }
+    if (phase != 2) {
     HIPCHK(hipMemsetAsync(gRef, 0, (size_t)M * 3 * sizeof(float), s));
 
     // ---- heads (transformer_parq.py:234-279)
@@ -534,16 +585,20 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
         HIPCHK(launch_linear(a, 1, s));
     }
     // ---- norm2 / cross-attention (transformer_parq.py:377-382)
+    if (phase == 1) gB = wsp + ws.g_res + k * MC;                                              // the residual gradient outlives this call
+    float* gDo = phase == 1 ? wsp + ws.g_do + k * MC : gA;
+    float* Dc = phase == 1 ? wsp + ws.g_Dall + (int64_t)k * B * H * flash_lq_pad(Q) : Dd;
     HIPCHK(launch_ln_bwd(gA, wi + ws.xb, wi + ws.ln2, A + L.n2_w, gB, M, C, 0, G + L.n2_w, G + L.n2_b, s));   // gB = d / d xb
     {
         const float* gd = through_dropout(gB, 3);
         if (!gd) return fail(PARQ_ERR_HIP, "dropout_apply failed");
         HIPCHK(launch_gemm_tn(gd, C, wi + ws.attn, C, G + L.cross_out_w, C, M, C, C, 1, s));
         HIPCHK(launch_colsum(gd, C, M, C, G + L.cross_out_b, 1, s));
-        LinearArgs a = mm(gd, C, coT, C, C, gA, C);                                            // gA = d / d attention output
+        LinearArgs a = mm(gd, C, coT, C, C, gDo, C);                                           // d / d attention output
         HIPCHK(launch_linear(a, 1, s));
     }
-    HIPCHK(launch_attn_bwd_rowdot(gA, wi + ws.attn, (int64_t)Q * C, C, B, H, Q, dh, Dd, s));
+    HIPCHK(launch_attn_bwd_rowdot(gDo, wi + ws.attn, (int64_t)Q * C, C, B, H, Q, dh, Dc, s));
+    if (phase == 1) return PARQ_OK;
     HIPCHK(hipMemsetAsync(gC, 0, (size_t)M * C * sizeof(float), s));                           // gC = d / d q (atomics)
     {
         const float* kv = wsp + (c->cache_mode() ? ws.kv_train : ws.kv) + (int64_t)li * B * 2 * N * C;
@@ -555,6 +610,7 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
                                attn_bwd_dq_partial_floats(B, H, Q, (int)N, dh) ? wsp + ws.g_dqp : nullptr, dp, c->site_seed(k, 2),
                                reinterpret_cast<unsigned int*>(wsp + ws.g_bs)));      // g_bs: free between the GroupNorm passes
     }
+    }   // phase != 2
     // q = (x1 + pos) Wq^T + bq,  x1 = norm1(xa)
     HIPCHK(launch_layernorm(wi + ws.xa, A + L.n1_w, A + L.n1_b, tmp, M, C, eps, s));
     HIPCHK(launch_add(tmp, wi + ws.pos, tmp, (int64_t)M * C, s));                              // tmp = x1 + pos
@@ -972,9 +1028,9 @@ int parq_backward(parq_handle h, const parq_scene* scene, void* workspace, size_
     const int64_t M = (int64_t)scene->B * h->Q;
     const int64_t N = (int64_t)scene->V * scene->h * scene->w;
     HIPCHK(hipMemsetAsync(grad_arena, 0, (size_t)h->ar.total * sizeof(float), s));
-    HIPCHK(hipMemsetAsync(wsp + ws.g_kv, 0, (size_t)h->nl * scene->B * 2 * N * h->C * sizeof(float), s));
+    if (!ws.bwd_batched) HIPCHK(hipMemsetAsync(wsp + ws.g_kv, 0, (size_t)h->nl * scene->B * 2 * N * h->C * sizeof(float), s));
     if (d_tokens) HIPCHK(hipMemsetAsync(d_tokens, 0, (size_t)scene->B * N * h->C * sizeof(float), s));
-    for (int k = h->I - 1; k >= 0; --k) {
+    auto iter_io = [&](int k) {
         BwdIO io;
         io.g_logits = g->pred_logits ? g->pred_logits + k * M * h->ncls : nullptr;
         io.g_center = g->center_unnormalized ? g->center_unnormalized + k * M * 3 : nullptr;
@@ -982,7 +1038,44 @@ int parq_backward(parq_handle h, const parq_scene* scene, void* workspace, size_
         io.g_rot = g->ortho6d ? g->ortho6d + k * M * 6 : nullptr;
         io.center = outs->center_unnormalized + k * M * 3;
         io.size = outs->size_unnormalized + k * M * 3;
-        rc = do_backward_iter(h, scene, wsp, ws, k, io, grad_arena, d_tokens, s);
+        return io;
+    };
+    if (!ws.bwd_batched) {
+        for (int k = h->I - 1; k >= 0; --k) {
+            rc = do_backward_iter(h, scene, wsp, ws, k, iter_io(k), grad_arena, d_tokens, s);
+            if (rc) return rc;
+        }
+        return do_backward_kvproj(h, scene, wsp, ws, grad_arena, d_tokens, s);
+    }
+    // ---- batched: (1) every iteration from its outputs down to dO, (2) ONE cross-attention backward over all iterations
+    // (dK / dV written once, accumulated in registers), (3) every iteration from its dQ down to the sampled features
+    const int I = h->I, B = scene->B, C = h->C, H = h->H, dh = h->dh, Q = h->Q;
+    rc = do_backward_transposes(h, wsp, ws, 0, s);
+    if (rc) return rc;
+    for (int k = I - 1; k >= 0; --k) {
+        rc = do_backward_iter(h, scene, wsp, ws, k, iter_io(k), grad_arena, d_tokens, s, 1);
+        if (rc) return rc;
+    }
+    {
+        int64_t q_off[16], lse_off[16];
+        uint32_t seeds[16];
+        for (int k = 0; k < I; ++k) {
+            q_off[k] = ws.shift(k);
+            lse_off[k] = ws.shift(k);
+            seeds[k] = h->site_seed(k, 2);
+        }
+        const float* kv = wsp + (h->cache_mode() ? ws.kv_train : ws.kv);
+        float* gkv = wsp + ws.g_kv;
+        const int64_t MC = M * C;
+        HIPCHK(hipMemsetAsync(wsp + ws.g_dq, 0, (size_t)I * MC * sizeof(float), s));      // the partial-sum reduction accumulates
+        HIPCHK(launch_attn_bwd_batched(wsp + ws.qc, q_off, (int64_t)Q * C, dh, C, kv, 2 * N * C, N * dh, dh, kv + (int64_t)H * N * dh,
+                                       2 * N * C, N * dh, dh, wsp + ws.g_do, MC, (int64_t)Q * C, dh, C, wsp + ws.lse_c, lse_off,
+                                       wsp + ws.g_Dall, (int64_t)B * H * flash_lq_pad(Q), wsp + ws.g_dq, MC, (int64_t)Q * C, dh, C, gkv,
+                                       2 * N * C, dh, 2 * C, gkv + C, 2 * N * C, dh, 2 * C, B, H, Q, (int)N, dh, I, s, wsp + ws.g_dqp,
+                                       h->drop_p, seeds, reinterpret_cast<unsigned int*>(wsp + ws.g_bs)));
+    }
+    for (int k = I - 1; k >= 0; --k) {
+        rc = do_backward_iter(h, scene, wsp, ws, k, iter_io(k), grad_arena, d_tokens, s, 2);
         if (rc) return rc;
     }
     return do_backward_kvproj(h, scene, wsp, ws, grad_arena, d_tokens, s);

@@ -18,6 +18,8 @@ namespace parq {
 
 namespace {
 
+constexpr int kMaxBwdIters = 16;
+
 struct AttnBwdArgs {
     const float* q; int64_t q_batch, q_head, q_row;
     const float* k; int64_t k_batch, k_head, k_row;
@@ -32,6 +34,13 @@ struct AttnBwdArgs {
     float* gv; int64_t gv_batch, gv_head, gv_row;
     int B, H, Lq, Lk, accumulate_kv;
     float drop_p; uint32_t drop_seed;   // dropout on the probabilities (same stream as the forward)
+    // split kernel only: the recurrent iterations that share K / V, processed by ONE launch (dK / dV accumulate in registers over all
+    // of them).  Iteration t reads q + q_off[t], lse + lse_off[t], dO + t * do_it, D + t * D_it with dropout stream seeds[t] and
+    // writes its dQ partials at gq_part + t * gqp_it.  n_it = 1 with zero offsets is the plain single-iteration call.
+    int n_it;
+    int64_t do_it, D_it, gqp_it;
+    int64_t q_off[kMaxBwdIters], lse_off[kMaxBwdIters];
+    uint32_t seeds[kMaxBwdIters];
 };
 
 template <int DH>
@@ -382,6 +391,13 @@ __global__ __launch_bounds__(512) void attn_bwd_split_kernel(AttnBwdArgs a, cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) { gk[dt][r] = 0.f; gv[dt][r] = 0.f; }
 
+    for (int it = 0; it < a.n_it; ++it) {
+    // wave-uniform per-iteration bases (scalar registers)
+    const float* q_it = a.q + a.q_off[it] + (int64_t)b * a.q_batch + (int64_t)h * a.q_head;
+    const float* do_it = a.dO + (int64_t)it * a.do_it + (int64_t)b * a.do_batch + (int64_t)h * a.do_head;
+    const float* lse_it = a.lse + a.lse_off[it] + (int64_t)bh * Lq_pad;
+    const float* D_it = a.D + (int64_t)it * a.D_it + (int64_t)bh * Lq_pad;
+    const uint32_t seed_it = a.seeds[it];
     for (int i0 = 0; i0 < a.Lq; i0 += 32) {
         __syncthreads();                                    // previous tile fully consumed (also orders the Kt writes)
         {   // tile loader: thread -> (query i, 4 consecutive d); both layouts, hi and lo
@@ -389,8 +405,8 @@ __global__ __launch_bounds__(512) void attn_bwd_split_kernel(AttnBwdArgs a, cons
             const bool ok = i0 + i < a.Lq;
             float q4[4] = {0.f, 0.f, 0.f, 0.f}, o4[4] = {0.f, 0.f, 0.f, 0.f};
             if (ok) {
-                const float4 qq = *reinterpret_cast<const float4*>(a.q + (int64_t)b * a.q_batch + (int64_t)h * a.q_head + (int64_t)(i0 + i) * a.q_row + d4);
-                const float4 oo = *reinterpret_cast<const float4*>(a.dO + (int64_t)b * a.do_batch + (int64_t)h * a.do_head + (int64_t)(i0 + i) * a.do_row + d4);
+                const float4 qq = *reinterpret_cast<const float4*>(q_it + (int64_t)(i0 + i) * a.q_row + d4);
+                const float4 oo = *reinterpret_cast<const float4*>(do_it + (int64_t)(i0 + i) * a.do_row + d4);
                 q4[0] = qq.x; q4[1] = qq.y; q4[2] = qq.z; q4[3] = qq.w;
                 o4[0] = oo.x * oscale; o4[1] = oo.y * oscale; o4[2] = oo.z * oscale; o4[3] = oo.w * oscale;
             }
@@ -414,9 +430,9 @@ __global__ __launch_bounds__(512) void attn_bwd_split_kernel(AttnBwdArgs a, cons
             }
         }
         if (tid < 32) {
-            st[tid] = i0 + tid < a.Lq ? a.lse[(int64_t)bh * Lq_pad + i0 + tid] : 0.f;
-            st[32 + tid] = i0 + tid < a.Lq ? a.D[(int64_t)bh * Lq_pad + i0 + tid] * oscale : 0.f;
-            if (DROP) reinterpret_cast<uint32_t*>(st + 64)[tid] = drop_rowhash(a.drop_seed, (uint32_t)(bh * a.Lq + i0 + tid));
+            st[tid] = i0 + tid < a.Lq ? lse_it[i0 + tid] : 0.f;
+            st[32 + tid] = i0 + tid < a.Lq ? D_it[i0 + tid] * oscale : 0.f;
+            if (DROP) reinterpret_cast<uint32_t*>(st + 64)[tid] = drop_rowhash(seed_it, (uint32_t)(bh * a.Lq + i0 + tid));
         }
         __syncthreads();
 
@@ -521,10 +537,10 @@ __global__ __launch_bounds__(512) void attn_bwd_split_kernel(AttnBwdArgs a, cons
             // accumulator: rows (wave>>2)*16 + 4 kq + r, column dcol
             const int qb = (wave >> 2) * 16;
             if (a.gq_part) {
-                float* part = a.gq_part + (((int64_t)bh * gridDim.x + blockIdx.x) * Lq_pad + i0) * 64;
+                float* part = a.gq_part + (int64_t)it * a.gqp_it + (((int64_t)bh * gridDim.x + blockIdx.x) * Lq_pad + i0) * 64;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) part[(qb + 4 * kq + r) * 64 + dcol] = g4[r] * cn * inv_os;
-            } else {
+            } else {                                        // single-iteration calls only (the launcher enforces it)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = i0 + qb + 4 * kq + r;
@@ -533,6 +549,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split_kernel(AttnBwdArgs a, cons
                 }
             }
         }
+    }
     }
     // ---- dK, dV of this wave's keys: (d x keys) accumulators -> [key][d] through LDS (the Ds region, free now), row-contiguous update
     __syncthreads();
@@ -579,8 +596,11 @@ __global__ void absmax_kernel(const float* __restrict__ x, int64_t n, unsigned i
 
 // gq[b][i][h*64 + d] += sum_kb part[bh][kb][i][d]
 __global__ __launch_bounds__(256) void attn_bwd_dq_reduce_kernel(const float* __restrict__ part, int nkb, int Lq, int Lq_pad, int H,
-                                                                 float* __restrict__ gq, int64_t gq_batch, int64_t gq_head, int64_t gq_row) {
+                                                                 float* __restrict__ gq, int64_t gq_batch, int64_t gq_head, int64_t gq_row,
+                                                                 int64_t part_it, int64_t gq_it) {
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    part += (int64_t)blockIdx.z * part_it;                  // recurrent iteration (batched backward)
+    gq += (int64_t)blockIdx.z * gq_it;
     const int idx = blockIdx.x * 256 + threadIdx.x;          // (i, d)
     const int i = idx >> 6, d = idx & 63;
     if (i >= Lq) return;
@@ -618,6 +638,17 @@ __global__ __launch_bounds__(256) void attn_bwd_rowdot_kernel(const float* __res
 
 }  // namespace
 
+constexpr size_t kSplitBwdLds = (size_t)(8 * 2048 + 2 * 8192 + 2 * 16384) * sizeof(_Float16) + 96 * sizeof(float);
+static hipError_t split_bwd_lds_attr() {
+    static bool done = false;
+    if (done) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitBwdLds);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitBwdLds);
+    if (e == hipSuccess) done = true;
+    return e;
+}
+
 // q/k/v/dO/g*: element strides (batch, head, row); lse, D: [B*H][pad32(Lq)].  gq must be zeroed by the caller.
 hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int64_t q_row, const float* k, int64_t k_batch,
                            int64_t k_head, int64_t k_row, const float* v, int64_t v_batch, int64_t v_head, int64_t v_row,
@@ -638,6 +669,10 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
     a.gv = gv; a.gv_batch = gv_batch; a.gv_head = gv_head; a.gv_row = gv_row;
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.accumulate_kv = accumulate_kv; a.gq_part = nullptr;
     a.drop_p = drop_p; a.drop_seed = drop_seed;
+    a.n_it = 1; a.do_it = a.D_it = a.gqp_it = 0;
+    memset(a.q_off, 0, sizeof(a.q_off));
+    memset(a.lse_off, 0, sizeof(a.lse_off));
+    for (int t = 0; t < kMaxBwdIters; ++t) a.seeds[t] = drop_seed;
     dim3 grid(ceil_div(Lk, 256), B * H);
     static const int force = [] {
         const char* e = getenv("PARQ_ATTN_BWD");            // "naive" / "mfma" (exact fp32 MFMA): debugging overrides of the split kernel
@@ -651,15 +686,9 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
         hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, s, dO, (int64_t)B * do_batch, absmax);
         float* oscale = reinterpret_cast<float*>(absmax + 1);
         hipLaunchKernelGGL(oscale_kernel, dim3(1), dim3(1), 0, s, absmax, oscale);
-        const size_t lds = (size_t)(8 * 2048 + 2 * 8192 + 2 * 16384) * sizeof(_Float16) + 96 * sizeof(float);
-        static bool attr_s = false;
-        if (!attr_s) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_s = true;
-        }
+        const size_t lds = kSplitBwdLds;
+        e = split_bwd_lds_attr();
+        if (e != hipSuccess) return e;
         dim3 g2(ceil_div(Lk, kSpKW), B * H);
         a.gq_part = gq_part;
         if (drop_p > 0.f) hipLaunchKernelGGL(attn_bwd_split_kernel<true>, g2, dim3(512), lds, s, a, oscale);
@@ -667,7 +696,7 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
         if (a.gq_part) {
             const int Lq_pad = (Lq + 31) & ~31;
             hipLaunchKernelGGL(attn_bwd_dq_reduce_kernel, dim3(ceil_div(Lq * 64, 256), B * H), dim3(256), 0, s, gq_part, (int)g2.x, Lq,
-                               Lq_pad, H, gq, gq_batch, gq_head, gq_row);
+                               Lq_pad, H, gq, gq_batch, gq_head, gq_row, (int64_t)0, (int64_t)0);
         }
         return hipGetLastError();
     }
@@ -692,7 +721,7 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
         if (a.gq_part) {
             const int Lq_pad = (Lq + 31) & ~31;
             hipLaunchKernelGGL(attn_bwd_dq_reduce_kernel, dim3(ceil_div(Lq * 64, 256), B * H), dim3(256), 0, s, gq_part, (int)g2.x, Lq,
-                               Lq_pad, H, gq, gq_batch, gq_head, gq_row);
+                               Lq_pad, H, gq, gq_batch, gq_head, gq_row, (int64_t)0, (int64_t)0);
         }
         return hipGetLastError();
     }
@@ -717,6 +746,56 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
         }
         hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, dim3(256), lds, s, a);
     }
+    return hipGetLastError();
+}
+
+// Cross-attention backward of n_it recurrent iterations that share K / V (hoisted projection, shared layer weights) in ONE launch of
+// the split-precision kernel: dK / dV are written once instead of read-modify-written per iteration, and the K / V prologue and the
+// transposing epilogue are paid once per key block instead of once per iteration.  q / lse of iteration t live at q + q_off[t] /
+// lse + lse_off[t] (activation stash); dO, D, the dQ partials and gq are arrays over the iterations with strides do_it, D_it,
+// attn_bwd_dq_partial_floats(...) and gq_it.  gk / gv are overwritten.  absmax: 8-byte device scratch.
+hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t q_batch, int64_t q_head, int64_t q_row, const float* k,
+                                   int64_t k_batch, int64_t k_head, int64_t k_row, const float* v, int64_t v_batch, int64_t v_head,
+                                   int64_t v_row, const float* dO, int64_t do_it, int64_t do_batch, int64_t do_head, int64_t do_row,
+                                   const float* lse, const int64_t* lse_off, const float* D, int64_t D_it, float* gq, int64_t gq_it,
+                                   int64_t gq_batch, int64_t gq_head, int64_t gq_row, float* gk, int64_t gk_batch, int64_t gk_head,
+                                   int64_t gk_row, float* gv, int64_t gv_batch, int64_t gv_head, int64_t gv_row, int B, int H, int Lq,
+                                   int Lk, int dh, int n_it, hipStream_t s, float* gq_part, float drop_p, const uint32_t* seeds,
+                                   unsigned int* absmax) {
+    if (dh != 64 || Lk < 2048 || n_it < 1 || n_it > kMaxBwdIters || !gq_part || !absmax) return hipErrorInvalidValue;
+    AttnBwdArgs a;
+    a.q = q; a.q_batch = q_batch; a.q_head = q_head; a.q_row = q_row;
+    a.k = k; a.k_batch = k_batch; a.k_head = k_head; a.k_row = k_row;
+    a.v = v; a.v_batch = v_batch; a.v_head = v_head; a.v_row = v_row;
+    a.dO = dO; a.do_batch = do_batch; a.do_head = do_head; a.do_row = do_row;
+    a.lse = lse; a.D = D;
+    a.gq = gq; a.gq_batch = gq_batch; a.gq_head = gq_head; a.gq_row = gq_row;
+    a.gk = gk; a.gk_batch = gk_batch; a.gk_head = gk_head; a.gk_row = gk_row;
+    a.gv = gv; a.gv_batch = gv_batch; a.gv_head = gv_head; a.gv_row = gv_row;
+    a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.accumulate_kv = 0; a.gq_part = gq_part;
+    a.drop_p = drop_p; a.drop_seed = seeds ? seeds[0] : 0;
+    a.n_it = n_it; a.do_it = do_it; a.D_it = D_it;
+    a.gqp_it = (int64_t)attn_bwd_dq_partial_floats(B, H, Lq, Lk, dh);
+    for (int t = 0; t < kMaxBwdIters; ++t) {
+        a.q_off[t] = t < n_it ? q_off[t] : 0;
+        a.lse_off[t] = t < n_it ? lse_off[t] : 0;
+        a.seeds[t] = (t < n_it && seeds) ? seeds[t] : 0;
+    }
+    // one power-of-two scale for all iterations: max |dO| over the whole [n_it] array
+    hipError_t e = hipMemsetAsync(absmax, 0, sizeof(unsigned int), s);
+    if (e != hipSuccess) return e;
+    for (int t = 0; t < n_it; ++t)
+        hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, s, dO + (int64_t)t * do_it, (int64_t)B * do_batch, absmax);
+    float* oscale = reinterpret_cast<float*>(absmax + 1);
+    hipLaunchKernelGGL(oscale_kernel, dim3(1), dim3(1), 0, s, absmax, oscale);
+    e = split_bwd_lds_attr();
+    if (e != hipSuccess) return e;
+    dim3 g2(ceil_div(Lk, kSpKW), B * H);
+    if (drop_p > 0.f) hipLaunchKernelGGL(attn_bwd_split_kernel<true>, g2, dim3(512), kSplitBwdLds, s, a, oscale);
+    else hipLaunchKernelGGL(attn_bwd_split_kernel<false>, g2, dim3(512), kSplitBwdLds, s, a, oscale);
+    const int Lq_pad = (Lq + 31) & ~31;
+    hipLaunchKernelGGL(attn_bwd_dq_reduce_kernel, dim3(ceil_div(Lq * 64, 256), B * H, n_it), dim3(256), 0, s, gq_part, (int)g2.x, Lq,
+                       Lq_pad, H, gq, gq_batch, gq_head, gq_row, a.gqp_it, gq_it);
     return hipGetLastError();
 }
 

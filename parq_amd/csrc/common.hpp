@@ -212,6 +212,15 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
                            int64_t gk_head, int64_t gk_row, float* gv, int64_t gv_batch, int64_t gv_head, int64_t gv_row, int B, int H,
                            int Lq, int Lk, int dh, int accumulate_kv, hipStream_t s, float* gq_part = nullptr, float drop_p = 0.f,
                            uint32_t drop_seed = 0, unsigned int* absmax = nullptr);   // absmax: 8-byte device scratch -> split-precision kernel
+// all recurrent iterations that share K / V in one launch (split-precision kernel; see attn_bwd.hip)
+hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t q_batch, int64_t q_head, int64_t q_row, const float* k,
+                                   int64_t k_batch, int64_t k_head, int64_t k_row, const float* v, int64_t v_batch, int64_t v_head,
+                                   int64_t v_row, const float* dO, int64_t do_it, int64_t do_batch, int64_t do_head, int64_t do_row,
+                                   const float* lse, const int64_t* lse_off, const float* D, int64_t D_it, float* gq, int64_t gq_it,
+                                   int64_t gq_batch, int64_t gq_head, int64_t gq_row, float* gk, int64_t gk_batch, int64_t gk_head,
+                                   int64_t gk_row, float* gv, int64_t gv_batch, int64_t gv_head, int64_t gv_row, int B, int H, int Lq,
+                                   int Lk, int dh, int n_it, hipStream_t s, float* gq_part, float drop_p, const uint32_t* seeds,
+                                   unsigned int* absmax);
 // dst = dropout(src): keep mask of stream `seed` over the (M, N) index space, scaled by 1 / (1 - p)
 hipError_t launch_dropout_apply(const float* src, float* dst, int M, int N, float p, uint32_t seed, hipStream_t s);
 size_t attn_bwd_dq_partial_floats(int B, int H, int Lq, int Lk, int dh);

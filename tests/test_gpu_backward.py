@@ -285,3 +285,36 @@ def test_dropout_forward_backward_match_masked_oracle(h, w):
     # a second call draws a new seed -> different outputs; eval mode ignores dropout
     outs2 = dec.forward_train(*scene_args(sc))
     assert not torch.equal(outs2[0]["ortho6d"], outs[0]["ortho6d"])
+
+
+@pytest.mark.parametrize("pdrop", [0.0, 0.2])
+def test_batched_cross_attention_backward_equals_per_iteration_launches(monkeypatch, pdrop):
+    """Training backward with shared layer weights: the cross-attention backward of all iterations as ONE launch (dK / dV
+    accumulated in registers, written once) against the per-iteration launches that read-modify-write dK / dV
+    (PARQ_BWD_BATCHED=0).  Same stash, same dropout streams; only summation order and the power-of-two dO scale differ."""
+    B, V, h, w, Q, heads, dim, ffn, I = 2, 3, 32, 40, 40, 2, 128, 96, 4
+    cfg = synth.decoder_cfg(dim=dim, queries=Q, heads=heads, ffn=ffn, layers=I, dropout=pdrop)
+    W = synth.make_decoder_weights(cfg, 171)
+    sc = synth.make_scene(172, B, V, h, w, dim, smooth=True)
+    ncls = cfg.NUM_SEMCLS + 1
+    cots = {"pred_logits": synth.normal(173, "cl", (I, B, Q, ncls)), "center_unnormalized": synth.normal(174, "cc", (I, B, Q, 3)),
+            "size_unnormalized": synth.normal(175, "cs", (I, B, Q, 3)), "ortho6d": synth.normal(176, "cr", (I, B, Q, 6))}
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PARQ_BWD_BATCHED", mode)
+        dec = make_decoder(cfg, W).train()
+        torch.manual_seed(99)                                     # the dropout seed of forward_train comes from torch's generator
+        dec.forward_train(*scene_args(sc))
+        grads, d_tok = dec.backward({k: torch.from_numpy(v) for k, v in cots.items()})
+        res[mode] = ({k: v.cpu().numpy().astype(np.float64) for k, v in grads.items()}, d_tok.cpu().numpy().astype(np.float64))
+    worst = 0.0
+    for name, a in res["1"][0].items():
+        b = res["0"][0][name]
+        if np.abs(b).max() == 0:
+            assert np.abs(a).max() == 0, name
+            continue
+        worst = max(worst, np.linalg.norm(a - b) / np.linalg.norm(b))
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 2e-5, name
+    ta, tb = res["1"][1], res["0"][1]
+    assert np.linalg.norm(ta - tb) / np.linalg.norm(tb) < 2e-5
+    print("\nbatched vs per-iteration backward: worst relative difference %.2e" % worst)
