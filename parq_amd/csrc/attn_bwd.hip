@@ -385,6 +385,9 @@ __global__ __launch_bounds__(512) void attn_bwd_split_kernel(AttnBwdArgs a, cons
             }
         }
     }
+    // dropout: this lane's key is the column of every element it handles -> one column hash for the whole launch
+    const uint32_t drop_col = DROP ? drop_colhash((uint32_t)j) : 0u;
+    const uint32_t drop_thr = DROP ? drop_threshold(a.drop_p) : 0u;
     f32x16 gk[2], gv[2];                    // dK^T, dV^T: rows d (2 x 32), columns this wave's keys
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split_kernel(AttnBwdArgs a, cons
             const uint32_t* rhs = reinterpret_cast<const uint32_t*>(st + 64);
 #pragma unroll 1
             for (int r = 0; r < 16; ++r)
-                keep_bits |= (drop_keep(rhs[(r & 3) + 8 * (r >> 2) + 4 * kh], (uint32_t)j, a.drop_p) ? 1u : 0u) << r;
+                keep_bits |= (drop_keep_h(rhs[(r & 3) + 8 * (r >> 2) + 4 * kh], drop_col, drop_thr) ? 1u : 0u) << r;
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m) {

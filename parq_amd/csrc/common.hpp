@@ -58,11 +58,16 @@ __host__ __device__ inline uint32_t rng_mix(uint32_t x) {
 __host__ __device__ inline uint32_t rng_stream(uint32_t base, uint32_t stream) { return rng_mix(base ^ rng_mix(stream * 0x9e3779b9U + 0x85ebca6bU)); }
 // The index space of a dropout site is 2-D, (row, col): activations (m, n); attention probabilities (bh * Lq + q, key).  The row
 // part of the hash is computed once per row (per lane in the forward attention kernels, per query tile in the backward ones),
-// leaving one multiply-xorshift round per element.
+// the column part once per column where a kernel can share it (below).
 __host__ __device__ inline uint32_t drop_rowhash(uint32_t seed, uint32_t row) { return rng_mix(seed ^ (row * 0x9e3779b1U)); }
+// keep(row, col) = ((rowhash(seed, row) ^ colhash(col)) >> 8) >= ceil(p * 2^24): the column part does not depend on the seed, so
+// the attention kernels hash a key ONCE (per stage in the forward, per lane in the backward, where a lane owns a key) and spend
+// one xor + compare per element; entries are uniform and pairwise independent (xor of two independently mixed words).
+__host__ __device__ inline uint32_t drop_colhash(uint32_t col) { return rng_mix(col * 0x85ebca77U + 0x6a09e667U); }
+__host__ __device__ inline uint32_t drop_threshold(float p) { return (uint32_t)ceilf(p * 16777216.0f); }
+__host__ __device__ inline bool drop_keep_h(uint32_t rowhash, uint32_t colhash, uint32_t thr) { return ((rowhash ^ colhash) >> 8) >= thr; }
 __host__ __device__ inline bool drop_keep(uint32_t rowhash, uint32_t col, float p) {
-    const uint32_t h = rng_mix(rowhash ^ (col * 0x85ebca77U));
-    return (float)(h >> 8) >= p * 16777216.0f;
+    return drop_keep_h(rowhash, drop_colhash(col), drop_threshold(p));
 }
 
 // 16-bit operand kinds of the matrix pipe.  A half8 is used as the raw 8 x 16-bit container for both.

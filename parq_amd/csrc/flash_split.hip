@@ -257,6 +257,10 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
     };
 
     const uint32_t drop_rh = DROP ? drop_rowhash(a.drop_seed, (uint32_t)(bh * a.Lq + q)) : 0u;      // this lane's query row
+    const uint32_t drop_thr = DROP ? drop_threshold(a.drop_p) : 0u;
+    // dropout column hashes of the 64 keys of the stage in flight: lane l of every wave hashes key l once, the wave reads them back
+    // as 16-byte groups (private 256-byte area per wave behind the ring: LDS operations of one wave execute in order)
+    uint32_t* drop_ch = reinterpret_cast<uint32_t*>(smem_h + (size_t)kRing * kStageBlks * kBlkHalfs) + wave * 64;
     // state of the stage in flight
     f32x16 sacc[2];
     half8 phi[2][2], plo[2][2];
@@ -268,6 +272,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
         const int nb = (nblk - t * kStageBlks) < kStageBlks ? (nblk - t * kStageBlks) : kStageBlks;   // wave-uniform
         const _Float16* S0 = smem_h + buf * kStageBlks * kBlkHalfs;
         const int ksw = (li >> 1) & 7;
+        if constexpr (DROP) drop_ch[lane] = drop_colhash((uint32_t)(t * kStageBlks * kBlkKeys + lane));
         static_assert(kStageBlks == 2, "the software pipeline below is written for two blocks per stage");
         // Software pipeline over the two 32-key blocks of the stage, written so that every VALU section
         // (softmax of one block) sits between the MFMAs of the other block and can issue in their shadow:
@@ -335,10 +340,12 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
                 }
                 if constexpr (DROP) {           // the normaliser above stays undropped (nn.MultiheadAttention dropout)
                     const float inv = 1.f / (1.f - a.drop_p);
+                    // keys mfma32_row(8 m + e, lane) = 16 m + 4 kh + (e & 3) + 8 (e >> 2) of block kb: two groups of 4 consecutive hashes
+                    const uint4 c0 = *reinterpret_cast<const uint4*>(drop_ch + kb * 32 + 16 * m + 4 * kh);
+                    const uint4 c1 = *reinterpret_cast<const uint4*>(drop_ch + kb * 32 + 16 * m + 4 * kh + 8);
+                    const uint32_t ch[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        p[e] = drop_keep(drop_rh, (uint32_t)((t * kStageBlks + kb) * kBlkKeys + mfma32_row(8 * m + e, lane)), a.drop_p)
-                                   ? p[e] * inv : 0.f;
+                    for (int e = 0; e < 8; ++e) p[e] = drop_keep_h(drop_rh, ch[e], drop_thr) ? p[e] * inv : 0.f;
                 }
                 if constexpr (TERMS == 3) split8(p, phi[kb][m], plo[kb][m]);
                 else phi[kb][m] = cvt8_rn<KIND>(p);
@@ -488,7 +495,7 @@ hipError_t launch_kvsplit_to_f32(const void* cache, int B, int H, int N, float* 
 template <int TERMS, int KIND, bool DROP = false>
 static hipError_t launch_flash_t(const FlashArgs& b, const void* cache, hipStream_t s) {
     static bool attr_set = false;
-    const size_t lds = (size_t)kRing * kStageBlks * Blk<TERMS>::bytes;
+    const size_t lds = (size_t)kRing * kStageBlks * Blk<TERMS>::bytes + (DROP ? kNW * 64 * sizeof(uint32_t) : 0);
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_split_kernel<TERMS, KIND, DROP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

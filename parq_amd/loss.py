@@ -96,20 +96,36 @@ class HungarianMatcherModified:
 
 # ---------------------------------------------------------------- targets (model/parq_decoder.py:165-203)
 def parse_target(obbs_padded: Obb3D, T_world_local):
-    T_local_world = Pose(raw(T_world_local)).inverse()
+    """Per scene: labels, centres / sizes / rotations / corners of the ground-truth boxes in the local frame
+    (model/parq_decoder.py:165-203).  Evaluated for the padded (B, max_box) array at once — one host read for the box counts —
+    and sliced per scene (the reference loops over scenes with a dozen small launches each)."""
+    X = raw(obbs_padded)
+    keep = ~torch.all(X == -1, dim=-1)
+    counts = keep.sum(-1).tolist() if X.ndim == 3 else None
+    if counts is None:
+        raise AssertionError("obbs_padded must be (B, max_box, 19)")
+    boxes = Obb3D(X)
+    T_local_world = Pose(raw(T_world_local)).inverse()                        # (B, 1, 12)
+    T_lo = Pose(raw(T_local_world)).compose(boxes.T_world_object)             # local <- object, (B, max_box, 12)
+    center = T_lo.transform(boxes.bb3_center_object.unsqueeze(-2)).squeeze(-2)
+    corners_obj = boxes.bb3corners_object
+    gt_corners = T_lo.transform(corners_obj)
+    gt_corners_world = boxes.T_world_object.transform(corners_obj)
+    T44 = T_lo.matrix
+    o6 = rot_to_6d(T_lo.R)
+    labels = boxes.sem_id.squeeze(-1).long()
+    size = boxes.bb3_size
     out = []
-    for i in range(raw(obbs_padded).shape[0]):
-        boxes = obbs_padded[i].remove_padding()
-        T_lo = Pose(raw(T_local_world[i])).compose(boxes.T_world_object)         # local <- object
+    for i, n in enumerate(counts):
         out.append({
-            "labels": boxes.sem_id.squeeze(-1).long(),
-            "center": T_lo.transform(boxes.bb3_center_object.unsqueeze(1)).squeeze(1),
-            "size": boxes.bb3_size,
-            "T_rig_object": T_lo.matrix.view(-1, 4, 4),
-            "gt_corners": T_lo.transform(boxes.bb3corners_object),
-            "gt_ortho6d": rot_to_6d(T_lo.R),
-            "gt_corners_world": boxes.T_world_object.transform(boxes.bb3corners_object),
-            "T_world_object": boxes.T_world_object,
+            "labels": labels[i, :n],
+            "center": center[i, :n],
+            "size": size[i, :n],
+            "T_rig_object": T44[i, :n].reshape(-1, 4, 4),
+            "gt_corners": gt_corners[i, :n],
+            "gt_ortho6d": o6[i, :n],
+            "gt_corners_world": gt_corners_world[i, :n],
+            "T_world_object": Pose(raw(boxes.T_world_object)[i, :n]),
         })
     return out
 
@@ -212,22 +228,23 @@ def decoder_loss_batched(out_dict_list, obbs_padded, T_world_local, sym=None, *,
         l1 = torch.cdist(torch.stack([o["coord_pos"] for o in out_dict_list]).flatten(0, 1), tc.repeat(I, 1, 1), p=1).view(I, B, Q, nmax)
         prob_h, l1_h = prob.cpu(), l1.cpu()
     seg, pi_all, gi_all, bi_all = [], [], [], []          # flat matched pairs: segment (k*B+b), query, box, scene
-    punish = torch.ones(I, B, Q)
-    has_punish = torch.zeros(I, B, dtype=torch.bool)
-    valid = torch.zeros(I, B, dtype=torch.bool)
+    punish_np = np.ones((I, B, Q), dtype=bool)
+    valid_np = np.zeros((I, B), dtype=bool)
+    prob_np, l1_np = prob_h.numpy(), l1_h.numpy()          # host loop on NumPy views: no per-(iteration, scene) torch dispatch or sync
+    ids_np = [t["labels"].cpu().numpy() for t in targets]
     for k in range(I):
         plist = []
         idx_k = []
         for b in range(B):
-            ids = targets[b]["labels"].cpu()
+            ids = ids_np[b]
             n = len(ids)
             if n == 0:
                 idx_k.append((np.zeros(0, np.int64), np.zeros(0, np.int64)))
                 continue
-            l1b = l1_h[k, b, :, :n]
-            cost = matcher.cost_bbox * l1b - matcher.cost_class * prob_h[k, b][:, ids]
+            l1b = l1_np[k, b, :, :n]
+            cost = matcher.cost_bbox * l1b - matcher.cost_class * prob_np[k, b][:, ids]
             rows, cols = linear_sum_assignment(cost)
-            near = (l1b < matcher.ratio).numpy()
+            near = l1b < matcher.ratio
             extra_p, extra_g, mask_np = [], [], None
             for j in range(n):
                 pidx = np.nonzero(near[:, j])[0]
@@ -247,20 +264,20 @@ def decoder_loss_batched(out_dict_list, obbs_padded, T_world_local, sym=None, *,
             pi, gi = idx_k[b]
             if len(pi) == 0:
                 continue
-            valid[k, b] = True
+            valid_np[k, b] = True
             seg.append(np.full(len(pi), k * B + b)); pi_all.append(pi); gi_all.append(gi); bi_all.append(np.full(len(pi), b))
-            punish[k, b] = torch.from_numpy(plist[b])          # the reference indexes its list by scene number (quirk kept)
-            has_punish[k, b] = True
+            punish_np[k, b] = plist[b]                         # the reference indexes its list by scene number (quirk kept)
+    punish = torch.from_numpy(punish_np).to(torch.float32)
+    valid = torch.from_numpy(valid_np)
     last = out_dict_list[-1]
     total0 = (last["ortho6d"].sum() * last["size_unnormalized"].sum() * last["center_unnormalized"].sum() * last["pred_logits"].sum() * 0)
-    valid_bs = int(valid.sum())
+    valid_bs = int(valid_np.sum())
     if valid_bs == 0:
         return {"center_loss": 0, "size_loss": 0, "rot_loss": 0, "cat_loss": 0, "total_loss": total0}
-    seg_t = torch.from_numpy(np.concatenate(seg)).to(dev)
+    packed = torch.from_numpy(np.stack([np.concatenate(seg), np.concatenate(pi_all), np.concatenate(gi_all),
+                                        np.concatenate(bi_all)]).astype(np.int64)).to(dev)          # one host -> device copy
+    seg_t, pi_t, gi_t, bi_t = packed[0], packed[1], packed[2], packed[3]
     kk = seg_t // B
-    pi_t = torch.from_numpy(np.concatenate(pi_all)).to(dev)
-    gi_t = torch.from_numpy(np.concatenate(gi_all)).to(dev)
-    bi_t = torch.from_numpy(np.concatenate(bi_all)).to(dev)
     nseg = I * B
     cnt = torch.zeros(nseg, device=dev).index_add_(0, seg_t, torch.ones_like(seg_t, dtype=torch.float32))
 
