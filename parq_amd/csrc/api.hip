@@ -68,7 +68,7 @@ struct Workspace {
     int64_t sa, ln3, lse_s, lse_c, refk;
     int64_t iter_begin, iter_end, stash;
     // backward scratch (training workspace only)
-    int64_t g_a, g_b, g_c, g_pos, g_tmp, g_ffh, g_h1, g_h2, g_z, g_act, g_h3, g_qkv, g_emb, g_ref, g_D, g_bs, wT, g_kv, g_dqp, g_drop, kv_train, g_do, g_res, g_dq, g_Dall;
+    int64_t g_a, g_b, g_c, g_pos, g_tmp, g_ffh, g_h1, g_h2, g_z, g_act, g_h3, g_qkv, g_emb, g_ref, g_D, g_bs, wT, g_kv, g_dqp, g_drop, kv_train, g_do, g_res, g_dq, g_Dall, g_kvmax;
     bool bwd_batched;                 // cross-attention backward of all iterations in one launch (shared layer weights, split cache)
     int64_t train_total;
     int64_t shift(int k) const { return k == 0 ? 0 : stash + (int64_t)(k - 1) * (iter_end - iter_begin) - iter_begin; }
@@ -196,6 +196,7 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     ws->g_res = take(ws->bwd_batched ? nit * M * C : 0);
     ws->g_dq = take(ws->bwd_batched ? nit * M * C : 0);
     ws->g_Dall = take(ws->bwd_batched ? nit * (int64_t)B * c->H * flash_lq_pad((int)Q) : 0);
+    ws->g_kvmax = take(4);                            // [0] bits of max |dK|, |dV| (batched backward), [1] the derived scale
     ws->train_total = off;
     return PARQ_OK;
 }
@@ -687,8 +688,15 @@ int do_backward_kvproj(parq_ctx* c, const parq_scene* sc, float* wsp, const Work
         const LayerW& L = c->ar.layers[li];
         const float* g = wsp + ws.g_kv + (int64_t)li * B * 2 * N * C;          // [B*N][2C]
         const int Mr = (int)(B * N);
-        HIPCHK(launch_gemm_tn(g, 2 * C, sc->tokens, C, G + L.cross_in_w + (int64_t)C * C, C, Mr, 2 * C, C, 1, s));
-        HIPCHK(launch_colsum(g, 2 * C, Mr, 2 * C, G + L.cross_in_b + C, 1, s));
+        static const bool split_off = [] { const char* e = getenv("PARQ_KVPROJ_BWD"); return e && e[0] == 'f'; }();   // "fp32": generic kernels
+        if (ws.bwd_batched && kvproj_bwd_split_supported(C) && !split_off) {
+            // dW, db on the fp16 matrix pipe (hi/lo split); g is scaled by the power of two derived from max |g| (attention epilogue)
+            HIPCHK(launch_kvproj_bwd_split(g, sc->tokens, Mr, C, G + L.cross_in_w + (int64_t)C * C, G + L.cross_in_b + C,
+                                           reinterpret_cast<const unsigned int*>(wsp + ws.g_kvmax), wsp + ws.g_kvmax + 1, s));
+        } else {
+            HIPCHK(launch_gemm_tn(g, 2 * C, sc->tokens, C, G + L.cross_in_w + (int64_t)C * C, C, Mr, 2 * C, C, 1, s));
+            HIPCHK(launch_colsum(g, 2 * C, Mr, 2 * C, G + L.cross_in_b + C, 1, s));
+        }
         if (g_tokens) {
             HIPCHK(launch_transpose(A + L.cross_in_w + (int64_t)C * C, C, wT, 2 * C, 2 * C, C, s));
             LinearArgs a = lin(g, 2 * C, wT, 2 * C, nullptr, g_tokens, C, Mr, C, 2 * C);
@@ -1072,7 +1080,8 @@ int parq_backward(parq_handle h, const parq_scene* scene, void* workspace, size_
                                        2 * N * C, N * dh, dh, wsp + ws.g_do, MC, (int64_t)Q * C, dh, C, wsp + ws.lse_c, lse_off,
                                        wsp + ws.g_Dall, (int64_t)B * H * flash_lq_pad(Q), wsp + ws.g_dq, MC, (int64_t)Q * C, dh, C, gkv,
                                        2 * N * C, dh, 2 * C, gkv + C, 2 * N * C, dh, 2 * C, B, H, Q, (int)N, dh, I, s, wsp + ws.g_dqp,
-                                       h->drop_p, seeds, reinterpret_cast<unsigned int*>(wsp + ws.g_bs)));
+                                       h->drop_p, seeds, reinterpret_cast<unsigned int*>(wsp + ws.g_bs),
+                                       reinterpret_cast<unsigned int*>(wsp + ws.g_kvmax)));
     }
     for (int k = I - 1; k >= 0; --k) {
         rc = do_backward_iter(h, scene, wsp, ws, k, iter_io(k), grad_arena, d_tokens, s, 2);

@@ -41,6 +41,7 @@ struct AttnBwdArgs {
     int64_t do_it, D_it, gqp_it;
     int64_t q_off[kMaxBwdIters], lse_off[kMaxBwdIters];
     uint32_t seeds[kMaxBwdIters];
+    unsigned int* kv_absmax;   // optional: atomicMax of the bit pattern of |dK|, |dV| as written (scale of the projection backward)
 };
 
 template <int DH>
@@ -557,6 +558,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split_kernel(AttnBwdArgs a, cons
     // ---- dK, dV of this wave's keys: (d x keys) accumulators -> [key][d] through LDS (the Ds region, free now), row-contiguous update
     __syncthreads();
     float* tr = reinterpret_cast<float*>(Ds) + wave * (32 * 65);         // 8 waves x 8.3 KB <= 32 KB + Kt head room
+    float kvmax = 0.f;
     for (int which = 0; which < 2; ++which) {
         const float scale = (which == 0 ? cn : 1.f) * inv_os;
 #pragma unroll
@@ -572,11 +574,18 @@ __global__ __launch_bounds__(512) void attn_bwd_split_kernel(AttnBwdArgs a, cons
             const int jj = idx >> 6, d = idx & 63;
             if (j0 + jj < a.Lk) {
                 float* o = g + (int64_t)(j0 + jj) * grow + d;
-                *o = (a.accumulate_kv ? *o : 0.f) + tr[jj * 65 + d];
+                const float val = (a.accumulate_kv ? *o : 0.f) + tr[jj * 65 + d];
+                *o = val;
+                kvmax = fmaxf(kvmax, fabsf(val));
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
+    }
+    if (a.kv_absmax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) kvmax = fmaxf(kvmax, __shfl_xor(kvmax, o));
+        if (lane == 0) atomicMax(a.kv_absmax, __float_as_uint(kvmax));
     }
 }
 
@@ -672,7 +681,7 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
     a.gv = gv; a.gv_batch = gv_batch; a.gv_head = gv_head; a.gv_row = gv_row;
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.accumulate_kv = accumulate_kv; a.gq_part = nullptr;
     a.drop_p = drop_p; a.drop_seed = drop_seed;
-    a.n_it = 1; a.do_it = a.D_it = a.gqp_it = 0;
+    a.n_it = 1; a.do_it = a.D_it = a.gqp_it = 0; a.kv_absmax = nullptr;
     memset(a.q_off, 0, sizeof(a.q_off));
     memset(a.lse_off, 0, sizeof(a.lse_off));
     for (int t = 0; t < kMaxBwdIters; ++t) a.seeds[t] = drop_seed;
@@ -764,7 +773,7 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
                                    int64_t gq_batch, int64_t gq_head, int64_t gq_row, float* gk, int64_t gk_batch, int64_t gk_head,
                                    int64_t gk_row, float* gv, int64_t gv_batch, int64_t gv_head, int64_t gv_row, int B, int H, int Lq,
                                    int Lk, int dh, int n_it, hipStream_t s, float* gq_part, float drop_p, const uint32_t* seeds,
-                                   unsigned int* absmax) {
+                                   unsigned int* absmax, unsigned int* kv_absmax) {
     if (dh != 64 || Lk < 2048 || n_it < 1 || n_it > kMaxBwdIters || !gq_part || !absmax) return hipErrorInvalidValue;
     AttnBwdArgs a;
     a.q = q; a.q_batch = q_batch; a.q_head = q_head; a.q_row = q_row;
@@ -777,7 +786,11 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
     a.gv = gv; a.gv_batch = gv_batch; a.gv_head = gv_head; a.gv_row = gv_row;
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.accumulate_kv = 0; a.gq_part = gq_part;
     a.drop_p = drop_p; a.drop_seed = seeds ? seeds[0] : 0;
-    a.n_it = n_it; a.do_it = do_it; a.D_it = D_it;
+    a.n_it = n_it; a.do_it = do_it; a.D_it = D_it; a.kv_absmax = kv_absmax;
+    if (kv_absmax) {
+        hipError_t e0 = hipMemsetAsync(kv_absmax, 0, sizeof(unsigned int), s);
+        if (e0 != hipSuccess) return e0;
+    }
     a.gqp_it = (int64_t)attn_bwd_dq_partial_floats(B, H, Lq, Lk, dh);
     for (int t = 0; t < kMaxBwdIters; ++t) {
         a.q_off[t] = t < n_it ? q_off[t] : 0;

@@ -225,7 +225,11 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
                                    int64_t gq_batch, int64_t gq_head, int64_t gq_row, float* gk, int64_t gk_batch, int64_t gk_head,
                                    int64_t gk_row, float* gv, int64_t gv_batch, int64_t gv_head, int64_t gv_row, int B, int H, int Lq,
                                    int Lk, int dh, int n_it, hipStream_t s, float* gq_part, float drop_p, const uint32_t* seeds,
-                                   unsigned int* absmax);
+                                   unsigned int* absmax, unsigned int* kv_absmax = nullptr);   // kv_absmax: out, max |dK|, |dV| (float bits)
+// kvproj_bwd.hip: dW_kv / db_kv of the hoisted projection on the fp16 matrix pipe (hi/lo split), C = 256
+bool kvproj_bwd_split_supported(int C);
+hipError_t launch_kvproj_bwd_split(const float* g, const float* tokens, int64_t M, int C, float* dW, float* db,
+                                   const unsigned int* absmax_bits, float* scale_scratch, hipStream_t s);
 // dst = dropout(src): keep mask of stream `seed` over the (M, N) index space, scaled by 1 / (1 - p)
 hipError_t launch_dropout_apply(const float* src, float* dst, int M, int N, float p, uint32_t seed, hipStream_t s);
 size_t attn_bwd_dq_partial_floats(int B, int H, int Lq, int Lk, int dh);

@@ -45,6 +45,7 @@ def oracle_grads(cfg, W, sc, cots):
     (1, 3, 6, 7, 40, 4, 256, 256, 3, True),
     (2, 2, 5, 6, 16, 2, 128, 64, 2, False),
     (2, 2, 32, 40, 40, 2, 128, 96, 2, True),       # N = 2560 keys: the MFMA cross-attention backward with dQ partial buffers
+    (2, 2, 32, 41, 24, 4, 256, 128, 3, True),      # d = 256, N = 2624 (ragged 32-row steps): batched backward + split-precision dW_kv
 ])
 def test_backward_matches_oracle_autograd(B, V, h, w, Q, heads, dim, ffn, layers, shared):
     cfg = synth.decoder_cfg(dim=dim, queries=Q, heads=heads, ffn=ffn, layers=layers, share_weights=shared, dropout=0.0)
