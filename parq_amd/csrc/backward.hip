@@ -580,11 +580,14 @@ hipError_t launch_gemm_tn(const float* A, int64_t lda, const float* B, int64_t l
     TnArgs a;
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.accumulate = accumulate;
     // many rows, few output tiles (the K/V projection backward: M = all tokens): split the rows, accumulate with atomics
+    // each wave walks its rows with dependent global loads (latency-bound): whenever the result is accumulated anyway, split the
+    // rows until ~4 workgroups per CU are in flight and every workgroup keeps at least 64 rows
     int splits = 1;
     const int tiles = ceil_div(N, 32) * ceil_div(K, 32);
-    if (accumulate && M >= 8192) {
+    if (accumulate && M >= 256) {
         splits = ceil_div(4 * device_num_cus(), tiles);
-        if (splits > M / 1024) splits = M / 1024;
+        const int cap = M >= 8192 ? M / 1024 : M / 64;
+        if (splits > cap) splits = cap;
         if (splits < 1) splits = 1;
     }
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), 0, s, a);
