@@ -68,7 +68,7 @@ struct Workspace {
     int64_t sa, ln3, lse_s, lse_c, refk;
     int64_t iter_begin, iter_end, stash;
     // backward scratch (training workspace only)
-    int64_t g_a, g_b, g_c, g_pos, g_tmp, g_ffh, g_h1, g_h2, g_z, g_act, g_h3, g_qkv, g_emb, g_ref, g_D, g_bs, wT, g_kv, g_dqp, g_drop, kv_train, g_do, g_res, g_dq, g_Dall, g_kvmax;
+    int64_t g_a, g_b, g_c, g_pos, g_tmp, g_ffh, g_h1, g_h2, g_z, g_act, g_h3, g_qkv, g_emb, g_ref, g_D, g_bs, wT, g_kv, g_dqp, g_drop, kv_train, g_do, g_res, g_dq, g_Dall, g_kvmax, g_pack;
     bool bwd_batched;                 // cross-attention backward of all iterations in one launch (shared layer weights, split cache)
     int64_t train_total;
     int64_t shift(int k) const { return k == 0 ? 0 : stash + (int64_t)(k - 1) * (iter_end - iter_begin) - iter_begin; }
@@ -196,6 +196,7 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     ws->g_res = take(ws->bwd_batched ? nit * M * C : 0);
     ws->g_dq = take(ws->bwd_batched ? nit * M * C : 0);
     ws->g_Dall = take(ws->bwd_batched ? nit * (int64_t)B * c->H * flash_lq_pad((int)Q) : 0);
+    ws->g_pack = take(ws->bwd_batched ? (int64_t)attn_bwd_pack_floats(B, c->H, (int)Q, (int)nit) : 0);
     ws->g_kvmax = take(4);                            // [0] bits of max |dK|, |dV| (batched backward), [1] the derived scale
     ws->train_total = off;
     return PARQ_OK;
@@ -1081,7 +1082,7 @@ int parq_backward(parq_handle h, const parq_scene* scene, void* workspace, size_
                                        wsp + ws.g_Dall, (int64_t)B * H * flash_lq_pad(Q), wsp + ws.g_dq, MC, (int64_t)Q * C, dh, C, gkv,
                                        2 * N * C, dh, 2 * C, gkv + C, 2 * N * C, dh, 2 * C, B, H, Q, (int)N, dh, I, s, wsp + ws.g_dqp,
                                        h->drop_p, seeds, reinterpret_cast<unsigned int*>(wsp + ws.g_bs),
-                                       reinterpret_cast<unsigned int*>(wsp + ws.g_kvmax)));
+                                       reinterpret_cast<unsigned int*>(wsp + ws.g_kvmax), wsp + ws.g_pack));
     }
     for (int k = I - 1; k >= 0; --k) {
         rc = do_backward_iter(h, scene, wsp, ws, k, iter_io(k), grad_arena, d_tokens, s, 2);

@@ -589,6 +589,290 @@ __global__ __launch_bounds__(512) void attn_bwd_split_kernel(AttnBwdArgs a, cons
     }
 }
 
+// ================================================================================================ split kernel, second version
+// Same arithmetic as attn_bwd_split_kernel, reorganised around two gfx950 features:
+//   * ds_read_b64_tr_b16 (LDS transpose read): within a 16-lane group, lane t supplies the address of the 8-byte piece
+//     (row t >> 2, 4 columns from 4 (t & 3)) of a [4 rows][16 columns] 16-bit block and lane c receives column c of it, i.e. the four
+//     rows of one column (probed on MI355X: tools/bench_src/tr16_probe.hip).  Operands whose contraction index runs along the ROWS of
+//     their LDS image (dO^T, Q^T for dV / dK; dS and K for dQ) are read straight from the natural image: no transposed copies of the
+//     Q / dO tile, dS written as 8-byte pieces instead of 32 two-byte stores per lane, K written as 16-byte chunks.
+//   * the hi/lo-split Q / dO tile (and lse, D, the dropout row hashes) is the same for every key block, so a pack kernel builds it
+//     ONCE per (iteration, scene, head, 32 queries) as the exact LDS image and the workgroups fetch it by LDS-DMA one tile ahead:
+//     no loader VALU, no loader LDS writes, no staging registers.
+// Two workgroup barriers per query tile instead of three.
+constexpr int kImgHalfs = 8448;                  // [Q_hi | Q_lo | dO_hi | dO_lo] 4 x 2048 + 256 halfs of statistics (lse, D, row hashes)
+// 16-byte chunk swizzle of a [rows][64 halfs] image (128-byte rows, two rows per 256-byte bank row).  With v = (r >> 1) & 7:
+//   * bit 2 of the swizzle = bit 1 of r: the transpose reads of dV / dK touch rows r .. r + 3 x 64 bytes, rows r and r + 2 must use
+//     different 64-byte halves;
+//   * bits 2..1 = (r bit 1, r bit 3): the dQ reads of the K image touch rows {j, j+1, j+2, j+3, j+8, .. j+11} x 32 bytes, the four
+//     same-parity rows must use four different 32-byte quarters;
+//   * a bijection of v: the 8 same-parity rows of a ds_read_b128 lane group hit 8 different chunks.
+__device__ __forceinline__ int img_swz(int r) {
+    const int v = (r >> 1) & 7;
+    return ((v & 1) << 2) | ((v >> 2) << 1) | ((v >> 1) & 1);
+}
+
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ half4v lds_tr16(const _Float16* p) {
+    typedef short short4v __attribute__((ext_vector_type(4)));
+    const short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(p));
+    return __builtin_bit_cast(half4v, v);
+}
+__device__ __forceinline__ half8 cat4(half4v a, half4v b) { return half8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+
+// one workgroup per (32-query tile, scene-head, iteration): the LDS image of that tile in global memory
+__global__ __launch_bounds__(256) void attn_bwd_pack_kernel(AttnBwdArgs a, const float* __restrict__ oscale_ptr, _Float16* __restrict__ pack) {
+    const float oscale = *oscale_ptr;
+    const int tile = blockIdx.x, bh = blockIdx.y, it = blockIdx.z;
+    const int b = bh / a.H, h = bh - b * a.H;
+    const int ntiles = gridDim.x, Lq_pad = (a.Lq + 31) & ~31;
+    _Float16* img = pack + (((int64_t)it * gridDim.y + bh) * ntiles + tile) * kImgHalfs;
+    const int i = threadIdx.x >> 3, c = threadIdx.x & 7;
+    const int qi = tile * 32 + i;
+    float qx[8], ox[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { qx[e] = 0.f; ox[e] = 0.f; }
+    if (qi < a.Lq) {
+        const float* qp = a.q + a.q_off[it] + (int64_t)b * a.q_batch + (int64_t)h * a.q_head + (int64_t)qi * a.q_row + c * 8;
+        const float* op = a.dO + (int64_t)it * a.do_it + (int64_t)b * a.do_batch + (int64_t)h * a.do_head + (int64_t)qi * a.do_row + c * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qx[e] = qp[e]; ox[e] = op[e] * oscale; }
+    }
+    half8 qh, ql, oh, ol;
+    split8(qx, qh, ql);
+    split8(ox, oh, ol);
+    const int off = i * 64 + ((c ^ img_swz(i)) << 3);
+    *reinterpret_cast<half8*>(img + off) = qh;
+    *reinterpret_cast<half8*>(img + 2048 + off) = ql;
+    *reinterpret_cast<half8*>(img + 4096 + off) = oh;
+    *reinterpret_cast<half8*>(img + 6144 + off) = ol;
+    if (threadIdx.x < 32) {
+        float* stf = reinterpret_cast<float*>(img + 8192);
+        const int q2 = tile * 32 + threadIdx.x;
+        const bool ok = q2 < a.Lq;
+        // rows past Lq: lse = +inf makes every probability exp2(s - lse) exactly 0
+        stf[threadIdx.x] = ok ? a.lse[a.lse_off[it] + (int64_t)bh * Lq_pad + q2] : INFINITY;
+        stf[32 + threadIdx.x] = ok ? a.D[(int64_t)it * a.D_it + (int64_t)bh * Lq_pad + q2] * oscale : 0.f;
+        reinterpret_cast<uint32_t*>(stf + 64)[threadIdx.x] = drop_rowhash(a.seeds[it], (uint32_t)(bh * a.Lq + q2));
+    }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, const float* __restrict__ oscale_ptr,
+                                                              const _Float16* __restrict__ pack) {
+    const float oscale = *oscale_ptr;
+    extern __shared__ __attribute__((aligned(16))) _Float16 sm[];
+    _Float16* Ds = sm;                      // dS^T [hi | lo][256 keys][32 queries], 8-byte pieces swizzled by (key >> 1) & 7 (64-byte rows:
+                                            // distinct for the same-parity rows of a write group; rows j and j + 8 of a read use different halves)
+    _Float16* Ki = Ds + 2 * 8192;           // K [hi | lo][256 keys][64 d], 16-byte chunks swizzled by img_swz(key)
+    _Float16* Stg = Ki + 2 * 16384;         // [2][kImgHalfs]: the Q / dO tile images, filled by LDS-DMA
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int t16 = lane & 15, g16 = lane >> 4;
+    const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+    const int jw = wave * 32 + li;                   // key inside the workgroup
+    const int j = blockIdx.x * kSpKW + jw;
+    const bool jok = j < a.Lk;
+    const int Lq_pad = (a.Lq + 31) & ~31;
+    const int ntiles = Lq_pad >> 5;
+    const float c2 = 1.4426950408889634f / 8.f, cn = 1.f / 8.f;
+    const float inv_os = 1.f / oscale;
+
+    // ---- K, V of this lane's key as B fragments: step t holds d = 16 t + 8 kh + e; K also goes into LDS (natural layout)
+    half8 kfh[4], kfl[4], vfh[4], vfl[4];
+    {
+        const float* kp = a.k + (int64_t)b * a.k_batch + (int64_t)h * a.k_head + (int64_t)(jok ? j : 0) * a.k_row;
+        const float* vp = a.v + (int64_t)b * a.v_batch + (int64_t)h * a.v_head + (int64_t)(jok ? j : 0) * a.v_row;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int d0 = 16 * t + 8 * kh;
+            float kx[8], vx[8];
+#pragma unroll
+            for (int e = 0; e < 8; e += 4) {
+                const float4 k4 = *reinterpret_cast<const float4*>(kp + d0 + e);
+                const float4 v4 = *reinterpret_cast<const float4*>(vp + d0 + e);
+                kx[e] = jok ? k4.x : 0.f; kx[e + 1] = jok ? k4.y : 0.f; kx[e + 2] = jok ? k4.z : 0.f; kx[e + 3] = jok ? k4.w : 0.f;
+                vx[e] = jok ? v4.x : 0.f; vx[e + 1] = jok ? v4.y : 0.f; vx[e + 2] = jok ? v4.z : 0.f; vx[e + 3] = jok ? v4.w : 0.f;
+            }
+            split8(kx, kfh[t], kfl[t]);
+            split8(vx, vfh[t], vfl[t]);
+            const int off = jw * 64 + (((2 * t + kh) ^ img_swz(jw)) << 3);
+            *reinterpret_cast<half8*>(Ki + off) = kfh[t];
+            *reinterpret_cast<half8*>(Ki + 16384 + off) = kfl[t];
+        }
+    }
+    const uint32_t drop_col = DROP ? drop_colhash((uint32_t)j) : 0u;
+    const uint32_t drop_thr = DROP ? drop_threshold(a.drop_p) : 0u;
+    const float drop_inv = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
+    f32x16 gk[2], gv[2];                    // dK^T, dV^T: rows d (2 x 32), columns this wave's keys
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { gk[dt][r] = 0.f; gv[dt][r] = 0.f; }
+
+    // tile stream: n = it * ntiles + tile, image n at pack + ((it * BH + bh) * ntiles + tile) * kImgHalfs
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    const int ntot = a.n_it * ntiles;
+    auto tile_dma = [&](int n, int slot) {
+        const int it = n / ntiles, tile = n - it * ntiles;
+        const char* src = reinterpret_cast<const char*>(pack + (((int64_t)it * gridDim.y + bh) * ntiles + tile) * kImgHalfs);
+        lds_byte* dst = (lds_byte*)(Stg + slot * kImgHalfs);
+        __builtin_amdgcn_global_load_lds(src + (size_t)tid * 16, dst + wave * 1024, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src + 8192 + (size_t)tid * 16, dst + 8192 + wave * 1024, 16, 0, 0);
+        if (tid < 32) __builtin_amdgcn_global_load_lds(src + 16384 + (size_t)tid * 16, dst + 16384, 16, 0, 0);
+    };
+    // per-lane pieces of the transpose reads (constant over the tiles)
+    //   dV / dK A operand (rows d = 32 dt + li, k = queries): piece row i_base + (t16 >> 2), i_base = 16 m + 4 kh (+ 8), d piece 32 dt + 16 (g16 & 1) + 4 (t16 & 3)
+    //   dQ A operand (rows = queries qb + t16, k = keys): piece row j0 + (t16 >> 2), query piece (qb >> 2) + (t16 & 3)
+    //   dQ B operand (cols = d db + t16, k = keys): piece row j0 + (t16 >> 2), d piece db + 4 (t16 & 3)
+    const int qb = (wave >> 2) * 16, db = (wave & 3) * 16;
+    tile_dma(0, 0);
+    for (int n = 0; n < ntot; ++n) {
+        const int it = n / ntiles, i0 = (n - it * ntiles) * 32;
+        const _Float16* Im = Stg + (n & 1) * kImgHalfs;
+        // this thread's DMA pieces of tile n have landed (the 4 dQ stores of the previous tile were issued after them and may stay in
+        // flight: VMEM operations retire in order); the barrier makes every wave's pieces visible and closes the previous tile's reads
+        if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __syncthreads();
+        if (n + 1 < ntot) tile_dma(n + 1, (n + 1) & 1);     // the other slot was last read before the barrier above
+        const float* st = reinterpret_cast<const float*>(Im + 8192);
+
+        // ---- S = Q K^T, dP = dO V^T  (rows = queries, columns = this wave's keys)
+        f32x16 sacc, pacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int pos = li * 64 + (((2 * t + kh) ^ img_swz(li)) << 3);
+            const half8 qh8 = *reinterpret_cast<const half8*>(Im + pos);
+            const half8 ql8 = *reinterpret_cast<const half8*>(Im + 2048 + pos);
+            const half8 oh8 = *reinterpret_cast<const half8*>(Im + 4096 + pos);
+            const half8 ol8 = *reinterpret_cast<const half8*>(Im + 6144 + pos);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh8, kfh[t], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh8, kfl[t], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql8, kfh[t], sacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh8, vfh[t], pacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh8, vfl[t], pacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ol8, vfh[t], pacc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- P (with dropout), dS; accumulator register r is query mfma32_row(r, lane), column = this lane's key
+        half8 ph[2], pl[2], sh[2], sl[2];
+        unsigned keep_bits = 0xffffu;
+        if constexpr (DROP) {
+            keep_bits = 0u;
+            const uint32_t* rhs = reinterpret_cast<const uint32_t*>(st + 64);
+#pragma unroll 1
+            for (int r = 0; r < 16; ++r)
+                keep_bits |= (drop_keep_h(rhs[(r & 3) + 8 * (r >> 2) + 4 * kh], drop_col, drop_thr) ? 1u : 0u) << r;
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            float pv[8], dv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = 8 * m + e;
+                const int qi = mfma32_row(r, lane);
+                const float p = jok ? __builtin_amdgcn_exp2f(sacc[r] * c2 - st[qi]) : 0.f;     // rows past Lq: lse = +inf -> 0
+                float keep = 1.f;
+                if constexpr (DROP) keep = ((keep_bits >> r) & 1u) ? drop_inv : 0.f;
+                pv[e] = p * keep;
+                dv[e] = p * (pacc[r] * keep - st[32 + qi]);
+            }
+            split8(pv, ph[m], pl[m]);
+            split8(dv, sh[m], sl[m]);
+            // dS^T row of this key: queries 16 m + 8 hh + 4 kh + (0..3) are registers 4 hh .. 4 hh + 3 -> query piece 4 m + 2 hh + kh
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int off = jw * 32 + (((4 * m + 2 * hh + kh) ^ ((jw >> 1) & 7)) << 2);
+                *reinterpret_cast<half4v*>(Ds + off) = half4v{sh[m][4 * hh], sh[m][4 * hh + 1], sh[m][4 * hh + 2], sh[m][4 * hh + 3]};
+                *reinterpret_cast<half4v*>(Ds + 8192 + off) = half4v{sl[m][4 * hh], sl[m][4 * hh + 1], sl[m][4 * hh + 2], sl[m][4 * hh + 3]};
+            }
+        }
+        // ---- dV^T += dO^T P, dK^T += Q^T dS: contraction over the queries; A operands by transpose reads of the natural images
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int dp = 32 * dt + 16 * (g16 & 1) + 4 * (t16 & 3);
+                const int r0 = 16 * m + 4 * kh + (t16 >> 2), r1 = r0 + 8;
+                const int p0 = r0 * 64 + (((dp >> 3) ^ img_swz(r0)) << 3) + (dp & 4);
+                const int p1 = r1 * 64 + (((dp >> 3) ^ img_swz(r1)) << 3) + (dp & 4);
+                const half8 qth = cat4(lds_tr16(Im + p0), lds_tr16(Im + p1));
+                const half8 qtl = cat4(lds_tr16(Im + 2048 + p0), lds_tr16(Im + 2048 + p1));
+                const half8 oth = cat4(lds_tr16(Im + 4096 + p0), lds_tr16(Im + 4096 + p1));
+                const half8 otl = cat4(lds_tr16(Im + 6144 + p0), lds_tr16(Im + 6144 + p1));
+                gv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(oth, ph[m], gv[dt], 0, 0, 0);
+                gv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(oth, pl[m], gv[dt], 0, 0, 0);
+                gv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(otl, ph[m], gv[dt], 0, 0, 0);
+                gk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qth, sh[m], gk[dt], 0, 0, 0);
+                gk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qth, sl[m], gk[dt], 0, 0, 0);
+                gk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtl, sh[m], gk[dt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        // ---- dQ tile = dS K over the 256 keys of the workgroup: wave w owns the 16 x 16 block (queries 16 (w>>2).., d 16 (w&3)..)
+        __syncthreads();
+        {
+            typedef float f32x4v __attribute__((ext_vector_type(4)));
+            f32x4v g4 = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int ja = 32 * t + 8 * g16 + (t16 >> 2), jb = ja + 4;       // keys of this lane's two pieces
+                const int qp = (qb >> 2) + (t16 & 3);
+                const int pa0 = ja * 32 + ((qp ^ ((ja >> 1) & 7)) << 2), pa1 = jb * 32 + ((qp ^ ((jb >> 1) & 7)) << 2);
+                const int dp = db + 4 * (t16 & 3);
+                const int pb0 = ja * 64 + (((dp >> 3) ^ img_swz(ja)) << 3) + (dp & 4);
+                const int pb1 = jb * 64 + (((dp >> 3) ^ img_swz(jb)) << 3) + (dp & 4);
+                const half8 ah = cat4(lds_tr16(Ds + pa0), lds_tr16(Ds + pa1));
+                const half8 al = cat4(lds_tr16(Ds + 8192 + pa0), lds_tr16(Ds + 8192 + pa1));
+                const half8 bh8 = cat4(lds_tr16(Ki + pb0), lds_tr16(Ki + pb1));
+                const half8 bl8 = cat4(lds_tr16(Ki + 16384 + pb0), lds_tr16(Ki + 16384 + pb1));
+                g4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh8, g4, 0, 0, 0);
+                g4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl8, g4, 0, 0, 0);
+                g4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh8, g4, 0, 0, 0);
+                if (t & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            // accumulator: rows qb + 4 g16 + r, column db + t16
+            float* part = a.gq_part + (int64_t)it * a.gqp_it + (((int64_t)bh * gridDim.x + blockIdx.x) * Lq_pad + i0) * 64;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(qb + 4 * g16 + r) * 64 + db + t16] = g4[r] * cn * inv_os;
+        }
+    }
+    // ---- dK, dV of this wave's keys: (d x keys) accumulators -> [key][d] through LDS (Ds + head of Ki, free now), row-contiguous stores
+    __syncthreads();
+    float* tr = reinterpret_cast<float*>(Ds) + wave * (32 * 65);
+    float kvmax = 0.f;
+    for (int which = 0; which < 2; ++which) {
+        const float scale = (which == 0 ? cn : 1.f) * inv_os;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tr[li * 65 + dt * 32 + mfma32_row(r, lane)] = (which == 0 ? gk[dt][r] : gv[dt][r]) * scale;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        float* g = which == 0 ? a.gk + (int64_t)b * a.gk_batch + (int64_t)h * a.gk_head : a.gv + (int64_t)b * a.gv_batch + (int64_t)h * a.gv_head;
+        const int64_t grow = which == 0 ? a.gk_row : a.gv_row;
+        const int j0 = blockIdx.x * kSpKW + wave * 32;
+        for (int idx = lane; idx < 32 * 64; idx += 64) {
+            const int jj = idx >> 6, d = idx & 63;
+            if (j0 + jj < a.Lk) {
+                float* o = g + (int64_t)(j0 + jj) * grow + d;
+                const float val = (a.accumulate_kv ? *o : 0.f) + tr[jj * 65 + d];
+                *o = val;
+                kvmax = fmaxf(kvmax, fabsf(val));
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (a.kv_absmax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) kvmax = fmaxf(kvmax, __shfl_xor(kvmax, o));
+        if (lane == 0) atomicMax(a.kv_absmax, __float_as_uint(kvmax));
+    }
+}
+
 // scale[0] = 2^(10 - exponent(max |dO|)) from the bit pattern left by absmax_kernel (1 when the gradient is all zero)
 __global__ void oscale_kernel(const unsigned int* __restrict__ bits, float* __restrict__ scale) {
     const float mx = __uint_as_float(bits[0]);
@@ -773,7 +1057,7 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
                                    int64_t gq_batch, int64_t gq_head, int64_t gq_row, float* gk, int64_t gk_batch, int64_t gk_head,
                                    int64_t gk_row, float* gv, int64_t gv_batch, int64_t gv_head, int64_t gv_row, int B, int H, int Lq,
                                    int Lk, int dh, int n_it, hipStream_t s, float* gq_part, float drop_p, const uint32_t* seeds,
-                                   unsigned int* absmax, unsigned int* kv_absmax) {
+                                   unsigned int* absmax, unsigned int* kv_absmax, void* pack) {
     if (dh != 64 || Lk < 2048 || n_it < 1 || n_it > kMaxBwdIters || !gq_part || !absmax) return hipErrorInvalidValue;
     AttnBwdArgs a;
     a.q = q; a.q_batch = q_batch; a.q_head = q_head; a.q_row = q_row;
@@ -804,15 +1088,38 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
         hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, s, dO + (int64_t)t * do_it, (int64_t)B * do_batch, absmax);
     float* oscale = reinterpret_cast<float*>(absmax + 1);
     hipLaunchKernelGGL(oscale_kernel, dim3(1), dim3(1), 0, s, absmax, oscale);
-    e = split_bwd_lds_attr();
-    if (e != hipSuccess) return e;
     dim3 g2(ceil_div(Lk, kSpKW), B * H);
-    if (drop_p > 0.f) hipLaunchKernelGGL(attn_bwd_split_kernel<true>, g2, dim3(512), kSplitBwdLds, s, a, oscale);
-    else hipLaunchKernelGGL(attn_bwd_split_kernel<false>, g2, dim3(512), kSplitBwdLds, s, a, oscale);
     const int Lq_pad = (Lq + 31) & ~31;
+    static const bool v1 = [] { const char* e = getenv("PARQ_ATTN_BWD_V"); return e && e[0] == '1'; }();
+    if (pack && !v1) {
+        // second version: tile images packed once, fetched by LDS-DMA; transpose reads
+        constexpr size_t lds2 = (size_t)(2 * 8192 + 2 * 16384 + 2 * kImgHalfs) * sizeof(_Float16);
+        static bool attr2 = false;
+        if (!attr2) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_split2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_split2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            if (e != hipSuccess) return e;
+            attr2 = true;
+        }
+        _Float16* pk = reinterpret_cast<_Float16*>(pack);
+        hipLaunchKernelGGL(attn_bwd_pack_kernel, dim3(Lq_pad / 32, B * H, n_it), dim3(256), 0, s, a, oscale, pk);
+        if (drop_p > 0.f) hipLaunchKernelGGL(attn_bwd_split2_kernel<true>, g2, dim3(512), lds2, s, a, oscale, pk);
+        else hipLaunchKernelGGL(attn_bwd_split2_kernel<false>, g2, dim3(512), lds2, s, a, oscale, pk);
+    } else {
+        e = split_bwd_lds_attr();
+        if (e != hipSuccess) return e;
+        if (drop_p > 0.f) hipLaunchKernelGGL(attn_bwd_split_kernel<true>, g2, dim3(512), kSplitBwdLds, s, a, oscale);
+        else hipLaunchKernelGGL(attn_bwd_split_kernel<false>, g2, dim3(512), kSplitBwdLds, s, a, oscale);
+    }
     hipLaunchKernelGGL(attn_bwd_dq_reduce_kernel, dim3(ceil_div(Lq * 64, 256), B * H, n_it), dim3(256), 0, s, gq_part, (int)g2.x, Lq,
                        Lq_pad, H, gq, gq_batch, gq_head, gq_row, a.gqp_it, gq_it);
     return hipGetLastError();
+}
+
+// scratch floats for the packed Q / dO tile images of launch_attn_bwd_batched
+size_t attn_bwd_pack_floats(int B, int H, int Lq, int n_it) {
+    return (size_t)n_it * B * H * (((Lq + 31) & ~31) / 32) * kImgHalfs / 2;
 }
 
 // scratch floats for the dQ partials of launch_attn_bwd (0 when the atomics path is taken)

@@ -225,7 +225,9 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
                                    int64_t gq_batch, int64_t gq_head, int64_t gq_row, float* gk, int64_t gk_batch, int64_t gk_head,
                                    int64_t gk_row, float* gv, int64_t gv_batch, int64_t gv_head, int64_t gv_row, int B, int H, int Lq,
                                    int Lk, int dh, int n_it, hipStream_t s, float* gq_part, float drop_p, const uint32_t* seeds,
-                                   unsigned int* absmax, unsigned int* kv_absmax = nullptr);   // kv_absmax: out, max |dK|, |dV| (float bits)
+                                   unsigned int* absmax, unsigned int* kv_absmax = nullptr,    // kv_absmax: out, max |dK|, |dV| (float bits)
+                                   void* pack = nullptr);   // pack: attn_bwd_pack_floats(...) floats of scratch -> second-version kernel
+size_t attn_bwd_pack_floats(int B, int H, int Lq, int n_it);
 // kvproj_bwd.hip: dW_kv / db_kv of the hoisted projection on the fp16 matrix pipe (hi/lo split), C = 256
 bool kvproj_bwd_split_supported(int C);
 hipError_t launch_kvproj_bwd_split(const float* g, const float* tokens, int64_t M, int C, float* dW, float* db,
