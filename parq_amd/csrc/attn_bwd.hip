@@ -657,6 +657,8 @@ __global__ __launch_bounds__(256) void attn_bwd_pack_kernel(AttnBwdArgs a, const
     }
 }
 
+// (no scheduling barriers inside the MFMA groups here: letting hipcc hoist the fragment reads over the previous step's MFMAs
+// measured 18.2 -> 16.6 ms; the first version needs them to stay inside its register budget)
 template <bool DROP>
 __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, const float* __restrict__ oscale_ptr,
                                                               const _Float16* __restrict__ pack) {
@@ -755,7 +757,6 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
             pacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh8, vfh[t], pacc, 0, 0, 0);
             pacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh8, vfl[t], pacc, 0, 0, 0);
             pacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ol8, vfh[t], pacc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- P (with dropout), dS; accumulator register r is query mfma32_row(r, lane), column = this lane's key
         half8 ph[2], pl[2], sh[2], sl[2];
@@ -809,8 +810,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
                 gk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qth, sh[m], gk[dt], 0, 0, 0);
                 gk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qth, sl[m], gk[dt], 0, 0, 0);
                 gk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtl, sh[m], gk[dt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                }
         // ---- dQ tile = dS K over the 256 keys of the workgroup: wave w owns the 16 x 16 block (queries 16 (w>>2).., d 16 (w&3)..)
         __syncthreads();
         {
@@ -831,7 +831,6 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
                 g4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh8, g4, 0, 0, 0);
                 g4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl8, g4, 0, 0, 0);
                 g4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh8, g4, 0, 0, 0);
-                if (t & 1) __builtin_amdgcn_sched_barrier(0);
             }
             // accumulator: rows qb + 4 g16 + r, column db + t16
             float* part = a.gq_part + (int64_t)it * a.gqp_it + (((int64_t)bh * gridDim.x + blockIdx.x) * Lq_pad + i0) * 64;
