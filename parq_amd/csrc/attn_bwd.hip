@@ -760,24 +760,23 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
         }
         // ---- P (with dropout), dS; accumulator register r is query mfma32_row(r, lane), column = this lane's key
         half8 ph[2], pl[2], sh[2], sl[2];
-        unsigned keep_bits = 0xffffu;
-        if constexpr (DROP) {
-            keep_bits = 0u;
-            const uint32_t* rhs = reinterpret_cast<const uint32_t*>(st + 64);
-#pragma unroll 1
-            for (int r = 0; r < 16; ++r)
-                keep_bits |= (drop_keep_h(rhs[(r & 3) + 8 * (r >> 2) + 4 * kh], drop_col, drop_thr) ? 1u : 0u) << r;
-        }
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             float pv[8], dv[8];
+            // row hashes of this half's 8 queries 16 m + 4 kh + {0..3, 8..11}: two 16-byte reads, then xor + compare per element
+            uint32_t rh[8];
+            if constexpr (DROP) {
+                const uint32_t* rhs = reinterpret_cast<const uint32_t*>(st + 64) + 16 * m + 4 * kh;
+                const uint4 h0 = *reinterpret_cast<const uint4*>(rhs), h1 = *reinterpret_cast<const uint4*>(rhs + 8);
+                rh[0] = h0.x; rh[1] = h0.y; rh[2] = h0.z; rh[3] = h0.w; rh[4] = h1.x; rh[5] = h1.y; rh[6] = h1.z; rh[7] = h1.w;
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int r = 8 * m + e;
                 const int qi = mfma32_row(r, lane);
                 const float p = jok ? __builtin_amdgcn_exp2f(sacc[r] * c2 - st[qi]) : 0.f;     // rows past Lq: lse = +inf -> 0
                 float keep = 1.f;
-                if constexpr (DROP) keep = ((keep_bits >> r) & 1u) ? drop_inv : 0.f;
+                if constexpr (DROP) keep = drop_keep_h(rh[e], drop_col, drop_thr) ? drop_inv : 0.f;
                 pv[e] = p * keep;
                 dv[e] = p * (pacc[r] * keep - st[32 + qi]);
             }
