@@ -679,6 +679,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
     const int ntiles = Lq_pad >> 5;
     const float c2 = 1.4426950408889634f / 8.f, cn = 1.f / 8.f;
     const float inv_os = 1.f / oscale;
+    const bool ragged = (int)(blockIdx.x + 1) * kSpKW > a.Lk;      // workgroup-uniform
 
     // ---- K, V of this lane's key as B fragments: step t holds d = 16 t + 8 kh + e; K also goes into LDS (natural layout)
     half8 kfh[4], kfl[4], vfh[4], vfl[4];
@@ -742,8 +743,9 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
 
         // ---- S = Q K^T, dP = dO V^T  (rows = queries, columns = this wave's keys)
         f32x16 sacc, pacc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // inline-constant C of the first MFMAs
+        sacc = zero16;
+        pacc = zero16;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int pos = li * 64 + (((2 * t + kh) ^ img_swz(li)) << 3);
@@ -774,7 +776,8 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
             for (int e = 0; e < 8; ++e) {
                 const int r = 8 * m + e;
                 const int qi = mfma32_row(r, lane);
-                const float p = jok ? __builtin_amdgcn_exp2f(sacc[r] * c2 - st[qi]) : 0.f;     // rows past Lq: lse = +inf -> 0
+                float p = __builtin_amdgcn_exp2f(sacc[r] * c2 - st[qi]);                     // rows past Lq: lse = +inf -> 0
+                if (ragged) p = jok ? p : 0.f;                                               // keys past Lk: last key block only
                 float keep = 1.f;
                 if constexpr (DROP) keep = drop_keep_h(rh[e], drop_col, drop_thr) ? drop_inv : 0.f;
                 pv[e] = p * keep;
