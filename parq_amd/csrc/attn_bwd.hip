@@ -11,6 +11,7 @@
 #include "common.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 #include <cstring>
 #include <cmath>
 
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(256) void attn_bwd_pack_kernel(AttnBwdArgs a, const
 
 // (no scheduling barriers inside the MFMA groups here: letting hipcc hoist the fragment reads over the previous step's MFMAs
 // measured 18.2 -> 16.6 ms; the first version needs them to stay inside its register budget)
-template <bool DROP>
+template <bool DROP, bool RAGGED>
 __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, const float* __restrict__ oscale_ptr,
                                                               const _Float16* __restrict__ pack) {
     const float oscale = *oscale_ptr;
@@ -679,7 +680,6 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
     const int ntiles = Lq_pad >> 5;
     const float c2 = 1.4426950408889634f / 8.f, cn = 1.f / 8.f;
     const float inv_os = 1.f / oscale;
-    const bool ragged = (int)(blockIdx.x + 1) * kSpKW > a.Lk;      // workgroup-uniform
 
     // ---- K, V of this lane's key as B fragments: step t holds d = 16 t + 8 kh + e; K also goes into LDS (natural layout)
     half8 kfh[4], kfl[4], vfh[4], vfl[4];
@@ -762,6 +762,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
         }
         // ---- P (with dropout), dS; accumulator register r is query mfma32_row(r, lane), column = this lane's key
         half8 ph[2], pl[2], sh[2], sl[2];
+        {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             float pv[8], dv[8];
@@ -777,7 +778,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
                 const int r = 8 * m + e;
                 const int qi = mfma32_row(r, lane);
                 float p = __builtin_amdgcn_exp2f(sacc[r] * c2 - st[qi]);                     // rows past Lq: lse = +inf -> 0
-                if (ragged) p = jok ? p : 0.f;                                               // keys past Lk: last key block only
+                if constexpr (RAGGED) p = jok ? p : 0.f;                                     // keys past Lk (launches whose Lk is not a multiple of 256)
                 float keep = 1.f;
                 if constexpr (DROP) keep = drop_keep_h(rh[e], drop_col, drop_thr) ? drop_inv : 0.f;
                 pv[e] = p * keep;
@@ -792,6 +793,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
                 *reinterpret_cast<half4v*>(Ds + off) = half4v{sh[m][4 * hh], sh[m][4 * hh + 1], sh[m][4 * hh + 2], sh[m][4 * hh + 3]};
                 *reinterpret_cast<half4v*>(Ds + 8192 + off) = half4v{sl[m][4 * hh], sl[m][4 * hh + 1], sl[m][4 * hh + 2], sl[m][4 * hh + 3]};
             }
+        }
         }
         // ---- dV^T += dO^T P, dK^T += Q^T dS: contraction over the queries; A operands by transpose reads of the natural images
 #pragma unroll
@@ -1095,18 +1097,22 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
     if (pack && !v1) {
         // second version: tile images packed once, fetched by LDS-DMA; transpose reads
         constexpr size_t lds2 = (size_t)(2 * 8192 + 2 * 16384 + 2 * kImgHalfs) * sizeof(_Float16);
-        static bool attr2 = false;
-        if (!attr2) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_split2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_split2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            if (e != hipSuccess) return e;
-            attr2 = true;
-        }
+        const bool rag = (Lk % kSpKW) != 0;
+        const void* fn = drop_p > 0.f ? (rag ? reinterpret_cast<const void*>(&attn_bwd_split2_kernel<true, true>)
+                                             : reinterpret_cast<const void*>(&attn_bwd_split2_kernel<true, false>))
+                                      : (rag ? reinterpret_cast<const void*>(&attn_bwd_split2_kernel<false, true>)
+                                             : reinterpret_cast<const void*>(&attn_bwd_split2_kernel<false, false>));
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e != hipSuccess) return e;
         _Float16* pk = reinterpret_cast<_Float16*>(pack);
         hipLaunchKernelGGL(attn_bwd_pack_kernel, dim3(Lq_pad / 32, B * H, n_it), dim3(256), 0, s, a, oscale, pk);
-        if (drop_p > 0.f) hipLaunchKernelGGL(attn_bwd_split2_kernel<true>, g2, dim3(512), lds2, s, a, oscale, pk);
-        else hipLaunchKernelGGL(attn_bwd_split2_kernel<false>, g2, dim3(512), lds2, s, a, oscale, pk);
+        if (drop_p > 0.f) {
+            if (rag) hipLaunchKernelGGL((attn_bwd_split2_kernel<true, true>), g2, dim3(512), lds2, s, a, oscale, pk);
+            else hipLaunchKernelGGL((attn_bwd_split2_kernel<true, false>), g2, dim3(512), lds2, s, a, oscale, pk);
+        } else {
+            if (rag) hipLaunchKernelGGL((attn_bwd_split2_kernel<false, true>), g2, dim3(512), lds2, s, a, oscale, pk);
+            else hipLaunchKernelGGL((attn_bwd_split2_kernel<false, false>), g2, dim3(512), lds2, s, a, oscale, pk);
+        }
     } else {
         e = split_bwd_lds_attr();
         if (e != hipSuccess) return e;

@@ -60,12 +60,17 @@ __host__ __device__ inline uint32_t rng_stream(uint32_t base, uint32_t stream) {
 // part of the hash is computed once per row (per lane in the forward attention kernels, per query tile in the backward ones),
 // the column part once per column where a kernel can share it (below).
 __host__ __device__ inline uint32_t drop_rowhash(uint32_t seed, uint32_t row) { return rng_mix(seed ^ (row * 0x9e3779b1U)); }
-// keep(row, col) = ((rowhash(seed, row) ^ colhash(col)) >> 8) >= ceil(p * 2^24): the column part does not depend on the seed, so
+// keep(row, col) = ((rowhash(seed, row) ^ colhash(col)) >> 8) >= ceil(p * 2^24)  (evaluated as one 32-bit compare): the column part does not depend on the seed, so
 // the attention kernels hash a key ONCE (per stage in the forward, per lane in the backward, where a lane owns a key) and spend
 // one xor + compare per element; entries are uniform and pairwise independent (xor of two independently mixed words).
 __host__ __device__ inline uint32_t drop_colhash(uint32_t col) { return rng_mix(col * 0x85ebca77U + 0x6a09e667U); }
-__host__ __device__ inline uint32_t drop_threshold(float p) { return (uint32_t)ceilf(p * 16777216.0f); }
-__host__ __device__ inline bool drop_keep_h(uint32_t rowhash, uint32_t colhash, uint32_t thr) { return ((rowhash ^ colhash) >> 8) >= thr; }
+// threshold in the scale of the full 32-bit hash: (h >> 8) >= ceil(p 2^24)  <=>  h >= ceil(p 2^24) * 256 (saturated: p ~ 1 keeps nothing
+// but h = 2^32 - 1)
+__host__ __device__ inline uint32_t drop_threshold(float p) {
+    const float t = ceilf(p * 16777216.0f);
+    return t >= 16777216.0f ? 0xffffffffU : ((uint32_t)t << 8);
+}
+__host__ __device__ inline bool drop_keep_h(uint32_t rowhash, uint32_t colhash, uint32_t thr) { return (rowhash ^ colhash) >= thr; }
 __host__ __device__ inline bool drop_keep(uint32_t rowhash, uint32_t col, float p) {
     return drop_keep_h(rowhash, drop_colhash(col), drop_threshold(p));
 }
