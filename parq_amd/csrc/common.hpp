@@ -35,8 +35,13 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void split_pair(float x0, float x1, half2v& hi, half2v& lo) {
     const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
     hi = __builtin_bit_cast(half2v, h);
-    const float b0 = (float)hi[0], b1 = (float)hi[1];
-    lo = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(x0 - b0, x1 - b1));
+    // x - hi as v_fma_mix_f32(hi (fp16 half of the packed register), -1.0, x): one instruction per element instead of cvt + sub
+    // (hipcc only forms the mixed fma when a multiply feeds the subtraction); the difference is exact either way
+    float d0, d1;
+    const unsigned int hp = __builtin_bit_cast(unsigned int, h);
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(hp), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(hp), "v"(x1));
+    lo = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(d0, d1));
 }
 
 __device__ __forceinline__ void split8(const float* x, half8& hi, half8& lo) {

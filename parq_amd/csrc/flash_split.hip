@@ -290,7 +290,9 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
                 }
             };
             auto qk_step = [&](int kb, int s) {
-                sacc[kb] = mfma16<KIND>(kf[kb][2 * s], qhi[s], sacc[kb]);
+                // the first product of a block starts from the inline constant 0 (no zeroing pass over the accumulators)
+                const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                sacc[kb] = mfma16<KIND>(kf[kb][2 * s], qhi[s], s == 0 ? zero16 : sacc[kb]);
                 if constexpr (TERMS == 3) {
                     sacc[kb] = mfma16<KIND>(kf[kb][2 * s], qlo[s], sacc[kb]);
                     sacc[kb] = mfma16<KIND>(kf[kb][2 * s + 1], qhi[s], sacc[kb]);
@@ -371,10 +373,6 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
             };
 
             auto first_half = [&](auto tail_tag) {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
                 rs = 0.f;
                 load_k(S0, 0);
                 load_k(S0, 1);
