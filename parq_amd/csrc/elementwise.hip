@@ -406,11 +406,14 @@ __global__ __launch_bounds__(256) void box_decode_kernel(BoxDecodeArgs a) {
     // sine embedding of the next reference point for the next iteration's position MLP
     if (a.emb_next) {
         const float n0 = __shfl(nref, 0), n1 = __shfl(nref, 1), n2 = __shfl(nref, 2);
-        for (int k = lane; k < 384; k += 64) {
-            const int blk = k >> 7, i = k & 127;
+        // entries 2 p and 2 p + 1 of an axis block are sin and cos of the SAME angle (dim_t[2p] == dim_t[2p+1]): one sincosf per pair
+#pragma unroll
+        for (int blk = 0; blk < 3; ++blk) {
             const float r = blk == 0 ? n1 : (blk == 1 ? n0 : n2);
-            const float ang = (r * 6.283185307179586f) / a.dim_t[i];
-            a.emb_next[(int64_t)m * 384 + k] = (i & 1) ? cosf(ang) : sinf(ang);
+            const float ang = (r * 6.283185307179586f) / a.dim_t[2 * lane];
+            float sn, cs;
+            sincosf(ang, &sn, &cs);
+            *reinterpret_cast<float2*>(a.emb_next + (int64_t)m * 384 + blk * 128 + 2 * lane) = float2{sn, cs};
         }
     }
 }
