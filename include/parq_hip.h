@@ -154,7 +154,12 @@ int parq_profile_read(parq_handle h, int32_t which, double *total_ms, int64_t *l
  * training workspace; parq_backward consumes them: `grads` holds d loss / d output per iteration (same (I,B,Q,k) layout as
  * the outputs, NULL = zero), `grad_arena` receives d loss / d weight in the layout of the packed weight arena
  * (parq_arena_lookup maps reference tensor names to offsets), `d_tokens` (B,N,C) or NULL receives d loss / d input tokens.
- * Reference points are detached between iterations as in the reference (transformer_parq.py:331-332). */
+ * Reference points are detached between iterations as in the reference (transformer_parq.py:331-332), which makes the iterations
+ * independent given the stash: with shared layer weights (one K / V per scene) parq_backward runs the cross-attention backward of
+ * ALL iterations as one launch (dK / dV written once) and the K/V-projection weight gradient on the fp16 matrix pipe (hi/lo split);
+ * the training workspace then also holds per-iteration dO / dQ and packed query tiles (parq_train_workspace_bytes accounts for it).
+ * Environment switches for A/B and debugging: PARQ_BWD_BATCHED=0 (per-iteration launches), PARQ_KVPROJ_BWD=fp32 (generic fp32
+ * TN GEMM), PARQ_ATTN_BWD_V=1 (first-version split kernel), PARQ_ATTN_BWD=naive|mfma (exact fp32 attention backward). */
 typedef struct parq_output_grads {
     const float *pred_logits, *center_unnormalized, *size_unnormalized, *ortho6d;
 } parq_output_grads;
