@@ -245,18 +245,25 @@ def decoder_loss_batched(out_dict_list, obbs_padded, T_world_local, sym=None, *,
             cost = matcher.cost_bbox * l1b - matcher.cost_class * prob_np[k, b][:, ids]
             rows, cols = linear_sum_assignment(cost)
             near = l1b < matcher.ratio
-            extra_p, extra_g, mask_np = [], [], None
-            for j in range(n):
-                pidx = np.nonzero(near[:, j])[0]
+            if near.sum(0).max() <= matcher.max_padding:
+                # no box has more neighbours than the cap: no random draw, every neighbour is an extra match (pairs ordered by box,
+                # then query, as the per-box loop appends them) and the punish mask (taken from the LAST box only) keeps everything
+                eg, ep = np.nonzero(near.T)
                 mask_np = np.ones(Q, dtype=bool)
-                mask_np[pidx] = False
-                if pidx.shape[0] > matcher.max_padding:
-                    pidx = pidx[np.random.choice(pidx.shape[0], matcher.max_padding, replace=False)]
-                mask_np[pidx] = True
-                extra_p.append(pidx)
-                extra_g.append(np.ones_like(pidx) * j)
-            p = np.concatenate([rows, np.concatenate(extra_p)])
-            g = np.concatenate([cols, np.concatenate(extra_g)])
+            else:
+                extra_p, extra_g, mask_np = [], [], None
+                for j in range(n):
+                    pidx = np.nonzero(near[:, j])[0]
+                    mask_np = np.ones(Q, dtype=bool)
+                    mask_np[pidx] = False
+                    if pidx.shape[0] > matcher.max_padding:
+                        pidx = pidx[np.random.choice(pidx.shape[0], matcher.max_padding, replace=False)]
+                    mask_np[pidx] = True
+                    extra_p.append(pidx)
+                    extra_g.append(np.ones_like(pidx) * j)
+                ep, eg = np.concatenate(extra_p), np.concatenate(extra_g)
+            p = np.concatenate([rows, ep])
+            g = np.concatenate([cols, eg])
             _, first = np.unique(p, return_index=True)
             idx_k.append((p[first], g[first]))
             plist.append(mask_np)

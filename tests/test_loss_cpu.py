@@ -74,3 +74,29 @@ def test_batched_loss_gradients_equal_the_loop_version():
         grads.append([o[k].grad.clone() for o in touts for k in ("pred_logits", "center_unnormalized", "size_unnormalized", "ortho6d")])
     for a, b in zip(*grads):
         assert torch.allclose(a, b, atol=1e-6, rtol=1e-5)
+
+
+def test_batched_loss_without_capped_clusters_equals_the_loop_version():
+    """The matcher's fast path (no box with more than 10 neighbours: no random draw) against the per-box loop of the loop version:
+    the clusters of the golden case are thinned to 6 + 3 reference points, one scene keeps none."""
+    c = LOSS_CASE
+    outs, obbs, T_wl, sym = loss_case_inputs(c)
+    rng = np.random.RandomState(3)
+    for o in outs:
+        o["coord_pos"][:, 6:14] = rng.uniform(2.5, 3.0, (o["coord_pos"].shape[0], 8, 3)).astype(np.float32)   # far from every box
+        o["coord_pos"][2, :18] = rng.uniform(2.5, 3.0, (18, 3)).astype(np.float32)
+    cw = torch.ones(10)
+    cw[9] = 0.1
+    res = []
+    for fn in (decoder_loss, decoder_loss_batched):
+        touts = [{k: torch.from_numpy(v).clone() for k, v in o.items()} for o in outs]
+        state = np.random.get_state()
+        np.random.seed(77)
+        l = fn(touts, Obb3D(torch.from_numpy(obbs)), Pose(torch.from_numpy(T_wl)), torch.from_numpy(sym),
+               matcher=HungarianMatcherModified(2, 0.25), loss_weight=[5.0, 5.0, 5.0, 1.0], num_semcls=9, class_weight=cw)
+        drew = np.random.random()                      # position of the global generator after the call
+        np.random.set_state(state)
+        res.append(({k: float(v) for k, v in l.items()}, drew))
+    assert res[0][1] == res[1][1] == np.random.RandomState(77).random_sample()          # neither version drew a sample
+    for k in res[0][0]:
+        assert abs(res[0][0][k] - res[1][0][k]) < 1e-5 * max(1.0, abs(res[0][0][k])), k
