@@ -340,14 +340,14 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
                     p[e] = __builtin_amdgcn_exp2f(sacc[kb][8 * m + e] - m_run);
                     rs += p[e];
                 }
-                if constexpr (DROP) {           // the normaliser above stays undropped (nn.MultiheadAttention dropout)
-                    const float inv = 1.f / (1.f - a.drop_p);
+                if constexpr (DROP) {           // the normaliser above stays undropped (nn.MultiheadAttention dropout); the factor
+                                                // 1 / (1 - p) of the kept entries is applied once to the partial output (epilogue)
                     // keys mfma32_row(8 m + e, lane) = 16 m + 4 kh + (e & 3) + 8 (e >> 2) of block kb: two groups of 4 consecutive hashes
                     const uint4 c0 = *reinterpret_cast<const uint4*>(drop_ch + kb * 32 + 16 * m + 4 * kh);
                     const uint4 c1 = *reinterpret_cast<const uint4*>(drop_ch + kb * 32 + 16 * m + 4 * kh + 8);
                     const uint32_t ch[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) p[e] = drop_keep_h(drop_rh, ch[e], drop_thr) ? p[e] * inv : 0.f;
+                    for (int e = 0; e < 8; ++e) p[e] = drop_keep_h(drop_rh, ch[e], drop_thr) ? p[e] : 0.f;
                 }
                 if constexpr (TERMS == 3) split8(p, phi[kb][m], plo[kb][m]);
                 else phi[kb][m] = cvt8_rn<KIND>(p);
@@ -437,10 +437,11 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
     if (active) {
         const int64_t pbase = (int64_t)bh * a.nsplit + split;
         float* op = a.o_part + pbase * kDH * Lq_pad;
+        const float drop_scale = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) op[(int64_t)(d * 32 + mfma32_row(r, lane)) * Lq_pad + q] = o[d][r];
+            for (int r = 0; r < 16; ++r) op[(int64_t)(d * 32 + mfma32_row(r, lane)) * Lq_pad + q] = o[d][r] * drop_scale;
         if (kh == 0) {
             a.m_part[pbase * Lq_pad + q] = m_run;
             a.l_part[pbase * Lq_pad + q] = l_run;
