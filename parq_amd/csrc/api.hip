@@ -94,7 +94,9 @@ struct parq_ctx {
     float drop_p = 0.f;               // training dropout (decoder layer, transformer_parq.py:339-386) and its base seed
     uint32_t drop_seed = 0;
     uint32_t site_seed(int k, int site) const { return rng_stream(drop_seed, (uint32_t)(k * 8 + site)); }
-    bool cache_mode() const { return attn_mode >= 1 && dh == 64; }
+    // split K/V cache in use: head dim 64 (all cache modes) or head dim 256 in split mode (a head = 4 virtual heads of 64)
+    bool cache_mode() const { return attn_mode >= 1 && (dh == 64 || (dh == 256 && attn_mode == 1)); }
+    int vheads() const { return C / 64; }            // heads of the cache layout
     int terms() const { return attn_mode == 1 ? 3 : 1; }
     int kind() const { return attn_mode == 3 ? kBF16 : kF16; }
     bool profiling = false;
@@ -166,9 +168,10 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     ws->iter_begin = ws->emb; ws->iter_end = off;
     const int cus = device_num_cus();
     ws->self_split = flash_pick_splits(B, c->H, c->Q, c->Q, c->dh, cus);
-    ws->cross_split = split_mode ? flash_split_pick_splits(B, c->H, c->Q, (int)N, cus)
+    ws->cross_split = split_mode ? (c->dh == 256 ? flash_split256_pick_splits(B, c->H, c->Q, (int)N, cus)
+                                                 : flash_split_pick_splits(B, c->H, c->Q, (int)N, cus))
                                  : flash_pick_splits(B, c->H, c->Q, (int)N, c->dh, cus);
-    ws->kvc = take(split_mode ? (int64_t)(c->nl * kvsplit_cache_bytes(B, c->H, (int)N, c->terms()) / sizeof(float)) : 0);
+    ws->kvc = take(split_mode ? (int64_t)(c->nl * kvsplit_cache_bytes(B, c->vheads(), (int)N, c->terms()) / sizeof(float)) : 0);
     ws->flags = take(64);
     const size_t fs = flash_scratch_bytes(B, c->H, c->Q, c->dh, ws->self_split);
     const size_t fc = flash_scratch_bytes(B, c->H, c->Q, c->dh, ws->cross_split);
@@ -266,8 +269,8 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         Prof p(c, s, PARQ_PROF_KV_PROJ);
         const LayerW& L = c->ar.layers[li];
         if (c->cache_mode()) {
-            char* cache = reinterpret_cast<char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, c->H, (int)N, c->terms());
-            HIPCHK(launch_kvproj_split(sc->tokens, A + L.kv_whi, A + L.kv_wlo, A + L.cross_in_b + C, B, (int)N, C, c->H,
+            char* cache = reinterpret_cast<char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, c->vheads(), (int)N, c->terms());
+            HIPCHK(launch_kvproj_split(sc->tokens, A + L.kv_whi, A + L.kv_wlo, A + L.cross_in_b + C, B, (int)N, C, c->vheads(),
                                        cache, reinterpret_cast<int*>(wsp + ws.flags), s, c->terms(), c->kind()));
         } else {
             LinearArgs a = lin(sc->tokens, C, A + L.cross_in_w + (int64_t)C * C, C, A + L.cross_in_b + C,
@@ -375,8 +378,9 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         fa.m_part = fa.o_part + (int64_t)B * H * fa.nsplit * dh * lp;
         fa.l_part = fa.m_part + (int64_t)B * H * fa.nsplit * lp;
         if (c->cache_mode()) {
-            const char* cache = reinterpret_cast<const char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, H, (int)N, c->terms());
-            HIPCHK(launch_flash_split(fa, cache, s, c->terms(), c->kind()));
+            const char* cache = reinterpret_cast<const char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, c->vheads(), (int)N, c->terms());
+            if (dh == 256) HIPCHK(launch_flash_split256(fa, cache, s));
+            else HIPCHK(launch_flash_split(fa, cache, s, c->terms(), c->kind()));
         } else {
             const float* kv = wsp + ws.kv + (int64_t)li * B * 2 * N * C;
             fa.k = kv;                       fa.k_batch = 2 * N * C; fa.k_head = N * dh; fa.k_row = dh;
@@ -1027,6 +1031,7 @@ int parq_backward(parq_handle h, const parq_scene* scene, void* workspace, size_
     if (!h || !workspace || !outs || !g || !grad_arena) return fail(PARQ_ERR_ARG, "NULL argument");
     if (!h->packed) return fail(PARQ_ERR_STATE, "parq_pack_weights must be called first");
     if (h->cache_mode() && h->terms() != 3) return fail(PARQ_ERR_STATE, "training needs attention mode 0 or 1");
+    if (h->cache_mode() && h->dh != 64) return fail(PARQ_ERR_STATE, "training at head dim 256 needs attention mode 0");
     int rc = check_scene(h, scene);
     if (rc) return rc;
     Workspace ws;

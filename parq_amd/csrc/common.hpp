@@ -174,6 +174,9 @@ hipError_t launch_flash_merge(const FlashArgs& a, hipStream_t s); // partials ->
 // cache blocks hold only [K | V] (8 KB instead of 16 KB).
 size_t kvsplit_cache_bytes(int B, int H, int N, int terms = 3);
 int flash_split_pick_splits(int B, int H, int Lq, int Lk, int num_cus);
+// flash_split256.hip: the same for head dim 256 (a head = 4 virtual heads of 64 in the cache; wave pairs split the head dim)
+int flash_split256_pick_splits(int B, int H, int Lq, int Lk, int num_cus);
+hipError_t launch_flash_split256(const FlashArgs& a, const void* cache, hipStream_t s);
 hipError_t launch_kvsplit_convert(const float* K, const float* V, int64_t k_batch, int64_t k_head, int64_t k_row,
                                   int64_t v_batch, int64_t v_head, int64_t v_row, int B, int H, int N, void* cache,
                                   int* overflow_flag, hipStream_t s, int terms = 3, int kind = kF16);

@@ -209,8 +209,9 @@ class PARQDecoder(nn.Module):
         self.refpoint = nn.Embedding(self.num_queries, 3)
 
         # cross-attention arithmetic: "split" = fp16 hi/lo 3-term products on the fp16 matrix pipe
-        # (fp32-class accuracy, head dim 64), "fp32" = fp32 MFMA.  include/parq_hip.h
-        self.attention_mode = "split" if Cd // self.num_heads == 64 else "fp32"
+        # (fp32-class accuracy; head dim 64, and head dim 256 = the reference's shipped DEC_DIM 1024 / 4 heads),
+        # "fp32" = fp32 MFMA.  include/parq_hip.h
+        self.attention_mode = "split" if Cd // self.num_heads in (64, 256) else "fp32"
         self._mean_sizes = mean_size_table(self.mean_size_path)     # (rows,3) float64
         self._h = None            # parq_handle
         self._arena = None
