@@ -247,6 +247,12 @@ size_t parq_k_attention_split_scratch_bytes(int32_t B, int32_t H, int32_t Lq, in
 int parq_k_attention_split(const float *q, const float *k, const float *v, float *out, int32_t B, int32_t H,
                            int32_t Lq, int32_t Lk, void *scratch, size_t scratch_bytes, parq_stream stream);
 
+/* the split-fp16 path at head dim 256 (the reference's shipped DEC_DIM 1024 / 4 heads, config/train.yaml:49-50): a head is
+ * stored as 4 virtual heads of 64 in the split cache, a pair of waves shares each 32-query tile. */
+size_t parq_k_attention_split256_scratch_bytes(int32_t B, int32_t H, int32_t Lq, int32_t Lk);
+int parq_k_attention_split256(const float *q, const float *k, const float *v, float *out, int32_t B, int32_t H,
+                              int32_t Lq, int32_t Lk, void *scratch, size_t scratch_bytes, parq_stream stream);
+
 /* the single-product reduced-precision variants (attention modes 2 / 3): bf16 != 0 selects bf16, else fp16 */
 size_t parq_k_attention_half_scratch_bytes(int32_t B, int32_t H, int32_t Lq, int32_t Lk);
 int parq_k_attention_half(const float *q, const float *k, const float *v, float *out, int32_t B, int32_t H,

@@ -1255,6 +1255,40 @@ int parq_k_attention_split(const float* q, const float* k, const float* v, float
     return PARQ_OK;
 }
 
+size_t parq_k_attention_split256_scratch_bytes(int32_t B, int32_t H, int32_t Lq, int32_t Lk) {
+    const int ns = flash_split256_pick_splits(B, H, Lq, Lk, device_num_cus());
+    return flash_scratch_bytes(B, H, Lq, 256, ns) + kvsplit_cache_bytes(B, 4 * H, Lk) + 256;
+}
+
+/* head dim 256: a head is stored as 4 virtual heads of 64 in the split cache (flash_split256.hip) */
+int parq_k_attention_split256(const float* q, const float* k, const float* v, float* out, int32_t B, int32_t H, int32_t Lq,
+                              int32_t Lk, void* scratch, size_t scratch_bytes, parq_stream stream) {
+    if (!q || !k || !v || !out || !scratch) return fail(PARQ_ERR_ARG, "NULL argument");
+    if (B < 1 || H < 1 || Lq < 1 || Lk < 1) return fail(PARQ_ERR_ARG, "bad dims");
+    if (scratch_bytes < parq_k_attention_split256_scratch_bytes(B, H, Lq, Lk)) return fail(PARQ_ERR_WORKSPACE, "attention scratch too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int dh = 256;
+    const int64_t C = (int64_t)H * dh;
+    FlashArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.B = B; fa.H = H; fa.Lq = Lq; fa.Lk = Lk; fa.dh = dh;
+    fa.q = q; fa.q_batch = Lq * C; fa.q_head = dh; fa.q_row = C;
+    fa.out = out; fa.out_batch = Lq * C; fa.out_row = C;
+    fa.nsplit = flash_split256_pick_splits(B, H, Lq, Lk, device_num_cus());
+    const int64_t lp = flash_lq_pad(Lq);
+    char* base = (char*)scratch;
+    int* flag = (int*)base;
+    char* cache = base + 256;
+    fa.o_part = (float*)(cache + kvsplit_cache_bytes(B, 4 * H, Lk));
+    fa.m_part = fa.o_part + (int64_t)B * H * fa.nsplit * dh * lp;
+    fa.l_part = fa.m_part + (int64_t)B * H * fa.nsplit * lp;
+    HIPCHK(hipMemsetAsync(flag, 0, 256, s));
+    HIPCHK(launch_kvsplit_convert(k, v, Lk * C, 64, C, Lk * C, 64, C, B, 4 * H, Lk, cache, flag, s));     // 4 H virtual heads of 64
+    HIPCHK(launch_flash_split256(fa, cache, s));
+    HIPCHK(launch_flash_merge(fa, s));
+    return PARQ_OK;
+}
+
 size_t parq_k_attention_half_scratch_bytes(int32_t B, int32_t H, int32_t Lq, int32_t Lk) {
     return parq_k_attention_split_scratch_bytes(B, H, Lq, Lk);      // the single-term cache is half the split one
 }

@@ -112,6 +112,29 @@ def test_attention_split_fp16x3(B, H, Lq, Lk):
     assert int(scratch[:1].view(torch.int32).item()) == 0          # no fp16 range overflow flagged
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 4, 256, 9600), (2, 2, 100, 1000), (1, 1, 32, 33), (1, 2, 130, 4097), (2, 1, 256, 70000)])
+def test_attention_split_head_dim_256(B, H, Lq, Lk):
+    """Split-precision attention at head dim 256 (the reference's shipped DEC_DIM 1024 / 4 heads): wave pairs share a query tile and
+    split the head dim.  fp32-class tolerance against float64; ragged Lq (inactive wave pairs, partial tiles) and Lk (masked last
+    block), one to many key splits, rows with exact fp16 ties."""
+    dh, Cn = 256, H * 256
+    q = synth.normal(11, "q", (B, Lq, Cn)); k = synth.normal(12, "k", (B, Lk, Cn), std=1.5); v = synth.normal(13, "v", (B, Lk, Cn), std=3.0)
+    k[0, 0, :dh] = 1.5 * q[0, 0, :dh]                 # a peaky row
+    ties = np.array([1 + 2.0 ** -11, -(2 + 2.0 ** -10), 0.5 + 2.0 ** -12, 3 * 2.0 ** -14 + 2.0 ** -25, 0.20623779296875], np.float32)
+    k[0, Lk - 1, 130:135] = ties
+    v[0, 0, 200:205] = ties
+    nbytes = lib().parq_k_attention_split256_scratch_bytes(B, H, Lq, Lk)
+    scratch = torch.empty(nbytes // 4 + 1, device="cuda")
+    out = torch.empty(B, Lq, Cn, device="cuda")
+    dq, dk, dv = dev(q), dev(k), dev(v)
+    _lib.check(lib().parq_k_attention_split256(_lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(out), B, H, Lq, Lk,
+                                              _lib.ptr(scratch), nbytes, sptr()), "attention_split256")
+    tq, tk, tv = (torch.from_numpy(x).double().view(B, -1, H, dh).transpose(1, 2) for x in (q, k, v))
+    want = (torch.softmax(tq @ tk.transpose(-1, -2) / dh ** 0.5, -1) @ tv).transpose(1, 2).reshape(B, Lq, Cn)
+    assert rel_err(out.cpu().numpy(), want.numpy()) < 2e-5
+    assert int(scratch[:1].view(torch.int32).item()) == 0          # no fp16 range overflow flagged
+
+
 @pytest.mark.parametrize("bf16,tol", [(0, 2e-3), (1, 1.5e-2)])
 @pytest.mark.parametrize("B,H,Lq,Lk", [(1, 4, 64, 9600), (2, 2, 100, 1000), (1, 1, 32, 64), (1, 2, 256, 4097)])
 def test_attention_half(B, H, Lq, Lk, bf16, tol):
