@@ -61,6 +61,7 @@ struct Workspace {
     int64_t T_cl, kv, ref, ref_next, emb, pe_h, pos, tgt, qkv, attn, xa, qc, xb, ffn, xc;
     int64_t h1, h2, gn_sums, ln1, ln2, flash;     // gn_sums: [2 layers][B][2 heads][2] fp64 moments; ln*: [M][2]
     int64_t kvc, flags;               // split-fp16 K/V cache, int flags (overflow)
+    int64_t xsplit;                   // fp16 hi/lo copy of the tokens for the large-C K/V projection (kvproj_big.hip), else empty
     int64_t total;
     int self_split, cross_split;
     // per-iteration activations live in [iter_begin, iter_end); a training forward keeps one copy per iteration:
@@ -135,6 +136,11 @@ void build_arena(parq_ctx* c) {
     a.total = off;
 }
 
+bool kvproj_big_on() {
+    const char* e = getenv("PARQ_KVPROJ_BIG");           // 0: keep the tiled kernel at C > 256 (A/B)
+    return !(e && e[0] == '0');
+}
+
 // Training: the cross-attention backward of all recurrent iterations can run as ONE launch when the iterations share the layer
 // weights (hence K / V) and the split-precision kernel applies (head dim 64, long key axis); PARQ_BWD_BATCHED=0 restores the
 // per-iteration launches.
@@ -173,6 +179,7 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
                                  : flash_pick_splits(B, c->H, c->Q, (int)N, c->dh, cus);
     ws->kvc = take(split_mode ? (int64_t)(c->nl * kvsplit_cache_bytes(B, c->vheads(), (int)N, c->terms()) / sizeof(float)) : 0);
     ws->flags = take(64);
+    ws->xsplit = take(split_mode && c->terms() == 3 && kvproj_big_on() ? (int64_t)kvproj_big_scratch_floats(B, (int)N, C) : 0);
     const size_t fs = flash_scratch_bytes(B, c->H, c->Q, c->dh, ws->self_split);
     const size_t fc = flash_scratch_bytes(B, c->H, c->Q, c->dh, ws->cross_split);
     ws->flash = take((int64_t)((fs > fc ? fs : fc) / sizeof(float)));
@@ -270,8 +277,12 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         const LayerW& L = c->ar.layers[li];
         if (c->cache_mode()) {
             char* cache = reinterpret_cast<char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, c->vheads(), (int)N, c->terms());
-            HIPCHK(launch_kvproj_split(sc->tokens, A + L.kv_whi, A + L.kv_wlo, A + L.cross_in_b + C, B, (int)N, C, c->vheads(),
-                                       cache, reinterpret_cast<int*>(wsp + ws.flags), s, c->terms(), c->kind()));
+            if (c->terms() == 3 && kvproj_big_on() && kvproj_big_scratch_floats(B, (int)N, C) > 0)
+                HIPCHK(launch_kvproj_big(sc->tokens, A + L.kv_whi, A + L.kv_wlo, A + L.cross_in_b + C, B, (int)N, C, cache,
+                                         reinterpret_cast<int*>(wsp + ws.flags), wsp + ws.xsplit, s));
+            else
+                HIPCHK(launch_kvproj_split(sc->tokens, A + L.kv_whi, A + L.kv_wlo, A + L.cross_in_b + C, B, (int)N, C, c->vheads(),
+                                           cache, reinterpret_cast<int*>(wsp + ws.flags), s, c->terms(), c->kind()));
         } else {
             LinearArgs a = lin(sc->tokens, C, A + L.cross_in_w + (int64_t)C * C, C, A + L.cross_in_b + C,
                                wsp + ws.kv + (int64_t)li * B * 2 * N * C, 0, (int)(B * N), 2 * C, C);

@@ -174,6 +174,10 @@ hipError_t launch_flash_merge(const FlashArgs& a, hipStream_t s); // partials ->
 // cache blocks hold only [K | V] (8 KB instead of 16 KB).
 size_t kvsplit_cache_bytes(int B, int H, int N, int terms = 3);
 int flash_split_pick_splits(int B, int H, int Lq, int Lk, int num_cus);
+// kvproj_big.hip: the K/V projection for C > 256 (pre-split tokens, LDS-DMA operands); scratch = kvproj_big_scratch_floats floats
+size_t kvproj_big_scratch_floats(int B, int N, int C);
+hipError_t launch_kvproj_big(const float* tokens, const void* Whi, const void* Wlo, const float* bias, int B, int N, int C,
+                             void* cache, int* overflow, float* scratch, hipStream_t s);
 // flash_split256.hip: the same for head dim 256 (a head = 4 virtual heads of 64 in the cache; wave pairs split the head dim)
 int flash_split256_pick_splits(int B, int H, int Lq, int Lk, int num_cus);
 hipError_t launch_flash_split256(const FlashArgs& a, const void* cache, hipStream_t s);
