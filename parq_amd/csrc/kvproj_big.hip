@@ -11,7 +11,10 @@
 //   K heads are computed TRANSPOSED (A = W rows, B = tokens), V heads normally, so that 8 consecutive accumulator registers are one
 //   16-byte chunk of the cache layout (as in kvproj_split.hip); the epilogue adds the bias, splits and sends every 8 KB [hi | lo]
 //   image of a (32-token block, head) through LDS so that each global store instruction writes 1 KB of contiguous cache.
+// At C = 256 the W-stationary kernel stays ahead (0.205 ms against 0.251 ms here: 8 k-steps per tile do not amortise the pre-pass
+// and the epilogue; PARQ_KVPROJ_BIG_MINC=256 reproduces the comparison).
 #include "common.hpp"
+#include <cstdlib>
 
 namespace parq {
 
@@ -209,7 +212,8 @@ __global__ __launch_bounds__(512) void kvproj_big_kernel(BigArgs a) {
 
 // scratch floats for the split tokens of launch_kvproj_big (0: the kernel does not apply to this shape)
 size_t kvproj_big_scratch_floats(int B, int N, int C) {
-    if (C <= 256 || C % 128 != 0) return 0;
+    static const int minc = [] { const char* e = getenv("PARQ_KVPROJ_BIG_MINC"); return e ? atoi(e) : 257; }();     // experiment knob
+    if (C < minc || C % 128 != 0) return 0;
     return (size_t)B * N * C;                                   // hi + lo fp16 = 4 bytes per element
 }
 
