@@ -69,7 +69,7 @@ struct Workspace {
     int64_t sa, ln3, lse_s, lse_c, refk;
     int64_t iter_begin, iter_end, stash;
     // backward scratch (training workspace only)
-    int64_t g_a, g_b, g_c, g_pos, g_tmp, g_ffh, g_h1, g_h2, g_z, g_act, g_h3, g_qkv, g_emb, g_ref, g_D, g_bs, wT, g_kv, g_dqp, g_drop, kv_train, g_do, g_res, g_dq, g_Dall, g_kvmax, g_pack;
+    int64_t g_a, g_b, g_c, g_pos, g_tmp, g_ffh, g_h1, g_h2, g_z, g_act, g_h3, g_qkv, g_emb, g_ref, g_D, g_bs, wT, g_kv, g_dqp, g_drop, kv_train, g_do, g_res, g_dq, g_Dall, g_kvmax, g_pack, g_mat;
     bool bwd_batched;                 // cross-attention backward of all iterations in one launch (shared layer weights, split cache)
     int64_t train_total;
     int64_t shift(int k) const { return k == 0 ? 0 : stash + (int64_t)(k - 1) * (iter_end - iter_begin) - iter_begin; }
@@ -207,6 +207,8 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     ws->g_dq = take(ws->bwd_batched ? nit * M * C : 0);
     ws->g_Dall = take(ws->bwd_batched ? nit * (int64_t)B * c->H * flash_lq_pad((int)Q) : 0);
     ws->g_pack = take(ws->bwd_batched ? (int64_t)attn_bwd_pack_floats(B, c->H, (int)Q, (int)nit) : 0);
+    // head dims without a register-resident attention backward (not 32 / 64): score-matrix scratch of the materialised path
+    ws->g_mat = take((c->dh == 64 || c->dh == 32) ? 0 : (int64_t)attn_bwd_mat_scratch_floats((int)Q, (int)(N > Q ? N : Q), c->dh));
     ws->g_kvmax = take(4);                            // [0] bits of max |dK|, |dV| (batched backward), [1] the derived scale
     ws->train_total = off;
     return PARQ_OK;
@@ -625,7 +627,8 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
                                gA, (int64_t)Q * C, dh, C, wi + ws.lse_c, Dd, gC, (int64_t)Q * C, dh, C, gkv, 2 * N * C, dh, 2 * C,
                                gkv + C, 2 * N * C, dh, 2 * C, B, H, Q, (int)N, dh, 1, s,
                                attn_bwd_dq_partial_floats(B, H, Q, (int)N, dh) ? wsp + ws.g_dqp : nullptr, dp, c->site_seed(k, 2),
-                               reinterpret_cast<unsigned int*>(wsp + ws.g_bs)));      // g_bs: free between the GroupNorm passes
+                               reinterpret_cast<unsigned int*>(wsp + ws.g_bs),        // g_bs: free between the GroupNorm passes
+                               (dh == 64 || dh == 32) ? nullptr : wsp + ws.g_mat));
     }
     }   // phase != 2
     // q = (x1 + pos) Wq^T + bq,  x1 = norm1(xa)
@@ -653,7 +656,8 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     HIPCHK(launch_attn_bwd(wi + ws.qkv, (int64_t)Q * 3 * C, dh, 3 * C, wi + ws.qkv + C, (int64_t)Q * 3 * C, dh, 3 * C,
                            wi + ws.qkv + 2 * C, (int64_t)Q * 3 * C, dh, 3 * C, gA, (int64_t)Q * C, dh, C, wi + ws.lse_s, Dd,
                            gQkv, (int64_t)Q * 3 * C, dh, 3 * C, gQkv + C, (int64_t)Q * 3 * C, dh, 3 * C, gQkv + 2 * C,
-                           (int64_t)Q * 3 * C, dh, 3 * C, B, H, Q, Q, dh, 0, s, nullptr, dp, c->site_seed(k, 0)));
+                           (int64_t)Q * 3 * C, dh, 3 * C, B, H, Q, Q, dh, 0, s, nullptr, dp, c->site_seed(k, 0), nullptr,
+                           (dh == 64 || dh == 32) ? nullptr : wsp + ws.g_mat));
     // in-projection: [q | k] = (tgt + pos) Wqk^T, v = tgt Wv^T
     HIPCHK(launch_add(wi + ws.tgt, wi + ws.pos, tmp, (int64_t)M * C, s));                      // tmp = tgt + pos
     HIPCHK(launch_gemm_tn(gQkv, 3 * C, tmp, C, G + L.self_in_w, C, M, 2 * C, C, 1, s));
@@ -993,7 +997,8 @@ int parq_forward_train(parq_handle h, const parq_scene* scene, void* workspace, 
     if (!h->packed) return fail(PARQ_ERR_STATE, "parq_pack_weights must be called first");
     if (h->cache_mode() && h->terms() != 3)
         return fail(PARQ_ERR_STATE, "training needs attention mode 0 or 1 (the backward works on fp32-accurate K / V)");
-    if (h->dh != 64 && h->dh != 32) return fail(PARQ_ERR_ARG, "training needs head dim 32 or 64");
+    if (h->dh % 16 != 0) return fail(PARQ_ERR_ARG, "training needs a head dim that is a multiple of 16");
+    if (h->cache_mode() && h->dh != 64) return fail(PARQ_ERR_STATE, "training at head dim 256 needs attention mode 0");
     int rc = check_scene(h, scene);
     if (rc) return rc;
     rc = check_outs(outs);

@@ -937,6 +937,88 @@ __global__ __launch_bounds__(256) void attn_bwd_rowdot_kernel(const float* __res
 
 }  // namespace
 
+// ================================================================================================ any head dim: materialised path
+// Attention backward for head dims the register-resident kernels do not cover (e.g. 256 = the reference's shipped size): per
+// (scene, head) the score matrix is materialised in global scratch, as the reference itself does, and every product is one of the
+// chain's generic fp32 GEMMs:  S = Q K^T,  P = exp2(S c - lse),  dV += Pd^T dO,  dP = dO V^T,  dS = P (dP keep/(1-p) - D) / sqrt(dh),
+// dQ += dS K,  dK += dS^T Q   (Pd = P with the dropout mask).  Functional, not fast: ~10 passes over Lq x Lk floats per head.
+__global__ void attn_mat_probs_kernel(float* __restrict__ S, float* __restrict__ Pd, const float* __restrict__ lse, int Lq, int Lk, int Lkp,
+                                      float c2, float drop_p, uint32_t seed, uint32_t row0) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)Lq * Lkp) return;
+    const int i = (int)(idx / Lkp), j = (int)(idx - (int64_t)i * Lkp);
+    float p = 0.f;
+    if (j < Lk) p = __builtin_amdgcn_exp2f(S[idx] * c2 - lse[i]);
+    S[idx] = p;
+    if (Pd) Pd[idx] = (j < Lk && drop_keep(drop_rowhash(seed, row0 + (uint32_t)i), (uint32_t)j, drop_p)) ? p / (1.f - drop_p) : 0.f;
+}
+__global__ void attn_mat_ds_kernel(const float* __restrict__ P, float* __restrict__ dP, const float* __restrict__ D, int Lq, int Lk, int Lkp,
+                                   float cn, float drop_p, uint32_t seed, uint32_t row0) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)Lq * Lkp) return;
+    const int i = (int)(idx / Lkp), j = (int)(idx - (int64_t)i * Lkp);
+    float g = 0.f;
+    if (j < Lk) {
+        float dp = dP[idx];
+        if (drop_p > 0.f) dp = drop_keep(drop_rowhash(seed, row0 + (uint32_t)i), (uint32_t)j, drop_p) ? dp / (1.f - drop_p) : 0.f;
+        g = P[idx] * (dp - D[i]) * cn;
+    }
+    dP[idx] = g;
+}
+
+static LinearArgs mat_lin(const float* X, int64_t ldx, const float* W, int64_t ldw, float* Y, int64_t ldy, int M, int N, int K) {
+    LinearArgs a;
+    memset(&a, 0, sizeof(a));
+    a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.Y = Y; a.M = M; a.N = N; a.K = K;
+    a.rows_per_batch = M; a.y_batch = 0; a.y_row = ldy; a.col_blk = N; a.y_blk = 0;
+    return a;
+}
+
+size_t attn_bwd_mat_scratch_floats(int Lq, int Lk, int dh) {
+    const int64_t Lkp = (Lk + 15) & ~15;
+    return (size_t)(2 * (int64_t)Lq * Lkp + (int64_t)dh * Lkp);
+}
+
+static hipError_t attn_bwd_materialised(const AttnBwdArgs& a, int dh, float* scratch, hipStream_t s) {
+    if (dh % 16 != 0 || !scratch) return hipErrorInvalidValue;
+    const int Lq = a.Lq, Lk = a.Lk, Lkp = (Lk + 15) & ~15, Lq_pad = (Lq + 31) & ~31;
+    float* Pb = scratch;                                     // [Lq][Lkp]  S, then P
+    float* Gb = Pb + (int64_t)Lq * Lkp;                      // [Lq][Lkp]  Pd, then dP, then dS
+    float* KT = Gb + (int64_t)Lq * Lkp;                      // [dh][Lkp]
+    const float c2 = 1.4426950408889634f / sqrtf((float)dh), cn = 1.f / sqrtf((float)dh);
+    const unsigned eb = (unsigned)ceil_div64((int64_t)Lq * Lkp, 256);
+    hipError_t e;
+    for (int b = 0; b < a.B; ++b)
+        for (int h = 0; h < a.H; ++h) {
+            const int bh = b * a.H + h;
+            const float* q = a.q + (int64_t)b * a.q_batch + (int64_t)h * a.q_head;
+            const float* k = a.k + (int64_t)b * a.k_batch + (int64_t)h * a.k_head;
+            const float* v = a.v + (int64_t)b * a.v_batch + (int64_t)h * a.v_head;
+            const float* dO = a.dO + (int64_t)b * a.do_batch + (int64_t)h * a.do_head;
+            float* gq = a.gq + (int64_t)b * a.gq_batch + (int64_t)h * a.gq_head;
+            float* gk = a.gk + (int64_t)b * a.gk_batch + (int64_t)h * a.gk_head;
+            float* gv = a.gv + (int64_t)b * a.gv_batch + (int64_t)h * a.gv_head;
+            const uint32_t row0 = (uint32_t)(bh * Lq);
+            LinearArgs l = mat_lin(q, a.q_row, k, a.k_row, Pb, Lkp, Lq, Lk, dh);                 // S = Q K^T
+            if ((e = launch_linear(l, 1, s)) != hipSuccess) return e;
+            const bool drop = a.drop_p > 0.f;
+            hipLaunchKernelGGL(attn_mat_probs_kernel, dim3(eb), dim3(256), 0, s, Pb, drop ? Gb : nullptr, a.lse + (int64_t)bh * Lq_pad, Lq, Lk,
+                               Lkp, c2, a.drop_p, a.drop_seed, row0);
+            if ((e = launch_gemm_tn(drop ? Gb : Pb, Lkp, dO, a.do_row, gv, a.gv_row, Lq, Lk, dh, a.accumulate_kv, s)) != hipSuccess) return e;
+            l = mat_lin(dO, a.do_row, v, a.v_row, Gb, Lkp, Lq, Lk, dh);                           // dP = dO V^T
+            if ((e = launch_linear(l, 1, s)) != hipSuccess) return e;
+            hipLaunchKernelGGL(attn_mat_ds_kernel, dim3(eb), dim3(256), 0, s, Pb, Gb, a.D + (int64_t)bh * Lq_pad, Lq, Lk, Lkp, cn, a.drop_p,
+                               a.drop_seed, row0);
+            if ((e = hipMemsetAsync(KT, 0, (size_t)dh * Lkp * sizeof(float), s)) != hipSuccess) return e;
+            if ((e = launch_transpose(k, a.k_row, KT, Lkp, Lk, dh, s)) != hipSuccess) return e;
+            l = mat_lin(Gb, Lkp, KT, Lkp, gq, a.gq_row, Lq, dh, Lkp);                              // dQ += dS K
+            l.R = gq; l.ldr = a.gq_row;
+            if ((e = launch_linear(l, 1, s)) != hipSuccess) return e;
+            if ((e = launch_gemm_tn(Gb, Lkp, q, a.q_row, gk, a.gk_row, Lq, Lk, dh, a.accumulate_kv, s)) != hipSuccess) return e;   // dK += dS^T Q
+        }
+    return hipGetLastError();
+}
+
 constexpr size_t kSplitBwdLds = (size_t)(8 * 2048 + 2 * 8192 + 2 * 16384) * sizeof(_Float16) + 96 * sizeof(float);
 static hipError_t split_bwd_lds_attr() {
     static bool done = false;
@@ -955,8 +1037,8 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
                            float* gq, int64_t gq_batch, int64_t gq_head, int64_t gq_row, float* gk, int64_t gk_batch,
                            int64_t gk_head, int64_t gk_row, float* gv, int64_t gv_batch, int64_t gv_head, int64_t gv_row, int B, int H,
                            int Lq, int Lk, int dh, int accumulate_kv, hipStream_t s, float* gq_part, float drop_p, uint32_t drop_seed,
-                           unsigned int* absmax) {
-    if (dh != 64 && dh != 32) return hipErrorInvalidValue;
+                           unsigned int* absmax, float* mat_scratch) {
+    if (dh != 64 && dh != 32 && !mat_scratch) return hipErrorInvalidValue;
     AttnBwdArgs a;
     a.q = q; a.q_batch = q_batch; a.q_head = q_head; a.q_row = q_row;
     a.k = k; a.k_batch = k_batch; a.k_head = k_head; a.k_row = k_row;
@@ -972,6 +1054,7 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
     memset(a.q_off, 0, sizeof(a.q_off));
     memset(a.lse_off, 0, sizeof(a.lse_off));
     for (int t = 0; t < kMaxBwdIters; ++t) a.seeds[t] = drop_seed;
+    if (dh != 64 && dh != 32) return attn_bwd_materialised(a, dh, mat_scratch, s);
     dim3 grid(ceil_div(Lk, 256), B * H);
     static const int force = [] {
         const char* e = getenv("PARQ_ATTN_BWD");            // "naive" / "mfma" (exact fp32 MFMA): debugging overrides of the split kernel

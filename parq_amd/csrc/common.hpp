@@ -233,7 +233,9 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
                            float* gq, int64_t gq_batch, int64_t gq_head, int64_t gq_row, float* gk, int64_t gk_batch,
                            int64_t gk_head, int64_t gk_row, float* gv, int64_t gv_batch, int64_t gv_head, int64_t gv_row, int B, int H,
                            int Lq, int Lk, int dh, int accumulate_kv, hipStream_t s, float* gq_part = nullptr, float drop_p = 0.f,
-                           uint32_t drop_seed = 0, unsigned int* absmax = nullptr);   // absmax: 8-byte device scratch -> split-precision kernel
+                           uint32_t drop_seed = 0, unsigned int* absmax = nullptr,    // absmax: 8-byte device scratch -> split-precision kernel
+                           float* mat_scratch = nullptr);   // attn_bwd_mat_scratch_floats(...) floats: head dims other than 32 / 64
+size_t attn_bwd_mat_scratch_floats(int Lq, int Lk, int dh);
 // all recurrent iterations that share K / V in one launch (split-precision kernel; see attn_bwd.hip)
 hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t q_batch, int64_t q_head, int64_t q_row, const float* k,
                                    int64_t k_batch, int64_t k_head, int64_t k_row, const float* v, int64_t v_batch, int64_t v_head,
