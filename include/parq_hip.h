@@ -150,7 +150,8 @@ int parq_profile_read(parq_handle h, int32_t which, double *total_ms, int64_t *l
 
 /* ---- training: forward with saved activations + backward (model/parq_lightning.py:97-100) ----------
  * The backward of the whole decoder chain as HIP kernels.  Attention mode 0 or 1 (in mode 1 the forward streams the split
- * cache and the backward gets fp32 K / V rebuilt from it), head dim 32/64.  parq_forward_train = parq_forward that keeps every iteration's activations in the (larger)
+ * cache and the backward gets fp32 K / V rebuilt from it).  Head dims 32 / 64 have register-resident attention backward kernels; any
+ * other multiple of 16 (e.g. 256, the reference's shipped size) runs a materialised fp32 path (functional, ~10x slower).  parq_forward_train = parq_forward that keeps every iteration's activations in the (larger)
  * training workspace; parq_backward consumes them: `grads` holds d loss / d output per iteration (same (I,B,Q,k) layout as
  * the outputs, NULL = zero), `grad_arena` receives d loss / d weight in the layout of the packed weight arena
  * (parq_arena_lookup maps reference tensor names to offsets), `d_tokens` (B,N,C) or NULL receives d loss / d input tokens.

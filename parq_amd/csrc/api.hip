@@ -998,7 +998,6 @@ int parq_forward_train(parq_handle h, const parq_scene* scene, void* workspace, 
     if (h->cache_mode() && h->terms() != 3)
         return fail(PARQ_ERR_STATE, "training needs attention mode 0 or 1 (the backward works on fp32-accurate K / V)");
     if (h->dh % 16 != 0) return fail(PARQ_ERR_ARG, "training needs a head dim that is a multiple of 16");
-    if (h->cache_mode() && h->dh != 64) return fail(PARQ_ERR_STATE, "training at head dim 256 needs attention mode 0");
     int rc = check_scene(h, scene);
     if (rc) return rc;
     rc = check_outs(outs);
@@ -1016,9 +1015,10 @@ int parq_forward_train(parq_handle h, const parq_scene* scene, void* workspace, 
         const int64_t N = (int64_t)scene->V * scene->h * scene->w;
         const int C = h->C, dh = h->dh, H = h->H, B = scene->B;
         for (int li = 0; li < h->nl; ++li) {
-            const char* cache = reinterpret_cast<const char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, H, (int)N, 3);
+            const char* cache = reinterpret_cast<const char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, h->vheads(), (int)N, 3);
             float* kv = wsp + ws.kv_train + (int64_t)li * B * 2 * N * C;
-            HIPCHK(launch_kvsplit_to_f32(cache, B, H, (int)N, kv, kv + (int64_t)H * N * dh, 2 * N * C, N * dh, 2 * N * C, N * dh, s));
+            HIPCHK(launch_kvsplit_to_f32(cache, B, h->vheads(), (int)N, kv, kv + (int64_t)H * N * dh, 2 * N * C, N * dh, 2 * N * C, N * dh, s,
+                                         dh / 64));
         }
     }
     // the reference points of iteration k live in that iteration's stash (initial_ref wrote ws.ref)
@@ -1047,7 +1047,6 @@ int parq_backward(parq_handle h, const parq_scene* scene, void* workspace, size_
     if (!h || !workspace || !outs || !g || !grad_arena) return fail(PARQ_ERR_ARG, "NULL argument");
     if (!h->packed) return fail(PARQ_ERR_STATE, "parq_pack_weights must be called first");
     if (h->cache_mode() && h->terms() != 3) return fail(PARQ_ERR_STATE, "training needs attention mode 0 or 1");
-    if (h->cache_mode() && h->dh != 64) return fail(PARQ_ERR_STATE, "training at head dim 256 needs attention mode 0");
     int rc = check_scene(h, scene);
     if (rc) return rc;
     Workspace ws;

@@ -118,15 +118,18 @@ __global__ __launch_bounds__(256) void kvsplit_convert_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------
 // split cache -> fp32 head-major K / V ([b][h][n][64]): hi + lo is the fp32 value to 2^-22.  Training runs the forward on
 // the split cache and hands the backward kernels plain fp32 K / V rebuilt from it (instead of a second, fp32 projection).
+// H counts the heads of the CACHE (64 dims each); a model head of 64 * chunks dims is `chunks` consecutive cache heads and comes
+// out as one [N][64 * chunks] plane (k_head / v_head are the strides of MODEL heads).
 __global__ __launch_bounds__(256) void kvsplit_to_f32_kernel(const _Float16* __restrict__ cache, int H, int N, float* __restrict__ K,
                                                              float* __restrict__ V, int64_t k_batch, int64_t k_head, int64_t v_batch,
-                                                             int64_t v_head) {
+                                                             int64_t v_head, int chunks) {
     const int blk = blockIdx.x, bh = blockIdx.y;
     const int b = bh / H, h = bh - b * H;
     const int nblk = (N + 31) / 32;
+    const int row = 64 * chunks;
     const _Float16* in = cache + ((int64_t)bh * nblk + blk) * Blk<3>::halfs;
-    float* kp = K + (int64_t)b * k_batch + (int64_t)h * k_head;
-    float* vp = V + (int64_t)b * v_batch + (int64_t)h * v_head;
+    float* kp = K + (int64_t)b * k_batch + (int64_t)(h / chunks) * k_head + (h % chunks) * 64;
+    float* vp = V + (int64_t)b * v_batch + (int64_t)(h / chunks) * v_head + (h % chunks) * 64;
     {   // K: thread -> (key, stored chunk position)
         const int key = threadIdx.x >> 3, pos = threadIdx.x & 7;
         const int c = pos ^ ((key >> 1) & 7), kh = c >> 2, s2 = c & 3;
@@ -137,8 +140,8 @@ __global__ __launch_bounds__(256) void kvsplit_to_f32_kernel(const _Float16* __r
             const int d0 = 32 * (s2 >> 1) + 16 * (s2 & 1) + 4 * kh;
             float4 a = {(float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]};
             float4 c4 = {(float)hi[4] + (float)lo[4], (float)hi[5] + (float)lo[5], (float)hi[6] + (float)lo[6], (float)hi[7] + (float)lo[7]};
-            *reinterpret_cast<float4*>(kp + (int64_t)n * 64 + d0) = a;
-            *reinterpret_cast<float4*>(kp + (int64_t)n * 64 + d0 + 8) = c4;
+            *reinterpret_cast<float4*>(kp + (int64_t)n * row + d0) = a;
+            *reinterpret_cast<float4*>(kp + (int64_t)n * row + d0 + 8) = c4;
         }
     }
     {   // V: thread -> (d, stored chunk position)
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void kvsplit_to_f32_kernel(const _Float16* __r
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int n = blk * 32 + 16 * m + 4 * kh + (e & 3) + 8 * (e >> 2);
-            if (n < N) vp[(int64_t)n * 64 + d] = (float)hi[e] + (float)lo[e];
+            if (n < N) vp[(int64_t)n * row + d] = (float)hi[e] + (float)lo[e];
         }
     }
 }
@@ -485,9 +488,10 @@ hipError_t launch_kvsplit_convert(const float* K, const float* V, int64_t k_batc
 }
 
 hipError_t launch_kvsplit_to_f32(const void* cache, int B, int H, int N, float* K, float* V, int64_t k_batch, int64_t k_head,
-                                 int64_t v_batch, int64_t v_head, hipStream_t s) {
+                                 int64_t v_batch, int64_t v_head, hipStream_t s, int chunks) {
+    if (chunks < 1 || H % chunks != 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(kvsplit_to_f32_kernel, dim3(ceil_div(N, kBlkKeys), B * H), dim3(256), 0, s, reinterpret_cast<const _Float16*>(cache),
-                       H, N, K, V, k_batch, k_head, v_batch, v_head);
+                       H, N, K, V, k_batch, k_head, v_batch, v_head, chunks);
     return hipGetLastError();
 }
 

@@ -247,7 +247,7 @@ class PARQDecoder(nn.Module):
     def _train_mode(self):
         """Attention arithmetic of the training entry points: the split-precision forward when the head dim allows it (the
         backward kernels then work on fp32 K / V rebuilt from the split cache), else the exact-fp32 kernels."""
-        return "split" if self.dim_in // self.num_heads == 64 and self.attention_mode != "fp32" else "fp32"
+        return "split" if self.dim_in // self.num_heads in (64, 256) and self.attention_mode != "fp32" else "fp32"
 
     def _handle_in_mode(self, mode):
         """The handle switched to `mode` without touching the user-facing ``attention_mode`` (the training entry points need

@@ -358,3 +358,33 @@ def test_backward_at_baseline_cfg3_size_batched_equals_per_iteration(monkeypatch
         worst = max(worst, (name, rel), key=lambda t: t[1])
         assert rel < 1e-4, (name, rel)
     print("\ncfg-3 size, batched vs per-iteration backward: worst relative difference %.2e (%s)" % (worst[1], worst[0]))
+
+
+def test_head_dim_256_training_split_forward_matches_fp32_path():
+    """Head dim 256 (the reference's shipped head size): the training forward on the split-precision kernels (virtual-head K/V cache,
+    fp32 K / V rebuilt from it for the materialised backward) against the exact-fp32 kernels: outputs 1e-4, gradients 1e-4 relative."""
+    B, V, h, w, Q, heads, dim, ffn, I = 1, 2, 24, 30, 48, 1, 256, 96, 2
+    cfg = synth.decoder_cfg(dim=dim, queries=Q, heads=heads, ffn=ffn, layers=I, dropout=0.0)
+    W = synth.make_decoder_weights(cfg, 371)
+    sc = synth.make_scene(372, B, V, h, w, dim, smooth=True)
+    ncls = cfg.NUM_SEMCLS + 1
+    cots = {"pred_logits": synth.normal(373, "cl", (I, B, Q, ncls)), "center_unnormalized": synth.normal(374, "cc", (I, B, Q, 3)),
+            "size_unnormalized": synth.normal(375, "cs", (I, B, Q, 3)), "ortho6d": synth.normal(376, "cr", (I, B, Q, 6))}
+    res = {}
+    for mode in ("split", "fp32"):
+        dec = make_decoder(cfg, W).train()
+        dec.attention_mode = mode
+        assert dec._train_mode() == mode
+        outs = dec.forward_train(*scene_args(sc))
+        grads, d_tok = dec.backward({k: torch.from_numpy(v) for k, v in cots.items()})
+        res[mode] = ([{k: o[k].cpu().numpy() for k in GKEYS} for o in outs], {k: v.double() for k, v in grads.items()}, d_tok.double())
+    for k in range(I):
+        for key in GKEYS:
+            a, b = res["split"][0][k][key], res["fp32"][0][k][key]
+            assert np.abs(a - b).max() / max(1.0, np.abs(b).max()) < 1e-4, (k, key)
+    for name, a in res["split"][1].items():
+        b = res["fp32"][1][name]
+        if float(b.norm()) == 0:
+            continue
+        assert float((a - b).norm()) / float(b.norm()) < 1e-4, name
+    assert float((res["split"][2] - res["fp32"][2]).norm()) / float(res["fp32"][2].norm()) < 1e-4
