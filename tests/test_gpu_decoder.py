@@ -129,6 +129,9 @@ def test_cfg2_reduced_precision_modes(mode, tol):
     (3, 1, 9, 7, 50, 2, 128, 96),          # single view, Q % 16 = 2, small dims (K = 96 is not a multiple of 64)
     (9, 2, 8, 8, 33, 4, 256, 768),         # M = 297 rows: 32x32 tiles (tiles32 >= CUs is not reached -> 16) with 9 scenes
     (1, 2, 6, 5, 7, 4, 256, 768),          # fewer queries than a tile
+    (2, 2, 23, 29, 40, 4, 1024, 768),      # the reference's shipped dims (head dim 256): N = 1334 = 5 token tiles + 54, 41 key blocks +
+                                           # 22 keys, two scenes: large-C projection kernel, wave-pair attention, masked last block
+    (1, 3, 9, 10, 150, 2, 512, 256),       # head dim 256 with two heads, Q = 150: a partly filled second query tile of 128
 ])
 def test_ragged_shapes_vs_fp64_oracle(B, V, h, w, Q, heads, dim, ffn):
     """Ragged query counts / scene counts / feature maps through the whole chain (tile tails of the small-GEMM,
