@@ -132,6 +132,8 @@ def test_cfg2_reduced_precision_modes(mode, tol):
     (2, 2, 23, 29, 40, 4, 1024, 768),      # the reference's shipped dims (head dim 256): N = 1334 = 5 token tiles + 54, 41 key blocks +
                                            # 22 keys, two scenes: large-C projection kernel, wave-pair attention, masked last block
     (1, 3, 9, 10, 150, 2, 512, 256),       # head dim 256 with two heads, Q = 150: a partly filled second query tile of 128
+    (3, 1, 7, 9, 300, 4, 1024, 768),       # three scenes of 63 tokens (< one token tile, 2 key blocks), Q = 300: three query tiles, the last
+                                           # with one inactive wave pair
 ])
 def test_ragged_shapes_vs_fp64_oracle(B, V, h, w, Q, heads, dim, ffn):
     """Ragged query counts / scene counts / feature maps through the whole chain (tile tails of the small-GEMM,
