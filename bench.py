@@ -8,13 +8,17 @@ metric  : decoder-iterations/sec = scenes x recurrent iterations / wall time of
 workload: BASELINE cfg 3 — 10 views of 480x640 images -> 120x160 feature maps (stride 4),
           256 queries, 8 iterations, d=256, 4 heads, FFN 768, fp32, synthetic features,
           random-init weights.  One "step" = one forward over the rank's batch of scenes.
-N > 1   : one process per GPU (torchrun), scenes sharded data-parallel (independent, no
-          data-path collective: SURVEY.md §8e); weak scaling, value = all ranks' iterations / max time.
+N > 1   : one process per GPU, scenes sharded data-parallel (independent, no data-path collective:
+          SURVEY.md §8e); weak scaling, value = all ranks' iterations / max time.  `python bench.py --gpus N`
+          works as typed: without a torchrun environment the parent starts N fresh ranks through
+          `python -m torch.distributed.run` BEFORE it touches the GPU, forwards rank 0's JSON line and
+          exits with the launcher's code; under torchrun (the driver's form) it is a rank.
 
 Also reported in the same JSON line:
-  roofline      dominant kernel (fp32-MFMA flash cross-attention): algorithmic FLOP per launch
+  roofline      dominant kernel (flash_split_kernel, the dense cross-attention): algorithmic FLOP per launch
                 (4*Q*N*C per scene) / mean launch time from hipEvents recorded by the library
                 on the launch stream during an instrumented repeat of the same K steps
+                (split mode: fp16 hi/lo 3-term products on the fp16 matrix pipe, fp32 accumulation)
   roofline_project_sample   HBM-bound gather: algorithmic bytes (4*V*Q*C + Q*C)*4 per scene
   cpu_baseline  the oracle in reference_ops mode (same ATen op sequence as the reference)
                 on the host cores, bounded sample (rank 0, N=1 only)
@@ -181,7 +185,7 @@ def train_bench(args):
         print(json.dumps({
             "metric": "training steps/sec (decoder forward + set loss + HIP backward + gradient all-reduce + AdamW)",
             "value": args.steps / dt, "unit": "steps/sec", "scenes_per_sec": args.steps * B * world / dt,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "rccl_ranks": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "final_loss": float(loss.detach()),
             "config": {"workload": "BASELINE cfg4 per-GPU shard: %d scenes, 10 views 480x640 (120x160 features), 256 queries, 8 iterations, "
@@ -190,6 +194,26 @@ def train_bench(args):
     if world > 1:
         parallel.barrier()
         torch.distributed.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` typed without a launcher: start N fresh ranks (one per GPU, RCCL rendezvous on
+    127.0.0.1) as CHILD processes of this one, which has not initialised the GPU (no HIP call, no torch.cuda query
+    besides device_count), and exit with the launcher's code.  Rank 0's JSON line is the child's stdout."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()                     # does not initialise the runtime on this image
+    if have < n:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (n, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -209,14 +233,15 @@ def main():
     WORKLOAD["dim"] = args.dim
     if args.dim != 256:
         args.no_cpu_baseline = True                     # the bounded CPU sample is sized for the headline configuration
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     if args.train:
         return train_bench(args)
 
     from parq_amd import parallel
     rank, local_rank, world = parallel.env_world()
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                         % (args.gpus, args.gpus))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -291,7 +316,7 @@ def main():
         out = {
             "metric": "decoder-iterations/sec (10 views, 256 queries, d=%d)%s" % (C, "" if C == 256 else " [not the BASELINE metric: non-default --dim]"),
             "value": total_iters / dt, "unit": "decoder-iterations/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": ("f32 (cross-attention and K/V projection as fp16 hi/lo split products with fp32 accumulation)" if split
                                           else "%s cross-attention and K/V projection operands, fp32 accumulation, fp32 elsewhere (reduced precision: not the headline configuration)" % mode if half

@@ -20,6 +20,8 @@ Cases:
   g6_shipped     shipped dims d=1024/H=4 (head dim 256), FFN 768, 2 views 15x20, Q=32, I=2
   g7_fp64        the g2 case run by the reference in float64
   g8_unshared    SHARE_WEIGHTS=False, 2 layers, d=128/H=2
+  g14_cfg3       BASELINE cfg 3 exactly (the benchmark's headline size): 10 views 120x160 feature maps
+                 (N = 192 000 tokens), Q=256, I=8, d=256, noise features — consumed teacher-forced
 """
 from __future__ import annotations
 
@@ -57,6 +59,8 @@ CASES = {
                     B=2, V=4, h=60, w=80, smooth=False, damped=False, double=True),
     "g8_unshared": dict(cfg=dict(dim=128, queries=32, heads=2, ffn=192, layers=2, share_weights=False),
                         wseed=18, sseed=108, B=1, V=2, h=12, w=16, smooth=False, damped=False),
+    "g14_cfg3": dict(cfg=dict(dim=256, queries=256, heads=4, ffn=768, layers=8), wseed=24, sseed=124,
+                     B=1, V=10, h=120, w=160, smooth=False, damped=False),
 }
 
 RAYPE_CASE = dict(dim=64, seed=15, sseed=105, B=1, V=2, h=6, w=8,

@@ -38,6 +38,16 @@ class PARQ(_Base):
                                    _get(tk, "MIN_DEPTH"), _get(tk, "MAX_DEPTH"))
         self.box3d_decoder = PARQDecoder(_get(cfg, "MODEL.DECODER"))
         self.for_vis = _get(cfg, "MODEL.DECODER.FOR_VIS")
+        self.synced_metrics = {}          # validation metrics averaged over the ranks (what the reference logs with sync_dist=True)
+
+    def set_data_parallel(self, on=True):
+        """One process per GPU, scenes sharded (train.py:103-108 runs DDP): with ``on`` every trainable tensor of the module —
+        the decoder's flat gradient arena and the ray-PE encoder's four tensors — is averaged over the default process group
+        (RCCL over xGMI) inside the two backward nodes, i.e. two collectives per step instead of DDP's per-tensor buckets.
+        Do not wrap the module in DistributedDataParallel as well."""
+        self.box3d_decoder.dp_all_reduce = bool(on)
+        self.add_ray_pe.dp_all_reduce = bool(on)
+        return self
 
     def forward(self, batch, batch_idx=0):
         if self.backbone2d is not None:
@@ -67,8 +77,17 @@ class PARQ(_Base):
         self.box3d_decoder.reset_metrics()
 
     def validation_epoch_end(self, outs=None):
-        """model/parq_lightning.py:118-142: {"0.25_f1", ...}; `eval.py` calls this directly and prints the result."""
-        return self.box3d_decoder.compute_metrics()
+        """model/parq_lightning.py:118-142: {"0.25_f1", ...}; `eval.py` calls this directly and prints the result.  As in the
+        reference the RETURNED dict is this rank's own; the scalars it logs with ``sync_dist=True`` (:133-140: mean over the
+        ranks) are kept in ``self.synced_metrics`` and, under Lightning, logged the same way."""
+        from .parallel import all_reduce_mean_scalars
+        metrics = self.box3d_decoder.compute_metrics()
+        self.synced_metrics = all_reduce_mean_scalars(metrics)
+        if _Base is not nn.Module:                        # pragma: no cover - Lightning is absent on the target image
+            for key, value in metrics.items():
+                if isinstance(value, (int, float)):
+                    self.log("val/metrics/{}".format(key), value, on_epoch=True, logger=True, sync_dist=True, rank_zero_only=False)
+        return metrics
 
     def test_step(self, batch, batch_idx=0):
         return self.forward(batch, batch_idx)

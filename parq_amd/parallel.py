@@ -81,3 +81,23 @@ def all_reduce_mean_(flat: torch.Tensor) -> torch.Tensor:
         torch.distributed.all_reduce(flat)
         flat /= torch.distributed.get_world_size()
     return flat
+
+
+def all_reduce_mean_scalars(metrics: dict, device=None) -> dict:
+    """Mean over ranks of a dict of host scalars — what Lightning's ``self.log(..., sync_dist=True)`` does with the
+    validation metrics (model/parq_lightning.py:133-140).  Non-scalar entries (arrays, images) pass through untouched, as
+    the reference skips them; every rank must call this with the same keys.  Identity without a process group."""
+    import numbers
+    keys = sorted(k for k, v in metrics.items() if isinstance(v, numbers.Number) and not isinstance(v, bool))
+    if not keys or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return dict(metrics)
+    if device is None:
+        device = (torch.device("cuda", torch.cuda.current_device())
+                  if dist.get_backend() == "nccl" and torch.cuda.is_available() else "cpu")
+    t = torch.tensor([float(metrics[k]) for k in keys], dtype=torch.float64, device=device)
+    dist.all_reduce(t)
+    t /= dist.get_world_size()
+    out = dict(metrics)
+    for k, v in zip(keys, t.tolist()):
+        out[k] = v
+    return out

@@ -40,14 +40,20 @@ class _RayPeFn(torch.autograd.Function):
         g = g_tokens.to(dtype=torch.float32).contiguous()
         nbytes = lib.parq_ray_pe_backward_workspace_bytes(B, V, h, w, Cd, S)
         bws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=dev)
-        dw1 = torch.empty(Cd, 3 * S, device=dev); db1 = torch.empty(Cd, device=dev)
-        dw2 = torch.empty(Cd, Cd, device=dev); db2 = torch.empty(Cd, device=dev)
+        # the four parameter gradients live in ONE flat buffer, so data-parallel training averages them with a single
+        # collective (train.py:103: DDP reduces every trainable parameter of the module, the encoder MLP included)
+        sizes = (Cd * 3 * S, Cd, Cd * Cd, Cd)
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        dw1, db1, dw2, db2 = (t.view(shape) for t, shape in zip(flat.split(sizes), ((Cd, 3 * S), (Cd,), (Cd, Cd), (Cd,))))
         dfeat = torch.empty(B, V, Cd, h, w, device=dev) if ctx.want_feat else None
         w2 = mod.encoder[2].weight.detach().to(device=dev, dtype=torch.float32).contiguous()
         _lib.check(lib.parq_ray_pe_backward(_lib.ptr(cam), _lib.ptr(T_cp), _lib.ptr(T_wp), _lib.ptr(T_wl), _lib.ptr(w2),
                                             (C.c_float * 6)(*mod.ray_points_scale), mod.min_depth, mod.max_depth, S, B, V, h, w, Cd,
                                             _lib.ptr(g), _lib.ptr(mod._ws), _lib.ptr(bws), bws.numel() * 4, _lib.ptr(dw1), _lib.ptr(db1),
                                             _lib.ptr(dw2), _lib.ptr(db2), _lib.ptr(dfeat), _lib.stream_ptr()), "parq_ray_pe_backward")
+        if mod.dp_all_reduce:
+            from .parallel import all_reduce_mean_
+            all_reduce_mean_(flat)
         return None, dfeat, None, None, None, None, dw1, db1, dw2, db2
 
 
@@ -62,6 +68,8 @@ class AddRayPE(nn.Module):
         self.max_depth = float(max_depth)
         self.encoder = nn.Sequential(nn.Linear(3 * num_samples, dim_out), nn.ReLU(), nn.Linear(dim_out, dim_out))
         self._ws = None
+        self._gen = 0                     # forward counter: the backward of an autograd node checks it still owns the workspace
+        self.dp_all_reduce = False        # True: the backward all-reduces (mean) the encoder gradients over the default process group
 
     def _run(self, camera, T_cp, T_wp, T_wl, feat_hw, features, nchw=False):
         cam, T_cp, T_wp, T_wl = (raw(x) for x in (camera, T_cp, T_wp, T_wl))

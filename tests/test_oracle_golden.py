@@ -32,6 +32,15 @@ def test_oracle_teacher_forced(name, reference_ops):
         G.compare(o, z, k, tol=2e-5, what=name)
 
 
+def test_oracle_teacher_forced_baseline_cfg3_size():
+    """The headline size (BASELINE cfg 3: 10 views 120x160, N = 192 000 tokens, Q = 256, 8 iterations): the hoisted oracle
+    against the golden captured from the reference at exactly that configuration."""
+    z, outs = _run("g14_cfg3", False, forced=True)
+    assert len(outs) == 8
+    for k, o in enumerate(outs):
+        G.compare(o, z, k, tol=2e-5, what="g14_cfg3")
+
+
 def test_oracle_free_running_damped():
     # damped fixture: fp32 self-noise of the reference stays below 1e-4 over 8 iterations
     z, outs = _run("g3_damped", False, forced=False)
