@@ -100,6 +100,8 @@ struct parq_ctx {
     int vheads() const { return C / 64; }            // heads of the cache layout
     int terms() const { return attn_mode == 1 ? 3 : 1; }
     int kind() const { return attn_mode == 3 ? kBF16 : kF16; }
+    bool bwd_batched_env = true;      // PARQ_BWD_BATCHED != 0, sampled by parq_create (the parity test makes one handle per setting)
+    float dim_t_host[128];            // 10000^(2*(i//2)/128): uploaded by parq_pack_weights from this persistent buffer (no stream sync)
     bool profiling = false;
     std::vector<ProfEvent> events;
     double prof_ms[PARQ_PROF_COUNT] = {0};
@@ -137,17 +139,16 @@ void build_arena(parq_ctx* c) {
 }
 
 bool kvproj_big_on() {
-    const char* e = getenv("PARQ_KVPROJ_BIG");           // 0: keep the tiled kernel at C > 256 (A/B)
-    return !(e && e[0] == '0');
+    static const bool on = [] { const char* e = getenv("PARQ_KVPROJ_BIG"); return !(e && e[0] == '0'); }();   // 0: keep the tiled kernel at C > 256 (A/B)
+    return on;
 }
 
 // Training: the cross-attention backward of all recurrent iterations can run as ONE launch when the iterations share the layer
 // weights (hence K / V) and the split-precision kernel applies (head dim 64, long key axis); PARQ_BWD_BATCHED=0 restores the
 // per-iteration launches.
 bool bwd_batched_ok(const parq_ctx* c, int64_t N) {
-    const char* e = getenv("PARQ_BWD_BATCHED");          // read per call: the parity test compares both paths in one process
-    const int env = e ? atoi(e) : 1;
-    return env != 0 && c->nl == 1 && c->dh == 64 && N >= 2048 && c->I > 1 && c->I <= 16;
+    // c->bwd_batched_env is read from PARQ_BWD_BATCHED when the handle is created (not on the launch path)
+    return c->bwd_batched_env && c->nl == 1 && c->dh == 64 && N >= 2048 && c->I > 1 && c->I <= 16;
 }
 
 int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws) {
@@ -741,7 +742,7 @@ int check_outs(const parq_outputs* o) {
 extern "C" {
 
 const char* parq_last_error(void) { return g_err; }
-const char* parq_version(void) { return "parq_hip 0.1 (gfx950, fp32 MFMA)"; }
+const char* parq_version(void) { return "parq_hip 0.2 (gfx950; cross-attention: fp16 hi/lo split MFMA products by default, exact fp32 MFMA on request)"; }
 
 int parq_create(const parq_config* cfg, parq_handle* out) {
     if (!cfg || !out) return fail(PARQ_ERR_ARG, "NULL argument");
@@ -762,6 +763,9 @@ int parq_create(const parq_config* cfg, parq_handle* out) {
     c->nl = cfg->share_weights ? 1 : cfg->num_layers;
     c->NH1 = 2 * c->C + ((c->ncls + 3 + 3) / 4) * 4;
     for (int i = 0; i < 3; ++i) { c->sb.lo[i] = cfg->scale[2 * i]; c->sb.hi[i] = cfg->scale[2 * i + 1]; }
+    if (const char* e = getenv("PARQ_BWD_BATCHED")) c->bwd_batched_env = atoi(e) != 0;
+    // dim_t[i] = 10000^(2*(i//2)/128) in float32 (transformer_parq.py:49-50)
+    for (int i = 0; i < 128; ++i) c->dim_t_host[i] = powf(10000.0f, 2.0f * (float)(i / 2) / 128.0f);
     build_arena(c);
     *out = c;
     return PARQ_OK;
@@ -846,12 +850,8 @@ int parq_pack_weights(parq_handle h, void* arena_v, size_t arena_bytes, parq_str
         !copy(hc + "8.bias", ar.heads3_b, 3) || !copy(hr + "8.bias", ar.heads3_b + 6, 6) ||
         !copy("mean_sizes", ar.mean_sizes, (int64_t)c->cfg.num_mean_sizes * 3))
         return rc;
-    // dim_t[i] = 10000^(2*(i//2)/128) in float32 (transformer_parq.py:49-50)
-    float dim_t[128];
-    for (int i = 0; i < 128; ++i) dim_t[i] = powf(10000.0f, 2.0f * (float)(i / 2) / 128.0f);
-    // small host table: stage it through a pageable copy (synchronous w.r.t. the host buffer)
-    HIPCHK(hipMemcpyAsync(A + ar.dim_t, dim_t, sizeof(dim_t), hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));   // dim_t lives on this stack frame
+    // small host table kept in the handle, so the copy needs no synchronisation with the stream
+    HIPCHK(hipMemcpyAsync(A + ar.dim_t, c->dim_t_host, sizeof(c->dim_t_host), hipMemcpyHostToDevice, s));
     c->arena = A;
     c->packed = true;
     c->prepared = false;

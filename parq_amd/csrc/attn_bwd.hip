@@ -1021,12 +1021,9 @@ static hipError_t attn_bwd_materialised(const AttnBwdArgs& a, int dh, float* scr
 
 constexpr size_t kSplitBwdLds = (size_t)(8 * 2048 + 2 * 8192 + 2 * 16384) * sizeof(_Float16) + 96 * sizeof(float);
 static hipError_t split_bwd_lds_attr() {
-    static bool done = false;
-    if (done) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitBwdLds);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitBwdLds);
-    if (e == hipSuccess) done = true;
+    static DynLdsOnce once_a, once_b;
+    hipError_t e = once_a.ensure(reinterpret_cast<const void*>(&attn_bwd_split_kernel<false>), kSplitBwdLds);
+    if (e == hipSuccess) e = once_b.ensure(reinterpret_cast<const void*>(&attn_bwd_split_kernel<true>), kSplitBwdLds);
     return e;
 }
 
@@ -1087,15 +1084,10 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
         const int nwv = big ? 8 : 2;
         const int KW = nwv * 32;
         const size_t lds = (size_t)(2 * 32 * kQs + 64 + 32 * (KW + 4) + KW * kKc) * sizeof(float);
-        static bool attr8 = false, attr2 = false;
-        bool& attr = big ? attr8 : attr2;
-        if (!attr) {
-            hipError_t e = hipFuncSetAttribute(big ? reinterpret_cast<const void*>(&attn_bwd_mfma_kernel<8>)
-                                                   : reinterpret_cast<const void*>(&attn_bwd_mfma_kernel<2>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr = true;
-        }
+        static DynLdsOnce once8, once2;
+        if (hipError_t e = (big ? once8 : once2).ensure(big ? reinterpret_cast<const void*>(&attn_bwd_mfma_kernel<8>)
+                                                             : reinterpret_cast<const void*>(&attn_bwd_mfma_kernel<2>), lds);
+            e != hipSuccess) return e;
         dim3 g2(ceil_div(Lk, KW), B * H);
         a.gq_part = big ? gq_part : nullptr;
         if (big) hipLaunchKernelGGL(attn_bwd_mfma_kernel<8>, g2, dim3(512), lds, s, a);
@@ -1109,23 +1101,13 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
     }
     if (dh == 64) {
         const size_t lds = (size_t)(2 * 32 * 64 + 32 * 257 + 256 * 65 + 64) * sizeof(float);
-        static bool attr = false;
-        if (!attr) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<64>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr = true;
-        }
+        static DynLdsOnce once;
+        if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&attn_bwd_kernel<64>), lds); e != hipSuccess) return e;
         hipLaunchKernelGGL(attn_bwd_kernel<64>, grid, dim3(256), lds, s, a);
     } else {
         const size_t lds = (size_t)(2 * 32 * 32 + 32 * 257 + 256 * 33 + 64) * sizeof(float);
-        static bool attr = false;
-        if (!attr) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<32>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr = true;
-        }
+        static DynLdsOnce once;
+        if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&attn_bwd_kernel<32>), lds); e != hipSuccess) return e;
         hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, dim3(256), lds, s, a);
     }
     return hipGetLastError();

@@ -1,5 +1,5 @@
 // Shared declarations of the gfx950 kernel chain behind libparq_hip.so.
-// Everything here targets CDNA4 (wave64, MFMA f32 32x32x2) directly.
+// Everything here targets CDNA4 (wave64; v_mfma_f32_32x32x16_f16 split products and fp32 MFMA) directly.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -13,6 +13,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kWave = 64;
 constexpr int kGnSlots = 64;    // GroupNorm moment accumulators per (scene, group): spreads the fp64 atomics
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: a process that drives several GPUs must set
+// it on each of them.  One static instance per kernel; bit d of `done` = already set on device ordinal d.
+struct DynLdsOnce {
+    unsigned long long done = 0;
+    hipError_t ensure(const void* fn, size_t bytes) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const bool track = dev >= 0 && dev < 64;
+        if (track && ((done >> dev) & 1ull)) return hipSuccess;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess && track) done |= 1ull << dev;
+        return e;
+    }
+};
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -65,9 +81,13 @@ __host__ __device__ inline uint32_t rng_stream(uint32_t base, uint32_t stream) {
 // part of the hash is computed once per row (per lane in the forward attention kernels, per query tile in the backward ones),
 // the column part once per column where a kernel can share it (below).
 __host__ __device__ inline uint32_t drop_rowhash(uint32_t seed, uint32_t row) { return rng_mix(seed ^ (row * 0x9e3779b1U)); }
-// keep(row, col) = ((rowhash(seed, row) ^ colhash(col)) >> 8) >= ceil(p * 2^24)  (evaluated as one 32-bit compare): the column part does not depend on the seed, so
+// keep(row, col) = mix(rowhash(seed, row) ^ colhash(col)) >= ceil(p * 2^24) * 256: the column part does not depend on the seed, so
 // the attention kernels hash a key ONCE (per stage in the forward, per lane in the backward, where a lane owns a key) and spend
-// one xor + compare per element; entries are uniform and pairwise independent (xor of two independently mixed words).
+// xor + multiply + shift-xor + compare per element.  The final mix matters: comparing the bare xor against a threshold makes the
+// dropped set of a row the preimage of `rowhash ^ [0, thr)`, whose large dyadic sub-blocks depend only on the top bits of the
+// row hash — 1/16 of all row pairs then share >60 % of their dropped columns at p = 0.1 (a 4-wise xor dependence that uniformity
+// and pairwise independence do not show).  A multiply by an odd constant + shift-xor after the xor breaks that linearity
+// (tests/test_gpu_kernels.py::test_dropout_masks_of_row_pairs_overlap_like_independent_draws).
 __host__ __device__ inline uint32_t drop_colhash(uint32_t col) { return rng_mix(col * 0x85ebca77U + 0x6a09e667U); }
 // threshold in the scale of the full 32-bit hash: (h >> 8) >= ceil(p 2^24)  <=>  h >= ceil(p 2^24) * 256 (saturated: p ~ 1 keeps nothing
 // but h = 2^32 - 1)
@@ -75,7 +95,11 @@ __host__ __device__ inline uint32_t drop_threshold(float p) {
     const float t = ceilf(p * 16777216.0f);
     return t >= 16777216.0f ? 0xffffffffU : ((uint32_t)t << 8);
 }
-__host__ __device__ inline bool drop_keep_h(uint32_t rowhash, uint32_t colhash, uint32_t thr) { return (rowhash ^ colhash) >= thr; }
+__host__ __device__ inline bool drop_keep_h(uint32_t rowhash, uint32_t colhash, uint32_t thr) {
+    uint32_t h = (rowhash ^ colhash) * 0x9E3779B1U;
+    h ^= h >> 15;
+    return h >= thr;
+}
 __host__ __device__ inline bool drop_keep(uint32_t rowhash, uint32_t col, float p) {
     return drop_keep_h(rowhash, drop_colhash(col), drop_threshold(p));
 }

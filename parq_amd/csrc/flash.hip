@@ -475,14 +475,9 @@ __global__ __launch_bounds__(512) void self_attn_kernel(const float* __restrict_
 
 template <int DH, int NW>
 hipError_t launch_one(const FlashArgs& a, hipStream_t s) {
-    static bool attr_set = false;
+    static DynLdsOnce once;
     const size_t lds = Tile<DH>::lds_bytes();
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_f32_kernel<DH, NW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_f32_kernel<DH, NW>), lds); e != hipSuccess) return e;
     dim3 grid(a.nsplit, ceil_div(a.Lq, 32 * NW), a.B * a.H);
     hipLaunchKernelGGL((flash_f32_kernel<DH, NW>), grid, dim3(NW * 64), lds, s, a);
     return hipGetLastError();
@@ -504,13 +499,8 @@ hipError_t launch_dh(const FlashArgs& a, int nw, hipStream_t s) {
 template <int DH>
 hipError_t merge_dh(const FlashArgs& a, hipStream_t s) {
     const size_t lds = ((size_t)a.nsplit * 32 + 8 * 32 + (size_t)2 * kMergeDG * 32) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_merge_kernel<DH>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DynLdsOnce once;
+    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_merge_kernel<DH>), 96 * 1024); e != hipSuccess) return e;
     dim3 grid(ceil_div(a.Lq, 32), a.B * a.H, DH / kMergeDG);
     hipLaunchKernelGGL((flash_merge_kernel<DH>), grid, dim3(256), lds, s, a);
     return hipGetLastError();

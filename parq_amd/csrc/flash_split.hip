@@ -497,14 +497,9 @@ hipError_t launch_kvsplit_to_f32(const void* cache, int B, int H, int N, float* 
 
 template <int TERMS, int KIND, bool DROP = false>
 static hipError_t launch_flash_t(const FlashArgs& b, const void* cache, hipStream_t s) {
-    static bool attr_set = false;
+    static DynLdsOnce once;
     const size_t lds = (size_t)kRing * kStageBlks * Blk<TERMS>::bytes + (DROP ? kNW * 64 * sizeof(uint32_t) : 0);
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_split_kernel<TERMS, KIND, DROP>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_split_kernel<TERMS, KIND, DROP>), lds); e != hipSuccess) return e;
     dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * b.H);
     hipLaunchKernelGGL((flash_split_kernel<TERMS, KIND, DROP>), grid, dim3(kNW * 64), lds, s, b, reinterpret_cast<const _Float16*>(cache));
     return hipGetLastError();
@@ -513,8 +508,8 @@ static hipError_t launch_flash_t(const FlashArgs& b, const void* cache, hipStrea
 hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t s, int terms, int kind) {
     if (a.dh != kDH || a.nsplit < 1 || a.nsplit > 256) return hipErrorInvalidValue;
     FlashArgs b = a;
-    b.defer_log2 = kDeferLog2;
-    if (const char* e = getenv("PARQ_DEFER_LOG2")) b.defer_log2 = (float)atof(e);      // debugging knob
+    static const float defer = [] { const char* e = getenv("PARQ_DEFER_LOG2"); return e ? (float)atof(e) : kDeferLog2; }();   // debugging knob, read once
+    b.defer_log2 = defer;
     if (terms == 3) return b.drop_p > 0.f ? launch_flash_t<3, kF16, true>(b, cache, s) : launch_flash_t<3, kF16>(b, cache, s);
     if (b.drop_p > 0.f) return hipErrorInvalidValue;           // dropout exists on the fp32-accurate paths only
     return kind == kF16 ? launch_flash_t<1, kF16>(b, cache, s) : launch_flash_t<1, kBF16>(b, cache, s);

@@ -225,14 +225,9 @@ int flash_split256_pick_splits(int B, int H, int Lq, int Lk, int num_cus) {
 // partial (O, m, l) of every (scene-head, key split) in the layout flash_merge_kernel<256> combines; cache: virtual-head split cache
 hipError_t launch_flash_split256(const FlashArgs& a, const void* cache, hipStream_t s) {
     if (a.dh != kDH || a.nsplit < 1 || a.nsplit > 256 || a.drop_p > 0.f) return hipErrorInvalidValue;
-    static bool attr_set = false;
+    static DynLdsOnce once;
     const size_t lds = (size_t)4 * kGrpHalfs * sizeof(_Float16) + (size_t)kNW * 16 * 64 * sizeof(float);       // 160 KB
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_split256_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_split256_kernel), lds); e != hipSuccess) return e;
     dim3 grid(a.nsplit, ceil_div(a.Lq, 128), a.B * a.H);
     hipLaunchKernelGGL(flash_split256_kernel, grid, dim3(kNW * 64), lds, s, a, reinterpret_cast<const _Float16*>(cache));
     return hipGetLastError();

@@ -220,14 +220,9 @@ size_t kvproj_big_scratch_floats(int B, int N, int C) {
 hipError_t launch_kvproj_big(const float* tokens, const void* Whi, const void* Wlo, const float* bias, int B, int N, int C,
                              void* cache, int* overflow, float* scratch, hipStream_t s) {
     if (!kvproj_big_scratch_floats(B, N, C) || !scratch || B > 65535) return hipErrorInvalidValue;
-    static bool attr = false;
+    static DynLdsOnce once;
     const size_t ldsb = (size_t)2 * kStage * sizeof(_Float16);              // 128 KB
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kvproj_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)ldsb);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&kvproj_big_kernel), ldsb); e != hipSuccess) return e;
     const int64_t n = (int64_t)B * N * C;
     _Float16* xhi = reinterpret_cast<_Float16*>(scratch);
     _Float16* xlo = xhi + n;

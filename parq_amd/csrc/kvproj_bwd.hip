@@ -176,14 +176,9 @@ bool kvproj_bwd_split_supported(int C) { return C == kCols; }
 hipError_t launch_kvproj_bwd_split(const float* g, const float* tokens, int64_t M, int C, float* dW, float* db,
                                    const unsigned int* absmax_bits, float* scale_scratch, hipStream_t s) {
     if (C != kCols || M < 1 || M > (int64_t)INT32_MAX) return hipErrorInvalidValue;
-    static bool attr = false;
+    static DynLdsOnce once;
     const size_t ldsb = (size_t)2 * kBufHalfs * sizeof(_Float16);          // 128 KB
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kvproj_bwd_split_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&kvproj_bwd_split_kernel), ldsb); e != hipSuccess) return e;
     hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, s, absmax_bits, scale_scratch);
     KvBwdArgs a;
     a.g = g; a.ldg = 2 * C; a.x = tokens; a.ldx = C; a.dW = dW; a.ldw = C; a.db = db; a.scale = scale_scratch; a.M = (int)M;

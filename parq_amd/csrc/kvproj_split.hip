@@ -495,14 +495,9 @@ __global__ void cvt16_kernel(const float* __restrict__ src, _Float16* __restrict
 
 template <int NWV, int TM, int TERMS, int KIND>
 static hipError_t launch_ws(const KvProjArgs& a, int B, hipStream_t s) {
-    static bool attr = false;
+    static DynLdsOnce once;
     const size_t lds = (size_t)2 * 2 * TM * kBK * sizeof(_Float16);
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kvproj_ws_kernel<NWV, TM, TERMS, KIND>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&kvproj_ws_kernel<NWV, TM, TERMS, KIND>), lds); e != hipSuccess) return e;
     const int nslice = 2 * a.C / (NWV * 32), nrt = ceil_div(a.N, TM);
     const int total_rt = B * nrt;
     int P = device_num_cus() / nslice;
@@ -532,14 +527,9 @@ hipError_t launch_split_f32(const float* src, void* hi, void* lo, int64_t n, hip
 hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void* Wlo, const float* bias, int B, int N,
                                int C, int H, void* cache, int* overflow, hipStream_t s, int terms, int kind) {
     if (C % kBK != 0 || C != H * 64 || (2 * C) % kBN != 0) return hipErrorInvalidValue;
-    static bool attr_set = false;
+    static DynLdsOnce once;
     const size_t ldsb = (size_t)(2 * kBM * kBK + 2 * kBN * kBK) * sizeof(_Float16);      // 64 KB
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kvproj_split_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&kvproj_split_kernel), ldsb); e != hipSuccess) return e;
     KvProjArgs a;
     a.X = tokens; a.Whi = reinterpret_cast<const _Float16*>(Whi); a.Wlo = reinterpret_cast<const _Float16*>(Wlo);
     a.bias = bias; a.cache = reinterpret_cast<_Float16*>(cache); a.overflow = overflow; a.N = N; a.C = C; a.H = H;

@@ -615,18 +615,11 @@ hipError_t launch_raype_fused(const float* cam, const float* T_cp, const float* 
     const int S = 64;
     const int64_t M64 = (int64_t)B * V * h * w;
     if (M64 > 0x7fffffffLL) return hipErrorInvalidValue;
-    static bool attr = false;
+    static DynLdsOnce once_a, once_b;
     const size_t lds_a = (size_t)2 * 3 * 2 * kFTM * 64 * sizeof(_Float16);      // 96 KB
     const size_t lds_b = (size_t)kFTM * kOtLd * sizeof(float) + (size_t)kFC * 64 * sizeof(float);   // 66.5 KB (overlays the 32 KB operand buffers) + 64 KB feature tile
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&raype_hidden_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&raype_tokens_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    if (hipError_t e = once_a.ensure(reinterpret_cast<const void*>(&raype_hidden_kernel), lds_a); e != hipSuccess) return e;
+    if (hipError_t e = once_b.ensure(reinterpret_cast<const void*>(&raype_tokens_kernel), lds_b); e != hipSuccess) return e;
     hipLaunchKernelGGL(raype_pose_kernel, dim3(ceil_div(B * V, 64)), dim3(64), 0, s, T_cp, T_wp, T_wl, B, V, min_depth, max_depth,
                        S, Tl, depth);
     RayFusedArgs a;
@@ -652,14 +645,9 @@ hipError_t launch_raype_fused(const float* cam, const float* T_cp, const float* 
 hipError_t launch_gemm_split(const float* X, int64_t ldx, const void* Whi, const void* Wlo, const float* bias, float* Y,
                              int64_t ldy, int M, int N, int K, int relu, const float* feat, int hw, hipStream_t s) {
     if (K % kBK != 0 || M < 1 || N < 1 || (relu && feat)) return hipErrorInvalidValue;
-    static bool attr_set = false;
+    static DynLdsOnce once;
     const size_t ldsb = 4 * 64 * 65 * sizeof(float);                    // 66560 B >= the 64 KB of operand staging
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&gemm_split_kernel), ldsb); e != hipSuccess) return e;
     GemmArgs a;
     a.X = X; a.ldx = ldx; a.Whi = reinterpret_cast<const _Float16*>(Whi); a.Wlo = reinterpret_cast<const _Float16*>(Wlo);
     a.bias = bias; a.Y = Y; a.ldy = ldy; a.M = M; a.N = N; a.K = K; a.relu = relu; a.feat = feat; a.hw = hw;

@@ -7,10 +7,15 @@ drivers (eval.py:26-47) can swap the import.  All arithmetic of the forward pass
 libparq_hip.so (include/parq_hip.h); this file only owns parameters, buffers and the
 packing of arguments.  There is no PyTorch/CPU fallback for the compute.
 
-Scope: the inference forward (rows a-e) and, as first versions of the "next" rows, training: in
-``train()`` mode under autograd the forward is one autograd node whose backward is the HIP backward chain
-(``parq_backward``; DROPOUT_RATE must be 0), and ``loss`` mirrors the reference's set loss.  Eval metrics
-(``update_metrics`` etc., §8f-4) raise NotImplementedError.
+Scope: the inference forward (rows a-e) and the "next" rows: in ``train()`` mode under autograd the
+forward is one autograd node whose backward is the HIP backward chain (``parq_backward``; the decoder layer's dropout,
+DROPOUT_RATE, is applied with counter-based masks), ``loss`` mirrors the reference's set loss, ``parse_pred`` runs on the
+device and ``update_metrics`` / ``compute_metrics`` / ``reset_metrics`` drive the scene-level F1 trackers (§8f-4).
+
+Weights are packed into one device arena the first time they are used and again whenever a parameter changes.  Changes
+are detected from ``(data_ptr, _version)`` of every parameter, which optimizers and ``load_state_dict`` bump; writes that
+bypass autograd's version counter (``p.data.copy_()``, ``p.data.mul_()``, EMA / SWA swaps through ``.data``) are invisible
+to it: call ``invalidate_weights()`` after such an update.
 """
 from __future__ import annotations
 
@@ -150,6 +155,7 @@ class _TrainFn(torch.autograd.Function):
         outs = dec.forward_train(tokens, camera, T_cp, T_wp, T_wl, feat_hw=feat_hw)
         stacked = dec._train_state[2]                       # six (I, B, Q, k) tensors
         ctx.dec = dec
+        ctx.gen = dec._train_gen                            # this node owns the stash only until the next training forward
         ctx.want_tokens = bool(tokens.requires_grad)
         ctx.mark_non_differentiable(stacked[4], stacked[5])  # sem_cls_prob / coord_pos carry no gradient (transformer_parq.py:261-265)
         del outs
@@ -158,6 +164,11 @@ class _TrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_logits, g_center, g_size, g_rot, _g_prob, _g_coord):
         dec = ctx.dec
+        if dec._train_gen != ctx.gen:
+            raise RuntimeError("parq_amd.PARQDecoder: backward of a training forward whose saved activations were overwritten by a "
+                               "later training forward of the same module (the stash, dropout seed and outputs live on the module: one "
+                               "outstanding forward per module).  Run backward before the next forward, e.g. accumulate "
+                               "loss(dec(a)).backward(); loss(dec(b)).backward() instead of (loss(dec(a)) + loss(dec(b))).backward()")
         grads, d_tokens = dec.backward({"pred_logits": g_logits, "center_unnormalized": g_center, "size_unnormalized": g_size,
                                         "ortho6d": g_rot}, want_token_grad=ctx.want_tokens)
         per_param = []
@@ -219,6 +230,8 @@ class PARQDecoder(nn.Module):
         self._ws = {}
         self._matcher = None
         self._train_ws = None
+        self._train_state = None
+        self._train_gen = 0               # bumped by every forward_train: an autograd node checks it still owns the stash
         self.loss_batched = True          # loss(): all (iteration, scene) pairs in ~40 launches (False: the reference's per-pair loop)
         self.dp_all_reduce = False        # True: backward() all-reduces the flat gradient arena over the default process group
         self._mean_dev = None
@@ -273,6 +286,12 @@ class PARQDecoder(nn.Module):
                 seen.add(id(p))
                 out.append((name, p))
         return out
+
+    def invalidate_weights(self):
+        """Force a re-pack of the weight arena at the next call.  Needed only after parameter writes that bypass the version
+        counter (``p.data.copy_()`` / ``.data.mul_()`` / EMA or SWA swaps through ``.data``); optimizer steps, ``load_state_dict``
+        and in-place ops on the parameters themselves are detected automatically."""
+        self._arena_key = None
 
     def _ensure_packed(self, device):
         params = self._unique_params()
@@ -361,9 +380,11 @@ class PARQDecoder(nn.Module):
             return self._forward_inference(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
 
     def _forward_autograd(self, tokens, camera, T_cp, T_wp, T_wl, feat_hw):
-        """Train-mode forward under autograd: one autograd node whose backward is the HIP backward chain.  Uses the exact
-        fp32 attention kernels for this call (``attention_mode`` keeps governing inference).  DROPOUT_RATE > 0 applies the
-        decoder layer's six dropout sites with counter-based masks (seeded from torch's generator per call)."""
+        """Train-mode forward under autograd: one autograd node whose backward is the HIP backward chain.  Attention
+        arithmetic = ``_train_mode()``: the split-precision kernels where the head dim has them (64 / 256) unless
+        ``attention_mode == "fp32"``, else the exact fp32 MFMA kernels.  DROPOUT_RATE > 0 applies the decoder layer's six
+        dropout sites with counter-based masks (seeded from torch's generator per call).  One outstanding forward per
+        module: the node raises in backward if a later training forward has replaced its stash."""
         params = [p for _, p in self._unique_params()]
         stacked = _TrainFn.apply(self, raw(tokens), camera, T_cp, T_wp, T_wl, feat_hw, *params)
         return [{k: t[i] for k, t in zip(OUTPUT_KEYS, stacked)} for i in range(self.num_layers)]
@@ -383,9 +404,8 @@ class PARQDecoder(nn.Module):
     # ------------------------------------------------------------------ training
     @torch.no_grad()
     def forward_train(self, intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw=None):
-        """Forward that keeps every iteration's activations for ``backward`` (exact-fp32 attention kernels; dropout when
-        the module is in train mode).
-        Returns the same list of dicts as ``forward``."""
+        """Forward that keeps every iteration's activations for ``backward`` (attention arithmetic: ``_train_mode()``;
+        dropout when the module is in train mode).  Returns the same list of dicts as ``forward``."""
         sc, keep, dev = self._scene(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
         self._ensure_packed(dev)
         lib, h = _lib.load(), self._handle_in_mode(self._train_mode())
@@ -402,6 +422,7 @@ class PARQDecoder(nn.Module):
         _lib.check(lib.parq_forward_train(h, C.byref(sc), _lib.ptr(self._train_ws), self._train_ws.numel() * 4, C.byref(po),
                                           _lib.stream_ptr()), "parq_forward_train")
         self._train_state = (sc, keep, outs, po, dev)
+        self._train_gen += 1
         return [{k: t[i] for k, t in zip(OUTPUT_KEYS, outs)} for i in range(self.num_layers)]
 
     @torch.no_grad()
@@ -409,6 +430,8 @@ class PARQDecoder(nn.Module):
         """Backward of the last ``forward_train``.  ``grad_outputs``: dict with any of pred_logits / center_unnormalized /
         size_unnormalized / ortho6d -> (I, B, Q, k) cotangents (missing = zero).  Returns ({reference tensor name:
         gradient}, d_tokens or None); gradients of tensors registered under two names are returned once per name."""
+        if self._train_state is None:
+            raise RuntimeError("backward() needs a preceding forward_train()")
         sc, keep, outs, po, dev = self._train_state
         lib, h = _lib.load(), self._handle_in_mode(self._train_mode())
         gs = []

@@ -198,6 +198,7 @@ def decoder_loss(out_dict_list, obbs_padded, T_world_local, sym=None, *, matcher
             terms["size_loss"] += s
             terms["rot_loss"] += r
             terms["cat_loss"] += k
+    matcher.last_valid_bs = valid_bs          # introspection for tests; the returned dict is the reference's
     if valid_bs != 0:
         total = total / valid_bs
         terms = {k: v / valid_bs for k, v in terms.items()}
@@ -279,6 +280,7 @@ def decoder_loss_batched(out_dict_list, obbs_padded, T_world_local, sym=None, *,
     last = out_dict_list[-1]
     total0 = (last["ortho6d"].sum() * last["size_unnormalized"].sum() * last["center_unnormalized"].sum() * last["pred_logits"].sum() * 0)
     valid_bs = int(valid_np.sum())
+    matcher.last_valid_bs = valid_bs
     if valid_bs == 0:
         return {"center_loss": 0, "size_loss": 0, "rot_loss": 0, "cat_loss": 0, "total_loss": total0}
     packed = torch.from_numpy(np.stack([np.concatenate(seg), np.concatenate(pi_all), np.concatenate(gi_all),

@@ -26,12 +26,16 @@ class _RayPeFn(torch.autograd.Function):
         out, dims, _ = mod._run(camera, T_cp, T_wp, T_wl, tuple(features.shape[-2:]), features)
         ctx.mod, ctx.dims = mod, dims
         ctx.geo = mod._last_geo
+        ctx.gen = mod._gen
         ctx.want_feat = bool(features.requires_grad)
         return out
 
     @staticmethod
     def backward(ctx, g_tokens):
         mod = ctx.mod
+        if mod._gen != ctx.gen:
+            raise RuntimeError("parq_amd.AddRayPE: backward of a tokens() call whose workspace (the hidden layer it saved) was "
+                               "overwritten by a later call of the same module: one outstanding forward per module")
         B, V, h, w = ctx.dims
         Cd, S = mod.dim_out, mod.num_samples
         cam, T_cp, T_wp, T_wl = ctx.geo
@@ -89,6 +93,7 @@ class AddRayPE(nn.Module):
             features = prep(features)
             assert features.shape == (B, V, Cd, h, w), tuple(features.shape)
         lib = _lib.load()
+        self._gen += 1
         nbytes = lib.parq_ray_pe_workspace_bytes(B, V, h, w, Cd, self.num_samples)
         if self._ws is None or self._ws.numel() * 4 < nbytes or self._ws.device != dev:
             self._ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=dev)

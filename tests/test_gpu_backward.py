@@ -388,3 +388,37 @@ def test_head_dim_256_training_split_forward_matches_fp32_path():
             continue
         assert float((a - b).norm()) / float(b.norm()) < 1e-4, name
     assert float((res["split"][2] - res["fp32"][2]).norm()) / float(res["fp32"][2].norm()) < 1e-4
+
+
+def test_two_outstanding_training_forwards_are_refused_not_silently_wrong():
+    """The stash, dropout seed and outputs of a training forward live on the module: a second train-mode forward
+    before the first one's backward must make that backward raise instead of using the wrong activations; the sequential
+    form accumulates correctly."""
+    B, V, h, w, Q, dim = 1, 2, 8, 10, 16, 128
+    cfg = synth.decoder_cfg(dim=dim, queries=Q, heads=2, ffn=96, layers=2, dropout=0.0)
+    W = synth.make_decoder_weights(cfg, 181)
+    dec = make_decoder(cfg, W).train()
+    a = scene_args(synth.make_scene(182, B, V, h, w, dim, smooth=True))
+    b = scene_args(synth.make_scene(183, B, V, h, w, dim, smooth=True))
+    f = lambda outs: sum(o["center_unnormalized"].sum() + o["ortho6d"].sum() for o in outs)
+    la, lb = f(dec(*a)), f(dec(*b))
+    with pytest.raises(RuntimeError, match="one outstanding forward"):
+        (la + lb).backward()
+    dec.zero_grad(set_to_none=True)
+    f(dec(*a)).backward()
+    ga = {n: p.grad.clone() for n, p in dec.named_parameters() if p.grad is not None}
+    f(dec(*b)).backward()                                          # accumulates into .grad
+    dec2 = make_decoder(cfg, W).train()
+    f(dec2(*b)).backward()
+    for n, p in dec2.named_parameters():
+        if p.grad is not None and float(p.grad.norm()) > 0:
+            tot = dict(dec.named_parameters())[n].grad
+            assert float((tot - ga[n] - p.grad).norm()) <= 1e-4 * float(tot.norm()) + 1e-7, n
+    # weight writes that bypass the version counter need invalidate_weights()
+    dec.eval()
+    with torch.no_grad():
+        o1 = dec(*a)[0]["ortho6d"].clone()
+        dec.refpoint.weight.data.add_(0.25)
+        dec.invalidate_weights()
+        o2 = dec(*a)[0]["ortho6d"]
+    assert not torch.equal(o1, o2)

@@ -248,3 +248,37 @@ def test_parse_pred_matches_reference_golden(for_vis, key):
     assert np.abs(obbs.cpu().numpy() - z["obbs"]).max() < 2e-6
     assert np.array_equal(mask.cpu().numpy().astype(bool), z[key])
     assert 0 < int(mask.sum()) < B * Q
+
+
+def test_dropout_masks_of_row_pairs_overlap_like_independent_draws():
+    """nn.Dropout draws i.i.d. masks; the library's counter-based masks must at least look pairwise AND jointly independent
+    across rows: for every pair of rows the fraction of one row's dropped columns that the other row drops too has to be ~p
+    (comparing the bare xor of a row hash and a column hash against the threshold gave 1/16 of all row pairs
+    >60 % shared drops at p = 0.1).  512 rows x 4096 columns, all 130 816 pairs, 6-sigma band."""
+    import ctypes as C
+    from parq_amd import _lib
+    from parq_amd.decoder import PARQDecoder
+    p, rows, cols = 0.1, 512, 4096
+    cfg = synth.decoder_cfg(dim=64, queries=16, heads=1, ffn=64, layers=2, dropout=p)
+    dec = PARQDecoder(cfg).cuda()
+    h = dec._handle(apply_mode=False)
+    l = _lib.load()
+    _lib.check(l.parq_set_dropout(h, p, 12345), "set_dropout")
+    for site in (2, 4):
+        m = torch.empty(rows, cols, device="cuda")
+        _lib.check(l.parq_k_dropout_mask(h, 0, site, rows, cols, _lib.ptr(m), _lib.stream_ptr()), "mask")
+        d = (m == 0).double()                                     # dropped indicator
+        frac = float(d.mean())
+        assert abs(frac - p) < 0.004, frac
+        per_row = d.sum(1)
+        assert float(per_row.min()) > 0.75 * p * cols and float(per_row.max()) < 1.25 * p * cols
+        shared = d @ d.t()                                        # (rows, rows): columns dropped by both
+        share = (shared / per_row[:, None]).fill_diagonal_(0.0)   # fraction of row i's drops that row j shares
+        sigma = (p * (1 - p) / float(per_row.min())) ** 0.5
+        worst = float(share.max())
+        print("\ndropout site %d: drop rate %.4f, worst shared-drop fraction over all row pairs %.3f (independent: %.3f +- %.3f)"
+              % (site, frac, worst, p, sigma))
+        assert worst < p + 6 * sigma, worst
+        # columns too: no column is dropped for (or spared by) whole groups of rows
+        per_col = d.sum(0)
+        assert float(per_col.max()) < p * rows + 7 * (p * (1 - p) * rows) ** 0.5
