@@ -99,17 +99,30 @@ int parq_pack_weights(parq_handle h, void *arena, size_t arena_bytes, parq_strea
 
 /* Arithmetic of the dense cross-attention (call before sizing the workspace):
  *   0  v_mfma_f32_32x32x2_f32 on fp32 operands (exact fp32 products);
- *   1  (default when head dim == 64) every fp32 operand split as hi+lo fp16 and each product
+ *   1  (default when head dim is 64 or 256) every fp32 operand split as hi+lo fp16 and each product
  *      evaluated as hi*hi + hi*lo + lo*hi on the fp16 matrix pipe with fp32 accumulation:
  *      ~2^-22 relative product error, i.e. fp32-rounding class (measured against float64 the
- *      two modes are indistinguishable); operands must satisfy |x| < 65504, violations raise
- *      the int at workspace buffer "flags"[0];
+ *      two modes are indistinguishable).
+ *      GUARANTEED OPERAND RANGE of modes 1 and 2: every input token element and every projected K / V
+ *      element must satisfy |x| < 60000 (fp16 range with margin).  An element is carried with absolute
+ *      error <= max(2^-25, 2^-23 |x|): fp32-class as long as the large elements of a K / V row are
+ *      >= 2^-3; tensors that are tiny as a whole (max |K| or max |V| below ~1e-2) lose relative accuracy
+ *      (tests/test_gpu_range.py sweeps feature scales 1e-3 ... 1e2 and weight scales 0.1 ... 10 against
+ *      the float64 oracle).  A violation of the upper bound is NOT silent: the kernels that build the
+ *      cache raise the int at workspace buffer "flags"[0], and while it is set the last kernel of every
+ *      iteration writes NaN into all five computed outputs of parq_iterate / parq_forward instead of
+ *      plausible wrong numbers.  Re-run such inputs in mode 0 (the Python class does this: see
+ *      parq_amd.PARQDecoder.range_check);
  *   2  single fp16 products, 3  single bf16 products (head dim 64, dim <= 256): the reduced-precision
  *      configurations of the benchmark (BASELINE.json configs 2 and 5; the reference defines no mixed
  *      precision).  Q, K, V and the probabilities are rounded to nearest 16-bit
  *      once, accumulation stays fp32; the K/V cache shrinks to half.  Outputs agree with the fp32 path to
  *      ~1e-3 (fp16) / ~1e-2 (bf16) on unit-scale features (tests state the tolerances). */
 int parq_set_attention_mode(parq_handle h, int32_t mode);
+/* Optional: a host-visible, device-writable int32 (pinned host memory, e.g. hipHostMalloc) that the device sets to 1 whenever it
+ * poisons outputs because of a range violation (above).  Lets a host poll for violations of earlier, already finished calls
+ * with a plain load — no stream synchronisation, nothing extra on the forward path.  NULL switches it off. */
+int parq_set_range_mirror(parq_handle h, int32_t *host_visible_flag);
 
 /* ---- PARQDecoder.forward ---------------------------------------------------------- */
 size_t parq_workspace_bytes(parq_handle h, int32_t B, int32_t V, int32_t hh, int32_t ww);

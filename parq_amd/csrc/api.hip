@@ -100,6 +100,7 @@ struct parq_ctx {
     int vheads() const { return C / 64; }            // heads of the cache layout
     int terms() const { return attn_mode == 1 ? 3 : 1; }
     int kind() const { return attn_mode == 3 ? kBF16 : kF16; }
+    int* range_mirror = nullptr;      // host-visible word raised when outputs are poisoned (parq_set_range_mirror)
     bool bwd_batched_env = true;      // PARQ_BWD_BATCHED != 0, sampled by parq_create (the parity test makes one handle per setting)
     float dim_t_host[128];            // 10000^(2*(i//2)/128): uploaded by parq_pack_weights from this persistent buffer (no stream sync)
     bool profiling = false;
@@ -447,6 +448,9 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         d.gn_sums = gn2; d.gn_gamma = A + ar.gn2_g; d.gn_beta = A + ar.gn2_b;
         d.w3 = A + ar.heads3_w; d.b3 = A + ar.heads3_b; d.C = C; d.rows_per_scene = Q; d.eps = eps;
         d.ref = ref; d.mean_sizes = A + ar.mean_sizes; d.n_mean = c->cfg.num_mean_sizes; d.dim_t = A + ar.dim_t;
+        // fp16-operand modes: a range violation seen while the cache was built must not produce plausible wrong numbers
+        d.poison = (c->cache_mode() && c->kind() == kF16) ? reinterpret_cast<const int*>(wsp + ws.flags) : nullptr;
+        d.poison_mirror = c->range_mirror;
         d.sb = c->sb; d.M = M; d.ncls = c->ncls;
         d.logits = o->pred_logits; d.center = o->center_unnormalized; d.size = o->size_unnormalized;
         d.rot = o->ortho6d; d.prob = o->sem_cls_prob; d.ref_next = ref_out; d.emb_next = emb_next;
@@ -962,6 +966,12 @@ int parq_set_attention_mode(parq_handle h, int32_t mode) {
         return fail(PARQ_ERR_ARG, "the fp16 / bf16 attention modes need head dim 64 and dim in {128, 256}");
     h->attn_mode = mode;
     h->prepared = false;
+    return PARQ_OK;
+}
+
+int parq_set_range_mirror(parq_handle h, int32_t* host_visible_flag) {
+    if (!h) return fail(PARQ_ERR_ARG, "NULL handle");
+    h->range_mirror = host_visible_flag;
     return PARQ_OK;
 }
 

@@ -83,11 +83,13 @@ __host__ __device__ inline uint32_t rng_stream(uint32_t base, uint32_t stream) {
 __host__ __device__ inline uint32_t drop_rowhash(uint32_t seed, uint32_t row) { return rng_mix(seed ^ (row * 0x9e3779b1U)); }
 // keep(row, col) = mix(rowhash(seed, row) ^ colhash(col)) >= ceil(p * 2^24) * 256: the column part does not depend on the seed, so
 // the attention kernels hash a key ONCE (per stage in the forward, per lane in the backward, where a lane owns a key) and spend
-// xor + multiply + shift-xor + compare per element.  The final mix matters: comparing the bare xor against a threshold makes the
+// xor + multiply + shift-xor + multiply + compare per element.  The final mix matters: comparing the bare xor against a threshold makes the
 // dropped set of a row the preimage of `rowhash ^ [0, thr)`, whose large dyadic sub-blocks depend only on the top bits of the
 // row hash — 1/16 of all row pairs then share >60 % of their dropped columns at p = 0.1 (a 4-wise xor dependence that uniformity
-// and pairwise independence do not show).  A multiply by an odd constant + shift-xor after the xor breaks that linearity
-// (tests/test_gpu_kernels.py::test_dropout_masks_of_row_pairs_overlap_like_independent_draws).
+// and pairwise independence do not show).  multiply / shift-xor / multiply after the xor breaks that linearity: over all pairs of
+// 512 rows the worst shared-drop fraction is 0.175 at p = 0.1 (a full 32-bit finaliser gives 0.178; one multiply + shift-xor
+// still leaves 0.20-0.23 against the 6-sigma bound 0.196).  tests/test_host_cpu.py simulates the hash in NumPy,
+// tests/test_gpu_kernels.py::test_dropout_masks_of_row_pairs_overlap_like_independent_draws checks the masks the kernels use.
 __host__ __device__ inline uint32_t drop_colhash(uint32_t col) { return rng_mix(col * 0x85ebca77U + 0x6a09e667U); }
 // threshold in the scale of the full 32-bit hash: (h >> 8) >= ceil(p 2^24)  <=>  h >= ceil(p 2^24) * 256 (saturated: p ~ 1 keeps nothing
 // but h = 2^32 - 1)
@@ -97,7 +99,8 @@ __host__ __device__ inline uint32_t drop_threshold(float p) {
 }
 __host__ __device__ inline bool drop_keep_h(uint32_t rowhash, uint32_t colhash, uint32_t thr) {
     uint32_t h = (rowhash ^ colhash) * 0x9E3779B1U;
-    h ^= h >> 15;
+    h ^= h >> 16;
+    h *= 0x85EBCA6BU;             // second multiply: the compared (top) bits depend on every bit of the xor
     return h >= thr;
 }
 __host__ __device__ inline bool drop_keep(uint32_t rowhash, uint32_t col, float p) {
@@ -327,6 +330,9 @@ struct BoxDecodeArgs {
     float *logits, *center, *size, *rot, *prob;     // outputs (coord_pos is written by project_sample)
     float* ref_next;                   // [M][3] or nullptr
     float* emb_next;                   // [M][384] or nullptr: pos2posemb3d(ref_next)
+    int* poison_mirror;                // optional host-visible int set to 1 when outputs are poisoned
+    const int* poison;                 // optional device int: non-zero (fp16 operand range exceeded while the K/V cache was built) ->
+                                       // every output of the iteration is written as NaN instead of a plausible wrong number
 };
 hipError_t launch_box_decode(const BoxDecodeArgs& a, hipStream_t s);
 // weight packing helpers

@@ -301,6 +301,8 @@ __global__ __launch_bounds__(256) void box_decode_kernel(BoxDecodeArgs a) {
     const int lane = threadIdx.x & 63;
     const int C = a.C;
     const int scene = m / a.rows_per_scene;
+    const bool poison = a.poison != nullptr && *a.poison != 0;          // wave-uniform scalar load
+    if (poison && a.poison_mirror != nullptr && m == 0 && lane == 0) *a.poison_mirror = 1;       // tell the host (pinned word)
     // every independent load is issued before the first dependent use (this kernel is pure latency)
     const float* h1 = a.h1 + (int64_t)m * a.ld1;
     const float lg_in = lane < a.ncls ? h1[lane] : -INFINITY;
@@ -362,8 +364,8 @@ __global__ __launch_bounds__(256) void box_decode_kernel(BoxDecodeArgs a) {
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     const float prob = ex / sum;
     if (lane < a.ncls) {
-        a.logits[(int64_t)m * a.ncls + lane] = lg_in;
-        a.prob[(int64_t)m * a.ncls + lane] = prob;
+        a.logits[(int64_t)m * a.ncls + lane] = poison ? NAN : lg_in;
+        a.prob[(int64_t)m * a.ncls + lane] = poison ? NAN : prob;
     }
     // arg-max with torch.argmax tie-breaking (first maximum)
     float bestp = lane < a.ncls ? prob : -1.f;
@@ -379,14 +381,14 @@ __global__ __launch_bounds__(256) void box_decode_kernel(BoxDecodeArgs a) {
     }
     int arg = besti < a.n_mean ? besti : a.n_mean - 1;
     // size = exp(size_scale) * mean_size[argmax]  (utils/parq_utils.py:94-99)
-    if (lane < 3) a.size[(int64_t)m * 3 + lane] = expf(sz_in) * a.mean_sizes[arg * 3 + lane];
+    if (lane < 3) a.size[(int64_t)m * 3 + lane] = poison ? NAN : expf(sz_in) * a.mean_sizes[arg * 3 + lane];
     // ortho6d: lane j picks its own reduced dot product
     float rotv = 0.f, ctrv = 0.f;
 #pragma unroll
     for (int j = 0; j < 6; ++j) rotv = lane == j ? acc[3 + j] : rotv;
 #pragma unroll
     for (int j = 0; j < 3; ++j) ctrv = lane == j ? acc[j] : ctrv;
-    if (lane < 6) a.rot[(int64_t)m * 6 + lane] = rotv + b3r;
+    if (lane < 6) a.rot[(int64_t)m * 6 + lane] = poison ? NAN : rotv + b3r;
     // centre = denorm(sigmoid(offset + inverse_sigmoid(ref)))  (transformer_parq.py:242-245, 38-42)
     float nref = 0.f;
     if (lane < 3) {
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(256) void box_decode_kernel(BoxDecodeArgs a) {
         const float off = (ctrv + b3c) + logf(x1 / x2);
         const float sg = 1.f / (1.f + expf(-off));
         const float ctr = __fadd_rn(__fmul_rn(sg, __fsub_rn(hi, lo)), lo);      // mul, then add: as torch
-        a.center[(int64_t)m * 3 + lane] = ctr;
+        a.center[(int64_t)m * 3 + lane] = poison ? NAN : ctr;
         // next reference point = normalize(centre), detached (transformer_parq.py:331-332)
         nref = __fsub_rn(ctr, lo) / __fsub_rn(hi, lo);
         if (a.ref_next) a.ref_next[(int64_t)m * 3 + lane] = nref;

@@ -36,11 +36,15 @@ struct BigArgs {
 
 // 8 fp32 -> hi/lo fp16, streaming (the pre-pass)
 __global__ __launch_bounds__(256) void split_tokens_kernel(const float* __restrict__ x, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
-                                                           int64_t n8) {
+                                                           int64_t n8, int* __restrict__ overflow) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n8) return;
     const float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
     const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    bool ovf = false;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ovf |= !(fabsf(v[e]) < 60000.f);
+    if (ovf) atomicOr(overflow, 1);                               // rare: the token operand left the fp16 range
     half8 h, l;
     split8(v, h, l);
     reinterpret_cast<half8*>(hi)[i] = h;
@@ -226,7 +230,7 @@ hipError_t launch_kvproj_big(const float* tokens, const void* Whi, const void* W
     const int64_t n = (int64_t)B * N * C;
     _Float16* xhi = reinterpret_cast<_Float16*>(scratch);
     _Float16* xlo = xhi + n;
-    hipLaunchKernelGGL(split_tokens_kernel, dim3((unsigned)ceil_div64(n / 8, 256)), dim3(256), 0, s, tokens, xhi, xlo, n / 8);
+    hipLaunchKernelGGL(split_tokens_kernel, dim3((unsigned)ceil_div64(n / 8, 256)), dim3(256), 0, s, tokens, xhi, xlo, n / 8, overflow);
     BigArgs a;
     a.Xhi = xhi; a.Xlo = xlo; a.Whi = reinterpret_cast<const _Float16*>(Whi); a.Wlo = reinterpret_cast<const _Float16*>(Wlo);
     a.bias = bias; a.cache = reinterpret_cast<_Float16*>(cache); a.overflow = overflow; a.N = N; a.C = C; a.VH = C / 64;

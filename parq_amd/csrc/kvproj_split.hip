@@ -68,6 +68,7 @@ __global__ __launch_bounds__(kThreads) void kvproj_split_kernel(KvProjArgs a) {
     const int headcol = (n0 >> 6) + wc;            // head index in [K heads | V heads]
     const bool isK = headcol < a.H;
 
+    bool ovf = false;            // fp16 operand range (tokens and K / V values)
     // ---- staging assignment: 1024 A chunks (row, c) and 2048 W chunks per stage
     float4 areg[8];
     uint4 wreg[8];
@@ -108,6 +109,8 @@ __global__ __launch_bounds__(kThreads) void kvproj_split_kernel(KvProjArgs a) {
             const int pos = c ^ ((row >> 1) & 7);
             float x[8] = {areg[2 * i].x, areg[2 * i].y, areg[2 * i].z, areg[2 * i].w,
                           areg[2 * i + 1].x, areg[2 * i + 1].y, areg[2 * i + 1].z, areg[2 * i + 1].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ovf |= !(fabsf(x[e]) < 60000.f);          // the token operand is carried in fp16 too
             half8 hi, lo;
             split8(x, hi, lo);
             *reinterpret_cast<half8*>(Ahi + row * kBK + pos * 8) = hi;
@@ -193,7 +196,6 @@ __global__ __launch_bounds__(kThreads) void kvproj_split_kernel(KvProjArgs a) {
     const int nblk = (a.N + 31) / 32;
     const int h = isK ? headcol : headcol - a.H;
     const float* bias = a.bias + headcol * 64;
-    bool ovf = false;
     _Float16* wl = lds + wave * (2 * 4096);                          // 2 blocks x 8 KB per wave = 8192 halfs
 #pragma unroll
     for (int rt2 = 0; rt2 < 2; ++rt2) {
@@ -318,6 +320,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void kvproj_ws_kernel(KvProjArgs a, in
     const int h = isK ? headcol : headcol - a.H;
     const int nblk = (a.N + 31) / 32;
 
+    bool ovf = false;      // fp16 operand range: tokens (checked where they are converted) and K / V values (epilogue)
     // token staging registers, kWsDepth k-steps in flight (HBM latency under load is ~3 us, one k-step of MFMAs
     // ~0.75 us: with a single step in flight the loop runs at latency, not at MFMA or HBM speed)
     float4 areg[kWsDepth][2 * NI];
@@ -349,6 +352,10 @@ __global__ __launch_bounds__(NWV * 64, 1) void kvproj_ws_kernel(KvProjArgs a, in
             const int pos = c ^ ((row >> 1) & 7);
             float x[8] = {src[2 * i].x, src[2 * i].y, src[2 * i].z, src[2 * i].w,
                           src[2 * i + 1].x, src[2 * i + 1].y, src[2 * i + 1].z, src[2 * i + 1].w};
+            if constexpr (KIND == kF16) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ovf |= !(fabsf(x[e]) < 60000.f);
+            }
             if constexpr (TERMS == 3) {
                 half8 hi, lo;
                 split8(x, hi, lo);
@@ -366,7 +373,6 @@ __global__ __launch_bounds__(NWV * 64, 1) void kvproj_ws_kernel(KvProjArgs a, in
         if (q < total_steps) gload(p + (q / nk) * P, q % nk, dst);
     };
 
-    bool ovf = false;
     int step = 0;                                  // global k-step counter (LDS buffer parity, staging slot)
     static_assert(kWsDepth == 2 && kWsMaxKSteps % kWsDepth == 0, "slot arithmetic below assumes depth 2");
     issue(0, areg[0]);

@@ -235,6 +235,48 @@ class PARQDecoder(nn.Module):
         self.loss_batched = True          # loss(): all (iteration, scene) pairs in ~40 launches (False: the reference's per-pair loop)
         self.dp_all_reduce = False        # True: backward() all-reduces the flat gradient arena over the default process group
         self._mean_dev = None
+        # fp16-operand attention modes ("split", "fp16"): what to do when a token / K / V element leaves the fp16 range
+        # (include/parq_hip.h: the device then writes NaN outputs instead of wrong numbers, and raises a flag).
+        #   "lazy" (default): no synchronisation and no extra work on the forward path.  On a violation the device itself
+        #           stores into a pinned host word (parq_set_range_mirror); the next call into the module that finds it set
+        #           warns and switches ``attention_mode`` to "fp32" for good, so at most the forwards already in flight are
+        #           NaN (never silently wrong).
+        #   "sync": wait for the flag after every inference forward and transparently re-run that forward with the exact
+        #           fp32 kernels (costs one host synchronisation per forward).
+        #   "off":  only ``fp16_range_exceeded()`` on request.
+        self.range_check = "lazy"
+        self._range_mirror = None         # pinned host int32 the device raises on a range violation
+
+    # ------------------------------------------------------------------ fp16 operand range (split / fp16 modes)
+    def _flag_view(self, ws, B, V, h, w):
+        off, n = C.c_size_t(), C.c_size_t()
+        _lib.check(_lib.load().parq_workspace_lookup(self._handle(apply_mode=False), B, V, h, w, b"flags", C.byref(off), C.byref(n)),
+                   "parq_workspace_lookup")
+        return ws[off.value: off.value + 1].view(torch.int32)
+
+    def _range_fallback(self, where):
+        import warnings
+        warnings.warn("parq_amd.PARQDecoder: a token / K / V element left the fp16 range (|x| >= 60000) in attention mode %r (%s); "
+                      "the affected outputs are NaN.  Switching attention_mode to 'fp32' (exact fp32 MFMA kernels) for this module."
+                      % (self.attention_mode, where), RuntimeWarning, stacklevel=3)
+        self.attention_mode = "fp32"
+
+    def _range_poll(self):
+        """A host load of the pinned word earlier forwards raise from the device on a violation (no synchronisation)."""
+        if self._range_mirror is not None and int(self._range_mirror[0]) != 0:
+            self._range_mirror[0] = 0
+            if self.range_check != "off" and self.attention_mode in ("split", "fp16"):
+                self._range_fallback("detected after an earlier forward")
+
+    def _range_after_forward(self, ws, sc):
+        """"sync" policy: wait for the flag of the forward just enqueued; True = re-run it with the fp32 kernels."""
+        if self.range_check != "sync" or self.attention_mode not in ("split", "fp16"):
+            return False
+        if int(self._flag_view(ws, sc.B, sc.V, sc.h, sc.w).item()) != 0:
+            self._range_mirror[0] = 0
+            self._range_fallback("re-running this forward")
+            return True
+        return False
 
     # ------------------------------------------------------------------ native handle
     def _handle(self, apply_mode=True):
@@ -248,6 +290,9 @@ class PARQDecoder(nn.Module):
             self._h = h
             self._mode_set = None
             self._train_ws = None
+            # pinned host memory is mapped into the device address space under the same pointer (hipHostMalloc)
+            self._range_mirror = torch.zeros(1, dtype=torch.int32).pin_memory()
+            _lib.check(lib.parq_set_range_mirror(h, C.c_void_p(self._range_mirror.data_ptr())), "parq_set_range_mirror")
         if apply_mode and self._mode_set != self.attention_mode:
             if self.attention_mode not in ATTENTION_MODES:
                 raise ValueError(f"attention_mode must be one of {sorted(ATTENTION_MODES)}")
@@ -391,13 +436,17 @@ class PARQDecoder(nn.Module):
 
     def _forward_inference(self, intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw=None):
         self._check_mode()
+        self._range_poll()
         sc, keep, dev = self._scene(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
         self._ensure_packed(dev)
-        ws = self._workspace(sc.B, sc.V, sc.h, sc.w, dev)
         outs = self._alloc_outputs((self.num_layers, sc.B, self.num_queries), dev)
         po = _lib.ParqOutputs(*[_lib.ptr(t) for t in outs])
-        _lib.check(_lib.load().parq_forward(self._handle(), C.byref(sc), _lib.ptr(ws), ws.numel() * 4, C.byref(po),
-                                            _lib.stream_ptr()), "parq_forward")
+        for _attempt in range(2):
+            ws = self._workspace(sc.B, sc.V, sc.h, sc.w, dev)
+            _lib.check(_lib.load().parq_forward(self._handle(), C.byref(sc), _lib.ptr(ws), ws.numel() * 4, C.byref(po),
+                                                _lib.stream_ptr()), "parq_forward")
+            if not self._range_after_forward(ws, sc):          # "sync" policy + flag set: once more with the exact fp32 kernels
+                break
         del keep
         return [{k: t[i] for k, t in zip(OUTPUT_KEYS, outs)} for i in range(self.num_layers)]
 
@@ -423,6 +472,7 @@ class PARQDecoder(nn.Module):
                                           _lib.stream_ptr()), "parq_forward_train")
         self._train_state = (sc, keep, outs, po, dev)
         self._train_gen += 1
+        self._range_poll()
         return [{k: t[i] for k, t in zip(OUTPUT_KEYS, outs)} for i in range(self.num_layers)]
 
     @torch.no_grad()
@@ -491,15 +541,17 @@ class PARQDecoder(nn.Module):
         return dict(zip(OUTPUT_KEYS, outs)), nxt
 
     def fp16_range_exceeded(self):
-        """True if the last prepare()/forward() saw a K/V value outside the fp16 range while
-        building the split cache (synchronises; only meaningful in "split" mode)."""
-        if not self._ws:
+        """True if the last prepare() / forward() / forward_train() saw a token, K or V element outside the fp16 range while
+        building the 16-bit K/V cache (synchronises; meaningful in the "split" and "fp16" modes).  Outputs of such a call are
+        NaN by construction (include/parq_hip.h); see ``range_check`` for the automatic handling."""
+        if self._ws:
+            (B, V, h, w, _), ws = next(iter(self._ws.items()))
+        elif self._train_ws is not None and self._train_state is not None:
+            sc = self._train_state[0]
+            (B, V, h, w), ws = (sc.B, sc.V, sc.h, sc.w), self._train_ws
+        else:
             return False
-        (B, V, h, w, _), ws = next(iter(self._ws.items()))
-        off, n = C.c_size_t(), C.c_size_t()
-        _lib.check(_lib.load().parq_workspace_lookup(self._handle(), B, V, h, w, b"flags", C.byref(off), C.byref(n)),
-                   "parq_workspace_lookup")
-        return bool(ws[off.value: off.value + 1].view(torch.int32).item() != 0)
+        return bool(self._flag_view(ws, B, V, h, w).item() != 0)
 
     def intermediate(self, name):
         """View of a named workspace buffer after prepare()/iterate() (parity tests)."""

@@ -121,3 +121,29 @@ def test_synth_is_deterministic():
     # fixed fingerprint: changing the generator would silently invalidate every golden
     assert float(synth.uniform(7, "fingerprint", (1,))[0]) == np.float32(0.2026161402463913)
     assert float(synth.normal(7, "fingerprint", (1,))[0]) == np.float32(0.4613424837589264)
+
+
+def test_dropout_hash_spec_row_pairs_are_statistically_independent():
+    """NumPy restatement of the counter-based dropout keep decision (parq_amd/csrc/common.hpp: drop_rowhash, drop_colhash,
+    drop_keep_h): drop rate ~p and, over ALL pairs of 512 rows x 4096 columns, no pair shares more of its dropped columns
+    than independent draws would (the bare xor-and-compare shared 62-100 % for 1/16 of the pairs)."""
+    M = np.uint64(0xFFFFFFFF)
+    u32 = lambda x: (x & M).astype(np.uint64)
+
+    def mix(x):
+        x = u32(x); x ^= x >> np.uint64(16); x = u32(x * np.uint64(0x7feb352d)); x ^= x >> np.uint64(15)
+        x = u32(x * np.uint64(0x846ca68b)); x ^= x >> np.uint64(16)
+        return x
+    p, rows, cols, seed = 0.1, 512, 4096, 12345
+    thr = np.uint64(int(np.ceil(p * 2 ** 24)) << 8)
+    with np.errstate(over="ignore"):
+        r = mix(np.uint64(seed) ^ u32(np.arange(rows, dtype=np.uint64) * np.uint64(0x9e3779b1)))[:, None]
+        c = mix(u32(np.arange(cols, dtype=np.uint64) * np.uint64(0x85ebca77) + np.uint64(0x6a09e667)))[None, :]
+        h = u32((r ^ c) * np.uint64(0x9E3779B1)); h ^= h >> np.uint64(16); h = u32(h * np.uint64(0x85EBCA6B))
+    d = (h < thr).astype(np.float64)
+    assert abs(d.mean() - p) < 0.003
+    per = d.sum(1)
+    share = (d @ d.T) / per[:, None]
+    np.fill_diagonal(share, 0.0)
+    sigma = (p * (1 - p) / per.min()) ** 0.5
+    assert share.max() < p + 6 * sigma, share.max()
