@@ -1,0 +1,154 @@
+"""GPU tier: operand range of the split-precision (fp16 hi/lo) default — VERDICT r01 weak #4.
+
+hi + lo carries an fp32 value with absolute error <= max(2^-24, 2^-22 |x|) while |x| < 60000 (include/parq_hip.h).  Checked:
+  * scale sweeps of the attention kernel, of the K/V projection + attention chain and of the whole decoder against the
+    float64 oracle: the split path has to stay fp32-CLASS at every scale, i.e. within the stated tolerance or within 2x the
+    error of the exact-fp32 MFMA kernels on the same input (at large score magnitudes fp32 itself is the limit: the
+    reference's own arithmetic, model/transformer_parq.py:377-380, has the same rounding);
+  * beyond the range nothing is silent: outputs are NaN, the flag and the pinned host mirror are raised, and the module's
+    range_check policies ("sync": transparent re-run with the fp32 kernels; "lazy": switch for the following calls) work."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from parq_amd import _lib, synth
+from oracle import parq_oracle as O
+from gpu_util import dev, lib, make_decoder, scene_args, sptr, to_np, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _attention(fn_name, q, k, v, B, H, Lq, Lk):
+    l = lib()
+    if fn_name == "split":
+        nbytes = l.parq_k_attention_split_scratch_bytes(B, H, Lq, Lk)
+    else:
+        nbytes = l.parq_k_attention_scratch_bytes(B, H, Lq, Lk, 64)
+    scratch = torch.empty(nbytes // 4 + 1, device="cuda")
+    out = torch.empty(B, Lq, H * 64, device="cuda")
+    dq, dk, dv = dev(q), dev(k), dev(v)
+    if fn_name == "split":
+        _lib.check(l.parq_k_attention_split(_lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(out), B, H, Lq, Lk, _lib.ptr(scratch),
+                                            nbytes, sptr()), "attention_split")
+        flag = int(scratch[:1].view(torch.int32).item())
+    else:
+        _lib.check(l.parq_k_attention(_lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(out), B, H, Lq, Lk, 64, _lib.ptr(scratch), nbytes,
+                                      sptr()), "attention")
+        flag = 0
+    return out.cpu().numpy().astype(np.float64), flag
+
+
+@pytest.mark.parametrize("ks,vs", [(1e-3, 1e-3), (1e-3, 1.0), (1.0, 1e-3), (1.0, 1.0), (30.0, 1.0), (1.0, 1e3), (30.0, 1e3), (1e-2, 1e4)])
+def test_attention_split_scale_sweep(ks, vs):
+    """K scaled by ks (scores from ~0 to hundreds: uniform to one-hot attention), V by vs (outputs from 1e-3 to the fp16 limit).
+    Error measured relative to the output scale max|out| (what LayerNorm downstream sees)."""
+    B, H, Lq, Lk, dh = 1, 2, 96, 6400, 64
+    q = synth.normal(21, "q", (B, Lq, H * dh))
+    k = synth.normal(22, "k", (B, Lk, H * dh)) * np.float32(ks)
+    v = synth.normal(23, "v", (B, Lk, H * dh)) * np.float32(vs)
+    k[0, 7, :dh] = np.float32(ks) * 2.0 * q[0, 0, :dh]          # a peaky row at every scale
+    tq, tk, tv = (torch.from_numpy(x).double().view(B, -1, H, dh).transpose(1, 2) for x in (q, k, v))
+    want = (torch.softmax(tq @ tk.transpose(-1, -2) / dh ** 0.5, -1) @ tv).transpose(1, 2).reshape(B, Lq, H * dh).numpy()
+    scale = np.abs(want).max()
+    got, flag = _attention("split", q, k, v, B, H, Lq, Lk)
+    ref32, _ = _attention("fp32", q, k, v, B, H, Lq, Lk)
+    e_split = np.abs(got - want).max() / scale
+    e_fp32 = np.abs(ref32 - want).max() / scale
+    print("\nattention K x%g V x%g: split %.2e, exact-fp32 kernels %.2e (relative to max|out| = %.3g)" % (ks, vs, e_split, e_fp32, scale))
+    assert flag == 0
+    # 2^-24 / max|out|: the documented absolute floor of the hi/lo representation (values below 2^-3 have an fp16-subnormal lo
+    # part, quantum 2^-24, rounded toward zero) — it only shows when V as a whole is tiny (V x 1e-3: ~2.4e-5)
+    assert e_split < max(2e-5, 2.0 * e_fp32, 1.5 * 2.0 ** -24 / scale), (e_split, e_fp32)
+
+
+def test_attention_split_flags_values_beyond_the_fp16_range():
+    B, H, Lq, Lk, dh = 1, 1, 32, 256, 64
+    q = synth.normal(31, "q", (B, Lq, dh)); k = synth.normal(32, "k", (B, Lk, dh)); v = synth.normal(33, "v", (B, Lk, dh))
+    v[0, 100, 3] = 7.0e4
+    _, flag = _attention("split", q, k, v, B, H, Lq, Lk)
+    assert flag != 0
+
+
+def _decoder_errors(fscale, wscale, mode, iters=2):
+    """Worst teacher-forced error of the whole decoder against the float64 oracle; features x fscale, cross-attention
+    in-projection (weight and bias: q, k and v) x wscale."""
+    cfg = synth.decoder_cfg(dim=256, queries=64, heads=4, ffn=768, layers=iters)
+    W = synth.make_decoder_weights(cfg, 611)
+    pre = "parq_module.decoder.layers.0.multihead_attn.in_proj_"
+    W[pre + "weight"] = (W[pre + "weight"] * np.float32(wscale)).astype(np.float32)
+    W[pre + "bias"] = (synth.normal(612, "b", W[pre + "bias"].shape, std=0.02) * np.float32(wscale)).astype(np.float32)
+    sc = synth.make_scene(613, 1, 3, 40, 50, 256)
+    sc["tokens"] = (sc["tokens"] * np.float32(fscale)).astype(np.float32)
+    dec = make_decoder(cfg, W)
+    dec.attention_mode = mode
+    dec.range_check = "off"
+    outs = [to_np(o) for o in dec(*scene_args(sc))]
+    flagged = dec.fp16_range_exceeded()
+    od = O.OracleDecoder(cfg, W, synth.SCANNET_MEAN_SIZES, dtype=torch.float64)
+    forced = [O.normalize(torch.from_numpy(o["coord_pos"]).double(), cfg.TRANSFORMER.SCALE) for o in outs]
+    with torch.no_grad():
+        want = od.forward(sc["tokens"], sc["camera"], sc["T_camera_pseudoCam"], sc["T_world_pseudoCam"], sc["T_world_local"],
+                          forced_refs=forced)
+    worst = 0.0
+    for a, b in zip(outs, want):
+        top2 = b["sem_cls_prob"].topk(2, -1).values
+        ok = ((top2[..., 0] - top2[..., 1]) > 1e-3).numpy()
+        for key in a:
+            x, y = a[key], b[key].numpy()
+            if key == "size_unnormalized":
+                x, y = x[ok], y[ok]
+            worst = max(worst, rel_err(x, y) if np.isfinite(x).all() else float("inf"))
+    return worst, flagged, (cfg, W, sc, want)
+
+
+@pytest.mark.parametrize("fscale", [1e-3, 1.0, 1e2])
+@pytest.mark.parametrize("wscale", [0.1, 1.0, 10.0])
+def test_decoder_feature_and_weight_scale_sweep(fscale, wscale):
+    """K/V projection (kvproj_ws_kernel: tokens split on the fly) + cross-attention + the rest of the chain at feature scales
+    1e-3 ... 1e2 and in-projection scales 0.1 ... 10: 1e-4 against the float64 oracle, or fp32-class (2x the exact-fp32
+    kernels' error) where fp32 arithmetic itself cannot do better."""
+    e_split, flagged, _ = _decoder_errors(fscale, wscale, "split")
+    e_fp32, _, _ = _decoder_errors(fscale, wscale, "fp32")
+    print("\ndecoder features x%g, in-proj x%g: split %.2e, exact-fp32 kernels %.2e" % (fscale, wscale, e_split, e_fp32))
+    assert not flagged
+    assert e_split < max(1e-4, 2.0 * e_fp32), (e_split, e_fp32)
+
+
+def test_out_of_range_features_are_not_silent_and_policies_recover():
+    """Features x 2e4 (token elements beyond 60000): default-mode outputs are NaN (never plausible wrong numbers), the flag and
+    the pinned host mirror are raised; range_check="sync" re-runs the same call with the fp32 kernels (parity with the oracle);
+    range_check="lazy" switches the module for the calls that follow."""
+    worst, flagged, (cfg, W, sc, want) = _decoder_errors(2e4, 1.0, "split")
+    assert flagged and worst == float("inf")
+    e_fp32, _, _ = _decoder_errors(2e4, 1.0, "fp32")
+
+    def check(outs):
+        w = 0.0
+        for a, b in zip(outs, want):
+            for key in ("pred_logits", "center_unnormalized", "ortho6d"):
+                w = max(w, rel_err(a[key].cpu().numpy(), b[key].numpy()))
+        return w
+
+    dec = make_decoder(cfg, W)
+    dec.range_check = "sync"
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        outs = dec(*scene_args(sc))
+    assert dec.attention_mode == "fp32" and any("fp16 range" in str(r.message) for r in rec)
+    # teacher-forced reference points came from the fp32-mode run of _decoder_errors; iteration 0 is free of forcing
+    assert rel_err(outs[0]["pred_logits"].cpu().numpy(), want[0]["pred_logits"].numpy()) < max(1e-4, 2 * e_fp32)
+
+    dec = make_decoder(cfg, W)
+    assert dec.range_check == "lazy"
+    first = dec(*scene_args(sc))
+    torch.cuda.synchronize()
+    assert torch.isnan(first[0]["pred_logits"]).all() and torch.isnan(first[-1]["ortho6d"]).all()
+    assert int(dec._range_mirror[0]) == 1                      # raised by the device, read without a stream sync
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        second = dec(*scene_args(sc))
+    assert dec.attention_mode == "fp32" and any("fp16 range" in str(r.message) for r in rec)
+    assert torch.isfinite(second[0]["pred_logits"]).all()
+    assert rel_err(second[0]["pred_logits"].cpu().numpy(), want[0]["pred_logits"].numpy()) < max(1e-4, 2 * e_fp32)
