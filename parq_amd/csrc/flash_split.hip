@@ -452,6 +452,377 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, cons
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Second-generation main kernel (TERMS = 3, no dropout): ONE software-pipelined step per 32-key block,
+//     step n :  QK(n+1)  ||  softmax(n)  ||  PV(n-1)
+// PMC stall attribution of the two-blocks-per-stage kernel above (profiles/r02_stall_*): MFMA pipe 52 % busy, the waves 36 %
+// parked (s_waitcnt / barrier) and 33 % issue-stalled; per stage the SIMD spends MFMA time (QK(b0), PV(b1): no VALU to issue)
+// PLUS VALU time (softmax regions with 7+ VALU per MFMA) instead of the maximum of the two.  Here every MFMA of a step has
+// softmax work of ANOTHER block to issue behind it (24 MFMAs : ~150 VALU, 6 per MFMA gap), consecutive MFMAs alternate between
+// the S^T accumulator and the two O^T accumulators (few back-to-back dependent pairs), the issue order is fixed by scheduling
+// fences (the sched_group_barrier pipeline was not honoured for this region), and the cross-half reductions use
+// v_permlane32_swap instead of ds_bpermute.  Same cache, same LDS ring / DMA protocol, same partial outputs.
+// v_permlane32_swap exchanges lanes 32..63 of its first operand with lanes 0..31 of its second: fed the same value twice, the first
+// comes back as the low half broadcast to both halves and the second as the high half.  Written as inline asm: with hipcc of
+// ROCm 7.2 the SECOND result of __builtin_amdgcn_permlane32_swap is mis-assigned to the first result's register ("r[0] + r[1]"
+// compiled to v0 + v0 even for unrelated inputs: the row sums came out doubled).  s_nop: VALU write -> permlane read hazard.
+__device__ __forceinline__ void xhalf_swap(float v, float& lo_bcast, float& hi_bcast) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    lo_bcast = a;
+    hi_bcast = b;
+}
+__device__ __forceinline__ float xhalf_max(float v) {       // max over the two 32-lane halves, result in every lane
+    float a, b, o;
+    xhalf_swap(v, a, b);
+    asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+    float a, b;
+    xhalf_swap(v, a, b);
+    return a + b;
+}
+
+// RING: LDS slots of one 64-key stage each.  A stage is requested AHEAD = RING - 3 barriers before the barrier that publishes it
+// (three stages are live at any time: V of the previous block, K / V of the current pair, K of the next pair).
+// PROBE (development only, results are wrong when non-zero): 1 no softmax VALU, 2 no PV MFMAs, 4 no QK MFMAs, 8 no barrier / DMA waits,
+// 16 no fragment reads from LDS — what each ingredient of a step costs when it is taken out.
+template <int RING, int PROBE = 0>
+__global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a, const _Float16* __restrict__ cache) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];       // [RING stages][kStageBlks][block]
+    constexpr int kBlkBytes = Blk<3>::bytes;
+    constexpr int kBlkHalfs = Blk<3>::halfs;
+    constexpr int NT = kNW * 64;
+    constexpr int STAGE16 = kStageBlks * kBlkBytes / 16;
+    constexpr int LD = STAGE16 / NT;
+    constexpr int AHEAD = RING - 3;
+    static_assert(kStageBlks == 2 && (RING == 4 || RING == 5), "slot arithmetic below");
+
+    const int split = blockIdx.x;
+    const int bh = blockIdx.z;
+    const int b = bh / a.H, h = bh - b * a.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int q0 = (blockIdx.y * kNW + wave) * 32;
+    const int q = q0 + li;
+    const bool active = q0 < a.Lq;
+    const int Lq_pad = (a.Lq + 31) & ~31;
+
+    half8 qhi[4], qlo[4];
+    {
+        const float scale = 1.4426950408889634f / sqrtf((float)kDH);
+        const float* qp = a.q + (int64_t)b * a.q_batch + (int64_t)h * a.q_head + (int64_t)(q < a.Lq ? q : 0) * a.q_row;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int d0 = 32 * (s >> 1) + 16 * (s & 1) + 4 * kh;
+            f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + d0);
+            f32x4 x1 = *reinterpret_cast<const f32x4*>(qp + d0 + 8);
+            if (q >= a.Lq) { x0 = f32x4{0.f, 0.f, 0.f, 0.f}; x1 = x0; }
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = (e < 4 ? x0[e & 3] : x1[e & 3]) * scale;
+            split8(x, qhi[s], qlo[s]);
+        }
+    }
+
+    const int nblk = (a.Lk + kBlkKeys - 1) / kBlkKeys;
+    const int nst = (nblk + kStageBlks - 1) / kStageBlks;
+    const int t_begin = (int)((int64_t)split * nst / a.nsplit);
+    const int t_end = (int)((int64_t)(split + 1) * nst / a.nsplit);
+    const uint4* gsrc = reinterpret_cast<const uint4*>(cache + (int64_t)bh * nblk * kBlkHalfs);
+    const int64_t total16 = (int64_t)nblk * (kBlkBytes / 16);
+    const int B0 = t_begin * kStageBlks;                                  // blocks of this split: [B0, B0 + nbk)
+    const int nbk = ((t_end * kStageBlks < nblk) ? t_end * kStageBlks : nblk) - B0;
+    const bool last_partial = (t_end == nst) && (a.Lk & 31) != 0;         // the split's last block is the cache's ragged last block
+
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    // every lane always issues its LD loads (addresses past the end of the cache are clamped to its last chunk: a redundant copy of
+    // valid data), so the number of outstanding VMEM instructions per stage is a constant and the waits below can be COUNTED
+    auto gload = [&](int st, int slot) {
+#pragma unroll
+        for (int i = 0; i < LD; ++i) {
+            int64_t idx = (int64_t)st * STAGE16 + tid + i * NT;
+            idx = idx < total16 ? idx : total16 - 1;
+            lds_byte* dst = (lds_byte*)(smem_h) + ((size_t)slot * STAGE16 + i * NT + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds(gsrc + idx, dst, 16, 0, 0);
+        }
+    };
+    // local block n -> its 16 KB image in the ring (stage j = n / 2 lives in slot j % RING)
+    auto lds_blk = [&](int n) -> const _Float16* { return smem_h + (size_t)((((n >> 1) % RING) << 1) | (n & 1)) * kBlkHalfs; };
+
+#pragma unroll
+    for (int j = 0; j < RING - 1; ++j)
+        if (t_begin + j < t_end) gload(t_begin + j, j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // after the step of local block 2 j + 1: stage j + 2 must be visible to every wave (its K is read two steps later); it was
+    // requested AHEAD barriers ago, so with RING = 5 the newest request stays in flight across this barrier (counted wait; LDS-DMA
+    // returns in order).  Stage j + RING - 1 then goes into the slot of stage j - 1 (last read by step 2 j: V of block 2 j - 1).
+    auto sync_point = [&](int j) {
+        if constexpr (!(PROBE & 8)) {
+            if (AHEAD >= 2 && t_begin + j + 3 < t_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (t_begin + j + RING - 1 < t_end) gload(t_begin + j + RING - 1, (j + RING - 1) % RING);
+    };
+
+    f32x16 o[2], sacc[2];
+    half8 Phi[2][2], Plo[2][2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) { Phi[c][m] = half8{0, 0, 0, 0, 0, 0, 0, 0}; Plo[c][m] = Phi[c][m]; }
+    float m_run = 0.f, l_run = 0.f, l_a = 0.f, l_b = 0.f;                  // row sum = l_run + l_a + l_b (two chains in the steady state)
+    // -m_run in 16 registers: the C operand of the first QK MFMA of every block, so the scores leave the matrix pipe already relative
+    // to the running maximum (saves a v_sub per score); rewritten only when the reference moves
+    f32x16 negm16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    half8 kf[8], vh[2], vl[2];                                             // fragments of the NEXT step, requested at the end of a step
+    const int ksw = (li >> 1) & 7;
+
+    auto load_k = [&](const _Float16* Kb, half8 (&kf)[8]) {
+        if constexpr (PROBE & 16) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) kf[s] = qhi[s & 3];
+            return;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int pos = (4 * kh + s) ^ ksw;
+            kf[2 * s] = *reinterpret_cast<const half8*>(Kb + li * 64 + pos * 8);
+            kf[2 * s + 1] = *reinterpret_cast<const half8*>(Kb + Blk<3>::k_lo + li * 64 + pos * 8);
+        }
+    };
+    auto load_v = [&](const _Float16* Vb, int m, half8 (&vh)[2], half8 (&vl)[2]) {
+        if constexpr (PROBE & 16) {
+            vh[0] = qhi[0]; vh[1] = qhi[1]; vl[0] = qlo[0]; vl[1] = qlo[1];
+            return;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int d = dt * 32 + li;
+            const int pos = (2 * m + kh) ^ ((d >> 2) & 3);
+            vh[dt] = *reinterpret_cast<const half8*>(Vb + Blk<3>::v_hi + d * 32 + pos * 8);
+            vl[dt] = *reinterpret_cast<const half8*>(Vb + Blk<3>::v_lo + d * 32 + pos * 8);
+        }
+    };
+    // max of the 16 scores of this lane (keys of one kh half), then over both halves: the block maximum of query li
+    // (plain fmaxf: hipcc forms v_max3 chains itself and — unlike for an asm statement — pads the MFMA-result -> VALU-read hazard)
+    auto block_max = [&](const f32x16& S) -> float {
+        float m0 = fmaxf(S[0], S[1]), m1 = fmaxf(S[8], S[9]);
+#pragma unroll
+        for (int r = 2; r < 8; ++r) { m0 = fmaxf(m0, S[r]); m1 = fmaxf(m1, S[8 + r]); }
+        return xhalf_max(fmaxf(m0, m1));
+    };
+    // probabilities of accumulator half m of block-parity CUR (epilogue; the steady state uses sm_pair)
+    auto softmax_half = [&](auto cur, int m) {
+        constexpr int CUR = decltype(cur)::value;
+        float p[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            p[e] = __builtin_amdgcn_exp2f(sacc[CUR][8 * m + e]);
+            l_run += p[e];
+        }
+        split8(p, Phi[CUR][m], Plo[CUR][m]);
+    };
+    auto pv_half = [&](auto par, int m, const half8 (&vh)[2], const half8 (&vl)[2]) {
+        constexpr int PAR = decltype(par)::value;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) o[dt] = mfma16<kF16>(vh[dt], Phi[PAR][m], o[dt]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) o[dt] = mfma16<kF16>(vl[dt], Phi[PAR][m], o[dt]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) o[dt] = mfma16<kF16>(vh[dt], Plo[PAR][m], o[dt]);
+    };
+    // rare, wave-uniform: the maximum of block n + 1 (accumulator parity NXT, relative to m_run) moves the reference.  The
+    // probabilities of block n (parity CUR) are still waiting for their PV: it is done here and then cleared, so that the
+    // PV of the next step adds zeros; (l, O) and the new scores move to the new reference.
+    auto move_reference = [&](auto cur, int n, float mx) {
+        constexpr int CUR = decltype(cur)::value, NXT = CUR ^ 1;
+        const _Float16* Vb = lds_blk(n);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            half8 vh2[2], vl2[2];
+            load_v(Vb, m, vh2, vl2);
+            pv_half(cur, m, vh2, vl2);
+            Phi[CUR][m] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            Plo[CUR][m] = Phi[CUR][m];
+        }
+        const float d = mx > a.defer_log2 ? mx : 0.f;
+        const float alpha = __builtin_amdgcn_exp2f(-d);
+        m_run += d;
+        l_run *= alpha;
+        l_a *= alpha;
+        l_b *= alpha;
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dd][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[NXT][r] -= d; negm16[r] = -m_run; }     // the scores of block n + 1 move to the new reference
+    };
+
+    // one softmax PAIR: elements (2 j, 2 j + 1) of accumulator half m = j / 4 -> one packed hi and one packed lo word of P[CUR][m]
+    // (10 VALU: 2 sub, 2 exp, 2 add, cvt_pkrtz, 2 fma_mix, cvt_pkrtz; 8 pairs per block).  Two partial row sums keep the add chain short.
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    auto sm_pair = [&](auto cur, auto jj) {
+        if constexpr (PROBE & 1) return;
+        constexpr int CUR = decltype(cur)::value, J = decltype(jj)::value, M = J >> 2, W = J & 3;
+        const float p0 = __builtin_amdgcn_exp2f(sacc[CUR][2 * J]);           // the accumulator holds score - m_run
+        const float p1 = __builtin_amdgcn_exp2f(sacc[CUR][2 * J + 1]);
+        l_a += p0;
+        l_b += p1;
+        half2v hi, lo;
+        split_pair(p0, p1, hi, lo);
+        u32x4 h4 = __builtin_bit_cast(u32x4, Phi[CUR][M]), l4 = __builtin_bit_cast(u32x4, Plo[CUR][M]);
+        h4[W] = __builtin_bit_cast(unsigned int, hi);
+        l4[W] = __builtin_bit_cast(unsigned int, lo);
+        Phi[CUR][M] = __builtin_bit_cast(half8, h4);
+        Plo[CUR][M] = __builtin_bit_cast(half8, l4);
+    };
+#define PARQ_FENCE() __builtin_amdgcn_sched_barrier(0)
+    // one pipelined step: QK(n + 1) -> sacc[NXT], softmax(n) from sacc[CUR] -> P[CUR], PV(n - 1) with P[NXT].  The order below IS the
+    // issue order (scheduling fences between the pieces): every MFMA is followed by at most one softmax pair, S^T and O^T
+    // accumulators alternate, fragment reads are issued a dozen MFMAs ahead of their use.
+    auto step = [&](auto cur, int n) {
+        constexpr int CUR = decltype(cur)::value, NXT = CUR ^ 1;
+        using IC = std::integral_constant<int, CUR>;
+        const _Float16* Vb = lds_blk(n > 0 ? n - 1 : 0);                  // n = 0: P[NXT] is zero, any finite V will do
+        // kf = K fragments of block n + 1 and vh / vl = V fragments (m = 0) of block n - 1 were requested by the previous step
+        PARQ_FENCE();
+        sm_pair(IC{}, std::integral_constant<int, 0>{});
+        PARQ_FENCE();
+#define PARQ_Q(i, A, Bq) if constexpr (!(PROBE & 4)) sacc[NXT] = mfma16<kF16>(A, Bq, (i) == 0 ? negm16 : sacc[NXT]); PARQ_FENCE()
+#define PARQ_P(D, A, Bp) if constexpr (!(PROBE & 2)) o[D] = mfma16<kF16>(A, Bp, o[D]); PARQ_FENCE()
+#define PARQ_S(J) sm_pair(IC{}, std::integral_constant<int, J>{}); PARQ_FENCE()
+        // m = 0 half of PV(n - 1), s = 0, 1 of QK(n + 1); 8 softmax pairs (16 scores per lane and block) spread over the 24 MFMAs
+        PARQ_Q(0, kf[0], qhi[0]);
+        PARQ_P(0, vh[0], Phi[NXT][0]);  PARQ_S(1);
+        PARQ_Q(1, kf[0], qlo[0]);
+        PARQ_P(1, vh[1], Phi[NXT][0]);
+        PARQ_Q(2, kf[1], qhi[0]);  PARQ_S(2);
+        PARQ_P(0, vl[0], Phi[NXT][0]);
+        PARQ_Q(3, kf[2], qhi[1]);
+        PARQ_P(1, vl[1], Phi[NXT][0]);  PARQ_S(3);
+        PARQ_Q(4, kf[2], qlo[1]);
+        PARQ_P(0, vh[0], Plo[NXT][0]);
+        PARQ_Q(5, kf[3], qhi[1]);
+        PARQ_P(1, vh[1], Plo[NXT][0]);
+        load_v(Vb, 1, vh, vl);                                            // m = 1 fragments (the m = 0 registers are free now)
+        PARQ_FENCE();
+        PARQ_S(4);
+        // m = 1 half, s = 2, 3
+        PARQ_Q(6, kf[4], qhi[2]);
+        PARQ_Q(7, kf[4], qlo[2]);  PARQ_S(5);
+        PARQ_Q(8, kf[5], qhi[2]);
+        PARQ_P(0, vh[0], Phi[NXT][1]);
+        PARQ_Q(9, kf[6], qhi[3]);  PARQ_S(6);
+        PARQ_P(1, vh[1], Phi[NXT][1]);
+        PARQ_Q(10, kf[6], qlo[3]);
+        PARQ_P(0, vl[0], Phi[NXT][1]);  PARQ_S(7);
+        PARQ_Q(11, kf[7], qhi[3]);
+        PARQ_P(1, vl[1], Phi[NXT][1]);
+        PARQ_P(0, vh[0], Plo[NXT][1]);
+        PARQ_P(1, vh[1], Plo[NXT][1]);
+#undef PARQ_Q
+#undef PARQ_P
+#undef PARQ_S
+        // fragments of the next step (K of block n + 2, clamped at the split's end; V of block n), in flight during the block maximum
+        load_k(lds_blk(n + 2 < nbk ? n + 2 : nbk - 1), kf);
+        load_v(lds_blk(n), 0, vh, vl);
+        PARQ_FENCE();
+        const float mx = block_max(sacc[NXT]);                              // relative to m_run
+        if (__any(mx > a.defer_log2)) move_reference(cur, n, mx);
+    };
+
+    if (nbk > 0) {
+        if (active) {
+            // prologue: scores of block 0 against a zero reference, then the reference becomes their maximum
+            load_k(lds_blk(0), kf);
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                sacc[0] = mfma16<kF16>(kf[2 * s], qhi[s], s == 0 ? zero16 : sacc[0]);
+                sacc[0] = mfma16<kF16>(kf[2 * s], qlo[s], sacc[0]);
+                sacc[0] = mfma16<kF16>(kf[2 * s + 1], qhi[s], sacc[0]);
+            }
+            if (nbk == 1 && last_partial) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (B0 * 32 + mfma32_row(r, lane) >= a.Lk) sacc[0][r] = -INFINITY;
+            }
+            m_run = block_max(sacc[0]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[0][r] -= m_run; negm16[r] = -m_run; }
+            load_k(lds_blk(nbk > 1 ? 1 : 0), kf);                          // fragments of step 0
+            load_v(lds_blk(0), 0, vh, vl);
+        }
+        // steady state: two steps (one LDS stage) per barrier
+        int n = 0;
+        for (; n + 2 < nbk; n += 2) {
+            if (active) {
+                step(std::integral_constant<int, 0>{}, n);
+                step(std::integral_constant<int, 1>{}, n + 1);
+            }
+            sync_point(n >> 1);
+        }
+        if (active) {
+            if (n + 1 < nbk) { step(std::integral_constant<int, 0>{}, n); ++n; }
+            // epilogue: softmax of the last block (ragged key axis masked here), PV of the last two blocks
+            auto finish = [&](auto cur) {
+                constexpr int CUR = decltype(cur)::value, NXT = CUR ^ 1;
+                if (last_partial) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if ((B0 + n) * 32 + mfma32_row(r, lane) >= a.Lk) sacc[CUR][r] = -INFINITY;
+                }
+                softmax_half(cur, 0);
+                softmax_half(cur, 1);
+                if (n > 0) {
+                    const _Float16* Vp = lds_blk(n - 1);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        half8 vh[2], vl[2];
+                        load_v(Vp, m, vh, vl);
+                        pv_half(std::integral_constant<int, NXT>{}, m, vh, vl);
+                    }
+                }
+                const _Float16* Vb = lds_blk(n);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    half8 vh[2], vl[2];
+                    load_v(Vb, m, vh, vl);
+                    pv_half(cur, m, vh, vl);
+                }
+            };
+            if (n & 1) finish(std::integral_constant<int, 1>{});
+            else finish(std::integral_constant<int, 0>{});
+        }
+    } else if (active) {
+        m_run = -INFINITY;                                                 // a split without keys: weight 0 in the merge
+    }
+
+    if (active) {
+        const int64_t pbase = (int64_t)bh * a.nsplit + split;
+        float* op = a.o_part + pbase * kDH * Lq_pad;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) op[(int64_t)(d * 32 + mfma32_row(r, lane)) * Lq_pad + q] = o[d][r];
+        const float l_tot = xhalf_sum(l_run + l_a + l_b);
+        if (kh == 0) {
+            a.m_part[pbase * Lq_pad + q] = m_run;
+            a.l_part[pbase * Lq_pad + q] = l_tot;
+        }
+    }
+}
+
 }  // namespace
 
 size_t kvsplit_cache_bytes(int B, int H, int N, int terms) {
@@ -510,6 +881,39 @@ hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t
     FlashArgs b = a;
     static const float defer = [] { const char* e = getenv("PARQ_DEFER_LOG2"); return e ? (float)atof(e) : kDeferLog2; }();   // debugging knob, read once
     b.defer_log2 = defer;
+    if (terms == 3 && !(b.drop_p > 0.f)) {
+        static const bool v1 = [] { const char* e = getenv("PARQ_FLASH_V"); return e && e[0] == '1'; }();    // A/B: the two-blocks-per-stage kernel
+        if (!v1) {
+            static const int ring = [] { const char* e = getenv("PARQ_FLASH_RING"); return e && e[0] == '5' ? 5 : 4; }();
+            static DynLdsOnce once4, once5;
+            const size_t lds = (size_t)ring * kStageBlks * Blk<3>::bytes;
+            dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * b.H);
+            static const int probe = [] { const char* e = getenv("PARQ_FLASH_PROBE"); return e ? atoi(e) : 0; }();
+            if (probe) {
+#define PARQ_PROBE_CASE(P)                                                                                                                    \
+    case P: {                                                                                                                                 \
+        static DynLdsOnce oncep;                                                                                                              \
+        if (hipError_t e = oncep.ensure(reinterpret_cast<const void*>(&flash_split_pipe_kernel<4, P>), (size_t)4 * kStageBlks * Blk<3>::bytes); e != hipSuccess) return e; \
+        hipLaunchKernelGGL((flash_split_pipe_kernel<4, P>), grid, dim3(kNW * 64), (size_t)4 * kStageBlks * Blk<3>::bytes, s, b, reinterpret_cast<const _Float16*>(cache)); \
+        return hipGetLastError();                                                                                                             \
+    }
+                switch (probe) {
+                    PARQ_PROBE_CASE(1) PARQ_PROBE_CASE(2) PARQ_PROBE_CASE(4) PARQ_PROBE_CASE(6) PARQ_PROBE_CASE(7) PARQ_PROBE_CASE(8)
+                    PARQ_PROBE_CASE(9) PARQ_PROBE_CASE(16) PARQ_PROBE_CASE(17) PARQ_PROBE_CASE(25) PARQ_PROBE_CASE(31)
+                    default: return hipErrorInvalidValue;
+                }
+#undef PARQ_PROBE_CASE
+            }
+            if (ring == 5) {
+                if (hipError_t e = once5.ensure(reinterpret_cast<const void*>(&flash_split_pipe_kernel<5>), lds); e != hipSuccess) return e;
+                hipLaunchKernelGGL(flash_split_pipe_kernel<5>, grid, dim3(kNW * 64), lds, s, b, reinterpret_cast<const _Float16*>(cache));
+            } else {
+                if (hipError_t e = once4.ensure(reinterpret_cast<const void*>(&flash_split_pipe_kernel<4>), lds); e != hipSuccess) return e;
+                hipLaunchKernelGGL(flash_split_pipe_kernel<4>, grid, dim3(kNW * 64), lds, s, b, reinterpret_cast<const _Float16*>(cache));
+            }
+            return hipGetLastError();
+        }
+    }
     if (terms == 3) return b.drop_p > 0.f ? launch_flash_t<3, kF16, true>(b, cache, s) : launch_flash_t<3, kF16>(b, cache, s);
     if (b.drop_p > 0.f) return hipErrorInvalidValue;           // dropout exists on the fp32-accurate paths only
     return kind == kF16 ? launch_flash_t<1, kF16>(b, cache, s) : launch_flash_t<1, kBF16>(b, cache, s);
