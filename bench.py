@@ -95,18 +95,45 @@ def cpu_baseline(cfg, W, inputs, min_seconds=12.0, max_iters=24):
                       % (budget_iters, dt, os.cpu_count() or 0)}
 
 
+def project_sample_b32(dec, device, h, w, scenes=32, steps=2):
+    """The HBM-bound gather at a size that does not fit the 256 MB Infinity Cache (BASELINE.md §3/§4 ask for B = 1 AND B = 32):
+    `scenes` synthetic scenes of the same workload (32 x 197 MB of tokens = 6.3 GB) through the same PARQDecoder.forward, the
+    project+sample launches timed by the library's hipEvents on the launch stream.  Algorithmic bytes per launch =
+    (4*V*Q*C + Q*C)*4 per scene."""
+    V, Q, C = WORKLOAD["views"], WORKLOAD["queries"], WORKLOAD["dim"]
+    inputs = build_inputs(scenes, device, seed=4242)
+    dec(*inputs, feat_hw=(h, w))                                   # warm-up (allocates the 32-scene workspace)
+    dec.profile_enable(True)
+    for _ in range(steps):
+        dec(*inputs, feat_hw=(h, w))
+    torch.cuda.synchronize()
+    prof = dec.profile_read()
+    dec.profile_enable(False)
+    ms, n = prof["project_sample"]
+    fw_ms = sum(v[0] for v in prof.values()) / steps
+    bytes_per_launch = (4.0 * V * Q * C + Q * C) * 4.0 * scenes
+    gbs = bytes_per_launch / (ms / n * 1e-3) / 1e9
+    del inputs
+    dec._ws.clear()
+    torch.cuda.empty_cache()
+    return {"bound": "hbm", "kernel": "project_sample_kernel", "scenes": scenes, "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": gbs / PEAK_HBM_GBS, "traffic": pmc_traffic("project_sample_kernel", scenes),
+            "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": ms / n, "launches": n,
+            "forward_kernel_ms_at_%d_scenes" % scenes: fw_ms,
+            "note": "tokens of %d scenes = %.1f GB (past the 256 MB Infinity Cache): a bandwidth figure; the B = 1 entry "
+                    "(roofline_project_sample) is latency-bound" % (scenes, scenes * V * h * w * C * 4 / 1e9)}
+
+
 def pmc_traffic(kernel, scenes):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc.json, written from
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r02_pmc.json, written from
     `tools/collect_profiles.sh` output: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950 wide streaming reads).  Counters cannot be read from inside this process,
     so the figure is the recorded one for the same kernel and scene count, or null."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc.json")
     try:
         with open(path) as f:
             rec = json.load(f)
-        e = rec["kernels"][kernel]
-        if rec.get("scenes_per_gpu") != scenes:
-            return None
+        e = rec["by_scenes"][str(scenes)][kernel]
         return (e["fetch_kb"] * e.get("fetch_correction", 2.0) + e["write_kb"]) * 1024.0
     except Exception:
         return None
@@ -223,6 +250,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scenes-per-gpu", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-b32", action="store_true", help="skip the 32-scene project+sample bandwidth measurement (6.3 GB of tokens)")
     ap.add_argument("--attention-mode", default=None, choices=["split", "fp32", "fp16", "bf16"],
                     help="cross-attention arithmetic; default = the library default (split: fp32-class accuracy). "
                          "fp16 / bf16 are the reduced-precision configurations (NOT the headline number)")
@@ -299,14 +327,14 @@ def main():
                      PEAK_F16_MATRIX_TFLOPS if half else PEAK_F32_MATRIX_TFLOPS)
         kv_bytes = 2.0 * N * C * (2.0 if half else 4.0) * B
         roofline = {"bound": "mfma",
-                    "kernel": (("flash_split_kernel<3>" if C // WORKLOAD["heads"] == 64 else "flash_split256_kernel") +
+                    "kernel": (("flash_split_pipe_kernel" if C // WORKLOAD["heads"] == 64 else "flash_split256_kernel") +
                                " (cross-attention QK^T+PV, fp16 hi/lo 3-term products, fp32 accumulate)" if split
                                else "flash_split_kernel<1> (cross-attention QK^T+PV, single %s products, fp32 accumulate)" % mode if half
                                else "flash_f32_kernel (cross-attention QK^T+PV, fp32 MFMA)"),
                     "achieved": ach_tflops, "peak": mfma_peak, "unit": "TFLOP/s",
                     "frac": (ach_tflops / mfma_peak) if ach_tflops else None,
-                    "traffic": pmc_traffic("flash_split_kernel", B) if (split and C == 256) else None,
-                    "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc.json); algorithmic stream = 2*N*C*4*B bytes",
+                    "traffic": pmc_traffic("flash_split_pipe_kernel", B) if (split and C == 256) else None,
+                    "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_pmc.json); algorithmic stream = 2*N*C*4*B bytes",
                     "avg_launch_ms": (ca_ms / ca_n) if ca_n else None, "launches": ca_n,
                     "algorithmic_gflop_per_launch": flop_per_launch / 1e9,
                     "peak_note": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 passes per product; the fp32-MFMA peak is %.1f"
@@ -326,16 +354,21 @@ def main():
                                    "256 queries, 8 iterations, d=%d, 4 heads, FFN 768, ResNet-FPN-shaped synthetic features" % C,
                        "scenes_per_gpu": B, "parallelism": "dp%d (scene-sharded, no data-path collective)" % world},
             "roofline": roofline,
-            "roofline_project_sample": {"bound": "hbm", "kernel": "project_sample_kernel",
+            "roofline_project_sample": {"bound": "hbm", "kernel": "project_sample_kernel", "scenes": B,
                                         "achieved": ps_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                         "frac": (ps_gbs / PEAK_HBM_GBS) if ps_gbs else None,
                                         "traffic": pmc_traffic("project_sample_kernel", B),
                                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                                        "avg_launch_ms": (ps_ms / ps_n) if ps_n else None, "launches": ps_n},
+                                        "avg_launch_ms": (ps_ms / ps_n) if ps_n else None, "launches": ps_n,
+                                        "note": ("latency-bound at one scene: a %.1f us launch over a 197 MB token tensor that sits in the 256 MB "
+                                                 "Infinity Cache; the bandwidth figure is roofline_project_sample_b32" % (ps_ms / ps_n * 1e3))
+                                                if (B == 1 and ps_n) else None},
             "kernel_groups_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
         }
         if C == 256:
             out["ray_pe"] = ray_pe_timing(B, device)
+        if world == 1 and C == 256 and B == 1 and not args.no_b32:
+            out["roofline_project_sample_b32"] = project_sample_b32(dec, device, h, w)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, W, inputs)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
