@@ -186,6 +186,7 @@ struct FlashArgs {
     float defer_log2;           // split kernel: running max moves only past this margin (0 = always)
     float* lse;                 // optional [B*H][Lq_pad]: log2-domain log-sum-exp of every query row (training)
     float drop_p; uint32_t drop_seed;   // training: dropout on the attention probabilities, element (row bh * Lq + q, col key)
+    int flags;                  // bit 0: raise the priority of the younger half of the workgroup (pipelined split kernel)
 };
 int flash_key_tile(int dh);                    // keys per LDS tile
 int flash_lq_pad(int Lq);

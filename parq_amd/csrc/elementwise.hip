@@ -11,6 +11,7 @@
 // All of these are HBM- or latency-bound: wide coalesced loads, one wave per row
 // (or per query-view pair), wavefront/LDS reductions, no MFMA.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace parq {
 
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(1024) void gn_stats_kernel(const float* __restrict_
 constexpr int kMaxCls = 32;
 
 __global__ __launch_bounds__(256) void box_decode_kernel(BoxDecodeArgs a) {
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (m >= a.M) return;
     const int lane = threadIdx.x & 63;
     const int C = a.C;
@@ -509,7 +510,10 @@ hipError_t launch_gn_stats(const float* X, int64_t ldx, int col0, int ncols, int
 
 hipError_t launch_box_decode(const BoxDecodeArgs& a, hipStream_t s) {
     if (a.ncls > kMaxCls || a.ncls < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(box_decode_kernel, dim3(ceil_div(a.M, 4)), dim3(256), 0, s, a);
+    // one row per wave; rows per workgroup: 1 while that still leaves CUs idle (pure latency: spread the rows over the chip), else 4
+    static const int rows_env = [] { const char* e = getenv("PARQ_DECODE_ROWS"); return e ? atoi(e) : 0; }();
+    const int rows = (rows_env >= 1 && rows_env <= 4) ? rows_env : (a.M <= 2 * device_num_cus() ? 1 : 4);
+    hipLaunchKernelGGL(box_decode_kernel, dim3(ceil_div(a.M, rows)), dim3(rows * 64), 0, s, a);
     return hipGetLastError();
 }
 

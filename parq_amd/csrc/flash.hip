@@ -20,6 +20,7 @@
 //   * grid = (key splits, query tiles, B*H): splits give >= 1-2 workgroups per CU even
 //     for B = 1; partial (O, m, l) are combined by flash_merge_kernel.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace parq {
 
@@ -221,14 +222,16 @@ __global__ __launch_bounds__(NW * 64) void flash_f32_kernel(FlashArgs a) {
 // (>= 128 workgroups at B = 1), each thread streams 16-byte rows of 4 queries for one d over half of the
 // splits, 8 loads deep; halves are reduced and the tile transposed through LDS so the output rows
 // (d-contiguous) are written coalesced.
-constexpr int kMergeDG = 16;
-
-template <int DH>
+// DG: head dims per workgroup (grid.z = DH / DG).  16 -> 2 split groups per (query, d); 8 -> 4 groups and twice the workgroups:
+// at one scene (4 heads x 8 query tiles) 256 workgroups instead of 128, i.e. the whole chip for this latency-bound pass.
+template <int DH, int DG>
 __global__ __launch_bounds__(256) void flash_merge_kernel(FlashArgs a) {
+    constexpr int kMergeDG = DG;
+    constexpr int NG = 256 / (8 * DG);               // split groups
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wsm = smem;                               // [nsplit][32]
     float* dsm = wsm + a.nsplit * 32;                // [8][32]
-    float* part = dsm + 8 * 32;                      // [2 halves][kMergeDG][32]
+    float* part = dsm + 8 * 32;                      // [NG split groups][kMergeDG][32]
     const int bh = blockIdx.y;
     const int b = bh / a.H;
     const int h = bh - b * a.H;
@@ -279,12 +282,12 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(FlashArgs a) {
     const float inv = 1.f / den;
     if (a.lse && blockIdx.z == 0 && td == 0 && q < a.Lq) a.lse[(int64_t)bh * Lq_pad + q] = mmax + log2f(den);
 
-    // thread -> (4 queries, one d, one half of the splits)
+    // thread -> (4 queries, one d, one of NG groups of the splits)
     const int q4 = threadIdx.x & 7;
-    const int dd = (threadIdx.x >> 3) & 15;
-    const int half = threadIdx.x >> 7;
-    const int s_begin = half ? (a.nsplit + 1) / 2 : 0;
-    const int s_end = half ? a.nsplit : (a.nsplit + 1) / 2;
+    const int dd = (threadIdx.x >> 3) & (DG - 1);
+    const int half = threadIdx.x / (8 * DG);
+    const int s_begin = (int)((int64_t)half * a.nsplit / NG);
+    const int s_end = (int)((int64_t)(half + 1) * a.nsplit / NG);
     const int64_t sstride = (int64_t)DH * Lq_pad;
     const float* o0 = a.o_part + (pb * DH + dg0 + dd) * (int64_t)Lq_pad + q0 + q4 * 4;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -307,8 +310,10 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(FlashArgs a) {
             float dn = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) dn += dsm[i * 32 + qq];
-            a.out[(int64_t)b * a.out_batch + (int64_t)(q0 + qq) * a.out_row + h * DH + dg0 + d] =
-                (part[d * 32 + qq] + part[(kMergeDG + d) * 32 + qq]) / dn;
+            float acc2 = 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < NG; ++g2) acc2 += part[(g2 * kMergeDG + d) * 32 + qq];
+            a.out[(int64_t)b * a.out_batch + (int64_t)(q0 + qq) * a.out_row + h * DH + dg0 + d] = acc2 / dn;
         }
     }
     (void)inv;
@@ -498,11 +503,20 @@ hipError_t launch_dh(const FlashArgs& a, int nw, hipStream_t s) {
 
 template <int DH>
 hipError_t merge_dh(const FlashArgs& a, hipStream_t s) {
-    const size_t lds = ((size_t)a.nsplit * 32 + 8 * 32 + (size_t)2 * kMergeDG * 32) * sizeof(float);
-    static DynLdsOnce once;
-    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_merge_kernel<DH>), 96 * 1024); e != hipSuccess) return e;
-    dim3 grid(ceil_div(a.Lq, 32), a.B * a.H, DH / kMergeDG);
-    hipLaunchKernelGGL((flash_merge_kernel<DH>), grid, dim3(256), lds, s, a);
+    const size_t lds = ((size_t)a.nsplit * 32 + 8 * 32 + (size_t)2 * 16 * 32) * sizeof(float);
+    static const int dg_env = [] { const char* e = getenv("PARQ_MERGE_DG"); return e ? atoi(e) : 0; }();
+    // 8 dims per workgroup while that is what it takes to cover the chip (one scene), else 16
+    const int64_t wg16 = (int64_t)ceil_div(a.Lq, 32) * a.B * a.H * (DH / 16);
+    const int dg = dg_env == 8 || dg_env == 16 ? dg_env : (wg16 < device_num_cus() ? 8 : 16);
+    if (dg == 8) {
+        static DynLdsOnce once;
+        if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_merge_kernel<DH, 8>), 96 * 1024); e != hipSuccess) return e;
+        hipLaunchKernelGGL((flash_merge_kernel<DH, 8>), dim3(ceil_div(a.Lq, 32), a.B * a.H, DH / 8), dim3(256), lds, s, a);
+    } else {
+        static DynLdsOnce once;
+        if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_merge_kernel<DH, 16>), 96 * 1024); e != hipSuccess) return e;
+        hipLaunchKernelGGL((flash_merge_kernel<DH, 16>), dim3(ceil_div(a.Lq, 32), a.B * a.H, DH / 16), dim3(256), lds, s, a);
+    }
     return hipGetLastError();
 }
 

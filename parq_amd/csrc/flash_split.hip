@@ -741,6 +741,9 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
         if (__any(mx > a.defer_log2)) move_reference(cur, n, mx);
     };
 
+    // the second-dispatched half of the workgroup loses every VALU arbitration against the older half (priority, then age):
+    // one static s_setprio for it, no per-phase flips (MI355X_MICROARCH.md, two waves per SIMD)
+    if ((a.flags & 1) && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
     if (nbk > 0) {
         if (active) {
             // prologue: scores of block 0 against a zero reference, then the reference becomes their maximum
@@ -881,6 +884,8 @@ hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t
     FlashArgs b = a;
     static const float defer = [] { const char* e = getenv("PARQ_DEFER_LOG2"); return e ? (float)atof(e) : kDeferLog2; }();   // debugging knob, read once
     b.defer_log2 = defer;
+    static const int prio = [] { const char* e = getenv("PARQ_FLASH_PRIO"); return e ? atoi(e) : 0; }();
+    b.flags = prio;
     if (terms == 3 && !(b.drop_p > 0.f)) {
         static const bool v1 = [] { const char* e = getenv("PARQ_FLASH_V"); return e && e[0] == '1'; }();    // A/B: the two-blocks-per-stage kernel
         if (!v1) {
