@@ -388,6 +388,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         Prof p(c, s, PARQ_PROF_CROSS_ATTN);
         fa.q = wi + ws.qc; fa.q_batch = (int64_t)Q * C; fa.q_head = dh; fa.q_row = C;
         fa.Lk = (int)N; fa.nsplit = ws.cross_split;
+        fa.flags = (layer_num & 1) ? 2 : 0;             // odd iterations sweep the K/V cache backwards (Infinity Cache reuse)
         const int64_t lp = flash_lq_pad(Q);
         fa.o_part = wsp + ws.flash;
         fa.m_part = fa.o_part + (int64_t)B * H * fa.nsplit * dh * lp;

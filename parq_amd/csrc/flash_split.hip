@@ -546,15 +546,23 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
             int64_t idx = (int64_t)st * STAGE16 + tid + i * NT;
             idx = idx < total16 ? idx : total16 - 1;
             lds_byte* dst = (lds_byte*)(smem_h) + ((size_t)slot * STAGE16 + i * NT + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds(gsrc + idx, dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(gsrc + idx, dst, 16, 0, 0);      // (nt policy, aux = 2: measured 2 us slower per launch)
         }
     };
-    // local block n -> its 16 KB image in the ring (stage j = n / 2 lives in slot j % RING)
-    auto lds_blk = [&](int n) -> const _Float16* { return smem_h + (size_t)((((n >> 1) % RING) << 1) | (n & 1)) * kBlkHalfs; };
+    // Direction of the sweep over this split's stages.  The K/V cache (393 MB at BASELINE cfg 3) does not fit the 256 MB Infinity
+    // Cache, and every recurrent iteration streams all of it: with the same direction each time an LRU-like cache never hits.
+    // Odd iterations therefore walk their stages (and the two blocks of a stage) backwards, starting on what the previous launch
+    // touched last.  Only for key counts that are a multiple of 64 (whole stages, no ragged block); a.flags bit 1.
+    const bool rev = (a.flags & 2) != 0;
+    auto src_stage = [&](int j) { return rev ? t_end - 1 - j : t_begin + j; };
+    // local block n -> its 16 KB image in the ring (local stage j = n / 2 lives in slot j % RING; backwards: block 1 of a stage first)
+    auto lds_blk = [&](int n) -> const _Float16* {
+        return smem_h + (size_t)((((n >> 1) % RING) << 1) | (rev ? 1 - (n & 1) : (n & 1))) * kBlkHalfs;
+    };
 
 #pragma unroll
     for (int j = 0; j < RING - 1; ++j)
-        if (t_begin + j < t_end) gload(t_begin + j, j);
+        if (t_begin + j < t_end) gload(src_stage(j), j);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // after the step of local block 2 j + 1: stage j + 2 must be visible to every wave (its K is read two steps later); it was
@@ -566,7 +574,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-        if (t_begin + j + RING - 1 < t_end) gload(t_begin + j + RING - 1, (j + RING - 1) % RING);
+        if (t_begin + j + RING - 1 < t_end) gload(src_stage(j + RING - 1), (j + RING - 1) % RING);
     };
 
     f32x16 o[2], sacc[2];
@@ -696,48 +704,55 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
         const _Float16* Vb = lds_blk(n > 0 ? n - 1 : 0);                  // n = 0: P[NXT] is zero, any finite V will do
         // kf = K fragments of block n + 1 and vh / vl = V fragments (m = 0) of block n - 1 were requested by the previous step
         PARQ_FENCE();
-        sm_pair(IC{}, std::integral_constant<int, 0>{});
-        PARQ_FENCE();
 #define PARQ_Q(i, A, Bq) if constexpr (!(PROBE & 4)) sacc[NXT] = mfma16<kF16>(A, Bq, (i) == 0 ? negm16 : sacc[NXT]); PARQ_FENCE()
 #define PARQ_P(D, A, Bp) if constexpr (!(PROBE & 2)) o[D] = mfma16<kF16>(A, Bp, o[D]); PARQ_FENCE()
 #define PARQ_S(J) sm_pair(IC{}, std::integral_constant<int, J>{}); PARQ_FENCE()
-        // m = 0 half of PV(n - 1), s = 0, 1 of QK(n + 1); 8 softmax pairs (16 scores per lane and block) spread over the 24 MFMAs
+        // m = 0 half of PV(n - 1), s = 0, 1 of QK(n + 1); 8 softmax pairs (16 scores per lane and block), one behind every third MFMA
         PARQ_Q(0, kf[0], qhi[0]);
-        PARQ_P(0, vh[0], Phi[NXT][0]);  PARQ_S(1);
+        PARQ_P(0, vh[0], Phi[NXT][0]);  PARQ_S(0);
         PARQ_Q(1, kf[0], qlo[0]);
         PARQ_P(1, vh[1], Phi[NXT][0]);
-        PARQ_Q(2, kf[1], qhi[0]);  PARQ_S(2);
+        PARQ_Q(2, kf[1], qhi[0]);  PARQ_S(1);
         PARQ_P(0, vl[0], Phi[NXT][0]);
         PARQ_Q(3, kf[2], qhi[1]);
-        PARQ_P(1, vl[1], Phi[NXT][0]);  PARQ_S(3);
+        PARQ_P(1, vl[1], Phi[NXT][0]);  PARQ_S(2);
         PARQ_Q(4, kf[2], qlo[1]);
         PARQ_P(0, vh[0], Plo[NXT][0]);
-        PARQ_Q(5, kf[3], qhi[1]);
+        PARQ_Q(5, kf[3], qhi[1]);  PARQ_S(3);
         PARQ_P(1, vh[1], Plo[NXT][0]);
         load_v(Vb, 1, vh, vl);                                            // m = 1 fragments (the m = 0 registers are free now)
         PARQ_FENCE();
-        PARQ_S(4);
         // m = 1 half, s = 2, 3
         PARQ_Q(6, kf[4], qhi[2]);
-        PARQ_Q(7, kf[4], qlo[2]);  PARQ_S(5);
+        PARQ_Q(7, kf[4], qlo[2]);  PARQ_S(4);
         PARQ_Q(8, kf[5], qhi[2]);
         PARQ_P(0, vh[0], Phi[NXT][1]);
-        PARQ_Q(9, kf[6], qhi[3]);  PARQ_S(6);
+        PARQ_Q(9, kf[6], qhi[3]);  PARQ_S(5);
         PARQ_P(1, vh[1], Phi[NXT][1]);
         PARQ_Q(10, kf[6], qlo[3]);
-        PARQ_P(0, vl[0], Phi[NXT][1]);  PARQ_S(7);
+        PARQ_P(0, vl[0], Phi[NXT][1]);  PARQ_S(6);
         PARQ_Q(11, kf[7], qhi[3]);
-        PARQ_P(1, vl[1], Phi[NXT][1]);
+        PARQ_P(1, vl[1], Phi[NXT][1]);  PARQ_S(7);
         PARQ_P(0, vh[0], Plo[NXT][1]);
+        // the maximum of the new scores (QK finished three MFMAs ago) is taken behind the last two PV MFMAs
+        float mx_lane;
+        {
+            const f32x16& S = sacc[NXT];
+            float m0 = fmaxf(S[0], S[1]), m1 = fmaxf(S[8], S[9]);
+#pragma unroll
+            for (int r = 2; r < 8; ++r) { m0 = fmaxf(m0, S[r]); m1 = fmaxf(m1, S[8 + r]); }
+            mx_lane = fmaxf(m0, m1);
+        }
+        PARQ_FENCE();
         PARQ_P(1, vh[1], Plo[NXT][1]);
 #undef PARQ_Q
 #undef PARQ_P
 #undef PARQ_S
-        // fragments of the next step (K of block n + 2, clamped at the split's end; V of block n), in flight during the block maximum
+        // fragments of the next step (K of block n + 2, clamped at the split's end; V of block n), in flight during the reduction
         load_k(lds_blk(n + 2 < nbk ? n + 2 : nbk - 1), kf);
         load_v(lds_blk(n), 0, vh, vl);
         PARQ_FENCE();
-        const float mx = block_max(sacc[NXT]);                              // relative to m_run
+        const float mx = xhalf_max(mx_lane);                                 // relative to m_run
         if (__any(mx > a.defer_log2)) move_reference(cur, n, mx);
     };
 
@@ -885,7 +900,9 @@ hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t
     static const float defer = [] { const char* e = getenv("PARQ_DEFER_LOG2"); return e ? (float)atof(e) : kDeferLog2; }();   // debugging knob, read once
     b.defer_log2 = defer;
     static const int prio = [] { const char* e = getenv("PARQ_FLASH_PRIO"); return e ? atoi(e) : 0; }();
-    b.flags = prio;
+    static const bool alt = [] { const char* e = getenv("PARQ_FLASH_ALTERNATE"); return !(e && e[0] == '0'); }();
+    // bit 1 (set by the caller for every other recurrent iteration): sweep backwards — only where the pipelined kernel supports it
+    b.flags = (prio & 1) | ((alt && (a.flags & 2) && (a.Lk % (kStageBlks * kBlkKeys)) == 0) ? 2 : 0);
     if (terms == 3 && !(b.drop_p > 0.f)) {
         static const bool v1 = [] { const char* e = getenv("PARQ_FLASH_V"); return e && e[0] == '1'; }();    // A/B: the two-blocks-per-stage kernel
         if (!v1) {
