@@ -164,8 +164,9 @@ int parq_profile_enable(parq_handle h, int32_t on);
 int parq_profile_read(parq_handle h, int32_t which, double *total_ms, int64_t *launches);
 
 /* ---- training: forward with saved activations + backward (model/parq_lightning.py:97-100) ----------
- * The backward of the whole decoder chain as HIP kernels.  Attention mode 0 or 1 (in mode 1 the forward streams the split
- * cache and the backward gets fp32 K / V rebuilt from it).  Head dims 32 / 64 have register-resident attention backward kernels; any
+ * The backward of the whole decoder chain as HIP kernels.  Every attention mode (in the cache modes 1 - 3 the forward streams the
+ * 16-bit cache and the backward gets fp32 K / V rebuilt from it: hi + lo in mode 1, the rounded values themselves in the fp16 /
+ * bf16 modes 2 / 3, i.e. the gradient is taken straight through the operand rounding of the reduced-precision forward).  Head dims 32 / 64 have register-resident attention backward kernels; any
  * other multiple of 16 (e.g. 256, the reference's shipped size) runs a materialised fp32 path (functional, ~10x slower).  parq_forward_train = parq_forward that keeps every iteration's activations in the (larger)
  * training workspace; parq_backward consumes them: `grads` holds d loss / d output per iteration (same (I,B,Q,k) layout as
  * the outputs, NULL = zero), `grad_arena` receives d loss / d weight in the layout of the packed weight arena

@@ -1006,8 +1006,6 @@ int parq_forward_train(parq_handle h, const parq_scene* scene, void* workspace, 
                        parq_stream stream) {
     if (!h || !workspace) return fail(PARQ_ERR_ARG, "NULL argument");
     if (!h->packed) return fail(PARQ_ERR_STATE, "parq_pack_weights must be called first");
-    if (h->cache_mode() && h->terms() != 3)
-        return fail(PARQ_ERR_STATE, "training needs attention mode 0 or 1 (the backward works on fp32-accurate K / V)");
     if (h->dh % 16 != 0) return fail(PARQ_ERR_ARG, "training needs a head dim that is a multiple of 16");
     int rc = check_scene(h, scene);
     if (rc) return rc;
@@ -1022,14 +1020,15 @@ int parq_forward_train(parq_handle h, const parq_scene* scene, void* workspace, 
     if (rc) return rc;
     const int64_t M = (int64_t)scene->B * h->Q;
     if (h->cache_mode()) {
-        // split mode: the forward streams the split cache; the backward gets fp32 K / V rebuilt from it (hi + lo)
+        // cache modes: the forward streams the 16-bit cache; the backward gets fp32 K / V rebuilt from it (hi + lo; in the fp16 /
+        // bf16 modes the rounded values themselves: the gradient is taken straight through the rounding)
         const int64_t N = (int64_t)scene->V * scene->h * scene->w;
         const int C = h->C, dh = h->dh, H = h->H, B = scene->B;
         for (int li = 0; li < h->nl; ++li) {
-            const char* cache = reinterpret_cast<const char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, h->vheads(), (int)N, 3);
+            const char* cache = reinterpret_cast<const char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, h->vheads(), (int)N, h->terms());
             float* kv = wsp + ws.kv_train + (int64_t)li * B * 2 * N * C;
             HIPCHK(launch_kvsplit_to_f32(cache, B, h->vheads(), (int)N, kv, kv + (int64_t)H * N * dh, 2 * N * C, N * dh, 2 * N * C, N * dh, s,
-                                         dh / 64));
+                                         dh / 64, h->terms(), h->kind()));
         }
     }
     // the reference points of iteration k live in that iteration's stash (initial_ref wrote ws.ref)
@@ -1057,7 +1056,6 @@ int parq_backward(parq_handle h, const parq_scene* scene, void* workspace, size_
                   const parq_output_grads* g, float* grad_arena, float* d_tokens, parq_stream stream) {
     if (!h || !workspace || !outs || !g || !grad_arena) return fail(PARQ_ERR_ARG, "NULL argument");
     if (!h->packed) return fail(PARQ_ERR_STATE, "parq_pack_weights must be called first");
-    if (h->cache_mode() && h->terms() != 3) return fail(PARQ_ERR_STATE, "training needs attention mode 0 or 1");
     int rc = check_scene(h, scene);
     if (rc) return rc;
     Workspace ws;

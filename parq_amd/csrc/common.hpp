@@ -214,7 +214,8 @@ hipError_t launch_kvsplit_convert(const float* K, const float* V, int64_t k_batc
                                   int* overflow_flag, hipStream_t s, int terms = 3, int kind = kF16);
 // split cache (terms = 3) -> fp32 head-major K / V ([n][64] rows per (b, h))
 hipError_t launch_kvsplit_to_f32(const void* cache, int B, int H, int N, float* K, float* V, int64_t k_batch, int64_t k_head,
-                                 int64_t v_batch, int64_t v_head, hipStream_t s, int chunks = 1);   // H cache heads = model heads x chunks
+                                 int64_t v_batch, int64_t v_head, hipStream_t s, int chunks = 1,   // H cache heads = model heads x chunks
+                                 int terms = 3, int kind = kF16);                                   // terms = 1: the single 16-bit cache
 hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t s, int terms = 3,
                               int kind = kF16);   // partials; merge as usual
 // kvproj_split.hip: tokens -> split cache directly (W pre-split with launch_split_f32)

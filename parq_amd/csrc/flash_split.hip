@@ -120,6 +120,9 @@ __global__ __launch_bounds__(256) void kvsplit_convert_kernel(const float* __res
 // the split cache and hands the backward kernels plain fp32 K / V rebuilt from it (instead of a second, fp32 projection).
 // H counts the heads of the CACHE (64 dims each); a model head of 64 * chunks dims is `chunks` consecutive cache heads and comes
 // out as one [N][64 * chunks] plane (k_head / v_head are the strides of MODEL heads).
+// TERMS = 1 (the fp16 / bf16 modes): the cache holds one rounded 16-bit value per element; the backward then differentiates through
+// exactly the values the forward multiplied (straight-through the rounding).
+template <int TERMS, int KIND>
 __global__ __launch_bounds__(256) void kvsplit_to_f32_kernel(const _Float16* __restrict__ cache, int H, int N, float* __restrict__ K,
                                                              float* __restrict__ V, int64_t k_batch, int64_t k_head, int64_t v_batch,
                                                              int64_t v_head, int chunks) {
@@ -127,19 +130,25 @@ __global__ __launch_bounds__(256) void kvsplit_to_f32_kernel(const _Float16* __r
     const int b = bh / H, h = bh - b * H;
     const int nblk = (N + 31) / 32;
     const int row = 64 * chunks;
-    const _Float16* in = cache + ((int64_t)bh * nblk + blk) * Blk<3>::halfs;
+    const _Float16* in = cache + ((int64_t)bh * nblk + blk) * Blk<TERMS>::halfs;
+    auto val = [](half8 hi, half8 lo, int e) -> float {
+        if constexpr (TERMS == 3) return (float)hi[e] + (float)lo[e];
+        else if constexpr (KIND == kF16) return (float)hi[e];
+        else return (float)__builtin_bit_cast(bf16x8, hi)[e];
+    };
     float* kp = K + (int64_t)b * k_batch + (int64_t)(h / chunks) * k_head + (h % chunks) * 64;
     float* vp = V + (int64_t)b * v_batch + (int64_t)(h / chunks) * v_head + (h % chunks) * 64;
     {   // K: thread -> (key, stored chunk position)
         const int key = threadIdx.x >> 3, pos = threadIdx.x & 7;
         const int c = pos ^ ((key >> 1) & 7), kh = c >> 2, s2 = c & 3;
         const half8 hi = *reinterpret_cast<const half8*>(in + key * 64 + pos * 8);
-        const half8 lo = *reinterpret_cast<const half8*>(in + Blk<3>::k_lo + key * 64 + pos * 8);
+        half8 lo = hi;
+        if constexpr (TERMS == 3) lo = *reinterpret_cast<const half8*>(in + Blk<3>::k_lo + key * 64 + pos * 8);
         const int n = blk * 32 + key;
         if (n < N) {
             const int d0 = 32 * (s2 >> 1) + 16 * (s2 & 1) + 4 * kh;
-            float4 a = {(float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]};
-            float4 c4 = {(float)hi[4] + (float)lo[4], (float)hi[5] + (float)lo[5], (float)hi[6] + (float)lo[6], (float)hi[7] + (float)lo[7]};
+            float4 a = {val(hi, lo, 0), val(hi, lo, 1), val(hi, lo, 2), val(hi, lo, 3)};
+            float4 c4 = {val(hi, lo, 4), val(hi, lo, 5), val(hi, lo, 6), val(hi, lo, 7)};
             *reinterpret_cast<float4*>(kp + (int64_t)n * row + d0) = a;
             *reinterpret_cast<float4*>(kp + (int64_t)n * row + d0 + 8) = c4;
         }
@@ -147,12 +156,13 @@ __global__ __launch_bounds__(256) void kvsplit_to_f32_kernel(const _Float16* __r
     {   // V: thread -> (d, stored chunk position)
         const int d = threadIdx.x >> 2, pos = threadIdx.x & 3;
         const int c = pos ^ ((d >> 2) & 3), m = c >> 1, kh = c & 1;
-        const half8 hi = *reinterpret_cast<const half8*>(in + Blk<3>::v_hi + d * 32 + pos * 8);
-        const half8 lo = *reinterpret_cast<const half8*>(in + Blk<3>::v_lo + d * 32 + pos * 8);
+        const half8 hi = *reinterpret_cast<const half8*>(in + Blk<TERMS>::v_hi + d * 32 + pos * 8);
+        half8 lo = hi;
+        if constexpr (TERMS == 3) lo = *reinterpret_cast<const half8*>(in + Blk<3>::v_lo + d * 32 + pos * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int n = blk * 32 + 16 * m + 4 * kh + (e & 3) + 8 * (e >> 2);
-            if (n < N) vp[(int64_t)n * row + d] = (float)hi[e] + (float)lo[e];
+            if (n < N) vp[(int64_t)n * row + d] = val(hi, lo, e);
         }
     }
 }
@@ -877,10 +887,13 @@ hipError_t launch_kvsplit_convert(const float* K, const float* V, int64_t k_batc
 }
 
 hipError_t launch_kvsplit_to_f32(const void* cache, int B, int H, int N, float* K, float* V, int64_t k_batch, int64_t k_head,
-                                 int64_t v_batch, int64_t v_head, hipStream_t s, int chunks) {
+                                 int64_t v_batch, int64_t v_head, hipStream_t s, int chunks, int terms, int kind) {
     if (chunks < 1 || H % chunks != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kvsplit_to_f32_kernel, dim3(ceil_div(N, kBlkKeys), B * H), dim3(256), 0, s, reinterpret_cast<const _Float16*>(cache),
-                       H, N, K, V, k_batch, k_head, v_batch, v_head, chunks);
+    const dim3 grid(ceil_div(N, kBlkKeys), B * H);
+    const _Float16* c = reinterpret_cast<const _Float16*>(cache);
+    if (terms == 3) hipLaunchKernelGGL((kvsplit_to_f32_kernel<3, kF16>), grid, dim3(256), 0, s, c, H, N, K, V, k_batch, k_head, v_batch, v_head, chunks);
+    else if (kind == kF16) hipLaunchKernelGGL((kvsplit_to_f32_kernel<1, kF16>), grid, dim3(256), 0, s, c, H, N, K, V, k_batch, k_head, v_batch, v_head, chunks);
+    else hipLaunchKernelGGL((kvsplit_to_f32_kernel<1, kBF16>), grid, dim3(256), 0, s, c, H, N, K, V, k_batch, k_head, v_batch, v_head, chunks);
     return hipGetLastError();
 }
 
@@ -937,7 +950,7 @@ hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t
         }
     }
     if (terms == 3) return b.drop_p > 0.f ? launch_flash_t<3, kF16, true>(b, cache, s) : launch_flash_t<3, kF16>(b, cache, s);
-    if (b.drop_p > 0.f) return hipErrorInvalidValue;           // dropout exists on the fp32-accurate paths only
+    if (b.drop_p > 0.f) return kind == kF16 ? launch_flash_t<1, kF16, true>(b, cache, s) : launch_flash_t<1, kBF16, true>(b, cache, s);
     return kind == kF16 ? launch_flash_t<1, kF16>(b, cache, s) : launch_flash_t<1, kBF16>(b, cache, s);
 }
 

@@ -303,9 +303,14 @@ class PARQDecoder(nn.Module):
         return self._h
 
     def _train_mode(self):
-        """Attention arithmetic of the training entry points: the split-precision forward when the head dim allows it (the
-        backward kernels then work on fp32 K / V rebuilt from the split cache), else the exact-fp32 kernels."""
-        return "split" if self.dim_in // self.num_heads in (64, 256) and self.attention_mode != "fp32" else "fp32"
+        """Attention arithmetic of the training entry points: ``attention_mode`` where the kernels exist — the split-precision
+        forward at head dims 64 / 256 (the backward kernels then work on fp32 K / V rebuilt from the split cache), the fp16 /
+        bf16 forward at head dim 64 (BASELINE cfg 5 trains in fp16: the backward differentiates straight through the rounded
+        K / V) — else the exact-fp32 kernels."""
+        dh = self.dim_in // self.num_heads
+        if self.attention_mode in ("fp16", "bf16") and dh == 64 and self.dim_in <= 256:
+            return self.attention_mode
+        return "split" if dh in (64, 256) and self.attention_mode != "fp32" else "fp32"
 
     def _handle_in_mode(self, mode):
         """The handle switched to `mode` without touching the user-facing ``attention_mode`` (the training entry points need

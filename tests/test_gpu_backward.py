@@ -51,7 +51,11 @@ def oracle_grads(cfg, W, sc, cots):
 ])
 def test_backward_matches_oracle_autograd(B, V, h, w, Q, heads, dim, ffn, layers, shared):
     cfg = synth.decoder_cfg(dim=dim, queries=Q, heads=heads, ffn=ffn, layers=layers, share_weights=shared, dropout=0.0)
-    W = synth.make_decoder_weights(cfg, 71)
+    # damped centre head: the comparison is FREE-RUNNING over 2-3 iterations, and with the undamped head a
+    # rounding-level difference of the forward (1e-6: e.g. another summation order in the split merge) grows to 1e-2 in the centre
+    # head's gradients by the third iteration — a property of the fixture (measured: two fp32 summation orders of the same kernels
+    # differ by that much from each other), not of the backward
+    W = synth.make_decoder_weights(cfg, 71, damped=True)
     sc = synth.make_scene(72, B, V, h, w, dim, smooth=True)
     ncls = cfg.NUM_SEMCLS + 1
     cots = {"pred_logits": synth.normal(73, "cl", (layers, B, Q, ncls)), "center_unnormalized": synth.normal(74, "cc", (layers, B, Q, 3)),
@@ -422,3 +426,51 @@ def test_two_outstanding_training_forwards_are_refused_not_silently_wrong():
         dec.invalidate_weights()
         o2 = dec(*a)[0]["ortho6d"]
     assert not torch.equal(o1, o2)
+
+
+@pytest.mark.parametrize("mode,out_tol,grad_tol", [("fp16", 1e-3, 2e-2), ("bf16", 1e-2, 1.5e-1)])
+def test_training_in_reduced_precision_attention_modes(mode, out_tol, grad_tol):
+    """BASELINE cfg 5 trains with fp16 cross-attention (cfg 2 names bf16): the training forward streams the single 16-bit K/V
+    cache and the backward differentiates straight through the rounded K / V (fp32 values rebuilt from the cache).  Judged
+    against float64 autograd of the oracle with the reduced-precision tolerances of the forward tests (operands rounded to
+    2^-11 / 2^-8 relative): outputs 1e-3 / 1e-2, gradients Frobenius-relative 2e-2 / 1.5e-1 per tensor, dropout included in a
+    second pass (finite, different from the dropout-free gradients)."""
+    B, V, h, w, Q, heads, dim, ffn, layers = 2, 2, 32, 41, 24, 4, 256, 128, 3
+    cfg = synth.decoder_cfg(dim=dim, queries=Q, heads=heads, ffn=ffn, layers=layers, dropout=0.0)
+    W = synth.make_decoder_weights(cfg, 571, damped=True)
+    sc = synth.make_scene(572, B, V, h, w, dim, smooth=True)
+    ncls = cfg.NUM_SEMCLS + 1
+    cots = {"pred_logits": synth.normal(573, "cl", (layers, B, Q, ncls)), "center_unnormalized": synth.normal(574, "cc", (layers, B, Q, 3)),
+            "size_unnormalized": synth.normal(575, "cs", (layers, B, Q, 3)), "ortho6d": synth.normal(576, "cr", (layers, B, Q, 6))}
+    want, want_tok, oouts = oracle_grads(cfg, W, sc, cots)
+    dec = make_decoder(cfg, W).train()
+    dec.attention_mode = mode
+    assert dec._train_mode() == mode
+    outs = dec.forward_train(*scene_args(sc))
+    for k in range(layers):
+        for key in GKEYS:
+            a, b = outs[k][key].cpu().numpy(), oouts[k][key].detach().numpy()
+            assert np.abs(a - b).max() / max(1.0, np.abs(b).max()) < out_tol, (k, key)
+    grads, d_tok = dec.backward({k: torch.from_numpy(v) for k, v in cots.items()})
+    worst = {}
+    for name, g in grads.items():
+        if name in want:
+            ref = want[name].numpy()
+            worst[name] = np.linalg.norm(g.cpu().numpy().astype(np.float64) - ref) / max(np.linalg.norm(ref), 1e-9)
+    print("\n%s training: worst gradient errors" % mode, sorted(worst.items(), key=lambda kv: -kv[1])[:4])
+    assert max(worst.values()) < grad_tol, max(worst.values())
+    rt = want_tok.numpy()
+    terr = np.linalg.norm(d_tok.cpu().numpy().astype(np.float64) - rt) / np.linalg.norm(rt)
+    print("token gradient error %.3e" % terr)
+    assert terr < grad_tol
+    assert not dec.fp16_range_exceeded()
+    # with dropout (the reference trains with 0.1): the single-term dropout instantiation of the attention kernel
+    cfg2 = synth.decoder_cfg(dim=dim, queries=Q, heads=heads, ffn=ffn, layers=layers, dropout=0.1)
+    dec2 = make_decoder(cfg2, W).train()
+    dec2.attention_mode = mode
+    torch.manual_seed(3)
+    dec2.forward_train(*scene_args(sc))
+    g2, t2 = dec2.backward({k: torch.from_numpy(v) for k, v in cots.items()})
+    assert all(torch.isfinite(v).all() for v in g2.values()) and torch.isfinite(t2).all()
+    name = "parq_module.decoder.layers.0.multihead_attn.out_proj.weight"
+    assert float((g2[name] - grads[name]).norm()) > 1e-3 * float(grads[name].norm())
