@@ -499,11 +499,13 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 // (three stages are live at any time: V of the previous block, K / V of the current pair, K of the next pair).
 // PROBE (development only, results are wrong when non-zero): 1 no softmax VALU, 2 no PV MFMAs, 4 no QK MFMAs, 8 no barrier / DMA waits,
 // 16 no fragment reads from LDS — what each ingredient of a step costs when it is taken out.
-template <int RING, int PROBE = 0>
+// TERMS = 3: fp16 hi/lo split products (24 MFMAs per block).  TERMS = 1: single fp16 / bf16 products (KIND; the reduced-precision
+// attention modes of BASELINE configs 2 and 5): 8 MFMAs per block with one softmax pair behind each, 8 KB cache blocks.
+template <int RING, int PROBE = 0, int TERMS = 3, int KIND = kF16>
 __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a, const _Float16* __restrict__ cache) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];       // [RING stages][kStageBlks][block]
-    constexpr int kBlkBytes = Blk<3>::bytes;
-    constexpr int kBlkHalfs = Blk<3>::halfs;
+    constexpr int kBlkBytes = Blk<TERMS>::bytes;
+    constexpr int kBlkHalfs = Blk<TERMS>::halfs;
     constexpr int NT = kNW * 64;
     constexpr int STAGE16 = kStageBlks * kBlkBytes / 16;
     constexpr int LD = STAGE16 / NT;
@@ -533,7 +535,8 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
             float x[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = (e < 4 ? x0[e & 3] : x1[e & 3]) * scale;
-            split8(x, qhi[s], qlo[s]);
+            if constexpr (TERMS == 3) split8(x, qhi[s], qlo[s]);
+            else { qhi[s] = cvt8_rn<KIND>(x); qlo[s] = qhi[s]; }
         }
     }
 
@@ -614,7 +617,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
         for (int s = 0; s < 4; ++s) {
             const int pos = (4 * kh + s) ^ ksw;
             kf[2 * s] = *reinterpret_cast<const half8*>(Kb + li * 64 + pos * 8);
-            kf[2 * s + 1] = *reinterpret_cast<const half8*>(Kb + Blk<3>::k_lo + li * 64 + pos * 8);
+            if constexpr (TERMS == 3) kf[2 * s + 1] = *reinterpret_cast<const half8*>(Kb + Blk<3>::k_lo + li * 64 + pos * 8);
         }
     };
     auto load_v = [&](const _Float16* Vb, int m, half8 (&vh)[2], half8 (&vl)[2]) {
@@ -626,8 +629,8 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
         for (int dt = 0; dt < 2; ++dt) {
             const int d = dt * 32 + li;
             const int pos = (2 * m + kh) ^ ((d >> 2) & 3);
-            vh[dt] = *reinterpret_cast<const half8*>(Vb + Blk<3>::v_hi + d * 32 + pos * 8);
-            vl[dt] = *reinterpret_cast<const half8*>(Vb + Blk<3>::v_lo + d * 32 + pos * 8);
+            vh[dt] = *reinterpret_cast<const half8*>(Vb + Blk<TERMS>::v_hi + d * 32 + pos * 8);
+            if constexpr (TERMS == 3) vl[dt] = *reinterpret_cast<const half8*>(Vb + Blk<3>::v_lo + d * 32 + pos * 8);
         }
     };
     // max of the 16 scores of this lane (keys of one kh half), then over both halves: the block maximum of query li
@@ -647,16 +650,19 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
             p[e] = __builtin_amdgcn_exp2f(sacc[CUR][8 * m + e]);
             l_run += p[e];
         }
-        split8(p, Phi[CUR][m], Plo[CUR][m]);
+        if constexpr (TERMS == 3) split8(p, Phi[CUR][m], Plo[CUR][m]);
+        else Phi[CUR][m] = cvt8_rn<KIND>(p);
     };
     auto pv_half = [&](auto par, int m, const half8 (&vh)[2], const half8 (&vl)[2]) {
         constexpr int PAR = decltype(par)::value;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) o[dt] = mfma16<kF16>(vh[dt], Phi[PAR][m], o[dt]);
+        for (int dt = 0; dt < 2; ++dt) o[dt] = mfma16<KIND>(vh[dt], Phi[PAR][m], o[dt]);
+        if constexpr (TERMS == 3) {
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) o[dt] = mfma16<kF16>(vl[dt], Phi[PAR][m], o[dt]);
+            for (int dt = 0; dt < 2; ++dt) o[dt] = mfma16<KIND>(vl[dt], Phi[PAR][m], o[dt]);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) o[dt] = mfma16<kF16>(vh[dt], Plo[PAR][m], o[dt]);
+            for (int dt = 0; dt < 2; ++dt) o[dt] = mfma16<KIND>(vh[dt], Plo[PAR][m], o[dt]);
+        }
     };
     // rare, wave-uniform: the maximum of block n + 1 (accumulator parity NXT, relative to m_run) moves the reference.  The
     // probabilities of block n (parity CUR) are still waiting for their PV: it is done here and then cleared, so that the
@@ -696,13 +702,26 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
         const float p1 = __builtin_amdgcn_exp2f(sacc[CUR][2 * J + 1]);
         l_a += p0;
         l_b += p1;
-        half2v hi, lo;
-        split_pair(p0, p1, hi, lo);
-        u32x4 h4 = __builtin_bit_cast(u32x4, Phi[CUR][M]), l4 = __builtin_bit_cast(u32x4, Plo[CUR][M]);
-        h4[W] = __builtin_bit_cast(unsigned int, hi);
-        l4[W] = __builtin_bit_cast(unsigned int, lo);
-        Phi[CUR][M] = __builtin_bit_cast(half8, h4);
-        Plo[CUR][M] = __builtin_bit_cast(half8, l4);
+        if constexpr (TERMS == 3) {
+            half2v hi, lo;
+            split_pair(p0, p1, hi, lo);
+            u32x4 h4 = __builtin_bit_cast(u32x4, Phi[CUR][M]), l4 = __builtin_bit_cast(u32x4, Plo[CUR][M]);
+            h4[W] = __builtin_bit_cast(unsigned int, hi);
+            l4[W] = __builtin_bit_cast(unsigned int, lo);
+            Phi[CUR][M] = __builtin_bit_cast(half8, h4);
+            Plo[CUR][M] = __builtin_bit_cast(half8, l4);
+        } else {                                                             // one round-to-nearest 16-bit value per probability
+            u32x4 h4 = __builtin_bit_cast(u32x4, Phi[CUR][M]);
+            if constexpr (KIND == kF16) {
+                const half2v hv = {(_Float16)p0, (_Float16)p1};
+                h4[W] = __builtin_bit_cast(unsigned int, hv);
+            } else {
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                const bf16x2 bv = {(__bf16)p0, (__bf16)p1};
+                h4[W] = __builtin_bit_cast(unsigned int, bv);
+            }
+            Phi[CUR][M] = __builtin_bit_cast(half8, h4);
+        }
     };
 #define PARQ_FENCE() __builtin_amdgcn_sched_barrier(0)
     // one pipelined step: QK(n + 1) -> sacc[NXT], softmax(n) from sacc[CUR] -> P[CUR], PV(n - 1) with P[NXT].  The order below IS the
@@ -714,9 +733,11 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
         const _Float16* Vb = lds_blk(n > 0 ? n - 1 : 0);                  // n = 0: P[NXT] is zero, any finite V will do
         // kf = K fragments of block n + 1 and vh / vl = V fragments (m = 0) of block n - 1 were requested by the previous step
         PARQ_FENCE();
-#define PARQ_Q(i, A, Bq) if constexpr (!(PROBE & 4)) sacc[NXT] = mfma16<kF16>(A, Bq, (i) == 0 ? negm16 : sacc[NXT]); PARQ_FENCE()
-#define PARQ_P(D, A, Bp) if constexpr (!(PROBE & 2)) o[D] = mfma16<kF16>(A, Bp, o[D]); PARQ_FENCE()
+        float mx_lane_out = 0.f;
+#define PARQ_Q(i, A, Bq) if constexpr (!(PROBE & 4)) sacc[NXT] = mfma16<KIND>(A, Bq, (i) == 0 ? negm16 : sacc[NXT]); PARQ_FENCE()
+#define PARQ_P(D, A, Bp) if constexpr (!(PROBE & 2)) o[D] = mfma16<KIND>(A, Bp, o[D]); PARQ_FENCE()
 #define PARQ_S(J) sm_pair(IC{}, std::integral_constant<int, J>{}); PARQ_FENCE()
+        if constexpr (TERMS == 3) {
         // m = 0 half of PV(n - 1), s = 0, 1 of QK(n + 1); 8 softmax pairs (16 scores per lane and block), one behind every third MFMA
         PARQ_Q(0, kf[0], qhi[0]);
         PARQ_P(0, vh[0], Phi[NXT][0]);  PARQ_S(0);
@@ -755,6 +776,31 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
         }
         PARQ_FENCE();
         PARQ_P(1, vh[1], Plo[NXT][1]);
+        mx_lane_out = mx_lane;
+        } else {
+        // single products: 4 + 4 MFMAs per block, one softmax pair behind each
+        PARQ_Q(0, kf[0], qhi[0]);  PARQ_S(0);
+        PARQ_P(0, vh[0], Phi[NXT][0]);  PARQ_S(1);
+        PARQ_Q(1, kf[2], qhi[1]);  PARQ_S(2);
+        PARQ_P(1, vh[1], Phi[NXT][0]);
+        load_v(Vb, 1, vh, vl);
+        PARQ_FENCE();
+        PARQ_S(3);
+        PARQ_Q(2, kf[4], qhi[2]);  PARQ_S(4);
+        PARQ_P(0, vh[0], Phi[NXT][1]);  PARQ_S(5);
+        PARQ_Q(3, kf[6], qhi[3]);  PARQ_S(6);
+        float mx_lane;
+        {
+            const f32x16& S = sacc[NXT];
+            float m0 = fmaxf(S[0], S[1]), m1 = fmaxf(S[8], S[9]);
+#pragma unroll
+            for (int r = 2; r < 8; ++r) { m0 = fmaxf(m0, S[r]); m1 = fmaxf(m1, S[8 + r]); }
+            mx_lane = fmaxf(m0, m1);
+        }
+        PARQ_S(7);
+        PARQ_P(1, vh[1], Phi[NXT][1]);
+        mx_lane_out = mx_lane;
+        }
 #undef PARQ_Q
 #undef PARQ_P
 #undef PARQ_S
@@ -762,7 +808,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
         load_k(lds_blk(n + 2 < nbk ? n + 2 : nbk - 1), kf);
         load_v(lds_blk(n), 0, vh, vl);
         PARQ_FENCE();
-        const float mx = xhalf_max(mx_lane);                                 // relative to m_run
+        const float mx = xhalf_max(mx_lane_out);                             // relative to m_run
         if (__any(mx > a.defer_log2)) move_reference(cur, n, mx);
     };
 
@@ -776,9 +822,11 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
             const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                sacc[0] = mfma16<kF16>(kf[2 * s], qhi[s], s == 0 ? zero16 : sacc[0]);
-                sacc[0] = mfma16<kF16>(kf[2 * s], qlo[s], sacc[0]);
-                sacc[0] = mfma16<kF16>(kf[2 * s + 1], qhi[s], sacc[0]);
+                sacc[0] = mfma16<KIND>(kf[2 * s], qhi[s], s == 0 ? zero16 : sacc[0]);
+                if constexpr (TERMS == 3) {
+                    sacc[0] = mfma16<KIND>(kf[2 * s], qlo[s], sacc[0]);
+                    sacc[0] = mfma16<KIND>(kf[2 * s + 1], qhi[s], sacc[0]);
+                }
             }
             if (nbk == 1 && last_partial) {
 #pragma unroll
@@ -951,6 +999,23 @@ hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t
     }
     if (terms == 3) return b.drop_p > 0.f ? launch_flash_t<3, kF16, true>(b, cache, s) : launch_flash_t<3, kF16>(b, cache, s);
     if (b.drop_p > 0.f) return kind == kF16 ? launch_flash_t<1, kF16, true>(b, cache, s) : launch_flash_t<1, kBF16, true>(b, cache, s);
+    {
+        static const bool v1h = [] { const char* e = getenv("PARQ_FLASH_V"); return e && e[0] == '1'; }();
+        if (!v1h) {
+            const size_t lds = (size_t)4 * kStageBlks * Blk<1>::bytes;
+            dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * b.H);
+            if (kind == kF16) {
+                static DynLdsOnce once;
+                if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_split_pipe_kernel<4, 0, 1, kF16>), lds); e != hipSuccess) return e;
+                hipLaunchKernelGGL((flash_split_pipe_kernel<4, 0, 1, kF16>), grid, dim3(kNW * 64), lds, s, b, reinterpret_cast<const _Float16*>(cache));
+            } else {
+                static DynLdsOnce once;
+                if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_split_pipe_kernel<4, 0, 1, kBF16>), lds); e != hipSuccess) return e;
+                hipLaunchKernelGGL((flash_split_pipe_kernel<4, 0, 1, kBF16>), grid, dim3(kNW * 64), lds, s, b, reinterpret_cast<const _Float16*>(cache));
+            }
+            return hipGetLastError();
+        }
+    }
     return kind == kF16 ? launch_flash_t<1, kF16>(b, cache, s) : launch_flash_t<1, kBF16>(b, cache, s);
 }
 
