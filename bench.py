@@ -15,7 +15,7 @@ N > 1   : one process per GPU, scenes sharded data-parallel (independent, no dat
           exits with the launcher's code; under torchrun (the driver's form) it is a rank.
 
 Also reported in the same JSON line:
-  roofline      dominant kernel (flash_split_kernel, the dense cross-attention): algorithmic FLOP per launch
+  roofline      dominant kernel (flash_split_pipe_kernel, the dense cross-attention): algorithmic FLOP per launch
                 (4*Q*N*C per scene) / mean launch time from hipEvents recorded by the library
                 on the launch stream during an instrumented repeat of the same K steps
                 (split mode: fp16 hi/lo 3-term products on the fp16 matrix pipe, fp32 accumulation)
@@ -329,7 +329,7 @@ def main():
         roofline = {"bound": "mfma",
                     "kernel": (("flash_split_pipe_kernel" if C // WORKLOAD["heads"] == 64 else "flash_split256_kernel") +
                                " (cross-attention QK^T+PV, fp16 hi/lo 3-term products, fp32 accumulate)" if split
-                               else "flash_split_kernel<1> (cross-attention QK^T+PV, single %s products, fp32 accumulate)" % mode if half
+                               else "flash_split_pipe_kernel<4,0,1> (cross-attention QK^T+PV, single %s products, fp32 accumulate)" % mode if half
                                else "flash_f32_kernel (cross-attention QK^T+PV, fp32 MFMA)"),
                     "achieved": ach_tflops, "peak": mfma_peak, "unit": "TFLOP/s",
                     "frac": (ach_tflops / mfma_peak) if ach_tflops else None,

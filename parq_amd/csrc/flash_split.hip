@@ -168,303 +168,15 @@ __global__ __launch_bounds__(256) void kvsplit_to_f32_kernel(const _Float16* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS holds a ring of kRing stages filled by LDS-DMA; every wave passes ONE workgroup barrier per stage (its
-// "sync point": wait for its own DMA of stage t+2, barrier, request stage t+3 into the slot of stage t-1).
-// Measured and rejected on this structure (flash launch, cfg 3): locking the two waves of a SIMD half a stage
-// apart by giving waves 4..7 their sync point mid-stage (165 us against 152 us in phase: out of phase the two
-// waves' MFMA runs collide, and the in-wave MFMA/VALU interleave already covers the dependent points);
-// reading the next stage's first K fragments before the barrier (+5..12 %, register pressure);
-// register staging instead of LDS-DMA (+0.5 %, 16 more VGPRs); one barrier per TWO stages (+4..6 %: the
-// barrier keeps the eight waves on the same LDS blocks, which the kernel evidently profits from).
+// LDS holds a ring of stages (two 32-key blocks each) filled by LDS-DMA; every wave passes ONE workgroup barrier per stage.
+// Round 1 ran a two-blocks-per-stage kernel here (QK(b0) | QK(b1) + softmax(b0) || PV(b0) + softmax(b1) | PV(b1), 148 us at
+// BASELINE cfg 3; measured and rejected on it: waves 4..7 half a stage out of phase, K fragments read ahead of the barrier,
+// register staging instead of LDS-DMA, one barrier per two stages).  The pipelined kernel below replaced it in round 2 for every
+// mode (split / fp16 / bf16, with and without training dropout).
 constexpr int kRing = 4;
 
-// TERMS = 3: fp16 hi/lo split products (fp32-class accuracy).  TERMS = 1: single fp16 / bf16 products (KIND) —
-// the reduced-precision modes of BASELINE configs 2 and 5; same structure, a third of the MFMAs, half the bytes.
-// DROP: training-time dropout on the probabilities (counter-based keep mask of FlashArgs::drop_seed, see common.hpp); a
-// separate instantiation so that the inference kernel keeps its register allocation.
-template <int TERMS, int KIND, bool DROP = false>
-__global__ __launch_bounds__(kNW * 64) void flash_split_kernel(FlashArgs a, const _Float16* __restrict__ cache) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];       // [kRing stages][kStageBlks][block]
-    constexpr int kBlkBytes = Blk<TERMS>::bytes;
-    constexpr int kBlkHalfs = Blk<TERMS>::halfs;
-    constexpr int NT = kNW * 64;
-    constexpr int STAGE16 = kStageBlks * kBlkBytes / 16;                     // 16-byte chunks per stage
-    constexpr int LD = STAGE16 / NT;                                         // per thread
-    static_assert(STAGE16 % NT == 0, "stage must divide over the workgroup");
-
-    const int split = blockIdx.x;
-    const int bh = blockIdx.z;
-    const int b = bh / a.H, h = bh - b * a.H;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, kh = lane >> 5;
-    const int q0 = (blockIdx.y * kNW + wave) * 32;
-    const int q = q0 + li;
-    const bool active = q0 < a.Lq;
-    const int Lq_pad = (a.Lq + 31) & ~31;
-
-    // Q fragments (B operand of S^T = K Q^T), pre-scaled by log2(e)/sqrt(dh), split hi/lo
-    half8 qhi[4], qlo[4];
-    {
-        const float scale = 1.4426950408889634f / sqrtf((float)kDH);
-        const float* qp = a.q + (int64_t)b * a.q_batch + (int64_t)h * a.q_head + (int64_t)(q < a.Lq ? q : 0) * a.q_row;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            // dmap(kh,s,e): two runs of 4 consecutive d
-            const int d0 = 32 * (s >> 1) + 16 * (s & 1) + 4 * kh;
-            f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + d0);
-            f32x4 x1 = *reinterpret_cast<const f32x4*>(qp + d0 + 8);
-            if (q >= a.Lq) { x0 = f32x4{0.f, 0.f, 0.f, 0.f}; x1 = x0; }
-            float x[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = (e < 4 ? x0[e & 3] : x1[e & 3]) * scale;
-            if constexpr (TERMS == 3) split8(x, qhi[s], qlo[s]);
-            else qhi[s] = cvt8_rn<KIND>(x);
-        }
-    }
-
-    const int nblk = (a.Lk + kBlkKeys - 1) / kBlkKeys;
-    const int nst = (nblk + kStageBlks - 1) / kStageBlks;                    // stages in total
-    const int t_begin = (int)((int64_t)split * nst / a.nsplit);
-    const int t_end = (int)((int64_t)(split + 1) * nst / a.nsplit);
-    const uint4* gsrc = reinterpret_cast<const uint4*>(cache + (int64_t)bh * nblk * kBlkHalfs);
-    const int64_t total16 = (int64_t)nblk * (kBlkBytes / 16);
-
-    // global -> LDS staging by LDS-DMA (global_load_lds_dwordx4): the LDS image of a stage equals its global
-    // image, so lane l of wave w copies 16-byte chunk (i*NT + w*64 + l) to the same chunk of the ring slot; no
-    // staging registers, no ds_write.  Lanes past the end of the cache are masked off (the slot keeps finite
-    // stale data there, see the zero fill below; such keys get probability 0).
-    typedef __attribute__((address_space(3))) unsigned char lds_byte;
-    auto gload = [&](int st, int slot) {
-#pragma unroll
-        for (int i = 0; i < LD; ++i) {
-            const int64_t idx = (int64_t)st * STAGE16 + tid + i * NT;
-            lds_byte* dst = (lds_byte*)(smem_h) + ((size_t)slot * STAGE16 + i * NT + wave * 64) * 16;
-            if (idx < total16) __builtin_amdgcn_global_load_lds(gsrc + idx, dst, 16, 0, 0);
-        }
-    };
-
-    f32x16 o[2];
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-
-    // a stage that reaches past the last cache block leaves part of its slot unwritten: make that finite
-    if ((nblk % kStageBlks) != 0 && t_end == nst) {
-        uint4* z = reinterpret_cast<uint4*>(smem_h);
-        for (int i = tid; i < kRing * STAGE16; i += NT) z[i] = uint4{0u, 0u, 0u, 0u};
-        __syncthreads();
-    }
-    if (t_begin < t_end) gload(t_begin, 0);
-    if (t_begin + 1 < t_end) gload(t_begin + 1, 1);
-    if (t_begin + 2 < t_end) gload(t_begin + 2, 2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // one per stage and wave: stage t+2 (requested a stage ago) is published, stage t+3 is requested into the
-    // slot of stage t-1, which every wave left before the previous barrier
-    auto sync_point = [&](int t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA has landed (hipcc does not wait for it)
-        __syncthreads();
-        if (t + 3 < t_end) gload(t + 3, (t + 3 - t_begin) & (kRing - 1));
-    };
-
-    const uint32_t drop_rh = DROP ? drop_rowhash(a.drop_seed, (uint32_t)(bh * a.Lq + q)) : 0u;      // this lane's query row
-    const uint32_t drop_thr = DROP ? drop_threshold(a.drop_p) : 0u;
-    // dropout column hashes of the 64 keys of the stage in flight: lane l of every wave hashes key l once, the wave reads them back
-    // as 16-byte groups (private 256-byte area per wave behind the ring: LDS operations of one wave execute in order)
-    uint32_t* drop_ch = reinterpret_cast<uint32_t*>(smem_h + (size_t)kRing * kStageBlks * kBlkHalfs) + wave * 64;
-    // state of the stage in flight
-    f32x16 sacc[2];
-    half8 phi[2][2], plo[2][2];
-    half8 kf[2][8];          // K fragments of both blocks: [kb][2*s + {hi,lo}]
-    float rs = 0.f, mx1 = 0.f;
-
-    for (int t = t_begin; t < t_end; ++t) {
-        const int buf = (t - t_begin) & (kRing - 1);
-        const int nb = (nblk - t * kStageBlks) < kStageBlks ? (nblk - t * kStageBlks) : kStageBlks;   // wave-uniform
-        const _Float16* S0 = smem_h + buf * kStageBlks * kBlkHalfs;
-        const int ksw = (li >> 1) & 7;
-        if constexpr (DROP) drop_ch[lane] = drop_colhash((uint32_t)(t * kStageBlks * kBlkKeys + lane));
-        static_assert(kStageBlks == 2, "the software pipeline below is written for two blocks per stage");
-        // Software pipeline over the two 32-key blocks of the stage, written so that every VALU section
-        // (softmax of one block) sits between the MFMAs of the other block and can issue in their shadow:
-        //     QK(b0) | QK(b1) + softmax(b0) || PV(b0) + softmax(b1) | PV(b1)
-        {
-            // LDS fragment reads are issued a full MFMA group ahead of their use (ds_read latency is
-            // otherwise exposed in front of every 3-MFMA step: ~30 % of the wave's time)
-            auto load_k = [&](const _Float16* St, int kb) {
-                const _Float16* B0 = St + kb * kBlkHalfs;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int pos = (4 * kh + s) ^ ksw;
-                    kf[kb][2 * s] = *reinterpret_cast<const half8*>(B0 + li * 64 + pos * 8);
-                    if constexpr (TERMS == 3) kf[kb][2 * s + 1] = *reinterpret_cast<const half8*>(B0 + Blk<3>::k_lo + li * 64 + pos * 8);
-                }
-            };
-            auto qk_step = [&](int kb, int s) {
-                // the first product of a block starts from the inline constant 0 (no zeroing pass over the accumulators)
-                const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                sacc[kb] = mfma16<KIND>(kf[kb][2 * s], qhi[s], s == 0 ? zero16 : sacc[kb]);
-                if constexpr (TERMS == 3) {
-                    sacc[kb] = mfma16<KIND>(kf[kb][2 * s], qlo[s], sacc[kb]);
-                    sacc[kb] = mfma16<KIND>(kf[kb][2 * s + 1], qhi[s], sacc[kb]);
-                }
-            };
-            // block maximum (scores absolute).  Tail masking (keys >= Lk, blocks past the end) exists only in the
-            // TAIL instantiation of the stage body, so the common path stays free of branches between the MFMA
-            // groups (the scheduler can only interleave inside one basic block).
-            auto block_mx = [&](int kb, auto tail_tag) -> float {
-                if constexpr (decltype(tail_tag)::value) {
-                    const int blk = t * kStageBlks + kb;
-                    if (kb >= nb) {                                       // block past the end of the cache (zero-filled)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) sacc[kb][r] = -INFINITY;
-                    } else if (blk == nblk - 1 && (a.Lk & 31) != 0) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (blk * 32 + mfma32_row(r, lane) >= a.Lk) sacc[kb][r] = -INFINITY;
-                    }
-                }
-                float mx = sacc[kb][0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
-                return fmaxf(mx, __shfl_xor(mx, 32));
-            };
-            // deferred running max: move the reference only past the margin; (l, O) rescale is rare and
-            // wave-uniform.  Must not be called while probabilities of the old reference await their PV.
-            auto rescale = [&](float mx) {
-                const bool need = mx > m_run + a.defer_log2;
-                const float m_new = need ? mx : m_run;
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // 1 for unchanged lanes, 0 at the start
-                l_run *= alpha;
-                rs *= alpha;                 // row sums of this stage already taken against the old reference
-                m_run = m_new;
-#pragma unroll
-                for (int d = 0; d < 2; ++d)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-            };
-            // probabilities of 8 accumulator registers (one MFMA k-step of PV) of block kb, split hi/lo
-            auto softmax_half = [&](int kb, int m) {
-                float p[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    p[e] = __builtin_amdgcn_exp2f(sacc[kb][8 * m + e] - m_run);
-                    rs += p[e];
-                }
-                if constexpr (DROP) {           // the normaliser above stays undropped (nn.MultiheadAttention dropout); the factor
-                                                // 1 / (1 - p) of the kept entries is applied once to the partial output (epilogue)
-                    // keys mfma32_row(8 m + e, lane) = 16 m + 4 kh + (e & 3) + 8 (e >> 2) of block kb: two groups of 4 consecutive hashes
-                    const uint4 c0 = *reinterpret_cast<const uint4*>(drop_ch + kb * 32 + 16 * m + 4 * kh);
-                    const uint4 c1 = *reinterpret_cast<const uint4*>(drop_ch + kb * 32 + 16 * m + 4 * kh + 8);
-                    const uint32_t ch[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) p[e] = drop_keep_h(drop_rh, ch[e], drop_thr) ? p[e] : 0.f;
-                }
-                if constexpr (TERMS == 3) split8(p, phi[kb][m], plo[kb][m]);
-                else phi[kb][m] = cvt8_rn<KIND>(p);
-            };
-            auto pv_step = [&](int kb, int m) {
-                const _Float16* B0 = S0 + kb * kBlkHalfs;
-                half8 vhi[2], vlo[2];
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const int d = dt * 32 + li;
-                    const int pos = (2 * m + kh) ^ ((d >> 2) & 3);
-                    vhi[dt] = *reinterpret_cast<const half8*>(B0 + Blk<TERMS>::v_hi + d * 32 + pos * 8);
-                    if constexpr (TERMS == 3) vlo[dt] = *reinterpret_cast<const half8*>(B0 + Blk<3>::v_lo + d * 32 + pos * 8);
-                }
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) o[dt] = mfma16<KIND>(vhi[dt], phi[kb][m], o[dt]);
-                if constexpr (TERMS == 3) {
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) o[dt] = mfma16<KIND>(vlo[dt], phi[kb][m], o[dt]);
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) o[dt] = mfma16<KIND>(vhi[dt], plo[kb][m], o[dt]);
-                }
-            };
-
-            auto first_half = [&](auto tail_tag) {
-                rs = 0.f;
-                load_k(S0, 0);
-                load_k(S0, 1);
-                // ---- QK(b0)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) qk_step(0, s);
-                {
-                    const float mx0 = block_mx(0, tail_tag);
-                    if (__any(mx0 > m_run + a.defer_log2)) rescale(mx0);
-                }
-                // ---- QK(b1) with softmax(b0) in its shadow: one straight-line region, the scheduler is told to
-                // place ~8 VALU/TRANS instructions behind every MFMA (in-order issue: VALU work that merely FOLLOWS
-                // a run of MFMAs cannot overlap them)
-                qk_step(1, 0);
-                qk_step(1, 1);
-                softmax_half(0, 0);
-                qk_step(1, 2);
-                qk_step(1, 3);
-                softmax_half(0, 1);
-#pragma unroll
-                for (int i = 0; i < 4 * TERMS; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x402, TERMS == 3 ? 9 : 16, 0);    // VALU / TRANS behind it
-                }
-                mx1 = block_mx(1, tail_tag);
-            };
-            auto second_half = [&]() {
-                if (!__any(mx1 > m_run + a.defer_log2)) {
-                    // ---- common case: PV(b0) with softmax(b1) in its shadow
-                    pv_step(0, 0);
-                    softmax_half(1, 0);
-                    pv_step(0, 1);
-                    softmax_half(1, 1);
-#pragma unroll
-                    for (int i = 0; i < 4 * TERMS; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-                        __builtin_amdgcn_sched_group_barrier(0x402, TERMS == 3 ? 9 : 16, 1);
-                    }
-                } else {
-                    pv_step(0, 0);
-                    pv_step(0, 1);
-                    rescale(mx1);
-                    softmax_half(1, 0);
-                    softmax_half(1, 1);
-                }
-                // ---- PV(b1)  (a block past the end has p = 0 and zero-filled V: contributes nothing)
-                pv_step(1, 0);
-                pv_step(1, 1);
-                rs += __shfl_xor(rs, 32);
-                l_run += rs;
-            };
-            const bool tail_stage = (nb < kStageBlks) || ((t + 1) * kStageBlks >= nblk && (a.Lk & 31) != 0);   // wave-uniform
-            if (active) {
-                if (tail_stage) first_half(std::true_type{});
-                else first_half(std::false_type{});
-            }
-            if (active) second_half();
-            sync_point(t);
-        }
-    }
-
-    if (active) {
-        const int64_t pbase = (int64_t)bh * a.nsplit + split;
-        float* op = a.o_part + pbase * kDH * Lq_pad;
-        const float drop_scale = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) op[(int64_t)(d * 32 + mfma32_row(r, lane)) * Lq_pad + q] = o[d][r] * drop_scale;
-        if (kh == 0) {
-            a.m_part[pbase * Lq_pad + q] = m_run;
-            a.l_part[pbase * Lq_pad + q] = l_run;
-        }
-    }
-}
-
-
 // ------------------------------------------------------------------------------------------------
-// Second-generation main kernel (TERMS = 3, no dropout): ONE software-pipelined step per 32-key block,
+// The cross-attention kernel: ONE software-pipelined step per 32-key block,
 //     step n :  QK(n+1)  ||  softmax(n)  ||  PV(n-1)
 // PMC stall attribution of the two-blocks-per-stage kernel above (profiles/r02_stall_*): MFMA pipe 52 % busy, the waves 36 %
 // parked (s_waitcnt / barrier) and 33 % issue-stalled; per stage the SIMD spends MFMA time (QK(b0), PV(b1): no VALU to issue)
@@ -501,7 +213,10 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 // 16 no fragment reads from LDS — what each ingredient of a step costs when it is taken out.
 // TERMS = 3: fp16 hi/lo split products (24 MFMAs per block).  TERMS = 1: single fp16 / bf16 products (KIND; the reduced-precision
 // attention modes of BASELINE configs 2 and 5): 8 MFMAs per block with one softmax pair behind each, 8 KB cache blocks.
-template <int RING, int PROBE = 0, int TERMS = 3, int KIND = kF16>
+// DROP: training-time dropout on the probabilities (counter-based keep mask of FlashArgs::drop_seed, common.hpp): the column hashes
+// of a block's 32 keys are computed once per wave (lane = key) into a wave-private LDS strip behind the ring and read back as
+// four 16-byte groups; the normaliser stays undropped, 1 / (1 - p) is applied once to the partial output.
+template <int RING, int PROBE = 0, int TERMS = 3, int KIND = kF16, bool DROP = false>
 __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a, const _Float16* __restrict__ cache) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];       // [RING stages][kStageBlks][block]
     constexpr int kBlkBytes = Blk<TERMS>::bytes;
@@ -641,6 +356,25 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
         for (int r = 2; r < 8; ++r) { m0 = fmaxf(m0, S[r]); m1 = fmaxf(m1, S[8 + r]); }
         return xhalf_max(fmaxf(m0, m1));
     };
+    const uint32_t drop_rh = DROP ? drop_rowhash(a.drop_seed, (uint32_t)(bh * a.Lq + q)) : 0u;      // this lane's query row
+    const uint32_t drop_thr = DROP ? drop_threshold(a.drop_p) : 0u;
+    uint32_t* drop_ch = reinterpret_cast<uint32_t*>(smem_h + (size_t)RING * kStageBlks * kBlkHalfs) + wave * 32;
+    uint32_t dch[16];                                                      // column hashes of this lane's 16 keys of the block in softmax
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dch[r] = 0u;
+    // global 32-key block of local block n (the dropout column index is the key's index in the head's key axis)
+    auto gblk = [&](int n) { return rev ? t_end * kStageBlks - 1 - n : B0 + n; };
+    auto load_drop = [&](int n) {
+        if constexpr (DROP) {
+            if (lane < 32) drop_ch[lane] = drop_colhash((uint32_t)(gblk(n) * kBlkKeys + lane));
+            // keys mfma32_row(r, lane) = (r & 3) + 8 (r >> 2) + 4 kh: register group g = r >> 2 reads hashes 8 g + 4 kh .. + 3
+#pragma unroll
+            for (int g2 = 0; g2 < 4; ++g2) {
+                const uint4 c4 = *reinterpret_cast<const uint4*>(drop_ch + 8 * g2 + 4 * kh);
+                dch[4 * g2] = c4.x; dch[4 * g2 + 1] = c4.y; dch[4 * g2 + 2] = c4.z; dch[4 * g2 + 3] = c4.w;
+            }
+        }
+    };
     // probabilities of accumulator half m of block-parity CUR (epilogue; the steady state uses sm_pair)
     auto softmax_half = [&](auto cur, int m) {
         constexpr int CUR = decltype(cur)::value;
@@ -649,6 +383,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
         for (int e = 0; e < 8; ++e) {
             p[e] = __builtin_amdgcn_exp2f(sacc[CUR][8 * m + e]);
             l_run += p[e];
+            if constexpr (DROP) p[e] = drop_keep_h(drop_rh, dch[8 * m + e], drop_thr) ? p[e] : 0.f;
         }
         if constexpr (TERMS == 3) split8(p, Phi[CUR][m], Plo[CUR][m]);
         else Phi[CUR][m] = cvt8_rn<KIND>(p);
@@ -698,10 +433,14 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
     auto sm_pair = [&](auto cur, auto jj) {
         if constexpr (PROBE & 1) return;
         constexpr int CUR = decltype(cur)::value, J = decltype(jj)::value, M = J >> 2, W = J & 3;
-        const float p0 = __builtin_amdgcn_exp2f(sacc[CUR][2 * J]);           // the accumulator holds score - m_run
-        const float p1 = __builtin_amdgcn_exp2f(sacc[CUR][2 * J + 1]);
+        float p0 = __builtin_amdgcn_exp2f(sacc[CUR][2 * J]);                 // the accumulator holds score - m_run
+        float p1 = __builtin_amdgcn_exp2f(sacc[CUR][2 * J + 1]);
         l_a += p0;
         l_b += p1;
+        if constexpr (DROP) {                                                // the normaliser above stays undropped
+            p0 = drop_keep_h(drop_rh, dch[2 * J], drop_thr) ? p0 : 0.f;
+            p1 = drop_keep_h(drop_rh, dch[2 * J + 1], drop_thr) ? p1 : 0.f;
+        }
         if constexpr (TERMS == 3) {
             half2v hi, lo;
             split_pair(p0, p1, hi, lo);
@@ -732,6 +471,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
         using IC = std::integral_constant<int, CUR>;
         const _Float16* Vb = lds_blk(n > 0 ? n - 1 : 0);                  // n = 0: P[NXT] is zero, any finite V will do
         // kf = K fragments of block n + 1 and vh / vl = V fragments (m = 0) of block n - 1 were requested by the previous step
+        load_drop(n);
         PARQ_FENCE();
         float mx_lane_out = 0.f;
 #define PARQ_Q(i, A, Bq) if constexpr (!(PROBE & 4)) sacc[NXT] = mfma16<KIND>(A, Bq, (i) == 0 ? negm16 : sacc[NXT]); PARQ_FENCE()
@@ -853,6 +593,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
             // epilogue: softmax of the last block (ragged key axis masked here), PV of the last two blocks
             auto finish = [&](auto cur) {
                 constexpr int CUR = decltype(cur)::value, NXT = CUR ^ 1;
+                load_drop(n);
                 if (last_partial) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -887,10 +628,11 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
     if (active) {
         const int64_t pbase = (int64_t)bh * a.nsplit + split;
         float* op = a.o_part + pbase * kDH * Lq_pad;
+        const float drop_scale = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) op[(int64_t)(d * 32 + mfma32_row(r, lane)) * Lq_pad + q] = o[d][r];
+            for (int r = 0; r < 16; ++r) op[(int64_t)(d * 32 + mfma32_row(r, lane)) * Lq_pad + q] = o[d][r] * drop_scale;
         const float l_tot = xhalf_sum(l_run + l_a + l_b);
         if (kh == 0) {
             a.m_part[pbase * Lq_pad + q] = m_run;
@@ -945,16 +687,6 @@ hipError_t launch_kvsplit_to_f32(const void* cache, int B, int H, int N, float* 
     return hipGetLastError();
 }
 
-template <int TERMS, int KIND, bool DROP = false>
-static hipError_t launch_flash_t(const FlashArgs& b, const void* cache, hipStream_t s) {
-    static DynLdsOnce once;
-    const size_t lds = (size_t)kRing * kStageBlks * Blk<TERMS>::bytes + (DROP ? kNW * 64 * sizeof(uint32_t) : 0);
-    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_split_kernel<TERMS, KIND, DROP>), lds); e != hipSuccess) return e;
-    dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * b.H);
-    hipLaunchKernelGGL((flash_split_kernel<TERMS, KIND, DROP>), grid, dim3(kNW * 64), lds, s, b, reinterpret_cast<const _Float16*>(cache));
-    return hipGetLastError();
-}
-
 hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t s, int terms, int kind) {
     if (a.dh != kDH || a.nsplit < 1 || a.nsplit > 256) return hipErrorInvalidValue;
     FlashArgs b = a;
@@ -962,61 +694,42 @@ hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t
     b.defer_log2 = defer;
     static const int prio = [] { const char* e = getenv("PARQ_FLASH_PRIO"); return e ? atoi(e) : 0; }();
     static const bool alt = [] { const char* e = getenv("PARQ_FLASH_ALTERNATE"); return !(e && e[0] == '0'); }();
-    // bit 1 (set by the caller for every other recurrent iteration): sweep backwards — only where the pipelined kernel supports it
+    // bit 1 (set by the caller for every other recurrent iteration): sweep backwards — only for whole 64-key stages
     b.flags = (prio & 1) | ((alt && (a.flags & 2) && (a.Lk % (kStageBlks * kBlkKeys)) == 0) ? 2 : 0);
-    if (terms == 3 && !(b.drop_p > 0.f)) {
-        static const bool v1 = [] { const char* e = getenv("PARQ_FLASH_V"); return e && e[0] == '1'; }();    // A/B: the two-blocks-per-stage kernel
-        if (!v1) {
-            static const int ring = [] { const char* e = getenv("PARQ_FLASH_RING"); return e && e[0] == '5' ? 5 : 4; }();
-            static DynLdsOnce once4, once5;
-            const size_t lds = (size_t)ring * kStageBlks * Blk<3>::bytes;
-            dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * b.H);
-            static const int probe = [] { const char* e = getenv("PARQ_FLASH_PROBE"); return e ? atoi(e) : 0; }();
-            if (probe) {
-#define PARQ_PROBE_CASE(P)                                                                                                                    \
-    case P: {                                                                                                                                 \
-        static DynLdsOnce oncep;                                                                                                              \
-        if (hipError_t e = oncep.ensure(reinterpret_cast<const void*>(&flash_split_pipe_kernel<4, P>), (size_t)4 * kStageBlks * Blk<3>::bytes); e != hipSuccess) return e; \
-        hipLaunchKernelGGL((flash_split_pipe_kernel<4, P>), grid, dim3(kNW * 64), (size_t)4 * kStageBlks * Blk<3>::bytes, s, b, reinterpret_cast<const _Float16*>(cache)); \
-        return hipGetLastError();                                                                                                             \
+    const dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * b.H);
+    const _Float16* c16 = reinterpret_cast<const _Float16*>(cache);
+#define PARQ_PIPE_LAUNCH(RING, PROBE, T, K, D)                                                                                           \
+    {                                                                                                                                    \
+        static DynLdsOnce once;                                                                                                          \
+        const size_t lds = (size_t)RING * kStageBlks * Blk<T>::bytes + ((D) ? kNW * 32 * sizeof(uint32_t) : 0);                          \
+        if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_split_pipe_kernel<RING, PROBE, T, K, D>), lds); e != hipSuccess) return e; \
+        hipLaunchKernelGGL((flash_split_pipe_kernel<RING, PROBE, T, K, D>), grid, dim3(kNW * 64), lds, s, b, c16);                        \
+        return hipGetLastError();                                                                                                        \
     }
-                switch (probe) {
-                    PARQ_PROBE_CASE(1) PARQ_PROBE_CASE(2) PARQ_PROBE_CASE(4) PARQ_PROBE_CASE(6) PARQ_PROBE_CASE(7) PARQ_PROBE_CASE(8)
-                    PARQ_PROBE_CASE(9) PARQ_PROBE_CASE(16) PARQ_PROBE_CASE(17) PARQ_PROBE_CASE(25) PARQ_PROBE_CASE(31)
-                    default: return hipErrorInvalidValue;
-                }
-#undef PARQ_PROBE_CASE
-            }
-            if (ring == 5) {
-                if (hipError_t e = once5.ensure(reinterpret_cast<const void*>(&flash_split_pipe_kernel<5>), lds); e != hipSuccess) return e;
-                hipLaunchKernelGGL(flash_split_pipe_kernel<5>, grid, dim3(kNW * 64), lds, s, b, reinterpret_cast<const _Float16*>(cache));
-            } else {
-                if (hipError_t e = once4.ensure(reinterpret_cast<const void*>(&flash_split_pipe_kernel<4>), lds); e != hipSuccess) return e;
-                hipLaunchKernelGGL(flash_split_pipe_kernel<4>, grid, dim3(kNW * 64), lds, s, b, reinterpret_cast<const _Float16*>(cache));
-            }
-            return hipGetLastError();
-        }
+    const bool drop = b.drop_p > 0.f;
+    if (terms != 3) {                                            // single fp16 / bf16 products (attention modes 2 / 3)
+        if (kind == kF16) { if (drop) PARQ_PIPE_LAUNCH(4, 0, 1, kF16, true) else PARQ_PIPE_LAUNCH(4, 0, 1, kF16, false) }
+        if (drop) PARQ_PIPE_LAUNCH(4, 0, 1, kBF16, true) else PARQ_PIPE_LAUNCH(4, 0, 1, kBF16, false)
     }
-    if (terms == 3) return b.drop_p > 0.f ? launch_flash_t<3, kF16, true>(b, cache, s) : launch_flash_t<3, kF16>(b, cache, s);
-    if (b.drop_p > 0.f) return kind == kF16 ? launch_flash_t<1, kF16, true>(b, cache, s) : launch_flash_t<1, kBF16, true>(b, cache, s);
-    {
-        static const bool v1h = [] { const char* e = getenv("PARQ_FLASH_V"); return e && e[0] == '1'; }();
-        if (!v1h) {
-            const size_t lds = (size_t)4 * kStageBlks * Blk<1>::bytes;
-            dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * b.H);
-            if (kind == kF16) {
-                static DynLdsOnce once;
-                if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_split_pipe_kernel<4, 0, 1, kF16>), lds); e != hipSuccess) return e;
-                hipLaunchKernelGGL((flash_split_pipe_kernel<4, 0, 1, kF16>), grid, dim3(kNW * 64), lds, s, b, reinterpret_cast<const _Float16*>(cache));
-            } else {
-                static DynLdsOnce once;
-                if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_split_pipe_kernel<4, 0, 1, kBF16>), lds); e != hipSuccess) return e;
-                hipLaunchKernelGGL((flash_split_pipe_kernel<4, 0, 1, kBF16>), grid, dim3(kNW * 64), lds, s, b, reinterpret_cast<const _Float16*>(cache));
-            }
-            return hipGetLastError();
-        }
+    if (drop) PARQ_PIPE_LAUNCH(4, 0, 3, kF16, true)
+    static const int probe = [] { const char* e = getenv("PARQ_FLASH_PROBE"); return e ? atoi(e) : 0; }();   // development: see the kernel
+    switch (probe) {
+        case 0: break;
+        case 1: PARQ_PIPE_LAUNCH(4, 1, 3, kF16, false)
+        case 2: PARQ_PIPE_LAUNCH(4, 2, 3, kF16, false)
+        case 4: PARQ_PIPE_LAUNCH(4, 4, 3, kF16, false)
+        case 6: PARQ_PIPE_LAUNCH(4, 6, 3, kF16, false)
+        case 7: PARQ_PIPE_LAUNCH(4, 7, 3, kF16, false)
+        case 8: PARQ_PIPE_LAUNCH(4, 8, 3, kF16, false)
+        case 16: PARQ_PIPE_LAUNCH(4, 16, 3, kF16, false)
+        case 25: PARQ_PIPE_LAUNCH(4, 25, 3, kF16, false)
+        case 31: PARQ_PIPE_LAUNCH(4, 31, 3, kF16, false)
+        default: return hipErrorInvalidValue;
     }
-    return kind == kF16 ? launch_flash_t<1, kF16>(b, cache, s) : launch_flash_t<1, kBF16>(b, cache, s);
+    static const int ring = [] { const char* e = getenv("PARQ_FLASH_RING"); return e && e[0] == '5' ? 5 : 4; }();
+    if (ring == 5) PARQ_PIPE_LAUNCH(5, 0, 3, kF16, false)
+    PARQ_PIPE_LAUNCH(4, 0, 3, kF16, false)
+#undef PARQ_PIPE_LAUNCH
 }
 
 }  // namespace parq

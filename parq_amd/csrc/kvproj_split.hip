@@ -1,5 +1,5 @@
 // Hoisted K/V in-projection of the memory tokens, written straight into the split-fp16
-// "fragment-ready" cache consumed by flash_split_kernel (layout: flash_split.hip header).
+// "fragment-ready" cache consumed by flash_split_pipe_kernel (layout: flash_split.hip header).
 //
 //   [K | V][b][n][:] = tokens[b][n][:] @ W_kv^T + b_kv        (transformer_parq.py:377-380, hoisted:
 //                                                              SURVEY.md 0.7 — weights shared, memory constant)
