@@ -16,6 +16,7 @@
 #include "common.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace parq {
 
@@ -274,7 +275,7 @@ constexpr int kWsDepth = 2;              // token k-steps in flight
 // other's MFMAs, and a token tile is re-read by 2 column slices instead of 4.
 // TERMS = 3: split products, cache blocks [K_hi|K_lo|V_hi|V_lo]; TERMS = 1: single fp16 / bf16 (KIND) products,
 // W given already converted in a.Whi, cache blocks [K|V] of 8 KB.
-template <int NWV, int TM, int TERMS, int KIND>
+template <int NWV, int TM, int TERMS, int KIND, int NK, bool RAGGED>
 __global__ __launch_bounds__(NWV * 64, 1) void kvproj_ws_kernel(KvProjArgs a, int total_rt, int nrt, int P) {
     constexpr int kBlkH = TERMS == 3 ? 8192 : 4096;      // 16-bit units per 32-key cache block
     constexpr int kVoff = TERMS == 3 ? 4096 : 2048;      // V_hi offset inside a block
@@ -282,17 +283,18 @@ __global__ __launch_bounds__(NWV * 64, 1) void kvproj_ws_kernel(KvProjArgs a, in
     constexpr int kCols = NWV * 32;
     constexpr int RT = TM / 32;                  // 32-row blocks per tile (accumulators per wave)
     constexpr int NI = TM * 8 / kThr;            // 8-float pieces of a k-step tile per thread
+    constexpr int C = NK * kBK;                  // the launcher instantiates NK = a.C / 64
+    static_assert(kWsDepth == 2 && NK % kWsDepth == 0 && NK <= kWsMaxKSteps, "slot / buffer parity below assumes depth 2, even NK");
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];      // [2 buffers][A_hi TMx64 | A_lo TMx64]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: everything derived from it branches uniformly
     const int li = lane & 31, kh = lane >> 5;
-    const int C = a.C;
-    const int nk = C / kBK;
-    const int nslice = 2 * C / kCols;
+    constexpr int nslice = 2 * C / kCols;
     // id -> (persistent slot p, column slice): the slices of one slot share p % 8, i.e. the XCD (L2 reuse of tokens)
     int p, slice;
     {
         const int w = blockIdx.x;
-        const int per = 8 * nslice;
+        constexpr int per = 8 * nslice;
         const int grp = w / per, r = w - grp * per;
         p = grp * 8 + (r & 7);
         slice = r >> 3;
@@ -300,49 +302,53 @@ __global__ __launch_bounds__(NWV * 64, 1) void kvproj_ws_kernel(KvProjArgs a, in
     if (p >= P) return;
     const int n0 = slice * kCols;
     const int col = n0 + wave * 32 + li;          // this lane's output column (B operand row of W_kv)
-    const int headcol = col >> 6;                 // wave-uniform: 32 columns never straddle a head
+    const int headcol = (n0 + wave * 32) >> 6;    // scalar: 32 columns never straddle a head
     const bool isK = headcol < a.H;
     const int ct = (wave & 1);                    // which 32-wide half of the head this wave owns
 
     // ---- W fragments, resident for the whole launch: [k-step][s][hi, lo]
-    half8 wfr[kWsMaxKSteps][4][2];
+    half8 wfr[NK][4][2];
 #pragma unroll
-    for (int ks = 0; ks < kWsMaxKSteps; ++ks)
+    for (int ks = 0; ks < NK; ++ks)
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
-            if (ks < nk) {
-                const int64_t off = (int64_t)col * C + ks * kBK + 32 * kh + 8 * s2;
-                wfr[ks][s2][0] = *reinterpret_cast<const half8*>(a.Whi + off);
-                if constexpr (TERMS == 3) wfr[ks][s2][1] = *reinterpret_cast<const half8*>(a.Wlo + off);
-            }
+            const int64_t off = (int64_t)col * C + ks * kBK + 32 * kh + 8 * s2;
+            wfr[ks][s2][0] = *reinterpret_cast<const half8*>(a.Whi + off);
+            if constexpr (TERMS == 3) wfr[ks][s2][1] = *reinterpret_cast<const half8*>(a.Wlo + off);
         }
     const float* bias = a.bias + headcol * 64;
     const int h = isK ? headcol : headcol - a.H;
     const int nblk = (a.N + 31) / 32;
 
-    bool ovf = false;      // fp16 operand range: tokens (checked where they are converted) and K / V values (epilogue)
-    // token staging registers, kWsDepth k-steps in flight (HBM latency under load is ~3 us, one k-step of MFMAs
-    // ~0.75 us: with a single step in flight the loop runs at latency, not at MFMA or HBM speed)
+    // Control flow matters here.  The token loads run kWsDepth k-steps ahead of their use; hipcc can only keep that distance when it
+    // can COUNT the outstanding VMEM operations, i.e. when loads, stores and uses sit in straight-line code.  With the loads under
+    // `if (q < total)` / `if (tok < N)` branches (the first version of this kernel) every join point got `s_waitcnt vmcnt(0)`: each
+    // k-step waited for the load issued ONE step earlier and the kernel ran at HBM latency per k-step (205 us at cfg 3).  So: loads
+    // are unconditional (clamped step index), NK is a template parameter, the K / V orientation (wave-uniform) selects one of two
+    // copies of the whole loop instead of branching inside it, and scenes whose token count is a multiple of the tile (RAGGED =
+    // false) run a loop without any conditional memory operation: the epilogue's stores are counted too (vmcnt is one in-order
+    // counter for loads and stores), a skipped store would force the conservative wait again.  RAGGED = true clamps the token index,
+    // zeroes rows past N at conversion and skips cache blocks past the scene.
+    const int my_tiles = (total_rt - p + P - 1) / P;          // >= 1: P <= total_rt
+    const int last_step = my_tiles * NK - 1;
     float4 areg[kWsDepth][2 * NI];
-    auto gload = [&](int tile, int ks, float4 (&dst)[2 * NI]) {
+    auto issue = [&](int q, float4 (&dst)[2 * NI]) {
+        const int qq = q < last_step ? q : last_step;          // past the end: re-read the last k-step (never used)
+        const int tile = p + (qq / NK) * P, ks = qq % NK;
         const int b = tile / nrt, m0 = (tile - b * nrt) * TM;
         const float* Xb = a.X + ((int64_t)b * a.N) * C + ks * kBK;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int id = tid + i * kThr;
             const int row = id >> 3, c = id & 7;
-            const int tok = m0 + row;
-            if (tok < a.N) {
-                const float4* q = reinterpret_cast<const float4*>(Xb + (int64_t)tok * C + c * 8);
-                dst[2 * i] = q[0];
-                dst[2 * i + 1] = q[1];
-            } else {
-                dst[2 * i] = float4{0.f, 0.f, 0.f, 0.f};
-                dst[2 * i + 1] = float4{0.f, 0.f, 0.f, 0.f};
-            }
+            const int tok = (!RAGGED || m0 + row < a.N) ? m0 + row : a.N - 1;
+            const float4* q4 = reinterpret_cast<const float4*>(Xb + (int64_t)tok * C + c * 8);
+            dst[2 * i] = q4[0];
+            dst[2 * i + 1] = q4[1];
         }
     };
-    auto swrite = [&](int buf, const float4 (&src)[2 * NI]) {
+    bool ovf = false;      // fp16 operand range: tokens (checked where they are converted) and K / V values (epilogue)
+    auto swrite = [&](int buf, const float4 (&src)[2 * NI], int m0) {
         _Float16* Ahi = lds + buf * (2 * TM * kBK);
         _Float16* Alo = Ahi + TM * kBK;
 #pragma unroll
@@ -350,8 +356,11 @@ __global__ __launch_bounds__(NWV * 64, 1) void kvproj_ws_kernel(KvProjArgs a, in
             const int id = tid + i * kThr;
             const int row = id >> 3, c = id & 7;
             const int pos = c ^ ((row >> 1) & 7);
+            const bool ok = !RAGGED || m0 + row < a.N;         // rows past the scene: zeros, as the cache layout expects
             float x[8] = {src[2 * i].x, src[2 * i].y, src[2 * i].z, src[2 * i].w,
                           src[2 * i + 1].x, src[2 * i + 1].y, src[2 * i + 1].z, src[2 * i + 1].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = ok ? x[e] : 0.f;
             if constexpr (KIND == kF16) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ovf |= !(fabsf(x[e]) < 60000.f);
@@ -366,29 +375,36 @@ __global__ __launch_bounds__(NWV * 64, 1) void kvproj_ws_kernel(KvProjArgs a, in
             }
         }
     };
-    // linear k-step stream over this workgroup's tiles: step q -> (tile p + (q / nk) * P, ks = q % nk)
-    const int my_tiles = p < total_rt ? (total_rt - p + P - 1) / P : 0;
-    const int total_steps = my_tiles * nk;
-    auto issue = [&](int q, float4 (&dst)[2 * NI]) {
-        if (q < total_steps) gload(p + (q / nk) * P, q % nk, dst);
-    };
 
-    int step = 0;                                  // global k-step counter (LDS buffer parity, staging slot)
-    static_assert(kWsDepth == 2 && kWsMaxKSteps % kWsDepth == 0, "slot arithmetic below assumes depth 2");
-    issue(0, areg[0]);
-    issue(1, areg[1]);
-    for (int tile = p; tile < total_rt; tile += P) {
-        f32x16 acc[RT];
+    auto run = [&](auto isk_tag) __attribute__((always_inline)) {
+        constexpr bool ISK = decltype(isk_tag)::value;
+        // bias of this lane's outputs, resident: K (transposed product) registers 8m + e are d = 32 ct + 16 m + 4 kh + (e&3) + 8 (e>>2),
+        // V registers are keys and the lane is d = 32 ct + li
+        float bK[ISK ? 16 : 1];
+        if constexpr (ISK) {
 #pragma unroll
-        for (int i = 0; i < RT; ++i)
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+                for (int e = 0; e < 8; ++e) bK[8 * m + e] = bias[32 * ct + 16 * m + 4 * kh + (e & 3) + 8 * (e >> 2)];
+        } else {
+            bK[0] = bias[32 * ct + li];
+        }
+        int step = 0;                                  // k-steps done (all tiles)
+        issue(0, areg[0]);
+        __builtin_amdgcn_sched_barrier(0);             // program order = issue order: the waits in the loop count on it
+        issue(1, areg[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int tile = p; tile < total_rt; tile += P) {
+            const int b = tile / nrt, m0 = (tile - b * nrt) * TM;
+            f32x16 acc[RT];
 #pragma unroll
-        for (int ks = 0; ks < kWsMaxKSteps; ++ks) {
-            if (ks < nk) {
-                const int buf = step & 1;
-                // nk is even (C % 128 == 0 on this path), so the staging slot of k-step ks is ks & 1 at compile time
-                swrite(buf, areg[ks & 1]);                     // tokens of this k-step (requested two steps ago)
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const int buf = ks & 1;                        // NK is even: LDS buffer and staging slot parity = ks parity
+                swrite(buf, areg[ks & 1], m0);                 // tokens of this k-step (requested two steps ago)
                 issue(step + kWsDepth, areg[ks & 1]);          // refill the slot: two k-steps ahead, across tiles
                 __syncthreads();
                 const _Float16* Ahi = lds + buf * (2 * TM * kBK);
@@ -404,7 +420,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void kvproj_ws_kernel(KvProjArgs a, in
                         if constexpr (TERMS == 3) xl[t] = *reinterpret_cast<const half8*>(Alo + row * kBK + posr * 8);
                     }
                     const half8 wh = wfr[ks][s2][0], wlo = wfr[ks][s2][1];
-                    if (isK) {          // transposed product: rows = d, cols = tokens
+                    if constexpr (ISK) {          // transposed product: rows = d, cols = tokens
 #pragma unroll
                         for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wh, xh[t], acc[t]);
                         if constexpr (TERMS == 3) {
@@ -426,48 +442,307 @@ __global__ __launch_bounds__(NWV * 64, 1) void kvproj_ws_kernel(KvProjArgs a, in
                 }
                 ++step;
             }
-        }
-        // ---- epilogue of this tile: bias, split, 16-byte chunks of the cache blocks (this wave owns one
-        // 32-wide half `ct` of its head: chunks 2ct+m (K) / rows 32ct+li (V))
-        const int b = tile / nrt, m0 = (tile - b * nrt) * TM;
+            // ---- epilogue of this tile: bias, split, 16-byte chunks of the cache blocks (this wave owns one
+            // 32-wide half `ct` of its head: chunks 2ct+m (K) / rows 32ct+li (V))
 #pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            const int blk = (m0 >> 5) + t;
-            if (blk >= nblk) continue;                                   // wave-uniform
-            _Float16* out = a.cache + (((int64_t)b * a.H + h) * nblk + blk) * kBlkH;
+            for (int t = 0; t < RT; ++t) {
+                const int blk = (m0 >> 5) + t;
+                if (RAGGED && blk >= nblk) continue;                         // wave-uniform (scalar)
+                _Float16* out = a.cache + (((int64_t)b * a.H + h) * nblk + blk) * kBlkH;
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                float x[8];
-                if (isK) {
+                for (int m = 0; m < 2; ++m) {
+                    float x[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        x[e] = acc[t][8 * m + e] + bias[32 * ct + 16 * m + 4 * kh + (e & 3) + 8 * (e >> 2)];
-                } else {
-                    const float bv = bias[32 * ct + li];
+                    for (int e = 0; e < 8; ++e) x[e] = acc[t][8 * m + e] + (ISK ? bK[ISK ? 8 * m + e : 0] : bK[0]);
+                    half8 hi, lo;
+                    if constexpr (TERMS == 3) split8(x, hi, lo);
+                    else hi = cvt8_rn<KIND>(x);
+                    if constexpr (KIND == kF16) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) x[e] = acc[t][8 * m + e] + bv;
-                }
-                half8 hi, lo;
-                if constexpr (TERMS == 3) split8(x, hi, lo);
-                else hi = cvt8_rn<KIND>(x);
-                if constexpr (KIND == kF16) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) ovf |= !(fabsf(x[e]) < 60000.f);
-                }
-                if (isK) {
-                    const int c = 4 * kh + 2 * ct + m;
-                    const int pos = c ^ ((li >> 1) & 7);
-                    *reinterpret_cast<half8*>(out + li * 64 + pos * 8) = hi;
-                    if constexpr (TERMS == 3) *reinterpret_cast<half8*>(out + 2048 + li * 64 + pos * 8) = lo;
-                } else {
-                    const int d = 32 * ct + li;
-                    const int pos = (2 * m + kh) ^ ((d >> 2) & 3);
-                    *reinterpret_cast<half8*>(out + kVoff + d * 32 + pos * 8) = hi;
-                    if constexpr (TERMS == 3) *reinterpret_cast<half8*>(out + 6144 + d * 32 + pos * 8) = lo;
+                        for (int e = 0; e < 8; ++e) ovf |= !(fabsf(x[e]) < 60000.f);
+                    }
+                    if constexpr (ISK) {
+                        const int c = 4 * kh + 2 * ct + m;
+                        const int pos = c ^ ((li >> 1) & 7);
+                        *reinterpret_cast<half8*>(out + li * 64 + pos * 8) = hi;
+                        if constexpr (TERMS == 3) *reinterpret_cast<half8*>(out + 2048 + li * 64 + pos * 8) = lo;
+                    } else {
+                        const int d = 32 * ct + li;
+                        const int pos = (2 * m + kh) ^ ((d >> 2) & 3);
+                        *reinterpret_cast<half8*>(out + kVoff + d * 32 + pos * 8) = hi;
+                        if constexpr (TERMS == 3) *reinterpret_cast<half8*>(out + 6144 + d * 32 + pos * 8) = lo;
+                    }
                 }
             }
         }
+    };
+    if (isK) run(std::true_type{});
+    else run(std::false_type{});
+    if (ovf) atomicOr(a.overflow, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same W-stationary walk with the token stream on LDS-DMA and a software-pipelined k-step.
+//
+//   raw[D][TM][64] fp32   filled by global_load_lds (no staging registers), D - 1 k-steps requested ahead
+//   hl[2][hi | lo][TM][64] fp16   the split image the MFMA fragments are read from
+//
+//   iteration q:   s_waitcnt vmcnt(N)      this thread's DMA pieces of k-step q + 1 have landed (N counted by hand, see below)
+//                  barrier                 -> everybody's pieces of q + 1 landed; hl[q & 1] (converted in iteration q - 1) is complete;
+//                                             hl[(q + 1) & 1] and raw[(q - 1) % D] are no longer read by anyone
+//                  DMA of k-step q + D - 1 -> raw[(q - 1) % D]
+//                  convert k-step q + 1: raw -> hl[(q + 1) & 1]        } independent instruction streams of one wave:
+//                  24 MFMAs of k-step q from hl[q & 1]                 } hipcc interleaves the conversion with the MFMAs
+//   ONE barrier per k-step, and the wave that converts is never the wave that waits for the matrix pipe.
+//
+// vmcnt is one in-order counter for loads AND stores.  The wait for k-step q + 1 (issued in iteration q - (D - 2)) may leave
+// outstanding: the DMAs of the D - 3 iterations in between, plus the stores of a tile epilogue if one lies in between (it does
+// when ks(q) < D - 2, except in the workgroup's first tile).  A tile with blocks past the scene skips stores, so its epilogue ends
+// with vmcnt(0) and the counts that follow are merely conservative.  Rows past the scene are read clamped and zeroed at conversion.
+template <int TM, int TERMS, int KIND, int NK, int D>
+__global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int total_rt, int nrt, int P) {
+    constexpr int NWV = 8;
+    constexpr int kBlkH = TERMS == 3 ? 8192 : 4096;      // 16-bit units per 32-key cache block
+    constexpr int kVoff = TERMS == 3 ? 4096 : 2048;      // V_hi offset inside a block
+    constexpr int kThr = NWV * 64;
+    constexpr int kCols = NWV * 32;
+    constexpr int RT = TM / 32;                  // 32-row blocks per tile (accumulators per wave)
+    constexpr int C = NK * kBK;
+    constexpr int kRawBytes = TM * kBK * 4;      // one k-step of fp32 tokens
+    constexpr int NDMA = kRawBytes / (kThr * 16);            // DMA instructions per thread and k-step
+    constexpr int NST = RT * 2 * (TERMS == 3 ? 2 : 1);       // store instructions per thread and tile
+    constexpr int NI = TM * 8 / kThr;            // 8-float pieces of a k-step per thread (conversion)
+    static_assert(D >= 3 && D - 2 <= NK && NDMA >= 1 && NI >= 1, "wait counts below assume at most one epilogue inside the prefetch window");
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    float* raw = reinterpret_cast<float*>(ldsb);
+    _Float16* hl = reinterpret_cast<_Float16*>(ldsb + D * kRawBytes);
+    _Float16* stg = hl + 2 * 2 * TM * kBK;       // epilogue strips: 2 KB per wave
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kh = lane >> 5;
+    constexpr int nslice = 2 * C / kCols;
+    int p, slice;
+    {
+        const int w = blockIdx.x;
+        constexpr int per = 8 * nslice;
+        const int grp = w / per, r = w - grp * per;
+        p = grp * 8 + (r & 7);
+        slice = r >> 3;
     }
+    if (p >= P) return;
+    const int n0 = slice * kCols;
+    const int headcol = (n0 + wave * 32) >> 6;    // scalar: the two waves ct = 0, 1 of a pair share a head
+    const bool isK = headcol < a.H;
+    const int ct = (wave & 1);
+    // Which 32 of the head's 64 dims a wave owns is chosen so that its outputs form whole 64-byte pieces of the cache image
+    // (see the epilogue): V waves own d = 32 ct + li (whole 64-byte V rows); K waves own the dims whose cache chunk has kh' = ct,
+    // accumulator row i <-> d = 32 (i >> 4) + 16 ((i >> 2) & 1) + 8 ((i >> 3) & 1) + 4 ct + (i & 3), so that lane (key, kh) holds in
+    // register group m the chunk s2 = 2 m + kh of its key's row: an aligned 64-byte half row per key and wave.
+    const int dsel = isK ? 32 * (li >> 4) + 16 * ((li >> 2) & 1) + 8 * ((li >> 3) & 1) + 4 * ct + (li & 3) : 32 * ct + li;
+    const int col = headcol * 64 + dsel;          // this lane's row of W_kv
+
+    const float* bias = a.bias + headcol * 64;
+    const int h = isK ? headcol : headcol - a.H;
+    const int nblk = (a.N + 31) / 32;
+    const int my_tiles = (total_rt - p + P - 1) / P;          // >= 1: P <= total_rt
+    const int last_step = my_tiles * NK - 1;
+
+    // k-step q of this workgroup -> (tile, ks); past the end: the last step again (requested, converted, never multiplied)
+    auto dma = [&](int q) {
+        const int qq = q < last_step ? q : last_step;
+        const int tile = p + (qq / NK) * P, ks = qq % NK;
+        const int b = tile / nrt, m0 = (tile - b * nrt) * TM;
+        const float* Xb = a.X + ((int64_t)b * a.N) * C + ks * kBK;
+        lds_byte* dst = (lds_byte*)(ldsb) + (q % D) * kRawBytes;
+#pragma unroll
+        for (int j = 0; j < NDMA; ++j) {
+            const int row = (wave * NDMA + j) * 4 + (lane >> 4);              // one instruction = 4 rows x 256 B = 1 KB of LDS
+            const int tok = m0 + row < a.N ? m0 + row : a.N - 1;
+            const char* src = reinterpret_cast<const char*>(Xb + (int64_t)tok * C) + (lane & 15) * 16;
+            __builtin_amdgcn_global_load_lds(src, dst + (wave * NDMA + j) * 1024, 16, 0, 0);
+        }
+    };
+    bool ovf = false;
+    // conversion of k-step q (tile origin m0): raw[q % D] -> hl[q & 1]
+    auto convert = [&](int q, int m0) {
+        float* src = raw + (q % D) * (TM * kBK);
+        _Float16* Ahi = hl + (q & 1) * (2 * TM * kBK);
+        _Float16* Alo = Ahi + TM * kBK;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int id = tid + i * kThr;
+            const int row = id >> 3, c = id & 7;
+            const int pos = c ^ ((row >> 1) & 7);
+            const bool ok = m0 + row < a.N;         // rows past the scene: zeros
+            // read through inline asm: a C++ read of the DMA ring makes hipcc wait for EVERY outstanding global_load_lds first
+            // (s_waitcnt vmcnt(0): it cannot tell the ring slots apart), which is exactly the prefetch distance this kernel is about
+            typedef float f32x4v __attribute__((ext_vector_type(4)));
+            f32x4v v0, v1;
+            const unsigned addr = (unsigned)(size_t)(lds_byte*)(src + row * kBK + c * 8);
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(v0), "=&v"(v1) : "v"(addr) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0), "+v"(v1)::"memory");
+            float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = ok ? x[e] : 0.f;
+            if constexpr (KIND == kF16) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ovf |= !(fabsf(x[e]) < 60000.f);
+            }
+            if constexpr (TERMS == 3) {
+                half8 hi, lo;
+                split8(x, hi, lo);
+                *reinterpret_cast<half8*>(Ahi + row * kBK + pos * 8) = hi;
+                *reinterpret_cast<half8*>(Alo + row * kBK + pos * 8) = lo;
+            } else {
+                *reinterpret_cast<half8*>(Ahi + row * kBK + pos * 8) = cvt8_rn<KIND>(x);
+            }
+        }
+    };
+    auto tile_m0 = [&](int tile) {
+        const int t = tile < total_rt ? tile : total_rt - 1;
+        const int b = t / nrt;
+        return (t - b * nrt) * TM;
+    };
+
+    auto run = [&](auto isk_tag) __attribute__((always_inline)) {
+        constexpr bool ISK = decltype(isk_tag)::value;
+        // W fragments of this lane's column, resident for the whole launch: [k-step][s][hi, lo]
+        half8 wfr[NK][4][2];
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const int64_t off = (int64_t)col * C + ks * kBK + 32 * kh + 8 * s2;
+                wfr[ks][s2][0] = *reinterpret_cast<const half8*>(a.Whi + off);
+                if constexpr (TERMS == 3) wfr[ks][s2][1] = *reinterpret_cast<const half8*>(a.Wlo + off);
+            }
+        float bK[ISK ? 16 : 1];
+        if constexpr (ISK) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bK[8 * m + e] = bias[16 * (2 * m + kh) + 4 * ct + (e & 3) + 8 * (e >> 2)];
+        } else {
+            bK[0] = bias[32 * ct + li];
+        }
+        // everything requested so far (W fragments, bias) has to be out of the counter before the counted waits start
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < D - 1; ++q) dma(q);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * NDMA) : "memory");
+        __builtin_amdgcn_s_barrier();
+        convert(0, tile_m0(p));
+        int step = 0;
+        bool first = true;
+        for (int tile = p; tile < total_rt; tile += P) {
+            const int b = tile / nrt, m0 = (tile - b * nrt) * TM;
+            const int m0_next = tile_m0(tile + P);
+            f32x16 acc[RT];
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                if (ks < D - 2 && !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 3) * NDMA + NST) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 3) * NDMA) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's conversion writes of k-step q
+                __builtin_amdgcn_s_barrier();
+                dma(step + D - 1);
+                __builtin_amdgcn_sched_barrier(0);
+                convert(step + 1, ks + 1 < NK ? m0 : m0_next);
+                __builtin_amdgcn_sched_barrier(0);
+                const _Float16* Ahi = hl + (ks & 1) * (2 * TM * kBK);      // NK even: buffer parity of step = parity of ks
+                const _Float16* Alo = Ahi + TM * kBK;
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    half8 xh[RT], xl[RT];
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) {
+                        const int row = t * 32 + li;
+                        const int posr = (4 * kh + s2) ^ ((row >> 1) & 7);
+                        xh[t] = *reinterpret_cast<const half8*>(Ahi + row * kBK + posr * 8);
+                        if constexpr (TERMS == 3) xl[t] = *reinterpret_cast<const half8*>(Alo + row * kBK + posr * 8);
+                    }
+                    const half8 wh = wfr[ks][s2][0], wlo = wfr[ks][s2][1];
+                    if constexpr (ISK) {          // transposed product: rows = d, cols = tokens
+#pragma unroll
+                        for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wh, xh[t], acc[t]);
+                        if constexpr (TERMS == 3) {
+#pragma unroll
+                            for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wh, xl[t], acc[t]);
+#pragma unroll
+                            for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wlo, xh[t], acc[t]);
+                        }
+                    } else {            // rows = tokens, cols = d
+#pragma unroll
+                        for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(xh[t], wh, acc[t]);
+                        if constexpr (TERMS == 3) {
+#pragma unroll
+                            for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(xh[t], wlo, acc[t]);
+#pragma unroll
+                            for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(xl[t], wh, acc[t]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                ++step;
+            }
+            // ---- epilogue of this tile: bias, split, and the wave's piece of the cache image through a wave-private LDS strip, so
+            // that every store instruction writes whole 64-byte pieces (16-byte chunks at a 128-byte stride, as the accumulator
+            // layout would give them, reach 3.4 TB/s on this traffic shape against 5.6 TB/s for whole pieces:
+            // tools/bench_src/hbm_stream.hip).  Strip = [32 rows][4 chunks of 16 B] in image order: K rows are keys (the wave's 64-byte
+            // half of each 128-byte row), V rows are the wave's 32 dims (whole 64-byte rows); one store instruction = 16 rows.
+            const bool whole = m0 + TM <= a.N;            // scalar
+            __builtin_amdgcn_sched_barrier(0);
+            _Float16* strip = stg + wave * 1024;
+            const int swz = ISK ? (li >> 1) & 3 : (li >> 2) & 3;     // low bits of the image's chunk swizzle for this lane's row
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                const int blk = (m0 >> 5) + t;
+                if (blk >= nblk) continue;                                   // scalar
+                _Float16* out = a.cache + (((int64_t)b * a.H + h) * nblk + blk) * kBlkH;
+                half8 hi[2], lo[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    float x[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = acc[t][8 * m + e] + (ISK ? bK[ISK ? 8 * m + e : 0] : bK[0]);
+                    if constexpr (TERMS == 3) split8(x, hi[m], lo[m]);
+                    else hi[m] = cvt8_rn<KIND>(x);
+                    if constexpr (KIND == kF16) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ovf |= !(fabsf(x[e]) < 60000.f);
+                    }
+                }
+#pragma unroll
+                for (int pl = 0; pl < (TERMS == 3 ? 2 : 1); ++pl) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        *reinterpret_cast<half8*>(strip + li * 32 + (((2 * m + kh) ^ swz) << 3)) = pl ? lo[m] : hi[m];
+                    // same-wave LDS round trip: DS operations of one wave complete in order
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int row = (lane >> 2) + 16 * j, pc = lane & 3;
+                        const half8 v = *reinterpret_cast<const half8*>(strip + row * 32 + pc * 8);
+                        if constexpr (ISK) {
+                            const int half_row = ct ^ ((row >> 3) & 1);           // bit 2 of the row's swizzle (key >> 1) & 7
+                            *reinterpret_cast<half8*>(out + pl * 2048 + row * 64 + ((4 * half_row + pc) << 3)) = v;
+                        } else {
+                            *reinterpret_cast<half8*>(out + kVoff + pl * 2048 + (32 * ct + row) * 32 + pc * 8) = v;
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (!whole) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // fewer stores than counted: drain
+            __builtin_amdgcn_sched_barrier(0);
+            first = false;
+        }
+    };
+    if (isK) run(std::true_type{});
+    else run(std::false_type{});
     if (ovf) atomicOr(a.overflow, 1);
 }
 
@@ -499,19 +774,51 @@ __global__ void cvt16_kernel(const float* __restrict__ src, _Float16* __restrict
     }
 }
 
-template <int NWV, int TM, int TERMS, int KIND>
-static hipError_t launch_ws(const KvProjArgs& a, int B, hipStream_t s) {
+template <int NWV, int TM, int TERMS, int KIND, int NK, bool RAGGED>
+static hipError_t launch_ws_nk(const KvProjArgs& a, int B, hipStream_t s) {
     static DynLdsOnce once;
     const size_t lds = (size_t)2 * 2 * TM * kBK * sizeof(_Float16);
-    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&kvproj_ws_kernel<NWV, TM, TERMS, KIND>), lds); e != hipSuccess) return e;
+    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&kvproj_ws_kernel<NWV, TM, TERMS, KIND, NK, RAGGED>), lds); e != hipSuccess) return e;
     const int nslice = 2 * a.C / (NWV * 32), nrt = ceil_div(a.N, TM);
     const int total_rt = B * nrt;
     int P = device_num_cus() / nslice;
     if (P < 1) P = 1;
     if (P > total_rt) P = total_rt;
     dim3 grid(ceil_div(P, 8) * 8 * nslice, 1, 1);
-    hipLaunchKernelGGL((kvproj_ws_kernel<NWV, TM, TERMS, KIND>), grid, dim3(NWV * 64), lds, s, a, total_rt, nrt, P);
+    hipLaunchKernelGGL((kvproj_ws_kernel<NWV, TM, TERMS, KIND, NK, RAGGED>), grid, dim3(NWV * 64), lds, s, a, total_rt, nrt, P);
     return hipGetLastError();
+}
+
+template <int TM, int TERMS, int KIND, int NK, int D>
+static hipError_t launch_dma_nk(const KvProjArgs& a, int B, hipStream_t s) {
+    static DynLdsOnce once;
+    const size_t lds = (size_t)D * TM * kBK * 4 + (size_t)2 * 2 * TM * kBK * sizeof(_Float16) + 8 * 2048;
+    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&kvproj_dma_kernel<TM, TERMS, KIND, NK, D>), lds); e != hipSuccess) return e;
+    const int nslice = 2 * a.C / 256, nrt = ceil_div(a.N, TM);
+    const int total_rt = B * nrt;
+    int P = device_num_cus() / nslice;
+    if (P < 1) P = 1;
+    if (P > total_rt) P = total_rt;
+    dim3 grid(ceil_div(P, 8) * 8 * nslice, 1, 1);
+    hipLaunchKernelGGL((kvproj_dma_kernel<TM, TERMS, KIND, NK, D>), grid, dim3(512), lds, s, a, total_rt, nrt, P);
+    return hipGetLastError();
+}
+
+template <int TERMS, int KIND, int D>
+static hipError_t launch_dma(const KvProjArgs& a, int B, hipStream_t s) {
+    if (a.C == 4 * kBK) return launch_dma_nk<64, TERMS, KIND, 4, D>(a, B, s);
+    if constexpr (D <= 4) {
+        if (a.C == 2 * kBK) return launch_dma_nk<64, TERMS, KIND, 2, D>(a, B, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <int NWV, int TM, int TERMS, int KIND>
+static hipError_t launch_ws(const KvProjArgs& a, int B, hipStream_t s) {
+    const bool ragged = a.N % TM != 0;
+    if (a.C == 2 * kBK) return ragged ? launch_ws_nk<NWV, TM, TERMS, KIND, 2, true>(a, B, s) : launch_ws_nk<NWV, TM, TERMS, KIND, 2, false>(a, B, s);
+    if (a.C == 4 * kBK) return ragged ? launch_ws_nk<NWV, TM, TERMS, KIND, 4, true>(a, B, s) : launch_ws_nk<NWV, TM, TERMS, KIND, 4, false>(a, B, s);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_cvt16(const float* src, void* dst, int64_t n, int kind, hipStream_t s) {
@@ -546,10 +853,17 @@ hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void*
             const char* e = getenv("PARQ_KVPROJ_WAVES");
             return e ? atoi(e) : 8;
         }();
+        static const int impl = [] {
+            const char* e = getenv("PARQ_KVPROJ_IMPL");      // 0: register-staged loads, 4 / 5: LDS-DMA ring depth
+            return e ? atoi(e) : 4;
+        }();
         if (terms != 3) {
             if ((2 * C) % 256 != 0) return hipErrorInvalidValue;
+            if (impl >= 4) return kind == kF16 ? launch_dma<1, kF16, 4>(a, B, s) : launch_dma<1, kBF16, 4>(a, B, s);
             return kind == kF16 ? launch_ws<8, 64, 1, kF16>(a, B, s) : launch_ws<8, 64, 1, kBF16>(a, B, s);
         }
+        if (impl == 5 && C == 256 && (2 * C) % 256 == 0) return launch_dma<3, kF16, 5>(a, B, s);
+        if (impl >= 4 && (2 * C) % 256 == 0) return launch_dma<3, kF16, 4>(a, B, s);
         if (waves == 8 && (2 * C) % 256 == 0) return launch_ws<8, 64, 3, kF16>(a, B, s);
         return launch_ws<4, 128, 3, kF16>(a, B, s);
     }
