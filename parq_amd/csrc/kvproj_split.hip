@@ -253,236 +253,13 @@ __global__ __launch_bounds__(kThreads) void kvproj_split_kernel(KvProjArgs a) {
 
 
 // ------------------------------------------------------------------------------------------------
-// W-stationary persistent variant (the one the decoder uses).
+// W-stationary persistent kernel (the one the decoder uses for C = 128 / 256).
 //
-// Measured on the tiled kernel above: 2.3 GB of global->CU traffic per scene (the 128-column W tile is
-// re-fetched for every row tile: 1.5 GB from L2; tokens re-read once per column tile) at ~21 GB/s per CU
-// — the load path, not HBM or MFMA, sets its time.  Here a workgroup OWNS a 128-column slice of W_kv:
-// each of its 4 waves keeps the hi/lo fragments of 32 columns x all K in registers (128 VGPRs) for the
-// whole launch and the workgroup walks the row tiles of the scene batch, streaming only tokens
-// (one 32 KB k-step in flight behind the MFMAs, across tile boundaries too).  LDS holds only the split
-// token tile (double-buffered, one barrier per k-step); B operands never touch LDS.
-// Measured and rejected on this kernel (MI355X, cfg 3, 205 us as is): 4 token k-steps in flight instead of 2 (no change:
-// the loop is not latency-bound); removing the stores -> 179 us, the MFMAs -> 178 us, the loads -> 221 us (no single
-// phase dominates); a software-pipelined k-step (fragments of step q read before the conversion + LDS write of step q+1,
-// barrier at the end) -> 239 us; that plus the previous tile's stores spread between the next tile's MFMAs -> 336 us
-// (64 more live registers, spills).
-constexpr int kWsMaxKSteps = 4;          // K = C <= 256
-constexpr int kWsDepth = 2;              // token k-steps in flight
-
-// NWV waves own NWV*32 output columns; TM token rows per tile.  <4,128>: one wave per SIMD, 388 registers.
-// <8,64>: two waves per SIMD (<= 256 registers each) so one wave's load/barrier stalls are covered by the
-// other's MFMAs, and a token tile is re-read by 2 column slices instead of 4.
-// TERMS = 3: split products, cache blocks [K_hi|K_lo|V_hi|V_lo]; TERMS = 1: single fp16 / bf16 (KIND) products,
-// W given already converted in a.Whi, cache blocks [K|V] of 8 KB.
-template <int NWV, int TM, int TERMS, int KIND, int NK, bool RAGGED>
-__global__ __launch_bounds__(NWV * 64, 1) void kvproj_ws_kernel(KvProjArgs a, int total_rt, int nrt, int P) {
-    constexpr int kBlkH = TERMS == 3 ? 8192 : 4096;      // 16-bit units per 32-key cache block
-    constexpr int kVoff = TERMS == 3 ? 4096 : 2048;      // V_hi offset inside a block
-    constexpr int kThr = NWV * 64;
-    constexpr int kCols = NWV * 32;
-    constexpr int RT = TM / 32;                  // 32-row blocks per tile (accumulators per wave)
-    constexpr int NI = TM * 8 / kThr;            // 8-float pieces of a k-step tile per thread
-    constexpr int C = NK * kBK;                  // the launcher instantiates NK = a.C / 64
-    static_assert(kWsDepth == 2 && NK % kWsDepth == 0 && NK <= kWsMaxKSteps, "slot / buffer parity below assumes depth 2, even NK");
-    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];      // [2 buffers][A_hi TMx64 | A_lo TMx64]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: everything derived from it branches uniformly
-    const int li = lane & 31, kh = lane >> 5;
-    constexpr int nslice = 2 * C / kCols;
-    // id -> (persistent slot p, column slice): the slices of one slot share p % 8, i.e. the XCD (L2 reuse of tokens)
-    int p, slice;
-    {
-        const int w = blockIdx.x;
-        constexpr int per = 8 * nslice;
-        const int grp = w / per, r = w - grp * per;
-        p = grp * 8 + (r & 7);
-        slice = r >> 3;
-    }
-    if (p >= P) return;
-    const int n0 = slice * kCols;
-    const int col = n0 + wave * 32 + li;          // this lane's output column (B operand row of W_kv)
-    const int headcol = (n0 + wave * 32) >> 6;    // scalar: 32 columns never straddle a head
-    const bool isK = headcol < a.H;
-    const int ct = (wave & 1);                    // which 32-wide half of the head this wave owns
-
-    // ---- W fragments, resident for the whole launch: [k-step][s][hi, lo]
-    half8 wfr[NK][4][2];
-#pragma unroll
-    for (int ks = 0; ks < NK; ++ks)
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-            const int64_t off = (int64_t)col * C + ks * kBK + 32 * kh + 8 * s2;
-            wfr[ks][s2][0] = *reinterpret_cast<const half8*>(a.Whi + off);
-            if constexpr (TERMS == 3) wfr[ks][s2][1] = *reinterpret_cast<const half8*>(a.Wlo + off);
-        }
-    const float* bias = a.bias + headcol * 64;
-    const int h = isK ? headcol : headcol - a.H;
-    const int nblk = (a.N + 31) / 32;
-
-    // Control flow matters here.  The token loads run kWsDepth k-steps ahead of their use; hipcc can only keep that distance when it
-    // can COUNT the outstanding VMEM operations, i.e. when loads, stores and uses sit in straight-line code.  With the loads under
-    // `if (q < total)` / `if (tok < N)` branches (the first version of this kernel) every join point got `s_waitcnt vmcnt(0)`: each
-    // k-step waited for the load issued ONE step earlier and the kernel ran at HBM latency per k-step (205 us at cfg 3).  So: loads
-    // are unconditional (clamped step index), NK is a template parameter, the K / V orientation (wave-uniform) selects one of two
-    // copies of the whole loop instead of branching inside it, and scenes whose token count is a multiple of the tile (RAGGED =
-    // false) run a loop without any conditional memory operation: the epilogue's stores are counted too (vmcnt is one in-order
-    // counter for loads and stores), a skipped store would force the conservative wait again.  RAGGED = true clamps the token index,
-    // zeroes rows past N at conversion and skips cache blocks past the scene.
-    const int my_tiles = (total_rt - p + P - 1) / P;          // >= 1: P <= total_rt
-    const int last_step = my_tiles * NK - 1;
-    float4 areg[kWsDepth][2 * NI];
-    auto issue = [&](int q, float4 (&dst)[2 * NI]) {
-        const int qq = q < last_step ? q : last_step;          // past the end: re-read the last k-step (never used)
-        const int tile = p + (qq / NK) * P, ks = qq % NK;
-        const int b = tile / nrt, m0 = (tile - b * nrt) * TM;
-        const float* Xb = a.X + ((int64_t)b * a.N) * C + ks * kBK;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int id = tid + i * kThr;
-            const int row = id >> 3, c = id & 7;
-            const int tok = (!RAGGED || m0 + row < a.N) ? m0 + row : a.N - 1;
-            const float4* q4 = reinterpret_cast<const float4*>(Xb + (int64_t)tok * C + c * 8);
-            dst[2 * i] = q4[0];
-            dst[2 * i + 1] = q4[1];
-        }
-    };
-    bool ovf = false;      // fp16 operand range: tokens (checked where they are converted) and K / V values (epilogue)
-    auto swrite = [&](int buf, const float4 (&src)[2 * NI], int m0) {
-        _Float16* Ahi = lds + buf * (2 * TM * kBK);
-        _Float16* Alo = Ahi + TM * kBK;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int id = tid + i * kThr;
-            const int row = id >> 3, c = id & 7;
-            const int pos = c ^ ((row >> 1) & 7);
-            const bool ok = !RAGGED || m0 + row < a.N;         // rows past the scene: zeros, as the cache layout expects
-            float x[8] = {src[2 * i].x, src[2 * i].y, src[2 * i].z, src[2 * i].w,
-                          src[2 * i + 1].x, src[2 * i + 1].y, src[2 * i + 1].z, src[2 * i + 1].w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = ok ? x[e] : 0.f;
-            if constexpr (KIND == kF16) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ovf |= !(fabsf(x[e]) < 60000.f);
-            }
-            if constexpr (TERMS == 3) {
-                half8 hi, lo;
-                split8(x, hi, lo);
-                *reinterpret_cast<half8*>(Ahi + row * kBK + pos * 8) = hi;
-                *reinterpret_cast<half8*>(Alo + row * kBK + pos * 8) = lo;
-            } else {
-                *reinterpret_cast<half8*>(Ahi + row * kBK + pos * 8) = cvt8_rn<KIND>(x);
-            }
-        }
-    };
-
-    auto run = [&](auto isk_tag) __attribute__((always_inline)) {
-        constexpr bool ISK = decltype(isk_tag)::value;
-        // bias of this lane's outputs, resident: K (transposed product) registers 8m + e are d = 32 ct + 16 m + 4 kh + (e&3) + 8 (e>>2),
-        // V registers are keys and the lane is d = 32 ct + li
-        float bK[ISK ? 16 : 1];
-        if constexpr (ISK) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bK[8 * m + e] = bias[32 * ct + 16 * m + 4 * kh + (e & 3) + 8 * (e >> 2)];
-        } else {
-            bK[0] = bias[32 * ct + li];
-        }
-        int step = 0;                                  // k-steps done (all tiles)
-        issue(0, areg[0]);
-        __builtin_amdgcn_sched_barrier(0);             // program order = issue order: the waits in the loop count on it
-        issue(1, areg[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        for (int tile = p; tile < total_rt; tile += P) {
-            const int b = tile / nrt, m0 = (tile - b * nrt) * TM;
-            f32x16 acc[RT];
-#pragma unroll
-            for (int i = 0; i < RT; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < NK; ++ks) {
-                const int buf = ks & 1;                        // NK is even: LDS buffer and staging slot parity = ks parity
-                swrite(buf, areg[ks & 1], m0);                 // tokens of this k-step (requested two steps ago)
-                issue(step + kWsDepth, areg[ks & 1]);          // refill the slot: two k-steps ahead, across tiles
-                __syncthreads();
-                const _Float16* Ahi = lds + buf * (2 * TM * kBK);
-                const _Float16* Alo = Ahi + TM * kBK;
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) {
-                    half8 xh[RT], xl[RT];
-#pragma unroll
-                    for (int t = 0; t < RT; ++t) {
-                        const int row = t * 32 + li;
-                        const int posr = (4 * kh + s2) ^ ((row >> 1) & 7);
-                        xh[t] = *reinterpret_cast<const half8*>(Ahi + row * kBK + posr * 8);
-                        if constexpr (TERMS == 3) xl[t] = *reinterpret_cast<const half8*>(Alo + row * kBK + posr * 8);
-                    }
-                    const half8 wh = wfr[ks][s2][0], wlo = wfr[ks][s2][1];
-                    if constexpr (ISK) {          // transposed product: rows = d, cols = tokens
-#pragma unroll
-                        for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wh, xh[t], acc[t]);
-                        if constexpr (TERMS == 3) {
-#pragma unroll
-                            for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wh, xl[t], acc[t]);
-#pragma unroll
-                            for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wlo, xh[t], acc[t]);
-                        }
-                    } else {            // rows = tokens, cols = d
-#pragma unroll
-                        for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(xh[t], wh, acc[t]);
-                        if constexpr (TERMS == 3) {
-#pragma unroll
-                            for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(xh[t], wlo, acc[t]);
-#pragma unroll
-                            for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(xl[t], wh, acc[t]);
-                        }
-                    }
-                }
-                ++step;
-            }
-            // ---- epilogue of this tile: bias, split, 16-byte chunks of the cache blocks (this wave owns one
-            // 32-wide half `ct` of its head: chunks 2ct+m (K) / rows 32ct+li (V))
-#pragma unroll
-            for (int t = 0; t < RT; ++t) {
-                const int blk = (m0 >> 5) + t;
-                if (RAGGED && blk >= nblk) continue;                         // wave-uniform (scalar)
-                _Float16* out = a.cache + (((int64_t)b * a.H + h) * nblk + blk) * kBlkH;
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    float x[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) x[e] = acc[t][8 * m + e] + (ISK ? bK[ISK ? 8 * m + e : 0] : bK[0]);
-                    half8 hi, lo;
-                    if constexpr (TERMS == 3) split8(x, hi, lo);
-                    else hi = cvt8_rn<KIND>(x);
-                    if constexpr (KIND == kF16) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) ovf |= !(fabsf(x[e]) < 60000.f);
-                    }
-                    if constexpr (ISK) {
-                        const int c = 4 * kh + 2 * ct + m;
-                        const int pos = c ^ ((li >> 1) & 7);
-                        *reinterpret_cast<half8*>(out + li * 64 + pos * 8) = hi;
-                        if constexpr (TERMS == 3) *reinterpret_cast<half8*>(out + 2048 + li * 64 + pos * 8) = lo;
-                    } else {
-                        const int d = 32 * ct + li;
-                        const int pos = (2 * m + kh) ^ ((d >> 2) & 3);
-                        *reinterpret_cast<half8*>(out + kVoff + d * 32 + pos * 8) = hi;
-                        if constexpr (TERMS == 3) *reinterpret_cast<half8*>(out + 6144 + d * 32 + pos * 8) = lo;
-                    }
-                }
-            }
-        }
-    };
-    if (isK) run(std::true_type{});
-    else run(std::false_type{});
-    if (ovf) atomicOr(a.overflow, 1);
-}
-
-// ------------------------------------------------------------------------------------------------
-// The same W-stationary walk with the token stream on LDS-DMA and a software-pipelined k-step.
+// Measured on the tiled kernel above: 2.3 GB of global->CU traffic per scene (the 128-column W tile is re-fetched for every row
+// tile: 1.5 GB from L2; tokens re-read once per column tile) — the load path, not HBM or MFMA, sets its time.  Here a workgroup
+// of 8 waves OWNS a 256-column slice of W_kv (all K heads or all V heads at C = 256): each wave keeps the hi/lo fragments of 32
+// columns x all K in registers (128 VGPRs) for the whole launch and the workgroup walks 64-token tiles of the scene batch,
+// streaming only tokens; B operands never touch LDS.  The token stream is LDS-DMA with a software-pipelined k-step:
 //
 //   raw[D][TM][64] fp32   filled by global_load_lds (no staging registers), D - 1 k-steps requested ahead
 //   hl[2][hi | lo][TM][64] fp16   the split image the MFMA fragments are read from
@@ -499,7 +276,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void kvproj_ws_kernel(KvProjArgs a, in
 // outstanding: the DMAs of the D - 3 iterations in between, plus the stores of a tile epilogue if one lies in between (it does
 // when ks(q) < D - 2, except in the workgroup's first tile).  A tile with blocks past the scene skips stores, so its epilogue ends
 // with vmcnt(0) and the counts that follow are merely conservative.  Rows past the scene are read clamped and zeroed at conversion.
-template <int TM, int TERMS, int KIND, int NK, int D>
+// PROBE (development, results wrong by construction; tools/kvproj_probe.sh): bit 0 no MFMAs, 1 no global stores, 2 no conversion
+// (MFMAs on whatever LDS holds), 3 no token DMA, 4 no epilogue at all
+template <int TM, int TERMS, int KIND, int NK, int D, int PROBE = 0>
 __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int total_rt, int nrt, int P) {
     constexpr int NWV = 8;
     constexpr int kBlkH = TERMS == 3 ? 8192 : 4096;      // 16-bit units per 32-key cache block
@@ -555,6 +334,7 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
         const int b = tile / nrt, m0 = (tile - b * nrt) * TM;
         const float* Xb = a.X + ((int64_t)b * a.N) * C + ks * kBK;
         lds_byte* dst = (lds_byte*)(ldsb) + (q % D) * kRawBytes;
+        if constexpr (PROBE & 8) return;
 #pragma unroll
         for (int j = 0; j < NDMA; ++j) {
             const int row = (wave * NDMA + j) * 4 + (lane >> 4);              // one instruction = 4 rows x 256 B = 1 KB of LDS
@@ -566,6 +346,7 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
     bool ovf = false;
     // conversion of k-step q (tile origin m0): raw[q % D] -> hl[q & 1]
     auto convert = [&](int q, int m0) {
+        if constexpr (PROBE & 4) return;
         float* src = raw + (q % D) * (TM * kBK);
         _Float16* Ahi = hl + (q & 1) * (2 * TM * kBK);
         _Float16* Alo = Ahi + TM * kBK;
@@ -645,14 +426,14 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) {
-                if (ks < D - 2 && !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 3) * NDMA + NST) : "memory");
+                if constexpr ((PROBE & (2 | 8 | 16)) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // counts do not hold
+                else if (ks < D - 2 && !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 3) * NDMA + NST) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 3) * NDMA) : "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's conversion writes of k-step q
                 __builtin_amdgcn_s_barrier();
                 dma(step + D - 1);
                 __builtin_amdgcn_sched_barrier(0);
                 convert(step + 1, ks + 1 < NK ? m0 : m0_next);
-                __builtin_amdgcn_sched_barrier(0);
                 const _Float16* Ahi = hl + (ks & 1) * (2 * TM * kBK);      // NK even: buffer parity of step = parity of ks
                 const _Float16* Alo = Ahi + TM * kBK;
 #pragma unroll
@@ -666,7 +447,10 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
                         if constexpr (TERMS == 3) xl[t] = *reinterpret_cast<const half8*>(Alo + row * kBK + posr * 8);
                     }
                     const half8 wh = wfr[ks][s2][0], wlo = wfr[ks][s2][1];
-                    if constexpr (ISK) {          // transposed product: rows = d, cols = tokens
+                    if constexpr (PROBE & 1) {
+#pragma unroll
+                        for (int t = 0; t < RT; ++t) acc[t][0] += (float)xh[t][0] * (float)wh[0] + (TERMS == 3 ? (float)xl[t][1] * (float)wlo[1] : 0.f);
+                    } else if constexpr (ISK) {          // transposed product: rows = d, cols = tokens
 #pragma unroll
                         for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wh, xh[t], acc[t]);
                         if constexpr (TERMS == 3) {
@@ -685,7 +469,6 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
                             for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(xl[t], wh, acc[t]);
                         }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
                 ++step;
             }
@@ -696,6 +479,11 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
             // half of each 128-byte row), V rows are the wave's 32 dims (whole 64-byte rows); one store instruction = 16 rows.
             const bool whole = m0 + TM <= a.N;            // scalar
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PROBE & 16) {
+                if (acc[0][0] == 123.456f) a.cache[tid] = (_Float16)acc[RT - 1][3];
+                first = false;
+                continue;
+            }
             _Float16* strip = stg + wave * 1024;
             const int swz = ISK ? (li >> 1) & 3 : (li >> 2) & 3;     // low bits of the image's chunk swizzle for this lane's row
 #pragma unroll
@@ -726,7 +514,9 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
                     for (int j = 0; j < 2; ++j) {
                         const int row = (lane >> 2) + 16 * j, pc = lane & 3;
                         const half8 v = *reinterpret_cast<const half8*>(strip + row * 32 + pc * 8);
-                        if constexpr (ISK) {
+                        if constexpr (PROBE & 2) {
+                            if (v[0] == (_Float16)123.f) out[tid] = v[1];
+                        } else if constexpr (ISK) {
                             const int half_row = ct ^ ((row >> 3) & 1);           // bit 2 of the row's swizzle (key >> 1) & 7
                             *reinterpret_cast<half8*>(out + pl * 2048 + row * 64 + ((4 * half_row + pc) << 3)) = v;
                         } else {
@@ -774,33 +564,18 @@ __global__ void cvt16_kernel(const float* __restrict__ src, _Float16* __restrict
     }
 }
 
-template <int NWV, int TM, int TERMS, int KIND, int NK, bool RAGGED>
-static hipError_t launch_ws_nk(const KvProjArgs& a, int B, hipStream_t s) {
-    static DynLdsOnce once;
-    const size_t lds = (size_t)2 * 2 * TM * kBK * sizeof(_Float16);
-    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&kvproj_ws_kernel<NWV, TM, TERMS, KIND, NK, RAGGED>), lds); e != hipSuccess) return e;
-    const int nslice = 2 * a.C / (NWV * 32), nrt = ceil_div(a.N, TM);
-    const int total_rt = B * nrt;
-    int P = device_num_cus() / nslice;
-    if (P < 1) P = 1;
-    if (P > total_rt) P = total_rt;
-    dim3 grid(ceil_div(P, 8) * 8 * nslice, 1, 1);
-    hipLaunchKernelGGL((kvproj_ws_kernel<NWV, TM, TERMS, KIND, NK, RAGGED>), grid, dim3(NWV * 64), lds, s, a, total_rt, nrt, P);
-    return hipGetLastError();
-}
-
-template <int TM, int TERMS, int KIND, int NK, int D>
+template <int TM, int TERMS, int KIND, int NK, int D, int PROBE = 0>
 static hipError_t launch_dma_nk(const KvProjArgs& a, int B, hipStream_t s) {
     static DynLdsOnce once;
     const size_t lds = (size_t)D * TM * kBK * 4 + (size_t)2 * 2 * TM * kBK * sizeof(_Float16) + 8 * 2048;
-    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&kvproj_dma_kernel<TM, TERMS, KIND, NK, D>), lds); e != hipSuccess) return e;
+    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&kvproj_dma_kernel<TM, TERMS, KIND, NK, D, PROBE>), lds); e != hipSuccess) return e;
     const int nslice = 2 * a.C / 256, nrt = ceil_div(a.N, TM);
     const int total_rt = B * nrt;
     int P = device_num_cus() / nslice;
     if (P < 1) P = 1;
     if (P > total_rt) P = total_rt;
     dim3 grid(ceil_div(P, 8) * 8 * nslice, 1, 1);
-    hipLaunchKernelGGL((kvproj_dma_kernel<TM, TERMS, KIND, NK, D>), grid, dim3(512), lds, s, a, total_rt, nrt, P);
+    hipLaunchKernelGGL((kvproj_dma_kernel<TM, TERMS, KIND, NK, D, PROBE>), grid, dim3(512), lds, s, a, total_rt, nrt, P);
     return hipGetLastError();
 }
 
@@ -810,14 +585,6 @@ static hipError_t launch_dma(const KvProjArgs& a, int B, hipStream_t s) {
     if constexpr (D <= 4) {
         if (a.C == 2 * kBK) return launch_dma_nk<64, TERMS, KIND, 2, D>(a, B, s);
     }
-    return hipErrorInvalidValue;
-}
-
-template <int NWV, int TM, int TERMS, int KIND>
-static hipError_t launch_ws(const KvProjArgs& a, int B, hipStream_t s) {
-    const bool ragged = a.N % TM != 0;
-    if (a.C == 2 * kBK) return ragged ? launch_ws_nk<NWV, TM, TERMS, KIND, 2, true>(a, B, s) : launch_ws_nk<NWV, TM, TERMS, KIND, 2, false>(a, B, s);
-    if (a.C == 4 * kBK) return ragged ? launch_ws_nk<NWV, TM, TERMS, KIND, 4, true>(a, B, s) : launch_ws_nk<NWV, TM, TERMS, KIND, 4, false>(a, B, s);
     return hipErrorInvalidValue;
 }
 
@@ -847,25 +614,25 @@ hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void*
     a.X = tokens; a.Whi = reinterpret_cast<const _Float16*>(Whi); a.Wlo = reinterpret_cast<const _Float16*>(Wlo);
     a.bias = bias; a.cache = reinterpret_cast<_Float16*>(cache); a.overflow = overflow; a.N = N; a.C = C; a.H = H;
     const int nct = 2 * C / kBN, nrt = ceil_div(N, kBM);
-    if (C <= kWsMaxKSteps * kBK && C % (2 * kBK) == 0) {
-        // W-stationary persistent kernel: one workgroup per CU, column slices of one slot on one XCD
-        static const int waves = [] {
-            const char* e = getenv("PARQ_KVPROJ_WAVES");
-            return e ? atoi(e) : 8;
-        }();
-        static const int impl = [] {
-            const char* e = getenv("PARQ_KVPROJ_IMPL");      // 0: register-staged loads, 4 / 5: LDS-DMA ring depth
-            return e ? atoi(e) : 4;
-        }();
-        if (terms != 3) {
-            if ((2 * C) % 256 != 0) return hipErrorInvalidValue;
-            if (impl >= 4) return kind == kF16 ? launch_dma<1, kF16, 4>(a, B, s) : launch_dma<1, kBF16, 4>(a, B, s);
-            return kind == kF16 ? launch_ws<8, 64, 1, kF16>(a, B, s) : launch_ws<8, 64, 1, kBF16>(a, B, s);
+    if (C <= 4 * kBK && C % (2 * kBK) == 0) {
+        // W-stationary persistent kernel: one workgroup per CU, the column slices of one slot on one XCD
+        if (terms != 3) return kind == kF16 ? launch_dma<1, kF16, 4>(a, B, s) : launch_dma<1, kBF16, 4>(a, B, s);
+        static const int probe = [] { const char* e = getenv("PARQ_KVPROJ_PROBE"); return e ? atoi(e) : 0; }();      // development
+        if (probe && C == 256) {
+            switch (probe) {
+                case 1: return launch_dma_nk<64, 3, kF16, 4, 4, 1>(a, B, s);
+                case 2: return launch_dma_nk<64, 3, kF16, 4, 4, 2>(a, B, s);
+                case 16: return launch_dma_nk<64, 3, kF16, 4, 4, 16>(a, B, s);
+                case 17: return launch_dma_nk<64, 3, kF16, 4, 4, 17>(a, B, s);
+                case 20: return launch_dma_nk<64, 3, kF16, 4, 4, 20>(a, B, s);
+                case 21: return launch_dma_nk<64, 3, kF16, 4, 4, 21>(a, B, s);
+                case 29: return launch_dma_nk<64, 3, kF16, 4, 4, 29>(a, B, s);
+                default: break;
+            }
         }
-        if (impl == 5 && C == 256 && (2 * C) % 256 == 0) return launch_dma<3, kF16, 5>(a, B, s);
-        if (impl >= 4 && (2 * C) % 256 == 0) return launch_dma<3, kF16, 4>(a, B, s);
-        if (waves == 8 && (2 * C) % 256 == 0) return launch_ws<8, 64, 3, kF16>(a, B, s);
-        return launch_ws<4, 128, 3, kF16>(a, B, s);
+        static const int depth = [] { const char* e = getenv("PARQ_KVPROJ_RING"); return e ? atoi(e) : 4; }();       // 5: one more k-step in flight (no gain measured)
+        if (depth == 5 && C == 256) return launch_dma<3, kF16, 5>(a, B, s);
+        return launch_dma<3, kF16, 4>(a, B, s);
     }
     if (terms != 3) return hipErrorInvalidValue;            // the single-term modes exist on the persistent kernel only
     dim3 grid(ceil_div(nrt, 8) * 8 * nct, B, 1);
