@@ -726,10 +726,10 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
     auto tile_dma = [&](int n, int slot) {
         const int it = n / ntiles, tile = n - it * ntiles;
         const char* src = reinterpret_cast<const char*>(pack + (((int64_t)it * gridDim.y + bh) * ntiles + tile) * kImgHalfs);
-        lds_byte* dst = (lds_byte*)(Stg + slot * kImgHalfs);
-        __builtin_amdgcn_global_load_lds(src + (size_t)tid * 16, dst + wave * 1024, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(src + 8192 + (size_t)tid * 16, dst + 8192 + wave * 1024, 16, 0, 0);
-        if (tid < 32) __builtin_amdgcn_global_load_lds(src + 16384 + (size_t)tid * 16, dst + 16384, 16, 0, 0);
+        const unsigned dst = (unsigned)(size_t)(lds_byte*)(Stg + slot * kImgHalfs);
+        lds_dma16(src + (size_t)tid * 16, dst + wave * 1024);
+        lds_dma16(src + 8192 + (size_t)tid * 16, dst + 8192 + wave * 1024);
+        if (tid < 32) lds_dma16(src + 16384 + (size_t)tid * 16, dst + 16384);
     };
     // per-lane pieces of the transpose reads (constant over the tiles)
     //   dV / dK A operand (rows d = 32 dt + li, k = queries): piece row i_base + (t16 >> 2), i_base = 16 m + 4 kh (+ 8), d piece 32 dt + 16 (g16 & 1) + 4 (t16 & 3)
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
         // flight: VMEM operations retire in order); the barrier makes every wave's pieces visible and closes the previous tile's reads
         if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        __syncthreads();
+        lds_barrier();                                      // LDS-only barrier: the dQ stores stay in flight
         if (n + 1 < ntot) tile_dma(n + 1, (n + 1) & 1);     // the other slot was last read before the barrier above
         const float* st = reinterpret_cast<const float*>(Im + 8192);
 
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
                 gk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtl, sh[m], gk[dt], 0, 0, 0);
                 }
         // ---- dQ tile = dS K over the 256 keys of the workgroup: wave w owns the 16 x 16 block (queries 16 (w>>2).., d 16 (w&3)..)
-        __syncthreads();
+        lds_barrier();
         {
             typedef float f32x4v __attribute__((ext_vector_type(4)));
             f32x4v g4 = f32x4v{0.f, 0.f, 0.f, 0.f};

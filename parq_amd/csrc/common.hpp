@@ -14,6 +14,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kWave = 64;
 constexpr int kGnSlots = 64;    // GroupNorm moment accumulators per (scene, group): spreads the fp64 atomics
 
+// LDS-DMA (global_load_lds, 16 bytes per lane, wave-uniform LDS base + lane * 16) issued through inline asm.  hipcc knows that the
+// builtin writes LDS asynchronously and answers with s_waitcnt vmcnt(0) in front of later C++ reads of LDS it cannot prove
+// disjoint — which turns a prefetch into a blocking load.  Through asm the compiler does not see it: the caller waits with a
+// counted s_waitcnt vmcnt(N) + a barrier before anybody reads the destination.
+// (M0 is written here behind the compiler's back: do not mix with __builtin_amdgcn_global_load_lds in one kernel.)
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_base) {
+    const unsigned base = __builtin_amdgcn_readfirstlane(lds_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(base), "v"(gsrc) : "memory");
+}
+// workgroup barrier that only orders LDS traffic: __syncthreads() is a release / acquire fence and makes hipcc wait for every
+// outstanding global store and load (s_waitcnt vmcnt(0)) first
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: a process that drives several GPUs must set
 // it on each of them.  One static instance per kernel; bit d of `done` = already set on device ordinal d.
 struct DynLdsOnce {
