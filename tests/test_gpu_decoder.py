@@ -134,6 +134,11 @@ def test_cfg2_reduced_precision_modes(mode, tol):
     (1, 3, 9, 10, 150, 2, 512, 256),       # head dim 256 with two heads, Q = 150: a partly filled second query tile of 128
     (3, 1, 7, 9, 300, 4, 1024, 768),       # three scenes of 63 tokens (< one token tile, 2 key blocks), Q = 300: three query tiles, the last
                                            # with one inactive wave pair
+    (2, 2, 69, 77, 32, 4, 256, 768),       # K/V projection walk: 2 x 10 626 tokens = 2 x 167 token tiles over 128 persistent slots, so
+                                           # workgroups carry 2-3 tiles, scene 0's partial tile (2 rows) sits in the MIDDLE of a walk
+                                           # (counted waits across a drained epilogue), and tiles cross the scene boundary
+    (1, 4, 70, 90, 32, 2, 128, 96),        # the same at C = 128 (two k-steps per tile: every wait has an epilogue inside its prefetch
+                                           # window): 25 200 tokens = 394 tiles over 256 slots, last tile 48 rows
 ])
 def test_ragged_shapes_vs_fp64_oracle(B, V, h, w, Q, heads, dim, ffn):
     """Ragged query counts / scene counts / feature maps through the whole chain (tile tails of the small-GEMM,
