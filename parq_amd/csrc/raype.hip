@@ -272,7 +272,7 @@ __global__ __launch_bounds__(kThreads) void gemm_split_kernel(GemmArgs a) {
 
 
 // ================================================================================================
-// Fused fast path (C = 256, 64 samples): two persistent W-stationary kernels, modelled on kvproj_ws_kernel.
+// Fused fast path (C = 256, 64 samples): two persistent W-stationary kernels, modelled on the K/V projection (kvproj_split.hip).
 //
 //   raype_hidden_kernel  hidden = relu(p W1^T + b1).  A workgroup of 8 waves owns all 256 hidden units (each wave
 //                        keeps the hi/lo fragments of its 32 rows of W1 in registers), walks 64-token tiles and

@@ -106,7 +106,7 @@ def _decoder_errors(fscale, wscale, mode, iters=2):
 @pytest.mark.parametrize("fscale", [1e-3, 1.0, 1e2])
 @pytest.mark.parametrize("wscale", [0.1, 1.0, 10.0])
 def test_decoder_feature_and_weight_scale_sweep(fscale, wscale):
-    """K/V projection (kvproj_ws_kernel: tokens split on the fly) + cross-attention + the rest of the chain at feature scales
+    """K/V projection (kvproj_dma_kernel: tokens split on the fly) + cross-attention + the rest of the chain at feature scales
     1e-3 ... 1e2 and in-projection scales 0.1 ... 10: 1e-4 against the float64 oracle, or fp32-class (2x the exact-fp32
     kernels' error) where fp32 arithmetic itself cannot do better."""
     e_split, flagged, _ = _decoder_errors(fscale, wscale, "split")
