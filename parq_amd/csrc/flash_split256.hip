@@ -17,7 +17,9 @@
 // LDS (all 160 KB): K ring 2 x 32 KB, V ring 2 x 32 KB ([chunk][hi | lo] images filled by LDS-DMA), exchange 32 KB.  One stage =
 // one 32-key block.  K_{t+2} is requested at the mid-stage barrier (every wave is past QK(t)), V_{t+2} at the end-of-stage barrier
 // (every wave is past PV(t)): each request has a full stage of compute to land.  VMEM operations retire in order, so the waits
-// count the DMA groups issued after the one that is needed (4 instructions per thread and group).
+// count the DMA groups issued after the one that is needed (4 instructions per thread and group).  The DMA is issued through asm
+// and the barriers order LDS only (common.hpp: lds_dma16 / lds_barrier): with the builtin and __syncthreads() hipcc put
+// s_waitcnt vmcnt(0) in front of the barriers and LDS reads, i.e. every stage waited for the requests it had just made.
 #include "common.hpp"
 #include <cstdlib>
 
@@ -78,11 +80,11 @@ __global__ __launch_bounds__(kNW * 64) void flash_split256_kernel(FlashArgs a, c
     // one DMA group = K (which = 0) or V (which = 1) of block t: instruction c copies the 8 KB [hi | lo] of chunk c
     auto gload = [&](int t, int which) {
         _Float16* ring = which ? Vr : Kr;
-        lds_byte* dst = (lds_byte*)(ring + ((t - t_begin) & 1) * kGrpHalfs);
+        const unsigned dst = (unsigned)(size_t)(lds_byte*)(ring + ((t - t_begin) & 1) * kGrpHalfs);
 #pragma unroll
         for (int c = 0; c < kChunks; ++c) {
             const _Float16* src = cbase + ((int64_t)c * nblk + t) * kSubHalfs + which * 4096 + tid * 8;
-            __builtin_amdgcn_global_load_lds(src, dst + (c * 512 + wave * 64) * 16, 16, 0, 0);
+            lds_dma16(src, dst + (c * 512 + wave * 64) * 16);      // asm-issued: hipcc must not answer with vmcnt(0) before LDS reads
         }
     };
     auto wait_groups = [&](int n) {                           // at most n DMA groups (4 instructions each) still in flight
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split256_kernel(FlashArgs a, c
     if (t_begin + 1 < t_end) { gload(t_begin + 1, 0); gload(t_begin + 1, 1); }
     // K of the first block must be complete and visible: groups issued after it = V_t0 (+ K, V of the second block)
     wait_groups(t_begin + 1 < t_end ? 3 : 1);
-    __syncthreads();
+    lds_barrier();
 
     const int ksw = (li >> 1) & 7;
     for (int t = t_begin; t < t_end; ++t) {
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split256_kernel(FlashArgs a, c
         }
         // V_t must be complete before the barrier that publishes it: groups issued after V_t are K_{t+1}, V_{t+1}
         wait_groups(more1 ? 2 : 0);
-        __syncthreads();                                     // mid-stage: partial scores exchanged, K slot of block t free, V_t visible
+        lds_barrier();                                       // mid-stage: partial scores exchanged, K slot of block t free, V_t visible
         if (more2) gload(t + 2, 0);
         if (active) {
 #pragma unroll
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split256_kernel(FlashArgs a, c
         }
         // K_{t+1} must be complete before the barrier that publishes it: groups issued after it are V_{t+1}, K_{t+2}
         if (more1) wait_groups(more2 ? 2 : 1);
-        __syncthreads();                                     // end of stage: V slot of block t and the exchange area are free, K_{t+1} visible
+        lds_barrier();                                       // end of stage: V slot of block t and the exchange area are free, K_{t+1} visible
         if (more2) gload(t + 2, 1);
     }
 
