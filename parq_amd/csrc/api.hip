@@ -149,7 +149,8 @@ bool kvproj_big_on() {
 // per-iteration launches.
 bool bwd_batched_ok(const parq_ctx* c, int64_t N) {
     // c->bwd_batched_env is read from PARQ_BWD_BATCHED when the handle is created (not on the launch path)
-    return c->bwd_batched_env && c->nl == 1 && c->dh == 64 && N >= 2048 && c->I > 1 && c->I <= 16;
+    // head dim 64: the register-resident split kernel (long key axes); head dim 256: the composition from split-precision GEMMs
+    return c->bwd_batched_env && c->nl == 1 && ((c->dh == 64 && N >= 2048) || c->dh == 256) && c->I > 1 && c->I <= 16;
 }
 
 int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws) {
@@ -210,7 +211,14 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     ws->g_Dall = take(ws->bwd_batched ? nit * (int64_t)B * c->H * flash_lq_pad((int)Q) : 0);
     ws->g_pack = take(ws->bwd_batched ? (int64_t)attn_bwd_pack_floats(B, c->H, (int)Q, (int)nit) : 0);
     // head dims without a register-resident attention backward (not 32 / 64): score-matrix scratch of the materialised path
-    ws->g_mat = take((c->dh == 64 || c->dh == 32) ? 0 : (int64_t)attn_bwd_mat_scratch_floats((int)Q, (int)(N > Q ? N : Q), c->dh));
+    {
+        int64_t mat = (c->dh == 64 || c->dh == 32) ? 0 : (int64_t)attn_bwd_mat_scratch_floats((int)Q, (int)(N > Q ? N : Q), c->dh);
+        if (ws->bwd_batched && c->dh == 256) {        // S^T / dP^T of all iterations of one (scene, head): 3.1 GB at cfg 3
+            const int64_t b256 = (int64_t)attn_bwd_batched256_scratch_floats(c->I, (int)Q, (int)N);
+            mat = b256 > mat ? b256 : mat;
+        }
+        ws->g_mat = take(mat);
+    }
     ws->g_kvmax = take(4);                            // [0] bits of max |dK|, |dV| (batched backward), [1] the derived scale
     ws->train_total = off;
     return PARQ_OK;
@@ -1111,7 +1119,11 @@ int parq_backward(parq_handle h, const parq_scene* scene, void* workspace, size_
                                        wsp + ws.g_Dall, (int64_t)B * H * flash_lq_pad(Q), wsp + ws.g_dq, MC, (int64_t)Q * C, dh, C, gkv,
                                        2 * N * C, dh, 2 * C, gkv + C, 2 * N * C, dh, 2 * C, B, H, Q, (int)N, dh, I, s, wsp + ws.g_dqp,
                                        h->drop_p, seeds, reinterpret_cast<unsigned int*>(wsp + ws.g_bs),
-                                       reinterpret_cast<unsigned int*>(wsp + ws.g_kvmax), wsp + ws.g_pack));
+                                       reinterpret_cast<unsigned int*>(wsp + ws.g_kvmax), wsp + ws.g_pack, wsp + ws.g_mat));
+        if (dh == 256) {                          // max |dK|, |dV| for the split-precision dW_kv GEMM (the dh = 64 kernel records it itself)
+            HIPCHK(hipMemsetAsync(wsp + ws.g_kvmax, 0, sizeof(unsigned int), s));
+            HIPCHK(launch_absmax(gkv, (int64_t)B * 2 * N * C, reinterpret_cast<unsigned int*>(wsp + ws.g_kvmax), s));
+        }
     }
     for (int k = I - 1; k >= 0; --k) {
         rc = do_backward_iter(h, scene, wsp, ws, k, iter_io(k), grad_arena, d_tokens, s, 2);

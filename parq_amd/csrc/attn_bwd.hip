@@ -1120,6 +1120,142 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
     return hipGetLastError();
 }
 
+// ================================================================================================ head dim 256, batched iterations
+// The reference's shipped decoder size (DEC_DIM 1024 / 4 heads).  A register-resident kernel like attn_bwd_split2_kernel does not fit
+// a 256-deep contraction, so the backward of all iterations that share K / V is composed, per (scene, head), from the split-precision
+// GEMMs the library already has (fp16 hi/lo operands, 3-term products: fp32-class), with the scores kept TRANSPOSED (rows = keys) so
+// that four of the five products are "tall matrix x small weight" launches of gemm_split_kernel (raype.hip):
+//     S^T  [Lk][R] = K  [Lk][256] . Q_all^T        R = n_it * Lq query rows of all iterations (padded to 512: QP)
+//     dP^T [Lk][R] = V  [Lk][256] . (s dO_all)^T   s = the power-of-two gradient scale of the split kernels
+//     P', dS' elementwise in place (P' = 2^14 P with dropout, dS' = s dS: same staging as attn_bwd_split2_kernel)
+//     dV [Lk][256] = P'^T-rows . dO_all   dK [Lk][256] = dS'^T-rows . Q_all        (contraction over the R query rows)
+//     dQ_all [R][256] = sum over keys dS'[key][r] K[key][d]: the 512 x 256 TN kernel of the K/V-projection backward, per 512-row slice
+// 3.1 GB of scratch at cfg 3 (two [Lk][2048] fp32 matrices), reused for every (scene, head).
+struct Bwd256Args {
+    const float* q; int64_t q_batch, q_head, q_row;
+    const float* dO; int64_t do_it, do_batch, do_head, do_row;
+    const float* lse; const float* D; int64_t D_it;
+    float* gq; int64_t gq_it, gq_batch, gq_head, gq_row;
+    int64_t q_off[kMaxBwdIters], lse_off[kMaxBwdIters];
+    uint32_t seeds[kMaxBwdIters];
+    int n_it, Lq, Lq_pad, Lk, QP, H;
+    float drop_p;
+};
+
+// fp16 hi/lo planes of Q_all and s dO_all, row-major [QP][256] and transposed [256][QP]; rows past n_it * Lq are zero
+__global__ __launch_bounds__(256) void bwd256_planes_kernel(Bwd256Args a, int b, int h, const float* __restrict__ oscale_ptr,
+                                                            _Float16* __restrict__ planes) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)a.QP * 256) return;
+    const int r = (int)(idx >> 8), d = (int)(idx & 255);
+    float qv = 0.f, ov = 0.f;
+    if (r < a.n_it * a.Lq) {
+        const int it = r / a.Lq, i = r - it * a.Lq;
+        qv = a.q[a.q_off[it] + (int64_t)b * a.q_batch + (int64_t)h * a.q_head + (int64_t)i * a.q_row + d];
+        ov = a.dO[(int64_t)it * a.do_it + (int64_t)b * a.do_batch + (int64_t)h * a.do_head + (int64_t)i * a.do_row + d] * *oscale_ptr;
+    }
+    half2v qh, ql, oh, ol;
+    split_pair(qv, 0.f, qh, ql);
+    split_pair(ov, 0.f, oh, ol);
+    const int64_t P = (int64_t)a.QP * 256;                   // one plane
+    planes[0 * P + idx] = qh[0]; planes[1 * P + idx] = ql[0];          // Q   [QP][256]
+    planes[2 * P + idx] = oh[0]; planes[3 * P + idx] = ol[0];          // dO  [QP][256]
+    const int64_t t = (int64_t)d * a.QP + r;
+    planes[4 * P + t] = qh[0]; planes[5 * P + t] = ql[0];              // Q^T  [256][QP]
+    planes[6 * P + t] = oh[0]; planes[7 * P + t] = ol[0];              // dO^T [256][QP]
+}
+
+// in place: ST -> P' (2^14 x probability, dropout applied), dPT -> dS' (gradient scale s still on it); max |dS'| for the TN kernel's range
+__global__ __launch_bounds__(256) void bwd256_elem_kernel(float* __restrict__ ST, float* __restrict__ dPT, Bwd256Args a, int bh,
+                                                          const float* __restrict__ oscale_ptr, float c2, unsigned int* __restrict__ ds_absmax) {
+    const int64_t n = (int64_t)a.Lk * a.QP;
+    float mx = 0.f;
+    const float os = *oscale_ptr;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
+        const int j = (int)(idx / a.QP), r = (int)(idx - (int64_t)j * a.QP);
+        float p = 0.f, ds = 0.f;
+        if (r < a.n_it * a.Lq) {
+            const int it = r / a.Lq, i = r - it * a.Lq;
+            const float lse = a.lse[a.lse_off[it] + (int64_t)bh * a.Lq_pad + i];
+            const float Dv = a.D[(int64_t)it * a.D_it + (int64_t)bh * a.Lq_pad + i];
+            p = __builtin_amdgcn_exp2f(ST[idx] * c2 - (lse - kPShift));
+            float keep = 1.f;
+            if (a.drop_p > 0.f)
+                keep = drop_keep(drop_rowhash(a.seeds[it], (uint32_t)(bh * a.Lq + i)), (uint32_t)j, a.drop_p) ? 1.f / (1.f - a.drop_p) : 0.f;
+            ds = p * (dPT[idx] * (keep * kPShiftInv) - Dv * os * kPShiftInv);
+            p *= keep;
+        }
+        ST[idx] = p;
+        dPT[idx] = ds;
+        mx = fmaxf(mx, fabsf(ds));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(ds_absmax, __float_as_uint(mx));
+}
+
+// gq[it][b][i][h * 256 + d] += dQ_all[r][d] * cn / s
+__global__ __launch_bounds__(256) void bwd256_dq_scatter_kernel(const float* __restrict__ dq_all, Bwd256Args a, int b, int h,
+                                                                const float* __restrict__ oscale_ptr, float cn) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)a.n_it * a.Lq * 256) return;
+    const int r = (int)(idx >> 8), d = (int)(idx & 255);
+    const int it = r / a.Lq, i = r - it * a.Lq;
+    a.gq[(int64_t)it * a.gq_it + (int64_t)b * a.gq_batch + (int64_t)h * a.gq_head + (int64_t)i * a.gq_row + d] += dq_all[idx] * (cn / *oscale_ptr);
+}
+
+static int bwd256_qp(int n_it, int Lq) { return (n_it * Lq + 511) & ~511; }
+
+size_t attn_bwd_batched256_scratch_floats(int n_it, int Lq, int Lk) {
+    const int64_t QP = bwd256_qp(n_it, Lq);
+    return (size_t)(2 * (int64_t)Lk * QP + 1024      // S^T / P' and dP^T / dS' (+ slack: the TN kernel reads whole 512-column slices)
+                    + QP * 1024                      // 8 fp16 planes of QP x 256
+                    + QP * 256 + QP + 16);           // dQ_all, a column-sum dummy, scalars
+}
+
+static hipError_t attn_bwd_batched_256(const AttnBwdArgs& a, int64_t gq_it, const float* oscale, float* scratch, hipStream_t s) {
+    const int Lq = a.Lq, Lk = a.Lk, QP = bwd256_qp(a.n_it, Lq);
+    Bwd256Args g;
+    g.q = a.q; g.q_batch = a.q_batch; g.q_head = a.q_head; g.q_row = a.q_row;
+    g.dO = a.dO; g.do_it = a.do_it; g.do_batch = a.do_batch; g.do_head = a.do_head; g.do_row = a.do_row;
+    g.lse = a.lse; g.D = a.D; g.D_it = a.D_it;
+    g.gq = a.gq; g.gq_it = gq_it; g.gq_batch = a.gq_batch; g.gq_head = a.gq_head; g.gq_row = a.gq_row;
+    for (int t = 0; t < kMaxBwdIters; ++t) { g.q_off[t] = a.q_off[t]; g.lse_off[t] = a.lse_off[t]; g.seeds[t] = a.seeds[t]; }
+    g.n_it = a.n_it; g.Lq = Lq; g.Lq_pad = (Lq + 31) & ~31; g.Lk = Lk; g.QP = QP; g.H = a.H; g.drop_p = a.drop_p;
+    float* ST = scratch;
+    float* dPT = ST + (int64_t)Lk * QP;
+    _Float16* planes = reinterpret_cast<_Float16*>(dPT + (int64_t)Lk * QP + 1024);
+    float* dq_all = reinterpret_cast<float*>(planes) + (int64_t)QP * 1024;
+    float* dummy = dq_all + (int64_t)QP * 256;
+    unsigned int* ds_absmax = reinterpret_cast<unsigned int*>(dummy + QP);
+    float* tn_scale = reinterpret_cast<float*>(ds_absmax + 1);
+    const int64_t P = (int64_t)QP * 256;
+    const float c2 = 1.4426950408889634f / 16.f, cn = 1.f / 16.f;
+    hipError_t e;
+    for (int b = 0; b < a.B; ++b)
+        for (int h = 0; h < a.H; ++h) {
+            const int bh = b * a.H + h;
+            const float* k = a.k + (int64_t)b * a.k_batch + (int64_t)h * a.k_head;
+            const float* v = a.v + (int64_t)b * a.v_batch + (int64_t)h * a.v_head;
+            float* gk = a.gk + (int64_t)b * a.gk_batch + (int64_t)h * a.gk_head;
+            float* gv = a.gv + (int64_t)b * a.gv_batch + (int64_t)h * a.gv_head;
+            hipLaunchKernelGGL(bwd256_planes_kernel, dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, s, g, b, h, oscale, planes);
+            if ((e = launch_gemm_split(k, a.k_row, planes + 0 * P, planes + 1 * P, nullptr, ST, QP, Lk, QP, 256, 0, nullptr, 1, s)) != hipSuccess) return e;
+            if ((e = launch_gemm_split(v, a.v_row, planes + 2 * P, planes + 3 * P, nullptr, dPT, QP, Lk, QP, 256, 0, nullptr, 1, s)) != hipSuccess) return e;
+            if ((e = hipMemsetAsync(ds_absmax, 0, sizeof(unsigned int), s)) != hipSuccess) return e;
+            hipLaunchKernelGGL(bwd256_elem_kernel, dim3(4096), dim3(256), 0, s, ST, dPT, g, bh, oscale, c2, ds_absmax);
+            // dV = P'^T dO' / (2^14 s),  dK = dS'^T Q cn / s
+            if ((e = launch_gemm_split(ST, QP, planes + 6 * P, planes + 7 * P, nullptr, gv, a.gv_row, Lk, 256, QP, 0, nullptr, 1, s, oscale, kPShiftInv)) != hipSuccess) return e;
+            if ((e = launch_gemm_split(dPT, QP, planes + 4 * P, planes + 5 * P, nullptr, gk, a.gk_row, Lk, 256, QP, 0, nullptr, 1, s, oscale, cn)) != hipSuccess) return e;
+            // dQ_all = dS'^T-contraction with K, 512 query rows per launch
+            if ((e = hipMemsetAsync(dq_all, 0, (size_t)QP * 256 * sizeof(float), s)) != hipSuccess) return e;
+            for (int r0 = 0; r0 < QP; r0 += 512)
+                if ((e = launch_tn_split_512x256(dPT + r0, QP, k, a.k_row, Lk, dq_all + (int64_t)r0 * 256, 256, nullptr, ds_absmax, tn_scale, s)) != hipSuccess) return e;
+            hipLaunchKernelGGL(bwd256_dq_scatter_kernel, dim3((unsigned)ceil_div64((int64_t)a.n_it * Lq * 256, 256)), dim3(256), 0, s, dq_all, g, b, h, oscale, cn);
+        }
+    return hipGetLastError();
+}
+
 // Cross-attention backward of n_it recurrent iterations that share K / V (hoisted projection, shared layer weights) in ONE launch of
 // the split-precision kernel: dK / dV are written once instead of read-modify-written per iteration, and the K / V prologue and the
 // transposing epilogue are paid once per key block instead of once per iteration.  q / lse of iteration t live at q + q_off[t] /
@@ -1132,8 +1268,9 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
                                    int64_t gq_batch, int64_t gq_head, int64_t gq_row, float* gk, int64_t gk_batch, int64_t gk_head,
                                    int64_t gk_row, float* gv, int64_t gv_batch, int64_t gv_head, int64_t gv_row, int B, int H, int Lq,
                                    int Lk, int dh, int n_it, hipStream_t s, float* gq_part, float drop_p, const uint32_t* seeds,
-                                   unsigned int* absmax, unsigned int* kv_absmax, void* pack) {
-    if (dh != 64 || Lk < 2048 || n_it < 1 || n_it > kMaxBwdIters || !gq_part || !absmax) return hipErrorInvalidValue;
+                                   unsigned int* absmax, unsigned int* kv_absmax, void* pack, float* mat_scratch) {
+    if (n_it < 1 || n_it > kMaxBwdIters || !absmax) return hipErrorInvalidValue;
+    if (dh == 256 ? !mat_scratch : (dh != 64 || Lk < 2048 || !gq_part)) return hipErrorInvalidValue;
     AttnBwdArgs a;
     a.q = q; a.q_batch = q_batch; a.q_head = q_head; a.q_row = q_row;
     a.k = k; a.k_batch = k_batch; a.k_head = k_head; a.k_row = k_row;
@@ -1163,6 +1300,7 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
         hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, s, dO + (int64_t)t * do_it, (int64_t)B * do_batch, absmax);
     float* oscale = reinterpret_cast<float*>(absmax + 1);
     hipLaunchKernelGGL(oscale_kernel, dim3(1), dim3(1), 0, s, absmax, oscale);
+    if (dh == 256) return attn_bwd_batched_256(a, gq_it, oscale, mat_scratch, s);     // (kv_absmax: taken by the caller over its dK | dV buffer)
     dim3 g2(ceil_div(Lk, kSpKW), B * H);
     const int Lq_pad = (Lq + 31) & ~31;
     static const bool v1 = [] { const char* e = getenv("PARQ_ATTN_BWD_V"); return e && e[0] == '1'; }();
@@ -1211,6 +1349,12 @@ hipError_t launch_attn_bwd_rowdot(const float* dO, const float* O, int64_t batch
                                   hipStream_t s) {
     hipLaunchKernelGGL(attn_bwd_rowdot_kernel, dim3((unsigned)ceil_div64((int64_t)B * H * Lq, 4)), dim3(256), 0, s, dO, O, batch, row,
                        B * H, H, Lq, dh, D);
+    return hipGetLastError();
+}
+
+// out[0] = max(out[0], bit pattern of max |x|) (out zeroed by the caller)
+hipError_t launch_absmax(const float* x, int64_t n, unsigned int* out, hipStream_t s) {
+    hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, s, x, n, out);
     return hipGetLastError();
 }
 

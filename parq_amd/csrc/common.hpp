@@ -291,15 +291,21 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
                                    int64_t gk_row, float* gv, int64_t gv_batch, int64_t gv_head, int64_t gv_row, int B, int H, int Lq,
                                    int Lk, int dh, int n_it, hipStream_t s, float* gq_part, float drop_p, const uint32_t* seeds,
                                    unsigned int* absmax, unsigned int* kv_absmax = nullptr,    // kv_absmax: out, max |dK|, |dV| (float bits)
-                                   void* pack = nullptr);   // pack: attn_bwd_pack_floats(...) floats of scratch -> second-version kernel
+                                   void* pack = nullptr,
+                                   float* mat_scratch = nullptr);  // pack: attn_bwd_pack_floats(...) floats of scratch -> second-version kernel;
+                                                                   // mat_scratch (dh == 256): attn_bwd_batched256_scratch_floats(n_it, Lq, Lk) floats
 size_t attn_bwd_pack_floats(int B, int H, int Lq, int n_it);
 // kvproj_bwd.hip: dW_kv / db_kv of the hoisted projection on the fp16 matrix pipe (hi/lo split), C = 256
 bool kvproj_bwd_split_supported(int C);
+hipError_t launch_tn_split_512x256(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t M, float* out, int64_t ldo,
+                                   float* db, const unsigned int* absmax_bits, float* scale_scratch, hipStream_t s);
 hipError_t launch_kvproj_bwd_split(const float* g, const float* tokens, int64_t M, int C, float* dW, float* db,
                                    const unsigned int* absmax_bits, float* scale_scratch, hipStream_t s);
 // dst = dropout(src): keep mask of stream `seed` over the (M, N) index space, scaled by 1 / (1 - p)
 hipError_t launch_dropout_apply(const float* src, float* dst, int M, int N, float p, uint32_t seed, hipStream_t s);
 size_t attn_bwd_dq_partial_floats(int B, int H, int Lq, int Lk, int dh);
+size_t attn_bwd_batched256_scratch_floats(int n_it, int Lq, int Lk);
+hipError_t launch_absmax(const float* x, int64_t n, unsigned int* out, hipStream_t s);
 hipError_t launch_attn_bwd_rowdot(const float* dO, const float* O, int64_t batch, int64_t row, int B, int H, int Lq, int dh, float* D,
                                   hipStream_t s);
 // postproc.hip: parse_pred + 3-D NMS on the device
@@ -307,7 +313,8 @@ hipError_t launch_parse_pred(const float* center, const float* size, const float
                              int num_semcls, const float* track_scale6, int for_vis, int enable_nms, float* obbs,
                              unsigned char* mask, hipStream_t s);
 hipError_t launch_gemm_split(const float* X, int64_t ldx, const void* Whi, const void* Wlo, const float* bias, float* Y,
-                             int64_t ldy, int M, int N, int K, int relu, const float* feat, int hw, hipStream_t s);
+                             int64_t ldy, int M, int N, int K, int relu, const float* feat, int hw, hipStream_t s,
+                             const float* scale_dev = nullptr, float scale_mul = 1.f);
 
 // ------------------------------------------------------------------ elementwise / gather kernels
 hipError_t launch_camera_local(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V,

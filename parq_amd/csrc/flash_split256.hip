@@ -34,6 +34,9 @@ constexpr int kGrpHalfs = kChunks * 4096;           // K (or V) of a stage: [chu
 constexpr int kNW = 8;
 constexpr float kDeferLog2 = 10.f;
 
+// DROP: training dropout on the probabilities (keep decision of element (row = scene-head * Lq + query, column = key), the stream
+// the backward regenerates); the row sum l is taken before the mask, 1 / (1 - p) is applied to the output partials.
+template <bool DROP>
 __global__ __launch_bounds__(kNW * 64) void flash_split256_kernel(FlashArgs a, const _Float16* __restrict__ cache) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
     _Float16* Kr = smem_h;                                   // [2][kGrpHalfs]
@@ -100,6 +103,8 @@ __global__ __launch_bounds__(kNW * 64) void flash_split256_kernel(FlashArgs a, c
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    const uint32_t drop_row = DROP ? drop_rowhash(a.drop_seed, (uint32_t)(bh * a.Lq + (q < a.Lq ? q : 0))) : 0u;
+    const uint32_t drop_thr = DROP ? drop_threshold(a.drop_p) : 0u;
 
     // issue order: K_t0, V_t0, K_t0+1, V_t0+1, then per stage K_{t+2} (mid barrier), V_{t+2} (end barrier)
     if (t_begin < t_end) { gload(t_begin, 0); gload(t_begin, 1); }
@@ -171,6 +176,9 @@ __global__ __launch_bounds__(kNW * 64) void flash_split256_kernel(FlashArgs a, c
                 for (int e = 0; e < 8; ++e) {
                     p[e] = __builtin_amdgcn_exp2f(sacc[8 * m + e] - m_run);
                     rs += p[e];
+                    if constexpr (DROP) {
+                        if (!drop_keep_h(drop_row, drop_colhash((uint32_t)(t * 32 + mfma32_row(8 * m + e, lane))), drop_thr)) p[e] = 0.f;
+                    }
                 }
                 split8(p, phi[m], plo[m]);
             }
@@ -199,10 +207,11 @@ __global__ __launch_bounds__(kNW * 64) void flash_split256_kernel(FlashArgs a, c
     if (active) {
         const int64_t pbase = (int64_t)bh * a.nsplit + split;
         float* op = a.o_part + pbase * kDH * Lq_pad;
+        const float drop_scale = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) op[(int64_t)(128 * half + j * 32 + mfma32_row(r, lane)) * Lq_pad + q] = o[j][r];
+            for (int r = 0; r < 16; ++r) op[(int64_t)(128 * half + j * 32 + mfma32_row(r, lane)) * Lq_pad + q] = o[j][r] * drop_scale;
         if (half == 0 && kh == 0) {
             a.m_part[pbase * Lq_pad + q] = m_run;
             a.l_part[pbase * Lq_pad + q] = l_run;
@@ -226,12 +235,17 @@ int flash_split256_pick_splits(int B, int H, int Lq, int Lk, int num_cus) {
 
 // partial (O, m, l) of every (scene-head, key split) in the layout flash_merge_kernel<256> combines; cache: virtual-head split cache
 hipError_t launch_flash_split256(const FlashArgs& a, const void* cache, hipStream_t s) {
-    if (a.dh != kDH || a.nsplit < 1 || a.nsplit > 256 || a.drop_p > 0.f) return hipErrorInvalidValue;
-    static DynLdsOnce once;
+    if (a.dh != kDH || a.nsplit < 1 || a.nsplit > 256) return hipErrorInvalidValue;
+    static DynLdsOnce once, once_drop;
     const size_t lds = (size_t)4 * kGrpHalfs * sizeof(_Float16) + (size_t)kNW * 16 * 64 * sizeof(float);       // 160 KB
-    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_split256_kernel), lds); e != hipSuccess) return e;
     dim3 grid(a.nsplit, ceil_div(a.Lq, 128), a.B * a.H);
-    hipLaunchKernelGGL(flash_split256_kernel, grid, dim3(kNW * 64), lds, s, a, reinterpret_cast<const _Float16*>(cache));
+    if (a.drop_p > 0.f) {
+        if (hipError_t e = once_drop.ensure(reinterpret_cast<const void*>(&flash_split256_kernel<true>), lds); e != hipSuccess) return e;
+        hipLaunchKernelGGL(flash_split256_kernel<true>, grid, dim3(kNW * 64), lds, s, a, reinterpret_cast<const _Float16*>(cache));
+    } else {
+        if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_split256_kernel<false>), lds); e != hipSuccess) return e;
+        hipLaunchKernelGGL(flash_split256_kernel<false>, grid, dim3(kNW * 64), lds, s, a, reinterpret_cast<const _Float16*>(cache));
+    }
     return hipGetLastError();
 }
 

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(512, 1) void kvproj_bwd_split_kernel(KvBwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) atomicAdd(o + (int64_t)mfma32_row(r, lane) * a.ldw, acc[i][j][r] * inv_sc);
         }
-    if (isA) atomicAdd(a.db + slab * kCols + col, csum);
+    if (isA && a.db) atomicAdd(a.db + slab * kCols + col, csum);
 }
 
 // scale[0] = 2^(10 - exponent(max)) from the float bit pattern in bits[0] (1 when the maximum is 0 or not finite)
@@ -173,6 +173,26 @@ bool kvproj_bwd_split_supported(int C) { return C == kCols; }
 
 // g [M][2C], tokens [M][C] -> dW [2C][C] (+=), db [2C] (+=).  absmax_bits: device word holding the bit pattern of max |g|
 // (non-negative floats order like unsigned integers); scale_scratch: one device float.
+// The same contraction for any [M][512-column slice] operand: out[n][k] += sum_m g[m][n] x[m][k], n < 512, k < 256; g rows ldg apart
+// (the head-dim-256 attention backward forms dQ^T slices this way: g = dS^T, x = K).  db may be null.
+hipError_t launch_tn_split_512x256(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t M, float* out, int64_t ldo,
+                                   float* db, const unsigned int* absmax_bits, float* scale_scratch, hipStream_t s) {
+    if (M < 1 || M > (int64_t)INT32_MAX) return hipErrorInvalidValue;
+    static DynLdsOnce once;
+    const size_t ldsb = (size_t)2 * kBufHalfs * sizeof(_Float16);          // 128 KB
+    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&kvproj_bwd_split_kernel), ldsb); e != hipSuccess) return e;
+    hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, s, absmax_bits, scale_scratch);
+    KvBwdArgs a;
+    a.g = g; a.ldg = ldg; a.x = x; a.ldx = ldx; a.dW = out; a.ldw = ldo; a.db = db; a.scale = scale_scratch; a.M = (int)M;
+    const int steps = (int)((M + kTM - 1) / kTM);
+    int nsplit = device_num_cus() / 2;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > steps) nsplit = steps;
+    a.nsplit = nsplit;
+    hipLaunchKernelGGL(kvproj_bwd_split_kernel, dim3(2 * nsplit), dim3(512), ldsb, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_kvproj_bwd_split(const float* g, const float* tokens, int64_t M, int C, float* dW, float* db,
                                    const unsigned int* absmax_bits, float* scale_scratch, hipStream_t s) {
     if (C != kCols || M < 1 || M > (int64_t)INT32_MAX) return hipErrorInvalidValue;

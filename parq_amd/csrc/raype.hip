@@ -110,6 +110,7 @@ struct GemmArgs {
     const float* bias;                 // [N]
     float* Y; int64_t ldy;             // [M][N] row-major
     int M, N, K, relu;
+    const float* scale_dev; float scale_mul;   // optional: Y = (X W^T) * scale_mul / *scale_dev (bias-free callers: attention backward)
     // optional: Y[m][n] += feat[(m / hw) * N * hw + n * hw + (m % hw)]   (NCHW feature maps, (B*V, C, h, w))
     const float* feat; int hw;
 };
@@ -258,12 +259,13 @@ __global__ __launch_bounds__(kThreads) void gemm_split_kernel(GemmArgs a) {
         __builtin_amdgcn_wave_barrier();
     }
     const int ncol = n0 + wc * 64 + lane;
-    const float bv = ncol < a.N ? a.bias[ncol] : 0.f;
+    const float bv = (a.bias && ncol < a.N) ? a.bias[ncol] : 0.f;
+    const float osc = a.scale_dev ? a.scale_mul / *a.scale_dev : a.scale_mul;
     for (int r = 0; r < 64; ++r) {
         const int m = m0 + wr * 64 + r;
         if (m >= a.M) break;
         if (ncol < a.N) {
-            float y = ot[r * 65 + lane] + bv;
+            float y = ot[r * 65 + lane] * osc + bv;
             if (a.relu) y = y > 0.f ? y : 0.f;
             a.Y[(int64_t)m * a.ldy + ncol] = y;
         }
@@ -643,7 +645,8 @@ hipError_t launch_raype_fused(const float* cam, const float* T_cp, const float* 
 
 // Y[M][N] = act(X[M][K] @ W^T + bias) (+ NCHW features); W given as fp16 hi/lo [N][K]; K % 64 == 0
 hipError_t launch_gemm_split(const float* X, int64_t ldx, const void* Whi, const void* Wlo, const float* bias, float* Y,
-                             int64_t ldy, int M, int N, int K, int relu, const float* feat, int hw, hipStream_t s) {
+                             int64_t ldy, int M, int N, int K, int relu, const float* feat, int hw, hipStream_t s,
+                             const float* scale_dev, float scale_mul) {
     if (K % kBK != 0 || M < 1 || N < 1 || (relu && feat)) return hipErrorInvalidValue;
     static DynLdsOnce once;
     const size_t ldsb = 4 * 64 * 65 * sizeof(float);                    // 66560 B >= the 64 KB of operand staging
@@ -651,6 +654,7 @@ hipError_t launch_gemm_split(const float* X, int64_t ldx, const void* Whi, const
     GemmArgs a;
     a.X = X; a.ldx = ldx; a.Whi = reinterpret_cast<const _Float16*>(Whi); a.Wlo = reinterpret_cast<const _Float16*>(Wlo);
     a.bias = bias; a.Y = Y; a.ldy = ldy; a.M = M; a.N = N; a.K = K; a.relu = relu; a.feat = feat; a.hw = hw;
+    a.scale_dev = scale_dev; a.scale_mul = scale_mul;
     const int nct = ceil_div(N, kBN), nrt = ceil_div(M, kBM);
     const int64_t wgs = (int64_t)ceil_div(nrt, 8) * 8 * nct;
     if (wgs > 0x7fffffffLL) return hipErrorInvalidValue;

@@ -46,7 +46,9 @@ def oracle_grads(cfg, W, sc, cots):
     (2, 2, 5, 6, 16, 2, 128, 64, 2, False),
     (2, 2, 32, 40, 40, 2, 128, 96, 2, True),       # N = 2560 keys: the MFMA cross-attention backward with dQ partial buffers
     (2, 2, 32, 41, 24, 4, 256, 128, 3, True),      # d = 256, N = 2624 (ragged 32-row steps): batched backward + split-precision dW_kv
-    (2, 2, 9, 11, 40, 1, 256, 96, 2, True),        # head dim 256 (the reference's shipped head size): materialised attention backward
+    (2, 2, 9, 11, 40, 1, 256, 96, 2, True),        # head dim 256 (the reference's shipped head size): all iterations in one composition
+                                                   # of split-precision GEMMs (S^T, dP^T, dV, dK; dQ by the 512 x 256 TN kernel)
+    (1, 2, 32, 41, 24, 4, 1024, 256, 3, True),     # the shipped dims themselves (d = 1024, 4 heads of 256), N = 2624, three iterations
     (1, 2, 10, 13, 20, 2, 256, 96, 2, False),      # head dim 128, unshared layers, ragged key count (N = 260)
 ])
 def test_backward_matches_oracle_autograd(B, V, h, w, Q, heads, dim, ffn, layers, shared):
@@ -211,16 +213,17 @@ def _masked_mha(xq, xk, xv, in_w, in_b, out_w, out_b, H, pmask):
     return torch.nn.functional.linear((p @ v).transpose(1, 2).reshape(B, Lq, Cd), out_w, out_b)
 
 
-@pytest.mark.parametrize("h,w,Hh", [(8, 10, 2), (32, 40, 2), (8, 10, 1)])    # N = 160: exact-fp32 attention backward; N = 2560: split-precision
-                                                                              # kernel; one head of 128 dims: materialised backward
-def test_dropout_forward_backward_match_masked_oracle(h, w, Hh):
+@pytest.mark.parametrize("h,w,Hh,dim", [(8, 10, 2, 128), (32, 40, 2, 128), (8, 10, 1, 128), (12, 14, 1, 256)])    # N = 160: exact-fp32 attention backward; N = 2560: split-precision
+                                                                              # kernel; one head of 128 dims: materialised backward;
+                                                                              # one head of 256 dims: the batched composition from split GEMMs
+def test_dropout_forward_backward_match_masked_oracle(h, w, Hh, dim):
     """Train-mode dropout (six sites of the decoder layer, transformer_parq.py:339-386): the library's counter-based masks are
     dumped (parq_k_dropout_mask) and applied at the same sites in a float64 torch restatement of the layer; outputs and all
     gradients must then agree like in the dropout-free test.  Also: masks change with the seed, the drop rate is ~p."""
     import ctypes as C
     from parq_amd import _lib
     F_ = torch.nn.functional
-    B, V, Q, dim, ffn, I = 2, 2, 32, 128, 96, 2
+    B, V, Q, ffn, I = 2, 2, 32, 96, 2
     pdrop = 0.25
     cfg = synth.decoder_cfg(dim=dim, queries=Q, heads=Hh, ffn=ffn, layers=I, dropout=pdrop)
     W = synth.make_decoder_weights(cfg, 101)
