@@ -166,8 +166,10 @@ int parq_profile_read(parq_handle h, int32_t which, double *total_ms, int64_t *l
 /* ---- training: forward with saved activations + backward (model/parq_lightning.py:97-100) ----------
  * The backward of the whole decoder chain as HIP kernels.  Every attention mode (in the cache modes 1 - 3 the forward streams the
  * 16-bit cache and the backward gets fp32 K / V rebuilt from it: hi + lo in mode 1, the rounded values themselves in the fp16 /
- * bf16 modes 2 / 3, i.e. the gradient is taken straight through the operand rounding of the reduced-precision forward).  Head dims 32 / 64 have register-resident attention backward kernels; any
- * other multiple of 16 (e.g. 256, the reference's shipped size) runs a materialised fp32 path (functional, ~10x slower).  parq_forward_train = parq_forward that keeps every iteration's activations in the (larger)
+ * bf16 modes 2 / 3, i.e. the gradient is taken straight through the operand rounding of the reduced-precision forward).  Head dims 32 / 64 have register-resident attention backward kernels; head dim 256
+ * (the reference's shipped size) with shared layer weights composes the backward of all iterations from split-precision GEMMs (the training
+ * workspace then holds two (N x 512-padded I*Q) fp32 score matrices: 3.1 GB at 10 views of 120x160); any other multiple of 16 runs a
+ * materialised fp32 path (functional, ~10x slower).  parq_forward_train = parq_forward that keeps every iteration's activations in the (larger)
  * training workspace; parq_backward consumes them: `grads` holds d loss / d output per iteration (same (I,B,Q,k) layout as
  * the outputs, NULL = zero), `grad_arena` receives d loss / d weight in the layout of the packed weight arena
  * (parq_arena_lookup maps reference tensor names to offsets), `d_tokens` (B,N,C) or NULL receives d loss / d input tokens.
