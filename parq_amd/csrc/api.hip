@@ -723,19 +723,39 @@ int do_backward_kvproj(parq_ctx* c, const parq_scene* sc, float* wsp, const Work
         const float* g = wsp + ws.g_kv + (int64_t)li * B * 2 * N * C;          // [B*N][2C]
         const int Mr = (int)(B * N);
         static const bool split_off = [] { const char* e = getenv("PARQ_KVPROJ_BWD"); return e && e[0] == 'f'; }();   // "fp32": generic kernels
-        if (ws.bwd_batched && kvproj_bwd_split_supported(C) && !split_off) {
+        const bool split_ok = ws.bwd_batched && !split_off;                      // the batched backward leaves max |g| in g_kvmax
+        if (split_ok && kvproj_bwd_split_supported(C)) {
             // dW, db on the fp16 matrix pipe (hi/lo split); g is scaled by the power of two derived from max |g| (attention epilogue)
             HIPCHK(launch_kvproj_bwd_split(g, sc->tokens, Mr, C, G + L.cross_in_w + (int64_t)C * C, G + L.cross_in_b + C,
                                            reinterpret_cast<const unsigned int*>(wsp + ws.g_kvmax), wsp + ws.g_kvmax + 1, s));
+        } else if (split_ok && C % 256 == 0) {
+            // wider models (C = 1024: 805 GFLOP): the same kernel per 512 x 256 block of dW_kv; the bias gradient falls out of the
+            // blocks of the first column slice
+            float* dW = G + L.cross_in_w + (int64_t)C * C;
+            float* db = G + L.cross_in_b + C;
+            for (int n0 = 0; n0 < 2 * C; n0 += 512)
+                for (int k0 = 0; k0 < C; k0 += 256)
+                    HIPCHK(launch_tn_split_512x256(g + n0, 2 * C, sc->tokens + k0, C, Mr, dW + (int64_t)n0 * C + k0, C, k0 == 0 ? db + n0 : nullptr,
+                                                   reinterpret_cast<const unsigned int*>(wsp + ws.g_kvmax), wsp + ws.g_kvmax + 1, s));
         } else {
             HIPCHK(launch_gemm_tn(g, 2 * C, sc->tokens, C, G + L.cross_in_w + (int64_t)C * C, C, Mr, 2 * C, C, 1, s));
             HIPCHK(launch_colsum(g, 2 * C, Mr, 2 * C, G + L.cross_in_b + C, 1, s));
         }
         if (g_tokens) {
             HIPCHK(launch_transpose(A + L.cross_in_w + (int64_t)C * C, C, wT, 2 * C, 2 * C, C, s));
-            LinearArgs a = lin(g, 2 * C, wT, 2 * C, nullptr, g_tokens, C, Mr, C, 2 * C);
-            a.R = g_tokens; a.ldr = C;
-            HIPCHK(launch_linear(a, 1, s));
+            if (split_ok && (kvproj_bwd_split_supported(C) || C % 256 == 0)) {        // (the dW launch above left the scale in g_kvmax[1])
+                // d tokens += g W_kv on the fp16 matrix pipe (201 GFLOP per scene at C = 256, 805 at C = 1024): W_kv^T split hi/lo
+                // once, g scaled by the power of two of the dW kernel (g_kvmax[1], written by the launch above) while it is split
+                _Float16* whi = reinterpret_cast<_Float16*>(wT + (int64_t)C * 2 * C);
+                _Float16* wlo = whi + (int64_t)C * 2 * C;
+                HIPCHK(launch_split_f32(wT, whi, wlo, (int64_t)C * 2 * C, s));
+                HIPCHK(launch_gemm_split(g, 2 * C, whi, wlo, nullptr, g_tokens, C, Mr, C, 2 * C, 0, nullptr, 1, s, wsp + ws.g_kvmax + 1, 1.f,
+                                         wsp + ws.g_kvmax + 1, 1));
+            } else {
+                LinearArgs a = lin(g, 2 * C, wT, 2 * C, nullptr, g_tokens, C, Mr, C, 2 * C);
+                a.R = g_tokens; a.ldr = C;
+                HIPCHK(launch_linear(a, 1, s));
+            }
         }
     }
     return PARQ_OK;

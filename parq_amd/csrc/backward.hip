@@ -10,6 +10,7 @@
 //     later reference points are detached, transformer_parq.py:331-332), project+sample backward (bilinear scatter
 //     into the token gradient with atomics, coordinate gradient for iteration 0), attention backwards.
 #include "common.hpp"
+#include <cstdint>
 
 #include <cstring>
 
@@ -47,6 +48,87 @@ struct TnArgs {
     int M, N, K;
     int accumulate;
 };
+
+// The same contraction for LARGE outputs with FEW rows (the C = 1024 layers of the reference's shipped size: out 1024 x 1024 ..
+// 3072 x 1024 from 256 .. 1024 rows), where the kernel below (one 4-byte load per lane and MFMA operand, 32 x 32 tiles) runs at
+// 5 TFLOP/s.  A workgroup owns a 64 x 64 output tile; 32 rows of both operands are staged per step as they lie in memory
+// ([m][64 columns], coalesced 256-byte row pieces) — for a contraction over m that layout IS the operand layout of
+// v_mfma_f32_32x32x2_f32 (lane = column, two consecutive m per instruction), so no transposes: 16 MFMAs per wave and step.
+__global__ __launch_bounds__(256) void gemm_tn_tile64_kernel(TnArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[2][32][64 + 32];      // dY rows m, columns n0 .. n0 + 63 (96-float rows: the two m of
+    __shared__ __attribute__((aligned(16))) float Bs[2][32][64 + 32];      // an instruction read disjoint halves of the 64 banks)
+    const int ntk = (a.K + 63) / 64;
+    const int k0 = (int)(blockIdx.x % ntk) * 64, n0 = (int)(blockIdx.x / ntk) * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int wn = wave >> 1, wk = wave & 1;                              // 32 x 32 quadrant of the tile
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // staging: thread -> (row tid >> 3 of the 32, 8 consecutive columns) of each operand
+    const int sr = tid >> 3, sc = (tid & 7) * 8;
+    float4 ra[2], rb[2];
+    // 16-byte loads where base and row stride allow them (row slices of wider buffers need not be aligned)
+    const bool avec = ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0) && (a.lda % 4 == 0);
+    const bool bvec = ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0) && (a.ldb % 4 == 0);
+    auto fetch = [&](int m0) {
+        const int m = m0 + sr;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            ra[e] = float4{0.f, 0.f, 0.f, 0.f};
+            rb[e] = float4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (m < a.M) {
+            const float* ap = a.A + (int64_t)m * a.lda + n0 + sc;
+            const float* bp = a.B + (int64_t)m * a.ldb + k0 + sc;
+            if (n0 + sc + 8 <= a.N && avec) { ra[0] = *reinterpret_cast<const float4*>(ap); ra[1] = *reinterpret_cast<const float4*>(ap + 4); }
+            else {
+                float t[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = n0 + sc + e < a.N ? ap[e] : 0.f;
+                ra[0] = float4{t[0], t[1], t[2], t[3]}; ra[1] = float4{t[4], t[5], t[6], t[7]};
+            }
+            if (k0 + sc + 8 <= a.K && bvec) { rb[0] = *reinterpret_cast<const float4*>(bp); rb[1] = *reinterpret_cast<const float4*>(bp + 4); }
+            else {
+                float t[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = k0 + sc + e < a.K ? bp[e] : 0.f;
+                rb[0] = float4{t[0], t[1], t[2], t[3]}; rb[1] = float4{t[4], t[5], t[6], t[7]};
+            }
+        }
+    };
+    auto stage = [&](int buf) {
+        *reinterpret_cast<float4*>(&As[buf][sr][sc]) = ra[0];
+        *reinterpret_cast<float4*>(&As[buf][sr][sc + 4]) = ra[1];
+        *reinterpret_cast<float4*>(&Bs[buf][sr][sc]) = rb[0];
+        *reinterpret_cast<float4*>(&Bs[buf][sr][sc + 4]) = rb[1];
+    };
+    const int steps = (a.M + 31) / 32;
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    for (int st = 0; st < steps; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < steps) fetch((st + 1) * 32);
+#pragma unroll
+        for (int mm = 0; mm < 32; mm += 2)          // lane (column li, kh) supplies row m = mm + kh of both operands
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][mm + kh][wn * 32 + li], Bs[buf][mm + kh][wk * 32 + li], acc, 0, 0, 0);
+        if (st + 1 < steps) stage(buf ^ 1);         // the other buffer was last read in step st - 1, closed by that step's barrier
+        __syncthreads();
+    }
+    // accumulator register r of lane (li, kh): row n = mfma32_row(r, lane) of the quadrant, column k = li
+    const int k = k0 + wk * 32 + li;
+    if (k < a.K) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn * 32 + mfma32_row(r, lane);
+            if (n < a.N) {
+                float* o = a.out + (int64_t)n * a.ldo + k;
+                *o = a.accumulate ? *o + acc[r] : acc[r];
+            }
+        }
+    }
+}
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
     __shared__ __attribute__((aligned(16))) float red[4 * 4 * 4 * 64];
@@ -579,6 +661,11 @@ hipError_t launch_gemm_tn(const float* A, int64_t lda, const float* B, int64_t l
                           int accumulate, hipStream_t s) {
     TnArgs a;
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.accumulate = accumulate;
+    // large outputs from few rows (C = 1024 layers): 64 x 64 tiles with LDS-staged rows
+    if ((int64_t)N * K >= (1 << 19) && M <= 4096) {
+        hipLaunchKernelGGL(gemm_tn_tile64_kernel, dim3(ceil_div(N, 64) * ceil_div(K, 64)), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     // many rows, few output tiles (the K/V projection backward: M = all tokens): split the rows, accumulate with atomics
     // each wave walks its rows with dependent global loads (latency-bound): whenever the result is accumulated anyway, split the
     // rows until ~4 workgroups per CU are in flight and every workgroup keeps at least 64 rows

@@ -314,7 +314,8 @@ hipError_t launch_parse_pred(const float* center, const float* size, const float
                              unsigned char* mask, hipStream_t s);
 hipError_t launch_gemm_split(const float* X, int64_t ldx, const void* Whi, const void* Wlo, const float* bias, float* Y,
                              int64_t ldy, int M, int N, int K, int relu, const float* feat, int hw, hipStream_t s,
-                             const float* scale_dev = nullptr, float scale_mul = 1.f);
+                             const float* scale_dev = nullptr, float scale_mul = 1.f, const float* xscale_dev = nullptr,
+                             int accumulate = 0);   // Y (+)= ((x * *xscale_dev) W^T) * scale_mul / *scale_dev + bias
 
 // ------------------------------------------------------------------ elementwise / gather kernels
 hipError_t launch_camera_local(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V,

@@ -111,6 +111,9 @@ struct GemmArgs {
     float* Y; int64_t ldy;             // [M][N] row-major
     int M, N, K, relu;
     const float* scale_dev; float scale_mul;   // optional: Y = (X W^T) * scale_mul / *scale_dev (bias-free callers: attention backward)
+    const float* xscale_dev;                   // optional: X is multiplied by *xscale_dev while it is split (gradient operands: a power
+                                               // of two that keeps small values' low halves out of the fp16 subnormals)
+    int accumulate;                            // Y += instead of Y =
     // optional: Y[m][n] += feat[(m / hw) * N * hw + n * hw + (m % hw)]   (NCHW feature maps, (B*V, C, h, w))
     const float* feat; int hw;
 };
@@ -141,6 +144,7 @@ __global__ __launch_bounds__(kThreads) void gemm_split_kernel(GemmArgs a) {
 
     float4 areg[8];
     uint4 wreg[8];
+    const float xs = a.xscale_dev ? *a.xscale_dev : 1.f;
     auto gload = [&](int ks) {
         const int k0 = ks * kBK;
 #pragma unroll
@@ -173,6 +177,8 @@ __global__ __launch_bounds__(kThreads) void gemm_split_kernel(GemmArgs a) {
             const int pos = c ^ ((row >> 1) & 7);
             float x[8] = {areg[2 * i].x, areg[2 * i].y, areg[2 * i].z, areg[2 * i].w,
                           areg[2 * i + 1].x, areg[2 * i + 1].y, areg[2 * i + 1].z, areg[2 * i + 1].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] *= xs;
             half8 hi, lo;
             split8(x, hi, lo);
             *reinterpret_cast<half8*>(Ahi + row * kBK + pos * 8) = hi;
@@ -267,6 +273,7 @@ __global__ __launch_bounds__(kThreads) void gemm_split_kernel(GemmArgs a) {
         if (ncol < a.N) {
             float y = ot[r * 65 + lane] * osc + bv;
             if (a.relu) y = y > 0.f ? y : 0.f;
+            if (a.accumulate) y += a.Y[(int64_t)m * a.ldy + ncol];
             a.Y[(int64_t)m * a.ldy + ncol] = y;
         }
     }
@@ -646,7 +653,7 @@ hipError_t launch_raype_fused(const float* cam, const float* T_cp, const float* 
 // Y[M][N] = act(X[M][K] @ W^T + bias) (+ NCHW features); W given as fp16 hi/lo [N][K]; K % 64 == 0
 hipError_t launch_gemm_split(const float* X, int64_t ldx, const void* Whi, const void* Wlo, const float* bias, float* Y,
                              int64_t ldy, int M, int N, int K, int relu, const float* feat, int hw, hipStream_t s,
-                             const float* scale_dev, float scale_mul) {
+                             const float* scale_dev, float scale_mul, const float* xscale_dev, int accumulate) {
     if (K % kBK != 0 || M < 1 || N < 1 || (relu && feat)) return hipErrorInvalidValue;
     static DynLdsOnce once;
     const size_t ldsb = 4 * 64 * 65 * sizeof(float);                    // 66560 B >= the 64 KB of operand staging
@@ -654,7 +661,7 @@ hipError_t launch_gemm_split(const float* X, int64_t ldx, const void* Whi, const
     GemmArgs a;
     a.X = X; a.ldx = ldx; a.Whi = reinterpret_cast<const _Float16*>(Whi); a.Wlo = reinterpret_cast<const _Float16*>(Wlo);
     a.bias = bias; a.Y = Y; a.ldy = ldy; a.M = M; a.N = N; a.K = K; a.relu = relu; a.feat = feat; a.hw = hw;
-    a.scale_dev = scale_dev; a.scale_mul = scale_mul;
+    a.scale_dev = scale_dev; a.scale_mul = scale_mul; a.xscale_dev = xscale_dev; a.accumulate = accumulate;
     const int nct = ceil_div(N, kBN), nrt = ceil_div(M, kBM);
     const int64_t wgs = (int64_t)ceil_div(nrt, 8) * 8 * nct;
     if (wgs > 0x7fffffffLL) return hipErrorInvalidValue;

@@ -49,6 +49,8 @@ def oracle_grads(cfg, W, sc, cots):
     (2, 2, 9, 11, 40, 1, 256, 96, 2, True),        # head dim 256 (the reference's shipped head size): all iterations in one composition
                                                    # of split-precision GEMMs (S^T, dP^T, dV, dK; dQ by the 512 x 256 TN kernel)
     (1, 2, 32, 41, 24, 4, 1024, 256, 3, True),     # the shipped dims themselves (d = 1024, 4 heads of 256), N = 2624, three iterations
+                                                   # (dW of the C = 1024 layers: the 64 x 64 tiled TN kernel, 24 rows = one partial row step)
+    (2, 1, 12, 16, 40, 4, 1024, 3072, 2, True),    # the same with the shipped FFN width (3072) and 80 rows (two row steps + 16)
     (1, 2, 10, 13, 20, 2, 256, 96, 2, False),      # head dim 128, unshared layers, ragged key count (N = 260)
 ])
 def test_backward_matches_oracle_autograd(B, V, h, w, Q, heads, dim, ffn, layers, shared):
