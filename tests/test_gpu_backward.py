@@ -166,15 +166,18 @@ def test_ray_pe_backward_matches_oracle_autograd(monkeypatch):
     assert np.abs(fg.grad.cpu().numpy() - ref).max() < 1e-6
 
 
-def test_parq_module_training_steps_with_set_loss():
+@pytest.mark.parametrize("Cd,heads,ffn,layers,pdrop,lr", [(128, 2, 96, 2, 0.0, 2e-3),
+                                                           (1024, 4, 3072, 3, 0.1, 1e-4)])    # the reference's shipped recipe: DEC_DIM 1024, 4 heads
+                                                                                              # of 256, FFN 3072, dropout 0.1 (config/train.yaml:45-56)
+def test_parq_module_training_steps_with_set_loss(Cd, heads, ffn, layers, pdrop, lr):
     """PARQ.training_step end to end (model/parq_lightning.py:97-100): ray-PE node -> decoder node -> the reference's set loss
     on synthetic boxes; every parameter of the encoder MLP and of the decoder receives a gradient and AdamW lowers the loss."""
     from types import SimpleNamespace as NS
     from parq_amd import PARQ, Camera, Obb3D, Pose
-    B, V, h, w, Cd, Qn = 2, 2, 8, 10, 128, 32
-    dcfg = synth.decoder_cfg(dim=Cd, queries=Qn, heads=2, ffn=96, layers=2, dropout=0.0)
+    B, V, h, w, Qn = 2, 2, 8, 10, 32
+    dcfg = synth.decoder_cfg(dim=Cd, queries=Qn, heads=heads, ffn=ffn, layers=layers, dropout=pdrop)
     cfg = NS(MODEL=NS(TOKENIZER=NS(OUT_CHANNELS=Cd, RAY_POINTS_SCALE=dcfg.TRANSFORMER.SCALE, NUM_SAMPLES=64, MIN_DEPTH=0.25, MAX_DEPTH=5.25),
-                      DECODER=dcfg), OPTIMIZER=NS(LEARNING_RATE=2e-3, AUTOSCALE_LR=False))
+                      DECODER=dcfg), OPTIMIZER=NS(LEARNING_RATE=lr, AUTOSCALE_LR=False))
     torch.manual_seed(0)
     model = PARQ(cfg).cuda().train()
     cam, T_cp, T_wp, T_wl = synth.make_geometry(95, B, V, h, w)
