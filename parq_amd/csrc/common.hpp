@@ -18,10 +18,15 @@ constexpr int kGnSlots = 64;    // GroupNorm moment accumulators per (scene, gro
 // builtin writes LDS asynchronously and answers with s_waitcnt vmcnt(0) in front of later C++ reads of LDS it cannot prove
 // disjoint — which turns a prefetch into a blocking load.  Through asm the compiler does not see it: the caller waits with a
 // counted s_waitcnt vmcnt(N) + a barrier before anybody reads the destination.
-// (M0 is written here behind the compiler's back: do not mix with __builtin_amdgcn_global_load_lds in one kernel.)
+// M0 (the LDS base of the instruction) is saved and restored inside the statement: hipcc does not honour an "m0" clobber, and it may
+// keep its own value there (indexed register access, its own LDS-DMA builtins).
 __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_base) {
     const unsigned base = __builtin_amdgcn_readfirstlane(lds_base);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(base), "v"(gsrc) : "memory");
+    unsigned saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(saved)
+                 : "s"(base), "v"(gsrc)
+                 : "memory");
 }
 // workgroup barrier that only orders LDS traffic: __syncthreads() is a release / acquire fence and makes hipcc wait for every
 // outstanding global store and load (s_waitcnt vmcnt(0)) first
