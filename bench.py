@@ -42,6 +42,7 @@ PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f3
 PEAK_F16_MATRIX_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
 SPLIT_PASSES = 3                    # fp16 MFMAs issued per fp32-accurate product (hi*hi + hi*lo + lo*hi)
 PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec peak
+PREWARM_STEPS = 24                 # untimed forwards before the warm-up steps (see main): ~50 ms of device spin-up
 
 
 def build_inputs(B, device, seed):
@@ -291,6 +292,11 @@ def main():
         parallel.barrier()
         torch.cuda.synchronize()
 
+    # Device spin-up, untimed and before the W warm-up steps: the first ~12 forwards of a process run 2 - 12 % slower than the steady
+    # state (lazy code-object loading on the first, then the clock / power controller settling: tools/step_times.py prints the
+    # per-forward times).  A throughput number should not depend on how few steps the caller asks for.
+    for _ in range(PREWARM_STEPS):
+        step()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -344,7 +350,7 @@ def main():
         out = {
             "metric": "decoder-iterations/sec (10 views, 256 queries, d=%d)%s" % (C, "" if C == 256 else " [not the BASELINE metric: non-default --dim]"),
             "value": total_iters / dt, "unit": "decoder-iterations/sec",
-            "n_gpus": world, "rccl_ranks": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": PREWARM_STEPS,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": ("f32 (cross-attention and K/V projection as fp16 hi/lo split products with fp32 accumulation)" if split
                                           else "%s cross-attention and K/V projection operands, fp32 accumulation, fp32 elsewhere (reduced precision: not the headline configuration)" % mode if half

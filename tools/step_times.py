@@ -1,0 +1,18 @@
+import os, sys, torch
+sys.path.insert(0, "/root/repo")
+import bench
+device = torch.device("cuda", 0)
+cfg, W, dec = bench.build_decoder(device)
+inputs = bench.build_inputs(1, device, seed=1000)
+h, w = bench.WORKLOAD["feat_hw"]
+with torch.no_grad():
+    for rep in range(3):
+        n = 16
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        torch.cuda.synchronize()
+        ev[0].record()
+        for i in range(n):
+            dec(*inputs, feat_hw=(h, w))
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        print("rep", rep, " ".join("%.3f" % ev[i].elapsed_time(ev[i + 1]) for i in range(n)))
