@@ -132,12 +132,13 @@ __global__ __launch_bounds__(1024) void project_sample_kernel(
             coord_pos[(int64_t)bq * 3 + i] = __fadd_rn(__fmul_rn(r, __fsub_rn(sb.hi[i], sb.lo[i])), sb.lo[i]);
     }
 
-    f32x4 acc[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int nvalid = 0;
-
-    for (int v = wv; v < V; v += nwv) {
+    // ---- geometry ONCE per (query, view): thread v projects into view v (float64) and leaves the bilinear footprint in LDS.  Every
+    // lane of a wave used to repeat its view's projection: ~150 quarter-rate float64 instructions per wave whatever the number of
+    // active lanes, i.e. 10 waves x 2400 cycles per workgroup — at 32 scenes the kernel was bound by that arithmetic (75 us per
+    // launch against ~150 MB of actual fetches), at one scene it was 1.5 of its 2.8 us in-kernel time.
+    struct Foot { int x0, y0; float w00, w01, w10, w11; int flags, pad; };      // flags: bit 0 valid view, bit 1 a corner is in range
+    Foot* foot = reinterpret_cast<Foot*>(smem + (size_t)nwv * C + nwv);
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
         const TPose* T = T_cl + ((int64_t)b * V + v) * 12;
         const float* cm = cam + ((int64_t)b * V + v) * 6;
         // Pose.transform: p @ R^T + t (utils/wrappers.py:259-267)
@@ -151,17 +152,39 @@ __global__ __launch_bounds__(1024) void project_sample_kernel(
         const double u = (x / zc) * (double)cm[2] + (double)cm[4];
         const double vv = (y / zc) * (double)cm[3] + (double)cm[5];
         const bool valid = front && (u >= 0.0) && (u <= (double)cm[0] - 1.0) && (vv >= 0.0) && (vv <= (double)cm[1] - 1.0);
-        nvalid += valid ? 1 : 0;
         // grid_sample(bilinear, zeros, align_corners=True): the normalised-grid round trip of
         // transformer_parq.py:148-152 is the identity on pixel coordinates
         const double fx0 = floor(u);
         const double fy0 = floor(vv);
         // any corner in range?  (tests in floating point: |u| can be ~1e6 when z was clamped)
-        if (!(fx0 >= -1.0 && fx0 <= (double)(w - 1) && fy0 >= -1.0 && fy0 <= (double)(h - 1))) continue;
-        const int x0 = (int)fx0;
-        const int y0 = (int)fy0;
+        const bool on = fx0 >= -1.0 && fx0 <= (double)(w - 1) && fy0 >= -1.0 && fy0 <= (double)(h - 1);
+        Foot f;
+        f.x0 = on ? (int)fx0 : 0;
+        f.y0 = on ? (int)fy0 : 0;
         const float wx1 = (float)(u - fx0), wx0 = (float)(1.0 - (u - fx0));
         const float wy1 = (float)(vv - fy0), wy0 = (float)(1.0 - (vv - fy0));
+        const bool x0ok = f.x0 >= 0, x1ok = f.x0 + 1 <= w - 1;
+        const bool y0ok = f.y0 >= 0, y1ok = f.y0 + 1 <= h - 1;
+        f.w00 = (x0ok && y0ok) ? wy0 * wx0 : 0.f;   // nw
+        f.w01 = (x1ok && y0ok) ? wy0 * wx1 : 0.f;   // ne
+        f.w10 = (x0ok && y1ok) ? wy1 * wx0 : 0.f;   // sw
+        f.w11 = (x1ok && y1ok) ? wy1 * wx1 : 0.f;   // se
+        f.flags = (valid ? 1 : 0) | (on ? 2 : 0);
+        f.pad = 0;
+        foot[v] = f;
+    }
+    __syncthreads();
+
+    f32x4 acc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int nvalid = 0;
+
+    for (int v = wv; v < V; v += nwv) {
+        const Foot f = foot[v];
+        nvalid += f.flags & 1;
+        if (!(f.flags & 2)) continue;
+        const int x0 = f.x0, y0 = f.y0;
         const bool x0ok = x0 >= 0, x1ok = x0 + 1 <= w - 1;
         const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= h - 1;
         const float* base = tokens + (((int64_t)b * V + v) * h) * (int64_t)w * C;
@@ -169,10 +192,7 @@ __global__ __launch_bounds__(1024) void project_sample_kernel(
         const float* r01 = base + ((int64_t)(y0ok ? y0 : 0) * w + (x1ok ? x0 + 1 : 0)) * C;
         const float* r10 = base + ((int64_t)(y1ok ? y0 + 1 : 0) * w + (x0ok ? x0 : 0)) * C;
         const float* r11 = base + ((int64_t)(y1ok ? y0 + 1 : 0) * w + (x1ok ? x0 + 1 : 0)) * C;
-        const float w00 = (x0ok && y0ok) ? wy0 * wx0 : 0.f;   // nw
-        const float w01 = (x1ok && y0ok) ? wy0 * wx1 : 0.f;   // ne
-        const float w10 = (x0ok && y1ok) ? wy1 * wx0 : 0.f;   // sw
-        const float w11 = (x1ok && y1ok) ? wy1 * wx1 : 0.f;   // se
+        const float w00 = f.w00, w01 = f.w01, w10 = f.w10, w11 = f.w11;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int c4 = lane + c * 64;
@@ -469,7 +489,7 @@ static hipError_t launch_project_sample_t(const float* tokens, const TPose* T_cl
                                           float* coord_pos, double* zero_f64, int zero_n, hipStream_t s) {
     if (C % 4 != 0 || C > 256 * kMaxChunks || V <= 0) return hipErrorInvalidValue;
     const int nwv = V < 16 ? V : 16;
-    const size_t smem = (size_t)nwv * C * sizeof(float) + (size_t)nwv * sizeof(int);
+    const size_t smem = (size_t)nwv * C * sizeof(float) + (size_t)nwv * sizeof(int) + (size_t)V * 32 + 16;      // partial sums, counts, footprints
     const int nch = ceil_div(C / 4, 64);
     dim3 grid(B * Q), block(nwv * 64);
     switch (nch) {
