@@ -125,6 +125,40 @@ def project_sample_b32(dec, device, h, w, scenes=32, steps=2):
                     "(roofline_project_sample) is latency-bound" % (scenes, scenes * V * h * w * C * 4 / 1e9)}
 
 
+def device_state_under_load(step, seconds=1.0):
+    """Socket power and shader clock (rocm-smi) sampled while the forward loops back to back — the two big kernels of this path run
+    at the 1400 W cap with the clock throttled below 2.4 GHz (profiles/r02_power_rocm_smi.txt), which is what
+    `roofline.frac` against the nominal peak has to be read with.  Best effort: null when rocm-smi is not usable."""
+    import subprocess
+    import threading
+    samples, stop = [], [False]
+
+    def sampler():
+        while not stop[0]:
+            try:
+                out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--csv"], capture_output=True, text=True, timeout=5).stdout
+                row = out.strip().split("\n")[-1].split(",")
+                samples.append((int(row[5].strip("()Mhz")), float(row[-1])))
+            except Exception:           # noqa: any parsing / availability problem -> no sample
+                pass
+            time.sleep(0.05)
+
+    th = threading.Thread(target=sampler)
+    th.start()
+    t_end = time.perf_counter() + seconds
+    while time.perf_counter() < t_end:
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+    stop[0] = True
+    th.join()
+    late = samples[len(samples) // 2:]
+    if not late:
+        return None
+    return {"sclk_mhz": sum(x[0] for x in late) / len(late), "socket_power_w": sum(x[1] for x in late) / len(late), "samples": len(late),
+            "note": "rocm-smi while the forward loops back to back; nominal shader clock 2400 MHz, socket cap 1400 W"}
+
+
 def pmc_traffic(kernel, scenes):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r02_pmc.json, written from
     `tools/collect_profiles.sh` output: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, FETCH_SIZE doubled as
@@ -373,6 +407,8 @@ def main():
         }
         if C == 256:
             out["ray_pe"] = ray_pe_timing(B, device)
+        if world == 1:
+            out["device_state_under_load"] = device_state_under_load(step)
         if world == 1 and C == 256 and B == 1 and not args.no_b32:
             out["roofline_project_sample_b32"] = project_sample_b32(dec, device, h, w)
         if world == 1 and not args.no_cpu_baseline:
