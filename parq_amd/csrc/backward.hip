@@ -320,11 +320,7 @@ __device__ __forceinline__ void gn_moments(const double* sums, int scene, int ng
         S += sums[((int64_t)(scene * ngroups + g) * kGnSlots + sl) * 2];
         Q += sums[((int64_t)(scene * ngroups + g) * kGnSlots + sl) * 2 + 1];
     }
-    const double mu = S / cnt;
-    double var = Q / cnt - mu * mu;
-    var = var < 0.0 ? 0.0 : var;
-    mean = (float)mu;
-    rstd = (float)(1.0 / sqrt(var + (double)eps));
+    gn_mean_rstd(S, Q, 1.0 / cnt, eps, mean, rstd);
 }
 
 struct GnArgs {

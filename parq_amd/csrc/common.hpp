@@ -255,6 +255,17 @@ hipError_t launch_raype_fused(const float* cam, const float* T_cp, const float* 
                               float min_depth, float max_depth, int B, int V, int h, int w, const void* W1hi, const void* W1lo,
                               const float* b1, const void* W2hi, const void* W2lo, const float* b2, const float* feat,
                               float* hidden, double* Tl, double* depth, float* out, int nchw_out, hipStream_t s);
+// GroupNorm(1, C) statistics from the float64 moments (sum, sum of squares) of a group: the mean and the variance — a difference of two
+// nearly equal numbers — in float64 with ONE reciprocal of the element count, the reciprocal square root in fp32 (its argument is
+// exact to 6e-8; the float64 sqrt + divisions this replaces were ~100 quarter-rate instructions in every wave of the consumers).
+// Used by the forward consumers and by the backward that re-normalises from the same moments.
+__device__ __forceinline__ void gn_mean_rstd(double S, double Q, double inv_cnt, float eps, float& mean, float& rstd) {
+    const double mu = S * inv_cnt;
+    double var = Q * inv_cnt - mu * mu;
+    var = var < 0.0 ? 0.0 : var;
+    mean = (float)mu;
+    rstd = 1.f / sqrtf((float)var + eps);
+}
 struct ScaleBox { float lo[3]; float hi[3]; };
 // ---- backward (backward.hip, attn_bwd.hip)
 hipError_t launch_transpose(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int R, int Cc, hipStream_t s);

@@ -305,11 +305,10 @@ __global__ __launch_bounds__(1024) void gn_stats_kernel(const float* __restrict_
             Qs += sh[1][i];
         }
         const double n = (double)rows_per_scene * (double)ncols;
-        const double mean = S / n;
-        double var = Qs / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        stats[((int64_t)b * ngroups + g) * 2 + 0] = (float)mean;
-        stats[((int64_t)b * ngroups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        float mean, rstd;
+        gn_mean_rstd(S, Qs, 1.0 / n, eps, mean, rstd);
+        stats[((int64_t)b * ngroups + g) * 2 + 0] = mean;
+        stats[((int64_t)b * ngroups + g) * 2 + 1] = rstd;
     }
 }
 
@@ -345,15 +344,9 @@ __global__ __launch_bounds__(256) void box_decode_kernel(BoxDecodeArgs a) {
         for (int o = 32; o > 0; o >>= 1) sums[j] += __shfl_xor(sums[j], o);
     // GroupNorm(1,C) of the second hidden layer from the scene-wide moments (generic_mlp.py:85-86)
     float mean[2], rstd[2];
+    const double inv_cnt = 1.0 / ((double)a.rows_per_scene * (double)C);
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const double cnt = (double)a.rows_per_scene * (double)C;
-        const double mu = sums[2 * g] / cnt;
-        double var = sums[2 * g + 1] / cnt - mu * mu;
-        var = var < 0.0 ? 0.0 : var;
-        mean[g] = (float)mu;
-        rstd[g] = (float)(1.0 / sqrt(var + (double)a.eps));
-    }
+    for (int g = 0; g < 2; ++g) gn_mean_rstd(sums[2 * g], sums[2 * g + 1], inv_cnt, a.eps, mean[g], rstd[g]);
     // output layers: centre (3 rows of group 0) and rotation (6 rows of group 1), K = C each
     float acc[9];
 #pragma unroll

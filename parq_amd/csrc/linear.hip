@@ -158,13 +158,12 @@ __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a
                 Sm += __shfl_xor(Sm, o);
                 Qs += __shfl_xor(Qs, o);
             }
-            const double mean = Sm / cnt;
-            double var = Qs / cnt - mean * mean;
-            var = var < 0.0 ? 0.0 : var;
+            float mean, rstd;
+            gn_mean_rstd(Sm, Qs, 1.0 / cnt, a.norm_eps, mean, rstd);
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                gn_mean[s] = (float)mean;
-                gn_rstd[s] = (float)(1.0 / sqrt(var + (double)a.norm_eps));
+                gn_mean[s] = mean;
+                gn_rstd[s] = rstd;
             }
         } else {
             // tile straddles scenes (rows_per_scene not a multiple of the tile): per-row serial sum
@@ -177,11 +176,7 @@ __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a
                     Sm += a.gn_sums[((int64_t)(scene * a.gn_ngroups + g) * kGnSlots + sl) * 2 + 0];
                     Qs += a.gn_sums[((int64_t)(scene * a.gn_ngroups + g) * kGnSlots + sl) * 2 + 1];
                 }
-                const double mean = Sm / cnt;
-                double var = Qs / cnt - mean * mean;
-                var = var < 0.0 ? 0.0 : var;
-                gn_mean[s] = (float)mean;
-                gn_rstd[s] = (float)(1.0 / sqrt(var + (double)a.norm_eps));
+                gn_mean_rstd(Sm, Qs, 1.0 / cnt, a.norm_eps, gn_mean[s], gn_rstd[s]);
             }
         }
     }
