@@ -92,10 +92,12 @@ __global__ __launch_bounds__(512) void kvproj_big_kernel(BigArgs a) {
             srcs[i] = (img == 2 ? a.Whi : a.Wlo) + (int64_t)(n0 + row) * C + chunk * 8;
         }
     }
+    // (asm-issued DMA + LDS-only barrier, common.hpp: with the builtin hipcc waited for the step it had just requested before every
+    // fragment read of the current one)
     auto gload = [&](int ks, int slot) {
-        lds_byte* dst = (lds_byte*)(lds + slot * kStage);
+        const unsigned dst = (unsigned)(size_t)(lds_byte*)(lds + slot * kStage);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) __builtin_amdgcn_global_load_lds(srcs[i] + ks * kTK, dst + (i * 512 + wave * 64) * 16, 16, 0, 0);
+        for (int i = 0; i < 8; ++i) lds_dma16(srcs[i] + ks * kTK, dst + (i * 512 + wave * 64) * 16);
     };
 
     const int headcol0 = (n0 >> 6) + 2 * wc;                    // first of this wave's two virtual heads, in [K heads | V heads]
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(512) void kvproj_big_kernel(BigArgs a) {
     gload(0, 0);
     for (int ks = 0; ks < nk; ++ks) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's pieces of step ks have landed
-        __syncthreads();                                        // ... everyone's; every wave is past the reads of step ks - 1
+        lds_barrier();                                          // ... everyone's; every wave is past the reads of step ks - 1
         if (ks + 1 < nk) gload(ks + 1, (ks + 1) & 1);
         const _Float16* S = lds + (ks & 1) * kStage;
 #pragma unroll
@@ -160,12 +162,29 @@ __global__ __launch_bounds__(512) void kvproj_big_kernel(BigArgs a) {
     const int nblk = (a.N + 31) / 32;
     bool ovf = false;
     _Float16* wl = lds + wave * 4096;                           // 8 KB per wave
+    // all bias values of this lane up front (64 for a K wave, 4 for a V wave): between the LDS round trips below each group's loads
+    // would otherwise be issued and waited for one after the other (16 dependent L2 round trips per tile)
+    float bK[2][2][2][8], bV[2][2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const float* bias = a.bias + (headcol0 + hh) * 64;
+            bV[hh][ct] = 0.f;
+            if (isK) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bK[hh][ct][m][e] = bias[32 * ct + 16 * m + 4 * kh + (e & 3) + 8 * (e >> 2)];
+            } else {
+                bV[hh][ct] = bias[32 * ct + li];
+            }
+        }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int headcol = headcol0 + hh;
-            const float* bias = a.bias + headcol * 64;
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -174,9 +193,9 @@ __global__ __launch_bounds__(512) void kvproj_big_kernel(BigArgs a) {
                     float x[8];
                     if (isK) {      // lane = key li, registers 8m .. 8m+7 = d 32 ct + 16 m + 4 kh + (e & 3) + 8 (e >> 2)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) x[e] = A[8 * m + e] + bias[32 * ct + 16 * m + 4 * kh + (e & 3) + 8 * (e >> 2)];
+                        for (int e = 0; e < 8; ++e) x[e] = A[8 * m + e] + bK[hh][ct][m][e];
                     } else {        // lane = d 32 ct + li, registers = keys 16 m + 4 kh + (e & 3) + 8 (e >> 2)
-                        const float bv = bias[32 * ct + li];
+                        const float bv = bV[hh][ct];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) x[e] = A[8 * m + e] + bv;
                     }
