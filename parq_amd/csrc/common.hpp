@@ -255,16 +255,16 @@ hipError_t launch_raype_fused(const float* cam, const float* T_cp, const float* 
                               float min_depth, float max_depth, int B, int V, int h, int w, const void* W1hi, const void* W1lo,
                               const float* b1, const void* W2hi, const void* W2lo, const float* b2, const float* feat,
                               float* hidden, double* Tl, double* depth, float* out, int nchw_out, hipStream_t s);
-// GroupNorm(1, C) statistics from the float64 moments (sum, sum of squares) of a group: the mean and the variance — a difference of two
-// nearly equal numbers — in float64 with ONE reciprocal of the element count, the reciprocal square root in fp32 (its argument is
-// exact to 6e-8; the float64 sqrt + divisions this replaces were ~100 quarter-rate instructions in every wave of the consumers).
-// Used by the forward consumers and by the backward that re-normalises from the same moments.
+// GroupNorm(1, C) statistics from the float64 moments (sum, sum of squares) of a group, all in float64 (the variance is a difference
+// of two nearly equal numbers) with one reciprocal of the element count.  Used by the forward consumers and by the backward that
+// re-normalises from the same moments.  (An fp32 reciprocal square root was measured: the consumers' times did not move — the
+// statistics hide behind the operand fetch — so the float64 form stays.)
 __device__ __forceinline__ void gn_mean_rstd(double S, double Q, double inv_cnt, float eps, float& mean, float& rstd) {
     const double mu = S * inv_cnt;
     double var = Q * inv_cnt - mu * mu;
     var = var < 0.0 ? 0.0 : var;
     mean = (float)mu;
-    rstd = 1.f / sqrtf((float)var + eps);
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
 }
 struct ScaleBox { float lo[3]; float hi[3]; };
 // ---- backward (backward.hip, attn_bwd.hip)
