@@ -1,5 +1,8 @@
+"""GPU box: per-forward times (hipEvents) of 16 consecutive forwards after a synchronisation, three repetitions — the first forward of a
+process loads the code objects, the next ~12 run 2-12 % slow while the clock / power controller settles (why bench.py spins the
+device up before its warm-up steps)."""
 import os, sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 device = torch.device("cuda", 0)
 cfg, W, dec = bench.build_decoder(device)
