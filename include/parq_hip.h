@@ -115,7 +115,8 @@ int parq_pack_weights(parq_handle h, void *arena, size_t arena_bytes, parq_strea
  *      iteration writes NaN into all five computed outputs of parq_iterate / parq_forward instead of
  *      plausible wrong numbers.  Re-run such inputs in mode 0 (the Python class does this: see
  *      parq_amd.PARQDecoder.range_check);
- *   2  single fp16 products, 3  single bf16 products (head dim 64, dim <= 256): the reduced-precision
+ *   2  single fp16 products, 3  single bf16 products (head dim 64 with dim 128 / 256, or head dim 256 with dim a multiple
+ *      of 128 — the reference's shipped DEC_DIM 1024 / 4 heads included): the reduced-precision
  *      configurations of the benchmark (BASELINE.json configs 2 and 5; the reference defines no mixed
  *      precision).  Q, K, V and the probabilities are rounded to nearest 16-bit
  *      once, accumulation stays fp32; the K/V cache shrinks to half.  Outputs agree with the fp32 path to

@@ -90,13 +90,13 @@ struct parq_ctx {
     bool prepared = false;
     bool emb_valid = false;           // workspace emb holds pos2posemb3d of the chained reference points
     int ref_state = 0;                // 0: none, 1: ws.ref valid
-    int attn_mode = 1;                // 0: fp32 MFMA, 1: split fp16x3, 2: fp16, 3: bf16 (1..3: head dim 64 only)
+    int attn_mode = 1;                // 0: fp32 MFMA, 1: split fp16x3, 2: fp16, 3: bf16 (1..3: head dims 64 and 256)
     int kv16_state = 1;               // what the arena's 16-bit W_kv copy currently holds (same numbering)
     float drop_p = 0.f;               // training dropout (decoder layer, transformer_parq.py:339-386) and its base seed
     uint32_t drop_seed = 0;
     uint32_t site_seed(int k, int site) const { return rng_stream(drop_seed, (uint32_t)(k * 8 + site)); }
     // split K/V cache in use: head dim 64 (all cache modes) or head dim 256 in split mode (a head = 4 virtual heads of 64)
-    bool cache_mode() const { return attn_mode >= 1 && (dh == 64 || (dh == 256 && attn_mode == 1)); }
+    bool cache_mode() const { return attn_mode >= 1 && (dh == 64 || dh == 256); }
     int vheads() const { return C / 64; }            // heads of the cache layout
     int terms() const { return attn_mode == 1 ? 3 : 1; }
     int kind() const { return attn_mode == 3 ? kBF16 : kF16; }
@@ -182,7 +182,7 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
                                  : flash_pick_splits(B, c->H, c->Q, (int)N, c->dh, cus);
     ws->kvc = take(split_mode ? (int64_t)(c->nl * kvsplit_cache_bytes(B, c->vheads(), (int)N, c->terms()) / sizeof(float)) : 0);
     ws->flags = take(64);
-    ws->xsplit = take(split_mode && c->terms() == 3 && kvproj_big_on() ? (int64_t)kvproj_big_scratch_floats(B, (int)N, C) : 0);
+    ws->xsplit = take(split_mode && kvproj_big_on() ? (int64_t)kvproj_big_scratch_floats(B, (int)N, C) : 0);
     const size_t fs = flash_scratch_bytes(B, c->H, c->Q, c->dh, ws->self_split);
     const size_t fc = flash_scratch_bytes(B, c->H, c->Q, c->dh, ws->cross_split);
     ws->flash = take((int64_t)((fs > fc ? fs : fc) / sizeof(float)));
@@ -289,9 +289,9 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         const LayerW& L = c->ar.layers[li];
         if (c->cache_mode()) {
             char* cache = reinterpret_cast<char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, c->vheads(), (int)N, c->terms());
-            if (c->terms() == 3 && kvproj_big_on() && kvproj_big_scratch_floats(B, (int)N, C) > 0)
+            if (kvproj_big_on() && kvproj_big_scratch_floats(B, (int)N, C) > 0)
                 HIPCHK(launch_kvproj_big(sc->tokens, A + L.kv_whi, A + L.kv_wlo, A + L.cross_in_b + C, B, (int)N, C, cache,
-                                         reinterpret_cast<int*>(wsp + ws.flags), wsp + ws.xsplit, s));
+                                         reinterpret_cast<int*>(wsp + ws.flags), wsp + ws.xsplit, s, c->terms(), c->kind()));
             else
                 HIPCHK(launch_kvproj_split(sc->tokens, A + L.kv_whi, A + L.kv_wlo, A + L.cross_in_b + C, B, (int)N, C, c->vheads(),
                                            cache, reinterpret_cast<int*>(wsp + ws.flags), s, c->terms(), c->kind()));
@@ -403,7 +403,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         fa.l_part = fa.m_part + (int64_t)B * H * fa.nsplit * lp;
         if (c->cache_mode()) {
             const char* cache = reinterpret_cast<const char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, c->vheads(), (int)N, c->terms());
-            if (dh == 256) HIPCHK(launch_flash_split256(fa, cache, s));
+            if (dh == 256) HIPCHK(launch_flash_split256(fa, cache, s, c->terms(), c->kind()));
             else HIPCHK(launch_flash_split(fa, cache, s, c->terms(), c->kind()));
         } else {
             const float* kv = wsp + ws.kv + (int64_t)li * B * 2 * N * C;
@@ -991,8 +991,8 @@ int parq_workspace_lookup(parq_handle h, int32_t B, int32_t V, int32_t hh, int32
 
 int parq_set_attention_mode(parq_handle h, int32_t mode) {
     if (!h || mode < 0 || mode > 3) return fail(PARQ_ERR_ARG, "attention mode must be 0 (fp32 MFMA), 1 (split fp16x3), 2 (fp16) or 3 (bf16)");
-    if (mode >= 2 && (h->dh != 64 || h->C > 256 || (2 * h->C) % 256 != 0))
-        return fail(PARQ_ERR_ARG, "the fp16 / bf16 attention modes need head dim 64 and dim in {128, 256}");
+    if (mode >= 2 && !((h->dh == 64 && h->C <= 256 && (2 * h->C) % 256 == 0) || (h->dh == 256 && h->C % 128 == 0 && (h->C == 256 || kvproj_big_on())))) 
+        return fail(PARQ_ERR_ARG, "the fp16 / bf16 attention modes need head dim 64 with dim in {128, 256}, or head dim 256 with dim a multiple of 128");
     h->attn_mode = mode;
     h->prepared = false;
     return PARQ_OK;

@@ -227,10 +227,10 @@ int flash_split_pick_splits(int B, int H, int Lq, int Lk, int num_cus);
 // kvproj_big.hip: the K/V projection for C > 256 (pre-split tokens, LDS-DMA operands); scratch = kvproj_big_scratch_floats floats
 size_t kvproj_big_scratch_floats(int B, int N, int C);
 hipError_t launch_kvproj_big(const float* tokens, const void* Whi, const void* Wlo, const float* bias, int B, int N, int C,
-                             void* cache, int* overflow, float* scratch, hipStream_t s);
+                             void* cache, int* overflow, float* scratch, hipStream_t s, int terms = 3, int kind = kF16);
 // flash_split256.hip: the same for head dim 256 (a head = 4 virtual heads of 64 in the cache; wave pairs split the head dim)
 int flash_split256_pick_splits(int B, int H, int Lq, int Lk, int num_cus);
-hipError_t launch_flash_split256(const FlashArgs& a, const void* cache, hipStream_t s);
+hipError_t launch_flash_split256(const FlashArgs& a, const void* cache, hipStream_t s, int terms = 3, int kind = kF16);
 hipError_t launch_kvsplit_convert(const float* K, const float* V, int64_t k_batch, int64_t k_head, int64_t k_row,
                                   int64_t v_batch, int64_t v_head, int64_t v_row, int B, int H, int N, void* cache,
                                   int* overflow_flag, hipStream_t s, int terms = 3, int kind = kF16);

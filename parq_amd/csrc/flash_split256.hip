@@ -29,15 +29,25 @@ namespace {
 
 constexpr int kDH = 256;
 constexpr int kChunks = 4;                          // 64-dim chunks per head
-constexpr int kSubHalfs = 8192;                     // one 16 KB cache block of a chunk: [K_hi | K_lo | V_hi | V_lo] x 2048 halfs
-constexpr int kGrpHalfs = kChunks * 4096;           // K (or V) of a stage: [chunk][hi 2048 | lo 2048] halfs = 32 KB
+constexpr int kNWconst = 8;
+// TERMS = 3 (split precision): one 16 KB cache block of a chunk is [K_hi | K_lo | V_hi | V_lo] x 2048 halfs, K (or V) of a stage is
+// [chunk][hi 2048 | lo 2048] halfs = 32 KB.  TERMS = 1 (single fp16 / bf16 products, KIND): blocks of 8 KB [K | V], 16 KB per stage.
+template <int TERMS> struct Lay {
+    static constexpr int sub = TERMS == 3 ? 8192 : 4096;          // halfs per cache block of a chunk
+    static constexpr int xoff = TERMS == 3 ? 4096 : 2048;         // V offset inside a block
+    static constexpr int img = TERMS == 3 ? 4096 : 2048;          // halfs of one chunk's K (or V) image in the ring
+    static constexpr int grp = kChunks * img;                     // one ring slot
+    static constexpr int ndma = grp * 2 / (kNWconst * 64 * 16);   // DMA instructions per thread and group (4 / 2)
+};
 constexpr int kNW = 8;
 constexpr float kDeferLog2 = 10.f;
 
 // DROP: training dropout on the probabilities (keep decision of element (row = scene-head * Lq + query, column = key), the stream
 // the backward regenerates); the row sum l is taken before the mask, 1 / (1 - p) is applied to the output partials.
-template <bool DROP>
+template <bool DROP, int TERMS, int KIND>
 __global__ __launch_bounds__(kNW * 64) void flash_split256_kernel(FlashArgs a, const _Float16* __restrict__ cache) {
+    typedef Lay<TERMS> L;
+    constexpr int kGrpHalfs = L::grp, kSubHalfs = L::sub, kImgH = L::img;
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
     _Float16* Kr = smem_h;                                   // [2][kGrpHalfs]
     _Float16* Vr = smem_h + 2 * kGrpHalfs;                   // [2][kGrpHalfs]
@@ -70,7 +80,8 @@ __global__ __launch_bounds__(kNW * 64) void flash_split256_kernel(FlashArgs a, c
                 float x[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[e] = (e < 4 ? x0[e & 3] : x1[e & 3]) * scale;
-                split8(x, qhi[cc][s], qlo[cc][s]);
+                if constexpr (TERMS == 3) split8(x, qhi[cc][s], qlo[cc][s]);
+                else { qhi[cc][s] = cvt8_rn<KIND>(x); qlo[cc][s] = qhi[cc][s]; }
             }
     }
 
@@ -84,17 +95,28 @@ __global__ __launch_bounds__(kNW * 64) void flash_split256_kernel(FlashArgs a, c
     auto gload = [&](int t, int which) {
         _Float16* ring = which ? Vr : Kr;
         const unsigned dst = (unsigned)(size_t)(lds_byte*)(ring + ((t - t_begin) & 1) * kGrpHalfs);
+        if constexpr (TERMS == 3) {
+            // instruction c copies the 8 KB [hi | lo] of chunk c
 #pragma unroll
-        for (int c = 0; c < kChunks; ++c) {
-            const _Float16* src = cbase + ((int64_t)c * nblk + t) * kSubHalfs + which * 4096 + tid * 8;
-            lds_dma16(src, dst + (c * 512 + wave * 64) * 16);      // asm-issued: hipcc must not answer with vmcnt(0) before LDS reads
+            for (int c = 0; c < kChunks; ++c) {
+                const _Float16* src = cbase + ((int64_t)c * nblk + t) * kSubHalfs + which * L::xoff + tid * 8;
+                lds_dma16(src, dst + (c * 512 + wave * 64) * 16);      // asm-issued: hipcc must not answer with vmcnt(0) before LDS reads
+            }
+        } else {
+            // instruction i copies the 4 KB images of chunks 2 i and 2 i + 1 (256 threads each)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = 2 * i + (tid >> 8), piece = tid & 255;
+                const _Float16* src = cbase + ((int64_t)c * nblk + t) * kSubHalfs + which * L::xoff + piece * 8;
+                lds_dma16(src, dst + (c * 256 + (piece >> 6) * 64) * 16);
+            }
         }
     };
-    auto wait_groups = [&](int n) {                           // at most n DMA groups (4 instructions each) still in flight
+    auto wait_groups = [&](int n) {                           // at most n DMA groups (L::ndma instructions each) still in flight
         if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (n == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (n == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (n == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::ndma) : "memory");
+        else if (n == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L::ndma) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * L::ndma) : "memory");
     };
 
     f32x16 o[4];                                             // O^T blocks: dims 128 half + 32 j + mfma32_row(r), column = this lane's query
@@ -116,8 +138,8 @@ __global__ __launch_bounds__(kNW * 64) void flash_split256_kernel(FlashArgs a, c
     const int ksw = (li >> 1) & 7;
     for (int t = t_begin; t < t_end; ++t) {
         const int slot = (t - t_begin) & 1;
-        const _Float16* Ks = Kr + slot * kGrpHalfs + (2 * half) * 4096;          // this wave's two chunks: [cc][hi | lo]
-        const _Float16* Vs = Vr + slot * kGrpHalfs + (2 * half) * 4096;
+        const _Float16* Ks = Kr + slot * kGrpHalfs + (2 * half) * kImgH;         // this wave's two chunks: [cc][hi | lo]
+        const _Float16* Vs = Vr + slot * kGrpHalfs + (2 * half) * kImgH;
         const bool more1 = t + 1 < t_end, more2 = t + 2 < t_end;
 
         // ---- partial S^T over this wave's 128 dims
@@ -130,11 +152,13 @@ __global__ __launch_bounds__(kNW * 64) void flash_split256_kernel(FlashArgs a, c
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int pos = (4 * kh + s) ^ ksw;
-                    const half8 kfh = *reinterpret_cast<const half8*>(Ks + cc * 4096 + li * 64 + pos * 8);
-                    const half8 kfl = *reinterpret_cast<const half8*>(Ks + cc * 4096 + 2048 + li * 64 + pos * 8);
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh, qhi[cc][s], sacc, 0, 0, 0);
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh, qlo[cc][s], sacc, 0, 0, 0);
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl, qhi[cc][s], sacc, 0, 0, 0);
+                    const half8 kfh = *reinterpret_cast<const half8*>(Ks + cc * kImgH + li * 64 + pos * 8);
+                    sacc = mfma16<KIND>(kfh, qhi[cc][s], sacc);
+                    if constexpr (TERMS == 3) {
+                        const half8 kfl = *reinterpret_cast<const half8*>(Ks + cc * kImgH + 2048 + li * 64 + pos * 8);
+                        sacc = mfma16<KIND>(kfh, qlo[cc][s], sacc);
+                        sacc = mfma16<KIND>(kfl, qhi[cc][s], sacc);
+                    }
                 }
 #pragma unroll
             for (int r = 0; r < 16; ++r) Xb[(wave * 16 + r) * 64 + lane] = sacc[r];
@@ -180,7 +204,8 @@ __global__ __launch_bounds__(kNW * 64) void flash_split256_kernel(FlashArgs a, c
                         if (!drop_keep_h(drop_row, drop_colhash((uint32_t)(t * 32 + mfma32_row(8 * m + e, lane))), drop_thr)) p[e] = 0.f;
                     }
                 }
-                split8(p, phi[m], plo[m]);
+                if constexpr (TERMS == 3) split8(p, phi[m], plo[m]);
+                else { phi[m] = cvt8_rn<KIND>(p); plo[m] = phi[m]; }
             }
             rs += __shfl_xor(rs, 32);
             l_run += rs;
@@ -191,11 +216,13 @@ __global__ __launch_bounds__(kNW * 64) void flash_split256_kernel(FlashArgs a, c
                 for (int j = 0; j < 4; ++j) {
                     const int cc = j >> 1, d = (j & 1) * 32 + li;
                     const int pos = (2 * m + kh) ^ ((d >> 2) & 3);
-                    const half8 vh = *reinterpret_cast<const half8*>(Vs + cc * 4096 + d * 32 + pos * 8);
-                    const half8 vl = *reinterpret_cast<const half8*>(Vs + cc * 4096 + 2048 + d * 32 + pos * 8);
-                    o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, phi[m], o[j], 0, 0, 0);
-                    o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, phi[m], o[j], 0, 0, 0);
-                    o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, plo[m], o[j], 0, 0, 0);
+                    const half8 vh = *reinterpret_cast<const half8*>(Vs + cc * kImgH + d * 32 + pos * 8);
+                    o[j] = mfma16<KIND>(vh, phi[m], o[j]);
+                    if constexpr (TERMS == 3) {
+                        const half8 vl = *reinterpret_cast<const half8*>(Vs + cc * kImgH + 2048 + d * 32 + pos * 8);
+                        o[j] = mfma16<KIND>(vl, phi[m], o[j]);
+                        o[j] = mfma16<KIND>(vh, plo[m], o[j]);
+                    }
                 }
         }
         // K_{t+1} must be complete before the barrier that publishes it: groups issued after it are V_{t+1}, K_{t+2}
@@ -234,19 +261,25 @@ int flash_split256_pick_splits(int B, int H, int Lq, int Lk, int num_cus) {
 }
 
 // partial (O, m, l) of every (scene-head, key split) in the layout flash_merge_kernel<256> combines; cache: virtual-head split cache
-hipError_t launch_flash_split256(const FlashArgs& a, const void* cache, hipStream_t s) {
-    if (a.dh != kDH || a.nsplit < 1 || a.nsplit > 256) return hipErrorInvalidValue;
+template <int TERMS, int KIND>
+static hipError_t launch_fs256(const FlashArgs& a, const void* cache, hipStream_t s) {
     static DynLdsOnce once, once_drop;
-    const size_t lds = (size_t)4 * kGrpHalfs * sizeof(_Float16) + (size_t)kNW * 16 * 64 * sizeof(float);       // 160 KB
+    const size_t lds = (size_t)4 * Lay<TERMS>::grp * sizeof(_Float16) + (size_t)kNW * 16 * 64 * sizeof(float);       // 160 KB (96 KB single-term)
     dim3 grid(a.nsplit, ceil_div(a.Lq, 128), a.B * a.H);
     if (a.drop_p > 0.f) {
-        if (hipError_t e = once_drop.ensure(reinterpret_cast<const void*>(&flash_split256_kernel<true>), lds); e != hipSuccess) return e;
-        hipLaunchKernelGGL(flash_split256_kernel<true>, grid, dim3(kNW * 64), lds, s, a, reinterpret_cast<const _Float16*>(cache));
+        if (hipError_t e = once_drop.ensure(reinterpret_cast<const void*>(&flash_split256_kernel<true, TERMS, KIND>), lds); e != hipSuccess) return e;
+        hipLaunchKernelGGL((flash_split256_kernel<true, TERMS, KIND>), grid, dim3(kNW * 64), lds, s, a, reinterpret_cast<const _Float16*>(cache));
     } else {
-        if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_split256_kernel<false>), lds); e != hipSuccess) return e;
-        hipLaunchKernelGGL(flash_split256_kernel<false>, grid, dim3(kNW * 64), lds, s, a, reinterpret_cast<const _Float16*>(cache));
+        if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_split256_kernel<false, TERMS, KIND>), lds); e != hipSuccess) return e;
+        hipLaunchKernelGGL((flash_split256_kernel<false, TERMS, KIND>), grid, dim3(kNW * 64), lds, s, a, reinterpret_cast<const _Float16*>(cache));
     }
     return hipGetLastError();
+}
+
+hipError_t launch_flash_split256(const FlashArgs& a, const void* cache, hipStream_t s, int terms, int kind) {
+    if (a.dh != kDH || a.nsplit < 1 || a.nsplit > 256) return hipErrorInvalidValue;
+    if (terms == 3) return launch_fs256<3, kF16>(a, cache, s);
+    return kind == kF16 ? launch_fs256<1, kF16>(a, cache, s) : launch_fs256<1, kBF16>(a, cache, s);
 }
 
 }  // namespace parq

@@ -55,8 +55,15 @@ __global__ __launch_bounds__(256) void split_tokens_kernel(const float* __restri
 // 16 lanes one ds_read_b128 cycle serves (rows li in {0-3, 12-15, 20-27} or their complements) must hit 16 different slots
 __device__ __forceinline__ int chunk_pos(int r, int c) { return c ^ ((r >> 2) & 3); }
 
+// TERMS = 3: split products (tokens and W as hi/lo planes, cache blocks of 16 KB); TERMS = 1: single fp16 / bf16 (KIND) products —
+// a.Xhi / a.Whi hold the rounded operands, the lo pointers are unused, cache blocks of 8 KB [K | V]
+template <int TERMS, int KIND>
 __global__ __launch_bounds__(512) void kvproj_big_kernel(BigArgs a) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];          // [2][kStage]
+    constexpr int NIMG = TERMS == 3 ? 4 : 2;                    // operand images per k-step: A_hi | A_lo | W_hi | W_lo, or A | W
+    constexpr int kStg = NIMG * kImg;
+    constexpr int NDMA = NIMG * 2;                              // DMA instructions per thread and k-step
+    constexpr int kBlkH = TERMS == 3 ? 8192 : 4096;             // halfs of one 32-key cache block of a head
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];          // [2][kStg]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
@@ -77,27 +84,29 @@ __global__ __launch_bounds__(512) void kvproj_big_kernel(BigArgs a) {
 
     // ---- LDS-DMA of one k-step: 8 instructions per thread, piece p = i * 512 + tid of the 4096 16-byte pieces of the stage
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
-    const _Float16* srcs[8];
+    const _Float16* srcs[NDMA];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NDMA; ++i) {
         const int p = i * 512 + tid;
-        const int img = p >> 10, pp = p & 1023;                 // image 0..3, piece inside it
+        const int img = p >> 10, pp = p & 1023;                 // image index, piece inside it
         const int row = pp >> 2, slot = pp & 3;
         const int chunk = slot ^ ((row >> 2) & 3);
-        if (img < 2) {
+        const bool isA = TERMS == 3 ? img < 2 : img < 1;
+        const bool lo = TERMS == 3 && (img & 1);
+        if (isA) {
             int tok = m0 + row;
             tok = tok < a.N ? tok : a.N - 1;                    // rows past the scene: any finite data (their cache entries are masked keys)
-            srcs[i] = (img == 0 ? a.Xhi : a.Xlo) + ((int64_t)b * a.N + tok) * C + chunk * 8;
+            srcs[i] = (lo ? a.Xlo : a.Xhi) + ((int64_t)b * a.N + tok) * C + chunk * 8;
         } else {
-            srcs[i] = (img == 2 ? a.Whi : a.Wlo) + (int64_t)(n0 + row) * C + chunk * 8;
+            srcs[i] = (lo ? a.Wlo : a.Whi) + (int64_t)(n0 + row) * C + chunk * 8;
         }
     }
     // (asm-issued DMA + LDS-only barrier, common.hpp: with the builtin hipcc waited for the step it had just requested before every
     // fragment read of the current one)
     auto gload = [&](int ks, int slot) {
-        const unsigned dst = (unsigned)(size_t)(lds_byte*)(lds + slot * kStage);
+        const unsigned dst = (unsigned)(size_t)(lds_byte*)(lds + slot * kStg);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) lds_dma16(srcs[i] + ks * kTK, dst + (i * 512 + wave * 64) * 16);
+        for (int i = 0; i < NDMA; ++i) lds_dma16(srcs[i] + ks * kTK, dst + (i * 512 + wave * 64) * 16);
     };
 
     const int headcol0 = (n0 >> 6) + 2 * wc;                    // first of this wave's two virtual heads, in [K heads | V heads]
@@ -116,41 +125,46 @@ __global__ __launch_bounds__(512) void kvproj_big_kernel(BigArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's pieces of step ks have landed
         lds_barrier();                                          // ... everyone's; every wave is past the reads of step ks - 1
         if (ks + 1 < nk) gload(ks + 1, (ks + 1) & 1);
-        const _Float16* S = lds + (ks & 1) * kStage;
+        const _Float16* S = lds + (ks & 1) * kStg;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             half8 xh[2], xl[2], wh[4], wl[4];
+            constexpr int kW = TERMS == 3 ? 2 * kImg : kImg;       // offset of the W image(s)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int r = wr * 64 + t * 32 + li;
                 const int off = r * kTK + chunk_pos(r, 2 * s + kh) * 8;
                 xh[t] = *reinterpret_cast<const half8*>(S + off);
-                xl[t] = *reinterpret_cast<const half8*>(S + kImg + off);
+                if constexpr (TERMS == 3) xl[t] = *reinterpret_cast<const half8*>(S + kImg + off);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = wc * 128 + j * 32 + li;
                 const int off = r * kTK + chunk_pos(r, 2 * s + kh) * 8;
-                wh[j] = *reinterpret_cast<const half8*>(S + 2 * kImg + off);
-                wl[j] = *reinterpret_cast<const half8*>(S + 3 * kImg + off);
+                wh[j] = *reinterpret_cast<const half8*>(S + kW + off);
+                if constexpr (TERMS == 3) wl[j] = *reinterpret_cast<const half8*>(S + kW + kImg + off);
             }
             if (isK) {          // transposed product: rows = d, cols = tokens
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], xh[t], acc[t][j], 0, 0, 0);
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], xl[t], acc[t][j], 0, 0, 0);
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], xh[t], acc[t][j], 0, 0, 0);
+                        acc[t][j] = mfma16<KIND>(wh[j], xh[t], acc[t][j]);
+                        if constexpr (TERMS == 3) {
+                            acc[t][j] = mfma16<KIND>(wh[j], xl[t], acc[t][j]);
+                            acc[t][j] = mfma16<KIND>(wl[j], xh[t], acc[t][j]);
+                        }
                     }
             } else {            // rows = tokens, cols = d
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[t], wh[j], acc[t][j], 0, 0, 0);
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[t], wl[j], acc[t][j], 0, 0, 0);
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[t], wh[j], acc[t][j], 0, 0, 0);
+                        acc[t][j] = mfma16<KIND>(xh[t], wh[j], acc[t][j]);
+                        if constexpr (TERMS == 3) {
+                            acc[t][j] = mfma16<KIND>(xh[t], wl[j], acc[t][j]);
+                            acc[t][j] = mfma16<KIND>(xl[t], wh[j], acc[t][j]);
+                        }
                     }
             }
         }
@@ -200,18 +214,21 @@ __global__ __launch_bounds__(512) void kvproj_big_kernel(BigArgs a) {
                         for (int e = 0; e < 8; ++e) x[e] = A[8 * m + e] + bv;
                     }
                     half8 hi, lo;
-                    split8(x, hi, lo);
+                    if constexpr (TERMS == 3) split8(x, hi, lo);
+                    else hi = cvt8_rn<KIND>(x);
+                    if constexpr (KIND == kF16) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) ovf |= !(fabsf(x[e]) < 60000.f);
+                        for (int e = 0; e < 8; ++e) ovf |= !(fabsf(x[e]) < 60000.f);
+                    }
                     if (isK) {
                         const int pos = (4 * kh + 2 * ct + m) ^ ((li >> 1) & 7);
                         *reinterpret_cast<half8*>(wl + li * 64 + pos * 8) = hi;
-                        *reinterpret_cast<half8*>(wl + 2048 + li * 64 + pos * 8) = lo;
+                        if constexpr (TERMS == 3) *reinterpret_cast<half8*>(wl + 2048 + li * 64 + pos * 8) = lo;
                     } else {
                         const int d = 32 * ct + li;
                         const int pos = (2 * m + kh) ^ ((d >> 2) & 3);
                         *reinterpret_cast<half8*>(wl + d * 32 + pos * 8) = hi;
-                        *reinterpret_cast<half8*>(wl + 2048 + d * 32 + pos * 8) = lo;
+                        if constexpr (TERMS == 3) *reinterpret_cast<half8*>(wl + 2048 + d * 32 + pos * 8) = lo;
                     }
                 }
             __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): same-wave LDS round trip
@@ -219,11 +236,11 @@ __global__ __launch_bounds__(512) void kvproj_big_kernel(BigArgs a) {
             const int blk = (m0 + wr * 64 + t * 32) >> 5;
             if (blk < nblk) {                                   // wave-uniform
                 const int hv = isK ? headcol : headcol - a.VH;
-                _Float16* gout = a.cache + (((int64_t)b * a.VH + hv) * nblk + blk) * kBlkHalfs + (isK ? 0 : 4096);
+                _Float16* gout = a.cache + (((int64_t)b * a.VH + hv) * nblk + blk) * kBlkH + (isK ? 0 : kBlkH / 2);
                 const uint4* src = reinterpret_cast<const uint4*>(wl);
                 uint4* dst = reinterpret_cast<uint4*>(gout);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) dst[i * 64 + lane] = src[i * 64 + lane];
+                for (int i = 0; i < (TERMS == 3 ? 8 : 4); ++i) dst[i * 64 + lane] = src[i * 64 + lane];      // the 8 KB [hi | lo] (4 KB single) image
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
@@ -240,23 +257,33 @@ size_t kvproj_big_scratch_floats(int B, int N, int C) {
     return (size_t)B * N * C;                                   // hi + lo fp16 = 4 bytes per element
 }
 
-hipError_t launch_kvproj_big(const float* tokens, const void* Whi, const void* Wlo, const float* bias, int B, int N, int C,
-                             void* cache, int* overflow, float* scratch, hipStream_t s) {
-    if (!kvproj_big_scratch_floats(B, N, C) || !scratch || B > 65535) return hipErrorInvalidValue;
+template <int TERMS, int KIND>
+static hipError_t launch_big_t(const BigArgs& a, int B, hipStream_t s) {
     static DynLdsOnce once;
-    const size_t ldsb = (size_t)2 * kStage * sizeof(_Float16);              // 128 KB
-    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&kvproj_big_kernel), ldsb); e != hipSuccess) return e;
+    const size_t ldsb = (size_t)2 * (TERMS == 3 ? 4 : 2) * kImg * sizeof(_Float16);              // 128 KB (64 KB single-term); >= the 64 KB of epilogue scratch
+    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&kvproj_big_kernel<TERMS, KIND>), ldsb); e != hipSuccess) return e;
+    const int nct = 2 * a.C / kTN, nrt = ceil_div(a.N, kTM);
+    dim3 grid(ceil_div(nrt, 8) * 8 * nct, B, 1);
+    hipLaunchKernelGGL((kvproj_big_kernel<TERMS, KIND>), grid, dim3(512), ldsb, s, a);
+    return hipGetLastError();
+}
+
+// terms = 3: Whi / Wlo are the hi / lo planes of W_kv; terms = 1: Whi holds W_kv rounded to `kind`, Wlo is unused
+hipError_t launch_kvproj_big(const float* tokens, const void* Whi, const void* Wlo, const float* bias, int B, int N, int C,
+                             void* cache, int* overflow, float* scratch, hipStream_t s, int terms, int kind) {
+    if (!kvproj_big_scratch_floats(B, N, C) || !scratch || B > 65535) return hipErrorInvalidValue;
     const int64_t n = (int64_t)B * N * C;
     _Float16* xhi = reinterpret_cast<_Float16*>(scratch);
     _Float16* xlo = xhi + n;
-    hipLaunchKernelGGL(split_tokens_kernel, dim3((unsigned)ceil_div64(n / 8, 256)), dim3(256), 0, s, tokens, xhi, xlo, n / 8, overflow);
     BigArgs a;
     a.Xhi = xhi; a.Xlo = xlo; a.Whi = reinterpret_cast<const _Float16*>(Whi); a.Wlo = reinterpret_cast<const _Float16*>(Wlo);
     a.bias = bias; a.cache = reinterpret_cast<_Float16*>(cache); a.overflow = overflow; a.N = N; a.C = C; a.VH = C / 64;
-    const int nct = 2 * C / kTN, nrt = ceil_div(N, kTM);
-    dim3 grid(ceil_div(nrt, 8) * 8 * nct, B, 1);
-    hipLaunchKernelGGL(kvproj_big_kernel, grid, dim3(512), ldsb, s, a);
-    return hipGetLastError();
+    if (terms == 3) {
+        hipLaunchKernelGGL(split_tokens_kernel, dim3((unsigned)ceil_div64(n / 8, 256)), dim3(256), 0, s, tokens, xhi, xlo, n / 8, overflow);
+        return launch_big_t<3, kF16>(a, B, s);
+    }
+    if (hipError_t e = launch_cvt16(tokens, xhi, n, kind, s); e != hipSuccess) return e;      // (token range: checked on the K / V values in the epilogue)
+    return kind == kF16 ? launch_big_t<1, kF16>(a, B, s) : launch_big_t<1, kBF16>(a, B, s);
 }
 
 }  // namespace parq

@@ -142,8 +142,8 @@ class _TransformerParams(nn.Module):
 # ---------------------------------------------------------------------------------------
 
 # cross-attention arithmetic (include/parq_hip.h, parq_set_attention_mode): "split" = fp16 hi/lo 3-term products
-# (fp32-class accuracy, default at head dim 64), "fp32" = exact fp32 MFMA, "fp16" / "bf16" = single reduced-precision
-# products (BASELINE configs 2 and 5)
+# (fp32-class accuracy, default at head dims 64 and 256), "fp32" = exact fp32 MFMA, "fp16" / "bf16" = single reduced-precision
+# products (BASELINE configs 2 and 5; head dim 64 with dim 128 / 256, head dim 256 with dim a multiple of 128)
 ATTENTION_MODES = {"fp32": 0, "split": 1, "fp16": 2, "bf16": 3}
 
 
@@ -305,10 +305,10 @@ class PARQDecoder(nn.Module):
     def _train_mode(self):
         """Attention arithmetic of the training entry points: ``attention_mode`` where the kernels exist — the split-precision
         forward at head dims 64 / 256 (the backward kernels then work on fp32 K / V rebuilt from the split cache), the fp16 /
-        bf16 forward at head dim 64 (BASELINE cfg 5 trains in fp16: the backward differentiates straight through the rounded
-        K / V) — else the exact-fp32 kernels."""
+        bf16 forward at head dim 64 (dim <= 256) and at head dim 256 (BASELINE cfg 5 trains in fp16: the backward differentiates
+        straight through the rounded K / V) — else the exact-fp32 kernels."""
         dh = self.dim_in // self.num_heads
-        if self.attention_mode in ("fp16", "bf16") and dh == 64 and self.dim_in <= 256:
+        if self.attention_mode in ("fp16", "bf16") and ((dh == 64 and self.dim_in <= 256) or (dh == 256 and self.dim_in % 128 == 0)):
             return self.attention_mode
         return "split" if dh in (64, 256) and self.attention_mode != "fp32" else "fp32"
 

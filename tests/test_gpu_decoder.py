@@ -79,11 +79,11 @@ def test_forward_equals_stepping_and_wrappers_accepted():
             assert torch.equal(o[key], outs[k][key]), (k, key)     # bit-identical: same kernels, same order
 
 
-def _cfg2_worst_error(mode):
+def _cfg2_worst_error(mode, dim=256, heads=4, geom=(5, 120, 160), queries=128):
     """cfg-2 geometry (5 views 120x160 features, Q=128, 4 iterations), teacher-forced against the float64 oracle."""
-    cfg = synth.decoder_cfg(dim=256, queries=128, heads=4, ffn=768, layers=4)
+    cfg = synth.decoder_cfg(dim=dim, queries=queries, heads=heads, ffn=768, layers=4)
     W = synth.make_decoder_weights(cfg, 31)
-    sc = synth.make_scene(32, 1, 5, 120, 160, 256)
+    sc = synth.make_scene(32, 1, geom[0], geom[1], geom[2], dim)
     dec = make_decoder(cfg, W)
     if mode is not None:
         dec.attention_mode = mode
@@ -101,6 +101,8 @@ def _cfg2_worst_error(mode):
             x, y = a[key], b[key].numpy()
             if key == "size_unnormalized":
                 x, y = x[ok], y[ok]
+                if x.size == 0:                 # no row with a clear arg-max class in this fixture: the mean-size gather is undecided
+                    continue
             worst[key] = max(worst.get(key, 0.0), rel_err(x, y))
     return worst, dec
 
@@ -120,6 +122,19 @@ def test_cfg2_reduced_precision_modes(mode, tol):
     print("\nreduced precision", mode, worst)
     assert max(worst.values()) < tol, worst
     assert max(worst.values()) > 1e-5          # the reduced-precision kernels really ran
+    if mode == "fp16":
+        assert not dec.fp16_range_exceeded()
+
+
+@pytest.mark.parametrize("mode,tol", [("fp16", 1e-3), ("bf16", 1e-2)])
+@pytest.mark.parametrize("dim,heads", [(256, 1), (1024, 4)])
+def test_reduced_precision_modes_at_head_dim_256(mode, tol, dim, heads):
+    """The same modes at head dim 256 (the reference's shipped head size; d = 1024 goes through the large-C projection kernel,
+    d = 256 with one head through the W-stationary one): 3 views of 40 x 50 features + 7 ragged keys worth of block tail."""
+    worst, dec = _cfg2_worst_error(mode, dim=dim, heads=heads, geom=(3, 41, 49), queries=72)
+    print("\nreduced precision at head dim 256", mode, dim, worst)
+    assert max(worst.values()) < tol, worst
+    assert max(worst.values()) > 1e-6
     if mode == "fp16":
         assert not dec.fp16_range_exceeded()
 
