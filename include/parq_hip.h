@@ -178,8 +178,10 @@ int parq_profile_read(parq_handle h, int32_t which, double *total_ms, int64_t *l
  * independent given the stash: with shared layer weights (one K / V per scene) parq_backward runs the cross-attention backward of
  * ALL iterations as one launch (dK / dV written once) and the K/V-projection weight gradient on the fp16 matrix pipe (hi/lo split);
  * the training workspace then also holds per-iteration dO / dQ and packed query tiles (parq_train_workspace_bytes accounts for it).
- * Environment switches for A/B and debugging: PARQ_BWD_BATCHED=0 (per-iteration launches), PARQ_KVPROJ_BWD=fp32 (generic fp32
- * TN GEMM), PARQ_ATTN_BWD_V=1 (first-version split kernel), PARQ_ATTN_BWD=naive|mfma (exact fp32 attention backward). */
+ * parq_set_backward_batched(h, 0) (before sizing the training workspace) selects the per-iteration launches instead: same
+ * gradients up to summation order, kept as the cross-check of the one-launch form.
+ * The library reads NO environment variables: development A/B switches and the kernels-with-ingredients-removed probes exist
+ * only in the separate development build (-DPARQ_DEV_PROBES, libparq_hip_dev.so, used by tools/). */
 typedef struct parq_output_grads {
     const float *pred_logits, *center_unnormalized, *size_unnormalized, *ortho6d;
 } parq_output_grads;
@@ -190,6 +192,7 @@ typedef struct parq_output_grads {
  * 0 self-attention probabilities (rows = B*H*Q, cols = Q), 1 self out-proj (B*Q x C), 2 cross-attention probabilities
  * (B*H*Q x N), 3 cross out-proj, 4 FFN hidden (B*Q x F), 5 FFN output — for tests that feed the same masks to an oracle. */
 int parq_set_dropout(parq_handle h, float p, uint32_t seed);
+int parq_set_backward_batched(parq_handle h, int32_t on);
 int parq_k_dropout_mask(parq_handle h, int32_t iteration, int32_t site, int64_t rows, int64_t cols, float *out,
                         parq_stream stream);
 size_t parq_train_workspace_bytes(parq_handle h, int32_t B, int32_t V, int32_t hh, int32_t ww);

@@ -14,6 +14,9 @@ import torch  # noqa: F401  (loads the HIP runtime before our library)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_C", "libparq_hip.so")
+# development build (-DPARQ_DEV_PROBES: environment A/B switches, probe kernels, in-kernel time stamps).  Never loaded by the
+# package itself: tools/ and `bench.py --dev-lib` opt in with use_dev_library() before the first load().
+DEV_LIB_PATH = os.path.join(_HERE, "_C", "libparq_hip_dev.so")
 
 PROF_KV_PROJ, PROF_PROJECT_SAMPLE, PROF_CROSS_ATTN, PROF_SELF_ATTN, PROF_LINEAR, PROF_OTHER, PROF_MERGE = range(7)
 PROF_NAMES = ["kv_proj", "project_sample", "cross_attn", "self_attn", "linear", "other", "cross_attn_merge"]
@@ -62,6 +65,7 @@ SYMBOLS = {
     "parq_profile_enable": (C.c_int, [_vp, _i32]),
     "parq_profile_read": (C.c_int, [_vp, _i32, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "parq_set_dropout": (C.c_int, [_vp, _f, C.c_uint32]),
+    "parq_set_backward_batched": (C.c_int, [_vp, _i32]),
     "parq_k_dropout_mask": (C.c_int, [_vp, _i32, _i32, _i64, _i64, _vp, _vp]),
     "parq_train_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32, _i32]),
     "parq_grad_arena_bytes": (_sz, [_vp]),
@@ -90,6 +94,18 @@ SYMBOLS = {
 }
 
 _lib = None
+
+
+def use_dev_library():
+    """Development only (tools/, `bench.py --dev-lib`): bind the -DPARQ_DEV_PROBES build instead of the product library."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("parq_amd: use_dev_library() must be called before the library is first loaded")
+    LIB_PATH = DEV_LIB_PATH
+
+
+def is_dev_library():
+    return LIB_PATH == DEV_LIB_PATH
 
 
 def load():

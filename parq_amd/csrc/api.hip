@@ -101,7 +101,7 @@ struct parq_ctx {
     int terms() const { return attn_mode == 1 ? 3 : 1; }
     int kind() const { return attn_mode == 3 ? kBF16 : kF16; }
     int* range_mirror = nullptr;      // host-visible word raised when outputs are poisoned (parq_set_range_mirror)
-    bool bwd_batched_env = true;      // PARQ_BWD_BATCHED != 0, sampled by parq_create (the parity test makes one handle per setting)
+    bool bwd_batched_env = true;      // parq_set_backward_batched (the parity test compares the two settings)
     float dim_t_host[128];            // 10000^(2*(i//2)/128): uploaded by parq_pack_weights from this persistent buffer (no stream sync)
     bool profiling = false;
     std::vector<ProfEvent> events;
@@ -140,15 +140,14 @@ void build_arena(parq_ctx* c) {
 }
 
 bool kvproj_big_on() {
-    static const bool on = [] { const char* e = getenv("PARQ_KVPROJ_BIG"); return !(e && e[0] == '0'); }();   // 0: keep the tiled kernel at C > 256 (A/B)
+    static const bool on = [] { const char* e = dev_env("PARQ_KVPROJ_BIG"); return !(e && e[0] == '0'); }();   // 0: keep the tiled kernel at C > 256 (A/B)
     return on;
 }
 
 // Training: the cross-attention backward of all recurrent iterations can run as ONE launch when the iterations share the layer
-// weights (hence K / V) and the split-precision kernel applies (head dim 64, long key axis); PARQ_BWD_BATCHED=0 restores the
+// weights (hence K / V) and the split-precision kernel applies (head dim 64, long key axis); parq_set_backward_batched(h, 0) restores the
 // per-iteration launches.
 bool bwd_batched_ok(const parq_ctx* c, int64_t N) {
-    // c->bwd_batched_env is read from PARQ_BWD_BATCHED when the handle is created (not on the launch path)
     // head dim 64: the register-resident split kernel (long key axes); head dim 256: the composition from split-precision GEMMs
     return c->bwd_batched_env && c->nl == 1 && ((c->dh == 64 && N >= 2048) || c->dh == 256) && c->I > 1 && c->I <= 16;
 }
@@ -722,7 +721,7 @@ int do_backward_kvproj(parq_ctx* c, const parq_scene* sc, float* wsp, const Work
         const LayerW& L = c->ar.layers[li];
         const float* g = wsp + ws.g_kv + (int64_t)li * B * 2 * N * C;          // [B*N][2C]
         const int Mr = (int)(B * N);
-        static const bool split_off = [] { const char* e = getenv("PARQ_KVPROJ_BWD"); return e && e[0] == 'f'; }();   // "fp32": generic kernels
+        static const bool split_off = [] { const char* e = dev_env("PARQ_KVPROJ_BWD"); return e && e[0] == 'f'; }();   // "fp32": generic kernels
         const bool split_ok = ws.bwd_batched && !split_off;                      // the batched backward leaves max |g| in g_kvmax
         if (split_ok && kvproj_bwd_split_supported(C)) {
             // dW, db on the fp16 matrix pipe (hi/lo split); g is scaled by the power of two derived from max |g| (attention epilogue)
@@ -775,7 +774,13 @@ int check_outs(const parq_outputs* o) {
 extern "C" {
 
 const char* parq_last_error(void) { return g_err; }
-const char* parq_version(void) { return "parq_hip 0.2 (gfx950; cross-attention: fp16 hi/lo split MFMA products by default, exact fp32 MFMA on request)"; }
+const char* parq_version(void) {
+#ifdef PARQ_DEV_PROBES
+    return "parq_hip 0.3-dev (gfx950; DEVELOPMENT build: environment A/B switches, probe kernels and time stamps compiled in)";
+#else
+    return "parq_hip 0.3 (gfx950; cross-attention: fp16 hi/lo split MFMA products by default, exact fp32 MFMA on request)";
+#endif
+}
 
 int parq_create(const parq_config* cfg, parq_handle* out) {
     if (!cfg || !out) return fail(PARQ_ERR_ARG, "NULL argument");
@@ -796,11 +801,27 @@ int parq_create(const parq_config* cfg, parq_handle* out) {
     c->nl = cfg->share_weights ? 1 : cfg->num_layers;
     c->NH1 = 2 * c->C + ((c->ncls + 3 + 3) / 4) * 4;
     for (int i = 0; i < 3; ++i) { c->sb.lo[i] = cfg->scale[2 * i]; c->sb.hi[i] = cfg->scale[2 * i + 1]; }
-    if (const char* e = getenv("PARQ_BWD_BATCHED")) c->bwd_batched_env = atoi(e) != 0;
     // dim_t[i] = 10000^(2*(i//2)/128) in float32 (transformer_parq.py:49-50)
     for (int i = 0; i < 128; ++i) c->dim_t_host[i] = powf(10000.0f, 2.0f * (float)(i / 2) / 128.0f);
     build_arena(c);
     *out = c;
+    return PARQ_OK;
+}
+
+#ifdef PARQ_DEV_PROBES
+// development build only (not declared in include/parq_hip.h): device buffer of in-kernel time stamps, see common.hpp.
+// buf = [cursor, 3 unused, records of 4 x u64 ...] with room for `cap` records; NULL switches the stamps off.  Synchronises.
+extern "C" int parq_dev_timeline(unsigned long long* buf, unsigned int cap) {
+    if (buf) HIPCHK(hipMemset(buf, 0, 32));
+    HIPCHK(tl_set_linear(buf, cap)); HIPCHK(tl_set_elementwise(buf, cap)); HIPCHK(tl_set_flash(buf, cap));
+    HIPCHK(tl_set_flash_split(buf, cap)); HIPCHK(tl_set_kvproj_split(buf, cap));
+    return PARQ_OK;
+}
+#endif
+
+int parq_set_backward_batched(parq_handle h, int32_t on) {
+    if (!h) return fail(PARQ_ERR_ARG, "NULL handle");
+    h->bwd_batched_env = on != 0;
     return PARQ_OK;
 }
 

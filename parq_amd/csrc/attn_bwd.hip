@@ -1061,7 +1061,7 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
     if (dh != 64 && dh != 32) return attn_bwd_materialised(a, dh, mat_scratch, s);
     dim3 grid(ceil_div(Lk, 256), B * H);
     static const int force = [] {
-        const char* e = getenv("PARQ_ATTN_BWD");            // "naive" / "mfma" (exact fp32 MFMA): debugging overrides of the split kernel
+        const char* e = dev_env("PARQ_ATTN_BWD");            // "naive" / "mfma" (exact fp32 MFMA): debugging overrides of the split kernel
         return e ? (e[0] == 'n' ? 1 : 2) : 0;
     }();
     if (dh == 64 && force == 0 && Lk >= 2048 && absmax) {
@@ -1303,7 +1303,7 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
     if (dh == 256) return attn_bwd_batched_256(a, gq_it, oscale, mat_scratch, s);     // (kv_absmax: taken by the caller over its dK | dV buffer)
     dim3 g2(ceil_div(Lk, kSpKW), B * H);
     const int Lq_pad = (Lq + 31) & ~31;
-    static const bool v1 = [] { const char* e = getenv("PARQ_ATTN_BWD_V"); return e && e[0] == '1'; }();
+    static const bool v1 = [] { const char* e = dev_env("PARQ_ATTN_BWD_V"); return e && e[0] == '1'; }();
     if (pack && !v1) {
         // second version: tile images packed once, fetched by LDS-DMA; transpose reads
         constexpr size_t lds2 = (size_t)(2 * 8192 + 2 * 16384 + 2 * kImgHalfs) * sizeof(_Float16);

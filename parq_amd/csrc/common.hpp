@@ -5,11 +5,68 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 namespace parq {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Development knobs (A/B switches, kernels with ingredients removed) are read from the environment ONLY in the development build
+// (-DPARQ_DEV_PROBES -> parq_amd/_C/libparq_hip_dev.so, loaded by tools/ through PARQ_HIP_LIB).  The product library never calls
+// getenv: every knob takes its default and the probe instantiations (wrong results by construction) are not compiled in.
+#ifdef PARQ_DEV_PROBES
+inline const char* dev_env(const char* name) { return getenv(name); }
+#else
+inline const char* dev_env(const char*) { return nullptr; }
+#endif
+
+// ---- in-kernel time stamps (development build only): where a launch spends its time between two kernel boundaries.
+// Wave 0 of every workgroup of an instrumented kernel appends {kernel id | grid size | XCD, linear block index, start, end} to a
+// device buffer (parq_dev_timeline); stamps are s_memrealtime (100 MHz, chip-wide), `end` is taken after the wave's own stores
+// have been acknowledged.  tools/iter_timeline_stamps.py turns the records into a per-launch table (first / last workgroup start,
+// last end, gap to the previous launch's last end = the dependent-dispatch boundary).
+enum : int { kTlLinear = 1, kTlProjectSample = 2, kTlSelfAttn = 3, kTlFlashSplit = 4, kTlFlashMerge = 5, kTlBoxDecode = 6, kTlPosemb = 7,
+             kTlKvProj = 8, kTlChain = 9 };
+#ifdef PARQ_DEV_PROBES
+static __device__ unsigned long long* parq_tl_buf = nullptr;      // one copy per translation unit (no relocatable device code)
+static __device__ unsigned int parq_tl_cap = 0;
+struct TlStamp {
+    unsigned long long t0; int id;
+    __device__ __forceinline__ TlStamp(int id_) : id(id_) { t0 = (threadIdx.x == 0 && parq_tl_buf) ? wall_clock64() : 0ull; }
+    __device__ __forceinline__ ~TlStamp() {
+        if (threadIdx.x == 0 && parq_tl_buf) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long t1 = wall_clock64();
+            const unsigned long long idx = atomicAdd(parq_tl_buf, 1ull);
+            if (idx < parq_tl_cap) {
+                unsigned long long* r = parq_tl_buf + 4 + idx * 4;
+                const unsigned long long nblk = (unsigned long long)gridDim.x * gridDim.y * gridDim.z;
+                const unsigned long long xcc = __builtin_amdgcn_s_getreg(6164) & 15u;     // HW_REG_XCC_ID
+                r[0] = (unsigned long long)id | (nblk << 8) | (xcc << 40);
+                r[1] = blockIdx.x + (unsigned long long)gridDim.x * (blockIdx.y + (unsigned long long)gridDim.y * blockIdx.z);
+                r[2] = t0; r[3] = t1;
+            }
+        }
+    }
+};
+#define PARQ_TL_KERNEL(id) ::parq::TlStamp parq_tl_stamp_(id)
+// each instrumented translation unit defines its setter with this macro; api.hip calls them all from parq_dev_timeline()
+#define PARQ_TL_DEFINE_SETTER(fn)                                                                              \
+    hipError_t fn(unsigned long long* buf, unsigned int cap) {                                                 \
+        hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(parq_tl_buf), &buf, sizeof(buf));                          \
+        if (e != hipSuccess) return e;                                                                         \
+        return hipMemcpyToSymbol(HIP_SYMBOL(parq_tl_cap), &cap, sizeof(cap));                                  \
+    }
+hipError_t tl_set_linear(unsigned long long*, unsigned int);
+hipError_t tl_set_elementwise(unsigned long long*, unsigned int);
+hipError_t tl_set_flash(unsigned long long*, unsigned int);
+hipError_t tl_set_flash_split(unsigned long long*, unsigned int);
+hipError_t tl_set_kvproj_split(unsigned long long*, unsigned int);
+#else
+#define PARQ_TL_KERNEL(id) do { } while (0)
+#define PARQ_TL_DEFINE_SETTER(fn)
+#endif
 
 constexpr int kWave = 64;
 constexpr int kGnSlots = 64;    // GroupNorm moment accumulators per (scene, group): spreads the fp64 atomics

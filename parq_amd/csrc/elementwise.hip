@@ -88,6 +88,7 @@ __global__ void initial_ref_kernel(const float* w, int B, int Q, float* ref) {
 // ---------------------------------------------------------------- sine embedding
 // emb[m][blk*128 + i], blk order (y, x, z); a = ref*2pi / dim_t[i]; even i -> sin, odd i -> cos.
 __global__ void posemb_kernel(const float* ref, const float* dim_t, int M, float* emb) {
+    PARQ_TL_KERNEL(kTlPosemb);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * 384) return;
     const int m = idx / 384;
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(1024) void project_sample_kernel(
     const float* __restrict__ tokens, const TPose* __restrict__ T_cl, const float* __restrict__ cam,
     const float* __restrict__ ref, ScaleBox sb, int V, int h, int w, int C, int Q, float* __restrict__ tgt,
     float* __restrict__ coord_pos, double* __restrict__ zero_f64, int zero_n) {
+    PARQ_TL_KERNEL(kTlProjectSample);
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [nwv][C] + [nwv] counts
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += gridDim.x * blockDim.x)
         zero_f64[i] = 0.0;                                          // accumulators of later kernels
@@ -316,6 +318,7 @@ __global__ __launch_bounds__(1024) void gn_stats_kernel(const float* __restrict_
 constexpr int kMaxCls = 32;
 
 __global__ __launch_bounds__(256) void box_decode_kernel(BoxDecodeArgs a) {
+    PARQ_TL_KERNEL(kTlBoxDecode);
     const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (m >= a.M) return;
     const int lane = threadIdx.x & 63;
@@ -524,7 +527,7 @@ hipError_t launch_gn_stats(const float* X, int64_t ldx, int col0, int ncols, int
 hipError_t launch_box_decode(const BoxDecodeArgs& a, hipStream_t s) {
     if (a.ncls > kMaxCls || a.ncls < 1) return hipErrorInvalidValue;
     // one row per wave; rows per workgroup: 1 while that still leaves CUs idle (pure latency: spread the rows over the chip), else 4
-    static const int rows_env = [] { const char* e = getenv("PARQ_DECODE_ROWS"); return e ? atoi(e) : 0; }();
+    static const int rows_env = [] { const char* e = dev_env("PARQ_DECODE_ROWS"); return e ? atoi(e) : 0; }();
     const int rows = (rows_env >= 1 && rows_env <= 4) ? rows_env : (a.M <= 2 * device_num_cus() ? 1 : 4);
     hipLaunchKernelGGL(box_decode_kernel, dim3(ceil_div(a.M, rows)), dim3(rows * 64), 0, s, a);
     return hipGetLastError();
@@ -547,5 +550,7 @@ hipError_t launch_fill(float* dst, float value, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, s, dst, value, n);
     return hipGetLastError();
 }
+
+PARQ_TL_DEFINE_SETTER(tl_set_elementwise)
 
 }  // namespace parq

@@ -226,6 +226,7 @@ __global__ __launch_bounds__(NW * 64) void flash_f32_kernel(FlashArgs a) {
 // at one scene (4 heads x 8 query tiles) 256 workgroups instead of 128, i.e. the whole chip for this latency-bound pass.
 template <int DH, int DG>
 __global__ __launch_bounds__(256) void flash_merge_kernel(FlashArgs a) {
+    PARQ_TL_KERNEL(kTlFlashMerge);
     constexpr int kMergeDG = DG;
     constexpr int NG = 256 / (8 * DG);               // split groups
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -335,6 +336,7 @@ template <int DH>
 __global__ __launch_bounds__(512) void self_attn_kernel(const float* __restrict__ qkv, int64_t row_stride, int H, int L,
                                                         float* __restrict__ out, int64_t out_row, float* __restrict__ lse,
                                                         float drop_p, uint32_t drop_seed) {
+    PARQ_TL_KERNEL(kTlSelfAttn);
     constexpr int NW = 8;
     constexpr int NDT = DH / 16;                 // 16-wide d sub-tiles of O^T
     constexpr int NC = DH / 16;                  // float4 chunks of a Q / K row per lane
@@ -504,7 +506,7 @@ hipError_t launch_dh(const FlashArgs& a, int nw, hipStream_t s) {
 template <int DH>
 hipError_t merge_dh(const FlashArgs& a, hipStream_t s) {
     const size_t lds = ((size_t)a.nsplit * 32 + 8 * 32 + (size_t)2 * 16 * 32) * sizeof(float);
-    static const int dg_env = [] { const char* e = getenv("PARQ_MERGE_DG"); return e ? atoi(e) : 0; }();
+    static const int dg_env = [] { const char* e = dev_env("PARQ_MERGE_DG"); return e ? atoi(e) : 0; }();
     // 8 dims per workgroup while that is what it takes to cover the chip (one scene), else 16
     const int64_t wg16 = (int64_t)ceil_div(a.Lq, 32) * a.B * a.H * (DH / 16);
     const int dg = dg_env == 8 || dg_env == 16 ? dg_env : (wg16 < device_num_cus() ? 8 : 16);
@@ -612,5 +614,7 @@ hipError_t launch_flash_merge(const FlashArgs& a, hipStream_t s) {
         default: return merge_dh<256>(a, s);
     }
 }
+
+PARQ_TL_DEFINE_SETTER(tl_set_flash)
 
 }  // namespace parq

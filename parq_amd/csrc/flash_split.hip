@@ -218,6 +218,7 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 // four 16-byte groups; the normaliser stays undropped, 1 / (1 - p) is applied once to the partial output.
 template <int RING, int PROBE = 0, int TERMS = 3, int KIND = kF16, bool DROP = false>
 __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a, const _Float16* __restrict__ cache) {
+    PARQ_TL_KERNEL(kTlFlashSplit);
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];       // [RING stages][kStageBlks][block]
     constexpr int kBlkBytes = Blk<TERMS>::bytes;
     constexpr int kBlkHalfs = Blk<TERMS>::halfs;
@@ -690,10 +691,10 @@ hipError_t launch_kvsplit_to_f32(const void* cache, int B, int H, int N, float* 
 hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t s, int terms, int kind) {
     if (a.dh != kDH || a.nsplit < 1 || a.nsplit > 256) return hipErrorInvalidValue;
     FlashArgs b = a;
-    static const float defer = [] { const char* e = getenv("PARQ_DEFER_LOG2"); return e ? (float)atof(e) : kDeferLog2; }();   // debugging knob, read once
+    static const float defer = [] { const char* e = dev_env("PARQ_DEFER_LOG2"); return e ? (float)atof(e) : kDeferLog2; }();   // debugging knob, read once
     b.defer_log2 = defer;
-    static const int prio = [] { const char* e = getenv("PARQ_FLASH_PRIO"); return e ? atoi(e) : 0; }();
-    static const bool alt = [] { const char* e = getenv("PARQ_FLASH_ALTERNATE"); return !(e && e[0] == '0'); }();
+    static const int prio = [] { const char* e = dev_env("PARQ_FLASH_PRIO"); return e ? atoi(e) : 0; }();
+    static const bool alt = [] { const char* e = dev_env("PARQ_FLASH_ALTERNATE"); return !(e && e[0] == '0'); }();
     // bit 1 (set by the caller for every other recurrent iteration): sweep backwards — only for whole 64-key stages
     b.flags = (prio & 1) | ((alt && (a.flags & 2) && (a.Lk % (kStageBlks * kBlkKeys)) == 0) ? 2 : 0);
     const dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * b.H);
@@ -712,7 +713,8 @@ hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t
         if (drop) PARQ_PIPE_LAUNCH(4, 0, 1, kBF16, true) else PARQ_PIPE_LAUNCH(4, 0, 1, kBF16, false)
     }
     if (drop) PARQ_PIPE_LAUNCH(4, 0, 3, kF16, true)
-    static const int probe = [] { const char* e = getenv("PARQ_FLASH_PROBE"); return e ? atoi(e) : 0; }();   // development: see the kernel
+#ifdef PARQ_DEV_PROBES
+    static const int probe = [] { const char* e = dev_env("PARQ_FLASH_PROBE"); return e ? atoi(e) : 0; }();   // development: see the kernel
     switch (probe) {
         case 0: break;
         case 1: PARQ_PIPE_LAUNCH(4, 1, 3, kF16, false)
@@ -726,10 +728,13 @@ hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t
         case 31: PARQ_PIPE_LAUNCH(4, 31, 3, kF16, false)
         default: return hipErrorInvalidValue;
     }
-    static const int ring = [] { const char* e = getenv("PARQ_FLASH_RING"); return e && e[0] == '5' ? 5 : 4; }();
+#endif
+    static const int ring = [] { const char* e = dev_env("PARQ_FLASH_RING"); return e && e[0] == '5' ? 5 : 4; }();
     if (ring == 5) PARQ_PIPE_LAUNCH(5, 0, 3, kF16, false)
     PARQ_PIPE_LAUNCH(4, 0, 3, kF16, false)
 #undef PARQ_PIPE_LAUNCH
 }
+
+PARQ_TL_DEFINE_SETTER(tl_set_flash_split)
 
 }  // namespace parq

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(512) void kvproj_big_kernel(BigArgs a) {
 
 // scratch floats for the split tokens of launch_kvproj_big (0: the kernel does not apply to this shape)
 size_t kvproj_big_scratch_floats(int B, int N, int C) {
-    static const int minc = [] { const char* e = getenv("PARQ_KVPROJ_BIG_MINC"); return e ? atoi(e) : 257; }();     // experiment knob
+    static const int minc = [] { const char* e = dev_env("PARQ_KVPROJ_BIG_MINC"); return e ? atoi(e) : 257; }();     // experiment knob
     if (C < minc || C % 128 != 0) return 0;
     return (size_t)B * N * C;                                   // hi + lo fp16 = 4 bytes per element
 }

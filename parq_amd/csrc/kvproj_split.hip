@@ -280,6 +280,7 @@ __global__ __launch_bounds__(kThreads) void kvproj_split_kernel(KvProjArgs a) {
 // (MFMAs on whatever LDS holds), 3 no token DMA, 4 no epilogue at all
 template <int TM, int TERMS, int KIND, int NK, int D, int PROBE = 0>
 __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int total_rt, int nrt, int P) {
+    PARQ_TL_KERNEL(kTlKvProj);
     constexpr int NWV = 8;
     constexpr int kBlkH = TERMS == 3 ? 8192 : 4096;      // 16-bit units per 32-key cache block
     constexpr int kVoff = TERMS == 3 ? 4096 : 2048;      // V_hi offset inside a block
@@ -617,7 +618,8 @@ hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void*
     if (C <= 4 * kBK && C % (2 * kBK) == 0) {
         // W-stationary persistent kernel: one workgroup per CU, the column slices of one slot on one XCD
         if (terms != 3) return kind == kF16 ? launch_dma<1, kF16, 4>(a, B, s) : launch_dma<1, kBF16, 4>(a, B, s);
-        static const int probe = [] { const char* e = getenv("PARQ_KVPROJ_PROBE"); return e ? atoi(e) : 0; }();      // development
+#ifdef PARQ_DEV_PROBES
+        static const int probe = [] { const char* e = dev_env("PARQ_KVPROJ_PROBE"); return e ? atoi(e) : 0; }();      // development
         if (probe && C == 256) {
             switch (probe) {
                 case 1: return launch_dma_nk<64, 3, kF16, 4, 4, 1>(a, B, s);
@@ -630,7 +632,8 @@ hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void*
                 default: break;
             }
         }
-        static const int depth = [] { const char* e = getenv("PARQ_KVPROJ_RING"); return e ? atoi(e) : 4; }();       // 5: one more k-step in flight (no gain measured)
+#endif
+        static const int depth = [] { const char* e = dev_env("PARQ_KVPROJ_RING"); return e ? atoi(e) : 4; }();       // 5: one more k-step in flight (no gain measured)
         if (depth == 5 && C == 256) return launch_dma<3, kF16, 5>(a, B, s);
         return launch_dma<3, kF16, 4>(a, B, s);
     }
@@ -640,5 +643,7 @@ hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void*
     hipLaunchKernelGGL(kvproj_split_kernel, grid, dim3(kThreads), ldsb, s, a);
     return hipGetLastError();
 }
+
+PARQ_TL_DEFINE_SETTER(tl_set_kvproj_split)
 
 }  // namespace parq

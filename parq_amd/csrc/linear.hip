@@ -36,6 +36,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 template <int T, int CB>                            // CB: 16-wide K chunks held in registers per batch
 __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a) {
+    PARQ_TL_KERNEL(kTlLinear);
     constexpr int S = T / 16;                       // 16x16 sub-tiles per tile edge
     constexpr int OPT = T * T / (kWaves * kWave);   // outputs per thread in the epilogue (1 or 4)
     constexpr int TPR = T / OPT;                    // threads per output row
@@ -400,12 +401,12 @@ __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a
 // tile edge: 16 while the 32x32 tiling would leave CUs idle (the latency-bound single-scene case)
 static int pick_tile(int64_t tiles32) {
     static const int forced = [] {
-        const char* e = getenv("PARQ_LINEAR_TILE");
+        const char* e = dev_env("PARQ_LINEAR_TILE");
         return e ? atoi(e) : 0;
     }();
     if (forced == 16 || forced == 32) return forced;
     static const int below = [] {
-        const char* e = getenv("PARQ_LINEAR_T16_BELOW");
+        const char* e = dev_env("PARQ_LINEAR_T16_BELOW");
         return e ? atoi(e) : 0;
     }();
     return tiles32 < (below > 0 ? below : device_num_cus()) ? 16 : 32;
@@ -429,5 +430,7 @@ hipError_t launch_linear(const LinearArgs& a, int groups, hipStream_t s) {
         hipLaunchKernelGGL((linear_f32_kernel<16, 12>), grid, dim3(kWaves * kWave), 0, s, a);
     return hipGetLastError();
 }
+
+PARQ_TL_DEFINE_SETTER(tl_set_linear)
 
 }  // namespace parq

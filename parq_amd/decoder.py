@@ -234,6 +234,9 @@ class PARQDecoder(nn.Module):
         self._train_gen = 0               # bumped by every forward_train: an autograd node checks it still owns the stash
         self.loss_batched = True          # loss(): all (iteration, scene) pairs in ~40 launches (False: the reference's per-pair loop)
         self.dp_all_reduce = False        # True: backward() all-reduces the flat gradient arena over the default process group
+        self.backward_batched = True      # cross-attention backward of all iterations as one launch (False: per-iteration launches,
+                                          # the cross-check form; include/parq_hip.h parq_set_backward_batched)
+        self.max_workspaces = 2           # inference workspaces (each holds a K/V cache) kept alive, least recently used first out
         self._mean_dev = None
         # fp16-operand attention modes ("split", "fp16"): what to do when a token / K / V element leaves the fp16 range
         # (include/parq_hip.h: the device then writes NaN outputs instead of wrong numbers, and raises a flag).
@@ -289,10 +292,15 @@ class PARQDecoder(nn.Module):
             _lib.check(lib.parq_create(C.byref(cfg), C.byref(h)), "parq_create")
             self._h = h
             self._mode_set = None
+            self._bwd_batched_set = None
             self._train_ws = None
             # pinned host memory is mapped into the device address space under the same pointer (hipHostMalloc)
             self._range_mirror = torch.zeros(1, dtype=torch.int32).pin_memory()
             _lib.check(lib.parq_set_range_mirror(h, C.c_void_p(self._range_mirror.data_ptr())), "parq_set_range_mirror")
+        if self._bwd_batched_set != bool(self.backward_batched):
+            _lib.check(_lib.load().parq_set_backward_batched(self._h, int(bool(self.backward_batched))), "parq_set_backward_batched")
+            self._bwd_batched_set = bool(self.backward_batched)
+            self._train_ws = None                      # the training workspace is carved differently
         if apply_mode and self._mode_set != self.attention_mode:
             if self.attention_mode not in ATTENTION_MODES:
                 raise ValueError(f"attention_mode must be one of {sorted(ATTENTION_MODES)}")
@@ -368,15 +376,18 @@ class PARQDecoder(nn.Module):
         self._arena_key = key
 
     def _workspace(self, B, V, h, w, device):
+        """Workspace (K/V cache + activations) of a batch shape.  The ``max_workspaces`` most recently used shapes stay alive, so
+        a driver that alternates two shapes (e.g. train / validation snippets) does not reallocate a K/V cache per call."""
         k = (B, V, h, w, str(device))
-        ws = self._ws.get(k)
+        ws = self._ws.pop(k, None)
         if ws is None:
             nbytes = _lib.load().parq_workspace_bytes(self._handle(), B, V, h, w)
             if nbytes == 0:
                 raise RuntimeError("parq_workspace_bytes returned 0 for B=%d V=%d h=%d w=%d" % (B, V, h, w))
-            self._ws.clear()                          # one live workspace: it holds the K/V cache
+            while len(self._ws) >= max(1, int(self.max_workspaces)):
+                self._ws.pop(next(iter(self._ws)))    # dicts iterate in insertion order: the first key is the least recently used
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
-            self._ws[k] = ws
+        self._ws[k] = ws                              # (re-)insert as the most recently used
         return ws
 
     # ------------------------------------------------------------------ argument packing
@@ -460,24 +471,37 @@ class PARQDecoder(nn.Module):
     def forward_train(self, intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw=None):
         """Forward that keeps every iteration's activations for ``backward`` (attention arithmetic: ``_train_mode()``;
         dropout when the module is in train mode).  Returns the same list of dicts as ``forward``."""
+        self._range_poll()                     # BEFORE the mode of this step is chosen: a fallback must not split forward / backward
         sc, keep, dev = self._scene(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
         self._ensure_packed(dev)
-        lib, h = _lib.load(), self._handle_in_mode(self._train_mode())
+        lib = _lib.load()
         # decoder-layer dropout (train mode only, as nn.Dropout): a fresh mask seed per call, reused by backward()
         p_drop = float(self.dropout_rate) if self.training else 0.0
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
-        _lib.check(lib.parq_set_dropout(h, p_drop, seed), "parq_set_dropout")
-        nbytes = lib.parq_train_workspace_bytes(h, sc.B, sc.V, sc.h, sc.w)
-        if self._train_ws is None or self._train_ws.numel() * 4 < nbytes or self._train_ws.device != dev:
-            self._ws.clear()
-            self._train_ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=dev)
         outs = self._alloc_outputs((self.num_layers, sc.B, self.num_queries), dev)
         po = _lib.ParqOutputs(*[_lib.ptr(t) for t in outs])
-        _lib.check(lib.parq_forward_train(h, C.byref(sc), _lib.ptr(self._train_ws), self._train_ws.numel() * 4, C.byref(po),
-                                          _lib.stream_ptr()), "parq_forward_train")
-        self._train_state = (sc, keep, outs, po, dev)
+        for _attempt in range(2):
+            mode = self._train_mode()
+            h = self._handle_in_mode(mode)
+            _lib.check(lib.parq_set_dropout(h, p_drop, seed), "parq_set_dropout")
+            nbytes = lib.parq_train_workspace_bytes(h, sc.B, sc.V, sc.h, sc.w)
+            if self._train_ws is None or self._train_ws.numel() * 4 < nbytes or self._train_ws.device != dev:
+                self._ws.clear()
+                self._train_ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=dev)
+            _lib.check(lib.parq_forward_train(h, C.byref(sc), _lib.ptr(self._train_ws), self._train_ws.numel() * 4, C.byref(po),
+                                              _lib.stream_ptr()), "parq_forward_train")
+            # Training never lets a range violation reach the optimizer: the set loss synchronises with the host anyway (the
+            # matcher runs there), so the device flag is read here — one host sync per step — and a poisoned forward is re-run with
+            # the exact fp32 kernels (same dropout seed) before anything is returned.
+            if (self.range_check != "off" and mode in ("split", "fp16")
+                    and int(self._flag_view(self._train_ws, sc.B, sc.V, sc.h, sc.w).item()) != 0):
+                self._range_mirror[0] = 0
+                self._range_fallback("re-running this training forward")
+                continue
+            break
+        # the stash is laid out for `mode`: backward() uses exactly this mode, whatever attention_mode says by then
+        self._train_state = (sc, keep, outs, po, dev, mode)
         self._train_gen += 1
-        self._range_poll()
         return [{k: t[i] for k, t in zip(OUTPUT_KEYS, outs)} for i in range(self.num_layers)]
 
     @torch.no_grad()
@@ -487,8 +511,9 @@ class PARQDecoder(nn.Module):
         gradient}, d_tokens or None); gradients of tensors registered under two names are returned once per name."""
         if self._train_state is None:
             raise RuntimeError("backward() needs a preceding forward_train()")
-        sc, keep, outs, po, dev = self._train_state
-        lib, h = _lib.load(), self._handle_in_mode(self._train_mode())
+        sc, keep, outs, po, dev, mode = self._train_state
+        # the mode the stash was written in (forward_train), not whatever attention_mode says now: the workspace layout differs
+        lib, h = _lib.load(), self._handle_in_mode(mode)
         gs = []
         for key, wd in (("pred_logits", self.num_semcls + 1), ("center_unnormalized", 3), ("size_unnormalized", 3), ("ortho6d", 6)):
             g = grad_outputs.get(key)
@@ -550,7 +575,7 @@ class PARQDecoder(nn.Module):
         building the 16-bit K/V cache (synchronises; meaningful in the "split" and "fp16" modes).  Outputs of such a call are
         NaN by construction (include/parq_hip.h); see ``range_check`` for the automatic handling."""
         if self._ws:
-            (B, V, h, w, _), ws = next(iter(self._ws.items()))
+            (B, V, h, w, _), ws = list(self._ws.items())[-1]        # the most recently used workspace
         elif self._train_ws is not None and self._train_state is not None:
             sc = self._train_state[0]
             (B, V, h, w), ws = (sc.B, sc.V, sc.h, sc.w), self._train_ws
@@ -626,6 +651,14 @@ class PARQDecoder(nn.Module):
         out["pred_corners_world"] = Pose(raw(T_world_local)).transform(obbs.T_world_object.transform(obbs.bb3corners_object))
         for calc in self.metrics_calculator:
             calc.step(out, targets)
+
+    def log_images(self, out_dict, obbs_padded, Ts_world_pseudoCam, Ts_world_local, T_camera_pseudoCam, rgb_img=None, calib_rgb=None,
+                   slaml_img=None, calib_slaml=None, slamr_img=None, calib_slamr=None):
+        """model/parq_decoder.py:470-538 draws predicted / ground-truth boxes into the input images (cv2, utils/parq_utils.py:108-225)
+        for TensorBoard; called from parq_lightning.py:280 (``get_log_images``).  Visualisation is outside this path's scope
+        (SURVEY.md §2): same name, same argument list, an empty dict of images, so that a reference-style driver with image logging
+        switched on keeps running instead of hitting AttributeError."""
+        return {}
 
     def compute_metrics(self):
         metrics = {}

@@ -86,18 +86,26 @@ def all_reduce_mean_(flat: torch.Tensor) -> torch.Tensor:
 def all_reduce_mean_scalars(metrics: dict, device=None) -> dict:
     """Mean over ranks of a dict of host scalars — what Lightning's ``self.log(..., sync_dist=True)`` does with the
     validation metrics (model/parq_lightning.py:133-140).  Non-scalar entries (arrays, images) pass through untouched, as
-    the reference skips them; every rank must call this with the same keys.  Identity without a process group."""
+    the reference skips them.  Ranks may hold DIFFERENT key sets (a rank that saw no valid scene returns fewer metrics): the key
+    lists are gathered first, the reduction runs over their sorted union, and a key is averaged over the ranks that hold it —
+    a rank without a key neither hangs the collective nor drags the mean towards zero.  Identity without a process group."""
     import numbers
-    keys = sorted(k for k, v in metrics.items() if isinstance(v, numbers.Number) and not isinstance(v, bool))
-    if not keys or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    mine = sorted(k for k, v in metrics.items() if isinstance(v, numbers.Number) and not isinstance(v, bool))
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return dict(metrics)
+    gathered = [None] * dist.get_world_size()
+    dist.all_gather_object(gathered, mine)
+    keys = sorted(set().union(*[set(g) for g in gathered]))
+    if not keys:
         return dict(metrics)
     if device is None:
         device = (torch.device("cuda", torch.cuda.current_device())
                   if dist.get_backend() == "nccl" and torch.cuda.is_available() else "cpu")
-    t = torch.tensor([float(metrics[k]) for k in keys], dtype=torch.float64, device=device)
+    have = set(mine)
+    t = torch.tensor([[float(metrics[k]) if k in have else 0.0 for k in keys], [1.0 if k in have else 0.0 for k in keys]],
+                     dtype=torch.float64, device=device)
     dist.all_reduce(t)
-    t /= dist.get_world_size()
     out = dict(metrics)
-    for k, v in zip(keys, t.tolist()):
-        out[k] = v
+    for k, total, count in zip(keys, t[0].tolist(), t[1].tolist()):
+        out[k] = total / count                    # count >= 1: the key came from somebody's list
     return out

@@ -307,7 +307,7 @@ def test_dropout_forward_backward_match_masked_oracle(h, w, Hh, dim):
 def test_batched_cross_attention_backward_equals_per_iteration_launches(monkeypatch, pdrop):
     """Training backward with shared layer weights: the cross-attention backward of all iterations as ONE launch (dK / dV
     accumulated in registers, written once) against the per-iteration launches that read-modify-write dK / dV
-    (PARQ_BWD_BATCHED=0).  Same stash, same dropout streams; only summation order and the power-of-two dO scale differ."""
+    (``backward_batched = False``: parq_set_backward_batched).  Same stash, same dropout streams; only summation order and the power-of-two dO scale differ."""
     B, V, h, w, Q, heads, dim, ffn, I = 2, 3, 32, 40, 40, 2, 128, 96, 4
     cfg = synth.decoder_cfg(dim=dim, queries=Q, heads=heads, ffn=ffn, layers=I, dropout=pdrop)
     W = synth.make_decoder_weights(cfg, 171)
@@ -317,8 +317,8 @@ def test_batched_cross_attention_backward_equals_per_iteration_launches(monkeypa
             "size_unnormalized": synth.normal(175, "cs", (I, B, Q, 3)), "ortho6d": synth.normal(176, "cr", (I, B, Q, 6))}
     res = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("PARQ_BWD_BATCHED", mode)
         dec = make_decoder(cfg, W).train()
+        dec.backward_batched = mode == "1"
         torch.manual_seed(99)                                     # the dropout seed of forward_train comes from torch's generator
         dec.forward_train(*scene_args(sc))
         grads, d_tok = dec.backward({k: torch.from_numpy(v) for k, v in cots.items()})
@@ -349,8 +349,8 @@ def test_backward_at_baseline_cfg3_size_batched_equals_per_iteration(monkeypatch
             "size_unnormalized": synth.normal(275, "cs", (I, 1, Q, 3)), "ortho6d": synth.normal(276, "cr", (I, 1, Q, 6))}
     res = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("PARQ_BWD_BATCHED", mode)
         dec = make_decoder(cfg, W).train()
+        dec.backward_batched = mode == "1"
         torch.manual_seed(7)
         dec.forward_train(*scene_args(sc), feat_hw=(h, w))
         grads, d_tok = dec.backward({k: torch.from_numpy(v) for k, v in cots.items()})

@@ -53,6 +53,11 @@ def _worker(rank, world, port, q):
     synced = parallel.all_reduce_mean_scalars({"0.25_f1": 0.2 + 0.4 * rank, "0.5_f1": float(rank), "curve": np.arange(3) + rank})
     assert abs(synced["0.25_f1"] - 0.4) < 1e-12 and abs(synced["0.5_f1"] - 0.5) < 1e-12
     assert np.array_equal(synced["curve"], np.arange(3) + rank)
+    # ranks with DIFFERENT key sets (rank 1 saw no valid scene: compute_metrics returned nothing; rank 0 has a key rank 1 lacks):
+    # no hang, no mismatched entries — a key is averaged over the ranks that hold it
+    ragged = parallel.all_reduce_mean_scalars({"0.25_f1": 0.8, "only_rank0": 3.0, "shared": 1.0} if rank == 0 else {"shared": 2.0})
+    assert abs(ragged["0.25_f1"] - 0.8) < 1e-12 and abs(ragged["only_rank0"] - 3.0) < 1e-12 and abs(ragged["shared"] - 1.5) < 1e-12
+    assert parallel.all_reduce_mean_scalars({}) == {}                 # every rank empty: nothing to reduce, still no hang
     q.put((rank, (lo, hi), full_ctr.numpy(), full_logits.numpy(), slowest))
     parallel.barrier()
     torch.distributed.destroy_process_group()
