@@ -125,23 +125,65 @@ def project_sample_b32(dec, device, h, w, scenes=32, steps=2):
                     "(roofline_project_sample) is latency-bound" % (scenes, scenes * V * h * w * C * 4 / 1e9)}
 
 
-def device_state_under_load(step, seconds=1.0):
-    """Socket power and shader clock (rocm-smi) sampled while the forward loops back to back — the two big kernels of this path run
-    at the 1400 W cap with the clock throttled below 2.4 GHz (profiles/r02_power_rocm_smi.txt), which is what
-    `roofline.frac` against the nominal peak has to be read with.  Best effort: null when rocm-smi is not usable."""
-    import subprocess
+def _amdgpu_sysfs(index):
+    """(hwmon power file, shader-clock file) of the amdgpu device behind cuda:`index`, or (None, None).  Plain sysfs reads: nothing
+    is spawned (a child started from a GPU-initialised process under rocprofv3 --pmc inherits the profiler preload)."""
+    import glob
+    cards = []
+    for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        try:
+            with open(os.path.join(d, "vendor")) as f:
+                if f.read().strip() != "0x1002":
+                    continue
+        except OSError:
+            continue
+        cards.append(d)
+    if not cards:
+        return None, None
+    visible = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or ""
+    try:
+        phys = int(visible.split(",")[index]) if visible else index
+    except (ValueError, IndexError):
+        phys = index
+    d = cards[phys] if phys < len(cards) else cards[0]
+    power = None
+    for name in ("power1_average", "power1_input"):
+        hits = glob.glob(os.path.join(d, "hwmon", "hwmon*", name))
+        if hits:
+            power = hits[0]
+            break
+    sclk = os.path.join(d, "pp_dpm_sclk")
+    return power, (sclk if os.path.exists(sclk) else None)
+
+
+def device_state_under_load(step, seconds=1.0, index=0):
+    """Socket power and shader clock sampled from sysfs (hwmon power1_average, pp_dpm_sclk) while the forward loops back to back —
+    the two big kernels of this path run at the 1400 W cap with the clock throttled below 2.4 GHz (DESIGN.md section 4,
+    profiles/r02_power_rocm_smi.txt), which is what `roofline.frac` against the nominal peak has to be read with.  Best effort:
+    null when the files are not readable.  In-process reads only — no child process is ever started here."""
     import threading
+    power_f, sclk_f = _amdgpu_sysfs(index)
+    if power_f is None and sclk_f is None:
+        return None
     samples, stop = [], [False]
 
     def sampler():
         while not stop[0]:
+            mhz = watts = None
             try:
-                out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--csv"], capture_output=True, text=True, timeout=5).stdout
-                row = out.strip().split("\n")[-1].split(",")
-                samples.append((int(row[5].strip("()Mhz")), float(row[-1])))
-            except Exception:           # noqa: any parsing / availability problem -> no sample
+                if sclk_f:
+                    with open(sclk_f) as f:
+                        for line in f:
+                            if "*" in line:
+                                mhz = float(line.split(":")[1].strip().rstrip("*").strip().lower().replace("mhz", ""))
+                if power_f:
+                    with open(power_f) as f:
+                        watts = float(f.read().strip()) * 1e-6
+            except (OSError, ValueError, IndexError):
                 pass
-            time.sleep(0.05)
+            if mhz is not None or watts is not None:
+                samples.append((mhz, watts))
+            time.sleep(0.02)
 
     th = threading.Thread(target=sampler)
     th.start()
@@ -155,8 +197,10 @@ def device_state_under_load(step, seconds=1.0):
     late = samples[len(samples) // 2:]
     if not late:
         return None
-    return {"sclk_mhz": sum(x[0] for x in late) / len(late), "socket_power_w": sum(x[1] for x in late) / len(late), "samples": len(late),
-            "note": "rocm-smi while the forward loops back to back; nominal shader clock 2400 MHz, socket cap 1400 W"}
+    mean = lambda xs: (sum(xs) / len(xs)) if xs else None
+    return {"sclk_mhz": mean([x[0] for x in late if x[0] is not None]), "socket_power_w": mean([x[1] for x in late if x[1] is not None]),
+            "samples": len(late), "source": "sysfs (pp_dpm_sclk, hwmon power1_average), read in-process",
+            "note": "sampled while the forward loops back to back; nominal shader clock 2400 MHz, socket cap 1400 W"}
 
 
 def pmc_traffic(kernel, scenes):
@@ -208,9 +252,9 @@ def train_bench(args):
     metric (which stays the inference number); dropout 0.1 as in config/train.yaml, exact-fp32 attention kernels."""
     from parq_amd import Obb3D, PARQDecoder, Pose, parallel, synth
     rank, local_rank, world = parallel.env_world()
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    parallel.init(backend="nccl" if world > 1 else None, device=device)
+    device, backend = rank_device_and_backend(args, local_rank, world)
+    parallel.init(backend=backend, device=device)
+    red_dev = device if backend == "nccl" else None
     B = args.scenes_per_gpu if args.scenes_per_gpu > 1 else 4
     V, (h, w), Q, C, I = WORKLOAD["views"], WORKLOAD["feat_hw"], WORKLOAD["queries"], WORKLOAD["dim"], WORKLOAD["iters"]
     cfg = synth.decoder_cfg(dim=C, queries=Q, heads=WORKLOAD["heads"], ffn=WORKLOAD["ffn"], layers=I, dropout=0.1)   # config/train.yaml:53
@@ -242,12 +286,14 @@ def train_bench(args):
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize(); parallel.barrier(); torch.cuda.synchronize()
-    dt = parallel.max_over_ranks(time.perf_counter() - t0, device=device)
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, device=red_dev)
     if rank == 0:
         print(json.dumps({
-            "metric": "training steps/sec (decoder forward + set loss + HIP backward + gradient all-reduce + AdamW)",
+            "metric": "training steps/sec (decoder forward + set loss + HIP backward + gradient all-reduce + AdamW)"
+                      + (" [development library or PARQ_* set: not a headline]" if (args.dev_lib or parq_env()) else ""),
             "value": args.steps / dt, "unit": "steps/sec", "scenes_per_sec": args.steps * B * world / dt,
-            "n_gpus": world, "rccl_ranks": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "collective_backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
+            "parq_env": parq_env(), "dev_lib": bool(args.dev_lib), "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "final_loss": float(loss.detach()),
             "config": {"workload": "BASELINE cfg4 per-GPU shard: %d scenes, 10 views 480x640 (120x160 features), 256 queries, 8 iterations, "
@@ -258,15 +304,31 @@ def train_bench(args):
         torch.distributed.destroy_process_group()
 
 
-def self_launch(n):
+def parq_env():
+    """Every PARQ_* variable of this process.  The product library reads none of them (only the -DPARQ_DEV_PROBES build does), but
+    the line records them and a run with any of them set — or with --dev-lib — is marked as not a headline number."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("PARQ_")}
+
+
+def rank_device_and_backend(args, local_rank, world):
+    """One GPU per rank over RCCL ("nccl"); with --share-device (fewer GPUs than ranks) every rank sits on cuda:0 and the group
+    runs over gloo.  Returns (device, backend or None for a single process)."""
+    if world > 1 and args.share_device and torch.cuda.device_count() < world:
+        torch.cuda.set_device(0)
+        return torch.device("cuda", 0), "gloo"
+    torch.cuda.set_device(local_rank)
+    return torch.device("cuda", local_rank), ("nccl" if world > 1 else None)
+
+
+def self_launch(n, share_device=False):
     """`python bench.py --gpus N` typed without a launcher: start N fresh ranks (one per GPU, RCCL rendezvous on
     127.0.0.1) as CHILD processes of this one, which has not initialised the GPU (no HIP call, no torch.cuda query
     besides device_count), and exit with the launcher's code.  Rank 0's JSON line is the child's stdout."""
     import socket
     import subprocess
     have = torch.cuda.device_count()                     # does not initialise the runtime on this image
-    if have < n:
-        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (n, have))
+    if have < n and not (share_device and have >= 1):
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (add --share-device to run the rank path on one GPU)" % (n, have))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -290,6 +352,10 @@ def main():
                     help="cross-attention arithmetic; default = the library default (split: fp32-class accuracy). "
                          "fp16 / bf16 are the reduced-precision configurations (NOT the headline number)")
     ap.add_argument("--train", action="store_true", help="time the training step of BASELINE config 4's per-GPU shard instead")
+    ap.add_argument("--dev-lib", action="store_true", help="development only: bind parq_amd/_C/libparq_hip_dev.so (-DPARQ_DEV_PROBES: "
+                    "environment A/B switches and probe kernels); the line is then marked as NOT a headline number")
+    ap.add_argument("--share-device", action="store_true", help="N > 1 on a box with fewer than N GPUs: every rank uses cuda:0 and the "
+                    "process group runs over gloo — exercises the rank path (sharding, barrier, max over ranks), not a scaling number")
     ap.add_argument("--dim", type=int, default=256, help="decoder width; 256 = the BASELINE metric (default).  1024 = the reference's "
                     "shipped DEC_DIM (head dim 256): reported beside the headline, NOT the BASELINE metric")
     args = ap.parse_args()
@@ -297,7 +363,10 @@ def main():
     if args.dim != 256:
         args.no_cpu_baseline = True                     # the bounded CPU sample is sized for the headline configuration
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(self_launch(args.gpus))
+        sys.exit(self_launch(args.gpus, args.share_device))
+    if args.dev_lib:
+        from parq_amd import _lib
+        _lib.use_dev_library()
     if args.train:
         return train_bench(args)
 
@@ -306,9 +375,9 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    parallel.init(backend="nccl" if world > 1 else None, device=device)      # "nccl" is RCCL on ROCm
+    device, backend = rank_device_and_backend(args, local_rank, world)
+    parallel.init(backend=backend, device=device)                             # "nccl" is RCCL on ROCm
+    red_dev = device if backend == "nccl" else None                           # gloo reduces host scalars on the host
 
     B = args.scenes_per_gpu
     I = WORKLOAD["iters"]
@@ -338,7 +407,19 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    dt = parallel.max_over_ranks(time.perf_counter() - t0, device=device)
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, device=red_dev)
+
+    # ---- per-step times from hipEvents on the launch stream (median of >= 20 runs); the wall-clock mean above stays
+    # the contract's `value`, this is its cross-check and its spread
+    n_ev = max(20, args.steps)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev + 1)]
+    evs[0].record()
+    for i in range(n_ev):
+        step()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n_ev))
+    pct = lambda q: step_ms[min(n_ev - 1, int(q * n_ev))]
 
     # ---- per-kernel-group times: hipEvents recorded by the library on the launch stream
     dec.profile_enable(True)
@@ -381,11 +462,33 @@ def main():
                                   % PEAK_F32_MATRIX_TFLOPS) if split else "dense fp16/bf16 MFMA peak" if half else "fp32 MFMA peak",
                     "hbm_stream_gbs": (kv_bytes / (ca_ms / ca_n * 1e-3) / 1e9) if ca_n else None,
                     "note": "launch time from hipEvents around this kernel alone (its merge kernel is group cross_attn_merge)"}
+        not_headline = bool(args.dev_lib or parq_env())
+        kv_ms, kv_n = prof["kv_proj"]
+        kvp_bytes = 3.0 * N * C * 4.0 * B if not half else (N * C * 4.0 + 2.0 * N * C * 2.0) * B     # tokens in, K and V out
+        roofline["hbm_frac"] = (roofline["hbm_stream_gbs"] / PEAK_HBM_GBS) if roofline["hbm_stream_gbs"] else None
+        roofline["traffic_source"] = "recorded: profiles/r02_pmc.json (rocprofv3 --pmc passes of the same command), not measured in this run"
+        roofline_kv = {"bound": "hbm", "kernel": "kvproj_dma_kernel (hoisted K/V in-projection, once per forward)",
+                       "achieved": (kvp_bytes / (kv_ms / kv_n * 1e-3) / 1e9) if kv_n else None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                       "frac": (kvp_bytes / (kv_ms / kv_n * 1e-3) / 1e9 / PEAK_HBM_GBS) if kv_n else None,
+                       "traffic": pmc_traffic("kvproj_dma_kernel", B), "traffic_source": "recorded: profiles/r02_pmc.json, or null",
+                       "algorithmic_bytes_per_launch": kvp_bytes, "avg_launch_ms": (kv_ms / kv_n) if kv_n else None, "launches": kv_n,
+                       "streaming_ceiling_ms": kvp_bytes / 5.6e12 * 1e3,
+                       "note": "reads N*C fp32 tokens, writes the K and V cache images; a plain streaming kernel with this 1:2 read/write "
+                               "shape reaches 5.6 TB/s on MI355X (profiles/r02_hbm_stream_ceiling.txt); also 4*N*C^2 = %.1f GFLOP x 3 "
+                               "fp16 passes on the matrix pipe" % (4.0 * N * C * C * B / 1e9)}
         out = {
-            "metric": "decoder-iterations/sec (10 views, 256 queries, d=%d)%s" % (C, "" if C == 256 else " [not the BASELINE metric: non-default --dim]"),
+            "metric": "decoder-iterations/sec (10 views, 256 queries, d=%d)%s%s" % (
+                C, "" if C == 256 else " [not the BASELINE metric: non-default --dim]",
+                " [development library or PARQ_* set: not a headline]" if not_headline else ""),
             "value": total_iters / dt, "unit": "decoder-iterations/sec",
-            "n_gpus": world, "rccl_ranks": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": PREWARM_STEPS,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "collective_backend": backend, "rccl_ranks": world if backend == "nccl" else (1 if world == 1 else 0),
+            "parq_env": parq_env(), "dev_lib": bool(args.dev_lib),
+            "steps": args.steps, "warmup": args.warmup, "prewarm_steps": PREWARM_STEPS,
+            "ms_per_step": dt / args.steps * 1e3,
+            "step_ms_hipevents": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": step_ms[0], "n": n_ev,
+                                  "iterations_per_sec_at_median": B * I / (pct(0.5) * 1e-3),
+                                  "note": "rank 0, one hipEvent pair per forward on the launch stream; `value` is the contract's wall-clock figure"},
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": ("f32 (cross-attention and K/V projection as fp16 hi/lo split products with fp32 accumulation)" if split
                                           else "%s cross-attention and K/V projection operands, fp32 accumulation, fp32 elsewhere (reduced precision: not the headline configuration)" % mode if half
                                           else "f32"),
@@ -394,6 +497,7 @@ def main():
                                    "256 queries, 8 iterations, d=%d, 4 heads, FFN 768, ResNet-FPN-shaped synthetic features" % C,
                        "scenes_per_gpu": B, "parallelism": "dp%d (scene-sharded, no data-path collective)" % world},
             "roofline": roofline,
+            "roofline_kv_proj": roofline_kv,
             "roofline_project_sample": {"bound": "hbm", "kernel": "project_sample_kernel", "scenes": B,
                                         "achieved": ps_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                         "frac": (ps_gbs / PEAK_HBM_GBS) if ps_gbs else None,
@@ -408,7 +512,7 @@ def main():
         if C == 256:
             out["ray_pe"] = ray_pe_timing(B, device)
         if world == 1:
-            out["device_state_under_load"] = device_state_under_load(step)
+            out["device_state_under_load"] = device_state_under_load(step, index=local_rank)
         if world == 1 and C == 256 and B == 1 and not args.no_b32:
             out["roofline_project_sample_b32"] = project_sample_b32(dec, device, h, w)
         if world == 1 and not args.no_cpu_baseline:

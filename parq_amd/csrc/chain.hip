@@ -1,0 +1,313 @@
+// Specialised small GEMMs of the per-iteration chain at one (or a few) scenes:  Y = act(pro(X) @ W^T + b) (+ R)
+//
+// Same arithmetic, same tiling idea and the same summation order as linear_f32_kernel (linear.hip) — 16-row tiles, 4 waves that
+// split K round-robin in 16-wide chunks, exact fp32 v_mfma_f32_16x16x4_f32 with row-contiguous float4 operand loads — but every
+// property the generic kernel tests at run time (K, the prologue, the addend, bias / ReLU / residual kind, GroupNorm moments,
+// bounds) is a template parameter here.  Why: the chain is latency-bound and a load under a run-time branch costs a full memory
+// round trip — hipcc cannot count outstanding loads across the join points and waits vmcnt(0) at each of them (the generic
+// 256^3 kernel spends 3.0 us in its body where the bare tile of tools/bench_src/chain_seam.hip takes 1.3, profiles/
+// r03_iter_timeline_stamped_before.txt).  Here a workgroup issues EVERY global load it will ever need — operands, prologue
+// parameters, row statistics, scene moments, bias, residual — in straight-line code before the first wait, so a launch is one round
+// trip + one MFMA chain + one LDS reduction + the stores.
+//   * a workgroup owns 16 rows x (16 NT) columns: NT column sub-tiles share the A fragments (N = 768 / 528 launches fit the chip
+//     with <= 256 .. 384 workgroups instead of 768 / 528);
+//   * epilogue: wave t finishes sub-tile t with one float4 per lane (16 rows x 64 bytes per store instruction);
+//   * GroupNorm moments of the output: one fp64 atomic pair per sub-tile wave (no workgroup reduction, no extra barrier).
+// launch_linear (linear.hip) routes here when the shape qualifies (chain_linear_supported) and keeps the generic kernel for
+// everything else (ragged shapes, ReLU masks of the backward, dropout, head-major output scatter, many scenes).
+#include "common.hpp"
+
+namespace parq {
+
+namespace {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+enum : int { kProNone = 0, kProLN = 1, kProGN = 2 };
+enum : int { kResNone = 0, kResPlain = 1, kResLN = 2 };
+
+template <int K, int NT, int PRO, bool ADD2, bool BIAS, bool RELU, int RES, bool GNOUT>
+__global__ __launch_bounds__(256) void chain_linear_kernel(LinearArgs a) {
+    PARQ_TL_KERNEL(kTlLinear);
+    static_assert(K % 64 == 0 && NT >= 1 && NT <= 4, "tile shape");
+    constexpr int NCH = K / 64;                       // 16-wide K chunks per wave
+    __shared__ __attribute__((aligned(16))) float red[4 * NT * 4 * 64];   // [wave][sub-tile][acc reg][lane]
+    __shared__ float lnred[4 * 16 * 2];
+
+    const int g = blockIdx.y;
+    const int ntn = a.N / (16 * NT);
+    int n0, m0;
+    if (a.tile_map == 0) {                            // column tiles fastest: XCD x (= blockIdx % 8) reads all of X and 1/8 of W
+        n0 = (int)(blockIdx.x % ntn) * 16 * NT;
+        m0 = (int)(blockIdx.x / ntn) * 16;
+    } else {                                          // a row block's column tiles on one XCD: XCD x reads 1/8 of X and all of W
+        const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        n0 = (loc % ntn) * 16 * NT;
+        m0 = (x * (a.M / 128) + loc / ntn) * 16;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    const int kbase = wave * 16 + kq * 4;             // lane's float4 of its c-th chunk sits at kbase + 64 c
+
+    const float* xrow = a.X + g * a.gX + (int64_t)(m0 + li) * a.ldx + kbase;
+    const float* wbase = a.W + g * a.gW + (int64_t)(n0 + li) * a.ldw + kbase;
+
+    // ---------------- every global load of the workgroup, before anything waits
+    f32x4v av[NCH], bv[NT][NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) av[c] = *reinterpret_cast<const f32x4v*>(xrow + c * 64);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) bv[t][c] = *reinterpret_cast<const f32x4v*>(wbase + (int64_t)t * 16 * a.ldw + c * 64);
+    f32x4v x2v[ADD2 ? NCH : 1];
+    if constexpr (ADD2) {
+        const float* x2row = a.X2 + (int64_t)(m0 + li) * a.ldx2 + kbase;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) x2v[c] = *reinterpret_cast<const f32x4v*>(x2row + c * 64);
+    }
+    f32x4v pg[PRO != kProNone ? NCH : 1], pb[PRO != kProNone ? NCH : 1];
+    float shift = 0.f;
+    double gsm = 0.0, gsq = 0.0;
+    if constexpr (PRO == kProLN) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            pg[c] = *reinterpret_cast<const f32x4v*>(a.ln_gamma + kbase + c * 64);
+            pb[c] = *reinterpret_cast<const f32x4v*>(a.ln_beta + kbase + c * 64);
+        }
+        shift = a.X[g * a.gX + (int64_t)(m0 + li) * a.ldx];
+    }
+    if constexpr (PRO == kProGN) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            pg[c] = *reinterpret_cast<const f32x4v*>(a.gn_gamma + g * a.gGamma + kbase + c * 64);
+            pb[c] = *reinterpret_cast<const f32x4v*>(a.gn_beta + g * a.gGamma + kbase + c * 64);
+        }
+        const double* src = a.gn_sums + ((int64_t)((m0 / a.gn_rows_per_scene) * a.gn_ngroups + g) * kGnSlots + lane) * 2;
+        gsm = src[0];
+        gsq = src[1];
+    }
+    // epilogue operands: wave t finishes sub-tile t (waves >= NT request the operands of sub-tile wave % NT and drop them)
+    const int et = wave % NT;
+    const int erow = lane >> 2, ec = (lane & 3) * 4;
+    const int om = m0 + erow, on = n0 + et * 16 + ec;
+    f32x4v e_bias = {0.f, 0.f, 0.f, 0.f}, e_r = {0.f, 0.f, 0.f, 0.f}, e_rg = {1.f, 1.f, 1.f, 1.f}, e_rb = {0.f, 0.f, 0.f, 0.f};
+    float rmean = 0.f, rrstd = 1.f;
+    if constexpr (BIAS) e_bias = *reinterpret_cast<const f32x4v*>(a.bias + g * a.gBias + on);
+    if constexpr (RES != kResNone) e_r = *reinterpret_cast<const f32x4v*>(a.R + (int64_t)om * a.ldr + on);
+    if constexpr (RES == kResLN) {
+        e_rg = *reinterpret_cast<const f32x4v*>(a.rln_gamma + on);
+        e_rb = *reinterpret_cast<const f32x4v*>(a.rln_beta + on);
+        rmean = a.rln_stats[(int64_t)om * 2 + 0];
+        rrstd = a.rln_stats[(int64_t)om * 2 + 1];
+    }
+    // the machine scheduler otherwise sinks the loads next to their uses (4 in flight, the epilogue operands after the MFMAs =
+    // a second round trip): nothing moves across this point
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---------------- prologue on A
+    if constexpr (PRO == kProLN) {
+        // row statistics over the full K: one pass over data shifted by the row's first element, reduced across the 4 kq lane
+        // groups (shuffles) and the 4 K-slices (LDS) — the order linear_f32_kernel uses
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = av[c][e] - shift;
+                sm += d;
+                sq += d * d;
+            }
+        sm += __shfl_xor(sm, 16); sq += __shfl_xor(sq, 16);
+        sm += __shfl_xor(sm, 32); sq += __shfl_xor(sq, 32);
+        if (kq == 0) { lnred[(wave * 16 + li) * 2 + 0] = sm; lnred[(wave * 16 + li) * 2 + 1] = sq; }
+        lds_barrier();
+        float Ssum = 0.f, Q2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { Ssum += lnred[(w * 16 + li) * 2 + 0]; Q2 += lnred[(w * 16 + li) * 2 + 1]; }
+        const float invK = 1.f / (float)K;
+        const float dm = Ssum * invK;
+        const float mean = shift + dm;
+        const float var = fmaxf(Q2 * invK - dm * dm, 0.f);
+        const float rstd = 1.f / sqrtf(var + a.norm_eps);
+        if (a.ln_stats_out && n0 == 0 && wave == 0 && kq == 0) {
+            a.ln_stats_out[(int64_t)(m0 + li) * 2 + 0] = mean;
+            a.ln_stats_out[(int64_t)(m0 + li) * 2 + 1] = rstd;
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[c][e] = (av[c][e] - mean) * rstd * pg[c][e] + pb[c][e];
+    }
+    if constexpr (ADD2) {
+        if (n0 < a.x2_ncols) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) av[c] += x2v[c];
+        }
+    }
+    if constexpr (PRO == kProGN) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { gsm += __shfl_xor(gsm, o); gsq += __shfl_xor(gsq, o); }
+        float mean, rstd;
+        gn_mean_rstd(gsm, gsq, 1.0 / ((double)a.gn_rows_per_scene * (double)K), a.norm_eps, mean, rstd);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float y = (av[c][e] - mean) * rstd * pg[c][e] + pb[c][e];
+                av[c][e] = y > 0.f ? y : 0.f;
+            }
+    }
+
+    // ---------------- MFMA chains (one per sub-tile), split-K partials to LDS
+    f32x4v acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][e], bv[t][c][e], acc[t], 0, 0, 0);
+    // acc[t][r]: row 4 * (lane >> 4) + r, column lane & 15 of sub-tile t
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * NT + t) * 4 + r) * 64 + lane] = acc[t][r];
+    lds_barrier();
+    if (wave >= NT) return;
+
+    // ---------------- epilogue of sub-tile `wave`: lane -> (row = lane >> 2, 4 consecutive columns)
+    const int src = (wave * 4 + (erow & 3)) * 64 + (erow >> 2) * 16 + ec;
+    f32x4v sum = *reinterpret_cast<const f32x4v*>(&red[src]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) sum += *reinterpret_cast<const f32x4v*>(&red[src + w * NT * 256]);
+    f32x4v y;
+    double gs = 0.0, gq = 0.0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v = sum[e] + e_bias[e];
+        if constexpr (RELU) v = v > 0.f ? v : 0.f;
+        if constexpr (RES == kResPlain) v += e_r[e];
+        if constexpr (RES == kResLN) v += (e_r[e] - rmean) * rrstd * e_rg[e] + e_rb[e];
+        y[e] = v;
+        if constexpr (GNOUT) { gs += (double)v; gq += (double)v * (double)v; }
+    }
+    *reinterpret_cast<f32x4v*>(a.Y + g * a.gY + (int64_t)om * a.y_row + on) = y;
+    if constexpr (GNOUT) {
+        const int nt0 = n0 + wave * 16;                     // first column of this sub-tile
+        if (nt0 < a.gn_out_ncols) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { gs += __shfl_xor(gs, o); gq += __shfl_xor(gq, o); }
+            if (lane == 0) {
+                const int grp = (nt0 + g * a.N) / a.gn_out_group_cols;
+                const int slot = (int)((blockIdx.x * NT + wave) % kGnSlots);
+                double* dst = a.gn_out_sums + (((int64_t)(m0 / a.gn_out_rows_per_scene) * a.gn_out_ngroups + grp) * kGnSlots + slot) * 2;
+                atomicAdd(dst, gs);
+                atomicAdd(dst + 1, gq);
+            }
+        }
+    }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// feature signature of a launch (what the template parameters must match)
+struct Sig { int K, pro; bool add2, bias, relu; int res; bool gnout; };
+
+Sig sig_of(const LinearArgs& a) {
+    Sig s;
+    s.K = a.K;
+    s.pro = a.ln_gamma ? kProLN : (a.gn_sums ? kProGN : kProNone);
+    s.add2 = a.X2 != nullptr;
+    s.bias = a.bias != nullptr;
+    s.relu = a.relu != 0;
+    s.res = a.R ? (a.rln_stats ? kResLN : kResPlain) : kResNone;
+    s.gnout = a.gn_out_sums != nullptr;
+    return s;
+}
+
+template <int K, int NT, int PRO, bool ADD2, bool BIAS, bool RELU, int RES, bool GNOUT>
+hipError_t go(const LinearArgs& a0, int groups, hipStream_t s) {
+    static const int map_env = [] { const char* e = dev_env("PARQ_CHAIN_MAP"); return e ? atoi(e) : 0; }();
+    LinearArgs a = a0;
+    a.tile_map = (map_env == 1 && a.M % 128 == 0) ? 1 : 0;
+    const dim3 grid((unsigned)((a.N / (16 * NT)) * (a.M / 16)), groups, 1);
+    hipLaunchKernelGGL((chain_linear_kernel<K, NT, PRO, ADD2, BIAS, RELU, RES, GNOUT>), grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// column sub-tiles per workgroup for an N-wide launch: the widest of {1, 2, 3, 4} that divides N / 16 (and the addend / moment
+// boundaries) while the grid still has at least ~3/4 of a workgroup per CU at one scene
+int pick_nt(const LinearArgs& a, int want) {
+    const int nt16 = a.N / 16;
+    for (int nt = want; nt > 1; --nt) {
+        if (nt16 % nt != 0) continue;
+        if (a.X2 && a.x2_ncols % (16 * nt) != 0 && a.x2_ncols < a.N) continue;
+        return nt;
+    }
+    return 1;
+}
+
+}  // namespace
+
+// The instantiations are the launches of one decoder iteration (api.hip do_iterate) at the reference's widths:
+//   pe1 (384 -> C, ReLU) | pe2 | self in-proj (+pos on the q, k columns) | self out-proj (+tgt) | cross q-proj (LN1, +pos) |
+//   cross out-proj (+LN1(xa)) | FFN1 (LN2, ReLU) | FFN2 (K = F, +LN2(xb)) | heads layer 1 (LN3, moments) | heads layer 2 (GN, moments)
+// returns hipErrorNotSupported when no instantiation matches (the caller then launches the generic kernel).
+hipError_t launch_chain_linear(const LinearArgs& a, int groups, hipStream_t s) {
+    // shape / layout conditions of the specialised kernel
+    if (a.M % 16 != 0 || a.N % 16 != 0) return hipErrorNotSupported;
+    if (a.relu_mask || a.drop_p > 0.f || a.rows_per_batch != a.M || a.col_blk != a.N) return hipErrorNotSupported;
+    if ((a.ldx | a.ldw | a.y_row) % 4 != 0 || !al16(a.X) || !al16(a.W) || !al16(a.Y)) return hipErrorNotSupported;
+    if ((a.gX | a.gW | a.gY | a.gBias | a.gGamma) % 4 != 0) return hipErrorNotSupported;
+    if (a.bias && !al16(a.bias)) return hipErrorNotSupported;
+    if (a.X2 && (a.ldx2 % 4 != 0 || !al16(a.X2) || a.x2_ncols % 16 != 0)) return hipErrorNotSupported;
+    if (a.R && (a.ldr % 4 != 0 || !al16(a.R))) return hipErrorNotSupported;
+    if (a.rln_stats && (!al16(a.rln_gamma) || !al16(a.rln_beta))) return hipErrorNotSupported;
+    if (a.ln_gamma && (a.gn_sums || !al16(a.ln_gamma) || !al16(a.ln_beta) || groups != 1)) return hipErrorNotSupported;
+    if (a.gn_sums && (a.gn_rows_per_scene % 16 != 0 || !al16(a.gn_gamma) || !al16(a.gn_beta))) return hipErrorNotSupported;
+    if (a.gn_out_sums && (a.gn_out_rows_per_scene % 16 != 0 || a.gn_out_ncols % 16 != 0 || a.gn_out_group_cols % 16 != 0))
+        return hipErrorNotSupported;
+    const Sig g = sig_of(a);
+    auto is = [&](int K, int pro, bool add2, bool bias, bool relu, int res, bool gnout) {
+        return g.K == K && g.pro == pro && g.add2 == add2 && g.bias == bias && g.relu == relu && g.res == res && g.gnout == gnout;
+    };
+    static const int nt_wide = [] { const char* e = dev_env("PARQ_CHAIN_NT_WIDE"); return e ? atoi(e) : 3; }();     // N = 768 / 528 launches
+    static const int nt_inproj = [] { const char* e = dev_env("PARQ_CHAIN_NT_INPROJ"); return e ? atoi(e) : 2; }();
+    static const int nt_heads2 = [] { const char* e = dev_env("PARQ_CHAIN_NT_HEADS2"); return e ? atoi(e) : 2; }();
+#define PARQ_NT_SWITCH(nt, K, PRO, ADD2, BIAS, RELU, RES, GNOUT)                                                \
+    switch (nt) {                                                                                               \
+        case 4: return go<K, 4, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s);                               \
+        case 3: return go<K, 3, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s);                               \
+        case 2: return go<K, 2, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s);                               \
+        default: return go<K, 1, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s);                              \
+    }
+    if (is(384, kProNone, false, true, true, kResNone, false)) return go<384, 1, kProNone, false, true, true, kResNone, false>(a, groups, s);      // pe1
+    if (is(256, kProNone, false, true, false, kResNone, false)) return go<256, 1, kProNone, false, true, false, kResNone, false>(a, groups, s);    // pe2
+    if (is(256, kProNone, true, true, false, kResNone, false)) {                                                                                   // self in-proj
+        const int nt = pick_nt(a, nt_inproj);
+        PARQ_NT_SWITCH(nt, 256, kProNone, true, true, false, kResNone, false)
+    }
+    if (is(256, kProNone, false, true, false, kResPlain, false)) return go<256, 1, kProNone, false, true, false, kResPlain, false>(a, groups, s);  // self out-proj
+    if (is(256, kProLN, true, true, false, kResNone, false)) return go<256, 1, kProLN, true, true, false, kResNone, false>(a, groups, s);          // cross q-proj
+    if (is(256, kProNone, false, true, false, kResLN, false)) return go<256, 1, kProNone, false, true, false, kResLN, false>(a, groups, s);        // cross out-proj
+    if (is(256, kProLN, false, true, true, kResNone, false)) {                                                                                     // FFN1
+        const int nt = pick_nt(a, nt_wide);
+        PARQ_NT_SWITCH(nt, 256, kProLN, false, true, true, kResNone, false)
+    }
+    if (is(768, kProNone, false, true, false, kResLN, false)) return go<768, 1, kProNone, false, true, false, kResLN, false>(a, groups, s);        // FFN2
+    if (is(256, kProLN, false, true, false, kResNone, true)) {                                                                                     // heads layer 1
+        const int nt = pick_nt(a, nt_wide);
+        PARQ_NT_SWITCH(nt, 256, kProLN, false, true, false, kResNone, true)
+    }
+    if (is(256, kProGN, false, false, false, kResNone, true)) {                                                                                    // heads layer 2
+        const int nt = pick_nt(a, nt_heads2);
+        PARQ_NT_SWITCH(nt, 256, kProGN, false, false, false, kResNone, true)
+    }
+#undef PARQ_NT_SWITCH
+    return hipErrorNotSupported;
+}
+
+PARQ_TL_DEFINE_SETTER(tl_set_chain)
+
+}  // namespace parq

@@ -32,13 +32,17 @@ enum : int { kTlLinear = 1, kTlProjectSample = 2, kTlSelfAttn = 3, kTlFlashSplit
 static __device__ unsigned long long* parq_tl_buf = nullptr;      // one copy per translation unit (no relocatable device code)
 static __device__ unsigned int parq_tl_cap = 0;
 struct TlStamp {
-    unsigned long long t0; int id;
-    __device__ __forceinline__ TlStamp(int id_) : id(id_) { t0 = (threadIdx.x == 0 && parq_tl_buf) ? wall_clock64() : 0ull; }
+    unsigned long long t0, idx; int id;
+    // the record slot is claimed at the START (the atomic's round trip overlaps the kernel); the end costs one wait for the wave's
+    // own stores and four fire-and-forget stores
+    __device__ __forceinline__ TlStamp(int id_) : id(id_) {
+        t0 = 0ull; idx = ~0ull;
+        if (threadIdx.x == 0 && parq_tl_buf) { t0 = wall_clock64(); idx = atomicAdd(parq_tl_buf, 1ull); }
+    }
     __device__ __forceinline__ ~TlStamp() {
         if (threadIdx.x == 0 && parq_tl_buf) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long t1 = wall_clock64();
-            const unsigned long long idx = atomicAdd(parq_tl_buf, 1ull);
             if (idx < parq_tl_cap) {
                 unsigned long long* r = parq_tl_buf + 4 + idx * 4;
                 const unsigned long long nblk = (unsigned long long)gridDim.x * gridDim.y * gridDim.z;
@@ -63,6 +67,7 @@ hipError_t tl_set_elementwise(unsigned long long*, unsigned int);
 hipError_t tl_set_flash(unsigned long long*, unsigned int);
 hipError_t tl_set_flash_split(unsigned long long*, unsigned int);
 hipError_t tl_set_kvproj_split(unsigned long long*, unsigned int);
+hipError_t tl_set_chain(unsigned long long*, unsigned int);
 #else
 #define PARQ_TL_KERNEL(id) do { } while (0)
 #define PARQ_TL_DEFINE_SETTER(fn)
@@ -248,8 +253,12 @@ struct LinearArgs {
     double* gn_out_sums; int gn_out_ncols; int gn_out_group_cols; int gn_out_rows_per_scene; int gn_out_ngroups;
     // grouped launch: blockIdx.y = g adds these element offsets
     int64_t gX, gW, gBias, gY, gGamma;
+    int tile_map;                       // chain.hip only: 1 = the workgroups of a row block run on one XCD (set by launch_chain_linear)
 };
 hipError_t launch_linear(const LinearArgs& a, int groups, hipStream_t s);
+// chain.hip: compile-time specialised kernels for the launches of one decoder iteration; hipErrorNotSupported = no instantiation
+// matches this launch (launch_linear then uses the generic kernel)
+hipError_t launch_chain_linear(const LinearArgs& a, int groups, hipStream_t s);
 
 // ------------------------------------------------------------------ attention
 struct FlashArgs {

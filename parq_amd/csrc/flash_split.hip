@@ -275,7 +275,9 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
             int64_t idx = (int64_t)st * STAGE16 + tid + i * NT;
             idx = idx < total16 ? idx : total16 - 1;
             lds_byte* dst = (lds_byte*)(smem_h) + ((size_t)slot * STAGE16 + i * NT + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds(gsrc + idx, dst, 16, 0, 0);      // (nt policy, aux = 2: measured 2 us slower per launch)
+            // a.flags bit 2: non-temporal policy (aux = 2) — the stream then does not displace the chain's weights and code from L2
+            if (a.flags & 4) __builtin_amdgcn_global_load_lds(gsrc + idx, dst, 16, 0, 2);
+            else __builtin_amdgcn_global_load_lds(gsrc + idx, dst, 16, 0, 0);
         }
     };
     // Direction of the sweep over this split's stages.  The K/V cache (393 MB at BASELINE cfg 3) does not fit the 256 MB Infinity
@@ -696,7 +698,8 @@ hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t
     static const int prio = [] { const char* e = dev_env("PARQ_FLASH_PRIO"); return e ? atoi(e) : 0; }();
     static const bool alt = [] { const char* e = dev_env("PARQ_FLASH_ALTERNATE"); return !(e && e[0] == '0'); }();
     // bit 1 (set by the caller for every other recurrent iteration): sweep backwards — only for whole 64-key stages
-    b.flags = (prio & 1) | ((alt && (a.flags & 2) && (a.Lk % (kStageBlks * kBlkKeys)) == 0) ? 2 : 0);
+    static const int nt = [] { const char* e = dev_env("PARQ_FLASH_NT"); return e ? atoi(e) : 0; }();
+    b.flags = (prio & 1) | ((alt && (a.flags & 2) && (a.Lk % (kStageBlks * kBlkKeys)) == 0) ? 2 : 0) | (nt ? 4 : 0);
     const dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * b.H);
     const _Float16* c16 = reinterpret_cast<const _Float16*>(cache);
 #define PARQ_PIPE_LAUNCH(RING, PROBE, T, K, D)                                                                                           \

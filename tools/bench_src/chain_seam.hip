@@ -115,6 +115,20 @@ __global__ __launch_bounds__(NW * 64) void layer_thin(const float* X, const floa
     tile_load_w<NW>(W, bias, cb * 16, t);
     tile_compute<NW, LD_PLAIN, ST_PLAIN>(X, Y, rb * 16, cb * 16, t, red);
 }
+// 14 copies of the same layer at 14 code addresses: a chain of DIFFERENT kernels (what the decoder iteration is) against a chain of
+// one kernel whose instructions stay in the instruction cache
+template <int ID>
+__global__ __launch_bounds__(256) void layer_id(const float* X, const float* W, const float* bias, float* Y, int map) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 256];
+    if (map == 1000 + ID) return;                      // keeps the instantiations distinct
+    int rb, cb; tile_of(blockIdx.x, map, rb, cb);
+    TileW<4> t;
+    tile_load_w<4>(W, bias, cb * 16, t);
+    tile_compute<4, LD_PLAIN, ST_PLAIN>(X, Y, rb * 16, cb * 16, t, red);
+}
+typedef void (*layer_fn)(const float*, const float*, const float*, float*, int);
+static layer_fn layer_table[14] = {layer_id<0>, layer_id<1>, layer_id<2>, layer_id<3>, layer_id<4>, layer_id<5>, layer_id<6>,
+                                   layer_id<7>, layer_id<8>, layer_id<9>, layer_id<10>, layer_id<11>, layer_id<12>, layer_id<13>};
 __global__ void empty_kernel(int) {}
 // keeps the device busy for `us` microseconds so that the host can enqueue the whole chain behind it: the timed region then
 // measures the DEVICE's dependent-dispatch rate, not the host's launch rate (3 - 4 us per hipLaunchKernelGGL)
@@ -303,6 +317,16 @@ int main(int argc, char** argv) {
             snprintf(nm, sizeof nm, "A launches, 5 plain args,   4 waves, map %d", map); report(nm, L, c, w, (L & 1) ? d1 : d0);
             c = timeit(thin8, true); w = timeit(thin8, false);
             snprintf(nm, sizeof nm, "A launches, 5 plain args,   8 waves, map %d", map); report(nm, L, c, w, (L & 1) ? d1 : d0);
+        }
+    }
+    for (int L : {14, 28}) {
+        // C: the same chain through 14 distinct kernels (cold = L2 swept before the chain: code AND weights come from HBM for every
+        // layer of the first 14; warm = back to back)
+        for (int map = 0; map < 2; ++map) {
+            auto distinct = [&]() { for (int s = 0; s < L; ++s) hipLaunchKernelGGL(layer_table[s % 14], dim3(256), dim3(256), 0, 0, (s & 1) ? d1 : d0, dW + (size_t)s * C * C, dB + s * C, (s & 1) ? d0 : d1, map); };
+            char nm[128];
+            const float c = timeit(distinct, true), w = timeit(distinct, false);
+            snprintf(nm, sizeof nm, "C launches of 14 DISTINCT kernels, 4 waves, map %d", map); report(nm, L, c, w, (L & 1) ? d1 : d0);
         }
     }
     {
