@@ -273,7 +273,7 @@ hipError_t launch_chain_linear(const LinearArgs& a, int groups, hipStream_t s) {
         return g.K == K && g.pro == pro && g.add2 == add2 && g.bias == bias && g.relu == relu && g.res == res && g.gnout == gnout;
     };
     static const int nt_wide = [] { const char* e = dev_env("PARQ_CHAIN_NT_WIDE"); return e ? atoi(e) : 3; }();     // N = 768 / 528 launches
-    static const int nt_inproj = [] { const char* e = dev_env("PARQ_CHAIN_NT_INPROJ"); return e ? atoi(e) : 2; }();
+    static const int nt_inproj = [] { const char* e = dev_env("PARQ_CHAIN_NT_INPROJ"); return e ? atoi(e) : 4; }();
     static const int nt_heads2 = [] { const char* e = dev_env("PARQ_CHAIN_NT_HEADS2"); return e ? atoi(e) : 2; }();
 #define PARQ_NT_SWITCH(nt, K, PRO, ADD2, BIAS, RELU, RES, GNOUT)                                                \
     switch (nt) {                                                                                               \

@@ -437,6 +437,145 @@ __global__ __launch_bounds__(256) void box_decode_kernel(BoxDecodeArgs a) {
     }
 }
 
+// The same decode for C = 256 with every global load requested before the first wait (the generic kernel above reads the weights
+// inside a strided loop, the mean-size row after the arg-max and the frequency table at the end: four dependent round trips in a
+// launch that is pure latency).  One wave per query row; lane l owns channels 4 l .. 4 l + 3 of both hidden blocks (float4 loads);
+// the mean-size table sits in two registers per lane and the arg-max row is fetched with a lane permute.
+__global__ __launch_bounds__(256) void box_decode256_kernel(BoxDecodeArgs a) {
+    PARQ_TL_KERNEL(kTlBoxDecode);
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    constexpr int C = 256;
+    const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (m >= a.M) return;
+    const int lane = threadIdx.x & 63;
+    const int scene = m / a.rows_per_scene;
+    const float* h1 = a.h1 + (int64_t)m * a.ld1;
+    const float* h2 = a.h2 + (int64_t)m * a.ld2;
+    const int l3 = lane < 3 ? lane : 2, l6 = lane < 6 ? lane : 5, lc = lane < a.ncls ? lane : a.ncls - 1;
+    const float lg_raw = h1[lc];
+    const float sz_raw = h1[a.ncls + l3];
+    const float ref_raw = a.ref[(int64_t)m * 3 + l3];
+    const float b3c_raw = a.b3[l3];
+    const float b3r_raw = a.b3[6 + l6];
+    double sums[4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const double* src = a.gn_sums + ((int64_t)(scene * 2 + g) * kGnSlots + lane) * 2;
+        sums[2 * g] = src[0];
+        sums[2 * g + 1] = src[1];
+    }
+    const f32x4v x0 = *reinterpret_cast<const f32x4v*>(h2 + 4 * lane);
+    const f32x4v x1 = *reinterpret_cast<const f32x4v*>(h2 + C + 4 * lane);
+    const f32x4v g0 = *reinterpret_cast<const f32x4v*>(a.gn_gamma + 4 * lane), g1 = *reinterpret_cast<const f32x4v*>(a.gn_gamma + C + 4 * lane);
+    const f32x4v be0 = *reinterpret_cast<const f32x4v*>(a.gn_beta + 4 * lane), be1 = *reinterpret_cast<const f32x4v*>(a.gn_beta + C + 4 * lane);
+    f32x4v w[9];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) w[j] = *reinterpret_cast<const f32x4v*>(a.w3 + (int64_t)j * C + 4 * lane);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) w[3 + j] = *reinterpret_cast<const f32x4v*>(a.w3 + (int64_t)(6 + j) * C + 4 * lane);
+    const float dimt = a.dim_t[2 * lane];
+    const int nms = a.n_mean * 3;                                       // <= 128 (launcher)
+    const float ms0 = a.mean_sizes[lane < nms ? lane : nms - 1];
+    const float ms1 = a.mean_sizes[64 + lane < nms ? 64 + lane : nms - 1];
+    __builtin_amdgcn_sched_barrier(0);                                   // keep every load above the first wait
+    const bool poison = a.poison != nullptr && *a.poison != 0;          // wave-uniform scalar load
+    if (poison && a.poison_mirror != nullptr && m == 0 && lane == 0) *a.poison_mirror = 1;
+
+    const float lg_in = lane < a.ncls ? lg_raw : -INFINITY;
+    const float sz_in = lane < 3 ? sz_raw : 0.f;
+    const float ref_in = lane < 3 ? ref_raw : 0.5f;
+    const float b3c = lane < 3 ? b3c_raw : 0.f;
+    const float b3r = lane < 6 ? b3r_raw : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sums[j] += __shfl_xor(sums[j], o);
+    float mean[2], rstd[2];
+    const double inv_cnt = 1.0 / ((double)a.rows_per_scene * (double)C);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) gn_mean_rstd(sums[2 * g], sums[2 * g + 1], inv_cnt, a.eps, mean[g], rstd[g]);
+    float acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float y0 = (x0[e] - mean[0]) * rstd[0] * g0[e] + be0[e];
+        float y1 = (x1[e] - mean[1]) * rstd[1] * g1[e] + be1[e];
+        y0 = y0 > 0.f ? y0 : 0.f;
+        y1 = y1 > 0.f ? y1 : 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] += y0 * w[j][e];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[3 + j] += y1 * w[3 + j][e];
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_xor(acc[j], o);
+
+    float mx = lg_in;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float ex = lane < a.ncls ? expf(lg_in - mx) : 0.f;
+    float sum = ex;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float prob = ex / sum;
+    if (lane < a.ncls) {
+        a.logits[(int64_t)m * a.ncls + lane] = poison ? NAN : lg_in;
+        a.prob[(int64_t)m * a.ncls + lane] = poison ? NAN : prob;
+    }
+    float bestp = lane < a.ncls ? prob : -1.f;
+    int besti = lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float op = __shfl_xor(bestp, o);
+        const int oi = __shfl_xor(besti, o);
+        if (op > bestp || (op == bestp && oi < besti)) {
+            bestp = op;
+            besti = oi;
+        }
+    }
+    const int arg = besti < a.n_mean ? besti : a.n_mean - 1;
+    {
+        const int idx = arg * 3 + l3;                                     // row `arg` of the mean-size table, from the lanes that hold it
+        const float lo_half = __shfl(ms0, idx & 63), hi_half = __shfl(ms1, idx & 63);
+        const float msz = idx < 64 ? lo_half : hi_half;
+        if (lane < 3) a.size[(int64_t)m * 3 + lane] = poison ? NAN : expf(sz_in) * msz;
+    }
+    float rotv = 0.f, ctrv = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) rotv = lane == j ? acc[3 + j] : rotv;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) ctrv = lane == j ? acc[j] : ctrv;
+    if (lane < 6) a.rot[(int64_t)m * 6 + lane] = poison ? NAN : rotv + b3r;
+    float nref = 0.f;
+    if (lane < 3) {
+        const float lo = lane == 0 ? a.sb.lo[0] : (lane == 1 ? a.sb.lo[1] : a.sb.lo[2]);
+        const float hi = lane == 0 ? a.sb.hi[0] : (lane == 1 ? a.sb.hi[1] : a.sb.hi[2]);
+        const float r = fminf(fmaxf(ref_in, 0.f), 1.f);
+        const float x1c = fmaxf(r, 1e-3f);
+        const float x2c = fmaxf(1.f - r, 1e-3f);
+        const float off = (ctrv + b3c) + logf(x1c / x2c);
+        const float sg = 1.f / (1.f + expf(-off));
+        const float ctr = __fadd_rn(__fmul_rn(sg, __fsub_rn(hi, lo)), lo);      // mul, then add: as torch
+        a.center[(int64_t)m * 3 + lane] = poison ? NAN : ctr;
+        nref = __fsub_rn(ctr, lo) / __fsub_rn(hi, lo);
+        if (a.ref_next) a.ref_next[(int64_t)m * 3 + lane] = nref;
+    }
+    if (a.emb_next) {
+        const float n0 = __shfl(nref, 0), n1 = __shfl(nref, 1), n2 = __shfl(nref, 2);
+#pragma unroll
+        for (int blk = 0; blk < 3; ++blk) {
+            const float r = blk == 0 ? n1 : (blk == 1 ? n0 : n2);
+            const float ang = (r * 6.283185307179586f) / dimt;
+            float sn, cs;
+            sincosf(ang, &sn, &cs);
+            *reinterpret_cast<float2*>(a.emb_next + (int64_t)m * 384 + blk * 128 + 2 * lane) = float2{sn, cs};
+        }
+    }
+}
+
 __global__ void zero_f64_kernel(double* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.0;
@@ -529,7 +668,13 @@ hipError_t launch_box_decode(const BoxDecodeArgs& a, hipStream_t s) {
     // one row per wave; rows per workgroup: 1 while that still leaves CUs idle (pure latency: spread the rows over the chip), else 4
     static const int rows_env = [] { const char* e = dev_env("PARQ_DECODE_ROWS"); return e ? atoi(e) : 0; }();
     const int rows = (rows_env >= 1 && rows_env <= 4) ? rows_env : (a.M <= 2 * device_num_cus() ? 1 : 4);
-    hipLaunchKernelGGL(box_decode_kernel, dim3(ceil_div(a.M, rows)), dim3(rows * 64), 0, s, a);
+    static const bool fast_off = [] { const char* e = dev_env("PARQ_DECODE_FAST"); return e && e[0] == '0'; }();
+    const bool al = ((reinterpret_cast<uintptr_t>(a.h2) | reinterpret_cast<uintptr_t>(a.gn_gamma) | reinterpret_cast<uintptr_t>(a.gn_beta) |
+                      reinterpret_cast<uintptr_t>(a.w3)) & 15u) == 0 && a.ld2 % 4 == 0;
+    if (a.C == 256 && a.n_mean * 3 <= 128 && a.n_mean >= 1 && al && !fast_off)
+        hipLaunchKernelGGL(box_decode256_kernel, dim3(ceil_div(a.M, rows)), dim3(rows * 64), 0, s, a);
+    else
+        hipLaunchKernelGGL(box_decode_kernel, dim3(ceil_div(a.M, rows)), dim3(rows * 64), 0, s, a);
     return hipGetLastError();
 }
 

@@ -480,6 +480,89 @@ __global__ __launch_bounds__(512) void self_attn_kernel(const float* __restrict_
     }
 }
 
+// The same merge with the split count a template parameter (NS key splits, whole 32-query tiles): every partial a thread will
+// combine — its NS / 8 (m, l) pairs and its NS / NG float4 rows of O^T — is requested before the first wait.  The generic kernel
+// above needs three dependent round trips (statistics, then two batches of 8 partial rows); at one scene this launch is pure
+// latency.  Same thread mapping and summation order: bit-identical results.
+template <int DH, int DG, int NS>
+__global__ __launch_bounds__(256) void flash_merge_fixed_kernel(FlashArgs a) {
+    PARQ_TL_KERNEL(kTlFlashMerge);
+    constexpr int NG = 256 / (8 * DG);               // split groups
+    constexpr int SPT = NS / NG;                     // partial rows per thread
+    constexpr int PER = NS / 8;                      // (m, l) pairs per thread
+    static_assert(NS % NG == 0 && NS % 8 == 0 && SPT <= 16, "split count");
+    __shared__ __attribute__((aligned(16))) float wsm[NS * 32];
+    __shared__ float dsm[8 * 32];
+    __shared__ __attribute__((aligned(16))) float part[NG * DG * 32];
+    const int bh = blockIdx.y;
+    const int b = bh / a.H;
+    const int h = bh - b * a.H;
+    const int q0 = blockIdx.x * 32;
+    const int dg0 = blockIdx.z * DG;
+    const int tq = threadIdx.x & 31;
+    const int td = threadIdx.x >> 5;
+    const int Lq_pad = a.Lq;                         // a.Lq % 32 == 0 (launcher)
+    const int q = q0 + tq;
+    const int64_t pb = (int64_t)bh * NS;
+    const int q4 = threadIdx.x & 7;
+    const int dd = (threadIdx.x >> 3) & (DG - 1);
+    const int half = threadIdx.x / (8 * DG);
+    const int s_begin = half * SPT;
+    const int64_t sstride = (int64_t)DH * Lq_pad;
+    const float* o0 = a.o_part + (pb * DH + dg0 + dd) * (int64_t)Lq_pad + q0 + q4 * 4;
+
+    float mloc[PER], lloc[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        mloc[i] = a.m_part[(pb + td + i * 8) * Lq_pad + q];
+        lloc[i] = a.l_part[(pb + td + i * 8) * Lq_pad + q];
+    }
+    f32x4 x[SPT];
+#pragma unroll
+    for (int u = 0; u < SPT; ++u) x[u] = *reinterpret_cast<const f32x4*>(o0 + (s_begin + u) * sstride);
+    __builtin_amdgcn_sched_barrier(0);               // keep every load above the first wait
+
+    float mmax = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) mmax = fmaxf(mmax, mloc[i]);
+    dsm[td * 32 + tq] = mmax;
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mmax = fmaxf(mmax, dsm[i * 32 + tq]);
+    lds_barrier();
+    float den = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const float w = __builtin_amdgcn_exp2f(mloc[i] - mmax);
+        wsm[(td + i * 8) * 32 + tq] = w;
+        den += w * lloc[i];
+    }
+    dsm[td * 32 + tq] = den;
+    lds_barrier();
+    if (a.lse && blockIdx.z == 0 && td == 0) {
+        float dn = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dn += dsm[i * 32 + tq];
+        a.lse[(int64_t)bh * Lq_pad + q] = mmax + log2f(dn);
+    }
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < SPT; ++u) acc += x[u] * *reinterpret_cast<const f32x4*>(&wsm[(s_begin + u) * 32 + q4 * 4]);
+    *reinterpret_cast<f32x4*>(&part[(half * DG + dd) * 32 + q4 * 4]) = acc;
+    lds_barrier();
+    for (int idx = threadIdx.x; idx < 32 * DG; idx += 256) {
+        const int qq = idx / DG;
+        const int d = idx - qq * DG;
+        float dn = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dn += dsm[i * 32 + qq];
+        float acc2 = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < NG; ++g2) acc2 += part[(g2 * DG + d) * 32 + qq];
+        a.out[(int64_t)b * a.out_batch + (int64_t)(q0 + qq) * a.out_row + h * DH + dg0 + d] = acc2 / dn;
+    }
+}
+
 template <int DH, int NW>
 hipError_t launch_one(const FlashArgs& a, hipStream_t s) {
     static DynLdsOnce once;
@@ -510,6 +593,13 @@ hipError_t merge_dh(const FlashArgs& a, hipStream_t s) {
     // 8 dims per workgroup while that is what it takes to cover the chip (one scene), else 16
     const int64_t wg16 = (int64_t)ceil_div(a.Lq, 32) * a.B * a.H * (DH / 16);
     const int dg = dg_env == 8 || dg_env == 16 ? dg_env : (wg16 < device_num_cus() ? 8 : 16);
+    static const bool fixed_off = [] { const char* e = dev_env("PARQ_MERGE_FIXED"); return e && e[0] == '0'; }();
+    if constexpr (DH == 64) {
+        if (dg == 8 && a.nsplit == 64 && a.Lq % 32 == 0 && !fixed_off) {       // the one-scene cross-attention merge: all loads up front
+            hipLaunchKernelGGL((flash_merge_fixed_kernel<DH, 8, 64>), dim3(a.Lq / 32, a.B * a.H, DH / 8), dim3(256), 0, s, a);
+            return hipGetLastError();
+        }
+    }
     if (dg == 8) {
         static DynLdsOnce once;
         if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_merge_kernel<DH, 8>), 96 * 1024); e != hipSuccess) return e;
