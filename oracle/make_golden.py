@@ -22,6 +22,12 @@ Cases:
   g8_unshared    SHARE_WEIGHTS=False, 2 layers, d=128/H=2
   g14_cfg3       BASELINE cfg 3 exactly (the benchmark's headline size): 10 views 120x160 feature maps
                  (N = 192 000 tokens), Q=256, I=8, d=256, noise features — consumed teacher-forced
+  g15_cfg5_shape BASELINE cfg 5's decoder shape on small feature maps: 20 views 24x32 (N = 15 360 tokens), Q=512 (two
+                 query tiles per head), I=12, d=256, noise features — consumed teacher-forced (split and fp16 modes)
+  g16_module     the MODULE-level composition, captured through the reference's own PARQ.forward
+                 (model/parq_lightning.py:68-95: backbone hand-off -> AddRayPE -> features + encoding -> tokenisation ->
+                 decoder) with a stub backbone that returns seeded features: per-iteration output dicts of the free-running
+                 (damped) decoder plus a float64 checksum of the token tensor
 """
 from __future__ import annotations
 
@@ -61,7 +67,72 @@ CASES = {
                         wseed=18, sseed=108, B=1, V=2, h=12, w=16, smooth=False, damped=False),
     "g14_cfg3": dict(cfg=dict(dim=256, queries=256, heads=4, ffn=768, layers=8), wseed=24, sseed=124,
                      B=1, V=10, h=120, w=160, smooth=False, damped=False),
+    "g15_cfg5_shape": dict(cfg=dict(dim=256, queries=512, heads=4, ffn=768, layers=12), wseed=25, sseed=125,
+                           B=1, V=20, h=24, w=32, smooth=False, damped=False),
 }
+
+# module-level case (g16): PARQ.forward = stub backbone -> AddRayPE -> tokenise -> decoder, free-running on damped weights
+MODULE_CASE = dict(cfg=dict(dim=256, queries=48, heads=4, ffn=768, layers=4), wseed=26, pseed=27, gseed=126, fseed=127,
+                   B=2, V=3, h=14, w=18, feat_std=0.5, ray_points_scale=[-3.0, 3.0, -2.0, 0.5, 0.25, 5.25])
+
+
+def module_case_inputs(c):
+    """(decoder cfg, decoder weights, ray-PE weights, geometry, features) of the module-level case — shared with the tests."""
+    cfg = synth.decoder_cfg(**c["cfg"])
+    W = synth.make_decoder_weights(cfg, c["wseed"], damped=True)
+    Wp = synth.make_ray_pe_weights(c["cfg"]["dim"], c["pseed"])
+    geom = synth.make_geometry(c["gseed"], c["B"], c["V"], c["h"], c["w"])
+    feat = synth.normal(c["fseed"], "feat", (c["B"], c["V"], c["cfg"]["dim"], c["h"], c["w"]), std=c["feat_std"])
+    return cfg, W, Wp, geom, feat
+
+
+def make_module_golden(ref):
+    """g16: run the reference's own PARQ.forward (model/parq_lightning.py:68-95).  The Lightning module is built without its
+    constructor (which downloads a torchvision ResNet): `backbone2d` is a stub that hands over seeded feature maps the way
+    ResnetFPN.forward does (batch['all_features']), `add_ray_pe` and `box3d_decoder` are the reference's real modules."""
+    from model import parq_lightning as PL              # noqa: E402  (reference module, imported in place)
+    c = MODULE_CASE
+    cfg, W, Wp, (cam, T_cp, T_wp, T_wl), feat = module_case_inputs(c)
+    model = PL.PARQ.__new__(PL.PARQ)
+    torch.nn.Module.__init__(model)
+
+    class StubBackbone(torch.nn.Module):
+        def forward(self, batch):
+            batch["all_features"] = torch.from_numpy(feat)
+            return batch
+
+    model.backbone2d = StubBackbone()
+    model.add_ray_pe = ref.AddRayPE(c["cfg"]["dim"], c["ray_points_scale"], 64, 0.25, 5.25)
+    model.add_ray_pe.load_state_dict({k: torch.from_numpy(v) for k, v in Wp.items()}, strict=True)
+    model.box3d_decoder = RL.build_reference_decoder(ref, cfg, W)
+    model.eval()
+    captured = {}
+    real_dec_forward = model.box3d_decoder.forward
+
+    def spy(tokens, *a, **k):                           # the token tensor the reference hands to its decoder
+        captured["tokens"] = tokens.detach().clone()
+        return real_dec_forward(tokens, *a, **k)
+
+    model.box3d_decoder.forward = spy
+    batch = {"camera_feature": ref.Camera(torch.from_numpy(cam)), "T_camera_pseudoCam": ref.Pose(torch.from_numpy(T_cp)),
+             "T_world_pseudoCam": ref.Pose(torch.from_numpy(T_wp)), "T_world_local": ref.Pose(torch.from_numpy(T_wl))}
+    with torch.no_grad():
+        losses, outs = PL.PARQ.forward(model, batch, 0)
+    assert losses == {"total_loss": 0}
+    tok = captured["tokens"]
+    arrays = {}
+    for k, o in enumerate(outs):
+        for key in KEYS:
+            arrays["it%d_%s" % (k, key)] = o[key].detach().numpy().astype(np.float32)
+    sc = dict(tokens=tok.numpy(), camera=cam, T_camera_pseudoCam=T_cp, T_world_pseudoCam=T_wp, T_world_local=T_wl)
+    arrays.update(margins(cfg, W, sc, outs))
+    # the token tensor itself is 2 x 756 x 256 floats: stored as checksums plus a strided sample
+    arrays["tokens_sum"] = np.array([tok.double().sum().item(), tok.double().abs().sum().item(), (tok.double() ** 2).sum().item()])
+    arrays["tokens_sample"] = tok.numpy()[:, ::37, ::5].copy()
+    arrays["meta"] = np.frombuffer(json.dumps(c, sort_keys=True).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT_DIR, "g16_module.npz"), **arrays)
+    print("wrote g16_module", tuple(tok.shape), len(outs))
+
 
 RAYPE_CASE = dict(dim=64, seed=15, sseed=105, B=1, V=2, h=6, w=8,
                   ray_points_scale=[-3.0, 3.0, -2.0, 0.5, 0.25, 5.25])
@@ -197,6 +268,8 @@ def main(only=None):
         np.savez_compressed(os.path.join(OUT_DIR, gname + ".npz"), encoding=enc.numpy(),
                             meta=np.frombuffer(json.dumps(c, sort_keys=True).encode(), dtype=np.uint8))
         print("wrote", gname, tuple(enc.shape))
+    if not only or "g16_module" in only:
+        make_module_golden(ref)
     if not only or "g10_loss" in only:
         make_loss_golden(ref)
     if not only or "g11_parse_pred" in only:

@@ -47,6 +47,28 @@ def test_golden_teacher_forced_fp32_mfma_mode(name):
     print(name, "fp32", _run_forced(name, mode="fp32"))
 
 
+@pytest.mark.parametrize("mode,tol", [(None, TOL), ("fp16", 3e-4)])
+def test_golden_cfg5_shape_teacher_forced(mode, tol):
+    """BASELINE cfg 5's decoder shape — Q = 512 (two query tiles per head), I = 12, 20 views — against the golden captured from
+    the REFERENCE (fp32) at that shape on small feature maps (g15): split mode to 1e-4; fp16 (the arithmetic cfg 5 names) to the
+    stated reduced-precision bound 3e-4 (K, V, Q and the probabilities rounded once to 11 significant bits)."""
+    case, z = G.load("g15_cfg5_shape")
+    cfg, W, sc = G.inputs(case)
+    dec = make_decoder(cfg, W)
+    if mode is not None:
+        dec.attention_mode = mode
+    dec.prepare(*scene_args(sc))
+    refs = G.forced_refs(z, cfg.TRANSFORMER.SCALE)
+    worst = {}
+    for k in range(12):
+        out, _ = dec.iterate(k, dev(refs[k]))
+        w = G.compare(to_np(out), z, k, tol, what="g15 %s" % (mode or "split"))
+        worst = {kk: max(v, worst.get(kk, 0.0)) for kk, v in w.items()}
+    print("\ng15_cfg5_shape", mode or "split", worst)
+    if mode == "fp16":
+        assert not dec.fp16_range_exceeded()
+
+
 def test_golden_cfg1_forward_api():
     """BASELINE cfg 1 through the public forward(): one iteration from sigmoid(refpoint)."""
     case, z = G.load("g1_cfg1")
@@ -113,7 +135,7 @@ def test_oracle_fresh_inputs_cfg2_shape():
     assert max(worst.values()) < TOL, worst
 
 
-@pytest.mark.parametrize("mode,tol", [("fp16", 1e-3), ("bf16", 1e-2)])
+@pytest.mark.parametrize("mode,tol", [("fp16", 3e-4), ("bf16", 2e-3)])
 def test_cfg2_reduced_precision_modes(mode, tol):
     """BASELINE config 2 names bf16 (config 5 fp16); the reference defines no mixed precision, so
     these modes are judged against the fp32/fp64 oracle with a looser, stated tolerance: cross-attention operands
@@ -126,7 +148,7 @@ def test_cfg2_reduced_precision_modes(mode, tol):
         assert not dec.fp16_range_exceeded()
 
 
-@pytest.mark.parametrize("mode,tol", [("fp16", 1e-3), ("bf16", 1e-2)])
+@pytest.mark.parametrize("mode,tol", [("fp16", 3e-4), ("bf16", 2e-3)])
 @pytest.mark.parametrize("dim,heads", [(256, 1), (1024, 4)])
 def test_reduced_precision_modes_at_head_dim_256(mode, tol, dim, heads):
     """The same modes at head dim 256 (the reference's shipped head size; d = 1024 goes through the large-C projection kernel,
@@ -390,6 +412,50 @@ def test_parq_module_forward_matches_oracle_pipeline():
         want, _, _ = od.iterate(ref0, 0)
     for key in ("pred_logits", "center_unnormalized", "ortho6d", "sem_cls_prob"):
         assert rel_err(outs[0][key].cpu().numpy(), want[key].numpy()) < TOL, key
+
+
+def test_parq_module_forward_matches_reference_module_golden():
+    """g16: PARQ.forward of this package against vectors captured through the REFERENCE's own PARQ.forward
+    (model/parq_lightning.py:68-95, stub backbone handing over seeded features): every iteration of the free-running (damped)
+    decoder within 1e-4, plus the token tensor the fused ray-PE + tokenisation kernels hand to the decoder (checksums and a
+    strided sample)."""
+    from types import SimpleNamespace as NS
+    from parq_amd import PARQ, Camera, Pose
+    from oracle import make_golden as MG
+    case, z = G.load("g16_module")
+    dcfg, W, Wp, (cam, T_cp, T_wp, T_wl), feat = MG.module_case_inputs(case)
+    Cd = case["cfg"]["dim"]
+    cfg = NS(MODEL=NS(TOKENIZER=NS(OUT_CHANNELS=Cd, RAY_POINTS_SCALE=case["ray_points_scale"], NUM_SAMPLES=64, MIN_DEPTH=0.25, MAX_DEPTH=5.25),
+                      DECODER=dcfg))
+    handed = {}
+
+    def backbone(batch):                                  # the hand-off of ResnetFPN.forward: adds batch['all_features']
+        batch["all_features"] = dev(feat)
+        handed["called"] = True
+        return batch
+
+    model = PARQ(cfg, backbone2d=backbone).eval()
+    sd = model.state_dict()
+    for k in sd:
+        if k.startswith("box3d_decoder."):
+            src = k[len("box3d_decoder."):].replace("parq_module.decoder.mlp_heads.", "mlp_heads.")
+            sd[k] = torch.from_numpy(W[src]).reshape(sd[k].shape)
+        else:
+            sd[k] = torch.from_numpy(Wp[k[len("add_ray_pe."):]])
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda()
+    batch = {"camera_feature": Camera(dev(cam)), "T_camera_pseudoCam": Pose(dev(T_cp)),
+             "T_world_pseudoCam": Pose(dev(T_wp)), "T_world_local": Pose(dev(T_wl))}
+    tokens = model.add_ray_pe.tokens(dev(feat), batch["camera_feature"], batch["T_camera_pseudoCam"], batch["T_world_pseudoCam"],
+                                     batch["T_world_local"])
+    tk = tokens.double()
+    got = np.array([tk.sum().item(), tk.abs().sum().item(), (tk ** 2).sum().item()])
+    assert np.allclose(got, z["tokens_sum"], rtol=5e-6, atol=1e-2), (got, z["tokens_sum"])
+    assert np.abs(tokens.cpu().numpy()[:, ::37, ::5] - z["tokens_sample"]).max() < 5e-5
+    losses, outs = model(batch, 0)
+    assert handed.get("called") and losses == {"total_loss": 0} and len(outs) == 4
+    for k, o in enumerate(outs):
+        G.compare(to_np(o), z, k, TOL, what="g16 module")
 
 
 def test_update_metrics_drives_the_f1_trackers():

@@ -10,6 +10,8 @@ tokens, 256 queries, 8 iterations, d = 256, 4 heads, FFN 768) held to the refere
   * the cfg-4 per-GPU shard (4 scenes in one call): gradients == sum of four single-scene runs.
 
 Reference lines: model/transformer_parq.py:283-337 (loop), :365-386 (layer), model/parq_decoder.py:134-163."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -72,6 +74,10 @@ def test_cfg3_golden_teacher_forced(g14, truth, mode):
     dec.prepare(*args, feat_hw=(FH, FW))
     refs = G.forced_refs(z, cfg.TRANSFORMER.SCALE)
     worst_truth = worst_gold = worst_ref = 0.0
+    # per-(iteration, output) table of the three errors and of the bound that applied: written next to the test output so that
+    # which comparisons took the relaxed branch is on record (profiles/r03_cfg3_parity_table_<mode>.txt is a copy of it)
+    rows = ["# g14_cfg3 [%s] teacher-forced, error = max |a - b| / max(1, |b|) over the decision-safe elements" % mode,
+            "# it output               HIP-vs-float64  HIP-vs-reference-fp32  reference-fp32-vs-float64  bound-on-HIP-vs-reference  branch"]
     for k in range(ITERS):
         out, _ = dec.iterate(k, dev(refs[k]))
         o = to_np(out)
@@ -81,8 +87,22 @@ def test_cfg3_golden_teacher_forced(g14, truth, mode):
             e_gold = _masked_err(o[key], g, z, k, key)
             e_ref = _masked_err(g, truth[k][key], z, k, key)              # the reference's own fp32-vs-float64 deviation
             worst_truth, worst_gold, worst_ref = max(worst_truth, e_truth), max(worst_gold, e_gold), max(worst_ref, e_ref)
+            relaxed = not (e_ref < 9e-5)
+            bound = e_ref + 1e-5 if relaxed else TOL
+            rows.append("%4d %-20s %14.3e  %21.3e  %25.3e  %25.3e  %s" % (k, key, e_truth, e_gold, e_ref, bound, "relaxed" if relaxed else "1e-4"))
             assert e_truth < TOL, (mode, k, key, e_truth)
-            assert e_gold < (TOL if e_ref < 9e-5 else e_ref + 1e-5), (mode, k, key, e_gold, e_ref)
+            assert e_gold < bound, (mode, k, key, e_gold, e_ref)
+    rows.append("# relaxed comparisons: %d of %d; HIP-vs-reference above 1e-4 on %d of them" % (
+        sum(r.endswith("relaxed") for r in rows), ITERS * len(G.KEYS),
+        sum(r.endswith("relaxed") and float(r.split()[3]) >= TOL for r in rows[2:])))
+    print("\n" + "\n".join(rows))
+    try:
+        d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "r03")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "cfg3_parity_table_%s.txt" % mode), "w") as f:
+            f.write("\n".join(rows) + "\n")
+    except OSError:
+        pass
     print("\ng14_cfg3 [%s]: HIP vs float64 oracle %.2e | HIP vs reference fp32 golden %.2e | reference fp32 vs float64 %.2e"
           % (mode, worst_truth, worst_gold, worst_ref))
     assert worst_truth <= worst_ref                                       # closer to the truth than the reference's fp32 run

@@ -7,6 +7,7 @@ hi + lo carries an fp32 value with absolute error <= max(2^-24, 2^-22 |x|) while
     reference's own arithmetic, model/transformer_parq.py:377-380, has the same rounding);
   * beyond the range nothing is silent: outputs are NaN, the flag and the pinned host mirror are raised, and the module's
     range_check policies ("sync": transparent re-run with the fp32 kernels; "lazy": switch for the following calls) work."""
+import os
 import warnings
 
 import numpy as np
@@ -152,3 +153,23 @@ def test_out_of_range_features_are_not_silent_and_policies_recover():
     assert dec.attention_mode == "fp32" and any("fp16 range" in str(r.message) for r in rec)
     assert torch.isfinite(second[0]["pred_logits"]).all()
     assert rel_err(second[0]["pred_logits"].cpu().numpy(), want[0]["pred_logits"].numpy()) < max(1e-4, 2 * e_fp32)
+
+
+def test_product_library_ignores_probe_environment(tmp_path):
+    """A stray development variable must not change results: a fresh process with PARQ_FLASH_PROBE /
+    PARQ_KVPROJ_PROBE / PARQ_CHAIN_MAX_M set runs golden g1 through the PRODUCT library and still meets 1e-4 — the probe
+    kernels ("results wrong by construction") are not compiled into it."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import golden_util as G\n"
+        "from gpu_util import make_decoder, scene_args, to_np\n"
+        "case, z = G.load('g1_cfg1'); cfg, W, sc = G.inputs(case)\n"
+        "outs = make_decoder(cfg, W)(*scene_args(sc))\n"
+        "print('worst', G.compare(to_np(outs[0]), z, 0, 1e-4, what='g1 under PARQ_* env'))\n"
+    ) % (os.path.dirname(os.path.abspath(__file__)), os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    env = dict(os.environ, PARQ_FLASH_PROBE="2", PARQ_KVPROJ_PROBE="4", PARQ_CHAIN_MAX_M="0", PARQ_LINEAR_TILE="32")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "worst" in r.stdout

@@ -58,6 +58,21 @@ def test_header_symbols_are_exported_and_typed():
     assert b"gfx950" in lib.parq_version()
 
 
+def test_product_library_reads_no_environment():
+    """VERDICT r02 #3 / ADVICE: the development knobs and the kernels-with-ingredients-removed probes (PARQ_FLASH_PROBE,
+    PARQ_KVPROJ_PROBE, ... — "results wrong by construction") exist only in the -DPARQ_DEV_PROBES build.  The product library
+    must not even import getenv and must not contain one PARQ_* variable name; the version string says which build it is."""
+    from parq_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"PARQ_FLASH_PROBE" not in blob and b"PARQ_KVPROJ_PROBE" not in blob
+    assert re.search(rb"PARQ_[A-Z][A-Z_0-9]{3,}", blob) is None
+    assert b"getenv" not in blob                                   # not in the dynamic symbol table, not anywhere
+    assert b"dev" not in _lib.load().parq_version().split(b"(")[0]
+    assert not hasattr(_lib.load(), "parq_dev_timeline_missing") and not _lib.is_dev_library()
+    with pytest.raises(AttributeError):
+        _lib.load().parq_dev_timeline                              # the development entry point is not exported
+
+
 def test_create_validates_config_without_gpu():
     from parq_amd import _lib
     lib = _lib.load()

@@ -41,6 +41,36 @@ def test_oracle_teacher_forced_baseline_cfg3_size():
         G.compare(o, z, k, tol=2e-5, what="g14_cfg3")
 
 
+def test_oracle_teacher_forced_cfg5_shape():
+    """BASELINE cfg 5's decoder shape (Q = 512: two query tiles per head, I = 12, 20 views) on small feature maps: the oracle
+    against the golden captured from the reference."""
+    z, outs = _run("g15_cfg5_shape", False, forced=True)
+    assert len(outs) == 12 and outs[0]["pred_logits"].shape == (1, 512, 10)
+    for k, o in enumerate(outs):
+        G.compare(o, z, k, tol=2e-5, what="g15_cfg5_shape")
+
+
+def test_oracle_module_pipeline_matches_reference_module_forward():
+    """g16: the reference's PARQ.forward (model/parq_lightning.py:68-95: features -> AddRayPE -> + -> tokenise -> decoder,
+    free-running, damped weights) against the oracle's composition of the same stages: token checksums, a strided sample of the
+    token tensor and every iteration's outputs."""
+    from oracle import make_golden as MG
+    case, z = G.load("g16_module")
+    cfg, W, Wp, (cam, T_cp, T_wp, T_wl), feat = MG.module_case_inputs(case)
+    with torch.no_grad():
+        enc = O.ray_pe(cam, T_cp, T_wp, T_wl, Wp, case["ray_points_scale"])
+        tokens = O.tokenize(torch.from_numpy(feat), enc)
+        tk = tokens.double()
+        got = np.array([tk.sum().item(), tk.abs().sum().item(), (tk ** 2).sum().item()])
+        assert np.allclose(got, z["tokens_sum"], rtol=2e-6, atol=1e-3), (got, z["tokens_sum"])
+        assert np.abs(tokens.numpy()[:, ::37, ::5] - z["tokens_sample"]).max() < 2e-5
+        od = O.OracleDecoder(cfg, W, synth.SCANNET_MEAN_SIZES)
+        outs = od.forward(tokens, cam, T_cp, T_wp, T_wl)
+    assert len(outs) == G.num_iters(z) == 4
+    for k, o in enumerate(outs):
+        G.compare({kk: v.numpy() for kk, v in o.items()}, z, k, tol=1e-4, what="g16_module")
+
+
 def test_oracle_free_running_damped():
     # damped fixture: fp32 self-noise of the reference stays below 1e-4 over 8 iterations
     z, outs = _run("g3_damped", False, forced=False)
