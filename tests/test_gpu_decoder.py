@@ -50,8 +50,11 @@ def test_golden_teacher_forced_fp32_mfma_mode(name):
 @pytest.mark.parametrize("mode,tol", [(None, TOL), ("fp16", 3e-4)])
 def test_golden_cfg5_shape_teacher_forced(mode, tol):
     """BASELINE cfg 5's decoder shape — Q = 512 (two query tiles per head), I = 12, 20 views — against the golden captured from
-    the REFERENCE (fp32) at that shape on small feature maps (g15): split mode to 1e-4; fp16 (the arithmetic cfg 5 names) to the
-    stated reduced-precision bound 3e-4 (K, V, Q and the probabilities rounded once to 11 significant bits)."""
+    the REFERENCE (fp32) at that shape on small feature maps (g15), teacher-forced.  Bounds: split mode 1e-4, fp16 (the
+    arithmetic cfg 5 names: K, V, Q and the probabilities rounded once to 11 significant bits) 3e-4, both
+      (a) against the float64 evaluation of the reference's algorithm at the same inputs, and
+      (b) against the reference's own fp32 vectors — where those sit further than 9e-5 from (a) themselves (white-noise
+          features: the reference's fp32 rounding, as at cfg 3), their deviation + the mode's bound / 10 is allowed on top."""
     case, z = G.load("g15_cfg5_shape")
     cfg, W, sc = G.inputs(case)
     dec = make_decoder(cfg, W)
@@ -59,12 +62,31 @@ def test_golden_cfg5_shape_teacher_forced(mode, tol):
         dec.attention_mode = mode
     dec.prepare(*scene_args(sc))
     refs = G.forced_refs(z, cfg.TRANSFORMER.SCALE)
-    worst = {}
+    od = O.OracleDecoder(cfg, W, synth.SCANNET_MEAN_SIZES, dtype=torch.float64)
+    od.prepare(sc["tokens"], sc["camera"], sc["T_camera_pseudoCam"], sc["T_world_pseudoCam"], sc["T_world_local"])
+
+    def masked(a, b, k, key):
+        vm, cm = G.safe_mask(z, k)
+        err = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / np.maximum(1.0, np.abs(np.asarray(b, np.float64)))
+        m = vm & cm if key == "size_unnormalized" else (np.ones_like(vm) if key == "coord_pos" else vm)
+        return float(err[m].max()) if err[m].size else 0.0
+
+    worst = {"truth": 0.0, "golden": 0.0, "reference_self": 0.0}
     for k in range(12):
         out, _ = dec.iterate(k, dev(refs[k]))
-        w = G.compare(to_np(out), z, k, tol, what="g15 %s" % (mode or "split"))
-        worst = {kk: max(v, worst.get(kk, 0.0)) for kk, v in w.items()}
-    print("\ng15_cfg5_shape", mode or "split", worst)
+        o = to_np(out)
+        with torch.no_grad():
+            t, _, _ = od.iterate(torch.from_numpy(refs[k]).double(), k)
+        for key in G.KEYS:
+            g = z["it%d_%s" % (k, key)]
+            e_truth, e_gold, e_ref = masked(o[key], t[key].numpy(), k, key), masked(o[key], g, k, key), masked(g, t[key].numpy(), k, key)
+            worst = {"truth": max(worst["truth"], e_truth), "golden": max(worst["golden"], e_gold), "reference_self": max(worst["reference_self"], e_ref)}
+            assert e_truth < tol, (mode, k, key, e_truth)
+            assert e_gold < (tol if e_ref < 9e-5 else e_ref + tol / 10), (mode, k, key, e_gold, e_ref)
+    print("\ng15_cfg5_shape [%s]: HIP vs float64 %.2e | HIP vs reference fp32 golden %.2e | reference fp32 vs float64 %.2e"
+          % (mode or "split", worst["truth"], worst["golden"], worst["reference_self"]))
+    if mode is None:
+        assert worst["truth"] <= worst["reference_self"]           # closer to the truth than the reference's own fp32 run
     if mode == "fp16":
         assert not dec.fp16_range_exceeded()
 
