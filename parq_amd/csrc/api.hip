@@ -54,6 +54,8 @@ struct Arena {
     int64_t gn2_g, gn2_b;             // [2][C]
     int64_t heads3_w, heads3_b;       // [2][6][C], [2][6]: centre.8 padded to 6 rows | rotation.8
     int64_t mean_sizes, dim_t;
+    int64_t rowmajor_total;           // end of the tensors above = size of the gradient arena (same layout)
+    int64_t tile_off;                 // start of the tile-ordered mirror: matrix at offset o has its chain.hip copy at tile_off + o
     int64_t total;
 };
 
@@ -136,7 +138,10 @@ void build_arena(parq_ctx* c) {
     a.heads3_w = take(2 * 6 * C); a.heads3_b = take(12);
     a.mean_sizes = take((int64_t)c->cfg.num_mean_sizes * 3);
     a.dim_t = take(128);
-    a.total = off;
+    a.rowmajor_total = off;
+    // tile-ordered copies of the matrices the per-iteration chain multiplies by (LinearArgs::Wp): same offsets, shifted
+    a.tile_off = off;
+    a.total = 2 * off;
 }
 
 bool kvproj_big_on() {
@@ -317,6 +322,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     const float dp = train ? c->drop_p : 0.f;          // dropout exists in training only (nn.Dropout / MHA dropout)
     const float* A = c->arena;
     const Arena& ar = c->ar;
+    const float* TP = A + ar.tile_off;                 // tile-ordered mirror of the chain's matrices (LinearArgs::Wp)
     const int li = c->cfg.share_weights ? 0 : layer_num;
     const LayerW& L = ar.layers[li];
     const int B = sc->B, C = c->C, Q = c->Q, H = c->H, dh = c->dh, F = c->F;
@@ -332,9 +338,10 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     {
         Prof p(c, s, PARQ_PROF_LINEAR);
         LinearArgs a = lin(wi + ws.emb, 384, A + ar.pe0_w, 384, A + ar.pe0_b, wi + ws.pe_h, C, M, C, 384);
-        a.relu = 1;
+        a.relu = 1; a.Wp = TP + ar.pe0_w;
         HIPCHK(launch_linear(a, 1, s));
         a = lin(wi + ws.pe_h, C, A + ar.pe2_w, C, A + ar.pe2_b, wi + ws.pos, C, M, C, C);
+        a.Wp = TP + ar.pe2_w;
         HIPCHK(launch_linear(a, 1, s));
     }
     // K4+K5: project + sample (transformer_parq.py:321); also clears this iteration's GroupNorm moments
@@ -347,7 +354,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     {
         Prof p(c, s, PARQ_PROF_LINEAR);
         LinearArgs a = lin(wi + ws.tgt, C, A + L.self_in_w, C, A + L.self_in_b, wi + ws.qkv, 3 * C, M, 3 * C, C);
-        a.X2 = wi + ws.pos; a.ldx2 = C; a.x2_ncols = 2 * C;
+        a.X2 = wi + ws.pos; a.ldx2 = C; a.x2_ncols = 2 * C; a.Wp = TP + L.self_in_w;
         HIPCHK(launch_linear(a, 1, s));
     }
     FlashArgs fa;
@@ -356,7 +363,9 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     fa.out = wi + ws.sa; fa.out_batch = (int64_t)Q * C; fa.out_row = C;
     {
         Prof p(c, s, PARQ_PROF_SELF_ATTN);
-        if (dh <= 64) {
+        static const bool self_one = [] { const char* e = dev_env("PARQ_SELF_ONE_LAUNCH"); return !(e && e[0] == '0'); }();
+        if (dh <= 64 || (self_one && (dh == 128 || dh == 256) && Q <= 1024)) {
+            // one launch: a workgroup = 16 queries of one head against all keys (the 256-key self-attention has no long axis to split)
             HIPCHK(launch_self_attn(wi + ws.qkv, 3 * C, B, H, Q, dh, wi + ws.sa, C, s, train ? wi + ws.lse_s : nullptr, dp,
                                     c->site_seed(layer_num, 0)));
         } else {
@@ -381,13 +390,13 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         // xa = tgt + self_attn @ Wo  (pre-LayerNorm; norm1 is applied by the consumers)
         Prof p(c, s, PARQ_PROF_LINEAR);
         LinearArgs a = lin(wi + ws.sa, C, A + L.self_out_w, C, A + L.self_out_b, wi + ws.xa, C, M, C, C);
-        a.R = wi + ws.tgt; a.ldr = C;
+        a.R = wi + ws.tgt; a.ldr = C; a.Wp = TP + L.self_out_w;
         a.drop_p = dp; a.drop_seed = c->site_seed(layer_num, 1);
         HIPCHK(launch_linear(a, 1, s));
         // K7: cross-attention query = (norm1(xa) + pos) @ Wq; publishes norm1's row statistics
         a = lin(wi + ws.xa, C, A + L.cross_in_w, C, A + L.cross_in_b, wi + ws.qc, C, M, C, C);
         a.ln_gamma = A + L.n1_w; a.ln_beta = A + L.n1_b; a.ln_stats_out = wi + ws.ln1; a.norm_eps = eps;
-        a.X2 = wi + ws.pos; a.ldx2 = C; a.x2_ncols = C;
+        a.X2 = wi + ws.pos; a.ldx2 = C; a.x2_ncols = C; a.Wp = TP + L.cross_in_w;
         HIPCHK(launch_linear(a, 1, s));
     }
     {
@@ -416,18 +425,18 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         Prof p(c, s, PARQ_PROF_LINEAR);
         // xb = norm1(xa) + cross_attn @ Wo   (residual recomputed from the published statistics)
         LinearArgs a = lin(wi + ws.attn, C, A + L.cross_out_w, C, A + L.cross_out_b, wi + ws.xb, C, M, C, C);
-        a.R = wi + ws.xa; a.ldr = C; a.rln_stats = wi + ws.ln1; a.rln_gamma = A + L.n1_w; a.rln_beta = A + L.n1_b;
+        a.R = wi + ws.xa; a.ldr = C; a.rln_stats = wi + ws.ln1; a.rln_gamma = A + L.n1_w; a.rln_beta = A + L.n1_b; a.Wp = TP + L.cross_out_w;
         a.drop_p = dp; a.drop_seed = c->site_seed(layer_num, 3);
         HIPCHK(launch_linear(a, 1, s));
         // K8: FFN (transformer_parq.py:383-385): relu(norm2(xb) @ W1), publishes norm2's statistics
         a = lin(wi + ws.xb, C, A + L.lin1_w, C, A + L.lin1_b, wi + ws.ffn, F, M, F, C);
         a.ln_gamma = A + L.n2_w; a.ln_beta = A + L.n2_b; a.ln_stats_out = wi + ws.ln2; a.norm_eps = eps;
-        a.relu = 1;
+        a.relu = 1; a.Wp = TP + L.lin1_w;
         a.drop_p = dp; a.drop_seed = c->site_seed(layer_num, 4);
         HIPCHK(launch_linear(a, 1, s));
         // xc = norm2(xb) + ffn @ W2
         a = lin(wi + ws.ffn, F, A + L.lin2_w, F, A + L.lin2_b, wi + ws.xc, C, M, C, F);
-        a.R = wi + ws.xb; a.ldr = C; a.rln_stats = wi + ws.ln2; a.rln_gamma = A + L.n2_w; a.rln_beta = A + L.n2_b;
+        a.R = wi + ws.xb; a.ldr = C; a.rln_stats = wi + ws.ln2; a.rln_gamma = A + L.n2_w; a.rln_beta = A + L.n2_b; a.Wp = TP + L.lin2_w;
         a.drop_p = dp; a.drop_seed = c->site_seed(layer_num, 5);
         HIPCHK(launch_linear(a, 1, s));
         // K9: heads (transformer_parq.py:234-252; generic_mlp.py:85-110) on norm3(xc); the first layers of the
@@ -436,12 +445,13 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         a = lin(wi + ws.xc, C, A + ar.heads1_w, C, A + ar.heads1_b, wi + ws.h1, NH1, M, NH1, C);
         a.ln_gamma = A + L.n3_w; a.ln_beta = A + L.n3_b; a.norm_eps = eps;
         if (train) a.ln_stats_out = wi + ws.ln3;
+        if (NH1 % 16 == 0) a.Wp = TP + ar.heads1_w;
         a.gn_out_sums = gn1; a.gn_out_ncols = 2 * C; a.gn_out_group_cols = C; a.gn_out_rows_per_scene = Q; a.gn_out_ngroups = 2;
         HIPCHK(launch_linear(a, 1, s));
         a = lin(wi + ws.h1, NH1, A + ar.heads2_w, C, nullptr, wi + ws.h2, 2 * C, M, C, C);
         a.gn_sums = gn1; a.gn_gamma = A + ar.gn1_g; a.gn_beta = A + ar.gn1_b; a.norm_eps = eps;
         a.gn_rows_per_scene = Q; a.gn_ngroups = 2;
-        a.gX = C; a.gW = (int64_t)C * C; a.gY = C; a.gGamma = C;
+        a.gX = C; a.gW = (int64_t)C * C; a.gY = C; a.gGamma = C; a.Wp = TP + ar.heads2_w;
         a.gn_out_sums = gn2; a.gn_out_ncols = C; a.gn_out_group_cols = C; a.gn_out_rows_per_scene = Q; a.gn_out_ngroups = 2;
         HIPCHK(launch_linear(a, 2, s));
     }
@@ -906,6 +916,21 @@ int parq_pack_weights(parq_handle h, void* arena_v, size_t arena_bytes, parq_str
         return rc;
     // small host table kept in the handle, so the copy needs no synchronisation with the stream
     HIPCHK(hipMemcpyAsync(A + ar.dim_t, c->dim_t_host, sizeof(c->dim_t_host), hipMemcpyHostToDevice, s));
+    // tile-ordered mirror of the chain's matrices (chain.hip: one contiguous KB per wave-wide fragment load)
+    {
+        const int64_t T = ar.tile_off;
+        auto tile = [&](int64_t off, int64_t N, int64_t K) { return launch_pack_w_tiles(A + off, K, (int)N, (int)K, A + T + off, s); };
+        for (int li = 0; li < c->nl; ++li) {
+            const LayerW& L = c->ar.layers[li];
+            HIPCHK(tile(L.self_in_w, 3 * C, C)); HIPCHK(tile(L.self_out_w, C, C));
+            HIPCHK(tile(L.cross_in_w, C, C));                                      // the query rows (K / V rows: kv_whi / kv_wlo)
+            HIPCHK(tile(L.cross_out_w, C, C));
+            if (F % 16 == 0) { HIPCHK(tile(L.lin1_w, F, C)); HIPCHK(tile(L.lin2_w, C, F)); }
+        }
+        HIPCHK(tile(ar.pe0_w, C, 384)); HIPCHK(tile(ar.pe2_w, C, C));
+        if (c->NH1 % 16 == 0) HIPCHK(tile(ar.heads1_w, c->NH1, C));
+        HIPCHK(tile(ar.heads2_w, C, C)); HIPCHK(tile(ar.heads2_w + C * C, C, C));
+    }
     c->arena = A;
     c->packed = true;
     c->prepared = false;
@@ -1049,7 +1074,7 @@ int parq_k_dropout_mask(parq_handle h, int32_t iteration, int32_t site, int64_t 
     return PARQ_OK;
 }
 
-size_t parq_grad_arena_bytes(parq_handle h) { return h ? (size_t)h->ar.total * sizeof(float) : 0; }
+size_t parq_grad_arena_bytes(parq_handle h) { return h ? (size_t)h->ar.rowmajor_total * sizeof(float) : 0; }
 
 int parq_forward_train(parq_handle h, const parq_scene* scene, void* workspace, size_t workspace_bytes, const parq_outputs* outs,
                        parq_stream stream) {
@@ -1114,7 +1139,7 @@ int parq_backward(parq_handle h, const parq_scene* scene, void* workspace, size_
     hipStream_t s = (hipStream_t)stream;
     const int64_t M = (int64_t)scene->B * h->Q;
     const int64_t N = (int64_t)scene->V * scene->h * scene->w;
-    HIPCHK(hipMemsetAsync(grad_arena, 0, (size_t)h->ar.total * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(grad_arena, 0, (size_t)h->ar.rowmajor_total * sizeof(float), s));
     if (!ws.bwd_batched) HIPCHK(hipMemsetAsync(wsp + ws.g_kv, 0, (size_t)h->nl * scene->B * 2 * N * h->C * sizeof(float), s));
     if (d_tokens) HIPCHK(hipMemsetAsync(d_tokens, 0, (size_t)scene->B * N * h->C * sizeof(float), s));
     auto iter_io = [&](int k) {

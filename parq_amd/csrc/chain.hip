@@ -26,13 +26,14 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 enum : int { kProNone = 0, kProLN = 1, kProGN = 2 };
 enum : int { kResNone = 0, kResPlain = 1, kResLN = 2 };
 
-template <int K, int NT, int PRO, bool ADD2, bool BIAS, bool RELU, int RES, bool GNOUT>
-__global__ __launch_bounds__(256) void chain_linear_kernel(LinearArgs a) {
+template <int K, int NT, int PRO, bool ADD2, bool BIAS, bool RELU, int RES, bool GNOUT, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void chain_linear_kernel(LinearArgs a) {
     PARQ_TL_KERNEL(kTlLinear);
-    static_assert(K % 64 == 0 && NT >= 1 && NT <= 4, "tile shape");
-    constexpr int NCH = K / 64;                       // 16-wide K chunks per wave
-    __shared__ __attribute__((aligned(16))) float red[4 * NT * 4 * 64];   // [wave][sub-tile][acc reg][lane]
-    __shared__ float lnred[4 * 16 * 2];
+    static_assert(K % (16 * NWV) == 0 && NT >= 1 && NT <= 4 && (NWV == 4 || NWV == 8), "tile shape");
+    constexpr int NCH = K / (16 * NWV);               // 16-wide K chunks per wave
+    constexpr int CS = 16 * NWV;                      // the workgroup's K step per chunk (wave w takes columns w*16 .. w*16+15 of it)
+    __shared__ __attribute__((aligned(16))) float red[NWV * NT * 4 * 64];   // [wave][sub-tile][acc reg][lane]
+    __shared__ float lnred[NWV * 16 * 2];
 
     const int g = blockIdx.y;
     const int ntn = a.N / (16 * NT);
@@ -46,24 +47,36 @@ __global__ __launch_bounds__(256) void chain_linear_kernel(LinearArgs a) {
         m0 = (x * (a.M / 128) + loc / ntn) * 16;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
-    const int kbase = wave * 16 + kq * 4;             // lane's float4 of its c-th chunk sits at kbase + 64 c
+    const int kbase = wave * 16 + kq * 4;             // lane's float4 of its c-th chunk sits at kbase + CS c
 
     const float* xrow = a.X + g * a.gX + (int64_t)(m0 + li) * a.ldx + kbase;
-    const float* wbase = a.W + g * a.gW + (int64_t)(n0 + li) * a.ldw + kbase;
+    // W fragments: row-major rows (16 rows x 64 bytes per wave-wide load, row stride ldw: at ldw = 1024 floats the 16 segments of
+    // a load sit 4 KB apart) or the tile-ordered copy (one contiguous KB per load); both are affine in (sub-tile, chunk)
+    const float* wbase;
+    int64_t wt_stride, wc_stride;
+    if (a.Wp) {
+        wbase = a.Wp + g * a.gW + ((int64_t)(n0 / 16) * (K / 16) + wave) * 256 + lane * 4;
+        wt_stride = (int64_t)(K / 16) * 256;
+        wc_stride = NWV * 256;
+    } else {
+        wbase = a.W + g * a.gW + (int64_t)(n0 + li) * a.ldw + kbase;
+        wt_stride = 16 * a.ldw;
+        wc_stride = CS;
+    }
 
     // ---------------- every global load of the workgroup, before anything waits
     f32x4v av[NCH], bv[NT][NCH];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) av[c] = *reinterpret_cast<const f32x4v*>(xrow + c * 64);
+    for (int c = 0; c < NCH; ++c) av[c] = *reinterpret_cast<const f32x4v*>(xrow + c * CS);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) bv[t][c] = *reinterpret_cast<const f32x4v*>(wbase + (int64_t)t * 16 * a.ldw + c * 64);
+        for (int c = 0; c < NCH; ++c) bv[t][c] = *reinterpret_cast<const f32x4v*>(wbase + t * wt_stride + c * wc_stride);
     f32x4v x2v[ADD2 ? NCH : 1];
     if constexpr (ADD2) {
         const float* x2row = a.X2 + (int64_t)(m0 + li) * a.ldx2 + kbase;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) x2v[c] = *reinterpret_cast<const f32x4v*>(x2row + c * 64);
+        for (int c = 0; c < NCH; ++c) x2v[c] = *reinterpret_cast<const f32x4v*>(x2row + c * CS);
     }
     f32x4v pg[PRO != kProNone ? NCH : 1], pb[PRO != kProNone ? NCH : 1];
     float shift = 0.f;
@@ -71,16 +84,16 @@ __global__ __launch_bounds__(256) void chain_linear_kernel(LinearArgs a) {
     if constexpr (PRO == kProLN) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            pg[c] = *reinterpret_cast<const f32x4v*>(a.ln_gamma + kbase + c * 64);
-            pb[c] = *reinterpret_cast<const f32x4v*>(a.ln_beta + kbase + c * 64);
+            pg[c] = *reinterpret_cast<const f32x4v*>(a.ln_gamma + kbase + c * CS);
+            pb[c] = *reinterpret_cast<const f32x4v*>(a.ln_beta + kbase + c * CS);
         }
         shift = a.X[g * a.gX + (int64_t)(m0 + li) * a.ldx];
     }
     if constexpr (PRO == kProGN) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            pg[c] = *reinterpret_cast<const f32x4v*>(a.gn_gamma + g * a.gGamma + kbase + c * 64);
-            pb[c] = *reinterpret_cast<const f32x4v*>(a.gn_beta + g * a.gGamma + kbase + c * 64);
+            pg[c] = *reinterpret_cast<const f32x4v*>(a.gn_gamma + g * a.gGamma + kbase + c * CS);
+            pb[c] = *reinterpret_cast<const f32x4v*>(a.gn_beta + g * a.gGamma + kbase + c * CS);
         }
         const double* src = a.gn_sums + ((int64_t)((m0 / a.gn_rows_per_scene) * a.gn_ngroups + g) * kGnSlots + lane) * 2;
         gsm = src[0];
@@ -123,7 +136,7 @@ __global__ __launch_bounds__(256) void chain_linear_kernel(LinearArgs a) {
         lds_barrier();
         float Ssum = 0.f, Q2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { Ssum += lnred[(w * 16 + li) * 2 + 0]; Q2 += lnred[(w * 16 + li) * 2 + 1]; }
+        for (int w = 0; w < NWV; ++w) { Ssum += lnred[(w * 16 + li) * 2 + 0]; Q2 += lnred[(w * 16 + li) * 2 + 1]; }
         const float invK = 1.f / (float)K;
         const float dm = Ssum * invK;
         const float mean = shift + dm;
@@ -180,7 +193,7 @@ __global__ __launch_bounds__(256) void chain_linear_kernel(LinearArgs a) {
     const int src = (wave * 4 + (erow & 3)) * 64 + (erow >> 2) * 16 + ec;
     f32x4v sum = *reinterpret_cast<const f32x4v*>(&red[src]);
 #pragma unroll
-    for (int w = 1; w < 4; ++w) sum += *reinterpret_cast<const f32x4v*>(&red[src + w * NT * 256]);
+    for (int w = 1; w < NWV; ++w) sum += *reinterpret_cast<const f32x4v*>(&red[src + w * NT * 256]);
     f32x4v y;
     double gs = 0.0, gq = 0.0;
 #pragma unroll
@@ -207,6 +220,205 @@ __global__ __launch_bounds__(256) void chain_linear_kernel(LinearArgs a) {
             }
         }
     }
+}
+
+// The same tile for LONG contractions (K = 1024: the reference's shipped decoder width, config/train.yaml:37-56): the A rows of
+// the tile stay in registers for the whole contraction (K / 64 float4 per lane), the W rows are streamed in batches of 256
+// contraction steps, double-buffered: batch b + 1 (with its prologue parameters) is requested before the MFMAs of batch b are
+// issued.  Same prologues, epilogue and summation order as chain_linear_kernel.
+template <int K, int NT, int PRO, bool ADD2, bool BIAS, bool RELU, int RES, bool GNOUT>
+__global__ __launch_bounds__(256) void chain_linear_stream_kernel(LinearArgs a) {
+    PARQ_TL_KERNEL(kTlLinear);
+    static_assert(K % 256 == 0 && NT >= 1 && NT <= 4, "tile shape");
+    constexpr int NCH = K / 64;                       // 16-wide K chunks per wave
+    constexpr int BCH = 4;                            // chunks per streamed batch (256 contraction steps per workgroup)
+    constexpr int NB = NCH / BCH;
+    __shared__ __attribute__((aligned(16))) float red[4 * NT * 4 * 64];
+    __shared__ float lnred[4 * 16 * 2];
+
+    const int g = blockIdx.y;
+    const int ntn = a.N / (16 * NT);
+    const int n0 = (int)(blockIdx.x % ntn) * 16 * NT;
+    const int m0 = (int)(blockIdx.x / ntn) * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    const int kbase = wave * 16 + kq * 4;
+    const float* xrow = a.X + g * a.gX + (int64_t)(m0 + li) * a.ldx + kbase;
+    const float* wbase;
+    int64_t wt_stride, wc_stride;
+    if (a.Wp) {
+        wbase = a.Wp + g * a.gW + ((int64_t)(n0 / 16) * (K / 16) + wave) * 256 + lane * 4;
+        wt_stride = (int64_t)(K / 16) * 256;
+        wc_stride = 4 * 256;
+    } else {
+        wbase = a.W + g * a.gW + (int64_t)(n0 + li) * a.ldw + kbase;
+        wt_stride = 16 * a.ldw;
+        wc_stride = 64;
+    }
+    const float* x2row = ADD2 ? a.X2 + (int64_t)(m0 + li) * a.ldx2 + kbase : nullptr;
+    const float* pgp = PRO == kProLN ? a.ln_gamma + kbase : (PRO == kProGN ? a.gn_gamma + g * a.gGamma + kbase : nullptr);
+    const float* pbp = PRO == kProLN ? a.ln_beta + kbase : (PRO == kProGN ? a.gn_beta + g * a.gGamma + kbase : nullptr);
+
+    struct Batch { f32x4v w[NT][BCH]; f32x4v pg[BCH], pb[BCH], x2[BCH]; };
+    auto load_batch = [&](Batch& B, int b) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int c = 0; c < BCH; ++c) B.w[t][c] = *reinterpret_cast<const f32x4v*>(wbase + t * wt_stride + (b * BCH + c) * wc_stride);
+        if constexpr (PRO != kProNone) {
+#pragma unroll
+            for (int c = 0; c < BCH; ++c) {
+                B.pg[c] = *reinterpret_cast<const f32x4v*>(pgp + (b * BCH + c) * 64);
+                B.pb[c] = *reinterpret_cast<const f32x4v*>(pbp + (b * BCH + c) * 64);
+            }
+        }
+        if constexpr (ADD2) {
+#pragma unroll
+            for (int c = 0; c < BCH; ++c) B.x2[c] = *reinterpret_cast<const f32x4v*>(x2row + (b * BCH + c) * 64);
+        }
+    };
+
+    f32x4v av[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) av[c] = *reinterpret_cast<const f32x4v*>(xrow + c * 64);
+    Batch bt[2];
+    load_batch(bt[0], 0);
+    float shift = 0.f;
+    double gsm = 0.0, gsq = 0.0;
+    if constexpr (PRO == kProLN) shift = a.X[g * a.gX + (int64_t)(m0 + li) * a.ldx];
+    if constexpr (PRO == kProGN) {
+        const double* src = a.gn_sums + ((int64_t)((m0 / a.gn_rows_per_scene) * a.gn_ngroups + g) * kGnSlots + lane) * 2;
+        gsm = src[0];
+        gsq = src[1];
+    }
+    const int et = wave % NT;
+    const int erow = lane >> 2, ec = (lane & 3) * 4;
+    const int om = m0 + erow, on = n0 + et * 16 + ec;
+    f32x4v e_bias = {0.f, 0.f, 0.f, 0.f}, e_r = {0.f, 0.f, 0.f, 0.f}, e_rg = {1.f, 1.f, 1.f, 1.f}, e_rb = {0.f, 0.f, 0.f, 0.f};
+    float rmean = 0.f, rrstd = 1.f;
+    if constexpr (BIAS) e_bias = *reinterpret_cast<const f32x4v*>(a.bias + g * a.gBias + on);
+    if constexpr (RES != kResNone) e_r = *reinterpret_cast<const f32x4v*>(a.R + (int64_t)om * a.ldr + on);
+    if constexpr (RES == kResLN) {
+        e_rg = *reinterpret_cast<const f32x4v*>(a.rln_gamma + on);
+        e_rb = *reinterpret_cast<const f32x4v*>(a.rln_beta + on);
+        rmean = a.rln_stats[(int64_t)om * 2 + 0];
+        rrstd = a.rln_stats[(int64_t)om * 2 + 1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    float mean = 0.f, rstd = 1.f;
+    if constexpr (PRO == kProLN) {
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = av[c][e] - shift;
+                sm += d;
+                sq += d * d;
+            }
+        sm += __shfl_xor(sm, 16); sq += __shfl_xor(sq, 16);
+        sm += __shfl_xor(sm, 32); sq += __shfl_xor(sq, 32);
+        if (kq == 0) { lnred[(wave * 16 + li) * 2 + 0] = sm; lnred[(wave * 16 + li) * 2 + 1] = sq; }
+        lds_barrier();
+        float Ssum = 0.f, Q2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { Ssum += lnred[(w * 16 + li) * 2 + 0]; Q2 += lnred[(w * 16 + li) * 2 + 1]; }
+        const float invK = 1.f / (float)K;
+        const float dm = Ssum * invK;
+        mean = shift + dm;
+        const float var = fmaxf(Q2 * invK - dm * dm, 0.f);
+        rstd = 1.f / sqrtf(var + a.norm_eps);
+        if (a.ln_stats_out && n0 == 0 && wave == 0 && kq == 0) {
+            a.ln_stats_out[(int64_t)(m0 + li) * 2 + 0] = mean;
+            a.ln_stats_out[(int64_t)(m0 + li) * 2 + 1] = rstd;
+        }
+    }
+    if constexpr (PRO == kProGN) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { gsm += __shfl_xor(gsm, o); gsq += __shfl_xor(gsq, o); }
+        gn_mean_rstd(gsm, gsq, 1.0 / ((double)a.gn_rows_per_scene * (double)K), a.norm_eps, mean, rstd);
+    }
+    const bool add2 = ADD2 && n0 < a.x2_ncols;
+
+    f32x4v acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (b + 1 < NB) load_batch(bt[(b + 1) & 1], b + 1);          // in flight behind this batch's arithmetic
+        __builtin_amdgcn_sched_barrier(0);
+        const Batch& B = bt[b & 1];
+#pragma unroll
+        for (int c = 0; c < BCH; ++c) {
+            f32x4v x = av[b * BCH + c];
+            if constexpr (PRO == kProLN) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = (x[e] - mean) * rstd * B.pg[c][e] + B.pb[c][e];
+            }
+            if constexpr (ADD2) {
+                if (add2) x += B.x2[c];
+            }
+            if constexpr (PRO == kProGN) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float y = (x[e] - mean) * rstd * B.pg[c][e] + B.pb[c][e];
+                    x[e] = y > 0.f ? y : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], B.w[t][c][e], acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * NT + t) * 4 + r) * 64 + lane] = acc[t][r];
+    lds_barrier();
+    if (wave >= NT) return;
+    const int src = (wave * 4 + (erow & 3)) * 64 + (erow >> 2) * 16 + ec;
+    f32x4v sum = *reinterpret_cast<const f32x4v*>(&red[src]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) sum += *reinterpret_cast<const f32x4v*>(&red[src + w * NT * 256]);
+    f32x4v y;
+    double gs = 0.0, gq = 0.0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v = sum[e] + e_bias[e];
+        if constexpr (RELU) v = v > 0.f ? v : 0.f;
+        if constexpr (RES == kResPlain) v += e_r[e];
+        if constexpr (RES == kResLN) v += (e_r[e] - rmean) * rrstd * e_rg[e] + e_rb[e];
+        y[e] = v;
+        if constexpr (GNOUT) { gs += (double)v; gq += (double)v * (double)v; }
+    }
+    *reinterpret_cast<f32x4v*>(a.Y + g * a.gY + (int64_t)om * a.y_row + on) = y;
+    if constexpr (GNOUT) {
+        const int nt0 = n0 + wave * 16;
+        if (nt0 < a.gn_out_ncols) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { gs += __shfl_xor(gs, o); gq += __shfl_xor(gq, o); }
+            if (lane == 0) {
+                const int grp = (nt0 + g * a.N) / a.gn_out_group_cols;
+                const int slot = (int)((blockIdx.x * NT + wave) % kGnSlots);
+                double* dst = a.gn_out_sums + (((int64_t)(m0 / a.gn_out_rows_per_scene) * a.gn_out_ngroups + grp) * kGnSlots + slot) * 2;
+                atomicAdd(dst, gs);
+                atomicAdd(dst + 1, gq);
+            }
+        }
+    }
+}
+
+// tile-ordered copy of a row-major weight matrix (LinearArgs::Wp): thread = one float4 of the destination
+__global__ void pack_w_tiles_kernel(const float* __restrict__ W, int64_t ldw, int N, int K, float* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // float4 index in dst
+    if (i >= (int64_t)N * K / 4) return;
+    const int lane = (int)(i & 63);
+    const int64_t blk = i >> 6;
+    const int kc = (int)(blk % (K / 16)), nt = (int)(blk / (K / 16));
+    const int li = lane & 15, kq = lane >> 4;
+    *reinterpret_cast<f32x4v*>(dst + i * 4) = *reinterpret_cast<const f32x4v*>(W + (int64_t)(nt * 16 + li) * ldw + kc * 16 + kq * 4);
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -236,6 +448,24 @@ hipError_t go(const LinearArgs& a0, int groups, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <int K, int NT, int PRO, bool ADD2, bool BIAS, bool RELU, int RES, bool GNOUT>
+hipError_t go8(const LinearArgs& a0, int groups, hipStream_t s) {          // 8 waves split K: twice the loads in flight per CU
+    LinearArgs a = a0;
+    a.tile_map = 0;
+    const dim3 grid((unsigned)((a.N / (16 * NT)) * (a.M / 16)), groups, 1);
+    hipLaunchKernelGGL((chain_linear_kernel<K, NT, PRO, ADD2, BIAS, RELU, RES, GNOUT, 8>), grid, dim3(512), 0, s, a);
+    return hipGetLastError();
+}
+
+template <int K, int NT, int PRO, bool ADD2, bool BIAS, bool RELU, int RES, bool GNOUT>
+hipError_t go_stream(const LinearArgs& a0, int groups, hipStream_t s) {
+    LinearArgs a = a0;
+    a.tile_map = 0;
+    const dim3 grid((unsigned)((a.N / (16 * NT)) * (a.M / 16)), groups, 1);
+    hipLaunchKernelGGL((chain_linear_stream_kernel<K, NT, PRO, ADD2, BIAS, RELU, RES, GNOUT>), grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 // column sub-tiles per workgroup for an N-wide launch: the widest of {1, 2, 3, 4} that divides N / 16 (and the addend / moment
 // boundaries) while the grid still has at least ~3/4 of a workgroup per CU at one scene
 int pick_nt(const LinearArgs& a, int want) {
@@ -254,7 +484,10 @@ int pick_nt(const LinearArgs& a, int want) {
 //   pe1 (384 -> C, ReLU) | pe2 | self in-proj (+pos on the q, k columns) | self out-proj (+tgt) | cross q-proj (LN1, +pos) |
 //   cross out-proj (+LN1(xa)) | FFN1 (LN2, ReLU) | FFN2 (K = F, +LN2(xb)) | heads layer 1 (LN3, moments) | heads layer 2 (GN, moments)
 // returns hipErrorNotSupported when no instantiation matches (the caller then launches the generic kernel).
-hipError_t launch_chain_linear(const LinearArgs& a, int groups, hipStream_t s) {
+hipError_t launch_chain_linear(const LinearArgs& a_in, int groups, hipStream_t s) {
+    static const bool wp_off = [] { const char* e = dev_env("PARQ_CHAIN_WPACK"); return e && e[0] == '0'; }();
+    LinearArgs a = a_in;
+    if (wp_off || (a.Wp && (!al16(a.Wp) || a.ldw != a.K))) a.Wp = nullptr;     // the tile-ordered copy mirrors a dense [N][K] matrix
     // shape / layout conditions of the specialised kernel
     if (a.M % 16 != 0 || a.N % 16 != 0) return hipErrorNotSupported;
     if (a.relu_mask || a.drop_p > 0.f || a.rows_per_batch != a.M || a.col_blk != a.N) return hipErrorNotSupported;
@@ -305,7 +538,44 @@ hipError_t launch_chain_linear(const LinearArgs& a, int groups, hipStream_t s) {
         PARQ_NT_SWITCH(nt, 256, kProGN, false, false, false, kResNone, true)
     }
 #undef PARQ_NT_SWITCH
+    // ---- K = 1024 (the reference's shipped DEC_DIM): streamed-W kernel.  Sub-tiles: 4 (64 columns per workgroup: at one scene
+    // N = 1024 gives 256 workgroups) where the addend / moment boundaries allow it
+    static const int nt_big = [] { const char* e = dev_env("PARQ_CHAIN_NT_K1024"); return e ? atoi(e) : 4; }();
+    // K = 1024 forms: "stream" (default; W double-buffered in 256-step batches, 4 waves: measured 1.55 ms of linears per shipped-size
+    // forward) or "8w" (8 waves split K, everything in flight at once: 1.66 ms)
+    static const bool stream_env = [] { const char* e = dev_env("PARQ_CHAIN_K1024"); return !(e && e[0] == '8'); }();
+#define PARQ_STREAM(PRO, ADD2, BIAS, RELU, RES, GNOUT)                                                          \
+    {                                                                                                           \
+        /* 8-wave form: 256 registers per lane — LayerNorm prologues (gamma, beta per lane) leave room for 3 sub-tiles, 2 with an addend */ \
+        const int nt = pick_nt(a, stream_env || PRO != kProLN ? nt_big : (ADD2 ? 2 : (nt_big < 3 ? nt_big : 3)));       \
+        if (!stream_env) {                                                                                      \
+            if (nt == 4) return go8<1024, 4, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s);                  \
+            if (nt == 3) return go8<1024, 3, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s);                  \
+            if (nt == 2) return go8<1024, 2, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s);                  \
+            return go8<1024, 1, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s);                               \
+        }                                                                                                       \
+        if (nt == 4) return go_stream<1024, 4, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s);                \
+        if (nt == 3) return go_stream<1024, 3, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s);                \
+        if (nt == 2) return go_stream<1024, 2, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s);                \
+        return go_stream<1024, 1, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s);                             \
+    }
+    if (is(1024, kProNone, false, true, false, kResNone, false)) PARQ_STREAM(kProNone, false, true, false, kResNone, false)     // pe2
+    if (is(1024, kProNone, true, true, false, kResNone, false)) PARQ_STREAM(kProNone, true, true, false, kResNone, false)       // self in-proj
+    if (is(1024, kProNone, false, true, false, kResPlain, false)) PARQ_STREAM(kProNone, false, true, false, kResPlain, false)   // self out-proj
+    if (is(1024, kProLN, true, true, false, kResNone, false)) PARQ_STREAM(kProLN, true, true, false, kResNone, false)           // cross q-proj
+    if (is(1024, kProNone, false, true, false, kResLN, false)) PARQ_STREAM(kProNone, false, true, false, kResLN, false)         // cross out-proj
+    if (is(1024, kProLN, false, true, true, kResNone, false)) PARQ_STREAM(kProLN, false, true, true, kResNone, false)           // FFN1
+    if (is(1024, kProLN, false, true, false, kResNone, true)) PARQ_STREAM(kProLN, false, true, false, kResNone, true)           // heads layer 1
+    if (is(1024, kProGN, false, false, false, kResNone, true)) PARQ_STREAM(kProGN, false, false, false, kResNone, true)         // heads layer 2
+#undef PARQ_STREAM
     return hipErrorNotSupported;
+}
+
+hipError_t launch_pack_w_tiles(const float* W, int64_t ldw, int N, int K, float* dst, hipStream_t s) {
+    if (N % 16 != 0 || K % 16 != 0 || ldw % 4 != 0) return hipErrorInvalidValue;
+    const int64_t n4 = (int64_t)N * K / 4;
+    hipLaunchKernelGGL(pack_w_tiles_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, W, ldw, N, K, dst);
+    return hipGetLastError();
 }
 
 PARQ_TL_DEFINE_SETTER(tl_set_chain)

@@ -253,12 +253,16 @@ struct LinearArgs {
     double* gn_out_sums; int gn_out_ncols; int gn_out_group_cols; int gn_out_rows_per_scene; int gn_out_ngroups;
     // grouped launch: blockIdx.y = g adds these element offsets
     int64_t gX, gW, gBias, gY, gGamma;
+    // chain.hip only: the same matrix in tile order (launch_pack_w_tiles): block (n / 16, k / 16) = 1 KB holding element (n % 16,
+    // k % 16) at float ((k % 16) / 4 * 16 + n % 16) * 4 + k % 4, i.e. one wave-wide float4 load = one contiguous KB.  nullptr: read W.
+    const float* Wp;
     int tile_map;                       // chain.hip only: 1 = the workgroups of a row block run on one XCD (set by launch_chain_linear)
 };
 hipError_t launch_linear(const LinearArgs& a, int groups, hipStream_t s);
 // chain.hip: compile-time specialised kernels for the launches of one decoder iteration; hipErrorNotSupported = no instantiation
 // matches this launch (launch_linear then uses the generic kernel)
 hipError_t launch_chain_linear(const LinearArgs& a, int groups, hipStream_t s);
+hipError_t launch_pack_w_tiles(const float* W, int64_t ldw, int N, int K, float* dst, hipStream_t s);   // N % 16 == K % 16 == 0
 
 // ------------------------------------------------------------------ attention
 struct FlashArgs {

@@ -332,12 +332,11 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(FlashArgs a) {
 //     exactly the B operand P^T[key][q] of O^T = V^T P^T when MFMA step (s, r) contracts over
 //     key = s*16 + 4*kq + r: probabilities never leave registers.  Its A operand V[key][d = 16 dt + j]
 //     is a lane-contiguous scalar load.
-template <int DH>
-__global__ __launch_bounds__(512) void self_attn_kernel(const float* __restrict__ qkv, int64_t row_stride, int H, int L,
+template <int DH, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void self_attn_kernel(const float* __restrict__ qkv, int64_t row_stride, int H, int L,
                                                         float* __restrict__ out, int64_t out_row, float* __restrict__ lse,
                                                         float drop_p, uint32_t drop_seed) {
     PARQ_TL_KERNEL(kTlSelfAttn);
-    constexpr int NW = 8;
     constexpr int NDT = DH / 16;                 // 16-wide d sub-tiles of O^T
     constexpr int NC = DH / 16;                  // float4 chunks of a Q / K row per lane
     typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -460,7 +459,7 @@ __global__ __launch_bounds__(512) void self_attn_kernel(const float* __restrict_
         Ls[wave * 16 + lj] = l_run;
     }
     __syncthreads();
-    for (int idx = tid; idx < 16 * DH; idx += 512) {
+    for (int idx = tid; idx < 16 * DH; idx += NW * 64) {
         const int qq = idx / DH;
         const int d = idx - qq * DH;
         float mmax = -INFINITY;
@@ -617,17 +616,26 @@ hipError_t merge_dh(const FlashArgs& a, hipStream_t s) {
 template <int DH>
 static hipError_t launch_self_dh(const float* qkv, int64_t row_stride, int B, int H, int L, float* out, int64_t out_row,
                                  hipStream_t s, float* lse, float drop_p, uint32_t drop_seed) {
-    const size_t lds = ((size_t)8 * DH * 17 + 2 * 8 * 16) * sizeof(float);
-    hipLaunchKernelGGL((self_attn_kernel<DH>), dim3(ceil_div(L, 16), B * H), dim3(512), lds, s, qkv, row_stride, H, L, out,
+    // head dims up to 64: 8 waves (two per SIMD); 128 / 256: 4 waves, one per SIMD, so that a wave may hold the Q / K / V fragments
+    // of a 32-key block and the whole O^T accumulator in the unified register file
+    constexpr int NW = DH <= 64 ? 8 : 4;
+    const size_t lds = ((size_t)NW * DH * 17 + 2 * NW * 16) * sizeof(float);
+    if (lds > 64 * 1024) {
+        static DynLdsOnce once;
+        if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&self_attn_kernel<DH, NW>), lds); e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((self_attn_kernel<DH, NW>), dim3(ceil_div(L, 16), B * H), dim3(NW * 64), lds, s, qkv, row_stride, H, L, out,
                        out_row, lse, drop_p, drop_seed);
     return hipGetLastError();
 }
 
-// qkv: (B, L, row_stride) with q | k | v at column offsets 0, H*dh, 2*H*dh.  dh in {32, 64}.
+// qkv: (B, L, row_stride) with q | k | v at column offsets 0, H*dh, 2*H*dh.  dh in {32, 64, 128, 256}.
 hipError_t launch_self_attn(const float* qkv, int64_t row_stride, int B, int H, int L, int dh, float* out,
                             int64_t out_row, hipStream_t s, float* lse, float drop_p, uint32_t drop_seed) {
     if (dh == 64) return launch_self_dh<64>(qkv, row_stride, B, H, L, out, out_row, s, lse, drop_p, drop_seed);
     if (dh == 32) return launch_self_dh<32>(qkv, row_stride, B, H, L, out, out_row, s, lse, drop_p, drop_seed);
+    if (dh == 128) return launch_self_dh<128>(qkv, row_stride, B, H, L, out, out_row, s, lse, drop_p, drop_seed);
+    if (dh == 256) return launch_self_dh<256>(qkv, row_stride, B, H, L, out, out_row, s, lse, drop_p, drop_seed);
     return hipErrorInvalidValue;
 }
 
