@@ -146,6 +146,25 @@ int parq_iterate(parq_handle h, const parq_scene *scene, void *workspace, size_t
                  int32_t layer_num, const float *ref_in, const parq_outputs *outs, float *ref_out,
                  parq_stream stream);
 
+/* Intra-scene view sharding ("split-N"; no reference analogue — the reference holds all views of a scene in one
+ * process, model/transformer_parq.py:129-161, 377-380).  A scene whose K/V stream is too large or too slow for one GPU (BASELINE
+ * cfg 5: 20 views of 240x320 features = 1.5 M keys) is split by VIEWS: every rank calls parq_prepare with ITS views (tokens,
+ * camera, poses of those views only: the K/V projection and cache are sharded) and runs each iteration in three phases around
+ * two small exchanges the caller performs with its own collective library (RCCL all-reduce / all-gather over xGMI):
+ *   phase 0  position MLP, project + sample of the local views      -> xchg_out: [B*Q*C undivided sums | B*Q valid-view counts]
+ *            caller: SUM all-reduce of that buffer over the ranks
+ *   phase 1  xchg_in = the reduced buffer -> view mean; self-attention block; cross-attention over the local keys
+ *                                                                   -> xchg_out: [B*Q*C outputs | B*H*pad32(Q) log2 log-sum-exp]
+ *            caller: all-gather of that buffer (rank-major)
+ *   phase 2  xchg_in = the nranks gathered records -> merged attention; out-proj, FFN, heads, decode: outs, ref_out
+ * Everything outside the two sharded stages is computed redundantly and identically on every rank.
+ * parq_shard_exchange_floats(h, B, which): floats of the phase-0 (which = 0) / phase-1 (which = 1) record.
+ * ref_in / outs / ref_out as in parq_iterate (pass the same ref_in to all three phases). */
+size_t parq_shard_exchange_floats(parq_handle h, int32_t B, int32_t which);
+int parq_iterate_sharded(parq_handle h, const parq_scene *scene, void *workspace, size_t workspace_bytes, int32_t layer_num,
+                         int32_t phase, const float *ref_in, const parq_outputs *outs, float *ref_out, const float *xchg_in,
+                         float *xchg_out, int32_t nranks, parq_stream stream);
+
 /* Introspection for parity tests: where a named intermediate of the last parq_iterate lives
  * inside the workspace (offset and element count in floats).  Names: "T_camera_local_f64" and
  * "gn_sums_f64" (float64 payloads), "kv_cache", "ref", "ref_next", "posemb", "pos_feat", "tgt",

@@ -135,7 +135,7 @@ def bilinear_zeros_align(feat, u, v):
     return out
 
 
-def project_and_sample(tokens, ref_denorm, T_cl, cam, h, w, reference_ops=False):
+def project_and_sample(tokens, ref_denorm, T_cl, cam, h, w, reference_ops=False, raw=False):
     """model/transformer_parq.py:129-161.  tokens (B,N,C) channels-last,
     ref_denorm (B,Q,3) in the local frame, T_cl/cam (B,V,·).  Returns the
     view-averaged pixel-aligned features (B,Q,C), pixel coords, validity."""
@@ -159,6 +159,8 @@ def project_and_sample(tokens, ref_denorm, T_cl, cam, h, w, reference_ops=False)
         f = torch.stack([bilinear_zeros_align(feat[b], u[b], v[b]) for b in range(B)])
     f = f.sum(dim=1)                                           # ALL views summed
     cnt = valid.sum(dim=1)
+    if raw:                                                    # view-sharded scenes: the undivided sum and the valid-view count
+        return f, cnt, p2d, valid
     cnt = torch.where(cnt == 0, torch.ones_like(cnt), cnt)     # divide by max(#valid, 1)
     return f / cnt.unsqueeze(-1).to(f.dtype), p2d, valid
 
@@ -185,6 +187,21 @@ def mha(query, key, value, in_w, in_b, out_w, out_b, H, reference_ops=False):
     a = torch.softmax((q * (1.0 / math.sqrt(dh))) @ k.transpose(-1, -2), dim=-1)
     o = (a @ v).transpose(1, 2).reshape(B, L, C)
     return F.linear(o, out_w, out_b)
+
+
+def cross_attention_shard(query, memory, in_w, in_b, H):
+    """The cross-attention of ``mha`` restricted to the keys of ``memory`` (a shard of the scene's tokens), before the output
+    projection: returns the shard-normalised output (B,H,L,dh) and the natural-log log-sum-exp of the shard's scores (B,H,L) —
+    what the ranks of a view-sharded scene exchange (parq_amd/parallel.py merge_attention_shards)."""
+    B, L, C = query.shape
+    S = memory.shape[1]
+    dh = C // H
+    q = F.linear(query, in_w[:C], in_b[:C]).view(B, L, H, dh).transpose(1, 2)
+    k = F.linear(memory, in_w[C:2 * C], in_b[C:2 * C]).view(B, S, H, dh).transpose(1, 2)
+    v = F.linear(memory, in_w[2 * C:], in_b[2 * C:]).view(B, S, H, dh).transpose(1, 2)
+    sc = (q * (1.0 / math.sqrt(dh))) @ k.transpose(-1, -2)
+    lse = torch.logsumexp(sc, dim=-1)
+    return torch.softmax(sc, dim=-1) @ v, lse
 
 
 def head_mlp(x_bcq, Wd, prefix):
@@ -288,6 +305,32 @@ class OracleDecoder:
         nxt = normalize(out["center_unnormalized"], self.T.SCALE)     # :331-332 (detached)
         return out, nxt, {"pos": pos, "tgt": tgt, "x": x, "p2d": p2d, "valid": valid,
                           "x1": self._x1, "x2": self._x2, "cross_out": self._cross}
+
+    def iterate_sharded(self, ref, layer_num, merge_sample, merge_attention):
+        """``iterate`` for a rank that holds only SOME views of the scene (``prepare`` was called with those views): the sampled
+        feature sums / valid-view counts and the cross-attention over the local keys go through the two merge callbacks
+        (parq_amd/parallel.py merge_sample_sums / merge_attention_shards); everything else is as in ``iterate`` / ``layer``.
+        No reference analogue (the reference keeps a scene in one process): the single-process ``iterate`` is the truth."""
+        W, H = self.W, self.T.DEC_HEADS
+        li = 0 if self.T.SHARE_WEIGHTS else layer_num
+        d = "parq_module.decoder.position_encoder."
+        pos = F.linear(F.relu(F.linear(pos2posemb3d(ref), W[d + "0.weight"], W[d + "0.bias"])), W[d + "2.weight"], W[d + "2.bias"])
+        sums, cnt, _, _ = project_and_sample(self.tokens, denormalize(ref, self.T.SCALE), self.T_cl, self.cam, self.h, self.w, raw=True)
+        tgt = merge_sample(sums, cnt)
+        p = "parq_module.decoder.layers.%d." % li
+        q = tgt + pos
+        t2 = mha(q, q, tgt, W[p + "self_attn.in_proj_weight"], W[p + "self_attn.in_proj_bias"],
+                 W[p + "self_attn.out_proj.weight"], W[p + "self_attn.out_proj.bias"], H)
+        x = layer_norm(tgt + t2, W[p + "norm1.weight"], W[p + "norm1.bias"])
+        o, lse = cross_attention_shard(x + pos, self.tokens, W[p + "multihead_attn.in_proj_weight"], W[p + "multihead_attn.in_proj_bias"], H)
+        o = merge_attention(o, lse)                                      # (B,H,L,dh) over ALL keys of the scene
+        B, L = o.shape[0], o.shape[2]
+        t2 = F.linear(o.transpose(1, 2).reshape(B, L, -1), W[p + "multihead_attn.out_proj.weight"], W[p + "multihead_attn.out_proj.bias"])
+        x = layer_norm(x + t2, W[p + "norm2.weight"], W[p + "norm2.bias"])
+        t2 = F.linear(F.relu(F.linear(x, W[p + "linear1.weight"], W[p + "linear1.bias"])), W[p + "linear2.weight"], W[p + "linear2.bias"])
+        x = layer_norm(x + t2, W[p + "norm3.weight"], W[p + "norm3.bias"])
+        out = box_heads(x, ref, W, self.T.SCALE, self.mean_sizes)
+        return out, normalize(out["center_unnormalized"], self.T.SCALE)
 
     def forward(self, tokens, camera, T_cp, T_wp, T_wl, forced_refs=None):
         """Free-running (forced_refs=None) or teacher-forced: iteration k is fed

@@ -314,10 +314,19 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
 
 // shift: offset (floats) of this iteration's activation copy (0 in inference: every iteration reuses one set);
 // emb_next: where the decode kernel leaves the next iteration's sine embedding; train: also keep what backward needs
+// View-sharded scenes (parq_iterate_sharded): an iteration runs in three phases around two exchanges the caller performs.
+//   phase bit 1: position MLP + project/sample of the LOCAL views -> `out` = [M*C undivided sums | M valid-view counts]
+//   phase bit 2: `in` = the ranks' pairs added up -> tgt; self-attention block, cross-attention over the LOCAL keys ->
+//                `out` = [M*C normalised attention outputs | B*H*Lq_pad log2 log-sum-exp rows]
+//   phase bit 4: `in` = `nranks` such records -> merged attention output; cross out-proj, FFN, heads, decode
+// mask 7 with in = out = nullptr is the ordinary iteration.
+struct ShardIO { int mask = 7; const float* in = nullptr; float* out = nullptr; int nranks = 1; };
+
 int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& ws, int layer_num, const float* ref,
                bool emb_valid, const parq_outputs* o, float* ref_out, hipStream_t s, int64_t shift = 0,
-               float* emb_next = nullptr, bool train = false) {
+               float* emb_next = nullptr, bool train = false, const ShardIO& sh = ShardIO()) {
     float* wi = wsp + shift;
+    const bool sharded = sh.mask != 7;
     if (!emb_next) emb_next = wi + ws.emb;
     const float dp = train ? c->drop_p : 0.f;          // dropout exists in training only (nn.Dropout / MHA dropout)
     const float* A = c->arena;
@@ -332,6 +341,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     double* gn1 = reinterpret_cast<double*>(wi + ws.gn_sums);          // [B][2][2]
     double* gn2 = gn1 + (int64_t)B * 4 * kGnSlots;
 
+    if (sh.mask & 1) {
     // K3: sine embedding (written by the previous iteration's decode kernel when chained) -> position MLP
     // (transformer_parq.py:317)
     if (!emb_valid) { Prof p(c, s, PARQ_PROF_OTHER); HIPCHK(launch_posemb(ref, A + ar.dim_t, M, wi + ws.emb, s)); }
@@ -348,8 +358,12 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     {
         Prof p(c, s, PARQ_PROF_PROJECT_SAMPLE);
         HIPCHK(launch_project_sample_f64(sc->tokens, reinterpret_cast<const double*>(wsp + ws.T_cl), sc->camera, ref, c->sb,
-                                         B, sc->V, sc->h, sc->w, C, Q, wi + ws.tgt, o->coord_pos, gn1, B * 8 * kGnSlots, s));
+                                         B, sc->V, sc->h, sc->w, C, Q, sharded ? sh.out : wi + ws.tgt, o->coord_pos, gn1, B * 8 * kGnSlots, s,
+                                         sharded ? sh.out + (int64_t)M * C : nullptr));
     }
+    }   // phase bit 1
+    if (sh.mask & 2) {
+    if (sharded) { Prof p(c, s, PARQ_PROF_PROJECT_SAMPLE); HIPCHK(launch_sample_finalize(sh.in, sh.in + (int64_t)M * C, M, C, wi + ws.tgt, s)); }
     // K6: self-attention, q = k = tgt + pos, v = tgt (transformer_parq.py:372-376)
     {
         Prof p(c, s, PARQ_PROF_LINEAR);
@@ -383,8 +397,8 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
             HIPCHK(launch_flash_merge(fa, s));
         }
     }
-    fa.out = wi + ws.attn;
-    fa.lse = train ? wi + ws.lse_c : nullptr;
+    fa.out = sharded ? sh.out : wi + ws.attn;
+    fa.lse = sharded ? sh.out + (int64_t)M * C : (train ? wi + ws.lse_c : nullptr);
     fa.drop_p = dp; fa.drop_seed = c->site_seed(layer_num, 2);
     {
         // xa = tgt + self_attn @ Wo  (pre-LayerNorm; norm1 is applied by the consumers)
@@ -421,6 +435,13 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         }
     }
     { Prof p(c, s, PARQ_PROF_MERGE); HIPCHK(launch_flash_merge(fa, s)); }
+    }   // phase bit 2
+    if (!(sh.mask & 4)) return PARQ_OK;
+    if (sharded) {
+        Prof p(c, s, PARQ_PROF_MERGE);
+        const int64_t rec = (int64_t)M * C + (int64_t)B * H * flash_lq_pad(Q);
+        HIPCHK(launch_attn_combine(sh.in, sh.nranks, rec, B, H, Q, flash_lq_pad(Q), dh, wi + ws.attn, s));
+    }
     {
         Prof p(c, s, PARQ_PROF_LINEAR);
         // xb = norm1(xa) + cross_attn @ Wo   (residual recomputed from the published statistics)
@@ -976,6 +997,44 @@ int parq_iterate(parq_handle h, const parq_scene* scene, void* workspace, size_t
     const size_t rb = (size_t)scene->B * h->Q * 3 * sizeof(float);
     HIPCHK(hipMemcpyAsync(wsp + ws.ref, wsp + ws.ref_next, rb, hipMemcpyDeviceToDevice, s));
     if (ref_out) HIPCHK(hipMemcpyAsync(ref_out, wsp + ws.ref_next, rb, hipMemcpyDeviceToDevice, s));
+    return PARQ_OK;
+}
+
+size_t parq_shard_exchange_floats(parq_handle h, int32_t B, int32_t which) {
+    if (!h || B < 1 || which < 0 || which > 1) return 0;
+    const int64_t M = (int64_t)B * h->Q;
+    return (size_t)(which == 0 ? M * h->C + M : M * h->C + (int64_t)B * h->H * flash_lq_pad(h->Q));
+}
+
+int parq_iterate_sharded(parq_handle h, const parq_scene* scene, void* workspace, size_t workspace_bytes, int32_t layer_num,
+                         int32_t phase, const float* ref_in, const parq_outputs* outs, float* ref_out, const float* xchg_in,
+                         float* xchg_out, int32_t nranks, parq_stream stream) {
+    if (!h || !workspace) return fail(PARQ_ERR_ARG, "NULL argument");
+    if (!h->packed || !h->prepared) return fail(PARQ_ERR_STATE, "parq_prepare must be called first");
+    int rc = check_scene(h, scene);
+    if (rc) return rc;
+    rc = check_outs(outs);
+    if (rc) return rc;
+    if (layer_num < 0 || layer_num >= h->I) return fail(PARQ_ERR_ARG, "layer_num out of range");
+    if (phase < 0 || phase > 2) return fail(PARQ_ERR_ARG, "phase must be 0, 1 or 2");
+    if ((phase <= 1 && !xchg_out) || (phase >= 1 && !xchg_in)) return fail(PARQ_ERR_ARG, "exchange buffer is NULL for phase %d", phase);
+    if (phase == 2 && nranks < 1) return fail(PARQ_ERR_ARG, "nranks must be >= 1");
+    Workspace ws;
+    carve_workspace(h, scene->B, scene->V, scene->h, scene->w, &ws);
+    if (workspace_bytes < (size_t)ws.total * sizeof(float)) return fail(PARQ_ERR_WORKSPACE, "workspace too small");
+    float* wsp = (float*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    const float* ref = ref_in ? ref_in : wsp + ws.ref;
+    ShardIO sh;
+    sh.mask = 1 << phase; sh.in = xchg_in; sh.out = xchg_out; sh.nranks = nranks;
+    rc = do_iterate(h, scene, wsp, ws, layer_num, ref, ref_in == nullptr && h->emb_valid, outs, wsp + ws.ref_next, s, 0, nullptr, false, sh);
+    if (rc) return rc;
+    if (phase == 2) {
+        h->emb_valid = true;                   // the decode kernel left pos2posemb3d(ref_next) in the workspace
+        const size_t rb = (size_t)scene->B * h->Q * 3 * sizeof(float);
+        HIPCHK(hipMemcpyAsync(wsp + ws.ref, wsp + ws.ref_next, rb, hipMemcpyDeviceToDevice, s));
+        if (ref_out) HIPCHK(hipMemcpyAsync(ref_out, wsp + ws.ref_next, rb, hipMemcpyDeviceToDevice, s));
+    }
     return PARQ_OK;
 }
 

@@ -111,7 +111,7 @@ template <int NCH, typename TPose>
 __global__ __launch_bounds__(1024) void project_sample_kernel(
     const float* __restrict__ tokens, const TPose* __restrict__ T_cl, const float* __restrict__ cam,
     const float* __restrict__ ref, ScaleBox sb, int V, int h, int w, int C, int Q, float* __restrict__ tgt,
-    float* __restrict__ coord_pos, double* __restrict__ zero_f64, int zero_n) {
+    float* __restrict__ coord_pos, double* __restrict__ zero_f64, int zero_n, float* __restrict__ raw_count) {
     PARQ_TL_KERNEL(kTlProjectSample);
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [nwv][C] + [nwv] counts
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += gridDim.x * blockDim.x)
@@ -220,7 +220,10 @@ __global__ __launch_bounds__(1024) void project_sample_kernel(
     __syncthreads();
     int total = 0;
     for (int i = 0; i < nwv; ++i) total += cnt[i];
-    const float denom = (float)(total > 0 ? total : 1);
+    // view-sharded scenes (raw_count != nullptr): this rank holds only some of the scene's views, so it leaves the UNDIVIDED sum of
+    // its views in tgt and its number of valid views in raw_count; the caller adds the ranks' pairs and divides (sample_finalize)
+    const float denom = raw_count ? 1.f : (float)(total > 0 ? total : 1);
+    if (raw_count && threadIdx.x == 0) raw_count[bq] = (float)total;
     for (int c4 = threadIdx.x; c4 < C4; c4 += blockDim.x) {
         f32x4 s = reinterpret_cast<const f32x4*>(part)[c4];
         for (int i = 1; i < nwv; ++i) s += reinterpret_cast<const f32x4*>(part + (size_t)i * C)[c4];
@@ -621,17 +624,17 @@ hipError_t launch_posemb(const float* ref, const float* dim_t, int M, float* emb
 template <typename TPose>
 static hipError_t launch_project_sample_t(const float* tokens, const TPose* T_cl, const float* cam, const float* ref,
                                           ScaleBox sb, int B, int V, int h, int w, int C, int Q, float* tgt,
-                                          float* coord_pos, double* zero_f64, int zero_n, hipStream_t s) {
+                                          float* coord_pos, double* zero_f64, int zero_n, hipStream_t s, float* raw_count = nullptr) {
     if (C % 4 != 0 || C > 256 * kMaxChunks || V <= 0) return hipErrorInvalidValue;
     const int nwv = V < 16 ? V : 16;
     const size_t smem = (size_t)nwv * C * sizeof(float) + (size_t)nwv * sizeof(int) + (size_t)V * 32 + 16;      // partial sums, counts, footprints
     const int nch = ceil_div(C / 4, 64);
     dim3 grid(B * Q), block(nwv * 64);
     switch (nch) {
-        case 1: hipLaunchKernelGGL((project_sample_kernel<1, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n); break;
-        case 2: hipLaunchKernelGGL((project_sample_kernel<2, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n); break;
-        case 3: hipLaunchKernelGGL((project_sample_kernel<3, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n); break;
-        default: hipLaunchKernelGGL((project_sample_kernel<4, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n); break;
+        case 1: hipLaunchKernelGGL((project_sample_kernel<1, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n, raw_count); break;
+        case 2: hipLaunchKernelGGL((project_sample_kernel<2, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n, raw_count); break;
+        case 3: hipLaunchKernelGGL((project_sample_kernel<3, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n, raw_count); break;
+        default: hipLaunchKernelGGL((project_sample_kernel<4, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n, raw_count); break;
     }
     return hipGetLastError();
 }
@@ -644,8 +647,50 @@ hipError_t launch_project_sample(const float* tokens, const float* T_cl, const f
 
 hipError_t launch_project_sample_f64(const float* tokens, const double* T_cl, const float* cam, const float* ref,
                                      ScaleBox sb, int B, int V, int h, int w, int C, int Q, float* tgt,
-                                     float* coord_pos, double* zero_f64, int zero_n, hipStream_t s) {
-    return launch_project_sample_t<double>(tokens, T_cl, cam, ref, sb, B, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n, s);
+                                     float* coord_pos, double* zero_f64, int zero_n, hipStream_t s, float* raw_count) {
+    return launch_project_sample_t<double>(tokens, T_cl, cam, ref, sb, B, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n, s, raw_count);
+}
+
+// ---- view-sharded scenes (parq_iterate_sharded): the two merges around the exchanges
+// tgt[m][c] = sum[m][c] / max(count[m], 1): the ranks' sample sums and valid-view counts were added by the caller's all-reduce
+__global__ void sample_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ counts, int64_t M, int C, float* __restrict__ tgt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * C) return;
+    const float n = counts[i / C];
+    tgt[i] = sums[i] / (n > 0.f ? n : 1.f);
+}
+// attention outputs of R key shards -> the attention output over all keys.  parts: R records of [M*C normalised outputs |
+// B*H*Lq_pad log2-domain log-sum-exp rows]; weight of shard r for (scene b, head h, query q) = 2^(lse_r - max_r lse)
+__global__ void attn_combine_kernel(const float* __restrict__ parts, int R, int64_t rec, int B, int H, int Q, int Lq_pad, int dh,
+                                    float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int C = H * dh;
+    const int64_t M = (int64_t)B * Q;
+    if (i >= M * C) return;
+    const int64_t m = i / C;
+    const int c = (int)(i - m * C);
+    const int b = (int)(m / Q), q = (int)(m - (int64_t)b * Q), hh = c / dh;
+    const int64_t lrow = M * C + ((int64_t)(b * H + hh)) * Lq_pad + q;
+    float mx = -INFINITY;
+    for (int r = 0; r < R; ++r) mx = fmaxf(mx, parts[r * rec + lrow]);
+    float num = 0.f, den = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const float wgt = __builtin_amdgcn_exp2f(parts[r * rec + lrow] - mx);
+        num += wgt * parts[r * rec + i];
+        den += wgt;
+    }
+    out[i] = num / den;
+}
+
+hipError_t launch_sample_finalize(const float* sums, const float* counts, int64_t M, int C, float* tgt, hipStream_t s) {
+    hipLaunchKernelGGL(sample_finalize_kernel, dim3((unsigned)((M * C + 255) / 256)), dim3(256), 0, s, sums, counts, M, C, tgt);
+    return hipGetLastError();
+}
+hipError_t launch_attn_combine(const float* parts, int R, int64_t rec, int B, int H, int Q, int Lq_pad, int dh, float* out, hipStream_t s) {
+    if (R < 1) return hipErrorInvalidValue;
+    const int64_t n = (int64_t)B * Q * H * dh;
+    hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, parts, R, rec, B, H, Q, Lq_pad, dh, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_layernorm(const float* X, const float* gamma, const float* beta, float* Y, int M, int C, float eps,

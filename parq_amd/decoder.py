@@ -570,6 +570,55 @@ class PARQDecoder(nn.Module):
                    "parq_iterate")
         return dict(zip(OUTPUT_KEYS, outs)), nxt
 
+    @torch.no_grad()
+    def forward_view_sharded(self, intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw=None,
+                             group=None, forced_refs=None):
+        """Intra-scene view sharding (SURVEY.md 8e "split-N"; include/parq_hip.h parq_iterate_sharded): THIS rank passes only
+        ITS views of every scene — tokens (B, V_local*h*w, C) and the camera / pose tensors of those views — and every rank of
+        ``group`` (default process group) calls this collectively.  The K/V projection, the K/V cache and the cross-attention
+        stream are sharded over the ranks; per iteration two small collectives merge the ranks' contributions (SUM all-reduce
+        of the sampled-feature sums and valid-view counts; all-gather of the per-shard attention outputs and log-sum-exp rows:
+        ~0.27 MB each at Q = 256, d = 256), everything else is computed identically on every rank.  Returns the same list of
+        per-iteration dicts as ``forward`` on every rank.  ``forced_refs``: optional list of (B,Q,3) reference points per
+        iteration (teacher forcing, as ``iterate``)."""
+        import torch.distributed as dist
+        self._check_mode()
+        sc, keep, dev = self._scene(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
+        self._ensure_packed(dev)
+        lib, h = _lib.load(), self._handle()
+        ws = self._workspace(sc.B, sc.V, sc.h, sc.w, dev)
+        _lib.check(lib.parq_prepare(h, C.byref(sc), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()), "parq_prepare")
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        na, nb = lib.parq_shard_exchange_floats(h, sc.B, 0), lib.parq_shard_exchange_floats(h, sc.B, 1)
+        xa = torch.empty(na, dtype=torch.float32, device=dev)
+        xb = torch.empty(nb, dtype=torch.float32, device=dev)
+        gathered = torch.empty(world * nb, dtype=torch.float32, device=dev)
+        results = []
+        for k in range(self.num_layers):
+            outs = self._alloc_outputs((sc.B, self.num_queries), dev)
+            po = _lib.ParqOutputs(*[_lib.ptr(t) for t in outs])
+            ref_in = None
+            if forced_refs is not None:
+                ref_in = forced_refs[k].to(device=dev, dtype=torch.float32).contiguous()
+
+            def phase(ph, xin, xout, _po=po, _ref=ref_in, _k=k):
+                _lib.check(lib.parq_iterate_sharded(h, C.byref(sc), _lib.ptr(ws), ws.numel() * 4, _k, ph, _lib.ptr(_ref), C.byref(_po),
+                                                    None, _lib.ptr(xin), _lib.ptr(xout), world, _lib.stream_ptr()),
+                           "parq_iterate_sharded(phase %d)" % ph)
+
+            phase(0, None, xa)
+            if world > 1:
+                dist.all_reduce(xa, group=group)
+            phase(1, xa, xb)
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, xb, group=group)
+            else:
+                gathered.copy_(xb)
+            phase(2, gathered, None)
+            results.append(dict(zip(OUTPUT_KEYS, outs)))
+        self._range_poll()
+        return results
+
     def fp16_range_exceeded(self):
         """True if the last prepare() / forward() / forward_train() saw a token, K or V element outside the fp16 range while
         building the 16-bit K/V cache (synchronises; meaningful in the "split" and "fp16" modes).  Outputs of such a call are

@@ -109,3 +109,41 @@ def all_reduce_mean_scalars(metrics: dict, device=None) -> dict:
     for k, total, count in zip(keys, t[0].tolist(), t[1].tolist()):
         out[k] = total / count                    # count >= 1: the key came from somebody's list
     return out
+
+
+# ---------------------------------------------------------------------------------------------------- intra-scene view sharding
+# The two merges of a view-sharded scene (include/parq_hip.h parq_iterate_sharded; PARQDecoder.forward_view_sharded) as plain
+# tensor arithmetic on any device.  The GPU path performs them inside the library (sample_finalize / attn_combine kernels) after the
+# same collectives; these host-level forms define the protocol and are what the CPU test runs over gloo with the oracle as compute.
+
+def merge_sample_sums(sums: torch.Tensor, counts: torch.Tensor, group=None) -> torch.Tensor:
+    """View mean of the sampled features over ALL views of a scene from this rank's undivided sums (B,Q,C) and valid-view counts
+    (B,Q): SUM all-reduce of both, then sum / max(count, 1) (model/transformer_parq.py:157-160)."""
+    sums, counts = sums.clone(), counts.clone().to(sums.dtype)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(sums, group=group)
+        dist.all_reduce(counts, group=group)
+    return sums / torch.where(counts > 0, counts, torch.ones_like(counts)).unsqueeze(-1)
+
+
+def merge_attention_shards(out: torch.Tensor, lse: torch.Tensor, group=None) -> torch.Tensor:
+    """Attention output over all keys from per-rank outputs over disjoint key shards: out (B,H,L,dh) normalised within the
+    shard, lse (B,H,L) natural-log log-sum-exp of the shard's scores.  All-gather, then the softmax-weighted combination
+    sum_r exp(lse_r - max) out_r / sum_r exp(lse_r - max)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return out
+    world = dist.get_world_size(group)
+    outs = [torch.empty_like(out) for _ in range(world)]
+    lses = [torch.empty_like(lse) for _ in range(world)]
+    dist.all_gather(outs, out.contiguous(), group=group)
+    dist.all_gather(lses, lse.contiguous(), group=group)
+    L = torch.stack(lses)                                   # (R,B,H,L)
+    wgt = torch.exp(L - L.max(dim=0, keepdim=True).values)
+    return (torch.stack(outs) * wgt.unsqueeze(-1)).sum(0) / wgt.sum(0).unsqueeze(-1)
+
+
+def view_shard(num_views: int, rank: int, world: int):
+    """Views [lo, hi) of a scene owned by ``rank`` (contiguous, balanced; every rank needs at least one view)."""
+    if num_views < world:
+        raise ValueError("view sharding needs at least one view per rank (%d views, %d ranks)" % (num_views, world))
+    return shard_range(num_views, rank, world)
