@@ -44,6 +44,9 @@ struct LayerW {
     int64_t lin1_w, lin1_b, lin2_w, lin2_b;
     int64_t n1_w, n1_b, n2_w, n2_b, n3_w, n3_b;
     int64_t kv_whi, kv_wlo;           // fp16 hi/lo split of in_proj_weight[C:3C] (each 2C*C halfs)
+    // the position MLP's last layer folded into its two consumers (inference): (x + h W2^T + b2) W^T = x W^T + h (W W2)^T + W b2
+    int64_t self_in_w2, self_in_b2;   // [3C][C]: rows < 2C = W_qk W2, rows >= 2C zero | [3C]: b_qk + W_qk b2, then b_v
+    int64_t cross_q_w2, cross_q_b2;   // [C][C] = W_q W2 | [C] = b_q + W_q b2
 };
 struct Arena {
     std::vector<LayerW> layers;
@@ -128,6 +131,8 @@ void build_arena(parq_ctx* c) {
         L.lin2_w = take(C * F); L.lin2_b = take(C);
         L.n1_w = take(C); L.n1_b = take(C); L.n2_w = take(C); L.n2_b = take(C); L.n3_w = take(C); L.n3_b = take(C);
         L.kv_whi = take(C * C); L.kv_wlo = take(C * C);
+        L.self_in_w2 = take(3 * C * C); L.self_in_b2 = take(3 * C);
+        L.cross_q_w2 = take(C * C); L.cross_q_b2 = take(C);
     }
     a.refpoint = take(Q * 3);
     a.pe0_w = take(C * 384); a.pe0_b = take(C); a.pe2_w = take(C * C); a.pe2_b = take(C);
@@ -340,6 +345,26 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     const float eps = 1e-5f;
     double* gn1 = reinterpret_cast<double*>(wi + ws.gn_sums);          // [B][2][2]
     double* gn2 = gn1 + (int64_t)B * 4 * kGnSlots;
+    // the two consumers of the position embedding, either with pos = pe2(h) as an addend on the A operand (reference order,
+    // transformer_parq.py:372-377) or with the position MLP's last layer folded into them (second operand pair h x (W W2)^T)
+    auto self_in_args = [&](bool fold) {
+        LinearArgs a = lin(wi + ws.tgt, C, A + L.self_in_w, C, A + (fold ? L.self_in_b2 : L.self_in_b), wi + ws.qkv, 3 * C, M, 3 * C, C);
+        a.ldx2 = C; a.x2_ncols = 2 * C; a.Wp = TP + L.self_in_w;
+        if (fold) { a.X2 = wi + ws.pe_h; a.W2 = A + L.self_in_w2; a.W2p = TP + L.self_in_w2; }
+        else a.X2 = wi + ws.pos;
+        return a;
+    };
+    auto cross_q_args = [&](bool fold) {
+        LinearArgs a = lin(wi + ws.xa, C, A + L.cross_in_w, C, A + (fold ? L.cross_q_b2 : L.cross_in_b), wi + ws.qc, C, M, C, C);
+        a.ln_gamma = A + L.n1_w; a.ln_beta = A + L.n1_b; a.ln_stats_out = wi + ws.ln1; a.norm_eps = eps;
+        a.ldx2 = C; a.x2_ncols = C; a.Wp = TP + L.cross_in_w;
+        if (fold) { a.X2 = wi + ws.pe_h; a.W2 = A + L.cross_q_w2; a.W2p = TP + L.cross_q_w2; }
+        else a.X2 = wi + ws.pos;
+        return a;
+    };
+    // inference only (the backward differentiates the unfolded layers from the stashed pos), and only where chain.hip has the kernels
+    static const bool fold_off = [] { const char* e = dev_env("PARQ_FOLD_POS"); return e && e[0] == '0'; }();
+    const bool fold_pos = !train && !fold_off && chain_linear_supported(self_in_args(true), 1) && chain_linear_supported(cross_q_args(true), 1);
 
     if (sh.mask & 1) {
     // K3: sine embedding (written by the previous iteration's decode kernel when chained) -> position MLP
@@ -350,9 +375,11 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         LinearArgs a = lin(wi + ws.emb, 384, A + ar.pe0_w, 384, A + ar.pe0_b, wi + ws.pe_h, C, M, C, 384);
         a.relu = 1; a.Wp = TP + ar.pe0_w;
         HIPCHK(launch_linear(a, 1, s));
-        a = lin(wi + ws.pe_h, C, A + ar.pe2_w, C, A + ar.pe2_b, wi + ws.pos, C, M, C, C);
-        a.Wp = TP + ar.pe2_w;
-        HIPCHK(launch_linear(a, 1, s));
+        if (!fold_pos) {
+            a = lin(wi + ws.pe_h, C, A + ar.pe2_w, C, A + ar.pe2_b, wi + ws.pos, C, M, C, C);
+            a.Wp = TP + ar.pe2_w;
+            HIPCHK(launch_linear(a, 1, s));
+        }
     }
     // K4+K5: project + sample (transformer_parq.py:321); also clears this iteration's GroupNorm moments
     {
@@ -367,8 +394,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     // K6: self-attention, q = k = tgt + pos, v = tgt (transformer_parq.py:372-376)
     {
         Prof p(c, s, PARQ_PROF_LINEAR);
-        LinearArgs a = lin(wi + ws.tgt, C, A + L.self_in_w, C, A + L.self_in_b, wi + ws.qkv, 3 * C, M, 3 * C, C);
-        a.X2 = wi + ws.pos; a.ldx2 = C; a.x2_ncols = 2 * C; a.Wp = TP + L.self_in_w;
+        LinearArgs a = self_in_args(fold_pos);
         HIPCHK(launch_linear(a, 1, s));
     }
     FlashArgs fa;
@@ -408,9 +434,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         a.drop_p = dp; a.drop_seed = c->site_seed(layer_num, 1);
         HIPCHK(launch_linear(a, 1, s));
         // K7: cross-attention query = (norm1(xa) + pos) @ Wq; publishes norm1's row statistics
-        a = lin(wi + ws.xa, C, A + L.cross_in_w, C, A + L.cross_in_b, wi + ws.qc, C, M, C, C);
-        a.ln_gamma = A + L.n1_w; a.ln_beta = A + L.n1_b; a.ln_stats_out = wi + ws.ln1; a.norm_eps = eps;
-        a.X2 = wi + ws.pos; a.ldx2 = C; a.x2_ncols = C; a.Wp = TP + L.cross_in_w;
+        a = cross_q_args(fold_pos);
         HIPCHK(launch_linear(a, 1, s));
     }
     {
@@ -937,6 +961,14 @@ int parq_pack_weights(parq_handle h, void* arena_v, size_t arena_bytes, parq_str
         return rc;
     // small host table kept in the handle, so the copy needs no synchronisation with the stream
     HIPCHK(hipMemcpyAsync(A + ar.dim_t, c->dim_t_host, sizeof(c->dim_t_host), hipMemcpyHostToDevice, s));
+    // position MLP layer 2 folded into the self-attention q/k projection and the cross-attention q projection (used by the inference
+    // iteration when chain.hip takes the launch): float64-accumulated products, rounded once
+    for (int li = 0; li < c->nl; ++li) {
+        const LayerW& L = c->ar.layers[li];
+        HIPCHK(launch_fold_pos_weights(A + L.self_in_w, A + L.self_in_b, A + ar.pe2_w, A + ar.pe2_b, (int)(2 * C), (int)C, A + L.self_in_w2, A + L.self_in_b2, s));
+        HIPCHK(hipMemcpyAsync(A + L.self_in_b2 + 2 * C, A + L.self_in_b + 2 * C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, s));   // b_v unchanged
+        HIPCHK(launch_fold_pos_weights(A + L.cross_in_w, A + L.cross_in_b, A + ar.pe2_w, A + ar.pe2_b, (int)C, (int)C, A + L.cross_q_w2, A + L.cross_q_b2, s));
+    }
     // tile-ordered mirror of the chain's matrices (chain.hip: one contiguous KB per wave-wide fragment load)
     {
         const int64_t T = ar.tile_off;
@@ -946,6 +978,7 @@ int parq_pack_weights(parq_handle h, void* arena_v, size_t arena_bytes, parq_str
             HIPCHK(tile(L.self_in_w, 3 * C, C)); HIPCHK(tile(L.self_out_w, C, C));
             HIPCHK(tile(L.cross_in_w, C, C));                                      // the query rows (K / V rows: kv_whi / kv_wlo)
             HIPCHK(tile(L.cross_out_w, C, C));
+            HIPCHK(tile(L.self_in_w2, 3 * C, C)); HIPCHK(tile(L.cross_q_w2, C, C));
             if (F % 16 == 0) { HIPCHK(tile(L.lin1_w, F, C)); HIPCHK(tile(L.lin2_w, C, F)); }
         }
         HIPCHK(tile(ar.pe0_w, C, 384)); HIPCHK(tile(ar.pe2_w, C, C));

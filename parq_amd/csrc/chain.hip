@@ -26,7 +26,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 enum : int { kProNone = 0, kProLN = 1, kProGN = 2 };
 enum : int { kResNone = 0, kResPlain = 1, kResLN = 2 };
 
-template <int K, int NT, int PRO, bool ADD2, bool BIAS, bool RELU, int RES, bool GNOUT, int NWV = 4>
+template <int K, int NT, int PRO, int ADD2, bool BIAS, bool RELU, int RES, bool GNOUT, int NWV = 4>
 __global__ __launch_bounds__(NWV * 64) void chain_linear_kernel(LinearArgs a) {
     PARQ_TL_KERNEL(kTlLinear);
     static_assert(K % (16 * NWV) == 0 && NT >= 1 && NT <= 4 && (NWV == 4 || NWV == 8), "tile shape");
@@ -73,10 +73,18 @@ __global__ __launch_bounds__(NWV * 64) void chain_linear_kernel(LinearArgs a) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) bv[t][c] = *reinterpret_cast<const f32x4v*>(wbase + t * wt_stride + c * wc_stride);
     f32x4v x2v[ADD2 ? NCH : 1];
-    if constexpr (ADD2) {
+    f32x4v b2v[ADD2 == 2 ? NT : 1][ADD2 == 2 ? NCH : 1];
+    if constexpr (ADD2 != 0) {
         const float* x2row = a.X2 + (int64_t)(m0 + li) * a.ldx2 + kbase;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) x2v[c] = *reinterpret_cast<const f32x4v*>(x2row + c * CS);
+    }
+    if constexpr (ADD2 == 2) {                        // second weight matrix, same addressing as W
+        const float* w2base = a.Wp ? a.W2p + (wbase - a.Wp) : a.W2 + (wbase - a.W);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) b2v[t][c] = *reinterpret_cast<const f32x4v*>(w2base + t * wt_stride + c * wc_stride);
     }
     f32x4v pg[PRO != kProNone ? NCH : 1], pb[PRO != kProNone ? NCH : 1];
     float shift = 0.f;
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(NWV * 64) void chain_linear_kernel(LinearArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) av[c][e] = (av[c][e] - mean) * rstd * pg[c][e] + pb[c][e];
     }
-    if constexpr (ADD2) {
+    if constexpr (ADD2 == 1) {
         if (n0 < a.x2_ncols) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) av[c] += x2v[c];
@@ -181,6 +189,16 @@ __global__ __launch_bounds__(NWV * 64) void chain_linear_kernel(LinearArgs a) {
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][e], bv[t][c][e], acc[t], 0, 0, 0);
+    if constexpr (ADD2 == 2) {
+        if (n0 < a.x2_ncols) {                        // the second operand pair feeds the same accumulators
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x2v[c][e], b2v[t][c][e], acc[t], 0, 0, 0);
+        }
+    }
     // acc[t][r]: row 4 * (lane >> 4) + r, column lane & 15 of sub-tile t
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -226,10 +244,10 @@ __global__ __launch_bounds__(NWV * 64) void chain_linear_kernel(LinearArgs a) {
 // the tile stay in registers for the whole contraction (K / 64 float4 per lane), the W rows are streamed in batches of 256
 // contraction steps, double-buffered: batch b + 1 (with its prologue parameters) is requested before the MFMAs of batch b are
 // issued.  Same prologues, epilogue and summation order as chain_linear_kernel.
-template <int K, int NT, int PRO, bool ADD2, bool BIAS, bool RELU, int RES, bool GNOUT>
+template <int K, int NT, int PRO, int ADD2, bool BIAS, bool RELU, int RES, bool GNOUT>
 __global__ __launch_bounds__(256) void chain_linear_stream_kernel(LinearArgs a) {
     PARQ_TL_KERNEL(kTlLinear);
-    static_assert(K % 256 == 0 && NT >= 1 && NT <= 4, "tile shape");
+    static_assert(K % 256 == 0 && NT >= 1 && NT <= 4 && ADD2 != 2, "tile shape");
     constexpr int NCH = K / 64;                       // 16-wide K chunks per wave
     constexpr int BCH = 4;                            // chunks per streamed batch (256 contraction steps per workgroup)
     constexpr int NB = NCH / BCH;
@@ -254,7 +272,7 @@ __global__ __launch_bounds__(256) void chain_linear_stream_kernel(LinearArgs a) 
         wt_stride = 16 * a.ldw;
         wc_stride = 64;
     }
-    const float* x2row = ADD2 ? a.X2 + (int64_t)(m0 + li) * a.ldx2 + kbase : nullptr;
+    const float* x2row = ADD2 != 0 ? a.X2 + (int64_t)(m0 + li) * a.ldx2 + kbase : nullptr;
     const float* pgp = PRO == kProLN ? a.ln_gamma + kbase : (PRO == kProGN ? a.gn_gamma + g * a.gGamma + kbase : nullptr);
     const float* pbp = PRO == kProLN ? a.ln_beta + kbase : (PRO == kProGN ? a.gn_beta + g * a.gGamma + kbase : nullptr);
 
@@ -338,7 +356,7 @@ __global__ __launch_bounds__(256) void chain_linear_stream_kernel(LinearArgs a) 
         for (int o = 32; o > 0; o >>= 1) { gsm += __shfl_xor(gsm, o); gsq += __shfl_xor(gsq, o); }
         gn_mean_rstd(gsm, gsq, 1.0 / ((double)a.gn_rows_per_scene * (double)K), a.norm_eps, mean, rstd);
     }
-    const bool add2 = ADD2 && n0 < a.x2_ncols;
+    const bool add2 = ADD2 != 0 && n0 < a.x2_ncols;
 
     f32x4v acc[NT];
 #pragma unroll
@@ -421,16 +439,32 @@ __global__ void pack_w_tiles_kernel(const float* __restrict__ W, int64_t ldw, in
     *reinterpret_cast<f32x4v*>(dst + i * 4) = *reinterpret_cast<const f32x4v*>(W + (int64_t)(nt * 16 + li) * ldw + kc * 16 + kq * 4);
 }
 
+// pack-time fold of the position MLP's last layer into a consumer: thread = one element of out_w (float64 accumulation)
+__global__ void fold_pos_weights_kernel(const float* __restrict__ Wa, const float* __restrict__ ba, const float* __restrict__ W2,
+                                        const float* __restrict__ b2, int R, int C, float* __restrict__ out_w, float* __restrict__ out_b) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)R * C) return;
+    const int r = (int)(i / C), k = (int)(i - (int64_t)r * C);
+    double acc = 0.0;
+    for (int j = 0; j < C; ++j) acc += (double)Wa[(int64_t)r * C + j] * (double)W2[(int64_t)j * C + k];
+    out_w[i] = (float)acc;
+    if (k == 0) {
+        double b = (double)ba[r];
+        for (int j = 0; j < C; ++j) b += (double)Wa[(int64_t)r * C + j] * (double)b2[j];
+        out_b[r] = (float)b;
+    }
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // feature signature of a launch (what the template parameters must match)
-struct Sig { int K, pro; bool add2, bias, relu; int res; bool gnout; };
+struct Sig { int K, pro; int add2; bool bias, relu; int res; bool gnout; };
 
 Sig sig_of(const LinearArgs& a) {
     Sig s;
     s.K = a.K;
     s.pro = a.ln_gamma ? kProLN : (a.gn_sums ? kProGN : kProNone);
-    s.add2 = a.X2 != nullptr;
+    s.add2 = a.X2 == nullptr ? 0 : (a.W2 != nullptr ? 2 : 1);
     s.bias = a.bias != nullptr;
     s.relu = a.relu != 0;
     s.res = a.R ? (a.rln_stats ? kResLN : kResPlain) : kResNone;
@@ -438,8 +472,11 @@ Sig sig_of(const LinearArgs& a) {
     return s;
 }
 
-template <int K, int NT, int PRO, bool ADD2, bool BIAS, bool RELU, int RES, bool GNOUT>
+thread_local bool g_dry_run = false;      // chain_linear_supported: match the launch against the instantiations without launching
+
+template <int K, int NT, int PRO, int ADD2, bool BIAS, bool RELU, int RES, bool GNOUT>
 hipError_t go(const LinearArgs& a0, int groups, hipStream_t s) {
+    if (g_dry_run) return hipSuccess;
     static const int map_env = [] { const char* e = dev_env("PARQ_CHAIN_MAP"); return e ? atoi(e) : 0; }();
     LinearArgs a = a0;
     a.tile_map = (map_env == 1 && a.M % 128 == 0) ? 1 : 0;
@@ -448,8 +485,9 @@ hipError_t go(const LinearArgs& a0, int groups, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int K, int NT, int PRO, bool ADD2, bool BIAS, bool RELU, int RES, bool GNOUT>
+template <int K, int NT, int PRO, int ADD2, bool BIAS, bool RELU, int RES, bool GNOUT>
 hipError_t go8(const LinearArgs& a0, int groups, hipStream_t s) {          // 8 waves split K: twice the loads in flight per CU
+    if (g_dry_run) return hipSuccess;
     LinearArgs a = a0;
     a.tile_map = 0;
     const dim3 grid((unsigned)((a.N / (16 * NT)) * (a.M / 16)), groups, 1);
@@ -457,8 +495,9 @@ hipError_t go8(const LinearArgs& a0, int groups, hipStream_t s) {          // 8 
     return hipGetLastError();
 }
 
-template <int K, int NT, int PRO, bool ADD2, bool BIAS, bool RELU, int RES, bool GNOUT>
+template <int K, int NT, int PRO, int ADD2, bool BIAS, bool RELU, int RES, bool GNOUT>
 hipError_t go_stream(const LinearArgs& a0, int groups, hipStream_t s) {
+    if (g_dry_run) return hipSuccess;
     LinearArgs a = a0;
     a.tile_map = 0;
     const dim3 grid((unsigned)((a.N / (16 * NT)) * (a.M / 16)), groups, 1);
@@ -486,6 +525,9 @@ int pick_nt(const LinearArgs& a, int want) {
 // returns hipErrorNotSupported when no instantiation matches (the caller then launches the generic kernel).
 hipError_t launch_chain_linear(const LinearArgs& a_in, int groups, hipStream_t s) {
     static const bool wp_off = [] { const char* e = dev_env("PARQ_CHAIN_WPACK"); return e && e[0] == '0'; }();
+    // the latency-bound regime (one or a few scenes); above it the generic kernel's 32 x 32 tiles fill the chip
+    static const int chain_max_m = [] { const char* e = dev_env("PARQ_CHAIN_MAX_M"); return e ? atoi(e) : 1024; }();   // 0: generic kernel only
+    if (a_in.M > chain_max_m) return hipErrorNotSupported;
     LinearArgs a = a_in;
     if (wp_off || (a.Wp && (!al16(a.Wp) || a.ldw != a.K))) a.Wp = nullptr;     // the tile-ordered copy mirrors a dense [N][K] matrix
     // shape / layout conditions of the specialised kernel
@@ -496,13 +538,14 @@ hipError_t launch_chain_linear(const LinearArgs& a_in, int groups, hipStream_t s
     if (a.bias && !al16(a.bias)) return hipErrorNotSupported;
     if (a.X2 && (a.ldx2 % 4 != 0 || !al16(a.X2) || a.x2_ncols % 16 != 0)) return hipErrorNotSupported;
     if (a.R && (a.ldr % 4 != 0 || !al16(a.R))) return hipErrorNotSupported;
+    if (a.W2 && (!a.X2 || !al16(a.W2) || (a.Wp && !a.W2p))) return hipErrorNotSupported;
     if (a.rln_stats && (!al16(a.rln_gamma) || !al16(a.rln_beta))) return hipErrorNotSupported;
     if (a.ln_gamma && (a.gn_sums || !al16(a.ln_gamma) || !al16(a.ln_beta) || groups != 1)) return hipErrorNotSupported;
     if (a.gn_sums && (a.gn_rows_per_scene % 16 != 0 || !al16(a.gn_gamma) || !al16(a.gn_beta))) return hipErrorNotSupported;
     if (a.gn_out_sums && (a.gn_out_rows_per_scene % 16 != 0 || a.gn_out_ncols % 16 != 0 || a.gn_out_group_cols % 16 != 0))
         return hipErrorNotSupported;
     const Sig g = sig_of(a);
-    auto is = [&](int K, int pro, bool add2, bool bias, bool relu, int res, bool gnout) {
+    auto is = [&](int K, int pro, int add2, bool bias, bool relu, int res, bool gnout) {
         return g.K == K && g.pro == pro && g.add2 == add2 && g.bias == bias && g.relu == relu && g.res == res && g.gnout == gnout;
     };
     static const int nt_wide = [] { const char* e = dev_env("PARQ_CHAIN_NT_WIDE"); return e ? atoi(e) : 3; }();     // N = 768 / 528 launches
@@ -521,6 +564,11 @@ hipError_t launch_chain_linear(const LinearArgs& a_in, int groups, hipStream_t s
         const int nt = pick_nt(a, nt_inproj);
         PARQ_NT_SWITCH(nt, 256, kProNone, true, true, false, kResNone, false)
     }
+    if (is(256, kProNone, 2, true, false, kResNone, false)) {                                                                                      // self in-proj, folded pos MLP
+        const int nt = pick_nt(a, nt_inproj);
+        PARQ_NT_SWITCH(nt, 256, kProNone, 2, true, false, kResNone, false)
+    }
+    if (is(256, kProLN, 2, true, false, kResNone, false)) return go<256, 1, kProLN, 2, true, false, kResNone, false>(a, groups, s);                 // cross q-proj, folded pos MLP
     if (is(256, kProNone, false, true, false, kResPlain, false)) return go<256, 1, kProNone, false, true, false, kResPlain, false>(a, groups, s);  // self out-proj
     if (is(256, kProLN, true, true, false, kResNone, false)) return go<256, 1, kProLN, true, true, false, kResNone, false>(a, groups, s);          // cross q-proj
     if (is(256, kProNone, false, true, false, kResLN, false)) return go<256, 1, kProNone, false, true, false, kResLN, false>(a, groups, s);        // cross out-proj
@@ -576,6 +624,20 @@ hipError_t launch_pack_w_tiles(const float* W, int64_t ldw, int N, int K, float*
     const int64_t n4 = (int64_t)N * K / 4;
     hipLaunchKernelGGL(pack_w_tiles_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, W, ldw, N, K, dst);
     return hipGetLastError();
+}
+
+hipError_t launch_fold_pos_weights(const float* Wa, const float* ba, const float* W2, const float* b2, int R, int C, float* out_w, float* out_b,
+                                   hipStream_t s) {
+    const int64_t n = (int64_t)R * C;
+    hipLaunchKernelGGL(fold_pos_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Wa, ba, W2, b2, R, C, out_w, out_b);
+    return hipGetLastError();
+}
+
+bool chain_linear_supported(const LinearArgs& a, int groups) {
+    g_dry_run = true;
+    const hipError_t e = launch_chain_linear(a, groups, nullptr);
+    g_dry_run = false;
+    return e == hipSuccess;
 }
 
 PARQ_TL_DEFINE_SETTER(tl_set_chain)

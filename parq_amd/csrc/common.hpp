@@ -253,6 +253,10 @@ struct LinearArgs {
     double* gn_out_sums; int gn_out_ncols; int gn_out_group_cols; int gn_out_rows_per_scene; int gn_out_ngroups;
     // grouped launch: blockIdx.y = g adds these element offsets
     int64_t gX, gW, gBias, gY, gGamma;
+    // chain.hip only: a SECOND operand pair accumulated into the same output, Y += X2 @ W2^T, for output columns < x2_ncols (the
+    // position MLP's last layer folded into its consumers: (x + h W2^T + b2) W^T = x W^T + h (W W2)^T + W b2).  X2 / ldx2 above is then
+    // the second A operand (K columns) instead of an addend; W2 is [N][K] row-major with row stride ldw, W2p its tile-ordered copy.
+    const float* W2; const float* W2p;
     // chain.hip only: the same matrix in tile order (launch_pack_w_tiles): block (n / 16, k / 16) = 1 KB holding element (n % 16,
     // k % 16) at float ((k % 16) / 4 * 16 + n % 16) * 4 + k % 4, i.e. one wave-wide float4 load = one contiguous KB.  nullptr: read W.
     const float* Wp;
@@ -262,7 +266,10 @@ hipError_t launch_linear(const LinearArgs& a, int groups, hipStream_t s);
 // chain.hip: compile-time specialised kernels for the launches of one decoder iteration; hipErrorNotSupported = no instantiation
 // matches this launch (launch_linear then uses the generic kernel)
 hipError_t launch_chain_linear(const LinearArgs& a, int groups, hipStream_t s);
+bool chain_linear_supported(const LinearArgs& a, int groups);      // would launch_chain_linear take this launch?
 hipError_t launch_pack_w_tiles(const float* W, int64_t ldw, int N, int K, float* dst, hipStream_t s);   // N % 16 == K % 16 == 0
+// pack time: out_w[r][k] = sum_j Wa[r][j] W2[j][k], out_b[r] = ba[r] + sum_j Wa[r][j] b2[j]  (float64 accumulation), r < R; Wa [R][C], W2 [C][C]
+hipError_t launch_fold_pos_weights(const float* Wa, const float* ba, const float* W2, const float* b2, int R, int C, float* out_w, float* out_b, hipStream_t s);
 
 // ------------------------------------------------------------------ attention
 struct FlashArgs {

@@ -415,11 +415,11 @@ static int pick_tile(int64_t tiles32) {
 hipError_t launch_linear(const LinearArgs& a, int groups, hipStream_t s) {
     if (a.K % 16 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
     // the latency-bound regime (one or a few scenes): compile-time specialised kernels of the decoder chain (chain.hip)
-    static const int chain_max_m = [] { const char* e = dev_env("PARQ_CHAIN_MAX_M"); return e ? atoi(e) : 1024; }();   // 0: generic kernel only
-    if (a.M <= chain_max_m) {
+    {
         const hipError_t e = launch_chain_linear(a, groups, s);
         if (e != hipErrorNotSupported) return e;
     }
+    if (a.W2) return hipErrorInvalidValue;          // a second operand pair exists in chain.hip only (callers test chain_linear_supported)
     const int64_t tiles32 = (int64_t)ceil_div(a.N, 32) * ceil_div(a.M, 32) * groups;
     const int T = pick_tile(tiles32);
     const int64_t tiles = (int64_t)ceil_div(a.N, T) * ceil_div(a.M, T);

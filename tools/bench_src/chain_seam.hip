@@ -129,6 +129,41 @@ __global__ __launch_bounds__(256) void layer_id(const float* X, const float* W, 
 typedef void (*layer_fn)(const float*, const float*, const float*, float*, int);
 static layer_fn layer_table[14] = {layer_id<0>, layer_id<1>, layer_id<2>, layer_id<3>, layer_id<4>, layer_id<5>, layer_id<6>,
                                    layer_id<7>, layer_id<8>, layer_id<9>, layer_id<10>, layer_id<11>, layer_id<12>, layer_id<13>};
+// D: the same layer with BOTH operands and the output in tile order: 16 x 16 blocks of 1 KB, element (r, k) of block (rb, kc) at
+// float ((k % 16) / 4 * 16 + r) * 4 + k % 4 — every wave-wide float4 load / store is one contiguous KB instead of 16 segments of 64
+// bytes at the row stride (1 KB here, 4 KB at K = 1024: the segments of a load then share an L2 channel)
+__global__ __launch_bounds__(256) void layer_tiled(const float* Xt, const float* Wt, const float* bias, float* Yt, int map) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 256];
+    int rb, cb; tile_of(blockIdx.x, map, rb, cb);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x4 av[4], bv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        av[c] = *reinterpret_cast<const f32x4*>(Xt + ((size_t)(rb * 16 + wave + c * 4) * 64 + lane) * 4);
+        bv[c] = *reinterpret_cast<const f32x4*>(Wt + ((size_t)(cb * 16 + wave + c * 4) * 64 + lane) * 4);
+    }
+    const f32x4 bs = *reinterpret_cast<const f32x4*>(bias + cb * 16 + (tid & 3) * 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][e], bv[c][e], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    if (tid < 64) {
+        const int row = tid >> 2, c4 = (tid & 3) * 4;
+        const int src = (row & 3) * 64 + (row >> 2) * 16 + c4;
+        f32x4 s = *reinterpret_cast<const f32x4*>(&red[src]);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) s += *reinterpret_cast<const f32x4*>(&red[w * 256 + src]);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float y = s[e] + bs[e]; o[e] = y > 0.f ? y : 0.f; }
+        // output block (rb, cb) of the NEXT layer's A operand: (row, k = c4 .. c4 + 3) -> float ((c4 / 4) * 16 + row) * 4
+        *reinterpret_cast<f32x4*>(Yt + ((size_t)(rb * 16 + cb) * 64 + (c4 >> 2) * 16 + row) * 4) = o;
+    }
+}
 __global__ void empty_kernel(int) {}
 // keeps the device busy for `us` microseconds so that the host can enqueue the whole chain behind it: the timed region then
 // measures the DEVICE's dependent-dispatch rate, not the host's launch rate (3 - 4 us per hipLaunchKernelGGL)
@@ -327,6 +362,34 @@ int main(int argc, char** argv) {
             char nm[128];
             const float c = timeit(distinct, true), w = timeit(distinct, false);
             snprintf(nm, sizeof nm, "C launches of 14 DISTINCT kernels, 4 waves, map %d", map); report(nm, L, c, w, (L & 1) ? d1 : d0);
+        }
+    }
+    {   // D: tile-ordered operands.  Host packs W per layer and X0; the result is compared after un-tiling.
+        std::vector<float> hWt(hW.size()), hXt(hX.size());
+        auto tile_idx = [](int r, int k, int ncb) { return ((size_t)((r / 16) * ncb + k / 16) * 64 + ((k % 16) / 4) * 16 + r % 16) * 4 + k % 4; };
+        for (int s2 = 0; s2 < LMAX; ++s2)
+            for (int n = 0; n < C; ++n)
+                for (int k = 0; k < C; ++k) hWt[(size_t)s2 * C * C + tile_idx(n, k, C / 16)] = hW[((size_t)s2 * C + n) * C + k];
+        for (int m = 0; m < M; ++m)
+            for (int k = 0; k < C; ++k) hXt[tile_idx(m, k, C / 16)] = hX[(size_t)m * C + k];
+        float *dWt, *dUn;
+        CK(hipMalloc(&dWt, hWt.size() * 4)); CK(hipMalloc(&dUn, hX.size() * 4));
+        CK(hipMemcpy(dWt, hWt.data(), hWt.size() * 4, hipMemcpyHostToDevice));
+        for (int L : {14, 28}) {
+            for (int map = 0; map < 2; ++map) {
+                auto tiled = [&]() { for (int s2 = 0; s2 < L; ++s2) hipLaunchKernelGGL(layer_tiled, dim3(256), dim3(256), 0, 0, (s2 & 1) ? d1 : d0, dWt + (size_t)s2 * C * C, dB + s2 * C, (s2 & 1) ? d0 : d1, map); };
+                // timeit uploads hX (row-major) into d0: swap in the tiled image for this section
+                std::vector<float> keep = hX; hX = hXt;
+                const float c = timeit(tiled, true), w = timeit(tiled, false);
+                hX = keep;
+                // un-tile the result on the host for the check
+                std::vector<float> ht((size_t)M * C), hr((size_t)M * C);
+                CK(hipMemcpy(ht.data(), (L & 1) ? d1 : d0, ht.size() * 4, hipMemcpyDeviceToHost));
+                for (int m = 0; m < M; ++m) for (int k = 0; k < C; ++k) hr[(size_t)m * C + k] = ht[tile_idx(m, k, C / 16)];
+                CK(hipMemcpy(dUn, hr.data(), hr.size() * 4, hipMemcpyHostToDevice));
+                char nm[128];
+                snprintf(nm, sizeof nm, "D launches, TILE-ORDERED X / W / Y, 4 waves, map %d", map); report(nm, L, c, w, dUn);
+            }
         }
     }
     {
