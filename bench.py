@@ -140,19 +140,31 @@ def _amdgpu_sysfs(index):
         cards.append(d)
     if not cards:
         return None, None
-    visible = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or ""
-    try:
-        phys = int(visible.split(",")[index]) if visible else index
-    except (ValueError, IndexError):
-        phys = index
-    d = cards[phys] if phys < len(cards) else cards[0]
+    d = None
+    try:                                        # the card whose PCI address is the HIP device's
+        pr = torch.cuda.get_device_properties(index)
+        bdf = "%04x:%02x:%02x." % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        for c in cards:
+            if bdf in os.path.realpath(c):
+                d = c
+                break
+    except Exception:                           # noqa: properties without PCI fields
+        d = None
+    if d is None:
+        visible = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or ""
+        try:
+            phys = int(visible.split(",")[index]) if visible else index
+        except (ValueError, IndexError):
+            phys = index
+        d = cards[phys] if phys < len(cards) else cards[0]
     power = None
     for name in ("power1_average", "power1_input"):
         hits = glob.glob(os.path.join(d, "hwmon", "hwmon*", name))
         if hits:
             power = hits[0]
             break
-    sclk = os.path.join(d, "pp_dpm_sclk")
+    freq = glob.glob(os.path.join(d, "hwmon", "hwmon*", "freq1_input"))          # current shader clock in Hz
+    sclk = freq[0] if freq else os.path.join(d, "pp_dpm_sclk")
     return power, (sclk if os.path.exists(sclk) else None)
 
 
@@ -171,7 +183,10 @@ def device_state_under_load(step, seconds=1.0, index=0):
         while not stop[0]:
             mhz = watts = None
             try:
-                if sclk_f:
+                if sclk_f and sclk_f.endswith("freq1_input"):
+                    with open(sclk_f) as f:
+                        mhz = float(f.read().strip()) * 1e-6
+                elif sclk_f:
                     with open(sclk_f) as f:
                         for line in f:
                             if "*" in line:
@@ -199,19 +214,31 @@ def device_state_under_load(step, seconds=1.0, index=0):
         return None
     mean = lambda xs: (sum(xs) / len(xs)) if xs else None
     return {"sclk_mhz": mean([x[0] for x in late if x[0] is not None]), "socket_power_w": mean([x[1] for x in late if x[1] is not None]),
-            "samples": len(late), "source": "sysfs (pp_dpm_sclk, hwmon power1_average), read in-process",
+            "samples": len(late), "source": "sysfs (%s, %s), read in-process" % (os.path.basename(sclk_f or "-"), os.path.basename(power_f or "-")), "sysfs_device": os.path.realpath(os.path.dirname(power_f or sclk_f)),
             "note": "sampled while the forward loops back to back; nominal shader clock 2400 MHz, socket cap 1400 W"}
 
 
+def _pmc_record():
+    """The newest committed rocprofv3 PMC record (profiles/rNN_pmc.json, written by tools/collect_profiles.sh +
+    tools/make_pmc_json.py), or (None, None)."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r[0-9][0-9]_pmc.json")))
+    for path in reversed(paths):
+        try:
+            with open(path) as f:
+                return json.load(f), os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
+        except Exception:      # noqa: unreadable record -> try the previous round's
+            continue
+    return None, None
+
+
 def pmc_traffic(kernel, scenes):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r02_pmc.json, written from
-    `tools/collect_profiles.sh` output: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950 wide streaming reads).  Counters cannot be read from inside this process,
-    so the figure is the recorded one for the same kernel and scene count, or null."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc.json")
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes (profiles/rNN_pmc.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 wide streaming
+    reads).  Counters cannot be read from inside this process, so the figure is the RECORDED one for the same kernel and scene
+    count (`traffic_source` in the line says which file), or null."""
+    rec, _ = _pmc_record()
     try:
-        with open(path) as f:
-            rec = json.load(f)
         e = rec["by_scenes"][str(scenes)][kernel]
         return (e["fetch_kb"] * e.get("fetch_correction", 2.0) + e["write_kb"]) * 1024.0
     except Exception:
@@ -455,7 +482,7 @@ def main():
                     "achieved": ach_tflops, "peak": mfma_peak, "unit": "TFLOP/s",
                     "frac": (ach_tflops / mfma_peak) if ach_tflops else None,
                     "traffic": pmc_traffic("flash_split_pipe_kernel", B) if (split and C == 256) else None,
-                    "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_pmc.json); algorithmic stream = 2*N*C*4*B bytes",
+                    "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, newest profiles/rNN_pmc.json); algorithmic stream = 2*N*C*4*B bytes",
                     "avg_launch_ms": (ca_ms / ca_n) if ca_n else None, "launches": ca_n,
                     "algorithmic_gflop_per_launch": flop_per_launch / 1e9,
                     "peak_note": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 passes per product; the fp32-MFMA peak is %.1f"
@@ -466,11 +493,11 @@ def main():
         kv_ms, kv_n = prof["kv_proj"]
         kvp_bytes = 3.0 * N * C * 4.0 * B if not half else (N * C * 4.0 + 2.0 * N * C * 2.0) * B     # tokens in, K and V out
         roofline["hbm_frac"] = (roofline["hbm_stream_gbs"] / PEAK_HBM_GBS) if roofline["hbm_stream_gbs"] else None
-        roofline["traffic_source"] = "recorded: profiles/r02_pmc.json (rocprofv3 --pmc passes of the same command), not measured in this run"
+        roofline["traffic_source"] = "recorded: %s (rocprofv3 --pmc passes of the same command), not measured in this run" % (_pmc_record()[1],)
         roofline_kv = {"bound": "hbm", "kernel": "kvproj_dma_kernel (hoisted K/V in-projection, once per forward)",
                        "achieved": (kvp_bytes / (kv_ms / kv_n * 1e-3) / 1e9) if kv_n else None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                        "frac": (kvp_bytes / (kv_ms / kv_n * 1e-3) / 1e9 / PEAK_HBM_GBS) if kv_n else None,
-                       "traffic": pmc_traffic("kvproj_dma_kernel", B), "traffic_source": "recorded: profiles/r02_pmc.json, or null",
+                       "traffic": pmc_traffic("kvproj_dma_kernel", B), "traffic_source": "recorded: %s, or null" % (_pmc_record()[1],),
                        "algorithmic_bytes_per_launch": kvp_bytes, "avg_launch_ms": (kv_ms / kv_n) if kv_n else None, "launches": kv_n,
                        "streaming_ceiling_ms": kvp_bytes / 5.6e12 * 1e3,
                        "note": "reads N*C fp32 tokens, writes the K and V cache images; a plain streaming kernel with this 1:2 read/write "

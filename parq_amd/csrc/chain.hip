@@ -526,7 +526,7 @@ int pick_nt(const LinearArgs& a, int want) {
 hipError_t launch_chain_linear(const LinearArgs& a_in, int groups, hipStream_t s) {
     static const bool wp_off = [] { const char* e = dev_env("PARQ_CHAIN_WPACK"); return e && e[0] == '0'; }();
     // the latency-bound regime (one or a few scenes); above it the generic kernel's 32 x 32 tiles fill the chip
-    static const int chain_max_m = [] { const char* e = dev_env("PARQ_CHAIN_MAX_M"); return e ? atoi(e) : 1024; }();   // 0: generic kernel only
+    static const int chain_max_m = [] { const char* e = dev_env("PARQ_CHAIN_MAX_M"); return e ? atoi(e) : 4096; }();   // 0: generic kernel only (measured at 8 scenes, M = 2048: 1.64 -> 1.37 ms of linears)
     if (a_in.M > chain_max_m) return hipErrorNotSupported;
     LinearArgs a = a_in;
     if (wp_off || (a.Wp && (!al16(a.Wp) || a.ldw != a.K))) a.Wp = nullptr;     // the tile-ordered copy mirrors a dense [N][K] matrix

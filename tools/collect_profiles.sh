@@ -3,7 +3,7 @@
 #   tools/collect_profiles.sh r02
 # bench lines (B=1 with the CPU baseline and the 32-scene project+sample figure, B=8, fp16 mode, training step), rocprofv3 kernel
 # stats of the default bench command, PMC passes (HBM bytes at 1 and 32 scenes; MFMA / LDS counters), then tools/make_pmc_json.py.
-tag=${1:-r02}
+tag=${1:-r03}
 cd /root/repo
 out=/root/repo/gpurun_out/$tag
 rm -rf $out; mkdir -p $out
@@ -11,6 +11,8 @@ python bench.py > $out/bench.json 2> $out/bench.err
 python bench.py --scenes-per-gpu 8 --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_8scenes.json 2>> $out/bench.err
 python bench.py --attention-mode fp16 --steps 10 --warmup 2 --no-cpu-baseline --no-b32 > $out/bench_fp16.json 2>> $out/bench.err
 python bench.py --train --steps 8 --warmup 2 > $out/bench_train.json 2>> $out/bench.err
+python bench.py --dim 1024 --steps 10 --warmup 2 --no-b32 > $out/bench_d1024.json 2>> $out/bench.err
+python bench.py --gpus 2 --share-device --steps 5 --warmup 1 --no-cpu-baseline --no-b32 > $out/bench_2ranks_shared.json 2>> $out/bench.err
 export TMPDIR=/tmp
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-b32 > $out/kt.log 2>&1)
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA"; do
