@@ -12,7 +12,7 @@ python bench.py --scenes-per-gpu 8 --steps 5 --warmup 2 --no-cpu-baseline > $out
 python bench.py --attention-mode fp16 --steps 10 --warmup 2 --no-cpu-baseline --no-b32 > $out/bench_fp16.json 2>> $out/bench.err
 python bench.py --train --steps 8 --warmup 2 > $out/bench_train.json 2>> $out/bench.err
 python bench.py --dim 1024 --steps 10 --warmup 2 --no-b32 > $out/bench_d1024.json 2>> $out/bench.err
-python bench.py --gpus 2 --share-device --steps 5 --warmup 1 --no-cpu-baseline --no-b32 > $out/bench_2ranks_shared.json 2>> $out/bench.err
+python bench.py --gpus 2 --share-device --steps 5 --warmup 1 --no-cpu-baseline --no-b32 2>> $out/bench.err | grep "^{" > $out/bench_2ranks_shared.json
 export TMPDIR=/tmp
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-b32 > $out/kt.log 2>&1)
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA"; do
