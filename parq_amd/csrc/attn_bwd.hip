@@ -667,7 +667,9 @@ __global__ __launch_bounds__(256) void attn_bwd_pack_kernel(AttnBwdArgs a, const
 
 // (no scheduling barriers inside the MFMA groups here: letting hipcc hoist the fragment reads over the previous step's MFMAs
 // measured 18.2 -> 16.6 ms; the first version needs them to stay inside its register budget)
-template <bool DROP, bool RAGGED>
+// PIPE (round 3): the dQ tile of query tile n - 1 is computed next to the softmax / dS arithmetic of tile n instead of at the end
+// of its own tile — same results (same operands, same order inside every accumulation), two barriers per tile as before.
+template <bool DROP, bool RAGGED, int PIPE = 1>
 __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, const float* __restrict__ oscale_ptr,
                                                               const _Float16* __restrict__ pack) {
     const float oscale = *oscale_ptr;
@@ -736,9 +738,37 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
     //   dQ A operand (rows = queries qb + t16, k = keys): piece row j0 + (t16 >> 2), query piece (qb >> 2) + (t16 & 3)
     //   dQ B operand (cols = d db + t16, k = keys): piece row j0 + (t16 >> 2), d piece db + 4 (t16 & 3)
     const int qb = (wave >> 2) * 16, db = (wave & 3) * 16;
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    // ---- dQ tile of query tile `nd` = dS K over the 256 keys of the workgroup: wave w owns the 16 x 16 block (queries 16 (w>>2).., d 16 (w&3)..).
+    // Reads Ds (the dS^T image of that tile) and Ki; 24 MFMAs + 32 transpose reads, no VALU to speak of.
+    auto dq_tile = [&](int nd) {
+        f32x4v g4 = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int ja = 32 * t + 8 * g16 + (t16 >> 2), jb = ja + 4;       // keys of this lane's two pieces
+            const int qp = (qb >> 2) + (t16 & 3);
+            const int pa0 = ja * 32 + ((qp ^ ((ja >> 1) & 7)) << 2), pa1 = jb * 32 + ((qp ^ ((jb >> 1) & 7)) << 2);
+            const int dp = db + 4 * (t16 & 3);
+            const int pb0 = ja * 64 + (((dp >> 3) ^ img_swz(ja)) << 3) + (dp & 4);
+            const int pb1 = jb * 64 + (((dp >> 3) ^ img_swz(jb)) << 3) + (dp & 4);
+            const half8 ah = cat4(lds_tr16(Ds + pa0), lds_tr16(Ds + pa1));
+            const half8 al = cat4(lds_tr16(Ds + 8192 + pa0), lds_tr16(Ds + 8192 + pa1));
+            const half8 bh8 = cat4(lds_tr16(Ki + pb0), lds_tr16(Ki + pb1));
+            const half8 bl8 = cat4(lds_tr16(Ki + 16384 + pb0), lds_tr16(Ki + 16384 + pb1));
+            g4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh8, g4, 0, 0, 0);
+            g4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl8, g4, 0, 0, 0);
+            g4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh8, g4, 0, 0, 0);
+        }
+        // accumulator: rows qb + 4 g16 + r, column db + t16
+        const int itd = nd / ntiles, i0d = (nd - itd * ntiles) * 32;
+        float* part = a.gq_part + (int64_t)itd * a.gqp_it + (((int64_t)bh * gridDim.x + blockIdx.x) * Lq_pad + i0d) * 64;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[(qb + 4 * g16 + r) * 64 + db + t16] = g4[r] * cn * inv_os;
+    };
+    // which waves go first: PIPE 1 = waves 4..7, PIPE 2 = odd waves (whichever pairs share a SIMD).  Wave-uniform: a scalar branch
+    const bool upper_wave = PIPE == 2 ? (__builtin_amdgcn_readfirstlane(wave) & 1) != 0 : __builtin_amdgcn_readfirstlane(wave) >= 4;
     tile_dma(0, 0);
     for (int n = 0; n < ntot; ++n) {
-        const int it = n / ntiles, i0 = (n - it * ntiles) * 32;
         const _Float16* Im = Stg + (n & 1) * kImgHalfs;
         // this thread's DMA pieces of tile n have landed (the 4 dQ stores of the previous tile were issued after them and may stay in
         // flight: VMEM operations retire in order); the barrier makes every wave's pieces visible and closes the previous tile's reads
@@ -747,6 +777,17 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
         lds_barrier();                                      // LDS-only barrier: the dQ stores stay in flight
         if (n + 1 < ntot) tile_dma(n + 1, (n + 1) & 1);     // the other slot was last read before the barrier above
         const float* st = reinterpret_cast<const float*>(Im + 8192);
+
+        // PIPE: the dQ tile of the PREVIOUS query tile (its dS^T image sits in Ds since the barrier above) is computed in THIS
+        // interval, by the upper four waves FIRST (then S / dP, P / dS, dV / dK) and by the lower four LAST.  A SIMD hosts waves w
+        // and w + 4: shifted by one phase, one of them is in its VALU phase (softmax, dS, hi/lo splits) while the other one feeds
+        // the matrix pipe (upper S/dP ‖ lower P/dS, upper P/dS ‖ lower dV/dK), instead of both running MFMA phase, VALU phase,
+        // MFMA phase in lockstep.  The dV / dK products need no barrier (registers + the Q / dO image), only the dS^T image does.  No fences, no extra live
+        // registers.  At n == 0 there is no previous tile: the same code runs on whatever Ds holds and its result lands in tile
+        // 0's slot, which the next iteration overwrites with the real dQ of tile 0 (same lanes, stores retire in order).
+        if constexpr (PIPE) {
+            if (upper_wave) dq_tile(n > 0 ? n - 1 : 0);
+        }
 
         // ---- S = Q K^T, dP = dO V^T  (rows = queries, columns = this wave's keys)
         f32x16 sacc, pacc;
@@ -793,15 +834,22 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
             }
             split8(pv, ph[m], pl[m]);
             split8(dv, sh[m], sl[m]);
-            // dS^T row of this key: queries 16 m + 8 hh + 4 kh + (0..3) are registers 4 hh .. 4 hh + 3 -> query piece 4 m + 2 hh + kh
+        }
+        }
+        // the dS^T rows of this wave's keys go into Ds: without PIPE right away (nobody reads Ds between the top barrier and the
+        // barrier below); with PIPE after a barrier, because every wave's dq_tile above was still reading the previous tile's image
+        auto write_ds = [&]() {
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int off = jw * 32 + (((4 * m + 2 * hh + kh) ^ ((jw >> 1) & 7)) << 2);
-                *reinterpret_cast<half4v*>(Ds + off) = half4v{sh[m][4 * hh], sh[m][4 * hh + 1], sh[m][4 * hh + 2], sh[m][4 * hh + 3]};
-                *reinterpret_cast<half4v*>(Ds + 8192 + off) = half4v{sl[m][4 * hh], sl[m][4 * hh + 1], sl[m][4 * hh + 2], sl[m][4 * hh + 3]};
-            }
-        }
-        }
+            for (int m = 0; m < 2; ++m)
+                // dS^T row of this key: queries 16 m + 8 hh + 4 kh + (0..3) are registers 4 hh .. 4 hh + 3 -> query piece 4 m + 2 hh + kh
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int off = jw * 32 + (((4 * m + 2 * hh + kh) ^ ((jw >> 1) & 7)) << 2);
+                    *reinterpret_cast<half4v*>(Ds + off) = half4v{sh[m][4 * hh], sh[m][4 * hh + 1], sh[m][4 * hh + 2], sh[m][4 * hh + 3]};
+                    *reinterpret_cast<half4v*>(Ds + 8192 + off) = half4v{sl[m][4 * hh], sl[m][4 * hh + 1], sl[m][4 * hh + 2], sl[m][4 * hh + 3]};
+                }
+        };
+        if constexpr (!PIPE) write_ds();
         // ---- dV^T += dO^T P, dK^T += Q^T dS: contraction over the queries; A operands by transpose reads of the natural images
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -822,32 +870,18 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
                 gk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qth, sl[m], gk[dt], 0, 0, 0);
                 gk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtl, sh[m], gk[dt], 0, 0, 0);
                 }
-        // ---- dQ tile = dS K over the 256 keys of the workgroup: wave w owns the 16 x 16 block (queries 16 (w>>2).., d 16 (w&3)..)
-        lds_barrier();
-        {
-            typedef float f32x4v __attribute__((ext_vector_type(4)));
-            f32x4v g4 = f32x4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int ja = 32 * t + 8 * g16 + (t16 >> 2), jb = ja + 4;       // keys of this lane's two pieces
-                const int qp = (qb >> 2) + (t16 & 3);
-                const int pa0 = ja * 32 + ((qp ^ ((ja >> 1) & 7)) << 2), pa1 = jb * 32 + ((qp ^ ((jb >> 1) & 7)) << 2);
-                const int dp = db + 4 * (t16 & 3);
-                const int pb0 = ja * 64 + (((dp >> 3) ^ img_swz(ja)) << 3) + (dp & 4);
-                const int pb1 = jb * 64 + (((dp >> 3) ^ img_swz(jb)) << 3) + (dp & 4);
-                const half8 ah = cat4(lds_tr16(Ds + pa0), lds_tr16(Ds + pa1));
-                const half8 al = cat4(lds_tr16(Ds + 8192 + pa0), lds_tr16(Ds + 8192 + pa1));
-                const half8 bh8 = cat4(lds_tr16(Ki + pb0), lds_tr16(Ki + pb1));
-                const half8 bl8 = cat4(lds_tr16(Ki + 16384 + pb0), lds_tr16(Ki + 16384 + pb1));
-                g4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh8, g4, 0, 0, 0);
-                g4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl8, g4, 0, 0, 0);
-                g4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh8, g4, 0, 0, 0);
-            }
-            // accumulator: rows qb + 4 g16 + r, column db + t16
-            float* part = a.gq_part + (int64_t)it * a.gqp_it + (((int64_t)bh * gridDim.x + blockIdx.x) * Lq_pad + i0) * 64;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) part[(qb + 4 * g16 + r) * 64 + db + t16] = g4[r] * cn * inv_os;
+        if constexpr (!PIPE) {
+            lds_barrier();
+            dq_tile(n);
+        } else {
+            if (!upper_wave) dq_tile(n > 0 ? n - 1 : 0);    // the lower waves' turn (their P / dS operands are dead by now)
+            lds_barrier();                                   // every wave has read the previous tile's dS^T image
+            write_ds();                                      // visible to the next interval through the barrier at the top of the loop
         }
+    }
+    if constexpr (PIPE) {
+        lds_barrier();                                      // the last tile's dS^T image is complete
+        dq_tile(ntot - 1);
     }
     // ---- dK, dV of this wave's keys: (d x keys) accumulators -> [key][d] through LDS (Ds + head of Ki, free now), row-contiguous stores
     __syncthreads();
@@ -1308,21 +1342,27 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
         // second version: tile images packed once, fetched by LDS-DMA; transpose reads
         constexpr size_t lds2 = (size_t)(2 * 8192 + 2 * 16384 + 2 * kImgHalfs) * sizeof(_Float16);
         const bool rag = (Lk % kSpKW) != 0;
-        const void* fn = drop_p > 0.f ? (rag ? reinterpret_cast<const void*>(&attn_bwd_split2_kernel<true, true>)
-                                             : reinterpret_cast<const void*>(&attn_bwd_split2_kernel<true, false>))
-                                      : (rag ? reinterpret_cast<const void*>(&attn_bwd_split2_kernel<false, true>)
-                                             : reinterpret_cast<const void*>(&attn_bwd_split2_kernel<false, false>));
-        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-        if (e != hipSuccess) return e;
+        static const int pipe = [] { const char* e = dev_env("PARQ_ATTN_BWD_PIPE"); return e ? atoi(e) : 1; }();
         _Float16* pk = reinterpret_cast<_Float16*>(pack);
         hipLaunchKernelGGL(attn_bwd_pack_kernel, dim3(Lq_pad / 32, B * H, n_it), dim3(256), 0, s, a, oscale, pk);
-        if (drop_p > 0.f) {
-            if (rag) hipLaunchKernelGGL((attn_bwd_split2_kernel<true, true>), g2, dim3(512), lds2, s, a, oscale, pk);
-            else hipLaunchKernelGGL((attn_bwd_split2_kernel<true, false>), g2, dim3(512), lds2, s, a, oscale, pk);
-        } else {
-            if (rag) hipLaunchKernelGGL((attn_bwd_split2_kernel<false, true>), g2, dim3(512), lds2, s, a, oscale, pk);
-            else hipLaunchKernelGGL((attn_bwd_split2_kernel<false, false>), g2, dim3(512), lds2, s, a, oscale, pk);
+#define PARQ_BWD2(DROP_, RAG_, PIPE_)                                                                                          \
+        {                                                                                                                      \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_split2_kernel<DROP_, RAG_, PIPE_>),                  \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                                    \
+            if (e != hipSuccess) return e;                                                                                     \
+            hipLaunchKernelGGL((attn_bwd_split2_kernel<DROP_, RAG_, PIPE_>), g2, dim3(512), lds2, s, a, oscale, pk);           \
         }
+        if (pipe == 1) {
+            if (drop_p > 0.f) { if (rag) PARQ_BWD2(true, true, 1) else PARQ_BWD2(true, false, 1) }
+            else { if (rag) PARQ_BWD2(false, true, 1) else PARQ_BWD2(false, false, 1) }
+        } else if (pipe == 2) {
+            if (drop_p > 0.f) { if (rag) PARQ_BWD2(true, true, 2) else PARQ_BWD2(true, false, 2) }
+            else { if (rag) PARQ_BWD2(false, true, 2) else PARQ_BWD2(false, false, 2) }
+        } else {
+            if (drop_p > 0.f) { if (rag) PARQ_BWD2(true, true, 0) else PARQ_BWD2(true, false, 0) }
+            else { if (rag) PARQ_BWD2(false, true, 0) else PARQ_BWD2(false, false, 0) }
+        }
+#undef PARQ_BWD2
     } else {
         e = split_bwd_lds_attr();
         if (e != hipSuccess) return e;
