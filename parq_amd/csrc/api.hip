@@ -370,23 +370,34 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     // K3: sine embedding (written by the previous iteration's decode kernel when chained) -> position MLP
     // (transformer_parq.py:317)
     if (!emb_valid) { Prof p(c, s, PARQ_PROF_OTHER); HIPCHK(launch_posemb(ref, A + ar.dim_t, M, wi + ws.emb, s)); }
+    LinearArgs pe1 = lin(wi + ws.emb, 384, A + ar.pe0_w, 384, A + ar.pe0_b, wi + ws.pe_h, C, M, C, 384);
+    pe1.relu = 1; pe1.Wp = TP + ar.pe0_w;
+    float* sample_out = sharded ? sh.out : wi + ws.tgt;
+    float* sample_cnt = sharded ? sh.out + (int64_t)M * C : nullptr;
+    // the position MLP's first layer and project + sample are independent (both read only what the previous decode left): one
+    // launch when the chain kernels apply; the profiled pass keeps them apart so that the per-kernel groups stay per kernel
+    static const bool fuse_off = [] { const char* e = dev_env("PARQ_FUSE_PE1_SAMPLE"); return e && e[0] == '0'; }();
+    bool fused = false;
+    if (!train && !fuse_off && !c->profiling) {
+        const hipError_t e = launch_pe1_sample(pe1, sc->tokens, reinterpret_cast<const double*>(wsp + ws.T_cl), sc->camera, ref, c->sb, B, sc->V,
+                                               sc->h, sc->w, C, Q, sample_out, o->coord_pos, gn1, B * 8 * kGnSlots, sample_cnt, s);
+        if (e == hipSuccess) fused = true;
+        else if (e != hipErrorNotSupported) return fail(PARQ_ERR_HIP, "launch_pe1_sample failed: %s", hipGetErrorString(e));
+    }
     {
         Prof p(c, s, PARQ_PROF_LINEAR);
-        LinearArgs a = lin(wi + ws.emb, 384, A + ar.pe0_w, 384, A + ar.pe0_b, wi + ws.pe_h, C, M, C, 384);
-        a.relu = 1; a.Wp = TP + ar.pe0_w;
-        HIPCHK(launch_linear(a, 1, s));
+        if (!fused) HIPCHK(launch_linear(pe1, 1, s));
         if (!fold_pos) {
-            a = lin(wi + ws.pe_h, C, A + ar.pe2_w, C, A + ar.pe2_b, wi + ws.pos, C, M, C, C);
+            LinearArgs a = lin(wi + ws.pe_h, C, A + ar.pe2_w, C, A + ar.pe2_b, wi + ws.pos, C, M, C, C);
             a.Wp = TP + ar.pe2_w;
             HIPCHK(launch_linear(a, 1, s));
         }
     }
     // K4+K5: project + sample (transformer_parq.py:321); also clears this iteration's GroupNorm moments
-    {
+    if (!fused) {
         Prof p(c, s, PARQ_PROF_PROJECT_SAMPLE);
         HIPCHK(launch_project_sample_f64(sc->tokens, reinterpret_cast<const double*>(wsp + ws.T_cl), sc->camera, ref, c->sb,
-                                         B, sc->V, sc->h, sc->w, C, Q, sharded ? sh.out : wi + ws.tgt, o->coord_pos, gn1, B * 8 * kGnSlots, s,
-                                         sharded ? sh.out + (int64_t)M * C : nullptr));
+                                         B, sc->V, sc->h, sc->w, C, Q, sample_out, o->coord_pos, gn1, B * 8 * kGnSlots, s, sample_cnt));
     }
     }   // phase bit 1
     if (sh.mask & 2) {

@@ -16,6 +16,7 @@
 // launch_linear (linear.hip) routes here when the shape qualifies (chain_linear_supported) and keeps the generic kernel for
 // everything else (ragged shapes, ReLU masks of the backward, dropout, head-major output scatter, many scenes).
 #include "common.hpp"
+#include "sample_body.hpp"
 
 namespace parq {
 
@@ -27,22 +28,21 @@ enum : int { kProNone = 0, kProLN = 1, kProGN = 2 };
 enum : int { kResNone = 0, kResPlain = 1, kResLN = 2 };
 
 template <int K, int NT, int PRO, int ADD2, bool BIAS, bool RELU, int RES, bool GNOUT, int NWV = 4>
-__global__ __launch_bounds__(NWV * 64) void chain_linear_kernel(LinearArgs a) {
-    PARQ_TL_KERNEL(kTlLinear);
+__device__ __forceinline__ void chain_tile(const LinearArgs& a, const int block_x, const int block_y) {
     static_assert(K % (16 * NWV) == 0 && NT >= 1 && NT <= 4 && (NWV == 4 || NWV == 8), "tile shape");
     constexpr int NCH = K / (16 * NWV);               // 16-wide K chunks per wave
     constexpr int CS = 16 * NWV;                      // the workgroup's K step per chunk (wave w takes columns w*16 .. w*16+15 of it)
     __shared__ __attribute__((aligned(16))) float red[NWV * NT * 4 * 64];   // [wave][sub-tile][acc reg][lane]
     __shared__ float lnred[NWV * 16 * 2];
 
-    const int g = blockIdx.y;
+    const int g = block_y;
     const int ntn = a.N / (16 * NT);
     int n0, m0;
-    if (a.tile_map == 0) {                            // column tiles fastest: XCD x (= blockIdx % 8) reads all of X and 1/8 of W
-        n0 = (int)(blockIdx.x % ntn) * 16 * NT;
-        m0 = (int)(blockIdx.x / ntn) * 16;
+    if (a.tile_map == 0) {                            // column tiles fastest: XCD x (= block index % 8) reads all of X and 1/8 of W
+        n0 = (int)(block_x % ntn) * 16 * NT;
+        m0 = (int)(block_x / ntn) * 16;
     } else {                                          // a row block's column tiles on one XCD: XCD x reads 1/8 of X and all of W
-        const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        const int x = block_x & 7, loc = block_x >> 3;
         n0 = (loc % ntn) * 16 * NT;
         m0 = (x * (a.M / 128) + loc / ntn) * 16;
     }
@@ -231,12 +231,40 @@ __global__ __launch_bounds__(NWV * 64) void chain_linear_kernel(LinearArgs a) {
             for (int o = 32; o > 0; o >>= 1) { gs += __shfl_xor(gs, o); gq += __shfl_xor(gq, o); }
             if (lane == 0) {
                 const int grp = (nt0 + g * a.N) / a.gn_out_group_cols;
-                const int slot = (int)((blockIdx.x * NT + wave) % kGnSlots);
+                const int slot = (int)((block_x * NT + wave) % kGnSlots);
                 double* dst = a.gn_out_sums + (((int64_t)(m0 / a.gn_out_rows_per_scene) * a.gn_out_ngroups + grp) * kGnSlots + slot) * 2;
                 atomicAdd(dst, gs);
                 atomicAdd(dst + 1, gq);
             }
         }
+    }
+}
+
+template <int K, int NT, int PRO, int ADD2, bool BIAS, bool RELU, int RES, bool GNOUT, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void chain_linear_kernel(LinearArgs a) {
+    PARQ_TL_KERNEL(kTlLinear);
+    chain_tile<K, NT, PRO, ADD2, BIAS, RELU, RES, GNOUT, NWV>(a, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// ONE launch for the two independent stages at the head of an iteration (both depend only on the previous iteration's decode):
+// workgroups [0, n_lin) are the tiles of the position MLP's first layer (384 -> C, ReLU; threads >= 256 leave at once),
+// workgroups [n_lin, n_lin + B*Q) project and sample one (scene, query) each (sample_body.hpp).  Saves one dependent launch
+// (1.9 us boundary + ramp) per iteration; the two bodies run side by side on different CUs.
+struct SampleArgs {
+    const float* tokens; const double* T_cl; const float* cam; const float* ref; ScaleBox sb; int V, h, w, C, Q;
+    float* tgt; float* coord_pos; double* zero_f64; int zero_n; float* raw_count;
+};
+template <int NCH>
+__global__ __launch_bounds__(1024) void pe1_sample_kernel(LinearArgs a, SampleArgs sa, int n_lin) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x < n_lin) {
+        PARQ_TL_KERNEL(kTlLinear);
+        if (threadIdx.x >= 256) return;
+        chain_tile<384, 1, kProNone, 0, true, true, kResNone, false, 4>(a, (int)blockIdx.x, 0);
+    } else {
+        PARQ_TL_KERNEL(kTlProjectSample);
+        project_sample_body<NCH, double>(sa.tokens, sa.T_cl, sa.cam, sa.ref, sa.sb, sa.V, sa.h, sa.w, sa.C, sa.Q, sa.tgt, sa.coord_pos,
+                                         sa.zero_f64, sa.zero_n, sa.raw_count, (int)blockIdx.x - n_lin, (int)gridDim.x - n_lin, smem);
     }
 }
 
@@ -630,6 +658,33 @@ hipError_t launch_fold_pos_weights(const float* Wa, const float* ba, const float
                                    hipStream_t s) {
     const int64_t n = (int64_t)R * C;
     hipLaunchKernelGGL(fold_pos_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Wa, ba, W2, b2, R, C, out_w, out_b);
+    return hipGetLastError();
+}
+
+// fused first launch of an iteration: pe1 (args `a`: K = 384, ReLU, bias) + project/sample.  hipErrorNotSupported when the shapes
+// do not fit (the caller then launches the two stages separately).
+hipError_t launch_pe1_sample(const LinearArgs& a_in, const float* tokens, const double* T_cl, const float* cam, const float* ref, ScaleBox sb,
+                             int B, int V, int h, int w, int C, int Q, float* tgt, float* coord_pos, double* zero_f64, int zero_n,
+                             float* raw_count, hipStream_t s) {
+    if (!chain_linear_supported(a_in, 1)) return hipErrorNotSupported;
+    const Sig g = sig_of(a_in);
+    if (!(g.K == 384 && g.pro == kProNone && g.add2 == 0 && g.bias && g.relu && g.res == kResNone && !g.gnout)) return hipErrorNotSupported;
+    if (C % 4 != 0 || C > 1024 || V <= 0 || V > 16) return hipErrorNotSupported;
+    static const bool wp_off = [] { const char* e = dev_env("PARQ_CHAIN_WPACK"); return e && e[0] == '0'; }();
+    LinearArgs a = a_in;
+    if (wp_off || (a.Wp && (!al16(a.Wp) || a.ldw != a.K))) a.Wp = nullptr;
+    a.tile_map = 0;
+    const int n_lin = (a.N / 16) * (a.M / 16);
+    const int nwv = V < 4 ? 4 : V;                                   // >= 4 waves: the linear tiles need 256 threads
+    const size_t smem = (size_t)nwv * C * sizeof(float) + (size_t)nwv * sizeof(int) + (size_t)V * 32 + 16;
+    SampleArgs sa{tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n, raw_count};
+    const dim3 grid((unsigned)(n_lin + B * Q)), block(nwv * 64);
+    switch ((C / 4 + 63) / 64) {
+        case 1: hipLaunchKernelGGL((pe1_sample_kernel<1>), grid, block, smem, s, a, sa, n_lin); break;
+        case 2: hipLaunchKernelGGL((pe1_sample_kernel<2>), grid, block, smem, s, a, sa, n_lin); break;
+        case 3: hipLaunchKernelGGL((pe1_sample_kernel<3>), grid, block, smem, s, a, sa, n_lin); break;
+        default: hipLaunchKernelGGL((pe1_sample_kernel<4>), grid, block, smem, s, a, sa, n_lin); break;
+    }
     return hipGetLastError();
 }
 
