@@ -92,6 +92,7 @@ struct parq_ctx {
     Arena ar;
     const float* arena = nullptr;     // device arena after pack
     bool packed = false;
+    bool derived_valid = false;       // build_derived_weights ran since the last parq_pack_weights
     bool prepared = false;
     bool emb_valid = false;           // workspace emb holds pos2posemb3d of the chained reference points
     int ref_state = 0;                // 0: none, 1: ws.ref valid
@@ -317,6 +318,41 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     return PARQ_OK;
 }
 
+// Weights DERIVED from the packed tensors for the inference chain (chain.hip): the position MLP's last layer folded into its two
+// consumers and the tile-ordered mirror of every matrix the chain multiplies by.  Built lazily by the first inference iteration
+// after parq_pack_weights (a training loop re-packs every step and never reads them: its forward keeps the reference's layer order
+// and row-major weights), on the caller's stream, into the caller's arena.
+int build_derived_weights(parq_ctx* c, hipStream_t s) {
+    float* A = const_cast<float*>(c->arena);
+    const Arena& ar = c->ar;
+    const int64_t C = c->C, F = c->F;
+    // float64-accumulated products, rounded once
+    for (int li = 0; li < c->nl; ++li) {
+        const LayerW& L = c->ar.layers[li];
+        HIPCHK(launch_fold_pos_weights(A + L.self_in_w, A + L.self_in_b, A + ar.pe2_w, A + ar.pe2_b, (int)(2 * C), (int)C, A + L.self_in_w2, A + L.self_in_b2, s));
+        HIPCHK(hipMemcpyAsync(A + L.self_in_b2 + 2 * C, A + L.self_in_b + 2 * C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, s));   // b_v unchanged
+        HIPCHK(launch_fold_pos_weights(A + L.cross_in_w, A + L.cross_in_b, A + ar.pe2_w, A + ar.pe2_b, (int)C, (int)C, A + L.cross_q_w2, A + L.cross_q_b2, s));
+    }
+    // tile-ordered mirror of the chain's matrices (chain.hip: one contiguous KB per wave-wide fragment load)
+    {
+        const int64_t T = ar.tile_off;
+        auto tile = [&](int64_t off, int64_t N, int64_t K) { return launch_pack_w_tiles(A + off, K, (int)N, (int)K, A + T + off, s); };
+        for (int li = 0; li < c->nl; ++li) {
+            const LayerW& L = c->ar.layers[li];
+            HIPCHK(tile(L.self_in_w, 3 * C, C)); HIPCHK(tile(L.self_out_w, C, C));
+            HIPCHK(tile(L.cross_in_w, C, C));                                      // the query rows (K / V rows: kv_whi / kv_wlo)
+            HIPCHK(tile(L.cross_out_w, C, C));
+            HIPCHK(tile(L.self_in_w2, 3 * C, C)); HIPCHK(tile(L.cross_q_w2, C, C));
+            if (F % 16 == 0) { HIPCHK(tile(L.lin1_w, F, C)); HIPCHK(tile(L.lin2_w, C, F)); }
+        }
+        HIPCHK(tile(ar.pe0_w, C, 384)); HIPCHK(tile(ar.pe2_w, C, C));
+        if (c->NH1 % 16 == 0) HIPCHK(tile(ar.heads1_w, c->NH1, C));
+        HIPCHK(tile(ar.heads2_w, C, C)); HIPCHK(tile(ar.heads2_w + C * C, C, C));
+    }
+    c->derived_valid = true;
+    return PARQ_OK;
+}
+
 // shift: offset (floats) of this iteration's activation copy (0 in inference: every iteration reuses one set);
 // emb_next: where the decode kernel leaves the next iteration's sine embedding; train: also keep what backward needs
 // View-sharded scenes (parq_iterate_sharded): an iteration runs in three phases around two exchanges the caller performs.
@@ -336,7 +372,9 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     const float dp = train ? c->drop_p : 0.f;          // dropout exists in training only (nn.Dropout / MHA dropout)
     const float* A = c->arena;
     const Arena& ar = c->ar;
-    const float* TP = A + ar.tile_off;                 // tile-ordered mirror of the chain's matrices (LinearArgs::Wp)
+    if (!train && !c->derived_valid) { const int rc = build_derived_weights(c, s); if (rc) return rc; }
+    // tile-ordered mirror of the chain's matrices (LinearArgs::Wp); the training forward reads the row-major tensors
+    const float* TP = train ? nullptr : A + ar.tile_off;
     const int li = c->cfg.share_weights ? 0 : layer_num;
     const LayerW& L = ar.layers[li];
     const int B = sc->B, C = c->C, Q = c->Q, H = c->H, dh = c->dh, F = c->F;
@@ -349,16 +387,16 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     // transformer_parq.py:372-377) or with the position MLP's last layer folded into them (second operand pair h x (W W2)^T)
     auto self_in_args = [&](bool fold) {
         LinearArgs a = lin(wi + ws.tgt, C, A + L.self_in_w, C, A + (fold ? L.self_in_b2 : L.self_in_b), wi + ws.qkv, 3 * C, M, 3 * C, C);
-        a.ldx2 = C; a.x2_ncols = 2 * C; a.Wp = TP + L.self_in_w;
-        if (fold) { a.X2 = wi + ws.pe_h; a.W2 = A + L.self_in_w2; a.W2p = TP + L.self_in_w2; }
+        a.ldx2 = C; a.x2_ncols = 2 * C; a.Wp = TP ? TP + L.self_in_w : nullptr;
+        if (fold) { a.X2 = wi + ws.pe_h; a.W2 = A + L.self_in_w2; a.W2p = TP ? TP + L.self_in_w2 : nullptr; }
         else a.X2 = wi + ws.pos;
         return a;
     };
     auto cross_q_args = [&](bool fold) {
         LinearArgs a = lin(wi + ws.xa, C, A + L.cross_in_w, C, A + (fold ? L.cross_q_b2 : L.cross_in_b), wi + ws.qc, C, M, C, C);
         a.ln_gamma = A + L.n1_w; a.ln_beta = A + L.n1_b; a.ln_stats_out = wi + ws.ln1; a.norm_eps = eps;
-        a.ldx2 = C; a.x2_ncols = C; a.Wp = TP + L.cross_in_w;
-        if (fold) { a.X2 = wi + ws.pe_h; a.W2 = A + L.cross_q_w2; a.W2p = TP + L.cross_q_w2; }
+        a.ldx2 = C; a.x2_ncols = C; a.Wp = TP ? TP + L.cross_in_w : nullptr;
+        if (fold) { a.X2 = wi + ws.pe_h; a.W2 = A + L.cross_q_w2; a.W2p = TP ? TP + L.cross_q_w2 : nullptr; }
         else a.X2 = wi + ws.pos;
         return a;
     };
@@ -371,7 +409,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     // (transformer_parq.py:317)
     if (!emb_valid) { Prof p(c, s, PARQ_PROF_OTHER); HIPCHK(launch_posemb(ref, A + ar.dim_t, M, wi + ws.emb, s)); }
     LinearArgs pe1 = lin(wi + ws.emb, 384, A + ar.pe0_w, 384, A + ar.pe0_b, wi + ws.pe_h, C, M, C, 384);
-    pe1.relu = 1; pe1.Wp = TP + ar.pe0_w;
+    pe1.relu = 1; pe1.Wp = TP ? TP + ar.pe0_w : nullptr;
     float* sample_out = sharded ? sh.out : wi + ws.tgt;
     float* sample_cnt = sharded ? sh.out + (int64_t)M * C : nullptr;
     // the position MLP's first layer and project + sample are independent (both read only what the previous decode left): one
@@ -389,7 +427,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         if (!fused) HIPCHK(launch_linear(pe1, 1, s));
         if (!fold_pos) {
             LinearArgs a = lin(wi + ws.pe_h, C, A + ar.pe2_w, C, A + ar.pe2_b, wi + ws.pos, C, M, C, C);
-            a.Wp = TP + ar.pe2_w;
+            a.Wp = TP ? TP + ar.pe2_w : nullptr;
             HIPCHK(launch_linear(a, 1, s));
         }
     }
@@ -441,7 +479,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         // xa = tgt + self_attn @ Wo  (pre-LayerNorm; norm1 is applied by the consumers)
         Prof p(c, s, PARQ_PROF_LINEAR);
         LinearArgs a = lin(wi + ws.sa, C, A + L.self_out_w, C, A + L.self_out_b, wi + ws.xa, C, M, C, C);
-        a.R = wi + ws.tgt; a.ldr = C; a.Wp = TP + L.self_out_w;
+        a.R = wi + ws.tgt; a.ldr = C; a.Wp = TP ? TP + L.self_out_w : nullptr;
         a.drop_p = dp; a.drop_seed = c->site_seed(layer_num, 1);
         HIPCHK(launch_linear(a, 1, s));
         // K7: cross-attention query = (norm1(xa) + pos) @ Wq; publishes norm1's row statistics
@@ -481,18 +519,18 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         Prof p(c, s, PARQ_PROF_LINEAR);
         // xb = norm1(xa) + cross_attn @ Wo   (residual recomputed from the published statistics)
         LinearArgs a = lin(wi + ws.attn, C, A + L.cross_out_w, C, A + L.cross_out_b, wi + ws.xb, C, M, C, C);
-        a.R = wi + ws.xa; a.ldr = C; a.rln_stats = wi + ws.ln1; a.rln_gamma = A + L.n1_w; a.rln_beta = A + L.n1_b; a.Wp = TP + L.cross_out_w;
+        a.R = wi + ws.xa; a.ldr = C; a.rln_stats = wi + ws.ln1; a.rln_gamma = A + L.n1_w; a.rln_beta = A + L.n1_b; a.Wp = TP ? TP + L.cross_out_w : nullptr;
         a.drop_p = dp; a.drop_seed = c->site_seed(layer_num, 3);
         HIPCHK(launch_linear(a, 1, s));
         // K8: FFN (transformer_parq.py:383-385): relu(norm2(xb) @ W1), publishes norm2's statistics
         a = lin(wi + ws.xb, C, A + L.lin1_w, C, A + L.lin1_b, wi + ws.ffn, F, M, F, C);
         a.ln_gamma = A + L.n2_w; a.ln_beta = A + L.n2_b; a.ln_stats_out = wi + ws.ln2; a.norm_eps = eps;
-        a.relu = 1; a.Wp = TP + L.lin1_w;
+        a.relu = 1; a.Wp = TP ? TP + L.lin1_w : nullptr;
         a.drop_p = dp; a.drop_seed = c->site_seed(layer_num, 4);
         HIPCHK(launch_linear(a, 1, s));
         // xc = norm2(xb) + ffn @ W2
         a = lin(wi + ws.ffn, F, A + L.lin2_w, F, A + L.lin2_b, wi + ws.xc, C, M, C, F);
-        a.R = wi + ws.xb; a.ldr = C; a.rln_stats = wi + ws.ln2; a.rln_gamma = A + L.n2_w; a.rln_beta = A + L.n2_b; a.Wp = TP + L.lin2_w;
+        a.R = wi + ws.xb; a.ldr = C; a.rln_stats = wi + ws.ln2; a.rln_gamma = A + L.n2_w; a.rln_beta = A + L.n2_b; a.Wp = TP ? TP + L.lin2_w : nullptr;
         a.drop_p = dp; a.drop_seed = c->site_seed(layer_num, 5);
         HIPCHK(launch_linear(a, 1, s));
         // K9: heads (transformer_parq.py:234-252; generic_mlp.py:85-110) on norm3(xc); the first layers of the
@@ -501,13 +539,13 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         a = lin(wi + ws.xc, C, A + ar.heads1_w, C, A + ar.heads1_b, wi + ws.h1, NH1, M, NH1, C);
         a.ln_gamma = A + L.n3_w; a.ln_beta = A + L.n3_b; a.norm_eps = eps;
         if (train) a.ln_stats_out = wi + ws.ln3;
-        if (NH1 % 16 == 0) a.Wp = TP + ar.heads1_w;
+        if (NH1 % 16 == 0) a.Wp = TP ? TP + ar.heads1_w : nullptr;
         a.gn_out_sums = gn1; a.gn_out_ncols = 2 * C; a.gn_out_group_cols = C; a.gn_out_rows_per_scene = Q; a.gn_out_ngroups = 2;
         HIPCHK(launch_linear(a, 1, s));
         a = lin(wi + ws.h1, NH1, A + ar.heads2_w, C, nullptr, wi + ws.h2, 2 * C, M, C, C);
         a.gn_sums = gn1; a.gn_gamma = A + ar.gn1_g; a.gn_beta = A + ar.gn1_b; a.norm_eps = eps;
         a.gn_rows_per_scene = Q; a.gn_ngroups = 2;
-        a.gX = C; a.gW = (int64_t)C * C; a.gY = C; a.gGamma = C; a.Wp = TP + ar.heads2_w;
+        a.gX = C; a.gW = (int64_t)C * C; a.gY = C; a.gGamma = C; a.Wp = TP ? TP + ar.heads2_w : nullptr;
         a.gn_out_sums = gn2; a.gn_out_ncols = C; a.gn_out_group_cols = C; a.gn_out_rows_per_scene = Q; a.gn_out_ngroups = 2;
         HIPCHK(launch_linear(a, 2, s));
     }
@@ -972,30 +1010,7 @@ int parq_pack_weights(parq_handle h, void* arena_v, size_t arena_bytes, parq_str
         return rc;
     // small host table kept in the handle, so the copy needs no synchronisation with the stream
     HIPCHK(hipMemcpyAsync(A + ar.dim_t, c->dim_t_host, sizeof(c->dim_t_host), hipMemcpyHostToDevice, s));
-    // position MLP layer 2 folded into the self-attention q/k projection and the cross-attention q projection (used by the inference
-    // iteration when chain.hip takes the launch): float64-accumulated products, rounded once
-    for (int li = 0; li < c->nl; ++li) {
-        const LayerW& L = c->ar.layers[li];
-        HIPCHK(launch_fold_pos_weights(A + L.self_in_w, A + L.self_in_b, A + ar.pe2_w, A + ar.pe2_b, (int)(2 * C), (int)C, A + L.self_in_w2, A + L.self_in_b2, s));
-        HIPCHK(hipMemcpyAsync(A + L.self_in_b2 + 2 * C, A + L.self_in_b + 2 * C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, s));   // b_v unchanged
-        HIPCHK(launch_fold_pos_weights(A + L.cross_in_w, A + L.cross_in_b, A + ar.pe2_w, A + ar.pe2_b, (int)C, (int)C, A + L.cross_q_w2, A + L.cross_q_b2, s));
-    }
-    // tile-ordered mirror of the chain's matrices (chain.hip: one contiguous KB per wave-wide fragment load)
-    {
-        const int64_t T = ar.tile_off;
-        auto tile = [&](int64_t off, int64_t N, int64_t K) { return launch_pack_w_tiles(A + off, K, (int)N, (int)K, A + T + off, s); };
-        for (int li = 0; li < c->nl; ++li) {
-            const LayerW& L = c->ar.layers[li];
-            HIPCHK(tile(L.self_in_w, 3 * C, C)); HIPCHK(tile(L.self_out_w, C, C));
-            HIPCHK(tile(L.cross_in_w, C, C));                                      // the query rows (K / V rows: kv_whi / kv_wlo)
-            HIPCHK(tile(L.cross_out_w, C, C));
-            HIPCHK(tile(L.self_in_w2, 3 * C, C)); HIPCHK(tile(L.cross_q_w2, C, C));
-            if (F % 16 == 0) { HIPCHK(tile(L.lin1_w, F, C)); HIPCHK(tile(L.lin2_w, C, F)); }
-        }
-        HIPCHK(tile(ar.pe0_w, C, 384)); HIPCHK(tile(ar.pe2_w, C, C));
-        if (c->NH1 % 16 == 0) HIPCHK(tile(ar.heads1_w, c->NH1, C));
-        HIPCHK(tile(ar.heads2_w, C, C)); HIPCHK(tile(ar.heads2_w + C * C, C, C));
-    }
+    c->derived_valid = false;          // folded position-MLP weights + tile-ordered mirror: built by the first inference iteration
     c->arena = A;
     c->packed = true;
     c->prepared = false;
