@@ -104,8 +104,8 @@ __device__ __forceinline__ void chain_tile(const LinearArgs& a, const int block_
             pb[c] = *reinterpret_cast<const f32x4v*>(a.gn_beta + g * a.gGamma + kbase + c * CS);
         }
         const double* src = a.gn_sums + ((int64_t)((m0 / a.gn_rows_per_scene) * a.gn_ngroups + g) * kGnSlots + lane) * 2;
-        gsm = src[0];
-        gsq = src[1];
+#pragma unroll
+        for (int i = 0; i < kGnSlots / 64; ++i) { gsm += src[i * 128]; gsq += src[i * 128 + 1]; }
     }
     // epilogue operands: wave t finishes sub-tile t (waves >= NT request the operands of sub-tile wave % NT and drop them)
     const int et = wave % NT;
@@ -231,10 +231,19 @@ __device__ __forceinline__ void chain_tile(const LinearArgs& a, const int block_
             for (int o = 32; o > 0; o >>= 1) { gs += __shfl_xor(gs, o); gq += __shfl_xor(gq, o); }
             if (lane == 0) {
                 const int grp = (nt0 + g * a.N) / a.gn_out_group_cols;
-                const int slot = (int)((block_x * NT + wave) % kGnSlots);
+                // this sub-tile's own slot when the (scene, group) block has at most kGnSlots sub-tiles: a plain store
+                const int cbs = a.gn_out_group_cols >> 4;
+                const int rb = (m0 % a.gn_out_rows_per_scene) >> 4, cb = ((nt0 + g * a.N) % a.gn_out_group_cols) >> 4;
+                const bool own = (a.gn_out_rows_per_scene >> 4) * cbs <= kGnSlots;
+                const int slot = own ? rb * cbs + cb : (int)((block_x * NT + wave) % kGnSlots);
                 double* dst = a.gn_out_sums + (((int64_t)(m0 / a.gn_out_rows_per_scene) * a.gn_out_ngroups + grp) * kGnSlots + slot) * 2;
-                atomicAdd(dst, gs);
-                atomicAdd(dst + 1, gq);
+                if (own) {
+                    typedef double f64x2 __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<f64x2*>(dst) = f64x2{gs, gq};
+                } else {
+                    atomicAdd(dst, gs);
+                    atomicAdd(dst + 1, gq);
+                }
             }
         }
     }
@@ -333,8 +342,8 @@ __global__ __launch_bounds__(256) void chain_linear_stream_kernel(LinearArgs a) 
     if constexpr (PRO == kProLN) shift = a.X[g * a.gX + (int64_t)(m0 + li) * a.ldx];
     if constexpr (PRO == kProGN) {
         const double* src = a.gn_sums + ((int64_t)((m0 / a.gn_rows_per_scene) * a.gn_ngroups + g) * kGnSlots + lane) * 2;
-        gsm = src[0];
-        gsq = src[1];
+#pragma unroll
+        for (int i = 0; i < kGnSlots / 64; ++i) { gsm += src[i * 128]; gsq += src[i * 128 + 1]; }
     }
     const int et = wave % NT;
     const int erow = lane >> 2, ec = (lane & 3) * 4;
@@ -447,10 +456,19 @@ __global__ __launch_bounds__(256) void chain_linear_stream_kernel(LinearArgs a) 
             for (int o = 32; o > 0; o >>= 1) { gs += __shfl_xor(gs, o); gq += __shfl_xor(gq, o); }
             if (lane == 0) {
                 const int grp = (nt0 + g * a.N) / a.gn_out_group_cols;
-                const int slot = (int)((blockIdx.x * NT + wave) % kGnSlots);
+                // this sub-tile's own slot when the (scene, group) block has at most kGnSlots sub-tiles: a plain store
+                const int cbs = a.gn_out_group_cols >> 4;
+                const int rb = (m0 % a.gn_out_rows_per_scene) >> 4, cb = ((nt0 + g * a.N) % a.gn_out_group_cols) >> 4;
+                const bool own = (a.gn_out_rows_per_scene >> 4) * cbs <= kGnSlots;
+                const int slot = own ? rb * cbs + cb : (int)((blockIdx.x * NT + wave) % kGnSlots);
                 double* dst = a.gn_out_sums + (((int64_t)(m0 / a.gn_out_rows_per_scene) * a.gn_out_ngroups + grp) * kGnSlots + slot) * 2;
-                atomicAdd(dst, gs);
-                atomicAdd(dst + 1, gq);
+                if (own) {
+                    typedef double f64x2 __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<f64x2*>(dst) = f64x2{gs, gq};
+                } else {
+                    atomicAdd(dst, gs);
+                    atomicAdd(dst + 1, gq);
+                }
             }
         }
     }

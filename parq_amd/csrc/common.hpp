@@ -74,7 +74,11 @@ hipError_t tl_set_chain(unsigned long long*, unsigned int);
 #endif
 
 constexpr int kWave = 64;
-constexpr int kGnSlots = 64;    // GroupNorm moment accumulators per (scene, group): spreads the fp64 atomics
+// GroupNorm moment slots per (scene, group).  Producers either OWN a slot (chain.hip: sub-tile (row block, column block) of a
+// 256-query x 256-channel block -> slot 16 rb + cb, a plain store: no atomic round trip at the end of the launch, and a summation
+// order that does not depend on arrival) or add into slot (tile % kGnSlots) with fp64 atomics (generic kernel; slots zeroed by the
+// iteration's first kernel).  Consumers sum all slots: 4 per lane and one shuffle tree.
+constexpr int kGnSlots = 256;
 
 // LDS-DMA (global_load_lds, 16 bytes per lane, wave-uniform LDS base + lane * 16) issued through inline asm.  hipcc knows that the
 // builtin writes LDS asynchronously and answers with s_waitcnt vmcnt(0) in front of later C++ reads of LDS it cannot prove

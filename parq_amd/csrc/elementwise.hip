@@ -224,13 +224,15 @@ __global__ __launch_bounds__(256) void box_decode_kernel(BoxDecodeArgs a) {
     const float ref_in = lane < 3 ? a.ref[(int64_t)m * 3 + lane] : 0.5f;
     const float b3c = lane < 3 ? a.b3[lane] : 0.f;
     const float b3r = lane < 6 ? a.b3[6 + lane] : 0.f;
-    // scene-wide GroupNorm moments: kGnSlots (= one per lane) partial accumulators per (scene, head)
+    // scene-wide GroupNorm moments: kGnSlots slots per (scene, head), kGnSlots / 64 per lane
     double sums[4];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const double* src = a.gn_sums + ((int64_t)(scene * 2 + g) * kGnSlots + lane) * 2;
-        sums[2 * g] = src[0];
-        sums[2 * g + 1] = src[1];
+        sums[2 * g] = 0.0;
+        sums[2 * g + 1] = 0.0;
+#pragma unroll
+        for (int i = 0; i < kGnSlots / 64; ++i) { sums[2 * g] += src[i * 128]; sums[2 * g + 1] += src[i * 128 + 1]; }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -352,8 +354,10 @@ __global__ __launch_bounds__(256) void box_decode256_kernel(BoxDecodeArgs a) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const double* src = a.gn_sums + ((int64_t)(scene * 2 + g) * kGnSlots + lane) * 2;
-        sums[2 * g] = src[0];
-        sums[2 * g + 1] = src[1];
+        sums[2 * g] = 0.0;
+        sums[2 * g + 1] = 0.0;
+#pragma unroll
+        for (int i = 0; i < kGnSlots / 64; ++i) { sums[2 * g] += src[i * 128]; sums[2 * g + 1] += src[i * 128 + 1]; }
     }
     const f32x4v x0 = *reinterpret_cast<const f32x4v*>(h2 + 4 * lane);
     const f32x4v x1 = *reinterpret_cast<const f32x4v*>(h2 + C + 4 * lane);

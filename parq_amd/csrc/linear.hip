@@ -151,9 +151,11 @@ __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a
         const int sc_lo = m0 / a.gn_rows_per_scene;
         const int sc_hi = (m0 + T - 1 < a.M ? m0 + T - 1 : a.M - 1) / a.gn_rows_per_scene;
         if (sc_lo == sc_hi) {
-            // the producer spread its atomics over kGnSlots (= one per lane) accumulators per (scene, group)
+            // the producer left its moments in kGnSlots slots per (scene, group): kGnSlots / 64 per lane, then one shuffle tree
             const double* src = a.gn_sums + ((int64_t)(sc_lo * a.gn_ngroups + g) * kGnSlots + lane) * 2;
-            double Sm = src[0], Qs = src[1];
+            double Sm = 0.0, Qs = 0.0;
+#pragma unroll
+            for (int i = 0; i < kGnSlots / 64; ++i) { Sm += src[i * 128]; Qs += src[i * 128 + 1]; }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 Sm += __shfl_xor(Sm, o);
