@@ -380,15 +380,29 @@ __global__ __launch_bounds__(NW * 64) void self_attn_kernel(const float* __restr
 #pragma unroll
             for (int c = 0; c < NC; ++c) kf[s][c] = *reinterpret_cast<const f32x4v*>(kr + c * 16);
         }
+        // V^T as the A operand of O^T += V^T P^T: MFMA row i = lj is head dim kVD(lj, dt) of sub-tile dt.  For head dims that are
+        // multiples of 64 the rows are dealt so that a lane's NDT values are CONSECUTIVE dims (d = NDT lj + dt): NDT / 4 float4 loads
+        // per key instead of NDT scalar ones (the output dim order is a free permutation, undone when O^T goes to LDS)
+        constexpr bool kV4 = (NDT % 4) == 0;
         float vv[2][4][NDT];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int vk = kb + s * 16 + 4 * kq + r;
-                const float* vr = base + 2 * C + (int64_t)(vk < L ? vk : 0) * row_stride + lj;
+                if constexpr (kV4) {
+                    const float* vr = base + 2 * C + (int64_t)(vk < L ? vk : 0) * row_stride + NDT * lj;
 #pragma unroll
-                for (int d = 0; d < NDT; ++d) vv[s][r][d] = vk < L ? vr[d * 16] : 0.f;
+                    for (int d4 = 0; d4 < NDT / 4; ++d4) {
+                        const f32x4v v4 = *reinterpret_cast<const f32x4v*>(vr + 4 * d4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vv[s][r][4 * d4 + e] = vk < L ? v4[e] : 0.f;
+                    }
+                } else {
+                    const float* vr = base + 2 * C + (int64_t)(vk < L ? vk : 0) * row_stride + lj;
+#pragma unroll
+                    for (int d = 0; d < NDT; ++d) vv[s][r][d] = vk < L ? vr[d * 16] : 0.f;
+                }
             }
         if (!q_scaled) {                          // scores in the log2 domain
 #pragma unroll
@@ -449,11 +463,13 @@ __global__ __launch_bounds__(NW * 64) void self_attn_kernel(const float* __restr
                 for (int d = 0; d < NDT; ++d)
                     o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[s][r][d], sacc[s][r], o[d], 0, 0, 0);
     }
-    // ---- combine the 8 key slices: O^T sub-tile d holds rows 16 d + 4 kq + r, column (query) lj
+    // ---- combine the key slices: O^T sub-tile d, accumulator register r holds MFMA row 4 kq + r = head dim 16 d + 4 kq + r
+    // (or NDT (4 kq + r) + d with the float4 V layout above), column (query) lj
+    constexpr bool kV4o = (NDT % 4) == 0;
 #pragma unroll
     for (int d = 0; d < NDT; ++d)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Os[(wave * DH + d * 16 + 4 * kq + r) * 17 + lj] = o[d][r];
+        for (int r = 0; r < 4; ++r) Os[(wave * DH + (kV4o ? NDT * (4 * kq + r) + d : d * 16 + 4 * kq + r)) * 17 + lj] = o[d][r];
     if (kq == 0) {
         Ms[wave * 16 + lj] = m_run;
         Ls[wave * 16 + lj] = l_run;
