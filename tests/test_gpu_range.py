@@ -155,6 +155,40 @@ def test_out_of_range_features_are_not_silent_and_policies_recover():
     assert rel_err(second[0]["pred_logits"].cpu().numpy(), want[0]["pred_logits"].numpy()) < max(1e-4, 2 * e_fp32)
 
 
+def test_training_forward_with_out_of_range_features_never_hands_nan_gradients_to_the_optimizer():
+    """a range violation during a TRAINING forward must not split forward and backward over two workspace
+    layouts, and must not let NaN gradients reach the optimizer.  forward_train reads the device flag before returning (the set
+    loss synchronises with the host anyway), re-runs the same step with the exact fp32 kernels (same dropout seed) and records the
+    mode the stash was written in; backward() uses that mode whatever attention_mode says by then."""
+    cfg = synth.decoder_cfg(dim=256, queries=32, heads=4, ffn=128, layers=2, dropout=0.0)
+    W = synth.make_decoder_weights(cfg, 711, damped=True)
+    sc = synth.make_scene(712, 1, 2, 32, 36, 256)                       # N = 2304 keys: the split-precision training kernels
+    sc["tokens"] = (sc["tokens"] * np.float32(2e4)).astype(np.float32)   # token elements beyond the fp16 range
+    ncls = cfg.NUM_SEMCLS + 1
+    cots = {"pred_logits": torch.from_numpy(synth.normal(713, "cl", (2, 1, 32, ncls))), "center_unnormalized": torch.from_numpy(synth.normal(714, "cc", (2, 1, 32, 3))),
+            "size_unnormalized": torch.from_numpy(synth.normal(715, "cs", (2, 1, 32, 3))), "ortho6d": torch.from_numpy(synth.normal(716, "cr", (2, 1, 32, 6)))}
+    dec = make_decoder(cfg, W).train()
+    assert dec._train_mode() == "split" and dec.range_check == "lazy"
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        outs = dec.forward_train(*scene_args(sc))
+    assert any("fp16 range" in str(r.message) for r in rec)
+    assert dec.attention_mode == "fp32" and dec._train_state[5] == "fp32"          # the stash was written by the fp32 re-run
+    assert all(torch.isfinite(o[k]).all() for o in outs for k in ("pred_logits", "center_unnormalized", "ortho6d"))
+    dec.attention_mode = "split"                                                  # a user flipping the mode between forward and backward
+    grads, d_tok = dec.backward(cots)
+    assert all(torch.isfinite(g).all() for g in grads.values()) and torch.isfinite(d_tok).all()
+    # the same step in fp32 mode from the start gives the same gradients (same kernels, same stash layout)
+    ref = make_decoder(cfg, W).train()
+    ref.attention_mode = "fp32"
+    ref.forward_train(*scene_args(sc))
+    g2, _ = ref.backward(cots)
+    for name in grads:
+        den = float(g2[name].norm())
+        if den > 0:
+            assert float((grads[name] - g2[name]).norm()) <= 1e-5 * den, name
+
+
 def test_product_library_ignores_probe_environment(tmp_path):
     """A stray development variable must not change results: a fresh process with PARQ_FLASH_PROBE /
     PARQ_KVPROJ_PROBE / PARQ_CHAIN_MAX_M set runs golden g1 through the PRODUCT library and still meets 1e-4 — the probe
