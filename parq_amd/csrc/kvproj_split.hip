@@ -361,10 +361,16 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
             // (s_waitcnt vmcnt(0): it cannot tell the ring slots apart), which is exactly the prefetch distance this kernel is about
             typedef float f32x4v __attribute__((ext_vector_type(4)));
             f32x4v v0, v1;
+            // a thread's piece is two 16-byte chunks of one 256-byte row; odd rows fetch theirs in the opposite order, so that the
+            // 16 lanes an LDS cycle serves ({0-3, 12-15, 20-27}: rows r, r+1, r+2, r+3) hit 16 different chunk positions instead of
+            // 8 positions twice (rows are exactly one bank period apart: 3.1e6 conflict cycles per launch before)
+            const unsigned odd = (unsigned)(row & 1) * 16u;
             const unsigned addr = (unsigned)(size_t)(lds_byte*)(src + row * kBK + c * 8);
-            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(v0), "=&v"(v1) : "v"(addr) : "memory");
+            const unsigned addrA = addr + odd, addrB = addr + 16u - odd;
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(v0), "=&v"(v1) : "v"(addrA), "v"(addrB) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0), "+v"(v1)::"memory");
-            float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            const f32x4v lo4 = odd ? v1 : v0, hi4 = odd ? v0 : v1;
+            float x[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = ok ? x[e] : 0.f;
             if constexpr (KIND == kF16) {
