@@ -632,10 +632,34 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
         const int64_t pbase = (int64_t)bh * a.nsplit + split;
         float* op = a.o_part + pbase * kDH * Lq_pad;
         const float drop_scale = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
+        if (a.flags & 8) {
+            // write-through publication (a.flags bit 3): the O^T tile of this wave goes through the (now idle) K/V ring so that a lane
+            // holds four consecutive queries of one dim, and leaves as 16-byte sc1 stores: the 64 KB a workgroup hands to the merge
+            // kernel then drain while other workgroups still compute instead of sitting dirty in L2 until the end-of-kernel
+            // write-back (MI355X_MICROARCH.md "publish-large")
+            __syncthreads();                                                    // every wave is done with the ring
+            float* tr = reinterpret_cast<float*>(smem_h) + wave * (64 * 36);
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tr[(d * 32 + mfma32_row(r, lane)) * 36 + (lane & 31)] = o[d][r] * drop_scale;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // same-wave LDS round trip
+            __builtin_amdgcn_wave_barrier();
+            const int q0w = q - (lane & 31);
+            typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)op, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = i * 64 + lane, dim = idx >> 3, q4 = idx & 7;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(tr + dim * 36 + q4 * 4);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), rs, (int)((dim * Lq_pad + q0w + q4 * 4) * 4), 0, 16);
+            }
+        } else {
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int r = 0; r < 16; ++r) op[(int64_t)(d * 32 + mfma32_row(r, lane)) * Lq_pad + q] = o[d][r] * drop_scale;
+        }
         const float l_tot = xhalf_sum(l_run + l_a + l_b);
         if (kh == 0) {
             a.m_part[pbase * Lq_pad + q] = m_run;
@@ -699,7 +723,8 @@ hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t
     static const bool alt = [] { const char* e = dev_env("PARQ_FLASH_ALTERNATE"); return !(e && e[0] == '0'); }();
     // bit 1 (set by the caller for every other recurrent iteration): sweep backwards — only for whole 64-key stages
     static const int nt = [] { const char* e = dev_env("PARQ_FLASH_NT"); return e ? atoi(e) : 0; }();
-    b.flags = (prio & 1) | ((alt && (a.flags & 2) && (a.Lk % (kStageBlks * kBlkKeys)) == 0) ? 2 : 0) | (nt ? 4 : 0);
+    static const int wt = [] { const char* e = dev_env("PARQ_FLASH_WT"); return e ? atoi(e) : 1; }();      // write-through partials (0: plain stores; measured 1.852 -> 1.846 ms)
+    b.flags = (prio & 1) | ((alt && (a.flags & 2) && (a.Lk % (kStageBlks * kBlkKeys)) == 0) ? 2 : 0) | (nt ? 4 : 0) | ((wt && a.Lq % 256 == 0 && terms == 3) ? 8 : 0);
     const dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * b.H);
     const _Float16* c16 = reinterpret_cast<const _Float16*>(cache);
 #define PARQ_PIPE_LAUNCH(RING, PROBE, T, K, D)                                                                                           \
