@@ -275,12 +275,13 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     const int64_t N = (int64_t)V * sc->h * sc->w;
     const int C = c->C;
     {
+        // T_camera_local (float64), sigmoid(refpoint) tiled over the scenes, its sine embedding for iteration 0 and the cleared range
+        // flags: one launch
         Prof p(c, s, PARQ_PROF_OTHER);
-        HIPCHK(launch_camera_local_f64(sc->T_camera_pseudoCam, sc->T_world_pseudoCam, sc->T_world_local, B, V,
-                                       reinterpret_cast<double*>(wsp + ws.T_cl), s));
-        HIPCHK(launch_initial_ref(A + c->ar.refpoint, B, c->Q, wsp + ws.ref, s));
+        HIPCHK(launch_forward_prologue(sc->T_camera_pseudoCam, sc->T_world_pseudoCam, sc->T_world_local, B, V,
+                                       reinterpret_cast<double*>(wsp + ws.T_cl), A + c->ar.refpoint, c->Q, wsp + ws.ref, A + c->ar.dim_t,
+                                       wsp + ws.emb, wsp + ws.flags, 64, s));
     }
-    HIPCHK(hipMemsetAsync(wsp + ws.flags, 0, 64 * sizeof(float), s));
     // hoisted K/V in-projection of the memory tokens: one GEMM per distinct layer,
     // written head-major [b][{K heads, V heads}][N][dh] so the attention kernel streams contiguous panels
     if ((int64_t)B * N > (int64_t)INT32_MAX) return fail(PARQ_ERR_ARG, "B*N too large");
@@ -313,7 +314,7 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         }
     }
     c->prepared = true;
-    c->emb_valid = false;
+    c->emb_valid = true;              // the prologue left pos2posemb3d(ws.ref) in ws.emb
     c->ref_state = 1;
     return PARQ_OK;
 }
@@ -1123,7 +1124,8 @@ int parq_forward(parq_handle h, const parq_scene* scene, void* workspace, size_t
         o.ortho6d = outs->ortho6d + k * M * 6;
         o.sem_cls_prob = outs->sem_cls_prob + k * M * h->ncls;
         o.coord_pos = outs->coord_pos + k * M * 3;
-        rc = do_iterate(h, scene, wsp, ws, k, ra, k > 0, &o, rb, s);     // ping-pong the reference points
+        rc = do_iterate(h, scene, wsp, ws, k, ra, true, &o, rb, s);      // ping-pong the reference points; the sine embedding of iteration 0
+                                                                         // comes from the prologue, later ones from the previous decode
         if (rc) return rc;
         float* t = ra; ra = rb; rb = t;
     }
@@ -1236,7 +1238,7 @@ int parq_forward_train(parq_handle h, const parq_scene* scene, void* workspace, 
         const bool last = k + 1 == h->I;
         float* ref_next = last ? wsp + ws.ref_next : wsp + ws.shift(k + 1) + ws.refk;
         float* emb_next = last ? wsp + ws.g_emb : wsp + ws.shift(k + 1) + ws.emb;
-        rc = do_iterate(h, scene, wsp, ws, k, wsp + ws.shift(k) + ws.refk, k > 0, &o, ref_next, s, ws.shift(k), emb_next, true);
+        rc = do_iterate(h, scene, wsp, ws, k, wsp + ws.shift(k) + ws.refk, true, &o, ref_next, s, ws.shift(k), emb_next, true);   // ws.emb of iteration 0: prologue
         if (rc) return rc;
     }
     h->ref_state = 0;

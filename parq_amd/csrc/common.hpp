@@ -420,6 +420,8 @@ hipError_t launch_camera_local(const float* T_cp, const float* T_wp, const float
 hipError_t launch_camera_local_f64(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V,
                                    double* T_cl, hipStream_t s);
 hipError_t launch_initial_ref(const float* refpoint_w, int B, int Q, float* ref, hipStream_t s);
+hipError_t launch_forward_prologue(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V, double* T_cl, const float* w, int Q,
+                                   float* ref, const float* dim_t, float* emb, float* flags, int nflags, hipStream_t s);
 hipError_t launch_posemb(const float* ref, const float* dim_t, int M, float* emb, hipStream_t s);
 hipError_t launch_zero_f64(double* p, int n, hipStream_t s);
 hipError_t launch_project_sample(const float* tokens, const float* T_cl, const float* cam, const float* ref,

@@ -102,6 +102,39 @@ __global__ void posemb_kernel(const float* ref, const float* dim_t, int M, float
     emb[idx] = (i & 1) ? cosf(a) : sinf(a);
 }
 
+// ---------------------------------------------------------------- forward prologue in one launch
+// T_camera_local of every (scene, view) in float64, the initial reference points sigmoid(refpoint.weight) tiled over the scenes,
+// their sine embedding (what posemb_kernel would compute from them: same arithmetic) and the cleared range flags: four tiny
+// launches (~5 us each behind a dependent boundary) as one.  Thread i plays every role its index is in range for.
+__global__ void forward_prologue_kernel(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V, double* T_cl,
+                                        const float* w, int Q, float* ref, const float* dim_t, float* emb, float* flags, int nflags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nflags) flags[i] = 0.f;
+    if (i < B * V) {
+        const int b = i / V;
+        const Pose12 cp = load_pose(T_cp + (int64_t)i * 12);
+        const Pose12 wp = load_pose(T_wp + (int64_t)i * 12);
+        const Pose12 wl = load_pose(T_wl + (int64_t)b * 12);
+        const Pose12 o = pose_compose(cp, pose_compose(pose_inverse(wp), wl));
+#pragma unroll
+        for (int k = 0; k < 9; ++k) T_cl[(int64_t)i * 12 + k] = (double)o.R[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) T_cl[(int64_t)i * 12 + 9 + k] = (double)o.t[k];
+    }
+    if (i < B * Q * 3) ref[i] = 1.f / (1.f + expf(-w[i % (Q * 3)]));
+    if (i < B * Q * 384) {
+        const int m = i / 384;
+        const int k = i - m * 384;
+        const int blk = k >> 7;
+        const int j = k & 127;
+        const int axis = blk == 0 ? 1 : (blk == 1 ? 0 : 2);
+        const float r = 1.f / (1.f + expf(-w[(m % Q) * 3 + axis]));
+        const float p = r * 6.283185307179586f;
+        const float a = p / dim_t[j];
+        emb[i] = (j & 1) ? cosf(a) : sinf(a);
+    }
+}
+
 // ---------------------------------------------------------------- project + sample
 // One workgroup per (scene, query); wave wv handles views wv, wv+nwv, ...; each lane owns
 // float4 channel groups, so one texel row (C floats, contiguous in the channels-last stack)
@@ -505,6 +538,16 @@ hipError_t launch_camera_local_f64(const float* T_cp, const float* T_wp, const f
 
 hipError_t launch_initial_ref(const float* w, int B, int Q, float* ref, hipStream_t s) {
     hipLaunchKernelGGL(initial_ref_kernel, dim3(ceil_div(B * Q * 3, 256)), dim3(256), 0, s, w, B, Q, ref);
+    return hipGetLastError();
+}
+
+hipError_t launch_forward_prologue(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V, double* T_cl, const float* w, int Q,
+                                   float* ref, const float* dim_t, float* emb, float* flags, int nflags, hipStream_t s) {
+    int n = B * Q * 384;
+    if (B * V > n) n = B * V;
+    if (nflags > n) n = nflags;
+    hipLaunchKernelGGL(forward_prologue_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, T_cp, T_wp, T_wl, B, V, T_cl, w, Q, ref, dim_t, emb,
+                       flags, nflags);
     return hipGetLastError();
 }
 
