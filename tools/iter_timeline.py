@@ -7,7 +7,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows = [r for r in rows if 'parq' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-fwd = [i for i, r in enumerate(rows) if 'camera_local' in r['Kernel_Name']]
+fwd = [i for i, r in enumerate(rows) if 'forward_prologue' in r['Kernel_Name'] or 'camera_local' in r['Kernel_Name']]
 seg = rows[fwd[4]:fwd[5]]                              # one whole forward in the steady state
 dec = [i for i, r in enumerate(seg) if 'box_decode' in r['Kernel_Name']]
 it = seg[dec[3] + 1:dec[4] + 1]                        # the fifth iteration
