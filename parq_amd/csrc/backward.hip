@@ -153,6 +153,41 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
     const int chunk = (((a.M + (int)gridDim.y - 1) / (int)gridDim.y) + 15) / 16 * 16;
     const int m_begin = (int)blockIdx.y * chunk;
     const int m_end = m_begin + chunk < a.M ? m_begin + chunk : a.M;
+    constexpr int kUp = 16;                       // row groups of a wave requested together (chunks of up to 256 rows)
+    if (chunk <= 16 * kUp) {
+        // short chunk (the row-split launches of the small dW GEMMs: up to 256 rows per workgroup): EVERY operand load of the wave
+        // is requested before the first MFMA — the loop below costs one dependent memory round trip per 4 rows (a conditional load
+        // per iteration; 34 us for a 1024-row chunk).  Out-of-range rows / columns read a valid
+        // address and are zeroed by a select.
+        float av[kUp][2], bv[kUp][2];
+        const int ncl[2] = {nok[0] ? 0 : -li, nok[1] ? 16 : -li};        // column offsets clamped into the matrix
+        const int kcl[2] = {kok[0] ? 0 : -li, kok[1] ? 16 : -li};
+#pragma unroll
+        for (int i = 0; i < kUp; ++i) {
+            const int m = m_begin + wave * 4 + i * 16 + kq;
+            const int mc = m < m_end ? m : a.M - 1;                       // any valid row: zeroed below
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                av[i][s] = Ap[(int64_t)mc * a.lda + ncl[s]];
+                bv[i][s] = Bp[(int64_t)mc * a.ldb + kcl[s]];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < kUp; ++i) {
+            const int m = m_begin + wave * 4 + i * 16 + kq;
+            const bool mok = m < m_end;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                av[i][s] = (mok && nok[s]) ? av[i][s] : 0.f;
+                bv[i][s] = (mok && kok[s]) ? bv[i][s] : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][s], bv[i][t], acc[s][t], 0, 0, 0);
+        }
+    } else
     for (int m0 = m_begin + wave * 4; m0 < m_end; m0 += 16) {
         const int m = m0 + kq;
         const bool mok = m < m_end;
@@ -663,13 +698,16 @@ hipError_t launch_gemm_tn(const float* A, int64_t lda, const float* B, int64_t l
         return hipGetLastError();
     }
     // many rows, few output tiles (the K/V projection backward: M = all tokens): split the rows, accumulate with atomics
-    // each wave walks its rows with dependent global loads (latency-bound): whenever the result is accumulated anyway, split the
-    // rows until ~4 workgroups per CU are in flight and every workgroup keeps at least 64 rows
+    // whenever the result is accumulated anyway, split the rows — but the split launch adds its partial tiles with float atomics
+    // (N*K*splits of them, executed memory-side) and THOSE bound the small dW GEMMs: 1024 rows into a 256 x 256 output ran 16.7 us
+    // at 64 rows per workgroup, 12.9 at 128, 8.95 at 256 (all operand loads of a wave in flight together, kernel above); 512-row
+    // chunks with twice the loads in flight measured the same 9.1 us.  Every workgroup keeps at least 256 rows.
     int splits = 1;
     const int tiles = ceil_div(N, 32) * ceil_div(K, 32);
     if (accumulate && M >= 256) {
         splits = ceil_div(4 * device_num_cus(), tiles);
-        const int cap = M >= 8192 ? M / 1024 : M / 64;
+        static const int min_rows = [] { const char* e = dev_env("PARQ_TN_ROWS"); return e && atoi(e) > 0 ? atoi(e) : 256; }();
+        const int cap = M >= 8192 ? M / 1024 : M / min_rows;
         if (splits > cap) splits = cap;
         if (splits < 1) splits = 1;
     }
