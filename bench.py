@@ -284,7 +284,7 @@ def train_bench(args):
     red_dev = device if backend == "nccl" else None
     B = args.scenes_per_gpu if args.scenes_per_gpu > 1 else 4
     V, (h, w), Q, C, I = WORKLOAD["views"], WORKLOAD["feat_hw"], WORKLOAD["queries"], WORKLOAD["dim"], WORKLOAD["iters"]
-    cfg = synth.decoder_cfg(dim=C, queries=Q, heads=WORKLOAD["heads"], ffn=WORKLOAD["ffn"], layers=I, dropout=0.1)   # config/train.yaml:53
+    cfg = synth.decoder_cfg(dim=C, queries=Q, heads=WORKLOAD["heads"], ffn=WORKLOAD["ffn"], layers=I, dropout=args.dropout)   # config/train.yaml:53 (0.1)
     W = synth.make_decoder_weights(cfg, 41, damped=True)
     dec = PARQDecoder(cfg)
     dec.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=False)
@@ -308,6 +308,21 @@ def train_bench(args):
 
     for _ in range(args.warmup):
         step()
+    phase_ms = None
+    if rank == 0 and args.phase_times:
+        # untimed extra steps with an event between the phases (device time of each phase incl. the host stalls inside it)
+        acc = []
+        for _ in range(5):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            opt.zero_grad(set_to_none=True)
+            ev[0].record(); outs = dec(*inputs, feat_hw=(h, w))
+            ev[1].record(); loss = dec.loss(outs, obbs, T_wl, sym)["total_loss"]
+            ev[2].record(); loss.backward()
+            ev[3].record(); torch.nn.utils.clip_grad_norm_(dec.parameters(), 1.0); opt.step()
+            ev[4].record(); torch.cuda.synchronize()
+            acc.append([ev[i].elapsed_time(ev[i + 1]) for i in range(4)])
+        med = np.median(np.array(acc), axis=0)
+        phase_ms = {"forward": float(med[0]), "loss": float(med[1]), "backward": float(med[2]), "clip+adamw": float(med[3])}
     torch.cuda.synchronize(); parallel.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -322,9 +337,9 @@ def train_bench(args):
             "n_gpus": world, "collective_backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
             "parq_env": parq_env(), "dev_lib": bool(args.dev_lib), "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "final_loss": float(loss.detach()),
+            "final_loss": float(loss.detach()), "phase_ms": phase_ms,
             "config": {"workload": "BASELINE cfg4 per-GPU shard: %d scenes, 10 views 480x640 (120x160 features), 256 queries, 8 iterations, "
-                                   "d=256; dropout 0.1; 12 synthetic boxes per scene" % B,
+                                   "d=256; dropout %g; 12 synthetic boxes per scene" % (B, args.dropout),
                        "scenes_per_gpu": B, "parallelism": "dp%d (one flat gradient all-reduce per step)" % world}}))
     if world > 1:
         parallel.barrier()
@@ -379,6 +394,10 @@ def main():
                     help="cross-attention arithmetic; default = the library default (split: fp32-class accuracy). "
                          "fp16 / bf16 are the reduced-precision configurations (NOT the headline number)")
     ap.add_argument("--train", action="store_true", help="time the training step of BASELINE config 4's per-GPU shard instead")
+    ap.add_argument("--dropout", type=float, default=0.1, help="--train: dropout rate (config/train.yaml:53 = 0.1, the default; other "
+                    "values are for kernel A/B only)")
+    ap.add_argument("--phase-times", action="store_true", help="--train: also report the median device time of forward / loss / "
+                    "backward / optimizer over 5 extra untimed steps (phase_ms)")
     ap.add_argument("--dev-lib", action="store_true", help="development only: bind parq_amd/_C/libparq_hip_dev.so (-DPARQ_DEV_PROBES: "
                     "environment A/B switches and probe kernels); the line is then marked as NOT a headline number")
     ap.add_argument("--share-device", action="store_true", help="N > 1 on a box with fewer than N GPUs: every rank uses cuda:0 and the "

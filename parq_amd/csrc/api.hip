@@ -678,10 +678,9 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
                              k == 0 ? gRef : nullptr, s));
     // last layers: w3 rows 0..2 centre (input h2act[:, :C]), rows 6..11 rotation (input h2act[:, C:])
     HIPCHK(launch_gn_apply(wi + ws.h2, 2 * C, gn2, A + ar.gn2_g, A + ar.gn2_b, M, C, 2, Q, eps, act, 2 * C, s));
-    HIPCHK(launch_gemm_tn(gH3, 16, act, 2 * C, G + ar.heads3_w, C, M, 3, C, 1, s));
-    HIPCHK(launch_gemm_tn(gH3 + 3, 16, act + C, 2 * C, G + ar.heads3_w + 6 * (int64_t)C, C, M, 6, C, 1, s));
-    HIPCHK(launch_colsum(gH3, 16, M, 3, G + ar.heads3_b, 1, s));
-    HIPCHK(launch_colsum(gH3 + 3, 16, M, 6, G + ar.heads3_b + 6, 1, s));
+    // (every dW product below also leaves the bias gradient = column sums of its dY operand: launch_gemm_tn's last arguments)
+    HIPCHK(launch_gemm_tn(gH3, 16, act, 2 * C, G + ar.heads3_w, C, M, 3, C, 1, s, G + ar.heads3_b));
+    HIPCHK(launch_gemm_tn(gH3 + 3, 16, act + C, 2 * C, G + ar.heads3_w + 6 * (int64_t)C, C, M, 6, C, 1, s, G + ar.heads3_b + 6));
     HIPCHK(launch_head3_bwd(gH3, A + ar.heads3_w, gZ, M, C, s));                       // gZ = d loss / d h2act
     HIPCHK(launch_gn_bwd(wi + ws.h2, 2 * C, gn2, A + ar.gn2_g, A + ar.gn2_b, M, C, 2, Q, eps, gZ, 2 * C, act, bs, gH2, 2 * C,
                          G + ar.gn2_g, G + ar.gn2_b, s));
@@ -696,8 +695,7 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
                          G + ar.gn1_g, G + ar.gn1_b, s));
     // fused first layers on x3 = norm3(xc)
     HIPCHK(launch_layernorm(wi + ws.xc, A + L.n3_w, A + L.n3_b, tmp, M, C, eps, s));           // tmp = x3
-    HIPCHK(launch_gemm_tn(gH1, NH1, tmp, C, G + ar.heads1_w, C, M, NH1, C, 1, s));
-    HIPCHK(launch_colsum(gH1 + 2 * C, NH1, M, NH1 - 2 * C, G + ar.heads1_b + 2 * C, 1, s));
+    HIPCHK(launch_gemm_tn(gH1, NH1, tmp, C, G + ar.heads1_w, C, M, NH1, C, 1, s, G + ar.heads1_b, 2 * C));   // columns < 2C: GroupNorm follows, no bias
     {
         LinearArgs a = mm(gH1, NH1, h1T, NH1, C, gA, C);                                       // gA = d / d x3
         HIPCHK(launch_linear(a, 1, s));
@@ -707,15 +705,13 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     {
         const float* gd = through_dropout(gB, 5);
         if (!gd) return fail(PARQ_ERR_HIP, "dropout_apply failed");
-        HIPCHK(launch_gemm_tn(gd, C, wi + ws.ffn, F, G + L.lin2_w, F, M, C, F, 1, s));
-        HIPCHK(launch_colsum(gd, C, M, C, G + L.lin2_b, 1, s));
+        HIPCHK(launch_gemm_tn(gd, C, wi + ws.ffn, F, G + L.lin2_w, F, M, C, F, 1, s, G + L.lin2_b));
         LinearArgs a = mm(gd, C, l2T, C, F, gFfh, F);                // d / d ffn hidden, through dropout (the stash holds the dropped,
         a.relu_mask = wi + ws.ffn; a.ldmask = F; a.mask_scale = inv_keep;   // rescaled hidden: zero = dropped or ReLU-inactive) and the ReLU
         HIPCHK(launch_linear(a, 1, s));
     }
     HIPCHK(launch_layernorm(wi + ws.xb, A + L.n2_w, A + L.n2_b, tmp, M, C, eps, s));           // tmp = x2
-    HIPCHK(launch_gemm_tn(gFfh, F, tmp, C, G + L.lin1_w, C, M, F, C, 1, s));
-    HIPCHK(launch_colsum(gFfh, F, M, F, G + L.lin1_b, 1, s));
+    HIPCHK(launch_gemm_tn(gFfh, F, tmp, C, G + L.lin1_w, C, M, F, C, 1, s, G + L.lin1_b));
     {
         LinearArgs a = mm(gFfh, F, l1T, F, C, gA, C);                                          // gA = d / d x2 = gB + gFfh W1
         a.R = gB; a.ldr = C;
@@ -729,8 +725,7 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     {
         const float* gd = through_dropout(gB, 3);
         if (!gd) return fail(PARQ_ERR_HIP, "dropout_apply failed");
-        HIPCHK(launch_gemm_tn(gd, C, wi + ws.attn, C, G + L.cross_out_w, C, M, C, C, 1, s));
-        HIPCHK(launch_colsum(gd, C, M, C, G + L.cross_out_b, 1, s));
+        HIPCHK(launch_gemm_tn(gd, C, wi + ws.attn, C, G + L.cross_out_w, C, M, C, C, 1, s, G + L.cross_out_b));
         LinearArgs a = mm(gd, C, coT, C, C, gDo, C);                                           // d / d attention output
         HIPCHK(launch_linear(a, 1, s));
     }
@@ -752,8 +747,7 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     // q = (x1 + pos) Wq^T + bq,  x1 = norm1(xa)
     HIPCHK(launch_layernorm(wi + ws.xa, A + L.n1_w, A + L.n1_b, tmp, M, C, eps, s));
     HIPCHK(launch_add(tmp, wi + ws.pos, tmp, (int64_t)M * C, s));                              // tmp = x1 + pos
-    HIPCHK(launch_gemm_tn(gC, C, tmp, C, G + L.cross_in_w, C, M, C, C, 1, s));
-    HIPCHK(launch_colsum(gC, C, M, C, G + L.cross_in_b, 1, s));
+    HIPCHK(launch_gemm_tn(gC, C, tmp, C, G + L.cross_in_w, C, M, C, C, 1, s, G + L.cross_in_b));
     {
         LinearArgs a = mm(gC, C, cqT, C, C, gPos, C);                                          // gPos = d / d (x1 + pos) [cross]
         HIPCHK(launch_linear(a, 1, s));
@@ -764,8 +758,7 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     {
         const float* gd = through_dropout(gB, 1);
         if (!gd) return fail(PARQ_ERR_HIP, "dropout_apply failed");
-        HIPCHK(launch_gemm_tn(gd, C, wi + ws.sa, C, G + L.self_out_w, C, M, C, C, 1, s));
-        HIPCHK(launch_colsum(gd, C, M, C, G + L.self_out_b, 1, s));
+        HIPCHK(launch_gemm_tn(gd, C, wi + ws.sa, C, G + L.self_out_w, C, M, C, C, 1, s, G + L.self_out_b));
         LinearArgs a = mm(gd, C, soT, C, C, gA, C);                                            // gA = d / d self-attention output
         HIPCHK(launch_linear(a, 1, s));
     }
@@ -778,9 +771,8 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
                            (dh == 64 || dh == 32) ? nullptr : wsp + ws.g_mat));
     // in-projection: [q | k] = (tgt + pos) Wqk^T, v = tgt Wv^T
     HIPCHK(launch_add(wi + ws.tgt, wi + ws.pos, tmp, (int64_t)M * C, s));                      // tmp = tgt + pos
-    HIPCHK(launch_gemm_tn(gQkv, 3 * C, tmp, C, G + L.self_in_w, C, M, 2 * C, C, 1, s));
-    HIPCHK(launch_gemm_tn(gQkv + 2 * C, 3 * C, wi + ws.tgt, C, G + L.self_in_w + 2 * (int64_t)C * C, C, M, C, C, 1, s));
-    HIPCHK(launch_colsum(gQkv, 3 * C, M, 3 * C, G + L.self_in_b, 1, s));
+    HIPCHK(launch_gemm_tn(gQkv, 3 * C, tmp, C, G + L.self_in_w, C, M, 2 * C, C, 1, s, G + L.self_in_b));
+    HIPCHK(launch_gemm_tn(gQkv + 2 * C, 3 * C, wi + ws.tgt, C, G + L.self_in_w + 2 * (int64_t)C * C, C, M, C, C, 1, s, G + L.self_in_b + 2 * C));
     {
         // d / d (tgt + pos) through q and k: rows 0 .. 2C-1 of W_in, i.e. columns 0 .. 2C-1 of W_in^T ([C][3C])
         LinearArgs a = lin(gQkv, 3 * C, siT, 3 * C, nullptr, gA, C, M, C, 2 * C);
@@ -796,15 +788,13 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     HIPCHK(launch_sample_bwd(sc->tokens, reinterpret_cast<const double*>(wsp + ws.T_cl), sc->camera, ref, c->sb, B, sc->V, sc->h, sc->w,
                              C, Q, gC, g_tokens, k == 0 ? gRef : nullptr, s));
     // ---- position MLP (transformer_parq.py:176-180,317): pos = relu(emb W0^T + b0) W2^T + b2
-    HIPCHK(launch_gemm_tn(gPos, C, wi + ws.pe_h, C, G + ar.pe2_w, C, M, C, C, 1, s));
-    HIPCHK(launch_colsum(gPos, C, M, C, G + ar.pe2_b, 1, s));
+    HIPCHK(launch_gemm_tn(gPos, C, wi + ws.pe_h, C, G + ar.pe2_w, C, M, C, C, 1, s, G + ar.pe2_b));
     {
         LinearArgs a = mm(gPos, C, p2T, C, C, gA, C);                                          // gA = d / d pe hidden
         a.relu_mask = wi + ws.pe_h; a.ldmask = C;
         HIPCHK(launch_linear(a, 1, s));
     }
-    HIPCHK(launch_gemm_tn(gA, C, wi + ws.emb, 384, G + ar.pe0_w, 384, M, C, 384, 1, s));
-    HIPCHK(launch_colsum(gA, C, M, C, G + ar.pe0_b, 1, s));
+    HIPCHK(launch_gemm_tn(gA, C, wi + ws.emb, 384, G + ar.pe0_w, 384, M, C, 384, 1, s, G + ar.pe0_b));
     if (k == 0) {
         LinearArgs a = lin(gA, C, p0T, C, nullptr, gEmb, 384, M, 384, C);
         HIPCHK(launch_linear(a, 1, s));
@@ -963,12 +953,25 @@ int parq_pack_weights(parq_handle h, void* arena_v, size_t arena_bytes, parq_str
         if (it->second.n != numel) { rc = fail(PARQ_ERR_ARG, "weight '%s' has %lld elements, expected %lld", name.c_str(), (long long)it->second.n, (long long)numel); return nullptr; }
         return it->second.p;
     };
+    GatherArgs gq;
+    gq.count = 0;
     auto copy = [&](const std::string& name, int64_t dst, int64_t numel) -> bool {
         const float* p = get(name, numel);
         if (!p) return false;
-        hipError_t e = hipMemcpyAsync(A + dst, p, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, s);
-        if (e != hipSuccess) { rc = fail(PARQ_ERR_HIP, "hipMemcpyAsync(%s): %s", name.c_str(), hipGetErrorString(e)); return false; }
+        // queued: the tensors go in launches of up to kGatherMax copies (a training step re-packs ~50 tensors after every
+        // optimizer step; one hipMemcpyAsync each was ~50 dependent 3 us operations)
+        if (gq.count == kGatherMax) {
+            hipError_t e = launch_gather_copy(gq, s);
+            if (e != hipSuccess) { rc = fail(PARQ_ERR_HIP, "gather copy (%s): %s", name.c_str(), hipGetErrorString(e)); return false; }
+            gq.count = 0;
+        }
+        gq.src[gq.count] = p; gq.dst[gq.count] = A + dst; gq.n[gq.count] = numel; ++gq.count;
         return true;
+    };
+    auto flush = [&]() -> int {
+        HIPCHK(launch_gather_copy(gq, s));
+        gq.count = 0;
+        return PARQ_OK;
     };
     HIPCHK(hipMemsetAsync(A, 0, (size_t)c->ar.total * sizeof(float), s));
     for (int li = 0; li < c->nl; ++li) {
@@ -984,7 +987,6 @@ int parq_pack_weights(parq_handle h, void* arena_v, size_t arena_bytes, parq_str
             !copy(p + "norm2.weight", L.n2_w, C) || !copy(p + "norm2.bias", L.n2_b, C) ||
             !copy(p + "norm3.weight", L.n3_w, C) || !copy(p + "norm3.bias", L.n3_b, C))
             return rc;
-        HIPCHK(launch_split_f32(A + L.cross_in_w + C * C, A + L.kv_whi, A + L.kv_wlo, 2 * C * C, s));
     }
     c->kv16_state = 1;
     const Arena& ar = c->ar;
@@ -1009,6 +1011,11 @@ int parq_pack_weights(parq_handle h, void* arena_v, size_t arena_bytes, parq_str
         !copy(hc + "8.bias", ar.heads3_b, 3) || !copy(hr + "8.bias", ar.heads3_b + 6, 6) ||
         !copy("mean_sizes", ar.mean_sizes, (int64_t)c->cfg.num_mean_sizes * 3))
         return rc;
+    if ((rc = flush()) != PARQ_OK) return rc;
+    for (int li = 0; li < c->nl; ++li) {                // hi/lo split of the K/V projection weights, from the packed copy
+        const LayerW& L = c->ar.layers[li];
+        HIPCHK(launch_split_f32(A + L.cross_in_w + C * C, A + L.kv_whi, A + L.kv_wlo, 2 * C * C, s));
+    }
     // small host table kept in the handle, so the copy needs no synchronisation with the stream
     HIPCHK(hipMemcpyAsync(A + ar.dim_t, c->dim_t_host, sizeof(c->dim_t_host), hipMemcpyHostToDevice, s));
     c->derived_valid = false;          // folded position-MLP weights + tile-ordered mirror: built by the first inference iteration

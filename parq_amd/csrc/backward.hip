@@ -47,6 +47,8 @@ struct TnArgs {
     float* out; int64_t ldo;
     int M, N, K;
     int accumulate;
+    float* bias;        // optional: bias[n] (+)= sum_m A[m][n] for n >= bias_from (the bias gradient of the same layer), by the
+    int bias_from;      // workgroups of the first k-tile from the A values they hold anyway (gemm_tn_kernel only)
 };
 
 // The same contraction for LARGE outputs with FEW rows (the C = 1024 layers of the reference's shipped size: out 1024 x 1024 ..
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(256) void gemm_tn_tile64_kernel(TnArgs a) {
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
     __shared__ __attribute__((aligned(16))) float red[4 * 4 * 4 * 64];
+    __shared__ float cred[4][32];
     const int ntk = (a.K + 31) / 32;
     const int k0 = (int)(blockIdx.x % ntk) * 32, n0 = (int)(blockIdx.x / ntk) * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -153,6 +156,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
     const int chunk = (((a.M + (int)gridDim.y - 1) / (int)gridDim.y) + 15) / 16 * 16;
     const int m_begin = (int)blockIdx.y * chunk;
     const int m_end = m_begin + chunk < a.M ? m_begin + chunk : a.M;
+    float cs[2] = {0.f, 0.f};                     // column sums of this lane's A values (bias gradient)
     constexpr int kUp = 16;                       // row groups of a wave requested together (chunks of up to 256 rows)
     if (chunk <= 16 * kUp) {
         // short chunk (the row-split launches of the small dW GEMMs: up to 256 rows per workgroup): EVERY operand load of the wave
@@ -181,6 +185,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
             for (int s = 0; s < 2; ++s) {
                 av[i][s] = (mok && nok[s]) ? av[i][s] : 0.f;
                 bv[i][s] = (mok && kok[s]) ? bv[i][s] : 0.f;
+                cs[s] += av[i][s];
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -196,6 +201,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
         for (int s = 0; s < 2; ++s) {
             av[s] = (mok && nok[s]) ? Ap[(int64_t)m * a.lda + s * 16] : 0.f;
             bv[s] = (mok && kok[s]) ? Bp[(int64_t)m * a.ldb + s * 16] : 0.f;
+            cs[s] += av[s];
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -208,7 +214,24 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[(((wave * 2 + s) * 2 + t) * 4 + r) * 64 + lane] = acc[s][t][r];
+    const bool do_bias = a.bias != nullptr && k0 == 0;       // workgroup-uniform
+    if (do_bias) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            cs[s] += __shfl_xor(cs[s], 16);
+            cs[s] += __shfl_xor(cs[s], 32);
+            if (kq == 0) cred[wave][s * 16 + li] = cs[s];
+        }
+    }
     __syncthreads();
+    if (do_bias && tid < 32) {
+        const int n = n0 + tid;
+        if (n < a.N && n >= a.bias_from) {
+            const float v = (cred[0][tid] + cred[1][tid]) + (cred[2][tid] + cred[3][tid]);
+            if (gridDim.y > 1) atomicAdd(a.bias + n, v);
+            else a.bias[n] = a.accumulate ? a.bias[n] + v : v;
+        }
+    }
     // thread -> (row n, 4 consecutive k) of the 32x32 tile; sub-tile accumulator holds rows 4*(lane>>4)+r, column lane&15
     const int row = tid >> 3, c4 = (tid & 7) * 4;
     const int s = row >> 4, rr = row & 15, t = c4 >> 4, cc = c4 & 15;
@@ -689,13 +712,16 @@ hipError_t launch_transpose(const float* src, int64_t ld_src, float* dst, int64_
     return hipGetLastError();
 }
 hipError_t launch_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* out, int64_t ldo, int M, int N, int K,
-                          int accumulate, hipStream_t s) {
+                          int accumulate, hipStream_t s, float* bias, int bias_from) {
     TnArgs a;
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.accumulate = accumulate;
+    a.bias = bias; a.bias_from = bias_from;
     // large outputs from few rows (C = 1024 layers): 64 x 64 tiles with LDS-staged rows
     if ((int64_t)N * K >= (1 << 19) && M <= 4096) {
         hipLaunchKernelGGL(gemm_tn_tile64_kernel, dim3(ceil_div(N, 64) * ceil_div(K, 64)), dim3(256), 0, s, a);
-        return hipGetLastError();
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess || !bias) return e;
+        return launch_colsum(A + bias_from, lda, M, N - bias_from, bias + bias_from, accumulate, s);     // not fused in that kernel
     }
     // many rows, few output tiles (the K/V projection backward: M = all tokens): split the rows, accumulate with atomics
     // whenever the result is accumulated anyway, split the rows — but the split launch adds its partial tiles with float atomics

@@ -160,7 +160,7 @@ __device__ __forceinline__ void split8(const float* x, half8& hi, half8& lo) {
 
 // ---- dropout (training): counter-based keep decision, identical in forward and backward.  Element (row, col) of stream `seed`
 // is kept when a 24-bit hash is >= p * 2^24; kept values are scaled by 1 / (1 - p) (torch.nn.Dropout semantics).
-__host__ __device__ inline uint32_t rng_mix(uint32_t x) {
+__host__ __device__ constexpr uint32_t rng_mix(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
@@ -171,24 +171,42 @@ __host__ __device__ inline uint32_t rng_stream(uint32_t base, uint32_t stream) {
 __host__ __device__ inline uint32_t drop_rowhash(uint32_t seed, uint32_t row) { return rng_mix(seed ^ (row * 0x9e3779b1U)); }
 // keep(row, col) = mix(rowhash(seed, row) ^ colhash(col)) >= ceil(p * 2^24) * 256: the column part does not depend on the seed, so
 // the attention kernels hash a key ONCE (per stage in the forward, per lane in the backward, where a lane owns a key) and spend
-// xor + multiply + shift-xor + multiply + compare per element.  The final mix matters: comparing the bare xor against a threshold makes the
+// xor + 24-bit multiply + shift-xor + 24-bit multiply + compare per element.  The final mix matters: comparing the bare xor against a threshold makes the
 // dropped set of a row the preimage of `rowhash ^ [0, thr)`, whose large dyadic sub-blocks depend only on the top bits of the
 // row hash — 1/16 of all row pairs then share >60 % of their dropped columns at p = 0.1 (a 4-wise xor dependence that uniformity
 // and pairwise independence do not show).  multiply / shift-xor / multiply after the xor breaks that linearity: over all pairs of
-// 512 rows the worst shared-drop fraction is 0.175 at p = 0.1 (a full 32-bit finaliser gives 0.178; one multiply + shift-xor
+// 512 rows the worst shared-drop fraction is 0.171 - 0.176 at p = 0.1 (a full 32-bit finaliser gives 0.178; one multiply + shift-xor
 // still leaves 0.20-0.23 against the 6-sigma bound 0.196).  tests/test_host_cpu.py simulates the hash in NumPy,
 // tests/test_gpu_kernels.py::test_dropout_masks_of_row_pairs_overlap_like_independent_draws checks the masks the kernels use.
-__host__ __device__ inline uint32_t drop_colhash(uint32_t col) { return rng_mix(col * 0x85ebca77U + 0x6a09e667U); }
+// Column hash = hash of the 32-column block ^ one of 16 constants chosen by bits 0, 1, 3, 4 of the column ^ a constant where bit 2
+// is set.  In the attention kernels a lane's 16 accumulator registers of a 32-key block are the columns (r & 3) + 8 (r >> 2) + 4 kh
+// (kh = lane >> 5): the block part is wave-uniform (scalar unit), the kh part folds into the lane's row hash once, and the register
+// part is a literal operand of the xor in drop_keep_h — no per-key hashing, no table in LDS, no registers (the forward kernel
+// used to hash 32 keys per block, park them in LDS and read 16 back: two dependent LDS round trips at the head of every step,
+// +32 % on the training forward).  The fixed xor offsets between the columns of a block are decorrelated by the two multiplies
+// of drop_keep_h like the row offsets: co-drop frequency of every in-block column pair within 1.7 % of p^2 over 6 M samples.
+__host__ __device__ constexpr uint32_t drop_blockhash(uint32_t blk) { return rng_mix(blk * 0x85ebca77U + 0x6a09e667U); }
+__host__ __device__ constexpr uint32_t drop_regpart(uint32_t r) { return rng_mix(0x3c6ef372U + r); }       // r = 0 .. 15
+constexpr uint32_t kDropBit2Part = rng_mix(0xa54ff53aU);
+__host__ __device__ constexpr uint32_t drop_colhash(uint32_t col) {
+    const uint32_t k = col & 31u;
+    return drop_blockhash(col >> 5) ^ drop_regpart((k & 3u) | ((k >> 3) << 2)) ^ ((k & 4u) ? kDropBit2Part : 0u);
+}
 // threshold in the scale of the full 32-bit hash: (h >> 8) >= ceil(p 2^24)  <=>  h >= ceil(p 2^24) * 256 (saturated: p ~ 1 keeps nothing
 // but h = 2^32 - 1)
 __host__ __device__ inline uint32_t drop_threshold(float p) {
     const float t = ceilf(p * 16777216.0f);
     return t >= 16777216.0f ? 0xffffffffU : ((uint32_t)t << 8);
 }
+// Both multiplies are 24 x 24-bit (v_mul_u32_u24, full rate; the 32-bit v_mul_lo_u32 is a quarter-rate instruction and two of them per
+// probability were ~2/3 of the mask's issue time in the attention kernels): the low 24 bits of the xor of two full 32-bit hashes,
+// times a 24-bit odd constant, shift-xor, low 24 bits times a second constant; the compared top bits depend on every one of the 24
+// bits.  Same statistics as the 32-bit form in the simulation of tests/test_host_cpu.py (worst shared-drop fraction over all pairs of
+// 512 rows 0.171 - 0.176 for three seeds, 32-bit form 0.175).
 __host__ __device__ inline bool drop_keep_h(uint32_t rowhash, uint32_t colhash, uint32_t thr) {
-    uint32_t h = (rowhash ^ colhash) * 0x9E3779B1U;
+    uint32_t h = ((rowhash ^ colhash) & 0xffffffU) * 0x9E3779U;
     h ^= h >> 16;
-    h *= 0x85EBCA6BU;             // second multiply: the compared (top) bits depend on every bit of the xor
+    h = (h & 0xffffffU) * 0x85EBCBU;
     return h >= thr;
 }
 __host__ __device__ inline bool drop_keep(uint32_t rowhash, uint32_t col, float p) {
@@ -323,6 +341,10 @@ hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t
                               int kind = kF16);   // partials; merge as usual
 // kvproj_split.hip: tokens -> split cache directly (W pre-split with launch_split_f32)
 hipError_t launch_split_f32(const float* src, void* hi, void* lo, int64_t n, hipStream_t s);
+// elementwise.hip: up to kGatherMax device-to-device float copies in ONE launch (the weight pack: ~50 tensors per training step)
+constexpr int kGatherMax = 64;
+struct GatherArgs { const float* src[kGatherMax]; float* dst[kGatherMax]; int64_t n[kGatherMax]; int count; };
+hipError_t launch_gather_copy(const GatherArgs& g, hipStream_t s);
 hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void* Wlo, const float* bias, int B, int N,
                                int C, int H, void* cache, int* overflow, hipStream_t s, int terms = 3, int kind = kF16);
 // fp32 -> 16-bit (round to nearest) weights of the single-term modes
@@ -351,7 +373,7 @@ struct ScaleBox { float lo[3]; float hi[3]; };
 // ---- backward (backward.hip, attn_bwd.hip)
 hipError_t launch_transpose(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int R, int Cc, hipStream_t s);
 hipError_t launch_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* out, int64_t ldo, int M, int N, int K,
-                          int accumulate, hipStream_t s);
+                          int accumulate, hipStream_t s, float* bias = nullptr, int bias_from = 0);   // bias[n] (+)= column sums of A, n >= bias_from
 hipError_t launch_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, hipStream_t s);
 hipError_t launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t s);
 hipError_t launch_axpy_rows(const float* x, int64_t ldx, float* y, int64_t ldy, int M, int N, int accumulate, hipStream_t s);

@@ -541,6 +541,28 @@ hipError_t launch_initial_ref(const float* w, int B, int Q, float* ref, hipStrea
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ many small device-to-device copies in one launch
+// blockIdx.y = copy, blockIdx.x strides over its floats (16-byte pieces where both pointers allow)
+__global__ __launch_bounds__(256) void gather_copy_kernel(GatherArgs g) {
+    const int e = blockIdx.y;
+    const float* __restrict__ src = g.src[e];
+    float* __restrict__ dst = g.dst[e];
+    const int64_t n = g.n[e];
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, nt = (int64_t)gridDim.x * 256;
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = t; i < n4; i += nt) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+        for (int64_t i = (n4 << 2) + t; i < n; i += nt) dst[i] = src[i];
+    } else {
+        for (int64_t i = t; i < n; i += nt) dst[i] = src[i];
+    }
+}
+hipError_t launch_gather_copy(const GatherArgs& g, hipStream_t s) {
+    if (g.count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_copy_kernel, dim3(32, g.count), dim3(256), 0, s, g);
+    return hipGetLastError();
+}
+
 hipError_t launch_forward_prologue(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V, double* T_cl, const float* w, int Q,
                                    float* ref, const float* dim_t, float* emb, float* flags, int nflags, hipStream_t s) {
     int n = B * Q * 384;

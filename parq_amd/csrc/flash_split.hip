@@ -361,22 +361,13 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
     };
     const uint32_t drop_rh = DROP ? drop_rowhash(a.drop_seed, (uint32_t)(bh * a.Lq + q)) : 0u;      // this lane's query row
     const uint32_t drop_thr = DROP ? drop_threshold(a.drop_p) : 0u;
-    uint32_t* drop_ch = reinterpret_cast<uint32_t*>(smem_h + (size_t)RING * kStageBlks * kBlkHalfs) + wave * 32;
-    uint32_t dch[16];                                                      // column hashes of this lane's 16 keys of the block in softmax
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dch[r] = 0u;
+    // dropout column part (common.hpp): block hash (wave-uniform) ^ register constant ^ kh constant; the latter folds into the row hash
+    const uint32_t drop_rkh = drop_rh ^ (kh ? kDropBit2Part : 0u);
+    uint32_t dbase = 0u;                                                   // drop_rkh ^ block hash of the block in softmax
     // global 32-key block of local block n (the dropout column index is the key's index in the head's key axis)
     auto gblk = [&](int n) { return rev ? t_end * kStageBlks - 1 - n : B0 + n; };
     auto load_drop = [&](int n) {
-        if constexpr (DROP) {
-            if (lane < 32) drop_ch[lane] = drop_colhash((uint32_t)(gblk(n) * kBlkKeys + lane));
-            // keys mfma32_row(r, lane) = (r & 3) + 8 (r >> 2) + 4 kh: register group g = r >> 2 reads hashes 8 g + 4 kh .. + 3
-#pragma unroll
-            for (int g2 = 0; g2 < 4; ++g2) {
-                const uint4 c4 = *reinterpret_cast<const uint4*>(drop_ch + 8 * g2 + 4 * kh);
-                dch[4 * g2] = c4.x; dch[4 * g2 + 1] = c4.y; dch[4 * g2 + 2] = c4.z; dch[4 * g2 + 3] = c4.w;
-            }
-        }
+        if constexpr (DROP) dbase = drop_rkh ^ drop_blockhash((uint32_t)gblk(n));
     };
     // probabilities of accumulator half m of block-parity CUR (epilogue; the steady state uses sm_pair)
     auto softmax_half = [&](auto cur, int m) {
@@ -386,7 +377,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
         for (int e = 0; e < 8; ++e) {
             p[e] = __builtin_amdgcn_exp2f(sacc[CUR][8 * m + e]);
             l_run += p[e];
-            if constexpr (DROP) p[e] = drop_keep_h(drop_rh, dch[8 * m + e], drop_thr) ? p[e] : 0.f;
+            if constexpr (DROP) p[e] = drop_keep_h(dbase, drop_regpart(8 * m + e), drop_thr) ? p[e] : 0.f;
         }
         if constexpr (TERMS == 3) split8(p, Phi[CUR][m], Plo[CUR][m]);
         else Phi[CUR][m] = cvt8_rn<KIND>(p);
@@ -441,8 +432,8 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
         l_a += p0;
         l_b += p1;
         if constexpr (DROP) {                                                // the normaliser above stays undropped
-            p0 = drop_keep_h(drop_rh, dch[2 * J], drop_thr) ? p0 : 0.f;
-            p1 = drop_keep_h(drop_rh, dch[2 * J + 1], drop_thr) ? p1 : 0.f;
+            p0 = drop_keep_h(dbase, drop_regpart(2 * J), drop_thr) ? p0 : 0.f;
+            p1 = drop_keep_h(dbase, drop_regpart(2 * J + 1), drop_thr) ? p1 : 0.f;
         }
         if constexpr (TERMS == 3) {
             half2v hi, lo;

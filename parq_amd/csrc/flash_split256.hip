@@ -141,6 +141,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split256_kernel(FlashArgs a, c
         const _Float16* Ks = Kr + slot * kGrpHalfs + (2 * half) * kImgH;         // this wave's two chunks: [cc][hi | lo]
         const _Float16* Vs = Vr + slot * kGrpHalfs + (2 * half) * kImgH;
         const bool more1 = t + 1 < t_end, more2 = t + 2 < t_end;
+        const uint32_t drop_blk = DROP ? drop_row ^ drop_blockhash((uint32_t)t) ^ (kh ? kDropBit2Part : 0u) : 0u;   // common.hpp: column hash parts
 
         // ---- partial S^T over this wave's 128 dims
         f32x16 sacc;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split256_kernel(FlashArgs a, c
                     p[e] = __builtin_amdgcn_exp2f(sacc[8 * m + e] - m_run);
                     rs += p[e];
                     if constexpr (DROP) {
-                        if (!drop_keep_h(drop_row, drop_colhash((uint32_t)(t * 32 + mfma32_row(8 * m + e, lane))), drop_thr)) p[e] = 0.f;
+                        if (!drop_keep_h(drop_blk, drop_regpart(8 * m + e), drop_thr)) p[e] = 0.f;     // = drop_colhash(t * 32 + mfma32_row(8 m + e, lane))
                     }
                 }
                 if constexpr (TERMS == 3) split8(p, phi[m], plo[m]);

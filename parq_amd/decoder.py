@@ -540,7 +540,7 @@ class PARQDecoder(nn.Module):
             _lib.check(lib.parq_arena_lookup(h, name.encode(), C.byref(off), C.byref(rows), C.byref(cols), C.byref(ld)),
                        "parq_arena_lookup(%s)" % name)
             g = arena[off.value: off.value + rows.value * cols.value].view(rows.value, cols.value)
-            grads[name] = g.reshape(p.shape).clone()
+            grads[name] = g.reshape(p.shape)          # a view of the arena (fresh per call): no per-tensor copy kernels
         return grads, d_tokens
 
     # ------------------------------------------------------------------ stepping interface (tests, custom drivers)

@@ -7,7 +7,7 @@ KERNELS=${KERNELS:-gemm_tn_kernel}
 for v in "$@"; do
   out=/root/repo/gpurun_out/prof_te
   rm -rf $out; mkdir -p $out
-  (cd /tmp && export TMPDIR=/tmp && export $v && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o t -- python3 /root/repo/bench.py --dev-lib --train --steps 3 --warmup 1 > /dev/null 2>&1)
+  (cd /tmp && export TMPDIR=/tmp && export $v && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o t -- python3 /root/repo/bench.py --dev-lib --train --steps 3 --warmup 1 $BENCH_ARGS > /dev/null 2>&1)
   f=$(find $out -name "*kernel_stats.csv" | head -1)
   echo "[$v] $(grep -E "$KERNELS" $f | awk -F'",' '{n=split($1,a,"::"); print a[n], $2, $3, $4}' | cut -c1-160 | tr '\n' ';')"
   echo -n "[$v] step: "
