@@ -43,6 +43,7 @@ struct AttnBwdArgs {
     int64_t q_off[kMaxBwdIters], lse_off[kMaxBwdIters];
     uint32_t seeds[kMaxBwdIters];
     unsigned int* kv_absmax;   // optional: atomicMax of the bit pattern of |dK|, |dV| as written (scale of the projection backward)
+    int probe;                     // development build only (PARQ_ATTN_BWD_PROBE): pieces of attn_bwd_split2_kernel left out, for timing
 };
 
 template <int DH>
@@ -673,6 +674,11 @@ template <bool DROP, bool RAGGED, int PIPE = 1>
 __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, const float* __restrict__ oscale_ptr,
                                                               const _Float16* __restrict__ pack) {
     const float oscale = *oscale_ptr;
+#ifdef PARQ_DEV_PROBES
+    const int probe = a.probe;              // 1: no dQ tile, 2: no softmax / dS arithmetic, 4: no dV / dK products, 8: no S / dP products
+#else
+    constexpr int probe = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) _Float16 sm[];
     _Float16* Ds = sm;                      // dS^T [hi | lo][256 keys][32 queries], 8-byte pieces swizzled by (key >> 1) & 7 (64-byte rows:
                                             // distinct for the same-parity rows of a write group; rows j and j + 8 of a read use different halves)
@@ -742,6 +748,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
     // ---- dQ tile of query tile `nd` = dS K over the 256 keys of the workgroup: wave w owns the 16 x 16 block (queries 16 (w>>2).., d 16 (w&3)..).
     // Reads Ds (the dS^T image of that tile) and Ki; 24 MFMAs + 32 transpose reads, no VALU to speak of.
     auto dq_tile = [&](int nd) {
+        if (probe & 1) return;
         f32x4v g4 = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -794,6 +801,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // inline-constant C of the first MFMAs
         sacc = zero16;
         pacc = zero16;
+        if (!(probe & 8))
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int pos = li * 64 + (((2 * t + kh) ^ img_swz(li)) << 3);
@@ -825,6 +833,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
             for (int e = 0; e < 8; ++e) {
                 const int r = 8 * m + e;
                 const int qi = mfma32_row(r, lane);
+                if (probe & 2) { pv[e] = sacc[r]; dv[e] = pacc[r]; continue; }
                 float p = __builtin_amdgcn_exp2f(sacc[r] * c2 - st[qi]);                     // rows past Lq: lse = +inf -> 0
                 if constexpr (RAGGED) p = jok ? p : 0.f;                                     // keys past Lk (launches whose Lk is not a multiple of 256)
                 float keep = 1.f;
@@ -851,6 +860,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
         };
         if constexpr (!PIPE) write_ds();
         // ---- dV^T += dO^T P, dK^T += Q^T dS: contraction over the queries; A operands by transpose reads of the natural images
+        if (!(probe & 4))
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1078,6 +1088,7 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
                            unsigned int* absmax, float* mat_scratch) {
     if (dh != 64 && dh != 32 && !mat_scratch) return hipErrorInvalidValue;
     AttnBwdArgs a;
+    a.probe = 0;
     a.q = q; a.q_batch = q_batch; a.q_head = q_head; a.q_row = q_row;
     a.k = k; a.k_batch = k_batch; a.k_head = k_head; a.k_row = k_row;
     a.v = v; a.v_batch = v_batch; a.v_head = v_head; a.v_row = v_row;
@@ -1306,6 +1317,7 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
     if (n_it < 1 || n_it > kMaxBwdIters || !absmax) return hipErrorInvalidValue;
     if (dh == 256 ? !mat_scratch : (dh != 64 || Lk < 2048 || !gq_part)) return hipErrorInvalidValue;
     AttnBwdArgs a;
+    a.probe = 0;
     a.q = q; a.q_batch = q_batch; a.q_head = q_head; a.q_row = q_row;
     a.k = k; a.k_batch = k_batch; a.k_head = k_head; a.k_row = k_row;
     a.v = v; a.v_batch = v_batch; a.v_head = v_head; a.v_row = v_row;
@@ -1344,6 +1356,8 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
         const bool rag = (Lk % kSpKW) != 0;
         static const int pipe = [] { const char* e = dev_env("PARQ_ATTN_BWD_PIPE"); return e ? atoi(e) : 1; }();
         _Float16* pk = reinterpret_cast<_Float16*>(pack);
+        static const int probe = [] { const char* e = dev_env("PARQ_ATTN_BWD_PROBE"); return e ? atoi(e) : 0; }();
+        a.probe = probe;
         hipLaunchKernelGGL(attn_bwd_pack_kernel, dim3(Lq_pad / 32, B * H, n_it), dim3(256), 0, s, a, oscale, pk);
 #define PARQ_BWD2(DROP_, RAG_, PIPE_)                                                                                          \
         {                                                                                                                      \
