@@ -218,6 +218,11 @@ size_t parq_train_workspace_bytes(parq_handle h, int32_t B, int32_t V, int32_t h
 size_t parq_grad_arena_bytes(parq_handle h);
 int parq_forward_train(parq_handle h, const parq_scene *scene, void *workspace, size_t workspace_bytes,
                        const parq_outputs *outs, parq_stream stream);
+/* Blocks the calling host thread until iteration k of the last enqueued parq_forward_train has written its outputs (an event
+ * recorded on the stream after every iteration).  The reference evaluates its set loss per iteration with a host-side Hungarian
+ * matcher (model/matcher.py, scipy): a caller can match iteration k while the device runs iterations k+1 .. I-1 (reading the
+ * outputs of iteration k on a second stream), instead of idling the device for the whole matcher after the last iteration. */
+int parq_wait_iteration(parq_handle h, int32_t k);
 int parq_backward(parq_handle h, const parq_scene *scene, void *workspace, size_t workspace_bytes, const parq_outputs *outs,
                   const parq_output_grads *grads, float *grad_arena, float *d_tokens, parq_stream stream);
 int parq_arena_lookup(parq_handle h, const char *name, int64_t *offset, int64_t *rows, int64_t *cols, int64_t *ld);

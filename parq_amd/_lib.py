@@ -72,6 +72,7 @@ SYMBOLS = {
     "parq_train_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32, _i32]),
     "parq_grad_arena_bytes": (_sz, [_vp]),
     "parq_forward_train": (C.c_int, [_vp, C.POINTER(ParqScene), _vp, _sz, C.POINTER(ParqOutputs), _vp]),
+    "parq_wait_iteration": (C.c_int, [_vp, C.c_int32]),
     "parq_backward": (C.c_int, [_vp, C.POINTER(ParqScene), _vp, _sz, C.POINTER(ParqOutputs), C.POINTER(ParqOutputGrads), _vp, _vp, _vp]),
     "parq_arena_lookup": (C.c_int, [_vp, C.c_char_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "parq_ray_pe_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32]),

@@ -109,6 +109,8 @@ struct parq_ctx {
     int* range_mirror = nullptr;      // host-visible word raised when outputs are poisoned (parq_set_range_mirror)
     bool bwd_batched_env = true;      // parq_set_backward_batched (the parity test compares the two settings)
     float dim_t_host[128];            // 10000^(2*(i//2)/128): uploaded by parq_pack_weights from this persistent buffer (no stream sync)
+    hipEvent_t iter_done[16] = {nullptr};   // parq_forward_train records one after every iteration (parq_wait_iteration)
+    bool iter_recorded[16] = {false};
     bool profiling = false;
     std::vector<ProfEvent> events;
     double prof_ms[PARQ_PROF_COUNT] = {0};
@@ -923,6 +925,7 @@ int parq_set_backward_batched(parq_handle h, int32_t on) {
 int parq_destroy(parq_handle h) {
     if (!h) return PARQ_OK;
     for (auto& e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (hipEvent_t e : h->iter_done) if (e) (void)hipEventDestroy(e);
     delete h;
     return PARQ_OK;
 }
@@ -1220,18 +1223,6 @@ int parq_forward_train(parq_handle h, const parq_scene* scene, void* workspace, 
     rc = do_prepare(h, scene, wsp, ws, s);
     if (rc) return rc;
     const int64_t M = (int64_t)scene->B * h->Q;
-    if (h->cache_mode()) {
-        // cache modes: the forward streams the 16-bit cache; the backward gets fp32 K / V rebuilt from it (hi + lo; in the fp16 /
-        // bf16 modes the rounded values themselves: the gradient is taken straight through the rounding)
-        const int64_t N = (int64_t)scene->V * scene->h * scene->w;
-        const int C = h->C, dh = h->dh, H = h->H, B = scene->B;
-        for (int li = 0; li < h->nl; ++li) {
-            const char* cache = reinterpret_cast<const char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, h->vheads(), (int)N, h->terms());
-            float* kv = wsp + ws.kv_train + (int64_t)li * B * 2 * N * C;
-            HIPCHK(launch_kvsplit_to_f32(cache, B, h->vheads(), (int)N, kv, kv + (int64_t)H * N * dh, 2 * N * C, N * dh, 2 * N * C, N * dh, s,
-                                         dh / 64, h->terms(), h->kind()));
-        }
-    }
     // the reference points of iteration k live in that iteration's stash (initial_ref wrote ws.ref)
     HIPCHK(hipMemcpyAsync(wsp + ws.shift(0) + ws.refk, wsp + ws.ref, (size_t)M * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
     for (int k = 0; k < h->I; ++k) {
@@ -1247,9 +1238,36 @@ int parq_forward_train(parq_handle h, const parq_scene* scene, void* workspace, 
         float* emb_next = last ? wsp + ws.g_emb : wsp + ws.shift(k + 1) + ws.emb;
         rc = do_iterate(h, scene, wsp, ws, k, wsp + ws.shift(k) + ws.refk, true, &o, ref_next, s, ws.shift(k), emb_next, true);   // ws.emb of iteration 0: prologue
         if (rc) return rc;
+        // outputs of iteration k are final from here on: a host that matches predictions to boxes per iteration (the set loss)
+        // can start on them while the later iterations run (parq_wait_iteration)
+        if (k < 16) {
+            if (!h->iter_done[k]) HIPCHK(hipEventCreateWithFlags(&h->iter_done[k], hipEventDisableTiming));
+            HIPCHK(hipEventRecord(h->iter_done[k], s));
+            h->iter_recorded[k] = true;
+        }
+    }
+    // (after the iterations, which do not read it: the stream gets to this while the host evaluates the loss)
+    if (h->cache_mode()) {
+        // cache modes: the forward streams the 16-bit cache; the backward gets fp32 K / V rebuilt from it (hi + lo; in the fp16 /
+        // bf16 modes the rounded values themselves: the gradient is taken straight through the rounding)
+        const int64_t N = (int64_t)scene->V * scene->h * scene->w;
+        const int C = h->C, dh = h->dh, H = h->H, B = scene->B;
+        for (int li = 0; li < h->nl; ++li) {
+            const char* cache = reinterpret_cast<const char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, h->vheads(), (int)N, h->terms());
+            float* kv = wsp + ws.kv_train + (int64_t)li * B * 2 * N * C;
+            HIPCHK(launch_kvsplit_to_f32(cache, B, h->vheads(), (int)N, kv, kv + (int64_t)H * N * dh, 2 * N * C, N * dh, 2 * N * C, N * dh, s,
+                                         dh / 64, h->terms(), h->kind()));
+        }
     }
     h->ref_state = 0;
     h->prepared = false;
+    return PARQ_OK;
+}
+
+int parq_wait_iteration(parq_handle h, int32_t k) {
+    if (!h || k < 0 || k >= 16 || k >= h->I) return fail(PARQ_ERR_ARG, "bad iteration index");
+    if (!h->iter_recorded[k]) return fail(PARQ_ERR_STATE, "parq_wait_iteration: no parq_forward_train has been enqueued");
+    HIPCHK(hipEventSynchronize(h->iter_done[k]));
     return PARQ_OK;
 }
 

@@ -152,7 +152,7 @@ class _TrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dec, tokens, camera, T_cp, T_wp, T_wl, feat_hw, *params):
-        outs = dec.forward_train(tokens, camera, T_cp, T_wp, T_wl, feat_hw=feat_hw)
+        outs = dec.forward_train(tokens, camera, T_cp, T_wp, T_wl, feat_hw=feat_hw, defer_range_check=bool(dec.overlap_loss_matching))
         stacked = dec._train_state[2]                       # six (I, B, Q, k) tensors
         ctx.dec = dec
         ctx.gen = dec._train_gen                            # this node owns the stash only until the next training forward
@@ -236,6 +236,11 @@ class PARQDecoder(nn.Module):
         self.dp_all_reduce = False        # True: backward() all-reduces the flat gradient arena over the default process group
         self.backward_batched = True      # cross-attention backward of all iterations as one launch (False: per-iteration launches,
                                           # the cross-check form; include/parq_hip.h parq_set_backward_batched)
+        self.overlap_loss_matching = True # loss() on the outputs of this module's own training forward matches iteration k on the
+                                          # host while the device runs iterations k+1.. (parq_wait_iteration); the fp16-range check
+                                          # of that forward is then resolved inside loss() (or raised by backward()) instead of
+                                          # by a host synchronisation at the end of forward_train
+        self._train_pending = None        # deferred range check of the last training forward: callable -> True if it re-ran
         self.max_workspaces = 2           # inference workspaces (each holds a K/V cache) kept alive, least recently used first out
         self._mean_dev = None
         # fp16-operand attention modes ("split", "fp16"): what to do when a token / K / V element leaves the fp16 range
@@ -468,9 +473,12 @@ class PARQDecoder(nn.Module):
 
     # ------------------------------------------------------------------ training
     @torch.no_grad()
-    def forward_train(self, intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw=None):
+    def forward_train(self, intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw=None,
+                      defer_range_check=False):
         """Forward that keeps every iteration's activations for ``backward`` (attention arithmetic: ``_train_mode()``;
-        dropout when the module is in train mode).  Returns the same list of dicts as ``forward``."""
+        dropout when the module is in train mode).  Returns the same list of dicts as ``forward``.  ``defer_range_check``
+        (the autograd path with ``overlap_loss_matching``): do not wait for the device here; ``loss()`` resolves the fp16-range
+        check of this forward while it matches, ``backward()`` raises if nobody did."""
         self._range_poll()                     # BEFORE the mode of this step is chosen: a fallback must not split forward / backward
         sc, keep, dev = self._scene(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
         self._ensure_packed(dev)
@@ -480,7 +488,8 @@ class PARQDecoder(nn.Module):
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
         outs = self._alloc_outputs((self.num_layers, sc.B, self.num_queries), dev)
         po = _lib.ParqOutputs(*[_lib.ptr(t) for t in outs])
-        for _attempt in range(2):
+
+        def enqueue():
             mode = self._train_mode()
             h = self._handle_in_mode(mode)
             _lib.check(lib.parq_set_dropout(h, p_drop, seed), "parq_set_dropout")
@@ -490,17 +499,29 @@ class PARQDecoder(nn.Module):
                 self._train_ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=dev)
             _lib.check(lib.parq_forward_train(h, C.byref(sc), _lib.ptr(self._train_ws), self._train_ws.numel() * 4, C.byref(po),
                                               _lib.stream_ptr()), "parq_forward_train")
-            # Training never lets a range violation reach the optimizer: the set loss synchronises with the host anyway (the
-            # matcher runs there), so the device flag is read here — one host sync per step — and a poisoned forward is re-run with
-            # the exact fp32 kernels (same dropout seed) before anything is returned.
-            if (self.range_check != "off" and mode in ("split", "fp16")
-                    and int(self._flag_view(self._train_ws, sc.B, sc.V, sc.h, sc.w).item()) != 0):
+            # the stash is laid out for `mode`: backward() uses exactly this mode, whatever attention_mode says by then
+            self._train_state = (sc, keep, outs, po, dev, mode)
+            return mode
+        mode = enqueue()
+        self._train_pending = None
+        if self.range_check != "off" and mode in ("split", "fp16"):
+            # Training never lets a range violation reach the optimizer: a poisoned forward (NaN outputs, device flag, pinned host
+            # word) is re-run with the exact fp32 kernels (same dropout seed, same output tensors) before its outputs are used.
+            def rerun_if_poisoned(completed):
+                """`completed`: the caller knows the forward has finished on the device (the pinned word is then current);
+                otherwise the device flag is read, which waits for the stream."""
+                poisoned = (int(self._range_mirror[0]) != 0) if completed else \
+                    int(self._flag_view(self._train_ws, sc.B, sc.V, sc.h, sc.w).item()) != 0
+                if not poisoned:
+                    return False
                 self._range_mirror[0] = 0
                 self._range_fallback("re-running this training forward")
-                continue
-            break
-        # the stash is laid out for `mode`: backward() uses exactly this mode, whatever attention_mode says by then
-        self._train_state = (sc, keep, outs, po, dev, mode)
+                enqueue()
+                return True
+            if defer_range_check:
+                self._train_pending = rerun_if_poisoned       # resolved by loss() / backward(): no host synchronisation here
+            else:
+                rerun_if_poisoned(False)                     # one host synchronisation per step
         self._train_gen += 1
         return [{k: t[i] for k, t in zip(OUTPUT_KEYS, outs)} for i in range(self.num_layers)]
 
@@ -511,6 +532,7 @@ class PARQDecoder(nn.Module):
         gradient}, d_tokens or None); gradients of tensors registered under two names are returned once per name."""
         if self._train_state is None:
             raise RuntimeError("backward() needs a preceding forward_train()")
+        self._resolve_train_range(in_backward=True)
         sc, keep, outs, po, dev, mode = self._train_state
         # the mode the stash was written in (forward_train), not whatever attention_mode says now: the workspace layout differs
         lib, h = _lib.load(), self._handle_in_mode(mode)
@@ -662,9 +684,50 @@ class PARQDecoder(nn.Module):
             self._matcher = HungarianMatcherModified(cost_class=2, cost_bbox=0.25)          # parq_decoder.py:71
             self._class_weight = torch.ones(self.num_semcls + 1)
             self._class_weight[self.num_semcls] = 0.1                                        # background (:46-48)
-        fn = decoder_loss_batched if self.loss_batched else decoder_loss
-        return fn(out_dict_list, obbs_padded, T_world_local, sym, matcher=self._matcher, loss_weight=self.loss_weight,
-                  num_semcls=self.num_semcls, class_weight=self._class_weight)
+        kw = dict(matcher=self._matcher, loss_weight=self.loss_weight, num_semcls=self.num_semcls, class_weight=self._class_weight)
+        if not self.loss_batched:
+            self._resolve_train_range()
+            return decoder_loss(out_dict_list, obbs_padded, T_world_local, sym, **kw)
+        ready = None
+        st = self._train_state
+        if (self.overlap_loss_matching and st is not None and len(out_dict_list) == self.num_layers
+                and out_dict_list[0]["pred_logits"].data_ptr() == st[2][0].data_ptr()):
+            ready = self._train_ready                      # these ARE the outputs of the training forward in flight
+        else:
+            self._resolve_train_range()
+        return decoder_loss_batched(out_dict_list, obbs_padded, T_world_local, sym, ready=ready, **kw)
+
+    def wait_iteration(self, k):
+        """Block the host until iteration k of the last training forward has written its outputs (parq_wait_iteration)."""
+        _lib.check(_lib.load().parq_wait_iteration(self._handle(apply_mode=False), int(k)), "parq_wait_iteration")
+
+    def _train_ready(self, k):
+        """loss(): outputs of iteration k are final; True = the forward was re-run (range fallback) and every iteration changed."""
+        self.wait_iteration(k)
+        if self._train_pending is None:
+            return False
+        if int(self._range_mirror[0]) == 0 and k + 1 < self.num_layers:
+            return False                                   # nothing raised so far
+        self.wait_iteration(self.num_layers - 1)           # the whole forward, then the pinned word is final
+        pending, self._train_pending = self._train_pending, None
+        return bool(pending(True))
+
+    def _resolve_train_range(self, in_backward=False):
+        """The deferred fp16-range check of the last training forward, for callers that did not go through the overlapped loss."""
+        if self._train_pending is None:
+            return
+        pending, self._train_pending = self._train_pending, None
+        if not in_backward:
+            pending(False)                                 # outputs not consumed yet by this module: re-run in place if poisoned
+            return
+        self.wait_iteration(self.num_layers - 1)
+        if int(self._range_mirror[0]) != 0:
+            self._range_mirror[0] = 0
+            self._range_fallback("detected in backward()")
+            raise RuntimeError("parq_amd.PARQDecoder: the training forward of this step left the fp16 operand range and its outputs are "
+                               "NaN; they were consumed outside PARQDecoder.loss, so the step cannot be repaired here.  Skip this step "
+                               "(the module now uses the exact fp32 kernels), or set overlap_loss_matching = False to have "
+                               "the training forward check and re-run before it returns.")
 
     @torch.no_grad()
     def parse_pred(self, out_dict):

@@ -13,6 +13,7 @@ because a drop-in must give the same numbers:
 """
 from __future__ import annotations
 
+import contextlib
 import math
 
 import numpy as np
@@ -206,8 +207,20 @@ def decoder_loss(out_dict_list, obbs_padded, T_world_local, sym=None, *, matcher
     return terms
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    """One extra stream per device for the matcher inputs of iterations whose successors are still running on the main stream."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
+
+
 # ---------------------------------------------------------------- batched evaluation (same numbers, ~40 launches per step)
-def decoder_loss_batched(out_dict_list, obbs_padded, T_world_local, sym=None, *, matcher, loss_weight, num_semcls, class_weight):
+def decoder_loss_batched(out_dict_list, obbs_padded, T_world_local, sym=None, *, matcher, loss_weight, num_semcls, class_weight,
+                         ready=None):
     """``decoder_loss`` with every (iteration, scene) pair evaluated together: one softmax / cdist / host copy for the matcher,
     the matched (prediction, box) pairs of all iterations and scenes gathered into flat index tensors, per-pair terms reduced
     with segment sums.  The matching itself (scipy LSAP, the np.random.choice cap, the punish-mask quirks) is the loop of
@@ -217,23 +230,49 @@ def decoder_loss_batched(out_dict_list, obbs_padded, T_world_local, sym=None, *,
     assert X.ndim == 3, tuple(X.shape)
     I, B = len(out_dict_list), X.shape[0]
     dev = out_dict_list[-1]["pred_logits"].device
-    targets = parse_target(obbs_padded, T_world_local)
-    nmax = max(1, max(len(t["labels"]) for t in targets))
-    tc = torch.zeros(B, nmax, 3, device=dev, dtype=out_dict_list[-1]["coord_pos"].dtype)
-    for b, t in enumerate(targets):
-        tc[b, :len(t["labels"])] = t["center"]
-    logits = torch.stack([o["pred_logits"] for o in out_dict_list])                  # (I, B, Q, ncls)
-    Q = logits.shape[2]
-    with torch.no_grad():
-        prob = logits.softmax(-1)
-        l1 = torch.cdist(torch.stack([o["coord_pos"] for o in out_dict_list]).flatten(0, 1), tc.repeat(I, 1, 1), p=1).view(I, B, Q, nmax)
-        prob_h, l1_h = prob.cpu(), l1.cpu()
+    # `ready` (PARQDecoder.loss on the outputs of its own training forward): ready(k) blocks until iteration k's outputs are written
+    # and returns True if the forward had to be re-run (fp16 range fallback) -> the matching starts over.  The target preparation
+    # and the per-iteration matcher inputs then run on a side stream while the device is still in the later iterations; the
+    # matching order (iteration, scene, box) and with it the np.random draws are the same as without it.
+    main = torch.cuda.current_stream(dev) if (ready is not None and dev.type == "cuda") else None
+    side = _side_stream(dev) if main is not None else None
+    on_side = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
+    with on_side():
+        targets = parse_target(obbs_padded, T_world_local)
+        nmax = max(1, max(len(t["labels"]) for t in targets))
+        tc = torch.zeros(B, nmax, 3, device=dev, dtype=out_dict_list[-1]["coord_pos"].dtype)
+        for b, t in enumerate(targets):
+            tc[b, :len(t["labels"])] = t["center"]
+        ids_np = [t["labels"].cpu().numpy() for t in targets]
+    Q = out_dict_list[-1]["pred_logits"].shape[1]
+
+    def matcher_inputs(k0, k1):
+        """softmax probabilities and L1 centre distances of iterations k0 .. k1-1 as NumPy arrays (one host copy each)"""
+        with torch.no_grad(), on_side():
+            lg = torch.stack([out_dict_list[k]["pred_logits"] for k in range(k0, k1)])
+            cp = torch.stack([out_dict_list[k]["coord_pos"] for k in range(k0, k1)])
+            prob = lg.softmax(-1)
+            l1 = torch.cdist(cp.flatten(0, 1), tc.repeat(k1 - k0, 1, 1), p=1).view(k1 - k0, B, Q, nmax)
+            return prob.cpu().numpy(), l1.cpu().numpy()
+    if ready is None:
+        prob_all, l1_all = matcher_inputs(0, I)
     seg, pi_all, gi_all, bi_all = [], [], [], []          # flat matched pairs: segment (k*B+b), query, box, scene
     punish_np = np.ones((I, B, Q), dtype=bool)
     valid_np = np.zeros((I, B), dtype=bool)
-    prob_np, l1_np = prob_h.numpy(), l1_h.numpy()          # host loop on NumPy views: no per-(iteration, scene) torch dispatch or sync
-    ids_np = [t["labels"].cpu().numpy() for t in targets]
-    for k in range(I):
+    k = -1
+    while k + 1 < I:
+        k += 1
+        if ready is not None:
+            if ready(k):                                   # outputs rewritten by a re-run of the forward: start over
+                seg, pi_all, gi_all, bi_all = [], [], [], []
+                punish_np[:] = True
+                valid_np[:] = False
+                k = -1
+                continue
+            prob_k, l1_k = matcher_inputs(k, k + 1)
+            prob_np, l1_np, kk_ = prob_k, l1_k, 0
+        else:
+            prob_np, l1_np, kk_ = prob_all, l1_all, k
         plist = []
         idx_k = []
         for b in range(B):
@@ -242,8 +281,8 @@ def decoder_loss_batched(out_dict_list, obbs_padded, T_world_local, sym=None, *,
             if n == 0:
                 idx_k.append((np.zeros(0, np.int64), np.zeros(0, np.int64)))
                 continue
-            l1b = l1_np[k, b, :, :n]
-            cost = matcher.cost_bbox * l1b - matcher.cost_class * prob_np[k, b][:, ids]
+            l1b = l1_np[kk_, b, :, :n]
+            cost = matcher.cost_bbox * l1b - matcher.cost_class * prob_np[kk_, b][:, ids]
             rows, cols = linear_sum_assignment(cost)
             near = l1b < matcher.ratio
             if near.sum(0).max() <= matcher.max_padding:
@@ -275,6 +314,11 @@ def decoder_loss_batched(out_dict_list, obbs_padded, T_world_local, sym=None, *,
             valid_np[k, b] = True
             seg.append(np.full(len(pi), k * B + b)); pi_all.append(pi); gi_all.append(gi); bi_all.append(np.full(len(pi), b))
             punish_np[k, b] = plist[b]                         # the reference indexes its list by scene number (quirk kept)
+    if main is not None:
+        main.wait_stream(side)                             # the target tensors were produced on the side stream
+        for t_ in [tc] + [v for t in targets for v in t.values() if torch.is_tensor(v)]:
+            t_.record_stream(main)
+    logits = torch.stack([o["pred_logits"] for o in out_dict_list])                  # (I, B, Q, ncls)
     punish = torch.from_numpy(punish_np).to(torch.float32)
     valid = torch.from_numpy(valid_np)
     last = out_dict_list[-1]

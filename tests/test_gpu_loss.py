@@ -136,3 +136,67 @@ def test_cfg5_full_size_fp16_training_step_end_to_end():
     del tokens, outs, losses
     dec._train_ws = None
     torch.cuda.empty_cache()
+
+
+def _train_step_loss(dec, sc_t, obbs, T_wl, sym, seed):
+    np.random.seed(seed)
+    torch.manual_seed(seed)                                  # the dropout seed of the forward is drawn from torch's generator
+    dec.zero_grad(set_to_none=True)
+    outs = dec(*sc_t)
+    terms = dec.loss(outs, obbs, T_wl, sym)
+    terms["total_loss"].backward()
+    return {k: float(v) for k, v in terms.items()}, {n: p.grad.clone() for n, p in dec.named_parameters() if p.grad is not None}
+
+
+def test_loss_matching_overlapped_with_the_forward_gives_the_same_step():
+    """PARQDecoder.loss on the outputs of the module's own training forward matches iteration k on the host while the device still
+    runs iterations k+1.. (parq_wait_iteration, matcher inputs on a side stream).  Same seeds -> same matches, same loss terms,
+    same gradients as with the synchronous order (overlap_loss_matching = False)."""
+    cfg = synth.decoder_cfg(dim=256, queries=64, heads=4, ffn=256, layers=4, dropout=0.1)
+    W = synth.make_decoder_weights(cfg, 811, damped=True)
+    sc = synth.make_scene(812, 2, 3, 32, 36, 256)
+    sc_t = [dev(sc[k]) for k in ("tokens", "camera", "T_camera_pseudoCam", "T_world_pseudoCam", "T_world_local")]
+    obbs, sym = synth.make_boxes(813, 2, 9)
+    obbs, sym, T_wl = Obb3D(dev(obbs)), dev(sym), Pose(sc_t[4])
+    res = {}
+    for overlap in (True, False):
+        dec = make_decoder(cfg, W).train()
+        dec.overlap_loss_matching = overlap
+        res[overlap] = _train_step_loss(dec, sc_t, obbs, T_wl, sym, 5)
+        assert (dec._train_pending is None)                  # resolved by loss() / never deferred
+    (ta, ga), (tb, gb) = res[True], res[False]
+    for k in TERMS:
+        assert abs(ta[k] - tb[k]) <= 1e-6 * max(1.0, abs(tb[k])), (k, ta[k], tb[k])
+    assert set(ga) == set(gb)
+    for n in ga:
+        den = float(gb[n].norm())
+        assert float((ga[n] - gb[n]).norm()) <= 1e-4 * max(den, 1e-6), n      # float atomics in the backward: not bit-identical
+
+
+def test_deferred_range_check_is_repaired_by_loss_and_raised_by_backward_otherwise():
+    """With overlap_loss_matching the autograd forward does not wait for the device; a forward whose tokens leave the fp16 range
+    (NaN outputs) is re-run with the exact fp32 kernels INSIDE loss() (finite loss, finite gradients); if the outputs were
+    consumed by something else, backward() raises instead of handing NaN gradients to the optimizer."""
+    import warnings
+    cfg = synth.decoder_cfg(dim=256, queries=32, heads=4, ffn=128, layers=2, dropout=0.0)
+    W = synth.make_decoder_weights(cfg, 821, damped=True)
+    sc = synth.make_scene(822, 1, 2, 32, 36, 256)
+    sc["tokens"] = (sc["tokens"] * np.float32(2e4)).astype(np.float32)
+    sc_t = [dev(sc[k]) for k in ("tokens", "camera", "T_camera_pseudoCam", "T_world_pseudoCam", "T_world_local")]
+    obbs, sym = synth.make_boxes(823, 1, 6)
+    obbs, sym, T_wl = Obb3D(dev(obbs)), dev(sym), Pose(sc_t[4])
+    dec = make_decoder(cfg, W).train()
+    assert dec._train_mode() == "split" and dec.overlap_loss_matching
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        terms, grads = _train_step_loss(dec, sc_t, obbs, T_wl, sym, 7)
+    assert any("fp16 range" in str(r.message) for r in rec)
+    assert dec.attention_mode == "fp32" and all(np.isfinite(v) for v in terms.values())
+    assert all(torch.isfinite(g).all() for g in grads.values())
+    # outputs consumed outside loss(): backward refuses
+    dec2 = make_decoder(cfg, W).train()
+    outs = dec2(*sc_t)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(RuntimeError, match="fp16 operand range"):
+            sum(o["pred_logits"].sum() for o in outs).backward()
