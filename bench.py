@@ -313,16 +313,20 @@ def train_bench(args):
         # untimed extra steps with an event between the phases (device time of each phase incl. the host stalls inside it)
         acc = []
         for _ in range(5):
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+            dec._phase_hook = lambda name, e=ev[5]: e.record()
             opt.zero_grad(set_to_none=True)
             ev[0].record(); outs = dec(*inputs, feat_hw=(h, w))
             ev[1].record(); loss = dec.loss(outs, obbs, T_wl, sym)["total_loss"]
             ev[2].record(); loss.backward()
             ev[3].record(); torch.nn.utils.clip_grad_norm_(dec.parameters(), 1.0); opt.step()
             ev[4].record(); torch.cuda.synchronize()
-            acc.append([ev[i].elapsed_time(ev[i + 1]) for i in range(4)])
+            dec._phase_hook = None
+            acc.append([ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[5]), ev[5].elapsed_time(ev[3]),
+                        ev[3].elapsed_time(ev[4])])
         med = np.median(np.array(acc), axis=0)
-        phase_ms = {"forward": float(med[0]), "loss": float(med[1]), "backward": float(med[2]), "clip+adamw": float(med[3])}
+        phase_ms = {"forward": float(med[0]), "loss": float(med[1]), "loss_autograd": float(med[2]), "hip_backward": float(med[3]),
+                    "clip+adamw": float(med[4])}
     torch.cuda.synchronize(); parallel.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):

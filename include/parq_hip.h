@@ -263,6 +263,23 @@ int parq_parse_pred(const float *center, const float *size, const float *ortho6d
                     int32_t Q, int32_t num_classes, const float *track_scale6_host, int32_t for_vis, int32_t enable_nms,
                     float *obbs_out, unsigned char *mask_out, parq_stream stream);
 
+/* ---- set loss for a given matching (model/parq_decoder.py:264-370), three launches --------------------------------------------
+ * The reference matches predictions to boxes per (iteration, scene) on the host (utils/matcher.py: scipy LSAP + a capped random
+ * neighbourhood) and then evaluates ~100 tiny tensor operations per step, forward and in autograd.  Given the matching, this entry
+ * writes the four loss terms (centre L1, size L1, rotation MSE minimised over the box's y-symmetry candidates, weighted class
+ * cross-entropy; terms[0..3], already divided by valid_bs and scaled by loss_weight) AND d term / d output of the one output
+ * tensor each term depends on (same (I,B,Q,k) layout as the outputs; rows without a match get zero).
+ *   pairs [4][P] int32: iteration, scene, query, box of every matched pair (a prediction appears at most once per iteration);
+ *   pair_coef [P] = 1 / (number of pairs of that (iteration, scene) * valid_bs);
+ *   row_weight [I*B*Q] = valid(iteration, scene) * punish_mask / sum_q punish_mask / valid_bs  (parq_decoder.py:341-362);
+ *   t_center / t_size (B,nmax,3), t_rot (B,nmax,3,3), t_label / t_sym (B,nmax) int32 (t_sym NULL: no symmetry classes);
+ *   the background class is num_classes - 1; class_scratch: I*B*Q int32.  loss_weight4_host is a host pointer. */
+int parq_set_loss(const float *pred_logits, const float *center_unnormalized, const float *size_unnormalized, const float *ortho6d,
+                  int32_t I, int32_t B, int32_t Q, int32_t num_classes, const float *t_center, const float *t_size, const float *t_rot,
+                  const int32_t *t_label, const int32_t *t_sym, int32_t nmax, const int32_t *pairs, const float *pair_coef, int32_t P,
+                  const float *row_weight, const float *class_weight, const float *loss_weight4_host, float *terms, float *g_logits,
+                  float *g_center, float *g_size, float *g_ortho6d, int32_t *class_scratch, parq_stream stream);
+
 /* ---- single kernels (parity tests, roofline measurements) --------------------------- */
 
 /* K4+K5: project (B,Q,3) normalised reference points into every view and bilinearly

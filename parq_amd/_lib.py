@@ -82,6 +82,8 @@ SYMBOLS = {
     "parq_ray_pe_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_f), _f, _f, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp,
                                        _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "parq_parse_pred": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, C.POINTER(_f), _i32, _i32, _vp, _vp, _vp]),
+    "parq_set_loss": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp,
+                                C.POINTER(_f), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "parq_k_project_sample": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(_f), _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "parq_k_camera_local": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "parq_k_linear": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

@@ -1679,6 +1679,21 @@ int parq_parse_pred(const float* center, const float* size, const float* ortho6d
     return PARQ_OK;
 }
 
+int parq_set_loss(const float* pred_logits, const float* center_unnormalized, const float* size_unnormalized, const float* ortho6d,
+                  int32_t I, int32_t B, int32_t Q, int32_t num_classes, const float* t_center, const float* t_size, const float* t_rot,
+                  const int32_t* t_label, const int32_t* t_sym, int32_t nmax, const int32_t* pairs, const float* pair_coef, int32_t P,
+                  const float* row_weight, const float* class_weight, const float* loss_weight4_host, float* terms, float* g_logits,
+                  float* g_center, float* g_size, float* g_ortho6d, int32_t* class_scratch, parq_stream stream) {
+    if (!pred_logits || !center_unnormalized || !size_unnormalized || !ortho6d || !t_center || !t_size || !t_rot || !t_label || !row_weight ||
+        !class_weight || !loss_weight4_host || !terms || !g_logits || !g_center || !g_size || !g_ortho6d || !class_scratch)
+        return fail(PARQ_ERR_ARG, "NULL argument");
+    if (I < 1 || B < 1 || Q < 1 || num_classes < 2 || nmax < 1 || P < 0 || (P > 0 && (!pairs || !pair_coef))) return fail(PARQ_ERR_ARG, "bad dims");
+    HIPCHK(launch_set_loss(pred_logits, center_unnormalized, size_unnormalized, ortho6d, I, B, Q, num_classes, t_center, t_size, t_rot,
+                           t_label, t_sym, nmax, pairs, pair_coef, P, row_weight, class_weight, loss_weight4_host, num_classes - 1, terms,
+                           g_logits, g_center, g_size, g_ortho6d, class_scratch, (hipStream_t)stream));
+    return PARQ_OK;
+}
+
 int parq_k_layernorm(const float* X, const float* gamma, const float* beta, float* Y, int32_t M, int32_t C, float eps,
                      parq_stream stream) {
     if (!X || !gamma || !beta || !Y || M < 1 || C < 1 || C > 1024) return fail(PARQ_ERR_ARG, "bad argument");

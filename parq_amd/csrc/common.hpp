@@ -345,6 +345,12 @@ hipError_t launch_split_f32(const float* src, void* hi, void* lo, int64_t n, hip
 constexpr int kGatherMax = 64;
 struct GatherArgs { const float* src[kGatherMax]; float* dst[kGatherMax]; int64_t n[kGatherMax]; int count; };
 hipError_t launch_gather_copy(const GatherArgs& g, hipStream_t s);
+// setloss.hip: loss terms + d term / d output for a given matching (three launches)
+hipError_t launch_set_loss(const float* logits, const float* center, const float* size, const float* o6, int I, int B, int Q, int ncls,
+                           const float* t_center, const float* t_size, const float* t_rot, const int32_t* t_label, const int32_t* t_sym,
+                           int nmax, const int32_t* pairs, const float* coef, int P, const float* row_weight, const float* class_weight,
+                           const float* w4, int background, float* terms, float* g_logits, float* g_center, float* g_size, float* g_o6,
+                           int32_t* cls, hipStream_t s);
 hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void* Wlo, const float* bias, int B, int N,
                                int C, int H, void* cache, int* overflow, hipStream_t s, int terms = 3, int kind = kF16);
 // fp32 -> 16-bit (round to nearest) weights of the single-term modes

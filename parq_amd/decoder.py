@@ -164,6 +164,8 @@ class _TrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_logits, g_center, g_size, g_rot, _g_prob, _g_coord):
         dec = ctx.dec
+        if dec._phase_hook is not None:
+            dec._phase_hook("hip_backward")                  # bench.py --phase-times: where the loss graph's autograd ends
         if dec._train_gen != ctx.gen:
             raise RuntimeError("parq_amd.PARQDecoder: backward of a training forward whose saved activations were overwritten by a "
                                "later training forward of the same module (the stash, dropout seed and outputs live on the module: one "
@@ -240,6 +242,7 @@ class PARQDecoder(nn.Module):
                                           # host while the device runs iterations k+1.. (parq_wait_iteration); the fp16-range check
                                           # of that forward is then resolved inside loss() (or raised by backward()) instead of
                                           # by a host synchronisation at the end of forward_train
+        self._phase_hook = None           # optional callable(name), called at the entry of the HIP backward (bench.py --phase-times)
         self._train_pending = None        # deferred range check of the last training forward: callable -> True if it re-ran
         self.max_workspaces = 2           # inference workspaces (each holds a K/V cache) kept alive, least recently used first out
         self._mean_dev = None

@@ -207,6 +207,77 @@ def decoder_loss(out_dict_list, obbs_padded, T_world_local, sym=None, *, matcher
     return terms
 
 
+_DIFF_KEYS = ("pred_logits", "center_unnormalized", "size_unnormalized", "ortho6d")
+DEVICE_SET_LOSS = True        # device tensors: loss terms + output gradients by parq_set_loss (False: the torch expression, kept as the
+                              # reference the kernel is tested against)
+
+
+def _stacked(out_dict_list, key):
+    """(I, B, Q, k) tensor of one output over the iterations: the tensor the per-iteration dicts are views of when they come from
+    PARQDecoder's training forward (no copy, and autograd reaches the decoder's node directly), else a stack."""
+    t0 = out_dict_list[0][key]
+    base, I = t0._base, len(out_dict_list)
+    if (base is not None and base.dim() == t0.dim() + 1 and base.shape[0] == I and base.is_contiguous()
+            and all(o[key]._base is base and o[key].shape == t0.shape and o[key].storage_offset() == base.storage_offset() + i * base.stride(0)
+                    for i, o in enumerate(out_dict_list))):
+        return base
+    return torch.stack([o[key] for o in out_dict_list]).contiguous()
+
+
+class _SetLossFn(torch.autograd.Function):
+    """parq_set_loss (parq_amd/csrc/setloss.hip): the four terms and d term / d output in three launches; each term depends on one
+    output tensor, so the backward is four scalings."""
+
+    @staticmethod
+    def forward(ctx, logits, ctr, siz, r6, aux):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        I, B, Q, ncls = logits.shape
+        dev = logits.device
+        logits, ctr, siz, r6 = (t.detach().contiguous() for t in (logits, ctr, siz, r6))
+        terms = torch.empty(4, dtype=torch.float32, device=dev)
+        g = [torch.empty_like(t) for t in (logits, ctr, siz, r6)]
+        scratch = torch.empty(I * B * Q, dtype=torch.int32, device=dev)
+        P = aux["P"]
+        host = aux["packed"]                               # int32 view: pairs [4][P] | coef [P] | row_weight [I*B*Q]
+        base = host.data_ptr()
+        w4 = (C.c_float * 4)(*[float(x) for x in aux["loss_weight"]])
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.check(lib.parq_set_loss(p(logits), p(ctr), p(siz), p(r6), I, B, Q, ncls, p(aux["t_center"]), p(aux["t_size"]), p(aux["t_rot"]),
+                                     p(aux["t_lab"]), p(aux["t_sym"]), aux["nmax"], C.c_void_p(base), C.c_void_p(base + 16 * P), P,
+                                     C.c_void_p(base + 20 * P), p(aux["class_weight"]), w4, p(terms), p(g[0]), p(g[1]), p(g[2]), p(g[3]),
+                                     p(scratch), _lib.stream_ptr()), "parq_set_loss")
+        ctx.grads = g
+        c, s_, r, k = terms.unbind(0)
+        return c, s_, r, k
+
+    @staticmethod
+    def backward(ctx, gc, gs, gr, gk):
+        gl, gcen, gsiz, gr6 = ctx.grads
+        return gl * gk, gcen * gc, gsiz * gs, gr6 * gr, None
+
+
+def _device_set_loss(out_dict_list, I, B, Q, nmax, tc, t_size, t_rot, t_lab, t_sym, cw_dev, seg, pi_all, gi_all, bi_all, punish_np,
+                     valid_np, valid_bs, loss_weight, num_semcls):
+    """Tail of decoder_loss_batched for device tensors: host-side constants of the matching in ONE upload, then parq_set_loss."""
+    dev = tc.device
+    seg_np = np.concatenate(seg)
+    P = int(seg_np.shape[0])
+    cnt = np.bincount(seg_np, minlength=I * B).astype(np.float32)
+    coef = (np.float32(1.0) / (cnt[seg_np] * np.float32(valid_bs))).astype(np.float32)
+    pm = punish_np.astype(np.float32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        rw = (pm / pm.sum(-1, keepdims=True) * valid_np[..., None].astype(np.float32) / np.float32(valid_bs)).astype(np.float32)
+    pairs = np.stack([seg_np // B, np.concatenate(bi_all), np.concatenate(pi_all), np.concatenate(gi_all)]).astype(np.int32)
+    packed = torch.from_numpy(np.concatenate([pairs.reshape(-1), coef.view(np.int32), rw.reshape(-1).view(np.int32)])).to(dev)
+    assert num_semcls + 1 == out_dict_list[0]["pred_logits"].shape[-1]
+    aux = {"P": P, "packed": packed, "loss_weight": loss_weight, "t_center": tc.contiguous(), "t_size": t_size, "t_rot": t_rot,
+           "t_lab": t_lab, "t_sym": t_sym, "nmax": int(nmax), "class_weight": cw_dev}
+    c, s_, r, k = _SetLossFn.apply(*[_stacked(out_dict_list, key) for key in _DIFF_KEYS], aux)
+    return {"center_loss": c, "size_loss": s_, "rot_loss": r, "cat_loss": k, "total_loss": c + s_ + r + k}
+
+
 _SIDE_STREAMS = {}
 
 
@@ -244,6 +315,16 @@ def decoder_loss_batched(out_dict_list, obbs_padded, T_world_local, sym=None, *,
         for b, t in enumerate(targets):
             tc[b, :len(t["labels"])] = t["center"]
         ids_np = [t["labels"].cpu().numpy() for t in targets]
+        fused = DEVICE_SET_LOSS and dev.type == "cuda" and all(o[k].dtype == torch.float32 for o in out_dict_list for k in _DIFF_KEYS)
+        if fused:                                          # padded targets of the device loss (parq_set_loss), built off the main stream
+            t_size = torch.zeros(B, nmax, 3, device=dev); t_rot = torch.zeros(B, nmax, 3, 3, device=dev)
+            t_lab = torch.zeros(B, nmax, dtype=torch.int32, device=dev)
+            for b, t in enumerate(targets):
+                n = len(t["labels"])
+                t_size[b, :n] = t["size"]; t_rot[b, :n] = t["T_rig_object"][:, :3, :3]; t_lab[b, :n] = t["labels"].to(torch.int32)
+            t_sym = raw(sym).to(dev)[:, :nmax].to(torch.int32).contiguous() if sym is not None else None
+            cw_dev = class_weight.to(device=dev, dtype=torch.float32).contiguous()
+            tc = tc.to(torch.float32)
     Q = out_dict_list[-1]["pred_logits"].shape[1]
 
     def matcher_inputs(k0, k1):
@@ -316,8 +397,14 @@ def decoder_loss_batched(out_dict_list, obbs_padded, T_world_local, sym=None, *,
             punish_np[k, b] = plist[b]                         # the reference indexes its list by scene number (quirk kept)
     if main is not None:
         main.wait_stream(side)                             # the target tensors were produced on the side stream
-        for t_ in [tc] + [v for t in targets for v in t.values() if torch.is_tensor(v)]:
+        for t_ in [tc] + [v for t in targets for v in t.values() if torch.is_tensor(v)] + \
+                ([t_size, t_rot, t_lab, cw_dev] + ([t_sym] if t_sym is not None else []) if fused else []):
             t_.record_stream(main)
+    valid_bs = int(valid_np.sum())
+    if fused and valid_bs > 0:
+        matcher.last_valid_bs = valid_bs
+        return _device_set_loss(out_dict_list, I, B, Q, nmax, tc, t_size, t_rot, t_lab, t_sym, cw_dev, seg, pi_all, gi_all, bi_all,
+                                punish_np, valid_np, valid_bs, loss_weight, num_semcls)
     logits = torch.stack([o["pred_logits"] for o in out_dict_list])                  # (I, B, Q, ncls)
     punish = torch.from_numpy(punish_np).to(torch.float32)
     valid = torch.from_numpy(valid_np)
