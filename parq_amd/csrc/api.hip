@@ -75,6 +75,8 @@ struct Workspace {
     int64_t iter_begin, iter_end, stash;
     // backward scratch (training workspace only)
     int64_t g_a, g_b, g_c, g_pos, g_tmp, g_ffh, g_h1, g_h2, g_z, g_act, g_h3, g_qkv, g_emb, g_ref, g_D, g_bs, wT, g_kv, g_dqp, g_drop, kv_train, g_do, g_res, g_dq, g_Dall, g_kvmax, g_pack, g_mat;
+    int64_t g_set_stride;             // floats between two copies of the per-iteration backward scratch [g_a, g_drop]
+    int g_sets;                       // copies of it: iterations of the batched backward run on that many streams at once
     bool bwd_batched;                 // cross-attention backward of all iterations in one launch (shared layer weights, split cache)
     int64_t train_total;
     int64_t shift(int k) const { return k == 0 ? 0 : stash + (int64_t)(k - 1) * (iter_end - iter_begin) - iter_begin; }
@@ -109,6 +111,8 @@ struct parq_ctx {
     int* range_mirror = nullptr;      // host-visible word raised when outputs are poisoned (parq_set_range_mirror)
     bool bwd_batched_env = true;      // parq_set_backward_batched (the parity test compares the two settings)
     float dim_t_host[128];            // 10000^(2*(i//2)/128): uploaded by parq_pack_weights from this persistent buffer (no stream sync)
+    hipStream_t aux_stream[7] = {nullptr};  // batched backward: iterations 1 .. g_sets-1 (mod g_sets) of a phase run here, 0 on the caller's stream
+    hipEvent_t fork_ev = nullptr, join_ev[7] = {nullptr};
     hipEvent_t iter_done[16] = {nullptr};   // parq_forward_train records one after every iteration (parq_wait_iteration)
     bool iter_recorded[16] = {false};
     bool profiling = false;
@@ -160,6 +164,11 @@ bool kvproj_big_on() {
 // Training: the cross-attention backward of all recurrent iterations can run as ONE launch when the iterations share the layer
 // weights (hence K / V) and the split-precision kernel applies (head dim 64, long key axis); parq_set_backward_batched(h, 0) restores the
 // per-iteration launches.
+int bwd_sets(int I) {          // concurrent iterations of the batched chain backward (development build: PARQ_BWD_SETS)
+    static const int want = [] { const char* e = dev_env("PARQ_BWD_SETS"); return e && atoi(e) > 0 ? atoi(e) : 8; }();
+    int n = want < I ? want : I;
+    return n < 1 ? 1 : (n > 8 ? 8 : n);
+}
 bool bwd_batched_ok(const parq_ctx* c, int64_t N) {
     // head dim 64: the register-resident split kernel (long key axes); head dim 256: the composition from split-precision GEMMs
     return c->bwd_batched_env && c->nl == 1 && ((c->dh == 64 && N >= 2048) || c->dh == 256) && c->I > 1 && c->I <= 16;
@@ -202,10 +211,20 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     // ---- training extras: activation stash of iterations 1..I-1, backward scratch
     ws->stash = take((int64_t)(c->I - 1) * (ws->iter_end - ws->iter_begin));
     const int64_t NH1 = c->NH1;
+    const int64_t g_set_begin = off;
     ws->g_a = take(M * C); ws->g_b = take(M * C); ws->g_c = take(M * C); ws->g_pos = take(M * C); ws->g_tmp = take(M * C);
     ws->g_ffh = take(M * F); ws->g_h1 = take(M * NH1); ws->g_h2 = take(M * 2 * C); ws->g_z = take(M * 2 * C);
     ws->g_act = take(M * 2 * C); ws->g_h3 = take(M * 16); ws->g_qkv = take(M * 3 * C); ws->g_emb = take(M * 384);
     ws->g_ref = take(M * 3); ws->g_D = take((int64_t)B * c->H * flash_lq_pad((int)Q)); ws->g_bs = take((int64_t)B * 2 * 2 * 2);
+    ws->g_drop = take(M * C);
+    // Given the stash the iterations are independent (reference points are detached between them), and the chain backward of one
+    // iteration is ~70 small dependent launches: in the batched backward up to 8 iterations run at once (measured 1 / 2 / 4 / 8 at once: 29.3 / 27.5 / 27.7 / 27.2 ms per step), each on its own stream
+    // with its own copy of the scratch above (weight gradients meet in the arena through atomics).  Only where every dW product
+    // takes the row-split kernel (its plain read-modify-write form and the 64 x 64-tile kernel are not safe for that).
+    ws->g_set_stride = off - g_set_begin;
+    ws->g_sets = (bwd_batched_ok(c, N) && c->dh == 64 && (int64_t)F * C < (1 << 19) && (int64_t)3 * C * C < (1 << 19) && true)
+                     ? bwd_sets(c->I) : 1;
+    take((ws->g_sets - 1) * ws->g_set_stride);
     // transposed weight copies of one layer: heads1 [C][NH1], heads2 2x[C][C], lin1^T [C][F], lin2^T [F][C],
     // cross_out^T, cross_q^T, self_out^T [C][C] each, self_in^T [C][3C], pe2^T [C][C], pe0^T [384][C]
     ws->wT = take(C * NH1 + 2 * C * C + 2 * C * F + 3 * C * C + 3 * C * C + C * C + 384 * C);
@@ -216,7 +235,6 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     ws->bwd_batched = bwd_batched_ok(c, N);
     const int64_t nit = ws->bwd_batched ? c->I : 1;
     ws->g_dqp = take(nit * (int64_t)attn_bwd_dq_partial_floats(B, c->H, (int)Q, (int)N, c->dh));
-    ws->g_drop = take(M * C);
     ws->g_do = take(ws->bwd_batched ? nit * M * C : 0);
     ws->g_res = take(ws->bwd_batched ? nit * M * C : 0);
     ws->g_dq = take(ws->bwd_batched ? nit * M * C : 0);
@@ -621,7 +639,7 @@ int do_backward_transposes(parq_ctx* c, float* wsp, const Workspace& ws, int li,
 // outputs down to dO (kept per iteration in ws.g_do, with the residual gradient in ws.g_res and the D rows in ws.g_Dall), the
 // attention backward of all iterations is one launch in parq_backward, and phase 2 continues from that iteration's dQ (ws.g_dq).
 int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& ws, int k, const BwdIO& io, float* G,
-                     float* g_tokens, hipStream_t s, int phase = 0) {
+                     float* g_tokens, hipStream_t s, int phase = 0, int set = 0) {
     const float* A = c->arena;
     const Arena& ar = c->ar;
     const int li = c->cfg.share_weights ? 0 : k;
@@ -634,11 +652,13 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     const double* gn1 = reinterpret_cast<const double*>(wi + ws.gn_sums);
     const double* gn2 = gn1 + (int64_t)B * 4 * kGnSlots;
     const float* ref = wi + ws.refk;
-    float *gA = wsp + ws.g_a, *gB = wsp + ws.g_b, *gC = wsp + ws.g_c, *gPos = wsp + ws.g_pos, *tmp = wsp + ws.g_tmp;
-    float *gFfh = wsp + ws.g_ffh, *gH1 = wsp + ws.g_h1, *gH2 = wsp + ws.g_h2, *gZ = wsp + ws.g_z, *act = wsp + ws.g_act;
-    float *gH3 = wsp + ws.g_h3, *gQkv = wsp + ws.g_qkv, *gEmb = wsp + ws.g_emb, *gRef = wsp + ws.g_ref, *Dd = wsp + ws.g_D;
-    double* bs = reinterpret_cast<double*>(wsp + ws.g_bs);
-    float* gD = wsp + ws.g_drop;                       // gradient entering a dropout site's branch
+    float* gsp = wsp + (int64_t)set * ws.g_set_stride;      // this stream's copy of the scratch (set 0 when the iterations run in turn)
+    const int acc = ws.g_sets > 1 ? 2 : 1;                   // dW accumulation: 2 = always by atomics (other iterations add concurrently)
+    float *gA = gsp + ws.g_a, *gB = gsp + ws.g_b, *gC = gsp + ws.g_c, *gPos = gsp + ws.g_pos, *tmp = gsp + ws.g_tmp;
+    float *gFfh = gsp + ws.g_ffh, *gH1 = gsp + ws.g_h1, *gH2 = gsp + ws.g_h2, *gZ = gsp + ws.g_z, *act = gsp + ws.g_act;
+    float *gH3 = gsp + ws.g_h3, *gQkv = gsp + ws.g_qkv, *gEmb = gsp + ws.g_emb, *gRef = gsp + ws.g_ref, *Dd = gsp + ws.g_D;
+    double* bs = reinterpret_cast<double*>(gsp + ws.g_bs);
+    float* gD = gsp + ws.g_drop;                       // gradient entering a dropout site's branch
     const float dp = c->drop_p;
     const float inv_keep = dp > 0.f ? 1.f / (1.f - dp) : 1.f;
     // the gradient that flows into a dropped branch: g * keep / (1 - p); the residual path keeps the plain g
@@ -681,15 +701,15 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     // last layers: w3 rows 0..2 centre (input h2act[:, :C]), rows 6..11 rotation (input h2act[:, C:])
     HIPCHK(launch_gn_apply(wi + ws.h2, 2 * C, gn2, A + ar.gn2_g, A + ar.gn2_b, M, C, 2, Q, eps, act, 2 * C, s));
     // (every dW product below also leaves the bias gradient = column sums of its dY operand: launch_gemm_tn's last arguments)
-    HIPCHK(launch_gemm_tn(gH3, 16, act, 2 * C, G + ar.heads3_w, C, M, 3, C, 1, s, G + ar.heads3_b));
-    HIPCHK(launch_gemm_tn(gH3 + 3, 16, act + C, 2 * C, G + ar.heads3_w + 6 * (int64_t)C, C, M, 6, C, 1, s, G + ar.heads3_b + 6));
+    HIPCHK(launch_gemm_tn(gH3, 16, act, 2 * C, G + ar.heads3_w, C, M, 3, C, acc, s, G + ar.heads3_b));
+    HIPCHK(launch_gemm_tn(gH3 + 3, 16, act + C, 2 * C, G + ar.heads3_w + 6 * (int64_t)C, C, M, 6, C, acc, s, G + ar.heads3_b + 6));
     HIPCHK(launch_head3_bwd(gH3, A + ar.heads3_w, gZ, M, C, s));                       // gZ = d loss / d h2act
     HIPCHK(launch_gn_bwd(wi + ws.h2, 2 * C, gn2, A + ar.gn2_g, A + ar.gn2_b, M, C, 2, Q, eps, gZ, 2 * C, act, bs, gH2, 2 * C,
                          G + ar.gn2_g, G + ar.gn2_b, s));
     // second layers (grouped): h2[:, g] = h1act[:, g] W2g^T
     HIPCHK(launch_gn_apply(wi + ws.h1, NH1, gn1, A + ar.gn1_g, A + ar.gn1_b, M, C, 2, Q, eps, act, 2 * C, s));   // act = h1act
     for (int g = 0; g < 2; ++g) {
-        HIPCHK(launch_gemm_tn(gH2 + g * C, 2 * C, act + g * C, 2 * C, G + ar.heads2_w + (int64_t)g * C * C, C, M, C, C, 1, s));
+        HIPCHK(launch_gemm_tn(gH2 + g * C, 2 * C, act + g * C, 2 * C, G + ar.heads2_w + (int64_t)g * C * C, C, M, C, C, acc, s));
         LinearArgs a = mm(gH2 + g * C, 2 * C, h2T + (int64_t)g * C * C, C, C, gZ + g * C, 2 * C);       // gZ = d / d h1act
         HIPCHK(launch_linear(a, 1, s));
     }
@@ -697,7 +717,7 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
                          G + ar.gn1_g, G + ar.gn1_b, s));
     // fused first layers on x3 = norm3(xc)
     HIPCHK(launch_layernorm(wi + ws.xc, A + L.n3_w, A + L.n3_b, tmp, M, C, eps, s));           // tmp = x3
-    HIPCHK(launch_gemm_tn(gH1, NH1, tmp, C, G + ar.heads1_w, C, M, NH1, C, 1, s, G + ar.heads1_b, 2 * C));   // columns < 2C: GroupNorm follows, no bias
+    HIPCHK(launch_gemm_tn(gH1, NH1, tmp, C, G + ar.heads1_w, C, M, NH1, C, acc, s, G + ar.heads1_b, 2 * C));   // columns < 2C: GroupNorm follows, no bias
     {
         LinearArgs a = mm(gH1, NH1, h1T, NH1, C, gA, C);                                       // gA = d / d x3
         HIPCHK(launch_linear(a, 1, s));
@@ -707,13 +727,13 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     {
         const float* gd = through_dropout(gB, 5);
         if (!gd) return fail(PARQ_ERR_HIP, "dropout_apply failed");
-        HIPCHK(launch_gemm_tn(gd, C, wi + ws.ffn, F, G + L.lin2_w, F, M, C, F, 1, s, G + L.lin2_b));
+        HIPCHK(launch_gemm_tn(gd, C, wi + ws.ffn, F, G + L.lin2_w, F, M, C, F, acc, s, G + L.lin2_b));
         LinearArgs a = mm(gd, C, l2T, C, F, gFfh, F);                // d / d ffn hidden, through dropout (the stash holds the dropped,
         a.relu_mask = wi + ws.ffn; a.ldmask = F; a.mask_scale = inv_keep;   // rescaled hidden: zero = dropped or ReLU-inactive) and the ReLU
         HIPCHK(launch_linear(a, 1, s));
     }
     HIPCHK(launch_layernorm(wi + ws.xb, A + L.n2_w, A + L.n2_b, tmp, M, C, eps, s));           // tmp = x2
-    HIPCHK(launch_gemm_tn(gFfh, F, tmp, C, G + L.lin1_w, C, M, F, C, 1, s, G + L.lin1_b));
+    HIPCHK(launch_gemm_tn(gFfh, F, tmp, C, G + L.lin1_w, C, M, F, C, acc, s, G + L.lin1_b));
     {
         LinearArgs a = mm(gFfh, F, l1T, F, C, gA, C);                                          // gA = d / d x2 = gB + gFfh W1
         a.R = gB; a.ldr = C;
@@ -727,7 +747,7 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     {
         const float* gd = through_dropout(gB, 3);
         if (!gd) return fail(PARQ_ERR_HIP, "dropout_apply failed");
-        HIPCHK(launch_gemm_tn(gd, C, wi + ws.attn, C, G + L.cross_out_w, C, M, C, C, 1, s, G + L.cross_out_b));
+        HIPCHK(launch_gemm_tn(gd, C, wi + ws.attn, C, G + L.cross_out_w, C, M, C, C, acc, s, G + L.cross_out_b));
         LinearArgs a = mm(gd, C, coT, C, C, gDo, C);                                           // d / d attention output
         HIPCHK(launch_linear(a, 1, s));
     }
@@ -749,7 +769,7 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     // q = (x1 + pos) Wq^T + bq,  x1 = norm1(xa)
     HIPCHK(launch_layernorm(wi + ws.xa, A + L.n1_w, A + L.n1_b, tmp, M, C, eps, s));
     HIPCHK(launch_add(tmp, wi + ws.pos, tmp, (int64_t)M * C, s));                              // tmp = x1 + pos
-    HIPCHK(launch_gemm_tn(gC, C, tmp, C, G + L.cross_in_w, C, M, C, C, 1, s, G + L.cross_in_b));
+    HIPCHK(launch_gemm_tn(gC, C, tmp, C, G + L.cross_in_w, C, M, C, C, acc, s, G + L.cross_in_b));
     {
         LinearArgs a = mm(gC, C, cqT, C, C, gPos, C);                                          // gPos = d / d (x1 + pos) [cross]
         HIPCHK(launch_linear(a, 1, s));
@@ -760,7 +780,7 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     {
         const float* gd = through_dropout(gB, 1);
         if (!gd) return fail(PARQ_ERR_HIP, "dropout_apply failed");
-        HIPCHK(launch_gemm_tn(gd, C, wi + ws.sa, C, G + L.self_out_w, C, M, C, C, 1, s, G + L.self_out_b));
+        HIPCHK(launch_gemm_tn(gd, C, wi + ws.sa, C, G + L.self_out_w, C, M, C, C, acc, s, G + L.self_out_b));
         LinearArgs a = mm(gd, C, soT, C, C, gA, C);                                            // gA = d / d self-attention output
         HIPCHK(launch_linear(a, 1, s));
     }
@@ -773,8 +793,8 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
                            (dh == 64 || dh == 32) ? nullptr : wsp + ws.g_mat));
     // in-projection: [q | k] = (tgt + pos) Wqk^T, v = tgt Wv^T
     HIPCHK(launch_add(wi + ws.tgt, wi + ws.pos, tmp, (int64_t)M * C, s));                      // tmp = tgt + pos
-    HIPCHK(launch_gemm_tn(gQkv, 3 * C, tmp, C, G + L.self_in_w, C, M, 2 * C, C, 1, s, G + L.self_in_b));
-    HIPCHK(launch_gemm_tn(gQkv + 2 * C, 3 * C, wi + ws.tgt, C, G + L.self_in_w + 2 * (int64_t)C * C, C, M, C, C, 1, s, G + L.self_in_b + 2 * C));
+    HIPCHK(launch_gemm_tn(gQkv, 3 * C, tmp, C, G + L.self_in_w, C, M, 2 * C, C, acc, s, G + L.self_in_b));
+    HIPCHK(launch_gemm_tn(gQkv + 2 * C, 3 * C, wi + ws.tgt, C, G + L.self_in_w + 2 * (int64_t)C * C, C, M, C, C, acc, s, G + L.self_in_b + 2 * C));
     {
         // d / d (tgt + pos) through q and k: rows 0 .. 2C-1 of W_in, i.e. columns 0 .. 2C-1 of W_in^T ([C][3C])
         LinearArgs a = lin(gQkv, 3 * C, siT, 3 * C, nullptr, gA, C, M, C, 2 * C);
@@ -790,13 +810,13 @@ int do_backward_iter(parq_ctx* c, const parq_scene* sc, float* wsp, const Worksp
     HIPCHK(launch_sample_bwd(sc->tokens, reinterpret_cast<const double*>(wsp + ws.T_cl), sc->camera, ref, c->sb, B, sc->V, sc->h, sc->w,
                              C, Q, gC, g_tokens, k == 0 ? gRef : nullptr, s));
     // ---- position MLP (transformer_parq.py:176-180,317): pos = relu(emb W0^T + b0) W2^T + b2
-    HIPCHK(launch_gemm_tn(gPos, C, wi + ws.pe_h, C, G + ar.pe2_w, C, M, C, C, 1, s, G + ar.pe2_b));
+    HIPCHK(launch_gemm_tn(gPos, C, wi + ws.pe_h, C, G + ar.pe2_w, C, M, C, C, acc, s, G + ar.pe2_b));
     {
         LinearArgs a = mm(gPos, C, p2T, C, C, gA, C);                                          // gA = d / d pe hidden
         a.relu_mask = wi + ws.pe_h; a.ldmask = C;
         HIPCHK(launch_linear(a, 1, s));
     }
-    HIPCHK(launch_gemm_tn(gA, C, wi + ws.emb, 384, G + ar.pe0_w, 384, M, C, 384, 1, s, G + ar.pe0_b));
+    HIPCHK(launch_gemm_tn(gA, C, wi + ws.emb, 384, G + ar.pe0_w, 384, M, C, 384, acc, s, G + ar.pe0_b));
     if (k == 0) {
         LinearArgs a = lin(gA, C, p0T, C, nullptr, gEmb, 384, M, 384, C);
         HIPCHK(launch_linear(a, 1, s));
@@ -926,6 +946,9 @@ int parq_destroy(parq_handle h) {
     if (!h) return PARQ_OK;
     for (auto& e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (hipEvent_t e : h->iter_done) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->join_ev) if (e) (void)hipEventDestroy(e);
+    if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
+    for (hipStream_t st : h->aux_stream) if (st) (void)hipStreamDestroy(st);
     delete h;
     return PARQ_OK;
 }
@@ -1309,10 +1332,33 @@ int parq_backward(parq_handle h, const parq_scene* scene, void* workspace, size_
     const int I = h->I, B = scene->B, C = h->C, H = h->H, dh = h->dh, Q = h->Q;
     rc = do_backward_transposes(h, wsp, ws, 0, s);
     if (rc) return rc;
-    for (int k = I - 1; k >= 0; --k) {
-        rc = do_backward_iter(h, scene, wsp, ws, k, iter_io(k), grad_arena, d_tokens, s, 1);
-        if (rc) return rc;
+    // the iterations of a phase on ws.g_sets streams (the caller's + the handle's own), joined back before the phase ends
+    const int ns = h->profiling ? 1 : ws.g_sets;
+    if (ns > 1 && !h->fork_ev) {
+        HIPCHK(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+        for (int i = 0; i < 7; ++i) {
+            HIPCHK(hipStreamCreateWithFlags(&h->aux_stream[i], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&h->join_ev[i], hipEventDisableTiming));
+        }
     }
+    auto run_phase = [&](int phase) -> int {
+        if (ns > 1) {
+            HIPCHK(hipEventRecord(h->fork_ev, s));
+            for (int i = 0; i + 1 < ns; ++i) HIPCHK(hipStreamWaitEvent(h->aux_stream[i], h->fork_ev, 0));
+        }
+        for (int k = I - 1, n = 0; k >= 0; --k, ++n) {
+            const int set = n % ns;
+            int r = do_backward_iter(h, scene, wsp, ws, k, iter_io(k), grad_arena, d_tokens, set == 0 ? s : h->aux_stream[set - 1], phase, set);
+            if (r) return r;
+        }
+        for (int i = 0; i + 1 < ns; ++i) {
+            HIPCHK(hipEventRecord(h->join_ev[i], h->aux_stream[i]));
+            HIPCHK(hipStreamWaitEvent(s, h->join_ev[i], 0));
+        }
+        return PARQ_OK;
+    };
+    rc = run_phase(1);
+    if (rc) return rc;
     {
         int64_t q_off[16], lse_off[16];
         uint32_t seeds[16];
@@ -1336,10 +1382,8 @@ int parq_backward(parq_handle h, const parq_scene* scene, void* workspace, size_
             HIPCHK(launch_absmax(gkv, (int64_t)B * 2 * N * C, reinterpret_cast<unsigned int*>(wsp + ws.g_kvmax), s));
         }
     }
-    for (int k = I - 1; k >= 0; --k) {
-        rc = do_backward_iter(h, scene, wsp, ws, k, iter_io(k), grad_arena, d_tokens, s, 2);
-        if (rc) return rc;
-    }
+    rc = run_phase(2);
+    if (rc) return rc;
     return do_backward_kvproj(h, scene, wsp, ws, grad_arena, d_tokens, s);
 }
 

@@ -46,7 +46,7 @@ struct TnArgs {
     const float* B; int64_t ldb;
     float* out; int64_t ldo;
     int M, N, K;
-    int accumulate;
+    int accumulate;     // 0 overwrite, 1 add (the launch owns out), 2 add with atomics (launches on other streams add to out too)
     float* bias;        // optional: bias[n] (+)= sum_m A[m][n] for n >= bias_from (the bias gradient of the same layer), by the
     int bias_from;      // workgroups of the first k-tile from the A values they hold anyway (gemm_tn_kernel only)
 };
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
         const int n = n0 + tid;
         if (n < a.N && n >= a.bias_from) {
             const float v = (cred[0][tid] + cred[1][tid]) + (cred[2][tid] + cred[3][tid]);
-            if (gridDim.y > 1) atomicAdd(a.bias + n, v);
+            if (gridDim.y > 1 || a.accumulate == 2) atomicAdd(a.bias + n, v);
             else a.bias[n] = a.accumulate ? a.bias[n] + v : v;
         }
     }
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
             const int k = k0 + c4 + e;
             if (k < a.K) {
                 float* o = a.out + (int64_t)n * a.ldo + k;
-                if (gridDim.y > 1) atomicAdd(o, sum[e]);          // row-split launch: out was zeroed / holds the running sum
+                if (gridDim.y > 1 || a.accumulate == 2) atomicAdd(o, sum[e]);   // row-split launch, or other streams add to the same out
                 else *o = a.accumulate ? *o + sum[e] : sum[e];
             }
         }
