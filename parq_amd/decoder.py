@@ -152,7 +152,7 @@ class _TrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dec, tokens, camera, T_cp, T_wp, T_wl, feat_hw, *params):
-        outs = dec.forward_train(tokens, camera, T_cp, T_wp, T_wl, feat_hw=feat_hw, defer_range_check=bool(dec.overlap_loss_matching))
+        outs = dec.forward_train(tokens, camera, T_cp, T_wp, T_wl, feat_hw=feat_hw, defer_range_check=bool(dec.overlap_loss_matching) and dec.num_layers <= 16)
         stacked = dec._train_state[2]                       # six (I, B, Q, k) tensors
         ctx.dec = dec
         ctx.gen = dec._train_gen                            # this node owns the stash only until the next training forward
@@ -693,7 +693,7 @@ class PARQDecoder(nn.Module):
             return decoder_loss(out_dict_list, obbs_padded, T_world_local, sym, **kw)
         ready = None
         st = self._train_state
-        if (self.overlap_loss_matching and st is not None and len(out_dict_list) == self.num_layers
+        if (self.overlap_loss_matching and st is not None and len(out_dict_list) == self.num_layers and self.num_layers <= 16
                 and out_dict_list[0]["pred_logits"].data_ptr() == st[2][0].data_ptr()):
             ready = self._train_ready                      # these ARE the outputs of the training forward in flight
         else:
