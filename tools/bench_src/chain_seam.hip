@@ -437,5 +437,42 @@ int main(int argc, char** argv) {
                    (double)(s[(L - 1) * 4 + 3] - s[1 * 4 + 3]) / (L - 2) * 0.01);
         }
     }
+    // ---- E: the launch chain of A (5 plain args, 4 waves) on a created stream, as individual launches and as ONE hipGraph replay
+    // (stream capture): does the graph form shorten the dependent-launch boundary?
+    {
+        hipStream_t cs; CK(hipStreamCreate(&cs));
+        hipEvent_t g0, g1; CK(hipEventCreate(&g0)); CK(hipEventCreate(&g1));
+        for (int L : {14, 28, 56}) {
+            auto chain = [&](hipStream_t st) { for (int s = 0; s < L; ++s) hipLaunchKernelGGL(layer_thin<4>, dim3(256), dim3(256), 0, st, (s & 1) ? d1 : d0, dW + (size_t)s * C * C, dB + s * C, (s & 1) ? d0 : d1, 0); };
+            hipGraph_t graph; hipGraphExec_t exec;
+            CK(hipStreamBeginCapture(cs, hipStreamCaptureModeGlobal));
+            chain(cs);
+            CK(hipStreamEndCapture(cs, &graph));
+            CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            auto time_on = [&](auto fn) {
+                std::vector<float> ts;
+                for (int r = 0; r < reps + 2; ++r) {
+                    CK(hipMemcpyAsync(d0, hX.data(), hX.size() * 4, hipMemcpyHostToDevice, cs));
+                    hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, cs, 400);
+                    CK(hipEventRecord(g0, cs));
+                    fn();
+                    CK(hipEventRecord(g1, cs));
+                    CK(hipEventSynchronize(g1));
+                    float ms; CK(hipEventElapsedTime(&ms, g0, g1));
+                    if (r >= 2) ts.push_back(ms * 1e3f);
+                }
+                std::sort(ts.begin(), ts.end());
+                return ts[ts.size() / 2];
+            };
+            const float tl = time_on([&]() { chain(cs); });
+            const float el = max_err((L & 1) ? d1 : d0, refL(L == 56 ? 56 : L));
+            const float tg = time_on([&]() { CK(hipGraphLaunch(exec, cs)); });
+            const float eg = max_err((L & 1) ? d1 : d0, refL(L == 56 ? 56 : L));
+            printf("E created stream, L=%2d: launches %7.2f us (%5.2f/layer, err %.1e)   hipGraph replay %7.2f us (%5.2f/layer, err %.1e)\n", L, tl, tl / L, el, tg,
+                   tg / L, eg);
+            fflush(stdout);
+            CK(hipGraphExecDestroy(exec)); CK(hipGraphDestroy(graph));
+        }
+    }
     return 0;
 }
