@@ -63,7 +63,10 @@ __global__ __launch_bounds__(256) void setloss_pairs_kernel(SetLossArgs a) {
     __shared__ float sh[4];
     const int t = blockIdx.x * 256 + threadIdx.x;
     float lc = 0.f, ls = 0.f, lr = 0.f;
-    if (t < a.P) {
+    // (a pair with an index outside the tensors is skipped: nothing is read or written through it)
+    const bool in_range = t < a.P && (unsigned)a.pairs[t] < (unsigned)a.I && (unsigned)a.pairs[a.P + t] < (unsigned)a.B &&
+                          (unsigned)a.pairs[2 * a.P + t] < (unsigned)a.Q && (unsigned)a.pairs[3 * a.P + t] < (unsigned)a.nmax;
+    if (in_range) {
         const int k = a.pairs[t], b = a.pairs[a.P + t], q = a.pairs[2 * a.P + t], g = a.pairs[3 * a.P + t];
         const int64_t row = ((int64_t)k * a.B + b) * a.Q + q;
         const int tb = b * a.nmax + g;
@@ -165,7 +168,8 @@ __global__ __launch_bounds__(256) void setloss_pairs_kernel(SetLossArgs a) {
                 a.g_o6[row * 6 + 3 + i] = gb[i];
             }
         }
-        a.cls[row] = a.t_label[tb];
+        const int lab = a.t_label[tb];
+        a.cls[row] = (unsigned)lab < (unsigned)a.ncls ? lab : a.background;
     }
     lc = block_sum(lc, sh);
     ls = block_sum(ls, sh);
