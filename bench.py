@@ -291,6 +291,8 @@ def train_bench(args):
     dec = dec.to(device).train()
     dec.dp_all_reduce = world > 1
     inputs = build_inputs(B, device, seed=2000 + rank)
+    if args.token_grad:                 # the gradient a trained backbone / ray-PE encoder in front of the decoder needs
+        inputs = (inputs[0].requires_grad_(True),) + tuple(inputs[1:])
     obbs, sym = synth.make_boxes(3000 + rank, B, 12)
     obbs, sym = Obb3D(torch.from_numpy(obbs).to(device)), torch.from_numpy(sym).to(device)
     T_wl = Pose(inputs[4])
@@ -343,7 +345,7 @@ def train_bench(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "final_loss": float(loss.detach()), "phase_ms": phase_ms,
             "config": {"workload": "BASELINE cfg4 per-GPU shard: %d scenes, 10 views 480x640 (120x160 features), 256 queries, 8 iterations, "
-                                   "d=256; dropout %g; 12 synthetic boxes per scene" % (B, args.dropout),
+                                   "d=256; dropout %g; 12 synthetic boxes per scene%s" % (B, args.dropout, "; token gradient" if args.token_grad else ""),
                        "scenes_per_gpu": B, "parallelism": "dp%d (one flat gradient all-reduce per step)" % world}}))
     if world > 1:
         parallel.barrier()
@@ -400,6 +402,8 @@ def main():
     ap.add_argument("--train", action="store_true", help="time the training step of BASELINE config 4's per-GPU shard instead")
     ap.add_argument("--dropout", type=float, default=0.1, help="--train: dropout rate (config/train.yaml:53 = 0.1, the default; other "
                     "values are for kernel A/B only)")
+    ap.add_argument("--token-grad", action="store_true", help="--train: also compute d loss / d tokens (B x N x C; what a trained "
+                    "backbone or the ray-PE encoder in front of the decoder consumes)")
     ap.add_argument("--phase-times", action="store_true", help="--train: also report the median device time of forward / loss / "
                     "backward / optimizer over 5 extra untimed steps (phase_ms)")
     ap.add_argument("--dev-lib", action="store_true", help="development only: bind parq_amd/_C/libparq_hip_dev.so (-DPARQ_DEV_PROBES: "
