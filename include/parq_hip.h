@@ -151,8 +151,11 @@ int parq_iterate(parq_handle h, const parq_scene *scene, void *workspace, size_t
  * cfg 5: 20 views of 240x320 features = 1.5 M keys) is split by VIEWS: every rank calls parq_prepare with ITS views (tokens,
  * camera, poses of those views only: the K/V projection and cache are sharded) and runs each iteration in three phases around
  * two small exchanges the caller performs with its own collective library (RCCL all-reduce / all-gather over xGMI):
- *   phase 0  position MLP, project + sample of the local views      -> xchg_out: [B*Q*C undivided sums | B*Q valid-view counts]
- *            caller: SUM all-reduce of that buffer over the ranks
+ *   phase 0  position MLP, project + sample of the local views      -> xchg_out: [B*Q*C undivided sums | B*Q valid-view counts |
+ *            1 fp16-range flag of this rank's K/V shard]; caller: SUM all-reduce of that buffer over the ranks.  A rank whose
+ *            shard left the fp16 operand range thereby poisons the iteration on EVERY rank (phase 1 raises the local device flag
+ *            from the reduced value, phase 2's decode writes NaN outputs and raises the host mirror): all ranks return NaN and
+ *            take the same fallback decision, none returns unflagged numbers merged from another rank's inf / NaN record
  *   phase 1  xchg_in = the reduced buffer -> view mean; self-attention block; cross-attention over the local keys
  *                                                                   -> xchg_out: [B*Q*C outputs | B*H*pad32(Q) log2 log-sum-exp]
  *            caller: all-gather of that buffer (rank-major)
@@ -226,6 +229,22 @@ int parq_wait_iteration(parq_handle h, int32_t k);
 int parq_backward(parq_handle h, const parq_scene *scene, void *workspace, size_t workspace_bytes, const parq_outputs *outs,
                   const parq_output_grads *grads, float *grad_arena, float *d_tokens, parq_stream stream);
 int parq_arena_lookup(parq_handle h, const char *name, int64_t *offset, int64_t *rows, int64_t *cols, int64_t *ld);
+/* Data-parallel gradient buckets (the reference trains under DDP, train.py:103-108: bucketed all-reduces overlapped with the
+ * backward).  The gradient arena is laid out in the order its parts become final inside parq_backward:
+ *   bucket 0 = floats [offset, offset + count) final after phase 1 of the batched backward — cross out-proj, FFN, norm2, norm3
+ *              and every head, i.e. everything above the cross-attention — while the cross-attention backward of all iterations
+ *              (half of the step) has not started yet;
+ *   bucket 1 = the front of the arena (reference points, position MLP, both in-projections, self out-proj, norm1), final at the end.
+ * With unshared layer weights bucket 0 is empty (count 0) and bucket 1 is the whole arena.
+ * parq_backward_wait_bucket makes `stream` wait (hipStreamWaitEvent, no host synchronisation) until the last enqueued
+ * parq_backward has finished writing that bucket: the caller then starts its collective (RCCL all-reduce) on `stream` beside the
+ * rest of the backward. */
+int parq_grad_bucket(parq_handle h, int32_t bucket, int64_t *offset, int64_t *count);
+int parq_backward_wait_bucket(parq_handle h, int32_t bucket, parq_stream stream);
+/* Iterations of the chain backward in flight at once (default 8: up to eight streams, weight gradients met in the arena through
+ * float atomics — the last bits of the gradients then vary from run to run).  1 = in turn on the caller's stream with plain
+ * accumulation (reproducible chain gradients).  Changes the training workspace size: call before parq_train_workspace_bytes. */
+int parq_set_backward_streams(parq_handle h, int32_t n);
 
 /* ---- AddRayPE.forward + tokenisation (model/ray_positional_encoding.py:61-139,
  *      model/parq_lightning.py:72-85), once per forward -------------------------------------

@@ -28,6 +28,17 @@ Cases:
                  (model/parq_lightning.py:68-95: backbone hand-off -> AddRayPE -> features + encoding -> tokenisation ->
                  decoder) with a stub backbone that returns seeded features: per-iteration output dicts of the free-running
                  (damped) decoder plus a float64 checksum of the token tensor
+  g17_grads      GRADIENTS of the reference's own autograd (float64, eval mode = dropout off, as the reference differentiates
+                 in eval mode too): two small damped cases (d=128/2 heads and d=256/4 heads, 2 scenes, 3 free-running
+                 iterations), each under (i) a linear cotangent loss sum_k <c_k, out_k> and (ii) the reference's own
+                 PARQDecoder.loss (Hungarian matcher, np.random.seed fixed) -> .backward(); per-parameter gradients (whole
+                 tensors up to 8192 elements, else norm + sum + strided sample), a strided sample of d tokens, and the names of
+                 the parameters the reference leaves without gradient.  Pins detach placement (transformer_parq.py:331-332),
+                 the no-grad probabilities (:261-265), the arg-max size gather (utils/parq_utils.py:96-98) and the loss
+  g18_cfg3_smooth BASELINE cfg 3's geometry (10 views 120x160, Q=256, I=8, d=256) on SMOOTH (FPN-like) features, where the
+                 reference's fp32 run stays within ~6e-5 of its float64 evaluation: consumed teacher-forced at an UNRELAXED 1e-4
+  g19_cfg2       BASELINE cfg 2's exact geometry: 5 views 120x160 (N = 96 000), Q=128, I=4, d=256, smooth features
+                 (teacher-forced: split mode at an unrelaxed 1e-4, bf16 / fp16 modes at their stated bounds)
 """
 from __future__ import annotations
 
@@ -69,7 +80,104 @@ CASES = {
                      B=1, V=10, h=120, w=160, smooth=False, damped=False),
     "g15_cfg5_shape": dict(cfg=dict(dim=256, queries=512, heads=4, ffn=768, layers=12), wseed=25, sseed=125,
                            B=1, V=20, h=24, w=32, smooth=False, damped=False),
+    # g18 / g19 are consumed at an UNRELAXED 1e-4 against the reference's fp32 vectors.  That is only meaningful where the
+    # reference's own fp32 run is well inside 1e-4 of its float64 evaluation; on undamped weights that deviation varies with the
+    # seed between 1e-5 and 2e-4 even on smooth features (profiles/r04_reference_self_noise_scan.txt: 4 seed pairs scanned for
+    # g18, 7 for g19, with this file's own run_reference + the float64 oracle).  The pairs below are the scanned ones with the
+    # smallest deviation (6.6e-5 / 1.0e-5); the rejected ones are listed in that file.
+    "g18_cfg3_smooth": dict(cfg=dict(dim=256, queries=256, heads=4, ffn=768, layers=8), wseed=38, sseed=138,
+                            B=1, V=10, h=120, w=160, smooth=True, damped=False),
+    "g19_cfg2": dict(cfg=dict(dim=256, queries=128, heads=4, ffn=768, layers=4), wseed=31, sseed=131,
+                     B=1, V=5, h=120, w=160, smooth=True, damped=False),
 }
+
+# gradient cases (g17): the reference's own autograd in float64, eval mode, free-running on damped weights / smooth features
+GRAD_CASES = {
+    "d128": dict(cfg=dict(dim=128, queries=24, heads=2, ffn=96, layers=3), wseed=41, sseed=141, cseed=241, bseed=341,
+                 B=2, V=3, h=10, w=12, nbox=4, max_box=8, np_seed=777),
+    "d256": dict(cfg=dict(dim=256, queries=32, heads=4, ffn=256, layers=3), wseed=42, sseed=142, cseed=242, bseed=342,
+                 B=2, V=2, h=12, w=16, nbox=5, max_box=8, np_seed=778),
+}
+GRAD_KEYS = ("pred_logits", "center_unnormalized", "size_unnormalized", "ortho6d")
+GRAD_FULL_MAX = 8192          # tensors up to this many elements are stored whole
+GRAD_STRIDE = 53              # larger ones: norm, sum and every 53rd element of the flattened tensor
+TOKEN_STRIDE = 17
+
+
+def grad_case_inputs(c):
+    """(cfg, weights, scene, cotangents, padded boxes, symmetry classes) of a gradient case — shared with the tests."""
+    cfg = synth.decoder_cfg(**c["cfg"])
+    W = synth.make_decoder_weights(cfg, c["wseed"], damped=True)
+    sc = synth.make_scene(c["sseed"], c["B"], c["V"], c["h"], c["w"], cfg.DIM_IN, smooth=True)
+    I, B, Q, ncls = cfg.TRANSFORMER.DEC_LAYERS, c["B"], cfg.NUM_QUERIES, cfg.NUM_SEMCLS + 1
+    cots = {k: synth.normal(c["cseed"] + i, "cot." + k, (I, B, Q, wd))
+            for i, (k, wd) in enumerate(zip(GRAD_KEYS, (ncls, 3, 3, 6)))}
+    obbs, sym = synth.make_boxes(c["bseed"], B, c["nbox"], max_box=c["max_box"])
+    return cfg, W, sc, cots, obbs, sym
+
+
+def grad_summary(g):
+    """What the fixture keeps of one gradient tensor (float64)."""
+    g = np.asarray(g, np.float64).reshape(-1)
+    if g.size <= GRAD_FULL_MAX:
+        return {"full": g}
+    return {"norm": np.array([np.linalg.norm(g), g.sum()]), "sample": g[::GRAD_STRIDE].copy()}
+
+
+def make_grad_golden(ref):
+    """g17: gradients of the imported reference (model/parq_lightning.py:97-100 differentiates losses['total_loss'];
+    model/parq_decoder.py:264-370 the loss; model/transformer_parq.py:331-332 detach between iterations)."""
+    arrays, meta = {}, {}
+    for tag, c in GRAD_CASES.items():
+        cfg, W, sc, cots, obbs, sym = grad_case_inputs(c)
+        for kind in ("linear", "setloss"):
+            dec = RL.build_reference_decoder(ref, cfg, W, double=True)          # eval mode: dropout off, autograd on
+            tokens = torch.from_numpy(sc["tokens"]).double().requires_grad_(True)
+            outs = dec(tokens, ref.Camera(torch.from_numpy(sc["camera"]).double()),
+                       ref.Pose(torch.from_numpy(sc["T_camera_pseudoCam"]).double()),
+                       ref.Pose(torch.from_numpy(sc["T_world_pseudoCam"]).double()),
+                       ref.Pose(torch.from_numpy(sc["T_world_local"]).double()))
+            if kind == "linear":
+                loss = sum((o[k] * torch.from_numpy(cots[k][i]).double()).sum() for i, o in enumerate(outs) for k in GRAD_KEYS)
+            else:
+                np.random.seed(c["np_seed"])
+                # the reference builds its y-rotation tables with torch.tensor(...) in the DEFAULT dtype (parq_decoder.py:205-262):
+                # float64 as the default makes its loss run in float64 end to end
+                torch.set_default_dtype(torch.float64)
+                dec.class_weight = dec.class_weight.double()          # a plain tensor attribute (parq_decoder.py:46-48): .double() skips it
+                try:
+                    ld = dec.loss(outs, ref.Obb3D(torch.from_numpy(obbs).double()),
+                                  ref.Pose(torch.from_numpy(sc["T_world_local"]).double()), torch.from_numpy(sym).double())
+                finally:
+                    torch.set_default_dtype(torch.float32)
+                loss = ld["total_loss"]
+                for k, v in ld.items():
+                    arrays["%s/%s/loss/%s" % (tag, kind, k)] = np.float64(float(v))
+            loss.backward()
+            arrays["%s/%s/loss_value" % (tag, kind)] = np.float64(float(loss))
+            nograd = []
+            seen = set()
+            for name, p in dec.named_parameters():                # remove_duplicate: the shared heads appear once (mlp_heads.*)
+                if id(p) in seen:
+                    continue
+                seen.add(id(p))
+                if p.grad is None:
+                    nograd.append(name)
+                    continue
+                for k, v in grad_summary(p.grad.numpy()).items():
+                    arrays["%s/%s/grad/%s/%s" % (tag, kind, name, k)] = v
+            tg = tokens.grad.numpy().reshape(-1)
+            arrays["%s/%s/dtokens/norm" % (tag, kind)] = np.array([np.linalg.norm(tg), tg.sum()])
+            arrays["%s/%s/dtokens/sample" % (tag, kind)] = tg[::TOKEN_STRIDE].copy()
+            for i, o in enumerate(outs):                          # the free-running forward outputs, for the forward half of the test
+                for k in KEYS:
+                    arrays["%s/%s/out/it%d_%s" % (tag, kind, i, k)] = o[k].detach().numpy()
+            meta["%s/%s/nograd" % (tag, kind)] = nograd
+            print("g17 %s %-8s loss %.6f  params with grad %d, without %s" % (tag, kind, float(loss), len(seen) - len(nograd), nograd))
+    meta["cases"] = GRAD_CASES
+    arrays["meta"] = np.frombuffer(json.dumps(meta, sort_keys=True).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT_DIR, "g17_grads.npz"), **arrays)
+    print("wrote g17_grads", len(arrays), "arrays")
 
 # module-level case (g16): PARQ.forward = stub backbone -> AddRayPE -> tokenise -> decoder, free-running on damped weights
 MODULE_CASE = dict(cfg=dict(dim=256, queries=48, heads=4, ffn=768, layers=4), wseed=26, pseed=27, gseed=126, fseed=127,
@@ -270,6 +378,8 @@ def main(only=None):
         print("wrote", gname, tuple(enc.shape))
     if not only or "g16_module" in only:
         make_module_golden(ref)
+    if not only or "g17_grads" in only:
+        make_grad_golden(ref)
     if not only or "g10_loss" in only:
         make_loss_golden(ref)
     if not only or "g11_parse_pred" in only:

@@ -75,6 +75,9 @@ SYMBOLS = {
     "parq_wait_iteration": (C.c_int, [_vp, C.c_int32]),
     "parq_backward": (C.c_int, [_vp, C.POINTER(ParqScene), _vp, _sz, C.POINTER(ParqOutputs), C.POINTER(ParqOutputGrads), _vp, _vp, _vp]),
     "parq_arena_lookup": (C.c_int, [_vp, C.c_char_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "parq_grad_bucket": (C.c_int, [_vp, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
+    "parq_backward_wait_bucket": (C.c_int, [_vp, _i32, _vp]),
+    "parq_set_backward_streams": (C.c_int, [_vp, _i32]),
     "parq_ray_pe_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "parq_ray_pe": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_f), _f, _f, _i32, _i32, _i32, _i32, _i32, _i32,
                               _vp, _vp, _i32, _vp, _sz, _vp]),

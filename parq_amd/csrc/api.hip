@@ -57,6 +57,7 @@ struct Arena {
     int64_t gn2_g, gn2_b;             // [2][C]
     int64_t heads3_w, heads3_b;       // [2][6][C], [2][6]: centre.8 padded to 6 rows | rotation.8
     int64_t mean_sizes, dim_t;
+    int64_t early_begin = 0, early_end = 0;   // [early_begin, early_end): gradients final after phase 1 of parq_backward (nl = 1)
     int64_t rowmajor_total;           // end of the tensors above = size of the gradient arena (same layout)
     int64_t tile_off;                 // start of the tile-ordered mirror: matrix at offset o has its chain.hip copy at tile_off + o
     int64_t total;
@@ -110,9 +111,12 @@ struct parq_ctx {
     int kind() const { return attn_mode == 3 ? kBF16 : kF16; }
     int* range_mirror = nullptr;      // host-visible word raised when outputs are poisoned (parq_set_range_mirror)
     bool bwd_batched_env = true;      // parq_set_backward_batched (the parity test compares the two settings)
+    int bwd_streams = 8;              // parq_set_backward_streams: iterations of the chain backward in flight at once (1 = in turn)
     float dim_t_host[128];            // 10000^(2*(i//2)/128): uploaded by parq_pack_weights from this persistent buffer (no stream sync)
     hipStream_t aux_stream[7] = {nullptr};  // batched backward: iterations 1 .. g_sets-1 (mod g_sets) of a phase run here, 0 on the caller's stream
     hipEvent_t fork_ev = nullptr, join_ev[7] = {nullptr};
+    hipEvent_t bucket_done[2] = {nullptr, nullptr};   // parq_backward: gradient bucket 0 / 1 final on the caller's stream (parq_backward_wait_bucket)
+    bool bucket_recorded = false;
     hipEvent_t iter_done[16] = {nullptr};   // parq_forward_train records one after every iteration (parq_wait_iteration)
     bool iter_recorded[16] = {false};
     bool profiling = false;
@@ -128,28 +132,38 @@ void build_arena(parq_ctx* c) {
     int64_t off = 0;
     auto take = [&](int64_t n) { int64_t o = off; off += align_up(n); return o; };
     const int64_t C = c->C, F = c->F, Q = c->Q;
+    // Order = when a tensor's GRADIENT is final inside parq_backward, so that data-parallel training can all-reduce the arena
+    // in two contiguous buckets (parq_grad_bucket): first everything that is only complete at the END of the backward (phase 2
+    // of the iterations and the hoisted K/V projection: reference points, position MLP, both in-projections, self out-proj,
+    // norm1), then what is complete after PHASE 1 (cross out-proj, FFN, norm2, norm3, all heads) — with shared layer weights
+    // (nl = 1) the split is one offset, `early_begin`; the derived inference tensors (no gradient) come last.
+    a.refpoint = take(Q * 3);
+    a.pe0_w = take(C * 384); a.pe0_b = take(C); a.pe2_w = take(C * C); a.pe2_b = take(C);
     a.layers.resize(c->nl);
     for (auto& L : a.layers) {
         L.self_in_w = take(3 * C * C); L.self_in_b = take(3 * C);
         L.self_out_w = take(C * C);    L.self_out_b = take(C);
         L.cross_in_w = take(3 * C * C); L.cross_in_b = take(3 * C);
+        L.n1_w = take(C); L.n1_b = take(C);
+        if (&L == &a.layers.back()) a.early_begin = off;
         L.cross_out_w = take(C * C);   L.cross_out_b = take(C);
         L.lin1_w = take(F * C); L.lin1_b = take(F);
         L.lin2_w = take(C * F); L.lin2_b = take(C);
-        L.n1_w = take(C); L.n1_b = take(C); L.n2_w = take(C); L.n2_b = take(C); L.n3_w = take(C); L.n3_b = take(C);
-        L.kv_whi = take(C * C); L.kv_wlo = take(C * C);
-        L.self_in_w2 = take(3 * C * C); L.self_in_b2 = take(3 * C);
-        L.cross_q_w2 = take(C * C); L.cross_q_b2 = take(C);
+        L.n2_w = take(C); L.n2_b = take(C); L.n3_w = take(C); L.n3_b = take(C);
     }
-    a.refpoint = take(Q * 3);
-    a.pe0_w = take(C * 384); a.pe0_b = take(C); a.pe2_w = take(C * C); a.pe2_b = take(C);
     a.heads1_w = take((int64_t)c->NH1 * C); a.heads1_b = take(c->NH1);
     a.gn1_g = take(2 * C); a.gn1_b = take(2 * C);
     a.heads2_w = take(2 * C * C);
     a.gn2_g = take(2 * C); a.gn2_b = take(2 * C);
     a.heads3_w = take(2 * 6 * C); a.heads3_b = take(12);
+    a.early_end = off;
     a.mean_sizes = take((int64_t)c->cfg.num_mean_sizes * 3);
     a.dim_t = take(128);
+    for (auto& L : a.layers) {
+        L.kv_whi = take(C * C); L.kv_wlo = take(C * C);
+        L.self_in_w2 = take(3 * C * C); L.self_in_b2 = take(3 * C);
+        L.cross_q_w2 = take(C * C); L.cross_q_b2 = take(C);
+    }
     a.rowmajor_total = off;
     // tile-ordered copies of the matrices the per-iteration chain multiplies by (LinearArgs::Wp): same offsets, shifted
     a.tile_off = off;
@@ -223,7 +237,7 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     // takes the row-split kernel (its plain read-modify-write form and the 64 x 64-tile kernel are not safe for that).
     ws->g_set_stride = off - g_set_begin;
     ws->g_sets = (bwd_batched_ok(c, N) && c->dh == 64 && (int64_t)F * C < (1 << 19) && (int64_t)3 * C * C < (1 << 19) && true)
-                     ? bwd_sets(c->I) : 1;
+                     ? (bwd_sets(c->I) < c->bwd_streams ? bwd_sets(c->I) : c->bwd_streams) : 1;
     take((ws->g_sets - 1) * ws->g_set_stride);
     // transposed weight copies of one layer: heads1 [C][NH1], heads2 2x[C][C], lin1^T [C][F], lin2^T [F][C],
     // cross_out^T, cross_q^T, self_out^T [C][C] each, self_in^T [C][3C], pe2^T [C][C], pe0^T [384][C]
@@ -458,9 +472,16 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         HIPCHK(launch_project_sample_f64(sc->tokens, reinterpret_cast<const double*>(wsp + ws.T_cl), sc->camera, ref, c->sb,
                                          B, sc->V, sc->h, sc->w, C, Q, sample_out, o->coord_pos, gn1, B * 8 * kGnSlots, s, sample_cnt));
     }
+    // view-sharded: this rank's fp16-range flag travels as the last float of the record (the caller's all-reduce adds the ranks')
+    if (sharded) HIPCHK(launch_shard_range_flag(c->cache_mode() && c->kind() == kF16 ? reinterpret_cast<const int*>(wsp + ws.flags) : nullptr,
+                                                sh.out + (int64_t)M * C + M, s));
     }   // phase bit 1
     if (sh.mask & 2) {
-    if (sharded) { Prof p(c, s, PARQ_PROF_PROJECT_SAMPLE); HIPCHK(launch_sample_finalize(sh.in, sh.in + (int64_t)M * C, M, C, wi + ws.tgt, s)); }
+    if (sharded) {
+        Prof p(c, s, PARQ_PROF_PROJECT_SAMPLE);
+        HIPCHK(launch_sample_finalize(sh.in, sh.in + (int64_t)M * C, M, C, wi + ws.tgt, s, sh.in + (int64_t)M * C + M,
+                                      c->cache_mode() && c->kind() == kF16 ? reinterpret_cast<int*>(wsp + ws.flags) : nullptr));
+    }
     // K6: self-attention, q = k = tgt + pos, v = tgt (transformer_parq.py:372-376)
     {
         Prof p(c, s, PARQ_PROF_LINEAR);
@@ -942,8 +963,20 @@ int parq_set_backward_batched(parq_handle h, int32_t on) {
     return PARQ_OK;
 }
 
+/* Iterations of the chain backward in flight at once (default 8 = up to eight streams; their weight gradients meet in the arena
+ * through float atomics, so the summation order — and the last bits of the gradients — vary from run to run).  1 runs the
+ * iterations in turn on the caller's stream with plain accumulation: reproducible gradients for the chain (the hoisted K/V
+ * projection's row-split and the set loss still reduce with atomics).  Changes the training workspace size: call before
+ * parq_train_workspace_bytes. */
+int parq_set_backward_streams(parq_handle h, int32_t n) {
+    if (!h || n < 1 || n > 8) return fail(PARQ_ERR_ARG, "parq_set_backward_streams: 1 <= n <= 8");
+    h->bwd_streams = n;
+    return PARQ_OK;
+}
+
 int parq_destroy(parq_handle h) {
     if (!h) return PARQ_OK;
+    for (hipEvent_t e : h->bucket_done) if (e) (void)hipEventDestroy(e);
     for (auto& e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (hipEvent_t e : h->iter_done) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->join_ev) if (e) (void)hipEventDestroy(e);
@@ -1096,7 +1129,8 @@ int parq_iterate(parq_handle h, const parq_scene* scene, void* workspace, size_t
 size_t parq_shard_exchange_floats(parq_handle h, int32_t B, int32_t which) {
     if (!h || B < 1 || which < 0 || which > 1) return 0;
     const int64_t M = (int64_t)B * h->Q;
-    return (size_t)(which == 0 ? M * h->C + M : M * h->C + (int64_t)B * h->H * flash_lq_pad(h->Q));
+    // which = 0: [M*C sample sums | M valid-view counts | 1 fp16-range flag] (SUM all-reduce); 1: [M*C outputs | lse rows] (all-gather)
+    return (size_t)(which == 0 ? M * h->C + M + 1 : M * h->C + (int64_t)B * h->H * flash_lq_pad(h->Q));
 }
 
 int parq_iterate_sharded(parq_handle h, const parq_scene* scene, void* workspace, size_t workspace_bytes, int32_t layer_num,
@@ -1320,12 +1354,22 @@ int parq_backward(parq_handle h, const parq_scene* scene, void* workspace, size_
         io.size = outs->size_unnormalized + k * M * 3;
         return io;
     };
+    for (int i = 0; i < 2; ++i)
+        if (!h->bucket_done[i]) HIPCHK(hipEventCreateWithFlags(&h->bucket_done[i], hipEventDisableTiming));
+    auto finish = [&](bool early_too) -> int {          // the end of the backward: every gradient is final
+        const int r = do_backward_kvproj(h, scene, wsp, ws, grad_arena, d_tokens, s);
+        if (r) return r;
+        if (early_too) HIPCHK(hipEventRecord(h->bucket_done[0], s));
+        HIPCHK(hipEventRecord(h->bucket_done[1], s));
+        h->bucket_recorded = true;
+        return PARQ_OK;
+    };
     if (!ws.bwd_batched) {
         for (int k = h->I - 1; k >= 0; --k) {
             rc = do_backward_iter(h, scene, wsp, ws, k, iter_io(k), grad_arena, d_tokens, s);
             if (rc) return rc;
         }
-        return do_backward_kvproj(h, scene, wsp, ws, grad_arena, d_tokens, s);
+        return finish(true);
     }
     // ---- batched: (1) every iteration from its outputs down to dO, (2) ONE cross-attention backward over all iterations
     // (dK / dV written once, accumulated in registers), (3) every iteration from its dQ down to the sampled features
@@ -1346,19 +1390,25 @@ int parq_backward(parq_handle h, const parq_scene* scene, void* workspace, size_
             HIPCHK(hipEventRecord(h->fork_ev, s));
             for (int i = 0; i + 1 < ns; ++i) HIPCHK(hipStreamWaitEvent(h->aux_stream[i], h->fork_ev, 0));
         }
-        for (int k = I - 1, n = 0; k >= 0; --k, ++n) {
+        int r = PARQ_OK;
+        for (int k = I - 1, n = 0; k >= 0 && r == PARQ_OK; --k, ++n) {
             const int set = n % ns;
-            int r = do_backward_iter(h, scene, wsp, ws, k, iter_io(k), grad_arena, d_tokens, set == 0 ? s : h->aux_stream[set - 1], phase, set);
-            if (r) return r;
+            r = do_backward_iter(h, scene, wsp, ws, k, iter_io(k), grad_arena, d_tokens, set == 0 ? s : h->aux_stream[set - 1], phase, set);
         }
+        // joined on the error path too: whatever the auxiliary streams were given must not outlive the call on a stream the
+        // caller does not know about
         for (int i = 0; i + 1 < ns; ++i) {
-            HIPCHK(hipEventRecord(h->join_ev[i], h->aux_stream[i]));
-            HIPCHK(hipStreamWaitEvent(s, h->join_ev[i], 0));
+            const hipError_t e1 = hipEventRecord(h->join_ev[i], h->aux_stream[i]);
+            const hipError_t e2 = hipStreamWaitEvent(s, h->join_ev[i], 0);
+            if (r == PARQ_OK && (e1 != hipSuccess || e2 != hipSuccess)) r = fail(PARQ_ERR_HIP, "joining the backward's auxiliary streams failed");
         }
-        return PARQ_OK;
+        return r;
     };
     rc = run_phase(1);
     if (rc) return rc;
+    // gradients of everything above the cross-attention (cross out-proj, FFN, norm2 / norm3, the heads) are final: a data-parallel
+    // caller may start all-reducing that bucket on another stream while the attention backward runs (parq_backward_wait_bucket)
+    HIPCHK(hipEventRecord(h->bucket_done[0], s));
     {
         int64_t q_off[16], lse_off[16];
         uint32_t seeds[16];
@@ -1384,7 +1434,28 @@ int parq_backward(parq_handle h, const parq_scene* scene, void* workspace, size_
     }
     rc = run_phase(2);
     if (rc) return rc;
-    return do_backward_kvproj(h, scene, wsp, ws, grad_arena, d_tokens, s);
+    return finish(false);
+}
+
+/* Data-parallel gradient buckets (train.py:103 DDP buckets its all-reduces and overlaps them with the backward): the gradient
+ * arena in the order its parts become final inside parq_backward.  Bucket 0 = [offset, offset + count) floats final after phase
+ * 1 of the batched backward (cross out-proj, FFN, norm2, norm3, every head: everything above the cross-attention), bucket 1 =
+ * the rest of the arena's front, final at the end.  With unshared layer weights (several layers interleave) bucket 0 is empty
+ * and bucket 1 is the whole arena. */
+int parq_grad_bucket(parq_handle h, int32_t bucket, int64_t* offset, int64_t* count) {
+    if (!h || !offset || !count || bucket < 0 || bucket > 1) return fail(PARQ_ERR_ARG, "bad argument");
+    const Arena& ar = h->ar;
+    const bool two = h->nl == 1 && ar.early_end > ar.early_begin;
+    if (bucket == 0) { *offset = two ? ar.early_begin : 0; *count = two ? ar.early_end - ar.early_begin : 0; }
+    else { *offset = 0; *count = two ? ar.early_begin : ar.rowmajor_total; }
+    return PARQ_OK;
+}
+
+int parq_backward_wait_bucket(parq_handle h, int32_t bucket, parq_stream stream) {
+    if (!h || bucket < 0 || bucket > 1) return fail(PARQ_ERR_ARG, "bad argument");
+    if (!h->bucket_recorded) return fail(PARQ_ERR_STATE, "parq_backward_wait_bucket: no parq_backward has been enqueued");
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->bucket_done[bucket], 0));
+    return PARQ_OK;
 }
 
 /* offset (in floats) and element count of a named reference tensor inside the packed weight / gradient arena;

@@ -462,7 +462,9 @@ hipError_t launch_project_sample_f64(const float* tokens, const double* T_cl, co
 hipError_t launch_pe1_sample(const LinearArgs& pe1, const float* tokens, const double* T_cl, const float* cam, const float* ref, ScaleBox sb,
                              int B, int V, int h, int w, int C, int Q, float* tgt, float* coord_pos, double* zero_f64, int zero_n,
                              float* raw_count, hipStream_t s);
-hipError_t launch_sample_finalize(const float* sums, const float* counts, int64_t M, int C, float* tgt, hipStream_t s);
+hipError_t launch_sample_finalize(const float* sums, const float* counts, int64_t M, int C, float* tgt, hipStream_t s,
+                                  const float* range_sum = nullptr, int* range_flag = nullptr);
+hipError_t launch_shard_range_flag(const int* range_flag, float* out, hipStream_t s);
 hipError_t launch_attn_combine(const float* parts, int R, int64_t rec, int B, int H, int Q, int Lq_pad, int dh, float* out, hipStream_t s);
 // self-attention of the Q queries in one launch (8 key slices per workgroup combined through LDS)
 hipError_t launch_self_attn(const float* qkv, int64_t row_stride, int B, int H, int Lq, int dh, float* out,

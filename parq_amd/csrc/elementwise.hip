@@ -610,11 +610,20 @@ hipError_t launch_project_sample_f64(const float* tokens, const double* T_cl, co
 
 // ---- view-sharded scenes (parq_iterate_sharded): the two merges around the exchanges
 // tgt[m][c] = sum[m][c] / max(count[m], 1): the ranks' sample sums and valid-view counts were added by the caller's all-reduce
-__global__ void sample_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ counts, int64_t M, int C, float* __restrict__ tgt) {
+// range_sum (the float behind the counts): the ranks' fp16-range flags added up by the same all-reduce.  A violation on ANY rank
+// poisons the shard it came from, so every rank raises its own device flag (the last kernel of the iteration then writes NaN
+// outputs and raises the host mirror): all ranks return NaN and take the same fallback, never unflagged numbers.
+__global__ void sample_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ counts, int64_t M, int C, float* __restrict__ tgt,
+                                       const float* __restrict__ range_sum, int* __restrict__ range_flag) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && range_sum != nullptr && range_flag != nullptr && *range_sum != 0.f) atomicOr(range_flag, 1);
     if (i >= M * C) return;
     const float n = counts[i / C];
     tgt[i] = sums[i] / (n > 0.f ? n : 1.f);
+}
+// this rank's fp16-range flag as one float of the first exchange record (summed over the ranks by the caller's all-reduce)
+__global__ void shard_range_flag_kernel(const int* __restrict__ range_flag, float* __restrict__ out) {
+    if (threadIdx.x == 0) *out = (range_flag != nullptr && *range_flag != 0) ? 1.f : 0.f;
 }
 // attention outputs of R key shards -> the attention output over all keys.  parts: R records of [M*C normalised outputs |
 // B*H*Lq_pad log2-domain log-sum-exp rows]; weight of shard r for (scene b, head h, query q) = 2^(lse_r - max_r lse)
@@ -639,8 +648,13 @@ __global__ void attn_combine_kernel(const float* __restrict__ parts, int R, int6
     out[i] = num / den;
 }
 
-hipError_t launch_sample_finalize(const float* sums, const float* counts, int64_t M, int C, float* tgt, hipStream_t s) {
-    hipLaunchKernelGGL(sample_finalize_kernel, dim3((unsigned)((M * C + 255) / 256)), dim3(256), 0, s, sums, counts, M, C, tgt);
+hipError_t launch_sample_finalize(const float* sums, const float* counts, int64_t M, int C, float* tgt, hipStream_t s,
+                                  const float* range_sum, int* range_flag) {
+    hipLaunchKernelGGL(sample_finalize_kernel, dim3((unsigned)((M * C + 255) / 256)), dim3(256), 0, s, sums, counts, M, C, tgt, range_sum, range_flag);
+    return hipGetLastError();
+}
+hipError_t launch_shard_range_flag(const int* range_flag, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(shard_range_flag_kernel, dim3(1), dim3(64), 0, s, range_flag, out);
     return hipGetLastError();
 }
 hipError_t launch_attn_combine(const float* parts, int R, int64_t rec, int B, int H, int Q, int Lq_pad, int dh, float* out, hipStream_t s) {

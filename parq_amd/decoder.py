@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -147,6 +148,17 @@ class _TransformerParams(nn.Module):
 ATTENTION_MODES = {"fp32": 0, "split": 1, "fp16": 2, "bf16": 3}
 
 
+class _Stash:
+    """What one training forward leaves for its backward: the training workspace (saved activations of every iteration, K / V,
+    log-sum-exp rows), the call's state tuple (scene, inputs, output tensors, attention mode, dropout probability and seed) and
+    the workspace generation it was written in.  Owned by the autograd node; the module only keeps a weak reference, so a later
+    training forward knows whether the workspace is still needed (then it takes a fresh one) or free to be reused."""
+    __slots__ = ("ws", "state", "gen", "consumed", "__weakref__")
+
+    def __init__(self, ws, state, gen):
+        self.ws, self.state, self.gen, self.consumed = ws, state, gen, False
+
+
 class _TrainFn(torch.autograd.Function):
     """Autograd node of the whole decoder: forward = parq_forward_train, backward = parq_backward (HIP kernels)."""
 
@@ -155,7 +167,11 @@ class _TrainFn(torch.autograd.Function):
         outs = dec.forward_train(tokens, camera, T_cp, T_wp, T_wl, feat_hw=feat_hw, defer_range_check=bool(dec.overlap_loss_matching) and dec.num_layers <= 16)
         stacked = dec._train_state[2]                       # six (I, B, Q, k) tensors
         ctx.dec = dec
-        ctx.gen = dec._train_gen                            # this node owns the stash only until the next training forward
+        # this node OWNS the stash of its forward: a later forward of the module, while this node is alive and has not run its
+        # backward, allocates a workspace of its own instead of overwriting this one (several outstanding forwards per module,
+        # e.g. (loss(dec(a)) + loss(dec(b))).backward(), work like they do with the reference)
+        ctx.stash = _Stash(dec._train_ws, dec._train_state, dec._train_gen)
+        dec._stash_owner = weakref.ref(ctx.stash)
         ctx.want_tokens = bool(tokens.requires_grad)
         ctx.mark_non_differentiable(stacked[4], stacked[5])  # sem_cls_prob / coord_pos carry no gradient (transformer_parq.py:261-265)
         del outs
@@ -166,13 +182,14 @@ class _TrainFn(torch.autograd.Function):
         dec = ctx.dec
         if dec._phase_hook is not None:
             dec._phase_hook("hip_backward")                  # bench.py --phase-times: where the loss graph's autograd ends
-        if dec._train_gen != ctx.gen:
-            raise RuntimeError("parq_amd.PARQDecoder: backward of a training forward whose saved activations were overwritten by a "
-                               "later training forward of the same module (the stash, dropout seed and outputs live on the module: one "
-                               "outstanding forward per module).  Run backward before the next forward, e.g. accumulate "
-                               "loss(dec(a)).backward(); loss(dec(b)).backward() instead of (loss(dec(a)) + loss(dec(b))).backward()")
+        st = ctx.stash
+        if getattr(st.ws, "_parq_gen", None) != st.gen:
+            raise RuntimeError("parq_amd.PARQDecoder: second backward through a training forward (retain_graph=True) whose saved "
+                               "activations were released by the first backward and have since been reused by a later forward of "
+                               "the same module.  Run the repeated backward before the next forward.")
         grads, d_tokens = dec.backward({"pred_logits": g_logits, "center_unnormalized": g_center, "size_unnormalized": g_size,
-                                        "ortho6d": g_rot}, want_token_grad=ctx.want_tokens)
+                                        "ortho6d": g_rot}, want_token_grad=ctx.want_tokens, _stash=st)
+        st.consumed = True                                   # the workspace may be reused by the next training forward
         per_param = []
         for name, p in dec._unique_params():
             per_param.append(grads.get(name) if p.requires_grad else None)
@@ -233,9 +250,13 @@ class PARQDecoder(nn.Module):
         self._matcher = None
         self._train_ws = None
         self._train_state = None
-        self._train_gen = 0               # bumped by every forward_train: an autograd node checks it still owns the stash
+        self._train_gen = 0               # bumped by every forward_train and stamped on its workspace (``_parq_gen``)
+        self._stash_owner = None          # weak reference to the _Stash of the autograd node that owns ``_train_ws`` (if any)
+        self._train_entry_event = None    # recorded on the caller's stream at the entry of forward_train (loss(): targets ready)
         self.loss_batched = True          # loss(): all (iteration, scene) pairs in ~40 launches (False: the reference's per-pair loop)
         self.dp_all_reduce = False        # True: backward() all-reduces the flat gradient arena over the default process group
+        self.dp_bucketed = True           # ... in two buckets, the first overlapped with the cross-attention backward (False: one flat all-reduce)
+        self._dp_stream = None
         self.backward_batched = True      # cross-attention backward of all iterations as one launch (False: per-iteration launches,
                                           # the cross-check form; include/parq_hip.h parq_set_backward_batched)
         self.overlap_loss_matching = True # loss() on the outputs of this module's own training forward matches iteration k on the
@@ -301,10 +322,18 @@ class PARQDecoder(nn.Module):
             self._h = h
             self._mode_set = None
             self._bwd_batched_set = None
+            self._bwd_streams_set = None
             self._train_ws = None
             # pinned host memory is mapped into the device address space under the same pointer (hipHostMalloc)
             self._range_mirror = torch.zeros(1, dtype=torch.int32).pin_memory()
             _lib.check(lib.parq_set_range_mirror(h, C.c_void_p(self._range_mirror.data_ptr())), "parq_set_range_mirror")
+        det = 1 if torch.are_deterministic_algorithms_enabled() else 8
+        if getattr(self, "_bwd_streams_set", None) != det:
+            # torch.use_deterministic_algorithms(True): the iterations of the chain backward run in turn with plain accumulation
+            # instead of on eight streams with float atomics (include/parq_hip.h parq_set_backward_streams)
+            _lib.check(_lib.load().parq_set_backward_streams(self._h, det), "parq_set_backward_streams")
+            self._bwd_streams_set = det
+            self._train_ws = None
         if self._bwd_batched_set != bool(self.backward_batched):
             _lib.check(_lib.load().parq_set_backward_batched(self._h, int(bool(self.backward_batched))), "parq_set_backward_batched")
             self._bwd_batched_set = bool(self.backward_batched)
@@ -443,17 +472,27 @@ class PARQDecoder(nn.Module):
 
     # ------------------------------------------------------------------ forward (model/parq_decoder.py:134-163)
     def forward(self, intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw=None):
-        if torch.is_grad_enabled() and self.training:
+        """Same dispatch as the reference module gets from autograd: with gradients enabled and anything to differentiate (a
+        parameter or the tokens require grad) the result carries a graph — in ``train()`` mode with the decoder layer's dropout,
+        in ``eval()`` mode without it (the reference differentiates in eval mode too, model/parq_decoder.py:134-163).  Under
+        ``torch.no_grad()`` (eval.py:46, Lightning's validation loop), or with nothing that requires grad, the inference chain
+        runs: no saved activations, the folded position MLP, one K/V workspace."""
+        if torch.is_grad_enabled() and (self.training or self._needs_graph(intput_tokens)):
             return self._forward_autograd(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
         with torch.no_grad():
             return self._forward_inference(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
 
+    def _needs_graph(self, tokens):
+        t = raw(tokens)
+        return bool(getattr(t, "requires_grad", False)) or any(p.requires_grad for p in self.parameters())
+
     def _forward_autograd(self, tokens, camera, T_cp, T_wp, T_wl, feat_hw):
-        """Train-mode forward under autograd: one autograd node whose backward is the HIP backward chain.  Attention
-        arithmetic = ``_train_mode()``: the split-precision kernels where the head dim has them (64 / 256) unless
-        ``attention_mode == "fp32"``, else the exact fp32 MFMA kernels.  DROPOUT_RATE > 0 applies the decoder layer's six
-        dropout sites with counter-based masks (seeded from torch's generator per call).  One outstanding forward per
-        module: the node raises in backward if a later training forward has replaced its stash."""
+        """Forward under autograd (train mode, or eval mode with something to differentiate): one autograd node whose backward
+        is the HIP backward chain.  Attention arithmetic = ``_train_mode()``: the split-precision kernels where the head dim has
+        them (64 / 256) unless ``attention_mode == "fp32"``, else the exact fp32 MFMA kernels.  In train mode DROPOUT_RATE > 0
+        applies the decoder layer's six dropout sites with counter-based masks (seeded from torch's generator per call); in eval
+        mode dropout is off, as nn.Dropout.  Every node owns the saved activations of its forward (``_Stash``): several forwards
+        may be outstanding, each holding one training workspace until its backward has run or its graph is dropped."""
         params = [p for _, p in self._unique_params()]
         stacked = _TrainFn.apply(self, raw(tokens), camera, T_cp, T_wp, T_wl, feat_hw, *params)
         return [{k: t[i] for k, t in zip(OUTPUT_KEYS, stacked)} for i in range(self.num_layers)]
@@ -483,9 +522,19 @@ class PARQDecoder(nn.Module):
         (the autograd path with ``overlap_loss_matching``): do not wait for the device here; ``loss()`` resolves the fp16-range
         check of this forward while it matches, ``backward()`` raises if nobody did."""
         self._range_poll()                     # BEFORE the mode of this step is chosen: a fallback must not split forward / backward
+        owner = self._stash_owner() if self._stash_owner is not None else None
+        if owner is not None and not owner.consumed and owner.ws is self._train_ws:
+            # an autograd node of an earlier forward still needs its activations: settle that forward's deferred range check
+            # (it would re-run into the workspace we are about to leave) and give this forward a workspace of its own
+            self._resolve_train_range()
+            self._train_ws = None
         sc, keep, dev = self._scene(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
         self._ensure_packed(dev)
         lib = _lib.load()
+        # everything the caller enqueued so far (in particular the targets loss() will read on its side stream: an asynchronous
+        # host-to-device copy, on-device augmentation) is ordered before this event
+        self._train_entry_event = torch.cuda.Event()
+        self._train_entry_event.record(torch.cuda.current_stream(dev))
         # decoder-layer dropout (train mode only, as nn.Dropout): a fresh mask seed per call, reused by backward()
         p_drop = float(self.dropout_rate) if self.training else 0.0
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
@@ -503,7 +552,10 @@ class PARQDecoder(nn.Module):
             _lib.check(lib.parq_forward_train(h, C.byref(sc), _lib.ptr(self._train_ws), self._train_ws.numel() * 4, C.byref(po),
                                               _lib.stream_ptr()), "parq_forward_train")
             # the stash is laid out for `mode`: backward() uses exactly this mode, whatever attention_mode says by then
-            self._train_state = (sc, keep, outs, po, dev, mode)
+            self._train_state = (sc, keep, outs, po, dev, mode, p_drop, seed)
+            own = self._stash_owner() if self._stash_owner is not None else None
+            if own is not None and own.ws is self._train_ws:
+                own.state = self._train_state          # a re-run (range fallback) after the autograd node took the stash: same workspace, new mode
             return mode
         mode = enqueue()
         self._train_pending = None
@@ -526,19 +578,24 @@ class PARQDecoder(nn.Module):
             else:
                 rerun_if_poisoned(False)                     # one host synchronisation per step
         self._train_gen += 1
+        self._train_ws._parq_gen = self._train_gen             # which forward's activations the workspace holds
         return [{k: t[i] for k, t in zip(OUTPUT_KEYS, outs)} for i in range(self.num_layers)]
 
     @torch.no_grad()
-    def backward(self, grad_outputs, want_token_grad=True):
+    def backward(self, grad_outputs, want_token_grad=True, _stash=None):
         """Backward of the last ``forward_train``.  ``grad_outputs``: dict with any of pred_logits / center_unnormalized /
         size_unnormalized / ortho6d -> (I, B, Q, k) cotangents (missing = zero).  Returns ({reference tensor name:
         gradient}, d_tokens or None); gradients of tensors registered under two names are returned once per name."""
-        if self._train_state is None:
+        if _stash is None and self._train_state is None:
             raise RuntimeError("backward() needs a preceding forward_train()")
-        self._resolve_train_range(in_backward=True)
-        sc, keep, outs, po, dev, mode = self._train_state
+        state = _stash.state if _stash is not None else self._train_state
+        train_ws = _stash.ws if _stash is not None else self._train_ws
+        if state is self._train_state:                         # the most recent forward: its range check may still be pending
+            self._resolve_train_range(in_backward=True)
+        sc, keep, outs, po, dev, mode, p_drop, seed = state
         # the mode the stash was written in (forward_train), not whatever attention_mode says now: the workspace layout differs
         lib, h = _lib.load(), self._handle_in_mode(mode)
+        _lib.check(lib.parq_set_dropout(h, p_drop, seed), "parq_set_dropout")      # the masks of THAT forward (another one may have run since)
         gs = []
         for key, wd in (("pred_logits", self.num_semcls + 1), ("center_unnormalized", 3), ("size_unnormalized", 3), ("ortho6d", 6)):
             g = grad_outputs.get(key)
@@ -550,13 +607,30 @@ class PARQDecoder(nn.Module):
         arena = torch.empty(lib.parq_grad_arena_bytes(h) // 4, dtype=torch.float32, device=dev)
         N = sc.V * sc.h * sc.w
         d_tokens = torch.empty(sc.B, N, self.dim_in, dtype=torch.float32, device=dev) if want_token_grad else None
-        _lib.check(lib.parq_backward(h, C.byref(sc), _lib.ptr(self._train_ws), self._train_ws.numel() * 4, C.byref(po), C.byref(pg),
+        _lib.check(lib.parq_backward(h, C.byref(sc), _lib.ptr(train_ws), train_ws.numel() * 4, C.byref(po), C.byref(pg),
                                      _lib.ptr(arena), _lib.ptr(d_tokens), _lib.stream_ptr()), "parq_backward")
         if self.dp_all_reduce:
-            # data-parallel training: the gradient arena is one flat buffer -> a single RCCL all-reduce (mean), instead
-            # of one bucket per tensor (train.py:103 DDP semantics: mean over ranks)
-            from .parallel import all_reduce_mean_
-            all_reduce_mean_(arena)
+            # data-parallel training (train.py:103 DDP semantics: mean over ranks): the gradient arena is one flat buffer laid
+            # out in the order parq_backward finishes it, so it is averaged in TWO buckets instead of one bucket per tensor —
+            # the first (everything above the cross-attention) on a side stream as soon as phase 1 of the backward has written
+            # it, i.e. beside the cross-attention backward that is still enqueued; the second at the end
+            from .parallel import all_reduce_mean_, all_reduce_mean_buckets_
+            if self.dp_bucketed and arena.is_cuda:
+                off, cnt = C.c_int64(), C.c_int64()
+                buckets = []
+                for b in (0, 1):
+                    _lib.check(lib.parq_grad_bucket(h, b, C.byref(off), C.byref(cnt)), "parq_grad_bucket")
+                    buckets.append((off.value, cnt.value))
+                which = [b for b in (0, 1) if buckets[b][1] > 0]
+
+                def ready(i, stream, _which=which):
+                    if stream is not None:
+                        _lib.check(lib.parq_backward_wait_bucket(h, _which[i], C.c_void_p(stream.cuda_stream)), "parq_backward_wait_bucket")
+                if self._dp_stream is None or self._dp_stream.device != arena.device:
+                    self._dp_stream = torch.cuda.Stream(device=arena.device)
+                all_reduce_mean_buckets_(arena, buckets, ready=ready, side_stream=self._dp_stream)
+            else:
+                all_reduce_mean_(arena)
         grads = {}
         off, rows, cols, ld = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         for name, p in self._unique_params():
@@ -605,43 +679,62 @@ class PARQDecoder(nn.Module):
         of the sampled-feature sums and valid-view counts; all-gather of the per-shard attention outputs and log-sum-exp rows:
         ~0.27 MB each at Q = 256, d = 256), everything else is computed identically on every rank.  Returns the same list of
         per-iteration dicts as ``forward`` on every rank.  ``forced_refs``: optional list of (B,Q,3) reference points per
-        iteration (teacher forcing, as ``iterate``)."""
+        iteration (teacher forcing, as ``iterate``).
+
+        fp16 operand range: the ranks' range flags travel in the first exchange (one float, summed), so a violation in ANY rank's
+        shard poisons the outputs on EVERY rank and every rank reads the same flag after the last iteration (one host
+        synchronisation per forward on this path, which already hands two collectives per iteration to the host): under
+        ``range_check = "sync"`` all ranks re-run the forward with the exact fp32 kernels, under "lazy" all ranks warn, return
+        the NaN outputs and use the fp32 kernels from the next call on.  The ranks never end up in different attention modes."""
         import torch.distributed as dist
         self._check_mode()
+        self._range_poll()
         sc, keep, dev = self._scene(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
         self._ensure_packed(dev)
-        lib, h = _lib.load(), self._handle()
-        ws = self._workspace(sc.B, sc.V, sc.h, sc.w, dev)
-        _lib.check(lib.parq_prepare(h, C.byref(sc), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()), "parq_prepare")
+        lib = _lib.load()
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        na, nb = lib.parq_shard_exchange_floats(h, sc.B, 0), lib.parq_shard_exchange_floats(h, sc.B, 1)
-        xa = torch.empty(na, dtype=torch.float32, device=dev)
-        xb = torch.empty(nb, dtype=torch.float32, device=dev)
-        gathered = torch.empty(world * nb, dtype=torch.float32, device=dev)
-        results = []
-        for k in range(self.num_layers):
-            outs = self._alloc_outputs((sc.B, self.num_queries), dev)
-            po = _lib.ParqOutputs(*[_lib.ptr(t) for t in outs])
-            ref_in = None
-            if forced_refs is not None:
-                ref_in = forced_refs[k].to(device=dev, dtype=torch.float32).contiguous()
+        for _attempt in range(2):
+            h = self._handle()
+            ws = self._workspace(sc.B, sc.V, sc.h, sc.w, dev)
+            _lib.check(lib.parq_prepare(h, C.byref(sc), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()), "parq_prepare")
+            na, nb = lib.parq_shard_exchange_floats(h, sc.B, 0), lib.parq_shard_exchange_floats(h, sc.B, 1)
+            xa = torch.empty(na, dtype=torch.float32, device=dev)
+            xb = torch.empty(nb, dtype=torch.float32, device=dev)
+            gathered = torch.empty(world * nb, dtype=torch.float32, device=dev)
+            results = []
+            for k in range(self.num_layers):
+                outs = self._alloc_outputs((sc.B, self.num_queries), dev)
+                po = _lib.ParqOutputs(*[_lib.ptr(t) for t in outs])
+                ref_in = None
+                if forced_refs is not None:
+                    ref_in = forced_refs[k].to(device=dev, dtype=torch.float32).contiguous()
 
-            def phase(ph, xin, xout, _po=po, _ref=ref_in, _k=k):
-                _lib.check(lib.parq_iterate_sharded(h, C.byref(sc), _lib.ptr(ws), ws.numel() * 4, _k, ph, _lib.ptr(_ref), C.byref(_po),
-                                                    None, _lib.ptr(xin), _lib.ptr(xout), world, _lib.stream_ptr()),
-                           "parq_iterate_sharded(phase %d)" % ph)
+                def phase(ph, xin, xout, _po=po, _ref=ref_in, _k=k):
+                    _lib.check(lib.parq_iterate_sharded(h, C.byref(sc), _lib.ptr(ws), ws.numel() * 4, _k, ph, _lib.ptr(_ref), C.byref(_po),
+                                                        None, _lib.ptr(xin), _lib.ptr(xout), world, _lib.stream_ptr()),
+                               "parq_iterate_sharded(phase %d)" % ph)
 
-            phase(0, None, xa)
-            if world > 1:
-                dist.all_reduce(xa, group=group)
-            phase(1, xa, xb)
-            if world > 1:
-                dist.all_gather_into_tensor(gathered, xb, group=group)
-            else:
-                gathered.copy_(xb)
-            phase(2, gathered, None)
-            results.append(dict(zip(OUTPUT_KEYS, outs)))
-        self._range_poll()
+                phase(0, None, xa)
+                if world > 1:
+                    dist.all_reduce(xa, group=group)
+                phase(1, xa, xb)
+                if world > 1:
+                    dist.all_gather_into_tensor(gathered, xb, group=group)
+                else:
+                    gathered.copy_(xb)
+                phase(2, gathered, None)
+                results.append(dict(zip(OUTPUT_KEYS, outs)))
+            if self.range_check == "off" or self.attention_mode not in ("split", "fp16"):
+                break
+            # identical on every rank (the flags were summed in the first exchange of every iteration)
+            if int(self._flag_view(ws, sc.B, sc.V, sc.h, sc.w).item()) == 0:
+                break
+            self._range_mirror[0] = 0
+            self._range_fallback("view-sharded forward: a rank's K/V shard left the range" +
+                                 ("; re-running on every rank" if self.range_check == "sync" else ""))
+            if self.range_check != "sync":
+                break
+        del keep
         return results
 
     def fp16_range_exceeded(self):
@@ -698,7 +791,8 @@ class PARQDecoder(nn.Module):
             ready = self._train_ready                      # these ARE the outputs of the training forward in flight
         else:
             self._resolve_train_range()
-        return decoder_loss_batched(out_dict_list, obbs_padded, T_world_local, sym, ready=ready, **kw)
+        return decoder_loss_batched(out_dict_list, obbs_padded, T_world_local, sym, ready=ready,
+                                    targets_ready=self._train_entry_event if ready is not None else None, **kw)
 
     def wait_iteration(self, k):
         """Block the host until iteration k of the last training forward has written its outputs (parq_wait_iteration)."""

@@ -291,7 +291,7 @@ def _side_stream(dev):
 
 # ---------------------------------------------------------------- batched evaluation (same numbers, ~40 launches per step)
 def decoder_loss_batched(out_dict_list, obbs_padded, T_world_local, sym=None, *, matcher, loss_weight, num_semcls, class_weight,
-                         ready=None):
+                         ready=None, targets_ready=None):
     """``decoder_loss`` with every (iteration, scene) pair evaluated together: one softmax / cdist / host copy for the matcher,
     the matched (prediction, box) pairs of all iterations and scenes gathered into flat index tensors, per-pair terms reduced
     with segment sums.  The matching itself (scipy LSAP, the np.random.choice cap, the punish-mask quirks) is the loop of
@@ -305,9 +305,20 @@ def decoder_loss_batched(out_dict_list, obbs_padded, T_world_local, sym=None, *,
     # and returns True if the forward had to be re-run (fp16 range fallback) -> the matching starts over.  The target preparation
     # and the per-iteration matcher inputs then run on a side stream while the device is still in the later iterations; the
     # matching order (iteration, scene, box) and with it the np.random draws are the same as without it.
+    # The side stream must not read the caller's targets (obbs_padded, T_world_local, sym) before the work that produced them
+    # has run: `targets_ready` is an event the module recorded on the main stream at the ENTRY of its training forward, so
+    # targets enqueued before that forward — a pinned-memory .to(device, non_blocking=True), on-device augmentation behind the
+    # previous step — are ordered in front of everything below, while the forward's iterations are not waited for.  Targets
+    # produced AFTER the forward was enqueued are the caller's to order; without an event the side stream waits for the whole
+    # main stream (correct, no overlap).
     main = torch.cuda.current_stream(dev) if (ready is not None and dev.type == "cuda") else None
     side = _side_stream(dev) if main is not None else None
     on_side = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
+    if side is not None:
+        if targets_ready is not None:
+            side.wait_event(targets_ready)
+        else:
+            side.wait_stream(main)
     with on_side():
         targets = parse_target(obbs_padded, T_world_local)
         nmax = max(1, max(len(t["labels"]) for t in targets))

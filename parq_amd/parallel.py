@@ -58,6 +58,17 @@ def max_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
+def gather_over_ranks(value: float, device=None):
+    """[value of rank 0, ..., value of rank W-1] on every rank (the benchmark prints every rank's step time next to the
+    maximum, so that a straggler — a rank on the far socket, a throttling GPU — is visible in the driver's log)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def all_gather_scenes(x: torch.Tensor, num_scenes: int) -> torch.Tensor:
     """Concatenate the per-rank scene shards of `x` (leading dim = local scenes) in rank order.
     Shards may be ragged (shard_range), so they are padded to the largest shard for the collective."""
@@ -81,6 +92,126 @@ def all_reduce_mean_(flat: torch.Tensor) -> torch.Tensor:
         torch.distributed.all_reduce(flat)
         flat /= torch.distributed.get_world_size()
     return flat
+
+
+def all_reduce_mean_buckets_(flat: torch.Tensor, buckets, ready=None, side_stream=None) -> torch.Tensor:
+    """``all_reduce_mean_`` of one flat gradient buffer in BUCKETS: ``buckets`` = [(offset, count), ...] in the order the
+    producer finishes them (include/parq_hip.h parq_grad_bucket: bucket 0 is final after phase 1 of parq_backward, half a step
+    before the rest).  ``ready(i, stream)`` (GPU: parq_backward_wait_bucket) makes ``stream`` wait, on the device, until bucket i
+    is written; each bucket's all-reduce is then issued on ``side_stream`` so that it runs beside what the backward still has
+    enqueued on the main stream, and the main stream joins the collectives at the end (what DDP's bucketed, overlapped all-reduce
+    does for the reference, train.py:103-108).  Ranges outside the buckets are not touched; empty buckets are skipped.  On CPU
+    tensors (the gloo tests) the buckets are reduced one after the other.  Same result as the flat all-reduce: a mean per element."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return flat
+    world = dist.get_world_size()
+    buckets = [(int(o), int(n)) for o, n in buckets if int(n) > 0]
+    if not flat.is_cuda or side_stream is None:
+        for i, (o, n) in enumerate(buckets):
+            if ready is not None:
+                ready(i, None)
+            dist.all_reduce(flat[o:o + n])
+            flat[o:o + n] /= world
+        return flat
+    main = torch.cuda.current_stream(flat.device)
+    works = []
+    for i, (o, n) in enumerate(buckets):
+        if ready is not None:
+            ready(i, side_stream)                    # device-side wait: the host runs ahead
+        else:
+            side_stream.wait_stream(main)
+        with torch.cuda.stream(side_stream):
+            view = flat[o:o + n]
+            works.append(dist.all_reduce(view, async_op=True))
+            # (RCCL: the collective is ordered behind `side_stream`; gloo on device tensors: the work object completes on wait())
+    for w in works:
+        w.wait()                                     # RCCL: the current stream of THIS context waits for the collective
+    with torch.cuda.stream(side_stream):
+        for o, n in buckets:
+            flat[o:o + n] /= world
+    main.wait_stream(side_stream)
+    flat.record_stream(side_stream)
+    return flat
+
+
+# ------------------------------------------------------------------------------------------------------------- host placement
+def _parse_cpulist(text: str):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_local_cpus(index: int, sysfs: str = "/sys", visible: str | None = None):
+    """Host CPUs on the NUMA node of the GPU that HIP enumerates as device ``index`` — WITHOUT touching the GPU runtime: the
+    GPU agents appear in the KFD topology (``/sys/class/kfd/kfd/topology/nodes/*/properties``, nodes with simd_count > 0) in the
+    order ROCr / HIP enumerate them; ``location_id`` / ``domain`` give the PCI address, whose ``local_cpulist`` is the answer.
+    ``visible``: HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES style list of physical indices (default: from the environment).
+    Returns [] when the topology cannot be read (containers without /sys/class/kfd)."""
+    import glob
+    if visible is None:
+        visible = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or ""
+    gpus = []
+    nodes = glob.glob(os.path.join(sysfs, "class/kfd/kfd/topology/nodes/*"))
+    for node in sorted(nodes, key=lambda p: int(os.path.basename(p)) if os.path.basename(p).isdigit() else 1 << 30):
+        props = {}
+        try:
+            with open(os.path.join(node, "properties")) as f:
+                for line in f:
+                    k, _, v = line.strip().partition(" ")
+                    props[k] = v
+        except OSError:
+            continue
+        try:
+            if int(props.get("simd_count", "0")) <= 0:
+                continue
+            loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+        except (KeyError, ValueError):
+            continue
+        gpus.append("%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 0x7))
+    try:
+        phys = [int(x) for x in visible.split(",") if x.strip() != ""] if visible else list(range(len(gpus)))
+        bdf = gpus[phys[index]]
+    except (ValueError, IndexError):
+        return []
+    try:
+        with open(os.path.join(sysfs, "bus/pci/devices", bdf, "local_cpulist")) as f:
+            return _parse_cpulist(f.read())
+    except (OSError, ValueError):
+        return []
+
+
+def pin_to_local_cores(local_rank: int, local_world: int | None = None, sysfs: str = "/sys"):
+    """Pin THIS process (and the threads it starts later) to the host cores next to its GPU, in-process
+    (``os.sched_setaffinity``; no re-exec, no numactl — call it BEFORE the first GPU call so that the runtime's helper threads
+    inherit the mask).  Ranks whose GPUs share a NUMA node split that node's cores among themselves, so eight ranks on a
+    two-socket host get disjoint eighths instead of all landing on socket 0 (the launcher's default), where four of them
+    would drive their GPUs across the inter-socket link.  Returns the CPU list it set, or [] if it left the mask alone (no
+    topology information, or the intersection with the allowed set is empty)."""
+    if not hasattr(os, "sched_setaffinity"):
+        return []
+    if local_world is None:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    mine = gpu_local_cpus(local_rank, sysfs)
+    if not mine:
+        return []
+    # ranks that share my NUMA node (same local_cpulist), in rank order: each takes a contiguous slice
+    sharing = [r for r in range(max(1, local_world)) if gpu_local_cpus(r, sysfs) == mine] or [local_rank]
+    allowed = sorted(set(mine) & set(os.sched_getaffinity(0)))
+    if not allowed:
+        return []
+    k, n = (sharing.index(local_rank) if local_rank in sharing else 0), len(sharing)
+    per = max(1, len(allowed) // n)
+    part = allowed[k * per:(k + 1) * per] if k < n - 1 else allowed[k * per:]
+    part = part or allowed
+    try:
+        os.sched_setaffinity(0, part)
+    except OSError:
+        return []
+    return part
 
 
 def all_reduce_mean_scalars(metrics: dict, device=None) -> dict:

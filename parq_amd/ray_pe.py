@@ -9,6 +9,7 @@ model/parq_lightning.py:72-85.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import torch
 from torch import nn
@@ -23,19 +24,23 @@ class _RayPeFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mod, features, camera, T_cp, T_wp, T_wl, w1, b1, w2, b2):
-        out, dims, _ = mod._run(camera, T_cp, T_wp, T_wl, tuple(features.shape[-2:]), features)
+        out, dims, _ = mod._run(camera, T_cp, T_wp, T_wl, tuple(features.shape[-2:]), features, own_workspace=True)
         ctx.mod, ctx.dims = mod, dims
         ctx.geo = mod._last_geo
-        ctx.gen = mod._gen
+        # the node owns the workspace of its forward (the hidden layer the backward reads): a later call, while this node is
+        # alive and has not run its backward, takes a workspace of its own (several outstanding forwards per module)
+        ctx.hold = _WsHold(mod._ws, mod._gen)
+        mod._ws_owner = weakref.ref(ctx.hold)
         ctx.want_feat = bool(features.requires_grad)
         return out
 
     @staticmethod
     def backward(ctx, g_tokens):
         mod = ctx.mod
-        if mod._gen != ctx.gen:
-            raise RuntimeError("parq_amd.AddRayPE: backward of a tokens() call whose workspace (the hidden layer it saved) was "
-                               "overwritten by a later call of the same module: one outstanding forward per module")
+        hold = ctx.hold
+        if getattr(hold.ws, "_parq_gen", None) != hold.gen:
+            raise RuntimeError("parq_amd.AddRayPE: second backward (retain_graph=True) through a tokens() call whose workspace was "
+                               "released by the first backward and has since been reused by a later call of the same module")
         B, V, h, w = ctx.dims
         Cd, S = mod.dim_out, mod.num_samples
         cam, T_cp, T_wp, T_wl = ctx.geo
@@ -53,12 +58,21 @@ class _RayPeFn(torch.autograd.Function):
         w2 = mod.encoder[2].weight.detach().to(device=dev, dtype=torch.float32).contiguous()
         _lib.check(lib.parq_ray_pe_backward(_lib.ptr(cam), _lib.ptr(T_cp), _lib.ptr(T_wp), _lib.ptr(T_wl), _lib.ptr(w2),
                                             (C.c_float * 6)(*mod.ray_points_scale), mod.min_depth, mod.max_depth, S, B, V, h, w, Cd,
-                                            _lib.ptr(g), _lib.ptr(mod._ws), _lib.ptr(bws), bws.numel() * 4, _lib.ptr(dw1), _lib.ptr(db1),
+                                            _lib.ptr(g), _lib.ptr(hold.ws), _lib.ptr(bws), bws.numel() * 4, _lib.ptr(dw1), _lib.ptr(db1),
                                             _lib.ptr(dw2), _lib.ptr(db2), _lib.ptr(dfeat), _lib.stream_ptr()), "parq_ray_pe_backward")
+        hold.consumed = True
         if mod.dp_all_reduce:
             from .parallel import all_reduce_mean_
             all_reduce_mean_(flat)
         return None, dfeat, None, None, None, None, dw1, db1, dw2, db2
+
+
+class _WsHold:
+    """The workspace one autograd node of AddRayPE reads in its backward, and the generation it was written in."""
+    __slots__ = ("ws", "gen", "consumed", "__weakref__")
+
+    def __init__(self, ws, gen):
+        self.ws, self.gen, self.consumed = ws, gen, False
 
 
 class AddRayPE(nn.Module):
@@ -72,10 +86,11 @@ class AddRayPE(nn.Module):
         self.max_depth = float(max_depth)
         self.encoder = nn.Sequential(nn.Linear(3 * num_samples, dim_out), nn.ReLU(), nn.Linear(dim_out, dim_out))
         self._ws = None
-        self._gen = 0                     # forward counter: the backward of an autograd node checks it still owns the workspace
+        self._gen = 0                     # forward counter, stamped on the workspace it wrote (``_parq_gen``)
+        self._ws_owner = None             # weak reference to the _WsHold of the autograd node that owns ``_ws`` (if any)
         self.dp_all_reduce = False        # True: the backward all-reduces (mean) the encoder gradients over the default process group
 
-    def _run(self, camera, T_cp, T_wp, T_wl, feat_hw, features, nchw=False):
+    def _run(self, camera, T_cp, T_wp, T_wl, feat_hw, features, nchw=False, own_workspace=False):
         cam, T_cp, T_wp, T_wl = (raw(x) for x in (camera, T_cp, T_wp, T_wl))
         if not cam.is_cuda:
             raise RuntimeError("parq_amd.AddRayPE runs on the GPU only (there is no CPU fallback)")
@@ -95,6 +110,9 @@ class AddRayPE(nn.Module):
         lib = _lib.load()
         self._gen += 1
         nbytes = lib.parq_ray_pe_workspace_bytes(B, V, h, w, Cd, self.num_samples)
+        owner = self._ws_owner() if self._ws_owner is not None else None
+        if owner is not None and not owner.consumed and owner.ws is self._ws:
+            self._ws = None                                  # an autograd node still needs the hidden layer saved there
         if self._ws is None or self._ws.numel() * 4 < nbytes or self._ws.device != dev:
             self._ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=dev)
         fused = Cd == 256 and self.num_samples == 64          # the library's fused path can write (B, V, C, h, w) directly
@@ -107,19 +125,32 @@ class AddRayPE(nn.Module):
                                    self.min_depth, self.max_depth, self.num_samples, B, V, h, w, Cd, _lib.ptr(features),
                                    _lib.ptr(out), int(nchw), _lib.ptr(self._ws), self._ws.numel() * 4, _lib.stream_ptr()),
                    "parq_ray_pe")
+        self._ws._parq_gen = self._gen
         return out, (B, V, h, w), nchw
 
-    @torch.no_grad()
+    def _needs_graph(self, features=None):
+        return torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())
+                                            or bool(getattr(features, "requires_grad", False)))
+
     def forward(self, images_feat, camera=None, T_camera_pseudoCam=None, T_world_pseudoCam=None, T_world_local=None):
-        """The encoding (B, T, C, H, W), as the reference returns it (images_feat only supplies the shape)."""
+        """The encoding (B, T, C, H, W), as the reference returns it (images_feat only supplies the shape).  With gradients
+        enabled and an encoder parameter that requires grad the result carries a graph, as the reference's does
+        (model/ray_positional_encoding.py:128-136): the same autograd node as ``tokens`` on zero feature maps."""
         hw = tuple(images_feat.shape[-2:])
-        enc, (B, V, h, w), nchw = self._run(camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, hw, None, nchw=True)
-        return enc if nchw else enc.view(B, V, h, w, self.dim_out).permute(0, 1, 4, 2, 3)
+        if self._needs_graph():
+            B, V = raw(camera).shape[:2]
+            zeros = torch.zeros(B, V, self.dim_out, hw[0], hw[1], dtype=torch.float32, device=raw(camera).device)
+            tok = self.tokens(zeros, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local)
+            return tok.view(B, V, hw[0], hw[1], self.dim_out).permute(0, 1, 4, 2, 3)
+        with torch.no_grad():
+            enc, (B, V, h, w), nchw = self._run(camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, hw, None, nchw=True)
+            return enc if nchw else enc.view(B, V, h, w, self.dim_out).permute(0, 1, 4, 2, 3)
 
     def tokens(self, images_feat, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local):
-        """features + encoding, tokenised channels-last (B, T*H*W, C) in one pass.  In train mode under autograd the call is
-        an autograd node (one outstanding forward per module: its workspace holds the hidden layer for the backward)."""
-        if torch.is_grad_enabled() and self.training:
+        """features + encoding, tokenised channels-last (B, T*H*W, C) in one pass.  With gradients enabled and anything to
+        differentiate (train mode, an encoder parameter or the feature maps requiring grad — eval mode included, like the
+        reference) the call is an autograd node that owns the workspace holding the hidden layer for its backward."""
+        if self._needs_graph(images_feat):
             e0, e2 = self.encoder[0], self.encoder[2]
             return _RayPeFn.apply(self, images_feat, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local,
                                   e0.weight, e0.bias, e2.weight, e2.bias)

@@ -60,3 +60,42 @@ def compare(out, z, k, tol, what=""):
     bad = {k2: v for k2, v in worst.items() if not v <= tol}
     assert not bad, "%s iteration %d exceeds %g: %s (all: %s)" % (what, k, tol, bad, worst)
     return worst
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# g17: gradients of the reference's own autograd (oracle/make_golden.py::make_grad_golden)
+
+def load_grads():
+    z = np.load(os.path.join(GOLDEN_DIR, "g17_grads.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    return meta, z
+
+
+def grad_names(z, tag, kind):
+    pre = "%s/%s/grad/" % (tag, kind)
+    return sorted({k[len(pre):].rsplit("/", 1)[0] for k in z.files if k.startswith(pre)})
+
+
+def grad_errors(z, tag, kind, name, g):
+    """(Frobenius-relative, max-relative) error of gradient tensor `g` against what the fixture keeps of the reference's:
+    the whole tensor, or its norm and every GRAD_STRIDE-th element."""
+    g = np.asarray(g, np.float64).reshape(-1)
+    pre = "%s/%s/grad/%s/" % (tag, kind, name)
+    if pre + "full" in z.files:
+        ref = z[pre + "full"]
+        d = g - ref
+        return np.linalg.norm(d) / max(np.linalg.norm(ref), 1e-300), np.abs(d).max() / max(np.abs(ref).max(), 1e-300)
+    ref = z[pre + "sample"]
+    d = g[::MG.GRAD_STRIDE] - ref
+    nrm = z[pre + "norm"]
+    fro = max(np.linalg.norm(d) / max(np.linalg.norm(ref), 1e-300), abs(np.linalg.norm(g) - nrm[0]) / max(nrm[0], 1e-300))
+    return fro, np.abs(d).max() / max(np.abs(ref).max(), 1e-300)
+
+
+def token_grad_errors(z, tag, kind, g):
+    g = np.asarray(g, np.float64).reshape(-1)
+    ref = z["%s/%s/dtokens/sample" % (tag, kind)]
+    d = g[::MG.TOKEN_STRIDE] - ref
+    nrm = z["%s/%s/dtokens/norm" % (tag, kind)]
+    fro = max(np.linalg.norm(d) / max(np.linalg.norm(ref), 1e-300), abs(np.linalg.norm(g) - nrm[0]) / max(nrm[0], 1e-300))
+    return fro, np.abs(d).max() / max(np.abs(ref).max(), 1e-300)

@@ -28,6 +28,13 @@ def scene_args(sc):
             dev(sc["T_world_local"]))
 
 
+def infer(dec, *args, **kw):
+    """An inference call the way the reference's drivers make it (eval.py:46: under torch.no_grad()).  Without no_grad an
+    eval-mode module whose parameters require grad builds a graph — like the reference — i.e. runs the training-forward kernels."""
+    with torch.no_grad():
+        return dec(*args, **kw)
+
+
 def to_np(out):
     return {k: v.detach().cpu().numpy() for k, v in out.items()}
 

@@ -402,30 +402,47 @@ def test_head_dim_256_training_split_forward_matches_fp32_path():
     assert float((res["split"][2] - res["fp32"][2]).norm()) / float(res["fp32"][2].norm()) < 1e-4
 
 
-def test_two_outstanding_training_forwards_are_refused_not_silently_wrong():
-    """The stash, dropout seed and outputs of a training forward live on the module: a second train-mode forward
-    before the first one's backward must make that backward raise instead of using the wrong activations; the sequential
-    form accumulates correctly."""
+def test_several_outstanding_forwards_each_own_their_activations():
+    """Every autograd node owns the saved activations of its forward (parq_amd/decoder.py _Stash): a second forward before the
+    first one's backward takes a workspace of its own, so (loss(dec(a)) + loss(dec(b))).backward() — gradient accumulation the
+    way a reference user may write it — gives the sum of the two separate gradients, with dropout masks of the right forward
+    (train mode, p = 0.1: a backward that regenerated the OTHER forward's masks would be off by tens of percent).  Once both
+    backwards have run the module is back to one training workspace.  Eval-mode forwards differentiate too (dropout off)."""
     B, V, h, w, Q, dim = 1, 2, 8, 10, 16, 128
-    cfg = synth.decoder_cfg(dim=dim, queries=Q, heads=2, ffn=96, layers=2, dropout=0.0)
+    cfg = synth.decoder_cfg(dim=dim, queries=Q, heads=2, ffn=96, layers=2, dropout=0.1)
     W = synth.make_decoder_weights(cfg, 181)
     dec = make_decoder(cfg, W).train()
     a = scene_args(synth.make_scene(182, B, V, h, w, dim, smooth=True))
     b = scene_args(synth.make_scene(183, B, V, h, w, dim, smooth=True))
     f = lambda outs: sum(o["center_unnormalized"].sum() + o["ortho6d"].sum() for o in outs)
+    torch.manual_seed(5)
     la, lb = f(dec(*a)), f(dec(*b))
-    with pytest.raises(RuntimeError, match="one outstanding forward"):
-        (la + lb).backward()
+    (la + lb).backward()
+    both = {n: p.grad.clone() for n, p in dec.named_parameters() if p.grad is not None}
     dec.zero_grad(set_to_none=True)
+    torch.manual_seed(5)                                           # the same two dropout seeds, one forward at a time
     f(dec(*a)).backward()
-    ga = {n: p.grad.clone() for n, p in dec.named_parameters() if p.grad is not None}
-    f(dec(*b)).backward()                                          # accumulates into .grad
-    dec2 = make_decoder(cfg, W).train()
-    f(dec2(*b)).backward()
-    for n, p in dec2.named_parameters():
+    f(dec(*b)).backward()
+    ws_before = dec._train_ws
+    for n, p in dec.named_parameters():
         if p.grad is not None and float(p.grad.norm()) > 0:
-            tot = dict(dec.named_parameters())[n].grad
-            assert float((tot - ga[n] - p.grad).norm()) <= 1e-4 * float(tot.norm()) + 1e-7, n
+            assert float((both[n] - p.grad).norm()) <= 1e-4 * float(p.grad.norm()) + 1e-7, n
+    f(dec(*a)).backward()
+    assert dec._train_ws is ws_before                              # consumed stashes are reused, not re-allocated
+    # eval mode under autograd: same graph, no dropout (the reference differentiates in eval mode, model/parq_decoder.py:134-163)
+    dec.eval()
+    dec.zero_grad(set_to_none=True)
+    outs = dec(*a)
+    assert outs[0]["ortho6d"].requires_grad
+    f(outs).backward()
+    g_eval = {n: p.grad.clone() for n, p in dec.named_parameters() if p.grad is not None}
+    outs2 = dec(*a)                                                # deterministic: no dropout in eval mode
+    assert torch.equal(outs[0]["ortho6d"].detach(), outs2[0]["ortho6d"].detach())
+    with torch.no_grad():
+        o_inf = dec(*a)                                            # the inference chain (folded position MLP): same numbers to rounding
+    assert not o_inf[0]["ortho6d"].requires_grad
+    assert float((o_inf[0]["ortho6d"] - outs[0]["ortho6d"].detach()).abs().max()) < 1e-4
+    assert len(g_eval) >= 30
     # weight writes that bypass the version counter need invalidate_weights()
     dec.eval()
     with torch.no_grad():

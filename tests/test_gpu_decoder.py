@@ -14,9 +14,19 @@ import torch
 from parq_amd import synth, Pose
 from oracle import parq_oracle as O
 import golden_util as G
-from gpu_util import dev, make_decoder, scene_args, to_np, rel_err
+from gpu_util import dev, infer, make_decoder, scene_args, to_np, rel_err
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _inference_like_the_reference_drivers():
+    """Every test of this file is an inference call: the reference's drivers make those under torch.no_grad() (eval.py:46,
+    Lightning's validation loop).  Without it an eval-mode module whose parameters require grad builds a graph, as the
+    reference's would — covered by tests/test_gpu_backward.py and tests/test_gpu_reference_pins.py."""
+    with torch.no_grad():
+        yield
+
 TOL = 1e-4
 
 
@@ -95,7 +105,7 @@ def test_golden_cfg1_forward_api():
     """BASELINE cfg 1 through the public forward(): one iteration from sigmoid(refpoint)."""
     case, z = G.load("g1_cfg1")
     cfg, W, sc = G.inputs(case)
-    outs = make_decoder(cfg, W)(*scene_args(sc))
+    outs = infer(make_decoder(cfg, W), *scene_args(sc))
     assert len(outs) == 1
     G.compare(to_np(outs[0]), z, 0, TOL, what="g1 forward")
 
@@ -103,7 +113,7 @@ def test_golden_cfg1_forward_api():
 def test_golden_free_running_damped():
     case, z = G.load("g3_damped")
     cfg, W, sc = G.inputs(case)
-    outs = make_decoder(cfg, W)(*scene_args(sc))
+    outs = infer(make_decoder(cfg, W), *scene_args(sc))
     assert len(outs) == 8
     for k, o in enumerate(outs):
         G.compare(to_np(o), z, k, TOL, what="g3 free-running")
@@ -131,7 +141,7 @@ def _cfg2_worst_error(mode, dim=256, heads=4, geom=(5, 120, 160), queries=128):
     dec = make_decoder(cfg, W)
     if mode is not None:
         dec.attention_mode = mode
-    outs = [to_np(o) for o in dec(*scene_args(sc))]
+    outs = [to_np(o) for o in infer(dec, *scene_args(sc))]
     od = O.OracleDecoder(cfg, W, synth.SCANNET_MEAN_SIZES, dtype=torch.float64)
     forced = [O.normalize(torch.from_numpy(o["coord_pos"]).double(), cfg.TRANSFORMER.SCALE) for o in outs]
     with torch.no_grad():
@@ -206,7 +216,7 @@ def test_ragged_shapes_vs_fp64_oracle(B, V, h, w, Q, heads, dim, ffn):
     W = synth.make_decoder_weights(cfg, 61)
     sc = synth.make_scene(62, B, V, h, w, dim, smooth=True)
     dec = make_decoder(cfg, W)
-    outs = [to_np(o) for o in dec(*scene_args(sc))]
+    outs = [to_np(o) for o in infer(dec, *scene_args(sc))]
     od = O.OracleDecoder(cfg, W, synth.SCANNET_MEAN_SIZES, dtype=torch.float64)
     forced = [O.normalize(torch.from_numpy(o["coord_pos"]).double(), cfg.TRANSFORMER.SCALE) for o in outs]
     with torch.no_grad():

@@ -113,7 +113,8 @@ def test_cfg3_forward_api_first_iteration_matches_golden(g14):
     """The public forward() at the headline size: iteration 0 starts from sigmoid(refpoint.weight) on both sides, so it needs no
     teacher forcing (later free-running iterations on white-noise features are chaotic in the reference itself: SURVEY.md App. D)."""
     cfg, W, sc, z, args = g14
-    outs = make_decoder(cfg, W)(*args, feat_hw=(FH, FW))
+    with torch.no_grad():
+        outs = make_decoder(cfg, W)(*args, feat_hw=(FH, FW))
     assert len(outs) == ITERS
     G.compare(to_np(outs[0]), z, 0, TOL, what="g14 forward()")
 

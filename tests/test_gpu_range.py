@@ -16,7 +16,7 @@ import torch
 
 from parq_amd import _lib, synth
 from oracle import parq_oracle as O
-from gpu_util import dev, lib, make_decoder, scene_args, sptr, to_np, rel_err
+from gpu_util import dev, infer, lib, make_decoder, scene_args, sptr, to_np, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -85,7 +85,7 @@ def _decoder_errors(fscale, wscale, mode, iters=2):
     dec = make_decoder(cfg, W)
     dec.attention_mode = mode
     dec.range_check = "off"
-    outs = [to_np(o) for o in dec(*scene_args(sc))]
+    outs = [to_np(o) for o in infer(dec, *scene_args(sc))]
     flagged = dec.fp16_range_exceeded()
     od = O.OracleDecoder(cfg, W, synth.SCANNET_MEAN_SIZES, dtype=torch.float64)
     forced = [O.normalize(torch.from_numpy(o["coord_pos"]).double(), cfg.TRANSFORMER.SCALE) for o in outs]
@@ -136,20 +136,20 @@ def test_out_of_range_features_are_not_silent_and_policies_recover():
     dec.range_check = "sync"
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")
-        outs = dec(*scene_args(sc))
+        outs = infer(dec, *scene_args(sc))
     assert dec.attention_mode == "fp32" and any("fp16 range" in str(r.message) for r in rec)
     # teacher-forced reference points came from the fp32-mode run of _decoder_errors; iteration 0 is free of forcing
     assert rel_err(outs[0]["pred_logits"].cpu().numpy(), want[0]["pred_logits"].numpy()) < max(1e-4, 2 * e_fp32)
 
     dec = make_decoder(cfg, W)
     assert dec.range_check == "lazy"
-    first = dec(*scene_args(sc))
+    first = infer(dec, *scene_args(sc))
     torch.cuda.synchronize()
     assert torch.isnan(first[0]["pred_logits"]).all() and torch.isnan(first[-1]["ortho6d"]).all()
     assert int(dec._range_mirror[0]) == 1                      # raised by the device, read without a stream sync
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")
-        second = dec(*scene_args(sc))
+        second = infer(dec, *scene_args(sc))
     assert dec.attention_mode == "fp32" and any("fp16 range" in str(r.message) for r in rec)
     assert torch.isfinite(second[0]["pred_logits"]).all()
     assert rel_err(second[0]["pred_logits"].cpu().numpy(), want[0]["pred_logits"].numpy()) < max(1e-4, 2 * e_fp32)
@@ -198,9 +198,9 @@ def test_product_library_ignores_probe_environment(tmp_path):
     code = (
         "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
         "import golden_util as G\n"
-        "from gpu_util import make_decoder, scene_args, to_np\n"
+        "from gpu_util import infer, make_decoder, scene_args, to_np\n"
         "case, z = G.load('g1_cfg1'); cfg, W, sc = G.inputs(case)\n"
-        "outs = make_decoder(cfg, W)(*scene_args(sc))\n"
+        "outs = infer(make_decoder(cfg, W), *scene_args(sc))\n"
         "print('worst', G.compare(to_np(outs[0]), z, 0, 1e-4, what='g1 under PARQ_* env'))\n"
     ) % (os.path.dirname(os.path.abspath(__file__)), os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     env = dict(os.environ, PARQ_FLASH_PROBE="2", PARQ_KVPROJ_PROBE="4", PARQ_CHAIN_MAX_M="0", PARQ_LINEAR_TILE="32")

@@ -48,7 +48,8 @@ def test_single_process_view_sharded_call_equals_forward():
     sc = synth.make_scene(96, 2, 3, 20, 24, 256, smooth=True)
     dec = make_decoder(cfg, W)
     a = scene_args(sc)
-    want = dec(*a, feat_hw=(20, 24))
+    with torch.no_grad():
+        want = dec(*a, feat_hw=(20, 24))
     got = dec.forward_view_sharded(*a, feat_hw=(20, 24))
     for k in range(3):
         for key in want[k]:

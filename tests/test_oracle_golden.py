@@ -41,6 +41,20 @@ def test_oracle_teacher_forced_baseline_cfg3_size():
         G.compare(o, z, k, tol=2e-5, what="g14_cfg3")
 
 
+@pytest.mark.parametrize("name,iters", [("g18_cfg3_smooth", 8), ("g19_cfg2", 4)])
+def test_oracle_teacher_forced_unrelaxed_fixtures(name, iters):
+    """The fixtures the GPU tier consumes at an unrelaxed 1e-4 (cfg 3's geometry on smooth features; cfg 2's exact geometry):
+    the oracle against the reference's vectors, and the fixture's own premise — the reference's fp32 run within 7e-5 of the
+    float64 evaluation of its algorithm on every (iteration, output)."""
+    z, outs = _run(name, False, forced=True)
+    assert len(outs) == iters
+    for k, o in enumerate(outs):
+        G.compare(o, z, k, tol=2e-5, what=name)
+    z, outs64 = _run(name, False, forced=True, dtype=torch.float64)
+    for k, o in enumerate(outs64):
+        G.compare(o, z, k, tol=7e-5, what=name + " reference fp32 vs float64")
+
+
 def test_oracle_teacher_forced_cfg5_shape():
     """BASELINE cfg 5's decoder shape (Q = 512: two query tiles per head, I = 12, 20 views) on small feature maps: the oracle
     against the golden captured from the reference."""

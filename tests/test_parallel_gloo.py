@@ -122,7 +122,19 @@ def _dp_worker(rank, world, port, q):
     cfg, W, sc = _case()
     lo, hi = parallel.shard_range(2, rank, world)                # 2 scenes, one per rank
     flat = _grad_flat(cfg, W, sc, lo, hi)
+    # the same gradient averaged in buckets, the way PARQDecoder.backward does it (bucket 0 = the part of the arena that is
+    # final after phase 1 of parq_backward, bucket 1 = the rest; include/parq_hip.h parq_grad_bucket): a ragged split with an
+    # empty bucket and an untouched tail, the `ready` hook called once per non-empty bucket in order
+    bucketed = flat.clone()
+    n = bucketed.numel()
+    cut, tail = n // 3 + 1, 5
+    calls = []
+    parallel.all_reduce_mean_buckets_(bucketed, [(cut, n - cut - tail), (0, 0), (0, cut)], ready=lambda i, stream: calls.append((i, stream)))
+    assert calls == [(0, None), (1, None)]
+    own_tail = flat[n - tail:].clone()
     parallel.all_reduce_mean_(flat)
+    assert torch.equal(bucketed[:n - tail], flat[:n - tail])             # bucketed == flat, bit for bit
+    assert torch.equal(bucketed[n - tail:], own_tail)                    # outside the buckets: untouched
     q.put((rank, flat.numpy()))
     parallel.barrier()
     torch.distributed.destroy_process_group()
@@ -165,3 +177,52 @@ def test_bench_gpus_n_self_launch_refuses_cleanly_without_enough_gpus():
                        capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode != 0
     assert "GPU(s) visible" in (r.stderr + r.stdout)
+
+
+# ---------------------------------------------------------------- host placement (NUMA-local cores per rank)
+def _fake_sysfs(root, gpus):
+    """A KFD topology + PCI tree like a two-socket, four-GPU host: node 0 / 1 are CPUs (simd_count 0), then the GPUs."""
+    os.makedirs(os.path.join(root, "class/kfd/kfd/topology/nodes/0"))
+    os.makedirs(os.path.join(root, "class/kfd/kfd/topology/nodes/1"))
+    for n in (0, 1):
+        with open(os.path.join(root, "class/kfd/kfd/topology/nodes/%d/properties" % n), "w") as f:
+            f.write("cpu_cores_count 16\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+    for i, (bus, cpulist) in enumerate(gpus):
+        d = os.path.join(root, "class/kfd/kfd/topology/nodes/%d" % (i + 2))
+        os.makedirs(d)
+        with open(os.path.join(d, "properties"), "w") as f:
+            f.write("cpu_cores_count 0\nsimd_count 1024\nlocation_id %d\ndomain 0\n" % (bus << 8))
+        p = os.path.join(root, "bus/pci/devices/0000:%02x:00.0" % bus)
+        os.makedirs(p)
+        with open(os.path.join(p, "local_cpulist"), "w") as f:
+            f.write(cpulist + "\n")
+
+
+def test_ranks_pin_to_the_cores_next_to_their_gpu(tmp_path):
+    root = str(tmp_path)
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 4:
+        pytest.skip("needs 4 allowed CPUs")
+    a, b = allowed[:len(allowed) // 2], allowed[len(allowed) // 2:]
+    fmt = lambda cpus: ",".join(str(c) for c in cpus)
+    _fake_sysfs(root, [(0x05, fmt(a)), (0x15, fmt(a)), (0x65, fmt(b)), (0x75, fmt(b))])
+    assert parallel.gpu_local_cpus(0, root, visible="") == a and parallel.gpu_local_cpus(3, root, visible="") == b
+    assert parallel.gpu_local_cpus(0, root, visible="2,3") == b           # HIP_VISIBLE_DEVICES remaps the ordinals
+    assert parallel.gpu_local_cpus(7, root, visible="") == []             # no such device: leave the mask alone
+    assert parallel._parse_cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11]
+    before = os.sched_getaffinity(0)
+    try:
+        os.environ.pop("HIP_VISIBLE_DEVICES", None); os.environ.pop("ROCR_VISIBLE_DEVICES", None)
+        got = [None] * 4
+        for r in range(4):
+            os.sched_setaffinity(0, before)
+            got[r] = parallel.pin_to_local_cores(r, 4, sysfs=root)
+            assert set(os.sched_getaffinity(0)) == set(got[r])
+        # ranks 0, 1 share socket A and split it; ranks 2, 3 split socket B: disjoint, local, complete
+        assert set(got[0]) | set(got[1]) == set(a) and not set(got[0]) & set(got[1])
+        assert set(got[2]) | set(got[3]) == set(b) and not set(got[2]) & set(got[3])
+        os.sched_setaffinity(0, before)
+        assert parallel.pin_to_local_cores(0, 4, sysfs=os.path.join(root, "nothing-here")) == []      # no topology: untouched
+        assert os.sched_getaffinity(0) == before
+    finally:
+        os.sched_setaffinity(0, before)

@@ -40,7 +40,8 @@ def main(out_path):
                  to(sc["T_world_local"]))
         full = (to(sc["tokens"]), to(sc["camera"]), to(sc["T_camera_pseudoCam"]), to(sc["T_world_pseudoCam"]), to(sc["T_world_local"]))
         dec = make_decoder(cfg, W)
-        want = dec(*full, feat_hw=(h, w))                                       # single process, all views (every rank computes it)
+        with torch.no_grad():
+            want = dec(*full, feat_hw=(h, w))                                       # single process, all views (every rank computes it)
         got = dec.forward_view_sharded(*local, feat_hw=(h, w))                 # free-running, sharded
         lo_s, hi_s = np.asarray(cfg.TRANSFORMER.SCALE[0::2], np.float32), np.asarray(cfg.TRANSFORMER.SCALE[1::2], np.float32)
         forced = [torch.from_numpy((o["coord_pos"].cpu().numpy() - lo_s) / (hi_s - lo_s)) for o in want]
