@@ -253,15 +253,21 @@ int parq_set_backward_streams(parq_handle h, int32_t n);
  * plus, when features_nchw (B, V, C, h, w) is given, the feature maps (the `+` and the einops
  * rearrange of parq_lightning.py:75-85).  w1 (C, 3*num_samples), b1 (C), w2 (C, C), b2 (C) are
  * AddRayPE.encoder.{0,2}.{weight,bias}; scale6_host = RAY_POINTS_SCALE (host pointer).
- * nchw_out != 0 writes the result as (B, V, C, h, w) instead (what AddRayPE.forward returns); available on the
- * fused path (C = 256, 64 samples: operand tile generated in-kernel, two persistent W-stationary kernels).
- * Requires (3*num_samples) % 64 == 0 and C % 64 == 0 (shipped: 64 samples, C = 1024 or 256). */
-size_t parq_ray_pe_workspace_bytes(int32_t B, int32_t V, int32_t hh, int32_t ww, int32_t C, int32_t num_samples);
+ * flags: PARQ_RAYPE_NCHW_OUT writes the result as (B, V, C, h, w) instead (what AddRayPE.forward returns); available on the
+ * one-pass path (C = 256, 64 samples: ONE persistent kernel generates the operand tile, keeps the 64-token hidden tile in LDS
+ * between the two layers and adds the feature maps — the hidden tensor is never written).  PARQ_RAYPE_NO_HIDDEN (inference):
+ * the fp32 hidden layer that parq_ray_pe_backward reads from the forward's workspace is not kept either, and the workspace is
+ * smaller by B*V*h*w*C floats (parq_ray_pe_workspace_bytes_flags; ignored off the one-pass path, which needs the tensor as an
+ * intermediate).  Requires (3*num_samples) % 64 == 0 and C % 64 == 0 (shipped: 64 samples, C = 1024 or 256). */
+enum { PARQ_RAYPE_NCHW_OUT = 1, PARQ_RAYPE_NO_HIDDEN = 2 };
+size_t parq_ray_pe_workspace_bytes(int32_t B, int32_t V, int32_t hh, int32_t ww, int32_t C, int32_t num_samples);   /* flags = 0 */
+size_t parq_ray_pe_workspace_bytes_flags(int32_t B, int32_t V, int32_t hh, int32_t ww, int32_t C, int32_t num_samples,
+                                         int32_t flags);
 int parq_ray_pe(const float *camera, const float *T_camera_pseudoCam, const float *T_world_pseudoCam,
                 const float *T_world_local, const float *w1, const float *b1, const float *w2, const float *b2,
                 const float *scale6_host, float min_depth, float max_depth, int32_t num_samples, int32_t B,
                 int32_t V, int32_t hh, int32_t ww, int32_t C, const float *features_nchw, float *tokens_out,
-                int32_t nchw_out, void *workspace, size_t workspace_bytes, parq_stream stream);
+                int32_t flags, void *workspace, size_t workspace_bytes, parq_stream stream);
 
 /* Backward of the encoding + tokenisation (training): given d loss / d tokens (B, V*h*w, C) it returns the gradients of
  * encoder.{0,2}.{weight,bias} and, optionally, d loss / d features (B, V, C, h, w).  `fwd_workspace` is the workspace the

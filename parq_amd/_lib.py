@@ -79,6 +79,7 @@ SYMBOLS = {
     "parq_backward_wait_bucket": (C.c_int, [_vp, _i32, _vp]),
     "parq_set_backward_streams": (C.c_int, [_vp, _i32]),
     "parq_ray_pe_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    "parq_ray_pe_workspace_bytes_flags": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "parq_ray_pe": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_f), _f, _f, _i32, _i32, _i32, _i32, _i32, _i32,
                               _vp, _vp, _i32, _vp, _sz, _vp]),
     "parq_ray_pe_backward_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32]),

@@ -533,7 +533,10 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         Prof p(c, s, PARQ_PROF_CROSS_ATTN);
         fa.q = wi + ws.qc; fa.q_batch = (int64_t)Q * C; fa.q_head = dh; fa.q_row = C;
         fa.Lk = (int)N; fa.nsplit = ws.cross_split;
-        fa.flags = (layer_num & 1) ? 2 : 0;             // odd iterations sweep the K/V cache backwards (Infinity Cache reuse)
+        // odd iterations sweep the K/V cache backwards (Infinity Cache reuse); development: PARQ_FLASH_ALT_PHASE=1 flips the parity,
+        // so that iteration 0 starts on the blocks the K/V projection wrote last
+        const int alt_phase = [] { const char* e = dev_env("PARQ_FLASH_ALT_PHASE"); return e && e[0] == '1' ? 1 : 0; }();
+        fa.flags = ((layer_num + alt_phase) & 1) ? 2 : 0;
         const int64_t lp = flash_lq_pad(Q);
         fa.o_part = wsp + ws.flash;
         fa.m_part = fa.o_part + (int64_t)B * H * fa.nsplit * dh * lp;
@@ -1686,46 +1689,61 @@ int parq_k_attention_half(const float* q, const float* k, const float* v, float*
 // ------------------------------------------------------------------ AddRayPE + tokenisation
 static int64_t raype_align(int64_t x) { return (x + 63) / 64 * 64; }
 
-size_t parq_ray_pe_workspace_bytes(int32_t B, int32_t V, int32_t hh, int32_t ww, int32_t C, int32_t num_samples) {
+// Workspace layout: [hidden [M][C] — only when the hidden layer is kept] | W1 hi/lo (C*K1 halfs each) | W2 hi/lo (C*C halfs each)
+// | W2 in fragment order (one-pass path) | pose + depth tables (float64) | points [M][K1] (generic path only).
+// The hidden layer is kept (first region: parq_ray_pe_backward reads it there) unless the caller passes PARQ_RAYPE_NO_HIDDEN on
+// the one-pass path (C = 256, 64 samples), where it never leaves the CU; the generic path needs it as an intermediate.
+static bool raype_keeps_hidden(int32_t C, int32_t num_samples, int32_t flags) {
+    return !((flags & PARQ_RAYPE_NO_HIDDEN) && C == 256 && num_samples == 64);
+}
+size_t parq_ray_pe_workspace_bytes_flags(int32_t B, int32_t V, int32_t hh, int32_t ww, int32_t C, int32_t num_samples, int32_t flags) {
     if (B < 1 || V < 1 || hh < 1 || ww < 1 || C < 1 || num_samples < 1) return 0;
     const int64_t M = (int64_t)B * V * hh * ww, K1 = 3 * (int64_t)num_samples;
-    // hidden [M][C] | W1 hi/lo (C*K1 halfs each) | W2 hi/lo (C*C halfs each) | pose + depth tables (float64)
-    // | points [M][K1] (generic path only: C != 256 or num_samples != 64)
     const bool fused = (C == 256 && num_samples == 64);
-    const int64_t floats = raype_align(M * C) + raype_align(C * K1) + raype_align((int64_t)C * C) +
-                           raype_align(2 * ((int64_t)B * V * 12 + num_samples)) + (fused ? 0 : raype_align(M * K1));
+    const int64_t floats = (raype_keeps_hidden(C, num_samples, flags) ? raype_align(M * C) : 0) + raype_align(C * K1) +
+                           2 * raype_align((int64_t)C * C) + raype_align(2 * ((int64_t)B * V * 12 + num_samples)) +
+                           (fused ? 0 : raype_align(M * K1));
     return (size_t)floats * sizeof(float);
+}
+size_t parq_ray_pe_workspace_bytes(int32_t B, int32_t V, int32_t hh, int32_t ww, int32_t C, int32_t num_samples) {
+    return parq_ray_pe_workspace_bytes_flags(B, V, hh, ww, C, num_samples, 0);
 }
 
 int parq_ray_pe(const float* camera, const float* T_cp, const float* T_wp, const float* T_wl, const float* w1,
                 const float* b1, const float* w2, const float* b2, const float* scale6_host, float min_depth,
                 float max_depth, int32_t num_samples, int32_t B, int32_t V, int32_t hh, int32_t ww, int32_t C,
-                const float* features_nchw, float* tokens_out, int32_t nchw_out, void* workspace, size_t workspace_bytes,
+                const float* features_nchw, float* tokens_out, int32_t flags, void* workspace, size_t workspace_bytes,
                 parq_stream stream) {
+    const int32_t nchw_out = flags & PARQ_RAYPE_NCHW_OUT;
     if (!camera || !T_cp || !T_wp || !T_wl || !w1 || !b1 || !w2 || !b2 || !scale6_host || !tokens_out || !workspace)
         return fail(PARQ_ERR_ARG, "NULL argument");
     if (B < 1 || V < 1 || hh < 1 || ww < 1 || num_samples < 1) return fail(PARQ_ERR_ARG, "bad dims");
     if ((3 * num_samples) % 64 != 0 || C % 64 != 0) return fail(PARQ_ERR_ARG, "3*num_samples and C must be multiples of 64");
     if (!(max_depth > min_depth && min_depth > 0.f)) return fail(PARQ_ERR_ARG, "need 0 < min_depth < max_depth");
-    if (workspace_bytes < parq_ray_pe_workspace_bytes(B, V, hh, ww, C, num_samples)) return fail(PARQ_ERR_WORKSPACE, "ray-PE workspace too small");
+    if (workspace_bytes < parq_ray_pe_workspace_bytes_flags(B, V, hh, ww, C, num_samples, flags)) return fail(PARQ_ERR_WORKSPACE, "ray-PE workspace too small");
     const int64_t M64 = (int64_t)B * V * hh * ww;
     if (M64 > INT32_MAX) return fail(PARQ_ERR_ARG, "too many tokens");
     const int M = (int)M64, K1 = 3 * num_samples;
     hipStream_t s = (hipStream_t)stream;
     float* wsp = (float*)workspace;
-    float* Hd = wsp;
-    float* W1s = Hd + raype_align((int64_t)M * C);
+    const bool keep = raype_keeps_hidden(C, num_samples, flags);
+    float* Hd = keep ? wsp : nullptr;
+    float* W1s = wsp + (keep ? raype_align((int64_t)M * C) : 0);
     float* W2s = W1s + raype_align((int64_t)C * K1);
-    double* tabs = reinterpret_cast<double*>(W2s + raype_align((int64_t)C * C));
+    float* W2f = W2s + raype_align((int64_t)C * C);
+    double* tabs = reinterpret_cast<double*>(W2f + raype_align((int64_t)C * C));
     float* P = reinterpret_cast<float*>(tabs) + raype_align(2 * ((int64_t)B * V * 12 + num_samples));
     char* w1hi = (char*)W1s; char* w1lo = w1hi + (size_t)C * K1 * 2;
     char* w2hi = (char*)W2s; char* w2lo = w2hi + (size_t)C * C * 2;
     HIPCHK(launch_split_f32(w1, w1hi, w1lo, (int64_t)C * K1, s));
     HIPCHK(launch_split_f32(w2, w2hi, w2lo, (int64_t)C * C, s));
     if (C == 256 && num_samples == 64) {
+        // development: PARQ_RAYPE_TWO_KERNELS=1 runs the round-1 form (hidden tensor written and re-read) for A/B
+        static const int two = [] { const char* e = dev_env("PARQ_RAYPE_TWO_KERNELS"); return e && e[0] == '1' ? 1 : 0; }();
+        if (two && !Hd) return fail(PARQ_ERR_ARG, "the two-kernel form needs the hidden region (do not pass the no-hidden flag)");
         HIPCHK(launch_raype_fused(camera, T_cp, T_wp, T_wl, scale6_host, min_depth, max_depth, B, V, hh, ww, w1hi, w1lo, b1,
                                   w2hi, w2lo, b2, features_nchw, Hd, tabs, tabs + (int64_t)B * V * 12, tokens_out,
-                                  nchw_out ? 1 : 0, s));
+                                  nchw_out ? 1 : 0, s, W2f, two));
         return PARQ_OK;
     }
     if (nchw_out) return fail(PARQ_ERR_ARG, "NCHW output needs the fused path (C = 256, 64 samples)");

@@ -363,7 +363,8 @@ hipError_t launch_raype_points(const float* cam, const float* T_cp, const float*
 hipError_t launch_raype_fused(const float* cam, const float* T_cp, const float* T_wp, const float* T_wl, const float* scale6,
                               float min_depth, float max_depth, int B, int V, int h, int w, const void* W1hi, const void* W1lo,
                               const float* b1, const void* W2hi, const void* W2lo, const float* b2, const float* feat,
-                              float* hidden, double* Tl, double* depth, float* out, int nchw_out, hipStream_t s);
+                              float* hidden, double* Tl, double* depth, float* out, int nchw_out, hipStream_t s,
+                              void* W2f = nullptr, int two_kernels = 0);
 // GroupNorm(1, C) statistics from the float64 moments (sum, sum of squares) of a group, all in float64 (the variance is a difference
 // of two nearly equal numbers) with one reciprocal of the element count.  Used by the forward consumers and by the backward that
 // re-normalises from the same moments.  (An fp32 reciprocal square root was measured: the consumers' times did not move — the

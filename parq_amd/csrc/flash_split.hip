@@ -45,6 +45,7 @@ struct Blk {
 constexpr int kStageBlks = 2;                       // 64 keys per LDS stage
 constexpr int kNW = 8;                              // waves per workgroup (32 queries each)
 constexpr float kDeferLog2 = 10.f;                  // running max moves only past this margin (log2 domain)
+constexpr int kFlashVar = 27;                       // step variant of the product build (flash_split_pipe_kernel VAR: 1 + 2 + 8 + 16; profiles/r04_flash_variants.txt)
 
 __device__ __forceinline__ int dmap(int kh, int s, int e) {
     return 32 * (s >> 1) + 16 * (s & 1) + 4 * kh + (e & 3) + 8 * (e >> 2);
@@ -216,7 +217,19 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 // DROP: training-time dropout on the probabilities (counter-based keep mask of FlashArgs::drop_seed, common.hpp): the column hashes
 // of a block's 32 keys are computed once per wave (lane = key) into a wave-private LDS strip behind the ring and read back as
 // four 16-byte groups; the normaliser stays undropped, 1 / (1 - p) is applied once to the partial output.
-template <int RING, int PROBE = 0, int TERMS = 3, int KIND = kF16, bool DROP = false>
+// VAR (round 4; bit mask, A/B'd on one box: profiles/r04_flash_variants.txt):
+//   1  step tail: the rare "reference moves" test is per lane (any lane's own 16 scores past the threshold — the same condition
+//      as the cross-half maximum past it: no v_permlane32_swap on the fast path), and the rare path no longer flushes the
+//      pending PV of the previous block (four LDS reads + 12 MFMAs under the branch, after which hipcc began EVERY step with
+//      s_waitcnt lgkmcnt(0) over all twelve fragment reads of the tail): it rescales l, moves the new scores and leaves the
+//      factor for the O^T accumulators PENDING; the next step applies it after its PV MFMAs have added that block
+//      ((O + P V) * alpha, the same value the flush produced)
+//   2  K fragments s = 0, 1 of the next step requested in the middle of the step (their registers are dead after the sixth
+//      QK MFMA) instead of at its end
+//   8  bare s_barrier between the stages (see sync_point)
+//   4  row sums with plain v_add_f32 (hipcc SLP-packs the sixteen adds of a step into v_pk_add_f32, which the guide prices
+//      above two plain adds beside MFMAs)
+template <int RING, int PROBE = 0, int TERMS = 3, int KIND = kF16, bool DROP = false, int VAR = 0>
 __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a, const _Float16* __restrict__ cache) {
     PARQ_TL_KERNEL(kTlFlashSplit);
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];       // [RING stages][kStageBlks][block]
@@ -231,7 +244,9 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
     const int split = blockIdx.x;
     const int bh = blockIdx.z;
     const int b = bh / a.H, h = bh - b * a.H;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // VAR & 16: the wave index as a scalar (readfirstlane): `active` and everything derived from it become scalar branches instead
+    // of exec-masked regions, around which hipcc merges the LDS / VMEM counters conservatively
+    const int tid = threadIdx.x, lane = tid & 63, wave = (VAR & 16) ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
     const int li = lane & 31, kh = lane >> 5;
     const int q0 = (blockIdx.y * kNW + wave) * 32;
     const int q = q0 + li;
@@ -303,7 +318,13 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
         if constexpr (!(PROBE & 8)) {
             if (AHEAD >= 2 && t_begin + j + 3 < t_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            // VAR & 8: the bare barrier.  __syncthreads() carries a workgroup fence, i.e. s_waitcnt lgkmcnt(0): the twelve fragment
+            // reads the step in front of it has just issued (slots of stages j and j + 1 — not the slot the DMA below refills)
+            // would be drained by every wave at the same moment.  What the barrier must order is covered without the fence: a
+            // wave's own DMA by the vmcnt wait above, the last reads of the refilled slot (V of block 2 j - 1, consumed by MFMAs
+            // a step ago) by program order.
+            if constexpr ((VAR & 8) != 0) __builtin_amdgcn_s_barrier();
+            else __syncthreads();
         }
         if (t_begin + j + RING - 1 < t_end) gload(src_stage(j + RING - 1), (j + RING - 1) % RING);
     };
@@ -319,6 +340,8 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
 #pragma unroll
         for (int m = 0; m < 2; ++m) { Phi[c][m] = half8{0, 0, 0, 0, 0, 0, 0, 0}; Plo[c][m] = Phi[c][m]; }
     float m_run = 0.f, l_run = 0.f, l_a = 0.f, l_b = 0.f;                  // row sum = l_run + l_a + l_b (two chains in the steady state)
+    float alpha_pend = 1.f;                                                // VAR & 1: factor the O^T accumulators still owe to a moved reference
+    bool pend = false;                                                     // (wave-uniform) alpha_pend is to be applied after the running PV
     // -m_run in 16 registers: the C operand of the first QK MFMA of every block, so the scores leave the matrix pipe already relative
     // to the running maximum (saves a v_sub per score); rewritten only when the reference moves
     f32x16 negm16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -333,6 +356,17 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+            const int pos = (4 * kh + s) ^ ksw;
+            kf[2 * s] = *reinterpret_cast<const half8*>(Kb + li * 64 + pos * 8);
+            if constexpr (TERMS == 3) kf[2 * s + 1] = *reinterpret_cast<const half8*>(Kb + Blk<3>::k_lo + li * 64 + pos * 8);
+        }
+    };
+    // chunks s = S0 .. S0 + 1 only (kf[2 S0] .. kf[2 S0 + 3])
+    auto load_k_pair = [&](const _Float16* Kb, half8 (&kf)[8], auto s0) {
+        constexpr int S0 = decltype(s0)::value;
+        if constexpr (PROBE & 16) return;
+#pragma unroll
+        for (int s = S0; s < S0 + 2; ++s) {
             const int pos = (4 * kh + s) ^ ksw;
             kf[2 * s] = *reinterpret_cast<const half8*>(Kb + li * 64 + pos * 8);
             if constexpr (TERMS == 3) kf[2 * s + 1] = *reinterpret_cast<const half8*>(Kb + Blk<3>::k_lo + li * 64 + pos * 8);
@@ -421,6 +455,29 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
         for (int r = 0; r < 16; ++r) { sacc[NXT][r] -= d; negm16[r] = -m_run; }     // the scores of block n + 1 move to the new reference
     };
 
+    // VAR & 1 forms of the two halves of move_reference: no LDS traffic, no MFMAs
+    auto apply_pending = [&]() {                                           // O^T now holds every block the old reference covered
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dd][r] *= alpha_pend;
+        alpha_pend = 1.f;
+        pend = false;
+    };
+    auto move_reference_lazy = [&](auto cur, float mx) {
+        constexpr int CUR = decltype(cur)::value, NXT = CUR ^ 1;
+        const float d = mx > a.defer_log2 ? mx : 0.f;
+        const float alpha = __builtin_amdgcn_exp2f(-d);
+        m_run += d;
+        l_run *= alpha;                                                    // the row sums already hold the block whose PV is pending
+        l_a *= alpha;
+        l_b *= alpha;
+        alpha_pend = alpha;
+        pend = true;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[NXT][r] -= d; negm16[r] = -m_run; }
+    };
+
     // one softmax PAIR: elements (2 j, 2 j + 1) of accumulator half m = j / 4 -> one packed hi and one packed lo word of P[CUR][m]
     // (10 VALU: 2 sub, 2 exp, 2 add, cvt_pkrtz, 2 fma_mix, cvt_pkrtz; 8 pairs per block).  Two partial row sums keep the add chain short.
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -429,8 +486,13 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
         constexpr int CUR = decltype(cur)::value, J = decltype(jj)::value, M = J >> 2, W = J & 3;
         float p0 = __builtin_amdgcn_exp2f(sacc[CUR][2 * J]);                 // the accumulator holds score - m_run
         float p1 = __builtin_amdgcn_exp2f(sacc[CUR][2 * J + 1]);
-        l_a += p0;
-        l_b += p1;
+        if constexpr (VAR & 4) {
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_a) : "v"(p0));
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_b) : "v"(p1));
+        } else {
+            l_a += p0;
+            l_b += p1;
+        }
         if constexpr (DROP) {                                                // the normaliser above stays undropped
             p0 = drop_keep_h(dbase, drop_regpart(2 * J), drop_thr) ? p0 : 0.f;
             p1 = drop_keep_h(dbase, drop_regpart(2 * J + 1), drop_thr) ? p1 : 0.f;
@@ -456,6 +518,32 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
             Phi[CUR][M] = __builtin_bit_cast(half8, h4);
         }
     };
+    // VAR & 32: a pair in two halves behind consecutive MFMAs (a: the two exponentials and the hi word, b: the lo word and the row
+    // sums), at most four vector instructions per MFMA gap instead of eight behind every third MFMA
+    float sp0 = 0.f, sp1 = 0.f;
+    half2v shi = {(_Float16)0.f, (_Float16)0.f};
+    auto sm_pair_a = [&](auto cur, auto jj) {
+        constexpr int CUR = decltype(cur)::value, J = decltype(jj)::value, M = J >> 2, W = J & 3;
+        sp0 = __builtin_amdgcn_exp2f(sacc[CUR][2 * J]);
+        sp1 = __builtin_amdgcn_exp2f(sacc[CUR][2 * J + 1]);
+        shi = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(sp0, sp1));
+        u32x4 h4 = __builtin_bit_cast(u32x4, Phi[CUR][M]);
+        h4[W] = __builtin_bit_cast(unsigned int, shi);
+        Phi[CUR][M] = __builtin_bit_cast(half8, h4);
+    };
+    auto sm_pair_b = [&](auto cur, auto jj) {
+        constexpr int CUR = decltype(cur)::value, J = decltype(jj)::value, M = J >> 2, W = J & 3;
+        l_a += sp0;
+        l_b += sp1;
+        float d0, d1;                                                     // p - hi as in split_pair (common.hpp): one mixed fma each, exact
+        const unsigned int hp = __builtin_bit_cast(unsigned int, shi);
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(hp), "v"(sp0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(hp), "v"(sp1));
+        const half2v lo = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(d0, d1));
+        u32x4 l4 = __builtin_bit_cast(u32x4, Plo[CUR][M]);
+        l4[W] = __builtin_bit_cast(unsigned int, lo);
+        Plo[CUR][M] = __builtin_bit_cast(half8, l4);
+    };
 #define PARQ_FENCE() __builtin_amdgcn_sched_barrier(0)
     // one pipelined step: QK(n + 1) -> sacc[NXT], softmax(n) from sacc[CUR] -> P[CUR], PV(n - 1) with P[NXT].  The order below IS the
     // issue order (scheduling fences between the pieces): every MFMA is followed by at most one softmax pair, S^T and O^T
@@ -471,7 +559,48 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
 #define PARQ_Q(i, A, Bq) if constexpr (!(PROBE & 4)) sacc[NXT] = mfma16<KIND>(A, Bq, (i) == 0 ? negm16 : sacc[NXT]); PARQ_FENCE()
 #define PARQ_P(D, A, Bp) if constexpr (!(PROBE & 2)) o[D] = mfma16<KIND>(A, Bp, o[D]); PARQ_FENCE()
 #define PARQ_S(J) sm_pair(IC{}, std::integral_constant<int, J>{}); PARQ_FENCE()
-        if constexpr (TERMS == 3) {
+#define PARQ_SA(J) sm_pair_a(IC{}, std::integral_constant<int, J>{}); PARQ_FENCE()
+#define PARQ_SB(J) sm_pair_b(IC{}, std::integral_constant<int, J>{}); PARQ_FENCE()
+        if constexpr (TERMS == 3 && (VAR & 32) != 0 && !DROP && !(PROBE & 1)) {
+        // the same 24 MFMAs, every softmax pair in two halves behind consecutive MFMAs
+        PARQ_Q(0, kf[0], qhi[0]);
+        PARQ_P(0, vh[0], Phi[NXT][0]);  PARQ_SA(0);
+        PARQ_Q(1, kf[0], qlo[0]);  PARQ_SB(0);
+        PARQ_P(1, vh[1], Phi[NXT][0]);
+        PARQ_Q(2, kf[1], qhi[0]);  PARQ_SA(1);
+        PARQ_P(0, vl[0], Phi[NXT][0]);  PARQ_SB(1);
+        PARQ_Q(3, kf[2], qhi[1]);
+        PARQ_P(1, vl[1], Phi[NXT][0]);  PARQ_SA(2);
+        PARQ_Q(4, kf[2], qlo[1]);  PARQ_SB(2);
+        PARQ_P(0, vh[0], Plo[NXT][0]);
+        PARQ_Q(5, kf[3], qhi[1]);  PARQ_SA(3);
+        PARQ_P(1, vh[1], Plo[NXT][0]);  PARQ_SB(3);
+        load_v(Vb, 1, vh, vl);
+        if constexpr ((VAR & 2) != 0) load_k_pair(lds_blk(n + 2 < nbk ? n + 2 : nbk - 1), kf, std::integral_constant<int, 0>{});
+        PARQ_FENCE();
+        PARQ_Q(6, kf[4], qhi[2]);
+        PARQ_Q(7, kf[4], qlo[2]);  PARQ_SA(4);
+        PARQ_Q(8, kf[5], qhi[2]);  PARQ_SB(4);
+        PARQ_P(0, vh[0], Phi[NXT][1]);
+        PARQ_Q(9, kf[6], qhi[3]);  PARQ_SA(5);
+        PARQ_P(1, vh[1], Phi[NXT][1]);  PARQ_SB(5);
+        PARQ_Q(10, kf[6], qlo[3]);
+        PARQ_P(0, vl[0], Phi[NXT][1]);  PARQ_SA(6);
+        PARQ_Q(11, kf[7], qhi[3]);  PARQ_SB(6);
+        PARQ_P(1, vl[1], Phi[NXT][1]);  PARQ_SA(7);
+        PARQ_P(0, vh[0], Plo[NXT][1]);  PARQ_SB(7);
+        float mx_lane;
+        {
+            const f32x16& S = sacc[NXT];
+            float m0 = fmaxf(S[0], S[1]), m1 = fmaxf(S[8], S[9]);
+#pragma unroll
+            for (int r = 2; r < 8; ++r) { m0 = fmaxf(m0, S[r]); m1 = fmaxf(m1, S[8 + r]); }
+            mx_lane = fmaxf(m0, m1);
+        }
+        PARQ_FENCE();
+        PARQ_P(1, vh[1], Plo[NXT][1]);
+        mx_lane_out = mx_lane;
+        } else if constexpr (TERMS == 3) {
         // m = 0 half of PV(n - 1), s = 0, 1 of QK(n + 1); 8 softmax pairs (16 scores per lane and block), one behind every third MFMA
         PARQ_Q(0, kf[0], qhi[0]);
         PARQ_P(0, vh[0], Phi[NXT][0]);  PARQ_S(0);
@@ -486,6 +615,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
         PARQ_Q(5, kf[3], qhi[1]);  PARQ_S(3);
         PARQ_P(1, vh[1], Plo[NXT][0]);
         load_v(Vb, 1, vh, vl);                                            // m = 1 fragments (the m = 0 registers are free now)
+        if constexpr ((VAR & 2) != 0) load_k_pair(lds_blk(n + 2 < nbk ? n + 2 : nbk - 1), kf, std::integral_constant<int, 0>{});   // kf[0..3] are dead
         PARQ_FENCE();
         // m = 1 half, s = 2, 3
         PARQ_Q(6, kf[4], qhi[2]);
@@ -538,12 +668,29 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
 #undef PARQ_Q
 #undef PARQ_P
 #undef PARQ_S
+#undef PARQ_SA
+#undef PARQ_SB
+        if constexpr ((VAR & 1) != 0) {
+            if constexpr ((VAR & 2) != 0 && TERMS == 3) load_k_pair(lds_blk(n + 2 < nbk ? n + 2 : nbk - 1), kf, std::integral_constant<int, 2>{});
+            else load_k(lds_blk(n + 2 < nbk ? n + 2 : nbk - 1), kf);
+            load_v(lds_blk(n), 0, vh, vl);
+            PARQ_FENCE();
+            // rare, wave-uniform, register-only: (1) a factor left pending by the previous step (its PV has been added by now),
+            // (2) the maximum of block n + 1 moves the reference (any lane's own maximum past the threshold <=> some query's)
+            const bool moves = __any(mx_lane_out > a.defer_log2);
+            if (pend || moves) {
+                if (pend) apply_pending();
+                if (moves) move_reference_lazy(cur, xhalf_max(mx_lane_out));
+            }
+        } else {
         // fragments of the next step (K of block n + 2, clamped at the split's end; V of block n), in flight during the reduction
-        load_k(lds_blk(n + 2 < nbk ? n + 2 : nbk - 1), kf);
+        if constexpr ((VAR & 2) != 0 && TERMS == 3) load_k_pair(lds_blk(n + 2 < nbk ? n + 2 : nbk - 1), kf, std::integral_constant<int, 2>{});
+        else load_k(lds_blk(n + 2 < nbk ? n + 2 : nbk - 1), kf);
         load_v(lds_blk(n), 0, vh, vl);
         PARQ_FENCE();
         const float mx = xhalf_max(mx_lane_out);                             // relative to m_run
         if (__any(mx > a.defer_log2)) move_reference(cur, n, mx);
+        }
     };
 
     // the second-dispatched half of the workgroup loses every VALU arbitration against the older half (priority, then age):
@@ -604,6 +751,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
                         pv_half(std::integral_constant<int, NXT>{}, m, vh, vl);
                     }
                 }
+                if constexpr ((VAR & 1) != 0) { if (pend) apply_pending(); }   // the last block's maximum moved the reference
                 const _Float16* Vb = lds_blk(n);
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
@@ -711,23 +859,31 @@ hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t
     static const float defer = [] { const char* e = dev_env("PARQ_DEFER_LOG2"); return e ? (float)atof(e) : kDeferLog2; }();   // debugging knob, read once
     b.defer_log2 = defer;
     static const int prio = [] { const char* e = dev_env("PARQ_FLASH_PRIO"); return e ? atoi(e) : 0; }();
-    static const bool alt = [] { const char* e = dev_env("PARQ_FLASH_ALTERNATE"); return !(e && e[0] == '0'); }();
+    const bool alt = [] { const char* e = dev_env("PARQ_FLASH_ALTERNATE"); return !(e && e[0] == '0'); }();     // (per launch: tools/flash_variants.py)
     // bit 1 (set by the caller for every other recurrent iteration): sweep backwards — only for whole 64-key stages
     static const int nt = [] { const char* e = dev_env("PARQ_FLASH_NT"); return e ? atoi(e) : 0; }();
     static const int wt = [] { const char* e = dev_env("PARQ_FLASH_WT"); return e ? atoi(e) : 1; }();      // write-through partials (0: plain stores; measured 1.852 -> 1.846 ms)
     b.flags = (prio & 1) | ((alt && (a.flags & 2) && (a.Lk % (kStageBlks * kBlkKeys)) == 0) ? 2 : 0) | (nt ? 4 : 0) | ((wt && a.Lq % 256 == 0 && terms == 3) ? 8 : 0);
     const dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * b.H);
     const _Float16* c16 = reinterpret_cast<const _Float16*>(cache);
-#define PARQ_PIPE_LAUNCH(RING, PROBE, T, K, D)                                                                                           \
+#define PARQ_PIPE_LAUNCH_V(RING, PROBE, T, K, D, V)                                                                                      \
     {                                                                                                                                    \
         static DynLdsOnce once;                                                                                                          \
         const size_t lds = (size_t)RING * kStageBlks * Blk<T>::bytes + ((D) ? kNW * 32 * sizeof(uint32_t) : 0);                          \
-        if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_split_pipe_kernel<RING, PROBE, T, K, D>), lds); e != hipSuccess) return e; \
-        hipLaunchKernelGGL((flash_split_pipe_kernel<RING, PROBE, T, K, D>), grid, dim3(kNW * 64), lds, s, b, c16);                        \
+        if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_split_pipe_kernel<RING, PROBE, T, K, D, V>), lds); e != hipSuccess) return e; \
+        hipLaunchKernelGGL((flash_split_pipe_kernel<RING, PROBE, T, K, D, V>), grid, dim3(kNW * 64), lds, s, b, c16);                     \
         return hipGetLastError();                                                                                                        \
     }
+#define PARQ_PIPE_LAUNCH(RING, PROBE, T, K, D) PARQ_PIPE_LAUNCH_V(RING, PROBE, T, K, D, kFlashVar)
     const bool drop = b.drop_p > 0.f;
     if (terms != 3) {                                            // single fp16 / bf16 products (attention modes 2 / 3)
+#ifdef PARQ_DEV_PROBES
+        if (!drop && kind == kF16) {
+            const int var1 = [] { const char* e = dev_env("PARQ_FLASH_VAR"); return e ? atoi(e) : kFlashVar; }();
+            if (var1 == 0) PARQ_PIPE_LAUNCH_V(4, 0, 1, kF16, false, 0)
+            if (var1 == 25) PARQ_PIPE_LAUNCH_V(4, 0, 1, kF16, false, 25)
+        }
+#endif
         if (kind == kF16) { if (drop) PARQ_PIPE_LAUNCH(4, 0, 1, kF16, true) else PARQ_PIPE_LAUNCH(4, 0, 1, kF16, false) }
         if (drop) PARQ_PIPE_LAUNCH(4, 0, 1, kBF16, true) else PARQ_PIPE_LAUNCH(4, 0, 1, kBF16, false)
     }
@@ -748,10 +904,35 @@ hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t
         default: return hipErrorInvalidValue;
     }
 #endif
-    static const int ring = [] { const char* e = dev_env("PARQ_FLASH_RING"); return e && e[0] == '5' ? 5 : 4; }();
+#ifdef PARQ_DEV_PROBES
+    static const int ring = [] { const char* e = dev_env("PARQ_FLASH_RING"); return e && e[0] == '5' ? 5 : 4; }();   // measured 2 % slower (round 2)
     if (ring == 5) PARQ_PIPE_LAUNCH(5, 0, 3, kF16, false)
+    const int var = [] { const char* e = dev_env("PARQ_FLASH_VAR"); return e ? atoi(e) : kFlashVar; }();   // step variants; read per launch: tools/flash_variants.py walks them in one process
+    switch (var) {
+        case 0: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 0)
+        case 1: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 1)
+        case 3: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 3)
+        case 4: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 4)
+        case 5: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 5)
+        case 7: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 7)
+        case 8: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 8)
+        case 9: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 9)
+        case 11: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 11)
+        case 13: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 13)
+        case 15: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 15)
+        case 16: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 16)
+        case 25: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 25)
+        case 27: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 27)
+        case 29: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 29)
+        case 31: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 31)
+        case 32: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 32)
+        case 59: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 59)
+        default: return hipErrorInvalidValue;
+    }
+#endif
     PARQ_PIPE_LAUNCH(4, 0, 3, kF16, false)
 #undef PARQ_PIPE_LAUNCH
+#undef PARQ_PIPE_LAUNCH_V
 }
 
 PARQ_TL_DEFINE_SETTER(tl_set_flash_split)

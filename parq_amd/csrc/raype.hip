@@ -301,6 +301,7 @@ struct RayFusedArgs {
     double lo[3], inv[3];      // box normalisation u = (p - lo) * inv
     int hw, w, S, M;           // M = B*V*h*w tokens
     const _Float16* Whi; const _Float16* Wlo; const float* bias;   // this kernel's weight [256][K] hi/lo, bias [256]
+    const _Float16* W2f; const float* bias2;                       // one-pass kernel: W2 in fragment order (raype_pack_w2_kernel), b2
     float* hidden;             // [M][256]
     const float* feat;         // NCHW features (B*V, 256, h, w) or nullptr
     float* out;                // tokens [M][256] (nchw_out = 0) or encoding (B*V, 256, h, w) (nchw_out = 1)
@@ -601,6 +602,274 @@ __global__ __launch_bounds__(kFThreads, 1) void raype_tokens_kernel(RayFusedArgs
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// ONE-PASS form (round 4): tokens = feat + relu(p W1^T + b1) W2^T + b2 with the 64-token hidden tile kept in LDS — the 197 MB
+// hidden tensor of the two-kernel form above (written by raype_hidden_kernel, re-read by raype_tokens_kernel: 786 MB moved for
+// 393 MB algorithmic at BASELINE cfg 3) never exists.  model/ray_positional_encoding.py:128-136 is one MLP.
+//
+//   registers  W1 fragments of the wave's 32 hidden units for the whole launch (96 VGPRs, as in raype_hidden_kernel); W2 does
+//              NOT fit beside them (128 more), so its fragments are STREAMED per k-step from a fragment-ordered copy
+//              (raype_pack_w2_kernel: one wave-wide 16-byte load = one contiguous KB, L2-resident 256 KB shared by every CU),
+//              four (k-step, s2) steps ahead of the MFMAs (ring of 4 x 8 VGPRs); the feature tile is loaded in the accumulator
+//              layout into the registers the first GEMM's accumulators leave free, in flight during the second GEMM
+//   LDS        pts [3 k-steps][hi | lo][64 x 64] 48 KB (generated, single buffer: refilled for the next tile beside the second
+//              GEMM) | hid [4 k-steps][hi | lo][64 x 64] 64 KB, overlaid by the epilogue's transpose tile ot[64][260] 65 KB
+//   per tile   GEMM 1 TRANSPOSED (rows = hidden units, columns = tokens: a lane's 4 consecutive registers are 4 consecutive
+//              units of one token = one 8-byte piece of the hid image) | relu, split, hid image; feature loads issued | barrier |
+//              GEMM 2 (rows = channels, columns = tokens, as raype_tokens_kernel) | barrier | + features + bias, transpose
+//              through ot | barrier | one 1 KB row per store instruction, generate(next tile) while they drain | barrier
+// KEEP: training keeps the fp32 hidden layer for parq_ray_pe_backward (16-byte pieces; the inference path writes nothing).
+__global__ void raype_pack_w2_kernel(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo, _Float16* __restrict__ out) {
+    // out[wave 8][ks 4][s2 4][hl 2][lane 64][8] <- W{hl}[col = 32 wave + (lane & 31)][k = 64 ks + 32 (lane >> 5) + 8 s2 + e]
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;            // one 16-byte piece
+    if (i >= 8 * 4 * 4 * 2 * 64) return;
+    const int lane = i & 63, hl = (i >> 6) & 1, s2 = (i >> 7) & 3, ks = (i >> 9) & 3, wave = i >> 11;
+    const int col = 32 * wave + (lane & 31), k = 64 * ks + 32 * (lane >> 5) + 8 * s2;
+    const _Float16* src = (hl ? lo : hi) + (int64_t)col * kFC + k;
+    *reinterpret_cast<half8*>(out + (int64_t)i * 8) = *reinterpret_cast<const half8*>(src);
+}
+
+template <bool KEEP>
+__global__ __launch_bounds__(kFThreads, 1) void raype_onepass_kernel(RayFusedArgs a, int ntiles, int P) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    __shared__ double dtab[64];
+    constexpr int kStep = 2 * kFTM * 64;                                // halfs per k-step (hi + lo)
+    _Float16* pts = lds;                                                // 3 k-steps
+    _Float16* hid = lds + 3 * kStep;                                    // 4 k-steps
+    float* ot = reinterpret_cast<float*>(hid);                          // [64][kOtLd], after the second GEMM
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kh = lane >> 5;
+    const int p = blockIdx.x;
+    if (tid < 64) dtab[tid] = tid < a.S ? a.depth[tid] : 1.0;
+    const int col = wave * 32 + li;                                     // this lane's row of W1 (A operand of the transposed product)
+    half8 wfr[3][4][2];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const int64_t off = (int64_t)col * kFK1 + ks * 64 + 32 * kh + 8 * s2;
+            wfr[ks][s2][0] = *reinterpret_cast<const half8*>(a.Whi + off);
+            wfr[ks][s2][1] = *reinterpret_cast<const half8*>(a.Wlo + off);
+        }
+    // W2 fragments of (wave, step = 4 ks + s2): two pieces [hi, lo] of 1 KB each, lane-contiguous (raype_pack_w2_kernel)
+    // (buffer loads: one lane offset, the piece as a scalar offset — 32 separate 64-bit addresses would cost 64 VGPRs)
+    __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.W2f + (int64_t)wave * 4 * 4 * 2 * 64 * 8), 0, 4 * 4 * 2 * 64 * 16, 0x00020000);
+    typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
+    auto load_w2 = [&](int step, half8 (&dst)[2]) {
+        dst[0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(w2rs, lane * 16, (step * 2) * 1024, 0));
+        dst[1] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(w2rs, lane * 16, (step * 2 + 1) * 1024, 0));
+    };
+    __syncthreads();
+
+    const int grow = tid & 63;
+    auto generate = [&](int tile) {                                      // as raype_hidden_kernel: the 64 x 192 operand image of `tile`
+        const int m = tile * kFTM + grow;
+        double G[3] = {0.0, 0.0, 0.0}, T3[3] = {0.5, 0.5, 0.5};
+        if (m < a.M) {
+            const int bv = m / a.hw, pix = m - bv * a.hw;
+            const int y = pix / a.w, x = pix - y * a.w;
+            const float* cm = a.cam + (int64_t)bv * 6;
+            const double rx = ((double)x - (double)cm[4]) / (double)cm[2];
+            const double ry = ((double)y - (double)cm[5]) / (double)cm[3];
+            const double* T = a.Tl + (int64_t)bv * 12;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                G[i] = (T[i * 3] * rx + T[i * 3 + 1] * ry + T[i * 3 + 2]) * a.inv[i];
+                T3[i] = (T[9 + i] - a.lo[i]) * a.inv[i];
+            }
+        }
+        double dj[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) dj[jj] = dtab[8 * wave + jj];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float x8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int q = 8 * i + e;
+                const int jj = q / 3, ax = q - 3 * jj;
+                double u = dj[jj] * G[ax] + T3[ax];
+                u = fmin(fmax(u, 0.0), 1.0);
+                const double x1 = fmax(u, 1e-3);
+                const double x2 = fmax(1.0 - u, 1e-3);
+                x8[e] = __logf(__fdividef((float)x1, (float)x2));
+            }
+            half8 hi, lo8;
+            split8(x8, hi, lo8);
+            const int chunk = 3 * wave + i;
+            const int ks = chunk >> 3, c = chunk & 7;
+            const int pos = c ^ ((grow >> 1) & 7);
+            _Float16* Ahi = pts + ks * kStep;
+            *reinterpret_cast<half8*>(Ahi + grow * 64 + pos * 8) = hi;
+            *reinterpret_cast<half8*>(Ahi + kFTM * 64 + grow * 64 + pos * 8) = lo8;
+        }
+    };
+
+    if (p < ntiles) generate(p);
+    __syncthreads();
+    for (int tile = p; tile < ntiles; tile += P) {
+        half8 w2r[4][2];                                                  // ring of four (k-step, s2) steps of W2 fragments
+        // ---- GEMM 1, transposed: acc1[t] rows = this wave's 32 hidden units, columns = tokens 32 t .. 32 t + 31
+        f32x16 acc1[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const _Float16* Ahi = pts + ks * kStep;
+            const _Float16* Alo = Ahi + kFTM * 64;
+            if (ks == 2) {                                                // the first W2 steps arrive behind the last third of GEMM 1
+#pragma unroll
+                for (int i = 0; i < 4; ++i) load_w2(i, w2r[i]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                half8 xh[2], xl[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int row = t * 32 + li;
+                    const int posr = (4 * kh + s2) ^ ((row >> 1) & 7);
+                    xh[t] = *reinterpret_cast<const half8*>(Ahi + row * 64 + posr * 8);
+                    xl[t] = *reinterpret_cast<const half8*>(Alo + row * 64 + posr * 8);
+                }
+                const half8 wh = wfr[ks][s2][0], wl = wfr[ks][s2][1];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[t], acc1[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[t], acc1[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[t], acc1[t], 0, 0, 0);
+            }
+        }
+        // ---- relu(acc1 + b1) -> hid image (B operand of GEMM 2: rows = tokens, 8-unit chunks, swizzled as every operand image).
+        // Registers 4 g .. 4 g + 3 of a lane are units 32 wave + 8 g + 4 kh .. + 3 of token 32 t + li: half a chunk, 8 bytes.
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int row = t * 32 + li;
+            const int m = tile * kFTM + row;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int u0 = wave * 32 + 8 * g4 + 4 * kh;
+                const float4 b4 = *reinterpret_cast<const float4*>(a.bias + u0);
+                float y[4] = {acc1[t][4 * g4] + b4.x, acc1[t][4 * g4 + 1] + b4.y, acc1[t][4 * g4 + 2] + b4.z, acc1[t][4 * g4 + 3] + b4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = y[e] > 0.f ? y[e] : 0.f;
+                if constexpr (KEEP) {
+                    if (m < a.M) *reinterpret_cast<float4*>(a.hidden + (int64_t)m * kFC + u0) = float4{y[0], y[1], y[2], y[3]};
+                }
+                half2v h01, l01, h23, l23;
+                split_pair(y[0], y[1], h01, l01);
+                split_pair(y[2], y[3], h23, l23);
+                const int ks2 = wave >> 1, c = (wave & 1) * 4 + g4;
+                const int pos = c ^ ((row >> 1) & 7);
+                _Float16* Hh = hid + ks2 * kStep + row * 64 + pos * 8 + 4 * kh;
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<u32x2*>(Hh) = u32x2{__builtin_bit_cast(unsigned int, h01), __builtin_bit_cast(unsigned int, h23)};
+                *reinterpret_cast<u32x2*>(Hh + kFTM * 64) = u32x2{__builtin_bit_cast(unsigned int, l01), __builtin_bit_cast(unsigned int, l23)};
+            }
+        }
+        // ---- the feature tile in the accumulator layout (register r of block t = channel 32 wave + mfma32_row(r, lane) of token
+        // tile*64 + 32 t + li: lanes walk consecutive pixels, 128-byte segments), requested now (acc1's registers are free) and
+        // added in the epilogue: the loads are in flight during the whole of GEMM 2
+        // (buffer loads: ONE lane-dependent byte offset per block t, the 16 channel strides as scalar offsets — global loads with
+        // 32 distinct 64-bit addresses per lane cost 64 VGPRs of addresses and spilled the tile loop.  The descriptor's base is
+        // the first image of the tile, so the 32-bit offsets stay small whatever the batch size.)
+        f32x16 fr[2];
+        {
+            const int bv0 = (tile * kFTM) / a.hw;                         // scalar: first image this tile touches
+            const float* fbase = (a.feat ? a.feat : a.bias) + (int64_t)bv0 * kFC * a.hw;
+            // no feature maps (AddRayPE.forward: the encoding alone): zero records -> every load returns 0, no branch per load
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)fbase, 0, a.feat ? 0x7fffffff : 0, 0x00020000);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int m = tile * kFTM + t * 32 + li;
+                const bool ok = m < a.M;                                 // rows past the end read (and discard) pixel 0 of image bv0
+                const int bv = ok ? m / a.hw : bv0, pix = ok ? m - bv * a.hw : 0;
+                const int voff = (((bv - bv0) * kFC + wave * 32 + 4 * kh) * a.hw + pix) * 4;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int soff = (8 * (r >> 2) + (r & 3)) * a.hw * 4;   // mfma32_row(r, lane) = 8 (r >> 2) + 4 kh + (r & 3)
+                    fr[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+                }
+            }
+        }
+        __syncthreads();                                                  // hid complete
+        // ---- GEMM 2: rows = channels, columns = tokens (as raype_tokens_kernel); W2 four steps ahead
+        f32x16 acc2[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+#pragma unroll
+        for (int step = 0; step < 16; ++step) {
+            const int ks = step >> 2, s2 = step & 3;
+            const _Float16* Ahi = hid + ks * kStep;
+            const _Float16* Alo = Ahi + kFTM * 64;
+            half8 xh[2], xl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int row = t * 32 + li;
+                const int posr = (4 * kh + s2) ^ ((row >> 1) & 7);
+                xh[t] = *reinterpret_cast<const half8*>(Ahi + row * 64 + posr * 8);
+                xl[t] = *reinterpret_cast<const half8*>(Alo + row * 64 + posr * 8);
+            }
+            const half8 wh = w2r[step & 3][0], wl = w2r[step & 3][1];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[t], acc2[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[t], acc2[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[t], acc2[t], 0, 0, 0);
+            if (step + 4 < 16) load_w2(step + 4, w2r[step & 3]);
+        }
+        __syncthreads();                                                  // hid is free: ot overlays it
+        // ---- epilogue (as raype_tokens_kernel): + features + b2, NCHW encoding lane-contiguous, or channels-last rows through ot
+        {
+            const int bv0 = (tile * kFTM) / a.hw;
+            __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (a.nchw_out ? (int64_t)bv0 * kFC * a.hw : 0)), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int m = tile * kFTM + t * 32 + li;
+                const bool ok = m < a.M;
+                const int bv = ok ? m / a.hw : bv0, pix = ok ? m - bv * a.hw : 0;
+                const int voff = (((bv - bv0) * kFC + wave * 32 + 4 * kh) * a.hw + pix) * 4;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int c0 = wave * 32 + 8 * g4 + 4 * kh;
+                    const float4 b4 = *reinterpret_cast<const float4*>(a.bias2 + c0);
+                    const float y[4] = {acc2[t][4 * g4] + fr[t][4 * g4] + b4.x, acc2[t][4 * g4 + 1] + fr[t][4 * g4 + 1] + b4.y,
+                                        acc2[t][4 * g4 + 2] + fr[t][4 * g4 + 2] + b4.z, acc2[t][4 * g4 + 3] + fr[t][4 * g4 + 3] + b4.w};
+                    if (a.nchw_out) {
+                        if (ok) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, y[e]), ors, voff, (8 * g4 + e) * a.hw * 4, 0);
+                        }
+                    } else {
+                        *reinterpret_cast<float4*>(ot + (t * 32 + li) * kOtLd + c0) = float4{y[0], y[1], y[2], y[3]};
+                    }
+                }
+            }
+        }
+        if (!a.nchw_out) {
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int row = wave * 8 + rr;
+                const int m = tile * kFTM + row;
+                if (m < a.M)
+                    *reinterpret_cast<float4*>(a.out + (int64_t)m * kFC + 4 * lane) =
+                        *reinterpret_cast<const float4*>(ot + row * kOtLd + 4 * lane);
+            }
+        }
+        // ---- the next tile's operand image while the row stores drain (every wave is done with pts since the first barrier)
+        if (tile + P < ntiles) generate(tile + P);
+        __syncthreads();                                                 // pts complete; ot (= hid) free for the next tile
+    }
+}
+
 }  // namespace
 
 hipError_t launch_raype_points(const float* cam, const float* T_cp, const float* T_wp, const float* T_wl,
@@ -620,7 +889,8 @@ hipError_t launch_raype_points(const float* cam, const float* T_cp, const float*
 hipError_t launch_raype_fused(const float* cam, const float* T_cp, const float* T_wp, const float* T_wl, const float* scale6,
                               float min_depth, float max_depth, int B, int V, int h, int w, const void* W1hi, const void* W1lo,
                               const float* b1, const void* W2hi, const void* W2lo, const float* b2, const float* feat,
-                              float* hidden, double* Tl, double* depth, float* out, int nchw_out, hipStream_t s) {
+                              float* hidden, double* Tl, double* depth, float* out, int nchw_out, hipStream_t s, void* W2f,
+                              int two_kernels) {
     const int S = 64;
     const int64_t M64 = (int64_t)B * V * h * w;
     if (M64 > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -643,6 +913,24 @@ hipError_t launch_raype_fused(const float* cam, const float* T_cp, const float* 
     int P = device_num_cus();
     if (P > ntiles) P = ntiles;
     a.Whi = reinterpret_cast<const _Float16*>(W1hi); a.Wlo = reinterpret_cast<const _Float16*>(W1lo); a.bias = b1;
+    a.W2f = nullptr; a.bias2 = nullptr;
+    if (!two_kernels && W2f) {
+        // one pass: the hidden tile never leaves the CU (hidden != nullptr: training keeps an fp32 copy for the backward)
+        static DynLdsOnce once_k, once_n;
+        const size_t lds_f = (size_t)3 * 2 * kFTM * 64 * sizeof(_Float16) + (size_t)kFTM * kOtLd * sizeof(float);      // 48 KB + 65 KB
+        hipLaunchKernelGGL(raype_pack_w2_kernel, dim3(8 * 4 * 4 * 2 * 64 / 256), dim3(256), 0, s, reinterpret_cast<const _Float16*>(W2hi),
+                           reinterpret_cast<const _Float16*>(W2lo), reinterpret_cast<_Float16*>(W2f));
+        a.W2f = reinterpret_cast<const _Float16*>(W2f); a.bias2 = b2;
+        a.feat = feat; a.out = out; a.nchw_out = nchw_out;
+        if (hidden) {
+            if (hipError_t e = once_k.ensure(reinterpret_cast<const void*>(&raype_onepass_kernel<true>), lds_f); e != hipSuccess) return e;
+            hipLaunchKernelGGL(raype_onepass_kernel<true>, dim3(P), dim3(kFThreads), lds_f, s, a, ntiles, P);
+        } else {
+            if (hipError_t e = once_n.ensure(reinterpret_cast<const void*>(&raype_onepass_kernel<false>), lds_f); e != hipSuccess) return e;
+            hipLaunchKernelGGL(raype_onepass_kernel<false>, dim3(P), dim3(kFThreads), lds_f, s, a, ntiles, P);
+        }
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(raype_hidden_kernel, dim3(P), dim3(kFThreads), lds_a, s, a, ntiles, P);
     a.Whi = reinterpret_cast<const _Float16*>(W2hi); a.Wlo = reinterpret_cast<const _Float16*>(W2lo); a.bias = b2;
     a.feat = feat; a.out = out; a.nchw_out = nchw_out;

@@ -109,21 +109,24 @@ class AddRayPE(nn.Module):
             assert features.shape == (B, V, Cd, h, w), tuple(features.shape)
         lib = _lib.load()
         self._gen += 1
-        nbytes = lib.parq_ray_pe_workspace_bytes(B, V, h, w, Cd, self.num_samples)
+        # include/parq_hip.h: 1 = NCHW output, 2 = inference (the hidden layer is not kept for a backward: on the one-pass path it
+        # never leaves the CU and the workspace shrinks by B*V*h*w*C floats)
+        fused = Cd == 256 and self.num_samples == 64          # the library's one-pass path can write (B, V, C, h, w) directly
+        nchw = bool(nchw and fused)
+        flags = (1 if nchw else 0) | (0 if own_workspace else 2)
+        nbytes = lib.parq_ray_pe_workspace_bytes_flags(B, V, h, w, Cd, self.num_samples, flags)
         owner = self._ws_owner() if self._ws_owner is not None else None
         if owner is not None and not owner.consumed and owner.ws is self._ws:
             self._ws = None                                  # an autograd node still needs the hidden layer saved there
         if self._ws is None or self._ws.numel() * 4 < nbytes or self._ws.device != dev:
             self._ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=dev)
-        fused = Cd == 256 and self.num_samples == 64          # the library's fused path can write (B, V, C, h, w) directly
-        nchw = bool(nchw and fused)
         out = torch.empty((B, V, Cd, h, w) if nchw else (B, V * h * w, Cd), dtype=torch.float32, device=dev)
         p = [prep(t.detach()) for t in (self.encoder[0].weight, self.encoder[0].bias, self.encoder[2].weight,
                                         self.encoder[2].bias)]
         _lib.check(lib.parq_ray_pe(_lib.ptr(cam), _lib.ptr(T_cp), _lib.ptr(T_wp), _lib.ptr(T_wl), _lib.ptr(p[0]),
                                    _lib.ptr(p[1]), _lib.ptr(p[2]), _lib.ptr(p[3]), (C.c_float * 6)(*self.ray_points_scale),
                                    self.min_depth, self.max_depth, self.num_samples, B, V, h, w, Cd, _lib.ptr(features),
-                                   _lib.ptr(out), int(nchw), _lib.ptr(self._ws), self._ws.numel() * 4, _lib.stream_ptr()),
+                                   _lib.ptr(out), flags, _lib.ptr(self._ws), self._ws.numel() * 4, _lib.stream_ptr()),
                    "parq_ray_pe")
         self._ws._parq_gen = self._gen
         return out, (B, V, h, w), nchw

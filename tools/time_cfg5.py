@@ -9,6 +9,9 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if len(sys.argv) > 2 and sys.argv[2] == "dev":          # development library (PARQ_* switches)
+    from parq_amd import _lib  # noqa: E402
+    _lib.use_dev_library()
 from parq_amd import synth  # noqa: E402
 from parq_amd.decoder import PARQDecoder  # noqa: E402
 

@@ -2,6 +2,8 @@
 import sys, time, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from parq_amd import AddRayPE, synth
+# inference (the default): no graph, the hidden layer is never written; RAYPE_GRAD=1: the autograd forward, which keeps it
+torch.set_grad_enabled(os.environ.get("RAYPE_GRAD", "0") == "1")
 B, V, h, w, C = 1, 10, 120, 160, 256
 pe = AddRayPE(C, synth.DEFAULT_SCALE, 64, 0.25, 5.25)
 Wp = synth.make_ray_pe_weights(C, 7)
