@@ -259,7 +259,9 @@ int parq_set_backward_streams(parq_handle h, int32_t n);
  * the fp32 hidden layer that parq_ray_pe_backward reads from the forward's workspace is not kept either, and the workspace is
  * smaller by B*V*h*w*C floats (parq_ray_pe_workspace_bytes_flags; ignored off the one-pass path, which needs the tensor as an
  * intermediate).  Requires (3*num_samples) % 64 == 0 and C % 64 == 0 (shipped: 64 samples, C = 1024 or 256). */
-enum { PARQ_RAYPE_NCHW_OUT = 1, PARQ_RAYPE_NO_HIDDEN = 2 };
+/* PARQ_RAYPE_WEIGHTS_CACHED: the workspace is the one the previous call used (same flags otherwise, same C and num_samples) and
+ * w1 / w2 have not changed since: their hi/lo split and fragment-ordered copies inside it are reused (three small launches less). */
+enum { PARQ_RAYPE_NCHW_OUT = 1, PARQ_RAYPE_NO_HIDDEN = 2, PARQ_RAYPE_WEIGHTS_CACHED = 4 };
 size_t parq_ray_pe_workspace_bytes(int32_t B, int32_t V, int32_t hh, int32_t ww, int32_t C, int32_t num_samples);   /* flags = 0 */
 size_t parq_ray_pe_workspace_bytes_flags(int32_t B, int32_t V, int32_t hh, int32_t ww, int32_t C, int32_t num_samples,
                                          int32_t flags);

@@ -1735,15 +1735,18 @@ int parq_ray_pe(const float* camera, const float* T_cp, const float* T_wp, const
     float* P = reinterpret_cast<float*>(tabs) + raype_align(2 * ((int64_t)B * V * 12 + num_samples));
     char* w1hi = (char*)W1s; char* w1lo = w1hi + (size_t)C * K1 * 2;
     char* w2hi = (char*)W2s; char* w2lo = w2hi + (size_t)C * C * 2;
-    HIPCHK(launch_split_f32(w1, w1hi, w1lo, (int64_t)C * K1, s));
-    HIPCHK(launch_split_f32(w2, w2hi, w2lo, (int64_t)C * C, s));
+    const bool cached = (flags & PARQ_RAYPE_WEIGHTS_CACHED) != 0;       // the workspace still holds this w1 / w2, split and packed
+    if (!cached) {
+        HIPCHK(launch_split_f32(w1, w1hi, w1lo, (int64_t)C * K1, s));
+        HIPCHK(launch_split_f32(w2, w2hi, w2lo, (int64_t)C * C, s));
+    }
     if (C == 256 && num_samples == 64) {
         // development: PARQ_RAYPE_TWO_KERNELS=1 runs the round-1 form (hidden tensor written and re-read) for A/B
         static const int two = [] { const char* e = dev_env("PARQ_RAYPE_TWO_KERNELS"); return e && e[0] == '1' ? 1 : 0; }();
         if (two && !Hd) return fail(PARQ_ERR_ARG, "the two-kernel form needs the hidden region (do not pass the no-hidden flag)");
         HIPCHK(launch_raype_fused(camera, T_cp, T_wp, T_wl, scale6_host, min_depth, max_depth, B, V, hh, ww, w1hi, w1lo, b1,
                                   w2hi, w2lo, b2, features_nchw, Hd, tabs, tabs + (int64_t)B * V * 12, tokens_out,
-                                  nchw_out ? 1 : 0, s, W2f, two));
+                                  nchw_out ? 1 : 0, s, W2f, two | (cached ? 2 : 0)));
         return PARQ_OK;
     }
     if (nchw_out) return fail(PARQ_ERR_ARG, "NCHW output needs the fused path (C = 256, 64 samples)");

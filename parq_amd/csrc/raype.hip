@@ -14,6 +14,7 @@
 // tokens 197 MB written (a single fused kernel would keep p and the hidden layer in LDS; this
 // two-GEMM form is the first correct version).
 #include "common.hpp"
+#include <cstdlib>
 
 namespace parq {
 
@@ -630,7 +631,9 @@ __global__ void raype_pack_w2_kernel(const _Float16* __restrict__ hi, const _Flo
     *reinterpret_cast<half8*>(out + (int64_t)i * 8) = *reinterpret_cast<const half8*>(src);
 }
 
-template <bool KEEP>
+// PROBE (development only, results wrong when non-zero): 1 W2 fragments loaded once instead of per tile, 2 operand image generated
+// once, 4 no feature loads, 8 no token stores — what each ingredient costs when it is taken out
+template <bool KEEP, int PROBE = 0>
 __global__ __launch_bounds__(kFThreads, 1) void raype_onepass_kernel(RayFusedArgs a, int ntiles, int P) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     __shared__ double dtab[64];
@@ -657,6 +660,7 @@ __global__ __launch_bounds__(kFThreads, 1) void raype_onepass_kernel(RayFusedArg
     __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.W2f + (int64_t)wave * 4 * 4 * 2 * 64 * 8), 0, 4 * 4 * 2 * 64 * 16, 0x00020000);
     typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
     auto load_w2 = [&](int step, half8 (&dst)[2]) {
+        if constexpr ((PROBE & 1) != 0) { if (step >= 4) return; }
         dst[0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(w2rs, lane * 16, (step * 2) * 1024, 0));
         dst[1] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(w2rs, lane * 16, (step * 2 + 1) * 1024, 0));
     };
@@ -689,11 +693,13 @@ __global__ __launch_bounds__(kFThreads, 1) void raype_onepass_kernel(RayFusedArg
             for (int e = 0; e < 8; ++e) {
                 const int q = 8 * i + e;
                 const int jj = q / 3, ax = q - 3 * jj;
-                double u = dj[jj] * G[ax] + T3[ax];
-                u = fmin(fmax(u, 0.0), 1.0);
-                const double x1 = fmax(u, 1e-3);
-                const double x2 = fmax(1.0 - u, 1e-3);
-                x8[e] = __logf(__fdividef((float)x1, (float)x2));
+                // u and 1 - u in float64 (the inverse-sigmoid is ill-conditioned at the clamp edges), the clamps on their fp32
+                // roundings: rounding is monotone, so max / min commute with it and the values equal the all-float64 clamps
+                const double u = dj[jj] * G[ax] + T3[ax];
+                const float uf = (float)u, wf = (float)(1.0 - u);
+                const float x1 = fmaxf(fminf(uf, 1.f), 1e-3f);             // max(clamp(u, 0, 1), 1e-3)
+                const float x2 = fmaxf(fminf(wf, 1.f), 1e-3f);             // max(1 - clamp(u, 0, 1), 1e-3)
+                x8[e] = __logf(__fdividef(x1, x2));
             }
             half8 hi, lo8;
             split8(x8, hi, lo8);
@@ -710,6 +716,35 @@ __global__ __launch_bounds__(kFThreads, 1) void raype_onepass_kernel(RayFusedArg
     __syncthreads();
     for (int tile = p; tile < ntiles; tile += P) {
         half8 w2r[4][2];                                                  // ring of four (k-step, s2) steps of W2 fragments
+        // ---- the feature tile in the accumulator layout (register r of block t = channel 32 wave + mfma32_row(r, lane) of token
+        // tile*64 + 32 t + li: lanes walk consecutive pixels, 128-byte segments), requested at the TOP of the tile and added in the
+        // epilogue.  VMEM returns in order: requested behind the first GEMM they sat in front of every W2 refill of the second one
+        // and each tile paid their HBM latency (probe: -75 us per launch with the loads removed, profiles/r04_raype_onepass.txt)
+        // (buffer loads: ONE lane-dependent byte offset per block t, the 16 channel strides as scalar offsets — global loads with
+        // 32 distinct 64-bit addresses per lane cost 64 VGPRs of addresses and spilled the tile loop.  The descriptor's base is
+        // the first image of the tile, so the 32-bit offsets stay small whatever the batch size.)
+        f32x16 fr[2];
+        {
+            const int bv0 = (tile * kFTM) / a.hw;                         // scalar: first image this tile touches
+            const float* fbase = (a.feat ? a.feat : a.bias) + (int64_t)bv0 * kFC * a.hw;
+            // no feature maps (AddRayPE.forward: the encoding alone): zero records -> every load returns 0, no branch per load
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)fbase, 0, a.feat ? 0x7fffffff : 0, 0x00020000);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int m = tile * kFTM + t * 32 + li;
+                const bool ok = m < a.M;                                 // rows past the end read (and discard) pixel 0 of image bv0
+                const int bv = ok ? m / a.hw : bv0, pix = ok ? m - bv * a.hw : 0;
+                const int voff = (((bv - bv0) * kFC + wave * 32 + 4 * kh) * a.hw + pix) * 4;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int soff = (8 * (r >> 2) + (r & 3)) * a.hw * 4;   // mfma32_row(r, lane) = 8 (r >> 2) + 4 kh + (r & 3)
+                    if constexpr ((PROBE & 4) != 0) fr[t][r] = 0.f;
+                    else fr[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_w2(i, w2r[i]);                    // the first W2 steps: behind the features, landed long before GEMM 2
         // ---- GEMM 1, transposed: acc1[t] rows = this wave's 32 hidden units, columns = tokens 32 t .. 32 t + 31
         f32x16 acc1[2];
 #pragma unroll
@@ -720,10 +755,6 @@ __global__ __launch_bounds__(kFThreads, 1) void raype_onepass_kernel(RayFusedArg
         for (int ks = 0; ks < 3; ++ks) {
             const _Float16* Ahi = pts + ks * kStep;
             const _Float16* Alo = Ahi + kFTM * 64;
-            if (ks == 2) {                                                // the first W2 steps arrive behind the last third of GEMM 1
-#pragma unroll
-                for (int i = 0; i < 4; ++i) load_w2(i, w2r[i]);
-            }
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) {
                 half8 xh[2], xl[2];
@@ -768,31 +799,6 @@ __global__ __launch_bounds__(kFThreads, 1) void raype_onepass_kernel(RayFusedArg
                 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                 *reinterpret_cast<u32x2*>(Hh) = u32x2{__builtin_bit_cast(unsigned int, h01), __builtin_bit_cast(unsigned int, h23)};
                 *reinterpret_cast<u32x2*>(Hh + kFTM * 64) = u32x2{__builtin_bit_cast(unsigned int, l01), __builtin_bit_cast(unsigned int, l23)};
-            }
-        }
-        // ---- the feature tile in the accumulator layout (register r of block t = channel 32 wave + mfma32_row(r, lane) of token
-        // tile*64 + 32 t + li: lanes walk consecutive pixels, 128-byte segments), requested now (acc1's registers are free) and
-        // added in the epilogue: the loads are in flight during the whole of GEMM 2
-        // (buffer loads: ONE lane-dependent byte offset per block t, the 16 channel strides as scalar offsets — global loads with
-        // 32 distinct 64-bit addresses per lane cost 64 VGPRs of addresses and spilled the tile loop.  The descriptor's base is
-        // the first image of the tile, so the 32-bit offsets stay small whatever the batch size.)
-        f32x16 fr[2];
-        {
-            const int bv0 = (tile * kFTM) / a.hw;                         // scalar: first image this tile touches
-            const float* fbase = (a.feat ? a.feat : a.bias) + (int64_t)bv0 * kFC * a.hw;
-            // no feature maps (AddRayPE.forward: the encoding alone): zero records -> every load returns 0, no branch per load
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)fbase, 0, a.feat ? 0x7fffffff : 0, 0x00020000);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int m = tile * kFTM + t * 32 + li;
-                const bool ok = m < a.M;                                 // rows past the end read (and discard) pixel 0 of image bv0
-                const int bv = ok ? m / a.hw : bv0, pix = ok ? m - bv * a.hw : 0;
-                const int voff = (((bv - bv0) * kFC + wave * 32 + 4 * kh) * a.hw + pix) * 4;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int soff = (8 * (r >> 2) + (r & 3)) * a.hw * 4;   // mfma32_row(r, lane) = 8 (r >> 2) + 4 kh + (r & 3)
-                    fr[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
-                }
             }
         }
         __syncthreads();                                                  // hid complete
@@ -859,13 +865,13 @@ __global__ __launch_bounds__(kFThreads, 1) void raype_onepass_kernel(RayFusedArg
             for (int rr = 0; rr < 8; ++rr) {
                 const int row = wave * 8 + rr;
                 const int m = tile * kFTM + row;
-                if (m < a.M)
+                if (m < a.M && (PROBE & 8) == 0)
                     *reinterpret_cast<float4*>(a.out + (int64_t)m * kFC + 4 * lane) =
                         *reinterpret_cast<const float4*>(ot + row * kOtLd + 4 * lane);
             }
         }
         // ---- the next tile's operand image while the row stores drain (every wave is done with pts since the first barrier)
-        if (tile + P < ntiles) generate(tile + P);
+        if constexpr ((PROBE & 2) == 0) { if (tile + P < ntiles) generate(tile + P); }
         __syncthreads();                                                 // pts complete; ot (= hid) free for the next tile
     }
 }
@@ -914,18 +920,28 @@ hipError_t launch_raype_fused(const float* cam, const float* T_cp, const float* 
     if (P > ntiles) P = ntiles;
     a.Whi = reinterpret_cast<const _Float16*>(W1hi); a.Wlo = reinterpret_cast<const _Float16*>(W1lo); a.bias = b1;
     a.W2f = nullptr; a.bias2 = nullptr;
+    const bool w2f_cached = (two_kernels & 2) != 0;                     // bit 1: W2f already holds this W2 (caller's weight cache)
+    two_kernels &= 1;
     if (!two_kernels && W2f) {
         // one pass: the hidden tile never leaves the CU (hidden != nullptr: training keeps an fp32 copy for the backward)
         static DynLdsOnce once_k, once_n;
         const size_t lds_f = (size_t)3 * 2 * kFTM * 64 * sizeof(_Float16) + (size_t)kFTM * kOtLd * sizeof(float);      // 48 KB + 65 KB
-        hipLaunchKernelGGL(raype_pack_w2_kernel, dim3(8 * 4 * 4 * 2 * 64 / 256), dim3(256), 0, s, reinterpret_cast<const _Float16*>(W2hi),
-                           reinterpret_cast<const _Float16*>(W2lo), reinterpret_cast<_Float16*>(W2f));
+        if (!w2f_cached)
+            hipLaunchKernelGGL(raype_pack_w2_kernel, dim3(8 * 4 * 4 * 2 * 64 / 256), dim3(256), 0, s, reinterpret_cast<const _Float16*>(W2hi),
+                               reinterpret_cast<const _Float16*>(W2lo), reinterpret_cast<_Float16*>(W2f));
         a.W2f = reinterpret_cast<const _Float16*>(W2f); a.bias2 = b2;
         a.feat = feat; a.out = out; a.nchw_out = nchw_out;
         if (hidden) {
             if (hipError_t e = once_k.ensure(reinterpret_cast<const void*>(&raype_onepass_kernel<true>), lds_f); e != hipSuccess) return e;
             hipLaunchKernelGGL(raype_onepass_kernel<true>, dim3(P), dim3(kFThreads), lds_f, s, a, ntiles, P);
         } else {
+#ifdef PARQ_DEV_PROBES
+            static const int probe = [] { const char* e = dev_env("PARQ_RAYPE_PROBE"); return e ? atoi(e) : 0; }();
+#define PARQ_RP(PB) case PB: { static DynLdsOnce o; if (hipError_t e = o.ensure(reinterpret_cast<const void*>(&raype_onepass_kernel<false, PB>), lds_f); e != hipSuccess) return e; \
+                               hipLaunchKernelGGL((raype_onepass_kernel<false, PB>), dim3(P), dim3(kFThreads), lds_f, s, a, ntiles, P); return hipGetLastError(); }
+            switch (probe) { PARQ_RP(1) PARQ_RP(2) PARQ_RP(3) PARQ_RP(4) PARQ_RP(8) PARQ_RP(15) default: break; }
+#undef PARQ_RP
+#endif
             if (hipError_t e = once_n.ensure(reinterpret_cast<const void*>(&raype_onepass_kernel<false>), lds_f); e != hipSuccess) return e;
             hipLaunchKernelGGL(raype_onepass_kernel<false>, dim3(P), dim3(kFThreads), lds_f, s, a, ntiles, P);
         }

@@ -86,6 +86,7 @@ class AddRayPE(nn.Module):
         self.max_depth = float(max_depth)
         self.encoder = nn.Sequential(nn.Linear(3 * num_samples, dim_out), nn.ReLU(), nn.Linear(dim_out, dim_out))
         self._ws = None
+        self._ws_key = None               # what the weight copies inside ``_ws`` were made from (see _run)
         self._gen = 0                     # forward counter, stamped on the workspace it wrote (``_parq_gen``)
         self._ws_owner = None             # weak reference to the _WsHold of the autograd node that owns ``_ws`` (if any)
         self.dp_all_reduce = False        # True: the backward all-reduces (mean) the encoder gradients over the default process group
@@ -120,6 +121,15 @@ class AddRayPE(nn.Module):
             self._ws = None                                  # an autograd node still needs the hidden layer saved there
         if self._ws is None or self._ws.numel() * 4 < nbytes or self._ws.device != dev:
             self._ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=dev)
+            self._ws_key = None
+        # the split / fragment-ordered weight copies inside the workspace are reused while the same workspace holds the same
+        # weights (data pointer and version of the four parameters: optimizer steps and load_state_dict bump the version;
+        # writes through .data need invalidate_weights()) in the same layout
+        key = (self._ws.data_ptr(), flags & 2, B, V, h, w) + tuple((t.data_ptr(), t._version) for t in
+                                                                     (self.encoder[0].weight, self.encoder[2].weight))
+        if key == self._ws_key:
+            flags |= 4
+        self._ws_key = key
         out = torch.empty((B, V, Cd, h, w) if nchw else (B, V * h * w, Cd), dtype=torch.float32, device=dev)
         p = [prep(t.detach()) for t in (self.encoder[0].weight, self.encoder[0].bias, self.encoder[2].weight,
                                         self.encoder[2].bias)]
@@ -130,6 +140,10 @@ class AddRayPE(nn.Module):
                    "parq_ray_pe")
         self._ws._parq_gen = self._gen
         return out, (B, V, h, w), nchw
+
+    def invalidate_weights(self):
+        """After parameter writes that bypass autograd's version counter (``p.data.copy_()``, EMA swaps through ``.data``)."""
+        self._ws_key = None
 
     def _needs_graph(self, features=None):
         return torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())

@@ -3,7 +3,7 @@
 #   tools/collect_profiles.sh r02
 # bench lines (B=1 with the CPU baseline and the 32-scene project+sample figure, B=8, fp16 mode, training step), rocprofv3 kernel
 # stats of the default bench command, PMC passes (HBM bytes at 1 and 32 scenes; MFMA / LDS counters), then tools/make_pmc_json.py.
-tag=${1:-r03}
+tag=${1:-r04}
 cd /root/repo
 out=/root/repo/gpurun_out/$tag
 rm -rf $out; mkdir -p $out
@@ -12,6 +12,11 @@ python bench.py --scenes-per-gpu 8 --steps 5 --warmup 2 --no-cpu-baseline > $out
 python bench.py --attention-mode fp16 --steps 10 --warmup 2 --no-cpu-baseline --no-b32 > $out/bench_fp16.json 2>> $out/bench.err
 python bench.py --train --steps 8 --warmup 2 > $out/bench_train.json 2>> $out/bench.err
 python bench.py --dim 1024 --steps 10 --warmup 2 --no-b32 > $out/bench_d1024.json 2>> $out/bench.err
+# the other BASELINE configurations as driver-reproducible lines (same JSON: workload string, roofline, bounded cpu_baseline)
+python bench.py --config cfg2 --steps 20 --warmup 3 > $out/bench_cfg2.json 2>> $out/bench.err
+python bench.py --config cfg5 --steps 10 --warmup 2 > $out/bench_cfg5.json 2>> $out/bench.err
+python bench.py --config shipped --steps 20 --warmup 3 > $out/bench_shipped.json 2>> $out/bench.err
+python bench.py --train --steps 8 --warmup 2 --phase-times > $out/bench_train_phases.json 2>> $out/bench.err
 python bench.py --gpus 2 --share-device --steps 5 --warmup 1 --no-cpu-baseline --no-b32 2>> $out/bench.err | grep "^{" > $out/bench_2ranks_shared.json
 export TMPDIR=/tmp
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-b32 > $out/kt.log 2>&1)
