@@ -173,6 +173,36 @@ def test_loss_matching_overlapped_with_the_forward_gives_the_same_step():
         assert float((ga[n] - gb[n]).norm()) <= 1e-4 * max(den, 1e-6), n      # float atomics in the backward: not bit-identical
 
 
+def test_targets_enqueued_behind_a_long_kernel_are_waited_for_by_the_overlapped_loss():
+    """The overlapped loss reads the caller's targets on a SIDE stream: targets that were produced asynchronously on
+    the main stream before the forward — here a pinned-memory copy queued behind ~20 ms of matrix products, into device buffers
+    that still hold other boxes — must be complete before parse_target reads them.  The side stream waits for the event recorded
+    at the entry of the training forward; the step equals the one with synchronously prepared targets."""
+    cfg = synth.decoder_cfg(dim=256, queries=64, heads=4, ffn=256, layers=4, dropout=0.0)
+    W = synth.make_decoder_weights(cfg, 831, damped=True)
+    sc = synth.make_scene(832, 2, 3, 32, 36, 256)
+    sc_t = [dev(sc[k]) for k in ("tokens", "camera", "T_camera_pseudoCam", "T_world_pseudoCam", "T_world_local")]
+    obbs_np, sym_np = synth.make_boxes(833, 2, 9)
+    wrong_np, wrong_sym = synth.make_boxes(834, 2, 3)
+    T_wl = Pose(sc_t[4])
+    dec = make_decoder(cfg, W).train()
+    assert dec.overlap_loss_matching
+    want, _ = _train_step_loss(dec, sc_t, Obb3D(dev(obbs_np)), T_wl, dev(sym_np), 5)
+    torch.cuda.synchronize()
+    # device buffers hold OTHER boxes; the right ones arrive by an asynchronous copy behind a long main-stream kernel
+    obbs_d, sym_d = dev(wrong_np), dev(wrong_sym)
+    obbs_h, sym_h = torch.from_numpy(obbs_np).pin_memory(), torch.from_numpy(sym_np).pin_memory()
+    big = torch.randn(8192, 8192, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(12):
+        big = (big @ big).clamp_(-1.0, 1.0)                 # ~20 ms of queue in front of the copies
+    obbs_d.copy_(obbs_h, non_blocking=True)
+    sym_d.copy_(sym_h, non_blocking=True)
+    got, _ = _train_step_loss(dec, sc_t, Obb3D(obbs_d), T_wl, sym_d, 5)
+    for k in TERMS:
+        assert abs(got[k] - want[k]) <= 1e-6 * max(1.0, abs(want[k])), (k, got[k], want[k])
+
+
 def test_deferred_range_check_is_repaired_by_loss_and_raised_by_backward_otherwise():
     """With overlap_loss_matching the autograd forward does not wait for the device; a forward whose tokens leave the fp16 range
     (NaN outputs) is re-run with the exact fp32 kernels INSIDE loss() (finite loss, finite gradients); if the outputs were

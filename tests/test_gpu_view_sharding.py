@@ -37,6 +37,11 @@ def test_two_rank_view_sharded_forward_equals_single_process(tmp_path):
             assert rk[tag]["worst_forced"] < 5e-5, rk
             assert rk[tag]["worst_free"] < 1e-4, rk
     assert res[0]["b2"]["views"] == [0, 3] and res[1]["b2"]["views"] == [3, 6]
+    # only rank 1's shard left the fp16 range: BOTH ranks flag it and decide alike (the flag is summed in the first exchange)
+    for rk in res:
+        lazy, sync = rk["range"]["lazy"], rk["range"]["sync"]
+        assert lazy["warned"] and lazy["mode_after"] == "fp32" and lazy["all_nan"], rk["range"]
+        assert sync["warned"] and sync["mode_after"] == "fp32" and sync["all_finite"] and sync["ranks_agree"], rk["range"]
 
 
 def test_single_process_view_sharded_call_equals_forward():

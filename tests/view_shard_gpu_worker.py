@@ -58,6 +58,34 @@ def main(out_path):
         dist.all_gather(gathered, t)
         res[tag] = {"worst_free": worst_free, "worst_forced": worst_forced,
                     "ranks_agree": bool(all(torch.equal(g, gathered[0]) for g in gathered)), "views": [lo, hi]}
+    # ---- fp16 operand range: ONE rank's shard is out of range.  The flag travels in the first exchange, so EVERY
+    # rank poisons its outputs (NaN, never unflagged numbers merged from the other rank's inf record) and every rank takes the
+    # same decision: "lazy" -> all warn and switch to the fp32 kernels; "sync" -> all re-run the forward with them.
+    import warnings
+    sc = synth.make_scene(93, 1, V, h, w, Cd, smooth=True)
+    lo, hi = parallel.view_shard(V, rank, world)
+    tok = sc["tokens"].reshape(1, V, h * w, Cd)[:, lo:hi].reshape(1, (hi - lo) * h * w, Cd).copy()
+    if rank == world - 1:
+        tok[0, 7, 3] = 9.0e4                                        # only the LAST rank holds an out-of-range token
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    local = (to(tok), to(sc["camera"][:, lo:hi]), to(sc["T_camera_pseudoCam"][:, lo:hi]), to(sc["T_world_pseudoCam"][:, lo:hi]),
+             to(sc["T_world_local"]))
+    rng = {}
+    for policy in ("lazy", "sync"):
+        dec = make_decoder(cfg, W)
+        dec.range_check = policy
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            outs = dec.forward_view_sharded(*local, feat_hw=(h, w))
+        torch.cuda.synchronize()
+        t = outs[-1]["center_unnormalized"]
+        rng[policy] = {"mode_after": dec.attention_mode, "warned": any("fp16 range" in str(r.message) for r in rec),
+                       "all_nan": bool(torch.isnan(t).all()), "all_finite": bool(torch.isfinite(t).all())}
+        if policy == "sync":                                        # the re-run must agree across the ranks
+            gathered = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(gathered, t.contiguous())
+            rng[policy]["ranks_agree"] = bool(all(torch.equal(g, gathered[0]) for g in gathered))
+    res["range"] = rng
     all_res = [None] * world
     dist.all_gather_object(all_res, res)
     if rank == 0:
