@@ -183,6 +183,10 @@ int bwd_sets(int I) {          // concurrent iterations of the batched chain bac
     int n = want < I ? want : I;
     return n < 1 ? 1 : (n > 8 ? 8 : n);
 }
+bool bwd_batched_ok(const parq_ctx* c, int64_t N);
+// the batched cross-attention backward at head dim 64 takes K / V straight from the forward's 16-bit cache: no fp32 rebuild
+// (kvsplit_to_f32: 0.57 ms and 1.5 GB of traffic per 4-scene step at cfg 3), no second copy of K / V in the training workspace
+bool bwd_reads_cache(const parq_ctx* c, const Workspace& ws) { return ws.bwd_batched && c->cache_mode() && c->dh == 64 && c->nl == 1; }
 bool bwd_batched_ok(const parq_ctx* c, int64_t N) {
     // head dim 64: the register-resident split kernel (long key axes); head dim 256: the composition from split-precision GEMMs
     return c->bwd_batched_env && c->nl == 1 && ((c->dh == 64 && N >= 2048) || c->dh == 256) && c->I > 1 && c->I <= 16;
@@ -243,7 +247,9 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     // cross_out^T, cross_q^T, self_out^T [C][C] each, self_in^T [C][3C], pe2^T [C][C], pe0^T [384][C]
     ws->wT = take(C * NH1 + 2 * C * C + 2 * C * F + 3 * C * C + 3 * C * C + C * C + 384 * C);
     ws->g_kv = take((int64_t)c->nl * B * 2 * N * C);
-    ws->kv_train = take(split_mode ? (int64_t)c->nl * B * 2 * N * C : 0);     // fp32 K / V rebuilt from the split cache for the backward
+    ws->bwd_batched = bwd_batched_ok(c, N);
+    // fp32 K / V rebuilt from the 16-bit cache for the backward — not needed where the backward reads the cache (bwd_reads_cache)
+    ws->kv_train = take(split_mode && !bwd_reads_cache(c, *ws) ? (int64_t)c->nl * B * 2 * N * C : 0);
     // batched cross-attention backward (see parq_backward): per-iteration dO, residual gradient, dQ and D rows, and one set of
     // dQ partials per iteration
     ws->bwd_batched = bwd_batched_ok(c, N);
@@ -1307,9 +1313,10 @@ int parq_forward_train(parq_handle h, const parq_scene* scene, void* workspace, 
         }
     }
     // (after the iterations, which do not read it: the stream gets to this while the host evaluates the loss)
-    if (h->cache_mode()) {
+    if (h->cache_mode() && !bwd_reads_cache(h, ws)) {
         // cache modes: the forward streams the 16-bit cache; the backward gets fp32 K / V rebuilt from it (hi + lo; in the fp16 /
-        // bf16 modes the rounded values themselves: the gradient is taken straight through the rounding)
+        // bf16 modes the rounded values themselves: the gradient is taken straight through the rounding).  Not at head dim 64 with
+        // the batched backward: attn_bwd_split2_kernel reads the cache itself (bwd_reads_cache)
         const int64_t N = (int64_t)scene->V * scene->h * scene->w;
         const int C = h->C, dh = h->dh, H = h->H, B = scene->B;
         for (int li = 0; li < h->nl; ++li) {
@@ -1429,7 +1436,8 @@ int parq_backward(parq_handle h, const parq_scene* scene, void* workspace, size_
                                        wsp + ws.g_Dall, (int64_t)B * H * flash_lq_pad(Q), wsp + ws.g_dq, MC, (int64_t)Q * C, dh, C, gkv,
                                        2 * N * C, dh, 2 * C, gkv + C, 2 * N * C, dh, 2 * C, B, H, Q, (int)N, dh, I, s, wsp + ws.g_dqp,
                                        h->drop_p, seeds, reinterpret_cast<unsigned int*>(wsp + ws.g_bs),
-                                       reinterpret_cast<unsigned int*>(wsp + ws.g_kvmax), wsp + ws.g_pack, wsp + ws.g_mat));
+                                       reinterpret_cast<unsigned int*>(wsp + ws.g_kvmax), wsp + ws.g_pack, wsp + ws.g_mat,
+                                       bwd_reads_cache(h, ws) ? reinterpret_cast<const void*>(wsp + ws.kvc) : nullptr, h->terms(), h->kind()));
         if (dh == 256) {                          // max |dK|, |dV| for the split-precision dW_kv GEMM (the dh = 64 kernel records it itself)
             HIPCHK(hipMemsetAsync(wsp + ws.g_kvmax, 0, sizeof(unsigned int), s));
             HIPCHK(launch_absmax(gkv, (int64_t)B * 2 * N * C, reinterpret_cast<unsigned int*>(wsp + ws.g_kvmax), s));

@@ -43,6 +43,10 @@ struct AttnBwdArgs {
     int64_t q_off[kMaxBwdIters], lse_off[kMaxBwdIters];
     uint32_t seeds[kMaxBwdIters];
     unsigned int* kv_absmax;   // optional: atomicMax of the bit pattern of |dK|, |dV| as written (scale of the projection backward)
+    // split kernel, second version: K / V straight from the forward's 16-bit cache (flash_split.hip layout: 32-key blocks
+    // [K_hi | K_lo | V_hi | V_lo], or [K | V] in the single-product modes) instead of fp32 k / v rebuilt from it
+    const _Float16* kvcache;
+    int cache_kind;            // kF16 / kBF16 of a single-product cache
     int probe;                     // development build only (PARQ_ATTN_BWD_PROBE): pieces of attn_bwd_split2_kernel left out, for timing
 };
 
@@ -670,7 +674,9 @@ __global__ __launch_bounds__(256) void attn_bwd_pack_kernel(AttnBwdArgs a, const
 // measured 18.2 -> 16.6 ms; the first version needs them to stay inside its register budget)
 // PIPE (round 3): the dQ tile of query tile n - 1 is computed next to the softmax / dS arithmetic of tile n instead of at the end
 // of its own tile — same results (same operands, same order inside every accumulation), two barriers per tile as before.
-template <bool DROP, bool RAGGED, int PIPE = 1>
+// CACHE: 0 = fp32 K / V (a.k, a.v); 3 / 1 = the forward's split / single-product cache (a.kvcache): the hi / lo pairs the forward
+// multiplied are used as they are (no fp32 rebuild pass over 2 N C floats per scene, no second copy of K / V in HBM)
+template <bool DROP, bool RAGGED, int PIPE = 1, int CACHE = 0>
 __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, const float* __restrict__ oscale_ptr,
                                                               const _Float16* __restrict__ pack) {
     const float oscale = *oscale_ptr;
@@ -698,7 +704,53 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
 
     // ---- K, V of this lane's key as B fragments: step t holds d = 16 t + 8 kh + e; K also goes into LDS (natural layout)
     half8 kfh[4], kfl[4], vfh[4], vfl[4];
-    {
+    if constexpr (CACHE != 0) {
+        // this wave's 32 keys are ONE cache block (key li of block 8 blockIdx.x + wave).  K_x: [32 keys][8 chunks][8]; chunk 4 kh' + s
+        // holds d = 32 (s >> 1) + 16 (s & 1) + 4 kh' + (e & 3) + 8 (e >> 2), stored at chunk position c ^ ((key >> 1) & 7): the eight
+        // d = 16 t + 8 kh + e of fragment t are elements 4 kh .. 4 kh + 3 of chunks t (e < 4) and 4 + t (e >= 4).  V_x: [64 d][4 chunks][8];
+        // chunk 2 m + kh'' holds keys 16 m + 4 kh'' + (e & 3) + 8 (e >> 2) at position c ^ ((d >> 2) & 3): one 16-bit element per d.
+        constexpr int kBH = CACHE == 3 ? 8192 : 4096, kVo = CACHE == 3 ? 4096 : 2048;
+        const int nblk = (a.Lk + 31) >> 5;
+        int blk = blockIdx.x * (kSpKW / 32) + wave;
+        blk = blk < nblk ? blk : nblk - 1;                         // past the end: any valid block (masked by jok below)
+        const _Float16* cb = a.kvcache + ((int64_t)bh * nblk + blk) * kBH;
+        const int ksw = (li >> 1) & 7;
+        const int vr = li & 15, vc = 2 * (li >> 4) + ((vr & 7) >> 2), ve = (vr & 3) + 4 * (vr >> 3);
+        const half8 zero8 = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        auto widen = [&](half8 raw, half8& hi, half8& lo) {          // single-product cache: the 16-bit value is the operand
+            if constexpr (CACHE == 3) { hi = raw; return; }
+            if (a.cache_kind == kBF16) {                            // bf16 bits -> fp32 -> fp16 hi / lo (exact: 8 significant bits)
+                const bf16x8 bv = __builtin_bit_cast(bf16x8, raw);
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = (float)bv[e];
+                split8(x, hi, lo);
+            } else { hi = raw; lo = zero8; }
+        };
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int o0 = li * 64 + ((t ^ ksw) << 3) + 4 * kh, o1 = li * 64 + (((4 + t) ^ ksw) << 3) + 4 * kh;
+            half8 kh8 = cat4(*reinterpret_cast<const half4v*>(cb + o0), *reinterpret_cast<const half4v*>(cb + o1));
+            half8 kl8 = zero8;
+            if constexpr (CACHE == 3) kl8 = cat4(*reinterpret_cast<const half4v*>(cb + 2048 + o0), *reinterpret_cast<const half4v*>(cb + 2048 + o1));
+            half8 vh8, vl8 = zero8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int d = 16 * t + 8 * kh + e;
+                const int ov = kVo + d * 32 + ((vc ^ ((d >> 2) & 3)) << 3) + ve;
+                vh8[e] = cb[ov];
+                if constexpr (CACHE == 3) vl8[e] = cb[2048 + ov];
+            }
+            widen(kh8, kfh[t], kl8);
+            if constexpr (CACHE == 3) kfl[t] = kl8; else kfl[t] = kl8;
+            widen(vh8, vfh[t], vl8);
+            vfl[t] = vl8;
+            if (!jok) { kfh[t] = zero8; kfl[t] = zero8; vfh[t] = zero8; vfl[t] = zero8; }
+            const int off = jw * 64 + (((2 * t + kh) ^ img_swz(jw)) << 3);
+            *reinterpret_cast<half8*>(Ki + off) = kfh[t];
+            *reinterpret_cast<half8*>(Ki + 16384 + off) = kfl[t];
+        }
+    } else {
         const float* kp = a.k + (int64_t)b * a.k_batch + (int64_t)h * a.k_head + (int64_t)(jok ? j : 0) * a.k_row;
         const float* vp = a.v + (int64_t)b * a.v_batch + (int64_t)h * a.v_head + (int64_t)(jok ? j : 0) * a.v_row;
 #pragma unroll
@@ -1313,7 +1365,8 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
                                    int64_t gq_batch, int64_t gq_head, int64_t gq_row, float* gk, int64_t gk_batch, int64_t gk_head,
                                    int64_t gk_row, float* gv, int64_t gv_batch, int64_t gv_head, int64_t gv_row, int B, int H, int Lq,
                                    int Lk, int dh, int n_it, hipStream_t s, float* gq_part, float drop_p, const uint32_t* seeds,
-                                   unsigned int* absmax, unsigned int* kv_absmax, void* pack, float* mat_scratch) {
+                                   unsigned int* absmax, unsigned int* kv_absmax, void* pack, float* mat_scratch, const void* kvcache,
+                                   int cache_terms, int cache_kind) {
     if (n_it < 1 || n_it > kMaxBwdIters || !absmax) return hipErrorInvalidValue;
     if (dh == 256 ? !mat_scratch : (dh != 64 || Lk < 2048 || !gq_part)) return hipErrorInvalidValue;
     AttnBwdArgs a;
@@ -1329,6 +1382,7 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.accumulate_kv = 0; a.gq_part = gq_part;
     a.drop_p = drop_p; a.drop_seed = seeds ? seeds[0] : 0;
     a.n_it = n_it; a.do_it = do_it; a.D_it = D_it; a.kv_absmax = kv_absmax;
+    a.kvcache = reinterpret_cast<const _Float16*>(kvcache); a.cache_kind = cache_kind;
     if (kv_absmax) {
         hipError_t e0 = hipMemsetAsync(kv_absmax, 0, sizeof(unsigned int), s);
         if (e0 != hipSuccess) return e0;
@@ -1350,11 +1404,13 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
     dim3 g2(ceil_div(Lk, kSpKW), B * H);
     const int Lq_pad = (Lq + 31) & ~31;
     static const bool v1 = [] { const char* e = dev_env("PARQ_ATTN_BWD_V"); return e && e[0] == '1'; }();
+    if (kvcache && (v1 || !pack)) return hipErrorNotSupported;          // only the second-version kernel reads the 16-bit cache
     if (pack && !v1) {
         // second version: tile images packed once, fetched by LDS-DMA; transpose reads
         constexpr size_t lds2 = (size_t)(2 * 8192 + 2 * 16384 + 2 * kImgHalfs) * sizeof(_Float16);
         const bool rag = (Lk % kSpKW) != 0;
         static const int pipe = [] { const char* e = dev_env("PARQ_ATTN_BWD_PIPE"); return e ? atoi(e) : 1; }();
+        if (kvcache && pipe != 1) return hipErrorNotSupported;
         _Float16* pk = reinterpret_cast<_Float16*>(pack);
         static const int probe = [] { const char* e = dev_env("PARQ_ATTN_BWD_PROBE"); return e ? atoi(e) : 0; }();
         a.probe = probe;
@@ -1366,7 +1422,22 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
             if (e != hipSuccess) return e;                                                                                     \
             hipLaunchKernelGGL((attn_bwd_split2_kernel<DROP_, RAG_, PIPE_>), g2, dim3(512), lds2, s, a, oscale, pk);           \
         }
-        if (pipe == 1) {
+#define PARQ_BWD2C(DROP_, RAG_, C_)                                                                                           \
+        {                                                                                                                      \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_split2_kernel<DROP_, RAG_, 1, C_>),                 \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                                    \
+            if (e != hipSuccess) return e;                                                                                     \
+            hipLaunchKernelGGL((attn_bwd_split2_kernel<DROP_, RAG_, 1, C_>), g2, dim3(512), lds2, s, a, oscale, pk);          \
+        }
+        if (kvcache && pipe == 1 && (cache_terms == 3 || cache_terms == 1)) {       // K / V from the forward's 16-bit cache
+            if (cache_terms == 3) {
+                if (drop_p > 0.f) { if (rag) PARQ_BWD2C(true, true, 3) else PARQ_BWD2C(true, false, 3) }
+                else { if (rag) PARQ_BWD2C(false, true, 3) else PARQ_BWD2C(false, false, 3) }
+            } else {
+                if (drop_p > 0.f) { if (rag) PARQ_BWD2C(true, true, 1) else PARQ_BWD2C(true, false, 1) }
+                else { if (rag) PARQ_BWD2C(false, true, 1) else PARQ_BWD2C(false, false, 1) }
+            }
+        } else if (pipe == 1) {
             if (drop_p > 0.f) { if (rag) PARQ_BWD2(true, true, 1) else PARQ_BWD2(true, false, 1) }
             else { if (rag) PARQ_BWD2(false, true, 1) else PARQ_BWD2(false, false, 1) }
         } else if (pipe == 2) {
@@ -1377,6 +1448,7 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
             else { if (rag) PARQ_BWD2(false, true, 0) else PARQ_BWD2(false, false, 0) }
         }
 #undef PARQ_BWD2
+#undef PARQ_BWD2C
     } else {
         e = split_bwd_lds_attr();
         if (e != hipSuccess) return e;

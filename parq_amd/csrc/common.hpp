@@ -418,7 +418,9 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
                                    int Lk, int dh, int n_it, hipStream_t s, float* gq_part, float drop_p, const uint32_t* seeds,
                                    unsigned int* absmax, unsigned int* kv_absmax = nullptr,    // kv_absmax: out, max |dK|, |dV| (float bits)
                                    void* pack = nullptr,
-                                   float* mat_scratch = nullptr);  // pack: attn_bwd_pack_floats(...) floats of scratch -> second-version kernel;
+                                   float* mat_scratch = nullptr,
+                                   const void* kvcache = nullptr, int cache_terms = 0, int cache_kind = 0);   // head dim 64: K / V from the 16-bit cache
+                                                                   // pack: attn_bwd_pack_floats(...) floats of scratch -> second-version kernel;
                                                                    // mat_scratch (dh == 256): attn_bwd_batched256_scratch_floats(n_it, Lq, Lk) floats
 size_t attn_bwd_pack_floats(int B, int H, int Lq, int n_it);
 // kvproj_bwd.hip: dW_kv / db_kv of the hoisted projection on the fp16 matrix pipe (hi/lo split), C = 256
