@@ -149,7 +149,10 @@ def project_sample_b32(dec, device, h, w, scenes=32, steps=2):
             "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": ms / n, "launches": n,
             "forward_kernel_ms_at_%d_scenes" % scenes: fw_ms,
             "note": "tokens of %d scenes = %.1f GB (past the 256 MB Infinity Cache): a bandwidth figure; the B = 1 entry "
-                    "(roofline_project_sample) is latency-bound" % (scenes, scenes * V * h * w * C * 4 / 1e9)}
+                    "(roofline_project_sample) is latency-bound.  `achieved` / `frac` are ALGORITHMIC bytes per second (BASELINE.md's "
+                    "definition of the >= 40 %% target); `traffic` (counter bytes) is about half of them: a query's four corner rows "
+                    "and neighbouring queries' texels are served again from L2 / the Infinity Cache, so the HBM side moves ~0.3 of peak"
+                    % (scenes, scenes * V * h * w * C * 4 / 1e9)}
 
 
 def _amdgpu_sysfs(index):

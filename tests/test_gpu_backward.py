@@ -500,3 +500,45 @@ def test_training_in_reduced_precision_attention_modes(mode, out_tol, grad_tol, 
     assert all(torch.isfinite(v).all() for v in g2.values()) and torch.isfinite(t2).all()
     name = "parq_module.decoder.layers.0.multihead_attn.out_proj.weight"
     assert float((g2[name] - grads[name]).norm()) > 1e-3 * float(grads[name].norm())
+
+
+def test_gradient_buckets_partition_the_arena_in_completion_order():
+    """parq_grad_bucket (include/parq_hip.h): bucket 0 = what is final after phase 1 of the batched backward — cross out-proj, FFN,
+    norm2 / norm3 and every head — bucket 1 = the front of the arena (reference points, position MLP, in-projections, self
+    out-proj, norm1).  Every reference tensor lies in exactly one of the two contiguous ranges, the ranges are adjacent, and
+    averaging them one after the other on ONE rank is the identity (world = 1 path of the bucketed all-reduce)."""
+    import ctypes as C
+    from parq_amd import _lib
+    cfg = synth.decoder_cfg(dim=128, queries=16, heads=2, ffn=96, layers=2)
+    dec = make_decoder(cfg, synth.make_decoder_weights(cfg, 191))
+    lib, h = _lib.load(), dec._handle()
+    off, cnt = C.c_int64(), C.c_int64()
+    rng = []
+    for b in (0, 1):
+        _lib.check(lib.parq_grad_bucket(h, b, C.byref(off), C.byref(cnt)), "parq_grad_bucket")
+        rng.append((off.value, cnt.value))
+    (o0, n0), (o1, n1) = rng
+    assert o1 == 0 and n1 > 0 and o0 == n1 and n0 > 0                     # late bucket in front, early bucket right behind it
+    assert (o0 + n0) * 4 <= lib.parq_grad_arena_bytes(h)
+    early = ("multihead_attn.out_proj", "linear1", "linear2", "norm2", "norm3", "mlp_heads.")
+    o, r, c_, ld = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    seen = {0: 0, 1: 0}
+    for name, p in dec._unique_params():
+        if name.startswith("parq_module.decoder.norm."):
+            continue
+        _lib.check(lib.parq_arena_lookup(h, name.encode(), C.byref(o), C.byref(r), C.byref(c_), C.byref(ld)), name)
+        first, last = o.value, o.value + (r.value - 1) * ld.value + c_.value
+        in0 = o0 <= first and last <= o0 + n0
+        in1 = o1 <= first and last <= o1 + n1
+        assert in0 != in1, name
+        assert in0 == any(k in name for k in early), (name, in0)
+        seen[0 if in0 else 1] += 1
+    assert seen[0] >= 20 and seen[1] >= 10, seen
+    # unshared layers: one bucket (the layers interleave), still covering everything
+    cfg2 = synth.decoder_cfg(dim=128, queries=16, heads=2, ffn=96, layers=2, share_weights=False)
+    dec2 = make_decoder(cfg2, synth.make_decoder_weights(cfg2, 192))
+    h2 = dec2._handle()
+    _lib.check(lib.parq_grad_bucket(h2, 0, C.byref(off), C.byref(cnt)), "parq_grad_bucket")
+    assert cnt.value == 0
+    _lib.check(lib.parq_grad_bucket(h2, 1, C.byref(off), C.byref(cnt)), "parq_grad_bucket")
+    assert off.value == 0 and cnt.value * 4 == lib.parq_grad_arena_bytes(h2)
