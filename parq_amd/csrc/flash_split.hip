@@ -600,6 +600,47 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
         PARQ_FENCE();
         PARQ_P(1, vh[1], Plo[NXT][1]);
         mx_lane_out = mx_lane;
+        } else if constexpr (TERMS == 3 && (VAR & 64) != 0 && !(PROBE & 1)) {
+        // VAR & 64: accumulator RUNS — consecutive MFMAs on the same accumulator (6 QK, 3 + 3 PV, 6 QK, 3 + 3 PV) instead of
+        // alternating S^T / O^T: a back-to-back dependent MFMA takes its C operand from the pipeline (no 4 KB accumulator read + write
+        // through the register file per MFMA), which is what a power-bound kernel would gain from; a softmax pair behind every third
+        PARQ_Q(0, kf[0], qhi[0]);
+        PARQ_Q(1, kf[0], qlo[0]);
+        PARQ_Q(2, kf[1], qhi[0]);  PARQ_S(0);
+        PARQ_Q(3, kf[2], qhi[1]);
+        PARQ_Q(4, kf[2], qlo[1]);
+        PARQ_Q(5, kf[3], qhi[1]);  PARQ_S(1);
+        if constexpr ((VAR & 2) != 0) { load_k_pair(lds_blk(n + 2 < nbk ? n + 2 : nbk - 1), kf, std::integral_constant<int, 0>{}); PARQ_FENCE(); }
+        PARQ_P(0, vh[0], Phi[NXT][0]);
+        PARQ_P(0, vl[0], Phi[NXT][0]);
+        PARQ_P(0, vh[0], Plo[NXT][0]);  PARQ_S(2);
+        PARQ_P(1, vh[1], Phi[NXT][0]);
+        PARQ_P(1, vl[1], Phi[NXT][0]);
+        PARQ_P(1, vh[1], Plo[NXT][0]);  PARQ_S(3);
+        load_v(Vb, 1, vh, vl);
+        PARQ_FENCE();
+        PARQ_Q(6, kf[4], qhi[2]);
+        PARQ_Q(7, kf[4], qlo[2]);
+        PARQ_Q(8, kf[5], qhi[2]);  PARQ_S(4);
+        PARQ_Q(9, kf[6], qhi[3]);
+        PARQ_Q(10, kf[6], qlo[3]);
+        PARQ_Q(11, kf[7], qhi[3]);  PARQ_S(5);
+        PARQ_P(0, vh[0], Phi[NXT][1]);
+        PARQ_P(0, vl[0], Phi[NXT][1]);
+        PARQ_P(0, vh[0], Plo[NXT][1]);  PARQ_S(6);
+        PARQ_P(1, vh[1], Phi[NXT][1]);
+        PARQ_P(1, vl[1], Phi[NXT][1]);  PARQ_S(7);
+        float mx_lane;
+        {
+            const f32x16& S = sacc[NXT];
+            float m0 = fmaxf(S[0], S[1]), m1 = fmaxf(S[8], S[9]);
+#pragma unroll
+            for (int r = 2; r < 8; ++r) { m0 = fmaxf(m0, S[r]); m1 = fmaxf(m1, S[8 + r]); }
+            mx_lane = fmaxf(m0, m1);
+        }
+        PARQ_FENCE();
+        PARQ_P(1, vh[1], Plo[NXT][1]);
+        mx_lane_out = mx_lane;
         } else if constexpr (TERMS == 3) {
         // m = 0 half of PV(n - 1), s = 0, 1 of QK(n + 1); 8 softmax pairs (16 scores per lane and block), one behind every third MFMA
         PARQ_Q(0, kf[0], qhi[0]);
@@ -927,6 +968,8 @@ hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t
         case 31: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 31)
         case 32: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 32)
         case 59: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 59)
+        case 91: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 91)
+        case 89: PARQ_PIPE_LAUNCH_V(4, 0, 3, kF16, false, 89)
         default: return hipErrorInvalidValue;
     }
 #endif

@@ -94,7 +94,7 @@ def all_reduce_mean_(flat: torch.Tensor) -> torch.Tensor:
     return flat
 
 
-def all_reduce_mean_buckets_(flat: torch.Tensor, buckets, ready=None, side_stream=None) -> torch.Tensor:
+def all_reduce_mean_buckets_(flat: torch.Tensor, buckets, ready=None, side_stream=None, _force=False) -> torch.Tensor:
     """``all_reduce_mean_`` of one flat gradient buffer in BUCKETS: ``buckets`` = [(offset, count), ...] in the order the
     producer finishes them (include/parq_hip.h parq_grad_bucket: bucket 0 is final after phase 1 of parq_backward, half a step
     before the rest).  ``ready(i, stream)`` (GPU: parq_backward_wait_bucket) makes ``stream`` wait, on the device, until bucket i
@@ -102,8 +102,8 @@ def all_reduce_mean_buckets_(flat: torch.Tensor, buckets, ready=None, side_strea
     enqueued on the main stream, and the main stream joins the collectives at the end (what DDP's bucketed, overlapped all-reduce
     does for the reference, train.py:103-108).  Ranges outside the buckets are not touched; empty buckets are skipped.  On CPU
     tensors (the gloo tests) the buckets are reduced one after the other.  Same result as the flat all-reduce: a mean per element."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return flat
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not _force):
+        return flat                                  # (_force: the one-rank RCCL test runs the stream protocol anyway)
     world = dist.get_world_size()
     buckets = [(int(o), int(n)) for o, n in buckets if int(n) > 0]
     if not flat.is_cuda or side_stream is None:
@@ -124,12 +124,12 @@ def all_reduce_mean_buckets_(flat: torch.Tensor, buckets, ready=None, side_strea
             view = flat[o:o + n]
             works.append(dist.all_reduce(view, async_op=True))
             # (RCCL: the collective is ordered behind `side_stream`; gloo on device tensors: the work object completes on wait())
-    for w in works:
-        w.wait()                                     # RCCL: the current stream of THIS context waits for the collective
     with torch.cuda.stream(side_stream):
-        for o, n in buckets:
+        for w in works:
+            w.wait()                                 # RCCL: the CURRENT stream — the side stream — waits for the collective
+        for o, n in buckets:                         # (gloo on device tensors: wait() blocks the host until the result is back)
             flat[o:o + n] /= world
-    main.wait_stream(side_stream)
+    main.wait_stream(side_stream)                    # the main stream joins once, behind the last bucket's mean
     flat.record_stream(side_stream)
     return flat
 

@@ -31,6 +31,20 @@ assert torch.equal(parts[0], x)
 sys.path.insert(0, sys.argv[1])
 from parq_amd import parallel
 assert parallel.max_over_ranks(1.25, device=dev) == 1.25
+assert parallel.gather_over_ranks(2.5, device=dev) == [2.5]
+# the bucketed gradient all-reduce of PARQDecoder.backward through RCCL: two buckets issued on a side stream behind a long
+# main-stream kernel that PRODUCES the buffer (ready=None: the side stream waits for the main stream), mean over one rank =
+# identity, the main stream joins at the end
+big = torch.randn(4096, 4096, device=dev)
+for _ in range(8):
+    big = (big @ big).clamp_(-1.0, 1.0)
+arena = (big.flatten()[:1475000] * 0.5 + 1.0).contiguous()                  # written behind the matrix products
+want = arena.clone()
+side = torch.cuda.Stream(device=dev)
+parallel.all_reduce_mean_buckets_(arena, [(800000, 675000), (0, 800000)], side_stream=side, _force=True)
+got = arena * 1.0                                                            # consumer on the main stream
+torch.cuda.synchronize()
+assert torch.equal(got, want)
 dist.destroy_process_group()
 print("RCCL_OK", torch.cuda.nccl.version())
 """
