@@ -35,6 +35,8 @@ Cases:
                  tensors up to 8192 elements, else norm + sum + strided sample), a strided sample of d tokens, and the names of
                  the parameters the reference leaves without gradient.  Pins detach placement (transformer_parq.py:331-332),
                  the no-grad probabilities (:261-265), the arg-max size gather (utils/parq_utils.py:96-98) and the loss
+  g20_raype_grads gradients of the reference's AddRayPE under its own autograd (float64): tokens = features + encoding, tokenised as
+                 model/parq_lightning.py:72-85 does, loss = <cotangent, tokens>; d encoder.{0,2}.{weight,bias} and d features
   g18_cfg3_smooth BASELINE cfg 3's geometry (10 views 120x160, Q=256, I=8, d=256) on SMOOTH (FPN-like) features, where the
                  reference's fp32 run stays within ~6e-5 of its float64 evaluation: consumed teacher-forced at an UNRELAXED 1e-4
   g19_cfg2       BASELINE cfg 2's exact geometry: 5 views 120x160 (N = 96 000), Q=128, I=4, d=256, smooth features
@@ -122,6 +124,44 @@ def grad_summary(g):
     if g.size <= GRAD_FULL_MAX:
         return {"full": g}
     return {"norm": np.array([np.linalg.norm(g), g.sum()]), "sample": g[::GRAD_STRIDE].copy()}
+
+
+RAYPE_GRAD_CASE = dict(dim=256, seed=91, gseed=92, fseed=93, cseed=94, B=2, V=3, h=7, w=9,
+                       ray_points_scale=[-3.0, 3.0, -2.0, 0.5, 0.25, 5.25])
+
+
+def raype_grad_case_inputs(c):
+    Wp = synth.make_ray_pe_weights(c["dim"], c["seed"])
+    geom = synth.make_geometry(c["gseed"], c["B"], c["V"], c["h"], c["w"])
+    feat = synth.normal(c["fseed"], "feat", (c["B"], c["V"], c["dim"], c["h"], c["w"]))
+    cot = synth.normal(c["cseed"], "cot", (c["B"], c["V"] * c["h"] * c["w"], c["dim"]))
+    return Wp, geom, feat, cot
+
+
+def make_raype_grad_golden(ref):
+    """g20: the reference's AddRayPE (model/ray_positional_encoding.py:61-139) in float64 under its own autograd, composed as
+    PARQ.forward composes it (model/parq_lightning.py:72-85: images_feat = features + encoding, then 'b t c h w -> b (t h w) c')."""
+    from einops import rearrange
+    c = RAYPE_GRAD_CASE
+    Wp, (cam, T_cp, T_wp, T_wl), feat, cot = raype_grad_case_inputs(c)
+    pe = ref.AddRayPE(c["dim"], c["ray_points_scale"], 64, 0.25, 5.25).double()
+    pe.load_state_dict({k: torch.from_numpy(v).double() for k, v in Wp.items()}, strict=True)
+    f = torch.from_numpy(feat).double().requires_grad_(True)
+    dbl = lambda a: torch.from_numpy(a).double()
+    enc = pe(f, ref.Camera(dbl(cam)), ref.Pose(dbl(T_cp)), ref.Pose(dbl(T_wp)), ref.Pose(dbl(T_wl)))
+    tokens = rearrange(f + enc, "b t c h w -> b (t h w) c")
+    loss = (tokens * dbl(cot)).sum()
+    loss.backward()
+    arrays = {"loss_value": np.float64(float(loss.detach())), "tokens_sample": tokens.detach().numpy()[:, ::11, ::7].copy()}
+    for name, p in pe.named_parameters():
+        for k, v in grad_summary(p.grad.numpy()).items():
+            arrays["grad/%s/%s" % (name, k)] = v
+    fg = f.grad.numpy().reshape(-1)
+    arrays["dfeat/norm"] = np.array([np.linalg.norm(fg), fg.sum()])
+    arrays["dfeat/sample"] = fg[::TOKEN_STRIDE].copy()
+    arrays["meta"] = np.frombuffer(json.dumps(c, sort_keys=True).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT_DIR, "g20_raype_grads.npz"), **arrays)
+    print("wrote g20_raype_grads: loss %.6f, %d arrays" % (float(loss.detach()), len(arrays)))
 
 
 def make_grad_golden(ref):
@@ -380,6 +420,8 @@ def main(only=None):
         make_module_golden(ref)
     if not only or "g17_grads" in only:
         make_grad_golden(ref)
+    if not only or "g20_raype_grads" in only:
+        make_raype_grad_golden(ref)
     if not only or "g10_loss" in only:
         make_loss_golden(ref)
     if not only or "g11_parse_pred" in only:

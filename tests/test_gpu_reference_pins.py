@@ -85,6 +85,36 @@ def test_gradients_match_reference_autograd(tag, kind):
     assert fro < 2e-3 and mx < 2e-2, ("d tokens", fro, mx)
 
 
+def test_ray_pe_gradients_match_reference_autograd():
+    """g20: AddRayPE.tokens as an autograd node (HIP forward + parq_ray_pe_backward), in eval() mode like the reference fixture,
+    against the reference's own autograd (float64): tokens, d encoder.{0,2}.{weight,bias} (1e-4 Frobenius), d features."""
+    import json
+    from parq_amd import AddRayPE
+    z = np.load(os.path.join(G.GOLDEN_DIR, "g20_raype_grads.npz"))
+    c = json.loads(bytes(z["meta"]).decode())
+    Wp, (cam, T_cp, T_wp, T_wl), feat, cot = MG.raype_grad_case_inputs(c)
+    pe = AddRayPE(c["dim"], c["ray_points_scale"], 64, 0.25, 5.25)
+    pe.load_state_dict({k: torch.from_numpy(v) for k, v in Wp.items()}, strict=True)
+    pe = pe.cuda().eval()
+    fg = torch.from_numpy(feat).cuda().requires_grad_(True)
+    tok = pe.tokens(fg, dev(cam), dev(T_cp), dev(T_wp), dev(T_wl))
+    assert tok.requires_grad
+    assert np.abs(tok.detach().cpu().numpy()[:, ::11, ::7] - z["tokens_sample"]).max() < 2e-5
+    (tok * torch.from_numpy(cot).cuda()).sum().backward()
+    for name, p in pe.named_parameters():
+        g = p.grad.cpu().numpy().astype(np.float64).reshape(-1)
+        if "grad/%s/full" % name in z.files:
+            ref = z["grad/%s/full" % name]
+            err = np.linalg.norm(g - ref) / np.linalg.norm(ref)
+        else:
+            ref = z["grad/%s/sample" % name]
+            err = max(np.linalg.norm(g[::MG.GRAD_STRIDE] - ref) / np.linalg.norm(ref),
+                      abs(np.linalg.norm(g) - z["grad/%s/norm" % name][0]) / z["grad/%s/norm" % name][0])
+        assert err < 1e-4, (name, err)
+    d = fg.grad.cpu().numpy().astype(np.float64).reshape(-1)
+    assert np.abs(d[::MG.TOKEN_STRIDE] - z["dfeat/sample"]).max() < 1e-6
+
+
 # ----------------------------------------------------------------------------------------------------------- g18 / g19
 def _teacher_forced_unrelaxed(name, mode, tol, table):
     case, z = G.load(name)

@@ -81,3 +81,36 @@ def test_oracle_autograd_equals_reference_autograd(tag, kind):
     fro, mx = G.token_grad_errors(z, tag, kind, od.tokens.grad.numpy())
     assert fro < tol_g and mx < tol_g, ("d tokens", fro, mx)
     print("\n%s %s: oracle autograd vs reference autograd, worst relative error %.2e (tokens %.2e)" % (tag, kind, worst, max(fro, mx)))
+
+
+def test_oracle_ray_pe_autograd_equals_reference_autograd(monkeypatch):
+    """g20: the reference's AddRayPE under its own autograd (float64; tokens = features + encoding, tokenised as
+    model/parq_lightning.py:72-85) against the oracle's ray_pe + tokenize: loss, a token sample, the four encoder gradients and
+    d features."""
+    import json
+    import os
+    z = np.load(os.path.join(G.GOLDEN_DIR, "g20_raype_grads.npz"))
+    c = json.loads(bytes(z["meta"]).decode())
+    assert c == MG.RAYPE_GRAD_CASE
+    Wp, (cam, T_cp, T_wp, T_wl), feat, cot = MG.raype_grad_case_inputs(c)
+    W64 = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in Wp.items()}
+    f64 = torch.from_numpy(feat).double().requires_grad_(True)
+    monkeypatch.setattr(O, "_as_torch", lambda Wd, dtype: Wd)            # leaf tensors passed through unchanged
+    enc = O.ray_pe(cam, T_cp, T_wp, T_wl, W64, c["ray_points_scale"], dtype=torch.float64)
+    tokens = O.tokenize(f64, enc)
+    loss = (tokens * torch.from_numpy(cot).double()).sum()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(z["loss_value"])) < 1e-9 * abs(float(z["loss_value"]))
+    assert np.abs(tokens.detach().numpy()[:, ::11, ::7] - z["tokens_sample"]).max() < 1e-10
+    for name, t in W64.items():
+        g = t.grad.numpy().reshape(-1)
+        if "grad/%s/full" % name in z.files:
+            ref = z["grad/%s/full" % name]
+            err = np.linalg.norm(g - ref) / np.linalg.norm(ref)
+        else:
+            ref = z["grad/%s/sample" % name]
+            err = max(np.linalg.norm(g[::MG.GRAD_STRIDE] - ref) / np.linalg.norm(ref),
+                      abs(np.linalg.norm(g) - z["grad/%s/norm" % name][0]) / z["grad/%s/norm" % name][0])
+        assert err < 1e-9, (name, err)
+    fg = f64.grad.numpy().reshape(-1)
+    assert np.abs(fg[::MG.TOKEN_STRIDE] - z["dfeat/sample"]).max() < 1e-12
