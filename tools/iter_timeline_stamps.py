@@ -14,7 +14,8 @@ import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np   # noqa: E402
-import torch         # noqa: E402
+import torch
+torch.set_grad_enabled(False)      # inference tools: the reference's drivers run these calls under no_grad (eval.py:46)         # noqa: E402
 
 from parq_amd import _lib   # noqa: E402
 
