@@ -3,6 +3,7 @@
 PARQ_KVPROJ_PROBE / PARQ_FLASH_PROBE select ingredient-removed kernels."""
 import os, subprocess, sys, threading, time
 import torch
+torch.set_grad_enabled(False)      # inference tool: the reference's drivers run these calls under no_grad (eval.py:46)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from parq_amd import _lib
 _lib.use_dev_library()          # the PARQ_*_PROBE switches exist in the development library only

@@ -2,6 +2,7 @@
 process loads the code objects, the next ~12 run 2-12 % slow while the clock / power controller settles (why bench.py spins the
 device up before its warm-up steps)."""
 import os, sys, torch
+torch.set_grad_enabled(False)      # inference tool: the reference's drivers run these calls under no_grad (eval.py:46)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 device = torch.device("cuda", 0)

@@ -2,6 +2,7 @@
 8 iterations) on the BASELINE cfg-3 geometry (10 views, 120x160 features).  Not the headline metric (BASELINE.json quotes d=256)."""
 import os, sys, time
 import torch
+torch.set_grad_enabled(False)      # inference tool: the reference's drivers run these calls under no_grad (eval.py:46)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 bench.WORKLOAD["dim"] = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
