@@ -170,7 +170,10 @@ int parq_iterate_sharded(parq_handle h, const parq_scene *scene, void *workspace
 
 /* Introspection for parity tests: where a named intermediate of the last parq_iterate lives
  * inside the workspace (offset and element count in floats).  Names: "T_camera_local_f64" and
- * "gn_sums_f64" (float64 payloads), "kv_cache", "ref", "ref_next", "posemb", "pos_feat", "tgt",
+ * "gn_sums_f64" (float64 payloads), "kv_cache", "ref", "ref_next", "posemb" (after an iteration: pos2posemb3d of the NEXT
+ * reference points, written by the decode kernel), "pos_hidden" (relu of the position MLP's first layer for THIS iteration's
+ * reference points), "pos_feat" (the position MLP's output; only written where its last layer is not folded into the two
+ * in-projections that consume it, i.e. by the training forward), "tgt",
  * "self_qkv", "attn", "xa_prenorm1", "cross_q", "xb_prenorm2", "ffn_hidden", "xc_prenorm3",
  * "heads1", "heads2", "ln1_stats", "ln2_stats", "flags". */
 int parq_workspace_lookup(parq_handle h, int32_t B, int32_t V, int32_t hh, int32_t ww, const char *name,

@@ -1220,7 +1220,7 @@ int parq_workspace_lookup(parq_handle h, int32_t B, int32_t V, int32_t hh, int32
     const E table[] = {
         {"T_camera_local_f64", ws.T_cl, (int64_t)B * V * 24},
         {"kv_cache", ws.kv, h->cache_mode() ? 0 : (int64_t)h->nl * B * 2 * N * C},
-        {"ref", ws.ref, M * 3}, {"ref_next", ws.ref_next, M * 3}, {"posemb", ws.emb, M * 384}, {"pos_feat", ws.pos, M * C},
+        {"ref", ws.ref, M * 3}, {"ref_next", ws.ref_next, M * 3}, {"posemb", ws.emb, M * 384}, {"pos_hidden", ws.pe_h, M * C}, {"pos_feat", ws.pos, M * C},
         {"tgt", ws.tgt, M * C}, {"self_qkv", ws.qkv, M * 3 * C}, {"attn", ws.attn, M * C}, {"xa_prenorm1", ws.xa, M * C},
         {"cross_q", ws.qc, M * C}, {"xb_prenorm2", ws.xb, M * C}, {"ffn_hidden", ws.ffn, M * F},
         {"xc_prenorm3", ws.xc, M * C}, {"heads1", ws.h1, M * h->NH1}, {"heads2", ws.h2, M * 2 * C},
