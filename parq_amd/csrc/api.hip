@@ -99,7 +99,7 @@ struct parq_ctx {
     bool prepared = false;
     bool emb_valid = false;           // workspace emb holds pos2posemb3d of the chained reference points
     int ref_state = 0;                // 0: none, 1: ws.ref valid
-    int attn_mode = 1;                // 0: fp32 MFMA, 1: split fp16x3, 2: fp16, 3: bf16 (1..3: head dims 64 and 256)
+    int attn_mode = 1;                // 0: fp32 MFMA, 1: split fp16x3, 2: fp16, 3: bf16 (1..3: head dims 64 and 256), 4: split with fp8 cross terms
     int kv16_state = 1;               // what the arena's 16-bit W_kv copy currently holds (same numbering)
     float drop_p = 0.f;               // training dropout (decoder layer, transformer_parq.py:339-386) and its base seed
     uint32_t drop_seed = 0;
@@ -107,7 +107,13 @@ struct parq_ctx {
     // split K/V cache in use: head dim 64 (all cache modes) or head dim 256 in split mode (a head = 4 virtual heads of 64)
     bool cache_mode() const { return attn_mode >= 1 && (dh == 64 || dh == 256); }
     int vheads() const { return C / 64; }            // heads of the cache layout
-    int terms() const { return attn_mode == 1 ? 3 : 1; }
+    int terms() const { return attn_mode == 1 || attn_mode == 4 ? 3 : 1; }
+    // mode 4 (flash_split8.hip) where its kernels apply — inference, head dim 64, d = 256, whole 64-key stages — and mode 1 otherwise:
+    // 8 = the stage cache with fp8 cross-term planes (same size as the split cache for such N)
+    int terms_for(int64_t N, bool train) const {
+        return (attn_mode == 4 && !train && C == 256 && flash_split8_supported(dh, (int)(N > INT32_MAX ? 0 : N))) ? 8 : terms();
+    }
+    int w16_state() const { return attn_mode == 4 ? 1 : attn_mode; }      // what the 16-bit copy of W_kv has to hold
     int kind() const { return attn_mode == 3 ? kBF16 : kF16; }
     int* range_mirror = nullptr;      // host-visible word raised when outputs are poisoned (parq_set_range_mirror)
     bool bwd_batched_env = true;      // parq_set_backward_batched (the parity test compares the two settings)
@@ -309,7 +315,7 @@ LinearArgs lin(const float* X, int64_t ldx, const float* W, int64_t ldw, const f
     return a;
 }
 
-int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& ws, hipStream_t s) {
+int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& ws, hipStream_t s, bool train = false) {
     const float* A = c->arena;
     const int B = sc->B, V = sc->V;
     const int64_t N = (int64_t)V * sc->h * sc->w;
@@ -325,15 +331,15 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     // hoisted K/V in-projection of the memory tokens: one GEMM per distinct layer,
     // written head-major [b][{K heads, V heads}][N][dh] so the attention kernel streams contiguous panels
     if ((int64_t)B * N > (int64_t)INT32_MAX) return fail(PARQ_ERR_ARG, "B*N too large");
-    if (c->cache_mode() && c->kv16_state != c->attn_mode) {
+    if (c->cache_mode() && c->kv16_state != c->w16_state()) {
         // the arena's 16-bit copy of W_kv follows the mode: hi/lo split, or one round-to-nearest fp16 / bf16 copy
         for (int li = 0; li < c->nl; ++li) {
             const LayerW& L = c->ar.layers[li];
             float* Aw = const_cast<float*>(A);
-            if (c->attn_mode == 1) HIPCHK(launch_split_f32(A + L.cross_in_w + C * C, Aw + L.kv_whi, Aw + L.kv_wlo, 2 * C * C, s));
+            if (c->terms() == 3) HIPCHK(launch_split_f32(A + L.cross_in_w + C * C, Aw + L.kv_whi, Aw + L.kv_wlo, 2 * C * C, s));
             else HIPCHK(launch_cvt16(A + L.cross_in_w + C * C, Aw + L.kv_whi, 2 * C * C, c->kind(), s));
         }
-        c->kv16_state = c->attn_mode;
+        c->kv16_state = c->w16_state();
     }
     for (int li = 0; li < c->nl; ++li) {
         Prof p(c, s, PARQ_PROF_KV_PROJ);
@@ -345,7 +351,7 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
                                          reinterpret_cast<int*>(wsp + ws.flags), wsp + ws.xsplit, s, c->terms(), c->kind()));
             else
                 HIPCHK(launch_kvproj_split(sc->tokens, A + L.kv_whi, A + L.kv_wlo, A + L.cross_in_b + C, B, (int)N, C, c->vheads(),
-                                           cache, reinterpret_cast<int*>(wsp + ws.flags), s, c->terms(), c->kind()));
+                                           cache, reinterpret_cast<int*>(wsp + ws.flags), s, c->terms_for(N, train), c->kind()));
         } else {
             LinearArgs a = lin(sc->tokens, C, A + L.cross_in_w + (int64_t)C * C, C, A + L.cross_in_b + C,
                                wsp + ws.kv + (int64_t)li * B * 2 * N * C, 0, (int)(B * N), 2 * C, C);
@@ -550,6 +556,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         if (c->cache_mode()) {
             const char* cache = reinterpret_cast<const char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, c->vheads(), (int)N, c->terms());
             if (dh == 256) HIPCHK(launch_flash_split256(fa, cache, s, c->terms(), c->kind()));
+            else if (c->terms_for(N, train) == 8) HIPCHK(launch_flash_split8(fa, cache, s));
             else HIPCHK(launch_flash_split(fa, cache, s, c->terms(), c->kind()));
         } else {
             const float* kv = wsp + ws.kv + (int64_t)li * B * 2 * N * C;
@@ -1232,8 +1239,9 @@ int parq_workspace_lookup(parq_handle h, int32_t B, int32_t V, int32_t hh, int32
 }
 
 int parq_set_attention_mode(parq_handle h, int32_t mode) {
-    if (!h || mode < 0 || mode > 3) return fail(PARQ_ERR_ARG, "attention mode must be 0 (fp32 MFMA), 1 (split fp16x3), 2 (fp16) or 3 (bf16)");
-    if (mode >= 2 && !((h->dh == 64 && h->C <= 256 && (2 * h->C) % 256 == 0) || (h->dh == 256 && h->C % 128 == 0 && (h->C == 256 || kvproj_big_on())))) 
+    if (!h || mode < 0 || mode > 4) return fail(PARQ_ERR_ARG, "attention mode must be 0 (fp32 MFMA), 1 (split fp16x3), 2 (fp16), 3 (bf16) or 4 (split, fp8 cross terms)");
+    if (mode == 4 && !(h->dh == 64 || h->dh == 256)) return fail(PARQ_ERR_ARG, "attention mode 4 needs a head dim of 64 (256: runs as mode 1)");
+    if (mode >= 2 && mode <= 3 && !((h->dh == 64 && h->C <= 256 && (2 * h->C) % 256 == 0) || (h->dh == 256 && h->C % 128 == 0 && (h->C == 256 || kvproj_big_on())))) 
         return fail(PARQ_ERR_ARG, "the fp16 / bf16 attention modes need head dim 64 with dim in {128, 256}, or head dim 256 with dim a multiple of 128");
     h->attn_mode = mode;
     h->prepared = false;
@@ -1286,7 +1294,7 @@ int parq_forward_train(parq_handle h, const parq_scene* scene, void* workspace, 
     if (workspace_bytes < (size_t)ws.train_total * sizeof(float)) return fail(PARQ_ERR_WORKSPACE, "training workspace too small: %zu < %zu", workspace_bytes, (size_t)ws.train_total * sizeof(float));
     float* wsp = (float*)workspace;
     hipStream_t s = (hipStream_t)stream;
-    rc = do_prepare(h, scene, wsp, ws, s);
+    rc = do_prepare(h, scene, wsp, ws, s, true);
     if (rc) return rc;
     const int64_t M = (int64_t)scene->B * h->Q;
     // the reference points of iteration k live in that iteration's stash (initial_ref wrote ws.ref)
@@ -1624,6 +1632,33 @@ int parq_k_attention_split(const float* q, const float* k, const float* v, float
     HIPCHK(hipMemsetAsync(flag, 0, 256, s));
     HIPCHK(launch_kvsplit_convert(k, v, Lk * C, dh, C, Lk * C, dh, C, B, H, Lk, cache, flag, s));
     HIPCHK(launch_flash_split(fa, cache, s));
+    HIPCHK(launch_flash_merge(fa, s));
+    return PARQ_OK;
+}
+
+/* mode 4: hi.hi on the fp16 matrix pipe, the cross terms as MX-scaled fp8 products (flash_split8.hip); Lk % 64 == 0 */
+int parq_k_attention_split8(const float* q, const float* k, const float* v, float* out, int32_t B, int32_t H, int32_t Lq,
+                            int32_t Lk, void* scratch, size_t scratch_bytes, parq_stream stream) {
+    if (!q || !k || !v || !out || !scratch) return fail(PARQ_ERR_ARG, "NULL argument");
+    if (B < 1 || H < 1 || Lq < 1 || Lk < 1) return fail(PARQ_ERR_ARG, "bad dims");
+    if (!flash_split8_supported(64, Lk)) return fail(PARQ_ERR_ARG, "attention mode 4 needs a key count that is a multiple of 64");
+    if (scratch_bytes < parq_k_attention_split_scratch_bytes(B, H, Lq, Lk)) return fail(PARQ_ERR_WORKSPACE, "attention scratch too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int dh = 64;
+    const int64_t C = (int64_t)H * dh;
+    FlashArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.B = B; fa.H = H; fa.Lq = Lq; fa.Lk = Lk; fa.dh = dh;
+    fa.q = q; fa.q_batch = Lq * C; fa.q_head = dh; fa.q_row = C;
+    fa.out = out; fa.out_batch = Lq * C; fa.out_row = C;
+    fa.nsplit = flash_split_pick_splits(B, H, Lq, Lk, device_num_cus());
+    const int64_t lp = flash_lq_pad(Lq);
+    char* cache = (char*)scratch + 256;
+    fa.o_part = (float*)(cache + kvsplit_cache_bytes(B, H, Lk));
+    fa.m_part = fa.o_part + (int64_t)B * H * fa.nsplit * dh * lp;
+    fa.l_part = fa.m_part + (int64_t)B * H * fa.nsplit * lp;
+    HIPCHK(launch_kvsplit8_convert(k, v, Lk * C, dh, C, Lk * C, dh, C, B, H, Lk, cache, s));
+    HIPCHK(launch_flash_split8(fa, cache, s));
     HIPCHK(launch_flash_merge(fa, s));
     return PARQ_OK;
 }

@@ -158,6 +158,37 @@ __device__ __forceinline__ void split8(const float* x, half8& hi, half8& lo) {
     }
 }
 
+// ---- fp8 (OCP e4m3) operand forms of the MX cross terms (flash_split8.hip, the K/V projection's mode-4 epilogue)
+__device__ __forceinline__ float clamp_e4m3(float x) { return __builtin_amdgcn_fmed3f(x, -448.f, 448.f); }
+// e4m3 of four floats, byte i = x[i]; values past +-448 saturate (v_cvt_pk_fp8_f32 itself returns NaN beyond its rounding range)
+__device__ __forceinline__ int pack4_e4m3(float a, float b, float c, float d) {
+    const int w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(a), clamp_e4m3(b), 0, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(c), clamp_e4m3(d), w, true);
+}
+// x0, x1 -> packed hi16 (round toward zero: the value split_pair takes its residual against) and the fp32 residuals x - hi (exact)
+__device__ __forceinline__ void split_rtz(float x0, float x1, unsigned& hi, float& d0, float& d1) {
+    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(hi), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(hi), "v"(x1));
+}
+constexpr float kLo8Scale = 1024.f;          // lo parts of K, V, Q enter e4m3 as lo * 2^10 (|lo| < 2^-10 |x|); E8M0 scale 117 undoes it
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// 16 floats -> 16 bytes e4m3(x) and 16 bytes e4m3((x - hi16(x)) * 2^10), byte i = x[i]
+__device__ __forceinline__ void pieces_e4m3(const float* x, i32x4& hi8, i32x4& lo8) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        unsigned h0, h1;
+        float d[4];
+        split_rtz(x[4 * w], x[4 * w + 1], h0, d[0], d[1]);
+        split_rtz(x[4 * w + 2], x[4 * w + 3], h1, d[2], d[3]);
+        hi8[w] = pack4_e4m3(x[4 * w], x[4 * w + 1], x[4 * w + 2], x[4 * w + 3]);
+        lo8[w] = pack4_e4m3(d[0] * kLo8Scale, d[1] * kLo8Scale, d[2] * kLo8Scale, d[3] * kLo8Scale);
+    }
+}
+// byte offsets inside a 64-key stage of the mode-4 cache (layout: flash_split8.hip)
+constexpr int kStage8Bytes = 32768;
+constexpr int kS8Kh16 = 0, kS8K8hi = 8192, kS8K8lo = 12288, kS8Vh16 = 16384, kS8V8hi = 24576, kS8V8lo = 28672;
+
 // ---- dropout (training): counter-based keep decision, identical in forward and backward.  Element (row, col) of stream `seed`
 // is kept when a 24-bit hash is >= p * 2^24; kept values are scaled by 1 / (1 - p) (torch.nn.Dropout semantics).
 __host__ __device__ constexpr uint32_t rng_mix(uint32_t x) {
@@ -339,6 +370,13 @@ hipError_t launch_kvsplit_to_f32(const void* cache, int B, int H, int N, float* 
                                  int terms = 3, int kind = kF16);                                   // terms = 1: the single 16-bit cache
 hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t s, int terms = 3,
                               int kind = kF16);   // partials; merge as usual
+// flash_split8.hip: the same with the two cross terms of every product on the MX-scaled fp8 matrix instruction (attention mode 4;
+// head dim 64, whole 64-key stages only: flash_split8_supported).  Cache = Lk / 64 stages of 32 KB per (scene, head) — the size
+// kvsplit_cache_bytes(.., 3) gives for such Lk.
+bool flash_split8_supported(int dh, int Lk);
+hipError_t launch_kvsplit8_convert(const float* K, const float* V, int64_t k_batch, int64_t k_head, int64_t k_row, int64_t v_batch,
+                                   int64_t v_head, int64_t v_row, int B, int H, int N, void* cache, hipStream_t s);
+hipError_t launch_flash_split8(const FlashArgs& a, const void* cache, hipStream_t s);
 // kvproj_split.hip: tokens -> split cache directly (W pre-split with launch_split_f32)
 hipError_t launch_split_f32(const float* src, void* hi, void* lo, int64_t n, hipStream_t s);
 // elementwise.hip: up to kGatherMax device-to-device float copies in ONE launch (the weight pack: ~50 tensors per training step)

@@ -282,15 +282,18 @@ template <int TM, int TERMS, int KIND, int NK, int D, int PROBE = 0>
 __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int total_rt, int nrt, int P) {
     PARQ_TL_KERNEL(kTlKvProj);
     constexpr int NWV = 8;
-    constexpr int kBlkH = TERMS == 3 ? 8192 : 4096;      // 16-bit units per 32-key cache block
-    constexpr int kVoff = TERMS == 3 ? 4096 : 2048;      // V_hi offset inside a block
+    constexpr bool SPLIT = TERMS != 1;         // three-term products (TERMS = 3, and 8: the same GEMM with the mode-4 epilogue)
+    constexpr bool F8 = TERMS == 8;
+    static_assert(!F8 || TM == 64, "a tile is one 64-key stage of the mode-4 cache");
+    constexpr int kBlkH = SPLIT ? 8192 : 4096;      // 16-bit units per 32-key cache block
+    constexpr int kVoff = SPLIT ? 4096 : 2048;      // V_hi offset inside a block
     constexpr int kThr = NWV * 64;
     constexpr int kCols = NWV * 32;
     constexpr int RT = TM / 32;                  // 32-row blocks per tile (accumulators per wave)
     constexpr int C = NK * kBK;
     constexpr int kRawBytes = TM * kBK * 4;      // one k-step of fp32 tokens
     constexpr int NDMA = kRawBytes / (kThr * 16);            // DMA instructions per thread and k-step
-    constexpr int NST = RT * 2 * (TERMS == 3 ? 2 : 1);       // store instructions per thread and tile
+    constexpr int NST = RT * 2 * (SPLIT ? 2 : 1);       // store instructions per thread and tile
     constexpr int NI = TM * 8 / kThr;            // 8-float pieces of a k-step per thread (conversion)
     static_assert(D >= 3 && D - 2 <= NK && NDMA >= 1 && NI >= 1, "wait counts below assume at most one epilogue inside the prefetch window");
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ovf |= !(fabsf(x[e]) < 60000.f);
             }
-            if constexpr (TERMS == 3) {
+            if constexpr (SPLIT) {
                 half8 hi, lo;
                 split8(x, hi, lo);
                 *reinterpret_cast<half8*>(Ahi + row * kBK + pos * 8) = hi;
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
             for (int s2 = 0; s2 < 4; ++s2) {
                 const int64_t off = (int64_t)col * C + ks * kBK + 32 * kh + 8 * s2;
                 wfr[ks][s2][0] = *reinterpret_cast<const half8*>(a.Whi + off);
-                if constexpr (TERMS == 3) wfr[ks][s2][1] = *reinterpret_cast<const half8*>(a.Wlo + off);
+                if constexpr (SPLIT) wfr[ks][s2][1] = *reinterpret_cast<const half8*>(a.Wlo + off);
             }
         float bK[ISK ? 16 : 1];
         if constexpr (ISK) {
@@ -451,16 +454,16 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
                         const int row = t * 32 + li;
                         const int posr = (4 * kh + s2) ^ ((row >> 1) & 7);
                         xh[t] = *reinterpret_cast<const half8*>(Ahi + row * kBK + posr * 8);
-                        if constexpr (TERMS == 3) xl[t] = *reinterpret_cast<const half8*>(Alo + row * kBK + posr * 8);
+                        if constexpr (SPLIT) xl[t] = *reinterpret_cast<const half8*>(Alo + row * kBK + posr * 8);
                     }
                     const half8 wh = wfr[ks][s2][0], wlo = wfr[ks][s2][1];
                     if constexpr (PROBE & 1) {
 #pragma unroll
-                        for (int t = 0; t < RT; ++t) acc[t][0] += (float)xh[t][0] * (float)wh[0] + (TERMS == 3 ? (float)xl[t][1] * (float)wlo[1] : 0.f);
+                        for (int t = 0; t < RT; ++t) acc[t][0] += (float)xh[t][0] * (float)wh[0] + (SPLIT ? (float)xl[t][1] * (float)wlo[1] : 0.f);
                     } else if constexpr (ISK) {          // transposed product: rows = d, cols = tokens
 #pragma unroll
                         for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wh, xh[t], acc[t]);
-                        if constexpr (TERMS == 3) {
+                        if constexpr (SPLIT) {
 #pragma unroll
                             for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wh, xl[t], acc[t]);
 #pragma unroll
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
                     } else {            // rows = tokens, cols = d
 #pragma unroll
                         for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(xh[t], wh, acc[t]);
-                        if constexpr (TERMS == 3) {
+                        if constexpr (SPLIT) {
 #pragma unroll
                             for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(xh[t], wlo, acc[t]);
 #pragma unroll
@@ -498,13 +501,30 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
                 const int blk = (m0 >> 5) + t;
                 if (blk >= nblk) continue;                                   // scalar
                 _Float16* out = a.cache + (((int64_t)b * a.H + h) * nblk + blk) * kBlkH;
+                if constexpr (F8) {
+                    // mode-4 stage image (flash_split8.hip): this block's hi16 plane at t * 4 KB of the K / V hi16 region, and the lane's
+                    // 16 accumulator registers as ONE 16-byte piece of the hi8 plane and one of the lo8 plane
+                    unsigned char* stage = reinterpret_cast<unsigned char*>(a.cache) + (((int64_t)b * a.H + h) * (nblk >> 1) + (m0 >> 6)) * kStage8Bytes;
+                    out = reinterpret_cast<_Float16*>(stage + (ISK ? kS8Kh16 : kS8Vh16 - 2 * kVoff) + t * 4096);
+                    float x16[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) x16[r] = acc[t][r] + (ISK ? bK[ISK ? r : 0] : bK[0]);
+                    i32x4 hi8, lo8;
+                    pieces_e4m3(x16, hi8, lo8);
+                    // K: piece (c = kh, h = ct) of key li;  V: piece (dt = ct, h = kh) of dim 32 ct + li
+                    const int piece = ISK ? ((t * 2 + kh) * 2 + ct) * 32 + li : ((t * 2 + ct) * 2 + kh) * 32 + li;
+                    if constexpr (!(PROBE & 2)) {
+                        *reinterpret_cast<i32x4*>(stage + (ISK ? kS8K8hi : kS8V8hi) + piece * 16) = hi8;
+                        *reinterpret_cast<i32x4*>(stage + (ISK ? kS8K8lo : kS8V8lo) + piece * 16) = lo8;
+                    }
+                }
                 half8 hi[2], lo[2];
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     float x[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) x[e] = acc[t][8 * m + e] + (ISK ? bK[ISK ? 8 * m + e : 0] : bK[0]);
-                    if constexpr (TERMS == 3) split8(x, hi[m], lo[m]);
+                    if constexpr (SPLIT) split8(x, hi[m], lo[m]);
                     else hi[m] = cvt8_rn<KIND>(x);
                     if constexpr (KIND == kF16) {
 #pragma unroll
@@ -623,6 +643,7 @@ hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void*
     const int nct = 2 * C / kBN, nrt = ceil_div(N, kBM);
     if (C <= 4 * kBK && C % (2 * kBK) == 0) {
         // W-stationary persistent kernel: one workgroup per CU, the column slices of one slot on one XCD
+        if (terms == 8) return (N % 64 == 0 && C == 256) ? launch_dma_nk<64, 8, kF16, 4, 4>(a, B, s) : hipErrorInvalidValue;
         if (terms != 3) return kind == kF16 ? launch_dma<1, kF16, 4>(a, B, s) : launch_dma<1, kBF16, 4>(a, B, s);
 #ifdef PARQ_DEV_PROBES
         static const int probe = [] { const char* e = dev_env("PARQ_KVPROJ_PROBE"); return e ? atoi(e) : 0; }();      // development

@@ -145,7 +145,7 @@ class _TransformerParams(nn.Module):
 # cross-attention arithmetic (include/parq_hip.h, parq_set_attention_mode): "split" = fp16 hi/lo 3-term products
 # (fp32-class accuracy, default at head dims 64 and 256), "fp32" = exact fp32 MFMA, "fp16" / "bf16" = single reduced-precision
 # products (BASELINE configs 2 and 5; head dim 64 with dim 128 / 256, head dim 256 with dim a multiple of 128)
-ATTENTION_MODES = {"fp32": 0, "split": 1, "fp16": 2, "bf16": 3}
+ATTENTION_MODES = {"fp32": 0, "split": 1, "fp16": 2, "bf16": 3, "split8": 4}
 
 
 class _Stash:
@@ -241,7 +241,11 @@ class PARQDecoder(nn.Module):
         # cross-attention arithmetic: "split" = fp16 hi/lo 3-term products on the fp16 matrix pipe
         # (fp32-class accuracy; head dim 64, and head dim 256 = the reference's shipped DEC_DIM 1024 / 4 heads),
         # "fp32" = fp32 MFMA.  include/parq_hip.h
-        self.attention_mode = "split" if Cd // self.num_heads in (64, 256) else "fp32"
+        # "split8" = the same with the two cross terms of every product as MX-scaled fp8 products (inference at head dim 64, dim 256,
+        # key counts that are multiples of 64 — every other case of this mode runs as "split"): 1e-6 from float64 at the outputs on
+        # the reference's fixtures against 2e-6 for "split", same 1e-4 bound against the reference's vectors; the default where it applies
+        dh_ = Cd // self.num_heads
+        self.attention_mode = "split8" if (dh_ == 64 and Cd == 256) else "split" if dh_ in (64, 256) else "fp32"
         self._mean_sizes = mean_size_table(self.mean_size_path)     # (rows,3) float64
         self._h = None            # parq_handle
         self._arena = None
@@ -267,7 +271,7 @@ class PARQDecoder(nn.Module):
         self._train_pending = None        # deferred range check of the last training forward: callable -> True if it re-ran
         self.max_workspaces = 2           # inference workspaces (each holds a K/V cache) kept alive, least recently used first out
         self._mean_dev = None
-        # fp16-operand attention modes ("split", "fp16"): what to do when a token / K / V element leaves the fp16 range
+        # fp16-operand attention modes ("split", "split8", "fp16"): what to do when a token / K / V element leaves the fp16 range
         # (include/parq_hip.h: the device then writes NaN outputs instead of wrong numbers, and raises a flag).
         #   "lazy" (default): no synchronisation and no extra work on the forward path.  On a violation the device itself
         #           stores into a pinned host word (parq_set_range_mirror); the next call into the module that finds it set
@@ -297,12 +301,12 @@ class PARQDecoder(nn.Module):
         """A host load of the pinned word earlier forwards raise from the device on a violation (no synchronisation)."""
         if self._range_mirror is not None and int(self._range_mirror[0]) != 0:
             self._range_mirror[0] = 0
-            if self.range_check != "off" and self.attention_mode in ("split", "fp16"):
+            if self.range_check != "off" and self.attention_mode in ("split", "split8", "fp16"):
                 self._range_fallback("detected after an earlier forward")
 
     def _range_after_forward(self, ws, sc):
         """"sync" policy: wait for the flag of the forward just enqueued; True = re-run it with the fp32 kernels."""
-        if self.range_check != "sync" or self.attention_mode not in ("split", "fp16"):
+        if self.range_check != "sync" or self.attention_mode not in ("split", "split8", "fp16"):
             return False
         if int(self._flag_view(ws, sc.B, sc.V, sc.h, sc.w).item()) != 0:
             self._range_mirror[0] = 0
@@ -559,7 +563,7 @@ class PARQDecoder(nn.Module):
             return mode
         mode = enqueue()
         self._train_pending = None
-        if self.range_check != "off" and mode in ("split", "fp16"):
+        if self.range_check != "off" and mode in ("split", "split8", "fp16"):
             # Training never lets a range violation reach the optimizer: a poisoned forward (NaN outputs, device flag, pinned host
             # word) is re-run with the exact fp32 kernels (same dropout seed, same output tensors) before its outputs are used.
             def rerun_if_poisoned(completed):
@@ -724,7 +728,7 @@ class PARQDecoder(nn.Module):
                     gathered.copy_(xb)
                 phase(2, gathered, None)
                 results.append(dict(zip(OUTPUT_KEYS, outs)))
-            if self.range_check == "off" or self.attention_mode not in ("split", "fp16"):
+            if self.range_check == "off" or self.attention_mode not in ("split", "split8", "fp16"):
                 break
             # identical on every rank (the flags were summed in the first exchange of every iteration)
             if int(self._flag_view(ws, sc.B, sc.V, sc.h, sc.w).item()) == 0:

@@ -59,10 +59,11 @@ def _masked_err(a, b, z, k, key):
     return float(e.max()) if e.size else 0.0
 
 
-@pytest.mark.parametrize("mode", ["split", "fp32"])
+@pytest.mark.parametrize("mode", ["split8", "split", "fp32"])
 def test_cfg3_golden_teacher_forced(g14, truth, mode):
-    """Every iteration of the headline configuration (64 key splits x 47 stages per head in split mode; the exact-fp32 MFMA
-    kernels are held to the same vectors), teacher-forced, against
+    """Every iteration of the headline configuration (64 key splits x 47 stages per head in the split modes — "split8", the default
+    here: cross terms as MX-scaled fp8 products, and "split": three fp16 products; the exact-fp32 MFMA kernels are held to the
+    same vectors), teacher-forced, against
       (a) the float64 evaluation of the reference's algorithm: 1e-4 on every output (measured: ~2e-6), and
       (b) golden g14 = the reference's own fp32 CPU run: 1e-4, or — on the outputs where the reference's fp32 run itself
           sits further than 9e-5 from its float64 evaluation at this size (N = 192 000 white-noise tokens: up to 1.4e-4 on
