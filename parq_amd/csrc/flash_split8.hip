@@ -148,7 +148,9 @@ __device__ __forceinline__ f32x16 mx64(i32x8 a, i32x8 b, f32x16 c, int sel_a, in
 // Running maximum: moves only when a score exceeds it by more than kDefer8, and then by an INTEGER d (ceil), so that everything
 // still waiting to be multiplied is rescaled exactly: the O^T accumulators and row sums by 2^-d, the pending fp16 probabilities
 // by 2^-d (a power of two), the pending fp8 probabilities through the E8M0 scale operand of their block.
-// PROBE (development, results wrong): 1 no softmax VALU, 2 no PV MFMAs, 4 no QK MFMAs, 8 no barrier / DMA waits, 16 no fragment reads.
+// PROBE (development, results wrong): 1 no softmax VALU, 2 no PV MFMAs, 4 no QK MFMAs, 8 no barrier / DMA waits, 16 no fragment reads;
+// 32 (results right): the written order of a step pinned with scheduling fences — 108.9 us against 105.3 for hipcc's own order of the
+// same instructions (round 4, one box), so the product build has none.
 template <int PROBE = 0, int RING = kRing>
 __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, const unsigned char* __restrict__ cache) {
     PARQ_TL_KERNEL(kTlFlashSplit);
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
             p8l[R] = (int)__builtin_amdgcn_perm((unsigned)wl, (unsigned)t8l, 0x05040100u);
         }
     };
-#define PARQ_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define PARQ_FENCE() do { if constexpr ((PROBE & 32) != 0) __builtin_amdgcn_sched_barrier(0); } while (0)
     // step n: QK(n + 1) -> sacc[NXT]; softmax(n) from sacc[CUR]; fp16 P V of block n - 1; odd n: at its end the fp8 cross terms of
     // the stage (n - 1, n), whose probabilities are complete by then (their V fragments are requested at the top of the step).
     // Fragments of the next step are requested as soon as their registers are dead (kf after the fourth fp16 Q K, k8 after the
@@ -581,6 +583,7 @@ hipError_t launch_flash_split8(const FlashArgs& a, const void* cache, hipStream_
         case 8: PARQ_F8_LAUNCH(8)
         case 16: PARQ_F8_LAUNCH(16)
         case 23: PARQ_F8_LAUNCH(23)
+        case 32: PARQ_F8_LAUNCH(32)
         default: return hipErrorInvalidValue;
     }
     const int ring = [] { const char* e = dev_env("PARQ_FLASH_RING"); return e && e[0] == '5' ? 5 : 4; }();
