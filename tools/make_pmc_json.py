@@ -9,7 +9,7 @@ import os
 import sys
 
 out = sys.argv[1]
-KERNELS = {"flash_split_pipe_kernel": 2.0, "flash_split_kernel": 2.0, "kvproj_dma_kernel": 2.0, "project_sample_kernel": 2.0, "flash_merge_kernel": 2.0, "flash_merge_fixed_kernel": 2.0}
+KERNELS = {"flash_split8_kernel": 2.0, "flash_split_pipe_kernel": 2.0, "flash_split_kernel": 2.0, "kvproj_dma_kernel": 2.0, "project_sample_kernel": 2.0, "flash_merge_kernel": 2.0, "flash_merge_fixed_kernel": 2.0}
 
 
 def means(pattern, counter):
