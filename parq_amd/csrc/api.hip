@@ -932,7 +932,7 @@ const char* parq_version(void) {
 #ifdef PARQ_DEV_PROBES
     return "parq_hip 0.3-dev (gfx950; DEVELOPMENT build: environment A/B switches, probe kernels and time stamps compiled in)";
 #else
-    return "parq_hip 0.3 (gfx950; cross-attention: fp16 hi/lo split MFMA products by default, exact fp32 MFMA on request)";
+    return "parq_hip 0.4 (gfx950; cross-attention: fp16 hi/lo split MFMA products, cross terms as MX-fp8 products in mode 4, exact fp32 MFMA on request)";
 #endif
 }
 
