@@ -322,7 +322,6 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
         return xhalf_max(fmaxf(m0, m1));
     };
     // one softmax pair: elements (2 J, 2 J + 1) of the accumulator -> one fp16 word of Ph[CUR][J / 4], two bytes of p8h and of p8l
-    int t8h = 0, t8l = 0;                                                  // the even pair's bytes, until the odd pair completes the register
     auto sm_pair = [&](auto cur, auto jj) {
         if constexpr (PROBE & 1) return;
         constexpr int CUR = decltype(cur)::value, J = decltype(jj)::value, M = J >> 2, W = J & 3;
@@ -336,21 +335,22 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
         u32x4 h4 = __builtin_bit_cast(u32x4, Ph[CUR][M]);
         h4[W] = hw;
         Ph[CUR][M] = __builtin_bit_cast(half8, h4);
-        // two probabilities -> two e4m3 bytes in the low half of a register (v_cvt_scalef32_pk_fp8_f32 converts x / scale); pairs J, J + 1
-        // make one register of p8h / p8l with a byte permute.  Written as asm with a plain output: the builtin's merging forms
-        // (op_sel high word into the previous value) lost the low-word conversions of three registers out of four to hipcc's dead
-        // code elimination (ROCm 7.2: only the high-word writes were left in the loop)
-        int wh, wl;
-        asm("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3" : "=v"(wh) : "v"(p0), "v"(p1), "s"(1.f / 64.f));
-        asm("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3" : "=v"(wl) : "v"(d0), "v"(d1), "s"(1.f / 65536.f));
+        // two probabilities -> two e4m3 bytes of p8h / p8l (v_cvt_scalef32_pk_fp8_f32 converts x / scale into the low or, with op_sel[3],
+        // the high half of its destination and keeps the other half).  Written as asm on the register itself: the builtin's merging
+        // form lost the low-half conversions of three registers out of four to hipcc's dead code elimination (ROCm 7.2: only the
+        // high-half writes were left in the loop).  s_nop: a VALU that reads a destination just written through op_sel / dst_sel
+        // needs one wait state on this family (the tied operand of the high-half form reads it)
+        constexpr int R = 4 * CUR + (J >> 1);
+        int wh = p8h[R], wl = p8l[R];
         if constexpr ((J & 1) == 0) {
-            t8h = wh;
-            t8l = wl;
+            asm("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3" : "+v"(wh) : "v"(p0), "v"(p1), "s"(1.f / 64.f));
+            asm("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3" : "+v"(wl) : "v"(d0), "v"(d1), "s"(1.f / 65536.f));
         } else {
-            constexpr int R = 4 * CUR + (J >> 1);
-            p8h[R] = (int)__builtin_amdgcn_perm((unsigned)wh, (unsigned)t8h, 0x05040100u);
-            p8l[R] = (int)__builtin_amdgcn_perm((unsigned)wl, (unsigned)t8l, 0x05040100u);
+            asm("s_nop 0\n\tv_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(wh) : "v"(p0), "v"(p1), "s"(1.f / 64.f));
+            asm("s_nop 0\n\tv_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(wl) : "v"(d0), "v"(d1), "s"(1.f / 65536.f));
         }
+        p8h[R] = wh;
+        p8l[R] = wl;
     };
 #define PARQ_FENCE() do { if constexpr ((PROBE & 32) != 0) __builtin_amdgcn_sched_barrier(0); } while (0)
     // step n: QK(n + 1) -> sacc[NXT]; softmax(n) from sacc[CUR]; fp16 P V of block n - 1; odd n: at its end the fp8 cross terms of
