@@ -6,11 +6,11 @@
 //            +  e4m3(a_lo 2^10) 2^-10 . e4m3(b)                                 } per cross term and 64-long contraction
 // The cross terms are 2^-11 of the product, so the 4 significant bits of e4m3 put their rounding at ~2^-16 of it: measured on the
 // reference's fixtures this arithmetic sits 1e-6 from float64 at the decoder outputs (the fp16 x 3 split: 3e-8; one fp16 product:
-// 5e-5; tests/emulate_attention_arithmetic.py is the CPU model of all three).  What it buys: on this part a whole-chip stream of
-// v_mfma_f32_32x32x16_f16 issues every ~50 cycles per SIMD, not every 32 (tools/bench_src/mx_energy.hip: the chip's power management
-// holds the fp16 matrix pipe there, with zero operands as with random ones), while the MX instruction runs at its nominal 64 cycles
-// for FOUR times the contraction: a 32 x 32 x 64 cross term costs 66 cycles instead of 200, a whole split product 4 x 50 + 2 x 66
-// instead of 12 x 50.
+// 5e-5; tests/emulate_attention_arithmetic.py is the CPU model of all three).  What it buys: this kernel family is bound by the
+// power the matrix pipe draws (profiles/r04_flash_power_budget_probe.txt): with real operand bits a whole-chip stream of
+// v_mfma_f32_32x32x16_f16 runs at 20 ns per instruction and SIMD (32.7 cycles of the 2.4 GHz clock on zero operands, ~48 on random
+// ones: tools/bench_src/mfma_operands.hip), and the MX instruction at 36 ns for FOUR times the contraction (tools/bench_src/mx_energy.hip).
+// A 32 x 32 x 64 cross term costs 36 ns instead of 80, a whole split product 4 x 20 + 2 x 36 = 152 ns instead of 240 (measured 157).
 //
 // Cache ("stage" = 64 keys = 32 KB, the LDS image equals the global image; written by kvsplit8_convert_kernel or by the K/V
 // projection), byte offsets inside a stage:

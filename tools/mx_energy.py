@@ -35,12 +35,14 @@ for data in ("random", "zeros"):
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         st = bench.device_state_under_load(step, seconds=1.5)
+        for _ in range(50):
+            step()
         e0.record()
-        for _ in range(10):
+        for _ in range(50):
             step()
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 10
+        ms = e0.elapsed_time(e1) / 50
         blocks = iters * 2                               # per wave
         ns_per_block = ms * 1e6 / blocks
         print("%-7s mode %d %-26s %.3f ms  = %.1f ns per block and wave (2 waves per SIMD)  clock %s MHz  power %s W  nan=%s" % (
