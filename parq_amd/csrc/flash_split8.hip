@@ -151,7 +151,7 @@ __device__ __forceinline__ f32x16 mx64(i32x8 a, i32x8 b, f32x16 c, int sel_a, in
 // PROBE (development, results wrong): 1 no softmax VALU, 2 no PV MFMAs, 4 no QK MFMAs, 8 no barrier / DMA waits, 16 no fragment reads;
 // 32 (results right): the written order of a step pinned with scheduling fences — 108.9 us against 105.3 for hipcc's own order of the
 // same instructions (round 4, one box), so the product build has none.
-template <int PROBE = 0, int RING = kRing>
+template <int PROBE = 0, int RING = kRing, bool REV = false>
 __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, const unsigned char* __restrict__ cache) {
     PARQ_TL_KERNEL(kTlFlashSplit);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [kRing stages]
@@ -202,21 +202,19 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
     const int t_begin = (int)((int64_t)split * nst / a.nsplit);
     const int t_end = (int)((int64_t)(split + 1) * nst / a.nsplit);
     const uint4* gsrc = reinterpret_cast<const uint4*>(cache + (int64_t)bh * nst * kStageBytes);
-    const int64_t total16 = (int64_t)nst * STAGE16;
     const int nbk = 2 * (t_end - t_begin);                                  // 32-key blocks of this split: always whole stages
 
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
     auto gload = [&](int st, int slot) {
 #pragma unroll
         for (int i = 0; i < LD; ++i) {
-            int64_t idx = (int64_t)st * STAGE16 + tid + i * NT;
-            idx = idx < total16 ? idx : total16 - 1;
+            const int64_t idx = (int64_t)st * STAGE16 + tid + i * NT;       // st is a stage of this split: always inside the cache
             lds_byte* dst = (lds_byte*)(smem) + ((size_t)slot * STAGE16 + i * NT + wave * 64) * 16;
             __builtin_amdgcn_global_load_lds(gsrc + idx, dst, 16, 0, 0);
         }
     };
     // odd iterations walk the stages (and the two blocks of a stage) backwards: flash_split.hip
-    const bool rev = (a.flags & 2) != 0;
+    constexpr bool rev = REV;                                              // a template parameter: the block-in-stage selects below are then literals
     auto src_stage = [&](int j) { return rev ? t_end - 1 - j : t_begin + j; };
     auto stage_of = [&](int n) -> const unsigned char* { return smem + (size_t)((n >> 1) % RING) * kStageBytes; };
     auto pblk = [&](int n) { return rev ? 1 - (n & 1) : (n & 1); };       // physical block of local block n inside its stage
@@ -563,13 +561,18 @@ hipError_t launch_flash_split8(const FlashArgs& a, const void* cache, hipStream_
     b.flags = ((a.flags & 2) ? 2 : 0) | ((wt && a.Lq % 256 == 0) ? 8 : 0);
     const dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * b.H);
     const unsigned char* c8 = reinterpret_cast<const unsigned char*>(cache);
-#define PARQ_F8_LAUNCH_R(PROBE, RING)                                                                                          \
+#define PARQ_F8_LAUNCH_RR(PROBE, RING, REV)                                                                                    \
     {                                                                                                                          \
         static DynLdsOnce once;                                                                                                \
         const size_t lds = (size_t)(RING) * kStageBytes;                                                                       \
-        if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_split8_kernel<PROBE, RING>), lds); e != hipSuccess) return e; \
-        hipLaunchKernelGGL((flash_split8_kernel<PROBE, RING>), grid, dim3(kNW * 64), lds, s, b, c8);                            \
+        if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_split8_kernel<PROBE, RING, REV>), lds); e != hipSuccess) return e; \
+        hipLaunchKernelGGL((flash_split8_kernel<PROBE, RING, REV>), grid, dim3(kNW * 64), lds, s, b, c8);                       \
         return hipGetLastError();                                                                                              \
+    }
+#define PARQ_F8_LAUNCH_R(PROBE, RING)                                                                                          \
+    {                                                                                                                          \
+        if (b.flags & 2) PARQ_F8_LAUNCH_RR(PROBE, RING, true)                                                                  \
+        PARQ_F8_LAUNCH_RR(PROBE, RING, false)                                                                                  \
     }
 #define PARQ_F8_LAUNCH(PROBE) PARQ_F8_LAUNCH_R(PROBE, kRing)
 #ifdef PARQ_DEV_PROBES
@@ -592,6 +595,7 @@ hipError_t launch_flash_split8(const FlashArgs& a, const void* cache, hipStream_
     PARQ_F8_LAUNCH(0)
 #undef PARQ_F8_LAUNCH
 #undef PARQ_F8_LAUNCH_R
+#undef PARQ_F8_LAUNCH_RR
 }
 
 }  // namespace parq
