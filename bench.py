@@ -540,6 +540,7 @@ def main():
     # ---- the same forward with all three terms of every cross-attention product in fp16 (attention_mode "split"), when the timed
     # mode was "split8": untimed by the contract, reported beside `value` with the largest difference of the two modes' outputs
     strict = None
+    guard_tripped = dec.attention_too_peaked() if hasattr(dec, "attention_too_peaked") else False
     if dec.attention_mode == "split8" and world == 1 and not (args.dev_lib or parq_env()):
         fast_out = [{k: v.clone() for k, v in o.items()} for o in step()]
         dec.attention_mode = "split"
@@ -669,6 +670,11 @@ def main():
         }
         if strict is not None:
             out["strict_fp16x3"] = strict
+        if hasattr(dec, "attention_too_peaked"):
+            # mode "split8" is kept only while every cross-attention row spreads over enough keys (its error model); a tripped guard
+            # would have switched the module to "split" and `dtype` / `roofline` above would say so
+            out["attention_mode"] = mode
+            out["attention_guard"] = {"row_probability_sum_threshold": 64, "tripped": bool(guard_tripped)}
         if C == 256:
             out["ray_pe"] = ray_pe_timing(B, device)
         if world == 1:

@@ -127,11 +127,16 @@ int parq_pack_weights(parq_handle h, void *arena, size_t arena_bytes, parq_strea
  *      1e-6 at the decoder outputs on the reference's fixtures (tests/emulate_attention_arithmetic.py, tests/test_gpu_split8.py).
  *      Inference, head dim 64, dim 256, key counts that are a multiple of 64; every other case of a handle in this mode runs
  *      as mode 1 (training forward / backward included).  Range: as mode 1; |K|, |V|, |q| past 448 saturate in their fp8 forms
- *      only (those elements keep the accuracy of mode 2, nothing is poisoned). */
+ *      only (those elements keep the accuracy of mode 2, nothing is poisoned).  The probabilities enter P V as one fp16 value each,
+ *      and the normaliser sums those same values.  The mode's error model assumes rows that spread over many keys (1e-6 .. 1e-5 at
+ *      the outputs while every row's probability sum, relative to its maximum, is above ~40; 1e-4 and more for rows that two or three
+ *      keys carry): the merge kernel raises workspace "flags"[1] — and bit 1 of the range mirror — when a row's sum is under 64;
+ *      outputs are NOT poisoned, the caller decides (the Python class falls back to mode 1: PARQDecoder.range_check). */
 int parq_set_attention_mode(parq_handle h, int32_t mode);
-/* Optional: a host-visible, device-writable int32 (pinned host memory, e.g. hipHostMalloc) that the device sets to 1 whenever it
- * poisons outputs because of a range violation (above).  Lets a host poll for violations of earlier, already finished calls
- * with a plain load — no stream synchronisation, nothing extra on the forward path.  NULL switches it off. */
+/* Optional: a host-visible, device-writable int32 (pinned host memory, e.g. hipHostMalloc) in which the device sets bit 0 whenever
+ * it poisons outputs because of a range violation (above) and bit 1 when attention mode 4 met a too-peaked row (above; outputs not
+ * poisoned).  Lets a host poll for events of earlier, already finished calls with a plain load — no stream synchronisation,
+ * nothing extra on the forward path.  NULL switches it off. */
 int parq_set_range_mirror(parq_handle h, int32_t *host_visible_flag);
 
 /* ---- PARQDecoder.forward ---------------------------------------------------------- */
@@ -182,7 +187,8 @@ int parq_iterate_sharded(parq_handle h, const parq_scene *scene, void *workspace
  * reference points), "pos_feat" (the position MLP's output; only written where its last layer is not folded into the two
  * in-projections that consume it, i.e. by the training forward), "tgt",
  * "self_qkv", "attn", "xa_prenorm1", "cross_q", "xb_prenorm2", "ffn_hidden", "xc_prenorm3",
- * "heads1", "heads2", "ln1_stats", "ln2_stats", "flags". */
+ * "heads1", "heads2", "ln1_stats", "ln2_stats", "flags" (int32 words: [0] fp16 operand range exceeded, [1] attention mode 4 met a
+ * row carried by too few keys). */
 int parq_workspace_lookup(parq_handle h, int32_t B, int32_t V, int32_t hh, int32_t ww, const char *name,
                           size_t *offset_floats, size_t *numel);
 
@@ -348,9 +354,11 @@ size_t parq_k_attention_split_scratch_bytes(int32_t B, int32_t H, int32_t Lq, in
 int parq_k_attention_split(const float *q, const float *k, const float *v, float *out, int32_t B, int32_t H,
                            int32_t Lq, int32_t Lk, void *scratch, size_t scratch_bytes, parq_stream stream);
 
-/* the same through the mode-4 path (fp8 cross terms); Lk % 64 == 0; scratch as for parq_k_attention_split */
+/* the same through the mode-4 path (fp8 cross terms); Lk % 64 == 0; scratch as for parq_k_attention_split.  p_lo = 0: the kernel as
+ * the decoder runs it (probabilities as one fp16 value each, normaliser over the same values); p_lo = 1: the probabilities keep an
+ * fp8 lo part (the kernel's other instantiation, used by the kernel tests to check the running-max bookkeeping of the fp8 operands) */
 int parq_k_attention_split8(const float *q, const float *k, const float *v, float *out, int32_t B, int32_t H,
-                            int32_t Lq, int32_t Lk, void *scratch, size_t scratch_bytes, parq_stream stream);
+                            int32_t Lq, int32_t Lk, int32_t p_lo, void *scratch, size_t scratch_bytes, parq_stream stream);
 
 /* the split-fp16 path at head dim 256 (the reference's shipped DEC_DIM 1024 / 4 heads, config/train.yaml:49-50): a head is
  * stored as 4 virtual heads of 64 in the split cache, a pair of waves shares each 32-query tile. */

@@ -15,6 +15,7 @@
 using namespace parq;
 
 namespace {
+constexpr float kPeakyL = 64.f;       // attention mode 4: smallest row sum of probabilities (relative to the row's reference maximum) it keeps
 
 thread_local char g_err[512] = "";
 
@@ -556,7 +557,13 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         if (c->cache_mode()) {
             const char* cache = reinterpret_cast<const char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, c->vheads(), (int)N, c->terms());
             if (dh == 256) HIPCHK(launch_flash_split256(fa, cache, s, c->terms(), c->kind()));
-            else if (c->terms_for(N, train) == 8) HIPCHK(launch_flash_split8(fa, cache, s));
+            else if (c->terms_for(N, train) == 8) {
+                // rows whose probability sum (relative to the row's reference maximum) is under kPeakyL are carried by too few keys for
+                // this mode's error model: flags[1] -> bit 1 of the range mirror -> the caller falls back to mode 1
+                fa.peaky = sharded ? nullptr : reinterpret_cast<int*>(wsp + ws.flags) + 1;
+                fa.peaky_l = kPeakyL;
+                HIPCHK(launch_flash_split8(fa, cache, s));
+            }
             else HIPCHK(launch_flash_split(fa, cache, s, c->terms(), c->kind()));
         } else {
             const float* kv = wsp + ws.kv + (int64_t)li * B * 2 * N * C;
@@ -621,6 +628,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         // fp16-operand modes: a range violation seen while the cache was built must not produce plausible wrong numbers
         d.poison = (c->cache_mode() && c->kind() == kF16) ? reinterpret_cast<const int*>(wsp + ws.flags) : nullptr;
         d.poison_mirror = c->range_mirror;
+        d.peaky = (!sharded && c->terms_for(N, train) == 8) ? reinterpret_cast<const int*>(wsp + ws.flags) + 1 : nullptr;
         d.sb = c->sb; d.M = M; d.ncls = c->ncls;
         d.logits = o->pred_logits; d.center = o->center_unnormalized; d.size = o->size_unnormalized;
         d.rot = o->ortho6d; d.prob = o->sem_cls_prob; d.ref_next = ref_out; d.emb_next = emb_next;
@@ -1638,7 +1646,7 @@ int parq_k_attention_split(const float* q, const float* k, const float* v, float
 
 /* mode 4: hi.hi on the fp16 matrix pipe, the cross terms as MX-scaled fp8 products (flash_split8.hip); Lk % 64 == 0 */
 int parq_k_attention_split8(const float* q, const float* k, const float* v, float* out, int32_t B, int32_t H, int32_t Lq,
-                            int32_t Lk, void* scratch, size_t scratch_bytes, parq_stream stream) {
+                            int32_t Lk, int32_t p_lo, void* scratch, size_t scratch_bytes, parq_stream stream) {
     if (!q || !k || !v || !out || !scratch) return fail(PARQ_ERR_ARG, "NULL argument");
     if (B < 1 || H < 1 || Lq < 1 || Lk < 1) return fail(PARQ_ERR_ARG, "bad dims");
     if (!flash_split8_supported(64, Lk)) return fail(PARQ_ERR_ARG, "attention mode 4 needs a key count that is a multiple of 64");
@@ -1658,7 +1666,7 @@ int parq_k_attention_split8(const float* q, const float* k, const float* v, floa
     fa.m_part = fa.o_part + (int64_t)B * H * fa.nsplit * dh * lp;
     fa.l_part = fa.m_part + (int64_t)B * H * fa.nsplit * lp;
     HIPCHK(launch_kvsplit8_convert(k, v, Lk * C, dh, C, Lk * C, dh, C, B, H, Lk, cache, s));
-    HIPCHK(launch_flash_split8(fa, cache, s));
+    HIPCHK(launch_flash_split8(fa, cache, s, p_lo != 0));
     HIPCHK(launch_flash_merge(fa, s));
     return PARQ_OK;
 }

@@ -339,6 +339,10 @@ struct FlashArgs {
     float* lse;                 // optional [B*H][Lq_pad]: log2-domain log-sum-exp of every query row (training)
     float drop_p; uint32_t drop_seed;   // training: dropout on the attention probabilities, element (row bh * Lq + q, col key)
     int flags;                  // bit 0: raise the priority of the younger half of the workgroup (pipelined split kernel)
+    // attention mode 4: its error grows as a row concentrates on few keys (flash_split8.hip).  The merge kernel knows every row's
+    // sum l of probabilities relative to the row's reference maximum — roughly the number of keys that carry the row — and
+    // raises *peaky when some row's l is under peaky_l (nullptr / 0: no check)
+    int* peaky; float peaky_l;
 };
 int flash_key_tile(int dh);                    // keys per LDS tile
 int flash_lq_pad(int Lq);
@@ -376,7 +380,8 @@ hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t
 bool flash_split8_supported(int dh, int Lk);
 hipError_t launch_kvsplit8_convert(const float* K, const float* V, int64_t k_batch, int64_t k_head, int64_t k_row, int64_t v_batch,
                                    int64_t v_head, int64_t v_row, int B, int H, int N, void* cache, hipStream_t s);
-hipError_t launch_flash_split8(const FlashArgs& a, const void* cache, hipStream_t s);
+hipError_t launch_flash_split8(const FlashArgs& a, const void* cache, hipStream_t s,
+                               bool p_lo = false);      // p_lo: the probabilities with their fp8 lo part too (kernel tests; the decoder runs without)
 // kvproj_split.hip: tokens -> split cache directly (W pre-split with launch_split_f32)
 hipError_t launch_split_f32(const float* src, void* hi, void* lo, int64_t n, hipStream_t s);
 // elementwise.hip: up to kGatherMax device-to-device float copies in ONE launch (the weight pack: ~50 tensors per training step)
@@ -532,7 +537,8 @@ struct BoxDecodeArgs {
     float *logits, *center, *size, *rot, *prob;     // outputs (coord_pos is written by project_sample)
     float* ref_next;                   // [M][3] or nullptr
     float* emb_next;                   // [M][384] or nullptr: pos2posemb3d(ref_next)
-    int* poison_mirror;                // optional host-visible int set to 1 when outputs are poisoned
+    int* poison_mirror;                // optional host-visible int: bit 0 set when outputs are poisoned, bit 1 when *peaky is set
+    const int* peaky;                  // optional device int raised by the cross-attention merge of attention mode 4 (FlashArgs::peaky)
     const int* poison;                 // optional device int: non-zero (fp16 operand range exceeded while the K/V cache was built) ->
                                        // every output of the iteration is written as NaN instead of a plausible wrong number
 };

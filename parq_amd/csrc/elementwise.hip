@@ -250,6 +250,7 @@ __global__ __launch_bounds__(256) void box_decode_kernel(BoxDecodeArgs a) {
     const int scene = m / a.rows_per_scene;
     const bool poison = a.poison != nullptr && *a.poison != 0;          // wave-uniform scalar load
     if (poison && a.poison_mirror != nullptr && m == 0 && lane == 0) *a.poison_mirror = 1;       // tell the host (pinned word)
+    if (a.peaky != nullptr && a.poison_mirror != nullptr && m == 0 && lane == 0 && *a.peaky != 0) atomicOr(a.poison_mirror, 2);
     // every independent load is issued before the first dependent use (this kernel is pure latency)
     const float* h1 = a.h1 + (int64_t)m * a.ld1;
     const float lg_in = lane < a.ncls ? h1[lane] : -INFINITY;
@@ -408,6 +409,7 @@ __global__ __launch_bounds__(256) void box_decode256_kernel(BoxDecodeArgs a) {
     __builtin_amdgcn_sched_barrier(0);                                   // keep every load above the first wait
     const bool poison = a.poison != nullptr && *a.poison != 0;          // wave-uniform scalar load
     if (poison && a.poison_mirror != nullptr && m == 0 && lane == 0) *a.poison_mirror = 1;
+    if (a.peaky != nullptr && a.poison_mirror != nullptr && m == 0 && lane == 0 && *a.peaky != 0) atomicOr(a.poison_mirror, 2);
 
     const float lg_in = lane < a.ncls ? lg_raw : -INFINITY;
     const float sz_in = lane < 3 ? sz_raw : 0.f;

@@ -282,6 +282,9 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(FlashArgs a) {
     for (int i = 0; i < 8; ++i) den += dsm[i * 32 + tq];
     const float inv = 1.f / den;
     if (a.lse && blockIdx.z == 0 && td == 0 && q < a.Lq) a.lse[(int64_t)bh * Lq_pad + q] = mmax + log2f(den);
+    if (a.peaky && blockIdx.z == 0 && td == 0) {                     // attention mode 4: a row carried by too few keys (FlashArgs)
+        if (__any(q < a.Lq && den < a.peaky_l) && tq == 0) atomicOr(a.peaky, 1);
+    }
 
     // thread -> (4 queries, one d, one of NG groups of the splits)
     const int q4 = threadIdx.x & 7;
@@ -559,6 +562,12 @@ __global__ __launch_bounds__(256) void flash_merge_fixed_kernel(FlashArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) dn += dsm[i * 32 + tq];
         a.lse[(int64_t)bh * Lq_pad + q] = mmax + log2f(dn);
+    }
+    if (a.peaky && blockIdx.z == 0 && td == 0) {                     // attention mode 4: a row carried by too few keys (FlashArgs)
+        float dn = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dn += dsm[i * 32 + tq];
+        if (__any(dn < a.peaky_l) && tq == 0) atomicOr(a.peaky, 1);
     }
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll

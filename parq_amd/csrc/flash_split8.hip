@@ -151,7 +151,11 @@ __device__ __forceinline__ f32x16 mx64(i32x8 a, i32x8 b, f32x16 c, int sel_a, in
 // PROBE (development, results wrong): 1 no softmax VALU, 2 no PV MFMAs, 4 no QK MFMAs, 8 no barrier / DMA waits, 16 no fragment reads;
 // 32 (results right): the written order of a step pinned with scheduling fences — 108.9 us against 105.3 for hipcc's own order of the
 // same instructions (round 4, one box), so the product build has none.
-template <int PROBE = 0, int RING = kRing, bool REV = false>
+// P16: the probabilities enter P V as ONE fp16 value each (no lo part: the P_lo . V_hi cross term, its conversions and its MX
+// instructions are gone) and the NORMALISER sums those same rounded values, so the weights p~ / sum p~ stay self-consistent: a row that
+// one key dominates is exact, a spread row averages the 2^-12 relative weight noise away (modelled on the reference's fixtures:
+// 3.5e-6 -> 3.9e-6 at 96 000 keys, 2.3e-6 -> 8.6e-6 at 3 840; tests/emulate_attention_arithmetic.py).  V keeps both of its terms.
+template <int PROBE = 0, int RING = kRing, bool REV = false, bool P16 = true>
 __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, const unsigned char* __restrict__ cache) {
     PARQ_TL_KERNEL(kTlFlashSplit);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [kRing stages]
@@ -299,10 +303,14 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
             for (int par = 0; par < 2; ++par) {
                 const int pb = rev ? 1 - par : par;
                 const int off = (((pb * 2 + dt) * 2 + kh) * 32 + li) * 16;
-                const i32x4 hv = *reinterpret_cast<const i32x4*>(st + oV8hi + off);
                 const i32x4 lv = *reinterpret_cast<const i32x4*>(st + oV8lo + off);
 #pragma unroll
-                for (int w = 0; w < 4; ++w) { v8h[dt][4 * par + w] = hv[w]; v8l[dt][4 * par + w] = lv[w]; }
+                for (int w = 0; w < 4; ++w) v8l[dt][4 * par + w] = lv[w];
+                if constexpr (!P16) {
+                    const i32x4 hv = *reinterpret_cast<const i32x4*>(st + oV8hi + off);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) v8h[dt][4 * par + w] = hv[w];
+                }
             }
     };
     // cross terms of P V for the stage whose probabilities sit in p8h / p8l
@@ -311,7 +319,8 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) o[dt] = mx64(v8l[dt], p8h, o[dt], 0, kE8Lo, 0, pscale);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) o[dt] = mx64(v8h[dt], p8l, o[dt], 0, kE8One, 1, pscale);
+        for (int dt = 0; dt < 2; ++dt)
+            if constexpr (!P16) o[dt] = mx64(v8h[dt], p8l, o[dt], 0, kE8One, 1, pscale);
     };
     auto block_max = [&](const f32x16& S) -> float {
         float m0 = fmaxf(S[0], S[1]), m1 = fmaxf(S[8], S[9]);
@@ -325,11 +334,18 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
         constexpr int CUR = decltype(cur)::value, J = decltype(jj)::value, M = J >> 2, W = J & 3;
         const float p0 = __builtin_amdgcn_exp2f(sacc[CUR][2 * J]);             // the accumulator holds score - m_run
         const float p1 = __builtin_amdgcn_exp2f(sacc[CUR][2 * J + 1]);
-        l_a += p0;
-        l_b += p1;
         unsigned hw;
-        float d0, d1;
-        split_rtz(p0, p1, hw, d0, d1);
+        float d0 = 0.f, d1 = 0.f;
+        if constexpr (P16) {
+            // the row sum takes the fp16 values the matrix pipe will multiply (round toward zero: a common bias cancels in p~ / sum p~)
+            hw = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p0, p1));
+            asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(l_a) : "v"(hw));
+            asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l_b) : "v"(hw));
+        } else {
+            l_a += p0;
+            l_b += p1;
+            split_rtz(p0, p1, hw, d0, d1);
+        }
         u32x4 h4 = __builtin_bit_cast(u32x4, Ph[CUR][M]);
         h4[W] = hw;
         Ph[CUR][M] = __builtin_bit_cast(half8, h4);
@@ -342,13 +358,13 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
         int wh = p8h[R], wl = p8l[R];
         if constexpr ((J & 1) == 0) {
             asm("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3" : "+v"(wh) : "v"(p0), "v"(p1), "s"(1.f / 64.f));
-            asm("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3" : "+v"(wl) : "v"(d0), "v"(d1), "s"(1.f / 65536.f));
+            if constexpr (!P16) asm("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3" : "+v"(wl) : "v"(d0), "v"(d1), "s"(1.f / 65536.f));
         } else {
             asm("s_nop 0\n\tv_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(wh) : "v"(p0), "v"(p1), "s"(1.f / 64.f));
-            asm("s_nop 0\n\tv_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(wl) : "v"(d0), "v"(d1), "s"(1.f / 65536.f));
+            if constexpr (!P16) asm("s_nop 0\n\tv_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(wl) : "v"(d0), "v"(d1), "s"(1.f / 65536.f));
         }
         p8h[R] = wh;
-        p8l[R] = wl;
+        if constexpr (!P16) p8l[R] = wl;
     };
 #define PARQ_FENCE() do { if constexpr ((PROBE & 32) != 0) __builtin_amdgcn_sched_barrier(0); } while (0)
     // step n: QK(n + 1) -> sacc[NXT]; softmax(n) from sacc[CUR]; fp16 P V of block n - 1; odd n: at its end the fp8 cross terms of
@@ -470,12 +486,11 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
                 float p[8], dl[8];
                 unsigned hw[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    p[e] = __builtin_amdgcn_exp2f(sacc[1][8 * m + e]);
-                    l_run += p[e];
-                }
+                for (int e = 0; e < 8; ++e) p[e] = __builtin_amdgcn_exp2f(sacc[1][8 * m + e]);
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) split_rtz(p[e], p[e + 1], hw[e >> 1], dl[e], dl[e + 1]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) l_run += P16 ? p[e] - dl[e] : p[e];         // P16: the fp16 value itself (p - lo, exact)
                 Ph[1][m] = __builtin_bit_cast(half8, u32x4{hw[0], hw[1], hw[2], hw[3]});
 #pragma unroll
                 for (int w = 0; w < 2; ++w) {
@@ -485,7 +500,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
                     asm("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3" : "=v"(b0) : "v"(dl[4 * w]), "v"(dl[4 * w + 1]), "s"(1.f / 65536.f));
                     asm("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3" : "=v"(b1) : "v"(dl[4 * w + 2]), "v"(dl[4 * w + 3]), "s"(1.f / 65536.f));
                     p8h[4 + 2 * m + w] = (int)__builtin_amdgcn_perm((unsigned)a1, (unsigned)a0, 0x05040100u);
-                    p8l[4 + 2 * m + w] = (int)__builtin_amdgcn_perm((unsigned)b1, (unsigned)b0, 0x05040100u);
+                    if constexpr (!P16) p8l[4 + 2 * m + w] = (int)__builtin_amdgcn_perm((unsigned)b1, (unsigned)b0, 0x05040100u);
                 }
             }
 #pragma unroll
@@ -553,7 +568,7 @@ hipError_t launch_kvsplit8_convert(const float* K, const float* V, int64_t k_bat
     return hipGetLastError();
 }
 
-hipError_t launch_flash_split8(const FlashArgs& a, const void* cache, hipStream_t s) {
+hipError_t launch_flash_split8(const FlashArgs& a, const void* cache, hipStream_t s, bool p_lo) {
     if (!flash_split8_supported(a.dh, a.Lk) || a.nsplit < 1 || a.nsplit > 256 || a.drop_p > 0.f) return hipErrorInvalidValue;
     FlashArgs b = a;
     b.defer_log2 = kDefer8;
@@ -561,14 +576,15 @@ hipError_t launch_flash_split8(const FlashArgs& a, const void* cache, hipStream_
     b.flags = ((a.flags & 2) ? 2 : 0) | ((wt && a.Lq % 256 == 0) ? 8 : 0);
     const dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * b.H);
     const unsigned char* c8 = reinterpret_cast<const unsigned char*>(cache);
-#define PARQ_F8_LAUNCH_RR(PROBE, RING, REV)                                                                                    \
+#define PARQ_F8_LAUNCH_RRP(PROBE, RING, REV, P16)                                                                              \
     {                                                                                                                          \
         static DynLdsOnce once;                                                                                                \
         const size_t lds = (size_t)(RING) * kStageBytes;                                                                       \
-        if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_split8_kernel<PROBE, RING, REV>), lds); e != hipSuccess) return e; \
-        hipLaunchKernelGGL((flash_split8_kernel<PROBE, RING, REV>), grid, dim3(kNW * 64), lds, s, b, c8);                       \
+        if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_split8_kernel<PROBE, RING, REV, P16>), lds); e != hipSuccess) return e; \
+        hipLaunchKernelGGL((flash_split8_kernel<PROBE, RING, REV, P16>), grid, dim3(kNW * 64), lds, s, b, c8);                  \
         return hipGetLastError();                                                                                              \
     }
+#define PARQ_F8_LAUNCH_RR(PROBE, RING, REV) PARQ_F8_LAUNCH_RRP(PROBE, RING, REV, true)
 #define PARQ_F8_LAUNCH_R(PROBE, RING)                                                                                          \
     {                                                                                                                          \
         if (b.flags & 2) PARQ_F8_LAUNCH_RR(PROBE, RING, true)                                                                  \
@@ -592,10 +608,12 @@ hipError_t launch_flash_split8(const FlashArgs& a, const void* cache, hipStream_
     const int ring = [] { const char* e = dev_env("PARQ_FLASH_RING"); return e && e[0] == '5' ? 5 : 4; }();
     if (ring == 5) PARQ_F8_LAUNCH_R(0, 5)
 #endif
+    if (p_lo) { if (b.flags & 2) PARQ_F8_LAUNCH_RRP(0, kRing, true, false) PARQ_F8_LAUNCH_RRP(0, kRing, false, false) }
     PARQ_F8_LAUNCH(0)
 #undef PARQ_F8_LAUNCH
 #undef PARQ_F8_LAUNCH_R
 #undef PARQ_F8_LAUNCH_RR
+#undef PARQ_F8_LAUNCH_RRP
 }
 
 }  // namespace parq

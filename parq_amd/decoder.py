@@ -280,15 +280,18 @@ class PARQDecoder(nn.Module):
         #   "sync": wait for the flag after every inference forward and transparently re-run that forward with the exact
         #           fp32 kernels (costs one host synchronisation per forward).
         #   "off":  only ``fp16_range_exceeded()`` on request.
+        # The same policy covers attention mode "split8" meeting rows that rest on too few keys for its error model (the merge kernel
+        # flags rows whose probability sum is under 64): "lazy" switches the module to "split" at the next call (the forwards in
+        # flight keep their numbers: reduced accuracy on those rows, not NaN), "sync" re-runs the forward in "split".
         self.range_check = "lazy"
         self._range_mirror = None         # pinned host int32 the device raises on a range violation
 
     # ------------------------------------------------------------------ fp16 operand range (split / fp16 modes)
-    def _flag_view(self, ws, B, V, h, w):
+    def _flag_view(self, ws, B, V, h, w, words=1):
         off, n = C.c_size_t(), C.c_size_t()
         _lib.check(_lib.load().parq_workspace_lookup(self._handle(apply_mode=False), B, V, h, w, b"flags", C.byref(off), C.byref(n)),
                    "parq_workspace_lookup")
-        return ws[off.value: off.value + 1].view(torch.int32)
+        return ws[off.value: off.value + words].view(torch.int32)
 
     def _range_fallback(self, where):
         import warnings
@@ -297,20 +300,40 @@ class PARQDecoder(nn.Module):
                       % (self.attention_mode, where), RuntimeWarning, stacklevel=3)
         self.attention_mode = "fp32"
 
+    def _peaky_fallback(self, where):
+        import warnings
+        warnings.warn("parq_amd.PARQDecoder: a cross-attention row rests on too few keys for attention mode 'split8' (%s): its error "
+                      "model (fp8 cross terms, fp16 probabilities) assumes rows that spread over many keys.  Switching attention_mode to "
+                      "'split' (all three terms of every product in fp16) for this module." % where, RuntimeWarning, stacklevel=3)
+        self.attention_mode = "split"
+
     def _range_poll(self):
-        """A host load of the pinned word earlier forwards raise from the device on a violation (no synchronisation)."""
-        if self._range_mirror is not None and int(self._range_mirror[0]) != 0:
+        """A host load of the pinned word earlier forwards raise from the device (no synchronisation): bit 0 = an operand left the
+        fp16 range (outputs of that forward are NaN), bit 1 = attention mode 'split8' met a row carried by too few keys (outputs of
+        that forward are numbers, at that mode's reduced accuracy for such rows)."""
+        v = int(self._range_mirror[0]) if self._range_mirror is not None else 0
+        if v != 0:
             self._range_mirror[0] = 0
-            if self.range_check != "off" and self.attention_mode in ("split", "split8", "fp16"):
+            if self.range_check == "off":
+                return
+            if (v & 1) and self.attention_mode in ("split", "split8", "fp16"):
                 self._range_fallback("detected after an earlier forward")
+            elif (v & 2) and self.attention_mode == "split8":
+                self._peaky_fallback("detected after an earlier forward")
 
     def _range_after_forward(self, ws, sc):
-        """"sync" policy: wait for the flag of the forward just enqueued; True = re-run it with the fp32 kernels."""
+        """"sync" policy: wait for the flags of the forward just enqueued; True = re-run it (with the fp32 kernels after a range
+        violation, in mode 'split' after a too-peaked row in mode 'split8')."""
         if self.range_check != "sync" or self.attention_mode not in ("split", "split8", "fp16"):
             return False
-        if int(self._flag_view(ws, sc.B, sc.V, sc.h, sc.w).item()) != 0:
+        flags = self._flag_view(ws, sc.B, sc.V, sc.h, sc.w, 2).tolist()
+        if flags[0] != 0:
             self._range_mirror[0] = 0
             self._range_fallback("re-running this forward")
+            return True
+        if flags[1] != 0 and self.attention_mode == "split8":
+            self._range_mirror[0] = 0
+            self._peaky_fallback("re-running this forward")
             return True
         return False
 
@@ -569,7 +592,7 @@ class PARQDecoder(nn.Module):
             def rerun_if_poisoned(completed):
                 """`completed`: the caller knows the forward has finished on the device (the pinned word is then current);
                 otherwise the device flag is read, which waits for the stream."""
-                poisoned = (int(self._range_mirror[0]) != 0) if completed else \
+                poisoned = ((int(self._range_mirror[0]) & 1) != 0) if completed else \
                     int(self._flag_view(self._train_ws, sc.B, sc.V, sc.h, sc.w).item()) != 0
                 if not poisoned:
                     return False
@@ -754,6 +777,16 @@ class PARQDecoder(nn.Module):
             return False
         return bool(self._flag_view(ws, B, V, h, w).item() != 0)
 
+    def attention_too_peaked(self):
+        """True if the last inference forward in attention mode "split8" met a cross-attention row whose probabilities (relative to
+        the row's reference maximum) sum to less than 64, i.e. a row that rests on too few keys for that mode's error model
+        (synchronises).  ``range_check`` handles it: "lazy" switches the module to "split" at the next call, "sync" re-runs the
+        forward in "split" before returning."""
+        if not self._ws:
+            return False
+        (B, V, h, w, _), ws = list(self._ws.items())[-1]
+        return bool(self._flag_view(ws, B, V, h, w, 2)[1].item() != 0)
+
     def intermediate(self, name):
         """View of a named workspace buffer after prepare()/iterate() (parity tests)."""
         sc, keep, ws, dev = self._step
@@ -807,7 +840,7 @@ class PARQDecoder(nn.Module):
         self.wait_iteration(k)
         if self._train_pending is None:
             return False
-        if int(self._range_mirror[0]) == 0 and k + 1 < self.num_layers:
+        if (int(self._range_mirror[0]) & 1) == 0 and k + 1 < self.num_layers:
             return False                                   # nothing raised so far
         self.wait_iteration(self.num_layers - 1)           # the whole forward, then the pinned word is final
         pending, self._train_pending = self._train_pending, None
@@ -822,7 +855,7 @@ class PARQDecoder(nn.Module):
             pending(False)                                 # outputs not consumed yet by this module: re-run in place if poisoned
             return
         self.wait_iteration(self.num_layers - 1)
-        if int(self._range_mirror[0]) != 0:
+        if (int(self._range_mirror[0]) & 1) != 0:
             self._range_mirror[0] = 0
             self._range_fallback("detected in backward()")
             raise RuntimeError("parq_amd.PARQDecoder: the training forward of this step left the fp16 operand range and its outputs are "

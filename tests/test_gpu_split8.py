@@ -13,38 +13,23 @@ from gpu_util import dev, lib, make_decoder, scene_args, sptr, to_np, rel_err
 pytestmark = pytest.mark.gpu
 
 
-def _attn(fn, q, k, v, B, H, Lq, Lk):
+def _attn(fn, q, k, v, B, H, Lq, Lk, *extra):
     nbytes = lib().parq_k_attention_split_scratch_bytes(B, H, Lq, Lk)
     scratch = torch.zeros(nbytes // 4 + 1, device="cuda")
     out = torch.empty(B, Lq, H * 64, device="cuda")
     dq, dk, dv = dev(q), dev(k), dev(v)
-    _lib.check(getattr(lib(), fn)(_lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(out), B, H, Lq, Lk, _lib.ptr(scratch), nbytes, sptr()), fn)
+    _lib.check(getattr(lib(), fn)(_lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(out), B, H, Lq, Lk, *extra, _lib.ptr(scratch), nbytes, sptr()), fn)
     torch.cuda.synchronize()
     return out.cpu().numpy()
+
+
+def _split8(q, k, v, B, H, Lq, Lk, p_lo=0):
+    return _attn("parq_k_attention_split8", q, k, v, B, H, Lq, Lk, p_lo)
 
 
 def _want(q, k, v, B, H, Lq):
     tq, tk, tv = (torch.from_numpy(x).double().view(B, -1, H, 64).transpose(1, 2) for x in (q, k, v))
     return (torch.softmax(tq @ tk.transpose(-1, -2) / 8.0, -1) @ tv).transpose(1, 2).reshape(B, Lq, H * 64).numpy()
-
-
-@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 1, 32, 64), (1, 1, 32, 128), (1, 4, 64, 9600), (2, 4, 256, 256), (1, 2, 40, 448), (1, 4, 256, 19200),
-                                       (2, 1, 300, 1024), (1, 4, 256, 192000)])
-def test_attention_split8_against_float64(B, H, Lq, Lk):
-    """Unit-scale q, k, v (scores of a few units: the regime of the decoder, where the measured distance of this mode from float64 at
-    the outputs is 1e-6 .. 4e-6): 5e-5 here, with ragged Lq, one to many key splits and both sweep directions of the long cases."""
-    Cn = H * 64
-    q = synth.normal(1, "q", (B, Lq, Cn)); k = synth.normal(2, "k", (B, Lk, Cn)); v = synth.normal(3, "v", (B, Lk, Cn))
-    ties = np.array([1 + 2.0 ** -11, -(2 + 2.0 ** -10), 0.5 + 2.0 ** -12, 3 * 2.0 ** -14 + 2.0 ** -25, 0.20623779296875], np.float32)
-    k[0, Lk - 1, :5] = ties
-    v[0, 0, :5] = ties
-    want = _want(q, k, v, B, H, Lq)
-    e8 = rel_err(_attn("parq_k_attention_split8", q, k, v, B, H, Lq, Lk), want)
-    e3 = rel_err(_attn("parq_k_attention_split", q, k, v, B, H, Lq, Lk), want)
-    e1 = rel_err(_attn_half(q, k, v, B, H, Lq, Lk), want)
-    print("\nsplit8 (%d,%d,%d,%d): vs float64 %.2e (fp16 x 3: %.2e, one fp16 product: %.2e)" % (B, H, Lq, Lk, e8, e3, e1))
-    assert e8 < 5e-5, e8
-    assert e8 < e1 / 8, (e8, e1)                   # an order of magnitude inside the single-product mode
 
 
 def _attn_half(q, k, v, B, H, Lq, Lk):
@@ -57,18 +42,41 @@ def _attn_half(q, k, v, B, H, Lq, Lk):
     return out.cpu().numpy()
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 1, 32, 64), (1, 1, 32, 128), (1, 4, 64, 9600), (2, 4, 256, 256), (1, 2, 40, 448), (1, 4, 256, 19200),
+                                       (2, 1, 300, 1024), (1, 4, 256, 192000)])
+def test_attention_split8_against_float64(B, H, Lq, Lk):
+    """Unit-scale q, k, v, ragged Lq, one to many key splits, both sweep directions of the long cases.  The kernel as the decoder
+    runs it carries each probability as ONE fp16 value (and normalises by the sum of those values): a row over N comparable keys
+    is off by ~2^-12 |v| / sqrt(N) — 3e-4 is the bound for the 64-key cases, 3e-5 from 9 600 keys on (measured 1e-5 and 2e-6).
+    With the probabilities' fp8 lo part (p_lo = 1, the kernel's other instantiation) the bound is 5e-5 at every size."""
+    Cn = H * 64
+    q = synth.normal(1, "q", (B, Lq, Cn)); k = synth.normal(2, "k", (B, Lk, Cn)); v = synth.normal(3, "v", (B, Lk, Cn))
+    ties = np.array([1 + 2.0 ** -11, -(2 + 2.0 ** -10), 0.5 + 2.0 ** -12, 3 * 2.0 ** -14 + 2.0 ** -25, 0.20623779296875], np.float32)
+    k[0, Lk - 1, :5] = ties
+    v[0, 0, :5] = ties
+    want = _want(q, k, v, B, H, Lq)
+    e8 = rel_err(_split8(q, k, v, B, H, Lq, Lk), want)
+    e8p = rel_err(_split8(q, k, v, B, H, Lq, Lk, 1), want)
+    e3 = rel_err(_attn("parq_k_attention_split", q, k, v, B, H, Lq, Lk), want)
+    e1 = rel_err(_attn_half(q, k, v, B, H, Lq, Lk), want)
+    print("\nsplit8 (%d,%d,%d,%d): vs float64 %.2e (with P lo: %.2e; fp16 x 3: %.2e; one fp16 product: %.2e)" % (B, H, Lq, Lk, e8, e8p, e3, e1))
+    assert e8 < (3e-5 if Lk >= 9600 else 3e-4), e8
+    assert e8p < 5e-5, e8p
+    assert e8 < e1                                  # inside the single-product mode (whose K, V, Q are rounded too)
+
+
 def test_attention_split8_error_grows_with_the_operand_scale_as_modelled():
     """The cross terms carry 4 significant bits, i.e. a score is off by ~2^-15 |q||k| and a probability by that times ln 2: large
     operands with peaky rows are the worst case of this mode (the fp16 x 3 mode stays at 3e-6 on it).  Stated bound for k of scale 2
-    with a row three times its query, v of scale 3: 5e-4 of max(1, |value|)."""
+    with a row three times its query, v of scale 3: 1e-3 of max(1, |value|)."""
     B, H, Lq, Lk = 1, 4, 64, 9600
     Cn = H * 64
     q = synth.normal(1, "q", (B, Lq, Cn)); k = synth.normal(2, "k", (B, Lk, Cn), std=2.0); v = synth.normal(3, "v", (B, Lk, Cn), std=3.0)
     k[0, 0, :64] = 3.0 * q[0, 0, :64]
     want = _want(q, k, v, B, H, Lq)
-    e8 = rel_err(_attn("parq_k_attention_split8", q, k, v, B, H, Lq, Lk), want)
+    e8 = rel_err(_split8(q, k, v, B, H, Lq, Lk), want)
     print("\nsplit8, k x 2, v x 3, one peaky row: %.2e" % e8)
-    assert 2e-6 < e8 < 5e-4, e8
+    assert 2e-6 < e8 < 1e-3, e8
 
 
 def _flat_with_spikes(spikes, Lk=1024, Lq=64):
@@ -89,18 +97,20 @@ def test_attention_split8_reference_moves(spikes):
     """The running maximum moves (by an integer, past a margin of 2 in the log2 domain) when a later key dominates: in the first
     and in the second block of a stage, twice in one stage, in consecutive stages, by more octaves than the fp16 / E8M0 ranges of
     the pending probabilities, in the last stage of a split.  Everything that waits for its P V at that moment is rescaled exactly
-    (accumulators, row sums, fp16 probabilities times 2^-d, fp8 probabilities through the scale operand of their block).  V is
-    chosen exactly representable in e4m3 here, so that only the probabilities carry cross terms: a row that ONE key dominates shows
-    the 2^-15 of that key's fp8 residual unaveraged (3e-5 of |v|: the resolution of this mode; bound 6e-5) — a block whose cross terms
-    missed their factor 2^-d, or had it applied twice, would be off by (2^d - 1) 2^-12 of that block's weight (2.4e-4 and up here)."""
+    (accumulators, row sums, fp16 probabilities times 2^-d, fp8 probabilities through the scale operand of their block).  Checked
+    on the instantiation whose probabilities keep their fp8 lo part (p_lo = 1): V is exactly representable in e4m3 here, so only
+    the probabilities carry cross terms; a row that ONE key dominates shows that key's 2^-15 unaveraged (bound 6e-5), a block
+    whose cross terms missed their factor 2^-d, or had it applied twice, would be off by (2^d - 1) 2^-12 of that block's weight
+    (2.4e-4 and up).  The decoder's instantiation (fp16 probabilities) on the same inputs: 3e-4 (its 2^-11 on the dominating key)."""
     q, k, v = _flat_with_spikes(spikes)
     want = _want(q, k, v, 1, 1, 64)
-    for Lk_used in (1024,):
-        got = _attn("parq_k_attention_split8", q, k, v, 1, 1, 64, Lk_used)
-        assert np.isfinite(got).all()
-        e = rel_err(got, want)
-        print("\nspikes %s: %.2e" % (spikes, e))
-        assert e < 6e-5, (spikes, e)
+    got = _split8(q, k, v, 1, 1, 64, 1024, 1)
+    assert np.isfinite(got).all()
+    e = rel_err(got, want)
+    e16 = rel_err(_split8(q, k, v, 1, 1, 64, 1024, 0), want)
+    print("\nspikes %s: with P lo %.2e, fp16 probabilities %.2e" % (spikes, e, e16))
+    assert e < 6e-5, (spikes, e)
+    assert e16 < 3e-4, (spikes, e16)
 
 
 def test_attention_split8_saturates_instead_of_poisoning():
@@ -111,7 +121,7 @@ def test_attention_split8_saturates_instead_of_poisoning():
     v[0, 5, 7] = 3000.0
     k[0, 9, 3] = -900.0
     want = _want(q, k, v, B, H, Lq)
-    got = _attn("parq_k_attention_split8", q, k, v, B, H, Lq, Lk)
+    got = _split8(q, k, v, B, H, Lq, Lk)
     assert np.isfinite(got).all()
     assert rel_err(got, want) < 5e-3
 
@@ -138,10 +148,68 @@ def _forced(name, mode):
 
 @pytest.mark.parametrize("name", ["g18_cfg3_smooth", "g19_cfg2"])
 def test_decoder_split8_against_the_reference_fixtures(name):
-    """Teacher-forced, every iteration: mode 4 against float64 (bound 2e-5; measured 1e-6 .. 4e-6) beside the fp16 x 3 mode, on the
+    """Teacher-forced, every iteration: mode 4 against float64 (bound 2e-5; measured 2e-6 .. 4e-6) beside the fp16 x 3 mode, on the
     fixtures captured from the reference at cfg 3's and cfg 2's geometry (the white-noise cfg-3 fixture g14 runs this mode in
     tests/test_gpu_headline.py, the pins against the reference's own vectors in tests/test_gpu_reference_pins.py)."""
     t8 = _forced(name, "split8")
     t3 = _forced(name, "split")
     print("\n%s: vs float64  split8 %.2e | split %.2e" % (name, t8, t3))
     assert t8 < 2e-5
+
+
+def _sharpened(scale):
+    """g15 (cfg 5's decoder shape on small feature maps: 15 360 keys, 512 queries) with the cross-attention query projection scaled:
+    x 1 spreads every row over thousands of keys, x 4 leaves rows that two or three keys carry."""
+    case, z = G.load("g15_cfg5_shape")
+    cfg, W, sc = G.inputs(case)
+    W = dict(W)
+    key = "parq_module.decoder.layers.0.multihead_attn.in_proj_weight"
+    w = W[key].copy()
+    w[:w.shape[1]] *= scale
+    W[key] = w
+    return cfg, W, sc, G.forced_refs(z, cfg.TRANSFORMER.SCALE)
+
+
+def test_split8_guard_lets_spread_attention_through():
+    cfg, W, sc, refs = _sharpened(1.0)
+    dec = make_decoder(cfg, W)
+    assert dec.attention_mode == "split8"
+    dec.range_check = "sync"
+    with torch.no_grad():
+        dec(*scene_args(sc))
+    assert dec.attention_mode == "split8" and not dec.attention_too_peaked()
+
+
+@pytest.mark.parametrize("policy", ["sync", "lazy"])
+def test_split8_guard_falls_back_on_peaked_attention(policy):
+    """Rows that rest on a handful of keys are outside mode 4's error model: the merge kernel flags them (probability sum under 64),
+    "sync" re-runs the forward with all three terms in fp16 before returning — the outputs ARE those of mode "split" — and "lazy"
+    switches the module at the next call."""
+    import warnings
+    cfg, W, sc, refs = _sharpened(4.0)
+    ref = make_decoder(cfg, W)
+    ref.attention_mode = "split"
+    with torch.no_grad():
+        want = [{k: v.clone() for k, v in o.items()} for o in ref(*scene_args(sc))]
+    dec = make_decoder(cfg, W)
+    dec.range_check = policy
+    assert dec.attention_mode == "split8"
+    with warnings.catch_warnings(record=True) as caught, torch.no_grad():
+        warnings.simplefilter("always")
+        got = [{k: v.clone() for k, v in o.items()} for o in dec(*scene_args(sc))]
+        torch.cuda.synchronize()
+        if policy == "sync":
+            assert dec.attention_mode == "split"
+            for a, b in zip(got, want):
+                for k in a:
+                    assert torch.equal(a[k], b[k]), k
+        else:
+            assert dec.attention_mode == "split8" and dec.attention_too_peaked()      # numbers, not NaN; the notice is pending
+            assert all(torch.isfinite(v).all() for o in got for v in o.values())
+            again = dec(*scene_args(sc))                                              # the next call polls the mirror first
+            torch.cuda.synchronize()
+            assert dec.attention_mode == "split"
+            for a, b in zip(again, want):
+                for k in a:
+                    assert torch.equal(a[k], b[k]), k
+    assert any("too few keys" in str(w.message) for w in caught)
