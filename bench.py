@@ -600,19 +600,19 @@ def main():
                     "note": "launch time from hipEvents around this kernel alone (its merge kernel is group cross_attn_merge)"}
         if split8:
             # mode 4: one fp16 product + two MX-fp8 products per algorithmic product.  Matrix roof for algorithmic flops:
-            # 1 / (1 / 2500 + 2 / 5000) = 1250 TFLOP/s = 40 us per launch at cfg 3; the K/V stream of the launch (2 N C values x 4 bytes:
+            # 1 / (1 / 2500 + 1.5 / 5000) = 1429 TFLOP/s = 35 us per launch at cfg 3; the K/V stream of the launch (2 N C values x 4 bytes:
             # hi16 + hi8 + lo8 planes) is 49 us at 8 TB/s, so HBM is the roof that bounds this kernel (stream-only build of the kernel:
             # 70 us = 5.6 TB/s, the streaming ceiling of this part; profiles/r04_split8_ingredient_probes.txt)
             stream_gbs = (kv_bytes / (ca_ms / ca_n * 1e-3) / 1e9) if ca_n else None
-            mx_peak = 1.0 / (1.0 / PEAK_F16_MATRIX_TFLOPS + 2.0 / (2.0 * PEAK_F16_MATRIX_TFLOPS))
-            roofline.update({"bound": "hbm", "kernel": "flash_split8_kernel (cross-attention QK^T+PV: hi.hi as fp16 products, the two cross terms "
+            mx_peak = 1.0 / (1.0 / PEAK_F16_MATRIX_TFLOPS + 1.5 / (2.0 * PEAK_F16_MATRIX_TFLOPS))
+            roofline.update({"bound": "hbm", "kernel": "flash_split8_kernel (cross-attention QK^T+PV: hi.hi as fp16 products, the cross terms "
                                                        "as MX-scaled fp8 e4m3 products, fp32 accumulate)",
                              "achieved": stream_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": (stream_gbs / PEAK_HBM_GBS) if stream_gbs else None,
                              "traffic": pmc_traffic("flash_split8_kernel", B) if args.config == "cfg3" else None,
                              "algorithmic_bytes_per_launch": kv_bytes,
                              "peak_note": "HBM3E 8 TB/s; a plain streaming kernel reaches 5.6 TB/s on this part (profiles/r02_hbm_stream_ceiling.txt)",
                              "mfma": {"achieved": ach_tflops, "peak": mx_peak, "unit": "TFLOP/s", "frac": (ach_tflops / mx_peak) if ach_tflops else None,
-                                      "note": "algorithmic flops against 1 / (1/2500 + 2/5000): one fp16 pass + two fp8 passes at twice the rate"}})
+                                      "note": "algorithmic flops against 1 / (1/2500 + 1.5/5000): one fp16 pass + 1.5 fp8 passes (two cross terms of QK, one of PV) at twice the rate"}})
         not_headline = bool(args.dev_lib or parq_env())
         kv_ms, kv_n = prof["kv_proj"]
         kvp_bytes = 3.0 * N * C * 4.0 * B if not half else (N * C * 4.0 + 2.0 * N * C * 2.0) * B     # tokens in, K and V out
@@ -643,10 +643,10 @@ def main():
                                   "iterations_per_sec_at_median": B * I / (pct(0.5) * 1e-3),
                                   "note": "rank 0, one hipEvent pair per forward on the launch stream; `value` is the contract's wall-clock figure"},
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": ("f32 (cross-attention: hi.hi fp16 products + MX-fp8 e4m3 cross terms, ~16 significant bits per product, fp32 "
-                                          "accumulation — 1e-6..4e-6 from float64 at the outputs on the reference's fixtures, the reference's own fp32 run: "
-                                          "6e-5..1.4e-4; K/V projection as fp16 hi/lo split products; `strict_fp16x3` is the same run with all "
-                                          "three terms in fp16)" if split8 else
+            "vs_baseline": None, "dtype": ("f32 (cross-attention: hi.hi fp16 products + MX-fp8 e4m3 cross terms, probabilities as fp16 with a self-consistent "
+                                          "normaliser, fp32 accumulation — 4e-6..7e-6 from float64 at the outputs on the reference's fixtures, the "
+                                          "reference's own fp32 run: 6e-5..1.4e-4; guarded: rows on too few keys fall back to fp16 x 3; K/V projection "
+                                          "as fp16 hi/lo split products; `strict_fp16x3` is the same run with all three terms in fp16)" if split8 else
                                           "f32 (cross-attention and K/V projection as fp16 hi/lo split products with fp32 accumulation)" if split
                                           else "%s cross-attention and K/V projection operands, fp32 accumulation, fp32 elsewhere (reduced precision: not the headline configuration)" % mode if half
                                           else "f32"),

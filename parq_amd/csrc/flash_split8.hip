@@ -144,7 +144,7 @@ __device__ __forceinline__ f32x16 mx64(i32x8 a, i32x8 b, f32x16 c, int sel_a, in
 // with the cross terms of P V taken once per STAGE: the MX contraction is 64 keys long, so P of blocks 2 j and 2 j + 1 is collected
 // in one pair of fp8 registers (16 + 16 bytes per lane) and multiplied at the end of step 2 j + 1 — four MX instructions per stage
 // (2 cross terms x 2 halves of the head dim) instead of 2 x 16 fp16 ones.  Per block: 8 fp16 MFMAs (4 QK, 4 PV) + 2 MX (QK) + 2 MX (PV,
-// amortised) against 24 fp16 MFMAs.
+// amortised; 1 in the decoder's P16 form) against 24 fp16 MFMAs.
 // Running maximum: moves only when a score exceeds it by more than kDefer8, and then by an INTEGER d (ceil), so that everything
 // still waiting to be multiplied is rescaled exactly: the O^T accumulators and row sums by 2^-d, the pending fp16 probabilities
 // by 2^-d (a power of two), the pending fp8 probabilities through the E8M0 scale operand of their block.
