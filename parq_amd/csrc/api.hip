@@ -1665,7 +1665,7 @@ int parq_k_attention_split8(const float* q, const float* k, const float* v, floa
     fa.o_part = (float*)(cache + kvsplit_cache_bytes(B, H, Lk));
     fa.m_part = fa.o_part + (int64_t)B * H * fa.nsplit * dh * lp;
     fa.l_part = fa.m_part + (int64_t)B * H * fa.nsplit * lp;
-    HIPCHK(launch_kvsplit8_convert(k, v, Lk * C, dh, C, Lk * C, dh, C, B, H, Lk, cache, s));
+    HIPCHK(launch_kvsplit8_convert(k, v, Lk * C, dh, C, Lk * C, dh, C, B, H, Lk, cache, s, p_lo != 0));
     HIPCHK(launch_flash_split8(fa, cache, s, p_lo != 0));
     HIPCHK(launch_flash_merge(fa, s));
     return PARQ_OK;

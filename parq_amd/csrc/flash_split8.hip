@@ -12,14 +12,14 @@
 // ones: tools/bench_src/mfma_operands.hip), and the MX instruction at 36 ns for FOUR times the contraction (tools/bench_src/mx_energy.hip).
 // A 32 x 32 x 64 cross term costs 36 ns instead of 80, a whole split product 4 x 20 + 2 x 36 = 152 ns instead of 240 (measured 157).
 //
-// Cache ("stage" = 64 keys = 32 KB, the LDS image equals the global image; written by kvsplit8_convert_kernel or by the K/V
+// Cache ("stage" = 64 keys = 28 KB, the LDS image equals the global image; written by kvsplit8_convert_kernel or by the K/V
 // projection), byte offsets inside a stage:
 //       0  K hi16  [2 blocks][32 keys][8 chunks][8 fp16]     chunk swizzle and d order as in the split cache (flash_split.hip)
 //    8192  K hi8   [2 blocks][2 c][2 h][32 keys][16 B]       piece (c, h) of a key: byte 8 m + e <-> d = 32 m + 16 c + 4 h + (e & 3) + 8 (e >> 2)
 //   12288  K lo8   same, e4m3(lo 2^10)
 //   16384  V hi16  [2 blocks][64 d][4 chunks][8 fp16]        as in the split cache
-//   24576  V hi8   [2 blocks][2 dt][2 h][32 li][16 B]        piece of d = 32 dt + li: byte r <-> key (r & 3) + 8 (r >> 2) + 4 h of the block
-//   28672  V lo8   same
+//   24576  V lo8   [2 blocks][2 dt][2 h][32 li][16 B]        piece of d = 32 dt + li: byte r <-> key (r & 3) + 8 (r >> 2) + 4 h of the block
+//  (28672  V hi8   same — only in the 32 KB form of the kernel tests' p_lo instantiation: the decoder's kernel has no P_lo . V_hi term)
 // The byte orders are the register orders of the 32 x 32 accumulator map, so (a) the K/V projection stores its accumulators as
 // 16-byte pieces, (b) the probabilities of a lane (S^T accumulator registers of two consecutive blocks) ARE the 32 k-values of the
 // MX B operand: P^T of a 64-key stage against V^T, one instruction per cross term and 32 output dims.
@@ -39,7 +39,6 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kDH = 64, kNW = 8, kRing = 4;
-constexpr int kStageBytes = kStage8Bytes;
 constexpr int oKh16 = kS8Kh16, oK8hi = kS8K8hi, oK8lo = kS8K8lo, oVh16 = kS8Vh16, oV8hi = kS8V8hi, oV8lo = kS8V8lo;
 constexpr float kDefer8 = 2.f;                       // probabilities stay under 2^2: p 2^6 fits e4m3 (max 448)
 constexpr int kE8One = 127, kE8Lo = 117;             // E8M0 scales: 2^0, 2^-10 (lo parts of K, V, Q)
@@ -49,6 +48,7 @@ __device__ __forceinline__ int dmap(int kh, int s, int e) { return 32 * (s >> 1)
 
 // ------------------------------------------------------------------------------------------------
 // fp32 head-major K / V -> stage cache.  One workgroup per (stage, b * h); tests and the stand-alone attention entry point.
+template <bool FULL>
 __global__ __launch_bounds__(256) void kvsplit8_convert_kernel(const float* __restrict__ K, const float* __restrict__ V, int64_t k_batch,
                                                                int64_t k_head, int64_t k_row, int64_t v_batch, int64_t v_head,
                                                                int64_t v_row, int H, int N, unsigned char* __restrict__ cache) {
@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void kvsplit8_convert_kernel(const float* __re
         vs[key][d] = vp[n * v_row + d];
     }
     __syncthreads();
+    constexpr int kStageBytes = FULL ? kStage8BytesFull : kStage8Bytes;
     unsigned char* out = cache + ((int64_t)bh * nst + st) * kStageBytes;
     auto hi16x8 = [](const float* x) {
         half8 hi, lo;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void kvsplit8_convert_kernel(const float* __re
         for (int r = 0; r < 16; ++r) x[r] = vs[32 * b2 + (r & 3) + 8 * (r >> 2) + 4 * hh][32 * dt + li];
         i32x4 hi8, lo8;
         pieces_e4m3(x, hi8, lo8);
-        *reinterpret_cast<i32x4*>(out + oV8hi + tid * 16) = hi8;
+        if constexpr (FULL) *reinterpret_cast<i32x4*>(out + oV8hi + tid * 16) = hi8;
         *reinterpret_cast<i32x4*>(out + oV8lo + tid * 16) = lo8;
     }
 }
@@ -160,8 +161,9 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
     PARQ_TL_KERNEL(kTlFlashSplit);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [kRing stages]
     constexpr int NT = kNW * 64;
+    constexpr int kStageBytes = P16 ? kStage8Bytes : kStage8BytesFull;        // 28 KB without the V hi8 plane, 32 KB with it
     constexpr int STAGE16 = kStageBytes / 16;
-    constexpr int LD = STAGE16 / NT;
+    constexpr int LD = (STAGE16 + NT - 1) / NT;                              // the last DMA row of a 28 KB stage is half a row: waves 0 .. 3
     constexpr int AHEAD = RING - 3;                                          // see flash_split.hip: a stage is requested AHEAD barriers before the one that publishes it
 
     const int split = blockIdx.x;
@@ -212,6 +214,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
     auto gload = [&](int st, int slot) {
 #pragma unroll
         for (int i = 0; i < LD; ++i) {
+            if ((i + 1) * NT > STAGE16 && i * NT + wave * 64 >= STAGE16) continue;        // scalar: past the end of a 28 KB stage
             const int64_t idx = (int64_t)st * STAGE16 + tid + i * NT;       // st is a stage of this split: always inside the cache
             lds_byte* dst = (lds_byte*)(smem) + ((size_t)slot * STAGE16 + i * NT + wave * 64) * 16;
             __builtin_amdgcn_global_load_lds(gsrc + idx, dst, 16, 0, 0);
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
     __syncthreads();
     auto sync_point = [&](int j) {
         if constexpr (!(PROBE & 8)) {
-            if (AHEAD >= 2 && t_begin + j + 3 < t_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD) : "memory");
+            if (AHEAD >= 2 && STAGE16 % NT == 0 && t_begin + j + 3 < t_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                    // bare barrier: see flash_split.hip (VAR & 8)
         }
@@ -561,10 +564,12 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
 bool flash_split8_supported(int dh, int Lk) { return dh == kDH && Lk >= 64 && Lk % 64 == 0; }
 
 hipError_t launch_kvsplit8_convert(const float* K, const float* V, int64_t k_batch, int64_t k_head, int64_t k_row, int64_t v_batch,
-                                   int64_t v_head, int64_t v_row, int B, int H, int N, void* cache, hipStream_t s) {
+                                   int64_t v_head, int64_t v_row, int B, int H, int N, void* cache, hipStream_t s, bool full) {
     if (!flash_split8_supported(kDH, N)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kvsplit8_convert_kernel, dim3(N / 64, B * H), dim3(256), 0, s, K, V, k_batch, k_head, k_row, v_batch, v_head,
-                       v_row, H, N, reinterpret_cast<unsigned char*>(cache));
+    if (full) hipLaunchKernelGGL(kvsplit8_convert_kernel<true>, dim3(N / 64, B * H), dim3(256), 0, s, K, V, k_batch, k_head, k_row, v_batch,
+                                 v_head, v_row, H, N, reinterpret_cast<unsigned char*>(cache));
+    else hipLaunchKernelGGL(kvsplit8_convert_kernel<false>, dim3(N / 64, B * H), dim3(256), 0, s, K, V, k_batch, k_head, k_row, v_batch,
+                            v_head, v_row, H, N, reinterpret_cast<unsigned char*>(cache));
     return hipGetLastError();
 }
 
@@ -579,7 +584,7 @@ hipError_t launch_flash_split8(const FlashArgs& a, const void* cache, hipStream_
 #define PARQ_F8_LAUNCH_RRP(PROBE, RING, REV, P16)                                                                              \
     {                                                                                                                          \
         static DynLdsOnce once;                                                                                                \
-        const size_t lds = (size_t)(RING) * kStageBytes;                                                                       \
+        const size_t lds = (size_t)(RING) * ((P16) ? kStage8Bytes : kStage8BytesFull);                                         \
         if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_split8_kernel<PROBE, RING, REV, P16>), lds); e != hipSuccess) return e; \
         hipLaunchKernelGGL((flash_split8_kernel<PROBE, RING, REV, P16>), grid, dim3(kNW * 64), lds, s, b, c8);                  \
         return hipGetLastError();                                                                                              \

@@ -293,7 +293,8 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
     constexpr int C = NK * kBK;
     constexpr int kRawBytes = TM * kBK * 4;      // one k-step of fp32 tokens
     constexpr int NDMA = kRawBytes / (kThr * 16);            // DMA instructions per thread and k-step
-    constexpr int NST = RT * 2 * (SPLIT ? 2 : 1);       // store instructions per thread and tile
+    constexpr int NST_K = RT * 2 * (SPLIT ? 2 : 1);     // store instructions per thread and tile (mode 4: K waves 2 + 1 + 1 per block,
+    constexpr int NST_V = F8 ? RT * 3 : NST_K;          // V waves 2 + 1: the stage cache has no V hi8 plane)
     constexpr int NI = TM * 8 / kThr;            // 8-float pieces of a k-step per thread (conversion)
     static_assert(D >= 3 && D - 2 <= NK && NDMA >= 1 && NI >= 1, "wait counts below assume at most one epilogue inside the prefetch window");
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) {
                 if constexpr ((PROBE & (2 | 8 | 16)) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // counts do not hold
-                else if (ks < D - 2 && !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 3) * NDMA + NST) : "memory");
+                else if (ks < D - 2 && !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 3) * NDMA + (ISK ? NST_K : NST_V)) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 3) * NDMA) : "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's conversion writes of k-step q
                 __builtin_amdgcn_s_barrier();
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
                     // K: piece (c = kh, h = ct) of key li;  V: piece (dt = ct, h = kh) of dim 32 ct + li
                     const int piece = ISK ? ((t * 2 + kh) * 2 + ct) * 32 + li : ((t * 2 + ct) * 2 + kh) * 32 + li;
                     if constexpr (!(PROBE & 2)) {
-                        *reinterpret_cast<i32x4*>(stage + (ISK ? kS8K8hi : kS8V8hi) + piece * 16) = hi8;
+                        if constexpr (ISK) *reinterpret_cast<i32x4*>(stage + kS8K8hi + piece * 16) = hi8;
                         *reinterpret_cast<i32x4*>(stage + (ISK ? kS8K8lo : kS8V8lo) + piece * 16) = lo8;
                     }
                 }
