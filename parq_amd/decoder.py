@@ -721,7 +721,8 @@ class PARQDecoder(nn.Module):
         lib = _lib.load()
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         for _attempt in range(2):
-            h = self._handle()
+            # mode "split8" runs as "split" here: its peakedness guard looks at whole rows, a rank sees only its shard of the keys
+            h = self._handle_in_mode("split") if self.attention_mode == "split8" else self._handle()
             ws = self._workspace(sc.B, sc.V, sc.h, sc.w, dev)
             _lib.check(lib.parq_prepare(h, C.byref(sc), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()), "parq_prepare")
             na, nb = lib.parq_shard_exchange_floats(h, sc.B, 0), lib.parq_shard_exchange_floats(h, sc.B, 1)
