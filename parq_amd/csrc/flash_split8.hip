@@ -4,9 +4,12 @@
 //      a.b  ~=  a_hi16 . b_hi16        v_mfma_f32_32x32x16_f16                 (exact 11 x 11-bit products, fp32 accumulate)
 //            +  e4m3(a) . e4m3(b_lo 2^10) 2^-10                                 } v_mfma_scale_f32_32x32x64_f8f6f4: one instruction
 //            +  e4m3(a_lo 2^10) 2^-10 . e4m3(b)                                 } per cross term and 64-long contraction
-// The cross terms are 2^-11 of the product, so the 4 significant bits of e4m3 put their rounding at ~2^-16 of it: measured on the
-// reference's fixtures this arithmetic sits 1e-6 from float64 at the decoder outputs (the fp16 x 3 split: 3e-8; one fp16 product:
-// 5e-5; tests/emulate_attention_arithmetic.py is the CPU model of all three).  What it buys: this kernel family is bound by the
+// The cross terms are 2^-11 of the product, so the 4 significant bits of e4m3 put their rounding at ~2^-15 of it.  The decoder's
+// instantiation carries the probabilities as one fp16 value each (P16 below), i.e. P V has the V_lo cross term only.  Measured on the
+// reference's fixtures the kernel sits 4e-6 .. 7e-6 from float64 at the decoder outputs (all three terms in fp16: 2e-6; one fp16
+// product for everything: 1e-4; tests/emulate_attention_arithmetic.py and tests/calibrate_split8_guard.py are the CPU models).  The
+// error model needs rows that spread over many keys: the merge kernel flags rows that do not (FlashArgs::peaky) and the caller
+// falls back to the fp16 x 3 kernel.  What it buys: this kernel family is bound by the
 // power the matrix pipe draws (profiles/r04_flash_power_budget_probe.txt): with real operand bits a whole-chip stream of
 // v_mfma_f32_32x32x16_f16 runs at 20 ns per instruction and SIMD (32.7 cycles of the 2.4 GHz clock on zero operands, ~48 on random
 // ones: tools/bench_src/mfma_operands.hip), and the MX instruction at 36 ns for FOUR times the contraction (tools/bench_src/mx_energy.hip).
@@ -155,7 +158,8 @@ __device__ __forceinline__ f32x16 mx64(i32x8 a, i32x8 b, f32x16 c, int sel_a, in
 // P16: the probabilities enter P V as ONE fp16 value each (no lo part: the P_lo . V_hi cross term, its conversions and its MX
 // instructions are gone) and the NORMALISER sums those same rounded values, so the weights p~ / sum p~ stay self-consistent: a row that
 // one key dominates is exact, a spread row averages the 2^-12 relative weight noise away (modelled on the reference's fixtures:
-// 3.5e-6 -> 3.9e-6 at 96 000 keys, 2.3e-6 -> 8.6e-6 at 3 840; tests/emulate_attention_arithmetic.py).  V keeps both of its terms.
+// 3.5e-6 -> 3.9e-6 at 96 000 keys, 2.3e-6 -> 8.6e-6 at 15 360; tests/calibrate_split8_guard.py; measured 6.7e-6 / 5.1e-6 on g19 / g18).
+// V keeps both of its terms.  P16 = false is the form of the kernel tests (parq_k_attention_split8 with p_lo = 1).
 template <int PROBE = 0, int RING = kRing, bool REV = false, bool P16 = true>
 __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, const unsigned char* __restrict__ cache) {
     PARQ_TL_KERNEL(kTlFlashSplit);
