@@ -285,6 +285,7 @@ class PARQDecoder(nn.Module):
         # flight keep their numbers: reduced accuracy on those rows, not NaN), "sync" re-runs the forward in "split".
         self.range_check = "lazy"
         self._range_mirror = None         # pinned host int32 the device raises on a range violation
+        self._peaky_checked = False       # the first inference forward in mode "split8" has been checked for too-peaked rows
 
     # ------------------------------------------------------------------ fp16 operand range (split / fp16 modes)
     def _flag_view(self, ws, B, V, h, w, words=1):
@@ -323,16 +324,22 @@ class PARQDecoder(nn.Module):
 
     def _range_after_forward(self, ws, sc):
         """"sync" policy: wait for the flags of the forward just enqueued; True = re-run it (with the fp32 kernels after a range
-        violation, in mode 'split' after a too-peaked row in mode 'split8')."""
-        if self.range_check != "sync" or self.attention_mode not in ("split", "split8", "fp16"):
+        violation, in mode 'split' after a too-peaked row in mode 'split8').  The FIRST inference forward of a module in mode
+        'split8' is checked this way under every policy but "off" (one synchronisation, once): a model whose attention is too
+        peaked for that mode is peaked from its first call on, and then not even that call returns the mode's numbers."""
+        first = self.attention_mode == "split8" and not self._peaky_checked and self.range_check != "off"
+        if not first and (self.range_check != "sync" or self.attention_mode not in ("split", "split8", "fp16")):
             return False
         flags = self._flag_view(ws, sc.B, sc.V, sc.h, sc.w, 2).tolist()
-        if flags[0] != 0:
+        if first:
+            self._peaky_checked = True
+        if flags[0] != 0 and self.range_check == "sync":
             self._range_mirror[0] = 0
             self._range_fallback("re-running this forward")
             return True
         if flags[1] != 0 and self.attention_mode == "split8":
-            self._range_mirror[0] = 0
+            if self._range_mirror is not None:
+                self._range_mirror[0] = int(self._range_mirror[0]) & 1
             self._peaky_fallback("re-running this forward")
             return True
         return False

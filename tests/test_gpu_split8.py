@@ -184,7 +184,8 @@ def test_split8_guard_lets_spread_attention_through():
 def test_split8_guard_falls_back_on_peaked_attention(policy):
     """Rows that rest on a handful of keys are outside mode 4's error model: the merge kernel flags them (probability sum under 64),
     "sync" re-runs the forward with all three terms in fp16 before returning — the outputs ARE those of mode "split" — and "lazy"
-    switches the module at the next call."""
+    switches the module at the next call.  (The FIRST inference forward of a module is checked synchronously under either policy:
+    test_split8_first_forward_is_checked_under_the_lazy_policy.)"""
     import warnings
     cfg, W, sc, refs = _sharpened(4.0)
     ref = make_decoder(cfg, W)
@@ -194,6 +195,8 @@ def test_split8_guard_falls_back_on_peaked_attention(policy):
     dec = make_decoder(cfg, W)
     dec.range_check = policy
     assert dec.attention_mode == "split8"
+    if policy == "lazy":
+        dec._peaky_checked = True          # as if an earlier (spread) forward had passed the first-call check: the lazy path proper
     with warnings.catch_warnings(record=True) as caught, torch.no_grad():
         warnings.simplefilter("always")
         got = [{k: v.clone() for k, v in o.items()} for o in dec(*scene_args(sc))]
@@ -212,4 +215,23 @@ def test_split8_guard_falls_back_on_peaked_attention(policy):
             for a, b in zip(again, want):
                 for k in a:
                     assert torch.equal(a[k], b[k]), k
+    assert any("too few keys" in str(w.message) for w in caught)
+
+
+def test_split8_first_forward_is_checked_under_the_lazy_policy():
+    import warnings
+    cfg, W, sc, refs = _sharpened(4.0)
+    ref = make_decoder(cfg, W)
+    ref.attention_mode = "split"
+    with torch.no_grad():
+        want = [{k: v.clone() for k, v in o.items()} for o in ref(*scene_args(sc))]
+    dec = make_decoder(cfg, W)
+    assert dec.attention_mode == "split8" and dec.range_check == "lazy"
+    with warnings.catch_warnings(record=True) as caught, torch.no_grad():
+        warnings.simplefilter("always")
+        got = dec(*scene_args(sc))
+    assert dec.attention_mode == "split"
+    for a, b in zip(got, want):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
     assert any("too few keys" in str(w.message) for w in caught)
