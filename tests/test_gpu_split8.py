@@ -235,3 +235,33 @@ def test_split8_first_forward_is_checked_under_the_lazy_policy():
         for k in a:
             assert torch.equal(a[k], b[k]), k
     assert any("too few keys" in str(w.message) for w in caught)
+
+
+@pytest.mark.parametrize("scale,flag", [(1.0, False), (2.0, False), (4.0, True)])
+def test_split8_guard_domain_at_cfg3_size(scale, flag):
+    """BASELINE cfg 3's size (192 000 keys, 256 queries), cross-attention sharpened by scaling the query projection, mode "split8"
+    with the fallback switched off against mode "split": while the guard's flag is down the two modes agree to 2e-5 (measured 4e-6 ..
+    5e-6: profiles/r04_split8_guard_sweep.txt); at x 4 — rows on a few dozen keys, difference 6e-5 — the flag is up."""
+    cfg = synth.decoder_cfg(dim=256, queries=256, heads=4, ffn=768, layers=1)
+    W = synth.make_decoder_weights(cfg, seed=2024)
+    key = "parq_module.decoder.layers.0.multihead_attn.in_proj_weight"
+    wq = W[key].copy()
+    wq[:256] *= scale
+    W[key] = wq
+    cam, T_cp, T_wp, T_wl = (torch.from_numpy(a).cuda() for a in synth.make_geometry(3024, 1, 10, 120, 160))
+    g = torch.Generator(device="cuda").manual_seed(3024)
+    tokens = torch.randn(1, 10 * 120 * 160, 256, device="cuda", generator=g)
+    outs = {}
+    with torch.no_grad():
+        for mode in ("split", "split8"):
+            dec = make_decoder(cfg, W)
+            dec.attention_mode = mode
+            dec.range_check = "off"
+            outs[mode] = {k: v.double().clone() for k, v in dec(tokens, cam, T_cp, T_wp, T_wl, feat_hw=(120, 160))[0].items()}
+            if mode == "split8":
+                assert dec.attention_too_peaked() == flag
+            dec._ws.clear()
+    diff = max(float(((outs["split8"][k] - outs["split"][k]).abs() / outs["split"][k].abs().clamp(min=1)).max()) for k in outs["split"])
+    print("\ncfg-3 size, W_q x %g: split8 vs split %.2e, flag %s" % (scale, diff, flag))
+    if not flag:
+        assert diff < 2e-5, diff
