@@ -6,7 +6,7 @@
 //            +  e4m3(a_lo 2^10) 2^-10 . e4m3(b)                                 } per cross term and 64-long contraction
 // The cross terms are 2^-11 of the product, so the 4 significant bits of e4m3 put their rounding at ~2^-15 of it.  The decoder's
 // instantiation carries the probabilities as one fp16 value each (P16 below), i.e. P V has the V_lo cross term only.  Measured on the
-// reference's fixtures the kernel sits 4e-6 .. 7e-6 from float64 at the decoder outputs (all three terms in fp16: 2e-6; one fp16
+// reference's fixtures the kernel sits 3.5e-6 .. 1e-5 from float64 at the decoder outputs (all three terms in fp16: 2e-6; one fp16
 // product for everything: 1e-4; tests/emulate_attention_arithmetic.py and tests/calibrate_split8_guard.py are the CPU models).  The
 // error model needs rows that spread over many keys: the merge kernel flags rows that do not (FlashArgs::peaky) and the caller
 // falls back to the fp16 x 3 kernel.  What it buys: this kernel family is bound by the
@@ -155,10 +155,10 @@ __device__ __forceinline__ f32x16 mx64(i32x8 a, i32x8 b, f32x16 c, int sel_a, in
 // PROBE (development, results wrong): 1 no softmax VALU, 2 no PV MFMAs, 4 no QK MFMAs, 8 no barrier / DMA waits, 16 no fragment reads;
 // 32 (results right): the written order of a step pinned with scheduling fences — 108.9 us against 105.3 for hipcc's own order of the
 // same instructions (round 4, one box), so the product build has none.
-// P16: the probabilities enter P V as ONE fp16 value each (no lo part: the P_lo . V_hi cross term, its conversions and its MX
+// P16: the probabilities enter P V as ONE fp16 value each (round to nearest; no lo part: the P_lo . V_hi cross term, its conversions and its MX
 // instructions are gone) and the NORMALISER sums those same rounded values, so the weights p~ / sum p~ stay self-consistent: a row that
 // one key dominates is exact, a spread row averages the 2^-12 relative weight noise away (modelled on the reference's fixtures:
-// 3.5e-6 -> 3.9e-6 at 96 000 keys, 2.3e-6 -> 8.6e-6 at 15 360; tests/calibrate_split8_guard.py; measured 6.7e-6 / 5.1e-6 on g19 / g18).
+// 3.5e-6 -> 3.9e-6 at 96 000 keys, 2.3e-6 -> 8.6e-6 at 15 360; tests/calibrate_split8_guard.py; measured 4.4e-6 / 3.5e-6 / 9.7e-6 on g19 / g18 / g15).
 // V keeps both of its terms.  P16 = false is the form of the kernel tests (parq_k_attention_split8 with p_lo = 1).
 template <int PROBE = 0, int RING = kRing, bool REV = false, bool P16 = true>
 __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, const unsigned char* __restrict__ cache) {
@@ -344,10 +344,15 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
         unsigned hw;
         float d0 = 0.f, d1 = 0.f;
         if constexpr (P16) {
-            // the row sum takes the fp16 values the matrix pipe will multiply (round toward zero: a common bias cancels in p~ / sum p~)
-            hw = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p0, p1));
-            asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(l_a) : "v"(hw));
-            asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l_b) : "v"(hw));
+            // one round-to-nearest conversion (v_cvt_pk_f16_f32: unbiased also in the fp16 subnormal range, where a long tail of small
+            // probabilities sits); the row sum takes exactly the values the matrix pipe will multiply — v_dot2_f32_f16 against (1, 1)
+            // adds both halves of the packed pair to the fp32 sum in one instruction, subnormals included (tools/bench_src/denorm_probe.hip)
+            typedef float f32x2p __attribute__((ext_vector_type(2)));
+            const half2v hp = __builtin_convertvector(f32x2p{p0, p1}, half2v);
+            hw = __builtin_bit_cast(unsigned, hp);
+            const half2v ones = {(_Float16)1.f, (_Float16)1.f};
+            if constexpr ((J & 1) == 0) l_a = __builtin_amdgcn_fdot2(hp, ones, l_a, false);
+            else l_b = __builtin_amdgcn_fdot2(hp, ones, l_b, false);
         } else {
             l_a += p0;
             l_b += p1;
@@ -495,9 +500,18 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
 #pragma unroll
                 for (int e = 0; e < 8; ++e) p[e] = __builtin_amdgcn_exp2f(sacc[1][8 * m + e]);
 #pragma unroll
-                for (int e = 0; e < 8; e += 2) split_rtz(p[e], p[e + 1], hw[e >> 1], dl[e], dl[e + 1]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) l_run += P16 ? p[e] - dl[e] : p[e];         // P16: the fp16 value itself (p - lo, exact)
+                for (int e = 0; e < 8; e += 2) {
+                    if constexpr (P16) {                                               // as sm_pair: one RNE conversion, summed as converted
+                        typedef float f32x2p __attribute__((ext_vector_type(2)));
+                        const half2v hp = __builtin_convertvector(f32x2p{p[e], p[e + 1]}, half2v);
+                        hw[e >> 1] = __builtin_bit_cast(unsigned, hp);
+                        l_run = __builtin_amdgcn_fdot2(hp, half2v{(_Float16)1.f, (_Float16)1.f}, l_run, false);
+                        dl[e] = dl[e + 1] = 0.f;
+                    } else {
+                        split_rtz(p[e], p[e + 1], hw[e >> 1], dl[e], dl[e + 1]);
+                        l_run += p[e] + p[e + 1];
+                    }
+                }
                 Ph[1][m] = __builtin_bit_cast(half8, u32x4{hw[0], hw[1], hw[2], hw[3]});
 #pragma unroll
                 for (int w = 0; w < 2; ++w) {
