@@ -121,16 +121,16 @@ int parq_pack_weights(parq_handle h, void *arena, size_t arena_bytes, parq_strea
  *      precision).  Q, K, V and the probabilities are rounded to nearest 16-bit
  *      once, accumulation stays fp32; the K/V cache shrinks to half.  Outputs agree with the fp32 path to
  *      ~1e-3 (fp16) / ~1e-2 (bf16) on unit-scale features (tests state the tolerances);
- *   4  mode 1 with the two CROSS terms of every product (hi.lo, lo.hi) evaluated as MX-scaled fp8 (e4m3) products — one
- *      v_mfma_scale_f32_32x32x64_f8f6f4 per cross term and 64-long contraction instead of four fp16 instructions; hi.hi stays an
- *      exact fp16 product (flash_split8.hip).  The cross terms are 2^-11 of a product, e4m3 rounds them at 2^-4: ~2^-16 per product,
- *      1e-6 at the decoder outputs on the reference's fixtures (tests/emulate_attention_arithmetic.py, tests/test_gpu_split8.py).
- *      Inference, head dim 64, dim 256, key counts that are a multiple of 64; every other case of a handle in this mode runs
- *      as mode 1 (training forward / backward included).  Range: as mode 1; |K|, |V|, |q| past 448 saturate in their fp8 forms
- *      only (those elements keep the accuracy of mode 2, nothing is poisoned).  The probabilities enter P V as one fp16 value each,
- *      and the normaliser sums those same values.  The mode's error model assumes rows that spread over many keys (1e-6 .. 1e-5 at
- *      the outputs while every row's probability sum, relative to its maximum, is above ~40; 1e-4 and more for rows that two or three
- *      keys carry): the merge kernel raises workspace "flags"[1] — and bit 1 of the range mirror — when a row's sum is under 64;
+ *   4  the scores as mode 1's hi.hi fp16 product plus the two CROSS terms (hi.lo, lo.hi) as MX-scaled fp8 (e4m3) products — one
+ *      v_mfma_scale_f32_32x32x64_f8f6f4 per cross term and 64-long contraction instead of four fp16 instructions (the cross terms
+ *      are 2^-11 of a product, e4m3 rounds them at 2^-4: ~2^-15 per score) — and P V as ONE fp16 product of probabilities and values
+ *      rounded to nearest, normalised by the sum of those same rounded probabilities (flash_split8.hip).  4e-6 .. 1.3e-5 at the
+ *      decoder outputs on the reference's fixtures (tests/emulate_attention_arithmetic.py, tests/test_gpu_split8.py).  Inference, head
+ *      dim 64, dim 256, key counts that are a multiple of 64; every other case of a handle in this mode runs as mode 1 (training
+ *      forward / backward included).  Range: as mode 1; |K|, |q| past 448 saturate in their fp8 forms only (those elements keep the
+ *      accuracy of mode 2, nothing is poisoned).  The mode's error model assumes rows that spread over many keys (1e-5 at the outputs
+ *      while every row's probability sum, relative to its maximum, is above ~40; 1e-4 and more for rows that two or three keys
+ *      carry): the merge kernel raises workspace "flags"[1] — and bit 1 of the range mirror — when a row's sum is under 64;
  *      outputs are NOT poisoned, the caller decides (the Python class falls back to mode 1: PARQDecoder.range_check). */
 int parq_set_attention_mode(parq_handle h, int32_t mode);
 /* Optional: a host-visible, device-writable int32 (pinned host memory, e.g. hipHostMalloc) in which the device sets bit 0 whenever
@@ -354,11 +354,10 @@ size_t parq_k_attention_split_scratch_bytes(int32_t B, int32_t H, int32_t Lq, in
 int parq_k_attention_split(const float *q, const float *k, const float *v, float *out, int32_t B, int32_t H,
                            int32_t Lq, int32_t Lk, void *scratch, size_t scratch_bytes, parq_stream stream);
 
-/* the same through the mode-4 path (fp8 cross terms); Lk % 64 == 0; scratch as for parq_k_attention_split.  p_lo = 0: the kernel as
- * the decoder runs it (probabilities as one fp16 value each, normaliser over the same values); p_lo = 1: the probabilities keep an
- * fp8 lo part (the kernel's other instantiation, used by the kernel tests to check the running-max bookkeeping of the fp8 operands) */
+/* the same through the mode-4 path (scores with fp8 cross terms, P V in fp16 with a self-consistent normaliser); Lk % 64 == 0; scratch
+ * as for parq_k_attention_split */
 int parq_k_attention_split8(const float *q, const float *k, const float *v, float *out, int32_t B, int32_t H,
-                            int32_t Lq, int32_t Lk, int32_t p_lo, void *scratch, size_t scratch_bytes, parq_stream stream);
+                            int32_t Lq, int32_t Lk, void *scratch, size_t scratch_bytes, parq_stream stream);
 
 /* the split-fp16 path at head dim 256 (the reference's shipped DEC_DIM 1024 / 4 heads, config/train.yaml:49-50): a head is
  * stored as 4 virtual heads of 64 in the split cache, a pair of waves shares each 32-query tile. */

@@ -95,7 +95,7 @@ SYMBOLS = {
     "parq_k_attention": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "parq_k_attention_split_scratch_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "parq_k_attention_split": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
-    "parq_k_attention_split8": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "parq_k_attention_split8": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "parq_k_attention_split256_scratch_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "parq_k_attention_split256": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "parq_k_attention_half_scratch_bytes": (_sz, [_i32, _i32, _i32, _i32]),

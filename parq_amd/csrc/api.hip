@@ -1646,7 +1646,7 @@ int parq_k_attention_split(const float* q, const float* k, const float* v, float
 
 /* mode 4: hi.hi on the fp16 matrix pipe, the cross terms as MX-scaled fp8 products (flash_split8.hip); Lk % 64 == 0 */
 int parq_k_attention_split8(const float* q, const float* k, const float* v, float* out, int32_t B, int32_t H, int32_t Lq,
-                            int32_t Lk, int32_t p_lo, void* scratch, size_t scratch_bytes, parq_stream stream) {
+                            int32_t Lk, void* scratch, size_t scratch_bytes, parq_stream stream) {
     if (!q || !k || !v || !out || !scratch) return fail(PARQ_ERR_ARG, "NULL argument");
     if (B < 1 || H < 1 || Lq < 1 || Lk < 1) return fail(PARQ_ERR_ARG, "bad dims");
     if (!flash_split8_supported(64, Lk)) return fail(PARQ_ERR_ARG, "attention mode 4 needs a key count that is a multiple of 64");
@@ -1665,8 +1665,8 @@ int parq_k_attention_split8(const float* q, const float* k, const float* v, floa
     fa.o_part = (float*)(cache + kvsplit_cache_bytes(B, H, Lk));
     fa.m_part = fa.o_part + (int64_t)B * H * fa.nsplit * dh * lp;
     fa.l_part = fa.m_part + (int64_t)B * H * fa.nsplit * lp;
-    HIPCHK(launch_kvsplit8_convert(k, v, Lk * C, dh, C, Lk * C, dh, C, B, H, Lk, cache, s, p_lo != 0));
-    HIPCHK(launch_flash_split8(fa, cache, s, p_lo != 0));
+    HIPCHK(launch_kvsplit8_convert(k, v, Lk * C, dh, C, Lk * C, dh, C, B, H, Lk, cache, s));
+    HIPCHK(launch_flash_split8(fa, cache, s));
     HIPCHK(launch_flash_merge(fa, s));
     return PARQ_OK;
 }

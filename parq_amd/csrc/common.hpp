@@ -185,11 +185,10 @@ __device__ __forceinline__ void pieces_e4m3(const float* x, i32x4& hi8, i32x4& l
         lo8[w] = pack4_e4m3(d[0] * kLo8Scale, d[1] * kLo8Scale, d[2] * kLo8Scale, d[3] * kLo8Scale);
     }
 }
-// byte offsets inside a 64-key stage of the mode-4 cache (layout: flash_split8.hip)
-// The decoder's cache has no V hi8 plane (its kernel carries the probabilities in fp16 only: the P_lo . V_hi term does not exist): 28 KB
-// per stage.  The kernel-test form with that plane appends it: 32 KB per stage.
-constexpr int kStage8Bytes = 28672, kStage8BytesFull = 32768;
-constexpr int kS8Kh16 = 0, kS8K8hi = 8192, kS8K8lo = 12288, kS8Vh16 = 16384, kS8V8lo = 24576, kS8V8hi = 28672;
+// byte offsets inside a 64-key stage of the mode-4 cache (layout: flash_split8.hip): K as hi16 + e4m3 hi8 + e4m3 lo8, V as fp16 (round to
+// nearest): 24 KB per stage, 3 bytes per element
+constexpr int kStage8Bytes = 24576;
+constexpr int kS8Kh16 = 0, kS8K8hi = 8192, kS8K8lo = 12288, kS8Vh16 = 16384;
 
 // ---- dropout (training): counter-based keep decision, identical in forward and backward.  Element (row, col) of stream `seed`
 // is kept when a 24-bit hash is >= p * 2^24; kept values are scaled by 1 / (1 - p) (torch.nn.Dropout semantics).
@@ -376,15 +375,13 @@ hipError_t launch_kvsplit_to_f32(const void* cache, int B, int H, int N, float* 
                                  int terms = 3, int kind = kF16);                                   // terms = 1: the single 16-bit cache
 hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t s, int terms = 3,
                               int kind = kF16);   // partials; merge as usual
-// flash_split8.hip: the same with the two cross terms of every product on the MX-scaled fp8 matrix instruction (attention mode 4;
-// head dim 64, whole 64-key stages only: flash_split8_supported).  Cache = Lk / 64 stages of 28 KB per (scene, head) (32 KB in the p_lo test form) — within
-// the size kvsplit_cache_bytes(.., 3) gives for such Lk.
+// flash_split8.hip: attention mode 4 — the scores with their two cross terms on the MX-scaled fp8 matrix instruction, P V in fp16 with a
+// self-consistent normaliser (head dim 64, whole 64-key stages only: flash_split8_supported).  Cache = Lk / 64 stages of 24 KB per
+// (scene, head) — within the size kvsplit_cache_bytes(.., 3) gives for such Lk.
 bool flash_split8_supported(int dh, int Lk);
 hipError_t launch_kvsplit8_convert(const float* K, const float* V, int64_t k_batch, int64_t k_head, int64_t k_row, int64_t v_batch,
-                                   int64_t v_head, int64_t v_row, int B, int H, int N, void* cache, hipStream_t s,
-                                   bool full = false);      // full: 32 KB stages with the V hi8 plane (launch_flash_split8 p_lo)
-hipError_t launch_flash_split8(const FlashArgs& a, const void* cache, hipStream_t s,
-                               bool p_lo = false);      // p_lo: the probabilities with their fp8 lo part too (kernel tests; the decoder runs without)
+                                   int64_t v_head, int64_t v_row, int B, int H, int N, void* cache, hipStream_t s);
+hipError_t launch_flash_split8(const FlashArgs& a, const void* cache, hipStream_t s);
 // kvproj_split.hip: tokens -> split cache directly (W pre-split with launch_split_f32)
 hipError_t launch_split_f32(const float* src, void* hi, void* lo, int64_t n, hipStream_t s);
 // elementwise.hip: up to kGatherMax device-to-device float copies in ONE launch (the weight pack: ~50 tensors per training step)

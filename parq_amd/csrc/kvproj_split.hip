@@ -294,7 +294,7 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
     constexpr int kRawBytes = TM * kBK * 4;      // one k-step of fp32 tokens
     constexpr int NDMA = kRawBytes / (kThr * 16);            // DMA instructions per thread and k-step
     constexpr int NST_K = RT * 2 * (SPLIT ? 2 : 1);     // store instructions per thread and tile (mode 4: K waves 2 + 1 + 1 per block,
-    constexpr int NST_V = F8 ? RT * 3 : NST_K;          // V waves 2 + 1: the stage cache has no V hi8 plane)
+    constexpr int NST_V = F8 ? RT * 2 : NST_K;          // V waves 2: the stage cache holds V as one fp16 plane)
     constexpr int NI = TM * 8 / kThr;            // 8-float pieces of a k-step per thread (conversion)
     static_assert(D >= 3 && D - 2 <= NK && NDMA >= 1 && NI >= 1, "wait counts below assume at most one epilogue inside the prefetch window");
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -503,20 +503,21 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
                 if (blk >= nblk) continue;                                   // scalar
                 _Float16* out = a.cache + (((int64_t)b * a.H + h) * nblk + blk) * kBlkH;
                 if constexpr (F8) {
-                    // mode-4 stage image (flash_split8.hip): this block's hi16 plane at t * 4 KB of the K / V hi16 region, and the lane's
-                    // 16 accumulator registers as ONE 16-byte piece of the hi8 plane and one of the lo8 plane
+                    // mode-4 stage image (flash_split8.hip): this block's fp16 plane at t * 4 KB of the K / V 16-bit region; K lanes also
+                    // store their 16 accumulator registers as ONE 16-byte piece of the hi8 plane and one of the lo8 plane
                     unsigned char* stage = reinterpret_cast<unsigned char*>(a.cache) + (((int64_t)b * a.H + h) * (nblk >> 1) + (m0 >> 6)) * kStage8Bytes;
                     out = reinterpret_cast<_Float16*>(stage + (ISK ? kS8Kh16 : kS8Vh16 - 2 * kVoff) + t * 4096);
-                    float x16[16];
+                    if constexpr (ISK) {
+                        float x16[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) x16[r] = acc[t][r] + (ISK ? bK[ISK ? r : 0] : bK[0]);
-                    i32x4 hi8, lo8;
-                    pieces_e4m3(x16, hi8, lo8);
-                    // K: piece (c = kh, h = ct) of key li;  V: piece (dt = ct, h = kh) of dim 32 ct + li
-                    const int piece = ISK ? ((t * 2 + kh) * 2 + ct) * 32 + li : ((t * 2 + ct) * 2 + kh) * 32 + li;
-                    if constexpr (!(PROBE & 2)) {
-                        if constexpr (ISK) *reinterpret_cast<i32x4*>(stage + kS8K8hi + piece * 16) = hi8;
-                        *reinterpret_cast<i32x4*>(stage + (ISK ? kS8K8lo : kS8V8lo) + piece * 16) = lo8;
+                        for (int r = 0; r < 16; ++r) x16[r] = acc[t][r] + bK[r];
+                        i32x4 hi8, lo8;
+                        pieces_e4m3(x16, hi8, lo8);
+                        const int piece = ((t * 2 + kh) * 2 + ct) * 32 + li;        // piece (c = kh, h = ct) of key li
+                        if constexpr (!(PROBE & 2)) {
+                            *reinterpret_cast<i32x4*>(stage + kS8K8hi + piece * 16) = hi8;
+                            *reinterpret_cast<i32x4*>(stage + kS8K8lo + piece * 16) = lo8;
+                        }
                     }
                 }
                 half8 hi[2], lo[2];
@@ -525,7 +526,8 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
                     float x[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) x[e] = acc[t][8 * m + e] + (ISK ? bK[ISK ? 8 * m + e : 0] : bK[0]);
-                    if constexpr (SPLIT) split8(x, hi[m], lo[m]);
+                    if constexpr (F8 && !ISK) hi[m] = cvt8_rn<kF16>(x);          // mode 4: V as one fp16 value, round to nearest
+                    else if constexpr (SPLIT) split8(x, hi[m], lo[m]);
                     else hi[m] = cvt8_rn<KIND>(x);
                     if constexpr (KIND == kF16) {
 #pragma unroll

@@ -40,9 +40,9 @@ def mha_variant(pmode):
             if pmode == "full":
                 o = E.product(p, v, "split8", a_scale8=64.0) / p.sum(-1, keepdim=True)
             else:
-                ph = E._rtz16(p)
-                vv = v.float().double(); vh = E._rtz16(vv); vl = vv - vh
-                o = (ph @ vh + E._e4(ph, 64.0) @ E._e4(vl, 1024.0)) / ph.sum(-1, keepdim=True)
+                # the decoder's kernel: probabilities and values as ONE fp16 value each (round to nearest), normaliser over the same values
+                ph = p.float().half().double()
+                o = (ph @ v.float().half().double()) / ph.sum(-1, keepdim=True)
         return F.linear(o.transpose(1, 2).reshape(B, L, C), out_w, out_b)
     return mha
 name = sys.argv[1]

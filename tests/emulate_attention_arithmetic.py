@@ -6,8 +6,8 @@ error of an arithmetic before (and independently of) the kernel that implements 
   "split8"  hi.hi as an fp16 product, the two cross terms as fp8 (e4m3) products:
             hi16.hi16 + e4m3(a) . e4m3(b_lo 2^10) 2^-10 + e4m3(a_lo 2^10) 2^-10 . e4m3(b)          (mode 4: MX-scaled fp8 MFMA, scale 2^-10)
             hi16 rounds toward zero as in the kernels; probabilities enter their fp8 forms scaled by 2^6 (e4m3 has no values under 2^-9)
-            (this is the kernel's p_lo instantiation; the decoder's kernel carries each probability as ONE fp16 value and sums those
-            values for the normaliser: tests/calibrate_split8_guard.py models that form, mode "p16" there)
+            (the decoder's kernel uses this product for the SCORES only; its P V is one fp16 product of probabilities and values rounded
+            to nearest, normalised by the sum of the same rounded probabilities: tests/calibrate_split8_guard.py models that form, "p16")
 
 `patched(mode)` swaps oracle.mha for the emulation on every attention whose key axis is longer than 1024 (the cross-attention).
 Everything else of the oracle stays float64, so the difference to the un-patched oracle IS the arithmetic's error."""
