@@ -600,23 +600,23 @@ def main():
                     "note": "launch time from hipEvents around this kernel alone (its merge kernel is group cross_attn_merge)"}
         if split8:
             # mode 4: one fp16 product + two MX-fp8 products per algorithmic product.  Matrix roof for algorithmic flops:
-            # 1 / (1 / 2500 + 1.5 / 5000) = 1429 TFLOP/s = 35 us per launch at cfg 3; the K/V stream of the launch (2 N C values x 3.5 bytes:
-            # K hi16 + hi8 + lo8, V hi16 + lo8) is 43 us at 8 TB/s, so HBM is the roof that bounds this kernel (stream-only build of the
-            # kernel: 63 us = 5.5 TB/s, the streaming ceiling of this part; profiles/r04_split8_ingredient_probes.txt)
-            kv_bytes = 2.0 * N * C * 3.5 * B                      # K: hi16 + hi8 + lo8, V: hi16 + lo8 (28 KB per 64-key stage and head)
+            # 2500 / 1.5 = 1667 TFLOP/s = 30 us per launch at cfg 3; the K/V stream of the launch (N C x (4 + 2) bytes:
+            # K hi16 + hi8 + lo8, V fp16) is 37 us at 8 TB/s, so HBM is the roof that bounds this kernel (stream-only build of the
+            # kernel: 54 us = 5.5 TB/s, the streaming ceiling of this part; profiles/r04_split8_ingredient_probes.txt)
+            kv_bytes = N * C * 6.0 * B                            # K: hi16 + hi8 + lo8, V: fp16 (24 KB per 64-key stage and head)
             stream_gbs = (kv_bytes / (ca_ms / ca_n * 1e-3) / 1e9) if ca_n else None
-            mx_peak = 1.0 / (1.0 / PEAK_F16_MATRIX_TFLOPS + 1.5 / (2.0 * PEAK_F16_MATRIX_TFLOPS))
-            roofline.update({"bound": "hbm", "kernel": "flash_split8_kernel (cross-attention QK^T+PV: hi.hi as fp16 products, the cross terms "
-                                                       "as MX-scaled fp8 e4m3 products, fp32 accumulate)",
+            mx_peak = PEAK_F16_MATRIX_TFLOPS / 1.5
+            roofline.update({"bound": "hbm", "kernel": "flash_split8_kernel (cross-attention: Q K^T = fp16 hi.hi + MX-scaled fp8 e4m3 cross terms, "
+                                                       "P V = fp16 product with a self-consistent normaliser, fp32 accumulate)",
                              "achieved": stream_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": (stream_gbs / PEAK_HBM_GBS) if stream_gbs else None,
                              "traffic": pmc_traffic("flash_split8_kernel", B) if args.config == "cfg3" else None,
                              "algorithmic_bytes_per_launch": kv_bytes, "hbm_stream_gbs": stream_gbs,
                              "peak_note": "HBM3E 8 TB/s; a plain streaming kernel reaches 5.6 TB/s on this part (profiles/r02_hbm_stream_ceiling.txt)",
                              "mfma": {"achieved": ach_tflops, "peak": mx_peak, "unit": "TFLOP/s", "frac": (ach_tflops / mx_peak) if ach_tflops else None,
-                                      "note": "algorithmic flops against 1 / (1/2500 + 1.5/5000): one fp16 pass + 1.5 fp8 passes (two cross terms of QK, one of PV) at twice the rate"}})
+                                      "note": "algorithmic flops against 2500 / 1.5: Q K^T = one fp16 pass + two fp8 passes at twice the rate, P V = one fp16 pass"}})
         not_headline = bool(args.dev_lib or parq_env())
         kv_ms, kv_n = prof["kv_proj"]
-        kvp_bytes = ((N * C * 4.0 + 2.0 * N * C * 3.5) * B if split8 else
+        kvp_bytes = ((N * C * 4.0 + N * C * 6.0) * B if split8 else
                      3.0 * N * C * 4.0 * B if not half else (N * C * 4.0 + 2.0 * N * C * 2.0) * B)     # tokens in, K and V cache images out
         roofline["hbm_frac"] = (roofline["hbm_stream_gbs"] / PEAK_HBM_GBS) if roofline["hbm_stream_gbs"] else None
         roofline["traffic_source"] = "recorded: %s (rocprofv3 --pmc passes of the same command), not measured in this run" % (_pmc_record()[1],)
@@ -627,7 +627,7 @@ def main():
                        "algorithmic_bytes_per_launch": kvp_bytes, "avg_launch_ms": (kv_ms / kv_n) if kv_n else None, "launches": kv_n,
                        "streaming_ceiling_ms": kvp_bytes / 5.6e12 * 1e3,
                        "note": "reads N*C fp32 tokens, writes the K and V cache images; a plain streaming kernel with this 1:2 read/write "
-                               "shape reaches 5.6 TB/s on MI355X (profiles/r02_hbm_stream_ceiling.txt; 28 of 32 KB per stage written in mode "
+                               "shape reaches 5.6 TB/s on MI355X (profiles/r02_hbm_stream_ceiling.txt; 24 of 32 KB per stage written in mode "
                                "split8); also 4*N*C^2 = %.1f GFLOP x 3 "
                                "fp16 passes on the matrix pipe" % (4.0 * N * C * C * B / 1e9)}
         out = {
@@ -646,8 +646,8 @@ def main():
                                   "iterations_per_sec_at_median": B * I / (pct(0.5) * 1e-3),
                                   "note": "rank 0, one hipEvent pair per forward on the launch stream; `value` is the contract's wall-clock figure"},
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": ("f32 (cross-attention: hi.hi fp16 products + MX-fp8 e4m3 cross terms, probabilities as fp16 with a self-consistent "
-                                          "normaliser, fp32 accumulation — 3.5e-6..1e-5 from float64 at the outputs on the reference's fixtures, the "
+            "vs_baseline": None, "dtype": ("f32 (cross-attention scores: fp16 hi.hi + MX-fp8 e4m3 cross terms; P V: fp16 probabilities and values with a "
+                                          "self-consistent normaliser; fp32 accumulation — 4e-6..1.5e-5 from float64 at the outputs on the reference's fixtures, the "
                                           "reference's own fp32 run: 6e-5..1.4e-4; guarded: rows on too few keys fall back to fp16 x 3; K/V projection "
                                           "as fp16 hi/lo split products; `strict_fp16x3` is the same run with all three terms in fp16)" if split8 else
                                           "f32 (cross-attention and K/V projection as fp16 hi/lo split products with fp32 accumulation)" if split
