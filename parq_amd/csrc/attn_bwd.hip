@@ -676,6 +676,13 @@ __global__ __launch_bounds__(256) void attn_bwd_pack_kernel(AttnBwdArgs a, const
 // of its own tile — same results (same operands, same order inside every accumulation), two barriers per tile as before.
 // CACHE: 0 = fp32 K / V (a.k, a.v); 3 / 1 = the forward's split / single-product cache (a.kvcache): the hi / lo pairs the forward
 // multiplied are used as they are (no fp32 rebuild pass over 2 N C floats per scene, no second copy of K / V in HBM)
+// kGrad1: in the three GRADIENT products of the tile (dV^T += dO^T P, dK^T += Q^T dS, dQ += dS K) the probabilities and dS enter as ONE fp16
+// value each, rounded to nearest, instead of a hi / lo pair: 56 MFMAs per tile instead of 72, no lo plane of the dS^T image (a quarter of
+// the dQ tile's LDS reads), no residual arithmetic.  These products contract over the 2048 queries of a (scene, head) (dV, dK) or over
+// all keys (dQ), so the unbiased 2^-12 rounding noise of the factors averages to ~1e-5 of a gradient and below; the recomputed scores
+// S and dP = dO V^T, which feed the exponential and dS itself, keep all three terms.  (false: the round-3 form, kept for A/B.)
+constexpr bool kGrad1 = true;
+
 template <bool DROP, bool RAGGED, int PIPE = 1, int CACHE = 0>
 __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, const float* __restrict__ oscale_ptr,
                                                               const _Float16* __restrict__ pack) {
@@ -811,12 +818,14 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
             const int pb0 = ja * 64 + (((dp >> 3) ^ img_swz(ja)) << 3) + (dp & 4);
             const int pb1 = jb * 64 + (((dp >> 3) ^ img_swz(jb)) << 3) + (dp & 4);
             const half8 ah = cat4(lds_tr16(Ds + pa0), lds_tr16(Ds + pa1));
-            const half8 al = cat4(lds_tr16(Ds + 8192 + pa0), lds_tr16(Ds + 8192 + pa1));
             const half8 bh8 = cat4(lds_tr16(Ki + pb0), lds_tr16(Ki + pb1));
             const half8 bl8 = cat4(lds_tr16(Ki + 16384 + pb0), lds_tr16(Ki + 16384 + pb1));
             g4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh8, g4, 0, 0, 0);
             g4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl8, g4, 0, 0, 0);
-            g4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh8, g4, 0, 0, 0);
+            if constexpr (!kGrad1) {
+                const half8 al = cat4(lds_tr16(Ds + 8192 + pa0), lds_tr16(Ds + 8192 + pa1));
+                g4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh8, g4, 0, 0, 0);
+            }
         }
         // accumulator: rows qb + 4 g16 + r, column db + t16
         const int itd = nd / ntiles, i0d = (nd - itd * ntiles) * 32;
@@ -893,8 +902,13 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
                 pv[e] = p * keep;                                                            // p = 2^14 x probability (kPShift)
                 dv[e] = p * (pacc[r] * (keep * kPShiftInv) - st[32 + qi]);
             }
-            split8(pv, ph[m], pl[m]);
-            split8(dv, sh[m], sl[m]);
+            if constexpr (kGrad1) {
+                ph[m] = cvt8_rn<kF16>(pv);             // one fp16 value each, round to nearest (v_cvt_pk_f16_f32): see kGrad1
+                sh[m] = cvt8_rn<kF16>(dv);
+            } else {
+                split8(pv, ph[m], pl[m]);
+                split8(dv, sh[m], sl[m]);
+            }
         }
         }
         // the dS^T rows of this wave's keys go into Ds: without PIPE right away (nobody reads Ds between the top barrier and the
@@ -907,7 +921,8 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
                 for (int hh = 0; hh < 2; ++hh) {
                     const int off = jw * 32 + (((4 * m + 2 * hh + kh) ^ ((jw >> 1) & 7)) << 2);
                     *reinterpret_cast<half4v*>(Ds + off) = half4v{sh[m][4 * hh], sh[m][4 * hh + 1], sh[m][4 * hh + 2], sh[m][4 * hh + 3]};
-                    *reinterpret_cast<half4v*>(Ds + 8192 + off) = half4v{sl[m][4 * hh], sl[m][4 * hh + 1], sl[m][4 * hh + 2], sl[m][4 * hh + 3]};
+                    if constexpr (!kGrad1)
+                        *reinterpret_cast<half4v*>(Ds + 8192 + off) = half4v{sl[m][4 * hh], sl[m][4 * hh + 1], sl[m][4 * hh + 2], sl[m][4 * hh + 3]};
                 }
         };
         if constexpr (!PIPE) write_ds();
@@ -926,10 +941,10 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
                 const half8 oth = cat4(lds_tr16(Im + 4096 + p0), lds_tr16(Im + 4096 + p1));
                 const half8 otl = cat4(lds_tr16(Im + 6144 + p0), lds_tr16(Im + 6144 + p1));
                 gv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(oth, ph[m], gv[dt], 0, 0, 0);
-                gv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(oth, pl[m], gv[dt], 0, 0, 0);
+                if constexpr (!kGrad1) gv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(oth, pl[m], gv[dt], 0, 0, 0);
                 gv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(otl, ph[m], gv[dt], 0, 0, 0);
                 gk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qth, sh[m], gk[dt], 0, 0, 0);
-                gk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qth, sl[m], gk[dt], 0, 0, 0);
+                if constexpr (!kGrad1) gk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qth, sl[m], gk[dt], 0, 0, 0);
                 gk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtl, sh[m], gk[dt], 0, 0, 0);
                 }
         if constexpr (!PIPE) {
