@@ -322,6 +322,9 @@ def train_bench(args):
     dec.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=False)
     dec = dec.to(device).train()
     dec.dp_all_reduce = world > 1
+    if args.attention_mode:
+        dec.attention_mode = args.attention_mode
+    dec.train_split8 = bool(args.train_split8)       # opt-in: mode 4 in the training forward, backward from its stage cache (decoder.py)
     inputs = build_inputs(B, device, seed=2000 + rank)
     if args.token_grad:                 # the gradient a trained backbone / ray-PE encoder in front of the decoder needs
         inputs = (inputs[0].requires_grad_(True),) + tuple(inputs[1:])
@@ -369,6 +372,20 @@ def train_bench(args):
     dt_own = time.perf_counter() - t0
     dt = parallel.max_over_ranks(dt_own, device=red_dev)
     per_rank_ms = [x / args.steps * 1e3 for x in parallel.gather_over_ranks(dt_own, device=red_dev)]
+    final_loss, train_mode = float(loss.detach()), dec._train_mode()
+    opt_in = None
+    if world == 1 and dec.attention_mode == "split8" and not dec.train_split8 and not (args.dev_lib or parq_env()):
+        # after the timed region: the same steps with the training forward in mode split8 (PARQDecoder.train_split8, off by default)
+        dec.train_split8 = True
+        for _ in range(max(2, args.warmup)):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        opt_in = {"train_attention_mode": dec._train_mode(), "ms_per_step": (time.perf_counter() - t1) / args.steps * 1e3}
+        dec.train_split8 = False
     if rank == 0:
         print(json.dumps({
             "per_rank_ms_per_step": per_rank_ms,
@@ -378,7 +395,7 @@ def train_bench(args):
             "n_gpus": world, "collective_backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
             "parq_env": parq_env(), "dev_lib": bool(args.dev_lib), "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "final_loss": float(loss.detach()), "phase_ms": phase_ms,
+            "final_loss": final_loss, "phase_ms": phase_ms, "train_attention_mode": train_mode, "opt_in_train_split8": opt_in,
             "config": {"workload": "BASELINE cfg4 per-GPU shard: %d scenes, 10 views 480x640 (120x160 features), 256 queries, 8 iterations, "
                                    "d=256; dropout %g; 12 synthetic boxes per scene%s" % (B, args.dropout, "; token gradient" if args.token_grad else ""),
                        "scenes_per_gpu": B, "parallelism": "dp%d (gradient arena all-reduced in two buckets, the first overlapped with the cross-attention backward)" % world}}))
@@ -431,6 +448,7 @@ def main():
     ap.add_argument("--scenes-per-gpu", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b32", action="store_true", help="skip the 32-scene project+sample bandwidth measurement (6.3 GB of tokens)")
+    ap.add_argument("--train-split8", action="store_true", help="--train: run the training forward in mode split8 (PARQDecoder.train_split8)")
     ap.add_argument("--attention-mode", default=None, choices=["split", "split8", "fp32", "fp16", "bf16"],
                     help="cross-attention arithmetic; default = the library default (split8 at d = 256 / head dim 64: fp16 hi.hi + fp8 cross terms; "
                          "split: three fp16 terms). "

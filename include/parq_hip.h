@@ -125,9 +125,10 @@ int parq_pack_weights(parq_handle h, void *arena, size_t arena_bytes, parq_strea
  *      v_mfma_scale_f32_32x32x64_f8f6f4 per cross term and 64-long contraction instead of four fp16 instructions (the cross terms
  *      are 2^-11 of a product, e4m3 rounds them at 2^-4: ~2^-15 per score) — and P V as ONE fp16 product of probabilities and values
  *      rounded to nearest, normalised by the sum of those same rounded probabilities (flash_split8.hip).  4e-6 .. 1.3e-5 at the
- *      decoder outputs on the reference's fixtures (tests/emulate_attention_arithmetic.py, tests/test_gpu_split8.py).  Inference, head
- *      dim 64, dim 256, key counts that are a multiple of 64; every other case of a handle in this mode runs as mode 1 (training
- *      forward / backward included).  Range: as mode 1; |K|, |q| past 448 saturate in their fp8 forms only (those elements keep the
+ *      decoder outputs on the reference's fixtures (tests/emulate_attention_arithmetic.py, tests/test_gpu_split8.py).  Head dim 64,
+ *      dim 256, key counts that are a multiple of 64 — inference, and training steps whose batched backward reads the forward's cache
+ *      (it then reads the stage cache: K = hi16 + e4m3 lo, V = the fp16 value); every other case of a handle in this mode runs as
+ *      mode 1.  (The Python class trains in mode 1 unless asked: PARQDecoder.train_split8.)  Range: as mode 1; |K|, |q| past 448 saturate in their fp8 forms only (those elements keep the
  *      accuracy of mode 2, nothing is poisoned).  The mode's error model assumes rows that spread over many keys (1e-5 at the outputs
  *      while every row's probability sum, relative to its maximum, is above ~40; 1e-4 and more for rows that two or three keys
  *      carry): the merge kernel raises workspace "flags"[1] — and bit 1 of the range mirror — when a row's sum is under 64;

@@ -111,8 +111,9 @@ struct parq_ctx {
     int terms() const { return attn_mode == 1 || attn_mode == 4 ? 3 : 1; }
     // mode 4 (flash_split8.hip) where its kernels apply — inference, head dim 64, d = 256, whole 64-key stages — and mode 1 otherwise:
     // 8 = the stage cache with fp8 cross-term planes (same size as the split cache for such N)
-    int terms_for(int64_t N, bool train) const {
-        return (attn_mode == 4 && !train && C == 256 && flash_split8_supported(dh, (int)(N > INT32_MAX ? 0 : N))) ? 8 : terms();
+    // training: only where the backward reads the forward's cache itself (bwd_reads_cache: `stage_bwd`) — there is no fp32 rebuild from stages
+    int terms_for(int64_t N, bool train, bool stage_bwd = false) const {
+        return (attn_mode == 4 && (!train || stage_bwd) && C == 256 && flash_split8_supported(dh, (int)(N > INT32_MAX ? 0 : N))) ? 8 : terms();
     }
     int w16_state() const { return attn_mode == 4 ? 1 : attn_mode; }      // what the 16-bit copy of W_kv has to hold
     int kind() const { return attn_mode == 3 ? kBF16 : kF16; }
@@ -352,7 +353,7 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
                                          reinterpret_cast<int*>(wsp + ws.flags), wsp + ws.xsplit, s, c->terms(), c->kind()));
             else
                 HIPCHK(launch_kvproj_split(sc->tokens, A + L.kv_whi, A + L.kv_wlo, A + L.cross_in_b + C, B, (int)N, C, c->vheads(),
-                                           cache, reinterpret_cast<int*>(wsp + ws.flags), s, c->terms_for(N, train), c->kind()));
+                                           cache, reinterpret_cast<int*>(wsp + ws.flags), s, c->terms_for(N, train, train && bwd_reads_cache(c, ws)), c->kind()));
         } else {
             LinearArgs a = lin(sc->tokens, C, A + L.cross_in_w + (int64_t)C * C, C, A + L.cross_in_b + C,
                                wsp + ws.kv + (int64_t)li * B * 2 * N * C, 0, (int)(B * N), 2 * C, C);
@@ -557,7 +558,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         if (c->cache_mode()) {
             const char* cache = reinterpret_cast<const char*>(wsp + ws.kvc) + (size_t)li * kvsplit_cache_bytes(B, c->vheads(), (int)N, c->terms());
             if (dh == 256) HIPCHK(launch_flash_split256(fa, cache, s, c->terms(), c->kind()));
-            else if (c->terms_for(N, train) == 8) {
+            else if (c->terms_for(N, train, train && bwd_reads_cache(c, ws)) == 8) {
                 // rows whose probability sum (relative to the row's reference maximum) is under kPeakyL are carried by too few keys for
                 // this mode's error model: flags[1] -> bit 1 of the range mirror -> the caller falls back to mode 1
                 fa.peaky = sharded ? nullptr : reinterpret_cast<int*>(wsp + ws.flags) + 1;
@@ -628,7 +629,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         // fp16-operand modes: a range violation seen while the cache was built must not produce plausible wrong numbers
         d.poison = (c->cache_mode() && c->kind() == kF16) ? reinterpret_cast<const int*>(wsp + ws.flags) : nullptr;
         d.poison_mirror = c->range_mirror;
-        d.peaky = (!sharded && c->terms_for(N, train) == 8) ? reinterpret_cast<const int*>(wsp + ws.flags) + 1 : nullptr;
+        d.peaky = (!sharded && c->terms_for(N, train, train && bwd_reads_cache(c, ws)) == 8) ? reinterpret_cast<const int*>(wsp + ws.flags) + 1 : nullptr;
         d.sb = c->sb; d.M = M; d.ncls = c->ncls;
         d.logits = o->pred_logits; d.center = o->center_unnormalized; d.size = o->size_unnormalized;
         d.rot = o->ortho6d; d.prob = o->sem_cls_prob; d.ref_next = ref_out; d.emb_next = emb_next;
@@ -1453,7 +1454,8 @@ int parq_backward(parq_handle h, const parq_scene* scene, void* workspace, size_
                                        2 * N * C, dh, 2 * C, gkv + C, 2 * N * C, dh, 2 * C, B, H, Q, (int)N, dh, I, s, wsp + ws.g_dqp,
                                        h->drop_p, seeds, reinterpret_cast<unsigned int*>(wsp + ws.g_bs),
                                        reinterpret_cast<unsigned int*>(wsp + ws.g_kvmax), wsp + ws.g_pack, wsp + ws.g_mat,
-                                       bwd_reads_cache(h, ws) ? reinterpret_cast<const void*>(wsp + ws.kvc) : nullptr, h->terms(), h->kind()));
+                                       bwd_reads_cache(h, ws) ? reinterpret_cast<const void*>(wsp + ws.kvc) : nullptr,
+                                       h->terms_for(N, true, bwd_reads_cache(h, ws)), h->kind()));
         if (dh == 256) {                          // max |dK|, |dV| for the split-precision dW_kv GEMM (the dh = 64 kernel records it itself)
             HIPCHK(hipMemsetAsync(wsp + ws.g_kvmax, 0, sizeof(unsigned int), s));
             HIPCHK(launch_absmax(gkv, (int64_t)B * 2 * N * C, reinterpret_cast<unsigned int*>(wsp + ws.g_kvmax), s));

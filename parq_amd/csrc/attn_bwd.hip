@@ -674,7 +674,7 @@ __global__ __launch_bounds__(256) void attn_bwd_pack_kernel(AttnBwdArgs a, const
 // measured 18.2 -> 16.6 ms; the first version needs them to stay inside its register budget)
 // PIPE (round 3): the dQ tile of query tile n - 1 is computed next to the softmax / dS arithmetic of tile n instead of at the end
 // of its own tile — same results (same operands, same order inside every accumulation), two barriers per tile as before.
-// CACHE: 0 = fp32 K / V (a.k, a.v); 3 / 1 = the forward's split / single-product cache (a.kvcache): the hi / lo pairs the forward
+// CACHE: 0 = fp32 K / V (a.k, a.v); 8 = the forward's mode-4 stage cache; 3 / 1 = the forward's split / single-product cache (a.kvcache): the hi / lo pairs the forward
 // multiplied are used as they are (no fp32 rebuild pass over 2 N C floats per scene, no second copy of K / V in HBM)
 // kGrad1: in the three GRADIENT products of the tile (dV^T += dO^T P, dK^T += Q^T dS, dQ += dS K) the probabilities and dS enter as ONE fp16
 // value each, rounded to nearest, instead of a hi / lo pair: 56 MFMAs per tile instead of 72, no lo plane of the dS^T image (a quarter of
@@ -711,7 +711,51 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
 
     // ---- K, V of this lane's key as B fragments: step t holds d = 16 t + 8 kh + e; K also goes into LDS (natural layout)
     half8 kfh[4], kfl[4], vfh[4], vfl[4];
-    if constexpr (CACHE != 0) {
+    if constexpr (CACHE == 8) {
+        // the forward's mode-4 stage cache (flash_split8.hip; 64 keys = 24 KB: K hi16 | K hi8 | K lo8 | V fp16): this wave's 32 keys are
+        // block blk & 1 of stage blk >> 1.  K = hi16 + e4m3 lo 2^-10 (what the forward's scores saw, to its 15 bits), V = the fp16 value
+        // (what the forward multiplied: the gradient goes straight through the rounding, as in the single-product modes).
+        // K hi16 / V planes: the layouts of the split cache's K_hi / V_hi blocks.  K lo8: piece (c, h) of a key holds byte 8 m + e' <->
+        // d = 32 m + 16 c + 4 h + (e' & 3) + 8 (e' >> 2); element e of fragment t (d = 16 t + 8 kh + e) is byte 8 (t >> 1) + 4 kh + (e & 3)
+        // of piece (c = t & 1, h = e >> 2).
+        const int nblk = (a.Lk + 31) >> 5;
+        int blk = blockIdx.x * (kSpKW / 32) + wave;
+        blk = blk < nblk ? blk : nblk - 1;
+        const unsigned char* stage = reinterpret_cast<const unsigned char*>(a.kvcache) + ((int64_t)bh * (nblk >> 1) + (blk >> 1)) * kStage8Bytes;
+        const int b2 = blk & 1;
+        const _Float16* kb = reinterpret_cast<const _Float16*>(stage + kS8Kh16 + b2 * 4096);
+        const _Float16* vb = reinterpret_cast<const _Float16*>(stage + kS8Vh16 + b2 * 4096);
+        const int ksw = (li >> 1) & 7;
+        const int vr = li & 15, vc = 2 * (li >> 4) + ((vr & 7) >> 2), ve = (vr & 3) + 4 * (vr >> 3);
+        const half8 zero8 = half8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int o0 = li * 64 + ((t ^ ksw) << 3) + 4 * kh, o1 = li * 64 + (((4 + t) ^ ksw) << 3) + 4 * kh;
+            kfh[t] = cat4(*reinterpret_cast<const half4v*>(kb + o0), *reinterpret_cast<const half4v*>(kb + o1));
+            half8 lo8;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int w = *reinterpret_cast<const int*>(stage + kS8K8lo + (((b2 * 2 + (t & 1)) * 2 + hh) * 32 + li) * 16 + 8 * (t >> 1) + 4 * kh);
+                lo8[4 * hh + 0] = (_Float16)(__builtin_amdgcn_cvt_f32_fp8(w, 0) * (1.f / kLo8Scale));
+                lo8[4 * hh + 1] = (_Float16)(__builtin_amdgcn_cvt_f32_fp8(w, 1) * (1.f / kLo8Scale));
+                lo8[4 * hh + 2] = (_Float16)(__builtin_amdgcn_cvt_f32_fp8(w, 2) * (1.f / kLo8Scale));
+                lo8[4 * hh + 3] = (_Float16)(__builtin_amdgcn_cvt_f32_fp8(w, 3) * (1.f / kLo8Scale));
+            }
+            kfl[t] = lo8;
+            half8 vh8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int d = 16 * t + 8 * kh + e;
+                vh8[e] = vb[d * 32 + ((vc ^ ((d >> 2) & 3)) << 3) + ve];
+            }
+            vfh[t] = vh8;
+            vfl[t] = zero8;
+            if (!jok) { kfh[t] = zero8; kfl[t] = zero8; vfh[t] = zero8; }
+            const int off = jw * 64 + (((2 * t + kh) ^ img_swz(jw)) << 3);
+            *reinterpret_cast<half8*>(Ki + off) = kfh[t];
+            *reinterpret_cast<half8*>(Ki + 16384 + off) = kfl[t];
+        }
+    } else if constexpr (CACHE != 0) {
         // this wave's 32 keys are ONE cache block (key li of block 8 blockIdx.x + wave).  K_x: [32 keys][8 chunks][8]; chunk 4 kh' + s
         // holds d = 32 (s >> 1) + 16 (s & 1) + 4 kh' + (e & 3) + 8 (e >> 2), stored at chunk position c ^ ((key >> 1) & 7): the eight
         // d = 16 t + 8 kh + e of fragment t are elements 4 kh .. 4 kh + 3 of chunks t (e < 4) and 4 + t (e >= 4).  V_x: [64 d][4 chunks][8];
@@ -1444,7 +1488,11 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
             if (e != hipSuccess) return e;                                                                                     \
             hipLaunchKernelGGL((attn_bwd_split2_kernel<DROP_, RAG_, 1, C_>), g2, dim3(512), lds2, s, a, oscale, pk);          \
         }
-        if (kvcache && pipe == 1 && (cache_terms == 3 || cache_terms == 1)) {       // K / V from the forward's 16-bit cache
+        if (kvcache && pipe == 1 && cache_terms == 8) {                            // K / V from the forward's mode-4 stage cache
+            if (Lk & 63) return hipErrorNotSupported;
+            if (drop_p > 0.f) { if (rag) PARQ_BWD2C(true, true, 8) else PARQ_BWD2C(true, false, 8) }
+            else { if (rag) PARQ_BWD2C(false, true, 8) else PARQ_BWD2C(false, false, 8) }
+        } else if (kvcache && pipe == 1 && (cache_terms == 3 || cache_terms == 1)) {       // K / V from the forward's 16-bit cache
             if (cache_terms == 3) {
                 if (drop_p > 0.f) { if (rag) PARQ_BWD2C(true, true, 3) else PARQ_BWD2C(true, false, 3) }
                 else { if (rag) PARQ_BWD2C(false, true, 3) else PARQ_BWD2C(false, false, 3) }

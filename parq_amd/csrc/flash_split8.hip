@@ -137,7 +137,9 @@ __device__ __forceinline__ f32x16 mx64(i32x8 a, i32x8 b, f32x16 c, int scale_a, 
 // REV: the sweep direction over the split's stages (a template parameter: the block-in-stage selects are then literals).
 // PROBE (development, results wrong): 2 no PV MFMAs, 4 no QK MFMAs, 8 no barrier / DMA waits, 16 no fragment reads; 32 (results right):
 // the written order of a step pinned with scheduling fences.
-template <int PROBE = 0, int RING = kRing, bool REV = false>
+// DROP: training-time dropout on the probabilities, the counter-based keep mask of FlashArgs::drop_seed exactly as in flash_split_pipe_kernel
+// (common.hpp; the backward kernels rebuild the same mask): the normaliser stays undropped, 1 / (1 - p) is applied once to the partial output.
+template <int PROBE = 0, int RING = kRing, bool REV = false, bool DROP = false>
 __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, const unsigned char* __restrict__ cache) {
     PARQ_TL_KERNEL(kTlFlashSplit);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [RING stages]
@@ -275,6 +277,13 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
         for (int r = 2; r < 8; ++r) { m0 = fmaxf(m0, S[r]); m1 = fmaxf(m1, S[8 + r]); }
         return xhalf_max(fmaxf(m0, m1));
     };
+    const uint32_t drop_rh = DROP ? drop_rowhash(a.drop_seed, (uint32_t)(bh * a.Lq + q)) : 0u;      // this lane's query row
+    const uint32_t drop_thr = DROP ? drop_threshold(a.drop_p) : 0u;
+    const uint32_t drop_rkh = drop_rh ^ (kh ? kDropBit2Part : 0u);
+    uint32_t dbase = 0u;                                                   // drop_rkh ^ block hash of the block in softmax
+    auto load_drop = [&](int n) {                                          // n -> its global 32-key block (the dropout column index is the key's)
+        if constexpr (DROP) dbase = drop_rkh ^ drop_blockhash((uint32_t)(rev ? 2 * t_end - 1 - n : 2 * t_begin + n));
+    };
     typedef float f32x2p __attribute__((ext_vector_type(2)));
     // one softmax pair: elements (2 J, 2 J + 1) of the accumulator -> one fp16 word of Ph[CUR][J / 4] and their sum into the row sum
     auto sm_pair = [&](auto cur, auto jj) {
@@ -286,8 +295,11 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
         const half2v ones = {(_Float16)1.f, (_Float16)1.f};
         if constexpr ((J & 1) == 0) l_a = __builtin_amdgcn_fdot2(hp, ones, l_a, false);
         else l_b = __builtin_amdgcn_fdot2(hp, ones, l_b, false);
+        unsigned hw = __builtin_bit_cast(unsigned, hp);
+        if constexpr (DROP)                                                 // the row sum above stays undropped
+            hw &= (drop_keep_h(dbase, drop_regpart(2 * J), drop_thr) ? 0xffffu : 0u) | (drop_keep_h(dbase, drop_regpart(2 * J + 1), drop_thr) ? 0xffff0000u : 0u);
         u32x4 h4 = __builtin_bit_cast(u32x4, Ph[CUR][M]);
-        h4[W] = __builtin_bit_cast(unsigned, hp);
+        h4[W] = hw;
         Ph[CUR][M] = __builtin_bit_cast(half8, h4);
     };
 #define PARQ_FENCE() do { if constexpr ((PROBE & 32) != 0) __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -296,6 +308,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
         constexpr int CUR = decltype(cur)::value, NXT = CUR ^ 1;
         using IC = std::integral_constant<int, CUR>;
         const int nk = n + 2 < nbk ? n + 2 : nbk - 1;                       // K of the next step (clamped at the split's end)
+        load_drop(n);
 #define PARQ_Q(i, Bq) if constexpr (!(PROBE & 4)) sacc[NXT] = mfma16<kF16>(kf[i], Bq, (i) == 0 ? negm16 : sacc[NXT]); PARQ_FENCE()
 #define PARQ_P(D, Bp) if constexpr (!(PROBE & 2)) o[D] = mfma16<kF16>(vh[D], Bp, o[D]); PARQ_FENCE()
 #define PARQ_S(J) sm_pair(IC{}, std::integral_constant<int, J>{}); PARQ_FENCE()
@@ -388,6 +401,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
             step(std::integral_constant<int, 0>{}, n);                       // n = nbk - 2
             ++n;
             // epilogue: softmax of the last block (odd), P V of the last two blocks
+            load_drop(n);
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 unsigned hw[4];
@@ -397,6 +411,9 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
                     const half2v hp = __builtin_convertvector(f32x2p{p0, p1}, half2v);
                     hw[e >> 1] = __builtin_bit_cast(unsigned, hp);
                     l_run = __builtin_amdgcn_fdot2(hp, half2v{(_Float16)1.f, (_Float16)1.f}, l_run, false);
+                    if constexpr (DROP)
+                        hw[e >> 1] &= (drop_keep_h(dbase, drop_regpart(8 * m + e), drop_thr) ? 0xffffu : 0u) |
+                                      (drop_keep_h(dbase, drop_regpart(8 * m + e + 1), drop_thr) ? 0xffff0000u : 0u);
                 }
                 Ph[1][m] = __builtin_bit_cast(half8, u32x4{hw[0], hw[1], hw[2], hw[3]});
             }
@@ -417,6 +434,13 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
     if (active) {
         const int64_t pbase = (int64_t)bh * a.nsplit + split;
         float* op = a.o_part + pbase * kDH * Lq_pad;
+        if constexpr (DROP) {
+            const float drop_scale = 1.f / (1.f - a.drop_p);
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= drop_scale;
+        }
         if (a.flags & 8) {
             // write-through publication of the partial outputs through the (idle) ring: see flash_split.hip
             __syncthreads();
@@ -463,7 +487,7 @@ hipError_t launch_kvsplit8_convert(const float* K, const float* V, int64_t k_bat
 }
 
 hipError_t launch_flash_split8(const FlashArgs& a, const void* cache, hipStream_t s) {
-    if (!flash_split8_supported(a.dh, a.Lk) || a.nsplit < 1 || a.nsplit > 256 || a.drop_p > 0.f) return hipErrorInvalidValue;
+    if (!flash_split8_supported(a.dh, a.Lk) || a.nsplit < 1 || a.nsplit > 256) return hipErrorInvalidValue;
     FlashArgs b = a;
     b.defer_log2 = kDefer8;
     static const int wt = [] { const char* e = dev_env("PARQ_FLASH_WT"); return e ? atoi(e) : 1; }();
@@ -483,6 +507,15 @@ hipError_t launch_flash_split8(const FlashArgs& a, const void* cache, hipStream_
         if (b.flags & 2) PARQ_F8_LAUNCH_RR(PROBE, kRing, true)                                                                 \
         PARQ_F8_LAUNCH_RR(PROBE, kRing, false)                                                                                 \
     }
+#define PARQ_F8_LAUNCH_DROP(REV)                                                                                               \
+    {                                                                                                                          \
+        static DynLdsOnce once;                                                                                                \
+        const size_t lds = (size_t)kRing * kStageBytes;                                                                        \
+        if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_split8_kernel<0, kRing, REV, true>), lds); e != hipSuccess) return e; \
+        hipLaunchKernelGGL((flash_split8_kernel<0, kRing, REV, true>), grid, dim3(kNW * 64), lds, s, b, c8);                    \
+        return hipGetLastError();                                                                                              \
+    }
+    if (b.drop_p > 0.f) { if (b.flags & 2) PARQ_F8_LAUNCH_DROP(true) PARQ_F8_LAUNCH_DROP(false) }
 #ifdef PARQ_DEV_PROBES
     static const int probe = [] { const char* e = dev_env("PARQ_FLASH_PROBE"); return e ? atoi(e) : 0; }();
     switch (probe) {
@@ -500,6 +533,7 @@ hipError_t launch_flash_split8(const FlashArgs& a, const void* cache, hipStream_
     PARQ_F8_LAUNCH(0)
 #undef PARQ_F8_LAUNCH
 #undef PARQ_F8_LAUNCH_RR
+#undef PARQ_F8_LAUNCH_DROP
 }
 
 }  // namespace parq

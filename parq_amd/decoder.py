@@ -285,6 +285,10 @@ class PARQDecoder(nn.Module):
         # flight keep their numbers: reduced accuracy on those rows, not NaN), "sync" re-runs the forward in "split".
         self.range_check = "lazy"
         self._range_mirror = None         # pinned host int32 the device raises on a range violation
+        # Training in mode "split8" (forward flash_split8_kernel with dropout, backward from its stage cache): 3 % faster per step at
+        # BASELINE cfg 4, and the forward's ~1e-5 arithmetic noise (ten times mode "split"'s) reaches the gradients amplified by the
+        # free-running chain (profiles/NOTES_r04.md).  Off by default: training steps then run in mode "split".
+        self.train_split8 = False
         self._peaky_checked = False       # the first inference forward in mode "split8" has been checked for too-peaked rows
 
     # ------------------------------------------------------------------ fp16 operand range (split / fp16 modes)
@@ -389,6 +393,10 @@ class PARQDecoder(nn.Module):
         dh = self.dim_in // self.num_heads
         if self.attention_mode in ("fp16", "bf16") and ((dh == 64 and self.dim_in <= 256) or (dh == 256 and self.dim_in % 128 == 0)):
             return self.attention_mode
+        if self.attention_mode == "split8" and dh == 64 and self.train_split8:
+            # opt-in (see __init__): the library runs mode 4 as mode "split" wherever its kernels do not apply (d != 256, ragged
+            # key counts, the per-iteration backward); the batched backward reads the forward's stage cache (attn_bwd.hip CACHE == 8)
+            return "split8"
         return "split" if dh in (64, 256) and self.attention_mode != "fp32" else "fp32"
 
     def _handle_in_mode(self, mode):

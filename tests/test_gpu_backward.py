@@ -218,7 +218,9 @@ def _masked_mha(xq, xk, xv, in_w, in_b, out_w, out_b, H, pmask):
     return torch.nn.functional.linear((p @ v).transpose(1, 2).reshape(B, Lq, Cd), out_w, out_b)
 
 
-@pytest.mark.parametrize("h,w,Hh,dim", [(8, 10, 2, 128), (32, 40, 2, 128), (8, 10, 1, 128), (12, 14, 1, 256)])    # N = 160: exact-fp32 attention backward; N = 2560: split-precision
+@pytest.mark.parametrize("h,w,Hh,dim", [(8, 10, 2, 128), (32, 40, 2, 128), (8, 10, 1, 128), (12, 14, 1, 256),
+                                        (32, 36, 4, 256), (32, 38, 4, 256)])   # the last two: mode "split8" in training (opt-in; N = 2304 / 2432 = whole 64-key stages, the second not whole 256-key backward tiles)
+                                                                              # N = 160: exact-fp32 attention backward; N = 2560: split-precision
                                                                               # kernel; one head of 128 dims: materialised backward;
                                                                               # one head of 256 dims: the batched composition from split GEMMs
 def test_dropout_forward_backward_match_masked_oracle(h, w, Hh, dim):
@@ -237,6 +239,8 @@ def test_dropout_forward_backward_match_masked_oracle(h, w, Hh, dim):
     cots = {"pred_logits": synth.normal(103, "cl", (I, B, Q, ncls)), "center_unnormalized": synth.normal(104, "cc", (I, B, Q, 3)),
             "size_unnormalized": synth.normal(105, "cs", (I, B, Q, 3)), "ortho6d": synth.normal(106, "cr", (I, B, Q, 6))}
     dec = make_decoder(cfg, W).train()
+    dec.train_split8 = True                   # takes effect where mode 4 applies (d = 256, head dim 64, whole stages, batched backward)
+    assert (dec._train_mode() == "split8") == ((dim, Hh) == (256, 4))
     torch.manual_seed(7)
     outs = dec.forward_train(*scene_args(sc))
     N, M = V * h * w, B * Q
