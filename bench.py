@@ -616,6 +616,15 @@ def main():
                                   % PEAK_F32_MATRIX_TFLOPS) if split else "dense fp16/bf16 MFMA peak" if half else "fp32 MFMA peak",
                     "hbm_stream_gbs": (kv_bytes / (ca_ms / ca_n * 1e-3) / 1e9) if ca_n else None,
                     "note": "launch time from hipEvents around this kernel alone (its merge kernel is group cross_attn_merge)"}
+        if not split8 and ca_n and kv_bytes / (PEAK_HBM_GBS * 1e9) > flop_per_launch / (mfma_peak * 1e12):
+            # the roof that bounds the launch is the larger of its two floors: with few queries per key (cfg 2: 128; the 16-bit modes at
+            # 256) streaming the K/V cache once at 8 TB/s takes longer than the launch's products at the dense matrix peak
+            stream_gbs = kv_bytes / (ca_ms / ca_n * 1e-3) / 1e9
+            roofline.update({"bound": "hbm", "achieved": stream_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": stream_gbs / PEAK_HBM_GBS,
+                             "algorithmic_bytes_per_launch": kv_bytes,
+                             "peak_note": "HBM3E 8 TB/s (floor %.1f us) against %.1f us of products at the matrix peak; a plain streaming kernel "
+                                          "reaches 5.6 TB/s on this part" % (kv_bytes / (PEAK_HBM_GBS * 1e9) * 1e6, flop_per_launch / (mfma_peak * 1e12) * 1e6),
+                             "mfma": {"achieved": ach_tflops, "peak": mfma_peak, "unit": "TFLOP/s", "frac": ach_tflops / mfma_peak}})
         if split8:
             # mode 4: one fp16 product + two MX-fp8 products per algorithmic product.  Matrix roof for algorithmic flops:
             # 2500 / 1.5 = 1667 TFLOP/s = 30 us per launch at cfg 3; the K/V stream of the launch (N C x (4 + 2) bytes:

@@ -120,7 +120,8 @@ int parq_pack_weights(parq_handle h, void *arena, size_t arena_bytes, parq_strea
  *      configurations of the benchmark (BASELINE.json configs 2 and 5; the reference defines no mixed
  *      precision).  Q, K, V and the probabilities are rounded to nearest 16-bit
  *      once, accumulation stays fp32; the K/V cache shrinks to half.  Outputs agree with the fp32 path to
- *      ~1e-3 (fp16) / ~1e-2 (bf16) on unit-scale features (tests state the tolerances);
+ *      ~1e-3 (fp16) / ~1e-2 (bf16) on unit-scale features (tests state the tolerances); on key counts that are a multiple of 64
+ *      the kernel is mode 4's without cross terms (probabilities normalised by the sum of their rounded values);
  *   4  the scores as mode 1's hi.hi fp16 product plus the two CROSS terms (hi.lo, lo.hi) as MX-scaled fp8 (e4m3) products — one
  *      v_mfma_scale_f32_32x32x64_f8f6f4 per cross term and 64-long contraction instead of four fp16 instructions (the cross terms
  *      are 2^-11 of a product, e4m3 rounds them at 2^-4: ~2^-15 per score) — and P V as ONE fp16 product of probabilities and values

@@ -977,7 +977,7 @@ int parq_create(const parq_config* cfg, parq_handle* out) {
 extern "C" int parq_dev_timeline(unsigned long long* buf, unsigned int cap) {
     if (buf) HIPCHK(hipMemset(buf, 0, 32));
     HIPCHK(tl_set_linear(buf, cap)); HIPCHK(tl_set_elementwise(buf, cap)); HIPCHK(tl_set_flash(buf, cap));
-    HIPCHK(tl_set_flash_split(buf, cap)); HIPCHK(tl_set_kvproj_split(buf, cap)); HIPCHK(tl_set_chain(buf, cap));
+    HIPCHK(tl_set_flash_split(buf, cap)); HIPCHK(tl_set_flash_split8(buf, cap)); HIPCHK(tl_set_kvproj_split(buf, cap)); HIPCHK(tl_set_chain(buf, cap));
     return PARQ_OK;
 }
 #endif

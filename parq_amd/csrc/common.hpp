@@ -66,6 +66,7 @@ hipError_t tl_set_linear(unsigned long long*, unsigned int);
 hipError_t tl_set_elementwise(unsigned long long*, unsigned int);
 hipError_t tl_set_flash(unsigned long long*, unsigned int);
 hipError_t tl_set_flash_split(unsigned long long*, unsigned int);
+hipError_t tl_set_flash_split8(unsigned long long*, unsigned int);
 hipError_t tl_set_kvproj_split(unsigned long long*, unsigned int);
 hipError_t tl_set_chain(unsigned long long*, unsigned int);
 #else
@@ -382,6 +383,8 @@ bool flash_split8_supported(int dh, int Lk);
 hipError_t launch_kvsplit8_convert(const float* K, const float* V, int64_t k_batch, int64_t k_head, int64_t k_row, int64_t v_batch,
                                    int64_t v_head, int64_t v_row, int B, int H, int N, void* cache, hipStream_t s);
 hipError_t launch_flash_split8(const FlashArgs& a, const void* cache, hipStream_t s);
+// attention modes 2 / 3 on whole 64-key stages of the single-product cache (flash_split8.hip); flash_split8_supported(dh, Lk) says where
+hipError_t launch_flash_single_stage(const FlashArgs& a, const void* cache, hipStream_t s, int kind);
 // kvproj_split.hip: tokens -> split cache directly (W pre-split with launch_split_f32)
 hipError_t launch_split_f32(const float* src, void* hi, void* lo, int64_t n, hipStream_t s);
 // elementwise.hip: up to kGatherMax device-to-device float copies in ONE launch (the weight pack: ~50 tensors per training step)

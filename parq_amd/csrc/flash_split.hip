@@ -917,6 +917,9 @@ hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t
     }
 #define PARQ_PIPE_LAUNCH(RING, PROBE, T, K, D) PARQ_PIPE_LAUNCH_V(RING, PROBE, T, K, D, kFlashVar)
     const bool drop = b.drop_p > 0.f;
+    static const bool stage1_off = [] { const char* e = dev_env("PARQ_FLASH_STAGE1"); return e && e[0] == '0'; }();
+    // modes 2 / 3 on whole 64-key stages: the step of the mode-4 kernel with one product (flash_split8.hip)
+    if (terms != 3 && !stage1_off && flash_split8_supported(a.dh, a.Lk)) return launch_flash_single_stage(a, cache, s, kind);
     if (terms != 3) {                                            // single fp16 / bf16 products (attention modes 2 / 3)
 #ifdef PARQ_DEV_PROBES
         if (!drop && kind == kF16) {

@@ -139,10 +139,19 @@ __device__ __forceinline__ f32x16 mx64(i32x8 a, i32x8 b, f32x16 c, int scale_a, 
 // the written order of a step pinned with scheduling fences.
 // DROP: training-time dropout on the probabilities, the counter-based keep mask of FlashArgs::drop_seed exactly as in flash_split_pipe_kernel
 // (common.hpp; the backward kernels rebuild the same mask): the normaliser stays undropped, 1 / (1 - p) is applied once to the partial output.
-template <int PROBE = 0, int RING = kRing, bool REV = false, bool DROP = false>
+// TERMS = 1 (attention modes 2 / 3 on whole 64-key stages): the same step with ONE KIND (fp16 / bf16) product for the scores — Q and K
+// rounded to nearest once, no cross terms — on the single-product cache of flash_split.hip (a stage = two 8 KB blocks [K | V]).
+template <int PROBE = 0, int RING = kRing, bool REV = false, bool DROP = false, int TERMS = 8, int KIND = kF16>
 __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, const unsigned char* __restrict__ cache) {
     PARQ_TL_KERNEL(kTlFlashSplit);
+    static_assert(TERMS == 8 || TERMS == 1, "mode 4 or a single 16-bit product");
+    static_assert(TERMS == 1 || KIND == kF16, "the split is an fp16 split");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [RING stages]
+    constexpr bool MX = TERMS == 8;
+    constexpr int kStageBytes = MX ? kStage8Bytes : 16384;                    // (shadows the file-level constant of the mode-4 stage)
+    // byte offset of physical block pb's K / V plane inside a stage
+    auto k16_off = [](int pb) { return MX ? oKh16 + pb * 4096 : pb * 8192; };
+    auto v16_off = [](int pb) { return MX ? oVh16 + pb * 4096 : pb * 8192 + 4096; };
     constexpr int NT = kNW * 64;
     constexpr int STAGE16 = kStageBytes / 16;
     constexpr int LD = STAGE16 / NT;
@@ -175,6 +184,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
             unsigned hw[4];
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = (e < 4 ? x0[e & 3] : x1[e & 3]) * scale;
+            if constexpr (!MX) { qh[s] = cvt8_rn<KIND>(x); continue; }
 #pragma unroll
             for (int e = 0; e < 8; e += 2) split_rtz(x[e], x[e + 1], hw[e >> 1], dl[e], dl[e + 1]);
             qh[s] = __builtin_bit_cast(half8, u32x4{hw[0], hw[1], hw[2], hw[3]});
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
 
     auto load_k16 = [&](int n) {
         if constexpr (PROBE & 16) return;
-        const _Float16* Kb = reinterpret_cast<const _Float16*>(stage_of(n) + oKh16 + pblk(n) * 4096);
+        const _Float16* Kb = reinterpret_cast<const _Float16*>(stage_of(n) + k16_off(pblk(n)));
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int pos = (4 * kh + s) ^ ksw;
@@ -249,7 +259,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
         }
     };
     auto load_k8 = [&](int n) {
-        if constexpr (PROBE & 16) return;
+        if constexpr ((PROBE & 16) || !MX) return;
         const unsigned char* st = stage_of(n);
         const int pb = pblk(n);
 #pragma unroll
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
     };
     auto load_v = [&](int n, int m, half8 (&vh)[2]) {
         if constexpr (PROBE & 16) { vh[0] = qh[0]; vh[1] = qh[1]; return; }
-        const _Float16* Vb = reinterpret_cast<const _Float16*>(stage_of(n) + oVh16 + pblk(n) * 4096);
+        const _Float16* Vb = reinterpret_cast<const _Float16*>(stage_of(n) + v16_off(pblk(n)));
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
             const int d = dt * 32 + li;
@@ -285,17 +295,29 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
         if constexpr (DROP) dbase = drop_rkh ^ drop_blockhash((uint32_t)(rev ? 2 * t_end - 1 - n : 2 * t_begin + n));
     };
     typedef float f32x2p __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2p __attribute__((ext_vector_type(2)));
+    // two probabilities -> one packed 16-bit pair, rounded to nearest (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32: unbiased also among fp16
+    // subnormals); l += exactly those two values (v_dot2c against (1, 1))
+    auto pack_sum = [&](float p0, float p1, float& l) -> unsigned {
+        if constexpr (KIND == kF16) {
+            const half2v hp = __builtin_convertvector(f32x2p{p0, p1}, half2v);
+            l = __builtin_amdgcn_fdot2(hp, half2v{(_Float16)1.f, (_Float16)1.f}, l, false);
+            return __builtin_bit_cast(unsigned, hp);
+        } else {
+            const bf16x2p bp = __builtin_convertvector(f32x2p{p0, p1}, bf16x2p);
+            l = __builtin_amdgcn_fdot2_f32_bf16(bp, bf16x2p{(__bf16)1.f, (__bf16)1.f}, l, false);
+            return __builtin_bit_cast(unsigned, bp);
+        }
+    };
     // one softmax pair: elements (2 J, 2 J + 1) of the accumulator -> one fp16 word of Ph[CUR][J / 4] and their sum into the row sum
     auto sm_pair = [&](auto cur, auto jj) {
         if constexpr (PROBE & 1) return;
         constexpr int CUR = decltype(cur)::value, J = decltype(jj)::value, M = J >> 2, W = J & 3;
         const float p0 = __builtin_amdgcn_exp2f(sacc[CUR][2 * J]);             // the accumulator holds score - m_run
         const float p1 = __builtin_amdgcn_exp2f(sacc[CUR][2 * J + 1]);
-        const half2v hp = __builtin_convertvector(f32x2p{p0, p1}, half2v);     // v_cvt_pk_f16_f32: round to nearest, unbiased also among subnormals
-        const half2v ones = {(_Float16)1.f, (_Float16)1.f};
-        if constexpr ((J & 1) == 0) l_a = __builtin_amdgcn_fdot2(hp, ones, l_a, false);
-        else l_b = __builtin_amdgcn_fdot2(hp, ones, l_b, false);
-        unsigned hw = __builtin_bit_cast(unsigned, hp);
+        unsigned hw;                                                        // the pair as the matrix pipe will read it, and its sum into the row sum
+        if constexpr ((J & 1) == 0) hw = pack_sum(p0, p1, l_a);
+        else hw = pack_sum(p0, p1, l_b);
         if constexpr (DROP)                                                 // the row sum above stays undropped
             hw &= (drop_keep_h(dbase, drop_regpart(2 * J), drop_thr) ? 0xffffu : 0u) | (drop_keep_h(dbase, drop_regpart(2 * J + 1), drop_thr) ? 0xffff0000u : 0u);
         u32x4 h4 = __builtin_bit_cast(u32x4, Ph[CUR][M]);
@@ -309,8 +331,8 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
         using IC = std::integral_constant<int, CUR>;
         const int nk = n + 2 < nbk ? n + 2 : nbk - 1;                       // K of the next step (clamped at the split's end)
         load_drop(n);
-#define PARQ_Q(i, Bq) if constexpr (!(PROBE & 4)) sacc[NXT] = mfma16<kF16>(kf[i], Bq, (i) == 0 ? negm16 : sacc[NXT]); PARQ_FENCE()
-#define PARQ_P(D, Bp) if constexpr (!(PROBE & 2)) o[D] = mfma16<kF16>(vh[D], Bp, o[D]); PARQ_FENCE()
+#define PARQ_Q(i, Bq) if constexpr (!(PROBE & 4)) sacc[NXT] = mfma16<KIND>(kf[i], Bq, (i) == 0 ? negm16 : sacc[NXT]); PARQ_FENCE()
+#define PARQ_P(D, Bp) if constexpr (!(PROBE & 2)) o[D] = mfma16<KIND>(vh[D], Bp, o[D]); PARQ_FENCE()
 #define PARQ_S(J) sm_pair(IC{}, std::integral_constant<int, J>{}); PARQ_FENCE()
         PARQ_Q(0, qh[0]);
         PARQ_P(0, Ph[NXT][0]);  PARQ_S(0);
@@ -323,11 +345,11 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
         load_k16(nk);
         PARQ_FENCE();
         PARQ_S(3);
-        if constexpr (!(PROBE & 4)) sacc[NXT] = mx64(k8l, q8h, sacc[NXT], kE8Lo, kE8One);
+        if constexpr (!(PROBE & 4) && MX) sacc[NXT] = mx64(k8l, q8h, sacc[NXT], kE8Lo, kE8One);
         PARQ_FENCE();
         PARQ_S(4);
         PARQ_P(0, Ph[NXT][1]);  PARQ_S(5);
-        if constexpr (!(PROBE & 4)) sacc[NXT] = mx64(k8h, q8l, sacc[NXT], kE8One, kE8Lo);
+        if constexpr (!(PROBE & 4) && MX) sacc[NXT] = mx64(k8h, q8l, sacc[NXT], kE8One, kE8Lo);
         PARQ_FENCE();
         load_k8(nk);
         PARQ_FENCE();
@@ -363,11 +385,21 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
             for (int r = 0; r < 16; ++r) { sacc[NXT][r] -= d; negm16[r] = -m_run; }
             // block n's probabilities (relative to the old reference) still wait for their P V: times 2^-d, exact in fp16 down to its
             // subnormals (what falls under them is under 2^-24 of the new reference)
-            const _Float16 ah = (_Float16)alpha;
+            if constexpr (KIND == kF16) {
+                const _Float16 ah = (_Float16)alpha;
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) Ph[CUR][m][e] *= ah;
+                    for (int e = 0; e < 8; ++e) Ph[CUR][m][e] *= ah;
+            } else {                                                        // bf16: exact through fp32 (8 significant bits, fp32's exponent range)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    bf16x8 bv = __builtin_bit_cast(bf16x8, Ph[CUR][m]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bv[e] = (__bf16)((float)bv[e] * alpha);
+                    Ph[CUR][m] = __builtin_bit_cast(half8, bv);
+                }
+            }
         }
     };
 
@@ -379,9 +411,11 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
             load_k8(0);
             const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 4; ++s) sacc[0] = mfma16<kF16>(kf[s], qh[s], s == 0 ? zero16 : sacc[0]);
-            sacc[0] = mx64(k8l, q8h, sacc[0], kE8Lo, kE8One);
-            sacc[0] = mx64(k8h, q8l, sacc[0], kE8One, kE8Lo);
+            for (int s = 0; s < 4; ++s) sacc[0] = mfma16<KIND>(kf[s], qh[s], s == 0 ? zero16 : sacc[0]);
+            if constexpr (MX) {
+                sacc[0] = mx64(k8l, q8h, sacc[0], kE8Lo, kE8One);
+                sacc[0] = mx64(k8h, q8l, sacc[0], kE8One, kE8Lo);
+            }
             m_run = block_max(sacc[0]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sacc[0][r] -= m_run; negm16[r] = -m_run; }
@@ -408,9 +442,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     const float p0 = __builtin_amdgcn_exp2f(sacc[1][8 * m + e]), p1 = __builtin_amdgcn_exp2f(sacc[1][8 * m + e + 1]);
-                    const half2v hp = __builtin_convertvector(f32x2p{p0, p1}, half2v);
-                    hw[e >> 1] = __builtin_bit_cast(unsigned, hp);
-                    l_run = __builtin_amdgcn_fdot2(hp, half2v{(_Float16)1.f, (_Float16)1.f}, l_run, false);
+                    hw[e >> 1] = pack_sum(p0, p1, l_run);
                     if constexpr (DROP)
                         hw[e >> 1] &= (drop_keep_h(dbase, drop_regpart(8 * m + e), drop_thr) ? 0xffffu : 0u) |
                                       (drop_keep_h(dbase, drop_regpart(8 * m + e + 1), drop_thr) ? 0xffff0000u : 0u);
@@ -424,7 +456,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
                     half8 v2[2];
                     load_v(n - 1 + blk, m, v2);
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) o[dt] = mfma16<kF16>(v2[dt], Ph[blk][m], o[dt]);
+                    for (int dt = 0; dt < 2; ++dt) o[dt] = mfma16<KIND>(v2[dt], Ph[blk][m], o[dt]);
                 }
         }
     } else if (active) {
@@ -535,5 +567,39 @@ hipError_t launch_flash_split8(const FlashArgs& a, const void* cache, hipStream_
 #undef PARQ_F8_LAUNCH_RR
 #undef PARQ_F8_LAUNCH_DROP
 }
+
+// Attention modes 2 / 3 (one fp16 / bf16 product per score and per output) on whole 64-key stages: the step of the kernel above without
+// cross terms, on the single-product cache.  Six 16 KB stages in the ring (the write-through epilogue needs 72 KB of it).
+hipError_t launch_flash_single_stage(const FlashArgs& a, const void* cache, hipStream_t s, int kind) {
+    if (!flash_split8_supported(a.dh, a.Lk) || a.nsplit < 1 || a.nsplit > 256 || (kind != kF16 && kind != kBF16)) return hipErrorInvalidValue;
+    FlashArgs b = a;
+    b.defer_log2 = kDefer8;
+    b.flags = ((a.flags & 2) ? 2 : 0) | ((a.Lq % 256 == 0) ? 8 : 0);
+    b.peaky = nullptr;
+    const dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * b.H);
+    const unsigned char* c8 = reinterpret_cast<const unsigned char*>(cache);
+    constexpr int kRing1 = 6;
+#define PARQ_F1_LAUNCH(REV, DROP, KIND)                                                                                        \
+    {                                                                                                                          \
+        static DynLdsOnce once;                                                                                                \
+        const size_t lds = (size_t)kRing1 * 16384;                                                                             \
+        if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_split8_kernel<0, kRing1, REV, DROP, 1, KIND>), lds); e != hipSuccess) return e; \
+        hipLaunchKernelGGL((flash_split8_kernel<0, kRing1, REV, DROP, 1, KIND>), grid, dim3(kNW * 64), lds, s, b, c8);          \
+        return hipGetLastError();                                                                                              \
+    }
+    const bool rev = (b.flags & 2) != 0, drop = b.drop_p > 0.f;
+    if (kind == kF16) {
+        if (drop) { if (rev) PARQ_F1_LAUNCH(true, true, kF16) PARQ_F1_LAUNCH(false, true, kF16) }
+        if (rev) PARQ_F1_LAUNCH(true, false, kF16)
+        PARQ_F1_LAUNCH(false, false, kF16)
+    }
+    if (drop) { if (rev) PARQ_F1_LAUNCH(true, true, kBF16) PARQ_F1_LAUNCH(false, true, kBF16) }
+    if (rev) PARQ_F1_LAUNCH(true, false, kBF16)
+    PARQ_F1_LAUNCH(false, false, kBF16)
+#undef PARQ_F1_LAUNCH
+}
+
+
+PARQ_TL_DEFINE_SETTER(tl_set_flash_split8)
 
 }  // namespace parq

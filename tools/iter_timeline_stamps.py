@@ -64,11 +64,20 @@ def launches(rec):
         j = order[i]
         g = int(nblk[j])
         idx = order[i:i + g]
-        assert (kid[idx] == kid[j]).all() and (nblk[idx] == g).all(), "records of two launches interleave (launch %d)" % len(out)
+        if not ((kid[idx] == kid[j]).all() and (nblk[idx] == g).all()):
+            # fewer records than workgroups (a launch whose late workgroups found the buffer switched off, or one cut by the stamped
+            # window): take the run of equal (kernel, grid) records
+            same = (kid[order[i:i + g]] == kid[j]) & (nblk[order[i:i + g]] == g)
+            g = int(np.argmin(same)) if not same.all() else g
+            idx = order[i:i + g]
+            print("# note: launch %d (%s) has %d records for %d workgroups" % (len(out), NAMES.get(int(kid[j]), str(kid[j])), g, int(nblk[j])))
         out.append({"kernel": NAMES.get(int(kid[j]), str(kid[j])), "wgs": g, "first_start": int(t0[idx].min()), "last_start": int(t0[idx].max()),
                     "first_end": int(t1[idx].min()), "last_end": int(t1[idx].max()),
                     "median_wg_us": float(np.median(t1[idx] - t0[idx])) * 0.01, "max_wg_us": float((t1[idx] - t0[idx]).max()) * 0.01,
-                    "xcds": len(set(xcc[idx].tolist()))})
+                    "xcds": len(set(xcc[idx].tolist())), "min_wg_us": float((t1[idx] - t0[idx]).min()) * 0.01,
+                    "p10_wg_us": float(np.percentile(t1[idx] - t0[idx], 10)) * 0.01, "p90_wg_us": float(np.percentile(t1[idx] - t0[idx], 90)) * 0.01,
+                    "start_p50": float(np.median(t0[idx] - t0[idx].min())) * 0.01, "end_p10": float(np.percentile(t1[idx] - t0[idx].min(), 10)) * 0.01,
+                    "end_p50": float(np.median(t1[idx] - t0[idx].min())) * 0.01})
         i += g
     return out
 
@@ -107,6 +116,11 @@ def main():
         print("%-18s %-15s %5d %9.2f %6.2f %7.2f %6.2f/%-6.2f %7.2f" % (lab, l["kernel"], l["wgs"], b, ramp, body, l["median_wg_us"], l["max_wg_us"], b + body))
         tot_b += b
         tot_body += body
+        if l["kernel"] == "flash_split":
+            print("#   cross-attention workgroups: run time min %.2f / p10 %.2f / median %.2f / p90 %.2f / max %.2f us; starts: median %.2f, last %.2f us after the "
+                  "first; ends: first %.2f, p10 %.2f, median %.2f, last %.2f us after the first start"
+                  % (l["min_wg_us"], l["p10_wg_us"], l["median_wg_us"], l["p90_wg_us"], l["max_wg_us"], l["start_p50"], ramp,
+                     (l["first_end"] - l["first_start"]) * 0.01, l["end_p10"], l["end_p50"], body))
         if l["kernel"] != "flash_split":
             small_b += b
             small_body += body
