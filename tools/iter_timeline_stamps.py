@@ -64,14 +64,26 @@ def launches(rec):
         j = order[i]
         g = int(nblk[j])
         idx = order[i:i + g]
-        if not ((kid[idx] == kid[j]).all() and (nblk[idx] == g).all()):
-            # fewer records than workgroups (a launch whose late workgroups found the buffer switched off, or one cut by the stamped
-            # window): take the run of equal (kernel, grid) records
-            same = (kid[order[i:i + g]] == kid[j]) & (nblk[order[i:i + g]] == g)
-            g = int(np.argmin(same)) if not same.all() else g
-            idx = order[i:i + g]
-            print("# note: launch %d (%s) has %d records for %d workgroups" % (len(out), NAMES.get(int(kid[j]), str(kid[j])), g, int(nblk[j])))
-        out.append({"kernel": NAMES.get(int(kid[j]), str(kid[j])), "wgs": g, "first_start": int(t0[idx].min()), "last_start": int(t0[idx].max()),
+        # (a fused launch stamps two kernel ids — pe1_sample_kernel: linear tiles + sampling workgroups — so a launch is the next g
+        # records of one grid size, whatever their ids)
+        assert (nblk[idx] == g).all(), "records of two launches interleave (launch %d)" % len(out)
+        ids = sorted(set(kid[idx].tolist()))
+        name = "+".join(NAMES.get(int(k), str(k)) for k in ids)
+        blk = rec[idx, 1].astype(np.int64)
+        dur = (t1[idx] - t0[idx]) * 0.01
+        sl = (blk % 16) >> 3                            # kvproj_dma_kernel at C = 256: slice 0 = K heads, 1 = V heads
+        extra = {}
+        if name == "flash_split":
+            # workgroup run time by XCD and by head (grid = (key splits, 1, heads): linear index = split + nsplit * head)
+            ns = g // 4 if g % 4 == 0 else g
+            extra["by_xcd"] = [(int(x), float(np.median(dur[xcc[idx] == x])), float(dur[xcc[idx] == x].max())) for x in sorted(set(xcc[idx].tolist()))]
+            extra["by_head"] = [(int(hd), float(np.median(dur[blk // ns == hd])), float(dur[blk // ns == hd].max())) for hd in sorted(set((blk // ns).tolist()))]
+            sp = blk % ns
+            extra["by_split_quarter"] = [(q, float(np.median(dur[(sp * 4) // ns == q])), float(dur[(sp * 4) // ns == q].max())) for q in range(4)]
+            extra["start_by_xcd"] = [(int(x), float(np.median((t0[idx] - t0[idx].min())[xcc[idx] == x])) * 0.01) for x in sorted(set(xcc[idx].tolist()))]
+        if name == "kv_proj" and (sl == 0).any() and (sl == 1).any():
+            extra = {"k_wg": (float(np.median(dur[sl == 0])), float(dur[sl == 0].max())), "v_wg": (float(np.median(dur[sl == 1])), float(dur[sl == 1].max()))}
+        out.append({**extra, "kernel": name, "wgs": g, "first_start": int(t0[idx].min()), "last_start": int(t0[idx].max()),
                     "first_end": int(t1[idx].min()), "last_end": int(t1[idx].max()),
                     "median_wg_us": float(np.median(t1[idx] - t0[idx])) * 0.01, "max_wg_us": float((t1[idx] - t0[idx]).max()) * 0.01,
                     "xcds": len(set(xcc[idx].tolist())), "min_wg_us": float((t1[idx] - t0[idx]).min()) * 0.01,
@@ -96,10 +108,16 @@ def main():
     ls = launches(rec)
     print("# %s" % _lib.load().parq_version().decode())
     print("# one stamped forward: %d workgroup records, %d launches; stamps are 10 ns ticks of s_memrealtime" % (len(rec), len(ls)))
+    for l in ls:
+        if l["kernel"] == "kv_proj":
+            print("# K/V projection: %d workgroups, body %.2f us; workgroup run time min %.2f / p10 %.2f / median %.2f / p90 %.2f / max %.2f us"
+                  % (l["wgs"], (l["last_end"] - l["first_start"]) * 0.01, l["min_wg_us"], l["p10_wg_us"], l["median_wg_us"], l["p90_wg_us"], l["max_wg_us"]))
+            if "k_wg" in l:
+                print("#   K-slice workgroups median %.2f / max %.2f us, V-slice workgroups median %.2f / max %.2f us" % (l["k_wg"] + l["v_wg"]))
     # per-iteration table: the chain of 15 launches starting at the first 'linear' after the (k-1)-th box_decode
     dec_idx = [i for i, l in enumerate(ls) if l["kernel"] == "box_decode"]
     k = args.iteration
-    lo = dec_idx[k - 1] + 1 if k > 0 else next(i for i, l in enumerate(ls) if l["kernel"] == "linear")
+    lo = dec_idx[k - 1] + 1 if k > 0 else next(i for i, l in enumerate(ls) if l["kernel"].startswith("linear"))
     hi = dec_idx[k] + 1
     it = ls[lo:hi]
     prev_end = ls[lo - 1]["last_end"]
@@ -121,6 +139,9 @@ def main():
                   "first; ends: first %.2f, p10 %.2f, median %.2f, last %.2f us after the first start"
                   % (l["min_wg_us"], l["p10_wg_us"], l["median_wg_us"], l["p90_wg_us"], l["max_wg_us"], l["start_p50"], ramp,
                      (l["first_end"] - l["first_start"]) * 0.01, l["end_p10"], l["end_p50"], body))
+        if l["kernel"] == "flash_split" and "by_xcd" in l:
+            print("#   run time median/max by XCD: " + ", ".join("%d: %.1f/%.1f" % t for t in l["by_xcd"]))
+            print("#   by head: " + ", ".join("%d: %.1f/%.1f" % t for t in l["by_head"]) + "; by quarter of the key axis: " + ", ".join("%d: %.1f/%.1f" % t for t in l["by_split_quarter"]))
         if l["kernel"] != "flash_split":
             small_b += b
             small_body += body
