@@ -136,7 +136,8 @@ def test_attention_split_head_dim_256(B, H, Lq, Lk):
 
 
 @pytest.mark.parametrize("bf16,tol", [(0, 2e-3), (1, 1.5e-2)])
-@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 4, 64, 9600), (2, 2, 100, 1000), (1, 1, 32, 64), (1, 2, 256, 4097)])
+@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 4, 64, 9600), (2, 2, 100, 1000), (1, 1, 32, 64), (1, 2, 256, 4097),
+                                       (2, 2, 100, 1024), (1, 4, 256, 12800)])      # whole 64-key stages: the stage kernel (ragged Lq; write-through epilogue)
 def test_attention_half(B, H, Lq, Lk, bf16, tol):
     """Single-product fp16 / bf16 attention (modes 2 / 3): tolerance = a few 16-bit ulps of the value scale
     (fp16 2^-11, bf16 2^-8 relative operand rounding), stated here; ragged Lq / Lk covered."""

@@ -32,12 +32,12 @@ def _want(q, k, v, B, H, Lq):
     return (torch.softmax(tq @ tk.transpose(-1, -2) / 8.0, -1) @ tv).transpose(1, 2).reshape(B, Lq, H * 64).numpy()
 
 
-def _attn_half(q, k, v, B, H, Lq, Lk):
+def _attn_half(q, k, v, B, H, Lq, Lk, bf16=0):
     nbytes = lib().parq_k_attention_half_scratch_bytes(B, H, Lq, Lk)
     scratch = torch.zeros(nbytes // 4 + 1, device="cuda")
     out = torch.empty(B, Lq, H * 64, device="cuda")
     dq, dk, dv = dev(q), dev(k), dev(v)
-    _lib.check(lib().parq_k_attention_half(_lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(out), B, H, Lq, Lk, 0, _lib.ptr(scratch), nbytes, sptr()), "half")
+    _lib.check(lib().parq_k_attention_half(_lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(out), B, H, Lq, Lk, bf16, _lib.ptr(scratch), nbytes, sptr()), "half")
     torch.cuda.synchronize()
     return out.cpu().numpy()
 
@@ -103,6 +103,14 @@ def test_attention_split8_reference_moves(spikes):
     e = rel_err(got, want)
     print("\nspikes %s: %.2e" % (spikes, e))
     assert e < 2e-4, (spikes, e)
+    # the same step without cross terms (attention modes 2 / 3 on whole stages: flash_split8_kernel<..., 1, fp16 | bf16>): same integer
+    # reference moves, pending fp16 / bf16 probabilities rescaled by 2^-d; bounds of tests/test_gpu_kernels.py::test_attention_half
+    for bf16, tol in ((0, 2e-3), (1, 1.5e-2)):
+        got1 = _attn_half(q, k, v, 1, 1, 64, 1024, bf16)
+        assert np.isfinite(got1).all()
+        e1 = rel_err(got1, want)
+        print("   single %s product: %.2e" % ("bf16" if bf16 else "fp16", e1))
+        assert e1 < tol, (spikes, bf16, e1)
 
 
 def test_attention_split8_saturates_instead_of_poisoning():
