@@ -918,7 +918,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh8, kfl[t], sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql8, kfh[t], sacc, 0, 0, 0);
             pacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh8, vfh[t], pacc, 0, 0, 0);
-            pacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh8, vfl[t], pacc, 0, 0, 0);
+            if constexpr (CACHE != 8) pacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh8, vfl[t], pacc, 0, 0, 0);     // (the stage cache holds V as one fp16 value)
             pacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ol8, vfh[t], pacc, 0, 0, 0);
         }
         // ---- P (with dropout), dS; accumulator register r is query mfma32_row(r, lane), column = this lane's key
