@@ -70,12 +70,17 @@ def build_inputs(B, device, seed):
     return tokens, dev(cam), dev(T_cp), dev(T_wp), dev(T_wl)
 
 
-def build_decoder(device):
+def build_decoder(device, wq_scale=1.0):
     from parq_amd import synth
     from parq_amd.decoder import PARQDecoder
     cfg = synth.decoder_cfg(dim=WORKLOAD["dim"], queries=WORKLOAD["queries"], heads=WORKLOAD["heads"],
                             ffn=WORKLOAD["ffn"], layers=WORKLOAD["iters"])
     W = synth.make_decoder_weights(cfg, seed=2024)
+    if wq_scale != 1.0:                  # sharpened cross-attention: the query rows of the in-projection (transformer_parq.py:377-380)
+        key = "parq_module.decoder.layers.0.multihead_attn.in_proj_weight"
+        wq = W[key].copy()
+        wq[:WORKLOAD["dim"]] *= wq_scale
+        W[key] = wq
     dec = PARQDecoder(cfg).eval()
     sd = dec.state_dict()
     for k in sd:
@@ -121,6 +126,57 @@ def cpu_baseline(cfg, W, inputs, min_seconds=12.0, max_iters=24, view_limit=None
                          "" if scale == 1.0 else "; only %d of the %d views were given to the CPU (the materialised scores of all of them do "
                          "not fit a bounded sample) and the measured rate was scaled by %d/%d: the reference's per-iteration cost is "
                          "linear in the key count" % (view_limit, V_all, view_limit, V_all))}
+
+
+def peaked_workload(device, inputs, h, w, steps, wq_scale=4.0):
+    """The number a model with NON-diffuse attention gets: the same workload with the cross-attention query projection
+    x 4 — rows that rest on a handful of keys, as trained detectors produce (xavier weights on white noise give
+    near-uniform rows).  Default policy: the module's first forward is checked synchronously and re-run with the flagged heads on the
+    fp16 x 3 tier (PARQDecoder.safe_heads); timed after the tiers have settled."""
+    import warnings
+    cfg, W, dec = build_decoder(device, wq_scale=wq_scale)
+    B, I = inputs[0].shape[0], WORKLOAD["iters"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        settle = 0
+        for settle in range(1, 9):                                   # the first call settles every head iteration 0 flags; later ones what is left
+            before = dec.safe_heads
+            out = dec(*inputs, feat_hw=(h, w))
+            torch.cuda.synchronize()
+            if dec.safe_heads == before and not dec.attention_too_peaked():
+                break
+        for _ in range(PREWARM_STEPS // 2):
+            dec(*inputs, feat_hw=(h, w))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = dec(*inputs, feat_hw=(h, w))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        finite = all(bool(torch.isfinite(v).all()) for o in out for v in o.values())
+        tripped_after = bool(dec.attention_too_peaked())
+        nh = WORKLOAD["heads"]
+        safe = dec.safe_heads
+        # the error the guard avoided: the same forward with every head forced onto the fast tier, against mode "split" (iteration 0)
+        ref = [{k: v.double().clone() for k, v in o.items()} for o in dec(*inputs, feat_hw=(h, w))][:1]
+        dec.range_check = "off"
+        dec.safe_heads = 0
+        raw = dec(*inputs, feat_hw=(h, w))[:1]
+        lmin = dec.attention_min_row_sum()
+        dec.attention_mode = "split"
+        strict = dec(*inputs, feat_hw=(h, w))[:1]
+        torch.cuda.synchronize()
+        err = lambda a, b: max(float(((x[k].double() - y[k].double()).abs() / y[k].double().abs().clamp(min=1.0)).max()) for x, y in zip(a, b) for k in x)
+        e_tiers, e_raw = err(ref, strict), err(raw, strict)
+    dec._ws.clear()
+    del dec
+    torch.cuda.empty_cache()
+    return {"workload": "the timed workload with the cross-attention query projection x %g (peaked rows)" % wq_scale,
+            "value": B * I * steps / dt, "unit": "decoder-iterations/sec", "ms_per_step": dt / steps * 1e3,
+            "safe_heads": "0b" + format(safe, "0%db" % nh), "heads_on_the_fast_tier": nh - bin(safe).count("1"),
+            "forwards_until_the_tiers_settled": settle, "outputs_finite": finite, "guard_tripped_in_the_timed_forwards": tripped_after,
+            "smallest_row_probability_sum": lmin,
+            "first_iteration_max_difference_to_mode_split": {"with_the_guard": e_tiers, "every_head_forced_onto_the_fast_tier": e_raw}}
 
 
 def project_sample_b32(dec, device, h, w, scenes=32, steps=2):
@@ -448,6 +504,7 @@ def main():
     ap.add_argument("--scenes-per-gpu", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b32", action="store_true", help="skip the 32-scene project+sample bandwidth measurement (6.3 GB of tokens)")
+    ap.add_argument("--no-peaked", action="store_true", help="skip the peaked_workload record (the same workload with sharpened cross-attention)")
     ap.add_argument("--train-split8", action="store_true", help="--train: run the training forward in mode split8 (PARQDecoder.train_split8)")
     ap.add_argument("--attention-mode", default=None, choices=["split", "split8", "fp32", "fp16", "bf16"],
                     help="cross-attention arithmetic; default = the library default (split8 at d = 256 / head dim 64: fp16 hi.hi + fp8 cross terms; "
@@ -559,6 +616,7 @@ def main():
     # mode was "split8": untimed by the contract, reported beside `value` with the largest difference of the two modes' outputs
     strict = None
     guard_tripped = dec.attention_too_peaked() if hasattr(dec, "attention_too_peaked") else False
+    guard_lmin = dec.attention_min_row_sum() if hasattr(dec, "attention_min_row_sum") else None
     if dec.attention_mode == "split8" and world == 1 and not (args.dev_lib or parq_env()):
         fast_out = [{k: v.clone() for k, v in o.items()} for o in step()]
         dec.attention_mode = "split"
@@ -704,7 +762,11 @@ def main():
             # mode "split8" is kept only while every cross-attention row spreads over enough keys (its error model); a tripped guard
             # would have switched the module to "split" and `dtype` / `roofline` above would say so
             out["attention_mode"] = mode
-            out["attention_guard"] = {"row_probability_sum_threshold": 64, "tripped": bool(guard_tripped)}
+            out["attention_guard"] = {"row_probability_sum_threshold": 256, "tripped": bool(guard_tripped),
+                                      "safe_heads": "0b" + format(int(getattr(dec, "safe_heads", 0)), "0%db" % WORKLOAD["heads"]),
+                                      "smallest_row_probability_sum": guard_lmin, "policy": dec.range_check}
+            if split8 and world == 1 and B == 1 and not args.no_peaked and not (args.dev_lib or parq_env()):
+                out["peaked_workload"] = peaked_workload(device, inputs, h, w, args.steps)
         if C == 256:
             out["ray_pe"] = ray_pe_timing(B, device)
         if world == 1:

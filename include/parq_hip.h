@@ -130,14 +130,25 @@ int parq_pack_weights(parq_handle h, void *arena, size_t arena_bytes, parq_strea
  *      dim 256, key counts that are a multiple of 64 — inference, and training steps whose batched backward reads the forward's cache
  *      (it then reads the stage cache: K = hi16 + e4m3 lo, V = the fp16 value); every other case of a handle in this mode runs as
  *      mode 1.  (The Python class trains in mode 1 unless asked: PARQDecoder.train_split8.)  Range: as mode 1; |K|, |q| past 448 saturate in their fp8 forms only (those elements keep the
- *      accuracy of mode 2, nothing is poisoned).  The mode's error model assumes rows that spread over many keys (1e-5 at the outputs
- *      while every row's probability sum, relative to its maximum, is above ~40; 1e-4 and more for rows that two or three keys
- *      carry): the merge kernel raises workspace "flags"[1] — and bit 1 of the range mirror — when a row's sum is under 64;
- *      outputs are NOT poisoned, the caller decides (the Python class falls back to mode 1: PARQDecoder.range_check). */
+ *      accuracy of mode 2, nothing is poisoned).  The mode's error model assumes rows that spread over many keys (within 2.4e-5
+ *      of mode 1 at the outputs while every row's probability sum, relative to its maximum, is above 256; 1e-4 and more for rows that
+ *      two or three keys carry): the merge kernel raises bit h of workspace "flags"[1] (and of "flags"[8 + iteration]; "flags"[2] keeps the smallest
+ *      row sum seen as 0x7fffffff - its float bits) — and bits 1 and 8 + h of the range mirror — when a row of head h has a sum
+ *      under 256; what happens then is the caller's policy, see parq_set_head_tiers. */
 int parq_set_attention_mode(parq_handle h, int32_t mode);
+/* Per-head tiers of attention mode 4 (inference; head dim 64, dim 256, at most 16 heads).  Bit h of `safe_mask` moves head h to the
+ * fp16 x 3 arithmetic of mode 1 INSIDE a mode-4 forward: the K/V projection writes that head's cache region in the split layout, the
+ * cross-attention of an iteration runs as two launches over complementary head sets (flash_split8_kernel over the others,
+ * flash_split_pipe_kernel over these; each with the key-split count that fills the chip with its heads), merged per set.  All heads
+ * safe = mode 1 exactly; a training forward with any safe head runs as mode 1.  `poison_on_peaked` != 0: an iteration in which a
+ * mode-4 head meets a too-peaked row (see mode 4 above) writes NaN outputs from that iteration on, like a range violation — the
+ * forward then never returns plausible numbers outside the mode's error model; the mirror's bits 8 + h say which heads to move.
+ * 0: outputs stay numbers (reduced accuracy on those rows), flags and mirror are raised all the same.
+ * The reference has one arithmetic (fp32, model/transformer_parq.py:377-380); this call only chooses how its result is approximated. */
+int parq_set_head_tiers(parq_handle h, uint32_t safe_mask, int32_t poison_on_peaked);
 /* Optional: a host-visible, device-writable int32 (pinned host memory, e.g. hipHostMalloc) in which the device sets bit 0 whenever
- * it poisons outputs because of a range violation (above) and bit 1 when attention mode 4 met a too-peaked row (above; outputs not
- * poisoned).  Lets a host poll for events of earlier, already finished calls with a plain load — no stream synchronisation,
+ * it poisons outputs because of a range violation (above), and bit 1 plus bit 8 + h when head h of attention mode 4 met a
+ * too-peaked row (above; outputs poisoned only if parq_set_head_tiers asked for it).  Lets a host poll for events of earlier, already finished calls with a plain load — no stream synchronisation,
  * nothing extra on the forward path.  NULL switches it off. */
 int parq_set_range_mirror(parq_handle h, int32_t *host_visible_flag);
 

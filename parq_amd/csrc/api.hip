@@ -15,7 +15,11 @@
 using namespace parq;
 
 namespace {
-constexpr float kPeakyL = 64.f;       // attention mode 4: smallest row sum of probabilities (relative to the row's reference maximum) it keeps
+// attention mode 4: smallest row sum of probabilities (relative to the row's reference maximum) it keeps.  Measured on the kernels at
+// BASELINE cfg 3's size (profiles/r05_split8_guard_sweep.txt): rows down to a sum of 255 keep the mode within 2.4e-5 of mode 1 on smooth
+// (FPN-like) features and within 6e-6 on white noise; at sums of 75 .. 87 smooth features are at 3.5e-5 (the round-4 threshold of 64 let
+// those through).  The benchmark's synthetic workload: smallest sum 3200 .. 4600.
+constexpr float kPeakyL = 256.f;
 
 thread_local char g_err[512] = "";
 
@@ -112,9 +116,18 @@ struct parq_ctx {
     // mode 4 (flash_split8.hip) where its kernels apply — inference, head dim 64, d = 256, whole 64-key stages — and mode 1 otherwise:
     // 8 = the stage cache with fp8 cross-term planes (same size as the split cache for such N)
     // training: only where the backward reads the forward's cache itself (bwd_reads_cache: `stage_bwd`) — there is no fp32 rebuild from stages
+    // per-head tiers (parq_set_head_tiers): heads of `safe_mask` run the fp16 x 3 kernel on the split layout inside a mode-4 forward
+    // (inference only; a training forward with any safe head runs as mode 1, and so does a forward whose heads are all safe)
     int terms_for(int64_t N, bool train, bool stage_bwd = false) const {
-        return (attn_mode == 4 && (!train || stage_bwd) && C == 256 && flash_split8_supported(dh, (int)(N > INT32_MAX ? 0 : N))) ? 8 : terms();
+        const bool m4 = attn_mode == 4 && (!train || stage_bwd) && C == 256 && flash_split8_supported(dh, (int)(N > INT32_MAX ? 0 : N));
+        if (!m4 || safe_heads() == all_heads() || (train && safe_heads() != 0)) return terms();
+        return 8;
     }
+    uint32_t safe_mask = 0;           // bit h: head h runs the fp16 x 3 kernel where the handle is in attention mode 4
+    int peaky_poison = 0;             // mode-4 heads that meet a too-peaked row: write that iteration's outputs (and what follows) as NaN
+    uint32_t all_heads() const { return H >= 32 ? 0xffffffffu : ((1u << H) - 1u); }
+    uint32_t safe_heads() const { return safe_mask & all_heads(); }
+    bool mixed_tiers(int64_t N, bool train, bool stage_bwd = false) const { return terms_for(N, train, stage_bwd) == 8 && safe_heads() != 0; }
     int w16_state() const { return attn_mode == 4 ? 1 : attn_mode; }      // what the 16-bit copy of W_kv has to hold
     int kind() const { return attn_mode == 3 ? kBF16 : kF16; }
     int* range_mirror = nullptr;      // host-visible word raised when outputs are poisoned (parq_set_range_mirror)
@@ -231,7 +244,16 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     ws->flags = take(64);
     ws->xsplit = take(split_mode && kvproj_big_on() ? (int64_t)kvproj_big_scratch_floats(B, (int)N, C) : 0);
     const size_t fs = flash_scratch_bytes(B, c->H, c->Q, c->dh, ws->self_split);
-    const size_t fc = flash_scratch_bytes(B, c->H, c->Q, c->dh, ws->cross_split);
+    size_t fc = flash_scratch_bytes(B, c->H, c->Q, c->dh, ws->cross_split);
+    if (c->attn_mode == 4 && c->dh == 64 && c->H <= 16) {
+        // per-head tiers: the mode-4 heads and the fp16 x 3 heads run as two launches, each with the key-split count that fills the
+        // chip with ITS heads, each with its own partials — room for the worst division of the heads
+        for (int nf = 1; nf < c->H; ++nf) {
+            const size_t two = flash_scratch_bytes(B, nf, c->Q, c->dh, flash_split_pick_splits(B, nf, c->Q, (int)N, cus)) +
+                               flash_scratch_bytes(B, c->H - nf, c->Q, c->dh, flash_split_pick_splits(B, c->H - nf, c->Q, (int)N, cus));
+            fc = two > fc ? two : fc;
+        }
+    }
     ws->flash = take((int64_t)((fs > fc ? fs : fc) / sizeof(float)));
     ws->total = off;
     // ---- training extras: activation stash of iterations 1..I-1, backward scratch
@@ -353,7 +375,9 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
                                          reinterpret_cast<int*>(wsp + ws.flags), wsp + ws.xsplit, s, c->terms(), c->kind()));
             else
                 HIPCHK(launch_kvproj_split(sc->tokens, A + L.kv_whi, A + L.kv_wlo, A + L.cross_in_b + C, B, (int)N, C, c->vheads(),
-                                           cache, reinterpret_cast<int*>(wsp + ws.flags), s, c->terms_for(N, train, train && bwd_reads_cache(c, ws)), c->kind()));
+                                           cache, reinterpret_cast<int*>(wsp + ws.flags), s,
+                                           c->mixed_tiers(N, train, train && bwd_reads_cache(c, ws)) ? 11 : c->terms_for(N, train, train && bwd_reads_cache(c, ws)),
+                                           c->kind(), c->safe_heads()));
         } else {
             LinearArgs a = lin(sc->tokens, C, A + L.cross_in_w + (int64_t)C * C, C, A + L.cross_in_b + C,
                                wsp + ws.kv + (int64_t)li * B * 2 * N * C, 0, (int)(B * N), 2 * C, C);
@@ -542,6 +566,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         a = cross_q_args(fold_pos);
         HIPCHK(launch_linear(a, 1, s));
     }
+    bool merged = false;              // the cross-attention launches below already merged their partials (per-head tiers)
     {
         // dense cross-attention against the cached K/V (transformer_parq.py:377-382)
         Prof p(c, s, PARQ_PROF_CROSS_ATTN);
@@ -560,10 +585,39 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
             if (dh == 256) HIPCHK(launch_flash_split256(fa, cache, s, c->terms(), c->kind()));
             else if (c->terms_for(N, train, train && bwd_reads_cache(c, ws)) == 8) {
                 // rows whose probability sum (relative to the row's reference maximum) is under kPeakyL are carried by too few keys for
-                // this mode's error model: flags[1] -> bit 1 of the range mirror -> the caller falls back to mode 1
-                fa.peaky = sharded ? nullptr : reinterpret_cast<int*>(wsp + ws.flags) + 1;
+                // this mode's error model: bit h of flags[1] (and of flags[8 + iteration]) -> bits 1 and 8 + h of
+                // the range mirror -> the caller moves head h to the fp16 x 3 tier (parq_set_head_tiers)
+                int* flg = reinterpret_cast<int*>(wsp + ws.flags);
+                fa.peaky = sharded ? nullptr : flg + 1;
+                fa.peaky_it = sharded ? nullptr : flg + 8 + (layer_num % 56);
+                fa.peaky_min = sharded ? nullptr : flg + 2;
                 fa.peaky_l = kPeakyL;
-                HIPCHK(launch_flash_split8(fa, cache, s));
+                const uint32_t safe = c->safe_heads();
+                if (safe == 0) HIPCHK(launch_flash_split8(fa, cache, s));
+                else {
+                    // per-head tiers: two launches over complementary head sets, each with the split count that fills the chip with its
+                    // heads and its own partials; every (scene, head) region of the cache spans the split layout's size (launch_kvproj_split)
+                    FlashArgs f8 = fa, f3 = fa;
+                    for (int hh = 0; hh < H; ++hh) {
+                        FlashArgs& t = ((safe >> hh) & 1u) ? f3 : f8;
+                        t.hmap |= (unsigned long long)hh << (4 * t.nh);
+                        ++t.nh;
+                    }
+                    const int cus = device_num_cus();
+                    f8.nsplit = flash_split_pick_splits(B, f8.nh, Q, (int)N, cus);
+                    f3.nsplit = flash_split_pick_splits(B, f3.nh, Q, (int)N, cus);
+                    f8.cache_head_bytes = f3.cache_head_bytes = (int64_t)kvsplit_cache_bytes(1, 1, (int)N, 3);
+                    f8.m_part = f8.o_part + (int64_t)B * f8.nh * f8.nsplit * dh * lp;
+                    f8.l_part = f8.m_part + (int64_t)B * f8.nh * f8.nsplit * lp;
+                    f3.o_part = f8.l_part + (int64_t)B * f8.nh * f8.nsplit * lp;
+                    f3.m_part = f3.o_part + (int64_t)B * f3.nh * f3.nsplit * dh * lp;
+                    f3.l_part = f3.m_part + (int64_t)B * f3.nh * f3.nsplit * lp;
+                    f3.peaky = nullptr; f3.peaky_it = nullptr; f3.peaky_min = nullptr;
+                    HIPCHK(launch_flash_split8(f8, cache, s));
+                    HIPCHK(launch_flash_split(f3, cache, s, 3, kF16));
+                    { Prof pm(c, s, PARQ_PROF_MERGE); HIPCHK(launch_flash_merge(f8, s)); HIPCHK(launch_flash_merge(f3, s)); }
+                    merged = true;
+                }
             }
             else HIPCHK(launch_flash_split(fa, cache, s, c->terms(), c->kind()));
         } else {
@@ -573,7 +627,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
             HIPCHK(launch_flash(fa, s));
         }
     }
-    { Prof p(c, s, PARQ_PROF_MERGE); HIPCHK(launch_flash_merge(fa, s)); }
+    if (!merged) { Prof p(c, s, PARQ_PROF_MERGE); HIPCHK(launch_flash_merge(fa, s)); }
     }   // phase bit 2
     if (!(sh.mask & 4)) return PARQ_OK;
     if (sharded) {
@@ -630,6 +684,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         d.poison = (c->cache_mode() && c->kind() == kF16) ? reinterpret_cast<const int*>(wsp + ws.flags) : nullptr;
         d.poison_mirror = c->range_mirror;
         d.peaky = (!sharded && c->terms_for(N, train, train && bwd_reads_cache(c, ws)) == 8) ? reinterpret_cast<const int*>(wsp + ws.flags) + 1 : nullptr;
+        d.peaky_poison = c->peaky_poison;
         d.sb = c->sb; d.M = M; d.ncls = c->ncls;
         d.logits = o->pred_logits; d.center = o->center_unnormalized; d.size = o->size_unnormalized;
         d.rot = o->ortho6d; d.prob = o->sem_cls_prob; d.ref_next = ref_out; d.emb_next = emb_next;
@@ -1254,6 +1309,15 @@ int parq_set_attention_mode(parq_handle h, int32_t mode) {
         return fail(PARQ_ERR_ARG, "the fp16 / bf16 attention modes need head dim 64 with dim in {128, 256}, or head dim 256 with dim a multiple of 128");
     h->attn_mode = mode;
     h->prepared = false;
+    return PARQ_OK;
+}
+
+int parq_set_head_tiers(parq_handle h, uint32_t safe_mask, int32_t poison_on_peaked) {
+    if (!h) return fail(PARQ_ERR_ARG, "NULL handle");
+    if (safe_mask != 0 && h->H > 16) return fail(PARQ_ERR_ARG, "per-head tiers need at most 16 heads");
+    if ((safe_mask & h->all_heads()) != h->safe_heads()) h->prepared = false;      // the K/V cache is laid out per tier
+    h->safe_mask = safe_mask;
+    h->peaky_poison = poison_on_peaked ? 1 : 0;
     return PARQ_OK;
 }
 

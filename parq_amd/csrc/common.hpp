@@ -343,9 +343,26 @@ struct FlashArgs {
     int flags;                  // bit 0: raise the priority of the younger half of the workgroup (pipelined split kernel)
     // attention mode 4: its error grows as a row concentrates on few keys (flash_split8.hip).  The merge kernel knows every row's
     // sum l of probabilities relative to the row's reference maximum — roughly the number of keys that carry the row — and
-    // raises *peaky when some row's l is under peaky_l (nullptr / 0: no check)
+    // raises bit h of *peaky (and of *peaky_it, this iteration's own word, if given) when some row of head h has l under peaky_l
+    // (nullptr / 0: no check); *peaky_min (optional) keeps the smallest l seen as 0x7fffffff - its bits (atomicMax; 0 = none)
     int* peaky; float peaky_l;
+    int* peaky_it; int* peaky_min;
+    // a launch over SOME of the heads (attention mode 4 with per-head tiers: the heads whose rows rest on few keys run the fp16 x 3
+    // kernel, the others the mode-4 kernel, each class with its own launch, key-split count and partial buffers).  nh = 0: all H heads.
+    // nh > 0: grid index z = b * nh + i covers head (hmap >> 4 i) & 15; partials are indexed by z, everything else by b * H + head.
+    int nh; unsigned long long hmap;
+    int64_t cache_head_bytes;   // bytes between the cache regions of two (scene, head) pairs; 0 = the kernel's own packed layout
 };
+struct FlashHead { int b, h, bh; };
+// grid index z of a partial-producing / merging launch -> (scene, head, b * H + head)
+__device__ __forceinline__ FlashHead flash_head(const FlashArgs& a, int z) {
+    FlashHead r;
+    if (a.nh > 0) { r.b = z / a.nh; r.h = (int)((a.hmap >> (4 * (z - r.b * a.nh))) & 15ull); }
+    else { r.b = z / a.H; r.h = z - r.b * a.H; }
+    r.bh = r.b * a.H + r.h;
+    return r;
+}
+inline int flash_launch_heads(const FlashArgs& a) { return a.nh > 0 ? a.nh : a.H; }
 int flash_key_tile(int dh);                    // keys per LDS tile
 int flash_lq_pad(int Lq);
 int flash_pick_nw(int B, int H, int Lq, int Lk, int dh, int num_cus);   // waves per workgroup
@@ -397,8 +414,10 @@ hipError_t launch_set_loss(const float* logits, const float* center, const float
                            int nmax, const int32_t* pairs, const float* coef, int P, const float* row_weight, const float* class_weight,
                            const float* w4, int background, float* terms, float* g_logits, float* g_center, float* g_size, float* g_o6,
                            int32_t* cls, hipStream_t s);
+// terms = 11: attention mode 4 with per-head tiers — head h as mode-4 stages, or in the split layout where bit h of safe_mask is set;
+// every (scene, head) region of the cache then spans ceil(N / 32) * 16 KB (the split layout's size)
 hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void* Wlo, const float* bias, int B, int N,
-                               int C, int H, void* cache, int* overflow, hipStream_t s, int terms = 3, int kind = kF16);
+                               int C, int H, void* cache, int* overflow, hipStream_t s, int terms = 3, int kind = kF16, unsigned safe_mask = 0);
 // fp32 -> 16-bit (round to nearest) weights of the single-term modes
 hipError_t launch_cvt16(const float* src, void* dst, int64_t n, int kind, hipStream_t s);
 
@@ -540,8 +559,11 @@ struct BoxDecodeArgs {
     float *logits, *center, *size, *rot, *prob;     // outputs (coord_pos is written by project_sample)
     float* ref_next;                   // [M][3] or nullptr
     float* emb_next;                   // [M][384] or nullptr: pos2posemb3d(ref_next)
-    int* poison_mirror;                // optional host-visible int: bit 0 set when outputs are poisoned, bit 1 when *peaky is set
-    const int* peaky;                  // optional device int raised by the cross-attention merge of attention mode 4 (FlashArgs::peaky)
+    int* poison_mirror;                // optional host-visible int: bit 0 set when outputs are poisoned by a range violation, bit 1 when
+                                       // *peaky is set, bits 8 + h: head h of *peaky
+    const int* peaky;                  // optional device int raised by the cross-attention merge of attention mode 4 (FlashArgs::peaky):
+                                       // bit h = head h ran the mode-4 kernel on a row that rests on too few keys
+    int peaky_poison;                  // non-zero: such an iteration's outputs are written as NaN too (never plausible wrong numbers)
     const int* poison;                 // optional device int: non-zero (fp16 operand range exceeded while the K/V cache was built) ->
                                        // every output of the iteration is written as NaN instead of a plausible wrong number
 };

@@ -248,9 +248,12 @@ __global__ __launch_bounds__(256) void box_decode_kernel(BoxDecodeArgs a) {
     const int lane = threadIdx.x & 63;
     const int C = a.C;
     const int scene = m / a.rows_per_scene;
-    const bool poison = a.poison != nullptr && *a.poison != 0;          // wave-uniform scalar load
-    if (poison && a.poison_mirror != nullptr && m == 0 && lane == 0) *a.poison_mirror = 1;       // tell the host (pinned word)
-    if (a.peaky != nullptr && a.poison_mirror != nullptr && m == 0 && lane == 0 && *a.peaky != 0) atomicOr(a.poison_mirror, 2);
+    const bool range_poison = a.poison != nullptr && *a.poison != 0;    // wave-uniform scalar loads
+    const int peaky = a.peaky != nullptr ? *a.peaky : 0;
+    const bool poison = range_poison || (a.peaky_poison && peaky != 0);
+    // tell the host (pinned word): bit 0 range violation, bit 1 + bits 8.. the heads attention mode 4 met too-peaked rows on
+    if (a.poison_mirror != nullptr && m == 0 && lane == 0 && (range_poison || peaky != 0))
+        atomicOr(a.poison_mirror, (range_poison ? 1 : 0) | (peaky != 0 ? (2 | (peaky << 8)) : 0));
     // every independent load is issued before the first dependent use (this kernel is pure latency)
     const float* h1 = a.h1 + (int64_t)m * a.ld1;
     const float lg_in = lane < a.ncls ? h1[lane] : -INFINITY;
@@ -407,9 +410,12 @@ __global__ __launch_bounds__(256) void box_decode256_kernel(BoxDecodeArgs a) {
     const float ms0 = a.mean_sizes[lane < nms ? lane : nms - 1];
     const float ms1 = a.mean_sizes[64 + lane < nms ? 64 + lane : nms - 1];
     __builtin_amdgcn_sched_barrier(0);                                   // keep every load above the first wait
-    const bool poison = a.poison != nullptr && *a.poison != 0;          // wave-uniform scalar load
-    if (poison && a.poison_mirror != nullptr && m == 0 && lane == 0) *a.poison_mirror = 1;
-    if (a.peaky != nullptr && a.poison_mirror != nullptr && m == 0 && lane == 0 && *a.peaky != 0) atomicOr(a.poison_mirror, 2);
+    const bool range_poison = a.poison != nullptr && *a.poison != 0;    // wave-uniform scalar loads
+    const int peaky = a.peaky != nullptr ? *a.peaky : 0;
+    const bool poison = range_poison || (a.peaky_poison && peaky != 0);
+    // tell the host (pinned word): bit 0 range violation, bit 1 + bits 8.. the heads attention mode 4 met too-peaked rows on
+    if (a.poison_mirror != nullptr && m == 0 && lane == 0 && (range_poison || peaky != 0))
+        atomicOr(a.poison_mirror, (range_poison ? 1 : 0) | (peaky != 0 ? (2 | (peaky << 8)) : 0));
 
     const float lg_in = lane < a.ncls ? lg_raw : -INFINITY;
     const float sz_in = lane < 3 ? sz_raw : 0.f;

@@ -233,16 +233,15 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(FlashArgs a) {
     float* wsm = smem;                               // [nsplit][32]
     float* dsm = wsm + a.nsplit * 32;                // [8][32]
     float* part = dsm + 8 * 32;                      // [NG split groups][kMergeDG][32]
-    const int bh = blockIdx.y;
-    const int b = bh / a.H;
-    const int h = bh - b * a.H;
+    const FlashHead fh = flash_head(a, blockIdx.y);
+    const int bh = fh.bh, b = fh.b, h = fh.h;
     const int q0 = blockIdx.x * 32;
     const int dg0 = blockIdx.z * kMergeDG;
     const int tq = threadIdx.x & 31;
     const int td = threadIdx.x >> 5;
     const int Lq_pad = (a.Lq + 31) & ~31;
     const int q = q0 + tq;
-    const int64_t pb = (int64_t)bh * a.nsplit;
+    const int64_t pb = (int64_t)blockIdx.y * a.nsplit;
 
     // softmax statistics of the 32 queries: thread (tq, td) owns splits td, td+8, ...; all of its loads are
     // issued together (a one-load-per-iteration loop here costs nsplit dependent L2 round trips)
@@ -283,7 +282,16 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(FlashArgs a) {
     const float inv = 1.f / den;
     if (a.lse && blockIdx.z == 0 && td == 0 && q < a.Lq) a.lse[(int64_t)bh * Lq_pad + q] = mmax + log2f(den);
     if (a.peaky && blockIdx.z == 0 && td == 0) {                     // attention mode 4: a row carried by too few keys (FlashArgs)
-        if (__any(q < a.Lq && den < a.peaky_l) && tq == 0) atomicOr(a.peaky, 1);
+        if (__any(q < a.Lq && den < a.peaky_l) && tq == 0) {
+            atomicOr(a.peaky, 1 << h);
+            if (a.peaky_it) atomicOr(a.peaky_it, 1 << h);
+        }
+        if (a.peaky_min) {
+            float dmin = q < a.Lq ? den : INFINITY;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, o));
+            if (tq == 0) atomicMax(a.peaky_min, 0x7fffffff - __float_as_int(dmin));
+        }
     }
 
     // thread -> (4 queries, one d, one of NG groups of the splits)
@@ -512,16 +520,15 @@ __global__ __launch_bounds__(256) void flash_merge_fixed_kernel(FlashArgs a) {
     __shared__ __attribute__((aligned(16))) float wsm[NS * 32];
     __shared__ float dsm[8 * 32];
     __shared__ __attribute__((aligned(16))) float part[NG * DG * 32];
-    const int bh = blockIdx.y;
-    const int b = bh / a.H;
-    const int h = bh - b * a.H;
+    const FlashHead fh = flash_head(a, blockIdx.y);
+    const int bh = fh.bh, b = fh.b, h = fh.h;
     const int q0 = blockIdx.x * 32;
     const int dg0 = blockIdx.z * DG;
     const int tq = threadIdx.x & 31;
     const int td = threadIdx.x >> 5;
     const int Lq_pad = a.Lq;                         // a.Lq % 32 == 0 (launcher)
     const int q = q0 + tq;
-    const int64_t pb = (int64_t)bh * NS;
+    const int64_t pb = (int64_t)blockIdx.y * NS;
     const int q4 = threadIdx.x & 7;
     const int dd = (threadIdx.x >> 3) & (DG - 1);
     const int half = threadIdx.x / (8 * DG);
@@ -567,7 +574,16 @@ __global__ __launch_bounds__(256) void flash_merge_fixed_kernel(FlashArgs a) {
         float dn = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) dn += dsm[i * 32 + tq];
-        if (__any(dn < a.peaky_l) && tq == 0) atomicOr(a.peaky, 1);
+        if (__any(dn < a.peaky_l) && tq == 0) {
+            atomicOr(a.peaky, 1 << h);
+            if (a.peaky_it) atomicOr(a.peaky_it, 1 << h);
+        }
+        if (a.peaky_min) {
+            float dmin = dn;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, o));
+            if (tq == 0) atomicMax(a.peaky_min, 0x7fffffff - __float_as_int(dmin));
+        }
     }
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -615,23 +631,23 @@ hipError_t merge_dh(const FlashArgs& a, hipStream_t s) {
     const size_t lds = ((size_t)a.nsplit * 32 + 8 * 32 + (size_t)2 * 16 * 32) * sizeof(float);
     static const int dg_env = [] { const char* e = dev_env("PARQ_MERGE_DG"); return e ? atoi(e) : 0; }();
     // 8 dims per workgroup while that is what it takes to cover the chip (one scene), else 16
-    const int64_t wg16 = (int64_t)ceil_div(a.Lq, 32) * a.B * a.H * (DH / 16);
+    const int64_t wg16 = (int64_t)ceil_div(a.Lq, 32) * a.B * flash_launch_heads(a) * (DH / 16);
     const int dg = dg_env == 8 || dg_env == 16 ? dg_env : (wg16 < device_num_cus() ? 8 : 16);
     static const bool fixed_off = [] { const char* e = dev_env("PARQ_MERGE_FIXED"); return e && e[0] == '0'; }();
     if constexpr (DH == 64) {
         if (dg == 8 && a.nsplit == 64 && a.Lq % 32 == 0 && !fixed_off) {       // the one-scene cross-attention merge: all loads up front
-            hipLaunchKernelGGL((flash_merge_fixed_kernel<DH, 8, 64>), dim3(a.Lq / 32, a.B * a.H, DH / 8), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((flash_merge_fixed_kernel<DH, 8, 64>), dim3(a.Lq / 32, a.B * flash_launch_heads(a), DH / 8), dim3(256), 0, s, a);
             return hipGetLastError();
         }
     }
     if (dg == 8) {
         static DynLdsOnce once;
         if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_merge_kernel<DH, 8>), 96 * 1024); e != hipSuccess) return e;
-        hipLaunchKernelGGL((flash_merge_kernel<DH, 8>), dim3(ceil_div(a.Lq, 32), a.B * a.H, DH / 8), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((flash_merge_kernel<DH, 8>), dim3(ceil_div(a.Lq, 32), a.B * flash_launch_heads(a), DH / 8), dim3(256), lds, s, a);
     } else {
         static DynLdsOnce once;
         if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&flash_merge_kernel<DH, 16>), 96 * 1024); e != hipSuccess) return e;
-        hipLaunchKernelGGL((flash_merge_kernel<DH, 16>), dim3(ceil_div(a.Lq, 32), a.B * a.H, DH / 16), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((flash_merge_kernel<DH, 16>), dim3(ceil_div(a.Lq, 32), a.B * flash_launch_heads(a), DH / 16), dim3(256), lds, s, a);
     }
     return hipGetLastError();
 }

@@ -242,8 +242,8 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
     static_assert(kStageBlks == 2 && (RING == 4 || RING == 5), "slot arithmetic below");
 
     const int split = blockIdx.x;
-    const int bh = blockIdx.z;
-    const int b = bh / a.H, h = bh - b * a.H;
+    const FlashHead fh = flash_head(a, blockIdx.z);                          // per-head tiers: this launch may cover some heads only
+    const int bh = fh.bh, b = fh.b, h = fh.h;
     // VAR & 16: the wave index as a scalar (readfirstlane): `active` and everything derived from it become scalar branches instead
     // of exec-masked regions, around which hipcc merges the LDS / VMEM counters conservatively
     const int tid = threadIdx.x, lane = tid & 63, wave = (VAR & 16) ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
@@ -275,7 +275,8 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
     const int nst = (nblk + kStageBlks - 1) / kStageBlks;
     const int t_begin = (int)((int64_t)split * nst / a.nsplit);
     const int t_end = (int)((int64_t)(split + 1) * nst / a.nsplit);
-    const uint4* gsrc = reinterpret_cast<const uint4*>(cache + (int64_t)bh * nblk * kBlkHalfs);
+    const uint4* gsrc = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(cache) +
+                                                       (int64_t)bh * (a.cache_head_bytes ? a.cache_head_bytes : (int64_t)nblk * kBlkHalfs * 2));
     const int64_t total16 = (int64_t)nblk * (kBlkBytes / 16);
     const int B0 = t_begin * kStageBlks;                                  // blocks of this split: [B0, B0 + nbk)
     const int nbk = ((t_end * kStageBlks < nblk) ? t_end * kStageBlks : nblk) - B0;
@@ -809,7 +810,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split_pipe_kernel(FlashArgs a,
     }
 
     if (active) {
-        const int64_t pbase = (int64_t)bh * a.nsplit + split;
+        const int64_t pbase = (int64_t)blockIdx.z * a.nsplit + split;
         float* op = a.o_part + pbase * kDH * Lq_pad;
         const float drop_scale = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
         if (a.flags & 8) {
@@ -905,7 +906,7 @@ hipError_t launch_flash_split(const FlashArgs& a, const void* cache, hipStream_t
     static const int nt = [] { const char* e = dev_env("PARQ_FLASH_NT"); return e ? atoi(e) : 0; }();
     static const int wt = [] { const char* e = dev_env("PARQ_FLASH_WT"); return e ? atoi(e) : 1; }();      // write-through partials (0: plain stores; measured 1.852 -> 1.846 ms)
     b.flags = (prio & 1) | ((alt && (a.flags & 2) && (a.Lk % (kStageBlks * kBlkKeys)) == 0) ? 2 : 0) | (nt ? 4 : 0) | ((wt && a.Lq % 256 == 0 && terms == 3) ? 8 : 0);
-    const dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * b.H);
+    const dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * flash_launch_heads(b));
     const _Float16* c16 = reinterpret_cast<const _Float16*>(cache);
 #define PARQ_PIPE_LAUNCH_V(RING, PROBE, T, K, D, V)                                                                                      \
     {                                                                                                                                    \

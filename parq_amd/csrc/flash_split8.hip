@@ -159,8 +159,8 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
     constexpr int AHEAD = RING - 3;                                          // see flash_split.hip: a stage is requested AHEAD barriers before the one that publishes it
 
     const int split = blockIdx.x;
-    const int bh = blockIdx.z;
-    const int b = bh / a.H, h = bh - b * a.H;
+    const FlashHead fh = flash_head(a, blockIdx.z);                          // per-head tiers: this launch may cover some heads only
+    const int bh = fh.bh, b = fh.b, h = fh.h;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kh = lane >> 5;
     const int q0 = (blockIdx.y * kNW + wave) * 32;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
     const int nst = a.Lk / 64;
     const int t_begin = (int)((int64_t)split * nst / a.nsplit);
     const int t_end = (int)((int64_t)(split + 1) * nst / a.nsplit);
-    const uint4* gsrc = reinterpret_cast<const uint4*>(cache + (int64_t)bh * nst * kStageBytes);
+    const uint4* gsrc = reinterpret_cast<const uint4*>(cache + (int64_t)bh * (a.cache_head_bytes ? a.cache_head_bytes : (int64_t)nst * kStageBytes));
     const int nbk = 2 * (t_end - t_begin);                                  // 32-key blocks of this split: always whole stages
 
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(kNW * 64) void flash_split8_kernel(FlashArgs a, con
     }
 
     if (active) {
-        const int64_t pbase = (int64_t)bh * a.nsplit + split;
+        const int64_t pbase = (int64_t)blockIdx.z * a.nsplit + split;
         float* op = a.o_part + pbase * kDH * Lq_pad;
         if constexpr (DROP) {
             const float drop_scale = 1.f / (1.f - a.drop_p);
@@ -524,7 +524,7 @@ hipError_t launch_flash_split8(const FlashArgs& a, const void* cache, hipStream_
     b.defer_log2 = kDefer8;
     static const int wt = [] { const char* e = dev_env("PARQ_FLASH_WT"); return e ? atoi(e) : 1; }();
     b.flags = ((a.flags & 2) ? 2 : 0) | ((wt && a.Lq % 256 == 0) ? 8 : 0);
-    const dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * b.H);
+    const dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * flash_launch_heads(b));
     const unsigned char* c8 = reinterpret_cast<const unsigned char*>(cache);
 #define PARQ_F8_LAUNCH_RR(PROBE, RING, REV)                                                                                    \
     {                                                                                                                          \
@@ -576,7 +576,7 @@ hipError_t launch_flash_single_stage(const FlashArgs& a, const void* cache, hipS
     b.defer_log2 = kDefer8;
     b.flags = ((a.flags & 2) ? 2 : 0) | ((a.Lq % 256 == 0) ? 8 : 0);
     b.peaky = nullptr;
-    const dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * b.H);
+    const dim3 grid(b.nsplit, ceil_div(b.Lq, 32 * kNW), b.B * flash_launch_heads(b));
     const unsigned char* c8 = reinterpret_cast<const unsigned char*>(cache);
     constexpr int kRing1 = 6;
 #define PARQ_F1_LAUNCH(REV, DROP, KIND)                                                                                        \

@@ -34,6 +34,9 @@ struct KvProjArgs {
     _Float16* cache;           // [B][H][nblk][16 KB]
     int* overflow;
     int N, C, H;
+    // TERMS == 11 (attention mode 4 with per-head tiers): bit h set = head h is written in the split layout (fp16 x 3 kernel), clear =
+    // as mode-4 stages; every (scene, head) region then spans head_bytes (the split layout's size)
+    unsigned safe_mask; int64_t head_bytes;
 };
 
 __global__ __launch_bounds__(kThreads) void kvproj_split_kernel(KvProjArgs a) {
@@ -282,9 +285,9 @@ template <int TM, int TERMS, int KIND, int NK, int D, int PROBE = 0>
 __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int total_rt, int nrt, int P) {
     PARQ_TL_KERNEL(kTlKvProj);
     constexpr int NWV = 8;
-    constexpr bool SPLIT = TERMS != 1;         // three-term products (TERMS = 3, and 8: the same GEMM with the mode-4 epilogue)
-    constexpr bool F8 = TERMS == 8;
-    static_assert(!F8 || TM == 64, "a tile is one 64-key stage of the mode-4 cache");
+    constexpr bool SPLIT = TERMS != 1;         // three-term products (TERMS = 3, and 8: the same GEMM with the mode-4 epilogue;
+    constexpr bool MIX = TERMS == 11;          // 11: each head in the layout of ITS tier, KvProjArgs::safe_mask)
+    static_assert((TERMS != 8 && !MIX) || TM == 64, "a tile is one 64-key stage of the mode-4 cache");
     constexpr int kBlkH = SPLIT ? 8192 : 4096;      // 16-bit units per 32-key cache block
     constexpr int kVoff = SPLIT ? 4096 : 2048;      // V_hi offset inside a block
     constexpr int kThr = NWV * 64;
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
     constexpr int kRawBytes = TM * kBK * 4;      // one k-step of fp32 tokens
     constexpr int NDMA = kRawBytes / (kThr * 16);            // DMA instructions per thread and k-step
     constexpr int NST_K = RT * 2 * (SPLIT ? 2 : 1);     // store instructions per thread and tile (mode 4: K waves 2 + 1 + 1 per block,
-    constexpr int NST_V = F8 ? RT * 2 : NST_K;          // V waves 2: the stage cache holds V as one fp16 plane)
+                                                        // V waves 2: the stage cache holds V as one fp16 plane — NST_V inside run())
     constexpr int NI = TM * 8 / kThr;            // 8-float pieces of a k-step per thread (conversion)
     static_assert(D >= 3 && D - 2 <= NK && NDMA >= 1 && NI >= 1, "wait counts below assume at most one epilogue inside the prefetch window");
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -397,8 +400,10 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
         return (t - b * nrt) * TM;
     };
 
-    auto run = [&](auto isk_tag) __attribute__((always_inline)) {
+    auto run = [&](auto isk_tag, auto f8_tag) __attribute__((always_inline)) {
         constexpr bool ISK = decltype(isk_tag)::value;
+        constexpr bool F8 = decltype(f8_tag)::value;             // this wave's head is written as mode-4 stages
+        constexpr int NST_V = F8 ? RT * 2 : NST_K;
         // W fragments of this lane's column, resident for the whole launch: [k-step][s][hi, lo]
         half8 wfr[NK][4][2];
 #pragma unroll
@@ -501,11 +506,13 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
             for (int t = 0; t < RT; ++t) {
                 const int blk = (m0 >> 5) + t;
                 if (blk >= nblk) continue;                                   // scalar
-                _Float16* out = a.cache + (((int64_t)b * a.H + h) * nblk + blk) * kBlkH;
+                _Float16* out = a.cache + (((int64_t)b * a.H + h) * nblk + blk) * kBlkH;          // (= head_bytes apart when MIX)
                 if constexpr (F8) {
                     // mode-4 stage image (flash_split8.hip): this block's fp16 plane at t * 4 KB of the K / V 16-bit region; K lanes also
                     // store their 16 accumulator registers as ONE 16-byte piece of the hi8 plane and one of the lo8 plane
-                    unsigned char* stage = reinterpret_cast<unsigned char*>(a.cache) + (((int64_t)b * a.H + h) * (nblk >> 1) + (m0 >> 6)) * kStage8Bytes;
+                    unsigned char* stage = reinterpret_cast<unsigned char*>(a.cache) +
+                                           (MIX ? ((int64_t)b * a.H + h) * a.head_bytes + (int64_t)(m0 >> 6) * kStage8Bytes
+                                                : (((int64_t)b * a.H + h) * (nblk >> 1) + (m0 >> 6)) * kStage8Bytes);
                     out = reinterpret_cast<_Float16*>(stage + (ISK ? kS8Kh16 : kS8Vh16 - 2 * kVoff) + t * 4096);
                     if constexpr (ISK) {
                         float x16[16];
@@ -535,7 +542,7 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
                     }
                 }
 #pragma unroll
-                for (int pl = 0; pl < (TERMS == 3 ? 2 : 1); ++pl) {
+                for (int pl = 0; pl < (SPLIT && !F8 ? 2 : 1); ++pl) {
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
                         *reinterpret_cast<half8*>(strip + li * 32 + (((2 * m + kh) ^ swz) << 3)) = pl ? lo[m] : hi[m];
@@ -561,8 +568,14 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
             first = false;
         }
     };
-    if (isK) run(std::true_type{});
-    else run(std::false_type{});
+    if constexpr (MIX) {
+        const bool safe = (a.safe_mask >> h) & 1u;                  // scalar: a wave works on one head
+        if (isK) { if (safe) run(std::true_type{}, std::false_type{}); else run(std::true_type{}, std::true_type{}); }
+        else { if (safe) run(std::false_type{}, std::false_type{}); else run(std::false_type{}, std::true_type{}); }
+    } else {
+        if (isK) run(std::true_type{}, std::integral_constant<bool, TERMS == 8>{});
+        else run(std::false_type{}, std::integral_constant<bool, TERMS == 8>{});
+    }
     if (ovf) atomicOr(a.overflow, 1);
 }
 
@@ -635,7 +648,7 @@ hipError_t launch_split_f32(const float* src, void* hi, void* lo, int64_t n, hip
 
 // tokens [B][N][C] -> split cache; Whi/Wlo [2C][C] fp16, bias [2C] fp32.  Needs C % 64 == 0, head dim 64.
 hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void* Wlo, const float* bias, int B, int N,
-                               int C, int H, void* cache, int* overflow, hipStream_t s, int terms, int kind) {
+                               int C, int H, void* cache, int* overflow, hipStream_t s, int terms, int kind, unsigned safe_mask) {
     if (C % kBK != 0 || C != H * 64 || (2 * C) % kBN != 0) return hipErrorInvalidValue;
     static DynLdsOnce once;
     const size_t ldsb = (size_t)(2 * kBM * kBK + 2 * kBN * kBK) * sizeof(_Float16);      // 64 KB
@@ -643,10 +656,12 @@ hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void*
     KvProjArgs a;
     a.X = tokens; a.Whi = reinterpret_cast<const _Float16*>(Whi); a.Wlo = reinterpret_cast<const _Float16*>(Wlo);
     a.bias = bias; a.cache = reinterpret_cast<_Float16*>(cache); a.overflow = overflow; a.N = N; a.C = C; a.H = H;
+    a.safe_mask = safe_mask; a.head_bytes = (int64_t)ceil_div(N, 32) * 16384;
     const int nct = 2 * C / kBN, nrt = ceil_div(N, kBM);
     if (C <= 4 * kBK && C % (2 * kBK) == 0) {
         // W-stationary persistent kernel: one workgroup per CU, the column slices of one slot on one XCD
         if (terms == 8) return (N % 64 == 0 && C == 256) ? launch_dma_nk<64, 8, kF16, 4, 4>(a, B, s) : hipErrorInvalidValue;
+        if (terms == 11) return (N % 64 == 0 && C == 256) ? launch_dma_nk<64, 11, kF16, 4, 4>(a, B, s) : hipErrorInvalidValue;
         if (terms != 3) return kind == kF16 ? launch_dma<1, kF16, 4>(a, B, s) : launch_dma<1, kBF16, 4>(a, B, s);
 #ifdef PARQ_DEV_PROBES
         static const int probe = [] { const char* e = dev_env("PARQ_KVPROJ_PROBE"); return e ? atoi(e) : 0; }();      // development

@@ -268,6 +268,10 @@ class PARQDecoder(nn.Module):
                                           # of that forward is then resolved inside loss() (or raised by backward()) instead of
                                           # by a host synchronisation at the end of forward_train
         self._phase_hook = None           # optional callable(name), called at the entry of the HIP backward (bench.py --phase-times)
+        self.loss_targets_late = False    # True: the targets handed to loss() may have been produced on the caller's stream AFTER the
+                                          # training forward was enqueued (a late .to(device, non_blocking=True), on-device box
+                                          # augmentation between dec(...) and dec.loss(...)): the loss's side stream then waits for the
+                                          # whole main stream before it reads them (correct, no overlap with the forward's iterations)
         self._train_pending = None        # deferred range check of the last training forward: callable -> True if it re-ran
         self.max_workspaces = 2           # inference workspaces (each holds a K/V cache) kept alive, least recently used first out
         self._mean_dev = None
@@ -281,15 +285,26 @@ class PARQDecoder(nn.Module):
         #           fp32 kernels (costs one host synchronisation per forward).
         #   "off":  only ``fp16_range_exceeded()`` on request.
         # The same policy covers attention mode "split8" meeting rows that rest on too few keys for its error model (the merge kernel
-        # flags rows whose probability sum is under 64): "lazy" switches the module to "split" at the next call (the forwards in
-        # flight keep their numbers: reduced accuracy on those rows, not NaN), "sync" re-runs the forward in "split".
+        # flags, per head, rows whose probability sum is under the guard threshold).  Under every policy but "off" such a forward
+        # NEVER returns plausible numbers from outside the error model: the iteration that met the row and everything after it is
+        # written as NaN by the device (like a range violation), and the flagged HEADS move to the fp16 x 3 tier (``safe_heads``):
+        #   "lazy": at the next call into the module (host load of the pinned word); forwards already in flight that meet such rows
+        #           are NaN too.  A module's FIRST inference forward (per weight version) is checked synchronously and re-run, so a
+        #           model whose attention is peaked from its first call on never returns NaN.
+        #   "sync": after every forward, which is re-run with the flagged heads moved (the caller always gets numbers).
+        #   "off":  no poisoning, no tier change; ``attention_too_peaked()`` / ``attention_peaked_map()`` on request.
         self.range_check = "lazy"
         self._range_mirror = None         # pinned host int32 the device raises on a range violation
         # Training in mode "split8" (forward flash_split8_kernel with dropout, backward from its stage cache): 3 % faster per step at
         # BASELINE cfg 4, and the forward's ~1e-5 arithmetic noise (ten times mode "split"'s) reaches the gradients amplified by the
         # free-running chain (profiles/NOTES_r04.md).  Off by default: training steps then run in mode "split".
         self.train_split8 = False
-        self._peaky_checked = False       # the first inference forward in mode "split8" has been checked for too-peaked rows
+        self._peaky_checked = False       # the first inference forward in mode "split8" (per weight version) has been checked for too-peaked rows
+        # Per-head tiers of attention mode "split8" (include/parq_hip.h parq_set_head_tiers): bit h = head h runs the fp16 x 3
+        # arithmetic of mode "split" inside a "split8" forward.  Heads are moved there by the peakedness guard (never back by
+        # themselves: ``reset_attention_tiers()``); a module whose heads are all safe runs exactly mode "split".
+        self.safe_heads = 0
+        self._tiers_set = None            # (safe mask, poison) the native handle currently holds
 
     # ------------------------------------------------------------------ fp16 operand range (split / fp16 modes)
     def _flag_view(self, ws, B, V, h, w, words=1):
@@ -305,17 +320,31 @@ class PARQDecoder(nn.Module):
                       % (self.attention_mode, where), RuntimeWarning, stacklevel=3)
         self.attention_mode = "fp32"
 
-    def _peaky_fallback(self, where):
+    def _peaky_fallback(self, heads, where):
+        """Move the flagged heads (bit mask) of attention mode 'split8' to the fp16 x 3 tier."""
         import warnings
-        warnings.warn("parq_amd.PARQDecoder: a cross-attention row rests on too few keys for attention mode 'split8' (%s): its error "
-                      "model (fp8 cross terms, fp16 probabilities) assumes rows that spread over many keys.  Switching attention_mode to "
-                      "'split' (all three terms of every product in fp16) for this module." % where, RuntimeWarning, stacklevel=3)
-        self.attention_mode = "split"
+        heads = int(heads) & ((1 << self.num_heads) - 1)
+        new = heads & ~self.safe_heads
+        if not new:
+            return False
+        self.safe_heads |= heads
+        names = ",".join(str(h) for h in range(self.num_heads) if (new >> h) & 1)
+        left = self.num_heads - bin(self.safe_heads).count("1")
+        warnings.warn("parq_amd.PARQDecoder: cross-attention head(s) %s have rows that rest on too few keys for attention mode 'split8' "
+                      "(%s): its error model (fp8 cross terms, fp16 probabilities) assumes rows that spread over many keys.  Those heads "
+                      "now run the fp16 x 3 arithmetic of mode 'split' (%d of %d heads stay on the fast tier); reset_attention_tiers() "
+                      "undoes it." % (names, where, left, self.num_heads), RuntimeWarning, stacklevel=3)
+        return True
+
+    def reset_attention_tiers(self):
+        """All heads back on the fast tier of attention mode 'split8'; the next inference forward is checked synchronously again."""
+        self.safe_heads = 0
+        self._peaky_checked = False
 
     def _range_poll(self):
         """A host load of the pinned word earlier forwards raise from the device (no synchronisation): bit 0 = an operand left the
-        fp16 range (outputs of that forward are NaN), bit 1 = attention mode 'split8' met a row carried by too few keys (outputs of
-        that forward are numbers, at that mode's reduced accuracy for such rows)."""
+        fp16 range (outputs of that forward are NaN), bit 1 = attention mode 'split8' met a row carried by too few keys on the heads of
+        bits 8.. (outputs of that forward are NaN from that iteration on unless ``range_check == "off"``)."""
         v = int(self._range_mirror[0]) if self._range_mirror is not None else 0
         if v != 0:
             self._range_mirror[0] = 0
@@ -324,28 +353,29 @@ class PARQDecoder(nn.Module):
             if (v & 1) and self.attention_mode in ("split", "split8", "fp16"):
                 self._range_fallback("detected after an earlier forward")
             elif (v & 2) and self.attention_mode == "split8":
-                self._peaky_fallback("detected after an earlier forward")
+                self._peaky_fallback(v >> 8, "detected after an earlier forward, whose outputs are NaN from that iteration on")
 
     def _range_after_forward(self, ws, sc):
         """"sync" policy: wait for the flags of the forward just enqueued; True = re-run it (with the fp32 kernels after a range
-        violation, in mode 'split' after a too-peaked row in mode 'split8').  The FIRST inference forward of a module in mode
-        'split8' is checked this way under every policy but "off" (one synchronisation, once): a model whose attention is too
-        peaked for that mode is peaked from its first call on, and then not even that call returns the mode's numbers."""
+        violation, with the flagged heads on the fp16 x 3 tier after a too-peaked row in mode 'split8').  The FIRST inference forward
+        of a module in mode 'split8' (per weight version) is checked this way under every policy but "off" (one synchronisation,
+        once): a model whose attention is too peaked for that mode is peaked from its first call on."""
         first = self.attention_mode == "split8" and not self._peaky_checked and self.range_check != "off"
         if not first and (self.range_check != "sync" or self.attention_mode not in ("split", "split8", "fp16")):
             return False
         flags = self._flag_view(ws, sc.B, sc.V, sc.h, sc.w, 2).tolist()
         if first:
             self._peaky_checked = True
-        if flags[0] != 0 and self.range_check == "sync":
+        if flags[0] != 0 and (self.range_check == "sync" or first):
             self._range_mirror[0] = 0
             self._range_fallback("re-running this forward")
             return True
         if flags[1] != 0 and self.attention_mode == "split8":
             if self._range_mirror is not None:
                 self._range_mirror[0] = int(self._range_mirror[0]) & 1
-            self._peaky_fallback("re-running this forward")
-            return True
+            if self._peaky_fallback(flags[1], "re-running this forward"):
+                self._peaky_checked = False if first else self._peaky_checked     # the re-run is checked too: other heads may follow
+                return True
         return False
 
     # ------------------------------------------------------------------ native handle
@@ -359,6 +389,7 @@ class PARQDecoder(nn.Module):
             _lib.check(lib.parq_create(C.byref(cfg), C.byref(h)), "parq_create")
             self._h = h
             self._mode_set = None
+            self._tiers_set = None
             self._bwd_batched_set = None
             self._bwd_streams_set = None
             self._train_ws = None
@@ -376,6 +407,10 @@ class PARQDecoder(nn.Module):
             _lib.check(_lib.load().parq_set_backward_batched(self._h, int(bool(self.backward_batched))), "parq_set_backward_batched")
             self._bwd_batched_set = bool(self.backward_batched)
             self._train_ws = None                      # the training workspace is carved differently
+        tiers = (int(self.safe_heads) if self.num_heads <= 16 else 0, 0 if self.range_check == "off" else 1)
+        if self._tiers_set != tiers:
+            _lib.check(_lib.load().parq_set_head_tiers(self._h, tiers[0], tiers[1]), "parq_set_head_tiers")
+            self._tiers_set = tiers
         if apply_mode and self._mode_set != self.attention_mode:
             if self.attention_mode not in ATTENTION_MODES:
                 raise ValueError(f"attention_mode must be one of {sorted(ATTENTION_MODES)}")
@@ -453,14 +488,19 @@ class PARQDecoder(nn.Module):
         _lib.check(lib.parq_pack_weights(h, _lib.ptr(self._arena), nbytes, _lib.stream_ptr()), "parq_pack_weights")
         del keep
         self._arena_key = key
+        self._peaky_checked = False                    # new weights: the next inference forward in mode "split8" is checked synchronously
 
-    def _workspace(self, B, V, h, w, device):
+    def _workspace(self, B, V, h, w, device, handle=None):
         """Workspace (K/V cache + activations) of a batch shape.  The ``max_workspaces`` most recently used shapes stay alive, so
-        a driver that alternates two shapes (e.g. train / validation snippets) does not reallocate a K/V cache per call."""
+        a driver that alternates two shapes (e.g. train / validation snippets) does not reallocate a K/V cache per call; each holds
+        a K/V cache (393 MB per scene at BASELINE cfg 3), so ``max_workspaces = 1`` halves the module's footprint for single-shape
+        drivers.  ``handle``: the native handle already switched to the mode of this call (else ``attention_mode`` is applied)."""
+        if handle is None:
+            handle = self._handle()                   # first: a pending mode change drops the cached workspaces (their carving differs)
         k = (B, V, h, w, str(device))
         ws = self._ws.pop(k, None)
         if ws is None:
-            nbytes = _lib.load().parq_workspace_bytes(self._handle(), B, V, h, w)
+            nbytes = _lib.load().parq_workspace_bytes(handle, B, V, h, w)
             if nbytes == 0:
                 raise RuntimeError("parq_workspace_bytes returned 0 for B=%d V=%d h=%d w=%d" % (B, V, h, w))
             while len(self._ws) >= max(1, int(self.max_workspaces)):
@@ -520,6 +560,13 @@ class PARQDecoder(nn.Module):
         ``torch.no_grad()`` (eval.py:46, Lightning's validation loop), or with nothing that requires grad, the inference chain
         runs: no saved activations, the folded position MLP, one K/V workspace."""
         if torch.is_grad_enabled() and (self.training or self._needs_graph(intput_tokens)):
+            if not self.training and not getattr(self, "_warned_eval_autograd", False):
+                import warnings
+                self._warned_eval_autograd = True
+                warnings.warn("parq_amd.PARQDecoder.forward in eval() mode with gradients enabled builds an autograd graph, as the reference "
+                              "module does: the training forward runs (attention mode 'split', saved activations of every iteration, one "
+                              "training workspace per output kept alive).  Wrap inference in torch.no_grad() (eval.py:46) for the "
+                              "inference chain.", RuntimeWarning, stacklevel=2)
             return self._forward_autograd(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
         with torch.no_grad():
             return self._forward_inference(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
@@ -546,11 +593,13 @@ class PARQDecoder(nn.Module):
         self._ensure_packed(dev)
         outs = self._alloc_outputs((self.num_layers, sc.B, self.num_queries), dev)
         po = _lib.ParqOutputs(*[_lib.ptr(t) for t in outs])
-        for _attempt in range(2):
+        for _attempt in range(self.num_heads + 2):
             ws = self._workspace(sc.B, sc.V, sc.h, sc.w, dev)
             _lib.check(_lib.load().parq_forward(self._handle(), C.byref(sc), _lib.ptr(ws), ws.numel() * 4, C.byref(po),
                                                 _lib.stream_ptr()), "parq_forward")
-            if not self._range_after_forward(ws, sc):          # "sync" policy + flag set: once more with the exact fp32 kernels
+            # "sync" policy / first forward + a flag: once more with the exact fp32 kernels (range) or with the flagged heads on
+            # the fp16 x 3 tier (each re-run can only add heads: at most num_heads of them)
+            if not self._range_after_forward(ws, sc):
                 break
         del keep
         return [{k: t[i] for k, t in zip(OUTPUT_KEYS, outs)} for i in range(self.num_layers)]
@@ -588,6 +637,7 @@ class PARQDecoder(nn.Module):
             h = self._handle_in_mode(mode)
             _lib.check(lib.parq_set_dropout(h, p_drop, seed), "parq_set_dropout")
             nbytes = lib.parq_train_workspace_bytes(h, sc.B, sc.V, sc.h, sc.w)
+            old_ws = self._train_ws
             if self._train_ws is None or self._train_ws.numel() * 4 < nbytes or self._train_ws.device != dev:
                 self._ws.clear()
                 self._train_ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=dev)
@@ -596,8 +646,13 @@ class PARQDecoder(nn.Module):
             # the stash is laid out for `mode`: backward() uses exactly this mode, whatever attention_mode says by then
             self._train_state = (sc, keep, outs, po, dev, mode, p_drop, seed)
             own = self._stash_owner() if self._stash_owner is not None else None
-            if own is not None and own.ws is self._train_ws:
-                own.state = self._train_state          # a re-run (range fallback) after the autograd node took the stash: same workspace, new mode
+            if own is not None and old_ws is not None and own.ws is old_ws and not own.consumed and getattr(old_ws, "_parq_gen", None) == own.gen:
+                # a re-run (range fallback) after the autograd node of THIS forward took the stash: new mode, and — where the new
+                # mode's workspace is larger — a new workspace; the node must not keep the poisoned forward's activations
+                own.state = self._train_state
+                if self._train_ws is not old_ws:
+                    own.ws = self._train_ws
+                    self._train_ws._parq_gen = own.gen
             return mode
         mode = enqueue()
         self._train_pending = None
@@ -607,12 +662,19 @@ class PARQDecoder(nn.Module):
             def rerun_if_poisoned(completed):
                 """`completed`: the caller knows the forward has finished on the device (the pinned word is then current);
                 otherwise the device flag is read, which waits for the stream."""
-                poisoned = ((int(self._range_mirror[0]) & 1) != 0) if completed else \
-                    int(self._flag_view(self._train_ws, sc.B, sc.V, sc.h, sc.w).item()) != 0
-                if not poisoned:
+                if completed:
+                    m = int(self._range_mirror[0])
+                    rng, peaked = (m & 1) != 0, (m >> 8) if (m & 2) else 0
+                else:
+                    f = self._flag_view(self._train_ws, sc.B, sc.V, sc.h, sc.w, 2).tolist()
+                    rng, peaked = f[0] != 0, f[1]
+                if not rng and not (peaked and mode == "split8"):
                     return False
                 self._range_mirror[0] = 0
-                self._range_fallback("re-running this training forward")
+                if rng:
+                    self._range_fallback("re-running this training forward")
+                else:                                        # train_split8: the flagged step is re-run in mode "split" (any safe head: mode 1)
+                    self._peaky_fallback(peaked, "re-running this training forward in mode 'split'")
                 enqueue()
                 return True
             if defer_range_check:
@@ -738,7 +800,7 @@ class PARQDecoder(nn.Module):
         for _attempt in range(2):
             # mode "split8" runs as "split" here: its peakedness guard looks at whole rows, a rank sees only its shard of the keys
             h = self._handle_in_mode("split") if self.attention_mode == "split8" else self._handle()
-            ws = self._workspace(sc.B, sc.V, sc.h, sc.w, dev)
+            ws = self._workspace(sc.B, sc.V, sc.h, sc.w, dev, handle=h)       # (not through _handle(): it would re-apply "split8")
             _lib.check(lib.parq_prepare(h, C.byref(sc), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()), "parq_prepare")
             na, nb = lib.parq_shard_exchange_floats(h, sc.B, 0), lib.parq_shard_exchange_floats(h, sc.B, 1)
             xa = torch.empty(na, dtype=torch.float32, device=dev)
@@ -803,6 +865,26 @@ class PARQDecoder(nn.Module):
         (B, V, h, w, _), ws = list(self._ws.items())[-1]
         return bool(self._flag_view(ws, B, V, h, w, 2)[1].item() != 0)
 
+    def attention_peaked_map(self):
+        """Per recurrent iteration of the last inference forward: bit mask of the heads on which attention mode "split8" met a row
+        under the guard threshold (synchronises).  The guard acts per head; this map says in which iterations."""
+        if not self._ws:
+            return []
+        (B, V, h, w, _), ws = list(self._ws.items())[-1]
+        f = self._flag_view(ws, B, V, h, w, 64).tolist()
+        return [f[8 + (k % 56)] for k in range(self.num_layers)]
+
+    def attention_min_row_sum(self):
+        """Smallest row probability sum (relative to the row's reference maximum) the mode-"split8" heads of the last inference forward
+        saw, or None (synchronises).  The guard threshold is 256 (include/parq_hip.h, attention mode 4)."""
+        if not self._ws:
+            return None
+        (B, V, h, w, _), ws = list(self._ws.items())[-1]
+        code = int(self._flag_view(ws, B, V, h, w, 3)[2].item())
+        if code == 0:
+            return None
+        return float(np.array([0x7fffffff - code], dtype=np.int32).view(np.float32)[0])
+
     def intermediate(self, name):
         """View of a named workspace buffer after prepare()/iterate() (parity tests)."""
         sc, keep, ws, dev = self._step
@@ -845,7 +927,7 @@ class PARQDecoder(nn.Module):
         else:
             self._resolve_train_range()
         return decoder_loss_batched(out_dict_list, obbs_padded, T_world_local, sym, ready=ready,
-                                    targets_ready=self._train_entry_event if ready is not None else None, **kw)
+                                    targets_ready=self._train_entry_event if (ready is not None and not self.loss_targets_late) else None, **kw)
 
     def wait_iteration(self, k):
         """Block the host until iteration k of the last training forward has written its outputs (parq_wait_iteration)."""
@@ -856,7 +938,7 @@ class PARQDecoder(nn.Module):
         self.wait_iteration(k)
         if self._train_pending is None:
             return False
-        if (int(self._range_mirror[0]) & 1) == 0 and k + 1 < self.num_layers:
+        if (int(self._range_mirror[0]) & 3) == 0 and k + 1 < self.num_layers:
             return False                                   # nothing raised so far
         self.wait_iteration(self.num_layers - 1)           # the whole forward, then the pinned word is final
         pending, self._train_pending = self._train_pending, None
@@ -871,13 +953,17 @@ class PARQDecoder(nn.Module):
             pending(False)                                 # outputs not consumed yet by this module: re-run in place if poisoned
             return
         self.wait_iteration(self.num_layers - 1)
-        if (int(self._range_mirror[0]) & 1) != 0:
+        m = int(self._range_mirror[0])
+        if (m & 3) != 0:
             self._range_mirror[0] = 0
-            self._range_fallback("detected in backward()")
-            raise RuntimeError("parq_amd.PARQDecoder: the training forward of this step left the fp16 operand range and its outputs are "
-                               "NaN; they were consumed outside PARQDecoder.loss, so the step cannot be repaired here.  Skip this step "
-                               "(the module now uses the exact fp32 kernels), or set overlap_loss_matching = False to have "
-                               "the training forward check and re-run before it returns.")
+            if m & 1:
+                self._range_fallback("detected in backward()")
+            else:
+                self._peaky_fallback(m >> 8, "detected in backward()")
+            raise RuntimeError("parq_amd.PARQDecoder: the training forward of this step left the fp16 operand range (or, with train_split8, "
+                               "met attention rows too peaked for mode 'split8') and its outputs are NaN; they were consumed outside "
+                               "PARQDecoder.loss, so the step cannot be repaired here.  Skip this step (the module now uses the safer "
+                               "kernels), or set overlap_loss_matching = False to have the training forward check and re-run before it returns.")
 
     @torch.no_grad()
     def parse_pred(self, out_dict):

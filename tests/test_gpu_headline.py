@@ -76,7 +76,7 @@ def test_cfg3_golden_teacher_forced(g14, truth, mode):
     refs = G.forced_refs(z, cfg.TRANSFORMER.SCALE)
     worst_truth = worst_gold = worst_ref = 0.0
     # per-(iteration, output) table of the three errors and of the bound that applied: written next to the test output so that
-    # which comparisons took the relaxed branch is on record (profiles/r03_cfg3_parity_table_<mode>.txt is a copy of it)
+    # which comparisons took the relaxed branch is on record (gpurun_out/parity_tables/; profiles/r03_cfg3_parity_table_<mode>.txt is a copy of one run)
     rows = ["# g14_cfg3 [%s] teacher-forced, error = max |a - b| / max(1, |b|) over the decision-safe elements" % mode,
             "# it output               HIP-vs-float64  HIP-vs-reference-fp32  reference-fp32-vs-float64  bound-on-HIP-vs-reference  branch"]
     for k in range(ITERS):
@@ -98,7 +98,7 @@ def test_cfg3_golden_teacher_forced(g14, truth, mode):
         sum(r.endswith("relaxed") and float(r.split()[3]) >= TOL for r in rows[2:])))
     print("\n" + "\n".join(rows))
     try:
-        d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "r03")
+        d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "parity_tables")
         os.makedirs(d, exist_ok=True)
         with open(os.path.join(d, "cfg3_parity_table_%s.txt" % mode), "w") as f:
             f.write("\n".join(rows) + "\n")

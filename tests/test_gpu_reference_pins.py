@@ -8,6 +8,9 @@
     the reference's fp32 vectors in both attention arithmetics (48/48 comparisons on the 1e-4 branch);
   * g19_cfg2 — BASELINE cfg 2's exact geometry (5 views 120x160, Q = 128, 4 iterations): split mode 1e-4 unrelaxed, bf16 (the
     arithmetic cfg 2 names) and fp16 at their stated bounds.
+  * g21_peaked — cfg 2's geometry with the cross-attention query projection x 4 (rows that rest on a handful of keys, the regime
+    the peakedness guard of attention mode "split8" exists for): the guard has to trip, and the tier it selects is held to the
+    reference's own vectors at an unrelaxed 1e-4.
 Error metric everywhere: max |a - b| / max(1, |b|) over the decision-safe elements (tests/golden_util.py)."""
 import os
 
@@ -26,7 +29,7 @@ TOL = 1e-4
 
 def _write_table(name, rows):
     try:
-        d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "r04")
+        d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "parity_tables")
         os.makedirs(d, exist_ok=True)
         with open(os.path.join(d, name), "w") as f:
             f.write("\n".join(rows) + "\n")
@@ -159,3 +162,56 @@ def test_cfg2_golden(mode, tol):
         assert worst > 1e-6                            # the reduced-precision kernels really ran
     if mode in ("split", "split8", "fp16"):
         assert not dec.fp16_range_exceeded()
+
+
+# ----------------------------------------------------------------------------------------------------------------- g21
+def test_peaked_golden_in_the_tier_the_guard_selects():
+    """g21 (reference: model/transformer_parq.py:283-337 on sharpened attention, captured by oracle/make_golden.py): the default
+    module — attention mode "split8", policy "lazy" — must trip its guard on this fixture (first-forward check), move the flagged
+    heads to the fp16 x 3 tier, and then match the reference's fp32 vectors teacher-forced at an unrelaxed 1e-4 on all 24 (iteration,
+    output) comparisons.  The same fixture with every head forced onto the fast tier (policy "off") is printed beside it."""
+    import warnings
+    case, z = G.load("g21_peaked")
+    cfg, W, sc = G.inputs(case)
+    refs = G.forced_refs(z, cfg.TRANSFORMER.SCALE)
+    dec = make_decoder(cfg, W)
+    assert dec.attention_mode == "split8" and dec.range_check == "lazy"
+    with warnings.catch_warnings(record=True) as caught, torch.no_grad():
+        warnings.simplefilter("always")
+        dec(*scene_args(sc), feat_hw=(case["h"], case["w"]))           # first forward: checked synchronously, re-run per flagged head set
+        assert dec.safe_heads != 0, "g21 is meant to trip the guard"
+        assert any("too few keys" in str(w.message) for w in caught)
+        for _attempt in range(dec.num_heads + 1):                       # teacher-forced stepping has no re-run of its own: NaN -> poll -> again
+            dec.prepare(*scene_args(sc), feat_hw=(case["h"], case["w"]))
+            outs = [to_np(dec.iterate(k, dev(refs[k]))[0]) for k in range(G.num_iters(z))]
+            torch.cuda.synchronize()
+            if not any(np.isnan(o["pred_logits"]).any() for o in outs):
+                break
+            dec._range_poll()
+    rows = ["# g21_peaked [split8 with per-head tiers, safe heads %s] teacher-forced, HIP vs the reference's own fp32 vectors; bound %g, no relaxed branch"
+            % (bin(dec.safe_heads), TOL), "# it output               HIP-vs-reference-fp32"]
+    worst = 0.0
+    for k, o in enumerate(outs):
+        w = G.compare(o, z, k, TOL, what="g21_peaked")
+        for key in G.KEYS:
+            rows.append("%4d %-20s %12.3e" % (k, key, w[key]))
+            worst = max(worst, w[key])
+    # what the guard avoided: every head on the fast tier
+    raw = make_decoder(cfg, W)
+    raw.range_check = "off"
+    with torch.no_grad():
+        raw.prepare(*scene_args(sc), feat_hw=(case["h"], case["w"]))
+        worst_raw = 0.0
+        for k in range(G.num_iters(z)):
+            o = to_np(raw.iterate(k, dev(refs[k]))[0])
+            vm, cm = G.safe_mask(z, k)
+            for key in G.KEYS:
+                b = z["it%d_%s" % (k, key)].astype(np.float64)
+                e = np.abs(o[key] - b) / np.maximum(1.0, np.abs(b))
+                m = np.ones_like(vm) if key == "coord_pos" else (vm & cm if key == "size_unnormalized" else vm)
+                worst_raw = max(worst_raw, float(e[m].max()) if m.any() else 0.0)
+    rows.append("# worst %.3e over %d comparisons, all under %g; with every head forced onto the fast tier (policy off): %.3e"
+                % (worst, len(outs) * len(G.KEYS), TOL, worst_raw))
+    _write_table("g21_peaked_parity_table.txt", rows)
+    print("\n" + "\n".join(rows))
+    assert worst < TOL

@@ -1,0 +1,238 @@
+"""GPU tier: what attention mode "split8" does when its peakedness guard trips (include/parq_hip.h parq_set_head_tiers,
+parq_amd/decoder.py).  The reference has ONE arithmetic for the cross-attention (fp32, model/transformer_parq.py:377-380); mode "split8"
+approximates it inside an error model that needs rows spread over many keys.  The contract tested here: a forward never returns
+plausible numbers from outside that model — the flagged heads move to the fp16 x 3 arithmetic of mode "split" (per head, inside the
+same forward: two launches over complementary head sets), and the forward that met the rows is either re-run ("sync", and the
+first forward of a module) or NaN from the flagged iteration on ("lazy")."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from parq_amd import synth
+from oracle import parq_oracle as O
+import golden_util as G
+from gpu_util import make_decoder, scene_args, to_np, rel_err
+
+pytestmark = pytest.mark.gpu
+
+WQ = "parq_module.decoder.layers.0.multihead_attn.in_proj_weight"
+
+
+def _case(scale, heads=None, name="g15_cfg5_shape"):
+    """A reference fixture's inputs with the cross-attention query projection scaled (all heads, or the 64 rows of each head in
+    `heads`): x 1 spreads every row over thousands of keys, x 4 leaves rows that two or three keys carry."""
+    case, z = G.load(name)
+    cfg, W, sc = G.inputs(case)
+    W = dict(W)
+    w = W[WQ].copy()
+    if heads is None:
+        w[:w.shape[1]] *= scale
+    else:
+        for h in heads:
+            w[64 * h: 64 * h + 64] *= scale
+    W[WQ] = w
+    return cfg, W, sc, G.forced_refs(z, cfg.TRANSFORMER.SCALE)
+
+
+def _run(dec, sc):
+    with torch.no_grad():
+        out = [{k: v.clone() for k, v in o.items()} for o in dec(*scene_args(sc))]
+    torch.cuda.synchronize()
+    return out
+
+
+def _split_reference(cfg, W, sc):
+    ref = make_decoder(cfg, W)
+    ref.attention_mode = "split"
+    return _run(ref, sc)
+
+
+def _worst(a, b):
+    return max(rel_err(x[k].cpu().numpy(), y[k].cpu().numpy()) for x, y in zip(a, b) for k in x)
+
+
+def test_sync_policy_reruns_with_the_flagged_heads_on_the_safe_tier():
+    """All four heads of the x 4 fixture are peaked: "sync" moves them all (a module whose heads are all safe runs exactly mode
+    "split": bit-identical outputs) and the caller never sees the first attempt."""
+    cfg, W, sc, _ = _case(4.0)
+    want = _split_reference(cfg, W, sc)
+    dec = make_decoder(cfg, W)
+    dec.range_check = "sync"
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        got = _run(dec, sc)
+    assert dec.attention_mode == "split8" and dec.safe_heads == 0b1111
+    for a, b in zip(got, want):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    assert any("too few keys" in str(w.message) for w in caught)
+
+
+def test_lazy_policy_never_returns_numbers_from_outside_the_error_model():
+    """"lazy", past the first-forward check: the forward that meets peaked rows is NaN from the flagged iteration on (here: from
+    iteration 0), the next call moves the heads and returns mode "split"'s numbers."""
+    cfg, W, sc, _ = _case(4.0)
+    want = _split_reference(cfg, W, sc)
+    dec = make_decoder(cfg, W)
+    assert dec.range_check == "lazy"
+    dec._peaky_checked = True              # as if an earlier (spread) forward had passed the first-call check: the lazy path proper
+    dec._ensure_packed(torch.device("cuda", torch.cuda.current_device()))
+    dec._peaky_checked = True              # (packing the weights re-arms the first-forward check)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        got = _run(dec, sc)
+        assert dec.safe_heads == 0 and dec.attention_too_peaked()
+        assert all(torch.isnan(v).all() for o in got for k, v in o.items() if k != "coord_pos"), "numbers from outside the error model"
+        again = _run(dec, sc)              # polls the pinned word first
+    assert dec.safe_heads == 0b1111
+    for a, b in zip(again, want):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    assert any("too few keys" in str(w.message) for w in caught)
+
+
+def test_first_forward_is_checked_under_the_lazy_policy():
+    cfg, W, sc, _ = _case(4.0)
+    want = _split_reference(cfg, W, sc)
+    dec = make_decoder(cfg, W)
+    assert dec.attention_mode == "split8" and dec.range_check == "lazy"
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        got = _run(dec, sc)
+    assert dec.safe_heads == 0b1111
+    for a, b in zip(got, want):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    assert any("too few keys" in str(w.message) for w in caught)
+
+
+def test_diffuse_scene_then_peaked_scene_same_module_lazy():
+    """peakedness is a property of the scene as much as of the model.  Same module, "lazy": a diffuse scene passes (fast
+    tier, numbers), then a scene whose tokens are 4 x larger (scores 4 x larger: peaked rows) — its outputs are NaN or mode "split"'s,
+    never plain wrong; the call after that is right."""
+    cfg, W, sc, _ = _case(1.0)
+    dec = make_decoder(cfg, W)
+    first = _run(dec, sc)
+    assert dec.safe_heads == 0 and all(torch.isfinite(v).all() for o in first for v in o.values())
+    sc2 = dict(sc)
+    sc2["tokens"] = (sc["tokens"] * 4.0).astype(np.float32)
+    want = _split_reference(cfg, W, sc2)
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        got = _run(dec, sc2)
+        assert dec.attention_too_peaked(), "the x 4 scene is meant to trip the guard"
+        for a, b in zip(got, want):
+            for k in a:
+                if k == "coord_pos":
+                    continue
+                assert torch.isnan(a[k]).all(), k           # (iteration 0 already meets peaked rows: everything is NaN)
+        again = _run(dec, sc2)
+    assert dec.safe_heads != 0
+    assert _worst(again[:1], want[:1]) < 2e-5          # (free-running: iteration 0; all heads safe -> bit-identical anyway)
+
+
+def test_off_policy_returns_numbers_and_reports_the_map():
+    cfg, W, sc, _ = _case(4.0)
+    dec = make_decoder(cfg, W)
+    dec.range_check = "off"
+    got = _run(dec, sc)
+    assert dec.safe_heads == 0 and dec.attention_too_peaked()
+    assert all(torch.isfinite(v).all() for o in got for v in o.values())
+    pm = dec.attention_peaked_map()
+    assert len(pm) == dec.num_layers and pm[0] != 0 and all(0 <= m < 16 for m in pm)
+    assert dec.attention_min_row_sum() < 256
+
+
+@pytest.mark.parametrize("heads", [[2], [0, 3]])
+def test_only_the_peaked_heads_move(heads):
+    """Per-head granularity: only the query rows of `heads` are sharpened.  "sync" ends with exactly those heads on the fp16 x 3 tier,
+    the others stay on the mode-4 kernel, and the mixed forward is within 2e-5 of mode "split" and of float64 (teacher-forced)."""
+    cfg, W, sc, refs = _case(4.0, heads=heads)
+    want = _split_reference(cfg, W, sc)
+    dec = make_decoder(cfg, W)
+    dec.range_check = "sync"
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        got = _run(dec, sc)
+    mask = sum(1 << h for h in heads)
+    assert dec.safe_heads == mask, bin(dec.safe_heads)
+    assert not dec.attention_too_peaked()                    # the last (mixed) run is inside the model
+    d = _worst(got[:1], want[:1])            # free-running: later iterations amplify any rounding difference (white-noise features)
+    # float64, teacher-forced on the reference's reference points, first two iterations
+    od = O.OracleDecoder(cfg, W, synth.SCANNET_MEAN_SIZES, dtype=torch.float64)
+    od.prepare(sc["tokens"], sc["camera"], sc["T_camera_pseudoCam"], sc["T_world_pseudoCam"], sc["T_world_local"])
+    with torch.no_grad():
+        dec.prepare(*scene_args(sc))
+        e = 0.0
+        for k in range(2):
+            exact = od.iterate(torch.from_numpy(refs[k]).double(), k)[0]
+            out, _ = dec.iterate(k, torch.from_numpy(refs[k]).cuda())
+            e = max(e, max(rel_err(out[key].cpu().numpy(), exact[key].numpy()) for key in G.KEYS))
+    print("\nheads %s peaked: mixed tiers vs split %.2e, vs float64 %.2e" % (heads, d, e))
+    assert d < 2e-5 and e < 2e-5
+
+
+@pytest.mark.parametrize("mask,B", [(0b0001, 1), (0b0110, 1), (0b1011, 2), (0b1000, 3)])
+def test_mixed_tiers_equal_their_own_kernels_per_head(mask, B):
+    """Forced tiers on spread attention (policy "off", nothing trips): in the cross-attention output of a mixed forward the columns
+    of a safe head equal mode "split"'s and the columns of a fast head equal mode "split8"'s, up to the summation order of the key
+    splits (each launch picks the split count that fills the chip with ITS heads): 1e-6."""
+    cfg = synth.decoder_cfg(dim=256, queries=96, heads=4, ffn=256, layers=2)
+    W = synth.make_decoder_weights(cfg, seed=77)
+    sc = synth.make_scene(78, B, 3, 24, 32, 256)
+    attn, outs = {}, {}
+    for mode, m in (("split", 0), ("split8", 0), ("mixed", mask)):
+        dec = make_decoder(cfg, W)
+        dec.range_check = "off"
+        dec.attention_mode = "split" if mode == "split" else "split8"
+        dec.safe_heads = m
+        with torch.no_grad():
+            dec.prepare(*scene_args(sc))
+            out, nxt = dec.iterate(0)
+            attn[mode] = dec.intermediate("attn").view(B * 96, 256).double().cpu().clone()
+            out2, _ = dec.iterate(1)
+            outs[mode] = {k: v.double().cpu() for k, v in out2.items()}
+    for h in range(4):
+        src = "split" if (mask >> h) & 1 else "split8"
+        a, b = attn["mixed"][:, 64 * h: 64 * h + 64], attn[src][:, 64 * h: 64 * h + 64]
+        assert float((a - b).abs().max() / b.abs().max()) < 1e-6, (h, src)
+    assert max(float(((outs["mixed"][k] - outs["split"][k]).abs() / outs["split"][k].abs().clamp(min=1)).max()) for k in outs["split"]) < 2e-5
+
+
+def test_mixed_tiers_at_cfg3_size():
+    """BASELINE cfg 3's geometry, one safe head of four (split counts 256 and 86, 393 MB regions per scene and head): the first
+    iteration against mode "split"."""
+    cfg = synth.decoder_cfg(dim=256, queries=256, heads=4, ffn=768, layers=1)
+    W = synth.make_decoder_weights(cfg, seed=2024)
+    cam, T_cp, T_wp, T_wl = (torch.from_numpy(a).cuda() for a in synth.make_geometry(3024, 1, 10, 120, 160))
+    g = torch.Generator(device="cuda").manual_seed(3024)
+    tokens = torch.randn(1, 10 * 120 * 160, 256, device="cuda", generator=g)
+    outs = {}
+    with torch.no_grad():
+        for mode, m in (("split", 0), ("mixed", 0b0100)):
+            dec = make_decoder(cfg, W)
+            dec.attention_mode = "split" if mode == "split" else "split8"
+            dec.range_check = "off"
+            dec.safe_heads = m
+            outs[mode] = {k: v.double().clone() for k, v in dec(tokens, cam, T_cp, T_wp, T_wl, feat_hw=(120, 160))[0].items()}
+            assert not dec.attention_too_peaked()
+            dec._ws.clear()
+    diff = max(float(((outs["mixed"][k] - outs["split"][k]).abs() / outs["split"][k].abs().clamp(min=1)).max()) for k in outs["split"])
+    print("\ncfg-3 size, one safe head: mixed vs split %.2e" % diff)
+    assert diff < 2e-5
+
+
+def test_reset_attention_tiers():
+    cfg, W, sc, _ = _case(4.0)
+    dec = make_decoder(cfg, W)
+    dec.range_check = "sync"
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        _run(dec, sc)
+        assert dec.safe_heads == 0b1111
+        dec.reset_attention_tiers()
+        assert dec.safe_heads == 0
+        _run(dec, sc)
+    assert dec.safe_heads == 0b1111

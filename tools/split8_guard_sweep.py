@@ -2,7 +2,8 @@
 (the query projection scaled), with the guard switched off so that mode 4 runs whatever the rows look like: the largest difference of
 the two modes' first-iteration outputs (mode "split" is 2e-6 from float64, so this IS mode 4's error to that accuracy), the state of
 the guard's flag, and the smallest row sum the guard saw.  Where the flag is down, the difference must be small — that is the
-guard's job.  usage: python tools/split8_guard_sweep.py [scale ...]"""
+guard's job.  SMOOTH=1: FPN-like smooth tokens (synth.make_scene(smooth=True)) instead of white noise — smooth features keep a larger error at
+the same row sum (fewer distinct values behind a row).  usage: python tools/split8_guard_sweep.py [scale ...]"""
 import os
 import sys
 
@@ -36,10 +37,15 @@ for seed in (2024, 7):
             dec.attention_mode = mode
             dec.range_check = "off"
             inputs = bench.build_inputs(1, dev, seed=1000 + seed)
+            if os.environ.get("SMOOTH"):
+                scn = synth.make_scene(1000 + seed, 1, 10, h, w, 256, smooth=True)
+                inputs = tuple(torch.from_numpy(scn[k]).to(dev) for k in ("tokens", "camera", "T_camera_pseudoCam", "T_world_pseudoCam", "T_world_local"))
             o = dec(*inputs, feat_hw=(h, w))[0]
             torch.cuda.synchronize()
             outs[mode] = {k: v.double().cpu() for k, v in o.items()}
             if mode == "split8":
                 flag = dec.attention_too_peaked()
+                lmin = dec.attention_min_row_sum()
         diff = max(float(((outs["split8"][k] - outs["split"][k]).abs() / outs["split"][k].abs().clamp(min=1)).max()) for k in outs["split"])
-        print("weights seed %4d, W_q x %.1f: split8 vs split %.2e   guard flag %s" % (seed, sc, diff, "UP (module would run split)" if flag else "down"), flush=True)
+        print("weights seed %4d, W_q x %.1f: split8 vs split %.2e   smallest row sum %8.1f   guard flag %s"
+              % (seed, sc, diff, lmin if lmin is not None else float("nan"), "UP (heads move to fp16 x 3)" if flag else "down"), flush=True)
