@@ -449,6 +449,7 @@ def train_bench(args):
                       + (" [development library or PARQ_* set: not a headline]" if (args.dev_lib or parq_env()) else ""),
             "value": args.steps / dt, "unit": "steps/sec", "scenes_per_sec": args.steps * B * world / dt,
             "n_gpus": world, "collective_backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
+            "rccl_version": (".".join(str(x) for x in torch.cuda.nccl.version()) if world > 1 and hasattr(torch.cuda, "nccl") else None),
             "parq_env": parq_env(), "dev_lib": bool(args.dev_lib), "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "final_loss": final_loss, "phase_ms": phase_ms, "train_attention_mode": train_mode, "opt_in_train_split8": opt_in,
@@ -552,7 +553,8 @@ def main():
         raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
     # host placement BEFORE the first GPU call (the runtime's helper threads inherit the mask): each rank on the cores of its
     # GPU's NUMA node, ranks that share a node on disjoint slices.  In-process sched_setaffinity, no re-exec.
-    pinned = parallel.pin_to_local_cores(local_rank) if world > 1 else []
+    shared_dev = world > 1 and args.share_device and torch.cuda.device_count() < world      # (device_count does not initialise the runtime)
+    pinned = parallel.pin_to_local_cores(local_rank, gpu_index_of=(lambda r: 0) if shared_dev else None) if world > 1 else []
     torch.set_grad_enabled(False)     # the metric is the inference forward; the reference's drivers run it under no_grad (eval.py:46)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
     device, backend = rank_device_and_backend(args, local_rank, world)
@@ -591,6 +593,7 @@ def main():
     dt = parallel.max_over_ranks(dt_own, device=red_dev)
     per_rank_ms = [x / args.steps * 1e3 for x in parallel.gather_over_ranks(dt_own, device=red_dev)]
     per_rank_cpus = parallel.gather_over_ranks(float(len(pinned)), device=red_dev)
+    per_rank_cpulists = [parallel.cpulist_string(c) for c in parallel.gather_objects(list(pinned))]
 
     # ---- per-step times from hipEvents on the launch stream (median of >= 20 runs); the wall-clock mean above stays
     # the contract's `value`, this is its cross-check and its spread
@@ -727,6 +730,8 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "per_rank_ms_per_step": per_rank_ms,       # every rank's own time over the same K steps (value uses the maximum): stragglers show
             "per_rank_pinned_cpus": [int(x) for x in per_rank_cpus],   # host cores each rank pinned itself to (0 = mask left alone)
+            "per_rank_pinned_cpulist": per_rank_cpulists,
+            "rccl_version": (".".join(str(x) for x in torch.cuda.nccl.version()) if world > 1 and hasattr(torch.cuda, "nccl") else None),
             "step_ms_hipevents": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": step_ms[0], "n": n_ev,
                                   "iterations_per_sec_at_median": B * I / (pct(0.5) * 1e-3),
                                   "note": "rank 0, one hipEvent pair per forward on the launch stream; `value` is the contract's wall-clock figure"},

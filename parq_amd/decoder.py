@@ -366,7 +366,7 @@ class PARQDecoder(nn.Module):
         flags = self._flag_view(ws, sc.B, sc.V, sc.h, sc.w, 2).tolist()
         if first:
             self._peaky_checked = True
-        if flags[0] != 0 and (self.range_check == "sync" or first):
+        if flags[0] != 0 and self.range_check == "sync":
             self._range_mirror[0] = 0
             self._range_fallback("re-running this forward")
             return True

@@ -184,22 +184,47 @@ def gpu_local_cpus(index: int, sysfs: str = "/sys", visible: str | None = None):
         return []
 
 
-def pin_to_local_cores(local_rank: int, local_world: int | None = None, sysfs: str = "/sys"):
+def gather_objects(obj):
+    """Every rank's picklable object, in rank order ([obj] without a process group)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def cpulist_string(cpus) -> str:
+    """[0, 1, 2, 5] -> "0-2,5" (the sysfs cpulist form)."""
+    cpus = sorted(set(int(c) for c in cpus))
+    runs, i = [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        runs.append(str(cpus[i]) if i == j else "%d-%d" % (cpus[i], cpus[j]))
+        i = j + 1
+    return ",".join(runs)
+
+
+def pin_to_local_cores(local_rank: int, local_world: int | None = None, sysfs: str = "/sys", gpu_index_of=None):
     """Pin THIS process (and the threads it starts later) to the host cores next to its GPU, in-process
     (``os.sched_setaffinity``; no re-exec, no numactl — call it BEFORE the first GPU call so that the runtime's helper threads
     inherit the mask).  Ranks whose GPUs share a NUMA node split that node's cores among themselves, so eight ranks on a
     two-socket host get disjoint eighths instead of all landing on socket 0 (the launcher's default), where four of them
-    would drive their GPUs across the inter-socket link.  Returns the CPU list it set, or [] if it left the mask alone (no
-    topology information, or the intersection with the allowed set is empty)."""
+    would drive their GPUs across the inter-socket link.  ``gpu_index_of``: local rank -> index of the GPU that rank uses (default:
+    its own local rank; ranks that share a device — bench.py --share-device — pass ``lambda r: 0`` and split that GPU's node).
+    Returns the CPU list it set, or [] if it left the mask alone (no topology information, or the intersection with the allowed
+    set is empty)."""
+    gpu = gpu_index_of if gpu_index_of is not None else (lambda r: r)
     if not hasattr(os, "sched_setaffinity"):
         return []
     if local_world is None:
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-    mine = gpu_local_cpus(local_rank, sysfs)
+    mine = gpu_local_cpus(gpu(local_rank), sysfs)
     if not mine:
         return []
     # ranks that share my NUMA node (same local_cpulist), in rank order: each takes a contiguous slice
-    sharing = [r for r in range(max(1, local_world)) if gpu_local_cpus(r, sysfs) == mine] or [local_rank]
+    sharing = [r for r in range(max(1, local_world)) if gpu_local_cpus(gpu(r), sysfs) == mine] or [local_rank]
     allowed = sorted(set(mine) & set(os.sched_getaffinity(0)))
     if not allowed:
         return []

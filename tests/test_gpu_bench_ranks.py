@@ -14,10 +14,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 
 
-def _run(extra):
+def _run(extra, gpus=2):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--no-cpu-baseline", "--no-b32"] + extra,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--share-device", "--no-cpu-baseline", "--no-b32"] + extra,
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -46,3 +46,25 @@ def test_bench_two_ranks_training_line():
     assert d["unit"] == "steps/sec" and d["value"] > 0
     assert abs(d["scenes_per_sec"] - d["value"] * 2 * 2) < 1e-6 * d["scenes_per_sec"]
     assert d["final_loss"] == d["final_loss"]                                   # finite (not NaN) after the all-reduced steps
+
+
+def test_bench_eight_ranks_launcher_smoke():
+    """the self-launcher, the rendezvous port, the per-rank host-core slices and the shutdown at EIGHT local ranks,
+    before the driver's first 8-GPU run (train.py:103-125 is the reference's launcher).  On a 1-GPU lease all eight ranks share cuda:0
+    over gloo — the numbers mean nothing, the rank path is the subject: eight per-rank step times, host-core slices that are
+    pairwise disjoint (where the topology is readable), one JSON line, exit code 0 (clean destroy_process_group)."""
+    d = _run(["--steps", "2", "--warmup", "1"], gpus=8)
+    want_backend = "nccl" if torch.cuda.device_count() >= 8 else "gloo"
+    assert d["n_gpus"] == 8 and d["collective_backend"] == want_backend
+    assert len(d["per_rank_ms_per_step"]) == 8 and all(t > 0 for t in d["per_rank_ms_per_step"])
+    assert len(d["per_rank_pinned_cpulist"]) == 8
+    assert d["rccl_version"]                                        # the RCCL the build links, whatever backend this box could use
+    from parq_amd.parallel import _parse_cpulist
+    sets = [set(_parse_cpulist(c)) for c in d["per_rank_pinned_cpulist"] if c]
+    assert len(sets) in (0, 8), d["per_rank_pinned_cpulist"]       # all ranks pinned, or none (no topology information)
+    for i in range(len(sets)):
+        for j in range(i + 1, len(sets)):
+            assert not (sets[i] & sets[j]), (i, j, d["per_rank_pinned_cpulist"])
+    iters = 8 * d["config"]["scenes_per_gpu"] * 8 * d["steps"]
+    assert abs(d["value"] - iters / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+    assert "dp8" in d["config"]["parallelism"]
