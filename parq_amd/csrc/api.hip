@@ -52,6 +52,9 @@ struct LayerW {
     // the position MLP's last layer folded into its two consumers (inference): (x + h W2^T + b2) W^T = x W^T + h (W W2)^T + W b2
     int64_t self_in_w2, self_in_b2;   // [3C][C]: rows < 2C = W_qk W2, rows >= 2C zero | [3C]: b_qk + W_qk b2, then b_v
     int64_t cross_q_w2, cross_q_b2;   // [C][C] = W_q W2 | [C] = b_q + W_q b2
+    // norm1 pushed through the cross-attention query projection (chain.hip seam_tile; inference):
+    //   q  = rstd1 (U - mean1 q_s) + V:   U = sa (Wq g1 Wo_s)^T + tgt (Wq g1)^T + qu_b,   V = pe_h cross_q_w2^T + qv_b
+    int64_t qg_w, qo_w, qu_b, q_s, qv_b;       // [C][C] Wq diag(g1) | [C][C] (Wq diag(g1)) Wo_self | [C] (Wq diag(g1)) bo_self | [C] row sums | [C] cross_q_b2 + Wq beta1
 };
 struct Arena {
     std::vector<LayerW> layers;
@@ -72,6 +75,7 @@ struct Workspace {
     int64_t T_cl, kv, ref, ref_next, emb, pe_h, pos, tgt, qkv, attn, xa, qc, xb, ffn, xc;
     int64_t h1, h2, gn_sums, ln1, ln2, flash;     // gn_sums: [2 layers][B][2 heads][2] fp64 moments; ln*: [M][2]
     int64_t kvc, flags;               // split-fp16 K/V cache, int flags (overflow)
+    int64_t seam_flags, lnp1;         // the norm1 seam inside one launch (chain.hip seam_tile): flags [M / 16][4], fp64 partial row sums of xa ([M][C/64][2])
     int64_t xsplit;                   // fp16 hi/lo copy of the tokens for the large-C K/V projection (kvproj_big.hip), else empty
     int64_t total;
     int self_split, cross_split;
@@ -123,6 +127,8 @@ struct parq_ctx {
         if (!m4 || safe_heads() == all_heads() || (train && safe_heads() != 0)) return terms();
         return 8;
     }
+    uint32_t seam_epoch = 0;          // one value per seam launch of this handle (chain.hip seam_tile flags); 0 is never used
+    uint32_t next_epoch() { if (++seam_epoch == 0) ++seam_epoch; return seam_epoch; }
     uint32_t safe_mask = 0;           // bit h: head h runs the fp16 x 3 kernel where the handle is in attention mode 4
     int peaky_poison = 0;             // mode-4 heads that meet a too-peaked row: write that iteration's outputs (and what follows) as NaN
     uint32_t all_heads() const { return H >= 32 ? 0xffffffffu : ((1u << H) - 1u); }
@@ -184,6 +190,7 @@ void build_arena(parq_ctx* c) {
         L.kv_whi = take(C * C); L.kv_wlo = take(C * C);
         L.self_in_w2 = take(3 * C * C); L.self_in_b2 = take(3 * C);
         L.cross_q_w2 = take(C * C); L.cross_q_b2 = take(C);
+        L.qg_w = take(C * C); L.qo_w = take(C * C); L.qu_b = take(C); L.q_s = take(C); L.qv_b = take(C);
     }
     a.rowmajor_total = off;
     // tile-ordered copies of the matrices the per-iteration chain multiplies by (LinearArgs::Wp): same offsets, shifted
@@ -242,6 +249,8 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
                                  : flash_pick_splits(B, c->H, c->Q, (int)N, c->dh, cus);
     ws->kvc = take(split_mode ? (int64_t)(c->nl * kvsplit_cache_bytes(B, c->vheads(), (int)N, c->terms()) / sizeof(float)) : 0);
     ws->flags = take(64);
+    ws->seam_flags = take((M / 16 + 1) * 4);         // directly behind `flags`: the forward prologue clears both in one go
+    ws->lnp1 = take(M * (C / 64) * 4);
     ws->xsplit = take(split_mode && kvproj_big_on() ? (int64_t)kvproj_big_scratch_floats(B, (int)N, C) : 0);
     const size_t fs = flash_scratch_bytes(B, c->H, c->Q, c->dh, ws->self_split);
     size_t fc = flash_scratch_bytes(B, c->H, c->Q, c->dh, ws->cross_split);
@@ -350,7 +359,7 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         Prof p(c, s, PARQ_PROF_OTHER);
         HIPCHK(launch_forward_prologue(sc->T_camera_pseudoCam, sc->T_world_pseudoCam, sc->T_world_local, B, V,
                                        reinterpret_cast<double*>(wsp + ws.T_cl), A + c->ar.refpoint, c->Q, wsp + ws.ref, A + c->ar.dim_t,
-                                       wsp + ws.emb, wsp + ws.flags, 64, s));
+                                       wsp + ws.emb, wsp + ws.flags, (int)(ws.lnp1 - ws.flags), s));     // the 64 flag words and the seam flags behind them
     }
     // hoisted K/V in-projection of the memory tokens: one GEMM per distinct layer,
     // written head-major [b][{K heads, V heads}][N][dh] so the attention kernel streams contiguous panels
@@ -405,6 +414,9 @@ int build_derived_weights(parq_ctx* c, hipStream_t s) {
         HIPCHK(launch_fold_pos_weights(A + L.self_in_w, A + L.self_in_b, A + ar.pe2_w, A + ar.pe2_b, (int)(2 * C), (int)C, A + L.self_in_w2, A + L.self_in_b2, s));
         HIPCHK(hipMemcpyAsync(A + L.self_in_b2 + 2 * C, A + L.self_in_b + 2 * C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, s));   // b_v unchanged
         HIPCHK(launch_fold_pos_weights(A + L.cross_in_w, A + L.cross_in_b, A + ar.pe2_w, A + ar.pe2_b, (int)C, (int)C, A + L.cross_q_w2, A + L.cross_q_b2, s));
+        // norm1 pushed through the cross-attention query projection (LayerW)
+        HIPCHK(launch_ln_fold(A + L.cross_in_w, A + L.cross_q_b2, A + L.n1_w, A + L.n1_b, (int)C, (int)C, A + L.qg_w, A + L.q_s, A + L.qv_b, s));
+        HIPCHK(launch_matmul_fold(A + L.qg_w, A + L.self_out_w, A + L.self_out_b, (int)C, (int)C, A + L.qo_w, A + L.qu_b, s));
     }
     // tile-ordered mirror of the chain's matrices (chain.hip: one contiguous KB per wave-wide fragment load)
     {
@@ -416,6 +428,7 @@ int build_derived_weights(parq_ctx* c, hipStream_t s) {
             HIPCHK(tile(L.cross_in_w, C, C));                                      // the query rows (K / V rows: kv_whi / kv_wlo)
             HIPCHK(tile(L.cross_out_w, C, C));
             HIPCHK(tile(L.self_in_w2, 3 * C, C)); HIPCHK(tile(L.cross_q_w2, C, C));
+            HIPCHK(tile(L.qg_w, C, C)); HIPCHK(tile(L.qo_w, C, C));
             if (F % 16 == 0) { HIPCHK(tile(L.lin1_w, F, C)); HIPCHK(tile(L.lin2_w, C, F)); }
         }
         HIPCHK(tile(ar.pe0_w, C, 384)); HIPCHK(tile(ar.pe2_w, C, C));
@@ -434,7 +447,8 @@ int build_derived_weights(parq_ctx* c, hipStream_t s) {
 //                `out` = [M*C normalised attention outputs | B*H*Lq_pad log2 log-sum-exp rows]
 //   phase bit 4: `in` = `nranks` such records -> merged attention output; cross out-proj, FFN, heads, decode
 // mask 7 with in = out = nullptr is the ordinary iteration.
-struct ShardIO { int mask = 7; const float* in = nullptr; float* out = nullptr; int nranks = 1; };
+struct ShardIO { int mask = 7; const float* in = nullptr; float* out = nullptr; int nranks = 1;
+                 bool keep = false; };     // stepping interface: also materialise intermediates that a fused launch would not (workspace "cross_q")
 
 int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& ws, int layer_num, const float* ref,
                bool emb_valid, const parq_outputs* o, float* ref_out, hipStream_t s, int64_t shift = 0,
@@ -476,6 +490,9 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     // inference only (the backward differentiates the unfolded layers from the stashed pos), and only where chain.hip has the kernels
     static const bool fold_off = [] { const char* e = dev_env("PARQ_FOLD_POS"); return e && e[0] == '0'; }();
     const bool fold_pos = !train && !fold_off && chain_linear_supported(self_in_args(true), 1) && chain_linear_supported(cross_q_args(true), 1);
+    // the norm1 seam (self out-projection | cross-attention query projection) as ONE launch (chain.hip seam_tile): inference at d = 256
+    static const int seams = [] { const char* e = dev_env("PARQ_FUSE_SEAMS"); return e ? atoi(e) : 1; }();      // 0: self out-projection and query projection as two launches (A/B)
+    const bool seam_ok = !train && !sharded && fold_pos && C == 256 && TP != nullptr && M % 16 == 0;
 
     if (sh.mask & 1) {
     // K3: sine embedding (written by the previous iteration's decode kernel when chained) -> position MLP
@@ -555,16 +572,40 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     fa.out = sharded ? sh.out : wi + ws.attn;
     fa.lse = sharded ? sh.out + (int64_t)M * C : (train ? wi + ws.lse_c : nullptr);
     fa.drop_p = dp; fa.drop_seed = c->site_seed(layer_num, 2);
+    bool fused_q = false;
     {
         // xa = tgt + self_attn @ Wo  (pre-LayerNorm; norm1 is applied by the consumers)
         Prof p(c, s, PARQ_PROF_LINEAR);
         LinearArgs a = lin(wi + ws.sa, C, A + L.self_out_w, C, A + L.self_out_b, wi + ws.xa, C, M, C, C);
         a.R = wi + ws.tgt; a.ldr = C; a.Wp = TP ? TP + L.self_out_w : nullptr;
         a.drop_p = dp; a.drop_seed = c->site_seed(layer_num, 1);
-        HIPCHK(launch_linear(a, 1, s));
-        // K7: cross-attention query = (norm1(xa) + pos) @ Wq; publishes norm1's row statistics
-        a = cross_q_args(fold_pos);
-        HIPCHK(launch_linear(a, 1, s));
+        if (seam_ok && (seams & 1)) {
+            // ... and, in the same launch, the query projection behind norm1 (chain.hip seam_tile): q tiles contract sa, tgt and pe_h with
+            // pack-time weight products and take norm1's statistics from the partial row sums the xa tiles publish
+            a.lnp_out = reinterpret_cast<double*>(wi + ws.lnp1);
+            a.lnp_flags = reinterpret_cast<unsigned*>(wsp + ws.seam_flags);
+            a.lnp_epoch = c->next_epoch();
+            SeamArgs q;
+            memset(&q, 0, sizeof(q));
+            q.X1 = wi + ws.sa; q.ldx1 = C; q.W1p = TP + L.qo_w;
+            q.X2 = wi + ws.tgt; q.ldx2 = C; q.W2p = TP + L.qg_w;
+            q.X3 = wi + ws.pe_h; q.ldx3 = C; q.W3p = TP + L.cross_q_w2;
+            q.b1 = A + L.qu_b; q.srow = A + L.q_s; q.b2 = A + L.qv_b;
+            q.Y = wi + ws.qc; q.ldy = C; q.M = M; q.N = C;
+            q.part = a.lnp_out; q.flags = a.lnp_flags; q.epoch = a.lnp_epoch; q.nparts = C / 64; q.width = C; q.eps = eps;
+            q.ln_out = wi + ws.ln1;               // norm1's statistics for the residual of the cross out-projection
+            q.err = reinterpret_cast<int*>(wsp + ws.flags);
+            const hipError_t e = launch_seam_q(a, q, s);
+            if (e == hipSuccess) fused_q = true;
+            else if (e != hipErrorNotSupported) return fail(PARQ_ERR_HIP, "launch_seam_q failed: %s", hipGetErrorString(e));
+            a.lnp_out = nullptr; a.lnp_flags = nullptr;
+        }
+        if (!fused_q) {
+            HIPCHK(launch_linear(a, 1, s));
+            // K7: cross-attention query = (norm1(xa) + pos) @ Wq; publishes norm1's row statistics
+            a = cross_q_args(fold_pos);
+            HIPCHK(launch_linear(a, 1, s));
+        }
     }
     bool merged = false;              // the cross-attention launches below already merged their partials (per-head tiers)
     {
@@ -1197,7 +1238,9 @@ int parq_iterate(parq_handle h, const parq_scene* scene, void* workspace, size_t
     float* wsp = (float*)workspace;
     hipStream_t s = (hipStream_t)stream;
     const float* ref = ref_in ? ref_in : wsp + ws.ref;
-    rc = do_iterate(h, scene, wsp, ws, layer_num, ref, ref_in == nullptr && h->emb_valid, outs, wsp + ws.ref_next, s);
+    ShardIO step_io;
+    step_io.keep = true;
+    rc = do_iterate(h, scene, wsp, ws, layer_num, ref, ref_in == nullptr && h->emb_valid, outs, wsp + ws.ref_next, s, 0, nullptr, false, step_io);
     h->emb_valid = (rc == PARQ_OK);        // the decode kernel left pos2posemb3d(ref_next) in the workspace
     if (rc) return rc;
     const size_t rb = (size_t)scene->B * h->Q * 3 * sizeof(float);

@@ -27,7 +27,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 enum : int { kProNone = 0, kProLN = 1, kProGN = 2 };
 enum : int { kResNone = 0, kResPlain = 1, kResLN = 2 };
 
-template <int K, int NT, int PRO, int ADD2, bool BIAS, bool RELU, int RES, bool GNOUT, int NWV = 4>
+template <int K, int NT, int PRO, int ADD2, bool BIAS, bool RELU, int RES, bool GNOUT, int NWV = 4, bool LNP = false>
 __device__ __forceinline__ void chain_tile(const LinearArgs& a, const int block_x, const int block_y) {
     static_assert(K % (16 * NWV) == 0 && NT >= 1 && NT <= 4 && (NWV == 4 || NWV == 8), "tile shape");
     constexpr int NCH = K / (16 * NWV);               // 16-wide K chunks per wave
@@ -89,6 +89,7 @@ __device__ __forceinline__ void chain_tile(const LinearArgs& a, const int block_
     f32x4v pg[PRO != kProNone ? NCH : 1], pb[PRO != kProNone ? NCH : 1];
     float shift = 0.f;
     double gsm = 0.0, gsq = 0.0;
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
     if constexpr (PRO == kProLN) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -221,9 +222,41 @@ __device__ __forceinline__ void chain_tile(const LinearArgs& a, const int block_
         if constexpr (RES == kResPlain) v += e_r[e];
         if constexpr (RES == kResLN) v += (e_r[e] - rmean) * rrstd * e_rg[e] + e_rb[e];
         y[e] = v;
-        if constexpr (GNOUT) { gs += (double)v; gq += (double)v * (double)v; }
+        if constexpr (GNOUT || LNP) { gs += (double)v; gq += (double)v * (double)v; }
     }
     *reinterpret_cast<f32x4v*>(a.Y + g * a.gY + (int64_t)om * a.y_row + on) = y;
+    if constexpr (LNP) {
+        // partial sums of this workgroup's 16 NT columns for every row, for the LayerNorm a later launch finishes: the 4 lanes of a
+        // row by shuffles, the NT sub-tile waves through LDS (NT == NWV: every wave is still here) -> ONE fp64 pair per (row, tile)
+        static_assert(NT == NWV, "the partial sums of a tile are combined by all waves");
+        __shared__ f64x2 lnpart[NWV * 16];
+        double ps = gs, pq = gq;
+        ps += __shfl_xor(ps, 1); pq += __shfl_xor(pq, 1);
+        ps += __shfl_xor(ps, 2); pq += __shfl_xor(pq, 2);
+        if ((lane & 3) == 0) lnpart[wave * 16 + erow] = f64x2{ps, pq};
+        lds_barrier();
+        if (wave == 0) {
+            const int ntile = a.N / (16 * NT), tile = n0 / (16 * NT);
+            if (lane < 16) {
+                f64x2 t = lnpart[lane];
+#pragma unroll
+                for (int w = 1; w < NWV; ++w) t += lnpart[w * 16 + lane];
+                if (a.lnp_flags) {
+                    // consumers are workgroups of THIS launch: write-through (sc1) payload, drained, then the flag (relaxed, agent scope)
+                    typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+                    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.lnp_out, 0, 0x7fffffff, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, t), rs, (int)((((int64_t)(m0 + lane)) * ntile + tile) * 16), 0, 16);
+                } else {
+                    reinterpret_cast<f64x2*>(a.lnp_out)[(int64_t)(m0 + lane) * ntile + tile] = t;
+                }
+            }
+            if (a.lnp_flags) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0)
+                    __hip_atomic_store(a.lnp_flags + (m0 >> 4) * ntile + tile, a.lnp_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
     if constexpr (GNOUT) {
         const int nt0 = n0 + wave * 16;                     // first column of this sub-tile
         if (nt0 < a.gn_out_ncols) {
@@ -277,6 +310,215 @@ __global__ __launch_bounds__(1024) void pe1_sample_kernel(LinearArgs a, SampleAr
     }
 }
 
+// ONE launch for two stages that a LayerNorm separates (api.hip do_iterate).  A LayerNorm is affine in its input once the row statistics
+// are known, so the linear map BEHIND it can be pushed in front of the statistics (SeamArgs, common.hpp): the consumer tiles contract
+// operands that exist before the launch, with pack-time products of the weights (float64-accumulated, rounded once:
+// build_derived_weights), and only their EPILOGUE needs (mean, rstd) — from the fp64 partial row sums that the tiles of x, workgroups
+// of the same launch with smaller block indices, publish write-through + flag (chain_tile LNP; cdna_hip_programming.md Guideline 16,
+// form R1: sc1 payload, drained, relaxed agent-scope flag; sc1 loads on the consumer).  The wait sits behind the consumer's own
+// contraction, so it is normally over before it starts; it is bounded (a flag that never arrives raises SeamArgs::err and the
+// outputs are NaN).  Producers never wait and have the smaller block indices: whatever the dispatch order, every workgroup a
+// consumer waits for is resident or finished (the grid fits the chip twice over).
+//   seam Q:  xa = tgt + sa Wo^T + bo (transformer_parq.py:375)  |  q = norm1(xa) Wq^T + pe_h (Wq W2)^T + b'  (:377)
+// Where it pays: a hand-off through memory costs ~4 us on a busy chip (MI355X_MICROARCH.md "handoff-flag"), about what the launch
+// boundary it replaces costs, so the consumer must have at least (producer tile + hand-off) of work of its own.  Seam Q does (three
+// operand pairs, 7 us, against a 4.5 us xa tile): the stage takes 8.5 us where the two launches took 14.1.  The same construction
+// at norm2 / FFN layer 1 was built and measured: f tiles 11 us median (6 us of own work + waiting), stage 14.0 against 14.6 us for the
+// two launches — no gain, not kept (profiles/r05_iter_timeline_stamps_seams_q_and_f.txt).
+__device__ __forceinline__ bool seam_wait(const unsigned* flag, unsigned epoch) {
+    for (int spin = 0; spin < (1 << 21); ++spin) {                 // ~0.1 s: never reached unless a producer died
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+
+template <int K1, bool LN1, int K2, int K3, int NT, bool RELU, bool GNOUT>
+__device__ __forceinline__ void seam_tile(const SeamArgs& a, const int block_x) {
+    constexpr int NWV = 4, CS = 64;
+    constexpr int NC1 = K1 / CS, NC2 = K2 / CS, NC3 = K3 > 0 ? K3 / CS : 1;
+    constexpr bool HAS3 = K3 > 0;
+    static_assert(K1 % CS == 0 && K2 % CS == 0 && K3 % CS == 0 && NT >= 1 && NT <= 4, "tile shape");
+    static_assert(!LN1 || K1 > 0, "LayerNorm(X1) with given statistics");
+    __shared__ __attribute__((aligned(16))) float red[(HAS3 ? 2 : 1) * NWV * NT * 4 * 64];   // [acc set][wave][sub-tile][acc reg][lane]
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+    const int ntn = a.N / (16 * NT);
+    const int n0 = (block_x % ntn) * 16 * NT, m0 = (block_x / ntn) * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    const int kbase = wave * 16 + kq * 4;
+    auto wptr = [&](const float* Wp, int K) { return Wp + ((int64_t)(n0 / 16) * (K / 16) + wave) * 256 + lane * 4; };
+
+    // ---------------- every global load that does not depend on the producers, before anything waits
+    f32x4v a1[NC1], a2[NC2], a3[NC3], w1[NT][NC1], w2[NT][NC2], w3[HAS3 ? NT : 1][NC3];
+    {
+        const float* x1 = a.X1 + (int64_t)(m0 + li) * a.ldx1 + kbase;
+        const float* x2 = a.X2 + (int64_t)(m0 + li) * a.ldx2 + kbase;
+#pragma unroll
+        for (int c = 0; c < NC1; ++c) a1[c] = *reinterpret_cast<const f32x4v*>(x1 + c * CS);
+#pragma unroll
+        for (int c = 0; c < NC2; ++c) a2[c] = *reinterpret_cast<const f32x4v*>(x2 + c * CS);
+        const float* p1 = wptr(a.W1p, K1);
+        const float* p2 = wptr(a.W2p, K2);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int c = 0; c < NC1; ++c) w1[t][c] = *reinterpret_cast<const f32x4v*>(p1 + (int64_t)t * (K1 / 16) * 256 + c * NWV * 256);
+#pragma unroll
+            for (int c = 0; c < NC2; ++c) w2[t][c] = *reinterpret_cast<const f32x4v*>(p2 + (int64_t)t * (K2 / 16) * 256 + c * NWV * 256);
+        }
+        if constexpr (HAS3) {
+            const float* x3 = a.X3 + (int64_t)(m0 + li) * a.ldx3 + kbase;
+            const float* p3 = wptr(a.W3p, K3);
+#pragma unroll
+            for (int c = 0; c < NC3; ++c) a3[c] = *reinterpret_cast<const f32x4v*>(x3 + c * CS);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int c = 0; c < NC3; ++c) w3[t][c] = *reinterpret_cast<const f32x4v*>(p3 + (int64_t)t * (K3 / 16) * 256 + c * NWV * 256);
+        }
+    }
+    f32x4v pg[LN1 ? NC1 : 1], pb[LN1 ? NC1 : 1];
+    float st_mean = 0.f, st_rstd = 1.f;
+    if constexpr (LN1) {
+#pragma unroll
+        for (int c = 0; c < NC1; ++c) {
+            pg[c] = *reinterpret_cast<const f32x4v*>(a.ln1_g + kbase + c * CS);
+            pb[c] = *reinterpret_cast<const f32x4v*>(a.ln1_b + kbase + c * CS);
+        }
+        st_mean = a.ln1_stats[(int64_t)(m0 + li) * 2 + 0];
+        st_rstd = a.ln1_stats[(int64_t)(m0 + li) * 2 + 1];
+    }
+    const int et = wave % NT;
+    const int erow = lane >> 2, ec = (lane & 3) * 4;
+    const int om = m0 + erow, on = n0 + et * 16 + ec;
+    const f32x4v e_b1 = *reinterpret_cast<const f32x4v*>(a.b1 + on), e_s = *reinterpret_cast<const f32x4v*>(a.srow + on);
+    f32x4v e_b2 = {0.f, 0.f, 0.f, 0.f};
+    if (a.b2) e_b2 = *reinterpret_cast<const f32x4v*>(a.b2 + on);
+    __builtin_amdgcn_sched_barrier(0);
+
+    if constexpr (LN1) {
+#pragma unroll
+        for (int c = 0; c < NC1; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a1[c][e] = (a1[c][e] - st_mean) * st_rstd * pg[c][e] + pb[c][e];
+    }
+    // ---------------- MFMA chains, split-K partials to LDS
+    f32x4v acc1[NT], acc2[HAS3 ? NT : 1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc1[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC1; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c][e], w1[t][c][e], acc1[t], 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < NC2; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[c][e], w2[t][c][e], acc1[t], 0, 0, 0);
+    if constexpr (HAS3) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc2[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC3; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[c][e], w3[t][c][e], acc2[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            red[((wave * NT + t) * 4 + r) * 64 + lane] = acc1[t][r];
+            if constexpr (HAS3) red[NWV * NT * 256 + ((wave * NT + t) * 4 + r) * 64 + lane] = acc2[t][r];
+        }
+    lds_barrier();
+    if (wave >= NT) return;
+
+    // ---------------- epilogue of sub-tile `wave`: lane -> (row = lane >> 2, 4 consecutive columns)
+    const int src = (wave * 4 + (erow & 3)) * 64 + (erow >> 2) * 16 + ec;
+    f32x4v u = *reinterpret_cast<const f32x4v*>(&red[src]);
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) u += *reinterpret_cast<const f32x4v*>(&red[src + w * NT * 256]);
+    f32x4v v = e_b2;
+    if constexpr (HAS3) {
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) v += *reinterpret_cast<const f32x4v*>(&red[NWV * NT * 256 + src + w * NT * 256]);
+    }
+    // the row's statistics: lane (lane & 3) = j waits for tile j of this row block and reads its partial (sc1: past this CU's and
+    // this XCD's caches), the four lanes of a row add up
+    double S = 0.0, Q = 0.0;
+    bool ok = true;
+    {
+        const int j = lane & 3;
+        if (j < a.nparts) {
+            ok = seam_wait(a.flags + (m0 >> 4) * a.nparts + j, a.epoch);
+            typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.part, 0, 0x7fffffff, 0x00020000);
+            const f64x2 pr = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((int64_t)om * a.nparts + j) * 16), 0, 16));
+            S = pr[0];
+            Q = pr[1];
+        }
+    }
+    S += __shfl_xor(S, 1); Q += __shfl_xor(Q, 1);
+    S += __shfl_xor(S, 2); Q += __shfl_xor(Q, 2);
+    if (!__all(ok)) {
+        if (lane == 0 && a.err) atomicOr(a.err, 4);
+        S = Q = __builtin_nan("");
+    }
+    const double inv = 1.0 / (double)a.width;
+    const double mu = S * inv;
+    double var = Q * inv - mu * mu;
+    var = var > 0.0 ? var : 0.0;
+    const float mean = (float)mu, vv = (float)var + a.eps;
+    float rstd = __builtin_amdgcn_rsqf(vv);
+    rstd = rstd * (1.5f - 0.5f * vv * rstd * rstd);
+    if (S != S) rstd = __builtin_nanf("");
+    if (a.ln_out && n0 == 0 && wave == 0 && (lane & 3) == 0) {
+        a.ln_out[(int64_t)om * 2 + 0] = mean;
+        a.ln_out[(int64_t)om * 2 + 1] = rstd;
+    }
+    f32x4v y;
+    double gs = 0.0, gq = 0.0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float t = rstd * (u[e] + e_b1[e] - mean * e_s[e]) + v[e];
+        if constexpr (RELU) t = t > 0.f ? t : 0.f;
+        y[e] = t;
+        if constexpr (GNOUT) { gs += (double)t; gq += (double)t * (double)t; }
+    }
+    *reinterpret_cast<f32x4v*>(a.Y + (int64_t)om * a.ldy + on) = y;
+    if constexpr (GNOUT) {
+        const int nt0 = n0 + wave * 16;
+        if (nt0 < a.gn_out_ncols) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { gs += __shfl_xor(gs, o); gq += __shfl_xor(gq, o); }
+            if (lane == 0) {
+                const int grp = nt0 / a.gn_out_group_cols;
+                const int cbs = a.gn_out_group_cols >> 4;
+                const int rb = (m0 % a.gn_out_rows_per_scene) >> 4, cb = (nt0 % a.gn_out_group_cols) >> 4;
+                const bool own = (a.gn_out_rows_per_scene >> 4) * cbs <= kGnSlots;
+                const int slot = own ? rb * cbs + cb : (int)((block_x * NT + wave) % kGnSlots);
+                double* dst = a.gn_out_sums + (((int64_t)(m0 / a.gn_out_rows_per_scene) * a.gn_out_ngroups + grp) * kGnSlots + slot) * 2;
+                if (own) *reinterpret_cast<f64x2*>(dst) = f64x2{gs, gq};
+                else { atomicAdd(dst, gs); atomicAdd(dst + 1, gq); }
+            }
+        }
+    }
+}
+
+// seam Q: workgroups [0, nA) are the tiles of xa (K = 256, plain residual, partials published), the rest the tiles of q
+template <int NTB>
+__global__ __launch_bounds__(256) void seam_q_kernel(LinearArgs aA, SeamArgs sb, int nA) {
+    PARQ_TL_KERNEL(kTlLinear);
+    const int bx = (int)blockIdx.x;
+    if (bx < nA) chain_tile<256, 4, kProNone, 0, true, false, kResPlain, false, 4, true>(aA, bx, 0);
+    else seam_tile<256, false, 256, 256, NTB, false, false>(sb, bx - nA);
+}
 // The same tile for LONG contractions (K = 1024: the reference's shipped decoder width, config/train.yaml:37-56): the A rows of
 // the tile stay in registers for the whole contraction (K / 64 float4 per lane), the W rows are streamed in batches of 256
 // contraction steps, double-buffered: batch b + 1 (with its prologue parameters) is requested before the MFMAs of batch b are
@@ -501,6 +743,38 @@ __global__ void fold_pos_weights_kernel(const float* __restrict__ Wa, const floa
     }
 }
 
+// pack time, LayerNorm pushed through a linear map (see outproj_qproj_kernel): thread = one row r of W [R][C]
+//   Wg[r][k] = W[r][k] gamma[k],   s[r] = sum_k Wg[r][k],   bb[r] = b[r] + sum_k W[r][k] beta[k]        (float64 sums)
+__global__ void ln_fold_kernel(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, int R, int C, float* __restrict__ Wg, float* __restrict__ srow, float* __restrict__ bb) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    double ss = 0.0, sb = (double)b[r];
+    for (int k = 0; k < C; ++k) {
+        const float wg = W[(int64_t)r * C + k] * gamma[k];
+        Wg[(int64_t)r * C + k] = wg;
+        ss += (double)wg;
+        sb += (double)W[(int64_t)r * C + k] * (double)beta[k];
+    }
+    srow[r] = (float)ss;
+    bb[r] = (float)sb;
+}
+// out[r][j] = sum_k A[r][k] Bm[k][j],  ob[r] = sum_k A[r][k] bv[k]   (A [R][C], Bm [C][C]; float64 accumulation): thread = one element
+__global__ void matmul_fold_kernel(const float* __restrict__ A, const float* __restrict__ Bm, const float* __restrict__ bv, int R, int C,
+                                   float* __restrict__ out, float* __restrict__ ob) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)R * C) return;
+    const int r = (int)(i / C), j = (int)(i - (int64_t)r * C);
+    double acc = 0.0;
+    for (int k = 0; k < C; ++k) acc += (double)A[(int64_t)r * C + k] * (double)Bm[(int64_t)k * C + j];
+    out[i] = (float)acc;
+    if (j == 0) {
+        double b = 0.0;
+        for (int k = 0; k < C; ++k) b += (double)A[(int64_t)r * C + k] * (double)bv[k];
+        ob[r] = (float)b;
+    }
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // feature signature of a launch (what the template parameters must match)
@@ -703,6 +977,36 @@ hipError_t launch_pe1_sample(const LinearArgs& a_in, const float* tokens, const 
         case 3: hipLaunchKernelGGL((pe1_sample_kernel<3>), grid, block, smem, s, a, sa, n_lin); break;
         default: hipLaunchKernelGGL((pe1_sample_kernel<4>), grid, block, smem, s, a, sa, n_lin); break;
     }
+    return hipGetLastError();
+}
+
+static bool fused_tile_ok(const LinearArgs& a) {
+    return a.M % 16 == 0 && a.N == 256 && a.K == 256 && (a.ldx | a.ldw | a.y_row) % 4 == 0 && al16(a.X) && al16(a.W) && al16(a.Y) &&
+           a.bias && al16(a.bias) && a.rows_per_batch == a.M && a.col_blk == a.N && !a.relu && !a.relu_mask && a.drop_p == 0.f && !a.X2 &&
+           a.R && a.ldr % 4 == 0 && al16(a.R) && a.Wp && al16(a.Wp) && a.ldw == a.K && a.lnp_out && a.lnp_flags;
+}
+static bool seam_ok(const SeamArgs& b, int M, int nt) {
+    return b.M == M && b.N % (16 * nt) == 0 && b.nparts == 4 && b.width == 256 && al16(b.X1) && al16(b.X2) && al16(b.W1p) && al16(b.W2p) &&
+           (b.ldx1 | b.ldx2 | b.ldy) % 4 == 0 && al16(b.b1) && al16(b.srow) && (!b.b2 || al16(b.b2)) && al16(b.Y) && b.part && b.flags;
+}
+
+// xa tiles (+ published partial row sums) | q tiles: see seam_tile
+hipError_t launch_seam_q(const LinearArgs& xa, const SeamArgs& q, hipStream_t s) {
+    if (!fused_tile_ok(xa) || xa.rln_stats || !seam_ok(q, xa.M, 2) || !q.X3 || !al16(q.X3) || !al16(q.W3p) || q.ldx3 % 4 != 0) return hipErrorNotSupported;
+    LinearArgs a = xa;
+    a.tile_map = 0;
+    const int nA = (a.N / 64) * (a.M / 16), nB = (q.N / 32) * (q.M / 16);
+    hipLaunchKernelGGL((seam_q_kernel<2>), dim3((unsigned)(nA + nB)), dim3(256), 0, s, a, q, nA);
+    return hipGetLastError();
+}
+
+hipError_t launch_ln_fold(const float* W, const float* b, const float* gamma, const float* beta, int R, int C, float* Wg, float* srow, float* bb, hipStream_t s) {
+    hipLaunchKernelGGL(ln_fold_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, s, W, b, gamma, beta, R, C, Wg, srow, bb);
+    return hipGetLastError();
+}
+hipError_t launch_matmul_fold(const float* A, const float* Bm, const float* bv, int R, int C, float* out, float* ob, hipStream_t s) {
+    const int64_t n = (int64_t)R * C;
+    hipLaunchKernelGGL(matmul_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A, Bm, bv, R, C, out, ob);
     return hipGetLastError();
 }
 

@@ -316,12 +316,44 @@ struct LinearArgs {
     // k % 16) at float ((k % 16) / 4 * 16 + n % 16) * 4 + k % 4, i.e. one wave-wide float4 load = one contiguous KB.  nullptr: read W.
     const float* Wp;
     int tile_map;                       // chain.hip only: 1 = the workgroups of a row block run on one XCD (set by launch_chain_linear)
+    // chain.hip only — LayerNorm seams inside one launch (seam_tile): a launch that produces rows x which a LayerNorm normalises
+    // publishes, per (row, workgroup tile of 64 columns), the fp64 partial sums (sum x, sum x^2): lnp_out[row][N / 64][2]
+    double* lnp_out;
+    // IN-LAUNCH publication of lnp_out (chain.hip seam kernels): the partials are stored write-through (sc1) and flag
+    // lnp_flags[row block][tile] = lnp_epoch follows once they are acknowledged; consumers are workgroups of the SAME launch with
+    // larger block indices (seam_tile)
+    unsigned* lnp_flags; unsigned lnp_epoch;
+};
+// A consumer tile of a LayerNorm seam inside ONE launch (chain.hip seam_tile).  The LayerNorm is pushed through the linear map behind it,
+//   LN(x) W^T + b = rstd (x Wg^T - mean s) + b',   Wg = W diag(gamma), s = row sums of Wg, b' = b + W beta,
+// and x Wg^T is computed from the operands x itself is made of (x = r + y Wo^T + bo  ->  x Wg^T = r Wg^T + y (Wg Wo)^T + Wg bo), so
+// the tile's contraction does not wait for x; only its epilogue needs (mean, rstd), which it takes from the fp64 partial row sums the
+// x tiles of the same launch publish.  out = act(rstd (acc1 + b1 - mean s) + acc2 + b2):
+//   acc1 = X1' W1^T + X2 W2^T   (X1' = X1, or LayerNorm(X1) with GIVEN statistics ln1_stats and gamma / beta ln1_g / ln1_b)
+//   acc2 = X3 W3^T              (optional: a part the LayerNorm does not scale)
+struct SeamArgs {
+    const float* X1; int64_t ldx1; const float* W1p;          // tile-ordered weights (launch_pack_w_tiles), [N][K1]
+    const float* X2; int64_t ldx2; const float* W2p;          // [N][K2]
+    const float* X3; int64_t ldx3; const float* W3p;          // [N][K3] or nullptr
+    const float* ln1_stats; const float* ln1_g; const float* ln1_b;
+    const float* b1; const float* srow; const float* b2;      // [N] each (b2 may be nullptr)
+    float* Y; int64_t ldy; int M, N;
+    const double* part; const unsigned* flags; unsigned epoch; int nparts; int width;   // the producer's partials / flags (nparts <= 4 per row)
+    float eps;
+    float* ln_out;                                             // optional [M][2]: (mean, rstd) of x published for later launches
+    double* gn_out_sums; int gn_out_ncols; int gn_out_group_cols; int gn_out_rows_per_scene; int gn_out_ngroups;   // as LinearArgs
+    int* err;                                                  // raised (bit 2) if a flag never arrives: outputs are then NaN
 };
 hipError_t launch_linear(const LinearArgs& a, int groups, hipStream_t s);
 // chain.hip: compile-time specialised kernels for the launches of one decoder iteration; hipErrorNotSupported = no instantiation
 // matches this launch (launch_linear then uses the generic kernel)
 hipError_t launch_chain_linear(const LinearArgs& a, int groups, hipStream_t s);
 bool chain_linear_supported(const LinearArgs& a, int groups);      // would launch_chain_linear take this launch?
+// chain.hip: two stages that a LayerNorm separates as ONE launch (SeamArgs below; seam_tile); hipErrorNotSupported = shapes do not fit
+hipError_t launch_seam_q(const LinearArgs& xa, const SeamArgs& q, hipStream_t s);
+// pack time: Wg = W diag(gamma), srow = row sums of Wg, bb = b + W beta | out = A Bm, ob = A bv  (float64 accumulation)
+hipError_t launch_ln_fold(const float* W, const float* b, const float* gamma, const float* beta, int R, int C, float* Wg, float* srow, float* bb, hipStream_t s);
+hipError_t launch_matmul_fold(const float* A, const float* Bm, const float* bv, int R, int C, float* out, float* ob, hipStream_t s);
 hipError_t launch_pack_w_tiles(const float* W, int64_t ldw, int N, int K, float* dst, hipStream_t s);   // N % 16 == K % 16 == 0
 // pack time: out_w[r][k] = sum_j Wa[r][j] W2[j][k], out_b[r] = ba[r] + sum_j Wa[r][j] b2[j]  (float64 accumulation), r < R; Wa [R][C], W2 [C][C]
 hipError_t launch_fold_pos_weights(const float* Wa, const float* ba, const float* W2, const float* b2, int R, int C, float* out_w, float* out_b, hipStream_t s);
