@@ -442,7 +442,7 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) {
-                if constexpr ((PROBE & (2 | 8 | 16)) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // counts do not hold
+                if constexpr ((PROBE & (2 | 8 | 16 | 32 | 64 | 128)) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // counts do not hold
                 else if (ks < D - 2 && !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 3) * NDMA + (ISK ? NST_K : NST_V)) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 3) * NDMA) : "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's conversion writes of k-step q
@@ -521,7 +521,12 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
                         i32x4 hi8, lo8;
                         pieces_e4m3(x16, hi8, lo8);
                         const int piece = ((t * 2 + kh) * 2 + ct) * 32 + li;        // piece (c = kh, h = ct) of key li
-                        if constexpr (!(PROBE & 2)) {
+                        if constexpr (PROBE & 32) {                                  // development: where does the read-back come from?
+                            if (hi8[0] == 0x12345678 && lo8[1] == 0x1234567) stage[tid] = 1;
+                        } else if constexpr (PROBE & 256) {                          // non-temporal: the written cache is not read again by this kernel
+                            __builtin_nontemporal_store(hi8, reinterpret_cast<i32x4*>(stage + kS8K8hi + piece * 16));
+                            __builtin_nontemporal_store(lo8, reinterpret_cast<i32x4*>(stage + kS8K8lo + piece * 16));
+                        } else if constexpr (!(PROBE & 2)) {
                             *reinterpret_cast<i32x4*>(stage + kS8K8hi + piece * 16) = hi8;
                             *reinterpret_cast<i32x4*>(stage + kS8K8lo + piece * 16) = lo8;
                         }
@@ -551,13 +556,17 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
                     for (int j = 0; j < 2; ++j) {
                         const int row = (lane >> 2) + 16 * j, pc = lane & 3;
                         const half8 v = *reinterpret_cast<const half8*>(strip + row * 32 + pc * 8);
-                        if constexpr (PROBE & 2) {
+                        if constexpr ((PROBE & 2) || ((PROBE & 64) && ISK) || ((PROBE & 128) && !ISK)) {
                             if (v[0] == (_Float16)123.f) out[tid] = v[1];
                         } else if constexpr (ISK) {
                             const int half_row = ct ^ ((row >> 3) & 1);           // bit 2 of the row's swizzle (key >> 1) & 7
-                            *reinterpret_cast<half8*>(out + pl * 2048 + row * 64 + ((4 * half_row + pc) << 3)) = v;
+                            half8* dst = reinterpret_cast<half8*>(out + pl * 2048 + row * 64 + ((4 * half_row + pc) << 3));
+                            if constexpr (PROBE & 256) __builtin_nontemporal_store(v, dst);
+                            else *dst = v;
                         } else {
-                            *reinterpret_cast<half8*>(out + kVoff + pl * 2048 + (32 * ct + row) * 32 + pc * 8) = v;
+                            half8* dst = reinterpret_cast<half8*>(out + kVoff + pl * 2048 + (32 * ct + row) * 32 + pc * 8);
+                            if constexpr (PROBE & 256) __builtin_nontemporal_store(v, dst);
+                            else *dst = v;
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -660,6 +669,19 @@ hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void*
     const int nct = 2 * C / kBN, nrt = ceil_div(N, kBM);
     if (C <= 4 * kBK && C % (2 * kBK) == 0) {
         // W-stationary persistent kernel: one workgroup per CU, the column slices of one slot on one XCD
+#ifdef PARQ_DEV_PROBES
+        if (terms == 8 && N % 64 == 0 && C == 256) {          // development: the mode-4 epilogue with one kind of store removed (results wrong)
+            static const int probe8 = [] { const char* e = dev_env("PARQ_KVPROJ_PROBE8"); return e ? atoi(e) : 0; }();
+            switch (probe8) {
+                case 32: return launch_dma_nk<64, 8, kF16, 4, 4, 32>(a, B, s);
+                case 64: return launch_dma_nk<64, 8, kF16, 4, 4, 64>(a, B, s);
+                case 128: return launch_dma_nk<64, 8, kF16, 4, 4, 128>(a, B, s);
+                case 224: return launch_dma_nk<64, 8, kF16, 4, 4, 224>(a, B, s);
+                case 256: return launch_dma_nk<64, 8, kF16, 4, 4, 256>(a, B, s);
+                default: break;
+            }
+        }
+#endif
         if (terms == 8) return (N % 64 == 0 && C == 256) ? launch_dma_nk<64, 8, kF16, 4, 4>(a, B, s) : hipErrorInvalidValue;
         if (terms == 11) return (N % 64 == 0 && C == 256) ? launch_dma_nk<64, 11, kF16, 4, 4>(a, B, s) : hipErrorInvalidValue;
         if (terms != 3) return kind == kF16 ? launch_dma<1, kF16, 4>(a, B, s) : launch_dma<1, kBF16, 4>(a, B, s);
