@@ -3,7 +3,7 @@
 #   tools/collect_profiles.sh r02
 # bench lines (B=1 with the CPU baseline and the 32-scene project+sample figure, B=8, fp16 mode, training step), rocprofv3 kernel
 # stats of the default bench command, PMC passes (HBM bytes at 1 and 32 scenes; MFMA / LDS counters), then tools/make_pmc_json.py.
-tag=${1:-r04}
+tag=${1:-r05}
 cd /root/repo
 out=/root/repo/gpurun_out/$tag
 rm -rf $out; mkdir -p $out
