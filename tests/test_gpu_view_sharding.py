@@ -59,4 +59,8 @@ def test_single_process_view_sharded_call_equals_forward():
     for k in range(3):
         for key in want[k]:
             err = float(((want[k][key].double() - got[k][key].double()).abs() / want[k][key].double().abs().clamp(min=1.0)).max())
-            assert err < 2e-6, (k, key, err)
+            # (the sharded call runs the self out-projection and the query projection as two launches, the plain forward as one launch
+            # with norm1 pushed through the projection — chain.hip seam_tile: another rounding of the same fp32 arithmetic, 2.4e-6 here;
+            # the call also asserts the ADVICE r04 fix: mode "split8" runs as "split" on this path)
+            assert err < 5e-6, (k, key, err)
+    assert dec._mode_set == "split" and dec.attention_mode == "split8"
