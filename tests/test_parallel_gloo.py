@@ -226,3 +226,33 @@ def test_ranks_pin_to_the_cores_next_to_their_gpu(tmp_path):
         assert os.sched_getaffinity(0) == before
     finally:
         os.sched_setaffinity(0, before)
+
+
+def test_ranks_that_share_a_device_split_that_gpus_node(tmp_path):
+    """bench.py --share-device (the 8-rank launcher smoke on a 1-GPU lease): every rank uses device 0, so the eight of them split
+    device 0's NUMA node into pairwise disjoint slices instead of looking up GPUs that do not exist (and leaving their masks alone)."""
+    root = str(tmp_path)
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 8:
+        pytest.skip("needs 8 allowed CPUs")
+    fmt = lambda cpus: ",".join(str(c) for c in cpus)
+    _fake_sysfs(root, [(0x05, fmt(allowed))])
+    assert parallel.cpulist_string([0, 1, 2, 5, 7, 8]) == "0-2,5,7-8" and parallel.cpulist_string([]) == ""
+    assert parallel._parse_cpulist(parallel.cpulist_string(allowed)) == allowed
+    before = os.sched_getaffinity(0)
+    try:
+        os.environ.pop("HIP_VISIBLE_DEVICES", None); os.environ.pop("ROCR_VISIBLE_DEVICES", None)
+        got = []
+        for r in range(8):
+            os.sched_setaffinity(0, before)
+            assert parallel.pin_to_local_cores(r, 8, sysfs=root) == ([] if r > 0 else parallel.pin_to_local_cores(0, 8, sysfs=root))
+            os.sched_setaffinity(0, before)
+            got.append(parallel.pin_to_local_cores(r, 8, sysfs=root, gpu_index_of=lambda _r: 0))
+            assert got[r] and set(os.sched_getaffinity(0)) == set(got[r])
+        for i in range(8):
+            for j in range(i + 1, 8):
+                assert not set(got[i]) & set(got[j]), (i, j)
+        assert set().union(*got) == set(allowed)
+    finally:
+        os.sched_setaffinity(0, before)
+    assert parallel.gather_objects({"a": 1}) == [{"a": 1}]                 # no process group: identity
