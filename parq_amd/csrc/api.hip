@@ -632,6 +632,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
                 fa.peaky = sharded ? nullptr : flg + 1;
                 fa.peaky_it = sharded ? nullptr : flg + 8 + (layer_num % 56);
                 fa.peaky_min = sharded ? nullptr : flg + 2;
+                fa.head_min = (sharded || H > 16) ? nullptr : flg + 32;    // flags[32 + h]: every head's smallest row sum of this forward
                 fa.peaky_l = kPeakyL;
                 const uint32_t safe = c->safe_heads();
                 if (safe == 0) HIPCHK(launch_flash_split8(fa, cache, s));
@@ -660,7 +661,11 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
                     merged = true;
                 }
             }
-            else HIPCHK(launch_flash_split(fa, cache, s, c->terms(), c->kind()));
+            else {
+                // a mode-4 handle whose heads are all on the fp16 x 3 tier: the per-head row sums are still recorded (a head may return)
+                if (c->attn_mode == 4 && !train && !sharded && H <= 16 && dh == 64) fa.head_min = reinterpret_cast<int*>(wsp + ws.flags) + 32;
+                HIPCHK(launch_flash_split(fa, cache, s, c->terms(), c->kind()));
+            }
         } else {
             const float* kv = wsp + ws.kv + (int64_t)li * B * 2 * N * C;
             fa.k = kv;                       fa.k_batch = 2 * N * C; fa.k_head = N * dh; fa.k_row = dh;

@@ -379,6 +379,8 @@ struct FlashArgs {
     // (nullptr / 0: no check); *peaky_min (optional) keeps the smallest l seen as 0x7fffffff - its bits (atomicMax; 0 = none)
     int* peaky; float peaky_l;
     int* peaky_it; int* peaky_min;
+    int* head_min;              // optional [H]: the smallest l of every head of this launch, same code (what a head on the fp16 x 3 tier would
+                                // look like to the guard: PARQDecoder.tier_return_after)
     // a launch over SOME of the heads (attention mode 4 with per-head tiers: the heads whose rows rest on few keys run the fp16 x 3
     // kernel, the others the mode-4 kernel, each class with its own launch, key-split count and partial buffers).  nh = 0: all H heads.
     // nh > 0: grid index z = b * nh + i covers head (hmap >> 4 i) & 15; partials are indexed by z, everything else by b * H + head.

@@ -281,16 +281,17 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(FlashArgs a) {
     for (int i = 0; i < 8; ++i) den += dsm[i * 32 + tq];
     const float inv = 1.f / den;
     if (a.lse && blockIdx.z == 0 && td == 0 && q < a.Lq) a.lse[(int64_t)bh * Lq_pad + q] = mmax + log2f(den);
-    if (a.peaky && blockIdx.z == 0 && td == 0) {                     // attention mode 4: a row carried by too few keys (FlashArgs)
-        if (__any(q < a.Lq && den < a.peaky_l) && tq == 0) {
+    if ((a.peaky || a.head_min) && blockIdx.z == 0 && td == 0) {     // attention mode 4: a row carried by too few keys (FlashArgs)
+        if (a.peaky && __any(q < a.Lq && den < a.peaky_l) && tq == 0) {
             atomicOr(a.peaky, 1 << h);
             if (a.peaky_it) atomicOr(a.peaky_it, 1 << h);
         }
-        if (a.peaky_min) {
+        if (a.peaky_min || a.head_min) {
             float dmin = q < a.Lq ? den : INFINITY;
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, o));
-            if (tq == 0) atomicMax(a.peaky_min, 0x7fffffff - __float_as_int(dmin));
+            if (tq == 0 && a.peaky_min) atomicMax(a.peaky_min, 0x7fffffff - __float_as_int(dmin));
+            if (tq == 0 && a.head_min) atomicMax(a.head_min + h, 0x7fffffff - __float_as_int(dmin));
         }
     }
 
@@ -570,19 +571,20 @@ __global__ __launch_bounds__(256) void flash_merge_fixed_kernel(FlashArgs a) {
         for (int i = 0; i < 8; ++i) dn += dsm[i * 32 + tq];
         a.lse[(int64_t)bh * Lq_pad + q] = mmax + log2f(dn);
     }
-    if (a.peaky && blockIdx.z == 0 && td == 0) {                     // attention mode 4: a row carried by too few keys (FlashArgs)
+    if ((a.peaky || a.head_min) && blockIdx.z == 0 && td == 0) {     // attention mode 4: a row carried by too few keys (FlashArgs)
         float dn = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) dn += dsm[i * 32 + tq];
-        if (__any(dn < a.peaky_l) && tq == 0) {
+        if (a.peaky && __any(dn < a.peaky_l) && tq == 0) {
             atomicOr(a.peaky, 1 << h);
             if (a.peaky_it) atomicOr(a.peaky_it, 1 << h);
         }
-        if (a.peaky_min) {
+        if (a.peaky_min || a.head_min) {
             float dmin = dn;
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, o));
-            if (tq == 0) atomicMax(a.peaky_min, 0x7fffffff - __float_as_int(dmin));
+            if (tq == 0 && a.peaky_min) atomicMax(a.peaky_min, 0x7fffffff - __float_as_int(dmin));
+            if (tq == 0 && a.head_min) atomicMax(a.head_min + h, 0x7fffffff - __float_as_int(dmin));
         }
     }
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -305,6 +305,12 @@ class PARQDecoder(nn.Module):
         # themselves: ``reset_attention_tiers()``); a module whose heads are all safe runs exactly mode "split".
         self.safe_heads = 0
         self._tiers_set = None            # (safe mask, poison) the native handle currently holds
+        # range_check = "sync" only (there a wrong guess costs a re-run, never a NaN forward): a head on the fp16 x 3 tier returns to the
+        # fast tier after this many CONSECUTIVE forwards in which all of its rows kept a probability sum of at least tier_return_margin x
+        # the guard threshold.  0 (default) = heads never return by themselves.
+        self.tier_return_after = 0
+        self.tier_return_margin = 4.0
+        self._calm_streak = {}
 
     # ------------------------------------------------------------------ fp16 operand range (split / fp16 modes)
     def _flag_view(self, ws, B, V, h, w, words=1):
@@ -363,7 +369,9 @@ class PARQDecoder(nn.Module):
         first = self.attention_mode == "split8" and not self._peaky_checked and self.range_check != "off"
         if not first and (self.range_check != "sync" or self.attention_mode not in ("split", "split8", "fp16")):
             return False
-        flags = self._flag_view(ws, sc.B, sc.V, sc.h, sc.w, 2).tolist()
+        want_calm = (self.range_check == "sync" and self.tier_return_after > 0 and self.safe_heads != 0 and self.attention_mode == "split8"
+                     and self.num_heads <= 16)
+        flags = self._flag_view(ws, sc.B, sc.V, sc.h, sc.w, 48 if want_calm else 2).tolist()
         if first:
             self._peaky_checked = True
         if flags[0] != 0 and self.range_check == "sync":
@@ -376,6 +384,19 @@ class PARQDecoder(nn.Module):
             if self._peaky_fallback(flags[1], "re-running this forward"):
                 self._peaky_checked = False if first else self._peaky_checked     # the re-run is checked too: other heads may follow
                 return True
+        if want_calm:
+            # heads on the fp16 x 3 tier whose rows all spread again (flags[32 + h]: the head's smallest row sum of this forward)
+            limit = 256.0 * float(self.tier_return_margin)
+            for h in range(self.num_heads):
+                if not (self.safe_heads >> h) & 1:
+                    self._calm_streak.pop(h, None)
+                    continue
+                code = flags[32 + h]
+                lmin = float(np.array([0x7fffffff - code], dtype=np.int32).view(np.float32)[0]) if code else 0.0
+                self._calm_streak[h] = self._calm_streak.get(h, 0) + 1 if lmin >= limit else 0
+                if self._calm_streak[h] >= int(self.tier_return_after):
+                    self.safe_heads &= ~(1 << h)                  # this forward's numbers stand (fp16 x 3); the next one tries the fast tier
+                    self._calm_streak.pop(h)
         return False
 
     # ------------------------------------------------------------------ native handle
@@ -874,16 +895,18 @@ class PARQDecoder(nn.Module):
         f = self._flag_view(ws, B, V, h, w, 64).tolist()
         return [f[8 + (k % 56)] for k in range(self.num_layers)]
 
-    def attention_min_row_sum(self):
+    def attention_min_row_sum(self, per_head=False):
         """Smallest row probability sum (relative to the row's reference maximum) the mode-"split8" heads of the last inference forward
-        saw, or None (synchronises).  The guard threshold is 256 (include/parq_hip.h, attention mode 4)."""
+        saw, or None (synchronises).  The guard threshold is 256 (include/parq_hip.h, attention mode 4).  ``per_head``: a list with
+        every head's smallest sum instead — heads on the fp16 x 3 tier included (what ``tier_return_after`` looks at)."""
         if not self._ws:
             return None
         (B, V, h, w, _), ws = list(self._ws.items())[-1]
-        code = int(self._flag_view(ws, B, V, h, w, 3)[2].item())
-        if code == 0:
-            return None
-        return float(np.array([0x7fffffff - code], dtype=np.int32).view(np.float32)[0])
+        dec = lambda code: float(np.array([0x7fffffff - code], dtype=np.int32).view(np.float32)[0]) if code else None
+        if per_head:
+            f = self._flag_view(ws, B, V, h, w, 48).tolist()
+            return [dec(f[32 + i]) for i in range(min(self.num_heads, 16))]
+        return dec(int(self._flag_view(ws, B, V, h, w, 3)[2].item()))
 
     def intermediate(self, name):
         """View of a named workspace buffer after prepare()/iterate() (parity tests)."""

@@ -239,3 +239,33 @@ def test_reset_attention_tiers():
         assert dec.safe_heads == 0
         _run(dec, sc)
     assert dec.safe_heads == 0b1111
+
+
+def test_a_head_returns_to_the_fast_tier_after_calm_forwards_under_the_sync_policy():
+    """`tier_return_after` (range_check = "sync" only): a head that was moved to the fp16 x 3 tier by a peaked scene returns after N
+    consecutive forwards in which all of its rows spread again — and moves back at once (re-run, never NaN) when the peaked scene comes back."""
+    cfg, W, sc, _ = _case(1.0)
+    dec = make_decoder(cfg, W)
+    dec.range_check = "sync"
+    dec.tier_return_after = 2
+    dec.tier_return_margin = 1.0                        # (this fixture's spread rows sit at sums of 300 .. 1000: margin 4 would keep the heads)
+    sc_peaked = dict(sc)
+    sc_peaked["tokens"] = (sc["tokens"] * 4.0).astype(np.float32)
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        _run(dec, sc_peaked)
+        moved = dec.safe_heads
+        assert moved != 0
+        mins = dec.attention_min_row_sum(per_head=True)
+        assert len(mins) == 4 and all(m is not None for m in mins)
+        _run(dec, sc)                                   # calm forward 1: still on the safe tier
+        assert dec.safe_heads == moved
+        assert min(m for m in dec.attention_min_row_sum(per_head=True)) >= 256
+        _run(dec, sc)                                   # calm forward 2: the heads return
+        assert dec.safe_heads == 0
+        out = _run(dec, sc)                             # ... and the fast tier runs clean
+        assert dec.safe_heads == 0 and not dec.attention_too_peaked()
+        assert all(torch.isfinite(v).all() for o in out for v in o.values())
+        got = _run(dec, sc_peaked)                      # the peaked scene again: re-run with the heads moved, numbers not NaN
+        assert dec.safe_heads != 0
+        assert all(torch.isfinite(v).all() for o in got for v in o.values())
