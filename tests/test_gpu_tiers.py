@@ -269,3 +269,40 @@ def test_a_head_returns_to_the_fast_tier_after_calm_forwards_under_the_sync_poli
         got = _run(dec, sc_peaked)                      # the peaked scene again: re-run with the heads moved, numbers not NaN
         assert dec.safe_heads != 0
         assert all(torch.isfinite(v).all() for o in got for v in o.values())
+
+
+def test_train_split8_step_on_peaked_attention_is_rerun_in_mode_split():
+    """`train_split8` (opt-in): a training forward whose mode-4 heads meet peaked rows is poisoned like an inference forward; forward_train
+    sees it before returning (one host synchronisation per step on this path), moves the heads and re-runs the step — with any safe head a
+    training step runs as mode "split" — so outputs are finite and the gradients are those of a mode-"split" step (same dropout seed)."""
+    B, V, h, w, Q, dim, I = 1, 2, 32, 36, 24, 256, 2
+    cfg = synth.decoder_cfg(dim=dim, queries=Q, heads=4, ffn=128, layers=I, dropout=0.0)
+    W = synth.make_decoder_weights(cfg, 71, damped=True)
+    wq = W[WQ].copy()
+    wq[:dim] *= 6.0                                                           # 2304 keys, sharpened: rows on a handful of keys
+    W[WQ] = wq
+    sc = synth.make_scene(72, B, V, h, w, dim, smooth=True)
+    ncls = cfg.NUM_SEMCLS + 1
+    cots = {"pred_logits": synth.normal(73, "cl", (I, B, Q, ncls)), "center_unnormalized": synth.normal(74, "cc", (I, B, Q, 3)),
+            "size_unnormalized": synth.normal(75, "cs", (I, B, Q, 3)), "ortho6d": synth.normal(76, "cr", (I, B, Q, 6))}
+    res = {}
+    for opt in (True, False):
+        dec = make_decoder(cfg, W)
+        dec.train_split8 = opt
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            outs = dec.forward_train(*scene_args(sc))
+            grads, d_tok = dec.backward({k: torch.from_numpy(v) for k, v in cots.items()})
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(o[k]).all() for o in outs for k in o)
+        if opt:
+            assert dec.safe_heads != 0 and any("too few keys" in str(x.message) for x in caught)
+        else:
+            assert dec.safe_heads == 0
+        res[opt] = {k: v.double().cpu() for k, v in grads.items()}
+        res[opt]["__tokens__"] = d_tok.double().cpu()
+    for name, a in res[True].items():
+        b = res[False][name]
+        assert torch.isfinite(a).all(), name
+        if float(b.norm()) > 0:
+            assert float((a - b).norm()) / float(b.norm()) < 1e-4, name      # both steps ran the fp16 x 3 kernels (atomics: ~1e-5 run to run)
