@@ -743,7 +743,7 @@ __global__ void fold_pos_weights_kernel(const float* __restrict__ Wa, const floa
     }
 }
 
-// pack time, LayerNorm pushed through a linear map (see outproj_qproj_kernel): thread = one row r of W [R][C]
+// pack time, LayerNorm pushed through a linear map (see seam_tile / SeamArgs): thread = one row r of W [R][C]
 //   Wg[r][k] = W[r][k] gamma[k],   s[r] = sum_k Wg[r][k],   bb[r] = b[r] + sum_k W[r][k] beta[k]        (float64 sums)
 __global__ void ln_fold_kernel(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ gamma,
                                const float* __restrict__ beta, int R, int C, float* __restrict__ Wg, float* __restrict__ srow, float* __restrict__ bb) {
