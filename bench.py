@@ -593,7 +593,10 @@ def main():
     dt = parallel.max_over_ranks(dt_own, device=red_dev)
     per_rank_ms = [x / args.steps * 1e3 for x in parallel.gather_over_ranks(dt_own, device=red_dev)]
     per_rank_cpus = parallel.gather_over_ranks(float(len(pinned)), device=red_dev)
-    per_rank_cpulists = [parallel.cpulist_string(c) for c in parallel.gather_objects(list(pinned))]
+    try:                                  # (object collectives pickle through the backend: never let a reporting extra end a multi-GPU run)
+        per_rank_cpulists = [parallel.cpulist_string(c) for c in parallel.gather_objects(list(pinned))]
+    except Exception as exc:              # noqa: BLE001
+        per_rank_cpulists = ["unavailable: %s" % type(exc).__name__] * world
 
     # ---- per-step times from hipEvents on the launch stream (median of >= 20 runs); the wall-clock mean above stays
     # the contract's `value`, this is its cross-check and its spread
