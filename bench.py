@@ -318,11 +318,63 @@ def _pmc_record():
     return None, None
 
 
+_LIVE_PMC = {"by_kernel": None, "scenes": None, "note": None}
+
+
+def live_pmc(args, B):
+    """HBM-side bytes of THIS command measured in THIS run (the line could not see a traffic regression): after the timed
+    region rank 0 starts two short child processes of this script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate
+    passes, --kernel-trace only, as MI355X_MICROARCH.md prescribes; the program itself behind `--`), each running a few forwards of the
+    same configuration (`--pmc-child`), and reads the per-kernel means from their counter CSVs.  Any failure (no rocprofv3, a timeout)
+    leaves the recorded figures of profiles/rNN_pmc.json in place; `roofline.traffic_source` says which it was."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    tool = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(tool):
+        _LIVE_PMC["note"] = "rocprofv3 not found"
+        return
+    here = os.path.abspath(__file__)
+    base = [sys.executable, here, "--pmc-child", "--steps", "2", "--warmup", "1", "--config", args.config, "--scenes-per-gpu", str(B)]
+    if args.attention_mode:
+        base += ["--attention-mode", args.attention_mode]
+    res = {}
+    t0 = time.perf_counter()
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            with tempfile.TemporaryDirectory(dir="/tmp") as d:
+                env = dict(os.environ, TMPDIR="/tmp")
+                r = subprocess.run([tool, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + base,
+                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+                if r.returncode != 0:
+                    _LIVE_PMC["note"] = "rocprofv3 --pmc %s exited with %d" % (ctr, r.returncode)
+                    return
+                acc = {}
+                for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    with open(path) as f:
+                        for row in csv.DictReader(f):
+                            if row.get("Counter_Name") == ctr:
+                                acc.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+                for k, v in acc.items():
+                    res.setdefault(k, {})[ctr] = sum(v) / len(v)
+    except Exception as exc:      # noqa: BLE001 — a measurement extra must not end the bench
+        _LIVE_PMC["note"] = "live PMC pass failed: %s" % type(exc).__name__
+        return
+    _LIVE_PMC.update(by_kernel=res, scenes=B, note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command in this run (two child passes, %.0f s)" % (time.perf_counter() - t0))
+
+
 def pmc_traffic(kernel, scenes):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes (profiles/rNN_pmc.json: FETCH_SIZE and
-    WRITE_SIZE collected in separate --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 wide streaming
-    reads).  Counters cannot be read from inside this process, so the figure is the RECORDED one for the same kernel and scene
-    count (`traffic_source` in the line says which file), or null."""
+    """HBM bytes per launch of `kernel`: FETCH_SIZE x 2 + WRITE_SIZE (KB counters; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    gfx950 wide streaming reads) — measured in this run where `live_pmc` succeeded for this scene count, else the RECORDED figure of the
+    newest committed passes (profiles/rNN_pmc.json); `traffic_source` in the line says which, or null."""
+    live = _LIVE_PMC["by_kernel"]
+    if live and _LIVE_PMC["scenes"] == scenes:
+        f = [v["FETCH_SIZE"] for k, v in live.items() if kernel in k and "FETCH_SIZE" in v]
+        w = [v["WRITE_SIZE"] for k, v in live.items() if kernel in k and "WRITE_SIZE" in v]
+        if f and w:
+            return (sum(f) / len(f) * 2.0 + sum(w) / len(w)) * 1024.0
     rec, _ = _pmc_record()
     try:
         e = rec["by_scenes"][str(scenes)][kernel]
@@ -506,6 +558,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b32", action="store_true", help="skip the 32-scene project+sample bandwidth measurement (6.3 GB of tokens)")
     ap.add_argument("--no-peaked", action="store_true", help="skip the peaked_workload record (the same workload with sharpened cross-attention)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (roofline.traffic then comes from profiles/rNN_pmc.json)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # internal: a few forwards of the configuration, no output (live_pmc)
     ap.add_argument("--train-split8", action="store_true", help="--train: run the training forward in mode split8 (PARQDecoder.train_split8)")
     ap.add_argument("--attention-mode", default=None, choices=["split", "split8", "fp32", "fp16", "bf16"],
                     help="cross-attention arithmetic; default = the library default (split8 at d = 256 / head dim 64: fp16 hi.hi + fp8 cross terms; "
@@ -571,6 +625,12 @@ def main():
 
     def step():
         return dec(*inputs, feat_hw=(h, w))
+
+    if args.pmc_child:                    # live_pmc(): the kernels of this configuration under rocprofv3 --pmc, nothing printed
+        for _ in range(args.warmup + args.steps):
+            step()
+        torch.cuda.synchronize()
+        return
 
     def barrier():
         torch.cuda.synchronize()
@@ -646,10 +706,13 @@ def main():
         step()
         torch.cuda.synchronize()
 
+    if rank == 0 and world == 1 and not args.no_pmc and not (args.dev_lib or parq_env()):
+        live_pmc(args, B)                 # two short child runs under rocprofv3 --pmc (after every timed region of this process)
     if rank == 0:
         V, Q, C = WORKLOAD["views"], WORKLOAD["queries"], WORKLOAD["dim"]
         N = V * h * w
         total_iters = world * B * I * args.steps
+        live = _LIVE_PMC["by_kernel"] is not None and _LIVE_PMC["scenes"] == B      # HBM-side bytes measured in this run (live_pmc)
         ca_ms, ca_n = prof["cross_attn"]
         ps_ms, ps_n = prof["project_sample"]
         flop_per_launch = 4.0 * Q * N * C * B                       # QK^T + PV, all heads, B scenes
@@ -672,8 +735,8 @@ def main():
                                else "flash_f32_kernel (cross-attention QK^T+PV, fp32 MFMA)"),
                     "achieved": ach_tflops, "peak": mfma_peak, "unit": "TFLOP/s",
                     "frac": (ach_tflops / mfma_peak) if ach_tflops else None,
-                    "traffic": pmc_traffic("flash_split_pipe_kernel", B) if (split and C == 256 and args.config == "cfg3") else None,
-                    "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, newest profiles/rNN_pmc.json); algorithmic stream = 2*N*C*4*B bytes",
+                    "traffic": pmc_traffic("flash_split_pipe_kernel", B) if (split and C == 256 and (args.config == "cfg3" or live)) else None,
+                    "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE: see traffic_source); algorithmic stream = 2*N*C*4*B bytes",
                     "avg_launch_ms": (ca_ms / ca_n) if ca_n else None, "launches": ca_n,
                     "algorithmic_gflop_per_launch": flop_per_launch / 1e9,
                     "peak_note": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 passes per product; the fp32-MFMA peak is %.1f"
@@ -700,7 +763,7 @@ def main():
             roofline.update({"bound": "hbm", "kernel": "flash_split8_kernel (cross-attention: Q K^T = fp16 hi.hi + MX-scaled fp8 e4m3 cross terms, "
                                                        "P V = fp16 product with a self-consistent normaliser, fp32 accumulate)",
                              "achieved": stream_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": (stream_gbs / PEAK_HBM_GBS) if stream_gbs else None,
-                             "traffic": pmc_traffic("flash_split8_kernel", B) if args.config == "cfg3" else None,
+                             "traffic": pmc_traffic("flash_split8_kernel", B) if (args.config == "cfg3" or live) else None,
                              "algorithmic_bytes_per_launch": kv_bytes, "hbm_stream_gbs": stream_gbs,
                              "peak_note": "HBM3E 8 TB/s; a plain streaming kernel reaches 5.6 TB/s on this part (profiles/r02_hbm_stream_ceiling.txt)",
                              "mfma": {"achieved": ach_tflops, "peak": mx_peak, "unit": "TFLOP/s", "frac": (ach_tflops / mx_peak) if ach_tflops else None,
@@ -710,11 +773,14 @@ def main():
         kvp_bytes = ((N * C * 4.0 + N * C * 6.0) * B if split8 else
                      3.0 * N * C * 4.0 * B if not half else (N * C * 4.0 + 2.0 * N * C * 2.0) * B)     # tokens in, K and V cache images out
         roofline["hbm_frac"] = (roofline["hbm_stream_gbs"] / PEAK_HBM_GBS) if roofline["hbm_stream_gbs"] else None
-        roofline["traffic_source"] = "recorded: %s (rocprofv3 --pmc passes of the same command), not measured in this run" % (_pmc_record()[1],)
+        traffic_source = (_LIVE_PMC["note"] if live else
+                          "recorded: %s (rocprofv3 --pmc passes of the same command), not measured in this run%s"
+                          % (_pmc_record()[1], "" if not _LIVE_PMC["note"] else " (%s)" % _LIVE_PMC["note"]))
+        roofline["traffic_source"] = traffic_source
         roofline_kv = {"bound": "hbm", "kernel": "kvproj_dma_kernel (hoisted K/V in-projection, once per forward)",
                        "achieved": (kvp_bytes / (kv_ms / kv_n * 1e-3) / 1e9) if kv_n else None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                        "frac": (kvp_bytes / (kv_ms / kv_n * 1e-3) / 1e9 / PEAK_HBM_GBS) if kv_n else None,
-                       "traffic": pmc_traffic("kvproj_dma_kernel", B) if args.config == "cfg3" else None, "traffic_source": "recorded: %s, or null" % (_pmc_record()[1],),
+                       "traffic": pmc_traffic("kvproj_dma_kernel", B) if (args.config == "cfg3" or live) else None, "traffic_source": traffic_source,
                        "algorithmic_bytes_per_launch": kvp_bytes, "avg_launch_ms": (kv_ms / kv_n) if kv_n else None, "launches": kv_n,
                        "streaming_ceiling_ms": kvp_bytes / 5.6e12 * 1e3,
                        "note": "reads N*C fp32 tokens, writes the K and V cache images; a plain streaming kernel with this 1:2 read/write "
@@ -756,7 +822,7 @@ def main():
             "roofline_project_sample": {"bound": "hbm", "kernel": "project_sample_kernel", "scenes": B,
                                         "achieved": ps_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                         "frac": (ps_gbs / PEAK_HBM_GBS) if ps_gbs else None,
-                                        "traffic": pmc_traffic("project_sample_kernel", B) if args.config == "cfg3" else None,
+                                        "traffic": pmc_traffic("project_sample_kernel", B) if (args.config == "cfg3" or live) else None,
                                         "algorithmic_bytes_per_launch": bytes_per_launch,
                                         "avg_launch_ms": (ps_ms / ps_n) if ps_n else None, "launches": ps_n,
                                         "note": ("latency-bound at one scene: a %.1f us launch over a 197 MB token tensor that sits in the 256 MB "
