@@ -186,3 +186,36 @@ def test_dropout_hash_spec_row_pairs_are_statistically_independent():
     off = ~np.eye(32, dtype=bool)
     sd = (p * p * (1 - p * p) / (16384 * 32)) ** 0.5          # 1.4 % of p^2 at this sample size
     assert np.abs(co[off] - p * p).max() < 5 * sd, np.abs(co[off] / (p * p) - 1).max()
+
+
+def test_layernorm_pushed_through_the_query_projection_is_an_identity():
+    """The algebra behind chain.hip's seam_tile (api.hip build_derived_weights: qg_w, qo_w, qu_b, q_s, qv_b), in float64 on random
+    data: the cross-attention query rows (norm1(xa) + pos) Wq^T + bq with xa = tgt + sa Wo^T + bo and pos = pe_h W2^T + b2
+    (model/transformer_parq.py:375-377) equal rstd (U - mean s) + V, where U and V contract operands that exist BEFORE xa does."""
+    rng = np.random.default_rng(5)
+    M, C = 48, 256
+    sa, tgt, peh = (rng.standard_normal((M, C)) for _ in range(3))
+    tgt = tgt + 0.7                                           # a row mean that is not small against the spread
+    Wo, Wq, W2 = (rng.standard_normal((C, C)) / 16 for _ in range(3))
+    bo, bq, b2, gamma, beta = (rng.standard_normal(C) for _ in range(5))
+    eps = 1e-5
+    xa = tgt + sa @ Wo.T + bo
+    mean, var = xa.mean(-1, keepdims=True), xa.var(-1, keepdims=True)
+    want = (((xa - mean) / np.sqrt(var + eps)) * gamma + beta + (peh @ W2.T + b2)) @ Wq.T + bq
+    # pack time
+    qg = Wq * gamma                                           # Wq diag(gamma)
+    qo = qg @ Wo
+    qu_b = qg @ bo
+    q_s = qg.sum(-1)
+    cross_q_w2, cross_q_b2 = Wq @ W2, bq + Wq @ b2            # (the position MLP's last layer folded: round 3)
+    qv_b = cross_q_b2 + Wq @ beta
+    # launch: query tiles
+    U = sa @ qo.T + tgt @ qg.T + qu_b
+    V = peh @ cross_q_w2.T + qv_b
+    # ... and their epilogue, with the statistics from partial row sums over four 64-column tiles of xa
+    S = sum(xa[:, 64 * t: 64 * t + 64].sum(-1) for t in range(4))
+    Q = sum((xa[:, 64 * t: 64 * t + 64] ** 2).sum(-1) for t in range(4))
+    mu = S / C
+    rstd = 1.0 / np.sqrt(Q / C - mu * mu + eps)
+    got = rstd[:, None] * (U - mu[:, None] * q_s) + V
+    assert np.abs(got - want).max() < 1e-10 * max(1.0, np.abs(want).max())
