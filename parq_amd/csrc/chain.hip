@@ -992,11 +992,21 @@ static bool seam_ok(const SeamArgs& b, int M, int nt) {
 
 // xa tiles (+ published partial row sums) | q tiles: see seam_tile
 hipError_t launch_seam_q(const LinearArgs& xa, const SeamArgs& q, hipStream_t s) {
-    if (!fused_tile_ok(xa) || xa.rln_stats || !seam_ok(q, xa.M, 2) || !q.X3 || !al16(q.X3) || !al16(q.W3p) || q.ldx3 % 4 != 0) return hipErrorNotSupported;
+    if (!fused_tile_ok(xa) || xa.rln_stats || !seam_ok(q, xa.M, 4) || !q.X3 || !al16(q.X3) || !al16(q.W3p) || q.ldx3 % 4 != 0) return hipErrorNotSupported;
     LinearArgs a = xa;
     a.tile_map = 0;
-    const int nA = (a.N / 64) * (a.M / 16), nB = (q.N / 32) * (q.M / 16);
-    hipLaunchKernelGGL((seam_q_kernel<2>), dim3((unsigned)(nA + nB)), dim3(256), 0, s, a, q, nA);
+    static const int ntq = [] { const char* e = dev_env("PARQ_SEAM_NT_Q"); return e ? atoi(e) : 2; }();      // column sub-tiles of a query workgroup (A/B)
+    const int nA = (a.N / 64) * (a.M / 16);
+    if (ntq == 1) {
+        const int nB = (q.N / 16) * (q.M / 16);
+        hipLaunchKernelGGL((seam_q_kernel<1>), dim3((unsigned)(nA + nB)), dim3(256), 0, s, a, q, nA);
+    } else if (ntq == 4) {
+        const int nB = (q.N / 64) * (q.M / 16);
+        hipLaunchKernelGGL((seam_q_kernel<4>), dim3((unsigned)(nA + nB)), dim3(256), 0, s, a, q, nA);
+    } else {
+        const int nB = (q.N / 32) * (q.M / 16);
+        hipLaunchKernelGGL((seam_q_kernel<2>), dim3((unsigned)(nA + nB)), dim3(256), 0, s, a, q, nA);
+    }
     return hipGetLastError();
 }
 
