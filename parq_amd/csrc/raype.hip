@@ -15,6 +15,8 @@
 // two-GEMM form is the first correct version).
 #include "common.hpp"
 #include <cstdlib>
+#include <cstdio>
+#include <vector>
 
 namespace parq {
 
@@ -633,18 +635,21 @@ __global__ void raype_pack_w2_kernel(const _Float16* __restrict__ hi, const _Flo
 
 // PROBE (development only, results wrong when non-zero): 1 W2 fragments loaded once instead of per tile, 2 operand image generated
 // once, 4 no feature loads, 8 no token stores — what each ingredient costs when it is taken out
-template <bool KEEP, int PROBE = 0>
+template <bool KEEP, int PROBE = 0, bool NCHW = false>
 __global__ __launch_bounds__(kFThreads, 1) void raype_onepass_kernel(RayFusedArgs a, int ntiles, int P) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     __shared__ double dtab[64];
     constexpr int kStep = 2 * kFTM * 64;                                // halfs per k-step (hi + lo)
-    _Float16* pts = lds;                                                // 3 k-steps
-    _Float16* hid = lds + 3 * kStep;                                    // 4 k-steps
-    float* ot = reinterpret_cast<float*>(hid);                          // [64][kOtLd], after the second GEMM
+    _Float16* hid = lds;                                                // 4 k-steps, at offset 0: every fragment read of the second GEMM
+    float* ot = reinterpret_cast<float*>(hid);                          // is (one of 4 lane addresses) + a 16-bit immediate.  ot = [64][kOtLd]
+    _Float16* pts = lds + kFTM * kOtLd * 2;                             // 3 k-steps, behind ot (65 KB)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kh = lane >> 5;
     const int p = blockIdx.x;
     if (tid < 64) dtab[tid] = tid < a.S ? a.depth[tid] : 1.0;
+    // b1 | b2 in LDS: vector-memory loads return in order, so a bias load inside the tile would sit behind the tile's feature loads
+    __shared__ __attribute__((aligned(16))) float bsh[2 * kFC];
+    bsh[tid] = tid < kFC ? a.bias[tid] : a.bias2[tid - kFC];
     const int col = wave * 32 + li;                                     // this lane's row of W1 (A operand of the transposed product)
     half8 wfr[3][4][2];
 #pragma unroll
@@ -667,27 +672,53 @@ __global__ __launch_bounds__(kFThreads, 1) void raype_onepass_kernel(RayFusedArg
     __syncthreads();
 
     const int grow = tid & 63;
-    auto generate = [&](int tile) {                                      // as raype_hidden_kernel: the 64 x 192 operand image of `tile`
+    // the operand image of a tile (as raype_hidden_kernel), in two steps so that the row stores of the tile before can be issued
+    // between its pieces: gen_setup = the ray of this thread's token (G, T3), gen_chunk(i) = eight values of axis-chunk i.
+    // The pose and intrinsics come through SCALAR loads when the whole tile lies in one image (h w % 64 == 0: always): vector
+    // loads would queue behind the row stores just issued and the generator would wait for their acknowledgement.
+    double G[3], T3[3];
+    auto gen_setup = [&](int tile) {
         const int m = tile * kFTM + grow;
-        double G[3] = {0.0, 0.0, 0.0}, T3[3] = {0.5, 0.5, 0.5};
+        G[0] = G[1] = G[2] = 0.0; T3[0] = T3[1] = T3[2] = 0.5;
+        const int bv0 = (tile * kFTM) / a.hw;                             // scalar
+        const int mlast = min(tile * kFTM + kFTM - 1, a.M - 1);
+        const bool one_image = (PROBE & 128) == 0 && mlast / a.hw == bv0;   // scalar
+        float cm[4]; double T[12];                                        // fx, fy, cx, cy | R (row-major), t
+        if (one_image) {
+            typedef const float __attribute__((address_space(4)))* kcf;   // constant address space: s_load
+            typedef const double __attribute__((address_space(4)))* kcd;
+            kcf c = (kcf)(a.cam + (int64_t)bv0 * 6 + 2);
+            kcd t = (kcd)(a.Tl + (int64_t)bv0 * 12);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cm[i] = c[i];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T[i] = t[i];
+        } else {
+            int bv = bv0;
+            for (int q = min(m, a.M - 1) - bv0 * a.hw; q >= a.hw; q -= a.hw) ++bv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cm[i] = a.cam[(int64_t)bv * 6 + 2 + i];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T[i] = a.Tl[(int64_t)bv * 12 + i];
+        }
         if (m < a.M) {
-            const int bv = m / a.hw, pix = m - bv * a.hw;
+            int pix = m - bv0 * a.hw;
+            while (pix >= a.hw) pix -= a.hw;
             const int y = pix / a.w, x = pix - y * a.w;
-            const float* cm = a.cam + (int64_t)bv * 6;
-            const double rx = ((double)x - (double)cm[4]) / (double)cm[2];
-            const double ry = ((double)y - (double)cm[5]) / (double)cm[3];
-            const double* T = a.Tl + (int64_t)bv * 12;
+            const double rx = ((double)x - (double)cm[2]) / (double)cm[0];
+            const double ry = ((double)y - (double)cm[3]) / (double)cm[1];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 G[i] = (T[i * 3] * rx + T[i * 3 + 1] * ry + T[i * 3 + 2]) * a.inv[i];
                 T3[i] = (T[9 + i] - a.lo[i]) * a.inv[i];
             }
         }
+    };
+    auto gen_chunk = [&](int i) {
         double dj[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) dj[jj] = dtab[8 * wave + jj];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        {
             float x8[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -712,79 +743,95 @@ __global__ __launch_bounds__(kFThreads, 1) void raype_onepass_kernel(RayFusedArg
         }
     };
 
-    if (p < ntiles) generate(p);
-    __syncthreads();
-    for (int tile = p; tile < ntiles; tile += P) {
-        half8 w2r[4][2];                                                  // ring of four (k-step, s2) steps of W2 fragments
-        // ---- the feature tile in the accumulator layout (register r of block t = channel 32 wave + mfma32_row(r, lane) of token
-        // tile*64 + 32 t + li: lanes walk consecutive pixels, 128-byte segments), requested at the TOP of the tile and added in the
-        // epilogue.  VMEM returns in order: requested behind the first GEMM they sat in front of every W2 refill of the second one
-        // and each tile paid their HBM latency (probe: -75 us per launch with the loads removed, profiles/r04_raype_onepass.txt)
-        // (buffer loads: ONE lane-dependent byte offset per block t, the 16 channel strides as scalar offsets — global loads with
-        // 32 distinct 64-bit addresses per lane cost 64 VGPRs of addresses and spilled the tile loop.  The descriptor's base is
-        // the first image of the tile, so the 32-bit offsets stay small whatever the batch size.)
-        f32x16 fr[2];
-        {
-            const int bv0 = (tile * kFTM) / a.hw;                         // scalar: first image this tile touches
-            const float* fbase = (a.feat ? a.feat : a.bias) + (int64_t)bv0 * kFC * a.hw;
-            // no feature maps (AddRayPE.forward: the encoding alone): zero records -> every load returns 0, no branch per load
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)fbase, 0, a.feat ? 0x7fffffff : 0, 0x00020000);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int m = tile * kFTM + t * 32 + li;
-                const bool ok = m < a.M;                                 // rows past the end read (and discard) pixel 0 of image bv0
-                const int bv = ok ? m / a.hw : bv0, pix = ok ? m - bv * a.hw : 0;
-                const int voff = (((bv - bv0) * kFC + wave * 32 + 4 * kh) * a.hw + pix) * 4;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int soff = (8 * (r >> 2) + (r & 3)) * a.hw * 4;   // mfma32_row(r, lane) = 8 (r >> 2) + 4 kh + (r & 3)
-                    if constexpr ((PROBE & 4) != 0) fr[t][r] = 0.f;
-                    else fr[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) load_w2(i, w2r[i]);                    // the first W2 steps: behind the features, landed long before GEMM 2
-        // ---- GEMM 1, transposed: acc1[t] rows = this wave's 32 hidden units, columns = tokens 32 t .. 32 t + 31
-        f32x16 acc1[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-            const _Float16* Ahi = pts + ks * kStep;
-            const _Float16* Alo = Ahi + kFTM * 64;
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                half8 xh[2], xl[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int row = t * 32 + li;
-                    const int posr = (4 * kh + s2) ^ ((row >> 1) & 7);
-                    xh[t] = *reinterpret_cast<const half8*>(Ahi + row * 64 + posr * 8);
-                    xl[t] = *reinterpret_cast<const half8*>(Alo + row * 64 + posr * 8);
-                }
-                const half8 wh = wfr[ks][s2][0], wl = wfr[ks][s2][1];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[t], acc1[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[t], acc1[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[t], acc1[t], 0, 0, 0);
-            }
-        }
-        // ---- relu(acc1 + b1) -> hid image (B operand of GEMM 2: rows = tokens, 8-unit chunks, swizzled as every operand image).
-        // Registers 4 g .. 4 g + 3 of a lane are units 32 wave + 8 g + 4 kh .. + 3 of token 32 t + li: half a chunk, 8 bytes.
+    // the feature tile goes straight INTO the second GEMM's accumulators (register r of block t = channel 32 wave +
+    // mfma32_row(r, lane) of token tile*64 + 32 t + li: lanes walk consecutive pixels, 128-byte segments), requested one tile
+    // ahead — right after the epilogue of the tile before has read the accumulators — so it travels under the row stores, the
+    // generator and the first GEMM, and nothing of a tile's own W2 stream ever queues behind it (vector memory returns in order).
+    // (buffer loads: ONE lane-dependent byte offset per block t, the 16 channel strides as scalar offsets — global loads with
+    // 32 distinct 64-bit addresses per lane cost 64 VGPRs of addresses and spilled the tile loop.  The descriptor's base is
+    // the first image of the tile, so the 32-bit offsets stay small whatever the batch size.)
+    f32x16 acc2[2];
+    auto load_features = [&](int tile) {
+        const int bv0 = (tile * kFTM) / a.hw;                             // scalar: first image this tile touches
+        const float* fbase = (a.feat ? a.feat : a.bias) + (int64_t)bv0 * kFC * a.hw;
+        // no feature maps (AddRayPE.forward: the encoding alone): zero records -> every load returns 0, no branch per load
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)fbase, 0, a.feat ? 0x7fffffff : 0, 0x00020000);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
+            const int m = tile * kFTM + t * 32 + li;
+            const bool ok = m < a.M;                                     // rows past the end read (and discard) pixel 0 of image bv0
+            int dbv = 0, pix = ok ? m - bv0 * a.hw : 0;                   // image index by stepping (a tile rarely leaves its first
+            while (pix >= a.hw) { pix -= a.hw; ++dbv; }                   // image): a per-lane division keeps its reciprocal live
+            const int voff = ((dbv * kFC + wave * 32 + 4 * kh) * a.hw + pix) * 4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int soff = (8 * (r >> 2) + (r & 3)) * a.hw * 4;   // mfma32_row(r, lane) = 8 (r >> 2) + 4 kh + (r & 3)
+                if constexpr ((PROBE & 4) != 0) acc2[t][r] = 0.f;
+                else acc2[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+            }
+        }
+    };
+
+    if (p < ntiles) {
+        gen_setup(p);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gen_chunk(i);
+        if constexpr ((PROBE & 32) != 0) load_features(p);
+    }
+    __syncthreads();
+    // PROBE 16 (development): s_memrealtime stamps (100 MHz) of waves 0 and 5 at ten points of every tile -> a.hidden as u64[P][2][16][10]
+    [[maybe_unused]] unsigned long long* stamps = nullptr;
+    if constexpr ((PROBE & 16) != 0) {
+        if ((wave == 0 || wave == 5) && lane == 0) stamps = reinterpret_cast<unsigned long long*>(a.hidden) + ((int64_t)p * 2 + (wave == 5)) * 160;
+    }
+    [[maybe_unused]] int tcount = 0;
+#define PARQ_RP_STAMP(k) do { if constexpr ((PROBE & 16) != 0) { if (stamps && tcount < 16) stamps[tcount * 10 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+    for (int tile = p; tile < ntiles; tile += P) {
+        PARQ_RP_STAMP(0);
+        constexpr int kRing = (PROBE & 256) ? 3 : 4;                      // (k-step, s2) steps of W2 fragments in flight
+        half8 w2r[kRing][2];
+        if constexpr ((PROBE & 32) == 0) load_features(tile);
+        // ---- GEMM 1, transposed, one 32-token block at a time: acc1 rows = this wave's 32 hidden units, columns = tokens
+        // 32 t .. 32 t + 31 (one accumulator set live beside W1 and the prefetched feature tile: both blocks at once spill, and a
+        // scratch reload waits for every vector-memory operation in front of it — the feature tile and the row stores)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x16 acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
             const int row = t * 32 + li;
+            // operand fragments one step ahead of the MFMAs that use them (sched_barrier: hipcc otherwise sinks every read to
+            // its first use and each step pays the LDS latency)
+            auto rd1 = [&](int st, half8 (&x)[2]) {
+                const int ks = st >> 2, s2 = st & 3;
+                const int posr = (4 * kh + s2) ^ ((row >> 1) & 7);
+                const _Float16* Ahi = pts + ks * kStep + row * 64 + posr * 8;
+                x[0] = *reinterpret_cast<const half8*>(Ahi);
+                x[1] = *reinterpret_cast<const half8*>(Ahi + kFTM * 64);
+            };
+            half8 xq[2][2];
+            rd1(0, xq[0]);
+#pragma unroll
+            for (int st = 0; st < 12; ++st) {
+                if (st + 1 < 12) rd1(st + 1, xq[(st + 1) & 1]);
+                if (t == 1 && st >= 12 - kRing) load_w2(st - (12 - kRing), w2r[st - (12 - kRing)]);   // the first W2 steps, late: a ring
+                const half8 wh = wfr[st >> 2][st & 3][0], wl = wfr[st >> 2][st & 3][1];             // live during this GEMM spills
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xq[st & 1][0], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xq[st & 1][1], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xq[st & 1][0], acc1, 0, 0, 0);
+                if (st + 1 < 12) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                   // the reads first,
+                if (t == 1 && st >= 12 - kRing) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);     // then the W2 requests,
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                    // then the MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- relu(acc1 + b1) -> hid image (B operand of GEMM 2: rows = tokens, 8-unit chunks, swizzled as every operand image).
+            // Registers 4 g .. 4 g + 3 of a lane are units 32 wave + 8 g + 4 kh .. + 3 of token 32 t + li: half a chunk, 8 bytes.
             const int m = tile * kFTM + row;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int u0 = wave * 32 + 8 * g4 + 4 * kh;
-                const float4 b4 = *reinterpret_cast<const float4*>(a.bias + u0);
-                float y[4] = {acc1[t][4 * g4] + b4.x, acc1[t][4 * g4 + 1] + b4.y, acc1[t][4 * g4 + 2] + b4.z, acc1[t][4 * g4 + 3] + b4.w};
+                const float4 b4 = *reinterpret_cast<const float4*>(bsh + u0);
+                float y[4] = {acc1[4 * g4] + b4.x, acc1[4 * g4 + 1] + b4.y, acc1[4 * g4 + 2] + b4.z, acc1[4 * g4 + 3] + b4.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = y[e] > 0.f ? y[e] : 0.f;
                 if constexpr (KEEP) {
@@ -801,40 +848,46 @@ __global__ __launch_bounds__(kFThreads, 1) void raype_onepass_kernel(RayFusedArg
                 *reinterpret_cast<u32x2*>(Hh + kFTM * 64) = u32x2{__builtin_bit_cast(unsigned int, l01), __builtin_bit_cast(unsigned int, l23)};
             }
         }
+        PARQ_RP_STAMP(1);
         __syncthreads();                                                  // hid complete
-        // ---- GEMM 2: rows = channels, columns = tokens (as raype_tokens_kernel); W2 four steps ahead
-        f32x16 acc2[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
-#pragma unroll
-        for (int step = 0; step < 16; ++step) {
-            const int ks = step >> 2, s2 = step & 3;
-            const _Float16* Ahi = hid + ks * kStep;
-            const _Float16* Alo = Ahi + kFTM * 64;
-            half8 xh[2], xl[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
+        PARQ_RP_STAMP(2);
+        // ---- GEMM 2 on top of the feature tile: rows = channels, columns = tokens (as raype_tokens_kernel); W2 four steps ahead
+        // in half steps (one k-step of one 32-token block): the fragments of half step n + 1 are requested in front of the MFMAs of
+        // half step n, a ring slot is refilled as soon as its step has been issued (sched_barrier pins that order: left alone, hipcc
+        // folds the ring into one slot and sinks the reads, and every step waits for an L2 round trip and an LDS latency)
+        {
+            auto rd2 = [&](int hs, half8 (&x)[2]) {
+                const int step = hs >> 1, t = hs & 1, ks = step >> 2, s2 = step & 3;
                 const int row = t * 32 + li;
                 const int posr = (4 * kh + s2) ^ ((row >> 1) & 7);
-                xh[t] = *reinterpret_cast<const half8*>(Ahi + row * 64 + posr * 8);
-                xl[t] = *reinterpret_cast<const half8*>(Alo + row * 64 + posr * 8);
+                const _Float16* Ahi = hid + ks * kStep + row * 64 + posr * 8;
+                x[0] = *reinterpret_cast<const half8*>(Ahi);
+                x[1] = *reinterpret_cast<const half8*>(Ahi + kFTM * 64);
+            };
+            half8 xq[2][2];
+            rd2(0, xq[0]);
+#pragma unroll
+            for (int hs = 0; hs < 32; ++hs) {
+                const int step = hs >> 1, t = hs & 1;
+                if (hs + 1 < 32) rd2(hs + 1, xq[(hs + 1) & 1]);
+                if (t == 0 && step >= 1 && step - 1 + kRing < 16) load_w2(step - 1 + kRing, w2r[(step - 1) % kRing]);
+                const half8 wh = w2r[step % kRing][0], wl = w2r[step % kRing][1];
+                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xq[hs & 1][0], acc2[t], 0, 0, 0);
+                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xq[hs & 1][1], acc2[t], 0, 0, 0);
+                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xq[hs & 1][0], acc2[t], 0, 0, 0);
+                if (hs + 1 < 32) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                if (t == 0 && step >= 1 && step - 1 + kRing < 16) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            const half8 wh = w2r[step & 3][0], wl = w2r[step & 3][1];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[t], acc2[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[t], acc2[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[t], acc2[t], 0, 0, 0);
-            if (step + 4 < 16) load_w2(step + 4, w2r[step & 3]);
         }
+        PARQ_RP_STAMP(3);
         __syncthreads();                                                  // hid is free: ot overlays it
+        PARQ_RP_STAMP(4);
         // ---- epilogue (as raype_tokens_kernel): + features + b2, NCHW encoding lane-contiguous, or channels-last rows through ot
         {
             const int bv0 = (tile * kFTM) / a.hw;
-            __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (a.nchw_out ? (int64_t)bv0 * kFC * a.hw : 0)), 0, 0x7fffffff, 0x00020000);
+            __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (NCHW ? (int64_t)bv0 * kFC * a.hw : 0)), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int m = tile * kFTM + t * 32 + li;
@@ -844,10 +897,9 @@ __global__ __launch_bounds__(kFThreads, 1) void raype_onepass_kernel(RayFusedArg
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int c0 = wave * 32 + 8 * g4 + 4 * kh;
-                    const float4 b4 = *reinterpret_cast<const float4*>(a.bias2 + c0);
-                    const float y[4] = {acc2[t][4 * g4] + fr[t][4 * g4] + b4.x, acc2[t][4 * g4 + 1] + fr[t][4 * g4 + 1] + b4.y,
-                                        acc2[t][4 * g4 + 2] + fr[t][4 * g4 + 2] + b4.z, acc2[t][4 * g4 + 3] + fr[t][4 * g4 + 3] + b4.w};
-                    if (a.nchw_out) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(bsh + kFC + c0);
+                    const float y[4] = {acc2[t][4 * g4] + b4.x, acc2[t][4 * g4 + 1] + b4.y, acc2[t][4 * g4 + 2] + b4.z, acc2[t][4 * g4 + 3] + b4.w};
+                    if constexpr (NCHW) {
                         if (ok) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
@@ -859,21 +911,40 @@ __global__ __launch_bounds__(kFThreads, 1) void raype_onepass_kernel(RayFusedArg
                 }
             }
         }
-        if (!a.nchw_out) {
-            __syncthreads();
+        const bool more = tile + P < ntiles;
+        if (more) { if constexpr ((PROBE & 32) != 0) load_features(tile + P); }
+        const float* otw = ot + wave * 8 * kOtLd + 4 * lane;              // one LDS address, the rows as immediate offsets
+        auto store_rows = [&](int r0, int r1) {
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                const int row = wave * 8 + rr;
-                const int m = tile * kFTM + row;
+            for (int rr = r0; rr < r1; ++rr) {
+                const int m = tile * kFTM + wave * 8 + rr;
                 if (m < a.M && (PROBE & 8) == 0)
-                    *reinterpret_cast<float4*>(a.out + (int64_t)m * kFC + 4 * lane) =
-                        *reinterpret_cast<const float4*>(ot + row * kOtLd + 4 * lane);
+                    *reinterpret_cast<float4*>(a.out + (int64_t)m * kFC + 4 * lane) = *reinterpret_cast<const float4*>(otw + rr * kOtLd);
             }
-        }
-        // ---- the next tile's operand image while the row stores drain (every wave is done with pts since the first barrier)
-        if constexpr ((PROBE & 2) == 0) { if (tile + P < ntiles) generate(tile + P); }
+        };
+        PARQ_RP_STAMP(5);
+        if constexpr (!NCHW) __syncthreads();
+        PARQ_RP_STAMP(6);
+        // ---- row stores and the next tile's operand image in turns (every wave is done with pts since the first barrier): a
+        // wave's stores stall at issue while the write path is full, the generator's vector work fills that time
+        if constexpr (!NCHW) store_rows(0, (PROBE & 64) ? 8 : 3);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr ((PROBE & 2) == 0) { if (more) { gen_setup(tile + P); gen_chunk(0); } }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!NCHW) if ( (PROBE & 64) == 0) store_rows(3, 6);
+        __builtin_amdgcn_sched_barrier(0);
+        PARQ_RP_STAMP(7);
+        if constexpr ((PROBE & 2) == 0) { if (more) gen_chunk(1); }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!NCHW) if ( (PROBE & 64) == 0) store_rows(6, 8);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr ((PROBE & 2) == 0) { if (more) gen_chunk(2); }
+        PARQ_RP_STAMP(8);
         __syncthreads();                                                 // pts complete; ot (= hid) free for the next tile
+        PARQ_RP_STAMP(9);
+        if constexpr ((PROBE & 16) != 0) ++tcount;
     }
+#undef PARQ_RP_STAMP
 }
 
 }  // namespace
@@ -931,16 +1002,61 @@ hipError_t launch_raype_fused(const float* cam, const float* T_cp, const float* 
                                reinterpret_cast<const _Float16*>(W2lo), reinterpret_cast<_Float16*>(W2f));
         a.W2f = reinterpret_cast<const _Float16*>(W2f); a.bias2 = b2;
         a.feat = feat; a.out = out; a.nchw_out = nchw_out;
-        if (hidden) {
+        if (hidden && nchw_out) {
+            static DynLdsOnce once_kn;
+            if (hipError_t e = once_kn.ensure(reinterpret_cast<const void*>(&raype_onepass_kernel<true, 0, true>), lds_f); e != hipSuccess) return e;
+            hipLaunchKernelGGL((raype_onepass_kernel<true, 0, true>), dim3(P), dim3(kFThreads), lds_f, s, a, ntiles, P);
+        } else if (hidden) {
             if (hipError_t e = once_k.ensure(reinterpret_cast<const void*>(&raype_onepass_kernel<true>), lds_f); e != hipSuccess) return e;
             hipLaunchKernelGGL(raype_onepass_kernel<true>, dim3(P), dim3(kFThreads), lds_f, s, a, ntiles, P);
+        } else if (nchw_out) {
+            static DynLdsOnce once_nn;
+            if (hipError_t e = once_nn.ensure(reinterpret_cast<const void*>(&raype_onepass_kernel<false, 0, true>), lds_f); e != hipSuccess) return e;
+            hipLaunchKernelGGL((raype_onepass_kernel<false, 0, true>), dim3(P), dim3(kFThreads), lds_f, s, a, ntiles, P);
         } else {
 #ifdef PARQ_DEV_PROBES
             static const int probe = [] { const char* e = dev_env("PARQ_RAYPE_PROBE"); return e ? atoi(e) : 0; }();
 #define PARQ_RP(PB) case PB: { static DynLdsOnce o; if (hipError_t e = o.ensure(reinterpret_cast<const void*>(&raype_onepass_kernel<false, PB>), lds_f); e != hipSuccess) return e; \
                                hipLaunchKernelGGL((raype_onepass_kernel<false, PB>), dim3(P), dim3(kFThreads), lds_f, s, a, ntiles, P); return hipGetLastError(); }
-            switch (probe) { PARQ_RP(1) PARQ_RP(2) PARQ_RP(3) PARQ_RP(4) PARQ_RP(8) PARQ_RP(15) default: break; }
+            switch (probe) { PARQ_RP(1) PARQ_RP(2) PARQ_RP(3) PARQ_RP(4) PARQ_RP(8) PARQ_RP(15) PARQ_RP(32) PARQ_RP(64) PARQ_RP(128) PARQ_RP(96) PARQ_RP(160) PARQ_RP(192) PARQ_RP(224) PARQ_RP(256) default: break; }
 #undef PARQ_RP
+            if (probe == 16) {                                            // phase stamps: printed to stderr, synchronises
+                static unsigned long long* sbuf = nullptr;
+                const size_t sbytes = (size_t)P * 2 * 160 * 8;
+                if (!sbuf && hipMalloc(&sbuf, sbytes) != hipSuccess) return hipErrorOutOfMemory;
+                (void)hipMemsetAsync(sbuf, 0, sbytes, s);
+                static DynLdsOnce o;
+                if (hipError_t e = o.ensure(reinterpret_cast<const void*>(&raype_onepass_kernel<false, 16>), lds_f); e != hipSuccess) return e;
+                a.hidden = reinterpret_cast<float*>(sbuf);
+                hipLaunchKernelGGL((raype_onepass_kernel<false, 16>), dim3(P), dim3(kFThreads), lds_f, s, a, ntiles, P);
+                (void)hipStreamSynchronize(s);
+                std::vector<unsigned long long> hb((size_t)P * 2 * 160);
+                (void)hipMemcpy(hb.data(), sbuf, sbytes, hipMemcpyDeviceToHost);
+                static int calls = 0;
+                if (++calls == 5) {
+                    const char* nm[10] = {"top", "gemm1+hid", "barrier1", "gemm2", "barrier2", "epilogue->ot", "barrier3", "row stores", "generate", "barrier4"};
+                    for (int wv = 0; wv < 2; ++wv) {
+                        double acc[10] = {0}; int n = 0; double tot = 0;
+                        for (int pp = 0; pp < P; ++pp)
+                            for (int t = 1; t < 10; ++t) {                // tiles 1..9 (steady state)
+                                const unsigned long long* r = hb.data() + ((size_t)pp * 2 + wv) * 160 + t * 10;
+                                if (!r[9]) continue;
+                                for (int k = 1; k < 10; ++k) acc[k] += (double)(r[k] - r[k - 1]) * 10.0;
+                                tot += (double)(r[9] - r[0]) * 10.0; ++n;
+                            }
+                        fprintf(stderr, "[raype stamps] wave %d: %d tiles, %.0f ns per tile:", wv ? 5 : 0, n, tot / n);
+                        for (int k = 1; k < 10; ++k) fprintf(stderr, " %s %.0f", nm[k], acc[k] / n);
+                        fprintf(stderr, "\n");
+                    }
+                    const unsigned long long* r0 = hb.data();
+                    unsigned long long lo = ~0ull, hi = 0;
+                    for (int pp = 0; pp < P; ++pp) { const unsigned long long* r = hb.data() + (size_t)pp * 2 * 160; if (r[0] && r[0] < lo) lo = r[0];
+                        for (int t = 0; t < 16; ++t) if (r[t * 10 + 9] > hi) hi = r[t * 10 + 9]; }
+                    (void)r0;
+                    fprintf(stderr, "[raype stamps] first tile top -> last tile end over all workgroups: %.1f us\n", (double)(hi - lo) * 0.01);
+                }
+                return hipGetLastError();
+            }
 #endif
             if (hipError_t e = once_n.ensure(reinterpret_cast<const void*>(&raype_onepass_kernel<false>), lds_f); e != hipSuccess) return e;
             hipLaunchKernelGGL(raype_onepass_kernel<false>, dim3(P), dim3(kFThreads), lds_f, s, a, ntiles, P);
