@@ -16,7 +16,6 @@
 #include "common.hpp"
 #include <cstdlib>
 #include <cstdio>
-#include <type_traits>
 #include <vector>
 
 namespace parq {
@@ -608,21 +607,33 @@ __global__ __launch_bounds__(kFThreads, 1) void raype_tokens_kernel(RayFusedArgs
 
 
 // ------------------------------------------------------------------------------------------------
-// ONE-PASS form (round 4): tokens = feat + relu(p W1^T + b1) W2^T + b2 with the 64-token hidden tile kept in LDS — the 197 MB
+// ONE-PASS form (round 4, re-scheduled in round 5): tokens = feat + relu(p W1^T + b1) W2^T + b2 with the 64-token hidden tile kept in LDS — the 197 MB
 // hidden tensor of the two-kernel form above (written by raype_hidden_kernel, re-read by raype_tokens_kernel: 786 MB moved for
 // 393 MB algorithmic at BASELINE cfg 3) never exists.  model/ray_positional_encoding.py:128-136 is one MLP.
 //
 //   registers  W1 fragments of the wave's 32 hidden units for the whole launch (96 VGPRs, as in raype_hidden_kernel); W2 does
 //              NOT fit beside them (128 more), so its fragments are STREAMED per k-step from a fragment-ordered copy
 //              (raype_pack_w2_kernel: one wave-wide 16-byte load = one contiguous KB, L2-resident 256 KB shared by every CU),
-//              four (k-step, s2) steps ahead of the MFMAs (ring of 4 x 8 VGPRs); the feature tile is loaded in the accumulator
-//              layout into the registers the first GEMM's accumulators leave free, in flight during the second GEMM
-//   LDS        pts [3 k-steps][hi | lo][64 x 64] 48 KB (generated, single buffer: refilled for the next tile beside the second
-//              GEMM) | hid [4 k-steps][hi | lo][64 x 64] 64 KB, overlaid by the epilogue's transpose tile ot[64][260] 65 KB
-//   per tile   GEMM 1 TRANSPOSED (rows = hidden units, columns = tokens: a lane's 4 consecutive registers are 4 consecutive
-//              units of one token = one 8-byte piece of the hid image) | relu, split, hid image; feature loads issued | barrier |
-//              GEMM 2 (rows = channels, columns = tokens, as raype_tokens_kernel) | barrier | + features + bias, transpose
-//              through ot | barrier | one 1 KB row per store instruction, generate(next tile) while they drain | barrier
+//              four (k-step, s2) steps ahead of the MFMAs (ring of 4 x 8 VGPRs, primed behind the first GEMM); the feature
+//              tile is loaded at the top of a tile straight INTO the second GEMM's accumulators (no separate registers, no
+//              add in the epilogue).  NO SPILLS (round 5): vector memory returns in order, so one scratch reload inside the
+//              tile waits for every feature load and row store in front of it — GEMM 1 runs one 32-token block at a time
+//              (one accumulator set), image indices are stepped instead of divided, the transpose rows share one LDS address
+//   LDS        hid [4 k-steps][hi | lo][64 x 64] 64 KB at offset 0, overlaid by the epilogue's transpose tile ot[64][260]
+//              65 KB | pts [3 k-steps][hi | lo][64 x 64] 48 KB (generated, single buffer) | b1, b2 2 KB (a bias load from
+//              memory inside the tile would queue behind the feature loads) | depth table
+//   per tile   features requested | GEMM 1 TRANSPOSED, block by block (rows = hidden units, columns = tokens: a lane's 4
+//              consecutive registers are 4 consecutive units of one token = one 8-byte piece of the hid image), relu, split,
+//              hid image | barrier | GEMM 2 in half steps (rows = channels, columns = tokens) | barrier | + b2, transpose
+//              through ot | barrier | row stores (1 KB per instruction) in turns with the pieces of generate(next tile) |
+//              barrier.  In both GEMMs the operand fragments of step n + 1 are requested in front of the MFMAs of step n and
+//              the order is pinned with sched_group_barrier / sched_barrier: left alone, hipcc sinks every LDS read to its
+//              first use and folds the W2 ring into one slot, and each step waits for an LDS latency and an L2 round trip.
+//   measured   (profiles/r05_raype.txt) AddRayPE.tokens at cfg 3: 0.244 -> 0.18 ms.  What is left adds up by construction:
+//              matrix + vector work of one SIMD do not overlap on this part (GEMMs + relu/split 107 us, generator 28 us), and the
+//              feature loads / row stores (25 + 25-35 us) run at the ~12 B/clk a CU gets from memory, with the waves blocked
+//              at issue.  A phased form (generator inside GEMM 2, row stores inside the next GEMM 1, or stores straight from
+//              the accumulators with two barriers per tile) measured the same and was not kept (commit fc35854).
 // KEEP: training keeps the fp32 hidden layer for parq_ray_pe_backward (16-byte pieces; the inference path writes nothing).
 __global__ void raype_pack_w2_kernel(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo, _Float16* __restrict__ out) {
     // out[wave 8][ks 4][s2 4][hl 2][lane 64][8] <- W{hl}[col = 32 wave + (lane & 31)][k = 64 ks + 32 (lane >> 5) + 8 s2 + e]
@@ -773,9 +784,6 @@ __global__ __launch_bounds__(kFThreads, 1) void raype_onepass_kernel(RayFusedArg
         }
     };
 
-    if constexpr ((PROBE & 512) != 0) {                                   // odd workgroups half a tile late: the chip's feature / store bursts in two shifts
-        if (p & 1) { for (int q = 0; q < (PROBE >> 10); ++q) __builtin_amdgcn_s_sleep(127); }
-    }
     if (p < ntiles) {
         gen_setup(p);
 #pragma unroll
@@ -952,318 +960,6 @@ __global__ __launch_bounds__(kFThreads, 1) void raype_onepass_kernel(RayFusedArg
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// PHASED form of the one-pass kernel (round 5): the same arithmetic, the tile loop re-cut so that no phase is vector-only or
-// memory-only while the matrix pipe idles.  The next tile's operand image is generated in slices placed between the dependent
-// MFMAs of the second GEMM (the first GEMM has released the operand buffer by then); the row stores of a tile leave between the
-// MFMAs of the NEXT tile's first block:
-//   P1  feature tile requested (into the second GEMM's accumulators) | GEMM 1 block 0  ||  row stores of the tile before
-//   -- barrier A: ot (= hid) read out
-//   P2  relu -> hid (block 0) | GEMM 1 block 1 | relu -> hid (block 1)
-//   -- barrier 1: hid complete, operand image free
-//   P3  GEMM 2  ||  the next tile's operand image
-//   -- barrier 2: hid free, next operand image complete
-//   P4  + b2 -> ot (or the NCHW stores)
-//   -- barrier 3: ot complete
-// Four barriers per tile as before; generator, row stores and feature loads no longer have a phase of their own.
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
-}
-
-template <bool KEEP, int PROBE = 0, bool NCHW = false>
-__global__ __launch_bounds__(kFThreads, 1) void raype_phased_kernel(RayFusedArgs a, int ntiles, int P) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
-    __shared__ double dtab[64];
-    __shared__ __attribute__((aligned(16))) float bsh[2 * kFC];        // b1 | b2 (a bias load from memory would queue behind the features)
-    constexpr int kStep = 2 * kFTM * 64;                                // halfs per k-step (hi + lo)
-    _Float16* hid = lds;                                                // 4 k-steps at offset 0 (fragment reads = lane address + immediate)
-    float* ot = reinterpret_cast<float*>(hid);                          // [64][kOtLd] over hid, after the second GEMM
-    _Float16* pts = lds + kFTM * kOtLd * 2;                             // 3 k-steps, behind ot (65 KB)
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, kh = lane >> 5;
-    const int p = blockIdx.x;
-    if (tid < 64) dtab[tid] = tid < a.S ? a.depth[tid] : 1.0;
-    bsh[tid] = tid < kFC ? a.bias[tid] : a.bias2[tid - kFC];
-    const int col = wave * 32 + li;                                     // this lane's row of W1 (A operand of the transposed product)
-    half8 wfr[3][4][2];
-#pragma unroll
-    for (int ks = 0; ks < 3; ++ks)
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-            const int64_t off = (int64_t)col * kFK1 + ks * 64 + 32 * kh + 8 * s2;
-            wfr[ks][s2][0] = *reinterpret_cast<const half8*>(a.Whi + off);
-            wfr[ks][s2][1] = *reinterpret_cast<const half8*>(a.Wlo + off);
-        }
-    __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.W2f + (int64_t)wave * 4 * 4 * 2 * 64 * 8), 0, 4 * 4 * 2 * 64 * 16, 0x00020000);
-    auto load_w2 = [&](int step, half8 (&dst)[2]) {
-        if constexpr ((PROBE & 1) != 0) { if (step >= 4) return; }
-        dst[0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(w2rs, lane * 16, (step * 2) * 1024, 0));
-        dst[1] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(w2rs, lane * 16, (step * 2 + 1) * 1024, 0));
-    };
-    __syncthreads();
-
-    // ---- generator (arithmetic of raype_hidden_kernel's): this wave's block, token row and depth group
-    const int grow = lane;                                               // thread = (token row of the tile, depth group = wave):
-    const int dg = wave;                                                 // depths 8 dg .. 8 dg + 7 = k 24 dg .. 24 dg + 23 = chunks 3 dg ..
-    double G[3], T3[3];
-    float x8[8];
-    auto gen_setup = [&](int tile) {
-        const int m = tile * kFTM + grow;
-        G[0] = G[1] = G[2] = 0.0; T3[0] = T3[1] = T3[2] = 0.5;
-        const int bv0 = (tile * kFTM) / a.hw;                             // scalar
-        const int mlast = min(tile * kFTM + kFTM - 1, a.M - 1);
-        const bool one_image = mlast / a.hw == bv0;                       // scalar: pose and intrinsics through s_load (vector loads
-        float cm[4]; double T[12];                                        // would queue behind the row stores and the features)
-        if (one_image) {
-            typedef const float __attribute__((address_space(4)))* kcf;
-            typedef const double __attribute__((address_space(4)))* kcd;
-            kcf c = (kcf)(a.cam + (int64_t)bv0 * 6 + 2);
-            kcd t = (kcd)(a.Tl + (int64_t)bv0 * 12);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) cm[i] = c[i];
-#pragma unroll
-            for (int i = 0; i < 12; ++i) T[i] = t[i];
-        } else {
-            int bv = bv0;
-            for (int q = min(m, a.M - 1) - bv0 * a.hw; q >= a.hw; q -= a.hw) ++bv;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) cm[i] = a.cam[(int64_t)bv * 6 + 2 + i];
-#pragma unroll
-            for (int i = 0; i < 12; ++i) T[i] = a.Tl[(int64_t)bv * 12 + i];
-        }
-        if (m < a.M) {
-            int pix = m - bv0 * a.hw;
-            while (pix >= a.hw) pix -= a.hw;
-            const int y = pix / a.w, x = pix - y * a.w;
-            const double rx = ((double)x - (double)cm[2]) / (double)cm[0];
-            const double ry = ((double)y - (double)cm[3]) / (double)cm[1];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                G[i] = (T[i * 3] * rx + T[i * 3 + 1] * ry + T[i * 3 + 2]) * a.inv[i];
-                T3[i] = (T[9 + i] - a.lo[i]) * a.inv[i];
-            }
-        }
-    };
-    // one value (v = 8 i + e: element e of this thread's chunk i) and, with the eighth, the chunk's two LDS writes
-    auto gen_value = [&](auto V) {
-        constexpr int v = decltype(V)::value;
-        constexpr int i = v / 8, e = v % 8;
-        constexpr int jj = v / 3, ax = v - 3 * jj;
-        // u and 1 - u in float64 (the inverse-sigmoid is ill-conditioned at the clamp edges), the clamps on their fp32
-        // roundings: rounding is monotone, so max / min commute with it and the values equal the all-float64 clamps
-        const double u = dtab[8 * dg + jj] * G[ax] + T3[ax];
-        const float uf = (float)u, wf = (float)(1.0 - u);
-        const float x1 = fmaxf(fminf(uf, 1.f), 1e-3f);                     // max(clamp(u, 0, 1), 1e-3)
-        const float x2 = fmaxf(fminf(wf, 1.f), 1e-3f);                     // max(1 - clamp(u, 0, 1), 1e-3)
-        x8[e] = __logf(__fdividef(x1, x2));
-        if constexpr (e == 7) {
-            half8 hi, lo8;
-            split8(x8, hi, lo8);
-            const int chunk = 3 * dg + i;
-            const int ks = chunk >> 3, c = chunk & 7;
-            const int pos = c ^ ((grow >> 1) & 7);
-            _Float16* Ahi = pts + ks * kStep + grow * 64 + pos * 8;
-            *reinterpret_cast<half8*>(Ahi) = hi;
-            *reinterpret_cast<half8*>(Ahi + kFTM * 64) = lo8;
-        }
-    };
-
-    // ---- the feature tile straight into the second GEMM's accumulators (see raype_onepass_kernel)
-    f32x16 acc2[2];
-    auto load_features = [&](int tile) {
-        const int bv0 = (tile * kFTM) / a.hw;
-        const float* fbase = (a.feat ? a.feat : a.bias) + (int64_t)bv0 * kFC * a.hw;
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)fbase, 0, a.feat ? 0x7fffffff : 0, 0x00020000);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int m = tile * kFTM + t * 32 + li;
-            const bool ok = m < a.M;
-            int dbv = 0, pix = ok ? m - bv0 * a.hw : 0;
-            while (pix >= a.hw) { pix -= a.hw; ++dbv; }
-            const int voff = ((dbv * kFC + wave * 32 + 4 * kh) * a.hw + pix) * 4;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int soff = (8 * (r >> 2) + (r & 3)) * a.hw * 4;
-                if constexpr ((PROBE & 4) != 0) acc2[t][r] = 0.f;
-                else acc2[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
-            }
-        }
-    };
-
-    // ---- GEMM 1 of one block with something between its MFMAs: `between(st)` runs after the first MFMA of step st
-    auto gemm1 = [&](int t, f32x16& acc1, auto&& between, auto&& late) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
-        const int row = t * 32 + li;
-        auto rd1 = [&](int st, half8 (&x)[2]) {
-            const int ks = st >> 2, s2 = st & 3;
-            const int posr = (4 * kh + s2) ^ ((row >> 1) & 7);
-            const _Float16* Ahi = pts + ks * kStep + row * 64 + posr * 8;
-            x[0] = *reinterpret_cast<const half8*>(Ahi);
-            x[1] = *reinterpret_cast<const half8*>(Ahi + kFTM * 64);
-        };
-        half8 xq[2][2];
-        rd1(0, xq[0]);
-        static_for<0, 12>([&](auto ST) {
-            constexpr int st = decltype(ST)::value;
-            if constexpr (st + 1 < 12) rd1(st + 1, xq[(st + 1) & 1]);    // fragments one step ahead (pinned: hipcc sinks them otherwise)
-            late(ST);
-            const half8 wh = wfr[st >> 2][st & 3][0], wl = wfr[st >> 2][st & 3][1];
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xq[st & 1][0], acc1, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            between(ST);
-            __builtin_amdgcn_sched_barrier(0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xq[st & 1][1], acc1, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xq[st & 1][0], acc1, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    };
-    // relu(acc1 + b1) -> hid image (B operand of GEMM 2: rows = tokens, 8-unit chunks, swizzled as every operand image).
-    // Registers 4 g .. 4 g + 3 of a lane are units 32 wave + 8 g + 4 kh .. + 3 of token 32 t + li: half a chunk, 8 bytes.
-    auto relu_to_hid = [&](int tile, int t, const f32x16& acc1) {
-        const int row = t * 32 + li;
-        const int m = tile * kFTM + row;
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const int u0 = wave * 32 + 8 * g4 + 4 * kh;
-            const float4 b4 = *reinterpret_cast<const float4*>(bsh + u0);
-            float y[4] = {acc1[4 * g4] + b4.x, acc1[4 * g4 + 1] + b4.y, acc1[4 * g4 + 2] + b4.z, acc1[4 * g4 + 3] + b4.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = y[e] > 0.f ? y[e] : 0.f;
-            if constexpr (KEEP) {
-                if (m < a.M) *reinterpret_cast<float4*>(a.hidden + (int64_t)m * kFC + u0) = float4{y[0], y[1], y[2], y[3]};
-            }
-            half2v h01, l01, h23, l23;
-            split_pair(y[0], y[1], h01, l01);
-            split_pair(y[2], y[3], h23, l23);
-            const int ks2 = wave >> 1, c = (wave & 1) * 4 + g4;
-            const int pos = c ^ ((row >> 1) & 7);
-            _Float16* Hh = hid + ks2 * kStep + row * 64 + pos * 8 + 4 * kh;
-            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<u32x2*>(Hh) = u32x2{__builtin_bit_cast(unsigned int, h01), __builtin_bit_cast(unsigned int, h23)};
-            *reinterpret_cast<u32x2*>(Hh + kFTM * 64) = u32x2{__builtin_bit_cast(unsigned int, l01), __builtin_bit_cast(unsigned int, l23)};
-        }
-    };
-    // one row (1 KB) of the tile before: ot -> registers -> memory
-    const float* otw = ot + wave * 8 * kOtLd + 4 * lane;
-    auto store_row = [&](int tile, int rr) {
-        const int m = tile * kFTM + wave * 8 + rr;
-        if (m < a.M && (PROBE & 8) == 0)
-            *reinterpret_cast<float4*>(a.out + (int64_t)m * kFC + 4 * lane) = *reinterpret_cast<const float4*>(otw + rr * kOtLd);
-    };
-
-    // ---- prologue: the first tile's operand image, both blocks at once
-    if (p < ntiles) {
-        gen_setup(p);
-        static_for<0, 24>([&](auto V) { gen_value(V); });
-    }
-    __syncthreads();
-
-    constexpr int kRing = 3;                                              // (k-step, s2) steps of W2 fragments in flight
-    constexpr bool DIRECT = NCHW || (PROBE & 32) != 0;                   // no transpose tile: the epilogue stores from the accumulators
-    int prev = -1;                                                        // the tile whose rows are still in ot
-    for (int tile = p; tile < ntiles; tile += P) {
-        // the next tile's operand image is generated unconditionally (a workgroup's last tile generates its own tile again, unused):
-        // under `if (next tile exists)` the generator's state (ray, eight pending values) is live around the whole loop
-        const int gtile = tile + P < ntiles ? tile + P : tile;
-        half8 w2r[kRing][2];
-        // ---- P1
-        load_features(tile);
-        f32x16 acc1a;
-        gemm1(0, acc1a,
-              [&](auto ST) { constexpr int st = decltype(ST)::value; if constexpr (!DIRECT && st < 8) { if (prev >= 0) store_row(prev, st); } },
-              [&](auto) {});
-        if constexpr (!DIRECT) __syncthreads();                           // A: ot read out
-        // ---- P2
-        relu_to_hid(tile, 0, acc1a);
-        f32x16 acc1b;
-        gemm1(1, acc1b,
-              [&](auto) {},
-              [&](auto ST) { constexpr int st = decltype(ST)::value;                                       // the first W2 steps
-                             if constexpr (st >= 12 - kRing) load_w2(st - (12 - kRing), w2r[st - (12 - kRing)]); });
-        relu_to_hid(tile, 1, acc1b);
-        __syncthreads();                                                  // 1: hid complete, operand block 1 free
-        // ---- P3: GEMM 2 on top of the feature tile, in half steps (one k-step of one 32-token block)
-        {
-            auto rd2 = [&](int hs, half8 (&x)[2]) {
-                const int step = hs >> 1, t = hs & 1, ks = step >> 2, s2 = step & 3;
-                const int row = t * 32 + li;
-                const int posr = (4 * kh + s2) ^ ((row >> 1) & 7);
-                const _Float16* Ahi = hid + ks * kStep + row * 64 + posr * 8;
-                x[0] = *reinterpret_cast<const half8*>(Ahi);
-                x[1] = *reinterpret_cast<const half8*>(Ahi + kFTM * 64);
-            };
-            half8 xq[2][2];
-            rd2(0, xq[0]);
-            if constexpr ((PROBE & 2) == 0) gen_setup(gtile);
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<0, 32>([&](auto HS) {
-                constexpr int hs = decltype(HS)::value;
-                constexpr int step = hs >> 1, t = hs & 1;
-                if constexpr (hs + 1 < 32) rd2(hs + 1, xq[(hs + 1) & 1]);
-                if constexpr (t == 0 && step >= 1 && step - 1 + kRing < 16) load_w2(step - 1 + kRing, w2r[(step - 1) % kRing]);
-                const half8 wh = w2r[step % kRing][0], wl = w2r[step % kRing][1];
-                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xq[hs & 1][0], acc2[t], 0, 0, 0);
-                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xq[hs & 1][1], acc2[t], 0, 0, 0);
-                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xq[hs & 1][0], acc2[t], 0, 0, 0);
-                // one generated value per half step, its vector instructions spread behind the three (dependent) MFMAs: both waves of
-                // a SIMD run this code in step, so a coarse slice would leave the matrix pipe idle while both generate
-                if constexpr (hs < 24 && (PROBE & 2) == 0) gen_value(std::integral_constant<int, hs>{});
-                if constexpr (hs + 1 < 32) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                if constexpr (t == 0 && step >= 1 && step - 1 + kRing < 16) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        }
-        __syncthreads();                                                  // 2: hid free (ot overlays it), next operand image complete
-        // ---- P4: + b2 (the features are already in the accumulators); NCHW encoding lane-contiguous, or channels-last rows via ot
-        {
-            const int bv0 = (tile * kFTM) / a.hw;
-            __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (NCHW ? (int64_t)bv0 * kFC * a.hw : 0)), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int m = tile * kFTM + t * 32 + li;
-                const bool ok = m < a.M;
-                int dbv = 0, pix = ok ? m - bv0 * a.hw : 0;
-                while (pix >= a.hw) { pix -= a.hw; ++dbv; }
-                const int voff = ((dbv * kFC + wave * 32 + 4 * kh) * a.hw + pix) * 4;
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int c0 = wave * 32 + 8 * g4 + 4 * kh;
-                    const float4 b4 = *reinterpret_cast<const float4*>(bsh + kFC + c0);
-                    const float y[4] = {acc2[t][4 * g4] + b4.x, acc2[t][4 * g4 + 1] + b4.y, acc2[t][4 * g4 + 2] + b4.z, acc2[t][4 * g4 + 3] + b4.w};
-                    if constexpr (NCHW) {
-                        if (ok) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, y[e]), ors, voff, (8 * g4 + e) * a.hw * 4, 0);
-                        }
-                    } else if constexpr (DIRECT) {
-                        // 16 bytes per lane straight into the channels-last row: lanes 0-31 = 32 token rows, lanes 32-63 the next 16
-                        // bytes of the same rows; the four g4 pieces of a wave complete one 128-byte line per row
-                        if (ok && (PROBE & 8) == 0) *reinterpret_cast<float4*>(a.out + (int64_t)m * kFC + c0) = float4{y[0], y[1], y[2], y[3]};
-                    } else {
-                        *reinterpret_cast<float4*>(ot + (t * 32 + li) * kOtLd + c0) = float4{y[0], y[1], y[2], y[3]};
-                    }
-                }
-            }
-        }
-        if constexpr (!DIRECT) __syncthreads();                           // 3: ot complete
-        prev = tile;
-    }
-    if constexpr (!DIRECT) {
-        if (prev >= 0) {
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) store_row(prev, rr);
-        }
-    }
-}
-
 }  // namespace
 
 hipError_t launch_raype_points(const float* cam, const float* T_cp, const float* T_wp, const float* T_wl,
@@ -1319,26 +1015,6 @@ hipError_t launch_raype_fused(const float* cam, const float* T_cp, const float* 
                                reinterpret_cast<const _Float16*>(W2lo), reinterpret_cast<_Float16*>(W2f));
         a.W2f = reinterpret_cast<const _Float16*>(W2f); a.bias2 = b2;
         a.feat = feat; a.out = out; a.nchw_out = nchw_out;
-#ifdef PARQ_DEV_PROBES
-        static const int v2 = [] { const char* e = dev_env("PARQ_RAYPE_V2"); return e ? atoi(e) : 0; }();
-#else
-        constexpr int v2 = 0;
-#endif
-        if (v2) {
-#define PARQ_RP2(K, PB, N) { static DynLdsOnce o; if (hipError_t e = o.ensure(reinterpret_cast<const void*>(&raype_phased_kernel<K, PB, N>), lds_f); e != hipSuccess) return e; \
-                             hipLaunchKernelGGL((raype_phased_kernel<K, PB, N>), dim3(P), dim3(kFThreads), lds_f, s, a, ntiles, P); return hipGetLastError(); }
-#ifdef PARQ_DEV_PROBES
-            static const int probe2 = [] { const char* e = dev_env("PARQ_RAYPE_PROBE"); return e ? atoi(e) : 0; }();
-            if (!hidden && !nchw_out) switch (probe2) { case 1: PARQ_RP2(false, 1, false) case 2: PARQ_RP2(false, 2, false) case 4: PARQ_RP2(false, 4, false)
-                                                        case 8: PARQ_RP2(false, 8, false) case 15: PARQ_RP2(false, 15, false) case 32: PARQ_RP2(false, 32, false)
-                                                        case 34: PARQ_RP2(false, 34, false) case 36: PARQ_RP2(false, 36, false) case 40: PARQ_RP2(false, 40, false) case 47: PARQ_RP2(false, 47, false) default: break; }
-#endif
-            if (hidden && nchw_out) PARQ_RP2(true, 0, true)
-            if (hidden) PARQ_RP2(true, 0, false)
-            if (nchw_out) PARQ_RP2(false, 0, true)
-            PARQ_RP2(false, 0, false)
-#undef PARQ_RP2
-        }
         if (hidden && nchw_out) {
             static DynLdsOnce once_kn;
             if (hipError_t e = once_kn.ensure(reinterpret_cast<const void*>(&raype_onepass_kernel<true, 0, true>), lds_f); e != hipSuccess) return e;
@@ -1355,7 +1031,7 @@ hipError_t launch_raype_fused(const float* cam, const float* T_cp, const float* 
             static const int probe = [] { const char* e = dev_env("PARQ_RAYPE_PROBE"); return e ? atoi(e) : 0; }();
 #define PARQ_RP(PB) case PB: { static DynLdsOnce o; if (hipError_t e = o.ensure(reinterpret_cast<const void*>(&raype_onepass_kernel<false, PB>), lds_f); e != hipSuccess) return e; \
                                hipLaunchKernelGGL((raype_onepass_kernel<false, PB>), dim3(P), dim3(kFThreads), lds_f, s, a, ntiles, P); return hipGetLastError(); }
-            switch (probe) { PARQ_RP(1) PARQ_RP(2) PARQ_RP(3) PARQ_RP(4) PARQ_RP(8) PARQ_RP(15) PARQ_RP(32) PARQ_RP(64) PARQ_RP(128) PARQ_RP(96) PARQ_RP(160) PARQ_RP(192) PARQ_RP(224) PARQ_RP(256) PARQ_RP(1536) PARQ_RP(2560) PARQ_RP(3584) PARQ_RP(4608) default: break; }
+            switch (probe) { PARQ_RP(1) PARQ_RP(2) PARQ_RP(3) PARQ_RP(4) PARQ_RP(8) PARQ_RP(15) PARQ_RP(32) PARQ_RP(64) PARQ_RP(128) PARQ_RP(96) PARQ_RP(160) PARQ_RP(192) PARQ_RP(224) PARQ_RP(256) default: break; }
 #undef PARQ_RP
             if (probe == 16) {                                            // phase stamps: printed to stderr, synchronises
                 static unsigned long long* sbuf = nullptr;
