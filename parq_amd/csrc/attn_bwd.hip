@@ -837,9 +837,11 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
     auto tile_dma = [&](int n, int slot) {
         const int it = n / ntiles, tile = n - it * ntiles;
         const char* src = reinterpret_cast<const char*>(pack + (((int64_t)it * gridDim.y + bh) * ntiles + tile) * kImgHalfs);
-        const unsigned dst = (unsigned)(size_t)(lds_byte*)(Stg + slot * kImgHalfs);
-        lds_dma16(src + (size_t)tid * 16, dst + wave * 1024);
-        lds_dma16(src + 8192 + (size_t)tid * 16, dst + 8192 + wave * 1024);
+        // destination = a SCALAR (the wave index through readfirstlane): kept as a vector value it was spilled, and its scratch reload at
+        // the top of every tile — vector memory retires in order — waited for the dQ stores the waitcnt above deliberately leaves in flight
+        const unsigned dst = (unsigned)(size_t)(lds_byte*)(Stg + slot * kImgHalfs) + __builtin_amdgcn_readfirstlane(wave) * 1024;
+        lds_dma16(src + (size_t)tid * 16, dst);
+        lds_dma16(src + 8192 + (size_t)tid * 16, dst + 8192);
         if (tid < 32) lds_dma16(src + 16384 + (size_t)tid * 16, dst + 16384);
     };
     // per-lane pieces of the transpose reads (constant over the tiles)

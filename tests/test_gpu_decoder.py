@@ -405,6 +405,30 @@ def test_ray_pe_vs_fp64_oracle_larger_grid():
     assert rel_err(tok.cpu().numpy(), want.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("B,V,h,w", [(2, 3, 5, 7), (1, 5, 3, 4), (3, 2, 9, 13)])
+def test_ray_pe_one_pass_kernel_on_images_smaller_than_a_tile(B, V, h, w):
+    """The one-pass kernel's 64-token tiles over images of fewer than 64 pixels (a tile touches up to six images: the image index of
+    a token is stepped, the pose goes through the per-lane path) and a ragged last tile; tokens and the NCHW encoding alone, against
+    the float64 oracle."""
+    from parq_amd import AddRayPE
+    Cd = 256
+    Wp = synth.make_ray_pe_weights(Cd, 41)
+    cam, T_cp, T_wp, T_wl = synth.make_geometry(42, B, V, h, w)
+    scale = synth.DEFAULT_SCALE
+    pe = AddRayPE(Cd, scale, 64, 0.25, 5.25)
+    pe.load_state_dict({k: torch.from_numpy(v) for k, v in Wp.items()}, strict=True)
+    pe = pe.cuda().eval()
+    feat = dev(synth.normal(43, "feat3", (B, V, Cd, h, w)))
+    with torch.no_grad():
+        tok = pe.tokens(feat, dev(cam), dev(T_cp), dev(T_wp), dev(T_wl))
+        enc = pe(feat, dev(cam), dev(T_cp), dev(T_wp), dev(T_wl))
+        enc64 = O.ray_pe(cam, T_cp, T_wp, T_wl, Wp, scale, dtype=torch.float64)
+    want = O.tokenize(feat.cpu().double(), enc64)
+    assert rel_err(tok.cpu().numpy(), want.numpy()) < 2e-5
+    assert tuple(enc.shape) == (B, V, Cd, h, w)
+    assert rel_err(enc.cpu().numpy(), enc64.reshape(enc.shape).numpy()) < 2e-5
+
+
 def test_parq_module_forward_matches_oracle_pipeline():
     """PARQ.forward (ray-PE + tokenisation + decoder, model/parq_lightning.py:68-95) vs the float64 oracle
     pipeline on a small synthetic batch, first iteration (free-running start)."""
