@@ -518,7 +518,10 @@ class PARQDecoder(nn.Module):
         drivers.  ``handle``: the native handle already switched to the mode of this call (else ``attention_mode`` is applied)."""
         if handle is None:
             handle = self._handle()                   # first: a pending mode change drops the cached workspaces (their carving differs)
-        k = (B, V, h, w, str(device))
+        # keyed by the launch stream too: forwards enqueued on different streams (two scenes in flight: the small-op chain of one
+        # leaves most of the chip to the K/V projection and cross-attention of the other, +18 % throughput at BASELINE cfg 3,
+        # profiles/r05_two_in_flight.txt) each own a workspace; a workspace is allocated, used and freed in the order of ONE stream
+        k = (B, V, h, w, str(device), int(torch.cuda.current_stream(device).cuda_stream))
         ws = self._ws.pop(k, None)
         if ws is None:
             nbytes = _lib.load().parq_workspace_bytes(handle, B, V, h, w)
@@ -868,7 +871,7 @@ class PARQDecoder(nn.Module):
         building the 16-bit K/V cache (synchronises; meaningful in the "split" and "fp16" modes).  Outputs of such a call are
         NaN by construction (include/parq_hip.h); see ``range_check`` for the automatic handling."""
         if self._ws:
-            (B, V, h, w, _), ws = list(self._ws.items())[-1]        # the most recently used workspace
+            (B, V, h, w, _, _), ws = list(self._ws.items())[-1]        # the most recently used workspace
         elif self._train_ws is not None and self._train_state is not None:
             sc = self._train_state[0]
             (B, V, h, w), ws = (sc.B, sc.V, sc.h, sc.w), self._train_ws
@@ -883,7 +886,7 @@ class PARQDecoder(nn.Module):
         forward in "split" before returning."""
         if not self._ws:
             return False
-        (B, V, h, w, _), ws = list(self._ws.items())[-1]
+        (B, V, h, w, _, _), ws = list(self._ws.items())[-1]
         return bool(self._flag_view(ws, B, V, h, w, 2)[1].item() != 0)
 
     def attention_peaked_map(self):
@@ -891,7 +894,7 @@ class PARQDecoder(nn.Module):
         under the guard threshold (synchronises).  The guard acts per head; this map says in which iterations."""
         if not self._ws:
             return []
-        (B, V, h, w, _), ws = list(self._ws.items())[-1]
+        (B, V, h, w, _, _), ws = list(self._ws.items())[-1]
         f = self._flag_view(ws, B, V, h, w, 64).tolist()
         return [f[8 + (k % 56)] for k in range(self.num_layers)]
 
@@ -901,7 +904,7 @@ class PARQDecoder(nn.Module):
         every head's smallest sum instead — heads on the fp16 x 3 tier included (what ``tier_return_after`` looks at)."""
         if not self._ws:
             return None
-        (B, V, h, w, _), ws = list(self._ws.items())[-1]
+        (B, V, h, w, _, _), ws = list(self._ws.items())[-1]
         dec = lambda code: float(np.array([0x7fffffff - code], dtype=np.int32).view(np.float32)[0]) if code else None
         if per_head:
             f = self._flag_view(ws, B, V, h, w, 48).tolist()
