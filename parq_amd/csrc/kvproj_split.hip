@@ -673,6 +673,13 @@ hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void*
         if (terms == 8 && N % 64 == 0 && C == 256) {          // development: the mode-4 epilogue with one kind of store removed (results wrong)
             static const int probe8 = [] { const char* e = dev_env("PARQ_KVPROJ_PROBE8"); return e ? atoi(e) : 0; }();
             switch (probe8) {
+                case 1: return launch_dma_nk<64, 8, kF16, 4, 4, 1>(a, B, s);          // the ingredient bits of PARQ_KVPROJ_PROBE on the mode-4 kernel
+                case 2: return launch_dma_nk<64, 8, kF16, 4, 4, 2>(a, B, s);
+                case 4: return launch_dma_nk<64, 8, kF16, 4, 4, 4>(a, B, s);
+                case 16: return launch_dma_nk<64, 8, kF16, 4, 4, 16>(a, B, s);
+                case 17: return launch_dma_nk<64, 8, kF16, 4, 4, 17>(a, B, s);
+                case 21: return launch_dma_nk<64, 8, kF16, 4, 4, 21>(a, B, s);
+                case 29: return launch_dma_nk<64, 8, kF16, 4, 4, 29>(a, B, s);
                 case 32: return launch_dma_nk<64, 8, kF16, 4, 4, 32>(a, B, s);
                 case 64: return launch_dma_nk<64, 8, kF16, 4, 4, 64>(a, B, s);
                 case 128: return launch_dma_nk<64, 8, kF16, 4, 4, 128>(a, B, s);

@@ -645,8 +645,10 @@ __global__ void raype_pack_w2_kernel(const _Float16* __restrict__ hi, const _Flo
     *reinterpret_cast<half8*>(out + (int64_t)i * 8) = *reinterpret_cast<const half8*>(src);
 }
 
-// PROBE (development only, results wrong when non-zero): 1 W2 fragments loaded once instead of per tile, 2 operand image generated
-// once, 4 no feature loads, 8 no token stores — what each ingredient costs when it is taken out
+// PROBE (development library only, PARQ_RAYPE_PROBE).  Ingredients taken out, results wrong: 1 W2 fragments loaded once instead of per
+// tile, 2 operand image generated once, 4 no feature loads, 8 no token stores.  Results right: 16 s_memrealtime stamps per phase (printed
+// by the launcher), 32 feature tile requested one tile ahead instead of at the tile top, 64 all row stores before the generator,
+// 128 pose through per-lane loads, 256 W2 ring of three (tools/r05_raype_variants.sh, profiles/r05_raype.txt)
 template <bool KEEP, int PROBE = 0, bool NCHW = false>
 __global__ __launch_bounds__(kFThreads, 1) void raype_onepass_kernel(RayFusedArgs a, int ntiles, int P) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
