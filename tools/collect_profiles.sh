@@ -31,4 +31,6 @@ python tools/pmc_summary.py $(find $out -name "*counter_collection.csv" | sort) 
 python tools/make_pmc_json.py $out > $out/pmc.json 2> $out/pmc_json.err
 cp $(find $out/kt -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv 2>/dev/null
 find $out -name "*kernel_trace.csv" -size +200k -delete
+# gpurun merges at most 64 MiB back: the per-dispatch counter tables have been summarised above
+find $out -name "*counter_collection.csv" -size +1M -delete; find $out -name "*.db" -delete
 ls -la $out | head -40
