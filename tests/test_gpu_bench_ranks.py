@@ -68,3 +68,26 @@ def test_bench_eight_ranks_launcher_smoke():
     iters = 8 * d["config"]["scenes_per_gpu"] * 8 * d["steps"]
     assert abs(d["value"] - iters / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
     assert "dp8" in d["config"]["parallelism"]
+
+
+def test_bench_single_rank_default_line_contract():
+    """The driver's N = 1 command (fewer steps, without the CPU baseline and the optional records): ONE JSON line with the contract's
+    fields, the roofline object of the dominant kernel, and the sub-records measured beside `value` — the strict fp16 x 3 run and two
+    scenes in flight on two HIP streams, whose outputs must be bit for bit those of one-at-a-time forwards."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-b32",
+                        "--no-peaked", "--no-pmc"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["unit"] == "decoder-iterations/sec" and d["higher_is_better"] is True
+    assert abs(d["value"] - 8 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and 0.2 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    two = d["two_scenes_in_flight"]
+    assert two["streams"] == 2 and two["outputs_bit_identical_to_one_at_a_time"] is True
+    assert two["value"] > 0.95 * d["value"]                      # never slower than one at a time (measured + 15-18 %)
+    assert d["strict_fp16x3"]["attention_mode"] == "split" and d["strict_fp16x3"]["value"] < d["value"]
