@@ -87,6 +87,8 @@ class AddRayPE(nn.Module):
         self.encoder = nn.Sequential(nn.Linear(3 * num_samples, dim_out), nn.ReLU(), nn.Linear(dim_out, dim_out))
         self._ws = None
         self._ws_key = None               # what the weight copies inside ``_ws`` were made from (see _run)
+        self._ws_stream = None            # the launch stream ``_ws`` belongs to, and the parked (workspace, key) pairs of other streams:
+        self._ws_parked = {}              # calls on different HIP streams (parq_amd.InFlight) each own their pose tables and weight copies
         self._gen = 0                     # forward counter, stamped on the workspace it wrote (``_parq_gen``)
         self._ws_owner = None             # weak reference to the _WsHold of the autograd node that owns ``_ws`` (if any)
         self.dp_all_reduce = False        # True: the backward all-reduces (mean) the encoder gradients over the default process group
@@ -110,6 +112,12 @@ class AddRayPE(nn.Module):
             assert features.shape == (B, V, Cd, h, w), tuple(features.shape)
         lib = _lib.load()
         self._gen += 1
+        sid = int(torch.cuda.current_stream(dev).cuda_stream)
+        if sid != self._ws_stream:        # another stream's call may still be reading this workspace: park it, take this stream's own
+            if self._ws is not None:
+                self._ws_parked[self._ws_stream] = (self._ws, self._ws_key)
+            self._ws, self._ws_key = self._ws_parked.pop(sid, (None, None))
+            self._ws_stream = sid
         # include/parq_hip.h: 1 = NCHW output, 2 = inference (the hidden layer is not kept for a backward: on the one-pass path it
         # never leaves the CU and the workspace shrinks by B*V*h*w*C floats)
         fused = Cd == 256 and self.num_samples == 64          # the library's one-pass path can write (B, V, C, h, w) directly

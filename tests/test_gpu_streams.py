@@ -68,3 +68,91 @@ def test_workspace_of_a_stream_is_reused_by_that_stream_only():
             assert next(reversed(dec._ws.values())) is not ws1
     torch.cuda.synchronize()
     assert len(dec._ws) == 2
+
+
+def test_inflight_runner_matches_one_at_a_time_calls():
+    """parq_amd.InFlight: four scenes through a depth-2 runner (inputs produced on the caller's stream right before each submit, outputs
+    consumed on the caller's stream after result()) against one-at-a-time calls — bit-identical, in submission order."""
+    from parq_amd import InFlight
+    V, h, w, Q, dim, I = 4, 60, 80, 64, 256, 2
+    cfg = synth.decoder_cfg(dim=dim, queries=Q, heads=4, ffn=256, layers=I)
+    W = synth.make_decoder_weights(cfg, 331, damped=True)
+    dec = make_decoder(cfg, W).eval()
+    dec.range_check = "off"
+    host = [scene_args(_scene(340 + i, V, h, w, dim)) for i in range(4)]
+    with torch.no_grad():
+        want = []
+        for a in host:
+            outs = dec(*a, feat_hw=(h, w))
+            want.append([{k: v.clone() for k, v in o.items()} for o in outs])
+        torch.cuda.synchronize()
+        runner = InFlight(dec, depth=2)
+        assert runner.depth == 2 and dec.max_workspaces >= 2
+        for rep in range(3):
+            tickets, got = [], []
+            for i, a in enumerate(host):
+                fresh = tuple(t.clone() if torch.is_tensor(t) else t for t in a)      # produced on the current stream, dropped right after
+                tickets.append(runner.submit(*fresh, feat_hw=(h, w)))
+                del fresh
+                if len(tickets) == 2:
+                    got.append(tickets.pop(0).result())
+            while tickets:
+                got.append(tickets.pop(0).result())
+            sums = [sum(float(o[k].double().sum()) for o in outs for k in o) for outs in got]      # consumed on the caller's stream
+            torch.cuda.synchronize()
+            for i in range(4):
+                for k in range(I):
+                    for key in want[i][k]:
+                        assert torch.equal(got[i][k][key], want[i][k][key]), (rep, i, k, key)
+            assert all(s == s for s in sums)
+        runner.drain()
+
+
+def test_inflight_runner_over_the_whole_module_ray_pe_and_decoder():
+    """InFlight over parq_amd.PARQ (model/parq_lightning.py:68-95: ray-PE + tokenisation + decoder, d = 256 = the one-pass ray-PE
+    kernel): AddRayPE keeps a workspace (pose tables, weight copies) per launch stream like the decoder does; three different batches
+    through a depth-2 runner equal one-at-a-time calls bit for bit."""
+    from types import SimpleNamespace as NS
+    from parq_amd import PARQ, Camera, Pose, InFlight
+    from gpu_util import dev
+    B, V, h, w, Cd, Qn = 1, 3, 24, 32, 256, 32
+    dcfg = synth.decoder_cfg(dim=Cd, queries=Qn, heads=4, ffn=192, layers=2)
+    scale = dcfg.TRANSFORMER.SCALE
+    cfg = NS(MODEL=NS(TOKENIZER=NS(OUT_CHANNELS=Cd, RAY_POINTS_SCALE=scale, NUM_SAMPLES=64, MIN_DEPTH=0.25, MAX_DEPTH=5.25),
+                      DECODER=dcfg))
+    model = PARQ(cfg).eval()
+    W = synth.make_decoder_weights(dcfg, 351, damped=True)
+    Wp = synth.make_ray_pe_weights(Cd, 352)
+    sd = model.state_dict()
+    for k in sd:
+        if k.startswith("box3d_decoder."):
+            src = k[len("box3d_decoder."):].replace("parq_module.decoder.mlp_heads.", "mlp_heads.")
+            sd[k] = torch.from_numpy(W[src]).reshape(sd[k].shape)
+        else:
+            sd[k] = torch.from_numpy(Wp[k[len("add_ray_pe."):]])
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda()
+    model.box3d_decoder.range_check = "off"
+
+    def batch(seed):
+        cam, T_cp, T_wp, T_wl = synth.make_geometry(seed, B, V, h, w)
+        feat = synth.normal(seed + 1, "feat", (B, V, Cd, h, w), std=0.5)
+        return {"all_features": dev(feat), "camera_feature": Camera(dev(cam)), "T_camera_pseudoCam": Pose(dev(T_cp)),
+                "T_world_pseudoCam": Pose(dev(T_wp)), "T_world_local": Pose(dev(T_wl))}
+    batches = [batch(360 + 10 * i) for i in range(3)]
+    with torch.no_grad():
+        want = []
+        for b in batches:
+            _, outs = model(dict(b), 0)
+            want.append([{k: v.clone() for k, v in o.items()} for o in outs])
+        torch.cuda.synchronize()
+        runner = InFlight(model, depth=2)
+        for rep in range(3):
+            tickets = [runner.submit(dict(b), 0) for b in batches]
+            got = [t.result()[1] for t in tickets]
+            torch.cuda.synchronize()
+            for i in range(3):
+                for k in range(2):
+                    for key in want[i][k]:
+                        assert torch.equal(got[i][k][key], want[i][k][key]), (rep, i, k, key)
+    assert len(model.add_ray_pe._ws_parked) + 1 >= 2                  # one ray-PE workspace per stream

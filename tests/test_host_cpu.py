@@ -219,3 +219,15 @@ def test_layernorm_pushed_through_the_query_projection_is_an_identity():
     rstd = 1.0 / np.sqrt(Q / C - mu * mu + eps)
     got = rstd[:, None] * (U - mu[:, None] * q_s) + V
     assert np.abs(got - want).max() < 1e-10 * max(1.0, np.abs(want).max())
+
+
+def test_inflight_helper_is_importable_without_a_gpu_and_finds_the_tensors_of_a_call():
+    """parq_amd.InFlight (several forwards of one module in flight): the module imports on a CPU-only host, and its argument walker
+    finds plain tensors, the package's wrappers and tensors inside containers — the ones it must hand to record_stream."""
+    import torch
+    import parq_amd
+    from parq_amd import inflight, Pose
+    assert parq_amd.InFlight is inflight.InFlight
+    a, b, c = torch.zeros(2), torch.ones(1, 12), torch.zeros(3)
+    found = list(inflight._tensors(((a, {"pose": Pose(b), "n": 3}), {"kw": [c, "text"]})))
+    assert len(found) == 3 and found[0] is a and found[1].shape == (1, 12) and found[2] is c
