@@ -677,7 +677,6 @@ __global__ __launch_bounds__(kFThreads, 1) void raype_onepass_kernel(RayFusedArg
     // W2 fragments of (wave, step = 4 ks + s2): two pieces [hi, lo] of 1 KB each, lane-contiguous (raype_pack_w2_kernel)
     // (buffer loads: one lane offset, the piece as a scalar offset — 32 separate 64-bit addresses would cost 64 VGPRs)
     __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.W2f + (int64_t)wave * 4 * 4 * 2 * 64 * 8), 0, 4 * 4 * 2 * 64 * 16, 0x00020000);
-    typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
     auto load_w2 = [&](int step, half8 (&dst)[2]) {
         if constexpr ((PROBE & 1) != 0) { if (step >= 4) return; }
         dst[0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(w2rs, lane * 16, (step * 2) * 1024, 0));
@@ -688,7 +687,7 @@ __global__ __launch_bounds__(kFThreads, 1) void raype_onepass_kernel(RayFusedArg
     const int grow = tid & 63;
     // the operand image of a tile (as raype_hidden_kernel), in two steps so that the row stores of the tile before can be issued
     // between its pieces: gen_setup = the ray of this thread's token (G, T3), gen_chunk(i) = eight values of axis-chunk i.
-    // The pose and intrinsics come through SCALAR loads when the whole tile lies in one image (h w % 64 == 0: always): vector
+    // The pose and intrinsics come through SCALAR loads when the whole tile lies in one image (always when h w is a multiple of 64): vector
     // loads would queue behind the row stores just issued and the generator would wait for their acknowledgement.
     double G[3], T3[3];
     auto gen_setup = [&](int tile) {
@@ -865,7 +864,7 @@ __global__ __launch_bounds__(kFThreads, 1) void raype_onepass_kernel(RayFusedArg
         PARQ_RP_STAMP(1);
         __syncthreads();                                                  // hid complete
         PARQ_RP_STAMP(2);
-        // ---- GEMM 2 on top of the feature tile: rows = channels, columns = tokens (as raype_tokens_kernel); W2 four steps ahead
+        // ---- GEMM 2 on top of the feature tile: rows = channels, columns = tokens (as raype_tokens_kernel); W2 kRing steps ahead,
         // in half steps (one k-step of one 32-token block): the fragments of half step n + 1 are requested in front of the MFMAs of
         // half step n, a ring slot is refilled as soon as its step has been issued (sched_barrier pins that order: left alone, hipcc
         // folds the ring into one slot and sinks the reads, and every step waits for an L2 round trip and an LDS latency)
