@@ -146,8 +146,16 @@ int parq_set_attention_mode(parq_handle h, int32_t mode);
  * 0: outputs stay numbers (reduced accuracy on those rows), flags and mirror are raised all the same.
  * The reference has one arithmetic (fp32, model/transformer_parq.py:377-380); this call only chooses how its result is approximated. */
 int parq_set_head_tiers(parq_handle h, uint32_t safe_mask, int32_t poison_on_peaked);
+/* In-launch hand-offs of the small-op chain (default on).  At d = 256 the self-attention out-projection and the cross-attention
+ * query projection behind norm1 (model/transformer_parq.py:375-377) run as ONE launch whose query tiles wait, in their epilogue, for the
+ * LayerNorm row sums the other tiles publish (chain.hip seam_tile).  The wait is bounded: if a producer workgroup has not published
+ * within ~0.1 s — which needs a dispatch order no HIP implementation has shown, the waiting tiles are placed behind the tiles they wait
+ * for — the launch gives up, the forward's outputs are NaN, workspace "flags"[0] gets bit 2 and the range mirror bit 2.  `on` = 0 runs
+ * every dependent stage as its own launch (placement-independent; about 1 % slower at BASELINE cfg 3); the Python class does this by
+ * itself after such a timeout.  Results of the two forms differ by fp32 rounding (the LayerNorm is pushed through the projection). */
+int parq_set_seam_fusion(parq_handle h, int32_t on);
 /* Optional: a host-visible, device-writable int32 (pinned host memory, e.g. hipHostMalloc) in which the device sets bit 0 whenever
- * it poisons outputs because of a range violation (above), and bit 1 plus bit 8 + h when head h of attention mode 4 met a
+ * it poisons outputs because of a range violation (above), bit 2 when an in-launch hand-off timed out (parq_set_seam_fusion), and bit 1 plus bit 8 + h when head h of attention mode 4 met a
  * too-peaked row (above; outputs poisoned only if parq_set_head_tiers asked for it).  Lets a host poll for events of earlier, already finished calls with a plain load — no stream synchronisation,
  * nothing extra on the forward path.  NULL switches it off. */
 int parq_set_range_mirror(parq_handle h, int32_t *host_visible_flag);

@@ -62,6 +62,7 @@ SYMBOLS = {
     "parq_workspace_lookup": (C.c_int, [_vp, _i32, _i32, _i32, _i32, C.c_char_p, C.POINTER(_sz), C.POINTER(_sz)]),
     "parq_set_attention_mode": (C.c_int, [_vp, _i32]),
     "parq_set_head_tiers": (C.c_int, [_vp, C.c_uint32, _i32]),
+    "parq_set_seam_fusion": (C.c_int, [_vp, _i32]),
     "parq_set_range_mirror": (C.c_int, [_vp, _vp]),
     "parq_shard_exchange_floats": (_sz, [_vp, _i32, _i32]),
     "parq_iterate_sharded": (C.c_int, [_vp, C.POINTER(ParqScene), _vp, _sz, _i32, _i32, _vp, C.POINTER(ParqOutputs), _vp, _vp, _vp, _i32, _vp]),

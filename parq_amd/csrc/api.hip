@@ -137,6 +137,7 @@ struct parq_ctx {
     int w16_state() const { return attn_mode == 4 ? 1 : attn_mode; }      // what the 16-bit copy of W_kv has to hold
     int kind() const { return attn_mode == 3 ? kBF16 : kF16; }
     int* range_mirror = nullptr;      // host-visible word raised when outputs are poisoned (parq_set_range_mirror)
+    bool seam_fusion = true;          // parq_set_seam_fusion: in-launch hand-offs of the chain (0 = every dependent stage its own launch)
     bool bwd_batched_env = true;      // parq_set_backward_batched (the parity test compares the two settings)
     int bwd_streams = 8;              // parq_set_backward_streams: iterations of the chain backward in flight at once (1 = in turn)
     float dim_t_host[128];            // 10000^(2*(i//2)/128): uploaded by parq_pack_weights from this persistent buffer (no stream sync)
@@ -492,7 +493,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     const bool fold_pos = !train && !fold_off && chain_linear_supported(self_in_args(true), 1) && chain_linear_supported(cross_q_args(true), 1);
     // the norm1 seam (self out-projection | cross-attention query projection) as ONE launch (chain.hip seam_tile): inference at d = 256
     static const int seams = [] { const char* e = dev_env("PARQ_FUSE_SEAMS"); return e ? atoi(e) : 1; }();      // 0: self out-projection and query projection as two launches (A/B)
-    const bool seam_ok = !train && !sharded && fold_pos && C == 256 && TP != nullptr && M % 16 == 0;
+    const bool seam_ok = !train && !sharded && fold_pos && C == 256 && TP != nullptr && M % 16 == 0 && c->seam_fusion;
 
     if (sh.mask & 1) {
     // K3: sine embedding (written by the previous iteration's decode kernel when chained) -> position MLP
@@ -1366,6 +1367,12 @@ int parq_set_head_tiers(parq_handle h, uint32_t safe_mask, int32_t poison_on_pea
     if ((safe_mask & h->all_heads()) != h->safe_heads()) h->prepared = false;      // the K/V cache is laid out per tier
     h->safe_mask = safe_mask;
     h->peaky_poison = poison_on_peaked ? 1 : 0;
+    return PARQ_OK;
+}
+
+int parq_set_seam_fusion(parq_handle h, int32_t on) {
+    if (!h) return fail(PARQ_ERR_ARG, "NULL handle");
+    h->seam_fusion = on != 0;
     return PARQ_OK;
 }
 

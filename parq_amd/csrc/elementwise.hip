@@ -248,12 +248,14 @@ __global__ __launch_bounds__(256) void box_decode_kernel(BoxDecodeArgs a) {
     const int lane = threadIdx.x & 63;
     const int C = a.C;
     const int scene = m / a.rows_per_scene;
-    const bool range_poison = a.poison != nullptr && *a.poison != 0;    // wave-uniform scalar loads
+    const int range_word = a.poison != nullptr ? *a.poison : 0;         // wave-uniform scalar loads.  Bit 2: an in-launch hand-off timed out
+    const bool range_poison = range_word != 0;
     const int peaky = a.peaky != nullptr ? *a.peaky : 0;
     const bool poison = range_poison || (a.peaky_poison && peaky != 0);
-    // tell the host (pinned word): bit 0 range violation, bit 1 + bits 8.. the heads attention mode 4 met too-peaked rows on
+    // tell the host (pinned word): bit 0 range violation, bit 2 hand-off timeout, bit 1 + bits 8.. the heads attention mode 4 met
+    // too-peaked rows on
     if (a.poison_mirror != nullptr && m == 0 && lane == 0 && (range_poison || peaky != 0))
-        atomicOr(a.poison_mirror, (range_poison ? 1 : 0) | (peaky != 0 ? (2 | (peaky << 8)) : 0));
+        atomicOr(a.poison_mirror, ((range_word & ~4) ? 1 : 0) | (range_word & 4) | (peaky != 0 ? (2 | (peaky << 8)) : 0));
     // every independent load is issued before the first dependent use (this kernel is pure latency)
     const float* h1 = a.h1 + (int64_t)m * a.ld1;
     const float lg_in = lane < a.ncls ? h1[lane] : -INFINITY;
@@ -410,12 +412,14 @@ __global__ __launch_bounds__(256) void box_decode256_kernel(BoxDecodeArgs a) {
     const float ms0 = a.mean_sizes[lane < nms ? lane : nms - 1];
     const float ms1 = a.mean_sizes[64 + lane < nms ? 64 + lane : nms - 1];
     __builtin_amdgcn_sched_barrier(0);                                   // keep every load above the first wait
-    const bool range_poison = a.poison != nullptr && *a.poison != 0;    // wave-uniform scalar loads
+    const int range_word = a.poison != nullptr ? *a.poison : 0;         // wave-uniform scalar loads.  Bit 2: an in-launch hand-off timed out
+    const bool range_poison = range_word != 0;
     const int peaky = a.peaky != nullptr ? *a.peaky : 0;
     const bool poison = range_poison || (a.peaky_poison && peaky != 0);
-    // tell the host (pinned word): bit 0 range violation, bit 1 + bits 8.. the heads attention mode 4 met too-peaked rows on
+    // tell the host (pinned word): bit 0 range violation, bit 2 hand-off timeout, bit 1 + bits 8.. the heads attention mode 4 met
+    // too-peaked rows on
     if (a.poison_mirror != nullptr && m == 0 && lane == 0 && (range_poison || peaky != 0))
-        atomicOr(a.poison_mirror, (range_poison ? 1 : 0) | (peaky != 0 ? (2 | (peaky << 8)) : 0));
+        atomicOr(a.poison_mirror, ((range_word & ~4) ? 1 : 0) | (range_word & 4) | (peaky != 0 ? (2 | (peaky << 8)) : 0));
 
     const float lg_in = lane < a.ncls ? lg_raw : -INFINITY;
     const float sz_in = lane < 3 ? sz_raw : 0.f;

@@ -305,6 +305,11 @@ class PARQDecoder(nn.Module):
         # themselves: ``reset_attention_tiers()``); a module whose heads are all safe runs exactly mode "split".
         self.safe_heads = 0
         self._tiers_set = None            # (safe mask, poison) the native handle currently holds
+        # In-launch hand-offs of the small-op chain (include/parq_hip.h parq_set_seam_fusion).  Their wait is bounded; after a timeout
+        # (never observed: it needs the waiting tiles dispatched before the tiles they wait for) the outputs of that forward are NaN,
+        # and the module switches to one launch per dependent stage for good, like the range fallback.
+        self.fuse_seams = True
+        self._seams_set = None
         # range_check = "sync" only (there a wrong guess costs a re-run, never a NaN forward): a head on the fp16 x 3 tier returns to the
         # fast tier after this many CONSECUTIVE forwards in which all of its rows kept a probability sum of at least tier_return_margin x
         # the guard threshold.  0 (default) = heads never return by themselves.
@@ -325,6 +330,12 @@ class PARQDecoder(nn.Module):
                       "the affected outputs are NaN.  Switching attention_mode to 'fp32' (exact fp32 MFMA kernels) for this module."
                       % (self.attention_mode, where), RuntimeWarning, stacklevel=3)
         self.attention_mode = "fp32"
+
+    def _seam_fallback(self, where):
+        import warnings
+        warnings.warn("parq_amd.PARQDecoder: an in-launch hand-off of the decoder chain timed out (%s); the outputs of that forward are NaN.  "
+                      "Switching this module to one launch per dependent stage (fuse_seams = False)." % where, RuntimeWarning, stacklevel=3)
+        self.fuse_seams = False
 
     def _peaky_fallback(self, heads, where):
         """Move the flagged heads (bit mask) of attention mode 'split8' to the fp16 x 3 tier."""
@@ -356,6 +367,8 @@ class PARQDecoder(nn.Module):
             self._range_mirror[0] = 0
             if self.range_check == "off":
                 return
+            if v & 4:
+                self._seam_fallback("detected after an earlier forward")
             if (v & 1) and self.attention_mode in ("split", "split8", "fp16"):
                 self._range_fallback("detected after an earlier forward")
             elif (v & 2) and self.attention_mode == "split8":
@@ -374,7 +387,12 @@ class PARQDecoder(nn.Module):
         flags = self._flag_view(ws, sc.B, sc.V, sc.h, sc.w, 48 if want_calm else 2).tolist()
         if first:
             self._peaky_checked = True
-        if flags[0] != 0 and self.range_check == "sync":
+        if (flags[0] & 4) and self.fuse_seams:                    # a hand-off timed out: re-run with one launch per stage (every policy that looks)
+            self._range_mirror[0] = int(self._range_mirror[0]) & ~5
+            self._seam_fallback("re-running this forward")
+            if not (flags[0] & ~4):
+                return True
+        if (flags[0] & ~4) != 0 and self.range_check == "sync":
             self._range_mirror[0] = 0
             self._range_fallback("re-running this forward")
             return True
@@ -411,6 +429,7 @@ class PARQDecoder(nn.Module):
             self._h = h
             self._mode_set = None
             self._tiers_set = None
+            self._seams_set = None
             self._bwd_batched_set = None
             self._bwd_streams_set = None
             self._train_ws = None
@@ -432,6 +451,9 @@ class PARQDecoder(nn.Module):
         if self._tiers_set != tiers:
             _lib.check(_lib.load().parq_set_head_tiers(self._h, tiers[0], tiers[1]), "parq_set_head_tiers")
             self._tiers_set = tiers
+        if self._seams_set != bool(self.fuse_seams):
+            _lib.check(_lib.load().parq_set_seam_fusion(self._h, int(bool(self.fuse_seams))), "parq_set_seam_fusion")
+            self._seams_set = bool(self.fuse_seams)
         if apply_mode and self._mode_set != self.attention_mode:
             if self.attention_mode not in ATTENTION_MODES:
                 raise ValueError(f"attention_mode must be one of {sorted(ATTENTION_MODES)}")

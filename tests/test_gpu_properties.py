@@ -97,3 +97,46 @@ def test_repeated_forwards_are_bit_identical_with_the_seam_inside_a_launch(B, Qn
                 for k in KEYS:
                     assert torch.equal(out[i][k], first[i][k]), (rep, i, k)
     assert not dec.fp16_range_exceeded()
+
+
+def test_seam_fusion_off_is_the_same_forward_up_to_fp32_rounding_and_the_timeout_policy_switches_it_off():
+    """include/parq_hip.h parq_set_seam_fusion.  (1) With the in-launch hand-off switched off (every dependent stage its own launch:
+    the placement-independent form) the first iteration equals the fused forward up to the rounding of pushing norm1 through the
+    query projection, and switching back reproduces the fused forward bit for bit.  (2) The policy for a hand-off timeout (never
+    observed; simulated by raising bit 2 of the pinned mirror word as the device would): the next call warns, switches the module to
+    the unfused form for good and leaves the attention mode alone."""
+    import warnings
+    B, Qn, Vn, h, w, I = 2, 64, 3, 24, 32, 2
+    cfg = synth.decoder_cfg(dim=256, queries=Qn, heads=4, ffn=768, layers=I)
+    dec = make_decoder(cfg, synth.make_decoder_weights(cfg, 731, damped=True))
+    dec.attention_mode = "split"                  # (2304 keys: the peakedness guard of mode "split8" is not the subject here)
+    dec.range_check = "off"
+    cam, T_cp, T_wp, T_wl = (torch.from_numpy(a).cuda() for a in synth.make_geometry(732, B, Vn, h, w))
+    g = torch.Generator(device="cuda").manual_seed(733)
+    tokens = torch.randn(B, Vn * h * w, 256, device="cuda", generator=g)
+
+    def run():
+        with torch.no_grad():
+            return [{k: v.clone() for k, v in o.items()} for o in dec(tokens, cam, T_cp, T_wp, T_wl, feat_hw=(h, w))]
+    fused = run()
+    dec.fuse_seams = False
+    plain = run()
+    dec.fuse_seams = True
+    again = run()
+    for k in KEYS:
+        assert _rel(plain[0][k], fused[0][k]) < 5e-6, k
+        for i in range(I):
+            assert torch.equal(again[i][k], fused[i][k]), (i, k)
+    # (2) the lazy policy
+    dec.range_check = "lazy"
+    mode = dec.attention_mode
+    run()
+    torch.cuda.synchronize()
+    dec._range_mirror[0] = int(dec._range_mirror[0]) | 4
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        out = run()
+    assert any("hand-off" in str(x.message) for x in rec)
+    assert dec.fuse_seams is False and dec.attention_mode == mode and dec._seams_set is False
+    for k in KEYS:
+        assert torch.equal(out[0][k], plain[0][k]), k
