@@ -336,6 +336,11 @@ def live_pmc(args, B):
     if not os.path.exists(tool):
         _LIVE_PMC["note"] = "rocprofv3 not found"
         return
+    if under_profiler():
+        # this process is itself running under rocprofv3 (tools/collect_profiles.sh): a nested profiler would inherit the outer one's
+        # preload (the GPU is then initialised in the launcher that has to start the child), and hardware counters are exclusive
+        _LIVE_PMC["note"] = "bench.py is itself running under a profiler: no nested rocprofv3 passes"
+        return
     here = os.path.abspath(__file__)
     base = [sys.executable, here, "--pmc-child", "--steps", "2", "--warmup", "1", "--config", args.config, "--scenes-per-gpu", str(B)]
     if args.attention_mode:
@@ -345,7 +350,7 @@ def live_pmc(args, B):
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             with tempfile.TemporaryDirectory(dir="/tmp") as d:
-                env = dict(os.environ, TMPDIR="/tmp")
+                env = scrubbed_env(TMPDIR="/tmp")
                 r = subprocess.run([tool, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + base,
                                    cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
                 if r.returncode != 0:
@@ -363,6 +368,28 @@ def live_pmc(args, B):
         _LIVE_PMC["note"] = "live PMC pass failed: %s" % type(exc).__name__
         return
     _LIVE_PMC.update(by_kernel=res, scenes=B, note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command in this run (two child passes, %.0f s)" % (time.perf_counter() - t0))
+
+
+_PROFILER_ENV = ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_", "ROCPROF_", "ROCP_", "HSA_TOOLS_LIB", "ROCTRACER_", "ROCTX_")
+
+
+def under_profiler():
+    """True when this process was started under rocprofv3 / rocprof (their tool library is preloaded or named in the environment)."""
+    if any("rocprof" in v.lower() or "roctracer" in v.lower() for v in (os.environ.get("LD_PRELOAD", ""), os.environ.get("HSA_TOOLS_LIB", ""))):
+        return True
+    return any(k.startswith(_PROFILER_ENV) for k in os.environ)
+
+
+def scrubbed_env(**extra):
+    """A copy of the environment without anything a profiler put there (for child processes that get a profiler of their own)."""
+    env = {k: v for k, v in os.environ.items() if not k.startswith(_PROFILER_ENV)}
+    pre = [x for x in env.get("LD_PRELOAD", "").replace(":", " ").split() if "rocprof" not in x.lower() and "roctracer" not in x.lower()]
+    if pre:
+        env["LD_PRELOAD"] = ":".join(pre)
+    else:
+        env.pop("LD_PRELOAD", None)
+    env.update(extra)
+    return env
 
 
 def pmc_traffic(kernel, scenes):
@@ -559,7 +586,9 @@ def main():
     ap.add_argument("--no-b32", action="store_true", help="skip the 32-scene project+sample bandwidth measurement (6.3 GB of tokens)")
     ap.add_argument("--no-peaked", action="store_true", help="skip the peaked_workload record (the same workload with sharpened cross-attention)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (roofline.traffic then comes from profiles/rNN_pmc.json)")
-    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # internal: a few forwards of the configuration, no output (live_pmc)
+    ap.add_argument("--pmc-child", "--kernels-only", dest="pmc_child", action="store_true",
+                    help="only the forwards of the configuration (warm-up + steps), nothing measured or printed: the command to put behind "
+                         "`rocprofv3 ... --` so that per-kernel statistics hold the timed workload's kernels and nothing else (live_pmc uses it)")
     ap.add_argument("--train-split8", action="store_true", help="--train: run the training forward in mode split8 (PARQDecoder.train_split8)")
     ap.add_argument("--attention-mode", default=None, choices=["split", "split8", "fp32", "fp16", "bf16"],
                     help="cross-attention arithmetic; default = the library default (split8 at d = 256 / head dim 64: fp16 hi.hi + fp8 cross terms; "
@@ -706,6 +735,45 @@ def main():
         step()
         torch.cuda.synchronize()
 
+    # ---- what the never-NaN default costs: the same K steps under each policy, alternating, after the timed region
+    policy_cost = None
+    if world == 1 and not (args.dev_lib or parq_env()) and dec.attention_mode in ("split", "split8", "fp16"):
+        default_policy = dec.range_check
+
+        def timed(policy, graph):
+            dec.range_check, dec.use_graph = policy, graph
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            host = 0.0
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                th = time.perf_counter()
+                step()
+                host += time.perf_counter() - th
+            torch.cuda.synchronize()
+            dtp = time.perf_counter() - t1
+            return {"value": B * I * args.steps / dtp, "ms_per_step": dtp / args.steps * 1e3, "host_ms_per_call": host / args.steps * 1e3}
+        rounds = [(pol, gr) for _ in range(2) for pol in ("sync", "lazy") for gr in (True, False)]
+        acc = {}
+        for pol, gr in rounds:
+            acc.setdefault((pol, gr), []).append(timed(pol, gr))
+        dec.range_check, dec.use_graph = default_policy, True
+        step()
+        torch.cuda.synchronize()
+        best = lambda k: max(acc[k], key=lambda r: r["value"])
+        policy_cost = {"default_policy": default_policy, "unit": "decoder-iterations/sec",
+                       "sync": best(("sync", True)), "lazy": best(("lazy", True)),
+                       "sync_without_captured_forward": best(("sync", False)), "lazy_without_captured_forward": best(("lazy", False)),
+                       "host_enqueue_ms": best(("lazy", True))["host_ms_per_call"],
+                       "host_enqueue_ms_without_captured_forward": best(("lazy", False))["host_ms_per_call"],
+                       "cost_of_the_default": 1.0 - best(("sync", True))["value"] / best(("lazy", True))["value"],
+                       "note": "same process, after the timed region, %d steps per figure, two alternating repeats (best of each); `value` of the line is "
+                               "measured under the default policy (sync: every forward waits for its stream and reads one pinned word before it "
+                               "returns, and is re-run with safer arithmetic if the device flagged it); lazy = no wait on the forward path (a "
+                               "flagged forward returns NaN); host_enqueue_ms = wall time of the Python call while the device is busy (lazy: "
+                               "nothing waits)" % args.steps}
+
     # ---- two scenes in flight (untimed by the contract, reported beside `value`): the same module called alternately on two HIP
     # streams with two sets of inputs — the small-op chain of one forward leaves most of the chip to the K/V projection and
     # cross-attention of the other.  What a server that keeps a second scene queued gets; `value` stays one forward at a time.
@@ -717,14 +785,21 @@ def main():
         for st in side:
             st.wait_stream(torch.cuda.current_stream(device))
 
+        from parq_amd import InFlight
         serial_out = [[{k: v.clone() for k, v in o.items()} for o in dec(*p_in, feat_hw=(h, w))] for p_in in pair]     # one at a time
         torch.cuda.synchronize()
+        runner = InFlight(dec, depth=2)
         last = [None, None]
 
         def go(n):
+            tickets = []
             for i in range(n):
-                with torch.cuda.stream(side[i & 1]):
-                    last[i & 1] = dec(*pair[i & 1], feat_hw=(h, w))
+                tickets.append((i & 1, runner.submit(*pair[i & 1], feat_hw=(h, w))))
+                if len(tickets) == 2:                              # the default policy's check of a forward happens in result()
+                    j, t = tickets.pop(0)
+                    last[j] = t.result()
+            for j, t in tickets:
+                last[j] = t.result()
         go(8)
         torch.cuda.synchronize()
         n2 = max(40, args.steps)
@@ -735,9 +810,10 @@ def main():
         same = all(torch.equal(a[k], b[k]) for j in (0, 1) for a, b in zip(last[j], serial_out[j]) for k in a)
         del serial_out, last
         in_flight = {"streams": 2, "value": B * I * n2 / dt2, "unit": "decoder-iterations/sec", "ms_per_step": dt2 / n2 * 1e3, "steps": n2,
-                     "outputs_bit_identical_to_one_at_a_time": bool(same),
-                     "note": "one module, forwards enqueued alternately on two HIP streams (a workspace per stream: tests/test_gpu_streams.py, "
-                             "results bit-identical to serial calls); not the contract's `value`"}
+                     "outputs_bit_identical_to_one_at_a_time": bool(same), "policy": dec.range_check,
+                     "note": "one module, parq_amd.InFlight(depth=2): forwards submitted alternately on two HIP streams (a workspace and a "
+                             "captured graph per stream: tests/test_gpu_streams.py, results bit-identical to serial calls); under the default "
+                             "policy every forward is checked in Ticket.result() before its outputs are handed out; not the contract's `value`"}
         del inputs2
 
     if rank == 0 and world == 1 and not args.no_pmc and not (args.dev_lib or parq_env()):
@@ -868,6 +944,9 @@ def main():
             out["strict_fp16x3"] = strict
         if in_flight is not None:
             out["two_scenes_in_flight"] = in_flight
+        if policy_cost is not None:
+            out["guard_policy_cost"] = policy_cost
+            out["host_enqueue_ms"] = policy_cost["host_enqueue_ms"]
         if hasattr(dec, "attention_too_peaked"):
             # mode "split8" is kept only while every cross-attention row spreads over enough keys (its error model); a tripped guard
             # would have switched the module to "split" and `dtype` / `roofline` above would say so

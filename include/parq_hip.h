@@ -159,6 +159,11 @@ int parq_set_seam_fusion(parq_handle h, int32_t on);
  * too-peaked row (above; outputs poisoned only if parq_set_head_tiers asked for it).  Lets a host poll for events of earlier, already finished calls with a plain load — no stream synchronisation,
  * nothing extra on the forward path.  NULL switches it off. */
 int parq_set_range_mirror(parq_handle h, int32_t *host_visible_flag);
+/* Host side of that word: returns its value and clears it in ONE atomic exchange, so that a bit the device raises between a plain
+ * load and a plain store of the host is never lost (several forwards in flight may share a word).  The pointer is read at ENQUEUE
+ * time (and recorded by parq_forward_capture): a caller with several forwards in flight may give every workspace its own word by
+ * calling parq_set_range_mirror before each forward. */
+int32_t parq_mirror_take(int32_t *host_visible_flag);
 
 /* ---- PARQDecoder.forward ---------------------------------------------------------- */
 size_t parq_workspace_bytes(parq_handle h, int32_t B, int32_t V, int32_t hh, int32_t ww);
@@ -167,6 +172,30 @@ size_t parq_workspace_bytes(parq_handle h, int32_t B, int32_t V, int32_t hh, int
  * (model/transformer_parq.py:283-337).  No host synchronisation inside. */
 int parq_forward(parq_handle h, const parq_scene *scene, void *workspace, size_t workspace_bytes,
                  const parq_outputs *outs, parq_stream stream);
+
+/* A captured forward.  The reference's loop stalls the host every iteration
+ * (model/transformer_parq.py:135,301; utils/parq_utils.py:96-98); parq_forward only enqueues, but its ~90 launches still cost the
+ * host ~0.35 ms per call.  parq_forward_capture records the I ITERATIONS of a forward of shape (B, V, hh, ww) in `workspace` — the
+ * same kernels with the same arguments as parq_forward enqueues, hence bit-identical results — into a HIP graph, WITHOUT running
+ * anything.  parq_forward_replay is then parq_forward for a call of that shape: it launches the prologue and the K/V projection
+ * directly, with THIS call's pointers, and replays the graph behind them (3 host calls instead of ~90; the graph launch overlaps the
+ * K/V projection on the device).  The recorded iterations hold no pointer of any particular call: the prologue launch leaves the
+ * call's token / output pointers and a copy of its cameras in the workspace, and the kernels that need them load them from there — so
+ * one graph serves every call of its shape, whatever tensors the caller passes.  What the graph DOES hold: the workspace, the packed
+ * weight arena, the range mirror word, and the handle's attention settings (mode, head tiers, seam fusion) at capture time;
+ * parq_forward_replay checks all of them and returns PARQ_ERR_STATE on a mismatch (capture again; parq_amd.PARQDecoder keys its graphs
+ * the same way and captures on the second forward of a kind).
+ * `stream` of parq_forward_capture: the stream of the first replay; the derived inference weights are built on it first if they are
+ * not yet (they must not become part of the graph).  The capture itself runs on a stream of the handle's own in relaxed mode (the
+ * caller's may be the legacy default stream) and launches nothing.  Not while parq_profile_enable is on.
+ * parq_graph_destroy: only after every replay of the graph has completed. */
+typedef struct parq_graph *parq_graph_t;
+int parq_forward_capture(parq_handle h, int32_t B, int32_t V, int32_t hh, int32_t ww, void *workspace, size_t workspace_bytes,
+                         parq_stream stream, parq_graph_t *out);
+int parq_forward_replay(parq_handle h, parq_graph_t g, const parq_scene *scene, void *workspace, size_t workspace_bytes,
+                        const parq_outputs *outs, parq_stream stream);
+int64_t parq_graph_nodes(parq_graph_t g);
+int parq_graph_destroy(parq_graph_t g);
 
 /* Stepping interface (teacher-forced parity tests, custom drivers):
  *   parq_prepare  : T_camera_local and the hoisted K/V cache (transformer_parq.py:298-305)

@@ -57,6 +57,10 @@ SYMBOLS = {
     "parq_pack_weights": (C.c_int, [_vp, _vp, _sz, _vp]),
     "parq_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32, _i32]),
     "parq_forward": (C.c_int, [_vp, C.POINTER(ParqScene), _vp, _sz, C.POINTER(ParqOutputs), _vp]),
+    "parq_forward_capture": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _sz, _vp, C.POINTER(_vp)]),
+    "parq_forward_replay": (C.c_int, [_vp, _vp, C.POINTER(ParqScene), _vp, _sz, C.POINTER(ParqOutputs), _vp]),
+    "parq_graph_nodes": (_i64, [_vp]),
+    "parq_graph_destroy": (C.c_int, [_vp]),
     "parq_prepare": (C.c_int, [_vp, C.POINTER(ParqScene), _vp, _sz, _vp]),
     "parq_iterate": (C.c_int, [_vp, C.POINTER(ParqScene), _vp, _sz, _i32, _vp, C.POINTER(ParqOutputs), _vp, _vp]),
     "parq_workspace_lookup": (C.c_int, [_vp, _i32, _i32, _i32, _i32, C.c_char_p, C.POINTER(_sz), C.POINTER(_sz)]),
@@ -64,6 +68,7 @@ SYMBOLS = {
     "parq_set_head_tiers": (C.c_int, [_vp, C.c_uint32, _i32]),
     "parq_set_seam_fusion": (C.c_int, [_vp, _i32]),
     "parq_set_range_mirror": (C.c_int, [_vp, _vp]),
+    "parq_mirror_take": (_i32, [_vp]),
     "parq_shard_exchange_floats": (_sz, [_vp, _i32, _i32]),
     "parq_iterate_sharded": (C.c_int, [_vp, C.POINTER(ParqScene), _vp, _sz, _i32, _i32, _vp, C.POINTER(ParqOutputs), _vp, _vp, _vp, _i32, _vp]),
     "parq_profile_enable": (C.c_int, [_vp, _i32]),

@@ -77,6 +77,7 @@ struct Workspace {
     int64_t kvc, flags;               // split-fp16 K/V cache, int flags (overflow)
     int64_t seam_flags, lnp1;         // the norm1 seam inside one launch (chain.hip seam_tile): flags [M / 16][4], fp64 partial row sums of xa ([M][C/64][2])
     int64_t xsplit;                   // fp16 hi/lo copy of the tokens for the large-C K/V projection (kvproj_big.hip), else empty
+    int64_t cam, ind;                 // a captured forward: this call's cameras and pointer block (common.hpp CallPtrs), left by its prologue
     int64_t total;
     int self_split, cross_split;
     // per-iteration activations live in [iter_begin, iter_end); a training forward keeps one copy per iteration:
@@ -141,6 +142,7 @@ struct parq_ctx {
     bool bwd_batched_env = true;      // parq_set_backward_batched (the parity test compares the two settings)
     int bwd_streams = 8;              // parq_set_backward_streams: iterations of the chain backward in flight at once (1 = in turn)
     float dim_t_host[128];            // 10000^(2*(i//2)/128): uploaded by parq_pack_weights from this persistent buffer (no stream sync)
+    hipStream_t cap_stream = nullptr;       // parq_forward_capture records on a stream of the handle's own
     hipStream_t aux_stream[7] = {nullptr};  // batched backward: iterations 1 .. g_sets-1 (mod g_sets) of a phase run here, 0 on the caller's stream
     hipEvent_t fork_ev = nullptr, join_ev[7] = {nullptr};
     hipEvent_t bucket_done[2] = {nullptr, nullptr};   // parq_backward: gradient bucket 0 / 1 final on the caller's stream (parq_backward_wait_bucket)
@@ -265,6 +267,8 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
         }
     }
     ws->flash = take((int64_t)((fs > fc ? fs : fc) / sizeof(float)));
+    ws->cam = take((int64_t)B * V * 6);
+    ws->ind = take(16);                               // 8 pointers
     ws->total = off;
     // ---- training extras: activation stash of iterations 1..I-1, backward scratch
     ws->stash = take((int64_t)(c->I - 1) * (ws->iter_end - ws->iter_begin));
@@ -349,24 +353,11 @@ LinearArgs lin(const float* X, int64_t ldx, const float* W, int64_t ldw, const f
     return a;
 }
 
-int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& ws, hipStream_t s, bool train = false) {
-    const float* A = c->arena;
-    const int B = sc->B, V = sc->V;
-    const int64_t N = (int64_t)V * sc->h * sc->w;
-    const int C = c->C;
-    {
-        // T_camera_local (float64), sigmoid(refpoint) tiled over the scenes, its sine embedding for iteration 0 and the cleared range
-        // flags: one launch
-        Prof p(c, s, PARQ_PROF_OTHER);
-        HIPCHK(launch_forward_prologue(sc->T_camera_pseudoCam, sc->T_world_pseudoCam, sc->T_world_local, B, V,
-                                       reinterpret_cast<double*>(wsp + ws.T_cl), A + c->ar.refpoint, c->Q, wsp + ws.ref, A + c->ar.dim_t,
-                                       wsp + ws.emb, wsp + ws.flags, (int)(ws.lnp1 - ws.flags), s));     // the 64 flag words and the seam flags behind them
-    }
-    // hoisted K/V in-projection of the memory tokens (SURVEY.md 0.7): one GEMM per distinct layer,
-    // written head-major [b][{K heads, V heads}][N][dh] so the attention kernel streams contiguous panels
-    if ((int64_t)B * N > (int64_t)INT32_MAX) return fail(PARQ_ERR_ARG, "B*N too large");
+// the arena's 16-bit copy of W_kv follows the attention mode: hi/lo split, or one round-to-nearest fp16 / bf16 copy
+int settle_weight_state(parq_ctx* c, hipStream_t s) {
     if (c->cache_mode() && c->kv16_state != c->w16_state()) {
-        // the arena's 16-bit copy of W_kv follows the mode: hi/lo split, or one round-to-nearest fp16 / bf16 copy
+        const float* A = c->arena;
+        const int C = c->C;
         for (int li = 0; li < c->nl; ++li) {
             const LayerW& L = c->ar.layers[li];
             float* Aw = const_cast<float*>(A);
@@ -375,6 +366,39 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         }
         c->kv16_state = c->w16_state();
     }
+    return PARQ_OK;
+}
+
+int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& ws, hipStream_t s, bool train = false,
+               const parq_outputs* call_outs = nullptr) {
+    const float* A = c->arena;
+    const int B = sc->B, V = sc->V;
+    const int64_t N = (int64_t)V * sc->h * sc->w;
+    const int C = c->C;
+    {
+        // T_camera_local (float64), sigmoid(refpoint) tiled over the scenes, its sine embedding for iteration 0 and the cleared range
+        // flags: one launch
+        Prof p(c, s, PARQ_PROF_OTHER);
+        // call_outs (parq_forward_replay): the launch also leaves this call's token / output pointers and cameras in the workspace for
+        // the recorded iterations (common.hpp CallPtrs)
+        PrologueCall pc;
+        memset(&pc, 0, sizeof(pc));
+        if (call_outs) {
+            pc.cam_src = sc->camera; pc.cam_dst = wsp + ws.cam; pc.ncam = B * V * 6;
+            pc.ind = reinterpret_cast<const void**>(wsp + ws.ind);
+            pc.ptrs.p[0] = sc->tokens; pc.ptrs.p[1] = call_outs->pred_logits; pc.ptrs.p[2] = call_outs->center_unnormalized;
+            pc.ptrs.p[3] = call_outs->size_unnormalized; pc.ptrs.p[4] = call_outs->ortho6d; pc.ptrs.p[5] = call_outs->sem_cls_prob;
+            pc.ptrs.p[6] = call_outs->coord_pos;
+        }
+        HIPCHK(launch_forward_prologue(sc->T_camera_pseudoCam, sc->T_world_pseudoCam, sc->T_world_local, B, V,
+                                       reinterpret_cast<double*>(wsp + ws.T_cl), A + c->ar.refpoint, c->Q, wsp + ws.ref, A + c->ar.dim_t,
+                                       wsp + ws.emb, wsp + ws.flags, (int)(ws.lnp1 - ws.flags), s,      // the 64 flag words and the seam flags behind them
+                                       call_outs ? &pc : nullptr));
+    }
+    // hoisted K/V in-projection of the memory tokens (SURVEY.md 0.7): one GEMM per distinct layer,
+    // written head-major [b][{K heads, V heads}][N][dh] so the attention kernel streams contiguous panels
+    if ((int64_t)B * N > (int64_t)INT32_MAX) return fail(PARQ_ERR_ARG, "B*N too large");
+    { const int rc = settle_weight_state(c, s); if (rc) return rc; }
     for (int li = 0; li < c->nl; ++li) {
         Prof p(c, s, PARQ_PROF_KV_PROJ);
         const LayerW& L = c->ar.layers[li];
@@ -448,12 +472,17 @@ int build_derived_weights(parq_ctx* c, hipStream_t s) {
 //                `out` = [M*C normalised attention outputs | B*H*Lq_pad log2 log-sum-exp rows]
 //   phase bit 4: `in` = `nranks` such records -> merged attention output; cross out-proj, FFN, heads, decode
 // mask 7 with in = out = nullptr is the ordinary iteration.
-struct ShardIO { int mask = 7; const float* in = nullptr; float* out = nullptr; int nranks = 1;
-                 bool keep = false; };     // stepping interface: also materialise intermediates that a fused launch would not (workspace "cross_q")
+struct ShardIO { int mask = 7; const float* in = nullptr; float* out = nullptr; int nranks = 1; };
 
 int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& ws, int layer_num, const float* ref,
                bool emb_valid, const parq_outputs* o, float* ref_out, hipStream_t s, int64_t shift = 0,
-               float* emb_next = nullptr, bool train = false, const ShardIO& sh = ShardIO()) {
+               float* emb_next = nullptr, bool train = false, const ShardIO& sh = ShardIO(), int64_t captured_row0 = -1) {
+    // captured_row0 >= 0 (parq_forward_capture): the iteration is being RECORDED — tokens, cameras and the six outputs are taken from the
+    // workspace's CallPtrs block / camera copy that the prologue of every replay fills in (`sc->tokens`, `sc->camera`, `o` are unused);
+    // captured_row0 = first output row of this iteration (k * B * Q)
+    const void* const* ind = captured_row0 >= 0 ? reinterpret_cast<const void* const*>(wsp + ws.ind) : nullptr;
+    const float* cam_in = ind ? wsp + ws.cam : sc->camera;
+    const int64_t row0 = captured_row0 >= 0 ? captured_row0 : 0;
     float* wi = wsp + shift;
     const bool sharded = sh.mask != 7;
     if (!emb_next) emb_next = wi + ws.emb;
@@ -508,8 +537,8 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     static const bool fuse_off = [] { const char* e = dev_env("PARQ_FUSE_PE1_SAMPLE"); return e && e[0] == '0'; }();
     bool fused = false;
     if (!train && !fuse_off && !c->profiling) {
-        const hipError_t e = launch_pe1_sample(pe1, sc->tokens, reinterpret_cast<const double*>(wsp + ws.T_cl), sc->camera, ref, c->sb, B, sc->V,
-                                               sc->h, sc->w, C, Q, sample_out, o->coord_pos, gn1, B * 8 * kGnSlots, sample_cnt, s);
+        const hipError_t e = launch_pe1_sample(pe1, sc->tokens, reinterpret_cast<const double*>(wsp + ws.T_cl), cam_in, ref, c->sb, B, sc->V,
+                                               sc->h, sc->w, C, Q, sample_out, o->coord_pos, gn1, B * 8 * kGnSlots, sample_cnt, s, ind, row0 * 3);
         if (e == hipSuccess) fused = true;
         else if (e != hipErrorNotSupported) return fail(PARQ_ERR_HIP, "launch_pe1_sample failed: %s", hipGetErrorString(e));
     }
@@ -525,8 +554,8 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     // K4+K5: project + sample (transformer_parq.py:321); also clears this iteration's GroupNorm moments
     if (!fused) {
         Prof p(c, s, PARQ_PROF_PROJECT_SAMPLE);
-        HIPCHK(launch_project_sample_f64(sc->tokens, reinterpret_cast<const double*>(wsp + ws.T_cl), sc->camera, ref, c->sb,
-                                         B, sc->V, sc->h, sc->w, C, Q, sample_out, o->coord_pos, gn1, B * 8 * kGnSlots, s, sample_cnt));
+        HIPCHK(launch_project_sample_f64(sc->tokens, reinterpret_cast<const double*>(wsp + ws.T_cl), cam_in, ref, c->sb,
+                                         B, sc->V, sc->h, sc->w, C, Q, sample_out, o->coord_pos, gn1, B * 8 * kGnSlots, s, sample_cnt, ind, row0 * 3));
     }
     // view-sharded: this rank's fp16-range flag travels as the last float of the record (the caller's all-reduce adds the ranks')
     if (sharded) HIPCHK(launch_shard_range_flag(c->cache_mode() && c->kind() == kF16 ? reinterpret_cast<const int*>(wsp + ws.flags) : nullptr,
@@ -728,13 +757,15 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         d.w3 = A + ar.heads3_w; d.b3 = A + ar.heads3_b; d.C = C; d.rows_per_scene = Q; d.eps = eps;
         d.ref = ref; d.mean_sizes = A + ar.mean_sizes; d.n_mean = c->cfg.num_mean_sizes; d.dim_t = A + ar.dim_t;
         // fp16-operand modes: a range violation seen while the cache was built must not produce plausible wrong numbers
-        d.poison = (c->cache_mode() && c->kind() == kF16) ? reinterpret_cast<const int*>(wsp + ws.flags) : nullptr;
+        d.poison = reinterpret_cast<const int*>(wsp + ws.flags);
+        d.poison_mask = (c->cache_mode() && c->kind() == kF16) ? ~0 : 4;     // (a hand-off timeout reaches the mirror in every attention mode)
         d.poison_mirror = c->range_mirror;
         d.peaky = (!sharded && c->terms_for(N, train, train && bwd_reads_cache(c, ws)) == 8) ? reinterpret_cast<const int*>(wsp + ws.flags) + 1 : nullptr;
         d.peaky_poison = c->peaky_poison;
         d.sb = c->sb; d.M = M; d.ncls = c->ncls;
         d.logits = o->pred_logits; d.center = o->center_unnormalized; d.size = o->size_unnormalized;
         d.rot = o->ortho6d; d.prob = o->sem_cls_prob; d.ref_next = ref_out; d.emb_next = emb_next;
+        d.ind = ind; d.out_row0 = row0;
         HIPCHK(launch_box_decode(d, s));
     }
     return PARQ_OK;
@@ -1109,6 +1140,7 @@ int parq_destroy(parq_handle h) {
     for (hipEvent_t e : h->join_ev) if (e) (void)hipEventDestroy(e);
     if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
     for (hipStream_t st : h->aux_stream) if (st) (void)hipStreamDestroy(st);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     delete h;
     return PARQ_OK;
 }
@@ -1244,9 +1276,7 @@ int parq_iterate(parq_handle h, const parq_scene* scene, void* workspace, size_t
     float* wsp = (float*)workspace;
     hipStream_t s = (hipStream_t)stream;
     const float* ref = ref_in ? ref_in : wsp + ws.ref;
-    ShardIO step_io;
-    step_io.keep = true;
-    rc = do_iterate(h, scene, wsp, ws, layer_num, ref, ref_in == nullptr && h->emb_valid, outs, wsp + ws.ref_next, s, 0, nullptr, false, step_io);
+    rc = do_iterate(h, scene, wsp, ws, layer_num, ref, ref_in == nullptr && h->emb_valid, outs, wsp + ws.ref_next, s);
     h->emb_valid = (rc == PARQ_OK);        // the decode kernel left pos2posemb3d(ref_next) in the workspace
     if (rc) return rc;
     const size_t rb = (size_t)scene->B * h->Q * 3 * sizeof(float);
@@ -1294,40 +1324,148 @@ int parq_iterate_sharded(parq_handle h, const parq_scene* scene, void* workspace
     return PARQ_OK;
 }
 
-int parq_forward(parq_handle h, const parq_scene* scene, void* workspace, size_t workspace_bytes,
-                 const parq_outputs* outs, parq_stream stream) {
+// the I iterations behind the prologue; captured: being recorded by parq_forward_capture (do_iterate)
+static int forward_iterations(parq_ctx* h, const parq_scene* scene, float* wsp, const Workspace& ws, const parq_outputs* outs, hipStream_t s,
+                              bool captured) {
+    const int64_t M = (int64_t)scene->B * h->Q;
+    float* ra = wsp + ws.ref;
+    float* rb = wsp + ws.ref_next;
+    for (int k = 0; k < h->I; ++k) {
+        parq_outputs o;
+        memset(&o, 0, sizeof(o));
+        if (!captured) {
+            o.pred_logits = outs->pred_logits + k * M * h->ncls;
+            o.center_unnormalized = outs->center_unnormalized + k * M * 3;
+            o.size_unnormalized = outs->size_unnormalized + k * M * 3;
+            o.ortho6d = outs->ortho6d + k * M * 6;
+            o.sem_cls_prob = outs->sem_cls_prob + k * M * h->ncls;
+            o.coord_pos = outs->coord_pos + k * M * 3;
+        }
+        const int rc = do_iterate(h, scene, wsp, ws, k, ra, true, &o, rb, s, 0, nullptr, false, ShardIO(),      // ping-pong the reference points; the sine
+                                  captured ? k * M : -1);                                                       // embedding of iteration 0 comes from the
+        if (rc) return rc;                                                                                      // prologue, later ones from the previous decode
+        float* t = ra; ra = rb; rb = t;
+    }
+    h->ref_state = 0;       // ws.ref / ws.ref_next roles depend on parity; stepping must re-prepare
+    h->prepared = false;
+    return PARQ_OK;
+}
+
+static int forward_checks(parq_handle h, const parq_scene* scene, void* workspace, size_t workspace_bytes, const parq_outputs* outs, Workspace* ws) {
     if (!h || !workspace) return fail(PARQ_ERR_ARG, "NULL argument");
     if (!h->packed) return fail(PARQ_ERR_STATE, "parq_pack_weights must be called first");
     int rc = check_scene(h, scene);
     if (rc) return rc;
     rc = check_outs(outs);
     if (rc) return rc;
+    carve_workspace(h, scene->B, scene->V, scene->h, scene->w, ws);
+    if (workspace_bytes < (size_t)ws->total * sizeof(float)) return fail(PARQ_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, (size_t)ws->total * sizeof(float));
+    return PARQ_OK;
+}
+
+int parq_forward(parq_handle h, const parq_scene* scene, void* workspace, size_t workspace_bytes,
+                 const parq_outputs* outs, parq_stream stream) {
     Workspace ws;
-    carve_workspace(h, scene->B, scene->V, scene->h, scene->w, &ws);
-    if (workspace_bytes < (size_t)ws.total * sizeof(float)) return fail(PARQ_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, (size_t)ws.total * sizeof(float));
-    float* wsp = (float*)workspace;
-    hipStream_t s = (hipStream_t)stream;
-    rc = do_prepare(h, scene, wsp, ws, s);
+    int rc = forward_checks(h, scene, workspace, workspace_bytes, outs, &ws);
     if (rc) return rc;
-    const int64_t M = (int64_t)scene->B * h->Q;
-    float* ra = wsp + ws.ref;
-    float* rb = wsp + ws.ref_next;
-    for (int k = 0; k < h->I; ++k) {
-        parq_outputs o;
-        o.pred_logits = outs->pred_logits + k * M * h->ncls;
-        o.center_unnormalized = outs->center_unnormalized + k * M * 3;
-        o.size_unnormalized = outs->size_unnormalized + k * M * 3;
-        o.ortho6d = outs->ortho6d + k * M * 6;
-        o.sem_cls_prob = outs->sem_cls_prob + k * M * h->ncls;
-        o.coord_pos = outs->coord_pos + k * M * 3;
-        rc = do_iterate(h, scene, wsp, ws, k, ra, true, &o, rb, s);      // ping-pong the reference points; the sine embedding of iteration 0
-                                                                         // comes from the prologue, later ones from the previous decode
-        if (rc) return rc;
-        float* t = ra; ra = rb; rb = t;
+    rc = do_prepare(h, scene, (float*)workspace, ws, (hipStream_t)stream);
+    if (rc) return rc;
+    return forward_iterations(h, scene, (float*)workspace, ws, outs, (hipStream_t)stream, false);
+}
+
+/* ---- a captured forward (include/parq_hip.h) ---------------------------------------------------------------------------------- */
+// what a graph was recorded with: parq_forward_replay refuses a graph whose recording no longer matches the handle or the call
+struct GraphKey {
+    int B, V, h, w, mode, seam, poison;
+    uint32_t safe;
+    const void* ws; const void* arena; const void* mirror;
+    bool operator==(const GraphKey& o) const {
+        return B == o.B && V == o.V && h == o.h && w == o.w && mode == o.mode && seam == o.seam && poison == o.poison && safe == o.safe &&
+               ws == o.ws && arena == o.arena && mirror == o.mirror;
     }
-    h->ref_state = 0;       // ws.ref / ws.ref_next roles depend on parity; stepping must re-prepare
+};
+static GraphKey graph_key(const parq_ctx* c, int B, int V, int hh, int ww, const void* wsp) {
+    return GraphKey{B, V, hh, ww, c->attn_mode, c->seam_fusion ? 1 : 0, c->peaky_poison, c->safe_heads(), wsp, c->arena, c->range_mirror};
+}
+struct parq_graph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; size_t nodes = 0; GraphKey key; };
+
+int parq_forward_capture(parq_handle h, int32_t B, int32_t V, int32_t hh, int32_t ww, void* workspace, size_t workspace_bytes,
+                         parq_stream stream, parq_graph_t* out) {
+    if (!h || !workspace || !out) return fail(PARQ_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    if (!h->packed) return fail(PARQ_ERR_STATE, "parq_pack_weights must be called first");
+    if (h->profiling) return fail(PARQ_ERR_STATE, "parq_forward_capture: switch parq_profile_enable off (its events are host-side records)");
+    parq_scene scene;
+    memset(&scene, 0, sizeof(scene));
+    scene.B = B; scene.V = V; scene.h = hh; scene.w = ww;
+    // (the recorded iterations take tokens / cameras / outputs from the workspace; the scene's pointers are never read)
+    scene.tokens = scene.camera = scene.T_camera_pseudoCam = scene.T_world_pseudoCam = scene.T_world_local = reinterpret_cast<const float*>(workspace);
+    int rc = check_scene(h, &scene);
+    if (rc) return rc;
+    Workspace ws;
+    carve_workspace(h, B, V, hh, ww, &ws);
+    if (workspace_bytes < (size_t)ws.total * sizeof(float)) return fail(PARQ_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, (size_t)ws.total * sizeof(float));
+    // Lazily built state must not end up inside the graph (it would be rebuilt by every replay): the derived inference weights are
+    // settled on the caller's stream, in front of the first replay.  (The mode's 16-bit copy of W_kv belongs to the K/V projection,
+    // which every replay launches directly.)
+    hipStream_t s = (hipStream_t)stream;
+    if (!h->derived_valid) { rc = build_derived_weights(h, s); if (rc) return rc; }
+    // recorded on a stream of the handle's own (the caller's may be the legacy default stream, which cannot capture); relaxed mode:
+    // other threads of the process (a data loader allocating, another module's launches) are not affected by the capture
+    if (!h->cap_stream) HIPCHK(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeRelaxed));
+    rc = forward_iterations(h, &scene, (float*)workspace, ws, nullptr, h->cap_stream, true);
+    parq_graph* g = new parq_graph();
+    const hipError_t e = hipStreamEndCapture(h->cap_stream, &g->graph);
+    if (rc != PARQ_OK || e != hipSuccess || !g->graph) {
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+        delete g;
+        (void)hipGetLastError();
+        return rc != PARQ_OK ? rc : fail(PARQ_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    }
+    (void)hipGraphGetNodes(g->graph, nullptr, &g->nodes);
+    const hipError_t e2 = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e2 != hipSuccess) {
+        (void)hipGraphDestroy(g->graph);
+        delete g;
+        return fail(PARQ_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e2));
+    }
+    g->key = graph_key(h, B, V, hh, ww, workspace);
+    *out = g;
+    return PARQ_OK;
+}
+
+int parq_forward_replay(parq_handle h, parq_graph_t g, const parq_scene* scene, void* workspace, size_t workspace_bytes,
+                        const parq_outputs* outs, parq_stream stream) {
+    if (!g || !g->exec) return fail(PARQ_ERR_ARG, "NULL graph");
+    Workspace ws;
+    int rc = forward_checks(h, scene, workspace, workspace_bytes, outs, &ws);
+    if (rc) return rc;
+    if (!(g->key == graph_key(h, scene->B, scene->V, scene->h, scene->w, workspace)) || !h->derived_valid)
+        return fail(PARQ_ERR_STATE, "parq_forward_replay: the graph was recorded for another shape / workspace / weight arena / range mirror or under "
+                                    "other attention settings (mode, head tiers, seam fusion): capture again");
+    hipStream_t s = (hipStream_t)stream;
+    // launched directly with THIS call's pointers: prologue (which also leaves them in the workspace for the recorded part) + K/V projection
+    rc = do_prepare(h, scene, (float*)workspace, ws, s, false, outs);
+    if (rc) return rc;
+    HIPCHK(hipGraphLaunch(g->exec, s));
+    h->ref_state = 0;
     h->prepared = false;
     return PARQ_OK;
+}
+
+int64_t parq_graph_nodes(parq_graph_t g) { return g ? (int64_t)g->nodes : 0; }
+
+int parq_graph_destroy(parq_graph_t g) {
+    if (!g) return PARQ_OK;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return PARQ_OK;
+}
+
+int32_t parq_mirror_take(int32_t* host_visible_flag) {
+    return host_visible_flag ? __atomic_exchange_n(host_visible_flag, 0, __ATOMIC_ACQ_REL) : 0;
 }
 
 int parq_workspace_lookup(parq_handle h, int32_t B, int32_t V, int32_t hh, int32_t ww, const char* name,

@@ -295,6 +295,7 @@ __global__ __launch_bounds__(NWV * 64) void chain_linear_kernel(LinearArgs a) {
 struct SampleArgs {
     const float* tokens; const double* T_cl; const float* cam; const float* ref; ScaleBox sb; int V, h, w, C, Q;
     float* tgt; float* coord_pos; double* zero_f64; int zero_n; float* raw_count;
+    const void* const* ind; int64_t coord_off;     // optional CallPtrs block of a captured forward: tokens = ind[0], coord_pos = ind[6] + coord_off
 };
 template <int NCH>
 __global__ __launch_bounds__(1024) void pe1_sample_kernel(LinearArgs a, SampleArgs sa, int n_lin) {
@@ -305,6 +306,10 @@ __global__ __launch_bounds__(1024) void pe1_sample_kernel(LinearArgs a, SampleAr
         chain_tile<384, 1, kProNone, 0, true, true, kResNone, false, 4>(a, (int)blockIdx.x, 0);
     } else {
         PARQ_TL_KERNEL(kTlProjectSample);
+        if (sa.ind != nullptr) {
+            sa.tokens = reinterpret_cast<const float*>(sa.ind[0]);
+            sa.coord_pos = reinterpret_cast<float*>(const_cast<void*>(sa.ind[6])) + sa.coord_off;
+        }
         project_sample_body<NCH, double>(sa.tokens, sa.T_cl, sa.cam, sa.ref, sa.sb, sa.V, sa.h, sa.w, sa.C, sa.Q, sa.tgt, sa.coord_pos,
                                          sa.zero_f64, sa.zero_n, sa.raw_count, (int)blockIdx.x - n_lin, (int)gridDim.x - n_lin, smem);
     }
@@ -326,11 +331,17 @@ __global__ __launch_bounds__(1024) void pe1_sample_kernel(LinearArgs a, SampleAr
 // at norm2 / FFN layer 1 was built and measured: f tiles 11 us median (6 us of own work + waiting), stage 14.0 against 14.6 us for the
 // two launches — no gain, not kept (profiles/r05_iter_timeline_stamps_seams_q_and_f.txt).
 __device__ __forceinline__ bool seam_wait(const unsigned* flag, unsigned epoch) {
-    for (int spin = 0; spin < (1 << 21); ++spin) {                 // ~0.1 s: never reached unless a producer died
-        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
+    // bounded by the 100 MHz wall clock (~0.1 s; looked at every 64 polls): never reached unless a producer died.  The acquire fence
+    // behind the successful poll orders the payload loads that follow after the flag load (program order alone does not)
+    const unsigned long long t0 = (unsigned long long)wall_clock64();
+    for (unsigned spin = 1;; ++spin) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            return true;
+        }
         __builtin_amdgcn_s_sleep(1);
+        if ((spin & 63u) == 0 && (unsigned long long)wall_clock64() - t0 > 10000000ull) return false;
     }
-    return false;
 }
 
 template <int K1, bool LN1, int K2, int K3, int NT, bool RELU, bool GNOUT>
@@ -957,7 +968,7 @@ hipError_t launch_fold_pos_weights(const float* Wa, const float* ba, const float
 // do not fit (the caller then launches the two stages separately).
 hipError_t launch_pe1_sample(const LinearArgs& a_in, const float* tokens, const double* T_cl, const float* cam, const float* ref, ScaleBox sb,
                              int B, int V, int h, int w, int C, int Q, float* tgt, float* coord_pos, double* zero_f64, int zero_n,
-                             float* raw_count, hipStream_t s) {
+                             float* raw_count, hipStream_t s, const void* const* ind, int64_t coord_off) {
     if (!chain_linear_supported(a_in, 1)) return hipErrorNotSupported;
     const Sig g = sig_of(a_in);
     if (!(g.K == 384 && g.pro == kProNone && g.add2 == 0 && g.bias && g.relu && g.res == kResNone && !g.gnout)) return hipErrorNotSupported;
@@ -969,7 +980,7 @@ hipError_t launch_pe1_sample(const LinearArgs& a_in, const float* tokens, const 
     const int n_lin = (a.N / 16) * (a.M / 16);
     const int nwv = V < 4 ? 4 : V;                                   // >= 4 waves: the linear tiles need 256 threads
     const size_t smem = (size_t)nwv * C * sizeof(float) + (size_t)nwv * sizeof(int) + (size_t)V * 32 + 16;
-    SampleArgs sa{tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n, raw_count};
+    SampleArgs sa{tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n, raw_count, ind, coord_off};
     const dim3 grid((unsigned)(n_lin + B * Q)), block(nwv * 64);
     switch ((C / 4 + 63) / 64) {
         case 1: hipLaunchKernelGGL((pe1_sample_kernel<1>), grid, block, smem, s, a, sa, n_lin); break;

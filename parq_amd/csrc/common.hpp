@@ -550,20 +550,29 @@ hipError_t launch_camera_local(const float* T_cp, const float* T_wp, const float
 hipError_t launch_camera_local_f64(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V,
                                    double* T_cl, hipStream_t s);
 hipError_t launch_initial_ref(const float* refpoint_w, int B, int Q, float* ref, hipStream_t s);
+// Per-call pointers of a captured forward (api.hip parq_forward_replay): the recorded iterations must not hold the caller's token and
+// output pointers themselves, so the prologue launch of every call (never part of the graph) leaves them in a block of the workspace —
+// [0] tokens, [1..5] pred_logits, centre, size, ortho6d, sem_cls_prob, [6] coord_pos — and copies the cameras beside it; the kernels of
+// the iterations that touch them (project + sample, box decode) load the pointers from that block when given one (`ind`).
+struct CallPtrs { const void* p[8]; };
+struct PrologueCall { const float* cam_src; float* cam_dst; int ncam; const void** ind; CallPtrs ptrs; };   // ind == nullptr: nothing to leave
 hipError_t launch_forward_prologue(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V, double* T_cl, const float* w, int Q,
-                                   float* ref, const float* dim_t, float* emb, float* flags, int nflags, hipStream_t s);
+                                   float* ref, const float* dim_t, float* emb, float* flags, int nflags, hipStream_t s,
+                                   const PrologueCall* call = nullptr);
 hipError_t launch_posemb(const float* ref, const float* dim_t, int M, float* emb, hipStream_t s);
 hipError_t launch_zero_f64(double* p, int n, hipStream_t s);
 hipError_t launch_project_sample(const float* tokens, const float* T_cl, const float* cam, const float* ref,
                                  ScaleBox sb, int B, int V, int h, int w, int C, int Q, float* tgt,
                                  float* coord_pos, hipStream_t s);
 // zero_f64/zero_n: accumulators (GroupNorm moments) this kernel clears for later kernels of the iteration
+// ind / coord_off: tokens = ind[0] and coord_pos = (float*)ind[6] + coord_off instead of the two pointer arguments (CallPtrs)
 hipError_t launch_project_sample_f64(const float* tokens, const double* T_cl, const float* cam, const float* ref,
                                      ScaleBox sb, int B, int V, int h, int w, int C, int Q, float* tgt,
-                                     float* coord_pos, double* zero_f64, int zero_n, hipStream_t s, float* raw_count = nullptr);
+                                     float* coord_pos, double* zero_f64, int zero_n, hipStream_t s, float* raw_count = nullptr,
+                                     const void* const* ind = nullptr, int64_t coord_off = 0);
 hipError_t launch_pe1_sample(const LinearArgs& pe1, const float* tokens, const double* T_cl, const float* cam, const float* ref, ScaleBox sb,
                              int B, int V, int h, int w, int C, int Q, float* tgt, float* coord_pos, double* zero_f64, int zero_n,
-                             float* raw_count, hipStream_t s);
+                             float* raw_count, hipStream_t s, const void* const* ind = nullptr, int64_t coord_off = 0);
 hipError_t launch_sample_finalize(const float* sums, const float* counts, int64_t M, int C, float* tgt, hipStream_t s,
                                   const float* range_sum = nullptr, int* range_flag = nullptr);
 hipError_t launch_shard_range_flag(const int* range_flag, float* out, hipStream_t s);
@@ -598,8 +607,12 @@ struct BoxDecodeArgs {
     const int* peaky;                  // optional device int raised by the cross-attention merge of attention mode 4 (FlashArgs::peaky):
                                        // bit h = head h ran the mode-4 kernel on a row that rests on too few keys
     int peaky_poison;                  // non-zero: such an iteration's outputs are written as NaN too (never plausible wrong numbers)
-    const int* poison;                 // optional device int: non-zero (fp16 operand range exceeded while the K/V cache was built) ->
-                                       // every output of the iteration is written as NaN instead of a plausible wrong number
+    const int* poison;                 // optional device int: non-zero (fp16 operand range exceeded while the K/V cache was built; bit 2:
+                                       // an in-launch hand-off timed out) -> every output of the iteration is written as NaN instead of
+                                       // a plausible wrong number
+    int poison_mask;                   // the bits of *poison that count (all of them in the fp16-operand cache modes, else only bit 2)
+    const void* const* ind;            // optional CallPtrs block: the five output pointers are ind[1..5] + out_row0 rows (a captured forward)
+    int64_t out_row0;
 };
 hipError_t launch_box_decode(const BoxDecodeArgs& a, hipStream_t s);
 // weight packing helpers

@@ -13,6 +13,7 @@
 #include "common.hpp"
 #include "sample_body.hpp"
 #include <cstdlib>
+#include <cstring>
 
 namespace parq {
 
@@ -107,9 +108,14 @@ __global__ void posemb_kernel(const float* ref, const float* dim_t, int M, float
 // their sine embedding (what posemb_kernel would compute from them: same arithmetic) and the cleared range flags: four tiny
 // launches (~5 us each behind a dependent boundary) as one.  Thread i plays every role its index is in range for.
 __global__ void forward_prologue_kernel(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V, double* T_cl,
-                                        const float* w, int Q, float* ref, const float* dim_t, float* emb, float* flags, int nflags) {
+                                        const float* w, int Q, float* ref, const float* dim_t, float* emb, float* flags, int nflags,
+                                        PrologueCall call) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nflags) flags[i] = 0.f;
+    if (call.ind != nullptr) {                     // a captured forward: this call's pointers and cameras for the recorded iterations
+        if (i < 8) call.ind[i] = call.ptrs.p[i];
+        if (i < call.ncam) call.cam_dst[i] = call.cam_src[i];
+    }
     if (i < B * V) {
         const int b = i / V;
         const Pose12 cp = load_pose(T_cp + (int64_t)i * 12);
@@ -145,9 +151,14 @@ template <int NCH, typename TPose>
 __global__ __launch_bounds__(1024) void project_sample_kernel(
     const float* __restrict__ tokens, const TPose* __restrict__ T_cl, const float* __restrict__ cam,
     const float* __restrict__ ref, ScaleBox sb, int V, int h, int w, int C, int Q, float* __restrict__ tgt,
-    float* __restrict__ coord_pos, double* __restrict__ zero_f64, int zero_n, float* __restrict__ raw_count) {
+    float* __restrict__ coord_pos, double* __restrict__ zero_f64, int zero_n, float* __restrict__ raw_count,
+    const void* const* __restrict__ ind, int64_t coord_off) {
     PARQ_TL_KERNEL(kTlProjectSample);
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [nwv][C] + [nwv] counts + footprints
+    if (ind != nullptr) {                                           // a captured forward: this call's pointers (CallPtrs; wave-uniform loads)
+        tokens = reinterpret_cast<const float*>(ind[0]);
+        coord_pos = reinterpret_cast<float*>(const_cast<void*>(ind[6])) + coord_off;
+    }
     project_sample_body<NCH, TPose>(tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n, raw_count,
                                     (int)blockIdx.x, (int)gridDim.x, smem);
 }
@@ -242,13 +253,20 @@ __global__ __launch_bounds__(1024) void gn_stats_kernel(const float* __restrict_
 constexpr int kMaxCls = 32;
 
 __global__ __launch_bounds__(256) void box_decode_kernel(BoxDecodeArgs a) {
+    if (a.ind != nullptr) {                        // a captured forward: this call's output pointers (CallPtrs; wave-uniform loads)
+        a.logits = reinterpret_cast<float*>(const_cast<void*>(a.ind[1])) + a.out_row0 * a.ncls;
+        a.center = reinterpret_cast<float*>(const_cast<void*>(a.ind[2])) + a.out_row0 * 3;
+        a.size = reinterpret_cast<float*>(const_cast<void*>(a.ind[3])) + a.out_row0 * 3;
+        a.rot = reinterpret_cast<float*>(const_cast<void*>(a.ind[4])) + a.out_row0 * 6;
+        a.prob = reinterpret_cast<float*>(const_cast<void*>(a.ind[5])) + a.out_row0 * a.ncls;
+    }
     PARQ_TL_KERNEL(kTlBoxDecode);
     const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (m >= a.M) return;
     const int lane = threadIdx.x & 63;
     const int C = a.C;
     const int scene = m / a.rows_per_scene;
-    const int range_word = a.poison != nullptr ? *a.poison : 0;         // wave-uniform scalar loads.  Bit 2: an in-launch hand-off timed out
+    const int range_word = a.poison != nullptr ? (*a.poison & a.poison_mask) : 0;         // wave-uniform scalar loads.  Bit 2: an in-launch hand-off timed out
     const bool range_poison = range_word != 0;
     const int peaky = a.peaky != nullptr ? *a.peaky : 0;
     const bool poison = range_poison || (a.peaky_poison && peaky != 0);
@@ -374,6 +392,13 @@ __global__ __launch_bounds__(256) void box_decode_kernel(BoxDecodeArgs a) {
 // launch that is pure latency).  One wave per query row; lane l owns channels 4 l .. 4 l + 3 of both hidden blocks (float4 loads);
 // the mean-size table sits in two registers per lane and the arg-max row is fetched with a lane permute.
 __global__ __launch_bounds__(256) void box_decode256_kernel(BoxDecodeArgs a) {
+    if (a.ind != nullptr) {                        // a captured forward: this call's output pointers (CallPtrs; wave-uniform loads)
+        a.logits = reinterpret_cast<float*>(const_cast<void*>(a.ind[1])) + a.out_row0 * a.ncls;
+        a.center = reinterpret_cast<float*>(const_cast<void*>(a.ind[2])) + a.out_row0 * 3;
+        a.size = reinterpret_cast<float*>(const_cast<void*>(a.ind[3])) + a.out_row0 * 3;
+        a.rot = reinterpret_cast<float*>(const_cast<void*>(a.ind[4])) + a.out_row0 * 6;
+        a.prob = reinterpret_cast<float*>(const_cast<void*>(a.ind[5])) + a.out_row0 * a.ncls;
+    }
     PARQ_TL_KERNEL(kTlBoxDecode);
     typedef float f32x4v __attribute__((ext_vector_type(4)));
     constexpr int C = 256;
@@ -412,7 +437,7 @@ __global__ __launch_bounds__(256) void box_decode256_kernel(BoxDecodeArgs a) {
     const float ms0 = a.mean_sizes[lane < nms ? lane : nms - 1];
     const float ms1 = a.mean_sizes[64 + lane < nms ? 64 + lane : nms - 1];
     __builtin_amdgcn_sched_barrier(0);                                   // keep every load above the first wait
-    const int range_word = a.poison != nullptr ? *a.poison : 0;         // wave-uniform scalar loads.  Bit 2: an in-launch hand-off timed out
+    const int range_word = a.poison != nullptr ? (*a.poison & a.poison_mask) : 0;         // wave-uniform scalar loads.  Bit 2: an in-launch hand-off timed out
     const bool range_poison = range_word != 0;
     const int peaky = a.peaky != nullptr ? *a.peaky : 0;
     const bool poison = range_poison || (a.peaky_poison && peaky != 0);
@@ -576,12 +601,16 @@ hipError_t launch_gather_copy(const GatherArgs& g, hipStream_t s) {
 }
 
 hipError_t launch_forward_prologue(const float* T_cp, const float* T_wp, const float* T_wl, int B, int V, double* T_cl, const float* w, int Q,
-                                   float* ref, const float* dim_t, float* emb, float* flags, int nflags, hipStream_t s) {
+                                   float* ref, const float* dim_t, float* emb, float* flags, int nflags, hipStream_t s, const PrologueCall* call) {
     int n = B * Q * 384;
     if (B * V > n) n = B * V;
     if (nflags > n) n = nflags;
+    PrologueCall pc;
+    memset(&pc, 0, sizeof(pc));
+    if (call) pc = *call;
+    if (pc.ncam > n) n = pc.ncam;
     hipLaunchKernelGGL(forward_prologue_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, T_cp, T_wp, T_wl, B, V, T_cl, w, Q, ref, dim_t, emb,
-                       flags, nflags);
+                       flags, nflags, pc);
     return hipGetLastError();
 }
 
@@ -593,17 +622,18 @@ hipError_t launch_posemb(const float* ref, const float* dim_t, int M, float* emb
 template <typename TPose>
 static hipError_t launch_project_sample_t(const float* tokens, const TPose* T_cl, const float* cam, const float* ref,
                                           ScaleBox sb, int B, int V, int h, int w, int C, int Q, float* tgt,
-                                          float* coord_pos, double* zero_f64, int zero_n, hipStream_t s, float* raw_count = nullptr) {
+                                          float* coord_pos, double* zero_f64, int zero_n, hipStream_t s, float* raw_count = nullptr,
+                                          const void* const* ind = nullptr, int64_t coord_off = 0) {
     if (C % 4 != 0 || C > 256 * kMaxChunks || V <= 0) return hipErrorInvalidValue;
     const int nwv = V < 16 ? V : 16;
     const size_t smem = (size_t)nwv * C * sizeof(float) + (size_t)nwv * sizeof(int) + (size_t)V * 32 + 16;      // partial sums, counts, footprints
     const int nch = ceil_div(C / 4, 64);
     dim3 grid(B * Q), block(nwv * 64);
     switch (nch) {
-        case 1: hipLaunchKernelGGL((project_sample_kernel<1, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n, raw_count); break;
-        case 2: hipLaunchKernelGGL((project_sample_kernel<2, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n, raw_count); break;
-        case 3: hipLaunchKernelGGL((project_sample_kernel<3, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n, raw_count); break;
-        default: hipLaunchKernelGGL((project_sample_kernel<4, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n, raw_count); break;
+        case 1: hipLaunchKernelGGL((project_sample_kernel<1, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n, raw_count, ind, coord_off); break;
+        case 2: hipLaunchKernelGGL((project_sample_kernel<2, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n, raw_count, ind, coord_off); break;
+        case 3: hipLaunchKernelGGL((project_sample_kernel<3, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n, raw_count, ind, coord_off); break;
+        default: hipLaunchKernelGGL((project_sample_kernel<4, TPose>), grid, block, smem, s, tokens, T_cl, cam, ref, sb, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n, raw_count, ind, coord_off); break;
     }
     return hipGetLastError();
 }
@@ -616,8 +646,9 @@ hipError_t launch_project_sample(const float* tokens, const float* T_cl, const f
 
 hipError_t launch_project_sample_f64(const float* tokens, const double* T_cl, const float* cam, const float* ref,
                                      ScaleBox sb, int B, int V, int h, int w, int C, int Q, float* tgt,
-                                     float* coord_pos, double* zero_f64, int zero_n, hipStream_t s, float* raw_count) {
-    return launch_project_sample_t<double>(tokens, T_cl, cam, ref, sb, B, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n, s, raw_count);
+                                     float* coord_pos, double* zero_f64, int zero_n, hipStream_t s, float* raw_count,
+                                     const void* const* ind, int64_t coord_off) {
+    return launch_project_sample_t<double>(tokens, T_cl, cam, ref, sb, B, V, h, w, C, Q, tgt, coord_pos, zero_f64, zero_n, s, raw_count, ind, coord_off);
 }
 
 // ---- view-sharded scenes (parq_iterate_sharded): the two merges around the exchanges

@@ -31,6 +31,12 @@ from . import _lib
 from .box_processor import mean_size_table
 from .wrappers import raw
 
+def _raw_stream(device):
+    """hipStream_t of the current stream of `device` as an int (the fast path of torch.cuda.current_stream(device).cuda_stream)."""
+    idx = device.index
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx)
+
+
 OUTPUT_KEYS = ("pred_logits", "center_unnormalized", "size_unnormalized", "ortho6d", "sem_cls_prob", "coord_pos")
 
 
@@ -38,7 +44,50 @@ OUTPUT_KEYS = ("pred_logits", "center_unnormalized", "size_unnormalized", "ortho
 # parameter containers that reproduce the reference's state_dict layout
 # ---------------------------------------------------------------------------------------
 
-class _WB(nn.Module):
+# Every parameter of the decoder lives in one of the small container classes below.  They bump this counter whenever a Parameter or
+# sub-module is (re-)assigned or deleted, which lets PARQDecoder._unique_params() reuse its walk of the module tree until then (the walk
+# costs ~0.15 ms per call — under ``range_check = "sync"`` that is device idle time between two forwards).
+_PARAM_EPOCH = [0]
+
+
+class _Tracked:
+    def __setattr__(self, name, value):
+        if isinstance(value, (nn.Parameter, nn.Module)) or name in self.__dict__.get("_parameters", ()) or name in self.__dict__.get("_modules", ()):
+            _PARAM_EPOCH[0] += 1
+        super().__setattr__(name, value)
+
+    def __delattr__(self, name):
+        _PARAM_EPOCH[0] += 1
+        super().__delattr__(name)
+
+    def register_parameter(self, name, param):
+        _PARAM_EPOCH[0] += 1
+        super().register_parameter(name, param)
+
+    def add_module(self, name, module):
+        _PARAM_EPOCH[0] += 1
+        super().add_module(name, module)
+
+
+class _TDict(_Tracked, nn.ModuleDict):
+    pass
+
+
+class _TList(_Tracked, nn.ModuleList):
+    def __setitem__(self, idx, module):
+        _PARAM_EPOCH[0] += 1
+        super().__setitem__(idx, module)
+
+    def __delitem__(self, idx):
+        _PARAM_EPOCH[0] += 1
+        super().__delitem__(idx)
+
+
+class _RefPoints(_Tracked, nn.Embedding):
+    """``refpoint`` (model/parq_decoder.py:62: nn.Embedding(num_queries, 3)); only its weight is read."""
+
+
+class _WB(_Tracked, nn.Module):
     """A leaf holding ``weight`` (and optionally ``bias``)."""
 
     def __init__(self, wshape, bias=True, bshape=None):
@@ -64,7 +113,7 @@ def _norm_init(m: _WB):
     nn.init.zeros_(m.bias)
 
 
-class _Head(nn.Module):
+class _Head(_Tracked, nn.Module):
     """GenericMLP parameter layout (model/generic_mlp.py:64-132): ``layers.<idx>``.
 
     hidden=[]     -> layers.0 = Conv1d(C, out)
@@ -74,7 +123,7 @@ class _Head(nn.Module):
 
     def __init__(self, C_in, out, hidden):
         super().__init__()
-        layers = nn.ModuleDict()
+        layers = _TDict()
         if hidden:
             layers["0"] = _WB((C_in, C_in, 1), bias=False)
             layers["1"] = _WB((C_in,), bshape=(C_in,))
@@ -91,7 +140,7 @@ class _Head(nn.Module):
         self.layers = layers
 
 
-class _MHA(nn.Module):
+class _MHA(_Tracked, nn.Module):
     """nn.MultiheadAttention parameter layout."""
 
     def __init__(self, C_):
@@ -102,7 +151,7 @@ class _MHA(nn.Module):
         nn.init.zeros_(self.out_proj.bias)
 
 
-class _Layer(nn.Module):
+class _Layer(_Tracked, nn.Module):
     def __init__(self, C_, F_):
         super().__init__()
         self.self_attn = _MHA(C_)
@@ -116,13 +165,13 @@ class _Layer(nn.Module):
             _norm_init(m)
 
 
-class _DecoderParams(nn.Module):
+class _DecoderParams(_Tracked, nn.Module):
     def __init__(self, C_, F_, n_layers):
         super().__init__()
-        self.layers = nn.ModuleList([_Layer(C_, F_) for _ in range(n_layers)])
+        self.layers = _TList([_Layer(C_, F_) for _ in range(n_layers)])
         self.norm = _WB((C_,), bshape=(C_,))          # in checkpoints, never applied (transformer_parq.py:174)
         _norm_init(self.norm)
-        pe = nn.ModuleDict()
+        pe = _TDict()
         pe["0"] = _WB((C_, 384))
         pe["2"] = _WB((C_, C_))
         _conv_init(pe["0"])
@@ -131,7 +180,7 @@ class _DecoderParams(nn.Module):
         self.mlp_heads = None                          # shared with PARQDecoder.mlp_heads (parq_decoder.py:66)
 
 
-class _TransformerParams(nn.Module):
+class _TransformerParams(_Tracked, nn.Module):
     def __init__(self, C_, F_, n_layers):
         super().__init__()
         self.decoder = _DecoderParams(C_, F_, n_layers)
@@ -157,6 +206,49 @@ class _Stash:
 
     def __init__(self, ws, state, gen):
         self.ws, self.state, self.gen, self.consumed = ws, state, gen, False
+
+
+class _WsEntry:
+    """One inference workspace of a module: the K/V cache + activations tensor of a (shape, device, stream), the pinned mirror word the
+    device raises for forwards that run in it, and the captured iterations of its forward (a HIP graph, include/parq_hip.h
+    parq_forward_capture) with the settings they were recorded under."""
+    __slots__ = ("ws", "slot", "stream", "graphs", "last_key", "replays")
+
+    def __init__(self, ws, slot, stream):
+        self.ws, self.slot, self.stream = ws, slot, stream
+        self.graphs = {}              # key -> parq_graph_t (one per (weights, attention settings): the current one; stale ones are retired)
+        self.last_key = None          # key of the previous forward in this workspace (a graph is captured when a key repeats)
+        self.replays = 0
+
+
+class _WsCache(dict):
+    """The module's inference workspaces, least recently used first.  Dropping an entry retires its graphs: they are destroyed once
+    an event recorded behind their last launch has completed (``PARQDecoder._purge_graphs``)."""
+
+    def __init__(self, owner):
+        super().__init__()
+        self._owner = weakref.ref(owner)
+
+    def _retire(self, entry):
+        dec = self._owner()
+        if dec is not None and entry is not None and entry.graphs:
+            dec._retire_graphs(entry)
+
+    def pop(self, key, *default):
+        had = key in self
+        entry = super().pop(key, *default)
+        if had:
+            self._retire(entry)
+        return entry
+
+    def take(self, key):
+        """Remove and return WITHOUT retiring (the entry is re-inserted as the most recently used)."""
+        return super().pop(key, None)
+
+    def clear(self):
+        for entry in list(self.values()):
+            self._retire(entry)
+        super().clear()
 
 
 class _TrainFn(torch.autograd.Function):
@@ -196,7 +288,7 @@ class _TrainFn(torch.autograd.Function):
         return (None, d_tokens, None, None, None, None, None, *per_param)
 
 
-class PARQDecoder(nn.Module):
+class PARQDecoder(_Tracked, nn.Module):
     """Drop-in for ``model.parq_decoder.PARQDecoder`` (forward path)."""
 
     def __init__(self, cfg):
@@ -228,7 +320,8 @@ class PARQDecoder(nn.Module):
         self.mean_size_path = getattr(cfg, "MEAN_SIZE_PATH", None)
 
         Cd, ncls = self.dim_in, self.num_semcls + 1
-        self.mlp_heads = nn.ModuleDict([
+        self._out_width = 2 * ncls + 3 + 3 + 6 + 3      # floats per (iteration, scene, query) over the six output tensors
+        self.mlp_heads = _TDict([
             ("sem_cls_head", _Head(Cd, ncls, hidden=False)),
             ("center_head", _Head(Cd, 3, hidden=True)),
             ("size_head", _Head(Cd, 3, hidden=False)),
@@ -236,7 +329,7 @@ class PARQDecoder(nn.Module):
         ])
         self.parq_module = _TransformerParams(Cd, self.ffn_dim, 1 if self.share_weights else self.num_layers)
         self.parq_module.decoder.mlp_heads = self.mlp_heads
-        self.refpoint = nn.Embedding(self.num_queries, 3)
+        self.refpoint = _RefPoints(self.num_queries, 3)
 
         # cross-attention arithmetic: "split" = fp16 hi/lo 3-term products on the fp16 matrix pipe
         # (fp32-class accuracy; head dim 64, and head dim 256 = the reference's shipped DEC_DIM 1024 / 4 heads),
@@ -250,7 +343,20 @@ class PARQDecoder(nn.Module):
         self._h = None            # parq_handle
         self._arena = None
         self._arena_key = None
-        self._ws = {}
+        self._ws = _WsCache(self)
+        self._graveyard = []              # (graphs, event): captured forwards of dropped workspaces, destroyed once the event has completed
+        self._arena_gen = 0               # bumped by every re-pack of the weight arena (part of a captured forward's key)
+        self._arena_event = None          # recorded behind the first forward after a (re-)pack: other streams wait for it once
+        self._arena_pack_stream = None
+        self._arena_streams = {}          # stream id -> stream object of every stream that is ordered behind the current arena
+        self._defer = None                # InFlight.submit(): list that receives the settle callable of a forward instead of a host wait
+        self._profiling = False
+        # Captured forward (include/parq_hip.h parq_forward_capture): the iterations of the second inference forward of a (shape,
+        # stream, weights, attention settings) are recorded into a HIP graph and later forwards replay it behind their directly
+        # launched prologue and K/V projection — 3 host calls instead of ~90 launches; the graph holds no pointer of a particular
+        # call (any tokens / cameras / outputs replay it) and its results are bit-identical to the uncaptured path.  False = always
+        # enqueue launch by launch.
+        self.use_graph = True
         self._matcher = None
         self._train_ws = None
         self._train_state = None
@@ -276,25 +382,27 @@ class PARQDecoder(nn.Module):
         self.max_workspaces = 2           # inference workspaces (each holds a K/V cache) kept alive, least recently used first out
         self._mean_dev = None
         # fp16-operand attention modes ("split", "split8", "fp16"): what to do when a token / K / V element leaves the fp16 range
-        # (include/parq_hip.h: the device then writes NaN outputs instead of wrong numbers, and raises a flag).
-        #   "lazy" (default): no synchronisation and no extra work on the forward path.  On a violation the device itself
-        #           stores into a pinned host word (parq_set_range_mirror); the next call into the module that finds it set
-        #           warns and switches ``attention_mode`` to "fp32" for good, so at most the forwards already in flight are
-        #           NaN (never silently wrong).
-        #   "sync": wait for the flag after every inference forward and transparently re-run that forward with the exact
-        #           fp32 kernels (costs one host synchronisation per forward).
-        #   "off":  only ``fp16_range_exceeded()`` on request.
-        # The same policy covers attention mode "split8" meeting rows that rest on too few keys for its error model (the merge kernel
-        # flags, per head, rows whose probability sum is under the guard threshold).  Under every policy but "off" such a forward
-        # NEVER returns plausible numbers from outside the error model: the iteration that met the row and everything after it is
-        # written as NaN by the device (like a range violation), and the flagged HEADS move to the fp16 x 3 tier (``safe_heads``):
-        #   "lazy": at the next call into the module (host load of the pinned word); forwards already in flight that meet such rows
-        #           are NaN too.  A module's FIRST inference forward (per weight version) is checked synchronously and re-run, so a
-        #           model whose attention is peaked from its first call on never returns NaN.
-        #   "sync": after every forward, which is re-run with the flagged heads moved (the caller always gets numbers).
-        #   "off":  no poisoning, no tier change; ``attention_too_peaked()`` / ``attention_peaked_map()`` on request.
-        self.range_check = "lazy"
-        self._range_mirror = None         # pinned host int32 the device raises on a range violation
+        # (include/parq_hip.h: the device then writes NaN outputs instead of wrong numbers, and raises a flag), and when attention mode
+        # "split8" meets rows that rest on too few keys for its error model (the merge kernel flags them per head; the iteration that
+        # met the row and everything after it is written as NaN, the flagged heads are named in the pinned mirror word).
+        #   "sync" (default): the reference never returns NaN on valid input (model/transformer_parq.py:283-337, eval.py:45-48), and
+        #           neither does this module: every inference forward waits for its stream once, reads the pinned word of its
+        #           workspace (a host load, no device copy) and, if it is raised, re-runs the forward — with the exact fp32 kernels
+        #           after a range violation, with the flagged HEADS moved to the fp16 x 3 tier (``safe_heads``) after a too-peaked row
+        #           — before it returns.  The caller always gets numbers.  Cost: the launch latency of the next forward is no longer
+        #           hidden behind the previous one (bench.py ``guard_policy_cost``); with ``InFlight`` the wait moves to
+        #           ``Ticket.result()`` and other forwards keep the device busy meanwhile.
+        #   "lazy": no synchronisation on the forward path (servers that keep forwards in flight and check tickets themselves).  On a
+        #           violation the NEXT call into the module that finds the pinned word set warns and moves the flagged heads / switches
+        #           to "fp32" for good; forwards already in flight that met such inputs return NaN (never silently wrong numbers).  A
+        #           module's FIRST inference forward per weight version is still checked synchronously and re-run.
+        #   "off":  no poisoning, no tier change; ``fp16_range_exceeded()`` / ``attention_too_peaked()`` / ``attention_peaked_map()``
+        #           on request.
+        # Heads moved to the fp16 x 3 tier stay there (``reset_attention_tiers()``; "sync" only, opt-in: ``tier_return_after``).
+        self.range_check = "sync"
+        self._range_mirror = None         # pinned host int32 words the device raises on a range violation (see _set_mirror)
+        self._mirror_np = None
+        self._mirror_set = None
         # Training in mode "split8" (forward flash_split8_kernel with dropout, backward from its stage cache): 3 % faster per step at
         # BASELINE cfg 4, and the forward's ~1e-5 arithmetic noise (ten times mode "split"'s) reaches the gradients amplified by the
         # free-running chain (profiles/NOTES_r04.md).  Off by default: training steps then run in mode "split".
@@ -358,50 +466,87 @@ class PARQDecoder(nn.Module):
         self.safe_heads = 0
         self._peaky_checked = False
 
-    def _range_poll(self):
-        """A host load of the pinned word earlier forwards raise from the device (no synchronisation): bit 0 = an operand left the
-        fp16 range (outputs of that forward are NaN), bit 1 = attention mode 'split8' met a row carried by too few keys on the heads of
-        bits 8.. (outputs of that forward are NaN from that iteration on unless ``range_check == "off"``)."""
-        v = int(self._range_mirror[0]) if self._range_mirror is not None else 0
-        if v != 0:
-            self._range_mirror[0] = 0
-            if self.range_check == "off":
-                return
-            if v & 4:
-                self._seam_fallback("detected after an earlier forward")
-            if (v & 1) and self.attention_mode in ("split", "split8", "fp16"):
-                self._range_fallback("detected after an earlier forward")
-            elif (v & 2) and self.attention_mode == "split8":
-                self._peaky_fallback(v >> 8, "detected after an earlier forward, whose outputs are NaN from that iteration on")
+    # mirror words: one pinned int32 per inference workspace (slots 1 ..), slot 0 for the training / stepping / view-sharded entry
+    # points.  The device ORs into the word of the workspace a forward runs in (the pointer is read at enqueue time, include/parq_hip.h);
+    # the host takes a word with one atomic exchange, so bits raised by another forward in flight are never lost.
+    _MIRROR_SLOTS = 16
 
-    def _range_after_forward(self, ws, sc):
-        """"sync" policy: wait for the flags of the forward just enqueued; True = re-run it (with the fp32 kernels after a range
-        violation, with the flagged heads on the fp16 x 3 tier after a too-peaked row in mode 'split8').  The FIRST inference forward
-        of a module in mode 'split8' (per weight version) is checked this way under every policy but "off" (one synchronisation,
-        once): a model whose attention is too peaked for that mode is peaked from its first call on."""
+    def _mirror_ptr(self, slot):
+        return self._range_mirror.data_ptr() + 4 * int(slot)
+
+    def _set_mirror(self, slot):
+        if self._mirror_set != slot:
+            _lib.check(_lib.load().parq_set_range_mirror(self._handle(apply_mode=False), C.c_void_p(self._mirror_ptr(slot))), "parq_set_range_mirror")
+            self._mirror_set = slot
+
+    def _mirror_take(self, slot):
+        return int(_lib.load().parq_mirror_take(C.c_void_p(self._mirror_ptr(slot)))) if self._range_mirror is not None else 0
+
+    def _free_slot(self):
+        used = {e.slot for e in self._ws.values()}
+        for sl in range(1, self._MIRROR_SLOTS):
+            if sl not in used:
+                return sl
+        return self._MIRROR_SLOTS - 1                   # more workspaces than words: the last word is shared (bits are still never lost)
+
+    def _range_poll(self):
+        """Host loads of the pinned words earlier forwards raise from the device (no synchronisation): bit 0 = an operand left the
+        fp16 range (outputs of that forward are NaN), bit 1 = attention mode 'split8' met a row carried by too few keys on the heads of
+        bits 8.. (outputs of that forward are NaN from that iteration on unless ``range_check == "off"``), bit 2 = an in-launch hand-off
+        timed out."""
+        if self._mirror_np is None or not self._mirror_np.any():
+            return
+        v = 0
+        for sl in np.nonzero(self._mirror_np)[0].tolist():
+            v |= self._mirror_take(sl)
+        if v == 0 or self.range_check == "off":
+            return
+        if v & 4:
+            self._seam_fallback("detected after an earlier forward")
+        if (v & 1) and self.attention_mode in ("split", "split8", "fp16"):
+            self._range_fallback("detected after an earlier forward")
+        elif (v & 2) and self.attention_mode == "split8":
+            self._peaky_fallback(v >> 8, "detected after an earlier forward, whose outputs are NaN from that iteration on")
+
+    def _range_after_forward(self, entry, sc, dev):
+        """"sync" policy: wait for the forward just enqueued in `entry` and read what it raised; True = re-run it (with the fp32 kernels
+        after a range violation, with the flagged heads on the fp16 x 3 tier after a too-peaked row in mode 'split8', with one launch
+        per stage after a hand-off timeout).  The FIRST inference forward of a module in mode 'split8' (per weight version) is checked
+        this way under every policy but "off" (one synchronisation, once): a model whose attention is too peaked for that mode is peaked
+        from its first call on."""
         first = self.attention_mode == "split8" and not self._peaky_checked and self.range_check != "off"
         if not first and (self.range_check != "sync" or self.attention_mode not in ("split", "split8", "fp16")):
             return False
         want_calm = (self.range_check == "sync" and self.tier_return_after > 0 and self.safe_heads != 0 and self.attention_mode == "split8"
                      and self.num_heads <= 16)
-        flags = self._flag_view(ws, sc.B, sc.V, sc.h, sc.w, 48 if want_calm else 2).tolist()
+        if want_calm:
+            # also needs every head's smallest row sum of this forward: a device read of the flag words (waits for the stream)
+            flags = self._flag_view(entry.ws, sc.B, sc.V, sc.h, sc.w, 48).tolist()
+            v = self._mirror_take(entry.slot)
+        else:
+            torch.cuda.current_stream(dev).synchronize()      # this stream only; the pinned word is final once its last kernel has retired
+            v = self._mirror_take(entry.slot)
+            flags = None
         if first:
             self._peaky_checked = True
-        if (flags[0] & 4) and self.fuse_seams:                    # a hand-off timed out: re-run with one launch per stage (every policy that looks)
-            self._range_mirror[0] = int(self._range_mirror[0]) & ~5
+        if v == 0 and not want_calm:
+            return False
+        if self.range_check == "off":
+            return False
+        rerun = False
+        if (v & 4) and self.fuse_seams:                           # a hand-off timed out: re-run with one launch per stage (every policy that looks)
             self._seam_fallback("re-running this forward")
-            if not (flags[0] & ~4):
+            rerun = True
+        if (v & 1) and self.attention_mode in ("split", "split8", "fp16"):
+            if self.range_check == "sync" or first:
+                self._range_fallback("re-running this forward")
                 return True
-        if (flags[0] & ~4) != 0 and self.range_check == "sync":
-            self._range_mirror[0] = 0
-            self._range_fallback("re-running this forward")
-            return True
-        if flags[1] != 0 and self.attention_mode == "split8":
-            if self._range_mirror is not None:
-                self._range_mirror[0] = int(self._range_mirror[0]) & 1
-            if self._peaky_fallback(flags[1], "re-running this forward"):
+        if (v & 2) and self.attention_mode == "split8":
+            if self._peaky_fallback(v >> 8, "re-running this forward"):
                 self._peaky_checked = False if first else self._peaky_checked     # the re-run is checked too: other heads may follow
                 return True
+        if rerun:
+            return True
         if want_calm:
             # heads on the fp16 x 3 tier whose rows all spread again (flags[32 + h]: the head's smallest row sum of this forward)
             limit = 256.0 * float(self.tier_return_margin)
@@ -434,8 +579,10 @@ class PARQDecoder(nn.Module):
             self._bwd_streams_set = None
             self._train_ws = None
             # pinned host memory is mapped into the device address space under the same pointer (hipHostMalloc)
-            self._range_mirror = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._range_mirror = torch.zeros(self._MIRROR_SLOTS, dtype=torch.int32).pin_memory()
+            self._mirror_np = self._range_mirror.numpy()
             _lib.check(lib.parq_set_range_mirror(h, C.c_void_p(self._range_mirror.data_ptr())), "parq_set_range_mirror")
+            self._mirror_set = 0
         det = 1 if torch.are_deterministic_algorithms_enabled() else 8
         if getattr(self, "_bwd_streams_set", None) != det:
             # torch.use_deterministic_algorithms(True): the iterations of the chain backward run in turn with plain accumulation
@@ -489,17 +636,49 @@ class PARQDecoder(nn.Module):
 
     def __del__(self):
         try:
+            self._ws.clear()
+            self._purge_graphs(wait=True)
             if self._h is not None:
                 _lib.load().parq_destroy(self._h)
         except Exception:
             pass
 
+    # ------------------------------------------------------------------ captured forwards (include/parq_hip.h parq_forward_capture)
+    def _retire_graphs(self, entry):
+        """The graphs of a workspace that is being dropped: destroyed once everything enqueued on its stream so far has completed."""
+        graphs, entry.graphs = list(entry.graphs.values()), {}
+        try:
+            ev = torch.cuda.Event()
+            ev.record(entry.stream)
+        except Exception:                                 # noqa: BLE001 - interpreter shutdown
+            ev = None
+        self._graveyard.append((graphs, ev))
+        self._purge_graphs()
+
+    def _purge_graphs(self, wait=False):
+        keep = []
+        for graphs, ev in self._graveyard:
+            if ev is not None and wait:
+                ev.synchronize()
+            if ev is None or ev.query():
+                for g in graphs:
+                    _lib.load().parq_graph_destroy(g)
+            else:
+                keep.append((graphs, ev))
+        self._graveyard = keep
+
     def _unique_params(self):
+        """(name, parameter) of every distinct parameter.  The module tree is walked once per change of its structure: every container
+        class of this module counts assignments of parameters / sub-modules in ``_PARAM_EPOCH``."""
+        cache = self.__dict__.get("_param_cache")
+        if cache is not None and cache[0] == _PARAM_EPOCH[0]:
+            return cache[1]
         seen, out = set(), []
         for name, p in self.named_parameters(remove_duplicate=True):
             if id(p) not in seen:
                 seen.add(id(p))
                 out.append((name, p))
+        self.__dict__["_param_cache"] = (_PARAM_EPOCH[0], out)
         return out
 
     def invalidate_weights(self):
@@ -527,13 +706,43 @@ class PARQDecoder(nn.Module):
         self._mean_dev = torch.from_numpy(self._mean_sizes.astype(np.float32)).to(device).contiguous()
         _lib.check(lib.parq_set_weight(h, b"mean_sizes", _lib.ptr(self._mean_dev), self._mean_dev.numel()), "mean_sizes")
         nbytes = lib.parq_packed_weights_bytes(h)
+        old = self._arena
+        if old is not None:
+            # forwards enqueued on OTHER streams may still read the old arena: the caching allocator must not hand its block out
+            # again before they have passed
+            for st in self._arena_streams.values():
+                old.record_stream(st)
+        cur = torch.cuda.current_stream(device)
         self._arena = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
         _lib.check(lib.parq_pack_weights(h, _lib.ptr(self._arena), nbytes, _lib.stream_ptr()), "parq_pack_weights")
         del keep
         self._arena_key = key
+        self._arena_gen += 1
+        self._arena_event, self._arena_pack_stream, self._arena_streams = None, cur, {}
         self._peaky_checked = False                    # new weights: the next inference forward in mode "split8" is checked synchronously
 
-    def _workspace(self, B, V, h, w, device, handle=None):
+    def _order_behind_pack(self, device):
+        """The weight arena is packed — and its lazily derived forms are built — on whichever stream got there first; a forward on any
+        OTHER stream waits (on the device) for that work once per (re-)pack."""
+        sid = _raw_stream(device)
+        if sid in self._arena_streams:
+            return
+        st = torch.cuda.current_stream(device)
+        if self._arena_event is not None:
+            st.wait_event(self._arena_event)
+        elif self._arena_pack_stream is not None and int(self._arena_pack_stream.cuda_stream) != sid:
+            st.wait_stream(self._arena_pack_stream)
+        self._arena_streams[sid] = st
+
+    def _mark_first_forward(self, device):
+        """Behind the first forward (inference or training) enqueued after a (re-)pack: the pack, the mode's 16-bit W_kv copy and the
+        derived inference weights are all in front of this event."""
+        if self._arena_event is None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+            self._arena_event = ev
+
+    def _workspace_entry(self, B, V, h, w, device, handle=None):
         """Workspace (K/V cache + activations) of a batch shape.  The ``max_workspaces`` most recently used shapes stay alive, so
         a driver that alternates two shapes (e.g. train / validation snippets) does not reallocate a K/V cache per call; each holds
         a K/V cache (393 MB per scene at BASELINE cfg 3), so ``max_workspaces = 1`` halves the module's footprint for single-shape
@@ -543,17 +752,21 @@ class PARQDecoder(nn.Module):
         # keyed by the launch stream too: forwards enqueued on different streams (two scenes in flight: the small-op chain of one
         # leaves most of the chip to the K/V projection and cross-attention of the other, +18 % throughput at BASELINE cfg 3,
         # profiles/r05_two_in_flight.txt) each own a workspace; a workspace is allocated, used and freed in the order of ONE stream
-        k = (B, V, h, w, str(device), int(torch.cuda.current_stream(device).cuda_stream))
-        ws = self._ws.pop(k, None)
-        if ws is None:
+        k = (B, V, h, w, device.index, _raw_stream(device))
+        entry = self._ws.take(k)
+        if entry is None:
+            st = torch.cuda.current_stream(device)
             nbytes = _lib.load().parq_workspace_bytes(handle, B, V, h, w)
             if nbytes == 0:
                 raise RuntimeError("parq_workspace_bytes returned 0 for B=%d V=%d h=%d w=%d" % (B, V, h, w))
             while len(self._ws) >= max(1, int(self.max_workspaces)):
                 self._ws.pop(next(iter(self._ws)))    # dicts iterate in insertion order: the first key is the least recently used
-            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
-        self._ws[k] = ws                              # (re-)insert as the most recently used
-        return ws
+            entry = _WsEntry(torch.empty(nbytes // 4, dtype=torch.float32, device=device), self._free_slot(), st)
+        self._ws[k] = entry                           # (re-)insert as the most recently used
+        return entry
+
+    def _workspace(self, B, V, h, w, device, handle=None):
+        return self._workspace_entry(B, V, h, w, device, handle).ws
 
     # ------------------------------------------------------------------ argument packing
     def _scene(self, tokens, camera, T_cp, T_wp, T_wl, feat_hw):
@@ -565,9 +778,10 @@ class PARQDecoder(nn.Module):
         dev = tokens.device
 
         def prep(t, last):
-            t = t.to(device=dev, dtype=torch.float32)
+            if t.device != dev or t.dtype != torch.float32:
+                t = t.to(device=dev, dtype=torch.float32)
             assert t.shape[-1] == last, (tuple(t.shape), last)
-            return t.contiguous()
+            return t if t.is_contiguous() else t.contiguous()
         tokens = prep(tokens, self.dim_in)
         cam, T_cp, T_wp, T_wl = prep(cam, 6), prep(T_cp, 12), prep(T_wp, 12), prep(T_wl, 12)
         B, N, _ = tokens.shape
@@ -590,6 +804,22 @@ class PARQDecoder(nn.Module):
         ncls = self.num_semcls + 1
         widths = (ncls, 3, 3, 6, ncls, 3)
         return [torch.empty(*lead, wd, dtype=torch.float32, device=device) for wd in widths]
+
+    def _alloc_outputs_flat(self, lead, device, flat=None):
+        """The six output tensors of an inference call as views of ONE allocation (`flat`: carve that tensor instead of a fresh one);
+        returns (views, flat)."""
+        ncls = self.num_semcls + 1
+        widths = (ncls, 3, 3, 6, ncls, 3)
+        rows = 1
+        for d in lead:
+            rows *= int(d)
+        if flat is None:
+            flat = torch.empty(rows * sum(widths), dtype=torch.float32, device=device)
+        outs, off = [], 0
+        for wd in widths:
+            outs.append(flat[off: off + rows * wd].view(*lead, wd))
+            off += rows * wd
+        return outs, flat
 
     def _check_mode(self):
         """Inference entry points ignore dropout exactly like nn.Dropout in eval mode; in train mode WITHOUT autograd
@@ -637,18 +867,77 @@ class PARQDecoder(nn.Module):
         self._range_poll()
         sc, keep, dev = self._scene(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
         self._ensure_packed(dev)
-        outs = self._alloc_outputs((self.num_layers, sc.B, self.num_queries), dev)
-        po = _lib.ParqOutputs(*[_lib.ptr(t) for t in outs])
-        for _attempt in range(self.num_heads + 2):
-            ws = self._workspace(sc.B, sc.V, sc.h, sc.w, dev)
-            _lib.check(_lib.load().parq_forward(self._handle(), C.byref(sc), _lib.ptr(ws), ws.numel() * 4, C.byref(po),
-                                                _lib.stream_ptr()), "parq_forward")
-            # "sync" policy / first forward + a flag: once more with the exact fp32 kernels (range) or with the flagged heads on
-            # the fp16 x 3 tier (each re-run can only add heads: at most num_heads of them)
-            if not self._range_after_forward(ws, sc):
-                break
-        del keep
-        return [{k: t[i] for k, t in zip(OUTPUT_KEYS, outs)} for i in range(self.num_layers)]
+        self._order_behind_pack(dev)
+        lead = (self.num_layers, sc.B, self.num_queries)
+        flat = torch.empty(self.num_layers * sc.B * self.num_queries * self._out_width, dtype=torch.float32, device=dev)
+        entry = self._enqueue_forward(sc, keep, flat, dev)
+        # (everything below runs while the device works on the forward)
+        per = [t.unbind(0) for t in self._alloc_outputs_flat(lead, dev, flat=flat)[0]]
+        result = [dict(zip(OUTPUT_KEYS, [p[i] for p in per])) for i in range(self.num_layers)]
+
+        def settle():
+            """What policy "sync" owes the caller (and every policy owes a module's first forward): wait, look, and re-run — with the
+            exact fp32 kernels (range), or with the flagged heads on the fp16 x 3 tier (each re-run can only add heads: at most
+            num_heads of them) — into the SAME output tensors."""
+            e = entry
+            for _attempt in range(self.num_heads + 2):
+                if not self._range_after_forward(e, sc, dev):
+                    break
+                e = self._enqueue_forward(sc, keep, flat, dev)
+            return result
+
+        if self._defer is not None and self.range_check == "sync" and self.attention_mode in ("split", "split8", "fp16"):
+            self._defer.append(settle)         # InFlight.submit: the wait belongs to Ticket.result(), other forwards keep the device busy
+            return result
+        return settle()
+
+    def _out_pointers(self, base, rows):
+        """parq_outputs over one flat allocation at device address `base`: the six tensors back to back, `rows` rows each."""
+        ncls = self.num_semcls + 1
+        ptrs, off = [], 0
+        for wd in (ncls, 3, 3, 6, ncls, 3):
+            ptrs.append(C.c_void_p(base + 4 * off))
+            off += rows * wd
+        return _lib.ParqOutputs(*ptrs)
+
+    def _enqueue_forward(self, sc, keep, flat, dev):
+        """One inference forward into `flat` (the six output tensors back to back).  From the second forward of a (workspace, weights,
+        attention settings) on, the iterations are replayed from a captured graph behind the directly launched prologue and K/V
+        projection (parq_forward_replay); launch by launch otherwise (parq_forward).  Returns the workspace entry."""
+        lib = _lib.load()
+        h = self._handle()
+        entry = self._workspace_entry(sc.B, sc.V, sc.h, sc.w, dev, handle=h)
+        ws = entry.ws
+        self._set_mirror(entry.slot)
+        stream = C.c_void_p(entry.stream.cuda_stream)
+        po = self._out_pointers(flat.data_ptr(), self.num_layers * sc.B * self.num_queries)
+        graph = None
+        if self.use_graph and not self._profiling:
+            key = (self._arena_gen, self._mode_set, self._tiers_set, self._seams_set)
+            graph = entry.graphs.get(key)
+            if graph is None and entry.last_key == key:
+                graph = self._capture(entry, key, sc, stream)
+            entry.last_key = key
+        if graph is not None:
+            _lib.check(lib.parq_forward_replay(h, graph, C.byref(sc), _lib.ptr(ws), ws.numel() * 4, C.byref(po), stream), "parq_forward_replay")
+            entry.replays += 1
+        else:
+            _lib.check(lib.parq_forward(h, C.byref(sc), _lib.ptr(ws), ws.numel() * 4, C.byref(po), stream), "parq_forward")
+        self._mark_first_forward(dev)
+        return entry
+
+    def _capture(self, entry, key, sc, stream):
+        """Record the iterations of this workspace's forward into a HIP graph (parq_forward_capture); graphs of earlier weights / settings
+        of the same workspace are retired."""
+        if entry.graphs:
+            stale = _WsEntry(None, 0, entry.stream)
+            stale.graphs, entry.graphs = entry.graphs, {}
+            self._retire_graphs(stale)
+        g = C.c_void_p()
+        _lib.check(_lib.load().parq_forward_capture(self._handle(), sc.B, sc.V, sc.h, sc.w, _lib.ptr(entry.ws), entry.ws.numel() * 4, stream,
+                                                    C.byref(g)), "parq_forward_capture")
+        entry.graphs[key] = g
+        return g
 
     # ------------------------------------------------------------------ training (SURVEY.md §8f-1)
     @torch.no_grad()
@@ -667,6 +956,8 @@ class PARQDecoder(nn.Module):
             self._train_ws = None
         sc, keep, dev = self._scene(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
         self._ensure_packed(dev)
+        self._order_behind_pack(dev)
+        self._set_mirror(0)
         lib = _lib.load()
         # everything the caller enqueued so far (in particular the targets loss() will read on its side stream: an asynchronous
         # host-to-device copy, on-device augmentation) is ordered before this event
@@ -689,6 +980,7 @@ class PARQDecoder(nn.Module):
                 self._train_ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=dev)
             _lib.check(lib.parq_forward_train(h, C.byref(sc), _lib.ptr(self._train_ws), self._train_ws.numel() * 4, C.byref(po),
                                               _lib.stream_ptr()), "parq_forward_train")
+            self._mark_first_forward(dev)
             # the stash is laid out for `mode`: backward() uses exactly this mode, whatever attention_mode says by then
             self._train_state = (sc, keep, outs, po, dev, mode, p_drop, seed)
             own = self._stash_owner() if self._stash_owner is not None else None
@@ -798,7 +1090,10 @@ class PARQDecoder(nn.Module):
         self._check_mode()
         sc, keep, dev = self._scene(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
         self._ensure_packed(dev)
-        ws = self._workspace(sc.B, sc.V, sc.h, sc.w, dev)
+        self._order_behind_pack(dev)
+        entry = self._workspace_entry(sc.B, sc.V, sc.h, sc.w, dev)
+        ws = entry.ws
+        self._set_mirror(entry.slot)
         _lib.check(_lib.load().parq_prepare(self._handle(), C.byref(sc), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()),
                    "parq_prepare")
         self._step = (sc, keep, ws, dev)
@@ -841,6 +1136,8 @@ class PARQDecoder(nn.Module):
         self._range_poll()
         sc, keep, dev = self._scene(intput_tokens, camera, T_camera_pseudoCam, T_world_pseudoCam, T_world_local, feat_hw)
         self._ensure_packed(dev)
+        self._order_behind_pack(dev)
+        self._set_mirror(0)
         lib = _lib.load()
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         for _attempt in range(2):
@@ -888,12 +1185,16 @@ class PARQDecoder(nn.Module):
         del keep
         return results
 
+    def _last_ws(self):
+        k, entry = list(self._ws.items())[-1]
+        return k, entry.ws
+
     def fp16_range_exceeded(self):
         """True if the last prepare() / forward() / forward_train() saw a token, K or V element outside the fp16 range while
         building the 16-bit K/V cache (synchronises; meaningful in the "split" and "fp16" modes).  Outputs of such a call are
         NaN by construction (include/parq_hip.h); see ``range_check`` for the automatic handling."""
         if self._ws:
-            (B, V, h, w, _, _), ws = list(self._ws.items())[-1]        # the most recently used workspace
+            (B, V, h, w, _, _), ws = self._last_ws()                   # the most recently used workspace
         elif self._train_ws is not None and self._train_state is not None:
             sc = self._train_state[0]
             (B, V, h, w), ws = (sc.B, sc.V, sc.h, sc.w), self._train_ws
@@ -903,12 +1204,12 @@ class PARQDecoder(nn.Module):
 
     def attention_too_peaked(self):
         """True if the last inference forward in attention mode "split8" met a cross-attention row whose probabilities (relative to
-        the row's reference maximum) sum to less than 64, i.e. a row that rests on too few keys for that mode's error model
-        (synchronises).  ``range_check`` handles it: "lazy" switches the module to "split" at the next call, "sync" re-runs the
-        forward in "split" before returning."""
+        the row's reference maximum) sum to less than 256 on a head of the fast tier, i.e. a row that rests on too few keys for that
+        mode's error model (synchronises).  ``range_check`` handles it: "sync" re-runs the forward with the flagged heads on the
+        fp16 x 3 tier before returning, "lazy" moves them at the next call (``safe_heads``)."""
         if not self._ws:
             return False
-        (B, V, h, w, _, _), ws = list(self._ws.items())[-1]
+        (B, V, h, w, _, _), ws = self._last_ws()
         return bool(self._flag_view(ws, B, V, h, w, 2)[1].item() != 0)
 
     def attention_peaked_map(self):
@@ -916,7 +1217,7 @@ class PARQDecoder(nn.Module):
         under the guard threshold (synchronises).  The guard acts per head; this map says in which iterations."""
         if not self._ws:
             return []
-        (B, V, h, w, _, _), ws = list(self._ws.items())[-1]
+        (B, V, h, w, _, _), ws = self._last_ws()
         f = self._flag_view(ws, B, V, h, w, 64).tolist()
         return [f[8 + (k % 56)] for k in range(self.num_layers)]
 
@@ -926,7 +1227,7 @@ class PARQDecoder(nn.Module):
         every head's smallest sum instead — heads on the fp16 x 3 tier included (what ``tier_return_after`` looks at)."""
         if not self._ws:
             return None
-        (B, V, h, w, _, _), ws = list(self._ws.items())[-1]
+        (B, V, h, w, _, _), ws = self._last_ws()
         dec = lambda code: float(np.array([0x7fffffff - code], dtype=np.int32).view(np.float32)[0]) if code else None
         if per_head:
             f = self._flag_view(ws, B, V, h, w, 48).tolist()
@@ -943,6 +1244,7 @@ class PARQDecoder(nn.Module):
 
     # ------------------------------------------------------------------ profiling hooks used by bench.py
     def profile_enable(self, on=True):
+        self._profiling = bool(on)                      # the library's per-group events are host-side records: no graph replay meanwhile
         _lib.check(_lib.load().parq_profile_enable(self._handle(), int(on)), "parq_profile_enable")
 
     def profile_read(self):

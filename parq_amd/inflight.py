@@ -8,7 +8,7 @@ second scene's K/V projection / cross-attention fills it: two scenes in flight r
     runner = InFlight(model, depth=2)            # model: PARQDecoder, AddRayPE, PARQ - anything whose call enqueues
     tickets = [runner.submit(*batch) for batch in batches[:2]]
     for nxt in batches[2:]:
-        out = tickets.pop(0).result()             # orders the CALLER's current stream behind that forward
+        out = tickets.pop(0).result()             # waits for THAT forward (the other one runs meanwhile), checks it, orders the caller's stream behind it
         ...                                       # consume `out` on the current stream
         tickets.append(runner.submit(*nxt))
 
@@ -35,21 +35,49 @@ def _tensors(obj):
 
 
 class Ticket:
-    """One submitted forward.  ``result()`` makes the caller's current stream wait for it and hands out its outputs."""
+    """One submitted forward.  ``result()`` hands out its outputs, ordered in front of whatever the caller enqueues next on its
+    current stream.  Under the decoder's default policy (``range_check = "sync"``: a forward never returns NaN, it is re-run with safer
+    arithmetic instead) the check that a one-at-a-time call makes before it returns is made HERE: ``result()`` waits on the host for
+    this forward — the other forwards in flight keep the device busy meanwhile — and, if the device flagged it, re-runs it on its
+    stream before handing the outputs out.  Under ``range_check = "lazy"`` / ``"off"`` nothing waits on the host; ``valid()`` tells
+    whether the outputs are numbers."""
 
-    def __init__(self, outputs, event, stream):
-        self._out, self._ev, self._stream = outputs, event, stream
+    def __init__(self, outputs, event, stream, settle=()):
+        self._out, self._ev, self._stream, self._settle = outputs, event, stream, list(settle)
 
     def done(self):
         return self._ev.query()
 
     def result(self):
+        if self._settle:
+            with torch.cuda.stream(self._stream):
+                for fn in self._settle:         # host wait + the pinned word of this forward's workspace; a flagged forward is re-run
+                    fn()
+                self._settle = []
+                self._ev = torch.cuda.Event()
+                self._ev.record(self._stream)
         cur = torch.cuda.current_stream(self._stream.device)
         cur.wait_event(self._ev)
         for t in _tensors(self._out):           # allocated on the side stream, consumed on the caller's: tell the caching allocator
             if t.is_cuda:
                 t.record_stream(cur)
         return self._out
+
+    def valid(self):
+        """True if every floating-point output of this forward is finite (waits for the forward; one small reduction per tensor).
+        For callers that run ``range_check = "lazy"``: a forward that met inputs outside its arithmetic's guarantees is all NaN."""
+        self._ev.synchronize()
+        with torch.cuda.stream(self._stream):
+            return all(bool(torch.isfinite(t).all()) for t in _tensors(self._out) if t.is_cuda and t.is_floating_point())
+
+
+def _decoders(module):
+    """The PARQDecoder(s) inside `module` (itself, or the ``box3d_decoder`` of a PARQ module)."""
+    out = []
+    for m in (module, getattr(module, "box3d_decoder", None)):
+        if m is not None and hasattr(m, "_defer") and hasattr(m, "range_check"):
+            out.append(m)
+    return out
 
 
 class InFlight:
@@ -62,11 +90,8 @@ class InFlight:
         self.module, self.device = module, torch.device(device)
         self._streams = [torch.cuda.Stream(self.device) for _ in range(depth)]
         self._next = 0
-        if hasattr(module, "max_workspaces"):    # one workspace per stream stays cached (PARQDecoder)
-            module.max_workspaces = max(int(module.max_workspaces), depth)
-        dec = getattr(getattr(module, "box3d_decoder", None), "max_workspaces", None)
-        if dec is not None:
-            module.box3d_decoder.max_workspaces = max(int(dec), depth)
+        for dec in _decoders(module):            # one workspace per stream stays cached (PARQDecoder)
+            dec.max_workspaces = max(int(dec.max_workspaces), depth)
 
     @property
     def depth(self):
@@ -82,11 +107,19 @@ class InFlight:
         for t in _tensors((args, kwargs)):       # the arguments were allocated on the caller's stream and are read on `side`
             if t.is_cuda:
                 t.record_stream(side)
-        with torch.cuda.stream(side):
-            out = self.module(*args, **kwargs)
-            ev = torch.cuda.Event()
-            ev.record(side)
-        return Ticket(out, ev, side)
+        decs = _decoders(self.module)
+        settle = []
+        for d in decs:
+            d._defer = settle                    # the decoder hands its post-forward check over instead of waiting inside the call
+        try:
+            with torch.cuda.stream(side):
+                out = self.module(*args, **kwargs)
+                ev = torch.cuda.Event()
+                ev.record(side)
+        finally:
+            for d in decs:
+                d._defer = None
+        return Ticket(out, ev, side, settle)
 
     def drain(self):
         for s in self._streams:

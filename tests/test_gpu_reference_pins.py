@@ -167,7 +167,7 @@ def test_cfg2_golden(mode, tol):
 # ----------------------------------------------------------------------------------------------------------------- g21
 def test_peaked_golden_in_the_tier_the_guard_selects():
     """g21 (reference: model/transformer_parq.py:283-337 on sharpened attention, captured by oracle/make_golden.py): the default
-    module — attention mode "split8", policy "lazy" — must trip its guard on this fixture (first-forward check), move the flagged
+    module — attention mode "split8", policy "sync" — must trip its guard on this fixture (every forward is checked), move the flagged
     heads to the fp16 x 3 tier, and then match the reference's fp32 vectors teacher-forced at an unrelaxed 1e-4 on all 24 (iteration,
     output) comparisons.  The same fixture with every head forced onto the fast tier (policy "off") is printed beside it."""
     import warnings
@@ -175,7 +175,7 @@ def test_peaked_golden_in_the_tier_the_guard_selects():
     cfg, W, sc = G.inputs(case)
     refs = G.forced_refs(z, cfg.TRANSFORMER.SCALE)
     dec = make_decoder(cfg, W)
-    assert dec.attention_mode == "split8" and dec.range_check == "lazy"
+    assert dec.attention_mode == "split8" and dec.range_check == "sync"
     with warnings.catch_warnings(record=True) as caught, torch.no_grad():
         warnings.simplefilter("always")
         dec(*scene_args(sc), feat_hw=(case["h"], case["w"]))           # first forward: checked synchronously, re-run per flagged head set

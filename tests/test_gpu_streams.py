@@ -156,3 +156,98 @@ def test_inflight_runner_over_the_whole_module_ray_pe_and_decoder():
                     for key in want[i][k]:
                         assert torch.equal(got[i][k][key], want[i][k][key]), (rep, i, k, key)
     assert len(model.add_ray_pe._ws_parked) + 1 >= 2                  # one ray-PE workspace per stream
+
+
+def test_cold_start_two_submits_on_a_fresh_module_and_a_repack_while_forwards_are_in_flight():
+    """the weight arena is packed — and its derived forms are built — on whichever stream calls first.  (1) A FRESH
+    module whose first two forwards are two InFlight submits (no serial call before): the second stream's forward must wait for the
+    pack + derived weights the first stream enqueued.  (2) A weight update between submits: forwards in flight keep reading the arena
+    they were enqueued with (the allocator may not hand its block out early), later ones see the new weights on every stream."""
+    from parq_amd import InFlight
+    V, h, w, Q, dim, I = 4, 60, 80, 64, 256, 2
+    cfg = synth.decoder_cfg(dim=dim, queries=Q, heads=4, ffn=256, layers=I)
+    W = synth.make_decoder_weights(cfg, 371, damped=True)
+    host = [scene_args(_scene(372 + i, V, h, w, dim)) for i in range(2)]
+    ref = make_decoder(cfg, W).eval()
+    ref.range_check = "off"
+    with torch.no_grad():
+        want = [[{k: v.clone() for k, v in o.items()} for o in ref(*a, feat_hw=(h, w))] for a in host]
+        torch.cuda.synchronize()
+        for rep in range(3):
+            dec = make_decoder(cfg, W).eval()             # never called before
+            dec.range_check = "off"
+            runner = InFlight(dec, depth=2)
+            tickets = [runner.submit(*a, feat_hw=(h, w)) for a in host]
+            got = [t.result() for t in tickets]
+            torch.cuda.synchronize()
+            for i in (0, 1):
+                for k in range(I):
+                    for key in want[i][k]:
+                        assert torch.equal(got[i][k][key], want[i][k][key]), (rep, i, k, key)
+        # (2) re-pack while in flight
+        bias = "mlp_heads.size_head.layers.0.bias"
+        W2 = dict(W)
+        W2[bias] = (W[bias] + 0.5).astype(W[bias].dtype)
+        ref2 = make_decoder(cfg, W2).eval()
+        ref2.range_check = "off"
+        want2 = [[{k: v.clone() for k, v in o.items()} for o in ref2(*a, feat_hw=(h, w))] for a in host]
+        torch.cuda.synchronize()
+        for rep in range(3):
+            dec = make_decoder(cfg, W).eval()
+            dec.range_check = "off"
+            runner = InFlight(dec, depth=2)
+            old = [runner.submit(*a, feat_hw=(h, w)) for a in host] + [runner.submit(*a, feat_hw=(h, w)) for a in host]
+            dec.mlp_heads["size_head"].layers["0"].bias.add_(0.5)          # an optimizer-style update while four forwards are queued
+            junk = [torch.empty_like(dec._arena).fill_(float("nan")) for _ in range(3)]     # what would land in a prematurely freed arena block
+            new = [runner.submit(*a, feat_hw=(h, w)) for a in host]
+            got_old, got_new = [t.result() for t in old], [t.result() for t in new]
+            torch.cuda.synchronize()
+            del junk
+            for i in range(4):
+                for k in range(I):
+                    for key in want[i % 2][k]:
+                        assert torch.equal(got_old[i][k][key], want[i % 2][k][key]), ("old", rep, i, k, key)
+            for i in (0, 1):
+                for k in range(I):
+                    for key in want2[i][k]:
+                        assert torch.equal(got_new[i][k][key], want2[i][k][key]), ("new", rep, i, k, key)
+
+
+def test_inflight_under_the_default_policy_settles_in_result_and_never_hands_out_nan():
+    """Default policy ("sync") + InFlight: submit() does not wait on the host (the ticket carries the check), result() waits for ITS
+    forward, and a scene with peaked cross-attention comes back finite and equal to mode "split" — re-run on its stream inside
+    result() — while the diffuse scene submitted beside it is untouched."""
+    import warnings
+    import numpy as np
+    from parq_amd import InFlight
+    import golden_util as G
+    case, z = G.load("g15_cfg5_shape")
+    cfg, W, sc = G.inputs(case)
+    sc2 = dict(sc)
+    sc2["tokens"] = (sc["tokens"] * 4.0).astype(np.float32)
+    a1, a2 = scene_args(sc), scene_args(sc2)
+    split = make_decoder(cfg, W).eval()
+    split.attention_mode = "split"
+    fast = make_decoder(cfg, W).eval()
+    with torch.no_grad(), warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        want2 = [{k: v.clone() for k, v in o.items()} for o in split(*a2)]
+        want1 = [{k: v.clone() for k, v in o.items()} for o in fast(*a1)]
+        torch.cuda.synchronize()
+        dec = make_decoder(cfg, W).eval()
+        assert dec.range_check == "sync"
+        dec(*a1)                                                  # the module's first forward (checked synchronously under every policy)
+        runner = InFlight(dec, depth=2)
+        t1 = runner.submit(*a1)
+        t2 = runner.submit(*a2)
+        assert dec.safe_heads == 0, "submit() must not have waited for the device"
+        got1, got2 = t1.result(), t2.result()
+        torch.cuda.synchronize()
+    assert dec.safe_heads == 0b1111
+    for a, b in zip(got1, want1):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    for a, b in zip(got2, want2):
+        for k in a:
+            assert torch.isfinite(a[k]).all() and torch.equal(a[k], b[k]), k
+    assert t1.valid() and t2.valid()

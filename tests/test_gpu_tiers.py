@@ -76,7 +76,7 @@ def test_lazy_policy_never_returns_numbers_from_outside_the_error_model():
     cfg, W, sc, _ = _case(4.0)
     want = _split_reference(cfg, W, sc)
     dec = make_decoder(cfg, W)
-    assert dec.range_check == "lazy"
+    dec.range_check = "lazy"               # opt-in (servers): the default is "sync"
     dec._peaky_checked = True              # as if an earlier (spread) forward had passed the first-call check: the lazy path proper
     dec._ensure_packed(torch.device("cuda", torch.cuda.current_device()))
     dec._peaky_checked = True              # (packing the weights re-arms the first-forward check)
@@ -97,7 +97,8 @@ def test_first_forward_is_checked_under_the_lazy_policy():
     cfg, W, sc, _ = _case(4.0)
     want = _split_reference(cfg, W, sc)
     dec = make_decoder(cfg, W)
-    assert dec.attention_mode == "split8" and dec.range_check == "lazy"
+    dec.range_check = "lazy"
+    assert dec.attention_mode == "split8"
     with warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter("always")
         got = _run(dec, sc)
@@ -114,6 +115,7 @@ def test_diffuse_scene_then_peaked_scene_same_module_lazy():
     never plain wrong; the call after that is right."""
     cfg, W, sc, _ = _case(1.0)
     dec = make_decoder(cfg, W)
+    dec.range_check = "lazy"
     first = _run(dec, sc)
     assert dec.safe_heads == 0 and all(torch.isfinite(v).all() for o in first for v in o.values())
     sc2 = dict(sc)
@@ -131,6 +133,100 @@ def test_diffuse_scene_then_peaked_scene_same_module_lazy():
         again = _run(dec, sc2)
     assert dec.safe_heads != 0
     assert _worst(again[:1], want[:1]) < 2e-5          # (free-running: iteration 0; all heads safe -> bit-identical anyway)
+
+
+def test_diffuse_scene_then_peaked_scene_same_module_default_policy_returns_mode_split_numbers():
+    """VERDICT r05, item 1 (reference behaviour: model/transformer_parq.py:377-380 never returns NaN; eval.py:45-48 consumes every
+    snippet's outputs).  The DEFAULT policy on the same sequence — a diffuse scene, then a peaked one, same module, also with the
+    forward replayed from its captured graph in between: the peaked scene's outputs are finite and equal mode "split"'s bit for bit
+    (all four heads trip and move: a module whose heads are all safe IS mode "split"), in the call that met the rows, not the next."""
+    cfg, W, sc, _ = _case(1.0)
+    dec = make_decoder(cfg, W)
+    assert dec.attention_mode == "split8" and dec.range_check == "sync", "the never-NaN policy is the default"
+    for _ in range(3):                                   # (the third call replays the captured forward)
+        first = _run(dec, sc)
+        assert dec.safe_heads == 0 and all(torch.isfinite(v).all() for o in first for v in o.values())
+    sc2 = dict(sc)
+    sc2["tokens"] = (sc["tokens"] * 4.0).astype(np.float32)
+    want = _split_reference(cfg, W, sc2)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        got = _run(dec, sc2)
+    assert dec.safe_heads == 0b1111 and any("too few keys" in str(w.message) for w in caught)
+    for a, b in zip(got, want):
+        for k in a:
+            assert torch.isfinite(a[k]).all(), k
+            assert torch.equal(a[k], b[k]), k
+    again = _run(dec, sc2)                               # and the calls after it (one of them from a graph) stay there
+    again = _run(dec, sc2)
+    for a, b in zip(again, want):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+
+
+def test_validation_step_over_three_snippets_with_one_peaked_snippet_default_policy():
+    """The same at module level, as eval.py drives it (eval.py:45-48: `model.validation_step(batch, 0)` per snippet): three snippets
+    through parq_amd.PARQ.validation_step with the default policy, the middle one with features x 6 (peaked cross-attention).  No snippet
+    loses its detections: snippet 1 is within mode "split8"'s stated distance of a mode-"split" module (fast tier, iteration 0),
+    snippets 2 and 3 equal the mode-"split" module bit for bit (the flagged heads moved inside snippet 2's call)."""
+    from types import SimpleNamespace as NS
+    from parq_amd import PARQ, Camera, Pose
+    from gpu_util import dev
+    B, V, h, w, Cd, Qn, I = 1, 4, 48, 64, 256, 64, 3
+    dcfg = synth.decoder_cfg(dim=Cd, queries=Qn, heads=4, ffn=768, layers=I)
+    pcfg = NS(MODEL=NS(TOKENIZER=NS(OUT_CHANNELS=Cd, RAY_POINTS_SCALE=dcfg.TRANSFORMER.SCALE, NUM_SAMPLES=64, MIN_DEPTH=0.25, MAX_DEPTH=5.25),
+                       DECODER=dcfg))
+    W = synth.make_decoder_weights(dcfg, 811)
+    Wp = synth.make_ray_pe_weights(Cd, 812)
+
+    def build(mode):
+        model = PARQ(pcfg).eval()
+        sd = model.state_dict()
+        for k in sd:
+            if k.startswith("box3d_decoder."):
+                src = k[len("box3d_decoder."):].replace("parq_module.decoder.mlp_heads.", "mlp_heads.")
+                sd[k] = torch.from_numpy(W[src]).reshape(sd[k].shape)
+            else:
+                sd[k] = torch.from_numpy(Wp[k[len("add_ray_pe."):]])
+        model.load_state_dict(sd, strict=True)
+        model = model.cuda()
+        if mode:
+            model.box3d_decoder.attention_mode = mode
+        return model
+
+    def snippet(seed, gain):
+        cam, T_cp, T_wp, T_wl = synth.make_geometry(seed, B, V, h, w)
+        feat = synth.normal(seed + 1, "feat", (B, V, Cd, h, w), std=1.0) * np.float32(gain)
+        return {"all_features": dev(feat), "camera_feature": Camera(dev(cam)), "T_camera_pseudoCam": Pose(dev(T_cp)),
+                "T_world_pseudoCam": Pose(dev(T_wp)), "T_world_local": Pose(dev(T_wl))}
+    snippets = [snippet(820, 1.0), snippet(830, 6.0), snippet(840, 1.0)]
+
+    def run(model):
+        got = []
+        real = model.box3d_decoder.forward
+        with torch.no_grad(), warnings.catch_warnings(record=True):
+            warnings.simplefilter("always")
+            for b in snippets:
+                seen = {}
+                model.box3d_decoder.forward = lambda *a, _r=real, **k: seen.setdefault("o", _r(*a, **k))
+                model.validation_step(dict(b), 0)
+                got.append([{k: v.clone() for k, v in o.items()} for o in seen["o"]])
+        model.box3d_decoder.forward = real
+        torch.cuda.synchronize()
+        return got
+    model = build(None)
+    assert model.box3d_decoder.range_check == "sync" and model.box3d_decoder.attention_mode == "split8"
+    got = run(model)
+    assert model.box3d_decoder.safe_heads == 0b1111, "the x 6 snippet is meant to trip the guard on every head"
+    want = run(build("split"))
+    for i in range(3):
+        for o in got[i]:
+            assert all(torch.isfinite(v).all() for v in o.values()), i
+    assert _worst(got[0][:1], want[0][:1]) < 3e-5
+    for i in (1, 2):
+        for a, b in zip(got[i], want[i]):
+            for k in a:
+                assert torch.equal(a[k], b[k]), (i, k)
 
 
 def test_off_policy_returns_numbers_and_reports_the_map():

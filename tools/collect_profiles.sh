@@ -19,13 +19,13 @@ python bench.py --config shipped --steps 20 --warmup 3 > $out/bench_shipped.json
 python bench.py --train --steps 8 --warmup 2 --phase-times > $out/bench_train_phases.json 2>> $out/bench.err
 python bench.py --gpus 2 --share-device --steps 5 --warmup 1 --no-cpu-baseline --no-b32 2>> $out/bench.err | grep "^{" > $out/bench_2ranks_shared.json
 export TMPDIR=/tmp
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-b32 > $out/kt.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 /root/repo/bench.py --kernels-only --steps 20 --warmup 3 > $out/kt.log 2>&1)
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA"; do
   name=$(echo $pass | cut -d' ' -f1)
-  (cd /tmp && rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $out/pmc_$name -o pmc -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-b32 > $out/pmc_$name.log 2>&1)
+  (cd /tmp && rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $out/pmc_$name -o pmc -- python3 /root/repo/bench.py --kernels-only --steps 2 --warmup 1 > $out/pmc_$name.log 2>&1)
 done
 for pass in "FETCH_SIZE" "WRITE_SIZE"; do
-  (cd /tmp && rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $out/pmc32_$pass -o pmc -- python3 /root/repo/bench.py --scenes-per-gpu 32 --steps 1 --warmup 1 --no-cpu-baseline --no-b32 > $out/pmc32_$pass.log 2>&1)
+  (cd /tmp && rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $out/pmc32_$pass -o pmc -- python3 /root/repo/bench.py --kernels-only --scenes-per-gpu 32 --steps 1 --warmup 1 > $out/pmc32_$pass.log 2>&1)
 done
 python tools/pmc_summary.py $(find $out -name "*counter_collection.csv" | sort) > $out/pmc_summary.txt 2>&1
 python tools/make_pmc_json.py $out > $out/pmc.json 2> $out/pmc_json.err

@@ -5,7 +5,7 @@ out=/root/repo/gpurun_out/${1:-r05_cfg5_pmc}
 mkdir -p $out
 export TMPDIR=/tmp
 for ctr in FETCH_SIZE; do
-  (cd /tmp && timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/$ctr -o pmc -- python3 /root/repo/bench.py --config cfg5 --steps 2 --warmup 1 --no-cpu-baseline --no-b32 --no-peaked > $out/$ctr.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/$ctr -o pmc -- python3 /root/repo/bench.py --kernels-only --config cfg5 --steps 2 --warmup 1 > $out/$ctr.log 2>&1)
 done
 python - <<PY
 import csv, glob, collections
