@@ -298,7 +298,8 @@ int carve_workspace(const parq_ctx* c, int B, int V, int h, int w, Workspace* ws
     // dQ partials per iteration
     ws->bwd_batched = bwd_batched_ok(c, N);
     const int64_t nit = ws->bwd_batched ? c->I : 1;
-    ws->g_dqp = take(nit * (int64_t)attn_bwd_dq_partial_floats(B, c->H, (int)Q, (int)N, c->dh));
+    // (batched head-dim-64 backward: a workgroup of attn_bwd_split2_kernel keeps one slot for its group of key blocks)
+    ws->g_dqp = take(nit * (int64_t)attn_bwd_dq_partial_floats(B, c->H, (int)Q, (int)N, c->dh, ws->bwd_batched && c->dh == 64));
     ws->g_do = take(ws->bwd_batched ? nit * M * C : 0);
     ws->g_res = take(ws->bwd_batched ? nit * M * C : 0);
     ws->g_dq = take(ws->bwd_batched ? nit * M * C : 0);

@@ -48,6 +48,7 @@ struct AttnBwdArgs {
     const _Float16* kvcache;
     int cache_kind;            // kF16 / kBF16 of a single-product cache
     int probe;                     // development build only (PARQ_ATTN_BWD_PROBE): pieces of attn_bwd_split2_kernel left out, for timing
+    int kb_group;                  // attn_bwd_split2_kernel: consecutive key blocks per workgroup (they share one slot of dQ partials)
 };
 
 template <int DH>
@@ -683,10 +684,11 @@ __global__ __launch_bounds__(256) void attn_bwd_pack_kernel(AttnBwdArgs a, const
 // S and dP = dO V^T, which feed the exponential and dS itself, keep all three terms.  (false: the round-3 form, kept for A/B.)
 constexpr bool kGrad1 = true;
 
-template <bool DROP, bool RAGGED, int PIPE = 1, int CACHE = 0>
-__global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, const float* __restrict__ oscale_ptr,
-                                                              const _Float16* __restrict__ pack) {
-    const float oscale = *oscale_ptr;
+// One key block of 256 keys (kbx) against every query tile of every iteration.  `add`: the workgroup has already written dQ partials of an
+// earlier key block of its group into its slot (attn_bwd_split2_kernel): this block's are added to them.
+template <bool DROP, bool RAGGED, int PIPE, int CACHE>
+__device__ __forceinline__ void attn_bwd_split2_block(const AttnBwdArgs& a, const float oscale, const _Float16* __restrict__ pack,
+                                                      const int kbx, const bool add) {
 #ifdef PARQ_DEV_PROBES
     const int probe = a.probe;              // 1: no dQ tile, 2: no softmax / dS arithmetic, 4: no dV / dK products, 8: no S / dP products
 #else
@@ -702,7 +704,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
     const int t16 = lane & 15, g16 = lane >> 4;
     const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
     const int jw = wave * 32 + li;                   // key inside the workgroup
-    const int j = blockIdx.x * kSpKW + jw;
+    const int j = kbx * kSpKW + jw;
     const bool jok = j < a.Lk;
     const int Lq_pad = (a.Lq + 31) & ~31;
     const int ntiles = Lq_pad >> 5;
@@ -719,7 +721,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
         // d = 32 m + 16 c + 4 h + (e' & 3) + 8 (e' >> 2); element e of fragment t (d = 16 t + 8 kh + e) is byte 8 (t >> 1) + 4 kh + (e & 3)
         // of piece (c = t & 1, h = e >> 2).
         const int nblk = (a.Lk + 31) >> 5;
-        int blk = blockIdx.x * (kSpKW / 32) + wave;
+        int blk = kbx * (kSpKW / 32) + wave;
         blk = blk < nblk ? blk : nblk - 1;
         const unsigned char* stage = reinterpret_cast<const unsigned char*>(a.kvcache) + ((int64_t)bh * (nblk >> 1) + (blk >> 1)) * kStage8Bytes;
         const int b2 = blk & 1;
@@ -762,7 +764,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
         // chunk 2 m + kh'' holds keys 16 m + 4 kh'' + (e & 3) + 8 (e >> 2) at position c ^ ((d >> 2) & 3): one 16-bit element per d.
         constexpr int kBH = CACHE == 3 ? 8192 : 4096, kVo = CACHE == 3 ? 4096 : 2048;
         const int nblk = (a.Lk + 31) >> 5;
-        int blk = blockIdx.x * (kSpKW / 32) + wave;
+        int blk = kbx * (kSpKW / 32) + wave;
         blk = blk < nblk ? blk : nblk - 1;                         // past the end: any valid block (masked by jok below)
         const _Float16* cb = a.kvcache + ((int64_t)bh * nblk + blk) * kBH;
         const int ksw = (li >> 1) & 7;
@@ -852,7 +854,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
     typedef float f32x4v __attribute__((ext_vector_type(4)));
     // ---- dQ tile of query tile `nd` = dS K over the 256 keys of the workgroup: wave w owns the 16 x 16 block (queries 16 (w>>2).., d 16 (w&3)..).
     // Reads Ds (the dS^T image of that tile) and Ki; 24 MFMAs + 32 transpose reads, no VALU to speak of.
-    auto dq_tile = [&](int nd) {
+    auto dq_tile = [&](int nd, bool real = true) {      // real = false: the placeholder call at n == 0 (see the loop)
         if (probe & 1) return;
         f32x4v g4 = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -876,8 +878,14 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
         // accumulator: rows qb + 4 g16 + r, column db + t16
         const int itd = nd / ntiles, i0d = (nd - itd * ntiles) * 32;
         float* part = a.gq_part + (int64_t)itd * a.gqp_it + (((int64_t)bh * gridDim.x + blockIdx.x) * Lq_pad + i0d) * 64;
+        if (add) {                               // scalar branch: four no-return atomics instead of four stores (same vmcnt count)
+            // (the placeholder call adds zeros: as stores its values are overwritten by tile 0's real ones, as atomics they would stay)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) part[(qb + 4 * g16 + r) * 64 + db + t16] = g4[r] * cn * inv_os;
+            for (int r = 0; r < 4; ++r) atomicAdd(part + (qb + 4 * g16 + r) * 64 + db + t16, real ? g4[r] * cn * inv_os : 0.f);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(qb + 4 * g16 + r) * 64 + db + t16] = g4[r] * cn * inv_os;
+        }
     };
     // which waves go first: PIPE 1 = waves 4..7, PIPE 2 = odd waves (whichever pairs share a SIMD).  Wave-uniform: a scalar branch
     const bool upper_wave = PIPE == 2 ? (__builtin_amdgcn_readfirstlane(wave) & 1) != 0 : __builtin_amdgcn_readfirstlane(wave) >= 4;
@@ -900,7 +908,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
         // registers.  At n == 0 there is no previous tile: the same code runs on whatever Ds holds and its result lands in tile
         // 0's slot, which the next iteration overwrites with the real dQ of tile 0 (same lanes, stores retire in order).
         if constexpr (PIPE) {
-            if (upper_wave) dq_tile(n > 0 ? n - 1 : 0);
+            if (upper_wave) dq_tile(n > 0 ? n - 1 : 0, n > 0);
         }
 
         // ---- S = Q K^T, dP = dO V^T  (rows = queries, columns = this wave's keys)
@@ -997,7 +1005,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
             lds_barrier();
             dq_tile(n);
         } else {
-            if (!upper_wave) dq_tile(n > 0 ? n - 1 : 0);    // the lower waves' turn (their P / dS operands are dead by now)
+            if (!upper_wave) dq_tile(n > 0 ? n - 1 : 0, n > 0);    // the lower waves' turn (their P / dS operands are dead by now)
             lds_barrier();                                   // every wave has read the previous tile's dS^T image
             write_ds();                                      // visible to the next interval through the barrier at the top of the loop
         }
@@ -1020,7 +1028,7 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
         __builtin_amdgcn_wave_barrier();
         float* g = which == 0 ? a.gk + (int64_t)b * a.gk_batch + (int64_t)h * a.gk_head : a.gv + (int64_t)b * a.gv_batch + (int64_t)h * a.gv_head;
         const int64_t grow = which == 0 ? a.gk_row : a.gv_row;
-        const int j0 = blockIdx.x * kSpKW + wave * 32;
+        const int j0 = kbx * kSpKW + wave * 32;
         for (int idx = lane; idx < 32 * 64; idx += 64) {
             const int jj = idx >> 6, d = idx & 63;
             if (j0 + jj < a.Lk) {
@@ -1037,6 +1045,23 @@ __global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, con
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) kvmax = fmaxf(kvmax, __shfl_xor(kvmax, o));
         if (lane == 0) atomicMax(a.kv_absmax, __float_as_uint(kvmax));
+    }
+}
+
+// A workgroup works through a.kb_group CONSECUTIVE key blocks and keeps ONE slot of dQ partials for all of them: the first block stores its
+// partial tiles, the later ones add theirs with no-return float atomics (the slot belongs to this workgroup alone: no contention, a fixed
+// order, the same vmcnt bookkeeping as stores).  The partial array — written by this kernel and read back by attn_bwd_dq_reduce_kernel — shrinks
+// by that factor: at BASELINE cfg 4's shard (4 scenes, 8 iterations) from 6.3 GB to 1.6 GB per step, the reduction from 1.05 to ~0.3 ms.
+template <bool DROP, bool RAGGED, int PIPE = 1, int CACHE = 0>
+__global__ __launch_bounds__(512) void attn_bwd_split2_kernel(AttnBwdArgs a, const float* __restrict__ oscale_ptr,
+                                                              const _Float16* __restrict__ pack) {
+    const float oscale = *oscale_ptr;
+    const int nkb = (a.Lk + kSpKW - 1) / kSpKW;
+    for (int pass = 0; pass < a.kb_group; ++pass) {
+        const int kbx = (int)blockIdx.x * a.kb_group + pass;
+        if (kbx >= nkb) break;
+        if (pass > 0) __syncthreads();          // the next block rewrites the K image and the staging slots
+        attn_bwd_split2_block<DROP, RAGGED, PIPE, CACHE>(a, oscale, pack, kbx, pass > 0);
     }
 }
 
@@ -1212,7 +1237,7 @@ hipError_t launch_attn_bwd(const float* q, int64_t q_batch, int64_t q_head, int6
     a.gv = gv; a.gv_batch = gv_batch; a.gv_head = gv_head; a.gv_row = gv_row;
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.accumulate_kv = accumulate_kv; a.gq_part = nullptr;
     a.drop_p = drop_p; a.drop_seed = drop_seed;
-    a.n_it = 1; a.do_it = a.D_it = a.gqp_it = 0; a.kv_absmax = nullptr;
+    a.n_it = 1; a.do_it = a.D_it = a.gqp_it = 0; a.kv_absmax = nullptr; a.kb_group = 1;
     memset(a.q_off, 0, sizeof(a.q_off));
     memset(a.lse_off, 0, sizeof(a.lse_off));
     for (int t = 0; t < kMaxBwdIters; ++t) a.seeds[t] = drop_seed;
@@ -1448,7 +1473,6 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
         hipError_t e0 = hipMemsetAsync(kv_absmax, 0, sizeof(unsigned int), s);
         if (e0 != hipSuccess) return e0;
     }
-    a.gqp_it = (int64_t)attn_bwd_dq_partial_floats(B, H, Lq, Lk, dh);
     for (int t = 0; t < kMaxBwdIters; ++t) {
         a.q_off[t] = t < n_it ? q_off[t] : 0;
         a.lse_off[t] = t < n_it ? lse_off[t] : 0;
@@ -1462,9 +1486,14 @@ hipError_t launch_attn_bwd_batched(const float* q, const int64_t* q_off, int64_t
     float* oscale = reinterpret_cast<float*>(absmax + 1);
     hipLaunchKernelGGL(oscale_kernel, dim3(1), dim3(1), 0, s, absmax, oscale);
     if (dh == 256) return attn_bwd_batched_256(a, gq_it, oscale, mat_scratch, s);     // (kv_absmax: taken by the caller over its dK | dV buffer)
-    dim3 g2(ceil_div(Lk, kSpKW), B * H);
-    const int Lq_pad = (Lq + 31) & ~31;
     static const bool v1 = [] { const char* e = dev_env("PARQ_ATTN_BWD_V"); return e && e[0] == '1'; }();
+    // second version: a workgroup takes kb_group consecutive key blocks and keeps one slot of dQ partials for them (see the kernel)
+    if (v1 || !pack) return hipErrorNotSupported;          // (the first-version kernel wants one partial slot per key block: the workspace no longer has them)
+    const bool grouped = true;
+    a.kb_group = grouped ? attn_bwd_kb_group(B, H, Lk) : 1;
+    a.gqp_it = (int64_t)attn_bwd_dq_partial_floats(B, H, Lq, Lk, dh, grouped);
+    dim3 g2(ceil_div(ceil_div(Lk, kSpKW), a.kb_group), B * H);
+    const int Lq_pad = (Lq + 31) & ~31;
     if (kvcache && (v1 || !pack)) return hipErrorNotSupported;          // only the second-version kernel reads the 16-bit cache
     if (pack && !v1) {
         // second version: tile images packed once, fetched by LDS-DMA; transpose reads
@@ -1531,9 +1560,19 @@ size_t attn_bwd_pack_floats(int B, int H, int Lq, int n_it) {
 }
 
 // scratch floats for the dQ partials of launch_attn_bwd (0 when the atomics path is taken)
-size_t attn_bwd_dq_partial_floats(int B, int H, int Lq, int Lk, int dh) {
+size_t attn_bwd_dq_partial_floats(int B, int H, int Lq, int Lk, int dh, bool grouped) {
     if (dh != 64 || Lk < 2048) return 0;
-    return (size_t)B * H * ceil_div(Lk, 256) * ((Lq + 31) & ~31) * 64;
+    const int slots = grouped ? ceil_div(ceil_div(Lk, 256), attn_bwd_kb_group(B, H, Lk)) : ceil_div(Lk, 256);
+    return (size_t)B * H * slots * ((Lq + 31) & ~31) * 64;
+}
+
+// key blocks per workgroup of the batched split-precision kernel (attn_bwd_split2_kernel): 4 while that leaves at least 512 workgroups
+int attn_bwd_kb_group(int B, int H, int Lk) {
+    const int nkb = ceil_div(Lk, 256);
+    static const int want = [] { const char* e = dev_env("PARQ_BWD_KB_GROUP"); return e && atoi(e) > 0 ? atoi(e) : 4; }();      // development A/B: 1 = one slot per key block
+    int g = want;
+    while (g > 1 && (int64_t)B * H * ceil_div(nkb, g) < 512) g >>= 1;
+    return g;
 }
 
 hipError_t launch_attn_bwd_rowdot(const float* dO, const float* O, int64_t batch, int64_t row, int B, int H, int Lq, int dh, float* D,

@@ -530,7 +530,8 @@ hipError_t launch_kvproj_bwd_split(const float* g, const float* tokens, int64_t 
                                    const unsigned int* absmax_bits, float* scale_scratch, hipStream_t s);
 // dst = dropout(src): keep mask of stream `seed` over the (M, N) index space, scaled by 1 / (1 - p)
 hipError_t launch_dropout_apply(const float* src, float* dst, int M, int N, float p, uint32_t seed, hipStream_t s);
-size_t attn_bwd_dq_partial_floats(int B, int H, int Lq, int Lk, int dh);
+size_t attn_bwd_dq_partial_floats(int B, int H, int Lq, int Lk, int dh, bool grouped = false);      // grouped: the batched kernel's slots
+int attn_bwd_kb_group(int B, int H, int Lk);
 size_t attn_bwd_batched256_scratch_floats(int n_it, int Lq, int Lk);
 hipError_t launch_absmax(const float* x, int64_t n, unsigned int* out, hipStream_t s);
 hipError_t launch_attn_bwd_rowdot(const float* dO, const float* O, int64_t batch, int64_t row, int B, int H, int Lq, int dh, float* D,

@@ -37,9 +37,6 @@ struct KvProjArgs {
     // TERMS == 11 (attention mode 4 with per-head tiers): bit h set = head h is written in the split layout (fp16 x 3 kernel), clear =
     // as mode-4 stages; every (scene, head) region then spans head_bytes (the split layout's size)
     unsigned safe_mask; int64_t head_bytes;
-    int stagger;               // W-stationary kernel: slot group (p / 8) % 4 starts stagger * 1024 cycles * its index late (see kvproj_dma_kernel)
-    int prio;                  // W-stationary kernel: waves 4 - 7 (the later-dispatched wave of each SIMD) run at s_setprio 1
-    int k_slots, v_slots;      // W-stationary kernel at two column slices: workgroups of the K slice / of the V slice (0: as many of each)
 };
 
 __global__ __launch_bounds__(kThreads) void kvproj_split_kernel(KvProjArgs a) {
@@ -284,22 +281,13 @@ __global__ __launch_bounds__(kThreads) void kvproj_split_kernel(KvProjArgs a) {
 // with vmcnt(0) and the counts that follow are merely conservative.  Rows past the scene are read clamped and zeroed at conversion.
 // PROBE (development, results wrong by construction; tools/kvproj_probe.sh): bit 0 no MFMAs, 1 no global stores, 2 no conversion
 // (MFMAs on whatever LDS holds), 3 no token DMA, 4 no epilogue at all
-// PP (round 6; three-term products at C = 256): the software-pipelined form of the loop below.  Stamped on the one-phase form
-// (profiles/r06_kvproj_stamps.txt: cycles per k-step of 3480, of which the slower wave of a SIMD spends 3100 in the body against 1536 of
-// matrix-pipe time for the SIMD's 48 MFMAs): a wave issues the fragment reads of a 16-wide k-slice, waits for them, issues that slice's
-// six MFMAs, and only then the next reads — with two waves per SIMD the matrix pipe idles about half of the time, and the k-step opens with
-// the conversion's LDS round trip in front of the first fragment read.  Here
-//   * the fragments of slice s + 1 are requested BEFORE the MFMAs of slice s are issued (two 16-register fragment buffers in turn),
-//   * the last slice of a k-step is multiplied BEHIND the next barrier, while the first reads of the new k-step are in flight (its
-//     fragments cross the barrier in registers), and a tile's epilogue follows at the head of the next tile's first k-step,
-//   * the conversion of k-step q + 1 comes after the MFMAs of k-step q have been issued,
-//   * every LDS address is a lane-dependent base register + an instruction offset (see below: what made the registers for this).
-// Same products in the same order per accumulator as the one-phase loop: bit-identical cache images.
-// development build: phase stamps of the one-phase loop (waves 0 and 4 of the first four workgroups, the first 96 k-steps), kept in LDS during
-// the launch and dumped at its end: point 0 = top of a k-step, 1 = this wave's DMA pieces and LDS writes have landed, 2 = behind the
-// barrier, 3 / 4 = around the epilogue, 5 - 7 inside it (tools/r06_kvproj_stamps.py)
-#ifdef PARQ_DEV_PROBES
-constexpr int kKvStampSteps = 96, kKvStampPts = 8, kKvStampBytes = 2 * kKvStampSteps * kKvStampPts * 8;      // LDS: [wave 0 | wave 4][k-step][point] cycle counters
+// Development build with -DPARQ_KV_STAMPS on top (PARQ_DEV_EXTRA_FLAGS=-DPARQ_KV_STAMPS python -c "import __graft_entry__ as g;
+// g.build_dev(force=True)"): cycle-counter stamps of waves 0 and 4 of the first four workgroups over the first 96 k-steps, kept in LDS during
+// the launch and dumped at its end (tools/r06_kvproj_stamps.py -> profiles/r06_kvproj_stamps.txt).  Point 0 = top of a k-step, 1 = this
+// wave's DMA pieces and LDS writes have landed, 2 = behind the barrier, 3 / 4 = around the epilogue, 5 - 7 inside it.  The stamp code
+// perturbs the loop it measures (the plain loop loses ~15 % with it, restructured variants less): use it for WHERE time goes, never for A/B.
+#if defined(PARQ_DEV_PROBES) && defined(PARQ_KV_STAMPS)
+constexpr int kKvStampSteps = 96, kKvStampPts = 8, kKvStampBytes = 2 * kKvStampSteps * kKvStampPts * 8;      // LDS: [wave 0 | wave 4][k-step][point]
 #define PARQ_KV_STAMP(pt)                                                                                                        \
     do {                                                                                                                         \
         if (kv_tl && (tid & 255) == 0 && step < kKvStampSteps)                                                                   \
@@ -309,7 +297,7 @@ constexpr int kKvStampSteps = 96, kKvStampPts = 8, kKvStampBytes = 2 * kKvStampS
 #define PARQ_KV_STAMP(pt) do { } while (0)
 #endif
 
-template <int TM, int TERMS, int KIND, int NK, int D, int PROBE = 0, bool PP = false>
+template <int TM, int TERMS, int KIND, int NK, int D, int PROBE = 0>
 __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int total_rt, int nrt, int P) {
     PARQ_TL_KERNEL(kTlKvProj);
     constexpr int NWV = 8;
@@ -333,8 +321,7 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
     float* raw = reinterpret_cast<float*>(ldsb);
     _Float16* hl = reinterpret_cast<_Float16*>(ldsb + D * kRawBytes);
     _Float16* stg = hl + 2 * 2 * TM * kBK;       // epilogue strips: 2 KB per wave
-#ifdef PARQ_DEV_PROBES
-    // phase stamps (development): kept in LDS during the launch (a stamp is one scalar clock read and one LDS write), dumped at the end
+#if defined(PARQ_DEV_PROBES) && defined(PARQ_KV_STAMPS)
     unsigned long long* kv_tl = (parq_tl_buf && blockIdx.x < 4) ? reinterpret_cast<unsigned long long*>(stg + 8 * 1024) : nullptr;
     if (kv_tl) { for (int i = threadIdx.x; i < kKvStampBytes / 8; i += blockDim.x) kv_tl[i] = 0ull; }
 #endif
@@ -350,24 +337,7 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
         p = grp * 8 + (r & 7);
         slice = r >> 3;
     }
-    if (a.k_slots > 0) {
-        // Mode-4 stage images: a K tile's epilogue is 402 vector instructions per wave (two e4m3 planes beside the fp16 plane), a V tile's
-        // 170 — stamped 4300 against ~2000 cycles of a 17 000-cycle tile.  With as many K workgroups as V workgroups the launch ends
-        // when the K slice does; k_slots : v_slots = 18 : 14 per XCD (144 + 112 of 256 CUs) evens the two slices out.
-        const int w = blockIdx.x, idx = w >> 3, kgrp = a.k_slots >> 3;
-        if (idx < kgrp) { slice = 0; p = idx * 8 + (w & 7); P = a.k_slots; }
-        else { slice = 1; p = (idx - kgrp) * 8 + (w & 7); P = a.v_slots; }
-    }
     if (p >= P) return;
-    // (development A/B, measured in round 6 and off by default: s_setprio 1 for waves 4 - 7 only swaps the roles of the two waves of a SIMD
-    // — the younger one then needs 2350 cycles for a k-step's body and the older one 3100 instead of the other way round; four slot
-    // groups started a quarter tile apart do not shorten the epilogue either: it is bound by its 402 vector instructions, not by a
-    // chip-wide store burst.  profiles/r06_kvproj_stamps.txt)
-    if (a.prio && wave >= NWV / 2) __builtin_amdgcn_s_setprio(1);
-    if (a.stagger > 0) {
-        const int late = ((p >> 3) & 3) * a.stagger;
-        for (int i = 0; i < late; ++i) __builtin_amdgcn_s_sleep(16);        // 16 x 64 cycles
-    }
     const int n0 = slice * kCols;
     const int headcol = (n0 + wave * 32) >> 6;    // scalar: the two waves ct = 0, 1 of a pair share a head
     const bool isK = headcol < a.H;
@@ -386,12 +356,12 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
     const int last_step = my_tiles * NK - 1;
 
     // k-step q of this workgroup -> (tile, ks); past the end: the last step again (requested, converted, never multiplied)
-    auto dma = [&](int q, int slot = -1) __attribute__((always_inline)) {      // slot: q % D where the caller knows it at compile time
+    auto dma = [&](int q) {
         const int qq = q < last_step ? q : last_step;
         const int tile = p + (qq / NK) * P, ks = qq % NK;
         const int b = tile / nrt, m0 = (tile - b * nrt) * TM;
         const float* Xb = a.X + ((int64_t)b * a.N) * C + ks * kBK;
-        lds_byte* dst = (lds_byte*)(ldsb) + (slot >= 0 ? slot : q % D) * kRawBytes;
+        lds_byte* dst = (lds_byte*)(ldsb) + (q % D) * kRawBytes;
         if constexpr (PROBE & 8) return;
 #pragma unroll
         for (int j = 0; j < NDMA; ++j) {
@@ -403,10 +373,10 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
     };
     bool ovf = false;
     // conversion of k-step q (tile origin m0): raw[q % D] -> hl[q & 1]
-    auto convert = [&](int q, int m0, int slot = -1) __attribute__((always_inline)) {
+    auto convert = [&](int q, int m0) {
         if constexpr (PROBE & 4) return;
-        float* src = raw + (slot >= 0 ? slot : q % D) * (TM * kBK);
-        _Float16* Ahi = hl + (slot >= 0 ? (slot & 1) : (q & 1)) * (2 * TM * kBK);       // (D even: the parity of q is the parity of its ring slot)
+        float* src = raw + (q % D) * (TM * kBK);
+        _Float16* Ahi = hl + (q & 1) * (2 * TM * kBK);
         _Float16* Alo = Ahi + TM * kBK;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -450,10 +420,9 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
         return (t - b * nrt) * TM;
     };
 
-    auto run = [&](auto isk_tag, auto f8_tag, auto lag_tag) __attribute__((always_inline)) {
+    auto run = [&](auto isk_tag, auto f8_tag) __attribute__((always_inline)) {
         constexpr bool ISK = decltype(isk_tag)::value;
         constexpr bool F8 = decltype(f8_tag)::value;             // this wave's head is written as mode-4 stages
-        constexpr bool LAG = decltype(lag_tag)::value;           // PP: this wave is the lagging one of its SIMD
         constexpr int NST_V = F8 ? RT * 2 : NST_K;
         // W fragments of this lane's column, resident for the whole launch: [k-step][s][hi, lo]
         half8 wfr[NK][4][2];
@@ -465,21 +434,15 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
                 wfr[ks][s2][0] = *reinterpret_cast<const half8*>(a.Whi + off);
                 if constexpr (SPLIT) wfr[ks][s2][1] = *reinterpret_cast<const half8*>(a.Wlo + off);
             }
-        // K bias of accumulator register r (V: one value per lane).  The two-phase form reads it where the epilogue uses it (an L2 hit per
-        // tile) instead of keeping 16 registers for the whole launch: it needs them for the fragments it carries across the barrier
-        float bK[(ISK && !PP) ? 16 : 1];
-        if constexpr (ISK && !PP) {
+        float bK[ISK ? 16 : 1];
+        if constexpr (ISK) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) bK[8 * m + e] = bias[16 * (2 * m + kh) + 4 * ct + (e & 3) + 8 * (e >> 2)];
-        } else if constexpr (!ISK) {
+        } else {
             bK[0] = bias[32 * ct + li];
         }
-        auto kbias = [&](int r) __attribute__((always_inline)) -> float {
-            if constexpr (ISK && !PP) return bK[r];
-            else return bias[16 * (2 * (r >> 3) + kh) + 4 * ct + (r & 3) + 8 * ((r & 7) >> 2)];
-        };
         // everything requested so far (W fragments, bias) has to be out of the counter before the counted waits start
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -489,18 +452,77 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
         convert(0, tile_m0(p));
         int step = 0;
         bool first = true;
-        f32x16 acc[RT];
-        // ---- epilogue of a tile (scene b, first token m0): bias, split, and the wave's piece of the cache image through a wave-private
-        // LDS strip, so that every store instruction writes whole 64-byte pieces (16-byte chunks at a 128-byte stride, as the accumulator
-        // layout would give them, reach 3.4 TB/s on this traffic shape against 5.6 TB/s for whole pieces:
-        // tools/bench_src/hbm_stream.hip).  Strip = [32 rows][4 chunks of 16 B] in image order: K rows are keys (the wave's 64-byte
-        // half of each 128-byte row), V rows are the wave's 32 dims (whole 64-byte rows); one store instruction = 16 rows.
-        auto epilogue = [&](int b, int m0) __attribute__((always_inline)) {
+        for (int tile = p; tile < total_rt; tile += P) {
+            const int b = tile / nrt, m0 = (tile - b * nrt) * TM;
+            const int m0_next = tile_m0(tile + P);
+            f32x16 acc[RT];
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                PARQ_KV_STAMP(0);
+                if constexpr ((PROBE & (2 | 8 | 16 | 32 | 64 | 128)) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // counts do not hold
+                else if (ks < D - 2 && !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 3) * NDMA + (ISK ? NST_K : NST_V)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 3) * NDMA) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's conversion writes of k-step q
+                PARQ_KV_STAMP(1);
+                __builtin_amdgcn_s_barrier();
+                PARQ_KV_STAMP(2);
+                dma(step + D - 1);
+                __builtin_amdgcn_sched_barrier(0);
+                convert(step + 1, ks + 1 < NK ? m0 : m0_next);
+                const _Float16* Ahi = hl + (ks & 1) * (2 * TM * kBK);      // NK even: buffer parity of step = parity of ks
+                const _Float16* Alo = Ahi + TM * kBK;
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    half8 xh[RT], xl[RT];
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) {
+                        const int row = t * 32 + li;
+                        const int posr = (4 * kh + s2) ^ ((row >> 1) & 7);
+                        xh[t] = *reinterpret_cast<const half8*>(Ahi + row * kBK + posr * 8);
+                        if constexpr (SPLIT) xl[t] = *reinterpret_cast<const half8*>(Alo + row * kBK + posr * 8);
+                    }
+                    const half8 wh = wfr[ks][s2][0], wlo = wfr[ks][s2][1];
+                    if constexpr (PROBE & 1) {
+#pragma unroll
+                        for (int t = 0; t < RT; ++t) acc[t][0] += (float)xh[t][0] * (float)wh[0] + (SPLIT ? (float)xl[t][1] * (float)wlo[1] : 0.f);
+                    } else if constexpr (ISK) {          // transposed product: rows = d, cols = tokens
+#pragma unroll
+                        for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wh, xh[t], acc[t]);
+                        if constexpr (SPLIT) {
+#pragma unroll
+                            for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wh, xl[t], acc[t]);
+#pragma unroll
+                            for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wlo, xh[t], acc[t]);
+                        }
+                    } else {            // rows = tokens, cols = d
+#pragma unroll
+                        for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(xh[t], wh, acc[t]);
+                        if constexpr (SPLIT) {
+#pragma unroll
+                            for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(xh[t], wlo, acc[t]);
+#pragma unroll
+                            for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(xl[t], wh, acc[t]);
+                        }
+                    }
+                }
+                ++step;
+            }
+            // ---- epilogue of this tile: bias, split, and the wave's piece of the cache image through a wave-private LDS strip, so
+            // that every store instruction writes whole 64-byte pieces (16-byte chunks at a 128-byte stride, as the accumulator
+            // layout would give them, reach 3.4 TB/s on this traffic shape against 5.6 TB/s for whole pieces:
+            // tools/bench_src/hbm_stream.hip).  Strip = [32 rows][4 chunks of 16 B] in image order: K rows are keys (the wave's 64-byte
+            // half of each 128-byte row), V rows are the wave's 32 dims (whole 64-byte rows); one store instruction = 16 rows.
             const bool whole = m0 + TM <= a.N;            // scalar
+            PARQ_KV_STAMP(3);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (PROBE & 16) {
                 if (acc[0][0] == 123.456f) a.cache[tid] = (_Float16)acc[RT - 1][3];
-                return;
+                first = false;
+                continue;
             }
             _Float16* strip = stg + wave * 1024;
             const int swz = ISK ? (li >> 1) & 3 : (li >> 2) & 3;     // low bits of the image's chunk swizzle for this lane's row
@@ -519,8 +541,10 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
                     if constexpr (ISK) {
                         float x16[16];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) x16[r] = acc[t][r] + kbias(r);
+                        for (int r = 0; r < 16; ++r) x16[r] = acc[t][r] + bK[r];
+#if defined(PARQ_DEV_PROBES) && defined(PARQ_KV_STAMPS)
                         if (t == 0) { asm volatile("" : "+v"(x16[0]), "+v"(x16[15])); PARQ_KV_STAMP(5); }
+#endif
                         i32x4 hi8, lo8;
                         pieces_e4m3(x16, hi8, lo8);
                         const int piece = ((t * 2 + kh) * 2 + ct) * 32 + li;        // piece (c = kh, h = ct) of key li
@@ -541,7 +565,7 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
                 for (int m = 0; m < 2; ++m) {
                     float x[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) x[e] = acc[t][8 * m + e] + (ISK ? kbias(8 * m + e) : bK[0]);
+                    for (int e = 0; e < 8; ++e) x[e] = acc[t][8 * m + e] + (ISK ? bK[ISK ? 8 * m + e : 0] : bK[0]);
                     if constexpr (F8 && !ISK) hi[m] = cvt8_rn<kF16>(x);          // mode 4: V as one fp16 value, round to nearest
                     else if constexpr (SPLIT) split8(x, hi[m], lo[m]);
                     else hi[m] = cvt8_rn<KIND>(x);
@@ -579,251 +603,20 @@ __global__ __launch_bounds__(512, 1) void kvproj_dma_kernel(KvProjArgs a, int to
             }
             if (!whole) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // fewer stores than counted: drain
             __builtin_amdgcn_sched_barrier(0);
-        };
-        if constexpr (PP) {
-            static_assert(SPLIT && NK == 4 && D == NK && RT == 2 && PROBE == 0 && NI == 1 && NDMA == 2, "the two-phase form: three-term products, C = 256, ring slot = k-step");
-            // Every LDS address of the loop is (a lane-dependent base register) + (a compile-time constant that fits the instruction's offset
-            // field): hipcc otherwise keeps one address register per unrolled (slot, parity, half, row block, hi / lo) combination alive across
-            // the whole launch — ~100 registers beside the 128 of the resident W fragments, i.e. spills.
-            typedef __attribute__((address_space(3))) half8 lds_half8;
-            constexpr int kPar = 2 * TM * kBK * 2, kLo = TM * kBK * 2;                  // bytes: hi/lo image of the other parity; lo plane
-            const unsigned hl_lds = (unsigned)(size_t)(lds_byte*)hl;
-            unsigned foff[4];                              // fragment reads: row li, chunk (4 kh + s2) ^ ((li >> 1) & 7)
-            {
-                const unsigned sw = (unsigned)(li >> 1) & 7u;
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) foff[s2] = hl_lds + (unsigned)li * (kBK * 2) + (((((unsigned)kh * 4u) ^ (sw & 4u)) | ((unsigned)s2 ^ (sw & 3u))) << 4);
-            }
-            const int crow = tid >> 3, cc = tid & 7;       // conversion: this thread's 8-float piece of a k-step
-            const unsigned codd = (unsigned)(crow & 1) * 16u;
-            const unsigned craw = (unsigned)(size_t)(lds_byte*)raw + (unsigned)(crow * kBK + cc * 8) * 4u;
-            const unsigned cwr = hl_lds + (unsigned)(crow * kBK + ((cc ^ ((crow >> 1) & 7)) << 3)) * 2u;
-            // the four fragments of 16-wide k-slice s2 of k-step ks (RT row blocks x hi / lo) and their six MFMAs, in the order of the
-            // one-phase loop below
-            auto frag4 = [&](auto ks_tag, auto s2_tag, half8 (&xh)[RT], half8 (&xl)[RT]) __attribute__((always_inline)) {
-                constexpr int ks = decltype(ks_tag)::value, s2 = decltype(s2_tag)::value;
-                const lds_byte* base = reinterpret_cast<const lds_byte*>((size_t)foff[s2]);
-#pragma unroll
-                for (int t = 0; t < RT; ++t) {
-                    xh[t] = *reinterpret_cast<const lds_half8*>(base + (ks & 1) * kPar + t * 32 * kBK * 2);
-                    xl[t] = *reinterpret_cast<const lds_half8*>(base + (ks & 1) * kPar + kLo + t * 32 * kBK * 2);
-                }
-            };
-            auto mma6 = [&](auto ks_tag, auto s2_tag, const half8 (&xh)[RT], const half8 (&xl)[RT]) __attribute__((always_inline)) {
-                constexpr int ks = decltype(ks_tag)::value, s2 = decltype(s2_tag)::value;
-                const half8 wh = wfr[ks][s2][0], wlo = wfr[ks][s2][1];
-                if constexpr (ISK) {
-#pragma unroll
-                    for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wh, xh[t], acc[t]);
-#pragma unroll
-                    for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wh, xl[t], acc[t]);
-#pragma unroll
-                    for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wlo, xh[t], acc[t]);
-                } else {
-#pragma unroll
-                    for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(xh[t], wh, acc[t]);
-#pragma unroll
-                    for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(xh[t], wlo, acc[t]);
-#pragma unroll
-                    for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(xl[t], wh, acc[t]);
-                }
-            };
-            // conversion of the k-step in ring slot SLOT (tile origin m0): raw[SLOT] -> hl[SLOT & 1], in two parts: the two LDS reads (issued
-            // one slice early, so that their latency passes under that slice's MFMAs) and the split + two LDS writes, which the scheduler is
-            // told to spread between the MFMAs of the k-step's last issued slice (a 32-cycle MFMA covers eight 4-cycle vector instructions)
-            typedef float f32x4v __attribute__((ext_vector_type(4)));
-            f32x4v cva, cvb;
-            auto convert_read = [&](auto slot_tag, f32x4v& cv0, f32x4v& cv1, unsigned addr_a, unsigned addr_b) __attribute__((always_inline)) {
-                constexpr int SLOT = decltype(slot_tag)::value;
-                asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4"
-                             : "=&v"(cv0), "=&v"(cv1) : "v"(addr_a), "v"(addr_b), "n"(SLOT * kRawBytes) : "memory");
-            };
-            auto convert_finish = [&](auto slot_tag, int m0, f32x4v& cv0, f32x4v& cv1) __attribute__((always_inline)) {
-                constexpr int SLOT = decltype(slot_tag)::value;
-                const bool ok = m0 + crow < a.N;
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cv0), "+v"(cv1)::"memory");
-                const f32x4v lo4 = codd ? cv1 : cv0, hi4 = codd ? cv0 : cv1;
-                float x[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = ok ? x[e] : 0.f;
-                if constexpr (KIND == kF16) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) ovf |= !(fabsf(x[e]) < 60000.f);
-                }
-                half8 hi, lo;
-                split8(x, hi, lo);
-                lds_byte* w = reinterpret_cast<lds_byte*>((size_t)cwr);
-                *reinterpret_cast<lds_half8*>(w + (SLOT & 1) * kPar) = hi;
-                *reinterpret_cast<lds_half8*>(w + (SLOT & 1) * kPar + kLo) = lo;
-            };
-            auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-                for (int i = 0; i < RT; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-            };
-            // no instruction: the accumulators pass through a volatile asm statement, which keeps the MFMAs in front of it on THIS side of
-            // the statements that follow (sched_barrier alone binds the scheduler, not the passes that sink pure instructions towards
-            // their first use — seen: a whole tile's MFMAs deferred by three barriers, with the fragments spilled in between)
-            auto pin = [&]() __attribute__((always_inline)) { asm volatile("" : "+v"(acc[0]), "+v"(acc[1])::"memory"); };
-            half8 fah[RT], fal[RT], fbh[RT], fbl[RT];      // two fragment buffers; fb carries slice 3 of the k-step before across the barrier
-            int b_prev = 0, m0_prev = 0;           // the tile whose accumulators await their epilogue
-            using S0 = std::integral_constant<int, 0>;
-            using S1 = std::integral_constant<int, 1>;
-            using S2 = std::integral_constant<int, 2>;
-            using S3 = std::integral_constant<int, 3>;
-            // one tile; FIRST (the workgroup's first tile, peeled: no runtime test inside a k-step, so that a k-step is ONE basic block and
-            // its MFMAs stay where they are written)
-            auto tile_body = [&](auto first_tag, int tile) __attribute__((always_inline)) {
-                constexpr bool FIRST = decltype(first_tag)::value;
-                const int b = tile / nrt, m0 = (tile - b * nrt) * TM;
-                const int m0_next = tile_m0(tile + P);
-                auto kstep = [&](auto ks_tag) __attribute__((always_inline)) {
-                    constexpr int ks = decltype(ks_tag)::value;
-                    using KS = std::integral_constant<int, ks>;
-                    using KP = std::integral_constant<int, (ks + NK - 1) % NK>;          // the k-step before (its last slice is pending)
-                    // this thread's DMA pieces of k-step q + 1 (requested two iterations ago).  May stay outstanding: the DMAs of the
-                    // iteration in between, and the stores of the epilogue at the head of this tile's first k-step when it lies in between
-                    PARQ_KV_STAMP(0);
-                    if constexpr ((ks == 1 || ks == 2) && !FIRST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 3) * NDMA + (ISK ? NST_K : NST_V)) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 3) * NDMA) : "memory");
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's conversion writes (and the pending fragments)
-                    PARQ_KV_STAMP(1);
-                    __builtin_amdgcn_s_barrier();
-                    PARQ_KV_STAMP(2);
-                    dma(step + D - 1, (ks + D - 1) % D);          // NK == D: the ring slot of a k-step is its position in the tile
-                    __builtin_amdgcn_sched_barrier(0);
-                    frag4(KS{}, S0{}, fah, fal);                  // in flight while the pending slice's MFMAs run
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (ks == 0) {
-                        if constexpr (!FIRST) { mma6(KP{}, S3{}, fbh, fbl); pin(); PARQ_KV_STAMP(3); epilogue(b_prev, m0_prev); PARQ_KV_STAMP(4); }
-                        zero_acc();
-                    } else {
-                        mma6(KP{}, S3{}, fbh, fbl);
-                        pin();
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    frag4(KS{}, S1{}, fbh, fbl);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mma6(KS{}, S0{}, fah, fal);
-                    pin();
-                    __builtin_amdgcn_sched_barrier(0);
-                    frag4(KS{}, S2{}, fah, fal);
-                    convert_read(std::integral_constant<int, (ks + 1) % D>{}, cva, cvb, craw + codd, craw + 16u - codd);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mma6(KS{}, S1{}, fbh, fbl);
-                    pin();
-                    __builtin_amdgcn_sched_barrier(0);
-                    frag4(KS{}, S3{}, fbh, fbl);
-                    __builtin_amdgcn_sched_barrier(0);
-                    PARQ_KV_STAMP(5);
-                    // the conversion's vector work between the MFMAs of the last slice issued in this k-step
-                    convert_finish(std::integral_constant<int, (ks + 1) % D>{}, ks + 1 < NK ? m0 : m0_next, cva, cvb);
-                    mma6(KS{}, S2{}, fah, fal);
-#pragma unroll
-                    for (int g = 0; g < 6; ++g) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA,
-                        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);      // eight vector instructions in its shadow
-                    }
-                    pin();
-                    __builtin_amdgcn_sched_barrier(0);
-                    ++step;
-                };
-                kstep(std::integral_constant<int, 0>{});
-                kstep(std::integral_constant<int, 1>{});
-                kstep(std::integral_constant<int, 2>{});
-                kstep(std::integral_constant<int, 3>{});
-                b_prev = b; m0_prev = m0;
-            };
-            tile_body(std::true_type{}, p);
-            for (int tile = p + P; tile < total_rt; tile += P) tile_body(std::false_type{}, tile);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            mma6(std::integral_constant<int, NK - 1>{}, S3{}, fbh, fbl);
-            pin();
-            epilogue(b_prev, m0_prev);
-            return;
-        }
-        for (int tile = p; tile < total_rt; tile += P) {
-            const int b = tile / nrt, m0 = (tile - b * nrt) * TM;
-            const int m0_next = tile_m0(tile + P);
-#pragma unroll
-            for (int i = 0; i < RT; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < NK; ++ks) {
-                PARQ_KV_STAMP(0);
-                if constexpr ((PROBE & (2 | 8 | 16 | 32 | 64 | 128)) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // counts do not hold
-                else if (ks < D - 2 && !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 3) * NDMA + (ISK ? NST_K : NST_V)) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 3) * NDMA) : "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's conversion writes of k-step q
-                PARQ_KV_STAMP(1);
-                __builtin_amdgcn_s_barrier();
-                PARQ_KV_STAMP(2);
-                dma(step + D - 1);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!(PROBE & 512)) convert(step + 1, ks + 1 < NK ? m0 : m0_next);
-                const _Float16* Ahi = hl + (ks & 1) * (2 * TM * kBK);      // NK even: buffer parity of step = parity of ks
-                const _Float16* Alo = Ahi + TM * kBK;
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) {
-                    half8 xh[RT], xl[RT];
-#pragma unroll
-                    for (int t = 0; t < RT; ++t) {
-                        const int row = t * 32 + li;
-                        const int posr = (4 * kh + s2) ^ ((row >> 1) & 7);
-                        xh[t] = *reinterpret_cast<const half8*>(Ahi + row * kBK + posr * 8);
-                        if constexpr (SPLIT) xl[t] = *reinterpret_cast<const half8*>(Alo + row * kBK + posr * 8);
-                    }
-                    const half8 wh = wfr[ks][s2][0], wlo = wfr[ks][s2][1];
-                    if constexpr (PROBE & 1) {
-#pragma unroll
-                        for (int t = 0; t < RT; ++t) acc[t][0] += (float)xh[t][0] * (float)wh[0] + (SPLIT ? (float)xl[t][1] * (float)wlo[1] : 0.f);
-                    } else if constexpr (ISK) {          // transposed product: rows = d, cols = tokens
-#pragma unroll
-                        for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wh, xh[t], acc[t]);
-                        if constexpr (SPLIT) {
-#pragma unroll
-                            for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wh, xl[t], acc[t]);
-#pragma unroll
-                            for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(wlo, xh[t], acc[t]);
-                        }
-                    } else {            // rows = tokens, cols = d
-#pragma unroll
-                        for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(xh[t], wh, acc[t]);
-                        if constexpr (SPLIT) {
-#pragma unroll
-                            for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(xh[t], wlo, acc[t]);
-#pragma unroll
-                            for (int t = 0; t < RT; ++t) acc[t] = mfma16<KIND>(xl[t], wh, acc[t]);
-                        }
-                    }
-                }
-                if constexpr ((PROBE & 512) != 0) {        // variant: the conversion of k-step q + 1 BEHIND the MFMAs of k-step q (the k-step opens with fragment reads)
-                    __builtin_amdgcn_sched_barrier(0);
-                    convert(step + 1, ks + 1 < NK ? m0 : m0_next);
-                }
-                ++step;
-            }
-            PARQ_KV_STAMP(3);
-            epilogue(b, m0);
             PARQ_KV_STAMP(4);
             first = false;
         }
     };
-    auto go = [&](auto lag_tag) __attribute__((always_inline)) {
-        if constexpr (MIX) {
-            const bool safe = (a.safe_mask >> h) & 1u;                  // scalar: a wave works on one head
-            if (isK) { if (safe) run(std::true_type{}, std::false_type{}, lag_tag); else run(std::true_type{}, std::true_type{}, lag_tag); }
-            else { if (safe) run(std::false_type{}, std::false_type{}, lag_tag); else run(std::false_type{}, std::true_type{}, lag_tag); }
-        } else {
-            if (isK) run(std::true_type{}, std::integral_constant<bool, TERMS == 8>{}, lag_tag);
-            else run(std::false_type{}, std::integral_constant<bool, TERMS == 8>{}, lag_tag);
-        }
-    };
-    go(std::false_type{});
+    if constexpr (MIX) {
+        const bool safe = (a.safe_mask >> h) & 1u;                  // scalar: a wave works on one head
+        if (isK) { if (safe) run(std::true_type{}, std::false_type{}); else run(std::true_type{}, std::true_type{}); }
+        else { if (safe) run(std::false_type{}, std::false_type{}); else run(std::false_type{}, std::true_type{}); }
+    } else {
+        if (isK) run(std::true_type{}, std::integral_constant<bool, TERMS == 8>{});
+        else run(std::false_type{}, std::integral_constant<bool, TERMS == 8>{});
+    }
     if (ovf) atomicOr(a.overflow, 1);
-#ifdef PARQ_DEV_PROBES
+#if defined(PARQ_DEV_PROBES) && defined(PARQ_KV_STAMPS)
     if (kv_tl) {
         __syncthreads();
         for (int i = threadIdx.x; i < 2 * kKvStampSteps * kKvStampPts; i += blockDim.x) {
@@ -870,29 +663,22 @@ __global__ void cvt16_kernel(const float* __restrict__ src, _Float16* __restrict
     }
 }
 
-template <int TM, int TERMS, int KIND, int NK, int D, int PROBE = 0, bool PP = false>
+template <int TM, int TERMS, int KIND, int NK, int D, int PROBE = 0>
 static hipError_t launch_dma_nk(const KvProjArgs& a, int B, hipStream_t s) {
     static DynLdsOnce once;
-#ifdef PARQ_DEV_PROBES
+#if defined(PARQ_DEV_PROBES) && defined(PARQ_KV_STAMPS)
     const size_t lds = (size_t)D * TM * kBK * 4 + (size_t)2 * 2 * TM * kBK * sizeof(_Float16) + 8 * 2048 + kKvStampBytes;
 #else
     const size_t lds = (size_t)D * TM * kBK * 4 + (size_t)2 * 2 * TM * kBK * sizeof(_Float16) + 8 * 2048;
 #endif
-    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&kvproj_dma_kernel<TM, TERMS, KIND, NK, D, PROBE, PP>), lds); e != hipSuccess) return e;
+    if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&kvproj_dma_kernel<TM, TERMS, KIND, NK, D, PROBE>), lds); e != hipSuccess) return e;
     const int nslice = 2 * a.C / 256, nrt = ceil_div(a.N, TM);
     const int total_rt = B * nrt;
     int P = device_num_cus() / nslice;
     if (P < 1) P = 1;
     if (P > total_rt) P = total_rt;
     dim3 grid(ceil_div(P, 8) * 8 * nslice, 1, 1);
-    KvProjArgs aa = a;
-    if (TERMS == 8 && nslice == 2 && P % 16 == 0 && total_rt >= 4 * P) {
-        // uneven slices (see the kernel): 18 : 14 per 32 workgroups (A/B over 16 .. 19 on the bench: 205 / 199 / 192 / 198 us in the development
-        // build, profiles/r06_ab_kvproj_kshare.txt); development: PARQ_KVPROJ_KSHARE = K workgroups per 32 (16 = even)
-        static const int kshare = [] { const char* e = dev_env("PARQ_KVPROJ_KSHARE"); return e ? atoi(e) : 18; }();
-        if (kshare > 16 && kshare < 32) { aa.k_slots = P / 16 * kshare; aa.v_slots = 2 * P - aa.k_slots; }
-    }
-    hipLaunchKernelGGL((kvproj_dma_kernel<TM, TERMS, KIND, NK, D, PROBE, PP>), grid, dim3(512), lds, s, aa, total_rt, nrt, P);
+    hipLaunchKernelGGL((kvproj_dma_kernel<TM, TERMS, KIND, NK, D, PROBE>), grid, dim3(512), lds, s, a, total_rt, nrt, P);
     return hipGetLastError();
 }
 
@@ -931,11 +717,6 @@ hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void*
     a.X = tokens; a.Whi = reinterpret_cast<const _Float16*>(Whi); a.Wlo = reinterpret_cast<const _Float16*>(Wlo);
     a.bias = bias; a.cache = reinterpret_cast<_Float16*>(cache); a.overflow = overflow; a.N = N; a.C = C; a.H = H;
     a.safe_mask = safe_mask; a.head_bytes = (int64_t)ceil_div(N, 32) * 16384;
-    static const int stagger = [] { const char* e = dev_env("PARQ_KVPROJ_STAGGER"); return e ? atoi(e) : 0; }();      // x 1024 cycles per group step (development A/B; measured: no effect, default off)
-    a.stagger = (B * (int64_t)N >= 65536) ? stagger : 0;               // (short launches: a start delay would not pay for itself)
-    static const int prio = [] { const char* e = dev_env("PARQ_KVPROJ_PRIO"); return e ? atoi(e) : 0; }();            // development A/B (measured: zero-sum, default off)
-    a.prio = prio;
-    a.k_slots = a.v_slots = 0;
     const int nct = 2 * C / kBN, nrt = ceil_div(N, kBM);
     if (C <= 4 * kBK && C % (2 * kBK) == 0) {
         // W-stationary persistent kernel: one workgroup per CU, the column slices of one slot on one XCD
@@ -955,15 +736,12 @@ hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void*
                 case 128: return launch_dma_nk<64, 8, kF16, 4, 4, 128>(a, B, s);
                 case 224: return launch_dma_nk<64, 8, kF16, 4, 4, 224>(a, B, s);
                 case 256: return launch_dma_nk<64, 8, kF16, 4, 4, 256>(a, B, s);
-                case 512: return launch_dma_nk<64, 8, kF16, 4, 4, 512>(a, B, s);          // (results right: a scheduling variant)
                 default: break;
             }
         }
 #endif
-        // the software-pipelined form (PP) wherever it exists: three-term products at C = 256; development: PARQ_KVPROJ_PP=0 selects the plain loop (A/B)
-        static const bool pp = [] { const char* e = dev_env("PARQ_KVPROJ_PP"); return !(e && e[0] == '0'); }();
-        if (terms == 8) return (N % 64 == 0 && C == 256) ? (pp ? launch_dma_nk<64, 8, kF16, 4, 4, 0, true>(a, B, s) : launch_dma_nk<64, 8, kF16, 4, 4>(a, B, s)) : hipErrorInvalidValue;
-        if (terms == 11) return (N % 64 == 0 && C == 256) ? (pp ? launch_dma_nk<64, 11, kF16, 4, 4, 0, true>(a, B, s) : launch_dma_nk<64, 11, kF16, 4, 4>(a, B, s)) : hipErrorInvalidValue;
+        if (terms == 8) return (N % 64 == 0 && C == 256) ? launch_dma_nk<64, 8, kF16, 4, 4>(a, B, s) : hipErrorInvalidValue;
+        if (terms == 11) return (N % 64 == 0 && C == 256) ? launch_dma_nk<64, 11, kF16, 4, 4>(a, B, s) : hipErrorInvalidValue;
         if (terms != 3) return kind == kF16 ? launch_dma<1, kF16, 4>(a, B, s) : launch_dma<1, kBF16, 4>(a, B, s);
 #ifdef PARQ_DEV_PROBES
         static const int probe = [] { const char* e = dev_env("PARQ_KVPROJ_PROBE"); return e ? atoi(e) : 0; }();      // development
@@ -982,7 +760,6 @@ hipError_t launch_kvproj_split(const float* tokens, const void* Whi, const void*
 #endif
         static const int depth = [] { const char* e = dev_env("PARQ_KVPROJ_RING"); return e ? atoi(e) : 4; }();       // 5: one more k-step in flight (no gain measured)
         if (depth == 5 && C == 256) return launch_dma<3, kF16, 5>(a, B, s);
-        if (pp && C == 256) return launch_dma_nk<64, 3, kF16, 4, 4, 0, true>(a, B, s);
         return launch_dma<3, kF16, 4>(a, B, s);
     }
     if (terms != 3) return hipErrorInvalidValue;            // the single-term modes exist on the persistent kernel only
