@@ -164,6 +164,15 @@ int parq_set_range_mirror(parq_handle h, int32_t *host_visible_flag);
  * time (and recorded by parq_forward_capture): a caller with several forwards in flight may give every workspace its own word by
  * calling parq_set_range_mirror before each forward. */
 int32_t parq_mirror_take(int32_t *host_visible_flag);
+/* Early completion signal of parq_forward / parq_forward_replay.  A caller that waits for a forward only to learn whether it has to be
+ * re-run (parq_amd.PARQDecoder's default policy) does not need the forward's end: no kernel behind the LAST iteration's cross-attention
+ * merge can raise a flag (range violations come from the K/V projection, hand-off timeouts from the launch in front of the
+ * cross-attention, too-peaked rows from the merge).  The first launch behind that merge therefore ORs what has been raised into the
+ * range mirror word and then stores `epoch` (the value given here before the forward was enqueued; the call's prologue launch carries it
+ * to the device) into `host_visible_word` with release semantics: a host that spins on the word sees the mirror bits once it sees the
+ * epoch, one chain tail (~36 us at BASELINE cfg 3) before the outputs are complete.  The outputs themselves are stream-ordered as always.
+ * The word's address is recorded by parq_forward_capture (part of what parq_forward_replay checks); the epoch is not.  NULL: off. */
+int parq_set_progress(parq_handle h, int32_t *host_visible_word, int32_t epoch);
 
 /* ---- PARQDecoder.forward ---------------------------------------------------------- */
 size_t parq_workspace_bytes(parq_handle h, int32_t B, int32_t V, int32_t hh, int32_t ww);

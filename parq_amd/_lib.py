@@ -69,6 +69,7 @@ SYMBOLS = {
     "parq_set_seam_fusion": (C.c_int, [_vp, _i32]),
     "parq_set_range_mirror": (C.c_int, [_vp, _vp]),
     "parq_mirror_take": (_i32, [_vp]),
+    "parq_set_progress": (C.c_int, [_vp, _vp, _i32]),
     "parq_shard_exchange_floats": (_sz, [_vp, _i32, _i32]),
     "parq_iterate_sharded": (C.c_int, [_vp, C.POINTER(ParqScene), _vp, _sz, _i32, _i32, _vp, C.POINTER(ParqOutputs), _vp, _vp, _vp, _i32, _vp]),
     "parq_profile_enable": (C.c_int, [_vp, _i32]),

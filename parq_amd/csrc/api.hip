@@ -138,6 +138,8 @@ struct parq_ctx {
     int w16_state() const { return attn_mode == 4 ? 1 : attn_mode; }      // what the 16-bit copy of W_kv has to hold
     int kind() const { return attn_mode == 3 ? kBF16 : kF16; }
     int* range_mirror = nullptr;      // host-visible word raised when outputs are poisoned (parq_set_range_mirror)
+    int* progress_word = nullptr;     // host-visible word that receives progress_epoch once a forward can raise no more flags (parq_set_progress)
+    int progress_epoch = 0;
     bool seam_fusion = true;          // parq_set_seam_fusion: in-launch hand-offs of the chain (0 = every dependent stage its own launch)
     bool bwd_batched_env = true;      // parq_set_backward_batched (the parity test compares the two settings)
     int bwd_streams = 8;              // parq_set_backward_streams: iterations of the chain backward in flight at once (1 = in turn)
@@ -371,7 +373,7 @@ int settle_weight_state(parq_ctx* c, hipStream_t s) {
 }
 
 int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& ws, hipStream_t s, bool train = false,
-               const parq_outputs* call_outs = nullptr) {
+               const parq_outputs* call_outs = nullptr, bool forward_call = false) {
     const float* A = c->arena;
     const int B = sc->B, V = sc->V;
     const int64_t N = (int64_t)V * sc->h * sc->w;
@@ -384,6 +386,10 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         // the recorded iterations (common.hpp CallPtrs)
         PrologueCall pc;
         memset(&pc, 0, sizeof(pc));
+        if (forward_call) {             // this call's epoch (the progress word's value once no flag can follow, LinearArgs::pub_epoch)
+            pc.ind = reinterpret_cast<const void**>(wsp + ws.ind);
+            pc.ptrs.p[7] = reinterpret_cast<const void*>((uintptr_t)(unsigned)c->progress_epoch);
+        }
         if (call_outs) {
             pc.cam_src = sc->camera; pc.cam_dst = wsp + ws.cam; pc.ncam = B * V * 6;
             pc.ind = reinterpret_cast<const void**>(wsp + ws.ind);
@@ -394,7 +400,7 @@ int do_prepare(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         HIPCHK(launch_forward_prologue(sc->T_camera_pseudoCam, sc->T_world_pseudoCam, sc->T_world_local, B, V,
                                        reinterpret_cast<double*>(wsp + ws.T_cl), A + c->ar.refpoint, c->Q, wsp + ws.ref, A + c->ar.dim_t,
                                        wsp + ws.emb, wsp + ws.flags, (int)(ws.lnp1 - ws.flags), s,      // the 64 flag words and the seam flags behind them
-                                       call_outs ? &pc : nullptr));
+                                       pc.ind ? &pc : nullptr));
     }
     // hoisted K/V in-projection of the memory tokens: one GEMM per distinct layer,
     // written head-major [b][{K heads, V heads}][N][dh] so the attention kernel streams contiguous panels
@@ -477,7 +483,8 @@ struct ShardIO { int mask = 7; const float* in = nullptr; float* out = nullptr; 
 
 int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& ws, int layer_num, const float* ref,
                bool emb_valid, const parq_outputs* o, float* ref_out, hipStream_t s, int64_t shift = 0,
-               float* emb_next = nullptr, bool train = false, const ShardIO& sh = ShardIO(), int64_t captured_row0 = -1) {
+               float* emb_next = nullptr, bool train = false, const ShardIO& sh = ShardIO(), int64_t captured_row0 = -1,
+               bool last_of_forward = false) {
     // captured_row0 >= 0 (parq_forward_capture): the iteration is being RECORDED — tokens, cameras and the six outputs are taken from the
     // workspace's CallPtrs block / camera copy that the prologue of every replay fills in (`sc->tokens`, `sc->camera`, `o` are unused);
     // captured_row0 = first output row of this iteration (k * B * Q)
@@ -718,6 +725,15 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         LinearArgs a = lin(wi + ws.attn, C, A + L.cross_out_w, C, A + L.cross_out_b, wi + ws.xb, C, M, C, C);
         a.R = wi + ws.xa; a.ldr = C; a.rln_stats = wi + ws.ln1; a.rln_gamma = A + L.n1_w; a.rln_beta = A + L.n1_b; a.Wp = TP ? TP + L.cross_out_w : nullptr;
         a.drop_p = dp; a.drop_seed = c->site_seed(layer_num, 3);
+        if (last_of_forward && c->progress_word != nullptr) {
+            // the last iteration's cross-attention has been merged: nothing behind this launch raises a flag (range: the K/V projection;
+            // hand-off timeouts: the seam launch in front of the cross-attention; too-peaked rows: the merge).  Tell the host now.
+            a.pub_flags = reinterpret_cast<const int*>(wsp + ws.flags);
+            a.pub_mirror = c->range_mirror; a.pub_word = c->progress_word;
+            a.pub_epoch = reinterpret_cast<const int*>(wsp + ws.ind) + 14;        // CallPtrs::p[7], low word
+            a.pub_mask = (c->cache_mode() && c->kind() == kF16) ? ~0 : 4;
+            a.pub_peaky = c->terms_for(N, false) == 8 ? 1 : 0;
+        }
         HIPCHK(launch_linear(a, 1, s));
         // K8: FFN (transformer_parq.py:383-385): relu(norm2(xb) @ W1), publishes norm2's statistics
         a = lin(wi + ws.xb, C, A + L.lin1_w, C, A + L.lin1_b, wi + ws.ffn, F, M, F, C);
@@ -760,7 +776,9 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         // fp16-operand modes: a range violation seen while the cache was built must not produce plausible wrong numbers
         d.poison = reinterpret_cast<const int*>(wsp + ws.flags);
         d.poison_mask = (c->cache_mode() && c->kind() == kF16) ? ~0 : 4;     // (a hand-off timeout reaches the mirror in every attention mode)
-        d.poison_mirror = c->range_mirror;
+        // (the last iteration of a forward with an early completion signal has published its bits already — LinearArgs::pub_mirror — and
+        // the host may have taken them by now: a second copy from here would be charged to the NEXT forward of the workspace)
+        d.poison_mirror = (last_of_forward && c->progress_word != nullptr) ? nullptr : c->range_mirror;
         d.peaky = (!sharded && c->terms_for(N, train, train && bwd_reads_cache(c, ws)) == 8) ? reinterpret_cast<const int*>(wsp + ws.flags) + 1 : nullptr;
         d.peaky_poison = c->peaky_poison;
         d.sb = c->sb; d.M = M; d.ncls = c->ncls;
@@ -1343,7 +1361,7 @@ static int forward_iterations(parq_ctx* h, const parq_scene* scene, float* wsp, 
             o.coord_pos = outs->coord_pos + k * M * 3;
         }
         const int rc = do_iterate(h, scene, wsp, ws, k, ra, true, &o, rb, s, 0, nullptr, false, ShardIO(),      // ping-pong the reference points; the sine
-                                  captured ? k * M : -1);                                                       // embedding of iteration 0 comes from the
+                                  captured ? k * M : -1, k + 1 == h->I);                                        // embedding of iteration 0 comes from the
         if (rc) return rc;                                                                                      // prologue, later ones from the previous decode
         float* t = ra; ra = rb; rb = t;
     }
@@ -1369,7 +1387,7 @@ int parq_forward(parq_handle h, const parq_scene* scene, void* workspace, size_t
     Workspace ws;
     int rc = forward_checks(h, scene, workspace, workspace_bytes, outs, &ws);
     if (rc) return rc;
-    rc = do_prepare(h, scene, (float*)workspace, ws, (hipStream_t)stream);
+    rc = do_prepare(h, scene, (float*)workspace, ws, (hipStream_t)stream, false, nullptr, true);
     if (rc) return rc;
     return forward_iterations(h, scene, (float*)workspace, ws, outs, (hipStream_t)stream, false);
 }
@@ -1379,14 +1397,14 @@ int parq_forward(parq_handle h, const parq_scene* scene, void* workspace, size_t
 struct GraphKey {
     int B, V, h, w, mode, seam, poison;
     uint32_t safe;
-    const void* ws; const void* arena; const void* mirror;
+    const void* ws; const void* arena; const void* mirror; const void* progress;
     bool operator==(const GraphKey& o) const {
         return B == o.B && V == o.V && h == o.h && w == o.w && mode == o.mode && seam == o.seam && poison == o.poison && safe == o.safe &&
-               ws == o.ws && arena == o.arena && mirror == o.mirror;
+               ws == o.ws && arena == o.arena && mirror == o.mirror && progress == o.progress;
     }
 };
 static GraphKey graph_key(const parq_ctx* c, int B, int V, int hh, int ww, const void* wsp) {
-    return GraphKey{B, V, hh, ww, c->attn_mode, c->seam_fusion ? 1 : 0, c->peaky_poison, c->safe_heads(), wsp, c->arena, c->range_mirror};
+    return GraphKey{B, V, hh, ww, c->attn_mode, c->seam_fusion ? 1 : 0, c->peaky_poison, c->safe_heads(), wsp, c->arena, c->range_mirror, c->progress_word};
 }
 struct parq_graph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; size_t nodes = 0; GraphKey key; };
 
@@ -1447,7 +1465,7 @@ int parq_forward_replay(parq_handle h, parq_graph_t g, const parq_scene* scene, 
                                     "other attention settings (mode, head tiers, seam fusion): capture again");
     hipStream_t s = (hipStream_t)stream;
     // launched directly with THIS call's pointers: prologue (which also leaves them in the workspace for the recorded part) + K/V projection
-    rc = do_prepare(h, scene, (float*)workspace, ws, s, false, outs);
+    rc = do_prepare(h, scene, (float*)workspace, ws, s, false, outs, true);
     if (rc) return rc;
     HIPCHK(hipGraphLaunch(g->exec, s));
     h->ref_state = 0;
@@ -1462,6 +1480,13 @@ int parq_graph_destroy(parq_graph_t g) {
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (g->graph) (void)hipGraphDestroy(g->graph);
     delete g;
+    return PARQ_OK;
+}
+
+int parq_set_progress(parq_handle h, int32_t* host_visible_word, int32_t epoch) {
+    if (!h) return fail(PARQ_ERR_ARG, "NULL handle");
+    h->progress_word = host_visible_word;
+    h->progress_epoch = epoch;
     return PARQ_OK;
 }
 

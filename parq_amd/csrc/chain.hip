@@ -29,6 +29,7 @@ enum : int { kResNone = 0, kResPlain = 1, kResLN = 2 };
 
 template <int K, int NT, int PRO, int ADD2, bool BIAS, bool RELU, int RES, bool GNOUT, int NWV = 4, bool LNP = false>
 __device__ __forceinline__ void chain_tile(const LinearArgs& a, const int block_x, const int block_y) {
+    if (block_x == 0 && block_y == 0) publish_progress(a);
     static_assert(K % (16 * NWV) == 0 && NT >= 1 && NT <= 4 && (NWV == 4 || NWV == 8), "tile shape");
     constexpr int NCH = K / (16 * NWV);               // 16-wide K chunks per wave
     constexpr int CS = 16 * NWV;                      // the workgroup's K step per chunk (wave w takes columns w*16 .. w*16+15 of it)
@@ -537,6 +538,7 @@ __global__ __launch_bounds__(256) void seam_q_kernel(LinearArgs aA, SeamArgs sb,
 template <int K, int NT, int PRO, int ADD2, bool BIAS, bool RELU, int RES, bool GNOUT>
 __global__ __launch_bounds__(256) void chain_linear_stream_kernel(LinearArgs a) {
     PARQ_TL_KERNEL(kTlLinear);
+    publish_progress(a);
     static_assert(K % 256 == 0 && NT >= 1 && NT <= 4 && ADD2 != 2, "tile shape");
     constexpr int NCH = K / 64;                       // 16-wide K chunks per wave
     constexpr int BCH = 4;                            // chunks per streamed batch (256 contraction steps per workgroup)

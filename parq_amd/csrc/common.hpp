@@ -323,7 +323,21 @@ struct LinearArgs {
     // lnp_flags[row block][tile] = lnp_epoch follows once they are acknowledged; consumers are workgroups of the SAME launch with
     // larger block indices (seam_tile)
     unsigned* lnp_flags; unsigned lnp_epoch;
+    // Early completion signal of a forward (api.hip: set on the first launch behind the LAST iteration's cross-attention merge — no
+    // kernel of the forward can raise a flag after it): thread 0 of workgroup (0, 0) copies what the forward has raised into the caller's
+    // host-visible mirror word (the bits of BoxDecodeArgs::poison_mirror) and then stores this call's epoch (left in the workspace by the
+    // call's prologue launch) into the host-visible progress word, so that a host that only needs to know WHETHER the forward has to
+    // be re-run can stop waiting one chain tail (~36 us at BASELINE cfg 3) before the forward ends.  nullptr: nothing to publish.
+    const int* pub_flags; int* pub_mirror; int* pub_word; const int* pub_epoch; int pub_mask; int pub_peaky;
 };
+__device__ __forceinline__ void publish_progress(const LinearArgs& a) {
+    if (a.pub_word != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        const int f0 = a.pub_flags[0] & a.pub_mask, pk = a.pub_peaky ? a.pub_flags[1] : 0;
+        const int bits = ((f0 & ~4) ? 1 : 0) | (f0 & 4) | (pk != 0 ? (2 | (pk << 8)) : 0);
+        if (bits != 0 && a.pub_mirror != nullptr) __hip_atomic_fetch_or(a.pub_mirror, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a.pub_word, *a.pub_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // behind the mirror bits
+    }
+}
 // A consumer tile of a LayerNorm seam inside ONE launch (chain.hip seam_tile).  The LayerNorm is pushed through the linear map behind it,
 //   LN(x) W^T + b = rstd (x Wg^T - mean s) + b',   Wg = W diag(gamma), s = row sums of Wg, b' = b + W beta,
 // and x Wg^T is computed from the operands x itself is made of (x = r + y Wo^T + bo  ->  x Wg^T = r Wg^T + y (Wg Wo)^T + Wg bo), so

@@ -37,6 +37,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <int T, int CB>                            // CB: 16-wide K chunks held in registers per batch
 __global__ __launch_bounds__(kWaves * kWave) void linear_f32_kernel(LinearArgs a) {
     PARQ_TL_KERNEL(kTlLinear);
+    publish_progress(a);
     constexpr int S = T / 16;                       // 16x16 sub-tiles per tile edge
     constexpr int OPT = T * T / (kWaves * kWave);   // outputs per thread in the epilogue (1 or 4)
     constexpr int TPR = T / OPT;                    // threads per output row

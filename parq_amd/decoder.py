@@ -212,10 +212,11 @@ class _WsEntry:
     """One inference workspace of a module: the K/V cache + activations tensor of a (shape, device, stream), the pinned mirror word the
     device raises for forwards that run in it, and the captured iterations of its forward (a HIP graph, include/parq_hip.h
     parq_forward_capture) with the settings they were recorded under."""
-    __slots__ = ("ws", "slot", "stream", "graphs", "last_key", "replays")
+    __slots__ = ("ws", "slot", "stream", "graphs", "last_key", "replays", "epoch")
 
     def __init__(self, ws, slot, stream):
         self.ws, self.slot, self.stream = ws, slot, stream
+        self.epoch = 0                # epoch of the last forward enqueued here (the device stores it into the slot's progress word)
         self.graphs = {}              # key -> parq_graph_t (one per (weights, attention settings): the current one; stale ones are retired)
         self.last_key = None          # key of the previous forward in this workspace (a graph is captured when a key repeats)
         self.replays = 0
@@ -350,6 +351,7 @@ class PARQDecoder(_Tracked, nn.Module):
         self._arena_pack_stream = None
         self._arena_streams = {}          # stream id -> stream object of every stream that is ordered behind the current arena
         self._defer = None                # InFlight.submit(): list that receives the settle callable of a forward instead of a host wait
+        self._epoch = 0                   # counter of inference forwards (parq_set_progress)
         self._profiling = False
         # Captured forward (include/parq_hip.h parq_forward_capture): the iterations of the second inference forward of a (shape,
         # stream, weights, attention settings) are recorded into a HIP graph and later forwards replay it behind their directly
@@ -468,8 +470,13 @@ class PARQDecoder(_Tracked, nn.Module):
 
     # mirror words: one pinned int32 per inference workspace (slots 1 ..), slot 0 for the training / stepping / view-sharded entry
     # points.  The device ORs into the word of the workspace a forward runs in (the pointer is read at enqueue time, include/parq_hip.h);
-    # the host takes a word with one atomic exchange, so bits raised by another forward in flight are never lost.
+    # the host takes a word with one atomic exchange, so bits raised by another forward in flight are never lost.  Behind the flag
+    # words sit the slots' PROGRESS words (parq_set_progress): the device stores a forward's epoch there as soon as the forward can
+    # raise no more flags — what policy "sync" waits for, one chain tail before the forward's end.
     _MIRROR_SLOTS = 16
+
+    def _progress_ptr(self, slot):
+        return self._range_mirror.data_ptr() + 4 * (self._MIRROR_SLOTS + int(slot))
 
     def _mirror_ptr(self, slot):
         return self._range_mirror.data_ptr() + 4 * int(slot)
@@ -494,10 +501,10 @@ class PARQDecoder(_Tracked, nn.Module):
         fp16 range (outputs of that forward are NaN), bit 1 = attention mode 'split8' met a row carried by too few keys on the heads of
         bits 8.. (outputs of that forward are NaN from that iteration on unless ``range_check == "off"``), bit 2 = an in-launch hand-off
         timed out."""
-        if self._mirror_np is None or not self._mirror_np.any():
+        if self._mirror_np is None or not self._mirror_np[:self._MIRROR_SLOTS].any():
             return
         v = 0
-        for sl in np.nonzero(self._mirror_np)[0].tolist():
+        for sl in np.nonzero(self._mirror_np[:self._MIRROR_SLOTS])[0].tolist():
             v |= self._mirror_take(sl)
         if v == 0 or self.range_check == "off":
             return
@@ -524,7 +531,7 @@ class PARQDecoder(_Tracked, nn.Module):
             flags = self._flag_view(entry.ws, sc.B, sc.V, sc.h, sc.w, 48).tolist()
             v = self._mirror_take(entry.slot)
         else:
-            torch.cuda.current_stream(dev).synchronize()      # this stream only; the pinned word is final once its last kernel has retired
+            self._wait_progress(entry, dev)                   # until this forward can raise no more flags (not: until it has finished)
             v = self._mirror_take(entry.slot)
             flags = None
         if first:
@@ -562,6 +569,22 @@ class PARQDecoder(_Tracked, nn.Module):
                     self._calm_streak.pop(h)
         return False
 
+    def _wait_progress(self, entry, dev):
+        """Spin on the slot's progress word until the device has stored this forward's epoch there (parq_set_progress: the first launch
+        behind the last iteration's cross-attention merge does — nothing after it can raise a flag, so the decision "re-run or not" is
+        final ~36 us before the outputs are; those stay stream-ordered as always).  A forward that never gets there (or a library
+        without the signal) ends the wait through the stream itself."""
+        word, want = self._mirror_np, entry.epoch
+        idx = self._MIRROR_SLOTS + entry.slot
+        if want:
+            query = entry.stream.query
+            for spin in range(1 << 30):
+                if word[idx] == want:
+                    return
+                if (spin & 1023) == 1023 and query():       # the stream has drained: the word is as final as it gets
+                    break
+        torch.cuda.current_stream(dev).synchronize()
+
     # ------------------------------------------------------------------ native handle
     def _handle(self, apply_mode=True):
         if self._h is None:
@@ -579,7 +602,7 @@ class PARQDecoder(_Tracked, nn.Module):
             self._bwd_streams_set = None
             self._train_ws = None
             # pinned host memory is mapped into the device address space under the same pointer (hipHostMalloc)
-            self._range_mirror = torch.zeros(self._MIRROR_SLOTS, dtype=torch.int32).pin_memory()
+            self._range_mirror = torch.zeros(2 * self._MIRROR_SLOTS, dtype=torch.int32).pin_memory()
             self._mirror_np = self._range_mirror.numpy()
             _lib.check(lib.parq_set_range_mirror(h, C.c_void_p(self._range_mirror.data_ptr())), "parq_set_range_mirror")
             self._mirror_set = 0
@@ -871,8 +894,12 @@ class PARQDecoder(_Tracked, nn.Module):
         lead = (self.num_layers, sc.B, self.num_queries)
         flat = torch.empty(self.num_layers * sc.B * self.num_queries * self._out_width, dtype=torch.float32, device=dev)
         entry = self._enqueue_forward(sc, keep, flat, dev)
+        self.__dict__["_last_flat"] = flat                     # (InFlight: the one allocation behind the outputs)
         # (everything below runs while the device works on the forward)
-        per = [t.unbind(0) for t in self._alloc_outputs_flat(lead, dev, flat=flat)[0]]
+        rows = self.num_layers * sc.B * self.num_queries
+        ncls = self.num_semcls + 1
+        widths = (ncls, 3, 3, 6, ncls, 3)
+        per = [seg.view(*lead, wd).unbind(0) for seg, wd in zip(flat.split([rows * wd for wd in widths]), widths)]
         result = [dict(zip(OUTPUT_KEYS, [p[i] for p in per])) for i in range(self.num_layers)]
 
         def settle():
@@ -909,6 +936,9 @@ class PARQDecoder(_Tracked, nn.Module):
         entry = self._workspace_entry(sc.B, sc.V, sc.h, sc.w, dev, handle=h)
         ws = entry.ws
         self._set_mirror(entry.slot)
+        self._epoch = (self._epoch % 0x7ffffff0) + 1
+        entry.epoch = self._epoch
+        _lib.check(lib.parq_set_progress(h, C.c_void_p(self._progress_ptr(entry.slot)), self._epoch), "parq_set_progress")
         stream = C.c_void_p(entry.stream.cuda_stream)
         po = self._out_pointers(flat.data_ptr(), self.num_layers * sc.B * self.num_queries)
         graph = None

@@ -20,6 +20,19 @@ import torch
 __all__ = ["InFlight", "Ticket"]
 
 
+def _storages(obj):
+    """One CUDA tensor per distinct storage reachable from `obj` (the 48 output tensors of a decoder forward are views of ONE
+    allocation: telling the caching allocator once is enough, and 47 calls cheaper)."""
+    seen, out = set(), []
+    for t in _tensors(obj):
+        if t.is_cuda:
+            key = t.untyped_storage().data_ptr()
+            if key not in seen:
+                seen.add(key)
+                out.append(t)
+    return out
+
+
 def _tensors(obj):
     """Tensors reachable from the arguments / results of a call: tensors, the package's wrappers (``_data``), containers."""
     if isinstance(obj, torch.Tensor):
@@ -42,8 +55,9 @@ class Ticket:
     stream before handing the outputs out.  Under ``range_check = "lazy"`` / ``"off"`` nothing waits on the host; ``valid()`` tells
     whether the outputs are numbers."""
 
-    def __init__(self, outputs, event, stream, settle=()):
+    def __init__(self, outputs, event, stream, settle=(), storages=None):
         self._out, self._ev, self._stream, self._settle = outputs, event, stream, list(settle)
+        self._storages = storages                # one tensor per allocation behind `outputs`, if the submitter knows them
 
     def done(self):
         return self._ev.query()
@@ -58,9 +72,8 @@ class Ticket:
                 self._ev.record(self._stream)
         cur = torch.cuda.current_stream(self._stream.device)
         cur.wait_event(self._ev)
-        for t in _tensors(self._out):           # allocated on the side stream, consumed on the caller's: tell the caching allocator
-            if t.is_cuda:
-                t.record_stream(cur)
+        for t in (self._storages if self._storages is not None else _storages(self._out)):
+            t.record_stream(cur)                # allocated on the side stream, consumed on the caller's: tell the caching allocator
         return self._out
 
     def valid(self):
@@ -90,7 +103,8 @@ class InFlight:
         self.module, self.device = module, torch.device(device)
         self._streams = [torch.cuda.Stream(self.device) for _ in range(depth)]
         self._next = 0
-        for dec in _decoders(module):            # one workspace per stream stays cached (PARQDecoder)
+        self._decs = _decoders(module)
+        for dec in self._decs:                   # one workspace per stream stays cached (PARQDecoder)
             dec.max_workspaces = max(int(dec.max_workspaces), depth)
 
     @property
@@ -104,13 +118,13 @@ class InFlight:
         self._next = (self._next + 1) % len(self._streams)
         cur = torch.cuda.current_stream(self.device)
         side.wait_stream(cur)
-        for t in _tensors((args, kwargs)):       # the arguments were allocated on the caller's stream and are read on `side`
-            if t.is_cuda:
-                t.record_stream(side)
-        decs = _decoders(self.module)
+        for t in _storages((args, kwargs)):      # the arguments were allocated on the caller's stream and are read on `side`
+            t.record_stream(side)
+        decs = self._decs
         settle = []
         for d in decs:
-            d._defer = settle                    # the decoder hands its post-forward check over instead of waiting inside the call
+            d.__dict__["_defer"] = settle        # the decoder hands its post-forward check over instead of waiting inside the call
+            d.__dict__["_last_flat"] = None      # (plain dict writes: nn.Module.__setattr__ costs 2.5 us a piece)
         try:
             with torch.cuda.stream(side):
                 out = self.module(*args, **kwargs)
@@ -118,8 +132,11 @@ class InFlight:
                 ev.record(side)
         finally:
             for d in decs:
-                d._defer = None
-        return Ticket(out, ev, side, settle)
+                d.__dict__["_defer"] = None
+        # the decoder's 48 output tensors are views of one allocation: hand the ticket that allocation instead of letting it walk them
+        flats = [d.__dict__.get("_last_flat") for d in decs]
+        own = [f for f in flats if f is not None] if (decs and (self.module is decs[0] or getattr(self.module, "box3d_decoder", None) is decs[0])) else None
+        return Ticket(out, ev, side, settle, own or None)
 
     def drain(self):
         for s in self._streams:

@@ -70,6 +70,17 @@ def test_bench_eight_ranks_launcher_smoke():
     assert "dp8" in d["config"]["parallelism"]
 
 
+def test_bench_eight_ranks_four_scenes_per_gpu_variant():
+    """SURVEY.md section 8(d) names two lines for the scaling runs: B = #GPUs and a B = 4 per GPU variant (BASELINE cfg 4's shard size).
+    The same launcher at eight ranks with --scenes-per-gpu 4, so that the driver's first 8-GPU run can take both lines."""
+    d = _run(["--steps", "1", "--warmup", "1", "--scenes-per-gpu", "4"], gpus=8)
+    assert d["n_gpus"] == 8 and d["config"]["scenes_per_gpu"] == 4 and "dp8" in d["config"]["parallelism"]
+    assert len(d["per_rank_ms_per_step"]) == 8 and all(t > 0 for t in d["per_rank_ms_per_step"])
+    iters = 8 * 4 * 8 * d["steps"]
+    assert abs(d["value"] - iters / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+    assert d["guard_policy_cost"] is None if "guard_policy_cost" in d else True     # (single-rank extras stay out of multi-rank lines)
+
+
 def test_bench_single_rank_default_line_contract():
     """The driver's N = 1 command (fewer steps, without the CPU baseline and the optional records): ONE JSON line with the contract's
     fields, the roofline object of the dominant kernel, and the sub-records measured beside `value` — the strict fp16 x 3 run and two
@@ -91,3 +102,8 @@ def test_bench_single_rank_default_line_contract():
     assert two["streams"] == 2 and two["outputs_bit_identical_to_one_at_a_time"] is True
     assert two["value"] > 0.95 * d["value"]                      # never slower than one at a time (measured + 15-18 %)
     assert d["strict_fp16x3"]["attention_mode"] == "split" and d["strict_fp16x3"]["value"] < d["value"]
+    # the never-NaN default and what it costs, the captured forward's host time (item 4)
+    g = d["guard_policy_cost"]
+    assert g["default_policy"] == "sync" and d["attention_guard"]["policy"] == "sync"
+    assert g["lazy"]["value"] >= 0.97 * g["sync"]["value"] and 0.0 <= g["cost_of_the_default"] < 0.15
+    assert d["host_enqueue_ms"] == g["host_enqueue_ms"] and d["host_enqueue_ms"] < g["host_enqueue_ms_without_captured_forward"]

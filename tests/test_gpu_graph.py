@@ -182,3 +182,26 @@ def test_capture_entry_points_of_the_c_abi_directly():
     assert lib.parq_forward_capture(h, sc.B, sc.V, sc.h, sc.w, _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr(), C.byref(g2)) != 0
     assert b"profile" in lib.parq_last_error()
     dec.profile_enable(False)
+
+
+def test_early_completion_signal_carries_the_epoch_and_the_flags():
+    """parq_set_progress (include/parq_hip.h): the first launch behind the last iteration's cross-attention merge stores the call's epoch
+    into the host-visible progress word — captured forward and launch-by-launch forward alike, a new epoch per call — and ORs what the
+    forward raised into the mirror word BEFORE it; the default policy waits for that word instead of the stream."""
+    cfg, W, dec, args, hw = _setup(seed=951, mode="split")
+    assert dec.range_check == "sync"
+    seen = []
+    for rep in range(4):                                    # launch by launch, captured, replayed, replayed
+        _run(dec, args, hw)
+        entry = next(reversed(dec._ws.values()))
+        seen.append((entry.epoch, int(dec._mirror_np[dec._MIRROR_SLOTS + entry.slot])))
+    assert [e for e, _ in seen] == sorted({e for e, _ in seen}) and all(e == w and e > 0 for e, w in seen), seen
+    assert _replays(dec) == 3
+    # a flagged forward: the bits are in the mirror word when the epoch is (the re-run decision is taken from them)
+    tokens = args[0].clone()
+    tokens.mul_(3e4)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        got = _run(dec, (tokens,) + tuple(args[1:]), hw)
+    assert dec.attention_mode == "fp32" and any("fp16 range" in str(r.message) for r in rec)
+    assert all(torch.isfinite(o[k]).all() for o in got for k in KEYS)
