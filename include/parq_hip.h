@@ -146,7 +146,8 @@ int parq_set_attention_mode(parq_handle h, int32_t mode);
  * 0: outputs stay numbers (reduced accuracy on those rows), flags and mirror are raised all the same.
  * The reference has one arithmetic (fp32, model/transformer_parq.py:377-380); this call only chooses how its result is approximated. */
 int parq_set_head_tiers(parq_handle h, uint32_t safe_mask, int32_t poison_on_peaked);
-/* In-launch hand-offs of the small-op chain (default on).  At d = 256 the self-attention out-projection and the cross-attention
+/* In-launch hand-offs of the small-op chain (default OFF since round 6: under graph replay the fused launch no longer pays for the
+ * spin-wait it contains, profiles/r06_ab_seam_q_under_graph_replay.txt).  With `on` != 0, at d = 256 the self-attention out-projection and the cross-attention
  * query projection behind norm1 (model/transformer_parq.py:375-377) run as ONE launch whose query tiles wait, in their epilogue, for the
  * LayerNorm row sums the other tiles publish (chain.hip seam_tile).  The wait is bounded: if a producer workgroup has not published
  * within ~0.1 s — which needs a dispatch order no HIP implementation has shown, the waiting tiles are placed behind the tiles they wait

@@ -140,7 +140,7 @@ struct parq_ctx {
     int* range_mirror = nullptr;      // host-visible word raised when outputs are poisoned (parq_set_range_mirror)
     int* progress_word = nullptr;     // host-visible word that receives progress_epoch once a forward can raise no more flags (parq_set_progress)
     int progress_epoch = 0;
-    bool seam_fusion = true;          // parq_set_seam_fusion: in-launch hand-offs of the chain (0 = every dependent stage its own launch)
+    bool seam_fusion = false;         // parq_set_seam_fusion: in-launch hand-offs of the chain (off by default since round 6: every dependent stage its own launch)
     bool bwd_batched_env = true;      // parq_set_backward_batched (the parity test compares the two settings)
     int bwd_streams = 8;              // parq_set_backward_streams: iterations of the chain backward in flight at once (1 = in turn)
     float dim_t_host[128];            // 10000^(2*(i//2)/128): uploaded by parq_pack_weights from this persistent buffer (no stream sync)

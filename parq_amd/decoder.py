@@ -415,10 +415,14 @@ class PARQDecoder(_Tracked, nn.Module):
         # themselves: ``reset_attention_tiers()``); a module whose heads are all safe runs exactly mode "split".
         self.safe_heads = 0
         self._tiers_set = None            # (safe mask, poison) the native handle currently holds
-        # In-launch hand-offs of the small-op chain (include/parq_hip.h parq_set_seam_fusion).  Their wait is bounded; after a timeout
-        # (never observed: it needs the waiting tiles dispatched before the tiles they wait for) the outputs of that forward are NaN,
-        # and the module switches to one launch per dependent stage for good, like the range fallback.
-        self.fuse_seams = True
+        # In-launch hand-offs of the small-op chain (include/parq_hip.h parq_set_seam_fusion): the self out-projection and the query
+        # projection behind norm1 as ONE launch whose query tiles wait (bounded) for row sums the other tiles publish.  OFF by default
+        # since round 6: it bought +1.1 % when every launch was enqueued from the host; with the iterations replayed from a captured
+        # graph two 4 x 300-step A/Bs on two boxes put it at -0.3 % and +0.6 % (profiles/r06_ab_seam_q_under_graph_replay.txt) — below what
+        # a spin-wait between workgroups of one launch has to earn (HIP does not promise their dispatch order).  True switches it on;
+        # after a timeout (never observed) the outputs of that forward are NaN (re-run under the default policy) and the module goes
+        # back to one launch per dependent stage for good.
+        self.fuse_seams = False
         self._seams_set = None
         # range_check = "sync" only (there a wrong guess costs a re-run, never a NaN forward): a head on the fp16 x 3 tier returns to the
         # fast tier after this many CONSECUTIVE forwards in which all of its rows kept a probability sum of at least tier_return_margin x

@@ -171,10 +171,11 @@ def test_capture_entry_points_of_the_c_abi_directly():
             for k in range(dec.num_layers):
                 assert torch.equal(outs[i][k], want[k][key]), (rep, key, k)
     # settings changed since the capture: refused with a status code, nothing enqueued
-    _lib.check(lib.parq_set_seam_fusion(h, 0), "seam")
+    flipped = 0 if dec.fuse_seams else 1
+    _lib.check(lib.parq_set_seam_fusion(h, flipped), "seam")
     assert lib.parq_forward_replay(h, g, C.byref(sc), _lib.ptr(ws), ws.numel() * 4, C.byref(po), _lib.stream_ptr()) == 3
     assert b"capture again" in lib.parq_last_error()
-    _lib.check(lib.parq_set_seam_fusion(h, 1), "seam")
+    _lib.check(lib.parq_set_seam_fusion(h, 1 - flipped), "seam")
     assert lib.parq_graph_destroy(g) == 0
     assert lib.parq_forward_replay(h, None, C.byref(sc), _lib.ptr(ws), ws.numel() * 4, C.byref(po), _lib.stream_ptr()) != 0
     dec.profile_enable(True)

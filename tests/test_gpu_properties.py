@@ -85,6 +85,7 @@ def test_repeated_forwards_are_bit_identical_with_the_seam_inside_a_launch(B, Qn
     I = 4
     cfg = synth.decoder_cfg(dim=256, queries=Qn, heads=4, ffn=768, layers=I)
     dec = make_decoder(cfg, synth.make_decoder_weights(cfg, 721, damped=True))
+    dec.fuse_seams = True                         # (opt-in since round 6)
     cam, T_cp, T_wp, T_wl = (torch.from_numpy(a).cuda() for a in synth.make_geometry(722, B, Vn, h, w))
     g = torch.Generator(device="cuda").manual_seed(723)
     tokens = torch.randn(B, Vn * h * w, 256, device="cuda", generator=g)
@@ -111,6 +112,7 @@ def test_seam_fusion_off_is_the_same_forward_up_to_fp32_rounding_and_the_timeout
     dec = make_decoder(cfg, synth.make_decoder_weights(cfg, 731, damped=True))
     dec.attention_mode = "split"                  # (2304 keys: the peakedness guard of mode "split8" is not the subject here)
     dec.range_check = "off"
+    dec.fuse_seams = True                         # (opt-in since round 6)
     cam, T_cp, T_wp, T_wl = (torch.from_numpy(a).cuda() for a in synth.make_geometry(732, B, Vn, h, w))
     g = torch.Generator(device="cuda").manual_seed(733)
     tokens = torch.randn(B, Vn * h * w, 256, device="cuda", generator=g)

@@ -1,3 +1,3 @@
 #!/bin/bash
 cd /root/repo
-timeout 600 python tools/r06_inflight_profile.py 2>&1 | grep -v amdgpu.ids | head -16
+bash tools/ab_env_long.sh PARQ_FUSE_SEAMS 1 0 2>&1 | tee gpurun_out/r06i_ab_seam_second_box.txt
