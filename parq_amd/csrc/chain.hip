@@ -729,6 +729,248 @@ __global__ __launch_bounds__(256) void chain_linear_stream_kernel(LinearArgs a) 
     }
 }
 
+// 32-row form of the streamed tile (round 6): 8 waves split K eight ways, every W fragment feeds TWO 16-row MFMAs (rows m0 .. m0 + 15
+// and m0 + 16 .. m0 + 31), so a launch reads W M / 32 times instead of M / 16 — the K = 1024 launches with thousands of columns
+// (self in-projection, head layers) are bound by that stream out of the L2s (profiles/NOTES_r06.md row 6).  A rows of both halves in
+// registers (K / 128 float4 per lane and half), W in double-buffered batches of two 16-step chunks, partial sums folded 8 -> 4 -> 1
+// through 32 KB of LDS.  Prologues / epilogue as in chain_linear_stream_kernel; the K split (and so the summation order) differs.
+template <int K, int NT, int PRO, int ADD2, bool BIAS, bool RELU, int RES, bool GNOUT>
+__global__ __launch_bounds__(512) void chain_linear_stream32_kernel(LinearArgs a) {
+    PARQ_TL_KERNEL(kTlLinear);
+    publish_progress(a);
+    static_assert(K % 256 == 0 && NT >= 1 && NT <= 4 && ADD2 != 2, "tile shape");
+    constexpr int NWV = 8;
+    constexpr int NCH = K / (16 * NWV);               // 16-wide K chunks per wave
+    constexpr int BCH = 2;                            // chunks per streamed batch
+    constexpr int NB = NCH / BCH;
+    static_assert(NCH % BCH == 0, "batches");
+    __shared__ __attribute__((aligned(16))) float red[4 * NT * 2 * 4 * 64];
+    __shared__ float lnred[NWV * 32 * 2];
+
+    const int g = blockIdx.y;
+    const int ntn = a.N / (16 * NT);
+    const int n0 = (int)(blockIdx.x % ntn) * 16 * NT;
+    const int m0 = (int)(blockIdx.x / ntn) * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    const int kbase = wave * 16 + kq * 4;
+    const float* xrow = a.X + g * a.gX + (int64_t)(m0 + li) * a.ldx + kbase;
+    const int64_t xh = 16 * a.ldx;
+    const float* wbase;
+    int64_t wt_stride, wc_stride;
+    if (a.Wp) {
+        wbase = a.Wp + g * a.gW + ((int64_t)(n0 / 16) * (K / 16) + wave) * 256 + lane * 4;
+        wt_stride = (int64_t)(K / 16) * 256;
+        wc_stride = NWV * 256;
+    } else {
+        wbase = a.W + g * a.gW + (int64_t)(n0 + li) * a.ldw + kbase;
+        wt_stride = 16 * a.ldw;
+        wc_stride = NWV * 16;
+    }
+    const float* x2row = ADD2 != 0 ? a.X2 + (int64_t)(m0 + li) * a.ldx2 + kbase : nullptr;
+    const int64_t x2h = ADD2 != 0 ? 16 * a.ldx2 : 0;
+    const float* pgp = PRO == kProLN ? a.ln_gamma + kbase : (PRO == kProGN ? a.gn_gamma + g * a.gGamma + kbase : nullptr);
+    const float* pbp = PRO == kProLN ? a.ln_beta + kbase : (PRO == kProGN ? a.gn_beta + g * a.gGamma + kbase : nullptr);
+
+    struct Batch { f32x4v w[NT][BCH]; f32x4v pg[BCH], pb[BCH], x2[2][BCH]; };
+    auto load_batch = [&](Batch& B, int b) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int c = 0; c < BCH; ++c) B.w[t][c] = *reinterpret_cast<const f32x4v*>(wbase + t * wt_stride + (b * BCH + c) * wc_stride);
+        if constexpr (PRO != kProNone) {
+#pragma unroll
+            for (int c = 0; c < BCH; ++c) {
+                B.pg[c] = *reinterpret_cast<const f32x4v*>(pgp + (b * BCH + c) * (NWV * 16));
+                B.pb[c] = *reinterpret_cast<const f32x4v*>(pbp + (b * BCH + c) * (NWV * 16));
+            }
+        }
+        if constexpr (ADD2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int c = 0; c < BCH; ++c) B.x2[h][c] = *reinterpret_cast<const f32x4v*>(x2row + h * x2h + (b * BCH + c) * (NWV * 16));
+        }
+    };
+
+    f32x4v av[2][NCH];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) av[h][c] = *reinterpret_cast<const f32x4v*>(xrow + h * xh + c * (NWV * 16));
+    Batch bt[2];
+    load_batch(bt[0], 0);
+    float shift[2] = {0.f, 0.f};
+    double gsm = 0.0, gsq = 0.0;
+    if constexpr (PRO == kProLN) {
+        shift[0] = a.X[g * a.gX + (int64_t)(m0 + li) * a.ldx];
+        shift[1] = a.X[g * a.gX + (int64_t)(m0 + 16 + li) * a.ldx];
+    }
+    if constexpr (PRO == kProGN) {
+        const double* src = a.gn_sums + ((int64_t)((m0 / a.gn_rows_per_scene) * a.gn_ngroups + g) * kGnSlots + lane) * 2;
+#pragma unroll
+        for (int i = 0; i < kGnSlots / 64; ++i) { gsm += src[i * 128]; gsq += src[i * 128 + 1]; }
+    }
+    const int et = wave % NT, eh = wave / NT;         // the 16 x 16 sub-tile this wave finishes (waves >= 2 NT have none)
+    const int erow = lane >> 2, ec = (lane & 3) * 4;
+    const int om = m0 + eh * 16 + erow, on = n0 + et * 16 + ec;
+    f32x4v e_bias = {0.f, 0.f, 0.f, 0.f}, e_r = {0.f, 0.f, 0.f, 0.f}, e_rg = {1.f, 1.f, 1.f, 1.f}, e_rb = {0.f, 0.f, 0.f, 0.f};
+    float rmean = 0.f, rrstd = 1.f;
+    if (wave < 2 * NT) {
+        if constexpr (BIAS) e_bias = *reinterpret_cast<const f32x4v*>(a.bias + g * a.gBias + on);
+        if constexpr (RES != kResNone) e_r = *reinterpret_cast<const f32x4v*>(a.R + (int64_t)om * a.ldr + on);
+        if constexpr (RES == kResLN) {
+            e_rg = *reinterpret_cast<const f32x4v*>(a.rln_gamma + on);
+            e_rb = *reinterpret_cast<const f32x4v*>(a.rln_beta + on);
+            rmean = a.rln_stats[(int64_t)om * 2 + 0];
+            rrstd = a.rln_stats[(int64_t)om * 2 + 1];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f};
+    if constexpr (PRO == kProLN) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = av[h][c][e] - shift[h];
+                    sm += d;
+                    sq += d * d;
+                }
+            sm += __shfl_xor(sm, 16); sq += __shfl_xor(sq, 16);
+            sm += __shfl_xor(sm, 32); sq += __shfl_xor(sq, 32);
+            if (kq == 0) { lnred[(wave * 32 + h * 16 + li) * 2 + 0] = sm; lnred[(wave * 32 + h * 16 + li) * 2 + 1] = sq; }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float Ssum = 0.f, Q2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) { Ssum += lnred[(w * 32 + h * 16 + li) * 2 + 0]; Q2 += lnred[(w * 32 + h * 16 + li) * 2 + 1]; }
+            const float invK = 1.f / (float)K;
+            const float dm = Ssum * invK;
+            mean[h] = shift[h] + dm;
+            const float var = fmaxf(Q2 * invK - dm * dm, 0.f);
+            rstd[h] = 1.f / sqrtf(var + a.norm_eps);
+            if (a.ln_stats_out && n0 == 0 && wave == 0 && kq == 0) {
+                a.ln_stats_out[(int64_t)(m0 + h * 16 + li) * 2 + 0] = mean[h];
+                a.ln_stats_out[(int64_t)(m0 + h * 16 + li) * 2 + 1] = rstd[h];
+            }
+        }
+    }
+    if constexpr (PRO == kProGN) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { gsm += __shfl_xor(gsm, o); gsq += __shfl_xor(gsq, o); }
+        gn_mean_rstd(gsm, gsq, 1.0 / ((double)a.gn_rows_per_scene * (double)K), a.norm_eps, mean[0], rstd[0]);
+        mean[1] = mean[0];
+        rstd[1] = rstd[0];
+    }
+    const bool add2 = ADD2 != 0 && n0 < a.x2_ncols;
+
+    f32x4v acc[2][NT];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[h][t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (b + 1 < NB) load_batch(bt[(b + 1) & 1], b + 1);          // in flight behind this batch's arithmetic
+        __builtin_amdgcn_sched_barrier(0);
+        const Batch& B = bt[b & 1];
+#pragma unroll
+        for (int c = 0; c < BCH; ++c) {
+            f32x4v x[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                x[h] = av[h][b * BCH + c];
+                if constexpr (PRO == kProLN) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[h][e] = (x[h][e] - mean[h]) * rstd[h] * B.pg[c][e] + B.pb[c][e];
+                }
+                if constexpr (ADD2) {
+                    if (add2) x[h] += B.x2[h][c];
+                }
+                if constexpr (PRO == kProGN) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = (x[h][e] - mean[h]) * rstd[h] * B.pg[c][e] + B.pb[c][e];
+                        x[h][e] = y > 0.f ? y : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[h][e], B.w[t][c][e], acc[h][t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // 8 partial tiles -> 4 (waves 4..7 hand theirs to waves 0..3) -> 1 (the finishing wave of each sub-tile adds four)
+    auto ridx = [&](int w4, int t, int h, int r) { return ((((w4 * NT + t) * 2 + h) * 4 + r) * 64); };
+    if (wave >= 4) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[ridx(wave - 4, t, h, r) + lane] = acc[h][t][r];
+    }
+    lds_barrier();
+    if (wave < 4) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[ridx(wave, t, h, r) + lane] += acc[h][t][r];
+    }
+    lds_barrier();
+    if (wave >= 2 * NT) return;
+    const int src = ridx(0, et, eh, erow & 3) + (erow >> 2) * 16 + ec;
+    f32x4v sum = *reinterpret_cast<const f32x4v*>(&red[src]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) sum += *reinterpret_cast<const f32x4v*>(&red[src + w * NT * 2 * 256]);
+    f32x4v y;
+    double gs = 0.0, gq = 0.0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v = sum[e] + e_bias[e];
+        if constexpr (RELU) v = v > 0.f ? v : 0.f;
+        if constexpr (RES == kResPlain) v += e_r[e];
+        if constexpr (RES == kResLN) v += (e_r[e] - rmean) * rrstd * e_rg[e] + e_rb[e];
+        y[e] = v;
+        if constexpr (GNOUT) { gs += (double)v; gq += (double)v * (double)v; }
+    }
+    *reinterpret_cast<f32x4v*>(a.Y + g * a.gY + (int64_t)om * a.y_row + on) = y;
+    if constexpr (GNOUT) {
+        const int nt0 = n0 + et * 16, mt0 = m0 + eh * 16;
+        if (nt0 < a.gn_out_ncols) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { gs += __shfl_xor(gs, o); gq += __shfl_xor(gq, o); }
+            if (lane == 0) {
+                const int grp = (nt0 + g * a.N) / a.gn_out_group_cols;
+                const int cbs = a.gn_out_group_cols >> 4;
+                const int rb = (mt0 % a.gn_out_rows_per_scene) >> 4, cb = ((nt0 + g * a.N) % a.gn_out_group_cols) >> 4;
+                const bool own = (a.gn_out_rows_per_scene >> 4) * cbs <= kGnSlots;
+                const int slot = own ? rb * cbs + cb : (int)(((blockIdx.x * 2 + eh) * NT + et) % kGnSlots);
+                double* dst = a.gn_out_sums + (((int64_t)(mt0 / a.gn_out_rows_per_scene) * a.gn_out_ngroups + grp) * kGnSlots + slot) * 2;
+                if (own) {
+                    typedef double f64x2 __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<f64x2*>(dst) = f64x2{gs, gq};
+                } else {
+                    atomicAdd(dst, gs);
+                    atomicAdd(dst + 1, gq);
+                }
+            }
+        }
+    }
+}
+
 // tile-ordered copy of a row-major weight matrix (LinearArgs::Wp): thread = one float4 of the destination
 __global__ void pack_w_tiles_kernel(const float* __restrict__ W, int64_t ldw, int N, int K, float* __restrict__ dst) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // float4 index in dst
@@ -838,6 +1080,16 @@ hipError_t go_stream(const LinearArgs& a0, int groups, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <int K, int NT, int PRO, int ADD2, bool BIAS, bool RELU, int RES, bool GNOUT>
+hipError_t go_stream32(const LinearArgs& a0, int groups, hipStream_t s) {
+    if (g_dry_run) return hipSuccess;
+    LinearArgs a = a0;
+    a.tile_map = 0;
+    const dim3 grid((unsigned)((a.N / (16 * NT)) * (a.M / 32)), groups, 1);
+    hipLaunchKernelGGL((chain_linear_stream32_kernel<K, NT, PRO, ADD2, BIAS, RELU, RES, GNOUT>), grid, dim3(512), 0, s, a);
+    return hipGetLastError();
+}
+
 // column sub-tiles per workgroup for an N-wide launch: the widest of {1, 2, 3, 4} that divides N / 16 (and the addend / moment
 // boundaries) while the grid still has at least ~3/4 of a workgroup per CU at one scene
 int pick_nt(const LinearArgs& a, int want) {
@@ -925,8 +1177,23 @@ hipError_t launch_chain_linear(const LinearArgs& a_in, int groups, hipStream_t s
     // K = 1024 forms: "stream" (default; W double-buffered in 256-step batches, 4 waves: measured 1.55 ms of linears per shipped-size
     // forward) or "8w" (8 waves split K, everything in flight at once: 1.66 ms)
     static const bool stream_env = [] { const char* e = dev_env("PARQ_CHAIN_K1024"); return !(e && e[0] == '8'); }();
+    // 32-row form (chain_linear_stream32_kernel) for launches whose 32-row grid still has a workgroup per CU (512 lanes and ~200
+    // registers: one per CU is all that fits).  Shipped geometry, per launch, 16-row -> 32-row (profiles/r06_ab_chain_rows32.txt):
+    // one scene: head layer 1 34.9 -> 32.5 us, head layer 2 23.3 -> 18.5, self in-projection 30.8 -> 31.6, the N = 1024 launches
+    // (128 workgroups: below the threshold) 10.8 -> 20; forward 2.380 -> 2.333 ms at one scene, 7.51 -> 6.82 ms at four
+    static const int min_wg32 = [] { const char* e = dev_env("PARQ_CHAIN_K1024_ROWS32"); return e ? atoi(e) : 256; }();   // 0: never
+    const bool rows32_ok = min_wg32 > 0 && a.M % 32 == 0 && (!a.gn_sums || a.gn_rows_per_scene % 32 == 0) &&
+                           (!a.gn_out_sums || a.gn_out_rows_per_scene % 32 == 0);
 #define PARQ_STREAM(PRO, ADD2, BIAS, RELU, RES, GNOUT)                                                          \
     {                                                                                                           \
+        if (rows32_ok) {                                                                                        \
+            const int nt = pick_nt(a, nt_big);                                                                  \
+            if ((int64_t)(a.N / (16 * nt)) * (a.M / 32) * groups >= min_wg32) {                                 \
+                if (nt == 4) return go_stream32<1024, 4, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s);      \
+                if (nt == 3) return go_stream32<1024, 3, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s);      \
+                if (nt == 2) return go_stream32<1024, 2, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s);      \
+            }                                                                                                   \
+        }                                                                                                       \
         /* 8-wave form: 256 registers per lane — LayerNorm prologues (gamma, beta per lane) leave room for 3 sub-tiles, 2 with an addend */ \
         const int nt = pick_nt(a, stream_env || PRO != kProLN ? nt_big : (ADD2 ? 2 : (nt_big < 3 ? nt_big : 3)));       \
         if (!stream_env) {                                                                                      \

@@ -203,6 +203,9 @@ def test_reduced_precision_modes_at_head_dim_256(mode, tol, dim, heads):
     (1, 3, 9, 10, 150, 2, 512, 256),       # head dim 256 with two heads, Q = 150: a partly filled second query tile of 128
     (3, 1, 7, 9, 300, 4, 1024, 768),       # three scenes of 63 tokens (< one token tile, 2 key blocks), Q = 300: three query tiles, the last
                                            # with one inactive wave pair
+    (1, 2, 12, 16, 256, 4, 1024, 768),     # shipped width with the shipped query count, one scene (M = 256): the 32-row streamed tile on
+                                           # the launches whose 32-row grid fills the chip (in-projection, head layers), 16-row on the others
+    (2, 1, 10, 12, 256, 4, 1024, 768),     # two scenes (M = 512): every K = 1024 launch takes the 32-row form, GroupNorm scenes = 8 row tiles
     (2, 2, 69, 77, 32, 4, 256, 768),       # K/V projection walk: 2 x 10 626 tokens = 2 x 167 token tiles over 128 persistent slots, so
                                            # workgroups carry 2-3 tiles, scene 0's partial tile (2 rows) sits in the MIDDLE of a walk
                                            # (counted waits across a drained epilogue), and tiles cross the scene boundary
