@@ -401,6 +401,15 @@ int parq_k_camera_local(const float *T_cp, const float *T_wp, const float *T_wl,
 int parq_k_linear(const float *X, const float *X2, const float *W, const float *bias, const float *R,
                   float *Y, int32_t M, int32_t N, int32_t K, int32_t relu, parq_stream stream);
 
+/* The same product on the fp16 matrix pipe with fp32-class accuracy (chain.hip chain_linear_h3_kernel: the tile the inference chain uses
+ * for contractions over 1024 / 768 — the reference's shipped decoder width, config/train.yaml:37-56 — in every attention mode but 0):
+ * operands carried as fp16 hi + lo, a_hi w_hi + a_hi w_lo + a_lo w_hi with fp32 accumulation, rows of X and rows of W scaled by exact
+ * powers of two (no range condition).  K in {1024, 768}, M % 16 == 0, N % 16 == 0; `scratch` (>= N * K * 4 + N * 4 bytes, 16-byte aligned)
+ * receives the packed weights (what parq_pack_weights' arena holds for the chain).  PARQ_ERR_ARG otherwise. */
+int parq_k_linear_half(const float *X, const float *X2, const float *W, const float *bias, const float *R,
+                       float *Y, int32_t M, int32_t N, int32_t K, int32_t relu, void *scratch, size_t scratch_bytes,
+                       parq_stream stream);
+
 /* softmax(Q K^T / sqrt(dh)) V for (B,H) heads; q (B,Lq,H*dh), k/v (B,Lk,H*dh) row-major;
  * out (B,Lq,H*dh).  scratch must hold parq_k_attention_scratch_bytes(). */
 size_t parq_k_attention_scratch_bytes(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t dh);

@@ -99,6 +99,7 @@ SYMBOLS = {
     "parq_k_project_sample": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(_f), _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "parq_k_camera_local": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "parq_k_linear": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "parq_k_linear_half": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "parq_k_attention_scratch_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "parq_k_attention": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "parq_k_attention_split_scratch_bytes": (_sz, [_i32, _i32, _i32, _i32]),

@@ -68,6 +68,8 @@ struct Arena {
     int64_t early_begin = 0, early_end = 0;   // [early_begin, early_end): gradients final after phase 1 of parq_backward (nl = 1)
     int64_t rowmajor_total;           // end of the tensors above = size of the gradient arena (same layout)
     int64_t tile_off;                 // start of the tile-ordered mirror: matrix at offset o has its chain.hip copy at tile_off + o
+    int64_t half_off = -1;            // start of the fp16 hi / lo mirror (LinearArgs::Wh) or -1: widths whose chain contracts over >= 768
+    int64_t hscale_off = -1;          // its column scales: matrix at offset o has them at hscale_off + hscale_slot(o)
     int64_t total;
 };
 
@@ -201,6 +203,21 @@ void build_arena(parq_ctx* c) {
     // tile-ordered copies of the matrices the per-iteration chain multiplies by (LinearArgs::Wp): same offsets, shifted
     a.tile_off = off;
     a.total = 2 * off;
+    // fp16 hi / lo mirror for the fp16 x 3 chain tile (chain.hip chain_linear_h3_kernel: contractions over 1024 or 768 only)
+    if (C % 256 == 0 && C >= 768) {
+        a.half_off = 2 * off;
+        a.hscale_off = (3 * off + 63) / 64 * 64;
+        a.total = a.hscale_off + ((off + 255) / 256 + 63) / 64 * 64 + 64;
+    }
+}
+
+// column scales of the fp16 hi / lo mirror: the matrix at arena offset o ([N][K], K >= 768) keeps its N scales at hscale_off + this
+// (16-byte aligned; disjoint: the next matrix starts N K / 256 >= 3 N slots further)
+inline int64_t hscale_slot(int64_t off) { return ((off >> 8) + 3) & ~(int64_t)3; }
+
+bool chain_h3_on() {
+    static const bool on = [] { const char* e = dev_env("PARQ_CHAIN_H3"); return !(e && e[0] == '0'); }();     // 0: fp32 MFMA tiles at every width (A/B)
+    return on;
 }
 
 bool kvproj_big_on() {
@@ -467,6 +484,27 @@ int build_derived_weights(parq_ctx* c, hipStream_t s) {
         if (c->NH1 % 16 == 0) HIPCHK(tile(ar.heads1_w, c->NH1, C));
         HIPCHK(tile(ar.heads2_w, C, C)); HIPCHK(tile(ar.heads2_w + C * C, C, C));
     }
+    if (ar.half_off >= 0) {
+        const int64_t H = ar.half_off, SC = ar.hscale_off;
+        // gamma / beta / bias: the LayerNorm in front of the launch that multiplies by this matrix, folded (chain.hip pack_w_half_kernel):
+        // gamma into the mirror unless an addend follows the LayerNorm, W beta + bias into the N floats behind the column scales
+        auto half = [&](int64_t off, int64_t N, int64_t K, const float* gamma = nullptr, const float* beta = nullptr, const float* bias = nullptr) {
+            if (N % 16 != 0 || !(K == 1024 || K == 768)) return hipSuccess;
+            float* scp = A + SC + hscale_slot(off);
+            return launch_pack_w_half(A + off, K, (int)N, (int)K, A + H + off, scp, s, gamma, beta, bias, beta ? scp + N : nullptr);
+        };
+        for (int li = 0; li < c->nl; ++li) {
+            const LayerW& L = c->ar.layers[li];
+            HIPCHK(half(L.self_in_w, 3 * C, C)); HIPCHK(half(L.self_out_w, C, C));
+            HIPCHK(half(L.cross_in_w, C, C, nullptr, A + L.n1_b, A + L.cross_in_b));                 // q rows: norm1, then + pos
+            HIPCHK(half(L.cross_out_w, C, C));
+            HIPCHK(half(L.lin1_w, F, C, A + L.n2_w, A + L.n2_b, A + L.lin1_b)); HIPCHK(half(L.lin2_w, C, F));
+        }
+        HIPCHK(half(ar.pe2_w, C, C));
+        if (c->nl == 1) HIPCHK(half(ar.heads1_w, c->NH1, C, A + ar.layers[0].n3_w, A + ar.layers[0].n3_b, A + ar.heads1_b));      // one norm3 in front of the shared heads
+        else HIPCHK(half(ar.heads1_w, c->NH1, C));                     // a norm3 per layer: no fold (that launch keeps the fp32 tile)
+        HIPCHK(half(ar.heads2_w, C, C)); HIPCHK(half(ar.heads2_w + C * C, C, C));
+    }
     c->derived_valid = true;
     return PARQ_OK;
 }
@@ -500,6 +538,16 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     if (!train && !c->derived_valid) { const int rc = build_derived_weights(c, s); if (rc) return rc; }
     // tile-ordered mirror of the chain's matrices (LinearArgs::Wp); the training forward reads the row-major tensors
     const float* TP = train ? nullptr : A + ar.tile_off;
+    // fp16 hi / lo mirror (LinearArgs::Wh: the fp16 x 3 tile of chain.hip for contractions over 1024 / 768) — inference, every attention
+    // mode but the exact-fp32 one (mode 0 keeps fp32 MFMA products in the chain as well)
+    const bool h3 = !train && ar.half_off >= 0 && c->attn_mode != 0 && chain_h3_on();
+    // fold: what build_derived_weights folded of the LayerNorm in front of this launch (LinearArgs::wh_fold)
+    auto halfw = [&](LinearArgs& la, int64_t off, int fold = 0) {
+        if (h3) {
+            la.Wh = A + ar.half_off + off; la.wh_scale = A + ar.hscale_off + hscale_slot(off);
+            if (fold) { la.wh_bias = la.wh_scale + la.N; la.wh_fold = fold; }
+        }
+    };
     const int li = c->cfg.share_weights ? 0 : layer_num;
     const LayerW& L = ar.layers[li];
     const int B = sc->B, C = c->C, Q = c->Q, H = c->H, dh = c->dh, F = c->F;
@@ -512,7 +560,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     // transformer_parq.py:372-377) or with the position MLP's last layer folded into them (second operand pair h x (W W2)^T)
     auto self_in_args = [&](bool fold) {
         LinearArgs a = lin(wi + ws.tgt, C, A + L.self_in_w, C, A + (fold ? L.self_in_b2 : L.self_in_b), wi + ws.qkv, 3 * C, M, 3 * C, C);
-        a.ldx2 = C; a.x2_ncols = 2 * C; a.Wp = TP ? TP + L.self_in_w : nullptr;
+        a.ldx2 = C; a.x2_ncols = 2 * C; a.Wp = TP ? TP + L.self_in_w : nullptr; halfw(a, L.self_in_w);
         if (fold) { a.X2 = wi + ws.pe_h; a.W2 = A + L.self_in_w2; a.W2p = TP ? TP + L.self_in_w2 : nullptr; }
         else a.X2 = wi + ws.pos;
         return a;
@@ -520,7 +568,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
     auto cross_q_args = [&](bool fold) {
         LinearArgs a = lin(wi + ws.xa, C, A + L.cross_in_w, C, A + (fold ? L.cross_q_b2 : L.cross_in_b), wi + ws.qc, C, M, C, C);
         a.ln_gamma = A + L.n1_w; a.ln_beta = A + L.n1_b; a.ln_stats_out = wi + ws.ln1; a.norm_eps = eps;
-        a.ldx2 = C; a.x2_ncols = C; a.Wp = TP ? TP + L.cross_in_w : nullptr;
+        a.ldx2 = C; a.x2_ncols = C; a.Wp = TP ? TP + L.cross_in_w : nullptr; halfw(a, L.cross_in_w, 2);
         if (fold) { a.X2 = wi + ws.pe_h; a.W2 = A + L.cross_q_w2; a.W2p = TP ? TP + L.cross_q_w2 : nullptr; }
         else a.X2 = wi + ws.pos;
         return a;
@@ -555,7 +603,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         if (!fused) HIPCHK(launch_linear(pe1, 1, s));
         if (!fold_pos) {
             LinearArgs a = lin(wi + ws.pe_h, C, A + ar.pe2_w, C, A + ar.pe2_b, wi + ws.pos, C, M, C, C);
-            a.Wp = TP ? TP + ar.pe2_w : nullptr;
+            a.Wp = TP ? TP + ar.pe2_w : nullptr; halfw(a, ar.pe2_w);
             HIPCHK(launch_linear(a, 1, s));
         }
     }
@@ -615,7 +663,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         // xa = tgt + self_attn @ Wo  (pre-LayerNorm; norm1 is applied by the consumers)
         Prof p(c, s, PARQ_PROF_LINEAR);
         LinearArgs a = lin(wi + ws.sa, C, A + L.self_out_w, C, A + L.self_out_b, wi + ws.xa, C, M, C, C);
-        a.R = wi + ws.tgt; a.ldr = C; a.Wp = TP ? TP + L.self_out_w : nullptr;
+        a.R = wi + ws.tgt; a.ldr = C; a.Wp = TP ? TP + L.self_out_w : nullptr; halfw(a, L.self_out_w);
         a.drop_p = dp; a.drop_seed = c->site_seed(layer_num, 1);
         if (seam_ok && (seams & 1)) {
             // ... and, in the same launch, the query projection behind norm1 (chain.hip seam_tile): q tiles contract sa, tgt and pe_h with
@@ -723,7 +771,7 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         Prof p(c, s, PARQ_PROF_LINEAR);
         // xb = norm1(xa) + cross_attn @ Wo   (residual recomputed from the published statistics)
         LinearArgs a = lin(wi + ws.attn, C, A + L.cross_out_w, C, A + L.cross_out_b, wi + ws.xb, C, M, C, C);
-        a.R = wi + ws.xa; a.ldr = C; a.rln_stats = wi + ws.ln1; a.rln_gamma = A + L.n1_w; a.rln_beta = A + L.n1_b; a.Wp = TP ? TP + L.cross_out_w : nullptr;
+        a.R = wi + ws.xa; a.ldr = C; a.rln_stats = wi + ws.ln1; a.rln_gamma = A + L.n1_w; a.rln_beta = A + L.n1_b; a.Wp = TP ? TP + L.cross_out_w : nullptr; halfw(a, L.cross_out_w);
         a.drop_p = dp; a.drop_seed = c->site_seed(layer_num, 3);
         if (last_of_forward && c->progress_word != nullptr) {
             // the last iteration's cross-attention has been merged: nothing behind this launch raises a flag (range: the K/V projection;
@@ -738,12 +786,12 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         // K8: FFN (transformer_parq.py:383-385): relu(norm2(xb) @ W1), publishes norm2's statistics
         a = lin(wi + ws.xb, C, A + L.lin1_w, C, A + L.lin1_b, wi + ws.ffn, F, M, F, C);
         a.ln_gamma = A + L.n2_w; a.ln_beta = A + L.n2_b; a.ln_stats_out = wi + ws.ln2; a.norm_eps = eps;
-        a.relu = 1; a.Wp = TP ? TP + L.lin1_w : nullptr;
+        a.relu = 1; a.Wp = TP ? TP + L.lin1_w : nullptr; halfw(a, L.lin1_w, 1);
         a.drop_p = dp; a.drop_seed = c->site_seed(layer_num, 4);
         HIPCHK(launch_linear(a, 1, s));
         // xc = norm2(xb) + ffn @ W2
         a = lin(wi + ws.ffn, F, A + L.lin2_w, F, A + L.lin2_b, wi + ws.xc, C, M, C, F);
-        a.R = wi + ws.xb; a.ldr = C; a.rln_stats = wi + ws.ln2; a.rln_gamma = A + L.n2_w; a.rln_beta = A + L.n2_b; a.Wp = TP ? TP + L.lin2_w : nullptr;
+        a.R = wi + ws.xb; a.ldr = C; a.rln_stats = wi + ws.ln2; a.rln_gamma = A + L.n2_w; a.rln_beta = A + L.n2_b; a.Wp = TP ? TP + L.lin2_w : nullptr; halfw(a, L.lin2_w);
         a.drop_p = dp; a.drop_seed = c->site_seed(layer_num, 5);
         HIPCHK(launch_linear(a, 1, s));
         // K9: heads (transformer_parq.py:234-252; generic_mlp.py:85-110) on norm3(xc); the first layers of the
@@ -752,13 +800,13 @@ int do_iterate(parq_ctx* c, const parq_scene* sc, float* wsp, const Workspace& w
         a = lin(wi + ws.xc, C, A + ar.heads1_w, C, A + ar.heads1_b, wi + ws.h1, NH1, M, NH1, C);
         a.ln_gamma = A + L.n3_w; a.ln_beta = A + L.n3_b; a.norm_eps = eps;
         if (train) a.ln_stats_out = wi + ws.ln3;
-        if (NH1 % 16 == 0) a.Wp = TP ? TP + ar.heads1_w : nullptr;
+        if (NH1 % 16 == 0) { a.Wp = TP ? TP + ar.heads1_w : nullptr; halfw(a, ar.heads1_w, c->nl == 1 ? 1 : 0); }
         a.gn_out_sums = gn1; a.gn_out_ncols = 2 * C; a.gn_out_group_cols = C; a.gn_out_rows_per_scene = Q; a.gn_out_ngroups = 2;
         HIPCHK(launch_linear(a, 1, s));
         a = lin(wi + ws.h1, NH1, A + ar.heads2_w, C, nullptr, wi + ws.h2, 2 * C, M, C, C);
         a.gn_sums = gn1; a.gn_gamma = A + ar.gn1_g; a.gn_beta = A + ar.gn1_b; a.norm_eps = eps;
         a.gn_rows_per_scene = Q; a.gn_ngroups = 2;
-        a.gX = C; a.gW = (int64_t)C * C; a.gY = C; a.gGamma = C; a.Wp = TP ? TP + ar.heads2_w : nullptr;
+        a.gX = C; a.gW = (int64_t)C * C; a.gY = C; a.gGamma = C; a.Wp = TP ? TP + ar.heads2_w : nullptr; halfw(a, ar.heads2_w);
         a.gn_out_sums = gn2; a.gn_out_ncols = C; a.gn_out_group_cols = C; a.gn_out_rows_per_scene = Q; a.gn_out_ngroups = 2;
         HIPCHK(launch_linear(a, 2, s));
     }
@@ -1865,6 +1913,25 @@ int parq_k_linear(const float* X, const float* X2, const float* W, const float* 
     a.X2 = X2; a.ldx2 = K; a.x2_ncols = N;
     a.R = R; a.ldr = N; a.relu = relu;
     HIPCHK(launch_linear(a, 1, (hipStream_t)stream));
+    return PARQ_OK;
+}
+
+int parq_k_linear_half(const float* X, const float* X2, const float* W, const float* bias, const float* R, float* Y,
+                       int32_t M, int32_t N, int32_t K, int32_t relu, void* scratch, size_t scratch_bytes, parq_stream stream) {
+    if (!X || !W || !Y || !scratch || M < 16 || N < 16 || M % 16 != 0 || N % 16 != 0 || !(K == 1024 || K == 768))
+        return fail(PARQ_ERR_ARG, "bad argument (K in {1024, 768}, M and N multiples of 16)");
+    if (scratch_bytes < ((size_t)N * K + N) * sizeof(float) || (reinterpret_cast<uintptr_t>(scratch) & 15u))
+        return fail(PARQ_ERR_ARG, "scratch: N * K * 4 + N * 4 bytes, 16-byte aligned");
+    float* wh = static_cast<float*>(scratch);
+    float* sc = wh + (size_t)N * K;
+    HIPCHK(launch_pack_w_half(W, K, N, K, wh, sc, (hipStream_t)stream));
+    LinearArgs a = lin(X, K, W, K, bias, Y, N, M, N, K);
+    a.X2 = X2; a.ldx2 = K; a.x2_ncols = N;
+    a.R = R; a.ldr = N; a.relu = relu;
+    a.Wh = wh; a.wh_scale = sc;
+    const hipError_t e = launch_chain_linear(a, 1, (hipStream_t)stream);
+    if (e == hipErrorNotSupported) return fail(PARQ_ERR_ARG, "no fp16 x 3 tile for this combination of addend / bias / ReLU / residual");
+    HIPCHK(e);
     return PARQ_OK;
 }
 

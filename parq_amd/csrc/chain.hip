@@ -971,6 +971,376 @@ __global__ __launch_bounds__(512) void chain_linear_stream32_kernel(LinearArgs a
     }
 }
 
+// ---- fp16 x 3 form of the tile for LONG contractions (round 6; K = 1024 / 768: the shipped decoder width) -------------------------
+// The fp32 MFMA (157 TF) bounds these launches: 0.54 GF per N = 1024 launch is 3.4 us at that peak with one tile per CU, 6.4 GF per
+// iteration 41 us (profiles/r06_chain_k1024_forms_per_launch.txt).  Here every fp32 operand is carried as hi + lo (two fp16 values,
+// 22 significant bits — the same arithmetic as the split-precision attention, flash_split.hip) and a product is
+// a_hi w_hi + a_hi w_lo + a_lo w_hi on v_mfma_f32_16x16x32_f16 with fp32 accumulation: 3 x 16 cycles per 32 contraction steps and
+// sub-tile instead of 8 x 32.  Range is not a condition: the A rows are scaled by an exact power of two per row (row maximum -> [2^10,
+// 2^11), found from the values the prologue produced) and the weight rows by one per output column at pack time
+// (pack_w_half_kernel), and the epilogue multiplies both back — all exact — so any finite fp32 input gives the fp32-class result.
+// Weights: LinearArgs::Wh, fragment-ordered (block (n / 16, k / 32) = 2 KB: plane hi then plane lo, lane (n % 16, (k % 32) / 8) holds
+// 8 consecutive k as one 16-byte load), wh_scale[n] = the inverse column scale.  Prologues / epilogue / moments as in
+// chain_linear_stream_kernel.  8 waves split K in 32-wide chunks and EVERY operand of the tile is requested before the first wait (with
+// 16-cycle products a streamed W batch would expose its whole round trip: the 4-wave double-buffered form measured 8.8 us per N = 1024
+// launch where the fp32 tile takes 10.8); RH = 2: 32-row tiles, every W fragment feeds two row halves.
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split8(const f32x4v& x0, const f32x4v& x1, f16x8v& hi, f16x8v& lo) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float u = p < 2 ? x0[2 * p] : x1[2 * p - 4], v = p < 2 ? x0[2 * p + 1] : x1[2 * p - 3];
+        const f16x2v h = __builtin_convertvector(f32x2v{u, v}, f16x2v);
+        const f16x2v l = __builtin_convertvector(f32x2v{u - (float)h[0], v - (float)h[1]}, f16x2v);
+        hi[2 * p] = h[0]; hi[2 * p + 1] = h[1];
+        lo[2 * p] = l[0]; lo[2 * p + 1] = l[1];
+    }
+}
+
+template <int K, int NT, int RH, int PRO, int ADD2, bool BIAS, bool RELU, int RES, bool GNOUT, int FOLD = 0>
+__global__ __launch_bounds__(512) void chain_linear_h3_kernel(LinearArgs a) {
+    PARQ_TL_KERNEL(kTlLinear);
+    publish_progress(a);
+    static_assert(K % 256 == 0 && NT >= 1 && NT <= 4 && (RH == 1 || RH == 2) && ADD2 != 2, "tile shape");
+    // FOLD (LayerNorm prologues; pack_w_half_kernel): 1 = gamma sits in Wh and W beta in wh_bias — the prologue is (x - mean) rstd;
+    // 2 = W beta in wh_bias only (an addend follows the LayerNorm: (x - mean) rstd gamma + x2)
+    static_assert(FOLD == 0 || (PRO == kProLN && BIAS && (FOLD == 1) == (ADD2 == 0)), "fold");
+    constexpr bool kGamma = PRO == kProGN || (PRO == kProLN && FOLD != 1), kBeta = PRO == kProGN || (PRO == kProLN && FOLD == 0);
+    // register budget: with prologue parameters or an addend in flight the second half of the W fragments is requested only after
+    // the prologue has consumed them (it lands behind the row-maximum barrier and the conversion)
+    constexpr bool kLateW = NT >= 2 && (ADD2 != 0 || kGamma);
+    constexpr int NT0 = kLateW ? NT / 2 : NT;
+    constexpr int NWV = 8;
+    constexpr int NCH = K / (32 * NWV);               // 32-wide K chunks per wave (4 at K = 1024): every operand of the tile is requested up front
+    constexpr int ROWS = 16 * RH;
+    __shared__ __attribute__((aligned(16))) float red[4 * NT * RH * 4 * 64];
+    __shared__ float lnred[NWV * ROWS * 2];
+    __shared__ float rmx[NWV * ROWS];
+    __shared__ float rinv[ROWS];
+
+    const int g = blockIdx.y;
+    const int ntn = a.N / (16 * NT);
+    const int n0 = (int)(blockIdx.x % ntn) * 16 * NT;
+    const int m0 = (int)(blockIdx.x / ntn) * ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    const int kbase = wave * 32 + kq * 8;             // the lane's 8 values of its c-th chunk sit at kbase + 256 c
+    const float* xrow = a.X + g * a.gX + (int64_t)(m0 + li) * a.ldx + kbase;
+    const int64_t xh = 16 * a.ldx;
+    const f32x4v* wbase = reinterpret_cast<const f32x4v*>(a.Wh + g * a.gW) + ((int64_t)(n0 / 16) * (K / 32) + wave) * 128 + lane;
+    constexpr int64_t wt_stride = (int64_t)(K / 32) * 128, wc_stride = NWV * 128;      // float4 units
+    const float* x2row = ADD2 != 0 ? a.X2 + (int64_t)(m0 + li) * a.ldx2 + kbase : nullptr;
+    const int64_t x2h = ADD2 != 0 ? 16 * a.ldx2 : 0;
+    const float* pgp = PRO == kProLN ? a.ln_gamma + kbase : (PRO == kProGN ? a.gn_gamma + g * a.gGamma + kbase : nullptr);
+    const float* pbp = PRO == kProLN ? a.ln_beta + kbase : (PRO == kProGN ? a.gn_beta + g * a.gGamma + kbase : nullptr);
+    const bool add2 = ADD2 != 0 && n0 < a.x2_ncols;
+
+    f32x4v av[RH][NCH][2];
+#pragma unroll
+    for (int h = 0; h < RH; ++h)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            av[h][c][0] = *reinterpret_cast<const f32x4v*>(xrow + h * xh + c * 256);
+            av[h][c][1] = *reinterpret_cast<const f32x4v*>(xrow + h * xh + c * 256 + 4);
+        }
+    f32x4v pg[NCH][2], pb[NCH][2], x2[RH][NCH][2];
+    if constexpr (kGamma) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) pg[c][q] = *reinterpret_cast<const f32x4v*>(pgp + c * 256 + q * 4);
+    }
+    if constexpr (kBeta) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) pb[c][q] = *reinterpret_cast<const f32x4v*>(pbp + c * 256 + q * 4);
+    }
+    if constexpr (ADD2) {
+        if (add2) {
+#pragma unroll
+            for (int h = 0; h < RH; ++h)
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) x2[h][c][q] = *reinterpret_cast<const f32x4v*>(x2row + h * x2h + c * 256 + q * 4);
+        }
+    }
+    f32x4v wh[NT][NCH], wl[NT][NCH];
+#pragma unroll
+    for (int t = 0; t < NT0; ++t)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            wh[t][c] = wbase[t * wt_stride + c * wc_stride];
+            wl[t][c] = wbase[t * wt_stride + c * wc_stride + 64];
+        }
+    float shift[RH];
+    double gsm = 0.0, gsq = 0.0;
+    if constexpr (PRO == kProLN) {
+#pragma unroll
+        for (int h = 0; h < RH; ++h) shift[h] = a.X[g * a.gX + (int64_t)(m0 + h * 16 + li) * a.ldx];
+    }
+    if constexpr (PRO == kProGN) {
+        const double* src = a.gn_sums + ((int64_t)((m0 / a.gn_rows_per_scene) * a.gn_ngroups + g) * kGnSlots + lane) * 2;
+#pragma unroll
+        for (int i = 0; i < kGnSlots / 64; ++i) { gsm += src[i * 128]; gsq += src[i * 128 + 1]; }
+    }
+    const int et = wave % NT, eh = wave / NT;         // the 16 x 16 sub-tile this wave finishes (waves >= NT RH have none)
+    const int erow = lane >> 2, ec = (lane & 3) * 4;
+    const int om = m0 + eh * 16 + erow, on = n0 + et * 16 + ec;
+    f32x4v e_bias = {0.f, 0.f, 0.f, 0.f}, e_r = {0.f, 0.f, 0.f, 0.f}, e_rg = {1.f, 1.f, 1.f, 1.f}, e_rb = {0.f, 0.f, 0.f, 0.f};
+    f32x4v e_ws = {1.f, 1.f, 1.f, 1.f};
+    float rmean = 0.f, rrstd = 1.f;
+    if (wave < NT * RH) {
+        e_ws = *reinterpret_cast<const f32x4v*>(a.wh_scale + g * (a.gW >> 8) + on);
+        if constexpr (BIAS) e_bias = *reinterpret_cast<const f32x4v*>((FOLD != 0 ? a.wh_bias : a.bias + g * a.gBias) + on);
+        if constexpr (RES != kResNone) e_r = *reinterpret_cast<const f32x4v*>(a.R + (int64_t)om * a.ldr + on);
+        if constexpr (RES == kResLN) {
+            e_rg = *reinterpret_cast<const f32x4v*>(a.rln_gamma + on);
+            e_rb = *reinterpret_cast<const f32x4v*>(a.rln_beta + on);
+            rmean = a.rln_stats[(int64_t)om * 2 + 0];
+            rrstd = a.rln_stats[(int64_t)om * 2 + 1];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    float mean[RH], rstd[RH];
+#pragma unroll
+    for (int h = 0; h < RH; ++h) { mean[h] = 0.f; rstd[h] = 1.f; }
+    if constexpr (PRO == kProLN) {
+#pragma unroll
+        for (int h = 0; h < RH; ++h) {
+            float sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = av[h][c][q][e] - shift[h];
+                        sm += d;
+                        sq += d * d;
+                    }
+            sm += __shfl_xor(sm, 16); sq += __shfl_xor(sq, 16);
+            sm += __shfl_xor(sm, 32); sq += __shfl_xor(sq, 32);
+            if (kq == 0) { lnred[(wave * ROWS + h * 16 + li) * 2 + 0] = sm; lnred[(wave * ROWS + h * 16 + li) * 2 + 1] = sq; }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int h = 0; h < RH; ++h) {
+            float Ssum = 0.f, Q2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) { Ssum += lnred[(w * ROWS + h * 16 + li) * 2 + 0]; Q2 += lnred[(w * ROWS + h * 16 + li) * 2 + 1]; }
+            const float invK = 1.f / (float)K;
+            const float dm = Ssum * invK;
+            mean[h] = shift[h] + dm;
+            const float var = fmaxf(Q2 * invK - dm * dm, 0.f);
+            rstd[h] = 1.f / sqrtf(var + a.norm_eps);
+            if (a.ln_stats_out && n0 == 0 && wave == 0 && kq == 0) {
+                a.ln_stats_out[(int64_t)(m0 + h * 16 + li) * 2 + 0] = mean[h];
+                a.ln_stats_out[(int64_t)(m0 + h * 16 + li) * 2 + 1] = rstd[h];
+            }
+        }
+    }
+    if constexpr (PRO == kProGN) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { gsm += __shfl_xor(gsm, o); gsq += __shfl_xor(gsq, o); }
+        gn_mean_rstd(gsm, gsq, 1.0 / ((double)a.gn_rows_per_scene * (double)K), a.norm_eps, mean[0], rstd[0]);
+        if constexpr (RH == 2) { mean[1] = mean[0]; rstd[1] = rstd[0]; }
+    }
+    // the prologue in fp32, in place; row maximum of what the products will see
+#pragma unroll
+    for (int h = 0; h < RH; ++h) {
+        float amax = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                f32x4v x = av[h][c][q];
+                if constexpr (PRO != kProNone) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x[e] = (x[e] - mean[h]) * rstd[h];
+                        if constexpr (kGamma) x[e] *= pg[c][q][e];
+                        if constexpr (kBeta) x[e] += pb[c][q][e];
+                        if constexpr (PRO == kProGN) x[e] = x[e] > 0.f ? x[e] : 0.f;
+                    }
+                }
+                if constexpr (ADD2) {
+                    if (add2) x += x2[h][c][q];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(x[e]));
+                av[h][c][q] = x;
+            }
+        amax = fmaxf(amax, __shfl_xor(amax, 16));
+        amax = fmaxf(amax, __shfl_xor(amax, 32));
+        if (kq == 0) rmx[wave * ROWS + h * 16 + li] = amax;
+    }
+    if constexpr (kLateW) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = NT0; t < NT; ++t)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                wh[t][c] = wbase[t * wt_stride + c * wc_stride];
+                wl[t][c] = wbase[t * wt_stride + c * wc_stride + 64];
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    lds_barrier();
+    f16x8v ah[RH][NCH], al[RH][NCH];
+#pragma unroll
+    for (int h = 0; h < RH; ++h) {
+        float amax = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) amax = fmaxf(amax, rmx[w * ROWS + h * 16 + li]);
+        // exact power of two that takes the row maximum into [2^10, 2^11) (1 for an all-zero, tiny or non-finite row: those go through as they are)
+        const int ex = (int)((__float_as_uint(amax) >> 23) & 255u);
+        const bool plain = ex < 16 || ex == 255;
+        const float sc = plain ? 1.f : __uint_as_float((unsigned)(127 + 10 + 127 - ex) << 23);
+        if (wave == 0 && kq == 0) rinv[h * 16 + li] = plain ? 1.f : __uint_as_float((unsigned)(ex - 10) << 23);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) split8(av[h][c][0] * sc, av[h][c][1] * sc, ah[h][c], al[h][c]);
+    }
+
+    f32x4v acc[RH][NT];
+#pragma unroll
+    for (int h = 0; h < RH; ++h)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[h][t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const f16x8v bh = __builtin_bit_cast(f16x8v, wh[t][c]), bl = __builtin_bit_cast(f16x8v, wl[t][c]);
+#pragma unroll
+            for (int h = 0; h < RH; ++h) {
+                acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[h][c], bh, acc[h][t], 0, 0, 0);
+                acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[h][c], bl, acc[h][t], 0, 0, 0);
+                acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[h][c], bh, acc[h][t], 0, 0, 0);
+            }
+        }
+    // 8 partial tiles -> 4 (waves 4..7 hand theirs to waves 0..3) -> 1 (the finishing wave of each sub-tile adds four)
+    auto ridx = [&](int w4, int t, int h, int r) { return ((((w4 * NT + t) * RH + h) * 4 + r) * 64); };
+    if (wave >= 4) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int h = 0; h < RH; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[ridx(wave - 4, t, h, r) + lane] = acc[h][t][r];
+    }
+    lds_barrier();
+    if (wave < 4) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int h = 0; h < RH; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[ridx(wave, t, h, r) + lane] += acc[h][t][r];
+    }
+    lds_barrier();
+    if (wave >= NT * RH) return;
+    const int src = ridx(0, et, eh, erow & 3) + (erow >> 2) * 16 + ec;
+    f32x4v sum = *reinterpret_cast<const f32x4v*>(&red[src]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) sum += *reinterpret_cast<const f32x4v*>(&red[src + w * NT * RH * 256]);
+    const float rs = rinv[eh * 16 + erow];
+    f32x4v y;
+    double gs = 0.0, gq = 0.0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v = sum[e] * (rs * e_ws[e]) + e_bias[e];
+        if constexpr (RELU) v = v > 0.f ? v : 0.f;
+        if constexpr (RES == kResPlain) v += e_r[e];
+        if constexpr (RES == kResLN) v += (e_r[e] - rmean) * rrstd * e_rg[e] + e_rb[e];
+        y[e] = v;
+        if constexpr (GNOUT) { gs += (double)v; gq += (double)v * (double)v; }
+    }
+    *reinterpret_cast<f32x4v*>(a.Y + g * a.gY + (int64_t)om * a.y_row + on) = y;
+    if constexpr (GNOUT) {
+        const int nt0 = n0 + et * 16, mt0 = m0 + eh * 16;
+        if (nt0 < a.gn_out_ncols) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { gs += __shfl_xor(gs, o); gq += __shfl_xor(gq, o); }
+            if (lane == 0) {
+                const int grp = (nt0 + g * a.N) / a.gn_out_group_cols;
+                const int cbs = a.gn_out_group_cols >> 4;
+                const int rb = (mt0 % a.gn_out_rows_per_scene) >> 4, cb = ((nt0 + g * a.N) % a.gn_out_group_cols) >> 4;
+                const bool own = (a.gn_out_rows_per_scene >> 4) * cbs <= kGnSlots;
+                const int slot = own ? rb * cbs + cb : (int)(((blockIdx.x * RH + eh) * NT + et) % kGnSlots);
+                double* dst = a.gn_out_sums + (((int64_t)(mt0 / a.gn_out_rows_per_scene) * a.gn_out_ngroups + grp) * kGnSlots + slot) * 2;
+                if (own) {
+                    typedef double f64x2 __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<f64x2*>(dst) = f64x2{gs, gq};
+                } else {
+                    atomicAdd(dst, gs);
+                    atomicAdd(dst + 1, gq);
+                }
+            }
+        }
+    }
+}
+
+// Wh / wh_scale of a row-major [N][K] matrix: one workgroup per 16 output columns.  Column scale 2^f takes the row's largest |w| into
+// [2^10, 2^11); hi = fp16(w 2^f), lo = fp16(w 2^f - hi) (round to nearest); scales[n] = 2^-f.  LayerNorm folds of the consumer's
+// prologue: gamma != nullptr packs W diag(gamma) (rounded to fp32 once); beta != nullptr writes bias_out[n] = bias[n] + sum_k W[n][k]
+// beta[k] (float64 sum, rounded once) — LN(x) W^T + b = ((x - mean) rstd) (W diag gamma)^T + (b + W beta).
+__global__ __launch_bounds__(256) void pack_w_half_kernel(const float* __restrict__ W, int64_t ldw, int N, int K, float* __restrict__ dst,
+                                                          float* __restrict__ scales, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ bias,
+                                                          float* __restrict__ bias_out) {
+    __shared__ float mx[16][17];
+    __shared__ double bs[16][17];
+    __shared__ float sc[16];
+    const int nt = blockIdx.x, tid = threadIdx.x;
+    {
+        const int r = tid >> 4, p = tid & 15;
+        const float* wr = W + (int64_t)(nt * 16 + r) * ldw;
+        float m = 0.f;
+        double bsum = 0.0;
+        for (int k = p; k < K; k += 16) {
+            const float w = wr[k];
+            m = fmaxf(m, fabsf(gamma ? w * gamma[k] : w));
+            if (beta) bsum += (double)w * (double)beta[k];
+        }
+        mx[r][p] = m;
+        bs[r][p] = bsum;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        float m = 0.f;
+        double bsum = 0.0;
+        for (int p = 0; p < 16; ++p) { m = fmaxf(m, mx[tid][p]); bsum += bs[tid][p]; }
+        const int ex = (int)((__float_as_uint(m) >> 23) & 255u);
+        const bool plain = ex < 16 || ex == 255;
+        sc[tid] = plain ? 1.f : __uint_as_float((unsigned)(127 + 10 + 127 - ex) << 23);
+        scales[nt * 16 + tid] = plain ? 1.f : __uint_as_float((unsigned)(ex - 10) << 23);
+        if (beta) bias_out[nt * 16 + tid] = (float)((bias ? (double)bias[nt * 16 + tid] : 0.0) + bsum);
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    const float s = sc[li];
+    const float* wr = W + (int64_t)(nt * 16 + li) * ldw + kq * 8;
+    f32x4v* out = reinterpret_cast<f32x4v*>(dst) + (int64_t)nt * (K / 32) * 128 + lane;
+    for (int kc = wave; kc < K / 32; kc += 4) {
+        f16x8v hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float w = wr[kc * 32 + j];
+            if (gamma) w *= gamma[kc * 32 + kq * 8 + j];
+            w *= s;
+            const _Float16 h = (_Float16)w;
+            hi[j] = h;
+            lo[j] = (_Float16)(w - (float)h);
+        }
+        out[(int64_t)kc * 128] = __builtin_bit_cast(f32x4v, hi);
+        out[(int64_t)kc * 128 + 64] = __builtin_bit_cast(f32x4v, lo);
+    }
+}
+
 // tile-ordered copy of a row-major weight matrix (LinearArgs::Wp): thread = one float4 of the destination
 __global__ void pack_w_tiles_kernel(const float* __restrict__ W, int64_t ldw, int N, int K, float* __restrict__ dst) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // float4 index in dst
@@ -1090,6 +1460,30 @@ hipError_t go_stream32(const LinearArgs& a0, int groups, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <int K, int NT, int PRO, int ADD2, bool BIAS, bool RELU, int RES, bool GNOUT>
+hipError_t go_h3(const LinearArgs& a0, int groups, hipStream_t s) {
+    // LayerNorm prologues exist in the folded forms only (pack_w_half_kernel: gamma in Wh unless an addend follows, W beta in wh_bias)
+    constexpr int FOLD = PRO == kProLN ? (ADD2 ? 2 : 1) : 0;
+    if (FOLD != 0 && (a0.wh_fold != FOLD || !a0.wh_bias || !al16(a0.wh_bias) || groups != 1)) return hipErrorNotSupported;
+    if (g_dry_run) return hipSuccess;
+    LinearArgs a = a0;
+    a.tile_map = 0;
+    // 32-row tiles (every W fragment feeds two row halves) while their grid still has a workgroup per CU
+    static const int min_wg32 = [] { const char* e = dev_env("PARQ_CHAIN_H3_ROWS32"); return e ? atoi(e) : 256; }();   // 0: never
+    const int64_t wg32 = (int64_t)(a.N / (16 * NT)) * (a.M / 32) * groups;
+    constexpr bool fits32 = !(PRO == kProLN && ADD2 != 0 && NT == 4);       // (that one would spill: gamma + addend + two row halves + four sub-tiles)
+    const bool rows32 = fits32 && min_wg32 > 0 && a.M % 32 == 0 && wg32 >= min_wg32 && (!a.gn_sums || a.gn_rows_per_scene % 32 == 0) &&
+                        (!a.gn_out_sums || a.gn_out_rows_per_scene % 32 == 0);
+    if (rows32) {
+        const dim3 grid((unsigned)((a.N / (16 * NT)) * (a.M / 32)), groups, 1);
+        hipLaunchKernelGGL((chain_linear_h3_kernel<K, NT, fits32 ? 2 : 1, PRO, ADD2, BIAS, RELU, RES, GNOUT, FOLD>), grid, dim3(512), 0, s, a);
+    } else {
+        const dim3 grid((unsigned)((a.N / (16 * NT)) * (a.M / 16)), groups, 1);
+        hipLaunchKernelGGL((chain_linear_h3_kernel<K, NT, 1, PRO, ADD2, BIAS, RELU, RES, GNOUT, FOLD>), grid, dim3(512), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
 // column sub-tiles per workgroup for an N-wide launch: the widest of {1, 2, 3, 4} that divides N / 16 (and the addend / moment
 // boundaries) while the grid still has at least ~3/4 of a workgroup per CU at one scene
 int pick_nt(const LinearArgs& a, int want) {
@@ -1133,6 +1527,30 @@ hipError_t launch_chain_linear(const LinearArgs& a_in, int groups, hipStream_t s
     auto is = [&](int K, int pro, int add2, bool bias, bool relu, int res, bool gnout) {
         return g.K == K && g.pro == pro && g.add2 == add2 && g.bias == bias && g.relu == relu && g.res == res && g.gnout == gnout;
     };
+    // ---- K = 1024 / 768 with the fp16 hi / lo mirror (LinearArgs::Wh): fp16 x 3 tile
+    if (a.Wh && a.wh_scale && al16(a.Wh) && al16(a.wh_scale) && a.ldw == a.K && (a.gW % 256) == 0) {
+        static const int nt_h3 = [] { const char* e = dev_env("PARQ_CHAIN_NT_H3"); return e ? atoi(e) : 4; }();
+#define PARQ_H3(KK, PRO, ADD2, BIAS, RELU, RES, GNOUT)                                                          \
+    {                                                                                                           \
+        const int nt = pick_nt(a, nt_h3);                                                                       \
+        const hipError_t e = nt == 4   ? go_h3<KK, 4, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s)          \
+                             : nt == 3 ? go_h3<KK, 3, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s)          \
+                             : nt == 2 ? go_h3<KK, 2, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s)          \
+                                       : go_h3<KK, 1, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s);         \
+        if (e != hipErrorNotSupported) return e;        /* (a LayerNorm launch whose mirror lacks the fold: fp32 tiles) */ \
+    }
+        if (is(1024, kProNone, false, true, false, kResNone, false)) PARQ_H3(1024, kProNone, false, true, false, kResNone, false)     // pe2
+        if (is(1024, kProNone, true, true, false, kResNone, false)) PARQ_H3(1024, kProNone, true, true, false, kResNone, false)       // self in-proj
+        if (is(1024, kProNone, false, true, false, kResPlain, false)) PARQ_H3(1024, kProNone, false, true, false, kResPlain, false)   // self out-proj
+        if (is(1024, kProLN, true, true, false, kResNone, false)) PARQ_H3(1024, kProLN, true, true, false, kResNone, false)           // cross q-proj
+        if (is(1024, kProNone, false, true, false, kResLN, false)) PARQ_H3(1024, kProNone, false, true, false, kResLN, false)         // cross out-proj
+        if (is(1024, kProLN, false, true, true, kResNone, false)) PARQ_H3(1024, kProLN, false, true, true, kResNone, false)           // FFN1
+        if (is(1024, kProLN, false, true, false, kResNone, true)) PARQ_H3(1024, kProLN, false, true, false, kResNone, true)           // heads layer 1
+        if (is(1024, kProGN, false, false, false, kResNone, true)) PARQ_H3(1024, kProGN, false, false, false, kResNone, true)         // heads layer 2
+        if (is(768, kProNone, false, true, false, kResLN, false) && a.N >= 512) PARQ_H3(768, kProNone, false, true, false, kResLN, false)   // FFN2 at the shipped width
+        if (is(768, kProNone, false, true, false, kResNone, false) && a.N >= 512) PARQ_H3(768, kProNone, false, true, false, kResNone, false)   // (kernel-level entry parq_k_linear_half)
+#undef PARQ_H3
+    }
     static const int nt_wide = [] { const char* e = dev_env("PARQ_CHAIN_NT_WIDE"); return e ? atoi(e) : 3; }();     // N = 768 / 528 launches
     static const int nt_inproj = [] { const char* e = dev_env("PARQ_CHAIN_NT_INPROJ"); return e ? atoi(e) : 4; }();
     static const int nt_heads2 = [] { const char* e = dev_env("PARQ_CHAIN_NT_HEADS2"); return e ? atoi(e) : 2; }();
@@ -1217,6 +1635,13 @@ hipError_t launch_chain_linear(const LinearArgs& a_in, int groups, hipStream_t s
     if (is(1024, kProGN, false, false, false, kResNone, true)) PARQ_STREAM(kProGN, false, false, false, kResNone, true)         // heads layer 2
 #undef PARQ_STREAM
     return hipErrorNotSupported;
+}
+
+hipError_t launch_pack_w_half(const float* W, int64_t ldw, int N, int K, float* dst, float* scales, hipStream_t s, const float* gamma,
+                              const float* beta, const float* bias, float* bias_out) {
+    if (N % 16 != 0 || K % 32 != 0 || (beta && !bias_out)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_w_half_kernel, dim3((unsigned)(N / 16)), dim3(256), 0, s, W, ldw, N, K, dst, scales, gamma, beta, bias, bias_out);
+    return hipGetLastError();
 }
 
 hipError_t launch_pack_w_tiles(const float* W, int64_t ldw, int N, int K, float* dst, hipStream_t s) {

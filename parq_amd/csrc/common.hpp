@@ -315,6 +315,11 @@ struct LinearArgs {
     // chain.hip only: the same matrix in tile order (launch_pack_w_tiles): block (n / 16, k / 16) = 1 KB holding element (n % 16,
     // k % 16) at float ((k % 16) / 4 * 16 + n % 16) * 4 + k % 4, i.e. one wave-wide float4 load = one contiguous KB.  nullptr: read W.
     const float* Wp;
+    // chain.hip only: the same matrix as fp16 hi / lo pairs in MFMA-fragment order with one power-of-two scale per output column
+    // (pack_w_half_kernel; element offsets as W's) and wh_scale[n] = the inverse scale.  nullptr: the fp32 kernels.
+    const float* Wh; const float* wh_scale;
+    // LayerNorm folds of that mirror (pack_w_half_kernel): wh_fold 1 = gamma inside Wh and W beta inside wh_bias, 2 = W beta inside wh_bias only
+    const float* wh_bias; int wh_fold;
     int tile_map;                       // chain.hip only: 1 = the workgroups of a row block run on one XCD (set by launch_chain_linear)
     // chain.hip only — LayerNorm seams inside one launch (seam_tile): a launch that produces rows x which a LayerNorm normalises
     // publishes, per (row, workgroup tile of 64 columns), the fp64 partial sums (sum x, sum x^2): lnp_out[row][N / 64][2]
@@ -368,6 +373,8 @@ hipError_t launch_seam_q(const LinearArgs& xa, const SeamArgs& q, hipStream_t s)
 // pack time: Wg = W diag(gamma), srow = row sums of Wg, bb = b + W beta | out = A Bm, ob = A bv  (float64 accumulation)
 hipError_t launch_ln_fold(const float* W, const float* b, const float* gamma, const float* beta, int R, int C, float* Wg, float* srow, float* bb, hipStream_t s);
 hipError_t launch_matmul_fold(const float* A, const float* Bm, const float* bv, int R, int C, float* out, float* ob, hipStream_t s);
+hipError_t launch_pack_w_half(const float* W, int64_t ldw, int N, int K, float* dst, float* scales, hipStream_t s, const float* gamma = nullptr,
+                              const float* beta = nullptr, const float* bias = nullptr, float* bias_out = nullptr);
 hipError_t launch_pack_w_tiles(const float* W, int64_t ldw, int N, int K, float* dst, hipStream_t s);   // N % 16 == K % 16 == 0
 // pack time: out_w[r][k] = sum_j Wa[r][j] W2[j][k], out_b[r] = ba[r] + sum_j Wa[r][j] b2[j]  (float64 accumulation), r < R; Wa [R][C], W2 [C][C]
 hipError_t launch_fold_pos_weights(const float* Wa, const float* ba, const float* W2, const float* b2, int R, int C, float* out_w, float* out_b, hipStream_t s);

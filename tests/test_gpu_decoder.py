@@ -235,6 +235,30 @@ def test_ragged_shapes_vs_fp64_oracle(B, V, h, w, Q, heads, dim, ffn):
             assert rel_err(x, y) < TOL, (k, key, rel_err(x, y))
 
 
+def test_shipped_width_with_a_layer_per_iteration_vs_fp64_oracle():
+    """d = 1024 with SHARE_WEIGHTS off: each iteration has its own norm3 in front of the shared heads, so the LayerNorm of head layer 1 is
+    not folded into the fp16 hi / lo weight mirror and that launch keeps the fp32 tile while the per-layer launches (own norm1 / norm2
+    folds) take the fp16 x 3 tile (chain.hip go_h3; api.hip build_derived_weights)."""
+    cfg = synth.decoder_cfg(dim=1024, queries=64, heads=4, ffn=768, layers=2, share_weights=False)
+    W = synth.make_decoder_weights(cfg, 71)
+    sc = synth.make_scene(72, 1, 2, 9, 12, 1024, smooth=True)
+    dec = make_decoder(cfg, W)
+    outs = [to_np(o) for o in infer(dec, *scene_args(sc))]
+    od = O.OracleDecoder(cfg, W, synth.SCANNET_MEAN_SIZES, dtype=torch.float64)
+    forced = [O.normalize(torch.from_numpy(o["coord_pos"]).double(), cfg.TRANSFORMER.SCALE) for o in outs]
+    with torch.no_grad():
+        want = od.forward(sc["tokens"], sc["camera"], sc["T_camera_pseudoCam"], sc["T_world_pseudoCam"],
+                          sc["T_world_local"], forced_refs=forced)
+    for k, (a, b) in enumerate(zip(outs, want)):
+        top2 = b["sem_cls_prob"].topk(2, -1).values
+        ok = ((top2[..., 0] - top2[..., 1]) > 1e-3).numpy()
+        for key in a:
+            x, y = a[key], b[key].numpy()
+            if key == "size_unnormalized":
+                x, y = x[ok], y[ok]
+            assert rel_err(x, y) < TOL, (k, key, rel_err(x, y))
+
+
 def test_closer_to_fp64_truth_than_the_fp32_reference():
     """g7 holds the reference run in float64 on the g2 inputs.  Teacher-forced with the SAME
     per-iteration reference points, the HIP fp32 path must be no further from that truth than

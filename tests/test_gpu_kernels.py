@@ -36,6 +36,55 @@ def test_linear(M, N, K, relu, use_x2, use_r):
     assert rel_err(Y.cpu().numpy(), want.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K,use_x2,use_r,spread", [
+    (256, 3072, 1024, True, False, 0), (256, 1024, 1024, False, True, 0), (64, 2064, 1024, False, False, 0),
+    (256, 1024, 768, False, False, 0), (32, 1024, 1024, False, False, 40), (48, 256, 1024, True, False, -40)])
+def test_linear_fp16x3_tile_is_fp32_class_at_any_magnitude(M, N, K, use_x2, use_r, spread):
+    """parq_k_linear_half (chain.hip chain_linear_h3_kernel: the inference chain's tile at the shipped width): fp16 hi / lo operands,
+    three fp16 MFMA products, fp32 accumulation — against a float64 product at the tolerance of the fp32 tile.  `spread`: rows of X and
+    rows of W scaled by 2^(+-spread) alternately (values far outside the fp16 range: the per-row / per-column power-of-two scales make
+    range a non-condition), plus an all-zero row and an all-zero weight row."""
+    X = synth.normal(1, "X", (M, K)); X2 = synth.normal(2, "X2", (M, K))
+    W = synth.normal(3, "W", (N, K), std=K ** -0.5); b = synth.normal(4, "b", (N,)); R = synth.normal(5, "R", (M, N))
+    if spread:
+        X = X * (2.0 ** (spread * (np.arange(M) % 3 - 1)))[:, None].astype(np.float32)
+        W = W * (2.0 ** (-spread * (np.arange(N) % 3 - 1) * 0.5))[:, None].astype(np.float32)
+        X[5] = 0.0
+        W[7] = 0.0
+        b = b * 0
+    Y = torch.full((M, N), float("nan"), device="cuda")
+    scratch = torch.empty(N * K + N, device="cuda")
+    dX, dX2, dW, db, dR = dev(X), dev(X2), dev(W), dev(b), dev(R)
+    rc = lib().parq_k_linear_half(_lib.ptr(dX), _lib.ptr(dX2) if use_x2 else None, _lib.ptr(dW), _lib.ptr(db),
+                                  _lib.ptr(dR) if use_r else None, _lib.ptr(Y), M, N, K, 0, _lib.ptr(scratch), scratch.numel() * 4, sptr())
+    _lib.check(rc, "parq_k_linear_half")
+    A = torch.from_numpy(X).double() + (torch.from_numpy(X2).double() if use_x2 else 0)
+    want = A @ torch.from_numpy(W).double().T + torch.from_numpy(b).double()
+    if use_r:
+        want = want + torch.from_numpy(R).double()
+    got = Y.cpu().double()
+    assert torch.isfinite(got).all()
+    if spread:          # per-element scale: |row of X| |row of W| sqrt(K) is the size of an output
+        scale = (A.norm(dim=1)[:, None] * torch.from_numpy(W).double().norm(dim=1)[None, :]).clamp(min=1e-300)
+        assert ((got - want).abs() / scale).max().item() < 2e-6
+        assert (got[:, 7] == 0).all() and (use_x2 or (got[5] == 0).all())
+    else:
+        assert rel_err(got.numpy(), want.numpy()) < 2e-5
+        fp32 = torch.empty(M, N, device="cuda")
+        _lib.check(lib().parq_k_linear(_lib.ptr(dX), _lib.ptr(dX2) if use_x2 else None, _lib.ptr(dW), _lib.ptr(db),
+                                       _lib.ptr(dR) if use_r else None, _lib.ptr(fp32), M, N, K, 0, sptr()), "parq_k_linear")
+        e16, e32 = (got - want).abs().max().item(), (fp32.cpu().double() - want).abs().max().item()
+        assert e16 < 4 * e32 + 1e-6, (e16, e32)       # the same error class as the fp32 MFMA tile
+
+
+def test_linear_fp16x3_rejects_what_it_has_no_tile_for():
+    X = torch.zeros(16, 512, device="cuda")
+    s = torch.empty(16 * 512 + 16, device="cuda")
+    assert lib().parq_k_linear_half(_lib.ptr(X), None, _lib.ptr(X), None, None, _lib.ptr(X), 16, 16, 512, 0, _lib.ptr(s), s.numel() * 4, sptr()) == 1
+    X = torch.zeros(16, 1024, device="cuda")
+    assert lib().parq_k_linear_half(_lib.ptr(X), None, _lib.ptr(X), None, None, _lib.ptr(X), 16, 16, 1024, 0, _lib.ptr(s), 64, sptr()) == 1
+
+
 def test_linear_rejects_bad_k():
     X = torch.zeros(4, 48, device="cuda")
     assert lib().parq_k_linear(_lib.ptr(X), None, _lib.ptr(X), None, None, _lib.ptr(X), 4, 4, 48, 0, sptr()) == 1
