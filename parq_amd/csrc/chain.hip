@@ -983,7 +983,9 @@ __global__ __launch_bounds__(512) void chain_linear_stream32_kernel(LinearArgs a
 // 8 consecutive k as one 16-byte load), wh_scale[n] = the inverse column scale.  Prologues / epilogue / moments as in
 // chain_linear_stream_kernel.  8 waves split K in 32-wide chunks and EVERY operand of the tile is requested before the first wait (with
 // 16-cycle products a streamed W batch would expose its whole round trip: the 4-wave double-buffered form measured 8.8 us per N = 1024
-// launch where the fp32 tile takes 10.8); RH = 2: 32-row tiles, every W fragment feeds two row halves.
+// launch where the fp32 tile takes 10.8); RH = 2: 32-row tiles, every W fragment feeds two row halves.  Measured and not kept (round 6,
+// profiles/NOTES_r06.md): branch-free operand requests with counted waits (the waves then reach the barriers at different times: +1.1 %
+// per forward), the other block -> XCD assignment (+5 %), touching the next launch's weights into the L2s from this launch (+0.6 %).
 typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
@@ -1178,6 +1180,7 @@ __global__ __launch_bounds__(512) void chain_linear_h3_kernel(LinearArgs a) {
         amax = fmaxf(amax, __shfl_xor(amax, 32));
         if (kq == 0) rmx[wave * ROWS + h * 16 + li] = amax;
     }
+    PARQ_TL_MARK();                                   // 1: A (and the prologue parameters) arrived, prologue + row maxima done
     if constexpr (kLateW) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1205,6 +1208,8 @@ __global__ __launch_bounds__(512) void chain_linear_h3_kernel(LinearArgs a) {
         for (int c = 0; c < NCH; ++c) split8(av[h][c][0] * sc, av[h][c][1] * sc, ah[h][c], al[h][c]);
     }
 
+    PARQ_TL_MARK();                                   // 2: row-maximum barrier passed, operands split
+
     f32x4v acc[RH][NT];
 #pragma unroll
     for (int h = 0; h < RH; ++h)
@@ -1222,6 +1227,7 @@ __global__ __launch_bounds__(512) void chain_linear_h3_kernel(LinearArgs a) {
                 acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[h][c], bh, acc[h][t], 0, 0, 0);
             }
         }
+    PARQ_TL_MARK();                                   // 3: W arrived, products issued
     // 8 partial tiles -> 4 (waves 4..7 hand theirs to waves 0..3) -> 1 (the finishing wave of each sub-tile adds four)
     auto ridx = [&](int w4, int t, int h, int r) { return ((((w4 * NT + t) * RH + h) * 4 + r) * 64); };
     if (wave >= 4) {
@@ -1242,6 +1248,7 @@ __global__ __launch_bounds__(512) void chain_linear_h3_kernel(LinearArgs a) {
                 for (int r = 0; r < 4; ++r) red[ridx(wave, t, h, r) + lane] += acc[h][t][r];
     }
     lds_barrier();
+    PARQ_TL_MARK();                                   // 4: partial sums folded
     if (wave >= NT * RH) return;
     const int src = ridx(0, et, eh, erow & 3) + (erow >> 2) * 16 + ec;
     f32x4v sum = *reinterpret_cast<const f32x4v*>(&red[src]);

@@ -33,6 +33,17 @@ static __device__ unsigned long long* parq_tl_buf = nullptr;      // one copy pe
 static __device__ unsigned int parq_tl_cap = 0;
 struct TlStamp {
     unsigned long long t0, idx; int id;
+    unsigned long long ph = 0ull; int nph = 0;        // up to four phase marks inside the kernel: 11-bit offsets from t0 in 10 ns ticks
+    __device__ __forceinline__ void mark() {
+        if (threadIdx.x == 0 && parq_tl_buf) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long d = wall_clock64() - t0;
+            d = d > 2047ull ? 2047ull : d;
+            ph |= d << (11 * nph);
+            ++nph;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
     // the record slot is claimed at the START (the atomic's round trip overlaps the kernel); the end costs one wait for the wave's
     // own stores and four fire-and-forget stores
     __device__ __forceinline__ TlStamp(int id_) : id(id_) {
@@ -48,13 +59,20 @@ struct TlStamp {
                 const unsigned long long nblk = (unsigned long long)gridDim.x * gridDim.y * gridDim.z;
                 const unsigned long long xcc = __builtin_amdgcn_s_getreg(6164) & 15u;     // HW_REG_XCC_ID
                 r[0] = (unsigned long long)id | (nblk << 8) | (xcc << 40);
-                r[1] = blockIdx.x + (unsigned long long)gridDim.x * (blockIdx.y + (unsigned long long)gridDim.y * blockIdx.z);
+                r[1] = (blockIdx.x + (unsigned long long)gridDim.x * (blockIdx.y + (unsigned long long)gridDim.y * blockIdx.z)) | (ph << 20);   // (block index < 2^20 wherever marks are used)
                 r[2] = t0; r[3] = t1;
             }
         }
     }
 };
 #define PARQ_TL_KERNEL(id) ::parq::TlStamp parq_tl_stamp_(id)
+// phase marks cost a pointer load and a branch each even with the timeline off: only in builds that ask for them
+// (PARQ_DEV_EXTRA_FLAGS=-DPARQ_TL_MARKS python -c 'import __graft_entry__ as g; g.build_dev()'; tools/r06_h3_phases.py)
+#ifdef PARQ_TL_MARKS
+#define PARQ_TL_MARK() parq_tl_stamp_.mark()
+#else
+#define PARQ_TL_MARK() do { } while (0)
+#endif
 // each instrumented translation unit defines its setter with this macro; api.hip calls them all from parq_dev_timeline()
 #define PARQ_TL_DEFINE_SETTER(fn)                                                                              \
     hipError_t fn(unsigned long long* buf, unsigned int cap) {                                                 \
@@ -71,6 +89,7 @@ hipError_t tl_set_kvproj_split(unsigned long long*, unsigned int);
 hipError_t tl_set_chain(unsigned long long*, unsigned int);
 #else
 #define PARQ_TL_KERNEL(id) do { } while (0)
+#define PARQ_TL_MARK() do { } while (0)
 #define PARQ_TL_DEFINE_SETTER(fn)
 #endif
 

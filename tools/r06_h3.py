@@ -6,6 +6,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from parq_amd import _lib  # noqa: E402
+if os.environ.get("PARQ_AB_SO"):          # A/B of two development builds on one box: parq_amd/_C/ab/libparq_hip_dev_{a,b}.so
+    _lib.DEV_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "parq_amd", "_C", "ab", os.environ["PARQ_AB_SO"])
 _lib.use_dev_library()
 import bench  # noqa: E402
 
@@ -45,4 +47,4 @@ for rep in range(3):
     e1.record()
     torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1) / n)
-print("H3=%s B=%d  forward %.3f ms   %s" % (tag, B, best, diff))
+print("%sH3=%s B=%d  forward %.3f ms   %s" % ((os.environ.get("PARQ_AB_SO", "") + " ") if os.environ.get("PARQ_AB_SO") else "", tag, B, best, diff))
