@@ -382,9 +382,15 @@ __global__ __launch_bounds__(NW * 64) void self_attn_kernel(const float* __restr
     float m_run = -INFINITY, l_run = 0.f;
     bool q_scaled = false;
 
-    for (int kb = k_begin; kb < k_end; kb += 32) {
-        // all loads of this 32-key block are issued up front (it is the load latency that sets this kernel's time)
-        f32x4v kf[2][NC];
+    // K fragments of a 32-key block: row j = key, float4 chunks of the head dim
+    constexpr bool kV4 = (NDT % 4) == 0;
+    // head dims >= 128 (4 waves, 2+ blocks per wave at Q = 256): the next block's K is requested as soon as this block's scores are
+    // done and its V as soon as this block's P V products are issued, so only the first block pays the round trip (the kernel is load
+    // latency + two dependent MFMA chains per block; 25.6 -> 23.4 us at head dim 256: what remains is 528 KB of K / V per CU on 64 CUs).  Same arithmetic, same order.
+    constexpr bool kPipe = DH >= 128;
+    f32x4v kf[2][NC];
+    float vv[2][4][NDT];
+    auto load_k = [&](int kb) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int key = kb + s * 16 + lj;
@@ -392,11 +398,12 @@ __global__ __launch_bounds__(NW * 64) void self_attn_kernel(const float* __restr
 #pragma unroll
             for (int c = 0; c < NC; ++c) kf[s][c] = *reinterpret_cast<const f32x4v*>(kr + c * 16);
         }
-        // V^T as the A operand of O^T += V^T P^T: MFMA row i = lj is head dim kVD(lj, dt) of sub-tile dt.  For head dims that are
-        // multiples of 64 the rows are dealt so that a lane's NDT values are CONSECUTIVE dims (d = NDT lj + dt): NDT / 4 float4 loads
-        // per key instead of NDT scalar ones (the output dim order is a free permutation, undone when O^T goes to LDS)
-        constexpr bool kV4 = (NDT % 4) == 0;
-        float vv[2][4][NDT];
+    };
+    // V^T as the A operand of O^T += V^T P^T: MFMA row i = lj is head dim kVD(lj, dt) of sub-tile dt.  For head dims that are
+    // multiples of 64 the rows are dealt so that a lane's NDT values are CONSECUTIVE dims (d = NDT lj + dt): NDT / 4 float4 loads
+    // per key instead of NDT scalar ones (the output dim order is a free permutation, undone when O^T goes to LDS).  Keys past L
+    // read row 0: their probabilities are exactly 0 (score -inf), in the pipelined form they are not zeroed a second time
+    auto load_v = [&](int kb) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -408,14 +415,21 @@ __global__ __launch_bounds__(NW * 64) void self_attn_kernel(const float* __restr
                     for (int d4 = 0; d4 < NDT / 4; ++d4) {
                         const f32x4v v4 = *reinterpret_cast<const f32x4v*>(vr + 4 * d4);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) vv[s][r][4 * d4 + e] = vk < L ? v4[e] : 0.f;
+                        for (int e = 0; e < 4; ++e) vv[s][r][4 * d4 + e] = (kPipe || vk < L) ? v4[e] : 0.f;
                     }
                 } else {
                     const float* vr = base + 2 * C + (int64_t)(vk < L ? vk : 0) * row_stride + lj;
 #pragma unroll
-                    for (int d = 0; d < NDT; ++d) vv[s][r][d] = vk < L ? vr[d * 16] : 0.f;
+                    for (int d = 0; d < NDT; ++d) vv[s][r][d] = (kPipe || vk < L) ? vr[d * 16] : 0.f;
                 }
             }
+    };
+    if constexpr (kPipe) {
+        if (k_begin < k_end) { load_k(k_begin); load_v(k_begin); }
+    }
+    for (int kb = k_begin; kb < k_end; kb += 32) {
+        // all loads of this 32-key block are issued up front (it is the load latency that sets this kernel's time)
+        if constexpr (!kPipe) { load_k(kb); load_v(kb); }
         if (!q_scaled) {                          // scores in the log2 domain
 #pragma unroll
             for (int c = 0; c < NC; ++c) qf[c] *= scale;
@@ -431,6 +445,9 @@ __global__ __launch_bounds__(NW * 64) void self_attn_kernel(const float* __restr
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
                     sacc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s][c][e], qf[c][e], sacc[s], 0, 0, 0);
+        if constexpr (kPipe) {
+            if (kb + 32 < k_end) load_k(kb + 32);
+        }
         if (kb + 32 > L) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -474,6 +491,9 @@ __global__ __launch_bounds__(NW * 64) void self_attn_kernel(const float* __restr
 #pragma unroll
                 for (int d = 0; d < NDT; ++d)
                     o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[s][r][d], sacc[s][r], o[d], 0, 0, 0);
+        if constexpr (kPipe) {
+            if (kb + 32 < k_end) load_v(kb + 32);
+        }
     }
     // ---- combine the key slices: O^T sub-tile d, accumulator register r holds MFMA row 4 kq + r = head dim 16 d + 4 kq + r
     // (or NDT (4 kq + r) + d with the float4 V layout above), column (query) lj
