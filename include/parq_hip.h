@@ -98,7 +98,10 @@ size_t parq_packed_weights_bytes(parq_handle h);
 int parq_pack_weights(parq_handle h, void *arena, size_t arena_bytes, parq_stream stream);
 
 /* Arithmetic of the dense cross-attention (call before sizing the workspace):
- *   0  v_mfma_f32_32x32x2_f32 on fp32 operands (exact fp32 products);
+ *   0  v_mfma_f32_32x32x2_f32 on fp32 operands (exact fp32 products) — and the only mode in which the per-iteration GEMMs of an
+ *      inference forward keep fp32 MFMA products at widths whose chain contracts over 1024 / 768: in modes 1..4 those run as fp16
+ *      hi / lo 3-term products on pre-split weights with exact power-of-two scales per row and per output column (no range
+ *      condition; see parq_k_linear_half);
  *   1  (default when head dim is 64 or 256) every fp32 operand split as hi+lo fp16 and each product
  *      evaluated as hi*hi + hi*lo + lo*hi on the fp16 matrix pipe with fp32 accumulation:
  *      ~2^-22 relative product error, i.e. fp32-rounding class (measured against float64 the
