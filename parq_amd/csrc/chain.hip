@@ -1479,7 +1479,12 @@ hipError_t go_h3(const LinearArgs& a0, int groups, hipStream_t s) {
     static const int min_wg32 = [] { const char* e = dev_env("PARQ_CHAIN_H3_ROWS32"); return e ? atoi(e) : 256; }();   // 0: never
     const int64_t wg32 = (int64_t)(a.N / (16 * NT)) * (a.M / 32) * groups;
     constexpr bool fits32 = !(PRO == kProLN && ADD2 != 0 && NT == 4);       // (that one would spill: gamma + addend + two row halves + four sub-tiles)
-    const bool rows32 = fits32 && min_wg32 > 0 && a.M % 32 == 0 && wg32 >= min_wg32 && (!a.gn_sums || a.gn_rows_per_scene % 32 == 0) &&
+    // (32 x 32 tiles for that launch — two sub-tiles, two row halves — measured worse than 16 x 64 at every scene count: 22.3 -> 29.5 us at
+    // two scenes, 41.0 -> 56.3 at four: the A rows and the addend cost more per byte than the weight fragments)
+    // measured per launch at the shipped width (profiles/r06_chain_fp16x3_rows32_threshold.txt): 32-row tiles win wherever their grid has a
+    // workgroup per CU, except the launch with a plain addend (self in-projection: A and the addend for two row halves) below two full rounds
+    const int64_t need32 = (PRO == kProNone && ADD2 != 0) ? 2 * (int64_t)min_wg32 : min_wg32;
+    const bool rows32 = fits32 && min_wg32 > 0 && a.M % 32 == 0 && wg32 >= need32 && (!a.gn_sums || a.gn_rows_per_scene % 32 == 0) &&
                         (!a.gn_out_sums || a.gn_out_rows_per_scene % 32 == 0);
     if (rows32) {
         const dim3 grid((unsigned)((a.N / (16 * NT)) * (a.M / 32)), groups, 1);
