@@ -1001,6 +1001,20 @@ __device__ __forceinline__ void split8(const f32x4v& x0, const f32x4v& x1, f16x8
     }
 }
 
+// LDS of the tile: the split A rows (hi plane, lo plane; row pitch K + 32 halfs so that the sixteen rows of a fragment read start 64 bytes
+// apart modulo 256), the partial sums of the fold (after the planes — or ON them in the 32-row form, behind one more barrier: 160 KB per CU)
+// and the inverse row scales.
+template <int K, int NT, int RH>
+struct H3Lds {
+    static constexpr int pitch = K + 32;                                   // halfs
+    static constexpr int plane_bytes = 16 * RH * pitch * 2;
+    static constexpr int red_bytes = 4 * NT * RH * 4 * 64 * 4;
+    static constexpr bool alias = RH == 2;
+    static constexpr int red_off = alias ? 0 : 2 * plane_bytes;
+    static constexpr int rinv_off = alias ? 2 * plane_bytes : 2 * plane_bytes + red_bytes;
+    static constexpr int bytes = rinv_off + 16 * RH * 4;
+};
+
 template <int K, int NT, int RH, int PRO, int ADD2, bool BIAS, bool RELU, int RES, bool GNOUT, int FOLD = 0>
 __global__ __launch_bounds__(512) void chain_linear_h3_kernel(LinearArgs a) {
     PARQ_TL_KERNEL(kTlLinear);
@@ -1010,65 +1024,62 @@ __global__ __launch_bounds__(512) void chain_linear_h3_kernel(LinearArgs a) {
     // 2 = W beta in wh_bias only (an addend follows the LayerNorm: (x - mean) rstd gamma + x2)
     static_assert(FOLD == 0 || (PRO == kProLN && BIAS && (FOLD == 1) == (ADD2 == 0)), "fold");
     constexpr bool kGamma = PRO == kProGN || (PRO == kProLN && FOLD != 1), kBeta = PRO == kProGN || (PRO == kProLN && FOLD == 0);
-    // register budget: with prologue parameters or an addend in flight the second half of the W fragments is requested only after
-    // the prologue has consumed them (it lands behind the row-maximum barrier and the conversion)
+    // register budget: with prologue parameters or an addend in flight the second half of the W fragments is requested only after the
+    // prologue has consumed them (it lands behind the barrier and the fragment reads)
     constexpr bool kLateW = NT >= 2 && (ADD2 != 0 || kGamma);
     constexpr int NT0 = kLateW ? NT / 2 : NT;
     constexpr int NWV = 8;
-    constexpr int NCH = K / (32 * NWV);               // 32-wide K chunks per wave (4 at K = 1024): every operand of the tile is requested up front
+    constexpr int NCH = K / (32 * NWV);               // 32-wide K chunks per wave in the products (4 at K = 1024)
     constexpr int ROWS = 16 * RH;
-    __shared__ __attribute__((aligned(16))) float red[4 * NT * RH * 4 * 64];
-    __shared__ float lnred[NWV * ROWS * 2];
-    __shared__ float rmx[NWV * ROWS];
-    __shared__ float rinv[ROWS];
+    constexpr int RPW = ROWS / NWV;                   // rows a wave brings in and prepares (2 or 4)
+    constexpr int KQ = K / 256;                       // whole-kilobyte requests per row
+    typedef H3Lds<K, NT, RH> Lds;
+    extern __shared__ __attribute__((aligned(16))) unsigned char h3_lds[];
+    _Float16* const plane_hi = reinterpret_cast<_Float16*>(h3_lds);
+    _Float16* const plane_lo = reinterpret_cast<_Float16*>(h3_lds + Lds::plane_bytes);
+    float* const red = reinterpret_cast<float*>(h3_lds + Lds::red_off);
+    float* const rinv = reinterpret_cast<float*>(h3_lds + Lds::rinv_off);
 
     const int g = blockIdx.y;
     const int ntn = a.N / (16 * NT);
+    // column tiles fastest: the row tiles of a column tile share an XCD (block index mod 8) and with it one L2 copy of their W columns
     const int n0 = (int)(blockIdx.x % ntn) * 16 * NT;
     const int m0 = (int)(blockIdx.x / ntn) * ROWS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
-    const int kbase = wave * 32 + kq * 8;             // the lane's 8 values of its c-th chunk sit at kbase + 256 c
-    const float* xrow = a.X + g * a.gX + (int64_t)(m0 + li) * a.ldx + kbase;
-    const int64_t xh = 16 * a.ldx;
-    const f32x4v* wbase = reinterpret_cast<const f32x4v*>(a.Wh + g * a.gW) + ((int64_t)(n0 / 16) * (K / 32) + wave) * 128 + lane;
-    constexpr int64_t wt_stride = (int64_t)(K / 32) * 128, wc_stride = NWV * 128;      // float4 units
-    const float* x2row = ADD2 != 0 ? a.X2 + (int64_t)(m0 + li) * a.ldx2 + kbase : nullptr;
-    const int64_t x2h = ADD2 != 0 ? 16 * a.ldx2 : 0;
-    const float* pgp = PRO == kProLN ? a.ln_gamma + kbase : (PRO == kProGN ? a.gn_gamma + g * a.gGamma + kbase : nullptr);
-    const float* pbp = PRO == kProLN ? a.ln_beta + kbase : (PRO == kProGN ? a.gn_beta + g * a.gGamma + kbase : nullptr);
     const bool add2 = ADD2 != 0 && n0 < a.x2_ncols;
 
-    f32x4v av[RH][NCH][2];
+    // ---- operands.  A (and the addend) arrive as WHOLE-KILOBYTE requests — wave w owns rows w RPW .. w RPW + RPW - 1 of the tile, a request
+    // is 1 KB of one row — not in the MFMA operand pattern (16 rows x 64 bytes per request), which costs several times more per byte
+    // (tools/bench_src/row_stride_loads.hip: 64 KB per workgroup over 768 workgroups 3.7 us against 0.17 us above the launch floor); the
+    // owner wave applies the prologue, finds the row maximum, splits, and the products read their fragments from LDS.
+    const float* xr = a.X + g * a.gX + (int64_t)(m0 + wave * RPW) * a.ldx + lane * 4;
+    f32x4v av[RPW][KQ];
 #pragma unroll
-    for (int h = 0; h < RH; ++h)
+    for (int j = 0; j < RPW; ++j)
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            av[h][c][0] = *reinterpret_cast<const f32x4v*>(xrow + h * xh + c * 256);
-            av[h][c][1] = *reinterpret_cast<const f32x4v*>(xrow + h * xh + c * 256 + 4);
-        }
-    f32x4v pg[NCH][2], pb[NCH][2], x2[RH][NCH][2];
+        for (int c = 0; c < KQ; ++c) av[j][c] = *reinterpret_cast<const f32x4v*>(xr + (int64_t)j * a.ldx + c * 256);
+    f32x4v pg[KQ], pb[KQ], x2[RPW][KQ];
     if constexpr (kGamma) {
+        const float* pgp = (PRO == kProLN ? a.ln_gamma : a.gn_gamma + g * a.gGamma) + lane * 4;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) pg[c][q] = *reinterpret_cast<const f32x4v*>(pgp + c * 256 + q * 4);
+        for (int c = 0; c < KQ; ++c) pg[c] = *reinterpret_cast<const f32x4v*>(pgp + c * 256);
     }
     if constexpr (kBeta) {
+        const float* pbp = (PRO == kProLN ? a.ln_beta : a.gn_beta + g * a.gGamma) + lane * 4;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) pb[c][q] = *reinterpret_cast<const f32x4v*>(pbp + c * 256 + q * 4);
+        for (int c = 0; c < KQ; ++c) pb[c] = *reinterpret_cast<const f32x4v*>(pbp + c * 256);
     }
     if constexpr (ADD2) {
         if (add2) {
+            const float* x2r = a.X2 + (int64_t)(m0 + wave * RPW) * a.ldx2 + lane * 4;
 #pragma unroll
-            for (int h = 0; h < RH; ++h)
+            for (int j = 0; j < RPW; ++j)
 #pragma unroll
-                for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) x2[h][c][q] = *reinterpret_cast<const f32x4v*>(x2row + h * x2h + c * 256 + q * 4);
+                for (int c = 0; c < KQ; ++c) x2[j][c] = *reinterpret_cast<const f32x4v*>(x2r + (int64_t)j * a.ldx2 + c * 256);
         }
     }
+    const f32x4v* wbase = reinterpret_cast<const f32x4v*>(a.Wh + g * a.gW) + ((int64_t)(n0 / 16) * (K / 32) + wave) * 128 + lane;
+    constexpr int64_t wt_stride = (int64_t)(K / 32) * 128, wc_stride = NWV * 128;      // float4 units
     f32x4v wh[NT][NCH], wl[NT][NCH];
 #pragma unroll
     for (int t = 0; t < NT0; ++t)
@@ -1077,12 +1088,7 @@ __global__ __launch_bounds__(512) void chain_linear_h3_kernel(LinearArgs a) {
             wh[t][c] = wbase[t * wt_stride + c * wc_stride];
             wl[t][c] = wbase[t * wt_stride + c * wc_stride + 64];
         }
-    float shift[RH];
     double gsm = 0.0, gsq = 0.0;
-    if constexpr (PRO == kProLN) {
-#pragma unroll
-        for (int h = 0; h < RH; ++h) shift[h] = a.X[g * a.gX + (int64_t)(m0 + h * 16 + li) * a.ldx];
-    }
     if constexpr (PRO == kProGN) {
         const double* src = a.gn_sums + ((int64_t)((m0 / a.gn_rows_per_scene) * a.gn_ngroups + g) * kGnSlots + lane) * 2;
 #pragma unroll
@@ -1107,80 +1113,80 @@ __global__ __launch_bounds__(512) void chain_linear_h3_kernel(LinearArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    float mean[RH], rstd[RH];
-#pragma unroll
-    for (int h = 0; h < RH; ++h) { mean[h] = 0.f; rstd[h] = 1.f; }
-    if constexpr (PRO == kProLN) {
-#pragma unroll
-        for (int h = 0; h < RH; ++h) {
-            float sm = 0.f, sq = 0.f;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float d = av[h][c][q][e] - shift[h];
-                        sm += d;
-                        sq += d * d;
-                    }
-            sm += __shfl_xor(sm, 16); sq += __shfl_xor(sq, 16);
-            sm += __shfl_xor(sm, 32); sq += __shfl_xor(sq, 32);
-            if (kq == 0) { lnred[(wave * ROWS + h * 16 + li) * 2 + 0] = sm; lnred[(wave * ROWS + h * 16 + li) * 2 + 1] = sq; }
-        }
-        lds_barrier();
-#pragma unroll
-        for (int h = 0; h < RH; ++h) {
-            float Ssum = 0.f, Q2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < NWV; ++w) { Ssum += lnred[(w * ROWS + h * 16 + li) * 2 + 0]; Q2 += lnred[(w * ROWS + h * 16 + li) * 2 + 1]; }
-            const float invK = 1.f / (float)K;
-            const float dm = Ssum * invK;
-            mean[h] = shift[h] + dm;
-            const float var = fmaxf(Q2 * invK - dm * dm, 0.f);
-            rstd[h] = 1.f / sqrtf(var + a.norm_eps);
-            if (a.ln_stats_out && n0 == 0 && wave == 0 && kq == 0) {
-                a.ln_stats_out[(int64_t)(m0 + h * 16 + li) * 2 + 0] = mean[h];
-                a.ln_stats_out[(int64_t)(m0 + h * 16 + li) * 2 + 1] = rstd[h];
-            }
-        }
-    }
+    // ---- the owner wave prepares its rows: statistics from its own registers (a whole row per wave: no workgroup reduction), prologue in
+    // fp32, exact power of two that takes the row maximum into [2^10, 2^11) (1 for an all-zero, tiny or non-finite row: those go through as
+    // they are), hi / lo halves into the LDS planes
+    float gmean = 0.f, grstd = 1.f;
     if constexpr (PRO == kProGN) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { gsm += __shfl_xor(gsm, o); gsq += __shfl_xor(gsq, o); }
-        gn_mean_rstd(gsm, gsq, 1.0 / ((double)a.gn_rows_per_scene * (double)K), a.norm_eps, mean[0], rstd[0]);
-        if constexpr (RH == 2) { mean[1] = mean[0]; rstd[1] = rstd[0]; }
+        gn_mean_rstd(gsm, gsq, 1.0 / ((double)a.gn_rows_per_scene * (double)K), a.norm_eps, gmean, grstd);
     }
-    // the prologue in fp32, in place; row maximum of what the products will see
 #pragma unroll
-    for (int h = 0; h < RH; ++h) {
+    for (int j = 0; j < RPW; ++j) {
+        const int row = wave * RPW + j;
+        float mean = gmean, rstd = grstd;
+        if constexpr (PRO == kProLN) {
+            const float shift = __shfl(av[j][0][0], 0);                   // X[row][0]
+            float sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int c = 0; c < KQ; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = av[j][c][e] - shift;
+                    sm += d;
+                    sq += d * d;
+                }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
+            const float invK = 1.f / (float)K;
+            const float dm = sm * invK;
+            mean = shift + dm;
+            const float var = fmaxf(sq * invK - dm * dm, 0.f);
+            rstd = 1.f / sqrtf(var + a.norm_eps);
+            if (a.ln_stats_out && n0 == 0 && lane == 0) {
+                a.ln_stats_out[(int64_t)(m0 + row) * 2 + 0] = mean;
+                a.ln_stats_out[(int64_t)(m0 + row) * 2 + 1] = rstd;
+            }
+        }
         float amax = 0.f;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c)
+        for (int c = 0; c < KQ; ++c) {
+            f32x4v x = av[j][c];
+            if constexpr (PRO != kProNone) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                f32x4v x = av[h][c][q];
-                if constexpr (PRO != kProNone) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        x[e] = (x[e] - mean[h]) * rstd[h];
-                        if constexpr (kGamma) x[e] *= pg[c][q][e];
-                        if constexpr (kBeta) x[e] += pb[c][q][e];
-                        if constexpr (PRO == kProGN) x[e] = x[e] > 0.f ? x[e] : 0.f;
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    x[e] = (x[e] - mean) * rstd;
+                    if constexpr (kGamma) x[e] *= pg[c][e];
+                    if constexpr (kBeta) x[e] += pb[c][e];
+                    if constexpr (PRO == kProGN) x[e] = x[e] > 0.f ? x[e] : 0.f;
                 }
-                if constexpr (ADD2) {
-                    if (add2) x += x2[h][c][q];
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(x[e]));
-                av[h][c][q] = x;
             }
-        amax = fmaxf(amax, __shfl_xor(amax, 16));
-        amax = fmaxf(amax, __shfl_xor(amax, 32));
-        if (kq == 0) rmx[wave * ROWS + h * 16 + li] = amax;
+            if constexpr (ADD2) {
+                if (add2) x += x2[j][c];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(x[e]));
+            av[j][c] = x;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        const int ex = (int)((__float_as_uint(amax) >> 23) & 255u);
+        const bool plain = ex < 16 || ex == 255;
+        const float sc = plain ? 1.f : __uint_as_float((unsigned)(127 + 10 + 127 - ex) << 23);
+        if (lane == 0) rinv[row] = plain ? 1.f : __uint_as_float((unsigned)(ex - 10) << 23);
+#pragma unroll
+        for (int c = 0; c < KQ; ++c) {
+            const f32x4v x = av[j][c] * sc;
+            const f16x2v h0 = __builtin_convertvector(f32x2v{x[0], x[1]}, f16x2v), h1 = __builtin_convertvector(f32x2v{x[2], x[3]}, f16x2v);
+            const f16x2v l0 = __builtin_convertvector(f32x2v{x[0] - (float)h0[0], x[1] - (float)h0[1]}, f16x2v);
+            const f16x2v l1 = __builtin_convertvector(f32x2v{x[2] - (float)h1[0], x[3] - (float)h1[1]}, f16x2v);
+            typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<f16x4v*>(plane_hi + row * Lds::pitch + c * 256 + lane * 4) = f16x4v{h0[0], h0[1], h1[0], h1[1]};
+            *reinterpret_cast<f16x4v*>(plane_lo + row * Lds::pitch + c * 256 + lane * 4) = f16x4v{l0[0], l0[1], l1[0], l1[1]};
+        }
     }
-    PARQ_TL_MARK();                                   // 1: A (and the prologue parameters) arrived, prologue + row maxima done
+    PARQ_TL_MARK();                                   // 1: A (and everything else this CU asked for) arrived, rows prepared
     if constexpr (kLateW) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1193,22 +1199,17 @@ __global__ __launch_bounds__(512) void chain_linear_h3_kernel(LinearArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     }
     lds_barrier();
+    // ---- fragments of the products: lane (row li, k group kq) holds 8 consecutive k of its c-th chunk, k = (8 c + wave) 32 + 8 kq
     f16x8v ah[RH][NCH], al[RH][NCH];
 #pragma unroll
-    for (int h = 0; h < RH; ++h) {
-        float amax = 0.f;
+    for (int h = 0; h < RH; ++h)
 #pragma unroll
-        for (int w = 0; w < NWV; ++w) amax = fmaxf(amax, rmx[w * ROWS + h * 16 + li]);
-        // exact power of two that takes the row maximum into [2^10, 2^11) (1 for an all-zero, tiny or non-finite row: those go through as they are)
-        const int ex = (int)((__float_as_uint(amax) >> 23) & 255u);
-        const bool plain = ex < 16 || ex == 255;
-        const float sc = plain ? 1.f : __uint_as_float((unsigned)(127 + 10 + 127 - ex) << 23);
-        if (wave == 0 && kq == 0) rinv[h * 16 + li] = plain ? 1.f : __uint_as_float((unsigned)(ex - 10) << 23);
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) split8(av[h][c][0] * sc, av[h][c][1] * sc, ah[h][c], al[h][c]);
-    }
-
-    PARQ_TL_MARK();                                   // 2: row-maximum barrier passed, operands split
+        for (int c = 0; c < NCH; ++c) {
+            const int off = (h * 16 + li) * Lds::pitch + (c * NWV + wave) * 32 + kq * 8;
+            ah[h][c] = *reinterpret_cast<const f16x8v*>(plane_hi + off);
+            al[h][c] = *reinterpret_cast<const f16x8v*>(plane_lo + off);
+        }
+    PARQ_TL_MARK();                                   // 2: barrier passed, fragments read
 
     f32x4v acc[RH][NT];
 #pragma unroll
@@ -1227,7 +1228,8 @@ __global__ __launch_bounds__(512) void chain_linear_h3_kernel(LinearArgs a) {
                 acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[h][c], bh, acc[h][t], 0, 0, 0);
             }
         }
-    PARQ_TL_MARK();                                   // 3: W arrived, products issued
+    PARQ_TL_MARK();                                   // 3: products issued
+    if constexpr (Lds::alias) lds_barrier();          // every wave has read its fragments: the partial sums may overwrite the planes
     // 8 partial tiles -> 4 (waves 4..7 hand theirs to waves 0..3) -> 1 (the finishing wave of each sub-tile adds four)
     auto ridx = [&](int w4, int t, int h, int r) { return ((((w4 * NT + t) * RH + h) * 4 + r) * 64); };
     if (wave >= 4) {
@@ -1487,11 +1489,18 @@ hipError_t go_h3(const LinearArgs& a0, int groups, hipStream_t s) {
     const bool rows32 = fits32 && min_wg32 > 0 && a.M % 32 == 0 && wg32 >= need32 && (!a.gn_sums || a.gn_rows_per_scene % 32 == 0) &&
                         (!a.gn_out_sums || a.gn_out_rows_per_scene % 32 == 0);
     if (rows32) {
+        constexpr int R2 = fits32 ? 2 : 1;
+        static DynLdsOnce once;
+        if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&chain_linear_h3_kernel<K, NT, R2, PRO, ADD2, BIAS, RELU, RES, GNOUT, FOLD>), (size_t)H3Lds<K, NT, R2>::bytes); e != hipSuccess) return e;
         const dim3 grid((unsigned)((a.N / (16 * NT)) * (a.M / 32)), groups, 1);
-        hipLaunchKernelGGL((chain_linear_h3_kernel<K, NT, fits32 ? 2 : 1, PRO, ADD2, BIAS, RELU, RES, GNOUT, FOLD>), grid, dim3(512), 0, s, a);
+        constexpr int lds = H3Lds<K, NT, R2>::bytes;
+        hipLaunchKernelGGL((chain_linear_h3_kernel<K, NT, R2, PRO, ADD2, BIAS, RELU, RES, GNOUT, FOLD>), grid, dim3(512), lds, s, a);
     } else {
+        static DynLdsOnce once;
+        if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&chain_linear_h3_kernel<K, NT, 1, PRO, ADD2, BIAS, RELU, RES, GNOUT, FOLD>), (size_t)H3Lds<K, NT, 1>::bytes); e != hipSuccess) return e;
         const dim3 grid((unsigned)((a.N / (16 * NT)) * (a.M / 16)), groups, 1);
-        hipLaunchKernelGGL((chain_linear_h3_kernel<K, NT, 1, PRO, ADD2, BIAS, RELU, RES, GNOUT, FOLD>), grid, dim3(512), 0, s, a);
+        constexpr int lds = H3Lds<K, NT, 1>::bytes;
+        hipLaunchKernelGGL((chain_linear_h3_kernel<K, NT, 1, PRO, ADD2, BIAS, RELU, RES, GNOUT, FOLD>), grid, dim3(512), lds, s, a);
     }
     return hipGetLastError();
 }
