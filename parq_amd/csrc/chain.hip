@@ -1042,9 +1042,14 @@ __global__ __launch_bounds__(512) void chain_linear_h3_kernel(LinearArgs a) {
 
     const int g = blockIdx.y;
     const int ntn = a.N / (16 * NT);
-    // column tiles fastest: the row tiles of a column tile share an XCD (block index mod 8) and with it one L2 copy of their W columns
-    const int n0 = (int)(blockIdx.x % ntn) * 16 * NT;
-    const int m0 = (int)(blockIdx.x / ntn) * ROWS;
+    // the row tiles of a column tile share an XCD (block index mod 8) and with it one L2 copy of their W columns — also when the column
+    // tile count is no multiple of 8 (head layer 1: 43): XCD x takes column tiles x, x + 8, ..., the grid is padded to 8 ceil(ntn / 8) per
+    // row tile and the workgroups past the last column tile leave at once (27.6 -> 23.0 us at one scene, 80.8 -> 66.0 at four)
+    const int ntn8 = (ntn + 7) >> 3;
+    const int ct = (int)(blockIdx.x & 7u) + 8 * (int)((blockIdx.x >> 3) % ntn8);
+    if (ct >= ntn) return;
+    const int n0 = ct * 16 * NT;
+    const int m0 = (int)((blockIdx.x >> 3) / ntn8) * ROWS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     const bool add2 = ADD2 != 0 && n0 < a.x2_ncols;
 
@@ -1480,25 +1485,24 @@ hipError_t go_h3(const LinearArgs& a0, int groups, hipStream_t s) {
     // 32-row tiles (every W fragment feeds two row halves) while their grid still has a workgroup per CU
     static const int min_wg32 = [] { const char* e = dev_env("PARQ_CHAIN_H3_ROWS32"); return e ? atoi(e) : 256; }();   // 0: never
     const int64_t wg32 = (int64_t)(a.N / (16 * NT)) * (a.M / 32) * groups;
-    constexpr bool fits32 = !(PRO == kProLN && ADD2 != 0 && NT == 4);       // (that one would spill: gamma + addend + two row halves + four sub-tiles)
-    // (32 x 32 tiles for that launch — two sub-tiles, two row halves — measured worse than 16 x 64 at every scene count: 22.3 -> 29.5 us at
-    // two scenes, 41.0 -> 56.3 at four: the A rows and the addend cost more per byte than the weight fragments)
+    constexpr bool fits32 = true;
     // measured per launch at the shipped width (profiles/r06_chain_fp16x3_rows32_threshold.txt): 32-row tiles win wherever their grid has a
     // workgroup per CU, except the launch with a plain addend (self in-projection: A and the addend for two row halves) below two full rounds
-    const int64_t need32 = (PRO == kProNone && ADD2 != 0) ? 2 * (int64_t)min_wg32 : min_wg32;
+    static const int add_factor = [] { const char* e = dev_env("PARQ_CHAIN_H3_ROWS32_ADD"); return e ? atoi(e) : 2; }();
+    const int64_t need32 = (PRO == kProNone && ADD2 != 0) ? add_factor * (int64_t)min_wg32 : min_wg32;
     const bool rows32 = fits32 && min_wg32 > 0 && a.M % 32 == 0 && wg32 >= need32 && (!a.gn_sums || a.gn_rows_per_scene % 32 == 0) &&
                         (!a.gn_out_sums || a.gn_out_rows_per_scene % 32 == 0);
     if (rows32) {
         constexpr int R2 = fits32 ? 2 : 1;
         static DynLdsOnce once;
         if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&chain_linear_h3_kernel<K, NT, R2, PRO, ADD2, BIAS, RELU, RES, GNOUT, FOLD>), (size_t)H3Lds<K, NT, R2>::bytes); e != hipSuccess) return e;
-        const dim3 grid((unsigned)((a.N / (16 * NT)) * (a.M / 32)), groups, 1);
+        const dim3 grid((unsigned)(((a.N / (16 * NT) + 7) / 8 * 8) * (a.M / 32)), groups, 1);
         constexpr int lds = H3Lds<K, NT, R2>::bytes;
         hipLaunchKernelGGL((chain_linear_h3_kernel<K, NT, R2, PRO, ADD2, BIAS, RELU, RES, GNOUT, FOLD>), grid, dim3(512), lds, s, a);
     } else {
         static DynLdsOnce once;
         if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&chain_linear_h3_kernel<K, NT, 1, PRO, ADD2, BIAS, RELU, RES, GNOUT, FOLD>), (size_t)H3Lds<K, NT, 1>::bytes); e != hipSuccess) return e;
-        const dim3 grid((unsigned)((a.N / (16 * NT)) * (a.M / 16)), groups, 1);
+        const dim3 grid((unsigned)(((a.N / (16 * NT) + 7) / 8 * 8) * (a.M / 16)), groups, 1);
         constexpr int lds = H3Lds<K, NT, 1>::bytes;
         hipLaunchKernelGGL((chain_linear_h3_kernel<K, NT, 1, PRO, ADD2, BIAS, RELU, RES, GNOUT, FOLD>), grid, dim3(512), lds, s, a);
     }
