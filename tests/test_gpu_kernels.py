@@ -38,7 +38,10 @@ def test_linear(M, N, K, relu, use_x2, use_r):
 
 @pytest.mark.parametrize("M,N,K,use_x2,use_r,spread", [
     (256, 3072, 1024, True, False, 0), (256, 1024, 1024, False, True, 0), (64, 2064, 1024, False, False, 0),
-    (256, 1024, 768, False, False, 0), (32, 1024, 1024, False, False, 40), (48, 256, 1024, True, False, -40)])
+    (256, 1024, 768, False, False, 0), (32, 1024, 1024, False, False, 40), (48, 256, 1024, True, False, -40),
+    (512, 1024, 1024, False, True, 0),       # 32-row tiles (their grid has a workgroup per CU): LDS planes shared with the fold
+    (1024, 2064, 1024, False, False, 0),     # 43 column tiles of 48: the grid is padded to 48 per row tile, 5 workgroups per row tile leave at once
+    (1024, 3072, 1024, True, False, 25)])    # the addend launch on 32-row tiles, rows x 2^+-25
 def test_linear_fp16x3_tile_is_fp32_class_at_any_magnitude(M, N, K, use_x2, use_r, spread):
     """parq_k_linear_half (chain.hip chain_linear_h3_kernel: the inference chain's tile at the shipped width): fp16 hi / lo operands,
     three fp16 MFMA products, fp32 accumulation — against a float64 product at the tolerance of the fp32 tile.  `spread`: rows of X and
