@@ -983,23 +983,14 @@ __global__ __launch_bounds__(512) void chain_linear_stream32_kernel(LinearArgs a
 // 8 consecutive k as one 16-byte load), wh_scale[n] = the inverse column scale.  Prologues / epilogue / moments as in
 // chain_linear_stream_kernel.  8 waves split K in 32-wide chunks and EVERY operand of the tile is requested before the first wait (with
 // 16-cycle products a streamed W batch would expose its whole round trip: the 4-wave double-buffered form measured 8.8 us per N = 1024
-// launch where the fp32 tile takes 10.8); RH = 2: 32-row tiles, every W fragment feeds two row halves.  Measured and not kept (round 6,
+// launch where the fp32 tile takes 10.8); RH = 2: 32-row tiles, every W fragment feeds two row halves.  The A rows (and the addend) come in as
+// whole-kilobyte requests owned by one wave per row, which prepares them and leaves hi / lo halves in LDS for the fragment reads (see the
+// kernel).  Measured and not kept (round 6,
 // profiles/NOTES_r06.md): branch-free operand requests with counted waits (the waves then reach the barriers at different times: +1.1 %
 // per forward), the other block -> XCD assignment (+5 %), touching the next launch's weights into the L2s from this launch (+0.6 %).
 typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ void split8(const f32x4v& x0, const f32x4v& x1, f16x8v& hi, f16x8v& lo) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const float u = p < 2 ? x0[2 * p] : x1[2 * p - 4], v = p < 2 ? x0[2 * p + 1] : x1[2 * p - 3];
-        const f16x2v h = __builtin_convertvector(f32x2v{u, v}, f16x2v);
-        const f16x2v l = __builtin_convertvector(f32x2v{u - (float)h[0], v - (float)h[1]}, f16x2v);
-        hi[2 * p] = h[0]; hi[2 * p + 1] = h[1];
-        lo[2 * p] = l[0]; lo[2 * p + 1] = l[1];
-    }
-}
 
 // LDS of the tile: the split A rows (hi plane, lo plane; row pitch K + 32 halfs so that the sixteen rows of a fragment read start 64 bytes
 // apart modulo 256), the partial sums of the fold (after the planes — or ON them in the 32-row form, behind one more barrier: 160 KB per CU)
