@@ -384,12 +384,61 @@ __global__ __launch_bounds__(NW * 64) void self_attn_kernel(const float* __restr
 
     // K fragments of a 32-key block: row j = key, float4 chunks of the head dim
     constexpr bool kV4 = (NDT % 4) == 0;
-    // head dims >= 128 (4 waves, 2+ blocks per wave at Q = 256): the next block's K is requested as soon as this block's scores are
-    // done and its V as soon as this block's P V products are issued, so only the first block pays the round trip (the kernel is load
-    // latency + two dependent MFMA chains per block; 25.6 -> 23.4 us at head dim 256: what remains is 528 KB of K / V per CU on 64 CUs).  Same arithmetic, same order.
+    // Head dim 64 (round 6): K and V come in as WHOLE-KILOBYTE requests (a request = four key rows x 256 bytes) and reach the MFMA operand
+    // layout through a wave-private LDS tile of 16 keys — the operand pattern itself (16 rows x 64 bytes per request) costs several times
+    // more per byte (tools/bench_src/row_stride_loads.hip).  A block's V is requested behind its K staging (it lands behind the scores) and
+    // the next block's K behind this block's V staging (it lands behind the P V products), so only the first K pays the round trip.  Same
+    // products in the same order: the results are those of the direct loads bit for bit (output digests equal, tools/r06_fwd_time.py;
+    // 1.396 -> 1.388 ms per cfg-3 forward on one box).  Keys past L read row 0: their probabilities are exactly 0 (score -inf).
+    constexpr bool kStage = DH == 64;
+    // head dims >= 128 (4 waves, 2+ blocks per wave at Q = 256) keep the direct loads, pipelined: the next block's K is requested as soon as
+    // this block's scores are done and its V as soon as this block's P V products are issued (25.6 -> 23.4 us at head dim 256; the staged
+    // form measured 1.959 -> 1.970 ms per shipped-size forward there: one sub-block at a time costs more than the requests save)
     constexpr bool kPipe = DH >= 128;
+    constexpr int RQ = DH / 16;                    // float4 requests per lane and 16-key sub-block (K or V)
+    constexpr int KP = DH + 16, VP = DH + 4;       // row pitch (floats) of the staging tile as K / as V (fragment reads of 16 rows / of rows 4 apart spread over the banks)
+    float* const stg = Ls + NW * 16 + wave * (16 * KP);
     f32x4v kf[2][NC];
     float vv[2][4][NDT];
+    constexpr int RQA = kStage ? RQ : 1, S2 = kStage ? 2 : 1;
+    f32x4v kr[S2][RQA], vr[S2][RQA];
+    auto graw = [&](f32x4v (&dst)[S2][RQA], int kb, int col0) {
+        if constexpr (kStage)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < RQ; ++i) {
+                const int f = i * 64 + lane, row = f / (DH / 4), c4 = f % (DH / 4);
+                const int key = kb + s * 16 + row;
+                dst[s][i] = *reinterpret_cast<const f32x4v*>(base + col0 + (int64_t)(key < L ? key : 0) * row_stride + c4 * 4);
+            }
+    };
+    auto to_lds = [&](const f32x4v (&src)[RQA], int pitch) {
+#pragma unroll
+        for (int i = 0; i < RQA; ++i) {
+            const int f = i * 64 + lane, row = f / (DH / 4), c4 = f % (DH / 4);
+            *reinterpret_cast<f32x4v*>(stg + row * pitch + c4 * 4) = src[i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the wave's own LDS writes have landed (no other wave touches the tile)
+    };
+    auto stage_k = [&](int s) {
+        to_lds(kr[s < S2 ? s : 0], KP);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) kf[0][c] = *reinterpret_cast<const f32x4v*>(stg + lj * KP + c * 16 + kq * 4);
+        asm volatile("" ::: "memory");
+    };
+    auto stage_v = [&](int s) {
+        to_lds(vr[s < S2 ? s : 0], VP);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int d4 = 0; d4 < NDT / 4; ++d4) {
+                const f32x4v v4 = *reinterpret_cast<const f32x4v*>(stg + (4 * kq + r) * VP + NDT * lj + 4 * d4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vv[0][r][4 * d4 + e] = v4[e];
+            }
+        asm volatile("" ::: "memory");
+    };
     auto load_k = [&](int kb) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -424,12 +473,13 @@ __global__ __launch_bounds__(NW * 64) void self_attn_kernel(const float* __restr
                 }
             }
     };
+    if constexpr (kStage) {
+        if (k_begin < k_end) graw(kr, k_begin, C);
+    }
     if constexpr (kPipe) {
         if (k_begin < k_end) { load_k(k_begin); load_v(k_begin); }
     }
     for (int kb = k_begin; kb < k_end; kb += 32) {
-        // all loads of this 32-key block are issued up front (it is the load latency that sets this kernel's time)
-        if constexpr (!kPipe) { load_k(kb); load_v(kb); }
         if (!q_scaled) {                          // scores in the log2 domain
 #pragma unroll
             for (int c = 0; c < NC; ++c) qf[c] *= scale;
@@ -438,15 +488,32 @@ __global__ __launch_bounds__(NW * 64) void self_attn_kernel(const float* __restr
         f32x4v sacc[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) sacc[s] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        if constexpr (kStage) {
+            // one 16-key sub-block at a time through the staging tile (the fragment registers of one sub-block, not two); each
+            // accumulator sees its products in the order of the direct form
+            stage_k(0);
+            graw(vr, kb, 2 * C);                  // this block's V lands behind its scores, the next block's K behind its P V products
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
+            for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e) sacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[0][c][e], qf[c][e], sacc[0], 0, 0, 0);
+            stage_k(1);
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
-                    sacc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s][c][e], qf[c][e], sacc[s], 0, 0, 0);
-        if constexpr (kPipe) {
-            if (kb + 32 < k_end) load_k(kb + 32);
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[0][c][e], qf[c][e], sacc[1], 0, 0, 0);
+        } else {
+            if constexpr (!kPipe) { load_k(kb); load_v(kb); }      // head dim 32: all loads of this 32-key block up front
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                        sacc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s][c][e], qf[c][e], sacc[s], 0, 0, 0);
+            if constexpr (kPipe) {
+                if (kb + 32 < k_end) load_k(kb + 32);
+            }
         }
         if (kb + 32 > L) {
 #pragma unroll
@@ -484,15 +551,29 @@ __global__ __launch_bounds__(NW * 64) void self_attn_kernel(const float* __restr
         }
 #pragma unroll
         for (int d = 0; d < NDT; ++d) o[d] *= alpha;
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
+        if constexpr (kStage) {
+            stage_v(0);
+            if (kb + 32 < k_end) graw(kr, kb + 32, C);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int d = 0; d < NDT; ++d)
-                    o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[s][r][d], sacc[s][r], o[d], 0, 0, 0);
-        if constexpr (kPipe) {
-            if (kb + 32 < k_end) load_v(kb + 32);
+                for (int d = 0; d < NDT; ++d) o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[0][r][d], sacc[0][r], o[d], 0, 0, 0);
+            stage_v(1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int d = 0; d < NDT; ++d) o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[0][r][d], sacc[1][r], o[d], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int d = 0; d < NDT; ++d)
+                        o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[s][r][d], sacc[s][r], o[d], 0, 0, 0);
+            if constexpr (kPipe) {
+                if (kb + 32 < k_end) load_v(kb + 32);
+            }
         }
     }
     // ---- combine the key slices: O^T sub-tile d, accumulator register r holds MFMA row 4 kq + r = head dim 16 d + 4 kq + r
@@ -682,7 +763,7 @@ static hipError_t launch_self_dh(const float* qkv, int64_t row_stride, int B, in
     // head dims up to 64: 8 waves (two per SIMD); 128 / 256: 4 waves, one per SIMD, so that a wave may hold the Q / K / V fragments
     // of a 32-key block and the whole O^T accumulator in the unified register file
     constexpr int NW = DH <= 64 ? 8 : 4;
-    const size_t lds = ((size_t)NW * DH * 17 + 2 * NW * 16) * sizeof(float);
+    const size_t lds = ((size_t)NW * DH * 17 + 2 * NW * 16 + (DH == 64 ? (size_t)NW * 16 * (DH + 16) : 0)) * sizeof(float);
     if (lds > 64 * 1024) {
         static DynLdsOnce once;
         if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&self_attn_kernel<DH, NW>), lds); e != hipSuccess) return e;
