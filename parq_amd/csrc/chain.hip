@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(512) void chain_linear_h3_kernel(LinearArgs a) {
     float* const rinv = reinterpret_cast<float*>(h3_lds + Lds::rinv_off);
 
     const int g = blockIdx.y;
-    const int ntn = a.N / (16 * NT);
+    const int ntn = (a.N / 16 + NT - 1) / NT;         // the last column tile may hold fewer than NT sub-tiles (head layer 1: 129 = 32 x 4 + 1)
     // the row tiles of a column tile share an XCD (block index mod 8) and with it one L2 copy of their W columns — also when the column
     // tile count is no multiple of 8 (head layer 1: 43): XCD x takes column tiles x, x + 8, ..., the grid is padded to 8 ceil(ntn / 8) per
     // row tile and the workgroups past the last column tile leave at once (27.6 -> 23.0 us at one scene, 80.8 -> 66.0 at four)
@@ -1040,6 +1040,7 @@ __global__ __launch_bounds__(512) void chain_linear_h3_kernel(LinearArgs a) {
     const int ct = (int)(blockIdx.x & 7u) + 8 * (int)((blockIdx.x >> 3) % ntn8);
     if (ct >= ntn) return;
     const int n0 = ct * 16 * NT;
+    const int ntv = a.N / 16 - ct * NT < NT ? a.N / 16 - ct * NT : NT;      // sub-tiles of this column tile (the others re-read sub-tile 0 and are dropped)
     const int m0 = (int)((blockIdx.x >> 3) / ntn8) * ROWS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     const bool add2 = ADD2 != 0 && n0 < a.x2_ncols;
@@ -1081,8 +1082,8 @@ __global__ __launch_bounds__(512) void chain_linear_h3_kernel(LinearArgs a) {
     for (int t = 0; t < NT0; ++t)
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            wh[t][c] = wbase[t * wt_stride + c * wc_stride];
-            wl[t][c] = wbase[t * wt_stride + c * wc_stride + 64];
+            wh[t][c] = wbase[(t < ntv ? t : 0) * wt_stride + c * wc_stride];
+            wl[t][c] = wbase[(t < ntv ? t : 0) * wt_stride + c * wc_stride + 64];
         }
     double gsm = 0.0, gsq = 0.0;
     if constexpr (PRO == kProGN) {
@@ -1096,7 +1097,7 @@ __global__ __launch_bounds__(512) void chain_linear_h3_kernel(LinearArgs a) {
     f32x4v e_bias = {0.f, 0.f, 0.f, 0.f}, e_r = {0.f, 0.f, 0.f, 0.f}, e_rg = {1.f, 1.f, 1.f, 1.f}, e_rb = {0.f, 0.f, 0.f, 0.f};
     f32x4v e_ws = {1.f, 1.f, 1.f, 1.f};
     float rmean = 0.f, rrstd = 1.f;
-    if (wave < NT * RH) {
+    if (wave < NT * RH && et < ntv) {
         e_ws = *reinterpret_cast<const f32x4v*>(a.wh_scale + g * (a.gW >> 8) + on);
         if constexpr (BIAS) e_bias = *reinterpret_cast<const f32x4v*>((FOLD != 0 ? a.wh_bias : a.bias + g * a.gBias) + on);
         if constexpr (RES != kResNone) e_r = *reinterpret_cast<const f32x4v*>(a.R + (int64_t)om * a.ldr + on);
@@ -1189,8 +1190,8 @@ __global__ __launch_bounds__(512) void chain_linear_h3_kernel(LinearArgs a) {
         for (int t = NT0; t < NT; ++t)
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                wh[t][c] = wbase[t * wt_stride + c * wc_stride];
-                wl[t][c] = wbase[t * wt_stride + c * wc_stride + 64];
+                wh[t][c] = wbase[(t < ntv ? t : 0) * wt_stride + c * wc_stride];
+                wl[t][c] = wbase[(t < ntv ? t : 0) * wt_stride + c * wc_stride + 64];
             }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -1247,7 +1248,7 @@ __global__ __launch_bounds__(512) void chain_linear_h3_kernel(LinearArgs a) {
     }
     lds_barrier();
     PARQ_TL_MARK();                                   // 4: partial sums folded
-    if (wave >= NT * RH) return;
+    if (wave >= NT * RH || et >= ntv) return;
     const int src = ridx(0, et, eh, erow & 3) + (erow >> 2) * 16 + ec;
     f32x4v sum = *reinterpret_cast<const f32x4v*>(&red[src]);
 #pragma unroll
@@ -1475,7 +1476,7 @@ hipError_t go_h3(const LinearArgs& a0, int groups, hipStream_t s) {
     a.tile_map = 0;
     // 32-row tiles (every W fragment feeds two row halves) while their grid still has a workgroup per CU
     static const int min_wg32 = [] { const char* e = dev_env("PARQ_CHAIN_H3_ROWS32"); return e ? atoi(e) : 256; }();   // 0: never
-    const int64_t wg32 = (int64_t)(a.N / (16 * NT)) * (a.M / 32) * groups;
+    const int64_t wg32 = (int64_t)((a.N / 16 + NT - 1) / NT) * (a.M / 32) * groups;
     constexpr bool fits32 = true;
     // measured per launch at the shipped width (profiles/r06_chain_fp16x3_rows32_threshold.txt): 32-row tiles win wherever their grid has a
     // workgroup per CU, except the launch with a plain addend (self in-projection: A and the addend for two row halves) below two full rounds
@@ -1487,13 +1488,13 @@ hipError_t go_h3(const LinearArgs& a0, int groups, hipStream_t s) {
         constexpr int R2 = fits32 ? 2 : 1;
         static DynLdsOnce once;
         if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&chain_linear_h3_kernel<K, NT, R2, PRO, ADD2, BIAS, RELU, RES, GNOUT, FOLD>), (size_t)H3Lds<K, NT, R2>::bytes); e != hipSuccess) return e;
-        const dim3 grid((unsigned)(((a.N / (16 * NT) + 7) / 8 * 8) * (a.M / 32)), groups, 1);
+        const dim3 grid((unsigned)((((a.N / 16 + NT - 1) / NT + 7) / 8 * 8) * (a.M / 32)), groups, 1);
         constexpr int lds = H3Lds<K, NT, R2>::bytes;
         hipLaunchKernelGGL((chain_linear_h3_kernel<K, NT, R2, PRO, ADD2, BIAS, RELU, RES, GNOUT, FOLD>), grid, dim3(512), lds, s, a);
     } else {
         static DynLdsOnce once;
         if (hipError_t e = once.ensure(reinterpret_cast<const void*>(&chain_linear_h3_kernel<K, NT, 1, PRO, ADD2, BIAS, RELU, RES, GNOUT, FOLD>), (size_t)H3Lds<K, NT, 1>::bytes); e != hipSuccess) return e;
-        const dim3 grid((unsigned)(((a.N / (16 * NT) + 7) / 8 * 8) * (a.M / 16)), groups, 1);
+        const dim3 grid((unsigned)((((a.N / 16 + NT - 1) / NT + 7) / 8 * 8) * (a.M / 16)), groups, 1);
         constexpr int lds = H3Lds<K, NT, 1>::bytes;
         hipLaunchKernelGGL((chain_linear_h3_kernel<K, NT, 1, PRO, ADD2, BIAS, RELU, RES, GNOUT, FOLD>), grid, dim3(512), lds, s, a);
     }
@@ -1546,9 +1547,14 @@ hipError_t launch_chain_linear(const LinearArgs& a_in, int groups, hipStream_t s
     // ---- K = 1024 / 768 with the fp16 hi / lo mirror (LinearArgs::Wh): fp16 x 3 tile
     if (a.Wh && a.wh_scale && al16(a.Wh) && al16(a.wh_scale) && a.ldw == a.K && (a.gW % 256) == 0) {
         static const int nt_h3 = [] { const char* e = dev_env("PARQ_CHAIN_NT_H3"); return e ? atoi(e) : 4; }();
+        static const bool h3_partial = [] { const char* e = dev_env("PARQ_CHAIN_H3_PARTIAL"); return !(e && e[0] == '0'); }();
 #define PARQ_H3(KK, PRO, ADD2, BIAS, RELU, RES, GNOUT)                                                          \
     {                                                                                                           \
-        const int nt = pick_nt(a, nt_h3);                                                                       \
+        int nt = pick_nt(a, nt_h3);                                                                             \
+        /* a ragged sub-tile count (head layer 1: 129) takes full-width tiles with a partial last one instead of narrower tiles */ \
+        /* where the grid is four rounds and more (head layer 1 at one / two / four / eight scenes: 23.0 | 24.2, 35.4 | 36.8, 66.0 | 60.5 us, -0.75 % per forward at eight) */ \
+        if (nt < nt_h3 && nt_h3 == 4 && a.N >= 1024 && (!a.X2 || a.x2_ncols >= a.N) && h3_partial &&             \
+            (int64_t)((a.N / 16 + 3) / 4) * (a.M / 32) * groups >= 1024) nt = 4;                                 \
         const hipError_t e = nt == 4   ? go_h3<KK, 4, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s)          \
                              : nt == 3 ? go_h3<KK, 3, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s)          \
                              : nt == 2 ? go_h3<KK, 2, PRO, ADD2, BIAS, RELU, RES, GNOUT>(a, groups, s)          \

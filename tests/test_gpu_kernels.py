@@ -41,7 +41,8 @@ def test_linear(M, N, K, relu, use_x2, use_r):
     (256, 1024, 768, False, False, 0), (32, 1024, 1024, False, False, 40), (48, 256, 1024, True, False, -40),
     (512, 1024, 1024, False, True, 0),       # 32-row tiles (their grid has a workgroup per CU): LDS planes shared with the fold
     (1024, 2064, 1024, False, False, 0),     # 43 column tiles of 48: the grid is padded to 48 per row tile, 5 workgroups per row tile leave at once
-    (1024, 3072, 1024, True, False, 25)])    # the addend launch on 32-row tiles, rows x 2^+-25
+    (1024, 3072, 1024, True, False, 25),     # the addend launch on 32-row tiles, rows x 2^+-25
+    (4096, 2064, 1024, False, False, 0)])    # 129 sub-tiles at four rounds and more: full-width column tiles, the last one with one sub-tile
 def test_linear_fp16x3_tile_is_fp32_class_at_any_magnitude(M, N, K, use_x2, use_r, spread):
     """parq_k_linear_half (chain.hip chain_linear_h3_kernel: the inference chain's tile at the shipped width): fp16 hi / lo operands,
     three fp16 MFMA products, fp32 accumulation — against a float64 product at the tolerance of the fp32 tile.  `spread`: rows of X and
