@@ -101,6 +101,8 @@ def test_bench_single_rank_default_line_contract():
     two = d["two_scenes_in_flight"]
     assert two["streams"] == 2 and two["outputs_bit_identical_to_one_at_a_time"] is True
     assert two["value"] > 0.95 * d["value"]                      # never slower than one at a time (measured + 15-18 %)
+    three = d["three_scenes_in_flight"]
+    assert three["streams"] == 3 and three["value"] > 0.95 * d["value"]
     assert d["strict_fp16x3"]["attention_mode"] == "split" and d["strict_fp16x3"]["value"] < d["value"]
     # the never-NaN default and what it costs, the captured forward's host time (item 4)
     g = d["guard_policy_cost"]
